@@ -1,0 +1,319 @@
+"""Generate golden input/output vectors from the REAL reference env layer.
+
+BUILD-CONTAINER ONLY (needs /root/reference).  Runs the reference's own
+`Anymal(LeggedRobot).step()` (`legged_gym/envs/anymal_c/anymal.py`,
+`legged_gym/envs/base/legged_robot.py:87-252`) on torch-CPU over the FakeGym of
+`ref_loader.py`: `simulate()` injects a scripted post-simulation state, every
+uniform draw is recorded by slot, and all persistent buffers are dumped before and
+after each step.  The resulting `.npz` files under `tests/golden/` are data
+(inputs + expected outputs); the oracle (`oracle/`) and the HIP path are both
+checked against them.
+
+Usage:  python tools/refgen/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader  # noqa: E402
+
+REPO = ref_loader.REPO_ROOT
+OUT = os.path.join(REPO, "tests", "golden")
+
+# uniform-draw slots (shared with include/lgstep.h: LG_RS_*)
+RS_CMD_CB, RS_PUSH, RS_LEVEL, RS_DOF, RS_ROOT_XY, RS_ROOT_VEL, RS_CMD_RESET, RS_NOISE = 0, 4, 6, 8, 20, 22, 28, 32
+
+
+def build(case):
+    ref_loader.load_reference()
+    from isaacgym import gymapi
+    from legged_gym.envs import Anymal, AnymalCFlatCfg, AnymalCRoughCfg
+    import legged_gym.envs.base.legged_robot as LR
+
+    ref_loader.FakeGym.robot = ref_loader.anymal_robot_description()
+    N = case["num_envs"]
+    cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
+    cfg.env.num_envs = N
+    cfg.control.use_actuator_network = case["actuator_net"]
+    cfg.domain_rand.push_interval_s = case["push_interval_s"]
+    cfg.commands.resampling_time = case["resampling_time"]
+    cfg.commands.heading_command = case["heading_command"]
+    cfg.env.episode_length_s = case["episode_length_s"]
+    if case["base"] == "rough":
+        cfg.terrain.mesh_type = "heightfield"
+        cfg.terrain.num_rows = case["num_rows"]
+        cfg.terrain.num_cols = case["num_cols"]
+        cfg.terrain.max_init_terrain_level = case["num_rows"] - 1
+        cfg.terrain.border_size = case["border_size"]
+    for k, v in case.get("scales", {}).items():
+        setattr(cfg.rewards.scales, k, v)
+    cfg.rewards.only_positive_rewards = case.get("only_positive_rewards", True)
+    sp = gymapi.SimParams()
+    sp.dt = cfg.sim.dt
+
+    rec = {"log": []}
+
+    def rand_float(lower, upper, shape, device):
+        u = torch.rand(*shape)
+        rec["log"].append((rec.get("ctx"), rec.get("sub"), rec.get("ids"), u.clone()))
+        return (upper - lower) * u + lower
+    LR.torch_rand_float = rand_float
+
+    orig_rand_like, orig_randint_like = torch.rand_like, torch.randint_like
+
+    def rand_like(t, **k):
+        u = orig_rand_like(t, **k)
+        rec["log"].append(("noise", None, None, u.clone()))
+        return u
+
+    def randint_like(t, high, **k):
+        u = torch.rand(t.shape)
+        rec["log"].append((rec.get("ctx"), "level", rec.get("ids"), u.clone()))
+        return torch.floor(u * high).to(t.dtype)
+
+    class Rec(Anymal):
+        def _post_physics_step_callback(self):
+            rec["ctx"] = "cb"
+            super()._post_physics_step_callback()
+
+        def reset_idx(self, env_ids):
+            rec["ctx"] = "reset"
+            super().reset_idx(env_ids)
+
+        def _resample_commands(self, env_ids):
+            rec["sub"], rec["ids"] = "cmd", env_ids.clone()
+            super()._resample_commands(env_ids)
+
+        def _reset_dofs(self, env_ids):
+            rec["sub"], rec["ids"] = "dofs", env_ids.clone()
+            super()._reset_dofs(env_ids)
+
+        def _reset_root_states(self, env_ids):
+            rec["sub"], rec["ids"] = "root", env_ids.clone()
+            super()._reset_root_states(env_ids)
+
+        def _push_robots(self):
+            rec["sub"], rec["ids"] = "push", torch.arange(self.num_envs)
+            super()._push_robots()
+
+        def _update_terrain_curriculum(self, env_ids):
+            rec["sub"], rec["ids"] = "curr", env_ids.clone()
+            torch.randint_like = randint_like
+            try:
+                super()._update_terrain_curriculum(env_ids)
+            finally:
+                torch.randint_like = orig_randint_like
+
+        def compute_observations(self):
+            torch.rand_like = rand_like
+            try:
+                super().compute_observations()
+            finally:
+                torch.rand_like = orig_rand_like
+
+    torch.manual_seed(case["seed"])
+    np.random.seed(case["seed"])
+    env = Rec(cfg, sp, gymapi.SIM_PHYSX, "cpu", True)
+    return env, cfg, rec
+
+
+def slots_from_log(log, N, nslots):
+    """Scatter the recorded draws into a dense (N, nslots) table, NaN = not drawn."""
+    tab = np.full((N, nslots), np.nan, dtype=np.float32)
+    counters = {}
+    for ctx, sub, ids, u in log:
+        if ctx == "noise":
+            tab[:, RS_NOISE:RS_NOISE + u.shape[1]] = u.numpy()
+            continue
+        key = (ctx, sub)
+        k = counters.get(key, 0)
+        counters[key] = k + 1
+        ids = ids.numpy()
+        u = u.numpy()
+        if sub == "cmd":
+            base = RS_CMD_CB if ctx == "cb" else RS_CMD_RESET
+            tab[ids, base + k] = u[:, 0]
+        elif sub == "push":
+            tab[ids, RS_PUSH:RS_PUSH + 2] = u
+        elif sub == "level":
+            tab[ids, RS_LEVEL] = u
+        elif sub == "dofs":
+            tab[ids, RS_DOF:RS_DOF + 12] = u
+        elif sub == "root":
+            if u.shape[1] == 2:
+                tab[ids, RS_ROOT_XY:RS_ROOT_XY + 2] = u
+            else:
+                tab[ids, RS_ROOT_VEL:RS_ROOT_VEL + 6] = u
+        else:
+            raise RuntimeError(f"unmapped draw {key}")
+    return tab
+
+
+def persistent(env):
+    d = dict(
+        root_states=env.root_states, dof_state=env.dof_state.view(env.num_envs, -1, 2),
+        last_actions=env.last_actions, last_dof_vel=env.last_dof_vel, last_root_vel=env.last_root_vel,
+        commands=env.commands, base_lin_acc=env.base_lin_acc, base_ang_acc=env.base_ang_acc,
+        base_lin_vel=env.base_lin_vel, base_ang_vel=env.base_ang_vel, projected_gravity=env.projected_gravity,
+        feet_air_time=env.feet_air_time, feet_contact_time=env.feet_contact_time, last_contacts=env.last_contacts,
+        episode_length_buf=env.episode_length_buf,
+        episode_sums=torch.stack([env.episode_sums[k] for k in env.episode_sums.keys()]),
+        env_origins=env.env_origins, gait_idx=env.gait_scheduler.gait_idx,
+        sea_hidden=env.sea_hidden_state, sea_cell=env.sea_cell_state,
+    )
+    if hasattr(env, "terrain_levels"):
+        d["terrain_levels"] = env.terrain_levels
+    return {k: v.detach().clone().numpy() for k, v in d.items()}
+
+
+def run_case(case):
+    env, cfg, rec = build(case)
+    gym = ref_loader.current_gym()
+    N, T = env.num_envs, case["steps"]
+    nb, nd = env.num_bodies, env.num_dof
+    g = torch.Generator().manual_seed(1000 + case["seed"])
+    nslots = RS_NOISE + env.num_obs
+    dec = cfg.control.decimation
+
+    def randn(*s):
+        return torch.randn(*s, generator=g)
+
+    def rand(*s):
+        return torch.rand(*s, generator=g)
+
+    cur = {}
+
+    def script(gym_, call_idx):
+        sub = call_idx % dec
+        dof = gym_.tensors["dof"].view(N, nd, 2)
+        dof[:, :, 0] = env.default_dof_pos + 0.3 * cur["dof_noise"][sub, :, :, 0]
+        dof[:, :, 1] = 3.0 * cur["dof_noise"][sub, :, :, 1]
+        cur["sim_dof"][sub] = dof.clone()
+        if sub == dec - 1:
+            gym_.tensors["root"][:] = cur["root"]
+            gym_.tensors["rigid"].view(N, nb, 13)[:] = cur["rigid"]
+            gym_.tensors["contact"].view(N, nb, 3)[:] = cur["contact"]
+    env.reset()
+    rec["log"].clear()
+    gym.script = script
+    gym.sim_calls = 0
+
+    names = list(env.episode_sums.keys())
+    steps = []
+    for t in range(T):
+        # occasionally force time-outs and command resampling through the runner-style write of episode_length_buf
+        if t == 2:
+            env.episode_length_buf[::5] = int(env.max_episode_length)         # > after += 1
+            env.episode_length_buf[1::7] = int(cfg.commands.resampling_time / env.dt) - 1
+        pre = persistent(env)
+        pre["common_step_counter"] = np.int64(env.common_step_counter)
+        pre["reset_buf"] = env.reset_buf.clone().numpy().astype(np.uint8)
+        actions = 1.5 * randn(N, 12)
+        actions[0, 0] = 150.0     # exercises clip_actions
+        # scripted post-simulation state
+        cur["dof_noise"] = randn(dec, N, nd, 2)
+        cur["sim_dof"] = torch.zeros(dec, N, nd, 2)
+        root = torch.zeros(N, 13)
+        root[:, :3] = env.env_origins + torch.cat([2.0 * (rand(N, 2) - 0.5) * 4.0, 0.5 + 0.1 * randn(N, 1)], dim=1)
+        q = torch.cat([0.15 * randn(N, 2), 1.5 * randn(N, 1), torch.ones(N, 1)], dim=1)
+        root[:, 3:7] = q / q.norm(dim=1, keepdim=True)
+        root[:, 7:10] = 0.7 * randn(N, 3)
+        root[:, 10:13] = 0.8 * randn(N, 3)
+        rigid = randn(N, nb, 13)
+        rigid[:, :, 0:3] = root[:, None, 0:3] + 0.4 * randn(N, nb, 3)
+        rigid[:, env.feet_indices, 2] = 0.05 + 0.1 * rand(N, 4)
+        contact = torch.zeros(N, nb, 3)
+        on = rand(N, 4) < 0.6
+        contact[:, env.feet_indices, 2] = on * (20.0 + 120.0 * rand(N, 4))
+        contact[:, env.feet_indices, 0:2] = on.unsqueeze(-1) * 60.0 * randn(N, 4, 2)
+        hit = rand(N, len(env.penalised_contact_indices)) < 0.15
+        contact[:, env.penalised_contact_indices, :] = hit.unsqueeze(-1) * 5.0 * randn(N, len(env.penalised_contact_indices), 3)
+        base_hit = rand(N) < 0.12
+        contact[:, 0, :] = base_hit.unsqueeze(-1) * 10.0 * randn(N, 3)
+        cur.update(root=root, rigid=rigid, contact=contact)
+
+        torq = []
+        orig_ct = env._compute_torques
+
+        def ct(a, _o=orig_ct):
+            r = _o(a)
+            torq.append(r.detach().clone().view(N, nd))
+            return r
+        env._compute_torques = ct
+        rec["log"].clear()
+        extras_before = env.extras.get("episode", None)
+        obs, _, rew, reset, extras = env.step(actions.clone())
+        env._compute_torques = orig_ct
+
+        post = persistent(env)
+        st = {f"pre_{k}": v for k, v in pre.items()}
+        st.update({f"post_{k}": v for k, v in post.items()})
+        st.update(actions=actions.numpy(), sim_dof=cur["sim_dof"].numpy(), sim_root=root.numpy(),
+                  sim_rigid=rigid.numpy(), sim_contact=contact.numpy(),
+                  rand=slots_from_log(rec["log"], N, nslots), torques=torch.stack(torq).numpy(),
+                  obs=obs.clone().numpy(), rew=rew.clone().numpy(), reset=reset.clone().numpy().astype(np.uint8),
+                  time_out=env.time_out_buf.clone().numpy().astype(np.uint8),
+                  clipped_actions=env.actions.clone().numpy())
+        mh = env.measured_heights
+        st["measured_heights"] = mh.clone().numpy() if torch.is_tensor(mh) else np.zeros((N, 0), np.float32)
+        ep = extras.get("episode", {})
+        fresh = ep is not extras_before
+        st["extras_fresh"] = np.uint8(fresh)
+        st["extras_episode"] = np.array([float(ep.get("rew_" + k, np.nan)) for k in names], dtype=np.float32)
+        st["extras_terrain_level"] = np.float32(ep.get("terrain_level", np.nan))
+        steps.append(st)
+
+    out = {k: np.stack([s[k] for s in steps]) for k in steps[0].keys()}
+    # static data the host must reproduce
+    out["noise_scale_vec"] = env.noise_scale_vec.numpy()
+    out["p_gains"], out["d_gains"] = env.p_gains.numpy(), env.d_gains.numpy()
+    out["default_dof_pos"] = env.default_dof_pos.numpy().reshape(-1)
+    out["torque_limits"] = env.torque_limits.numpy()
+    out["dof_pos_limits"] = env.dof_pos_limits.numpy()
+    out["dof_vel_limits"] = env.dof_vel_limits.numpy()
+    out["reward_scales"] = np.array([env.reward_scales[k] for k in names], dtype=np.float64)
+    out["feet_indices"] = env.feet_indices.numpy()
+    out["penalised_contact_indices"] = env.penalised_contact_indices.numpy()
+    out["termination_contact_indices"] = env.termination_contact_indices.numpy()
+    if env.cfg.terrain.measure_heights:
+        out["height_points"] = env.height_points[0].numpy()
+    if env.height_samples is not None:
+        out["height_samples"] = env.height_samples.numpy()
+        out["terrain_origins"] = env.terrain_origins.numpy()
+        out["terrain_types"] = env.terrain_types.numpy()
+    meta = dict(case=case, reward_names=names, num_obs=int(env.num_obs), num_envs=N, dt=float(env.dt),
+                max_episode_length=float(env.max_episode_length), push_interval=float(cfg.domain_rand.push_interval),
+                dof_names=env.dof_names, command_ranges={k: [float(x) for x in v] for k, v in env.command_ranges.items()},
+                max_episode_length_s=float(env.max_episode_length_s))
+    out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"anymal_{case['name']}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", "resets per step:", out["reset"].sum(axis=1))
+
+
+ALL_SCALES = dict(  # turn every reward term on (non-zero) for the 'allrew' case
+    termination=-2.0, orientation=-5.0, dof_vel=-1e-4, base_height=-1.0, feet_stumble=-0.5, stand_still=-0.2,
+    base_foot_height=-0.7, dof_pos_limits=-3.0, dof_vel_limits=-0.3, torque_limits=-0.05, feet_stumble_liftup=0.3,
+    feet_slip=-0.1, jump_air=-0.4, feet_contact_forces=-0.01, gait_2_step=-0.3, four_footup=-0.6, gait_scheduler=-1.5)
+
+CASES = [
+    dict(name="flat_pd", base="flat", num_envs=24, steps=6, seed=0, actuator_net=False, push_interval_s=0.06,
+         resampling_time=0.1, heading_command=False, episode_length_s=20),
+    dict(name="flat_lstm", base="flat", num_envs=24, steps=6, seed=1, actuator_net=True, push_interval_s=15,
+         resampling_time=4.0, heading_command=True, episode_length_s=20),
+    dict(name="rough_lstm", base="rough", num_envs=32, steps=6, seed=2, actuator_net=True, push_interval_s=0.08,
+         resampling_time=0.1, heading_command=False, episode_length_s=20, num_rows=3, num_cols=4, border_size=5),
+    dict(name="rough_allrew", base="rough", num_envs=32, steps=6, seed=3, actuator_net=False, push_interval_s=0.06,
+         resampling_time=0.1, heading_command=True, episode_length_s=20, num_rows=3, num_cols=4, border_size=5,
+         scales=ALL_SCALES, only_positive_rewards=False),
+]
+
+if __name__ == "__main__":
+    for c in CASES:
+        run_case(c)
