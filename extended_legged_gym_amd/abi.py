@@ -1,0 +1,130 @@
+"""ctypes mirror of `include/lgstep.h` (the C ABI of the env-step library).
+
+Only declarations live here: struct layouts, enum values and function prototypes.  `tests/test_abi.py` parses the
+header and checks every enum value and struct size against this file so the two cannot drift apart.
+"""
+import ctypes as C
+
+LG_ABI_VERSION = 1
+LG_NUM_LEGS, LG_JOINTS_PER_LEG, LG_NUM_DOF = 4, 3, 12
+LG_MAX_CP, LG_MAX_BODIES, LG_MAX_REWARD_TERMS, LG_MAX_INDEX_LIST = 8, 17, 32, 16
+LG_LSTM_NPARAM = 969
+
+LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_UNSUPPORTED, LG_ERR_NO_DEVICE = 0, -1, -2, -3, -4
+LG_F32, LG_I64, LG_U8, LG_I16, LG_I32 = 0, 1, 2, 3, 4
+LG_CTRL_P, LG_CTRL_V, LG_CTRL_T, LG_CTRL_ACTUATOR_NET = 0, 1, 2, 3
+LG_MESH_PLANE, LG_MESH_HEIGHTFIELD = 0, 1
+LG_RNG_PHILOX, LG_RNG_INJECT = 0, 1
+
+RAND_SLOTS = dict(LG_RS_CMD_CB=0, LG_RS_PUSH=4, LG_RS_LEVEL=6, LG_RS_DOF=8, LG_RS_ROOT_XY=20, LG_RS_ROOT_VEL=22,
+                  LG_RS_CMD_RESET=28, LG_RS_NOISE=32)
+LG_RS_NOISE = RAND_SLOTS["LG_RS_NOISE"]
+
+# reward term name (as in cfg.rewards.scales) -> lg_reward_term
+REWARD_TERMS = [
+    "action_rate", "ang_vel_xy", "base_foot_height", "base_height", "collision", "dof_acc", "dof_pos_limits", "dof_vel",
+    "dof_vel_limits", "feet_air_time", "feet_contact_forces", "feet_slip", "feet_stumble", "feet_stumble_liftup",
+    "four_footup", "gait_2_step", "gait_scheduler", "jump_air", "lin_vel_z", "orientation", "stand_still", "termination",
+    "torque_limits", "torques", "tracking_ang_vel", "tracking_lin_vel"]
+REWARD_TERM_ID = {n: i for i, n in enumerate(REWARD_TERMS)}
+
+TENSOR_NAMES = [
+    "root_states", "dof_state", "rigid_body_state", "contact_forces", "torques", "actions", "last_actions", "last_dof_vel",
+    "last_root_vel", "commands", "base_lin_vel", "base_ang_vel", "projected_gravity", "base_lin_acc", "base_ang_acc",
+    "feet_air_time", "feet_contact_time", "last_contacts", "measured_heights", "obs_buf", "rew_buf", "reset_buf",
+    "time_out_buf", "episode_length_buf", "episode_sums", "terrain_levels", "terrain_types", "env_origins",
+    "friction_coeffs", "base_mass_added", "sea_hidden_state", "sea_cell_state", "gait_idx", "gait_foot_z",
+    "extras_episode", "rand_inject", "step_counters", "height_samples", "terrain_origins"]
+TENSOR_ID = {n: i for i, n in enumerate(TENSOR_NAMES)}
+LG_T_COUNT = len(TENSOR_NAMES)
+
+f32, i32 = C.c_float, C.c_int32
+
+
+class lg_robot_model(C.Structure):
+    _fields_ = [
+        ("num_bodies", i32), ("has_foot_body", i32),
+        ("base_mass", f32), ("base_com", f32 * 3), ("base_inertia", f32 * 6),
+        ("joint_pos", (f32 * 3) * 3 * 4), ("joint_rot", (f32 * 9) * 3 * 4), ("joint_axis", (f32 * 3) * 3 * 4),
+        ("link_mass", (f32 * 3) * 4), ("link_com", (f32 * 3) * 3 * 4), ("link_inertia", (f32 * 6) * 3 * 4),
+        ("foot_pos", (f32 * 3) * 4), ("foot_rot", (f32 * 9) * 4),
+        ("dof_lower", f32 * 12), ("dof_upper", f32 * 12), ("dof_vel_limit", f32 * 12), ("torque_limit", f32 * 12),
+        ("cp_count", i32 * 4), ("cp_link", (i32 * LG_MAX_CP) * 4), ("cp_body", (i32 * LG_MAX_CP) * 4),
+        ("cp_pos", (f32 * 3) * LG_MAX_CP * 4), ("cp_radius", (f32 * LG_MAX_CP) * 4),
+        ("feet_indices", i32 * 4),
+        ("num_penalised", i32), ("penalised_contact_indices", i32 * LG_MAX_INDEX_LIST),
+        ("num_termination", i32), ("termination_contact_indices", i32 * LG_MAX_INDEX_LIST),
+    ]
+
+
+class lg_terrain(C.Structure):
+    _fields_ = [
+        ("mesh_type", i32), ("rows", i32), ("cols", i32),
+        ("horizontal_scale", f32), ("vertical_scale", f32), ("border_size", f32), ("static_friction", f32),
+        ("height_samples", C.POINTER(C.c_int16)),
+        ("num_levels", i32), ("num_types", i32),
+        ("terrain_origins", C.POINTER(f32)),
+        ("env_length", f32),
+    ]
+
+
+class lg_config(C.Structure):
+    _fields_ = [
+        ("abi_version", i32), ("num_envs", i32), ("num_obs", i32), ("num_height_points", i32),
+        ("sim_dt", f32), ("decimation", i32), ("gravity", f32 * 3),
+        ("control_type", i32), ("action_scale", f32),
+        ("p_gains", f32 * 12), ("d_gains", f32 * 12), ("default_dof_pos", f32 * 12),
+        ("clip_actions", f32), ("clip_observations", f32),
+        ("actuator_net", f32 * LG_LSTM_NPARAM), ("actuator_in_scale", f32 * 2), ("actuator_out_scale", f32),
+        ("obs_scale_lin_vel", f32), ("obs_scale_ang_vel", f32), ("obs_scale_dof_pos", f32), ("obs_scale_dof_vel", f32),
+        ("obs_scale_height", f32),
+        ("measure_heights", i32), ("add_noise", i32),
+        ("noise_scale_vec", C.POINTER(f32)), ("height_points", C.POINTER(f32)),
+        ("heading_command", i32), ("resampling_steps", i32),
+        ("cmd_lin_vel_x", f32 * 2), ("cmd_lin_vel_y", f32 * 2), ("cmd_ang_vel_yaw", f32 * 2), ("cmd_heading", f32 * 2),
+        ("push_robots", i32), ("push_interval", i32), ("max_push_vel_xy", f32),
+        ("num_reward_terms", i32), ("reward_term_ids", i32 * LG_MAX_REWARD_TERMS),
+        ("reward_scales", f32 * LG_MAX_REWARD_TERMS), ("only_positive_rewards", i32),
+        ("tracking_sigma", f32), ("base_height_target", f32), ("max_contact_force", f32), ("soft_dof_vel_limit", f32),
+        ("soft_torque_limit", f32),
+        ("dof_pos_limits", (f32 * 2) * 12),
+        ("max_episode_length", f32), ("max_episode_length_s", f32),
+        ("curriculum", i32), ("custom_origins", i32), ("max_terrain_level", i32),
+        ("base_init_state", f32 * 13),
+        ("gait_enabled", i32), ("gait_period", f32), ("gait_swing_height", f32), ("gait_foot_phases", f32 * 4),
+        ("solver_iterations", i32), ("contact_offset", f32), ("max_depenetration_velocity", f32), ("erp", f32),
+        ("cfm", f32),
+        ("seed", C.c_uint64), ("rng_mode", i32),
+    ]
+
+
+def declare_product(lib):
+    """Prototypes of liblgstep.so (include/lgstep.h)."""
+    vp = C.c_void_p
+    lib.lg_abi_sizes.argtypes = [C.POINTER(i32)]
+    lib.lg_abi_sizes.restype = None
+    lib.lg_arena_bytes.argtypes = [C.POINTER(lg_config), C.POINTER(lg_robot_model), C.POINTER(lg_terrain)]
+    lib.lg_arena_bytes.restype = C.c_size_t
+    lib.lg_create.argtypes = [C.POINTER(lg_config), C.POINTER(lg_robot_model), C.POINTER(lg_terrain), C.c_int, vp]
+    lib.lg_create.restype = vp
+    lib.lg_get_tensor.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32)]
+    lib.lg_get_tensor.restype = C.c_int
+    lib.lg_step.argtypes = [vp, vp, vp]
+    lib.lg_step.restype = C.c_int
+    lib.lg_compute_torques.argtypes = [vp, vp, vp]
+    lib.lg_compute_torques.restype = C.c_int
+    lib.lg_simulate.argtypes = [vp, vp]
+    lib.lg_simulate.restype = C.c_int
+    lib.lg_post_physics_step.argtypes = [vp, vp]
+    lib.lg_post_physics_step.restype = C.c_int
+    lib.lg_reset_idx.argtypes = [vp, vp, i32, i32, vp]
+    lib.lg_reset_idx.restype = C.c_int
+    lib.lg_last_error.argtypes = [vp]
+    lib.lg_last_error.restype = C.c_char_p
+    lib.lg_destroy.argtypes = [vp]
+    lib.lg_destroy.restype = None
+    return lib
+
+
+PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_compute_torques",
+                   "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_last_error", "lg_destroy"]

@@ -1,0 +1,257 @@
+"""Translate the Python-side configuration (nested `LeggedRobotCfg`, robot model, terrain) into the plain-C structs
+of `include/lgstep.h`.  Pure Python / numpy: no GPU, no native library needed, so the same builders feed the HIP
+library at run time and the CPU oracle in the tests.
+
+Derivations follow the reference's host code: `_parse_cfg` (legged_robot.py:847-860), `_prepare_reward_function`
+(:649-674), `_get_noise_scale_vec` (:533-556), `_init_height_points` (:884-898), PD gains by substring (:630-647),
+soft DOF limits (:357-371).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from extended_legged_gym_amd import abi
+from extended_legged_gym_amd.utils.helpers import class_to_dict
+from extended_legged_gym_amd.utils import urdf as urdf_mod
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def load_robot_model(asset_cfg):
+    """Robot model dict for `cfg.asset`: parse the URDF if the file exists, else the pre-reduced JSON model that ships
+    with the package under resources/robots/<urdf-basename>.json."""
+    path = asset_cfg.file.format(LEGGED_GYM_ROOT_DIR=PKG_ROOT)
+    if os.path.isfile(path) and path.endswith(".urdf"):
+        return urdf_mod.load_urdf(path, asset_cfg.foot_name, asset_cfg.penalize_contacts_on,
+                                  asset_cfg.terminate_after_contacts_on, asset_cfg.collapse_fixed_joints)
+    stem = os.path.splitext(os.path.basename(path))[0]
+    js = os.path.join(PKG_ROOT, "resources", "robots", stem + ".json")
+    if not os.path.isfile(js):
+        raise FileNotFoundError(f"robot asset not found: neither {path} nor {js}")
+    m = urdf_mod.load_model(js)
+    return urdf_mod.finalize_indices(m, asset_cfg.foot_name, asset_cfg.penalize_contacts_on,
+                                     asset_cfg.terminate_after_contacts_on)
+
+
+def load_actuator_net(path_template):
+    stem = os.path.splitext(os.path.basename(path_template))[0]
+    js = os.path.join(PKG_ROOT, "resources", "actuator_nets", stem + ".json")
+    with open(js) as f:
+        return json.load(f)
+
+
+def _fill(arr, values):
+    a = np.asarray(values, dtype=np.float64)
+    flat = a.reshape(-1)
+    dst = (C.c_float * flat.size).from_buffer(arr)
+    for i, v in enumerate(flat):
+        dst[i] = float(v)
+
+
+def model_struct(m):
+    s = abi.lg_robot_model()
+    s.num_bodies, s.has_foot_body = int(m["num_bodies"]), int(m["has_foot_body"])
+    s.base_mass = float(m["base_mass"])
+    for name in ("base_com", "base_inertia", "joint_pos", "joint_rot", "joint_axis", "link_mass", "link_com",
+                 "link_inertia", "foot_pos", "foot_rot", "dof_lower", "dof_upper", "dof_vel_limit", "torque_limit",
+                 "cp_pos", "cp_radius"):
+        _fill(getattr(s, name), m[name])
+    for l in range(4):
+        s.cp_count[l] = int(m["cp_count"][l])
+        for k in range(abi.LG_MAX_CP):
+            s.cp_link[l][k] = int(m["cp_link"][l][k])
+            s.cp_body[l][k] = int(m["cp_body"][l][k])
+    feet = m["feet_indices"]
+    if len(feet) != 4:
+        raise ValueError(f"expected 4 feet bodies, got {feet} (cfg.asset.foot_name)")
+    for i in range(4):
+        s.feet_indices[i] = int(feet[i])
+    pen, term = m["penalised_contact_indices"], m["termination_contact_indices"]
+    if len(pen) > abi.LG_MAX_INDEX_LIST or len(term) > abi.LG_MAX_INDEX_LIST:
+        raise ValueError("too many penalised / termination bodies")
+    s.num_penalised, s.num_termination = len(pen), len(term)
+    for i, b in enumerate(pen):
+        s.penalised_contact_indices[i] = int(b)
+    for i, b in enumerate(term):
+        s.termination_contact_indices[i] = int(b)
+    return s
+
+
+def reward_setup(cfg, dt, stage=None):
+    """Names and dt-scaled scales of the active reward terms, in the reference's evaluation order
+    (`class_to_dict` → alphabetical; zero scales dropped; `legged_robot.py:649-674`, rew_mixin `:15-29`)."""
+    scales = class_to_dict(cfg.rewards.scales)
+    if cfg.rewards.multi_stage_rewards:
+        st = cfg.rewards.reward_min_stage if stage is None else stage
+        scales = {k: (v if not isinstance(v, list) else (v[-1] if st >= len(v) else v[st])) for k, v in scales.items()}
+    names, vals = [], []
+    for k, v in scales.items():
+        if v == 0:
+            continue
+        if k not in abi.REWARD_TERM_ID:
+            raise AttributeError(f"'_reward_{k}' is not a reward term of the native step")
+        names.append(k)
+        vals.append(v * dt)
+    return names, vals
+
+
+def noise_scale_vec(cfg, num_obs):
+    v = np.zeros(num_obs, dtype=np.float32)
+    ns, lvl, os_ = cfg.noise.noise_scales, cfg.noise.noise_level, cfg.normalization.obs_scales
+    v[:3] = ns.lin_vel * lvl * os_.lin_vel
+    v[3:6] = ns.ang_vel * lvl * os_.ang_vel
+    v[6:9] = ns.gravity * lvl
+    v[12:24] = ns.dof_pos * lvl * os_.dof_pos
+    v[24:36] = ns.dof_vel * lvl * os_.dof_vel
+    if cfg.terrain.measure_heights:
+        v[48:235] = ns.height_measurements * lvl * os_.height_measurements
+    return v
+
+
+def height_points(cfg):
+    """(P, 2) scan grid, x-major like `torch.meshgrid(x, y)` flattened (`legged_robot.py:890-898`)."""
+    x = np.asarray(cfg.terrain.measured_points_x, dtype=np.float32)
+    y = np.asarray(cfg.terrain.measured_points_y, dtype=np.float32)
+    gx, gy = np.meshgrid(x, y, indexing="ij")
+    return np.stack([gx.reshape(-1), gy.reshape(-1)], axis=1).astype(np.float32)
+
+
+class NativeSetup:
+    """Owns the structs plus the numpy buffers their pointers refer to (keeps them alive)."""
+
+    def __init__(self, cfg, sim_params, model, terrain=None, seed=0, rng_mode=abi.LG_RNG_PHILOX, gait=None,
+                 reward_stage=None):
+        self.model_dict = model
+        self.model = model_struct(model)
+        dt = cfg.control.decimation * sim_params.dt
+        self.dt = dt
+        N = cfg.env.num_envs
+        num_obs = cfg.env.num_observations
+        c = abi.lg_config()
+        c.abi_version = abi.LG_ABI_VERSION
+        c.num_envs, c.num_obs = N, num_obs
+        c.sim_dt, c.decimation = sim_params.dt, cfg.control.decimation
+        _fill(c.gravity, cfg.sim.gravity)
+
+        # control
+        dof_names = model["dof_names"]
+        self.dof_names = dof_names
+        p_gains, d_gains, default_pos = np.zeros(12), np.zeros(12), np.zeros(12)
+        for i, name in enumerate(dof_names):
+            default_pos[i] = cfg.init_state.default_joint_angles[name]
+            found = False
+            for key in cfg.control.stiffness.keys():
+                if key in name:
+                    p_gains[i], d_gains[i], found = cfg.control.stiffness[key], cfg.control.damping[key], True
+            if not found and cfg.control.control_type in ["P", "V"]:
+                print(f"PD gain of joint {name} were not defined, setting them to zero")
+        self.p_gains, self.d_gains, self.default_dof_pos = p_gains, d_gains, default_pos
+        _fill(c.p_gains, p_gains)
+        _fill(c.d_gains, d_gains)
+        _fill(c.default_dof_pos, default_pos)
+        use_net = bool(getattr(cfg.control, "use_actuator_network", False))
+        if use_net:
+            net = load_actuator_net(cfg.control.actuator_net_file)
+            _fill(c.actuator_net, net["params"])
+            _fill(c.actuator_in_scale, net["in_scale"])
+            c.actuator_out_scale = net["out_scale"]
+            c.control_type = abi.LG_CTRL_ACTUATOR_NET
+        else:
+            try:
+                c.control_type = {"P": abi.LG_CTRL_P, "V": abi.LG_CTRL_V, "T": abi.LG_CTRL_T}[cfg.control.control_type]
+            except KeyError:
+                raise NameError(f"Unknown controller type: {cfg.control.control_type}")
+        c.action_scale = cfg.control.action_scale
+        c.clip_actions, c.clip_observations = cfg.normalization.clip_actions, cfg.normalization.clip_observations
+
+        # observations
+        os_ = cfg.normalization.obs_scales
+        c.obs_scale_lin_vel, c.obs_scale_ang_vel, c.obs_scale_dof_pos = os_.lin_vel, os_.ang_vel, os_.dof_pos
+        c.obs_scale_dof_vel, c.obs_scale_height = os_.dof_vel, os_.height_measurements
+        c.measure_heights, c.add_noise = int(cfg.terrain.measure_heights), int(cfg.noise.add_noise)
+        self.noise_scale_vec = noise_scale_vec(cfg, num_obs)
+        c.noise_scale_vec = self.noise_scale_vec.ctypes.data_as(C.POINTER(C.c_float))
+        self.height_points = height_points(cfg) if cfg.terrain.measure_heights else np.zeros((0, 2), np.float32)
+        c.num_height_points = self.height_points.shape[0]
+        c.height_points = self.height_points.ctypes.data_as(C.POINTER(C.c_float))
+        expect = 48 + (c.num_height_points if cfg.terrain.measure_heights else 0)
+        if num_obs != expect:
+            raise ValueError(f"num_observations={num_obs} but the observation layout has {expect} entries")
+
+        # commands
+        rng = cfg.commands.ranges
+        c.heading_command = int(cfg.commands.heading_command)
+        c.resampling_steps = int(cfg.commands.resampling_time / dt)
+        _fill(c.cmd_lin_vel_x, rng.lin_vel_x)
+        _fill(c.cmd_lin_vel_y, rng.lin_vel_y)
+        _fill(c.cmd_ang_vel_yaw, rng.ang_vel_yaw)
+        _fill(c.cmd_heading, rng.heading)
+
+        # domain randomisation
+        c.push_robots = int(cfg.domain_rand.push_robots)
+        self.push_interval = np.ceil(cfg.domain_rand.push_interval_s / dt)
+        c.push_interval = int(self.push_interval)
+        c.max_push_vel_xy = cfg.domain_rand.max_push_vel_xy
+
+        # rewards
+        self.reward_names, self.reward_scales = reward_setup(cfg, dt, reward_stage)
+        c.num_reward_terms = len(self.reward_names)
+        for k, (n, v) in enumerate(zip(self.reward_names, self.reward_scales)):
+            c.reward_term_ids[k] = abi.REWARD_TERM_ID[n]
+            c.reward_scales[k] = v
+        r = cfg.rewards
+        c.only_positive_rewards = int(r.only_positive_rewards)
+        c.tracking_sigma, c.base_height_target, c.max_contact_force = r.tracking_sigma, r.base_height_target, r.max_contact_force
+        c.soft_dof_vel_limit, c.soft_torque_limit = r.soft_dof_vel_limit, r.soft_torque_limit
+        lo, hi = np.asarray(model["dof_lower"], np.float32), np.asarray(model["dof_upper"], np.float32)
+        mid, rng_ = (lo + hi) / 2, hi - lo
+        self.dof_pos_limits = np.stack([mid - 0.5 * rng_ * r.soft_dof_pos_limit, mid + 0.5 * rng_ * r.soft_dof_pos_limit], 1)
+        _fill(c.dof_pos_limits, self.dof_pos_limits)
+
+        # episode / curriculum
+        self.max_episode_length_s = cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / dt)
+        c.max_episode_length, c.max_episode_length_s = self.max_episode_length, self.max_episode_length_s
+        rough = cfg.terrain.mesh_type in ['heightfield', 'trimesh', 'confined_trimesh']
+        c.curriculum = int(cfg.terrain.curriculum and rough)
+        c.custom_origins = int(rough)
+        c.max_terrain_level = cfg.terrain.num_rows
+        init = cfg.init_state
+        _fill(c.base_init_state, list(init.pos) + list(init.rot) + list(init.lin_vel) + list(init.ang_vel))
+
+        # gait scheduler (Anymal only)
+        if gait is not None:
+            c.gait_enabled, c.gait_period, c.gait_swing_height = 1, gait["period"], gait["swing_height"]
+            _fill(c.gait_foot_phases, gait["foot_phases"])
+
+        # contact solver
+        px = sim_params.physx
+        c.solver_iterations = int(getattr(px, "num_position_iterations", 4))
+        c.contact_offset = float(getattr(px, "contact_offset", 0.01))
+        c.max_depenetration_velocity = float(getattr(px, "max_depenetration_velocity", 1.0))
+        c.erp, c.cfm = 0.2, 1e-6
+        c.seed, c.rng_mode = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_mode)
+        self.cfg = c
+
+        # terrain
+        t = abi.lg_terrain()
+        t.static_friction = cfg.terrain.static_friction
+        if rough:
+            if terrain is None:
+                raise ValueError("rough terrain needs a Terrain object")
+            self.height_samples = np.ascontiguousarray(terrain.heightsamples, dtype=np.int16)
+            self.terrain_origins = np.ascontiguousarray(terrain.env_origins, dtype=np.float32)
+            t.mesh_type = abi.LG_MESH_HEIGHTFIELD
+            t.rows, t.cols = self.height_samples.shape
+            t.horizontal_scale, t.vertical_scale = cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale
+            t.border_size = cfg.terrain.border_size
+            t.height_samples = self.height_samples.ctypes.data_as(C.POINTER(C.c_int16))
+            t.num_levels, t.num_types = self.terrain_origins.shape[0], self.terrain_origins.shape[1]
+            t.terrain_origins = self.terrain_origins.ctypes.data_as(C.POINTER(C.c_float))
+            t.env_length = terrain.env_length
+        else:
+            t.mesh_type = abi.LG_MESH_PLANE
+            self.height_samples, self.terrain_origins = None, None
+        self.terrain = t

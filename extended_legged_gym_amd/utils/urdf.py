@@ -1,0 +1,249 @@
+"""URDF → reduced quadruped model (what `gym.load_asset` does for the reference).
+
+Replaces the Isaac Gym URDF importer behind `legged_robot.py:738-763` for the robots the hot path
+supports: a floating base with four 3-revolute-joint legs.  Follows the asset options the reference sets
+(`legged_robot_config.py:159-180`): `collapse_fixed_joints=True` (links behind fixed joints are merged into
+their parent: inertia, collision shapes, child joints), `dont_collapse="true"` fixed joints keep their child
+as a reported rigid body (the FOOT links, `anymal_c.urdf:701`), `replace_cylinder_with_capsule=True`.
+Bodies and DOFs are ordered depth-first with children sorted by name, which reproduces Isaac Gym's
+LF, LH, RF, RH order for ANYmal-C (`anymal_c_rough_config.py:43-58`).
+
+Collision shapes are reduced to spheres: sphere → itself; capsule → spheres at both segment ends (+ centre when
+long); box → its 8 corners.  Mesh collisions are ignored.
+"""
+import json
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+MAX_CP = 8
+NUM_LEGS = 4
+
+
+def rpy_to_mat(rpy):
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+def _vec(s, n=3, default=0.0):
+    if s is None:
+        return np.full(n, default)
+    return np.array([float(x) for x in s.split()])
+
+
+def _origin(el):
+    o = el.find("origin") if el is not None else None
+    if o is None:
+        return np.eye(3), np.zeros(3)
+    return rpy_to_mat(_vec(o.get("rpy"))), _vec(o.get("xyz"))
+
+
+def _shift(d):
+    return np.dot(d, d) * np.eye(3) - np.outer(d, d)
+
+
+class _Body:
+    def __init__(self, name):
+        self.name = name
+        self.mass = 0.0
+        self.com = np.zeros(3)
+        self.inertia = np.zeros((3, 3))   # about com, body axes
+        self.spheres = []                 # (pos, radius)
+        self.children = []                # (joint dict, _Body)
+
+    def add_inertia(self, m, c, I):
+        if m <= 0.0:
+            return
+        mt = self.mass + m
+        cn = (self.mass * self.com + m * c) / mt
+        self.inertia = self.inertia + self.mass * _shift(self.com - cn) + I + m * _shift(c - cn)
+        self.mass, self.com = mt, cn
+
+
+def _link_spheres(link):
+    out = []
+    for col in link.findall("collision"):
+        R, p = _origin(col)
+        g = col.find("geometry")
+        if g is None or len(g) == 0:
+            continue
+        s = g[0]
+        if s.tag == "sphere":
+            out.append((p, float(s.get("radius"))))
+        elif s.tag in ("cylinder", "capsule"):
+            L, r = float(s.get("length")), float(s.get("radius"))
+            ends = [p + R @ np.array([0, 0, 0.5 * L]), p - R @ np.array([0, 0, 0.5 * L])]
+            out += [(e, r) for e in ends]
+            if L > 4.0 * r:
+                out.append((p, r))
+        elif s.tag == "box":
+            sz = _vec(s.get("size"))
+            for sx in (-0.5, 0.5):
+                for sy in (-0.5, 0.5):
+                    for szz in (-0.5, 0.5):
+                        out.append((p + R @ (sz * np.array([sx, sy, szz])), 0.0))
+    return out
+
+
+def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on, collapse_fixed_joints=True):
+    """Returns a plain-dict robot model with the fields of `lg_robot_model` (include/lgstep.h)."""
+    root = ET.parse(path).getroot()
+    links = {l.get("name"): l for l in root.findall("link")}
+    joints = []
+    child_names = set()
+    for j in root.findall("joint"):
+        R, p = _origin(j)
+        lim = j.find("limit")
+        ax = j.find("axis")
+        joints.append(dict(name=j.get("name"), type=j.get("type"), parent=j.find("parent").get("link"),
+                           child=j.find("child").get("link"), R=R, p=p,
+                           axis=_vec(ax.get("xyz")) if ax is not None else np.array([1.0, 0, 0]),
+                           lower=float(lim.get("lower")) if lim is not None and lim.get("lower") else 0.0,
+                           upper=float(lim.get("upper")) if lim is not None and lim.get("upper") else 0.0,
+                           effort=float(lim.get("effort", 0)) if lim is not None else 0.0,
+                           velocity=float(lim.get("velocity", 0)) if lim is not None else 0.0,
+                           keep=j.get("dont_collapse") == "true"))
+        child_names.add(j.find("child").get("link"))
+    roots = [n for n in links if n not in child_names]
+    assert len(roots) == 1, f"expected a single root link, got {roots}"
+    by_parent = {}
+    for j in joints:
+        by_parent.setdefault(j["parent"], []).append(j)
+
+    def absorb(body, link_name, R, p):
+        """Merge URDF link `link_name`, placed at (R, p) in `body`'s frame, and everything fixed to it."""
+        link = links[link_name]
+        ine = link.find("inertial")
+        if ine is not None:
+            Ri, pi = _origin(ine)
+            m = float(ine.find("mass").get("value"))
+            t = ine.find("inertia")
+            I = np.array([[float(t.get("ixx")), float(t.get("ixy")), float(t.get("ixz"))],
+                          [float(t.get("ixy")), float(t.get("iyy")), float(t.get("iyz"))],
+                          [float(t.get("ixz")), float(t.get("iyz")), float(t.get("izz"))]])
+            Rw = R @ Ri
+            body.add_inertia(m, p + R @ pi, Rw @ I @ Rw.T)
+        for (sp, sr) in _link_spheres(link):
+            body.spheres.append((p + R @ sp, sr))
+        for j in sorted(by_parent.get(link_name, []), key=lambda jj: jj["child"]):
+            Rj, pj = R @ j["R"], p + R @ j["p"]
+            if j["type"] == "fixed" and collapse_fixed_joints and not j["keep"]:
+                absorb(body, j["child"], Rj, pj)
+            else:
+                cb = _Body(j["child"])
+                absorb(cb, j["child"], np.eye(3), np.zeros(3))
+                body.children.append((dict(j, R=Rj, p=pj), cb))
+
+    base = _Body(roots[0])
+    absorb(base, roots[0], np.eye(3), np.zeros(3))
+    base.children.sort(key=lambda jc: jc[1].name)
+    legs = [jc for jc in base.children if jc[0]["type"] in ("revolute", "continuous")]
+    assert len(legs) == NUM_LEGS, f"hot path supports 4-legged robots, found {len(legs)} revolute children of the base"
+
+    m = dict(base_mass=base.mass, base_com=base.com.tolist(), base_inertia=_sym6(base.inertia),
+             joint_pos=[], joint_rot=[], joint_axis=[], link_mass=[], link_com=[], link_inertia=[],
+             foot_pos=[], foot_rot=[], dof_lower=[], dof_upper=[], dof_vel_limit=[], torque_limit=[],
+             cp_count=[], cp_link=[], cp_body=[], cp_pos=[], cp_radius=[])
+    body_names, dof_names = [base.name], []
+    has_foot = True
+    base_spheres = list(base.spheres)
+    for l, (j0, b0) in enumerate(legs):
+        chain, j, b = [], j0, b0
+        foot = None
+        while True:
+            chain.append((j, b))
+            nxt = [jc for jc in b.children if jc[0]["type"] in ("revolute", "continuous")]
+            fixed = [jc for jc in b.children if jc[0]["type"] == "fixed"]
+            if not nxt:
+                foot = fixed[0] if fixed else None
+                break
+            assert len(nxt) == 1 and not fixed, "legs must be serial chains"
+            j, b = nxt[0]
+        assert len(chain) == 3, f"leg {b0.name}: expected 3 revolute joints, got {len(chain)}"
+        jp, jr, ja, lm, lc, li = [], [], [], [], [], []
+        cps = []   # (link, body index, pos, radius)
+        for k, (jj, bb) in enumerate(chain):
+            body_index = len(body_names)
+            body_names.append(bb.name)
+            dof_names.append(jj["name"])
+            mass, com, ine = bb.mass, bb.com.copy(), bb.inertia.copy()
+            spheres = [(k, body_index, sp, sr) for (sp, sr) in bb.spheres]
+            if k == 2:
+                if foot is not None:
+                    fj, fb = foot
+                    tmp = _Body("tmp")
+                    tmp.add_inertia(mass, com, ine)
+                    tmp.add_inertia(fb.mass, fj["p"] + fj["R"] @ fb.com, fj["R"] @ fb.inertia @ fj["R"].T)
+                    mass, com, ine = tmp.mass, tmp.com, tmp.inertia
+                    m["foot_pos"].append(fj["p"].tolist())
+                    m["foot_rot"].append(fj["R"].reshape(-1).tolist())
+                    foot_index = body_index + 1
+                    spheres = [(3, foot_index, fj["p"] + fj["R"] @ sp, sr) for (sp, sr) in fb.spheres] + spheres
+                else:
+                    has_foot = False
+                    m["foot_pos"].append([0.0, 0.0, 0.0])
+                    m["foot_rot"].append(np.eye(3).reshape(-1).tolist())
+            cps = spheres + cps   # distal links first: feet lead the Gauss-Seidel order
+            jp.append(jj["p"].tolist())
+            jr.append(jj["R"].reshape(-1).tolist())
+            ax = jj["axis"] / np.linalg.norm(jj["axis"])
+            ja.append(ax.tolist())
+            lm.append(mass)
+            lc.append(com.tolist())
+            li.append(_sym6(ine))
+            m["dof_lower"].append(jj["lower"])
+            m["dof_upper"].append(jj["upper"])
+            m["dof_vel_limit"].append(jj["velocity"])
+            m["torque_limit"].append(jj["effort"])
+        if foot is not None:
+            body_names.append(foot[1].name)
+        for bi, (sp, sr) in enumerate(base_spheres):
+            if bi % NUM_LEGS == l:
+                cps.append((-1, 0, sp, sr))
+        cps = cps[:MAX_CP]
+        pad = MAX_CP - len(cps)
+        m["cp_count"].append(len(cps))
+        m["cp_link"].append([c[0] for c in cps] + [0] * pad)
+        m["cp_body"].append([c[1] for c in cps] + [0] * pad)
+        m["cp_pos"].append([np.asarray(c[2]).tolist() for c in cps] + [[0.0, 0.0, 0.0]] * pad)
+        m["cp_radius"].append([c[3] for c in cps] + [0.0] * pad)
+        for key, val in (("joint_pos", jp), ("joint_rot", jr), ("joint_axis", ja), ("link_mass", lm),
+                         ("link_com", lc), ("link_inertia", li)):
+            m[key].append(val)
+
+    m["has_foot_body"] = int(has_foot)
+    m["num_bodies"] = len(body_names)
+    m["body_names"], m["dof_names"] = body_names, dof_names
+    finalize_indices(m, foot_name, penalize_contacts_on, terminate_after_contacts_on)
+    return m
+
+
+def finalize_indices(m, foot_name, penalize_contacts_on, terminate_after_contacts_on):
+    """Body-index lists by substring match, as `legged_robot.py:764-770,801-815`."""
+    names = m["body_names"]
+    m["feet_indices"] = [i for i, s in enumerate(names) if foot_name in s]
+    pen = []
+    for n in penalize_contacts_on:
+        pen.extend([i for i, s in enumerate(names) if n in s])
+    term = []
+    for n in terminate_after_contacts_on:
+        term.extend([i for i, s in enumerate(names) if n in s])
+    m["penalised_contact_indices"], m["termination_contact_indices"] = pen, term
+    return m
+
+
+def _sym6(I):
+    return [float(I[0, 0]), float(I[0, 1]), float(I[0, 2]), float(I[1, 1]), float(I[1, 2]), float(I[2, 2])]
+
+
+def save_model(m, path):
+    with open(path, "w") as f:
+        json.dump(m, f, indent=1)
+
+
+def load_model(path):
+    with open(path) as f:
+        return json.load(f)

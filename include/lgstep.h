@@ -1,0 +1,246 @@
+/*
+ * lgstep.h — C ABI of the MI355X-native batched legged-robot environment step.
+ *
+ * This is the drop-in boundary that replaces, for the LeggedRobot.step() hot path,
+ * the Isaac Gym tensor API the reference calls from Python
+ * (reference: legged_gym/legged_gym/envs/base/legged_robot.py):
+ *
+ *   lg_create / lg_get_tensor     <->  gym.create_sim + gym.acquire_*_tensor + gymtorch.wrap_tensor   (:258, :564-584)
+ *   lg_step                       <->  LeggedRobot.step(): 4 x {_compute_torques, set_dof_actuation_force_tensor,
+ *                                      simulate, refresh_dof_state_tensor} + post_physics_step          (:87-111, :113-153)
+ *   lg_compute_torques            <->  LeggedRobot._compute_torques (:425-448) / Anymal._compute_torques (anymal.py:93-105)
+ *   lg_simulate                   <->  gym.set_dof_actuation_force_tensor + gym.simulate + refresh_*    (:99-103, :118-120)
+ *   lg_post_physics_step          <->  LeggedRobot.post_physics_step (:113-153) [+ Anymal.post_physics_step, anymal.py:107-110]
+ *   lg_reset_idx                  <->  LeggedRobot.reset_idx (:162-213) incl. set_*_tensor_indexed (:463-465, :487-489)
+ *
+ * Rules of the ABI: plain C, plain pointers and sizes, no torch types.  Every tensor lives in ONE device arena;
+ * the arena is either supplied by the host (e.g. a torch uint8 tensor, so torch owns the memory and views it
+ * zero-copy) or hipMalloc'ed by the library.  All entry points are asynchronous on the hipStream_t passed in,
+ * return 0 on success or a negative lg_status, and never throw.  One context per GPU, not re-entrant per context.
+ */
+#ifndef LGSTEP_H
+#define LGSTEP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LG_ABI_VERSION 1
+
+#define LG_NUM_LEGS 4
+#define LG_JOINTS_PER_LEG 3
+#define LG_NUM_DOF 12
+#define LG_MAX_CP 8            /* collision points per leg lane */
+#define LG_MAX_BODIES 17       /* base + 4 x (HIP, THIGH, SHANK, FOOT) */
+#define LG_MAX_REWARD_TERMS 32
+#define LG_MAX_INDEX_LIST 16
+#define LG_LSTM_HIDDEN 8
+#define LG_LSTM_NPARAM 969     /* 2-layer LSTM(2->8->8) + Linear(8->1), anydrive_v3_lstm */
+
+/* status codes */
+enum lg_status {
+  LG_OK = 0,
+  LG_ERR_INVALID = -1,     /* bad argument / config */
+  LG_ERR_HIP = -2,         /* a HIP runtime call failed */
+  LG_ERR_UNSUPPORTED = -3, /* config asks for something this build does not implement */
+  LG_ERR_NO_DEVICE = -4
+};
+
+/* element types of arena tensors */
+enum lg_dtype { LG_F32 = 0, LG_I64 = 1, LG_U8 = 2, LG_I16 = 3, LG_I32 = 4 };
+
+/* control_type (legged_robot.py:438-447; anymal.py:93-105) */
+enum lg_control { LG_CTRL_P = 0, LG_CTRL_V = 1, LG_CTRL_T = 2, LG_CTRL_ACTUATOR_NET = 3 };
+
+/* terrain mesh type (legged_robot.py:259-274).  LG_MESH_HEIGHTFIELD collides against the int16 grid itself. */
+enum lg_mesh { LG_MESH_PLANE = 0, LG_MESH_HEIGHTFIELD = 1 };
+
+/* rng_mode: counter-based Philox4x32-10 in-kernel, or uniforms injected by the host (parity / golden tests) */
+enum lg_rng { LG_RNG_PHILOX = 0, LG_RNG_INJECT = 1 };
+
+/* slots of the per-env uniform-draw table (one row per env, LG_RS_NOISE + num_obs columns) */
+enum lg_rand_slot {
+  LG_RS_CMD_CB = 0,     /* 3 draws: _resample_commands from _post_physics_step_callback (:391-393) */
+  LG_RS_PUSH = 4,       /* 2 draws: _push_robots (:495) */
+  LG_RS_LEVEL = 6,      /* 1 draw : randint_like in _update_terrain_curriculum (:516) */
+  LG_RS_DOF = 8,        /* 12 draws: _reset_dofs (:459) */
+  LG_RS_ROOT_XY = 20,   /* 2 draws: _reset_root_states (:479) */
+  LG_RS_ROOT_VEL = 22,  /* 6 draws: _reset_root_states (:485) */
+  LG_RS_CMD_RESET = 28, /* 3 draws: _resample_commands from reset_idx (:185) */
+  LG_RS_NOISE = 32      /* num_obs draws: compute_observations (:252) */
+};
+
+/* reward terms: legged_robot_rew_mixin.py:41-234 (+ Anymal._reward_gait_scheduler, anymal.py:112-114) */
+enum lg_reward_term {
+  LG_REW_ACTION_RATE = 0, LG_REW_ANG_VEL_XY, LG_REW_BASE_FOOT_HEIGHT, LG_REW_BASE_HEIGHT, LG_REW_COLLISION,
+  LG_REW_DOF_ACC, LG_REW_DOF_POS_LIMITS, LG_REW_DOF_VEL, LG_REW_DOF_VEL_LIMITS, LG_REW_FEET_AIR_TIME,
+  LG_REW_FEET_CONTACT_FORCES, LG_REW_FEET_SLIP, LG_REW_FEET_STUMBLE, LG_REW_FEET_STUMBLE_LIFTUP, LG_REW_FOUR_FOOTUP,
+  LG_REW_GAIT_2_STEP, LG_REW_GAIT_SCHEDULER, LG_REW_JUMP_AIR, LG_REW_LIN_VEL_Z, LG_REW_ORIENTATION,
+  LG_REW_STAND_STILL, LG_REW_TERMINATION, LG_REW_TORQUE_LIMITS, LG_REW_TORQUES, LG_REW_TRACKING_ANG_VEL,
+  LG_REW_TRACKING_LIN_VEL, LG_REW_COUNT
+};
+
+/* arena tensors (names follow the reference's attribute names, legged_robot.py:559-647, base_task.py:71-79) */
+enum lg_tensor_id {
+  LG_T_ROOT_STATES = 0,     /* (N,13) f32  pos3, quat xyzw4, lin vel3, ang vel3 — world frame          */
+  LG_T_DOF_STATE,           /* (N,12,2) f32 pos, vel                                                   */
+  LG_T_RIGID_BODY_STATE,    /* (N,B,13) f32                                                            */
+  LG_T_CONTACT_FORCES,      /* (N,B,3) f32 net contact force per body, world frame, last substep       */
+  LG_T_TORQUES,             /* (N,12) f32                                                              */
+  LG_T_ACTIONS,             /* (N,12) f32 clipped actions                                              */
+  LG_T_LAST_ACTIONS,        /* (N,12)                                                                  */
+  LG_T_LAST_DOF_VEL,        /* (N,12)                                                                  */
+  LG_T_LAST_ROOT_VEL,       /* (N,6)                                                                   */
+  LG_T_COMMANDS,            /* (N,4)                                                                   */
+  LG_T_BASE_LIN_VEL,        /* (N,3)                                                                   */
+  LG_T_BASE_ANG_VEL,        /* (N,3)                                                                   */
+  LG_T_PROJECTED_GRAVITY,   /* (N,3)                                                                   */
+  LG_T_BASE_LIN_ACC,        /* (N,3)                                                                   */
+  LG_T_BASE_ANG_ACC,        /* (N,3)                                                                   */
+  LG_T_FEET_AIR_TIME,       /* (N,4)                                                                   */
+  LG_T_FEET_CONTACT_TIME,   /* (N,4)                                                                   */
+  LG_T_LAST_CONTACTS,       /* (N,4) u8                                                                */
+  LG_T_MEASURED_HEIGHTS,    /* (N,P) f32                                                               */
+  LG_T_OBS_BUF,             /* (N,num_obs) f32                                                         */
+  LG_T_REW_BUF,             /* (N) f32                                                                 */
+  LG_T_RESET_BUF,           /* (N) u8                                                                  */
+  LG_T_TIME_OUT_BUF,        /* (N) u8                                                                  */
+  LG_T_EPISODE_LENGTH_BUF,  /* (N) i64                                                                 */
+  LG_T_EPISODE_SUMS,        /* (K,N) f32, row k = episode_sums[reward_names[k]]                        */
+  LG_T_TERRAIN_LEVELS,      /* (N) i64                                                                 */
+  LG_T_TERRAIN_TYPES,       /* (N) i64                                                                 */
+  LG_T_ENV_ORIGINS,         /* (N,3) f32                                                               */
+  LG_T_FRICTION_COEFFS,     /* (N) f32 per-env shape friction (legged_robot.py:332-343)                */
+  LG_T_BASE_MASS_ADDED,     /* (N) f32 per-env payload (legged_robot.py:381-383)                       */
+  LG_T_SEA_HIDDEN_STATE,    /* (2,N*12,8) f32 (anymal.py:88)                                           */
+  LG_T_SEA_CELL_STATE,      /* (2,N*12,8) f32 (anymal.py:89)                                           */
+  LG_T_GAIT_IDX,            /* (N) f32 (gait_scheduler.py:60)                                          */
+  LG_T_GAIT_FOOT_Z,         /* (N,4) f32 foot heights handed to GaitScheduler.step by the previous step (gait_scheduler.py:71) */
+  LG_T_EXTRAS_EPISODE,      /* (K+1) f32: mean episode sum / max_episode_length_s per reward term over the
+                               envs reset in the most recent step that reset any (:200-203); [K] = mean terrain level */
+  LG_T_RAND_INJECT,         /* (N, LG_RS_NOISE+num_obs) f32, only read when rng_mode == LG_RNG_INJECT   */
+  LG_T_STEP_COUNTERS,       /* (4) i64: [0] common_step_counter, [1] #envs reset by the last step       */
+  LG_T_HEIGHT_SAMPLES,      /* (rows, cols) i16, read-only terrain grid                                */
+  LG_T_TERRAIN_ORIGINS,     /* (levels, types, 3) f32                                                  */
+  LG_T_COUNT
+};
+
+typedef struct lg_robot_model {
+  int32_t num_bodies;                 /* 1 + 4*(3 + has_foot_body) */
+  int32_t has_foot_body;              /* FOOT links kept by dont_collapse="true" */
+  float base_mass;
+  float base_com[3];                  /* base frame */
+  float base_inertia[6];              /* about COM, base axes: xx xy xz yy yz zz */
+  /* DOF / leg order = Isaac Gym asset order (alphabetical depth-first): leg l, joint j -> dof 3*l+j */
+  float joint_pos[LG_NUM_LEGS][LG_JOINTS_PER_LEG][3];   /* joint frame origin in parent body frame */
+  float joint_rot[LG_NUM_LEGS][LG_JOINTS_PER_LEG][9];   /* row-major rotation parent body -> joint frame at q = 0 */
+  float joint_axis[LG_NUM_LEGS][LG_JOINTS_PER_LEG][3];  /* unit axis, joint frame */
+  float link_mass[LG_NUM_LEGS][LG_JOINTS_PER_LEG];
+  float link_com[LG_NUM_LEGS][LG_JOINTS_PER_LEG][3];    /* link frame */
+  float link_inertia[LG_NUM_LEGS][LG_JOINTS_PER_LEG][6];/* about COM, link axes */
+  float foot_pos[LG_NUM_LEGS][3];     /* FOOT body frame in the last link's frame */
+  float foot_rot[LG_NUM_LEGS][9];
+  float dof_lower[LG_NUM_DOF], dof_upper[LG_NUM_DOF]; /* hard limits; lower >= upper means unlimited */
+  float dof_vel_limit[LG_NUM_DOF];
+  float torque_limit[LG_NUM_DOF];     /* URDF effort */
+  /* collision spheres, grouped by the leg lane that owns them; link -1 = base, 0..2 = leg link, 3 = foot body */
+  int32_t cp_count[LG_NUM_LEGS];
+  int32_t cp_link[LG_NUM_LEGS][LG_MAX_CP];
+  int32_t cp_body[LG_NUM_LEGS][LG_MAX_CP];              /* rigid-body index the contact force is reported on */
+  float cp_pos[LG_NUM_LEGS][LG_MAX_CP][3];              /* in the owning link's frame (foot: last link frame) */
+  float cp_radius[LG_NUM_LEGS][LG_MAX_CP];
+  int32_t feet_indices[LG_NUM_LEGS];
+  int32_t num_penalised, penalised_contact_indices[LG_MAX_INDEX_LIST];
+  int32_t num_termination, termination_contact_indices[LG_MAX_INDEX_LIST];
+} lg_robot_model;
+
+typedef struct lg_terrain {
+  int32_t mesh_type;                  /* lg_mesh */
+  int32_t rows, cols;                 /* height_samples shape (tot_rows, tot_cols); 0 for plane */
+  float horizontal_scale, vertical_scale, border_size;
+  float static_friction;
+  const int16_t* height_samples;      /* HOST pointer, rows*cols, copied at lg_create */
+  int32_t num_levels, num_types;      /* terrain_origins shape (num_levels, num_types, 3) */
+  const float* terrain_origins;       /* HOST pointer, copied at lg_create */
+  float env_length;                   /* terrain.env_length, curriculum distance threshold (:510) */
+} lg_terrain;
+
+typedef struct lg_config {
+  int32_t abi_version;
+  int32_t num_envs, num_obs, num_height_points;
+  float sim_dt; int32_t decimation; float gravity[3];
+  /* control */
+  int32_t control_type; float action_scale;
+  float p_gains[LG_NUM_DOF], d_gains[LG_NUM_DOF], default_dof_pos[LG_NUM_DOF];
+  float clip_actions, clip_observations;
+  float actuator_net[LG_LSTM_NPARAM]; /* w_ih0(32x2) w_hh0(32x8) b_ih0(32) b_hh0(32) w_ih1(32x8) w_hh1(32x8) b_ih1 b_hh1 lin_w(8) lin_b(1) */
+  float actuator_in_scale[2], actuator_out_scale;
+  /* observations (legged_robot.py:234-252) */
+  float obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_height;
+  int32_t measure_heights, add_noise;
+  const float* noise_scale_vec;       /* HOST, num_obs */
+  const float* height_points;         /* HOST, num_height_points x 2 (x, y) base-frame scan grid (:884-898) */
+  /* commands (:405-423) */
+  int32_t heading_command, resampling_steps;
+  float cmd_lin_vel_x[2], cmd_lin_vel_y[2], cmd_ang_vel_yaw[2], cmd_heading[2];
+  /* domain randomisation (:491-496) */
+  int32_t push_robots, push_interval; float max_push_vel_xy;
+  /* rewards (:215-232, :649-674) — terms in evaluation order, scales already multiplied by dt */
+  int32_t num_reward_terms;           /* K, incl. termination if present (always last row) */
+  int32_t reward_term_ids[LG_MAX_REWARD_TERMS];
+  float reward_scales[LG_MAX_REWARD_TERMS];
+  int32_t only_positive_rewards;
+  float tracking_sigma, base_height_target, max_contact_force, soft_dof_vel_limit, soft_torque_limit;
+  float dof_pos_limits[LG_NUM_DOF][2];/* soft limits (:366-370) */
+  /* episode / curriculum */
+  float max_episode_length, max_episode_length_s;
+  int32_t curriculum, custom_origins, max_terrain_level;
+  float base_init_state[13];
+  /* gait scheduler (anymal.py:59-63, gait_scheduler.py:63-81) */
+  int32_t gait_enabled; float gait_period, gait_swing_height, gait_foot_phases[LG_NUM_LEGS];
+  /* contact solver (legged_robot_config.py:250-267) */
+  int32_t solver_iterations;          /* physx.num_position_iterations */
+  float contact_offset, max_depenetration_velocity, erp, cfm;
+  /* rng */
+  uint64_t seed; int32_t rng_mode;
+} lg_config;
+
+typedef struct lg_ctx lg_ctx;
+
+/* sizes of the ABI structs as compiled into the library, for binding-side sanity checks */
+void lg_abi_sizes(int32_t out[4]); /* {LG_ABI_VERSION, sizeof(lg_config), sizeof(lg_robot_model), sizeof(lg_terrain)} */
+
+/* Bytes of device arena a context with this configuration needs (256-B aligned tensors). */
+size_t lg_arena_bytes(const lg_config* cfg, const lg_robot_model* model, const lg_terrain* terrain);
+
+/* Create a context on `device_id`.  `arena` is a device pointer to lg_arena_bytes() bytes owned by the host
+ * (zero-initialised by the library), or NULL to let the library hipMalloc it.  Returns NULL on failure;
+ * lg_last_error(NULL) then holds the reason. */
+lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_terrain* terrain,
+                  int device_id, void* arena);
+
+/* Device pointer / shape / dtype of an arena tensor.  Pointers stay valid until lg_destroy. */
+int lg_get_tensor(lg_ctx* ctx, int tensor_id, void** dptr, int64_t shape[4], int32_t* ndim, int32_t* dtype);
+
+/* One policy step: clip actions, `decimation` x (actuator torques + articulated dynamics + contact), then the
+ * fused post-physics step.  `actions` is a device pointer to (N,12) f32.  Replaces legged_robot.py:93-110. */
+int lg_step(lg_ctx* ctx, const float* actions, void* stream);
+
+/* Pieces of lg_step, exposed because the reference exposes them as overridable methods / gym calls. */
+int lg_compute_torques(lg_ctx* ctx, const float* actions, void* stream);  /* -> LG_T_TORQUES (and LSTM state) */
+int lg_simulate(lg_ctx* ctx, void* stream);                               /* one dt with LG_T_TORQUES applied */
+int lg_post_physics_step(lg_ctx* ctx, void* stream);
+
+/* Reset the listed envs (device pointer to n int32 ids).  `update_curriculum` = the reference's init_done. */
+int lg_reset_idx(lg_ctx* ctx, const int32_t* env_ids, int32_t n, int32_t update_curriculum, void* stream);
+
+const char* lg_last_error(lg_ctx* ctx);
+void lg_destroy(lg_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGSTEP_H */

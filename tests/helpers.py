@@ -1,0 +1,92 @@
+"""Shared test plumbing: build configs / native setups for the golden cases, and drive an env core (the CPU oracle or
+the HIP library, both expose the same tensor names) through one golden step."""
+import json
+import os
+
+import numpy as np
+
+from extended_legged_gym_amd import abi
+from extended_legged_gym_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
+from extended_legged_gym_amd.envs.base.native_config import NativeSetup, load_robot_model
+from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_CASES = ["flat_pd", "flat_lstm", "rough_lstm", "rough_allrew"]
+ANYMAL_GAIT = dict(period=0.6, swing_height=0.15, foot_phases=[0.0, 0.5, 0.5, 0.0])   # anymal.py:59-63
+
+
+class FixtureTerrain:
+    def __init__(self, heightsamples, env_origins, env_length):
+        self.heightsamples, self.env_origins, self.env_length = heightsamples, env_origins, env_length
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"anymal_{name}.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return z, meta
+
+
+def sim_params_for(cfg):
+    return parse_sim_params(get_args([]), {"sim": class_to_dict(cfg.sim)})
+
+
+def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
+    """Our own config classes, edited exactly as tools/refgen/make_golden.py edited the reference's."""
+    case = meta["case"]
+    cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
+    cfg.env.num_envs = case["num_envs"]
+    cfg.control.use_actuator_network = case["actuator_net"]
+    cfg.domain_rand.push_interval_s = case["push_interval_s"]
+    cfg.commands.resampling_time = case["resampling_time"]
+    cfg.commands.heading_command = case["heading_command"]
+    cfg.env.episode_length_s = case["episode_length_s"]
+    terrain = None
+    if case["base"] == "rough":
+        cfg.terrain.mesh_type = "heightfield"
+        cfg.terrain.num_rows, cfg.terrain.num_cols = case["num_rows"], case["num_cols"]
+        cfg.terrain.max_init_terrain_level = case["num_rows"] - 1
+        cfg.terrain.border_size = case["border_size"]
+        terrain = FixtureTerrain(z["height_samples"], z["terrain_origins"], cfg.terrain.terrain_length)
+    for k, v in case.get("scales", {}).items():
+        setattr(cfg.rewards.scales, k, v)
+    cfg.rewards.only_positive_rewards = case.get("only_positive_rewards", True)
+    model = load_robot_model(cfg.asset)
+    # the harness robot (tools/refgen/ref_loader.py:anymal_robot_description) carries these DOF limits
+    model["dof_lower"], model["dof_upper"] = [-9.42] * 12, [9.42] * 12
+    model["dof_vel_limit"], model["torque_limit"] = [20.0] * 12, [80.0] * 12
+    setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ANYMAL_GAIT)
+    return cfg, setup
+
+
+PRE_KEYS = ["root_states", "dof_state", "last_actions", "last_dof_vel", "last_root_vel", "commands", "base_lin_acc",
+            "base_ang_acc", "base_lin_vel", "base_ang_vel", "projected_gravity", "feet_air_time", "feet_contact_time",
+            "last_contacts", "episode_length_buf", "episode_sums", "env_origins", "gait_idx", "gait_foot_z"]
+
+
+def load_pre_state(core_t, z, t, write):
+    """`write(name, array)` stores into the env core's tensor `name`."""
+    for k in PRE_KEYS:
+        write(k, z["pre_" + k][t])
+    write("sea_hidden_state", z["pre_sea_hidden"][t])
+    write("sea_cell_state", z["pre_sea_cell"][t])
+    if "pre_terrain_levels" in z.files:
+        write("terrain_levels", z["pre_terrain_levels"][t])
+        write("terrain_types", z["terrain_types"])
+    sc = np.zeros(4, np.int64)
+    sc[0] = int(z["pre_common_step_counter"][t])
+    write("step_counters", sc)
+    write("reset_buf", z["pre_reset_buf"][t])
+    write("rand_inject", np.nan_to_num(z["rand"][t], nan=0.0))
+
+
+# name of the env-core tensor -> golden key, compared after a step
+POST_KEYS = {"root_states": "post_root_states", "dof_state": "post_dof_state", "last_actions": "post_last_actions",
+             "last_dof_vel": "post_last_dof_vel", "last_root_vel": "post_last_root_vel", "commands": "post_commands",
+             "base_lin_acc": "post_base_lin_acc", "base_ang_acc": "post_base_ang_acc", "base_lin_vel": "post_base_lin_vel",
+             "base_ang_vel": "post_base_ang_vel", "projected_gravity": "post_projected_gravity",
+             "feet_air_time": "post_feet_air_time", "feet_contact_time": "post_feet_contact_time",
+             "last_contacts": "post_last_contacts", "episode_length_buf": "post_episode_length_buf",
+             "episode_sums": "post_episode_sums", "env_origins": "post_env_origins", "gait_idx": "post_gait_idx",
+             "sea_hidden_state": "post_sea_hidden", "sea_cell_state": "post_sea_cell",
+             "obs_buf": "obs", "rew_buf": "rew", "reset_buf": "reset", "time_out_buf": "time_out", "actions": "clipped_actions"}

@@ -164,6 +164,7 @@ def persistent(env):
         episode_length_buf=env.episode_length_buf,
         episode_sums=torch.stack([env.episode_sums[k] for k in env.episode_sums.keys()]),
         env_origins=env.env_origins, gait_idx=env.gait_scheduler.gait_idx,
+        gait_foot_z=env.gait_scheduler.foot_pos[:, :, 2],
         sea_hidden=env.sea_hidden_state, sea_cell=env.sea_cell_state,
     )
     if hasattr(env, "terrain_levels"):
