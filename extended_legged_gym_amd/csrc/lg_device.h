@@ -1,0 +1,116 @@
+// lg_device.h — device-side math for the gfx950 env-step kernels (vectors, quaternions, Philox, terrain lookup).
+// Written for CDNA4 wave64: one leg per lane, four lanes (a DPP quad) per environment.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lgstep.h"
+
+#define LG_DEV __device__ __forceinline__
+
+struct V3 { float x, y, z; };
+LG_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+LG_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+LG_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+LG_DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+LG_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+LG_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+LG_DEV float norm(V3 a) { return sqrtf(dot(a, a)); }
+LG_DEV V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+
+struct M3 { float m[9]; };
+LG_DEV V3 mul(const M3& A, V3 v) {
+  return v3(A.m[0] * v.x + A.m[1] * v.y + A.m[2] * v.z, A.m[3] * v.x + A.m[4] * v.y + A.m[5] * v.z,
+            A.m[6] * v.x + A.m[7] * v.y + A.m[8] * v.z);
+}
+LG_DEV M3 mul(const M3& A, const M3& B) {
+  M3 C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+  return C;
+}
+LG_DEV M3 ldm3(const float* p) { M3 A;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) A.m[i] = p[i];
+  return A; }
+
+// symmetric 3x3 stored xx xy xz yy yz zz
+struct S3 { float xx, xy, xz, yy, yz, zz; };
+LG_DEV V3 mul(const S3& A, V3 v) { return v3(A.xx * v.x + A.xy * v.y + A.xz * v.z, A.xy * v.x + A.yy * v.y + A.yz * v.z, A.xz * v.x + A.yz * v.y + A.zz * v.z); }
+LG_DEV S3 operator+(S3 a, S3 b) { return S3{a.xx + b.xx, a.xy + b.xy, a.xz + b.xz, a.yy + b.yy, a.yz + b.yz, a.zz + b.zz}; }
+// R * diag-sym(I6) * R^T
+LG_DEV S3 rotate_inertia(const M3& R, const float* I6) {
+  M3 I = M3{{I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]}};
+  M3 T = mul(R, I);
+  S3 o;
+  o.xx = T.m[0] * R.m[0] + T.m[1] * R.m[1] + T.m[2] * R.m[2];
+  o.xy = T.m[0] * R.m[3] + T.m[1] * R.m[4] + T.m[2] * R.m[5];
+  o.xz = T.m[0] * R.m[6] + T.m[1] * R.m[7] + T.m[2] * R.m[8];
+  o.yy = T.m[3] * R.m[3] + T.m[4] * R.m[4] + T.m[5] * R.m[5];
+  o.yz = T.m[3] * R.m[6] + T.m[4] * R.m[7] + T.m[5] * R.m[8];
+  o.zz = T.m[6] * R.m[6] + T.m[7] * R.m[7] + T.m[8] * R.m[8];
+  return o;
+}
+// inertia about a point offset r from the COM (parallel-axis)
+LG_DEV S3 inertia_about(S3 Ic, float m, V3 r) {
+  float rr = dot(r, r);
+  Ic.xx += m * (rr - r.x * r.x); Ic.xy -= m * r.x * r.y; Ic.xz -= m * r.x * r.z;
+  Ic.yy += m * (rr - r.y * r.y); Ic.yz -= m * r.y * r.z; Ic.zz += m * (rr - r.z * r.z);
+  return Ic;
+}
+
+LG_DEV M3 quat_to_mat(const float* q) {
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  return M3{{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+             2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+             2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+}
+LG_DEV M3 axis_angle(V3 a, float q) {
+  float s, c; sincosf(q, &s, &c); float t = 1 - c;
+  return M3{{t * a.x * a.x + c, t * a.x * a.y - s * a.z, t * a.x * a.z + s * a.y,
+             t * a.x * a.y + s * a.z, t * a.y * a.y + c, t * a.y * a.z - s * a.x,
+             t * a.x * a.z - s * a.y, t * a.y * a.z + s * a.x, t * a.z * a.z + c}};
+}
+LG_DEV void mat_to_quat(const M3& R, float* q) {
+  float tr = R.m[0] + R.m[4] + R.m[8];
+  float x, y, z, w;
+  if (tr > 0) { float s = sqrtf(tr + 1.f) * 2; w = 0.25f * s; x = (R.m[7] - R.m[5]) / s; y = (R.m[2] - R.m[6]) / s; z = (R.m[3] - R.m[1]) / s; }
+  else if (R.m[0] > R.m[4] && R.m[0] > R.m[8]) { float s = sqrtf(1.f + R.m[0] - R.m[4] - R.m[8]) * 2; w = (R.m[7] - R.m[5]) / s; x = 0.25f * s; y = (R.m[1] + R.m[3]) / s; z = (R.m[2] + R.m[6]) / s; }
+  else if (R.m[4] > R.m[8]) { float s = sqrtf(1.f + R.m[4] - R.m[0] - R.m[8]) * 2; w = (R.m[2] - R.m[6]) / s; x = (R.m[1] + R.m[3]) / s; y = 0.25f * s; z = (R.m[5] + R.m[7]) / s; }
+  else { float s = sqrtf(1.f + R.m[8] - R.m[0] - R.m[4]) * 2; w = (R.m[3] - R.m[1]) / s; x = (R.m[2] + R.m[6]) / s; y = (R.m[5] + R.m[7]) / s; z = 0.25f * s; }
+  q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+}
+// isaacgym.torch_utils.quat_rotate_inverse / quat_apply (xyzw), see extended_legged_gym_amd/utils/isaac_torch_utils.py
+LG_DEV V3 quat_rotate_inverse(const float* q, V3 v) {
+  float qw = q[3]; V3 qv = v3(q[0], q[1], q[2]);
+  V3 a = (2.0f * qw * qw - 1.0f) * v;
+  V3 b = 2.0f * (qw * cross(qv, v));
+  V3 c = 2.0f * (dot(qv, v) * qv);
+  return a - b + c;
+}
+LG_DEV V3 quat_apply(const float* q, V3 b) {
+  V3 xyz = v3(q[0], q[1], q[2]);
+  V3 t = 2.0f * cross(xyz, b);
+  return (b + q[3] * t) + cross(xyz, t);
+}
+
+// ---- quad (4-lane) all-reduce through DPP quad_perm: two v_add_f32_dpp, no LDS
+LG_DEV float dpp_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); }
+LG_DEV float dpp_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)); }
+LG_DEV float quad_sum(float x) { x += dpp_xor1(x); x += dpp_xor2(x); return x; }
+LG_DEV V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
+LG_DEV S3 quad_sum(S3 a) { return S3{quad_sum(a.xx), quad_sum(a.xy), quad_sum(a.xz), quad_sum(a.yy), quad_sum(a.yz), quad_sum(a.zz)}; }
+
+// ---- Philox4x32-10; counter = (env, step, slot group, stream), key = seed
+LG_DEV void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+LG_DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }

@@ -1,0 +1,869 @@
+// lg_step.hip — gfx950 (MI355X) kernels and C-ABI implementation of the legged-robot environment step.
+// ABI: include/lgstep.h.  Reference behaviour: legged_gym/envs/base/legged_robot.py ("LR"),
+// legged_robot_rew_mixin.py ("RM"), anymal_c/anymal.py, utils/gait_scheduler.py, utils/math_utils.py.
+//
+// Kernels
+//   physics_kernel   one DPP quad (4 lanes) per env, one leg per lane, 16 envs per wave64; clip actions, then
+//                    `decimation` x (actuator torques [PD | LSTM] + articulated dynamics + contact) entirely in
+//                    registers/LDS; state is read once and written once per policy step.
+//   post_kernel      16 envs per 256-thread workgroup: (1) cooperative terrain height scan, (2) one lane per env for the
+//                    scalar logic (commands, termination, rewards, reset, curriculum), (3) cooperative observation
+//                    assembly + noise with coalesced row stores.
+//   finalize_kernel  one workgroup: fixed-order reduction of the per-workgroup episode statistics (deterministic).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "lg_physics.h"
+
+#define EPB 16          // envs per workgroup in post_kernel / per wave in physics_kernel
+#define MAX_P 192       // height-scan points per env held in LDS
+
+struct DevCtx {
+  lg_config cfg;
+  lg_robot_model model;
+  int N, B, K, P, per_leg;
+  TerrainView ter;
+  float terrain_mu, env_length; int num_levels, num_types;
+  // tensors (device pointers into the arena)
+  float *root, *dof, *rigid, *cforce, *torques, *actions, *last_actions, *last_dof_vel, *last_root_vel, *commands;
+  float *base_lin_vel, *base_ang_vel, *proj_grav, *base_lin_acc, *base_ang_acc, *feet_air, *feet_ctime;
+  uint8_t* last_contacts;
+  float *heights, *obs, *rew;
+  uint8_t *reset_buf, *time_out;
+  int64_t* ep_len;
+  float* ep_sums;
+  int64_t *levels, *types;
+  float *origins, *friction, *mass_added, *sea_h, *sea_c, *gait_idx, *gait_foot_z, *extras, *rand_inject;
+  int64_t* counters;
+  const float* terrain_origins;
+  const float *noise_vec, *height_points;
+  float* partials;     // [nblocks][K + 2] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels
+  int nblocks_post;
+};
+
+struct TensorInfo { size_t off; int64_t shape[4]; int ndim; int dtype; };
+
+struct lg_ctx {
+  DevCtx h;            // host copy
+  DevCtx* d = nullptr; // device copy
+  void* arena = nullptr; bool own_arena = false; size_t arena_bytes = 0;
+  void* aux = nullptr; // noise_vec, height_points, partials
+  TensorInfo t[LG_T_COUNT];
+  int device = 0;
+  std::string err;
+};
+
+static thread_local std::string g_err;
+
+// ============================================================================================ device: RNG
+LG_DEV float uniform_draw(const DevCtx* __restrict__ C, int e, int slot, int64_t step, uint32_t stream) {
+  if (C->cfg.rng_mode == LG_RNG_INJECT) return C->rand_inject[(size_t)e * (LG_RS_NOISE + C->cfg.num_obs) + slot];
+  uint32_t o[4];
+  philox4((uint32_t)e, (uint32_t)step, (uint32_t)(slot >> 2), stream, (uint32_t)C->cfg.seed, (uint32_t)(C->cfg.seed >> 32), o);
+  uint32_t x = (slot & 3) == 0 ? o[0] : ((slot & 3) == 1 ? o[1] : ((slot & 3) == 2 ? o[2] : o[3]));
+  return u01(x);
+}
+LG_DEV float rand_float(float lo, float hi, float u) { return (hi - lo) * u + lo; }
+
+// ============================================================================================ device: actuators
+LG_DEV float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+LG_DEV float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+
+// one LSTM-actuator evaluation for one joint (anymal.py:93-105); h*/c* are this joint's 8-float states
+LG_DEV float lstm_actuator(const float* __restrict__ W, float x0, float x1, float* h0, float* c0, float* h1, float* c1,
+                           float out_scale) {
+  const float *wih0 = W, *whh0 = W + 64, *bih0 = W + 320, *bhh0 = W + 352, *wih1 = W + 384, *whh1 = W + 640,
+              *bih1 = W + 896, *bhh1 = W + 928, *lw = W + 960, *lb = W + 968;
+  float g[32], hn0[8], hn1[8];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    float s = bih0[r] + bhh0[r] + wih0[2 * r] * x0 + wih0[2 * r + 1] * x1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += whh0[8 * r + k] * h0[k];
+    g[r] = s;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float cn = fast_sigmoid(g[8 + k]) * c0[k] + fast_sigmoid(g[k]) * fast_tanh(g[16 + k]);
+    c0[k] = cn; hn0[k] = fast_sigmoid(g[24 + k]) * fast_tanh(cn);
+  }
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    float s = bih1[r] + bhh1[r];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += wih1[8 * r + k] * hn0[k] + whh1[8 * r + k] * h1[k];
+    g[r] = s;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float cn = fast_sigmoid(g[8 + k]) * c1[k] + fast_sigmoid(g[k]) * fast_tanh(g[16 + k]);
+    c1[k] = cn; hn1[k] = fast_sigmoid(g[24 + k]) * fast_tanh(cn);
+  }
+  float o = lb[0];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { o += lw[k] * hn1[k]; h0[k] = hn0[k]; h1[k] = hn1[k]; }
+  return out_scale * o;
+}
+
+struct LegActuator { float h[2][3][8], c[2][3][8]; };   // LSTM state of this lane's three joints
+
+LG_DEV void load_lstm(const DevCtx* __restrict__ C, int e, int l, LegActuator& A) {
+  const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + 3 * l;
+#pragma unroll
+  for (int lay = 0; lay < 2; ++lay)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        A.h[lay][j][k] = C->sea_h[(lay * N12 + row + j) * 8 + k];
+        A.c[lay][j][k] = C->sea_c[(lay * N12 + row + j) * 8 + k];
+      }
+}
+LG_DEV void store_lstm(const DevCtx* __restrict__ C, int e, int l, const LegActuator& A) {
+  const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + 3 * l;
+#pragma unroll
+  for (int lay = 0; lay < 2; ++lay)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        C->sea_h[(lay * N12 + row + j) * 8 + k] = A.h[lay][j][k];
+        C->sea_c[(lay * N12 + row + j) * 8 + k] = A.c[lay][j][k];
+      }
+}
+
+// torques of this lane's three joints (LR:425-448 / anymal.py:93-105)
+LG_DEV void leg_torques(const DevCtx* __restrict__ C, int l, const float act[3], const float q[3], const float qd[3],
+                        const float last_qd[3], LegActuator& A, float tau[3]) {
+  const lg_config& g = C->cfg;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int d = 3 * l + j;
+    float a = act[j] * g.action_scale;
+    if (g.control_type == LG_CTRL_ACTUATOR_NET) {
+      float x0 = (a + g.default_dof_pos[d] - q[j]) * g.actuator_in_scale[0], x1 = qd[j] * g.actuator_in_scale[1];
+      tau[j] = lstm_actuator(g.actuator_net, x0, x1, A.h[0][j], A.c[0][j], A.h[1][j], A.c[1][j], g.actuator_out_scale);
+    } else {
+      float t;
+      if (g.control_type == LG_CTRL_P) t = g.p_gains[d] * (a + g.default_dof_pos[d] - q[j]) - g.d_gains[d] * qd[j];
+      else if (g.control_type == LG_CTRL_V) t = g.p_gains[d] * (a - qd[j]) - g.d_gains[d] * (qd[j] - last_qd[j]) / g.sim_dt;
+      else t = a;
+      float lim = C->model.torque_limit[d];
+      tau[j] = fminf(fmaxf(t, -lim), lim);
+    }
+  }
+}
+
+// ============================================================================================ physics kernel
+// MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
+// MODE 2: lg_compute_torques only.
+template <int MODE>
+__global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub) {
+  __shared__ float cst[LG_MAX_CP * CF_FIELDS * 64];
+  const int lane = threadIdx.x;
+  int e = blockIdx.x * EPB + (lane >> 2);
+  const int l = lane & 3;
+  const bool valid = e < C->N;
+  if (!valid) e = C->N - 1;          // whole quads are (in)valid together; invalid quads compute on a copy and store nothing
+  const lg_robot_model* __restrict__ m = &C->model;
+  const lg_config& g = C->cfg;
+
+  QuadState s;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) s.root[i] = C->root[(size_t)e * 13 + i];
+  float last_qd[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    s.q[j] = C->dof[((size_t)e * 12 + 3 * l + j) * 2];
+    s.qd[j] = C->dof[((size_t)e * 12 + 3 * l + j) * 2 + 1];
+    last_qd[j] = C->last_dof_vel[(size_t)e * 12 + 3 * l + j];
+  }
+  float act[3] = {0, 0, 0};
+  if (MODE != 1) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float a = actions_in ? actions_in[(size_t)e * 12 + 3 * l + j] : C->actions[(size_t)e * 12 + 3 * l + j];
+      a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);        // LR:93-94
+      act[j] = a;
+      if (valid && actions_in) C->actions[(size_t)e * 12 + 3 * l + j] = a;
+    }
+  }
+  LegActuator A;
+  const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
+  if (MODE != 1 && net) load_lstm(C, e, l, A);
+
+  float tau[3];
+  if (MODE == 2) {
+    leg_torques(C, l, act, s.q, s.qd, last_qd, A, tau);
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) C->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
+      if (net) store_lstm(C, e, l, A);
+    }
+    return;
+  }
+
+  PhysParams P;
+  P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
+  P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm;
+  P.terrain_mu = C->terrain_mu;
+  const TerrainView T = C->ter;
+  const float mu_robot = C->friction[e], madd = C->mass_added[e];
+  V3 fbody[5];
+#pragma unroll 1
+  for (int sub = 0; sub < nsub; ++sub) {
+    if (MODE == 0) leg_torques(C, l, act, s.q, s.qd, last_qd, A, tau);
+    else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) tau[j] = C->torques[(size_t)e * 12 + 3 * l + j];
+    }
+    physics_substep(m, T, P, l, lane, cst, s, tau, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr);
+  }
+  if (!valid) return;
+
+  // ---- write back state, torques, contact forces
+  if (l == 0) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) C->root[(size_t)e * 13 + i] = s.root[i];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    C->dof[((size_t)e * 12 + 3 * l + j) * 2] = s.q[j];
+    C->dof[((size_t)e * 12 + 3 * l + j) * 2 + 1] = s.qd[j];
+    if (MODE == 0) C->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
+  }
+  if (MODE == 0 && net) store_lstm(C, e, l, A);
+  const int per_leg = C->per_leg, B = C->B;
+  {
+    float* cf = C->cforce + (size_t)e * B * 3;
+    if (l == 0) { cf[0] = fbody[0].x; cf[1] = fbody[0].y; cf[2] = fbody[0].z; }
+    float* cl = cf + (size_t)(1 + per_leg * l) * 3;
+    V3 last = fbody[3];
+    if (per_leg == 3) last = last + fbody[4];      // no separate foot body: its spheres report on the last link
+    cl[0] = fbody[1].x; cl[1] = fbody[1].y; cl[2] = fbody[1].z;
+    cl[3] = fbody[2].x; cl[4] = fbody[2].y; cl[5] = fbody[2].z;
+    cl[6] = last.x; cl[7] = last.y; cl[8] = last.z;
+    if (per_leg == 4) { cl[9] = fbody[4].x; cl[10] = fbody[4].y; cl[11] = fbody[4].z; }
+  }
+  // ---- rigid-body state of the post-step configuration (LR:118-120 refresh_rigid_body_state_tensor)
+  {
+    const M3 Rb = quat_to_mat(s.root + 3);
+    const V3 pb = v3(s.root[0], s.root[1], s.root[2]), vb = v3(s.root[7], s.root[8], s.root[9]), wb = v3(s.root[10], s.root[11], s.root[12]);
+    LegKin k;
+    leg_kinematics(m, l, Rb, pb, vb, wb, s.q, s.qd, k);
+    float* rb = C->rigid + (size_t)e * B * 13;
+    if (l == 0) {
+#pragma unroll
+      for (int i = 0; i < 13; ++i) rb[i] = s.root[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float* o = rb + (size_t)(1 + per_leg * l + j) * 13;
+      float qq[4]; mat_to_quat(k.R[j], qq);
+      o[0] = k.O[j].x; o[1] = k.O[j].y; o[2] = k.O[j].z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
+      o[7] = k.vO[j].x; o[8] = k.vO[j].y; o[9] = k.vO[j].z; o[10] = k.w[j].x; o[11] = k.w[j].y; o[12] = k.w[j].z;
+    }
+    if (per_leg == 4) {
+      float* o = rb + (size_t)(1 + per_leg * l + 3) * 13;
+      V3 r = mul(k.R[2], ld3(m->foot_pos[l]));
+      V3 p = k.O[2] + r, v = k.vO[2] + cross(k.w[2], r);
+      float qq[4]; mat_to_quat(mul(k.R[2], ldm3(m->foot_rot[l])), qq);
+      o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
+      o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = k.w[2].x; o[11] = k.w[2].y; o[12] = k.w[2].z;
+    }
+  }
+}
+
+// ============================================================================================ post-physics helpers
+LG_DEV float wrap_to_pi(float a) {   // math_utils.py:55-58
+  const float two_pi = 6.28318530717958647692f, pi = 3.14159265358979323846f;
+  float r = fmodf(a, two_pi);
+  if (r != 0.f && r < 0.f) r += two_pi;
+  if (r > pi) r -= two_pi;
+  return r;
+}
+
+LG_DEV void resample_commands(const DevCtx* __restrict__ C, int e, int slot0, int64_t step, uint32_t stream) {  // LR:405-423
+  const lg_config& g = C->cfg; float* cmd = C->commands + (size_t)e * 4;
+  float c0 = rand_float(g.cmd_lin_vel_x[0], g.cmd_lin_vel_x[1], uniform_draw(C, e, slot0, step, stream));
+  float c1 = rand_float(g.cmd_lin_vel_y[0], g.cmd_lin_vel_y[1], uniform_draw(C, e, slot0 + 1, step, stream));
+  float u2 = uniform_draw(C, e, slot0 + 2, step, stream);
+  if (g.heading_command) cmd[3] = rand_float(g.cmd_heading[0], g.cmd_heading[1], u2);
+  else cmd[2] = rand_float(g.cmd_ang_vel_yaw[0], g.cmd_ang_vel_yaw[1], u2);
+  float keep = sqrtf(c0 * c0 + c1 * c1) > 0.2f ? 1.f : 0.f;
+  cmd[0] = c0 * keep; cmd[1] = c1 * keep;
+}
+
+// LR:900-938 + math_utils.quat_apply_yaw: the index arithmetic must round exactly like the reference's separate
+// fp32 torch kernels, so contraction into FMAs is disabled for this function.
+#pragma clang fp contract(off)
+LG_DEV float terrain_height_at(const DevCtx* __restrict__ C, float qz, float qw, float px0, float py0, float bx, float by) {
+  float tx = (0.f - qz * by) * 2.f, ty = (qz * bx - 0.f) * 2.f;
+  float rx = (bx + qw * tx) + (0.f - qz * ty);
+  float ry = (by + qw * ty) + (qz * tx - 0.f);
+  float px = ((rx + px0) + C->ter.border) / C->ter.hscale;
+  float py = ((ry + py0) + C->ter.border) / C->ter.hscale;
+  int ix = (int)px, iy = (int)py;                       // trunc toward zero (tensor.long())
+  ix = max(0, min(ix, C->ter.rows - 2)); iy = max(0, min(iy, C->ter.cols - 2));
+  const int16_t* H = C->ter.H + (size_t)ix * C->ter.cols + iy;
+  int16_t h1 = H[0], h2 = H[C->ter.cols], h3 = H[1];
+  int16_t h = h1 < h2 ? h1 : h2; h = h < h3 ? h : h3;
+  return (float)h * C->ter.vscale;
+}
+#pragma clang fp contract(fast)
+
+LG_DEV void reset_env(const DevCtx* __restrict__ C, int e, int update_curriculum, int64_t step, uint32_t stream) {  // LR:162-213
+  const lg_config& g = C->cfg;
+  float* root = C->root + (size_t)e * 13; float* dof = C->dof + (size_t)e * 24;
+  float* org = C->origins + (size_t)e * 3; float* cmd = C->commands + (size_t)e * 4;
+  if (g.curriculum && update_curriculum) {   // LR:498-518
+    int64_t typ = C->types[e];
+    float dx = root[0] - org[0], dy = root[1] - org[1];
+    float dist = sqrtf(dx * dx + dy * dy);
+    bool up = dist > C->env_length / 2;
+    bool down = (dist < sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) * g.max_episode_length_s * 0.5f) && !up;
+    int64_t L = C->levels[e] + (up ? 1 : 0) - (down ? 1 : 0);
+    if (L >= g.max_terrain_level) L = (int64_t)floorf(uniform_draw(C, e, LG_RS_LEVEL, step, stream) * (float)g.max_terrain_level);
+    else if (L < 0) L = 0;
+    C->levels[e] = L;
+    const float* to = C->terrain_origins + ((size_t)L * C->num_types + typ) * 3;
+    org[0] = to[0]; org[1] = to[1]; org[2] = to[2];
+  }
+  for (int d = 0; d < 12; ++d) {   // LR:450-465
+    dof[2 * d] = g.default_dof_pos[d] * rand_float(0.5f, 1.5f, uniform_draw(C, e, LG_RS_DOF + d, step, stream));
+    dof[2 * d + 1] = 0.f;
+  }
+  float r[13];
+  for (int i = 0; i < 13; ++i) r[i] = g.base_init_state[i];   // LR:467-489
+  r[0] += org[0]; r[1] += org[1]; r[2] += org[2];
+  if (g.custom_origins) {
+    r[0] += rand_float(-0.5f, 0.5f, uniform_draw(C, e, LG_RS_ROOT_XY, step, stream));
+    r[1] += rand_float(-0.5f, 0.5f, uniform_draw(C, e, LG_RS_ROOT_XY + 1, step, stream));
+  }
+  for (int i = 0; i < 6; ++i) r[7 + i] = rand_float(-0.5f, 0.5f, uniform_draw(C, e, LG_RS_ROOT_VEL + i, step, stream));
+  for (int i = 0; i < 13; ++i) root[i] = r[i];
+  resample_commands(C, e, LG_RS_CMD_RESET, step, stream);
+  for (int d = 0; d < 12; ++d) { C->last_actions[(size_t)e * 12 + d] = 0.f; C->last_dof_vel[(size_t)e * 12 + d] = 0.f; }
+  for (int f = 0; f < 4; ++f) { C->feet_air[(size_t)e * 4 + f] = 0.f; C->feet_ctime[(size_t)e * 4 + f] = 0.f; }
+  C->ep_len[e] = 0;
+  C->reset_buf[e] = 1;
+  if (g.control_type == LG_CTRL_ACTUATOR_NET) {   // anymal.py:78-82
+    const size_t N12 = (size_t)C->N * 12;
+    for (int lay = 0; lay < 2; ++lay)
+      for (int k = 0; k < 96; ++k) {
+        C->sea_h[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
+        C->sea_c[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
+      }
+  }
+}
+
+// every _reward_* of RM:41-234 (+ anymal.py:112-114), selected by id
+LG_DEV float reward_term(const DevCtx* __restrict__ C, int e, int id, const float* s_h, int64_t step) {
+  const lg_config& g = C->cfg; const lg_robot_model& m = C->model; const float dt = g.sim_dt * g.decimation;
+  const float* root = C->root + (size_t)e * 13; const float* dof = C->dof + (size_t)e * 24;
+  const float* blv = C->base_lin_vel + (size_t)e * 3; const float* bav = C->base_ang_vel + (size_t)e * 3;
+  const float* pg = C->proj_grav + (size_t)e * 3; const float* cmd = C->commands + (size_t)e * 4;
+  const float* tq = C->torques + (size_t)e * 12; const float* act = C->actions + (size_t)e * 12;
+  const float* lact = C->last_actions + (size_t)e * 12; const float* ldv = C->last_dof_vel + (size_t)e * 12;
+  const float* cf = C->cforce + (size_t)e * C->B * 3; const float* rb = C->rigid + (size_t)e * C->B * 13;
+  float* air = C->feet_air + (size_t)e * 4; float* ctime = C->feet_ctime + (size_t)e * 4;
+  uint8_t* lastc = C->last_contacts + (size_t)e * 4;
+  const float cmdn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
+#define SQ(x) ((x) * (x))
+#define FNORM(b) sqrtf(SQ(cf[3 * (b)]) + SQ(cf[3 * (b) + 1]) + SQ(cf[3 * (b) + 2]))
+  switch (id) {
+    case LG_REW_LIN_VEL_Z: return SQ(blv[2]);
+    case LG_REW_ANG_VEL_XY: return SQ(bav[0]) + SQ(bav[1]);
+    case LG_REW_ORIENTATION: return SQ(pg[0]) + SQ(pg[1]);
+    case LG_REW_BASE_HEIGHT: {
+      float s = root[2];
+      if (g.measure_heights) { s = 0.f; for (int p = 0; p < C->P; ++p) s += root[2] - s_h[p]; s /= (float)C->P; }
+      return SQ(s - g.base_height_target);
+    }
+    case LG_REW_BASE_FOOT_HEIGHT: {
+      float s = 0.f; int n = 0;
+      for (int f = 0; f < 4; ++f) if (ctime[f] > 1e-3f) { s += rb[(size_t)m.feet_indices[f] * 13 + 2]; ++n; }
+      float est = n > 0 ? s / (float)n : root[2] - g.base_height_target;
+      return SQ((root[2] - est) - g.base_height_target);
+    }
+    case LG_REW_TORQUES: { float s = 0.f; for (int d = 0; d < 12; ++d) s += SQ(tq[d]); return s; }
+    case LG_REW_DOF_VEL: { float s = 0.f; for (int d = 0; d < 12; ++d) s += SQ(dof[2 * d + 1]); return s; }
+    case LG_REW_DOF_ACC: { float s = 0.f; for (int d = 0; d < 12; ++d) s += SQ((ldv[d] - dof[2 * d + 1]) / dt); return s; }
+    case LG_REW_ACTION_RATE: { float s = 0.f; for (int d = 0; d < 12; ++d) s += SQ(lact[d] - act[d]); return s; }
+    case LG_REW_DOF_POS_LIMITS: {
+      float s = 0.f;
+      for (int d = 0; d < 12; ++d) { float lo = dof[2 * d] - g.dof_pos_limits[d][0], hi = dof[2 * d] - g.dof_pos_limits[d][1]; s += -fminf(lo, 0.f) + fmaxf(hi, 0.f); }
+      return s;
+    }
+    case LG_REW_DOF_VEL_LIMITS: { float s = 0.f; for (int d = 0; d < 12; ++d) s += fminf(fmaxf(fabsf(dof[2 * d + 1]) - m.dof_vel_limit[d] * g.soft_dof_vel_limit, 0.f), 1.f); return s; }
+    case LG_REW_TORQUE_LIMITS: { float s = 0.f; for (int d = 0; d < 12; ++d) s += fmaxf(fabsf(tq[d]) - m.torque_limit[d] * g.soft_torque_limit, 0.f); return s; }
+    case LG_REW_COLLISION: { float s = 0.f; for (int i = 0; i < m.num_penalised; ++i) s += FNORM(m.penalised_contact_indices[i]) > 0.1f ? 1.f : 0.f; return s; }
+    case LG_REW_FEET_STUMBLE: {
+      bool any = false;
+      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; any |= sqrtf(SQ(cf[3 * b]) + SQ(cf[3 * b + 1])) > 5.f * fabsf(cf[3 * b + 2]); }
+      return any ? 1.f : 0.f;
+    }
+    case LG_REW_FEET_STUMBLE_LIFTUP: {
+      float s = 0.f;
+      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool st = sqrtf(SQ(cf[3 * b]) + SQ(cf[3 * b + 1])) > 5.f * fabsf(cf[3 * b + 2]); s += (st ? 1.f : 0.f) * rb[(size_t)b * 13 + 9]; }
+      return s;
+    }
+    case LG_REW_FEET_SLIP: {
+      float s = 0.f;
+      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool cfl = (cf[3 * b + 2] > 1.f) || lastc[f]; float vn = sqrtf(SQ(rb[(size_t)b * 13 + 7]) + SQ(rb[(size_t)b * 13 + 8])); s += (cfl ? 1.f : 0.f) * SQ(vn); }
+      return s;
+    }
+    case LG_REW_JUMP_AIR: {
+      float s = 0.f;
+      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool cfl = (cf[3 * b + 2] > 1.f) || lastc[f]; s += (cfl ? 0.f : 1.f) * (air[f] - 0.5f); }
+      return fmaxf(s - 2.f, 0.f);
+    }
+    case LG_REW_FEET_AIR_TIME: {   // RM:150-163, stateful
+      float s = 0.f;
+      for (int f = 0; f < 4; ++f) {
+        int b = m.feet_indices[f]; bool contact = cf[3 * b + 2] > 1.f; bool cfl = contact || lastc[f];
+        lastc[f] = contact ? 1 : 0;
+        float first = (air[f] > 0.f && cfl) ? 1.f : 0.f;
+        float a = air[f] + dt, ct = ctime[f] + dt;
+        s += (a - 0.5f) * first;
+        air[f] = a * (cfl ? 0.f : 1.f); ctime[f] = ct * (cfl ? 1.f : 0.f);
+      }
+      return s * (cmdn > 0.1f ? 1.f : 0.f);
+    }
+    case LG_REW_FEET_CONTACT_FORCES: { float s = 0.f; for (int f = 0; f < 4; ++f) s += fmaxf(FNORM(m.feet_indices[f]) - g.max_contact_force, 0.f); return s; }
+    case LG_REW_GAIT_2_STEP: {
+#define SYNC(a, b) (fminf(SQ(air[a] - air[b]), 4.f) + fminf(SQ(ctime[a] - ctime[b]), 4.f))
+#define ASYN(a, b) (fminf(SQ(air[a] - ctime[b]), 4.f) + fminf(SQ(ctime[a] - air[b]), 4.f))
+      float sr = (SYNC(0, 3) + SYNC(1, 2)) / 2;
+      float ar = (ASYN(0, 1) + ASYN(0, 2) + ASYN(3, 2) + ASYN(3, 1)) / 4;
+      float other = g.heading_command ? cmd[3] : cmd[2];
+      bool on = cmdn > 0.1f || fabsf(other) >= 0.05f;
+      return (sr + ar) * (on ? 1.f : 0.f);
+    }
+    case LG_REW_FOUR_FOOTUP: { bool all = true; for (int f = 0; f < 4; ++f) all &= cf[3 * m.feet_indices[f] + 2] < 1.f; return 0.1f * (all ? 1.f : 0.f); }
+    case LG_REW_TERMINATION: return (C->reset_buf[e] && !C->time_out[e]) ? 1.f : 0.f;
+    case LG_REW_STAND_STILL: { float s = 0.f; for (int d = 0; d < 12; ++d) s += fabsf(dof[2 * d] - g.default_dof_pos[d]); return s * (cmdn < 0.1f ? 1.f : 0.f); }
+    case LG_REW_TRACKING_LIN_VEL: return expf(-(SQ(cmd[0] - blv[0]) + SQ(cmd[1] - blv[1])) / g.tracking_sigma);
+    case LG_REW_TRACKING_ANG_VEL: return expf(-SQ(cmd[2] - bav[2]) / g.tracking_sigma);
+    case LG_REW_GAIT_SCHEDULER: {   // gait_scheduler.py:74-81 on the foot heights / phase stored by the previous step
+      if (!g.gait_enabled || step <= 1) return 0.f;
+      float gi = C->gait_idx[e]; const float* fz = C->gait_foot_z + (size_t)e * 4; float s = 0.f;
+      for (int f = 0; f < 4; ++f) {
+        float ph = fmodf(gi + g.gait_foot_phases[f], 1.0f);
+        float tgt = ph < 0.5f ? g.gait_swing_height * sinf(6.28318530717958647692f * ph) : 0.f;
+        s += SQ(tgt - fz[f]);
+      }
+      return s;
+    }
+  }
+  return 0.f;
+}
+
+// ============================================================================================ post-physics kernel
+__global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C) {
+  __shared__ float s_h[EPB][MAX_P];
+  __shared__ float s_prop[EPB][48];
+  __shared__ float s_rootz[EPB];
+  __shared__ float s_part[EPB][LG_MAX_REWARD_TERMS + 2];
+  const lg_config& g = C->cfg; const lg_robot_model& m = C->model;
+  const int tid = threadIdx.x, e0 = blockIdx.x * EPB;
+  const int nenv = min(EPB, C->N - e0);
+  const int P = g.measure_heights ? C->P : 0;
+  const int64_t step = C->counters[0] + 1;   // LR:123 (finalize_kernel stores it)
+  const float dt = g.sim_dt * g.decimation;
+
+  // ---- (1) height scan from the post-physics root pose (LR:400-401), all lanes, row-contiguous stores
+  if (P > 0) {
+    for (int idx = tid; idx < nenv * P; idx += 256) {
+      int el = idx / P, p = idx - el * P, e = e0 + el;
+      float hgt = 0.f;
+      if (C->ter.mesh_type != LG_MESH_PLANE) {
+        const float* root = C->root + (size_t)e * 13;
+        float qz = root[5], qw = root[6];
+        float nrm = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
+        hgt = terrain_height_at(C, qz / nrm, qw / nrm, root[0], root[1], C->height_points[2 * p], C->height_points[2 * p + 1]);
+      }
+      s_h[el][p] = hgt;
+      C->heights[(size_t)e * C->P + p] = hgt;
+    }
+  }
+  __syncthreads();
+
+  // ---- (2) one lane per env: everything scalar, in the reference's order
+  if (tid < nenv) {
+    const int el = tid, e = e0 + el;
+    float* root = C->root + (size_t)e * 13; float* dof = C->dof + (size_t)e * 24;
+    float* blv = C->base_lin_vel + (size_t)e * 3; float* bav = C->base_ang_vel + (size_t)e * 3; float* pg = C->proj_grav + (size_t)e * 3;
+    float* bla = C->base_lin_acc + (size_t)e * 3; float* baa = C->base_ang_acc + (size_t)e * 3;
+    float* lrv = C->last_root_vel + (size_t)e * 6; float* cmd = C->commands + (size_t)e * 4;
+    const float* cf = C->cforce + (size_t)e * C->B * 3; const float* act = C->actions + (size_t)e * 12;
+    int64_t eplen = C->ep_len[e] + 1;                                             // LR:122
+    C->ep_len[e] = eplen;
+    float q[4] = {root[3], root[4], root[5], root[6]};
+    V3 lin = v3(root[7], root[8], root[9]), ang = v3(root[10], root[11], root[12]);
+    V3 v = quat_rotate_inverse(q, lin);                                           // LR:128-134
+    V3 dl = quat_rotate_inverse(q, lin - v3(lrv[0], lrv[1], lrv[2]));
+    const float ema = 0.9f, oma = (float)(1 - 0.9);
+    bla[0] = bla[0] * ema + oma * dl.x / dt; bla[1] = bla[1] * ema + oma * dl.y / dt; bla[2] = bla[2] * ema + oma * dl.z / dt;
+    V3 w = quat_rotate_inverse(q, ang);
+    V3 da = quat_rotate_inverse(q, ang - v3(lrv[3], lrv[4], lrv[5]));
+    baa[0] = baa[0] * ema + oma * da.x / dt; baa[1] = baa[1] * ema + oma * da.y / dt; baa[2] = baa[2] * ema + oma * da.z / dt;
+    V3 gv = quat_rotate_inverse(q, v3(0, 0, -1));
+    blv[0] = v.x; blv[1] = v.y; blv[2] = v.z; bav[0] = w.x; bav[1] = w.y; bav[2] = w.z; pg[0] = gv.x; pg[1] = gv.y; pg[2] = gv.z;
+    // _post_physics_step_callback (LR:386-403)
+    if (eplen % g.resampling_steps == 0) resample_commands(C, e, LG_RS_CMD_CB, step, 0);
+    if (g.heading_command) {
+      V3 f = quat_apply(q, v3(1, 0, 0));
+      float x = 0.5f * wrap_to_pi(cmd[3] - atan2f(f.y, f.x));
+      cmd[2] = fminf(fmaxf(x, -1.f), 1.f);
+    }
+    if (g.push_robots && (step % g.push_interval == 0)) {                           // LR:402-403, 491-496
+      root[7] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, uniform_draw(C, e, LG_RS_PUSH, step, 0));
+      root[8] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, uniform_draw(C, e, LG_RS_PUSH + 1, step, 0));
+    }
+    // check_termination (LR:155-160)
+    bool term = false;
+    for (int i = 0; i < m.num_termination; ++i) { int b = m.termination_contact_indices[i]; term |= FNORM(b) > 1.f; }
+    bool tout = (float)eplen > g.max_episode_length;
+    C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0;
+    // compute_reward (LR:215-232)
+    float rew = 0.f;
+    for (int k = 0; k < g.num_reward_terms; ++k) {
+      int id = g.reward_term_ids[k]; if (id == LG_REW_TERMINATION) continue;
+      float r = reward_term(C, e, id, s_h[el], step) * g.reward_scales[k];
+      rew += r; C->ep_sums[(size_t)k * C->N + e] += r;
+    }
+    if (g.only_positive_rewards) rew = fmaxf(rew, 0.f);
+    for (int k = 0; k < g.num_reward_terms; ++k) if (g.reward_term_ids[k] == LG_REW_TERMINATION) {
+      float r = reward_term(C, e, LG_REW_TERMINATION, s_h[el], step) * g.reward_scales[k];
+      rew += r; C->ep_sums[(size_t)k * C->N + e] += r;
+    }
+    C->rew[e] = rew;
+    // reset (LR:144-145) and the episode statistics of LR:200-206
+    const bool do_reset = term || tout;
+    if (do_reset) reset_env(C, e, 1, step, 0);
+    for (int k = 0; k < g.num_reward_terms; ++k) {
+      float sv = 0.f;
+      if (do_reset) { sv = C->ep_sums[(size_t)k * C->N + e]; C->ep_sums[(size_t)k * C->N + e] = 0.f; }
+      s_part[el][k] = sv;
+    }
+    s_part[el][g.num_reward_terms] = do_reset ? 1.f : 0.f;
+    s_part[el][g.num_reward_terms + 1] = g.curriculum ? (float)C->levels[e] : 0.f;
+    // proprioceptive part of the observation (LR:237-244), from the post-reset state
+    float* sp = s_prop[el];
+    sp[0] = blv[0] * g.obs_scale_lin_vel; sp[1] = blv[1] * g.obs_scale_lin_vel; sp[2] = blv[2] * g.obs_scale_lin_vel;
+    sp[3] = bav[0] * g.obs_scale_ang_vel; sp[4] = bav[1] * g.obs_scale_ang_vel; sp[5] = bav[2] * g.obs_scale_ang_vel;
+    sp[6] = pg[0]; sp[7] = pg[1]; sp[8] = pg[2];
+    sp[9] = cmd[0] * g.obs_scale_lin_vel; sp[10] = cmd[1] * g.obs_scale_lin_vel; sp[11] = cmd[2] * g.obs_scale_ang_vel;
+    for (int d = 0; d < 12; ++d) {
+      sp[12 + d] = (dof[2 * d] - g.default_dof_pos[d]) * g.obs_scale_dof_pos;
+      sp[24 + d] = dof[2 * d + 1] * g.obs_scale_dof_vel;
+      sp[36 + d] = act[d];
+    }
+    s_rootz[el] = root[2];
+    // history buffers (LR:148-150)
+    for (int d = 0; d < 12; ++d) { C->last_actions[(size_t)e * 12 + d] = act[d]; C->last_dof_vel[(size_t)e * 12 + d] = dof[2 * d + 1]; }
+    for (int i = 0; i < 6; ++i) lrv[i] = root[7 + i];
+    // Anymal.post_physics_step: gait scheduler (anymal.py:107-110)
+    if (g.gait_enabled) {
+      float x = fmodf(C->gait_idx[e] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
+      C->gait_idx[e] = x;
+      const float* rb = C->rigid + (size_t)e * C->B * 13;
+      for (int f = 0; f < 4; ++f) C->gait_foot_z[(size_t)e * 4 + f] = rb[(size_t)m.feet_indices[f] * 13 + 2];
+    }
+  }
+  __syncthreads();
+
+  // ---- per-workgroup episode statistics, summed in fixed env order (deterministic)
+  const int KP = g.num_reward_terms + 2;
+  if (tid < KP) {
+    float s = 0.f;
+    for (int el = 0; el < nenv; ++el) s += s_part[el][tid];
+    C->partials[(size_t)blockIdx.x * (LG_MAX_REWARD_TERMS + 2) + tid] = s;
+  }
+
+  // ---- (3) observation rows: proprio | heights, + uniform noise, clipped (LR:245-252, :107-108); 4 entries per lane
+  const int O = g.num_obs, G4 = (O + 3) >> 2;
+  for (int gi = tid; gi < nenv * G4; gi += 256) {
+    int el = gi / G4, gq = gi - el * G4, e = e0 + el;
+    float u[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+    if (g.add_noise) {
+      if (g.rng_mode == LG_RNG_INJECT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (4 * gq + i < O) u[i] = C->rand_inject[(size_t)e * (LG_RS_NOISE + O) + LG_RS_NOISE + 4 * gq + i];
+      } else {
+        uint32_t o4[4];
+        philox4((uint32_t)e, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), 0u, (uint32_t)g.seed, (uint32_t)(g.seed >> 32), o4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = u01(o4[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int idx = 4 * gq + i;
+      if (idx >= O) break;
+      float o;
+      if (idx < 48) o = s_prop[el][idx];
+      else { float h = (s_rootz[el] - 0.5f) - s_h[el][idx - 48]; o = fminf(fmaxf(h, -1.f), 1.f) * g.obs_scale_height; }
+      if (g.add_noise) o += (2.f * u[i] - 1.f) * C->noise_vec[idx];
+      o = fminf(fmaxf(o, -g.clip_observations), g.clip_observations);
+      C->obs[(size_t)e * O + idx] = o;
+    }
+  }
+}
+
+// one workgroup: fixed-order reduction of the per-workgroup partials -> extras (LR:200-206), step counters
+__global__ __launch_bounds__(64) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step) {
+  const int K = C->cfg.num_reward_terms, tid = threadIdx.x;
+  __shared__ float tot[LG_MAX_REWARD_TERMS + 2];
+  if (tid < K + 2) {
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += C->partials[(size_t)b * (LG_MAX_REWARD_TERMS + 2) + tid];
+    tot[tid] = s;
+  }
+  __syncthreads();
+  const float cnt = tot[K];
+  if (cnt > 0.f) {
+    if (tid < K) C->extras[tid] = tot[tid] / cnt / C->cfg.max_episode_length_s;
+    if (tid == K && C->cfg.curriculum) C->extras[K] = tot[K + 1] / (float)C->N;
+  }
+  if (tid == 0) {
+    if (bump_step) C->counters[0] += 1; else C->counters[2] += 1;
+    C->counters[1] = (int64_t)cnt;
+  }
+}
+
+// lg_reset_idx: one workgroup, loops over the id list; statistics summed in list order
+__global__ __launch_bounds__(256) void reset_idx_kernel(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int update_curriculum) {
+  const int tid = threadIdx.x, K = C->cfg.num_reward_terms;
+  const int64_t step = C->counters[2] + 1;
+  for (int i = tid; i < n; i += 256) reset_env(C, ids[i], update_curriculum, step, 1);
+  __syncthreads();
+  __threadfence_block();
+  if (tid < K) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) { size_t o = (size_t)tid * C->N + ids[i]; s += C->ep_sums[o]; C->ep_sums[o] = 0.f; }
+    C->partials[tid] = s;
+  }
+  if (tid == K) C->partials[K] = (float)n;
+  if (tid == K + 1) {
+    float s = 0.f;
+    if (C->cfg.curriculum) for (int e = 0; e < C->N; ++e) s += (float)C->levels[e];
+    C->partials[K + 1] = s;
+  }
+}
+
+// ============================================================================================ host side
+static size_t dtype_size(int d) { return d == LG_F32 ? 4 : d == LG_I64 ? 8 : d == LG_U8 ? 1 : d == LG_I16 ? 2 : 4; }
+
+static size_t build_layout(const lg_config* cfg, const lg_robot_model* model, const lg_terrain* ter, TensorInfo* t) {
+  const int64_t N = cfg->num_envs, B = model->num_bodies, K = cfg->num_reward_terms, P = cfg->num_height_points, O = cfg->num_obs;
+  auto set = [&](int id, int dtype, std::initializer_list<int64_t> shp) {
+    TensorInfo& T = t[id]; T.dtype = dtype; T.ndim = (int)shp.size(); int i = 0;
+    for (auto s : shp) T.shape[i++] = s;
+    for (; i < 4; ++i) T.shape[i] = 1;
+  };
+  set(LG_T_ROOT_STATES, LG_F32, {N, 13}); set(LG_T_DOF_STATE, LG_F32, {N, 12, 2});
+  set(LG_T_RIGID_BODY_STATE, LG_F32, {N, B, 13}); set(LG_T_CONTACT_FORCES, LG_F32, {N, B, 3});
+  set(LG_T_TORQUES, LG_F32, {N, 12}); set(LG_T_ACTIONS, LG_F32, {N, 12}); set(LG_T_LAST_ACTIONS, LG_F32, {N, 12});
+  set(LG_T_LAST_DOF_VEL, LG_F32, {N, 12}); set(LG_T_LAST_ROOT_VEL, LG_F32, {N, 6}); set(LG_T_COMMANDS, LG_F32, {N, 4});
+  set(LG_T_BASE_LIN_VEL, LG_F32, {N, 3}); set(LG_T_BASE_ANG_VEL, LG_F32, {N, 3}); set(LG_T_PROJECTED_GRAVITY, LG_F32, {N, 3});
+  set(LG_T_BASE_LIN_ACC, LG_F32, {N, 3}); set(LG_T_BASE_ANG_ACC, LG_F32, {N, 3});
+  set(LG_T_FEET_AIR_TIME, LG_F32, {N, 4}); set(LG_T_FEET_CONTACT_TIME, LG_F32, {N, 4}); set(LG_T_LAST_CONTACTS, LG_U8, {N, 4});
+  set(LG_T_MEASURED_HEIGHTS, LG_F32, {N, P > 0 ? P : 1}); set(LG_T_OBS_BUF, LG_F32, {N, O}); set(LG_T_REW_BUF, LG_F32, {N});
+  set(LG_T_RESET_BUF, LG_U8, {N}); set(LG_T_TIME_OUT_BUF, LG_U8, {N}); set(LG_T_EPISODE_LENGTH_BUF, LG_I64, {N});
+  set(LG_T_EPISODE_SUMS, LG_F32, {K > 0 ? K : 1, N}); set(LG_T_TERRAIN_LEVELS, LG_I64, {N}); set(LG_T_TERRAIN_TYPES, LG_I64, {N});
+  set(LG_T_ENV_ORIGINS, LG_F32, {N, 3}); set(LG_T_FRICTION_COEFFS, LG_F32, {N}); set(LG_T_BASE_MASS_ADDED, LG_F32, {N});
+  set(LG_T_SEA_HIDDEN_STATE, LG_F32, {2, N * 12, 8}); set(LG_T_SEA_CELL_STATE, LG_F32, {2, N * 12, 8});
+  set(LG_T_GAIT_IDX, LG_F32, {N}); set(LG_T_GAIT_FOOT_Z, LG_F32, {N, 4}); set(LG_T_EXTRAS_EPISODE, LG_F32, {K + 1});
+  set(LG_T_RAND_INJECT, LG_F32, {N, LG_RS_NOISE + O}); set(LG_T_STEP_COUNTERS, LG_I64, {4});
+  int64_t r = ter->rows > 0 ? ter->rows : 1, cc = ter->cols > 0 ? ter->cols : 1;
+  set(LG_T_HEIGHT_SAMPLES, LG_I16, {r, cc});
+  set(LG_T_TERRAIN_ORIGINS, LG_F32, {ter->num_levels > 0 ? ter->num_levels : 1, ter->num_types > 0 ? ter->num_types : 1, 3});
+  size_t off = 0;
+  for (int i = 0; i < LG_T_COUNT; ++i) {
+    TensorInfo& T = t[i]; size_t n = dtype_size(T.dtype);
+    for (int d = 0; d < T.ndim; ++d) n *= (size_t)T.shape[d];
+    T.off = off; off += (n + 255) & ~(size_t)255;
+  }
+  return off;
+}
+
+static const char* validate(const lg_config* cfg, const lg_robot_model* model, const lg_terrain* ter) {
+  if (!cfg || !model || !ter) return "null argument";
+  if (cfg->abi_version != LG_ABI_VERSION) return "abi_version mismatch";
+  if (cfg->num_envs <= 0) return "num_envs must be positive";
+  if (cfg->num_reward_terms < 0 || cfg->num_reward_terms > LG_MAX_REWARD_TERMS) return "too many reward terms";
+  if (cfg->num_height_points > MAX_P) return "num_height_points exceeds the 192 points the post kernel stages in LDS";
+  if (cfg->num_obs != 48 + (cfg->measure_heights ? cfg->num_height_points : 0)) return "num_obs does not match the observation layout";
+  if (model->num_bodies != 1 + 4 * (3 + model->has_foot_body) || model->num_bodies > LG_MAX_BODIES) return "unsupported body count";
+  if (cfg->decimation <= 0 || cfg->sim_dt <= 0.f) return "bad dt / decimation";
+  if (cfg->resampling_steps <= 0) return "resampling_steps must be positive";
+  if (cfg->push_robots && cfg->push_interval <= 0) return "push_interval must be positive";
+  if (ter->mesh_type == LG_MESH_HEIGHTFIELD && (ter->rows < 2 || ter->cols < 2 || !ter->height_samples)) return "heightfield terrain without samples";
+  if (cfg->curriculum && (ter->num_levels <= 0 || ter->num_types <= 0 || !ter->terrain_origins)) return "curriculum needs terrain_origins";
+  for (int l = 0; l < 4; ++l) if (model->cp_count[l] < 0 || model->cp_count[l] > LG_MAX_CP) return "bad cp_count";
+  for (int k = 0; k < cfg->num_reward_terms; ++k) if (cfg->reward_term_ids[k] < 0 || cfg->reward_term_ids[k] >= LG_REW_COUNT) return "unknown reward term id";
+  if (!cfg->noise_scale_vec) return "noise_scale_vec is null";
+  if (cfg->num_height_points > 0 && !cfg->height_points) return "height_points is null";
+  return nullptr;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+  do { hipError_t _e = (expr);                                                                   \
+       if (_e != hipSuccess) { (c)->err = std::string(#expr) + ": " + hipGetErrorString(_e); return LG_ERR_HIP; } } while (0)
+
+extern "C" {
+
+void lg_abi_sizes(int32_t out[4]) {
+  out[0] = LG_ABI_VERSION; out[1] = (int32_t)sizeof(lg_config); out[2] = (int32_t)sizeof(lg_robot_model); out[3] = (int32_t)sizeof(lg_terrain);
+}
+
+size_t lg_arena_bytes(const lg_config* cfg, const lg_robot_model* model, const lg_terrain* terrain) {
+  if (validate(cfg, model, terrain)) return 0;
+  TensorInfo t[LG_T_COUNT];
+  return build_layout(cfg, model, terrain, t);
+}
+
+const char* lg_last_error(lg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+void lg_destroy(lg_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->d) (void)hipFree(c->d);
+  if (c->aux) (void)hipFree(c->aux);
+  if (c->own_arena && c->arena) (void)hipFree(c->arena);
+  delete c;
+}
+
+lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_terrain* ter, int device_id, void* arena) {
+  if (const char* why = validate(cfg, model, ter)) { g_err = why; return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device: the env step has no CPU path"; return nullptr; }
+  if (device_id < 0 || device_id >= ndev) { g_err = "device_id out of range"; return nullptr; }
+  if (hipSetDevice(device_id) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+  lg_ctx* c = new lg_ctx();
+  c->device = device_id;
+  c->arena_bytes = build_layout(cfg, model, ter, c->t);
+  auto fail = [&](const std::string& why) { g_err = why; lg_destroy(c); return (lg_ctx*)nullptr; };
+  if (arena) c->arena = arena;
+  else { if (hipMalloc(&c->arena, c->arena_bytes) != hipSuccess) return fail("hipMalloc(arena) failed"); c->own_arena = true; }
+  if (hipMemset(c->arena, 0, c->arena_bytes) != hipSuccess) return fail("hipMemset(arena) failed");
+
+  DevCtx& h = c->h;
+  memset(&h, 0, sizeof(h));
+  h.cfg = *cfg; h.model = *model;
+  h.cfg.noise_scale_vec = nullptr; h.cfg.height_points = nullptr;
+  h.N = cfg->num_envs; h.B = model->num_bodies; h.K = cfg->num_reward_terms; h.P = cfg->num_height_points;
+  h.per_leg = 3 + model->has_foot_body;
+  h.terrain_mu = ter->static_friction; h.env_length = ter->env_length; h.num_levels = ter->num_levels; h.num_types = ter->num_types;
+  char* base = (char*)c->arena;
+  auto P = [&](int id) { return (void*)(base + c->t[id].off); };
+  h.root = (float*)P(LG_T_ROOT_STATES); h.dof = (float*)P(LG_T_DOF_STATE); h.rigid = (float*)P(LG_T_RIGID_BODY_STATE);
+  h.cforce = (float*)P(LG_T_CONTACT_FORCES); h.torques = (float*)P(LG_T_TORQUES); h.actions = (float*)P(LG_T_ACTIONS);
+  h.last_actions = (float*)P(LG_T_LAST_ACTIONS); h.last_dof_vel = (float*)P(LG_T_LAST_DOF_VEL); h.last_root_vel = (float*)P(LG_T_LAST_ROOT_VEL);
+  h.commands = (float*)P(LG_T_COMMANDS); h.base_lin_vel = (float*)P(LG_T_BASE_LIN_VEL); h.base_ang_vel = (float*)P(LG_T_BASE_ANG_VEL);
+  h.proj_grav = (float*)P(LG_T_PROJECTED_GRAVITY); h.base_lin_acc = (float*)P(LG_T_BASE_LIN_ACC); h.base_ang_acc = (float*)P(LG_T_BASE_ANG_ACC);
+  h.feet_air = (float*)P(LG_T_FEET_AIR_TIME); h.feet_ctime = (float*)P(LG_T_FEET_CONTACT_TIME); h.last_contacts = (uint8_t*)P(LG_T_LAST_CONTACTS);
+  h.heights = (float*)P(LG_T_MEASURED_HEIGHTS); h.obs = (float*)P(LG_T_OBS_BUF); h.rew = (float*)P(LG_T_REW_BUF);
+  h.reset_buf = (uint8_t*)P(LG_T_RESET_BUF); h.time_out = (uint8_t*)P(LG_T_TIME_OUT_BUF); h.ep_len = (int64_t*)P(LG_T_EPISODE_LENGTH_BUF);
+  h.ep_sums = (float*)P(LG_T_EPISODE_SUMS); h.levels = (int64_t*)P(LG_T_TERRAIN_LEVELS); h.types = (int64_t*)P(LG_T_TERRAIN_TYPES);
+  h.origins = (float*)P(LG_T_ENV_ORIGINS); h.friction = (float*)P(LG_T_FRICTION_COEFFS); h.mass_added = (float*)P(LG_T_BASE_MASS_ADDED);
+  h.sea_h = (float*)P(LG_T_SEA_HIDDEN_STATE); h.sea_c = (float*)P(LG_T_SEA_CELL_STATE); h.gait_idx = (float*)P(LG_T_GAIT_IDX);
+  h.gait_foot_z = (float*)P(LG_T_GAIT_FOOT_Z); h.extras = (float*)P(LG_T_EXTRAS_EPISODE); h.rand_inject = (float*)P(LG_T_RAND_INJECT);
+  h.counters = (int64_t*)P(LG_T_STEP_COUNTERS); h.terrain_origins = (const float*)P(LG_T_TERRAIN_ORIGINS);
+  h.ter.mesh_type = ter->mesh_type; h.ter.rows = ter->rows; h.ter.cols = ter->cols;
+  h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
+  h.ter.H = (const int16_t*)P(LG_T_HEIGHT_SAMPLES);
+  h.nblocks_post = (h.N + EPB - 1) / EPB;
+
+  // aux buffer: noise_vec | height_points | partials
+  size_t n_noise = (size_t)cfg->num_obs, n_hp = (size_t)2 * cfg->num_height_points;
+  size_t n_part = (size_t)h.nblocks_post * (LG_MAX_REWARD_TERMS + 2);
+  size_t aux_floats = n_noise + n_hp + n_part;
+  if (hipMalloc(&c->aux, aux_floats * 4) != hipSuccess) return fail("hipMalloc(aux) failed");
+  if (hipMemset(c->aux, 0, aux_floats * 4) != hipSuccess) return fail("hipMemset(aux) failed");
+  float* aux = (float*)c->aux;
+  h.noise_vec = aux; h.height_points = aux + n_noise; h.partials = aux + n_noise + n_hp;
+  if (hipMemcpy(aux, cfg->noise_scale_vec, n_noise * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy noise_scale_vec failed");
+  if (n_hp && hipMemcpy(aux + n_noise, cfg->height_points, n_hp * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy height_points failed");
+  if (ter->mesh_type == LG_MESH_HEIGHTFIELD &&
+      hipMemcpy(P(LG_T_HEIGHT_SAMPLES), ter->height_samples, (size_t)ter->rows * ter->cols * 2, hipMemcpyHostToDevice) != hipSuccess)
+    return fail("copy height_samples failed");
+  if (ter->num_levels > 0 && ter->terrain_origins &&
+      hipMemcpy(P(LG_T_TERRAIN_ORIGINS), ter->terrain_origins, (size_t)ter->num_levels * ter->num_types * 12, hipMemcpyHostToDevice) != hipSuccess)
+    return fail("copy terrain_origins failed");
+  // initial values: identity base quaternion, reset_buf = 1 (base_task.py:73)
+  {
+    std::vector<float> root((size_t)h.N * 13, 0.f);
+    for (int e = 0; e < h.N; ++e) root[(size_t)e * 13 + 6] = 1.f;
+    if (hipMemcpy(h.root, root.data(), root.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("init root_states failed");
+    if (hipMemset(h.reset_buf, 1, (size_t)h.N) != hipSuccess) return fail("init reset_buf failed");
+  }
+  if (hipMalloc((void**)&c->d, sizeof(DevCtx)) != hipSuccess) return fail("hipMalloc(ctx) failed");
+  if (hipMemcpy(c->d, &h, sizeof(DevCtx), hipMemcpyHostToDevice) != hipSuccess) return fail("copy ctx failed");
+  if (hipDeviceSynchronize() != hipSuccess) return fail("device sync failed");
+  return c;
+}
+
+int lg_get_tensor(lg_ctx* c, int id, void** dptr, int64_t shape[4], int32_t* ndim, int32_t* dtype) {
+  if (!c) return LG_ERR_INVALID;
+  if (id < 0 || id >= LG_T_COUNT) { c->err = "tensor id out of range"; return LG_ERR_INVALID; }
+  *dptr = (char*)c->arena + c->t[id].off;
+  for (int i = 0; i < 4; ++i) shape[i] = c->t[id].shape[i];
+  *ndim = c->t[id].ndim; *dtype = c->t[id].dtype;
+  return LG_OK;
+}
+
+static int launch_post(lg_ctx* c, hipStream_t st) {
+  hipLaunchKernelGGL(post_kernel, dim3(c->h.nblocks_post), dim3(256), 0, st, c->d);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, c->d, c->h.nblocks_post, 1);
+  HIP_TRY(c, hipGetLastError());
+  return LG_OK;
+}
+
+int lg_step(lg_ctx* c, const float* actions, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (!actions) { c->err = "actions is null"; return LG_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (c->h.N + EPB - 1) / EPB;
+  hipLaunchKernelGGL(physics_kernel<0>, dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation);
+  return launch_post(c, st);
+}
+
+int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  const int nb = (c->h.N + EPB - 1) / EPB;
+  hipLaunchKernelGGL(physics_kernel<2>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0);
+  HIP_TRY(c, hipGetLastError());
+  return LG_OK;
+}
+
+int lg_simulate(lg_ctx* c, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  const int nb = (c->h.N + EPB - 1) / EPB;
+  hipLaunchKernelGGL(physics_kernel<1>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1);
+  HIP_TRY(c, hipGetLastError());
+  return LG_OK;
+}
+
+int lg_post_physics_step(lg_ctx* c, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  return launch_post(c, (hipStream_t)stream);
+}
+
+int lg_reset_idx(lg_ctx* c, const int32_t* env_ids, int32_t n, int32_t update_curriculum, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (n < 0 || (n > 0 && !env_ids)) { c->err = "bad env id list"; return LG_ERR_INVALID; }
+  if (n == 0) return LG_OK;                         // LR:172-173
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(reset_idx_kernel, dim3(1), dim3(256), 0, st, c->d, env_ids, n, update_curriculum);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, c->d, 1, 0);
+  HIP_TRY(c, hipGetLastError());
+  return LG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""Loader and thin ctypes binding of the HIP env-step library (`csrc/liblgstep.so`, C ABI in `include/lgstep.h`).
+
+PyTorch is plumbing here: it owns the device arena (one uint8 tensor) and hands out zero-copy typed views of it, and
+its current HIP stream is the stream every library call is enqueued on.  There is NO CPU path: if the library is
+missing, or no GPU is present, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from extended_legged_gym_amd import abi
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblgstep.so")
+_TORCH_DTYPE = {abi.LG_F32: torch.float32, abi.LG_I64: torch.int64, abi.LG_U8: torch.uint8, abi.LG_I16: torch.int16,
+                abi.LG_I32: torch.int32}
+_lib = None
+
+
+def load_library():
+    """dlopen liblgstep.so and check that its struct layouts are the ones this Python side was written against."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                           f"g.build()'` (or `make -C extended_legged_gym_amd/csrc`). There is no CPU fallback.")
+    lib = abi.declare_product(C.CDLL(LIB_PATH))
+    sizes = (C.c_int32 * 4)()
+    lib.lg_abi_sizes(sizes)
+    want = [abi.LG_ABI_VERSION, C.sizeof(abi.lg_config), C.sizeof(abi.lg_robot_model), C.sizeof(abi.lg_terrain)]
+    if list(sizes) != want:
+        raise RuntimeError(f"ABI mismatch between liblgstep.so {list(sizes)} and extended_legged_gym_amd/abi.py {want}")
+    _lib = lib
+    return lib
+
+
+class NativeCore:
+    """One env-step context on one GPU; `self.t[name]` are torch views of the library's tensors."""
+
+    def __init__(self, setup, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError(f"the env step runs on an MI355X GPU only (got sim_device='{device}'); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible to PyTorch-ROCm; the env step has no CPU path")
+        self.lib = load_library()
+        self.setup = setup
+        self.device = dev
+        self.device_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        nbytes = self.lib.lg_arena_bytes(C.byref(setup.cfg), C.byref(setup.model), C.byref(setup.terrain))
+        if nbytes == 0:
+            raise ValueError("lg_arena_bytes rejected the configuration: " + self._err(None))
+        self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        self.ctx = self.lib.lg_create(C.byref(setup.cfg), C.byref(setup.model), C.byref(setup.terrain),
+                                      self.device_index, C.c_void_p(self.arena.data_ptr()))
+        if not self.ctx:
+            raise RuntimeError("lg_create failed: " + self._err(None))
+        self.t = {}
+        base = self.arena.data_ptr()
+        for name, tid in abi.TENSOR_ID.items():
+            p, shp, nd, dt = C.c_void_p(), (C.c_int64 * 4)(), C.c_int32(), C.c_int32()
+            self._check(self.lib.lg_get_tensor(self.ctx, tid, C.byref(p), shp, C.byref(nd), C.byref(dt)))
+            shape = tuple(shp[i] for i in range(nd.value))
+            tdt = _TORCH_DTYPE[dt.value]
+            n = int(np.prod(shape)) * torch.empty((), dtype=tdt).element_size()
+            off = p.value - base
+            self.t[name] = self.arena[off:off + n].view(tdt).view(shape)
+
+    # ------------------------------------------------------------------ helpers
+    def _err(self, ctx):
+        s = self.lib.lg_last_error(ctx)
+        return s.decode() if s else ""
+
+    def _check(self, rc):
+        if rc != abi.LG_OK:
+            raise RuntimeError(f"liblgstep call failed ({rc}): {self._err(self.ctx)}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _f32(t):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(torch.float32).contiguous()
+        return t
+
+    # ------------------------------------------------------------------ ABI calls
+    def step(self, actions):
+        a = self._f32(actions)
+        self._check(self.lib.lg_step(self.ctx, C.c_void_p(a.data_ptr()), self._stream()))
+
+    def compute_torques(self, actions=None):
+        if actions is None:
+            self._check(self.lib.lg_compute_torques(self.ctx, None, self._stream()))
+        else:
+            a = self._f32(actions)
+            self._check(self.lib.lg_compute_torques(self.ctx, C.c_void_p(a.data_ptr()), self._stream()))
+
+    def simulate(self):
+        self._check(self.lib.lg_simulate(self.ctx, self._stream()))
+
+    def post_physics_step(self):
+        self._check(self.lib.lg_post_physics_step(self.ctx, self._stream()))
+
+    def reset_idx(self, env_ids, update_curriculum=0):
+        ids = env_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        self._check(self.lib.lg_reset_idx(self.ctx, C.c_void_p(ids.data_ptr()), int(ids.numel()), int(update_curriculum),
+                                          self._stream()))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.lg_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,58 @@
+"""GPU parity, part 1: the HIP post-physics path (through the C ABI) against the reference's golden vectors, with the
+same bar as the oracle: integer / bool / terrain-height outputs bit-exact, fp32 within rtol 2e-5 / atol 2e-6
+(torques from the LSTM actuator atol 5e-5: 20 x a cancelling 8-term dot product, fast exp on the device)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN_CASES, POST_KEYS, golden_setup, load_golden, load_pre_state
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 2e-5, 2e-6
+ATOL_BY_NAME = {"torques": 5e-5, "sea_hidden_state": 1e-5, "sea_cell_state": 1e-5}
+EXACT = {"last_contacts", "episode_length_buf", "reset_buf", "time_out_buf"}
+
+
+def check(name, got, want, t):
+    got = got.detach().cpu().numpy()
+    want = np.asarray(want).reshape(got.shape)
+    if name in EXACT or got.dtype.kind in "iub":
+        assert np.array_equal(got.astype(np.int64), want.astype(np.int64)), f"step {t}: {name} differs"
+    else:
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL_BY_NAME.get(name, ATOL), err_msg=f"step {t}: {name}")
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_hip_step_matches_reference(case):
+    from extended_legged_gym_amd.native import NativeCore
+    z, meta = load_golden(case)
+    cfg, s = golden_setup(z, meta)
+    core = NativeCore(s, "cuda:0")
+    T, dec = z["actions"].shape[0], cfg.control.decimation
+
+    def write(name, arr):
+        tt = core.t[name]
+        tt.copy_(torch.from_numpy(np.ascontiguousarray(arr).reshape(tuple(tt.shape))).to(tt.dtype))
+
+    for t in range(T):
+        load_pre_state(core.t, z, t, write)
+        for sub in range(dec):
+            core.compute_torques(torch.from_numpy(z["actions"][t]).cuda() if sub == 0 else None)
+            check("torques", core.t["torques"], z["torques"][t, sub], t)
+            write("dof_state", z["sim_dof"][t, sub])
+        write("root_states", z["sim_root"][t])
+        write("rigid_body_state", z["sim_rigid"][t])
+        write("contact_forces", z["sim_contact"][t])
+        core.post_physics_step()
+        torch.cuda.synchronize()
+        if cfg.terrain.measure_heights:
+            assert np.array_equal(core.t["measured_heights"].cpu().numpy(), z["measured_heights"][t]), f"step {t}: heights"
+        if "post_terrain_levels" in z.files:
+            assert np.array_equal(core.t["terrain_levels"].cpu().numpy(), z["post_terrain_levels"][t])
+        for name, key in POST_KEYS.items():
+            check(name, core.t[name], z[key][t], t)
+        if z["extras_fresh"][t]:
+            K = len(meta["reward_names"])
+            np.testing.assert_allclose(core.t["extras_episode"][:K].cpu().numpy(), z["extras_episode"][t], rtol=1e-4, atol=1e-6)
+        assert int(core.t["step_counters"][1]) == int(z["reset"][t].sum())
+    core.close()

@@ -1,0 +1,113 @@
+"""GPU parity, part 2: the full HIP step (actuator + articulated dynamics + contact + post-physics) against the CPU
+oracle on the same seeded inputs.  The two share the model but not the algorithm (dense 18x18 Cholesky and explicit
+Jacobians there; per-leg Schur complement over DPP quads here) nor the fp32 operation order, so the bar is a stated
+fp32 tolerance: after ONE policy step (4 substeps) from identical state
+    |x_hip - x_oracle| <= 2e-3 * max(1, |x|) for at least 99.5 % of the entries of every state tensor, and the median
+    error <= 2e-5,
+(a contact that is within rounding of its activation threshold may switch on in one and not the other: those are the
+allowed outliers), bit-exact for the integer / index outputs of envs whose float state agrees."""
+import numpy as np
+import pytest
+import torch
+
+from extended_legged_gym_amd import abi
+from extended_legged_gym_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
+from extended_legged_gym_amd.envs.base.native_config import NativeSetup, load_robot_model
+from extended_legged_gym_amd.utils.terrain import Terrain
+from tests.helpers import ANYMAL_GAIT, sim_params_for
+
+pytestmark = pytest.mark.gpu
+
+STATE = ["root_states", "dof_state", "rigid_body_state", "contact_forces", "torques", "obs_buf", "rew_buf",
+         "base_lin_vel", "base_ang_vel", "projected_gravity", "commands", "measured_heights", "sea_hidden_state",
+         "sea_cell_state", "feet_air_time", "episode_sums", "last_dof_vel", "last_root_vel", "base_lin_acc"]
+COPY = ["root_states", "dof_state", "friction_coeffs", "base_mass_added", "terrain_levels", "terrain_types", "env_origins",
+        "commands", "last_actions", "last_dof_vel", "last_root_vel", "episode_length_buf", "sea_hidden_state",
+        "sea_cell_state", "feet_air_time", "feet_contact_time", "last_contacts", "episode_sums", "gait_idx",
+        "base_lin_acc", "base_ang_acc", "step_counters", "gait_foot_z"]
+
+
+def build(kind, n, seed):
+    cfg = AnymalCFlatCfg() if kind.startswith("flat") else AnymalCRoughCfg()
+    cfg.env.num_envs = n
+    cfg.control.use_actuator_network = kind.endswith("lstm")
+    terrain = None
+    if kind.startswith("rough"):
+        cfg.terrain.mesh_type = "heightfield"
+        cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = 4, 4, 5
+        cfg.terrain.max_init_terrain_level = 3
+        np.random.seed(seed)
+        terrain = Terrain(cfg.terrain, n)
+    model = load_robot_model(cfg.asset)
+    return cfg, NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=seed, gait=ANYMAL_GAIT), terrain
+
+
+def init_oracle(o, cfg, s, terrain, n, seed):
+    rng = np.random.default_rng(seed)
+    o.t["friction_coeffs"][:] = rng.uniform(0.5, 1.25, n)
+    o.t["base_mass_added"][:] = rng.uniform(-5, 5, n)
+    if terrain is not None:
+        lv = rng.integers(0, 4, n); ty = np.floor(np.arange(n) / (n / 4)).astype(np.int64)
+        o.t["terrain_levels"][:] = lv; o.t["terrain_types"][:] = ty
+        o.t["env_origins"][:] = terrain.env_origins[lv, ty]
+    o.reset_idx(np.arange(n))
+    return rng
+
+
+def compare(core, o, names, frac_ok=0.995, tol=2e-3, med=2e-5):
+    torch.cuda.synchronize()
+    worst = {}
+    for name in names:
+        a = core.t[name].detach().cpu().numpy().astype(np.float64).reshape(-1)
+        b = o.t[name].astype(np.float64).reshape(-1)
+        err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+        assert np.isfinite(a).all(), f"{name}: non-finite values on the GPU"
+        ok = (err <= tol).mean()
+        worst[name] = (float(np.median(err)), float(err.max()), float(ok))
+        assert ok >= frac_ok, f"{name}: only {ok:.4f} of entries within {tol} (max {err.max():.3g})"
+        assert np.median(err) <= med, f"{name}: median error {np.median(err):.3g}"
+    return worst
+
+
+@pytest.mark.parametrize("kind", ["flat_pd", "flat_lstm", "rough_lstm"])
+def test_single_step_parity_from_identical_state(kind):
+    from extended_legged_gym_amd.native import NativeCore
+    from oracle.oracle_lib import OracleEnv
+    n = 256
+    cfg, s, terrain = build(kind, n, seed=11)
+    o = OracleEnv(s)
+    core = NativeCore(s, "cuda:0")
+    rng = init_oracle(o, cfg, s, terrain, n, 11)
+    # let the oracle run the robots into varied, contact-rich states, then compare single steps from synced state
+    for it in range(40):
+        act = rng.normal(size=(n, 12)).astype(np.float32)
+        if it % 10 == 9:
+            for name in COPY:
+                core.t[name].copy_(torch.from_numpy(o.t[name].copy()))
+            o.step(act)
+            core.step(torch.from_numpy(act).cuda())
+            compare(core, o, STATE)
+            # integer outputs: identical wherever the float state agrees
+            ra, rb = core.t["reset_buf"].cpu().numpy(), o.t["reset_buf"]
+            assert (ra != rb).mean() <= 0.01
+            assert np.array_equal(core.t["episode_length_buf"].cpu().numpy()[ra == rb], o.t["episode_length_buf"][ra == rb])
+        else:
+            o.step(act)
+    core.close(); o.close()
+
+
+def test_philox_streams_are_bit_identical():
+    """Noise, command resampling and reset draws come from the same counter-based generator on both sides."""
+    from extended_legged_gym_amd.native import NativeCore
+    from oracle.oracle_lib import OracleEnv
+    n = 64
+    cfg, s, terrain = build("flat_pd", n, seed=5)
+    o = OracleEnv(s); core = NativeCore(s, "cuda:0")
+    o.t["friction_coeffs"][:] = 1.0; core.t["friction_coeffs"].fill_(1.0)
+    ids = np.arange(n)
+    o.reset_idx(ids); core.reset_idx(torch.arange(n))
+    torch.cuda.synchronize()
+    for name in ["root_states", "dof_state", "commands"]:
+        assert np.array_equal(core.t[name].cpu().numpy(), o.t[name]), name
+    core.close(); o.close()
