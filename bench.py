@@ -1,0 +1,178 @@
+"""Headline benchmark: env-steps/s of `LeggedRobot.step()` for ANYmal-C on rough heightfield terrain, 4096 envs per
+MI355X (BASELINE.json configs[1]); the reference's own measurement loop is `legged_gym/tests/test_env_simstep_time.py:10-17`
+(random-normal actions, mean wall time of env.step).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; envs shard by rank (weak scaling: 4096 envs per GPU) with no data-path collective; after the timed
+region every rank contributes its episode statistics to one RCCL all-gather.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+# Algorithmic HBM bytes per env per policy step for the tensors the kernels actually materialise:
+# each is read once and/or written once per lg_step because the 4 substeps run on-chip.
+PHYSICS_BYTES = dict(
+    read=48 + 52 + 96 + 48 + 1536 + 4 + 4,                 # actions, root, dof, last_dof_vel, LSTM h+c, friction, payload
+    write=48 + 52 + 96 + 48 + 1536 + 17 * 12 + 17 * 52,    # clipped actions, root, dof, torques, LSTM h+c, contact forces, rigid-body state
+)
+POST_BYTES = dict(
+    read=52 + 96 + 24 + 24 + 16 + 204 + 4 * 52 + 48 + 48 + 48 + 48 + 8 + 32 + 4 + 36 + 187 * 3 * 2 + 16 + 16,
+    write=748 + 940 + 4 + 2 + 8 + 36 + 24 + 48 + 48 + 24 + 32 + 4 + 36 + 16 + 4 + 16,
+)
+
+
+def build_env(rank, world, num_envs):
+    from extended_legged_gym_amd.envs import Anymal, AnymalCRoughCfg
+    from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params, set_seed
+    cfg = AnymalCRoughCfg()
+    cfg.env.num_envs = num_envs
+    cfg.terrain.mesh_type = "heightfield"          # BASELINE config 2: collide against the 900x900 int16 grid
+    cfg.seed = 1
+    cfg.env.global_env_offset = rank * num_envs    # terrain columns are assigned by GLOBAL env index
+    cfg.env.global_num_envs = world * num_envs
+    cfg.rng_stream_offset = rank                   # decorrelates the in-kernel Philox streams of the shards
+    args = get_args([])
+    args.sim_device = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        set_seed(1)                                # identical terrain (np.random seed 1) on every rank
+    sp = parse_sim_params(args, {"sim": class_to_dict(cfg.sim)})
+    return Anymal(cfg, sp, args.physics_engine, args.sim_device, True), cfg
+
+
+def cpu_baseline(env, actions_pool, budget_s=15.0):
+    """The oracle (a scalar C++ port of the same step, OpenMP over envs) timed on this host, on a bounded sample of
+    the same workload: the same 4096 envs continued from the GPU env's current state for as many policy steps as fit
+    in ~budget_s seconds."""
+    from oracle.oracle_lib import OracleEnv, lib
+    o = OracleEnv(env.setup)
+    for name in ["root_states", "dof_state", "friction_coeffs", "base_mass_added", "terrain_levels", "terrain_types",
+                 "env_origins", "commands", "last_actions", "last_dof_vel", "last_root_vel", "episode_length_buf",
+                 "sea_hidden_state", "sea_cell_state", "feet_air_time", "feet_contact_time", "last_contacts",
+                 "episode_sums", "gait_idx", "gait_foot_z", "base_lin_acc", "base_ang_acc", "step_counters"]:
+        o.t[name][...] = env.core.t[name].cpu().numpy()
+    acts = [a.cpu().numpy() for a in actions_pool[:8]]
+    cores = lib().lgo_max_threads()
+    t0 = time.perf_counter()
+    o.step(acts[0])
+    o.step(acts[1])
+    per_step = (time.perf_counter() - t0) / 2
+    n = int(max(4, min(400, budget_s / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    for i in range(n):
+        o.step(acts[i % len(acts)])
+    dt = time.perf_counter() - t0
+    val = env.num_envs * n / dt
+    o.close()
+    return dict(value=val, unit="env-steps/s", cores=int(cores), kind="port",
+                sample=f"{n} policy steps x {env.num_envs} envs of the same workload, oracle/lg_oracle.cpp with OpenMP on {cores} threads, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=1000)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if a.gpus != world:
+        if rank == 0:
+            print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    env, cfg = build_env(rank, world, a.envs_per_gpu)
+    N = env.num_envs
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    pool = [torch.randn(N, 12, generator=gen).to(dev) for _ in range(64)]   # resident in HBM before timing starts
+
+    env.reset()
+    for i in range(a.warmup):
+        env.step(pool[i % len(pool)])
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+
+    samples = min(256, a.steps)
+    env.core.profile_begin(samples, max(1, a.steps // samples))
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        env.step(pool[i % len(pool)])
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    prof = env.core.profile_end()
+
+    # episode statistics of every shard: one all-gather (RCCL over xGMI when world > 1)
+    stats = env.core.t["episode_stats"].clone()
+    if dist is not None:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        stats_all = torch.stack(gathered).sum(0).cpu().numpy()
+    else:
+        stats_all = stats.cpu().numpy()
+    finite = bool(torch.isfinite(env.obs_buf).all().item() and torch.isfinite(env.root_states).all().item())
+
+    if rank == 0:
+        value = world * N * a.steps / elapsed
+        phys_bytes = PHYSICS_BYTES["read"] + PHYSICS_BYTES["write"]
+        achieved = phys_bytes * N / (prof["physics_ms"] * 1e-3) / 1e9 if prof["physics_ms"] > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec, ANYmal-C rough 4096 envs/GPU", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ANYmal-C rough heightfield terrain (8x8 tiles, 900x900 int16 grid, seed 1), "
+                                   f"{N} envs/GPU, LSTM actuator net, 235-dim obs, noise+pushes+curriculum on, "
+                                   "actions N(0,1), one step = 4 physics substeps + post-physics",
+                       "num_envs_per_gpu": N, "decimation": 4, "sim_dt": 0.005, "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "physics_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_env_step": phys_bytes, "kernel_ms": prof["physics_ms"],
+                         "post_kernel_ms": prof["post_ms"], "finalize_kernel_ms": prof["finalize_ms"],
+                         "hip_event_samples": prof["samples"],
+                         "whole_step_bytes_per_env_step": phys_bytes + POST_BYTES["read"] + POST_BYTES["write"]},
+            "episode_stats": {"sum_return": float(stats_all[0]), "sum_length": float(stats_all[1]),
+                              "episodes": float(stats_all[2]), "env_steps": float(stats_all[3])},
+            "finite": finite,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(env, pool)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,7 +11,7 @@ LG_MAX_CP, LG_MAX_BODIES, LG_MAX_REWARD_TERMS, LG_MAX_INDEX_LIST = 8, 17, 32, 16
 LG_LSTM_NPARAM = 969
 
 LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_UNSUPPORTED, LG_ERR_NO_DEVICE = 0, -1, -2, -3, -4
-LG_F32, LG_I64, LG_U8, LG_I16, LG_I32 = 0, 1, 2, 3, 4
+LG_F32, LG_I64, LG_U8, LG_I16, LG_I32, LG_F64 = 0, 1, 2, 3, 4, 5
 LG_CTRL_P, LG_CTRL_V, LG_CTRL_T, LG_CTRL_ACTUATOR_NET = 0, 1, 2, 3
 LG_MESH_PLANE, LG_MESH_HEIGHTFIELD = 0, 1
 LG_RNG_PHILOX, LG_RNG_INJECT = 0, 1
@@ -34,7 +34,7 @@ TENSOR_NAMES = [
     "feet_air_time", "feet_contact_time", "last_contacts", "measured_heights", "obs_buf", "rew_buf", "reset_buf",
     "time_out_buf", "episode_length_buf", "episode_sums", "terrain_levels", "terrain_types", "env_origins",
     "friction_coeffs", "base_mass_added", "sea_hidden_state", "sea_cell_state", "gait_idx", "gait_foot_z",
-    "extras_episode", "rand_inject", "step_counters", "height_samples", "terrain_origins"]
+    "extras_episode", "rand_inject", "step_counters", "height_samples", "terrain_origins", "episode_stats"]
 TENSOR_ID = {n: i for i, n in enumerate(TENSOR_NAMES)}
 LG_T_COUNT = len(TENSOR_NAMES)
 
@@ -119,6 +119,10 @@ def declare_product(lib):
     lib.lg_post_physics_step.restype = C.c_int
     lib.lg_reset_idx.argtypes = [vp, vp, i32, i32, vp]
     lib.lg_reset_idx.restype = C.c_int
+    lib.lg_profile_begin.argtypes = [vp, i32, i32]
+    lib.lg_profile_begin.restype = C.c_int
+    lib.lg_profile_end.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
+    lib.lg_profile_end.restype = C.c_int
     lib.lg_last_error.argtypes = [vp]
     lib.lg_last_error.restype = C.c_char_p
     lib.lg_destroy.argtypes = [vp]
@@ -127,4 +131,5 @@ def declare_product(lib):
 
 
 PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_compute_torques",
-                   "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_last_error", "lg_destroy"]
+                   "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
+                   "lg_destroy"]

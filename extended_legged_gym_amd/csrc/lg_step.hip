@@ -20,6 +20,7 @@
 
 #define EPB 16          // envs per workgroup in post_kernel / per wave in physics_kernel
 #define MAX_P 192       // height-scan points per env held in LDS
+#define PART_STRIDE (LG_MAX_REWARD_TERMS + 3)
 
 struct DevCtx {
   lg_config cfg;
@@ -38,9 +39,10 @@ struct DevCtx {
   int64_t *levels, *types;
   float *origins, *friction, *mass_added, *sea_h, *sea_c, *gait_idx, *gait_foot_z, *extras, *rand_inject;
   int64_t* counters;
+  double* ep_stats;
   const float* terrain_origins;
   const float *noise_vec, *height_points;
-  float* partials;     // [nblocks][K + 2] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels
+  float* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
   int nblocks_post;
 };
 
@@ -54,6 +56,8 @@ struct lg_ctx {
   TensorInfo t[LG_T_COUNT];
   int device = 0;
   std::string err;
+  // optional per-kernel timing (lg_profile_begin / lg_profile_end)
+  std::vector<hipEvent_t> ev; int prof_max = 0, prof_stride = 1, prof_n = 0; long prof_calls = 0;
 };
 
 static thread_local std::string g_err;
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
   __shared__ float s_h[EPB][MAX_P];
   __shared__ float s_prop[EPB][48];
   __shared__ float s_rootz[EPB];
-  __shared__ float s_part[EPB][LG_MAX_REWARD_TERMS + 2];
+  __shared__ float s_part[EPB][PART_STRIDE];
   const lg_config& g = C->cfg; const lg_robot_model& m = C->model;
   const int tid = threadIdx.x, e0 = blockIdx.x * EPB;
   const int nenv = min(EPB, C->N - e0);
@@ -544,6 +548,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     C->rew[e] = rew;
     // reset (LR:144-145) and the episode statistics of LR:200-206
     const bool do_reset = term || tout;
+    s_part[el][g.num_reward_terms + 2] = do_reset ? (float)eplen : 0.f;
     if (do_reset) reset_env(C, e, 1, step, 0);
     for (int k = 0; k < g.num_reward_terms; ++k) {
       float sv = 0.f;
@@ -578,11 +583,11 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
   __syncthreads();
 
   // ---- per-workgroup episode statistics, summed in fixed env order (deterministic)
-  const int KP = g.num_reward_terms + 2;
+  const int KP = g.num_reward_terms + 3;
   if (tid < KP) {
     float s = 0.f;
     for (int el = 0; el < nenv; ++el) s += s_part[el][tid];
-    C->partials[(size_t)blockIdx.x * (LG_MAX_REWARD_TERMS + 2) + tid] = s;
+    C->partials[(size_t)blockIdx.x * PART_STRIDE + tid] = s;
   }
 
   // ---- (3) observation rows: proprio | heights, + uniform noise, clipped (LR:245-252, :107-108); 4 entries per lane
@@ -618,10 +623,10 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
 // one workgroup: fixed-order reduction of the per-workgroup partials -> extras (LR:200-206), step counters
 __global__ __launch_bounds__(64) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step) {
   const int K = C->cfg.num_reward_terms, tid = threadIdx.x;
-  __shared__ float tot[LG_MAX_REWARD_TERMS + 2];
-  if (tid < K + 2) {
+  __shared__ float tot[PART_STRIDE];
+  if (tid < K + 3) {
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += C->partials[(size_t)b * (LG_MAX_REWARD_TERMS + 2) + tid];
+    for (int b = 0; b < nblocks; ++b) s += C->partials[(size_t)b * PART_STRIDE + tid];
     tot[tid] = s;
   }
   __syncthreads();
@@ -633,6 +638,10 @@ __global__ __launch_bounds__(64) void finalize_kernel(const DevCtx* __restrict__
   if (tid == 0) {
     if (bump_step) C->counters[0] += 1; else C->counters[2] += 1;
     C->counters[1] = (int64_t)cnt;
+    double ret = 0.0;
+    for (int k = 0; k < K; ++k) ret += (double)tot[k];
+    C->ep_stats[0] += ret; C->ep_stats[1] += (double)tot[K + 2]; C->ep_stats[2] += (double)cnt;
+    if (bump_step) C->ep_stats[3] += (double)C->N;
   }
 }
 
@@ -640,6 +649,12 @@ __global__ __launch_bounds__(64) void finalize_kernel(const DevCtx* __restrict__
 __global__ __launch_bounds__(256) void reset_idx_kernel(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int update_curriculum) {
   const int tid = threadIdx.x, K = C->cfg.num_reward_terms;
   const int64_t step = C->counters[2] + 1;
+  if (tid == K + 2) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += (float)C->ep_len[ids[i]];
+    C->partials[K + 2] = s;
+  }
+  __syncthreads();
   for (int i = tid; i < n; i += 256) reset_env(C, ids[i], update_curriculum, step, 1);
   __syncthreads();
   __threadfence_block();
@@ -657,7 +672,7 @@ __global__ __launch_bounds__(256) void reset_idx_kernel(const DevCtx* __restrict
 }
 
 // ============================================================================================ host side
-static size_t dtype_size(int d) { return d == LG_F32 ? 4 : d == LG_I64 ? 8 : d == LG_U8 ? 1 : d == LG_I16 ? 2 : 4; }
+static size_t dtype_size(int d) { return d == LG_F32 ? 4 : (d == LG_I64 || d == LG_F64) ? 8 : d == LG_U8 ? 1 : d == LG_I16 ? 2 : 4; }
 
 static size_t build_layout(const lg_config* cfg, const lg_robot_model* model, const lg_terrain* ter, TensorInfo* t) {
   const int64_t N = cfg->num_envs, B = model->num_bodies, K = cfg->num_reward_terms, P = cfg->num_height_points, O = cfg->num_obs;
@@ -683,6 +698,7 @@ static size_t build_layout(const lg_config* cfg, const lg_robot_model* model, co
   int64_t r = ter->rows > 0 ? ter->rows : 1, cc = ter->cols > 0 ? ter->cols : 1;
   set(LG_T_HEIGHT_SAMPLES, LG_I16, {r, cc});
   set(LG_T_TERRAIN_ORIGINS, LG_F32, {ter->num_levels > 0 ? ter->num_levels : 1, ter->num_types > 0 ? ter->num_types : 1, 3});
+  set(LG_T_EPISODE_STATS, LG_F64, {4});
   size_t off = 0;
   for (int i = 0; i < LG_T_COUNT; ++i) {
     TensorInfo& T = t[i]; size_t n = dtype_size(T.dtype);
@@ -736,6 +752,7 @@ void lg_destroy(lg_ctx* c) {
   if (c->d) (void)hipFree(c->d);
   if (c->aux) (void)hipFree(c->aux);
   if (c->own_arena && c->arena) (void)hipFree(c->arena);
+  for (auto e : c->ev) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -774,7 +791,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.origins = (float*)P(LG_T_ENV_ORIGINS); h.friction = (float*)P(LG_T_FRICTION_COEFFS); h.mass_added = (float*)P(LG_T_BASE_MASS_ADDED);
   h.sea_h = (float*)P(LG_T_SEA_HIDDEN_STATE); h.sea_c = (float*)P(LG_T_SEA_CELL_STATE); h.gait_idx = (float*)P(LG_T_GAIT_IDX);
   h.gait_foot_z = (float*)P(LG_T_GAIT_FOOT_Z); h.extras = (float*)P(LG_T_EXTRAS_EPISODE); h.rand_inject = (float*)P(LG_T_RAND_INJECT);
-  h.counters = (int64_t*)P(LG_T_STEP_COUNTERS); h.terrain_origins = (const float*)P(LG_T_TERRAIN_ORIGINS);
+  h.counters = (int64_t*)P(LG_T_STEP_COUNTERS); h.ep_stats = (double*)P(LG_T_EPISODE_STATS); h.terrain_origins = (const float*)P(LG_T_TERRAIN_ORIGINS);
   h.ter.mesh_type = ter->mesh_type; h.ter.rows = ter->rows; h.ter.cols = ter->cols;
   h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
   h.ter.H = (const int16_t*)P(LG_T_HEIGHT_SAMPLES);
@@ -782,7 +799,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
 
   // aux buffer: noise_vec | height_points | partials
   size_t n_noise = (size_t)cfg->num_obs, n_hp = (size_t)2 * cfg->num_height_points;
-  size_t n_part = (size_t)h.nblocks_post * (LG_MAX_REWARD_TERMS + 2);
+  size_t n_part = (size_t)h.nblocks_post * PART_STRIDE;
   size_t aux_floats = n_noise + n_hp + n_part;
   if (hipMalloc(&c->aux, aux_floats * 4) != hipSuccess) return fail("hipMalloc(aux) failed");
   if (hipMemset(c->aux, 0, aux_floats * 4) != hipSuccess) return fail("hipMemset(aux) failed");
@@ -818,9 +835,11 @@ int lg_get_tensor(lg_ctx* c, int id, void** dptr, int64_t shape[4], int32_t* ndi
   return LG_OK;
 }
 
-static int launch_post(lg_ctx* c, hipStream_t st) {
+static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev) {
   hipLaunchKernelGGL(post_kernel, dim3(c->h.nblocks_post), dim3(256), 0, st, c->d);
+  if (ev) (void)hipEventRecord(ev[2], st);
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, c->d, c->h.nblocks_post, 1);
+  if (ev) (void)hipEventRecord(ev[3], st);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -830,8 +849,39 @@ int lg_step(lg_ctx* c, const float* actions, void* stream) {
   if (!actions) { c->err = "actions is null"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = (c->h.N + EPB - 1) / EPB;
+  hipEvent_t* ev = nullptr;
+  if (c->prof_max > 0) {
+    if (c->prof_n < c->prof_max && (c->prof_calls % c->prof_stride) == 0) ev = &c->ev[(size_t)4 * c->prof_n++];
+    c->prof_calls++;
+  }
+  if (ev) (void)hipEventRecord(ev[0], st);
   hipLaunchKernelGGL(physics_kernel<0>, dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation);
-  return launch_post(c, st);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  return launch_post(c, st, ev);
+}
+
+int lg_profile_begin(lg_ctx* c, int32_t max_samples, int32_t stride) {
+  if (!c || max_samples <= 0 || stride <= 0) return LG_ERR_INVALID;
+  for (auto e : c->ev) (void)hipEventDestroy(e);
+  c->ev.assign((size_t)4 * max_samples, nullptr);
+  for (auto& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+  c->prof_max = max_samples; c->prof_stride = stride; c->prof_n = 0; c->prof_calls = 0;
+  return LG_OK;
+}
+
+int lg_profile_end(lg_ctx* c, float mean_ms[3], int32_t* nsamples) {
+  if (!c || !mean_ms || !nsamples) return LG_ERR_INVALID;
+  double acc[3] = {0, 0, 0};
+  for (int i = 0; i < c->prof_n; ++i) {
+    hipEvent_t* ev = &c->ev[(size_t)4 * i];
+    HIP_TRY(c, hipEventSynchronize(ev[3]));
+    for (int k = 0; k < 3; ++k) { float ms = 0.f; HIP_TRY(c, hipEventElapsedTime(&ms, ev[k], ev[k + 1])); acc[k] += ms; }
+  }
+  *nsamples = c->prof_n;
+  for (int k = 0; k < 3; ++k) mean_ms[k] = c->prof_n > 0 ? (float)(acc[k] / c->prof_n) : 0.f;
+  for (auto e : c->ev) (void)hipEventDestroy(e);
+  c->ev.clear(); c->prof_max = 0; c->prof_n = 0;
+  return LG_OK;
 }
 
 int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
@@ -852,7 +902,7 @@ int lg_simulate(lg_ctx* c, void* stream) {
 
 int lg_post_physics_step(lg_ctx* c, void* stream) {
   if (!c) return LG_ERR_INVALID;
-  return launch_post(c, (hipStream_t)stream);
+  return launch_post(c, (hipStream_t)stream, nullptr);
 }
 
 int lg_reset_idx(lg_ctx* c, const int32_t* env_ids, int32_t n, int32_t update_curriculum, void* stream) {

@@ -1,0 +1,247 @@
+"""`LeggedRobot`: the environment class callers see (reference `envs/base/legged_robot.py`).
+
+Same constructor, attributes and return tuples as the reference; the body of `step()` — torques, four physics
+substeps, `post_physics_step` with rewards / termination / reset / observations — is ONE call into the HIP library
+(`lg_step`, include/lgstep.h) instead of ~200 PyTorch launches plus PhysX.  Every tensor attribute is a zero-copy view
+of a library-owned device buffer, like `gymtorch.wrap_tensor` views in the reference (:564-584).
+
+Not overridable in Python (they are fused in the kernels): `check_termination`, `compute_reward`,
+`compute_observations`, `_reward_*`.  Reward terms are selected by name through `cfg.rewards.scales` exactly as before.
+"""
+import numpy as np
+import torch
+
+from extended_legged_gym_amd import abi
+from extended_legged_gym_amd.native import NativeCore
+from extended_legged_gym_amd.utils.helpers import class_to_dict
+from extended_legged_gym_amd.utils.isaac_torch_utils import get_axis_params, to_torch, torch_rand_float
+from extended_legged_gym_amd.utils.terrain import Terrain
+from .base_task import BaseTask
+from .legged_robot_config import LeggedRobotCfg
+from .native_config import NativeSetup, load_robot_model
+
+
+class LeggedRobot(BaseTask):
+    def __init__(self, cfg: LeggedRobotCfg, sim_params, physics_engine, sim_device, headless):
+        self.cfg = cfg
+        self.sim_params = sim_params
+        self.height_samples = None
+        self.debug_viz = False
+        self.init_done = False
+        self._parse_cfg(self.cfg)
+        super().__init__(self.cfg, sim_params, physics_engine, sim_device, headless)
+        self._init_buffers()
+        self._prepare_reward_function()
+        self.init_done = True
+        self.acc_ema = 0.9
+
+    # ------------------------------------------------------------------ the hot path
+    def step(self, actions):
+        """Apply actions, simulate `decimation` substeps, run the post-physics step (`legged_robot.py:87-111`)."""
+        self.core.step(actions.to(self.device))
+        self.common_step_counter += 1
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def post_physics_step(self):
+        self.core.post_physics_step()
+        self.common_step_counter += 1
+
+    def reset_idx(self, env_ids):
+        """Reset some environments (`legged_robot.py:162-213`); curriculum only moves once `init_done`."""
+        if len(env_ids) == 0:
+            return
+        self.core.reset_idx(env_ids, update_curriculum=int(self.init_done))
+
+    def _compute_torques(self, actions):
+        """One actuator evaluation from the current DOF state (`:425-448`, `anymal.py:93-105`); returns `torques`."""
+        self.core.compute_torques(actions.to(self.device))
+        return self.torques
+
+    # ------------------------------------------------------------------ construction
+    def create_sim(self):
+        """Terrain, robot model, per-env randomisation and the native context (`legged_robot.py:254-293,725-815`)."""
+        self.up_axis_idx = 2
+        mesh_type = self.cfg.terrain.mesh_type
+        if mesh_type in ['heightfield', 'trimesh']:
+            if self.cfg.terrain.use_terrain_obj:
+                raise NotImplementedError("TerrainObj (OBJ mesh terrain) is not part of the native step yet")
+            self.terrain = Terrain(self.cfg.terrain, self.num_envs)
+        elif mesh_type == 'confined_trimesh':
+            raise NotImplementedError("confined_trimesh terrain is not part of the native step yet")
+        elif mesh_type == 'plane':
+            self.terrain = None
+        else:
+            raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh, confined_trimesh]")
+
+        self.robot_model = load_robot_model(self.cfg.asset)
+        self.body_names = self.robot_model["body_names"]
+        self.dof_names = self.robot_model["dof_names"]
+        self.num_bodies = len(self.body_names)
+        self.num_dof = self.num_dofs = len(self.dof_names)
+        seed = getattr(self.cfg, "seed", 1)
+        seed = int(seed) if seed is not None and seed >= 0 else 0
+        # env shards of a multi-GPU job draw from disjoint Philox streams
+        seed += 1000003 * int(getattr(self.cfg, "rng_stream_offset", 0))
+        self.setup = NativeSetup(self.cfg, self.sim_params, self.robot_model, terrain=self.terrain, seed=seed,
+                                 gait=self._gait_config())
+        self.core = NativeCore(self.setup, self.device)
+        t = self.core.t
+
+        def idx(lst):
+            return torch.tensor(lst, dtype=torch.long, device=self.device)
+        self.feet_indices = idx(self.robot_model["feet_indices"])
+        self.penalised_contact_indices = idx(self.robot_model["penalised_contact_indices"])
+        self.termination_contact_indices = idx(self.robot_model["termination_contact_indices"])
+        init = self.cfg.init_state
+        self.base_init_state = to_torch(init.pos + init.rot + init.lin_vel + init.ang_vel, device=self.device)
+
+        self._get_env_origins()
+        # per-env friction: 64 buckets (`:332-343`); base payload (`:381-383`)
+        if self.cfg.domain_rand.randomize_friction:
+            fr = self.cfg.domain_rand.friction_range
+            bucket_ids = torch.randint(0, 64, (self.num_envs, 1))
+            buckets = torch_rand_float(fr[0], fr[1], (64, 1), device='cpu')
+            self.friction_coeffs = buckets[bucket_ids]
+            t["friction_coeffs"].copy_(self.friction_coeffs.view(-1))
+        else:
+            t["friction_coeffs"].fill_(1.0)
+        if self.cfg.domain_rand.randomize_base_mass:
+            rng = self.cfg.domain_rand.added_mass_range
+            t["base_mass_added"].copy_(torch.from_numpy(np.random.uniform(rng[0], rng[1], self.num_envs).astype(np.float32)))
+
+        # DOF limits (`:357-371`)
+        m = self.robot_model
+        self.dof_pos_limits = torch.tensor(self.setup.dof_pos_limits, dtype=torch.float, device=self.device)
+        self.dof_vel_limits = torch.tensor(m["dof_vel_limit"], dtype=torch.float, device=self.device)
+        self.torque_limits = torch.tensor(m["torque_limit"], dtype=torch.float, device=self.device)
+        if self.terrain is not None:
+            self.height_samples = t["height_samples"]
+
+    def _gait_config(self):
+        return None
+
+    def _get_env_origins(self):
+        """Terrain platforms on rough terrain, a grid otherwise (`legged_robot.py:817-844`)."""
+        t = self.core.t
+        self.env_origins = t["env_origins"]
+        if self.cfg.terrain.mesh_type in ["heightfield", "trimesh", "confined_trimesh"]:
+            self.custom_origins = True
+            max_init_level = self.cfg.terrain.max_init_terrain_level
+            if not self.cfg.terrain.curriculum:
+                max_init_level = self.cfg.terrain.num_rows - 1
+            self.terrain_levels = t["terrain_levels"]
+            self.terrain_types = t["terrain_types"]
+            self.terrain_levels.copy_(torch.randint(0, max_init_level + 1, (self.num_envs,), device=self.device))
+            # a shard of a multi-GPU job indexes terrain columns by GLOBAL env id, so the union of the shards has the
+            # single-GPU layout (`legged_robot.py:829-830` with num_envs = the job's total)
+            offset = int(getattr(self.cfg.env, "global_env_offset", 0))
+            total = int(getattr(self.cfg.env, "global_num_envs", self.num_envs))
+            self.terrain_types.copy_(torch.div(offset + torch.arange(self.num_envs, device=self.device),
+                                               (total / self.cfg.terrain.num_cols), rounding_mode='floor').to(torch.long))
+            self.max_terrain_level = self.cfg.terrain.num_rows
+            self.terrain_origins = t["terrain_origins"]
+            self.env_origins[:] = self.terrain_origins[self.terrain_levels, self.terrain_types]
+        else:
+            self.custom_origins = False
+            num_cols = np.floor(np.sqrt(self.num_envs))
+            num_rows = np.ceil(self.num_envs / num_cols)
+            xx, yy = torch.meshgrid(torch.arange(num_rows), torch.arange(num_cols), indexing="ij")
+            spacing = self.cfg.env.env_spacing
+            self.env_origins[:, 0] = (spacing * xx.flatten()[:self.num_envs]).to(self.device)
+            self.env_origins[:, 1] = (spacing * yy.flatten()[:self.num_envs]).to(self.device)
+            self.env_origins[:, 2] = 0.
+
+    def _parse_cfg(self, cfg):
+        self.dt = self.cfg.control.decimation * self.sim_params.dt
+        self.obs_scales = self.cfg.normalization.obs_scales
+        self.reward_scales_stage = self.cfg.rewards.reward_min_stage
+        self.reward_scales = self._get_reward_scales(self.reward_scales_stage)
+        self.command_ranges = class_to_dict(self.cfg.commands.ranges)
+        if self.cfg.terrain.mesh_type not in ['heightfield', 'trimesh', 'confined_trimesh']:
+            self.cfg.terrain.curriculum = False
+        self.max_episode_length_s = self.cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        self.cfg.domain_rand.push_interval = np.ceil(self.cfg.domain_rand.push_interval_s / self.dt)
+
+    def _get_reward_scales(self, stage=0):
+        scales = class_to_dict(self.cfg.rewards.scales)
+        if self.cfg.rewards.multi_stage_rewards:
+            return {k: (v if not isinstance(v, list) else (v[-1] if stage >= len(v) else v[stage])) for k, v in scales.items()}
+        return scales
+
+    def update_reward_scales(self, mean_reward):
+        if self.cfg.rewards.multi_stage_rewards:
+            raise NotImplementedError("multi-stage reward scales are not re-uploaded to the native step yet")
+        return False
+
+    def _init_buffers(self):
+        """Bind the reference's attribute names to views of the library's tensors (`legged_robot.py:559-647`)."""
+        t = self.core.t
+        N = self.num_envs
+        self.root_states = t["root_states"]
+        self.dof_state = t["dof_state"].view(N * self.num_dof, 2)
+        self.dof_pos = t["dof_state"][..., 0]
+        self.dof_vel = t["dof_state"][..., 1]
+        self.base_pos = self.root_states[:, :3]
+        self.base_quat = self.root_states[:, 3:7]
+        self.contact_forces = t["contact_forces"]
+        self.rigid_body_state = t["rigid_body_state"].view(N * self.num_bodies, 13)
+        self.common_step_counter = 0
+        self.extras = {}
+        self.noise_scale_vec = torch.from_numpy(self.setup.noise_scale_vec).to(self.device)
+        self.add_noise = self.cfg.noise.add_noise
+        self.gravity_vec = to_torch(get_axis_params(-1., self.up_axis_idx), device=self.device).repeat((N, 1))
+        self.forward_vec = to_torch([1., 0., 0.], device=self.device).repeat((N, 1))
+        self.torques = t["torques"]
+        self.p_gains = torch.tensor(self.setup.p_gains, dtype=torch.float, device=self.device)
+        self.d_gains = torch.tensor(self.setup.d_gains, dtype=torch.float, device=self.device)
+        self.actions = t["actions"]
+        self.last_actions = t["last_actions"]
+        self.last_dof_vel = t["last_dof_vel"]
+        self.last_root_vel = t["last_root_vel"]
+        self.commands = t["commands"]
+        os_ = self.obs_scales
+        self.commands_scale = torch.tensor([os_.lin_vel, os_.lin_vel, os_.ang_vel], device=self.device, requires_grad=False)
+        self.feet_air_time = t["feet_air_time"]
+        self.feet_contact_time = t["feet_contact_time"]
+        self.last_contacts = t["last_contacts"].view(torch.bool)
+        rb = t["rigid_body_state"]
+        self.foot_positions = rb[:, self.feet_indices, 0:3]
+        self.foot_velocities = rb[:, self.feet_indices, 7:10]
+        self.base_lin_vel = t["base_lin_vel"]
+        self.base_ang_vel = t["base_ang_vel"]
+        self.base_lin_acc = t["base_lin_acc"]
+        self.base_ang_acc = t["base_ang_acc"]
+        self.projected_gravity = t["projected_gravity"]
+        if self.cfg.terrain.measure_heights:
+            hp = torch.from_numpy(self.setup.height_points).to(self.device)
+            self.num_height_points = hp.shape[0]
+            self.height_points = torch.zeros(N, self.num_height_points, 3, device=self.device)
+            self.height_points[:, :, :2] = hp
+            self.measured_heights = t["measured_heights"]
+        else:
+            self.measured_heights = 0
+        self.default_dof_pos = torch.tensor(self.setup.default_dof_pos, dtype=torch.float, device=self.device).unsqueeze(0)
+
+    def _prepare_reward_function(self):
+        """Names / dt-scaled scales of the active terms and their episode sums (`legged_robot.py:649-674`)."""
+        names, vals = self.setup.reward_names, self.setup.reward_scales
+        self.reward_scales = dict(zip(names, vals))
+        self.reward_names = [n for n in names if n != "termination"]
+        es = self.core.t["episode_sums"]
+        self.episode_sums = {n: es[k] for k, n in enumerate(names)}
+        ex = self.core.t["extras_episode"]
+        episode = {"rew_" + n: ex[k] for k, n in enumerate(names)}
+        if self.cfg.terrain.curriculum:
+            episode["terrain_level"] = ex[len(names)]
+        if self.cfg.commands.curriculum:
+            episode["max_command_x"] = self.command_ranges["lin_vel_x"][1]
+        self.extras["episode"] = episode
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self.time_out_buf
+
+    def _get_heights(self, env_ids=None):
+        return self.core.t["measured_heights"]
+
+    def _get_noise_scale_vec(self, cfg):
+        return self.noise_scale_vec

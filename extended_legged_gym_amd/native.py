@@ -14,7 +14,7 @@ from extended_legged_gym_amd import abi
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblgstep.so")
 _TORCH_DTYPE = {abi.LG_F32: torch.float32, abi.LG_I64: torch.int64, abi.LG_U8: torch.uint8, abi.LG_I16: torch.int16,
-                abi.LG_I32: torch.int32}
+                abi.LG_I32: torch.int32, abi.LG_F64: torch.float64}
 _lib = None
 
 
@@ -109,6 +109,14 @@ class NativeCore:
         ids = env_ids.to(device=self.device, dtype=torch.int32).contiguous()
         self._check(self.lib.lg_reset_idx(self.ctx, C.c_void_p(ids.data_ptr()), int(ids.numel()), int(update_curriculum),
                                           self._stream()))
+
+    def profile_begin(self, max_samples=256, stride=1):
+        self._check(self.lib.lg_profile_begin(self.ctx, int(max_samples), int(stride)))
+
+    def profile_end(self):
+        ms, n = (C.c_float * 3)(), C.c_int32()
+        self._check(self.lib.lg_profile_end(self.ctx, ms, C.byref(n)))
+        return dict(physics_ms=ms[0], post_ms=ms[1], finalize_ms=ms[2], samples=n.value)
 
     def close(self):
         if getattr(self, "ctx", None):

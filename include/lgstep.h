@@ -50,7 +50,7 @@ enum lg_status {
 };
 
 /* element types of arena tensors */
-enum lg_dtype { LG_F32 = 0, LG_I64 = 1, LG_U8 = 2, LG_I16 = 3, LG_I32 = 4 };
+enum lg_dtype { LG_F32 = 0, LG_I64 = 1, LG_U8 = 2, LG_I16 = 3, LG_I32 = 4, LG_F64 = 5 };
 
 /* control_type (legged_robot.py:438-447; anymal.py:93-105) */
 enum lg_control { LG_CTRL_P = 0, LG_CTRL_V = 1, LG_CTRL_T = 2, LG_CTRL_ACTUATOR_NET = 3 };
@@ -125,6 +125,9 @@ enum lg_tensor_id {
   LG_T_STEP_COUNTERS,       /* (4) i64: [0] common_step_counter, [1] #envs reset by the last step       */
   LG_T_HEIGHT_SAMPLES,      /* (rows, cols) i16, read-only terrain grid                                */
   LG_T_TERRAIN_ORIGINS,     /* (levels, types, 3) f32                                                  */
+  LG_T_EPISODE_STATS,       /* (4) f64 running totals since lg_create: sum of finished-episode returns, sum of their
+                               lengths, #finished episodes, #env-steps — what a rank contributes to the cross-GPU
+                               all-gather of episode statistics                                         */
   LG_T_COUNT
 };
 
@@ -236,6 +239,13 @@ int lg_post_physics_step(lg_ctx* ctx, void* stream);
 
 /* Reset the listed envs (device pointer to n int32 ids).  `update_curriculum` = the reference's init_done. */
 int lg_reset_idx(lg_ctx* ctx, const int32_t* env_ids, int32_t n, int32_t update_curriculum, void* stream);
+
+/* Per-kernel timing with HIP events recorded on the caller's stream around the kernels of lg_step.
+ * lg_profile_begin arms up to `max_samples` instrumented steps (every `stride`-th lg_step call is sampled);
+ * lg_profile_end synchronises the events and returns the mean duration in ms of {physics, post-physics, finalize}
+ * and the number of sampled steps.  Used by bench.py for the roofline figure. */
+int lg_profile_begin(lg_ctx* ctx, int32_t max_samples, int32_t stride);
+int lg_profile_end(lg_ctx* ctx, float mean_ms[3], int32_t* nsamples);
 
 const char* lg_last_error(lg_ctx* ctx);
 void lg_destroy(lg_ctx* ctx);

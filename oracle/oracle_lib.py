@@ -10,7 +10,7 @@ from extended_legged_gym_amd import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblg_oracle.so")
-_NP = {abi.LG_F32: np.float32, abi.LG_I64: np.int64, abi.LG_U8: np.uint8, abi.LG_I16: np.int16, abi.LG_I32: np.int32}
+_NP = {abi.LG_F32: np.float32, abi.LG_I64: np.int64, abi.LG_U8: np.uint8, abi.LG_I16: np.int16, abi.LG_I32: np.int32, abi.LG_F64: np.float64}
 
 
 def build(force=False):
