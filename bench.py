@@ -67,7 +67,8 @@ def cpu_baseline(env, actions_pool, budget_s=15.0):
                  "episode_sums", "gait_idx", "gait_foot_z", "base_lin_acc", "base_ang_acc", "step_counters"]:
         o.t[name][...] = env.core.t[name].cpu().numpy()
     acts = [a.cpu().numpy() for a in actions_pool[:8]]
-    cores = lib().lgo_max_threads()
+    cores = len(os.sched_getaffinity(0))           # the cores this process may actually run on
+    lib().lgo_set_threads(cores)
     t0 = time.perf_counter()
     o.step(acts[0])
     o.step(acts[1])
@@ -80,7 +81,8 @@ def cpu_baseline(env, actions_pool, budget_s=15.0):
     val = env.num_envs * n / dt
     o.close()
     return dict(value=val, unit="env-steps/s", cores=int(cores), kind="port",
-                sample=f"{n} policy steps x {env.num_envs} envs of the same workload, oracle/lg_oracle.cpp with OpenMP on {cores} threads, {dt:.1f} s")
+                sample=f"{n} policy steps x {env.num_envs} envs of the same workload, oracle/lg_oracle.cpp with OpenMP on {cores} threads "
+                       f"(os.cpu_count()={os.cpu_count()}), {dt:.1f} s")
 
 
 def main():

@@ -620,14 +620,18 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
   }
 }
 
-// one workgroup: fixed-order reduction of the per-workgroup partials -> extras (LR:200-206), step counters
+// one wave: fixed-order reduction of the per-workgroup partials -> extras (LR:200-206), step counters, running stats.
+// Column c is summed by all 64 lanes (lane i takes workgroups i, i+64, ...) and folded with a fixed xor butterfly, so
+// the result does not depend on scheduling.
 __global__ __launch_bounds__(64) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step) {
   const int K = C->cfg.num_reward_terms, tid = threadIdx.x;
   __shared__ float tot[PART_STRIDE];
-  if (tid < K + 3) {
+  for (int c = 0; c < K + 3; ++c) {
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += C->partials[(size_t)b * PART_STRIDE + tid];
-    tot[tid] = s;
+    for (int b = tid; b < nblocks; b += 64) s += C->partials[(size_t)b * PART_STRIDE + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (tid == 0) tot[c] = s;
   }
   __syncthreads();
   const float cnt = tot[K];
