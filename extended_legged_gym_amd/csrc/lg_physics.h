@@ -364,6 +364,13 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const TerrainV
     }
   }
 
+  // ---------------------------------------------------------------- joint speed limit (URDF <limit velocity>)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float lim = m->dof_vel_limit[3 * l + j];
+    if (lim > 0.f) vK[j] = fminf(fmaxf(vK[j], -lim), lim);
+  }
+
   // ---------------------------------------------------------------- net contact force per body (world frame)
   if (fbody) {
     V3 fb[5] = {v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0)};

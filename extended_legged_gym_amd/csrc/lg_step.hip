@@ -217,6 +217,7 @@ __global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ 
   const TerrainView T = C->ter;
   const float mu_robot = C->friction[e], madd = C->mass_added[e];
   V3 fbody[5];
+  bool fault = false;
 #pragma unroll 1
   for (int sub = 0; sub < nsub; ++sub) {
     if (MODE == 0) leg_torques(C, l, act, s.q, s.qd, last_qd, A, tau);
@@ -224,9 +225,35 @@ __global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 3; ++j) tau[j] = C->torques[(size_t)e * 12 + 3 * l + j];
     }
+    float root0[7], q0[3];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) root0[i] = s.root[i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) q0[j] = s.q[j];
     physics_substep(m, T, P, l, lane, cst, s, tau, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr);
+    // fault guard: a non-finite state is rolled back to the pre-step pose at rest and flagged for termination
+    float acc = 0.f, acc0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) acc += s.root[i] * 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { acc += s.q[j] * 0.f + s.qd[j] * 0.f; acc0 += q0[j] * 0.f; }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc0 += root0[i] * 0.f;
+    acc = quad_sum(acc); acc0 = quad_sum(acc0);
+    if (!(acc == 0.f)) {
+      const bool ok0 = acc0 == 0.f;
+      fault = true;
+#pragma unroll
+      for (int i = 0; i < 13; ++i)
+        s.root[i] = ok0 ? (i < 7 ? root0[i] : 0.f) : g.base_init_state[i] + (i < 3 ? C->origins[(size_t)e * 3 + i] : 0.f);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { s.q[j] = ok0 ? q0[j] : g.default_dof_pos[3 * l + j]; s.qd[j] = 0.f; }
+#pragma unroll
+      for (int b = 0; b < 5; ++b) fbody[b] = v3(0, 0, 0);
+    }
   }
   if (!valid) return;
+  if (fault && l == 0) C->reset_buf[e] = 2;
 
   // ---- write back state, torques, contact forces
   if (l == 0) {
@@ -531,6 +558,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     // check_termination (LR:155-160)
     bool term = false;
     for (int i = 0; i < m.num_termination; ++i) { int b = m.termination_contact_indices[i]; term |= FNORM(b) > 1.f; }
+    term |= C->reset_buf[e] == 2;   // physics fault flagged by physics_kernel
     bool tout = (float)eplen > g.max_episode_length;
     C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0;
     // compute_reward (LR:215-232)

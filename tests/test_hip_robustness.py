@@ -1,0 +1,39 @@
+"""GPU: long random-action rollouts stay finite, and the fault guard turns an injected non-finite state into a
+terminated episode instead of poisoning the batch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rough_4096_envs_2000_steps_stay_finite():
+    from tests.test_env_api import make
+    env = make("anymal_c_rough", 4096, **{"terrain.mesh_type": "heightfield"})
+    env.reset()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    pool = [torch.randn(4096, 12, generator=g).cuda() for _ in range(32)]
+    for i in range(2000):
+        env.step(pool[i % 32])
+        if i % 100 == 99:
+            for name in ["obs_buf", "root_states", "dof_state", "rew_buf", "contact_forces", "rigid_body_state"]:
+                assert torch.isfinite(env.core.t[name]).all(), f"{name} non-finite at step {i}"
+            assert float(env.dof_vel.abs().max()) <= 20.0 + 1e-3        # URDF joint-speed cap
+            assert float(env.root_states[:, 7:13].abs().max()) < 100.0
+    st = env.core.t["episode_stats"].cpu().numpy()
+    assert np.isfinite(st).all() and st[2] > 0
+
+
+def test_injected_nan_is_contained_and_terminates_the_episode():
+    from tests.test_env_api import make
+    env = make("anymal_c_flat", 64)
+    env.reset()
+    for i in range(5):
+        env.step(torch.zeros(64, 12, device=env.device))
+    env.dof_vel[7, 3] = float("nan")
+    env.root_states[9, 8] = float("inf")
+    o, _, r, d, _ = env.step(torch.zeros(64, 12, device=env.device))
+    assert bool(d[7]) and bool(d[9]) and int(d.sum()) == 2
+    for name in ["obs_buf", "root_states", "dof_state", "rew_buf", "contact_forces", "rigid_body_state", "episode_sums"]:
+        assert torch.isfinite(env.core.t[name]).all(), name
+    assert int(env.episode_length_buf[7]) == 0 and int(env.episode_length_buf[9]) == 0

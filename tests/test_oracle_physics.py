@@ -49,7 +49,7 @@ def momenta(model, rb, added_mass=0.0):
     return M, P, L, KE
 
 
-def make(cfg_cls=AnymalCFlatCfg, n=4, control="T", gravity=(0, 0, -9.81), terrain=None, mutate=None):
+def make(cfg_cls=AnymalCFlatCfg, n=4, control="T", gravity=(0, 0, -9.81), terrain=None, mutate=None, speed_limit=True):
     cfg = cfg_cls()
     cfg.env.num_envs = n
     cfg.control.use_actuator_network = False
@@ -60,6 +60,8 @@ def make(cfg_cls=AnymalCFlatCfg, n=4, control="T", gravity=(0, 0, -9.81), terrai
     if mutate:
         mutate(cfg)
     model = load_robot_model(cfg.asset)
+    if not speed_limit:
+        model["dof_vel_limit"] = [0.0] * 12      # the URDF joint-speed cap is a non-conservative clamp: off for conservation tests
     s = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=3, gait=ANYMAL_GAIT)
     o = OracleEnv(s)
     o.t["friction_coeffs"][:] = 1.0
@@ -69,7 +71,7 @@ def make(cfg_cls=AnymalCFlatCfg, n=4, control="T", gravity=(0, 0, -9.81), terrai
 def _free_fall_error(dt, steps):
     def mut(cfg):
         cfg.sim.dt = dt
-    cfg, s, model, o = make(mutate=mut)
+    cfg, s, model, o = make(mutate=mut, speed_limit=False)
     rng = np.random.default_rng(0)
     n = 4
     o.t["root_states"][:, :3] = [0, 0, 50.0]
@@ -120,7 +122,7 @@ def sum_com(model, rb):
 
 
 def test_zero_gravity_conserves_momentum_and_energy_without_torques():
-    cfg, s, model, o = make(gravity=(0, 0, 0))
+    cfg, s, model, o = make(gravity=(0, 0, 0), speed_limit=False)
     rng = np.random.default_rng(1)
     n = 4
     o.t["root_states"][:, :3] = [0, 0, 30.0]
