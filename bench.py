@@ -38,13 +38,11 @@ POST_BYTES = dict(
 def build_env(rank, world, num_envs):
     from extended_legged_gym_amd.envs import Anymal, AnymalCRoughCfg
     from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params, set_seed
+    from extended_legged_gym_amd.utils.sharding import shard_env_cfg
     cfg = AnymalCRoughCfg()
-    cfg.env.num_envs = num_envs
     cfg.terrain.mesh_type = "heightfield"          # BASELINE config 2: collide against the 900x900 int16 grid
     cfg.seed = 1
-    cfg.env.global_env_offset = rank * num_envs    # terrain columns are assigned by GLOBAL env index
-    cfg.env.global_num_envs = world * num_envs
-    cfg.rng_stream_offset = rank                   # decorrelates the in-kernel Philox streams of the shards
+    shard_env_cfg(cfg, rank, world, num_envs)      # global terrain-column indexing + private Philox stream per shard
     args = get_args([])
     args.sim_device = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
     import contextlib
@@ -134,16 +132,13 @@ def main():
     prof = env.core.profile_end()
 
     # episode statistics of every shard: one all-gather (RCCL over xGMI when world > 1)
-    stats = env.core.t["episode_stats"].clone()
+    from extended_legged_gym_amd.utils.sharding import gather_episode_stats
     if dist is not None:
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
-        gathered = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
-        stats_all = torch.stack(gathered).sum(0).cpu().numpy()
-    else:
-        stats_all = stats.cpu().numpy()
+    _, totals = gather_episode_stats(env.core.t["episode_stats"].clone(), dist)
+    stats_all = totals.cpu().numpy()
     finite = bool(torch.isfinite(env.obs_buf).all().item() and torch.isfinite(env.root_states).all().item())
 
     if rank == 0:

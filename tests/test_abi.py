@@ -1,0 +1,72 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/lgstep.h declares, and agrees with the ctypes
+mirror (extended_legged_gym_amd/abi.py) on enum values and struct sizes.  No compute calls here."""
+import ctypes
+import os
+import re
+
+from extended_legged_gym_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "lgstep.h")).read()
+LIB = os.path.join(ROOT, "extended_legged_gym_amd", "csrc", "liblgstep.so")
+
+
+def parse_enum(name):
+    body = re.search(r"enum\s+%s\s*\{(.*?)\};" % name, HEADER, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    vals, cur = {}, -1
+    for item in body.split(","):
+        item = item.strip()
+        if not item:
+            continue
+        if "=" in item:
+            k, v = [x.strip() for x in item.split("=")]
+            cur = int(v, 0)
+        else:
+            k, cur = item, cur + 1
+        vals[k] = cur
+    return vals
+
+
+def test_enums_match_the_header():
+    t = parse_enum("lg_tensor_id")
+    assert t.pop("LG_T_COUNT") == abi.LG_T_COUNT
+    assert {k[len("LG_T_"):].lower(): v for k, v in t.items()} == abi.TENSOR_ID
+    r = parse_enum("lg_reward_term")
+    assert r.pop("LG_REW_COUNT") == len(abi.REWARD_TERMS)
+    assert {k[len("LG_REW_"):].lower(): v for k, v in r.items()} == abi.REWARD_TERM_ID
+    assert parse_enum("lg_rand_slot") == abi.RAND_SLOTS
+    d = parse_enum("lg_dtype")
+    assert (d["LG_F32"], d["LG_I64"], d["LG_U8"], d["LG_I16"], d["LG_I32"], d["LG_F64"]) == (
+        abi.LG_F32, abi.LG_I64, abi.LG_U8, abi.LG_I16, abi.LG_I32, abi.LG_F64)
+    c = parse_enum("lg_control")
+    assert c == dict(LG_CTRL_P=abi.LG_CTRL_P, LG_CTRL_V=abi.LG_CTRL_V, LG_CTRL_T=abi.LG_CTRL_T,
+                     LG_CTRL_ACTUATOR_NET=abi.LG_CTRL_ACTUATOR_NET)
+    for macro, val in [("LG_MAX_CP", abi.LG_MAX_CP), ("LG_MAX_REWARD_TERMS", abi.LG_MAX_REWARD_TERMS),
+                       ("LG_LSTM_NPARAM", abi.LG_LSTM_NPARAM), ("LG_ABI_VERSION", abi.LG_ABI_VERSION),
+                       ("LG_MAX_INDEX_LIST", abi.LG_MAX_INDEX_LIST)]:
+        assert int(re.search(r"#define\s+%s\s+(\d+)" % macro, HEADER).group(1)) == val
+
+
+def test_library_exports_every_declared_symbol_and_struct_sizes_agree():
+    declared = sorted(set(re.findall(r"\b(lg_[a-z_]+)\s*\(", HEADER)))
+    assert sorted(abi.PRODUCT_SYMBOLS) == declared
+    lib = ctypes.CDLL(LIB)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    abi.declare_product(lib)
+    sizes = (ctypes.c_int32 * 4)()
+    lib.lg_abi_sizes(sizes)
+    assert list(sizes) == [abi.LG_ABI_VERSION, ctypes.sizeof(abi.lg_config), ctypes.sizeof(abi.lg_robot_model),
+                           ctypes.sizeof(abi.lg_terrain)]
+
+
+def test_product_has_no_path_through_the_oracle():
+    """The package must never import or link the checker."""
+    pkg = os.path.join(ROOT, "extended_legged_gym_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for needle in ("import oracle", "from oracle", "liblg_oracle", "lgo_", "oracle_lib", "lg_oracle"):
+                    assert needle not in txt, f"{f} reaches into the oracle ({needle})"
