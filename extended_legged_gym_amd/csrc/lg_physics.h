@@ -14,27 +14,70 @@
 #pragma once
 #include "lg_device.h"
 
+// Per-leg model constants staged in LDS as [field][leg]: lane l reads field*4 + l, i.e. a wave touches 4 consecutive
+// dwords per field (broadcast, conflict-free) instead of issuing ~100 dependent global loads per substep.
+enum { LM_JPOS = 0, LM_JROT = 9, LM_JAXIS = 36, LM_MASS = 45, LM_COM = 48, LM_INERTIA = 57, LM_FOOT_POS = 75, LM_FOOT_ROT = 78,
+       LM_VEL_LIMIT = 87, LM_TORQUE_LIMIT = 90, LM_DEFAULT_POS = 93, LM_PGAIN = 96, LM_DGAIN = 99, LM_CP_COUNT = 102,
+       LM_CP_LINK = 103, LM_CP_POS = 111, LM_CP_RADIUS = 135, LM_FIELDS = 143 };
+struct LegModel {
+  const float* t; int l;
+  LG_DEV float f(int field) const { return t[field * 4 + l]; }
+  LG_DEV V3 v(int field) const { return v3(f(field), f(field + 1), f(field + 2)); }
+  LG_DEV int i(int field) const { return __float_as_int(f(field)); }
+};
+// cooperative fill by one wave (64 lanes); call before any LegModel read, followed by a barrier
+LG_DEV void fill_leg_model(float* t, const lg_robot_model* __restrict__ m, const lg_config* __restrict__ g, int lane) {
+  for (int idx = lane; idx < LM_FIELDS * 4; idx += 64) {
+    const int field = idx >> 2, l = idx & 3;
+    float val;
+    if (field < LM_JROT) val = m->joint_pos[l][field / 3][field % 3];
+    else if (field < LM_JAXIS) { int k = field - LM_JROT; val = m->joint_rot[l][k / 9][k % 9]; }
+    else if (field < LM_MASS) { int k = field - LM_JAXIS; val = m->joint_axis[l][k / 3][k % 3]; }
+    else if (field < LM_COM) val = m->link_mass[l][field - LM_MASS];
+    else if (field < LM_INERTIA) { int k = field - LM_COM; val = m->link_com[l][k / 3][k % 3]; }
+    else if (field < LM_FOOT_POS) { int k = field - LM_INERTIA; val = m->link_inertia[l][k / 6][k % 6]; }
+    else if (field < LM_FOOT_ROT) val = m->foot_pos[l][field - LM_FOOT_POS];
+    else if (field < LM_VEL_LIMIT) val = m->foot_rot[l][field - LM_FOOT_ROT];
+    else if (field < LM_TORQUE_LIMIT) val = m->dof_vel_limit[3 * l + field - LM_VEL_LIMIT];
+    else if (field < LM_DEFAULT_POS) val = m->torque_limit[3 * l + field - LM_TORQUE_LIMIT];
+    else if (field < LM_PGAIN) val = g->default_dof_pos[3 * l + field - LM_DEFAULT_POS];
+    else if (field < LM_DGAIN) val = g->p_gains[3 * l + field - LM_PGAIN];
+    else if (field < LM_CP_COUNT) val = g->d_gains[3 * l + field - LM_DGAIN];
+    else if (field < LM_CP_LINK) val = __int_as_float(m->cp_count[l]);
+    else if (field < LM_CP_POS) val = __int_as_float(m->cp_link[l][field - LM_CP_LINK]);
+    else if (field < LM_CP_RADIUS) { int k = field - LM_CP_POS; val = m->cp_pos[l][k / 3][k % 3]; }
+    else val = m->cp_radius[l][field - LM_CP_RADIUS];
+    t[idx] = val;
+  }
+}
+LG_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 struct LegKin {
   M3 R[3];
   V3 O[3], ax[3], com[3], w[3], vO[3];
   S3 Ic[3];
 };
 
-LG_DEV void leg_kinematics(const lg_robot_model* __restrict__ m, int l, const M3& Rb, V3 pb, V3 vb, V3 wb,
+LG_DEV void leg_kinematics(const LegModel& lm_, const M3& Rb, V3 pb, V3 vb, V3 wb,
                            const float q[3], const float qd[3], LegKin& k) {
   M3 Rp = Rb; V3 Op = pb, wp = wb, vp = vb;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    M3 fix = ldm3(m->joint_rot[l][j]);
-    V3 a = ld3(m->joint_axis[l][j]);
-    k.O[j] = Op + mul(Rp, ld3(m->joint_pos[l][j]));
+    M3 fix;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fix.m[i] = lm_.f(LM_JROT + 9 * j + i);
+    V3 a = lm_.v(LM_JAXIS + 3 * j);
+    k.O[j] = Op + mul(Rp, lm_.v(LM_JPOS + 3 * j));
     M3 R0 = mul(Rp, fix);
     k.ax[j] = mul(R0, a);
     k.R[j] = mul(R0, axis_angle(a, q[j]));
-    k.com[j] = k.O[j] + mul(k.R[j], ld3(m->link_com[l][j]));
+    k.com[j] = k.O[j] + mul(k.R[j], lm_.v(LM_COM + 3 * j));
     k.vO[j] = vp + cross(wp, k.O[j] - Op);
     k.w[j] = wp + qd[j] * k.ax[j];
-    k.Ic[j] = rotate_inertia(k.R[j], m->link_inertia[l][j]);
+    float I6[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) I6[i] = lm_.f(LM_INERTIA + 6 * j + i);
+    k.Ic[j] = rotate_inertia(k.R[j], I6);
     Rp = k.R[j]; Op = k.O[j]; wp = k.w[j]; vp = k.vO[j];
   }
 }
@@ -43,7 +86,7 @@ LG_DEV void leg_kinematics(const lg_robot_model* __restrict__ m, int l, const M3
 
 LG_DEV void sym3_inverse(const float a[6], float o[6]) {  // a: 00 01 02 11 12 22
   float c00 = a[3] * a[5] - a[4] * a[4], c01 = a[2] * a[4] - a[1] * a[5], c02 = a[1] * a[4] - a[2] * a[3];
-  float id = 1.0f / (a[0] * c00 + a[1] * c01 + a[2] * c02);
+  float id = frcp(a[0] * c00 + a[1] * c01 + a[2] * c02);
   o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
   o[3] = (a[0] * a[5] - a[2] * a[2]) * id; o[4] = (a[1] * a[2] - a[0] * a[4]) * id; o[5] = (a[0] * a[3] - a[1] * a[1]) * id;
 }
@@ -59,7 +102,7 @@ LG_DEV void chol6(float* A) {
     float d = A[LT(j, j)];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= A[LT(j, k)] * A[LT(j, k)];
-    float inv = 1.0f / sqrtf(fmaxf(d, 1e-20f));
+    float inv = __builtin_amdgcn_rsqf(fmaxf(d, 1e-20f));
     A[LT(j, j)] = inv;
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
@@ -87,11 +130,47 @@ LG_DEV void solve6(const float* L, float* b) {
   }
 }
 
+// explicit inverse of an SPD 6x6 from its Cholesky factor (packed lower, inverted diagonal): Linv, then Sinv = Linv^T Linv.
+// Applying S^-1 as a dense symmetric mat-vec has no dependent chain, unlike forward/back substitution.
+LG_DEV void spd6_inverse_from_chol(const float* L, float* Si) {
+  float Li[21];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    Li[LT(j, j)] = L[LT(j, j)];
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int k = j; k < i; ++k) sacc += L[LT(i, k)] * Li[LT(k, j)];
+      Li[LT(i, j)] = -sacc * L[LT(i, i)];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int k = a; k < 6; ++k) sacc += Li[LT(k, a)] * Li[LT(k, b)];
+      Si[LT(a, b)] = sacc;
+    }
+}
+LG_DEV void symv6(const float* Si, const float* x, float* y) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) sacc += (b <= a ? Si[LT(a, b)] : Si[LT(b, a)]) * x[b];
+    y[a] = sacc;
+  }
+}
+
 // terrain surface under (x, y): height and unit normal of the regular-grid triangulation (diagonal v(i,j)->v(i+1,j+1))
 struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t* __restrict__ H; };
 LG_DEV void terrain_query(const TerrainView& T, float x, float y, float* h, V3* n) {
   if (T.mesh_type == LG_MESH_PLANE) { *h = 0.f; *n = v3(0, 0, 1); return; }
-  float fx = (x + T.border) / T.hscale, fy = (y + T.border) / T.hscale;
+  const float ihs = frcp(T.hscale);
+  float fx = (x + T.border) * ihs, fy = (y + T.border) * ihs;
   int i = (int)floorf(fx), j = (int)floorf(fy);
   i = max(0, min(i, T.rows - 2)); j = max(0, min(j, T.cols - 2));
   float u = fminf(fmaxf(fx - (float)i, 0.f), 1.f), v = fminf(fmaxf(fy - (float)j, 0.f), 1.f);
@@ -100,16 +179,27 @@ LG_DEV void terrain_query(const TerrainView& T, float x, float y, float* h, V3* 
   float dhdu, dhdv;
   if (v >= u) { dhdu = h3 - h1; dhdv = h1 - h0; } else { dhdu = h2 - h0; dhdv = h3 - h2; }
   *h = h0 + u * dhdu + v * dhdv;
-  V3 g = v3(-dhdu / T.hscale, -dhdv / T.hscale, 1.f);
-  *n = (1.f / norm(g)) * g;
+  V3 g = v3(-dhdu * ihs, -dhdv * ihs, 1.f);
+  *n = __builtin_amdgcn_rsqf(dot(g, g)) * g;
 }
 
 // per-contact-slot scratch in LDS, laid out [slot][field][lane] (lane-contiguous: conflict-free ds_read_b32)
 enum { CF_N = 0, CF_T1 = 3, CF_T2 = 6, CF_R = 9, CF_JK0 = 12, CF_JK1 = 15, CF_JK2 = 18,
-       CF_ANN = 21, CF_AN1, CF_AN2, CF_A11, CF_A12, CF_A22, CF_BN, CF_L0, CF_L1, CF_L2, CF_ACTIVE, CF_FIELDS = 32 };
+       CF_ANN = 21, CF_AN1, CF_AN2, CF_A11, CF_A12, CF_A22, CF_BN, CF_L0, CF_L1, CF_L2, CF_ACTIVE,
+       CF_WB = 32 /* 3 x 6: base response per unit contact-frame impulse */, CF_ZC = 50 /* 3 x 3: Mkk^-1 J_k^T */, CF_FIELDS = 60 };
 #define CS(slot, f) cst[((slot) * CF_FIELDS + (f)) * 64 + lane]
 LG_DEV V3 lds3(const float* cst, int slot, int f, int lane) { return v3(CS(slot, f), CS(slot, f + 1), CS(slot, f + 2)); }
 LG_DEV void sts3(float* cst, int slot, int f, int lane, V3 a) { CS(slot, f) = a.x; CS(slot, f + 1) = a.y; CS(slot, f + 2) = a.z; }
+
+// Diagnostic build only (-DLG_STAMPS): lane 0 of workgroup 0 accumulates shader-clock deltas per phase.
+#ifdef LG_STAMPS
+#define STAMP(i) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                      if (stamps) { stamps[i] += _t - stamp_t; } stamp_t = _t; } while (0)
+#define STAMP_DECL unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(i)
+#define STAMP_DECL
+#endif
 
 struct PhysParams {
   float dt; V3 grav; int iters; float contact_offset, max_depen, erp, cfm, terrain_mu;
@@ -120,54 +210,89 @@ struct QuadState {           // per lane: replicated base + own leg
   float q[3], qd[3];
 };
 
-// One physics step of length P.dt for the env this quad owns.  tau[3] = this leg's joint torques.
+// Leg part of the bias forces: recursive Newton-Euler with zero generalised acceleration, moments about the base origin.
+// Outputs the three joint bias torques and the leg's total force / moment (the caller adds the base and quad-sums).
+LG_DEV void leg_bias(const LegModel& lm_, const LegKin& k, V3 pb, V3 wb, const float qd[3], V3 grav, float bk[3], V3& Fs, V3& Ns) {
+  const float lm[3] = {lm_.f(LM_MASS), lm_.f(LM_MASS + 1), lm_.f(LM_MASS + 2)};
+  V3 wp = wb, alp = v3(0, 0, 0), aOp = v3(0, 0, 0), Op = pb;
+  V3 F[3], NP[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    V3 d = k.O[j] - Op;
+    V3 aO = aOp + cross(alp, d) + cross(wp, cross(wp, d));
+    V3 al = alp + qd[j] * cross(wp, k.ax[j]);
+    V3 w = k.w[j];
+    V3 rc = k.com[j] - k.O[j];
+    V3 ac = aO + cross(al, rc) + cross(w, cross(w, rc));
+    F[j] = lm[j] * (ac - grav);
+    NP[j] = mul(k.Ic[j], al) + cross(w, mul(k.Ic[j], w)) + cross(k.com[j] - pb, F[j]);
+    wp = w; alp = al; aOp = aO; Op = k.O[j];
+  }
+  Fs = v3(0, 0, 0); Ns = v3(0, 0, 0);
+#pragma unroll
+  for (int j = 2; j >= 0; --j) {
+    Fs = Fs + F[j]; Ns = Ns + NP[j];
+    bk[j] = dot(k.ax[j], Ns - cross(k.O[j] - pb, Fs));
+  }
+}
+
+// Contact detection for slots [S0, S1): sphere centre, terrain surface under it, gap, activation; results go to the
+// LDS slot table (CF_ACTIVE, CF_N, CF_R, CF_BN, zeroed impulses).  Unrolled and branch-free so the lookups overlap.
+template <int S0, int S1>
+LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k, const M3& Rb, V3 pb,
+                           float* cst, int lane) {
+  const int ncp = lm_.i(LM_CP_COUNT);
+  const float idt_ = frcp(P.dt);
+  V3 xs[S1 - S0]; float rads[S1 - S0];
+#pragma unroll
+  for (int sl = S0; sl < S1; ++sl) {
+    const int link = lm_.i(LM_CP_LINK + sl);
+    const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
+    rads[sl - S0] = lm_.f(LM_CP_RADIUS + sl);
+    const V3 xb = pb + mul(Rb, lp), x0 = k.O[0] + mul(k.R[0], lp), x1 = k.O[1] + mul(k.R[1], lp), x2 = k.O[2] + mul(k.R[2], lp);
+    xs[sl - S0] = link < 0 ? xb : (link == 0 ? x0 : (link == 1 ? x1 : x2));
+  }
+  float hh[S1 - S0]; V3 nn[S1 - S0];
+#pragma unroll
+  for (int i = 0; i < S1 - S0; ++i) terrain_query(T, xs[i].x, xs[i].y, &hh[i], &nn[i]);
+#pragma unroll
+  for (int sl = S0; sl < S1; ++sl) {
+    const V3 n = nn[sl - S0], x = xs[sl - S0];
+    const float phi = (x.z - hh[sl - S0]) * n.z - rads[sl - S0];
+    const bool active = (sl < ncp) && (phi < P.contact_offset);
+    CS(sl, CF_ACTIVE) = active ? 1.f : 0.f;
+    CS(sl, CF_L0) = 0.f; CS(sl, CF_L1) = 0.f; CS(sl, CF_L2) = 0.f;
+    sts3(cst, sl, CF_N, lane, n);
+    sts3(cst, sl, CF_R, lane, (x - rads[sl - S0] * n) - pb);
+    CS(sl, CF_BN) = phi >= 0.f ? -phi * idt_ : fminf(-phi * P.erp * idt_, P.max_depen);
+  }
+}
+
+// One physics step of length P.dt for the env this quad owns.  tau_fn(tau[3]) delivers this leg's joint torques; it is
+// called after everything that does not depend on them (kinematics, bias, mass matrix, contact set-up).
 // fbody[5] (optional) receives the net contact force on {base (already quad-summed), link0, link1, link2, foot}.
-LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const TerrainView& T, const PhysParams& P, int l, int lane,
-                            float* cst, QuadState& s, const float tau[3], float mu_robot, float madd, V3* fbody) {
+// prep_fn(bk, Fs, Ns) returns true when helper waves have produced the leg bias and the contact detection (it then
+// holds the rendezvous and fills the three outputs); false means this wave computes them itself.
+template <class TauFn, class PrepFn>
+LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel& lm_, const TerrainView& T, const PhysParams& P,
+                            int lane, float* cst, QuadState& s, TauFn tau_fn, PrepFn prep_fn, float mu_robot, float madd, V3* fbody,
+                            unsigned long long* stamps = nullptr) {
+  STAMP_DECL
   const float dt = P.dt;
   const V3 pb = v3(s.root[0], s.root[1], s.root[2]);
   const V3 vb = v3(s.root[7], s.root[8], s.root[9]), wb = v3(s.root[10], s.root[11], s.root[12]);
   const M3 Rb = quat_to_mat(s.root + 3);
   LegKin k;
-  leg_kinematics(m, l, Rb, pb, vb, wb, s.q, s.qd, k);
+  leg_kinematics(lm_, Rb, pb, vb, wb, s.q, s.qd, k);
 
+  STAMP(1);
   // ---------------------------------------------------------------- bias forces (RNEA, zero generalised acceleration)
-  const float m0 = m->base_mass + madd, iscale = m0 / m->base_mass;
+  const float m0 = m->base_mass + madd, iscale = m0 * frcp(m->base_mass);
   const V3 rc0 = mul(Rb, ld3(m->base_com));
   S3 I0 = rotate_inertia(Rb, m->base_inertia);
   I0.xx *= iscale; I0.xy *= iscale; I0.xz *= iscale; I0.yy *= iscale; I0.yz *= iscale; I0.zz *= iscale;
-  float lm[3] = {m->link_mass[l][0], m->link_mass[l][1], m->link_mass[l][2]};
-  float bk[3]; V3 Fs = v3(0, 0, 0), Ns = v3(0, 0, 0);
-  {
-    V3 wp = wb, alp = v3(0, 0, 0), aOp = v3(0, 0, 0), Op = pb;
-    V3 F[3], NP[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      V3 d = k.O[j] - Op;
-      V3 aO = aOp + cross(alp, d) + cross(wp, cross(wp, d));
-      V3 al = alp + s.qd[j] * cross(wp, k.ax[j]);
-      V3 w = k.w[j];
-      V3 rc = k.com[j] - k.O[j];
-      V3 ac = aO + cross(al, rc) + cross(w, cross(w, rc));
-      F[j] = lm[j] * (ac - P.grav);
-      NP[j] = mul(k.Ic[j], al) + cross(w, mul(k.Ic[j], w)) + cross(k.com[j] - pb, F[j]);
-      wp = w; alp = al; aOp = aO; Op = k.O[j];
-    }
-#pragma unroll
-    for (int j = 2; j >= 0; --j) {
-      Fs = Fs + F[j]; Ns = Ns + NP[j];
-      bk[j] = dot(k.ax[j], Ns - cross(k.O[j] - pb, Fs));
-    }
-  }
-  float bb[6];
-  {
-    V3 ac = cross(wb, cross(wb, rc0));
-    V3 Fb = m0 * (ac - P.grav);
-    V3 Nb = cross(wb, mul(I0, wb)) + cross(rc0, Fb);
-    V3 Ft = Fb + quad_sum(Fs), Nt = Nb + quad_sum(Ns);
-    bb[0] = Ft.x; bb[1] = Ft.y; bb[2] = Ft.z; bb[3] = Nt.x; bb[4] = Nt.y; bb[5] = Nt.z;
-  }
-
+  float lm[3] = {lm_.f(LM_MASS), lm_.f(LM_MASS + 1), lm_.f(LM_MASS + 2)};
+  STAMP(2);
   // ---------------------------------------------------------------- joint-space inertia (CRBA) and its factorisation
   float Mkk[6];            // 00 01 02 11 12 22
   float Mbk[6][3];
@@ -215,62 +340,50 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const TerrainV
     L[LT(4, 4)] += It.yy; L[LT(5, 4)] += It.yz; L[LT(5, 5)] += It.zz;
     chol6(L);
   }
+  float Si[21];
+  spd6_inverse_from_chol(L, Si);
 
-  // ---------------------------------------------------------------- unconstrained velocity v* = v + dt M^-1 (tau - c)
-  float vB[6] = {vb.x, vb.y, vb.z, wb.x, wb.y, wb.z};
-  float vK[3] = {s.qd[0], s.qd[1], s.qd[2]};
-  {
-    float rk[3] = {tau[0] - bk[0], tau[1] - bk[1], tau[2] - bk[2]}, y[3];
-    sym3_mul(Mi, rk, y);
-    float g[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) g[a] = -bb[a] - quad_sum(Mbk[a][0] * y[0] + Mbk[a][1] * y[1] + Mbk[a][2] * y[2]);
-    solve6(L, g);
-#pragma unroll
-    for (int a = 0; a < 6; ++a) vB[a] += dt * g[a];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float yk = y[j];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) yk -= Y[j][a] * g[a];
-      vK[j] += dt * yk;
-    }
+  STAMP(3);
+  // ---------------------------------------------------------------- leg bias + contact detection: helper waves or inline
+  float bk[3]; V3 Fs, Ns;
+  if (!prep_fn(bk, Fs, Ns)) {
+    leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);
+    contact_detect<0, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
   }
-
-  // ---------------------------------------------------------------- contact detection + per-contact setup
+  float bb[6];
+  {
+    V3 ac = cross(wb, cross(wb, rc0));
+    V3 Fb = m0 * (ac - P.grav);
+    V3 Nb = cross(wb, mul(I0, wb)) + cross(rc0, Fb);
+    V3 Ft = Fb + quad_sum(Fs), Nt = Nb + quad_sum(Ns);
+    bb[0] = Ft.x; bb[1] = Ft.y; bb[2] = Ft.z; bb[3] = Nt.x; bb[4] = Nt.y; bb[5] = Nt.z;
+  }
   const float mu = 0.5f * (mu_robot + P.terrain_mu);   // PhysX default friction combine mode: average
-  const int ncp = m->cp_count[l];
+  const float idt_ = frcp(dt);
+  const int ncp = lm_.i(LM_CP_COUNT);
   unsigned slot_mask = 0;    // wave-uniform: slots with at least one active contact in this wave
+#pragma unroll
+  for (int sl = 0; sl < LG_MAX_CP; ++sl)
+    if (__ballot(CS(sl, CF_ACTIVE) != 0.f) != 0ull) slot_mask |= 1u << sl;
+#ifdef LG_STAMPS
+  if (stamps) { stamps[16] += __popc(slot_mask); stamps[17] += 1; unsigned long long am = 0; for (int sl = 0; sl < LG_MAX_CP; ++sl) am += __popcll(__ballot(CS(sl, CF_ACTIVE) != 0.f)); stamps[18] += am; }
+#endif
+  STAMP(5);
+  // pass B: per-contact solver data, only for slots some lane of the wave needs
 #pragma unroll 1
   for (int sl = 0; sl < LG_MAX_CP; ++sl) {
-    bool active = false;
-    V3 n = v3(0, 0, 1), x = pb; float phi = 0.f, rad = 0.f; int lk = -1;
-    if (sl < ncp) {
-      int link = m->cp_link[l][sl];
-      lk = link < 0 ? -1 : (link > 2 ? 2 : link);
-      V3 lp = ld3(m->cp_pos[l][sl]);
-      rad = m->cp_radius[l][sl];
-      if (lk < 0) x = pb + mul(Rb, lp);
-      else if (lk == 0) x = k.O[0] + mul(k.R[0], lp);
-      else if (lk == 1) x = k.O[1] + mul(k.R[1], lp);
-      else x = k.O[2] + mul(k.R[2], lp);
-      float h; terrain_query(T, x.x, x.y, &h, &n);
-      phi = (x.z - h) * n.z - rad;
-      active = phi < P.contact_offset;
-    }
-    CS(sl, CF_ACTIVE) = active ? 1.f : 0.f;
-    CS(sl, CF_L0) = 0.f; CS(sl, CF_L1) = 0.f; CS(sl, CF_L2) = 0.f;
-    if (__ballot(active) == 0ull) continue;
-    slot_mask |= 1u << sl;
+    if (!((slot_mask >> sl) & 1u)) continue;
+    int lk = -1;
+    if (sl < ncp) { int link = lm_.i(LM_CP_LINK + sl); lk = link < 0 ? -1 : (link > 2 ? 2 : link); }
+    const V3 n = lds3(cst, sl, CF_N, lane), r = lds3(cst, sl, CF_R, lane);
+    const V3 p = r + pb;
     // contact frame and Jacobian pieces (computed on every lane of the wave; inactive lanes carry harmless values)
-    V3 p = x - rad * n, r = p - pb;
     V3 a0 = fabsf(n.x) < 0.57735f ? v3(1, 0, 0) : v3(0, 1, 0);
-    V3 t1 = cross(a0, n); t1 = (1.f / norm(t1)) * t1;
+    V3 t1 = cross(a0, n); t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
     V3 t2 = cross(n, t1);
     V3 jk[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) jk[j] = j <= lk ? cross(k.ax[j], p - k.O[j]) : v3(0, 0, 0);
-    float bn = phi >= 0.f ? -phi / dt : fminf(-phi * P.erp / dt, P.max_depen);
     // A = J M^-1 J^T in the contact frame (rows n, t1, t2)
     V3 dirs[3] = {n, t1, t2};
     float Wb[3][6], Wk[3][3];   // M^-1 J^T columns: base part and own-leg part
@@ -283,15 +396,16 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const TerrainV
       float g[6] = {d.x, d.y, d.z, rd.x, rd.y, rd.z};
 #pragma unroll
       for (int a = 0; a < 6; ++a) g[a] -= Mbk[a][0] * z[0] + Mbk[a][1] * z[1] + Mbk[a][2] * z[2];
-      solve6(L, g);
+      symv6(Si, g, Wb[c]);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) Wb[c][a] = g[a];
+      for (int a = 0; a < 6; ++a) CS(sl, CF_WB + 6 * c + a) = Wb[c][a];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         float w = z[j];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) w -= Y[j][a] * g[a];
+        for (int a = 0; a < 6; ++a) w -= Y[j][a] * Wb[c][a];
         Wk[c][j] = w;
+        CS(sl, CF_ZC + 3 * c + j) = z[j];
       }
     }
     float A[3][3];
@@ -308,11 +422,35 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const TerrainV
         A[b][c] = sacc;
       }
     }
-    sts3(cst, sl, CF_N, lane, n); sts3(cst, sl, CF_T1, lane, t1); sts3(cst, sl, CF_T2, lane, t2); sts3(cst, sl, CF_R, lane, r);
+    sts3(cst, sl, CF_T1, lane, t1); sts3(cst, sl, CF_T2, lane, t2);
     sts3(cst, sl, CF_JK0, lane, jk[0]); sts3(cst, sl, CF_JK1, lane, jk[1]); sts3(cst, sl, CF_JK2, lane, jk[2]);
     CS(sl, CF_ANN) = A[0][0] + P.cfm; CS(sl, CF_AN1) = A[1][0]; CS(sl, CF_AN2) = A[2][0];
     CS(sl, CF_A11) = A[1][1] + P.cfm; CS(sl, CF_A12) = A[1][2]; CS(sl, CF_A22) = A[2][2] + P.cfm;
-    CS(sl, CF_BN) = bn;
+  }
+
+  STAMP(6);
+  // ---------------------------------------------------------------- unconstrained velocity v* = v + dt M^-1 (tau - c)
+  float tau[3];
+  tau_fn(tau);            // multi-wave builds: rendezvous with the actuator waves happens here
+  STAMP(4);
+  float vB[6] = {vb.x, vb.y, vb.z, wb.x, wb.y, wb.z};
+  float vK[3] = {s.qd[0], s.qd[1], s.qd[2]};
+  {
+    float rk[3] = {tau[0] - bk[0], tau[1] - bk[1], tau[2] - bk[2]}, y[3];
+    sym3_mul(Mi, rk, y);
+    float g[6], g0[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) g0[a] = -bb[a] - quad_sum(Mbk[a][0] * y[0] + Mbk[a][1] * y[1] + Mbk[a][2] * y[2]);
+    symv6(Si, g0, g);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) vB[a] += dt * g[a];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float yk = y[j];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) yk -= Y[j][a] * g[a];
+      vK[j] += dt * yk;
+    }
   }
 
   // ---------------------------------------------------------------- projected Gauss-Seidel
@@ -332,30 +470,26 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const TerrainV
         float l0 = CS(sl, CF_L0), l1 = CS(sl, CF_L1), l2 = CS(sl, CF_L2);
         float Ann = CS(sl, CF_ANN), An1 = CS(sl, CF_AN1), An2 = CS(sl, CF_AN2);
         float A11 = CS(sl, CF_A11), A12 = CS(sl, CF_A12), A22 = CS(sl, CF_A22);
-        float ln = fmaxf(l0 - (u0 - CS(sl, CF_BN)) / Ann, 0.f);
+        float ln = fmaxf(l0 - (u0 - CS(sl, CF_BN)) * frcp(Ann), 0.f);
         float dn = ln - l0;
         float w1 = u1 + An1 * dn, w2 = u2 + An2 * dn;
-        float det = A11 * A22 - A12 * A12;
-        float n1 = l1 - (A22 * w1 - A12 * w2) / det;
-        float n2 = l2 - (-A12 * w1 + A11 * w2) / det;
-        float lim = mu * ln, mag = sqrtf(n1 * n1 + n2 * n2);
-        if (mag > lim) { float sc = mag > 0.f ? lim / mag : 0.f; n1 *= sc; n2 *= sc; }
+        float idet = frcp(A11 * A22 - A12 * A12);
+        float n1 = l1 - (A22 * w1 - A12 * w2) * idet;
+        float n2 = l2 - (-A12 * w1 + A11 * w2) * idet;
+        float lim = mu * ln, m2 = n1 * n1 + n2 * n2;
+        if (m2 > lim * lim) { float sc = m2 > 0.f ? lim * __builtin_amdgcn_rsqf(m2) : 0.f; n1 *= sc; n2 *= sc; }
         float d0 = active ? dn : 0.f, d1 = active ? n1 - l1 : 0.f, d2 = active ? n2 - l2 : 0.f;
         if (active) { CS(sl, CF_L0) = ln; CS(sl, CF_L1) = n1; CS(sl, CF_L2) = n2; }
-        // apply: world impulse f at the contact point
-        V3 f = d0 * n + d1 * t1 + d2 * t2;
-        float jkf[3] = {dot(jk0, f), dot(jk1, f), dot(jk2, f)}, z[3];
-        sym3_mul(Mi, jkf, z);
-        V3 rf = cross(r, f);
-        float g[6] = {f.x, f.y, f.z, rf.x, rf.y, rf.z};
+        // apply: base response of this lane's impulse from the stored M^-1 J^T columns, summed over the quad
+        float g[6];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) g[a] = quad_sum(g[a] - (Mbk[a][0] * z[0] + Mbk[a][1] * z[1] + Mbk[a][2] * z[2]));
-        solve6(L, g);
+        for (int a = 0; a < 6; ++a)
+          g[a] = quad_sum(d0 * CS(sl, CF_WB + a) + d1 * CS(sl, CF_WB + 6 + a) + d2 * CS(sl, CF_WB + 12 + a));
 #pragma unroll
         for (int a = 0; a < 6; ++a) vB[a] += g[a];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          float w = z[j];
+          float w = d0 * CS(sl, CF_ZC + j) + d1 * CS(sl, CF_ZC + 3 + j) + d2 * CS(sl, CF_ZC + 6 + j);
 #pragma unroll
           for (int a = 0; a < 6; ++a) w -= Y[j][a] * g[a];
           vK[j] += w;
@@ -364,23 +498,24 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const TerrainV
     }
   }
 
+  STAMP(7);
   // ---------------------------------------------------------------- joint speed limit (URDF <limit velocity>)
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    float lim = m->dof_vel_limit[3 * l + j];
+    float lim = lm_.f(LM_VEL_LIMIT + j);
     if (lim > 0.f) vK[j] = fminf(fmaxf(vK[j], -lim), lim);
   }
 
   // ---------------------------------------------------------------- net contact force per body (world frame)
   if (fbody) {
     V3 fb[5] = {v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0)};
-    const float idt = 1.f / dt;
+    const float idt = idt_;
 #pragma unroll 1
     for (int sl = 0; sl < LG_MAX_CP; ++sl) {
       if (!((slot_mask >> sl) & 1u)) continue;
       if (CS(sl, CF_ACTIVE) == 0.f) continue;
       V3 f = idt * (CS(sl, CF_L0) * lds3(cst, sl, CF_N, lane) + CS(sl, CF_L1) * lds3(cst, sl, CF_T1, lane) + CS(sl, CF_L2) * lds3(cst, sl, CF_T2, lane));
-      int link = m->cp_link[l][sl];
+      int link = lm_.i(LM_CP_LINK + sl);
       int slotb = link < 0 ? 0 : (link > 3 ? 4 : link + 1);
 #pragma unroll
       for (int b = 0; b < 5; ++b) if (b == slotb) fb[b] = fb[b] + f;
@@ -396,16 +531,17 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const TerrainV
   {
     V3 w = v3(vB[3], vB[4], vB[5]); float wn = norm(w), ang = wn * dt;
     float sh, ch; sincosf(0.5f * ang, &sh, &ch);
-    sh = wn > 1e-9f ? sh / wn : 0.5f * dt;
+    sh = wn > 1e-9f ? sh * frcp(wn) : 0.5f * dt;
     float dq0 = sh * w.x, dq1 = sh * w.y, dq2 = sh * w.z, dq3 = ch;
     float* qq = s.root + 3;
     float x = dq3 * qq[0] + dq0 * qq[3] + dq1 * qq[2] - dq2 * qq[1];
     float y = dq3 * qq[1] - dq0 * qq[2] + dq1 * qq[3] + dq2 * qq[0];
     float z = dq3 * qq[2] + dq0 * qq[1] - dq1 * qq[0] + dq2 * qq[3];
     float w4 = dq3 * qq[3] - dq0 * qq[0] - dq1 * qq[1] - dq2 * qq[2];
-    float inv = 1.f / sqrtf(x * x + y * y + z * z + w4 * w4);
+    float inv = __builtin_amdgcn_rsqf(x * x + y * y + z * z + w4 * w4);
     qq[0] = x * inv; qq[1] = y * inv; qq[2] = z * inv; qq[3] = w4 * inv;
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) { s.qd[j] = vK[j]; s.q[j] += dt * vK[j]; }
+  STAMP(8);
 }

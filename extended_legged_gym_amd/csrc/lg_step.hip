@@ -12,13 +12,15 @@
 //   finalize_kernel  one workgroup: fixed-order reduction of the per-workgroup episode statistics (deterministic).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
 
 #include "lg_physics.h"
 
-#define EPB 16          // envs per workgroup in post_kernel / per wave in physics_kernel
+#define EPB 16          // envs per workgroup (= per main wave) in physics_kernel
+#define EPBP 4          // envs per 256-thread workgroup in post_kernel: short per-phase loops, 4 workgroups per CU at N = 4096
 #define MAX_P 192       // height-scan points per env held in LDS
 #define PART_STRIDE (LG_MAX_REWARD_TERMS + 3)
 
@@ -44,6 +46,7 @@ struct DevCtx {
   const float *noise_vec, *height_points;
   float* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
   int nblocks_post;
+  unsigned long long* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
 };
 
 struct TensorInfo { size_t off; int64_t shape[4]; int ndim; int dtype; };
@@ -55,6 +58,7 @@ struct lg_ctx {
   void* aux = nullptr; // noise_vec, height_points, partials
   TensorInfo t[LG_T_COUNT];
   int device = 0;
+  int split = 1;       // fused step: run the LSTM actuators on three extra waves (LG_SPLIT=0 disables, diagnostic)
   std::string err;
   // optional per-kernel timing (lg_profile_begin / lg_profile_end)
   std::vector<hipEvent_t> ev; int prof_max = 0, prof_stride = 1, prof_n = 0; long prof_calls = 0;
@@ -71,40 +75,123 @@ LG_DEV float uniform_draw(const DevCtx* __restrict__ C, int e, int slot, int64_t
   return u01(x);
 }
 LG_DEV float rand_float(float lo, float hi, float u) { return (hi - lo) * u + lo; }
+// the four uniforms of slot group `grp` (slots 4*grp .. 4*grp+3) with ONE Philox call
+LG_DEV void uniform_draw4(const DevCtx* __restrict__ C, int e, int grp, int64_t step, uint32_t stream, float u[4]) {
+  if (C->cfg.rng_mode == LG_RNG_INJECT) {
+    const float* p = C->rand_inject + (size_t)e * (LG_RS_NOISE + C->cfg.num_obs) + 4 * grp;
+    u[0] = p[0]; u[1] = p[1]; u[2] = p[2]; u[3] = p[3];
+    return;
+  }
+  uint32_t o[4];
+  philox4((uint32_t)e, (uint32_t)step, (uint32_t)grp, stream, (uint32_t)C->cfg.seed, (uint32_t)(C->cfg.seed >> 32), o);
+  u[0] = u01(o[0]); u[1] = u01(o[1]); u[2] = u01(o[2]); u[3] = u01(o[3]);
+}
 
 // ============================================================================================ device: actuators
-LG_DEV float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
-LG_DEV float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+LG_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+LG_DEV float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
-// one LSTM-actuator evaluation for one joint (anymal.py:93-105); h*/c* are this joint's 8-float states
-LG_DEV float lstm_actuator(const float* __restrict__ W, float x0, float x1, float* h0, float* c0, float* h1, float* c1,
-                           float out_scale) {
+struct LegActuator { float h[2][3][8], c[2][3][8]; };   // LSTM state of this lane's three joints
+
+// The ANYdrive LSTM actuator for this lane's three joints at once (anymal.py:93-105): 2-layer LSTM(2->8->8) + Linear(8->1).
+// W = the 969 weights staged in LDS (every lane reads the same address: broadcast); each weight row is read once and
+// used for all three joints.  Torch gate order i, f, g, o.
+LG_DEV void lstm_actuator3(const float* __restrict__ W, const float x0[3], const float x1[3], LegActuator& A, float out_scale,
+                           float tau[3]) {
   const float *wih0 = W, *whh0 = W + 64, *bih0 = W + 320, *bhh0 = W + 352, *wih1 = W + 384, *whh1 = W + 640,
               *bih1 = W + 896, *bhh1 = W + 928, *lw = W + 960, *lb = W + 968;
-  float g[32], hn0[8], hn1[8];
+  float hn0[3][8];
 #pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    float s = bih0[r] + bhh0[r] + wih0[2 * r] * x0 + wih0[2 * r + 1] * x1;
+  for (int k = 0; k < 8; ++k) {
+    float gt[4][3];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += whh0[8 * r + k] * h0[k];
-    g[r] = s;
+    for (int gi = 0; gi < 4; ++gi) {
+      const int r = 8 * gi + k;
+      const float b = bih0[r] + bhh0[r], w0 = wih0[2 * r], w1 = wih0[2 * r + 1];
+      float wh[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) wh[kk] = whh0[8 * r + kk];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float s = b + w0 * x0[j] + w1 * x1[j];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) s += wh[kk] * A.h[0][j][kk];
+        gt[gi][j] = s;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float cn = fast_sigmoid(gt[1][j]) * A.c[0][j][k] + fast_sigmoid(gt[0][j]) * fast_tanh(gt[2][j]);
+      A.c[0][j][k] = cn; hn0[j][k] = fast_sigmoid(gt[3][j]) * fast_tanh(cn);
+    }
+  }
+  float hn1[3][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float gt[4][3];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const int r = 8 * gi + k;
+      const float b = bih1[r] + bhh1[r];
+      float wi[8], wh[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) { wi[kk] = wih1[8 * r + kk]; wh[kk] = whh1[8 * r + kk]; }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float s = b;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) s += wi[kk] * hn0[j][kk] + wh[kk] * A.h[1][j][kk];
+        gt[gi][j] = s;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float cn = fast_sigmoid(gt[1][j]) * A.c[1][j][k] + fast_sigmoid(gt[0][j]) * fast_tanh(gt[2][j]);
+      A.c[1][j][k] = cn; hn1[j][k] = fast_sigmoid(gt[3][j]) * fast_tanh(cn);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float o = lb[0];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { o += lw[k] * hn1[j][k]; A.h[0][j][k] = hn0[j][k]; A.h[1][j][k] = hn1[j][k]; }
+    tau[j] = out_scale * o;     // no torque clip on this path (anymal.py:101-102)
+  }
+}
+
+// One joint per lane (actuator waves of the 4-wave step): same arithmetic as lstm_actuator3, state h0,c0,h1,c1 of 8 each.
+LG_DEV float lstm_actuator1(const float* __restrict__ W, float x0, float x1, float* h0, float* c0, float* h1, float* c1,
+                            float out_scale) {
+  const float *wih0 = W, *whh0 = W + 64, *bih0 = W + 320, *bhh0 = W + 352, *wih1 = W + 384, *whh1 = W + 640,
+              *bih1 = W + 896, *bhh1 = W + 928, *lw = W + 960, *lb = W + 968;
+  float hn0[8], hn1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float gt[4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const int r = 8 * gi + k;
+      float s = (bih0[r] + bhh0[r]) + wih0[2 * r] * x0 + wih0[2 * r + 1] * x1;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) s += whh0[8 * r + kk] * h0[kk];
+      gt[gi] = s;
+    }
+    float cn = fast_sigmoid(gt[1]) * c0[k] + fast_sigmoid(gt[0]) * fast_tanh(gt[2]);
+    c0[k] = cn; hn0[k] = fast_sigmoid(gt[3]) * fast_tanh(cn);
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float cn = fast_sigmoid(g[8 + k]) * c0[k] + fast_sigmoid(g[k]) * fast_tanh(g[16 + k]);
-    c0[k] = cn; hn0[k] = fast_sigmoid(g[24 + k]) * fast_tanh(cn);
-  }
+    float gt[4];
 #pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    float s = bih1[r] + bhh1[r];
+    for (int gi = 0; gi < 4; ++gi) {
+      const int r = 8 * gi + k;
+      float s = bih1[r] + bhh1[r];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += wih1[8 * r + k] * hn0[k] + whh1[8 * r + k] * h1[k];
-    g[r] = s;
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float cn = fast_sigmoid(g[8 + k]) * c1[k] + fast_sigmoid(g[k]) * fast_tanh(g[16 + k]);
-    c1[k] = cn; hn1[k] = fast_sigmoid(g[24 + k]) * fast_tanh(cn);
+      for (int kk = 0; kk < 8; ++kk) s += wih1[8 * r + kk] * hn0[kk] + whh1[8 * r + kk] * h1[kk];
+      gt[gi] = s;
+    }
+    float cn = fast_sigmoid(gt[1]) * c1[k] + fast_sigmoid(gt[0]) * fast_tanh(gt[2]);
+    c1[k] = cn; hn1[k] = fast_sigmoid(gt[3]) * fast_tanh(cn);
   }
   float o = lb[0];
 #pragma unroll
@@ -112,52 +199,59 @@ LG_DEV float lstm_actuator(const float* __restrict__ W, float x0, float x1, floa
   return out_scale * o;
 }
 
-struct LegActuator { float h[2][3][8], c[2][3][8]; };   // LSTM state of this lane's three joints
-
 LG_DEV void load_lstm(const DevCtx* __restrict__ C, int e, int l, LegActuator& A) {
   const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + 3 * l;
 #pragma unroll
   for (int lay = 0; lay < 2; ++lay)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        A.h[lay][j][k] = C->sea_h[(lay * N12 + row + j) * 8 + k];
-        A.c[lay][j][k] = C->sea_c[(lay * N12 + row + j) * 8 + k];
-      }
+    for (int j = 0; j < 3; ++j) {
+      const float4* ph = (const float4*)(C->sea_h + (lay * N12 + row + j) * 8);
+      const float4* pc = (const float4*)(C->sea_c + (lay * N12 + row + j) * 8);
+      float4 h0 = ph[0], h1 = ph[1], c0 = pc[0], c1 = pc[1];
+      A.h[lay][j][0] = h0.x; A.h[lay][j][1] = h0.y; A.h[lay][j][2] = h0.z; A.h[lay][j][3] = h0.w;
+      A.h[lay][j][4] = h1.x; A.h[lay][j][5] = h1.y; A.h[lay][j][6] = h1.z; A.h[lay][j][7] = h1.w;
+      A.c[lay][j][0] = c0.x; A.c[lay][j][1] = c0.y; A.c[lay][j][2] = c0.z; A.c[lay][j][3] = c0.w;
+      A.c[lay][j][4] = c1.x; A.c[lay][j][5] = c1.y; A.c[lay][j][6] = c1.z; A.c[lay][j][7] = c1.w;
+    }
 }
 LG_DEV void store_lstm(const DevCtx* __restrict__ C, int e, int l, const LegActuator& A) {
   const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + 3 * l;
 #pragma unroll
   for (int lay = 0; lay < 2; ++lay)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        C->sea_h[(lay * N12 + row + j) * 8 + k] = A.h[lay][j][k];
-        C->sea_c[(lay * N12 + row + j) * 8 + k] = A.c[lay][j][k];
-      }
+    for (int j = 0; j < 3; ++j) {
+      float4* ph = (float4*)(C->sea_h + (lay * N12 + row + j) * 8);
+      float4* pc = (float4*)(C->sea_c + (lay * N12 + row + j) * 8);
+      ph[0] = make_float4(A.h[lay][j][0], A.h[lay][j][1], A.h[lay][j][2], A.h[lay][j][3]);
+      ph[1] = make_float4(A.h[lay][j][4], A.h[lay][j][5], A.h[lay][j][6], A.h[lay][j][7]);
+      pc[0] = make_float4(A.c[lay][j][0], A.c[lay][j][1], A.c[lay][j][2], A.c[lay][j][3]);
+      pc[1] = make_float4(A.c[lay][j][4], A.c[lay][j][5], A.c[lay][j][6], A.c[lay][j][7]);
+    }
 }
 
 // torques of this lane's three joints (LR:425-448 / anymal.py:93-105)
-LG_DEV void leg_torques(const DevCtx* __restrict__ C, int l, const float act[3], const float q[3], const float qd[3],
-                        const float last_qd[3], LegActuator& A, float tau[3]) {
+LG_DEV void leg_torques(const DevCtx* __restrict__ C, const LegModel& lm_, const float* __restrict__ Wlds, const float act[3],
+                        const float q[3], const float qd[3], const float last_qd[3], LegActuator& A, float tau[3]) {
   const lg_config& g = C->cfg;
+  if (g.control_type == LG_CTRL_ACTUATOR_NET) {
+    float x0[3], x1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      x0[j] = (act[j] * g.action_scale + lm_.f(LM_DEFAULT_POS + j) - q[j]) * g.actuator_in_scale[0];
+      x1[j] = qd[j] * g.actuator_in_scale[1];
+    }
+    lstm_actuator3(Wlds, x0, x1, A, g.actuator_out_scale, tau);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int d = 3 * l + j;
-    float a = act[j] * g.action_scale;
-    if (g.control_type == LG_CTRL_ACTUATOR_NET) {
-      float x0 = (a + g.default_dof_pos[d] - q[j]) * g.actuator_in_scale[0], x1 = qd[j] * g.actuator_in_scale[1];
-      tau[j] = lstm_actuator(g.actuator_net, x0, x1, A.h[0][j], A.c[0][j], A.h[1][j], A.c[1][j], g.actuator_out_scale);
-    } else {
-      float t;
-      if (g.control_type == LG_CTRL_P) t = g.p_gains[d] * (a + g.default_dof_pos[d] - q[j]) - g.d_gains[d] * qd[j];
-      else if (g.control_type == LG_CTRL_V) t = g.p_gains[d] * (a - qd[j]) - g.d_gains[d] * (qd[j] - last_qd[j]) / g.sim_dt;
-      else t = a;
-      float lim = C->model.torque_limit[d];
-      tau[j] = fminf(fmaxf(t, -lim), lim);
-    }
+    const float a = act[j] * g.action_scale, kp = lm_.f(LM_PGAIN + j), kd = lm_.f(LM_DGAIN + j);
+    float t;
+    if (g.control_type == LG_CTRL_P) t = kp * (a + lm_.f(LM_DEFAULT_POS + j) - q[j]) - kd * qd[j];
+    else if (g.control_type == LG_CTRL_V) t = kp * (a - qd[j]) - kd * (qd[j] - last_qd[j]) / g.sim_dt;
+    else t = a;
+    const float lim = lm_.f(LM_TORQUE_LIMIT + j);
+    tau[j] = fminf(fmaxf(t, -lim), lim);
   }
 }
 
@@ -165,15 +259,98 @@ LG_DEV void leg_torques(const DevCtx* __restrict__ C, int l, const float act[3],
 // MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
 // MODE 2: lg_compute_torques only.
 template <int MODE>
-__global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub) {
+__global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, int nact) {
+  // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
+  // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
+  // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
   __shared__ float cst[LG_MAX_CP * CF_FIELDS * 64];
-  const int lane = threadIdx.x;
+  __shared__ float lmod[LM_FIELDS * 4];
+  __shared__ __attribute__((aligned(16))) float wlstm[LG_LSTM_NPARAM + 3];
+  __shared__ float xq[3][64], xqd[3][64], xtau[3][64], xroot[13][64], xbias[9][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int e = blockIdx.x * EPB + (lane >> 2);
   const int l = lane & 3;
   const bool valid = e < C->N;
   if (!valid) e = C->N - 1;          // whole quads are (in)valid together; invalid quads compute on a copy and store nothing
   const lg_robot_model* __restrict__ m = &C->model;
   const lg_config& g = C->cfg;
+  const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
+  if (wv == 0) fill_leg_model(lmod, m, &C->cfg, lane);
+  if (MODE != 1 && net)
+    for (int i = threadIdx.x; i < LG_LSTM_NPARAM; i += blockDim.x) wlstm[i] = g.actuator_net[i];
+  __syncthreads();
+  const LegModel lm_{lmod, l};
+
+  if (MODE == 0 && wv > 0) {
+    // ---------------------------------------------------------------- actuator wave: joint j of leg l of env e
+    const int j = wv - 1, d = 3 * l + j;
+    float a = actions_in[(size_t)e * 12 + d];
+    a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);
+    const float tgt = a * g.action_scale + lm_.f(LM_DEFAULT_POS + j);
+    const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + d;
+    float h0[8], c0[8], h1[8], c1[8];
+    {
+      const float4* p = (const float4*)(C->sea_h + row * 8); float4 u = p[0], v = p[1];
+      h0[0] = u.x; h0[1] = u.y; h0[2] = u.z; h0[3] = u.w; h0[4] = v.x; h0[5] = v.y; h0[6] = v.z; h0[7] = v.w;
+      p = (const float4*)(C->sea_c + row * 8); u = p[0]; v = p[1];
+      c0[0] = u.x; c0[1] = u.y; c0[2] = u.z; c0[3] = u.w; c0[4] = v.x; c0[5] = v.y; c0[6] = v.z; c0[7] = v.w;
+      p = (const float4*)(C->sea_h + (N12 + row) * 8); u = p[0]; v = p[1];
+      h1[0] = u.x; h1[1] = u.y; h1[2] = u.z; h1[3] = u.w; h1[4] = v.x; h1[5] = v.y; h1[6] = v.z; h1[7] = v.w;
+      p = (const float4*)(C->sea_c + (N12 + row) * 8); u = p[0]; v = p[1];
+      c1[0] = u.x; c1[1] = u.y; c1[2] = u.z; c1[3] = u.w; c1[4] = v.x; c1[5] = v.y; c1[6] = v.z; c1[7] = v.w;
+    }
+    PhysParams P;
+    P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
+    P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm;
+    P.terrain_mu = C->terrain_mu;
+    const TerrainView T = C->ter;
+#pragma unroll 1
+    for (int sub = 0; sub < nsub; ++sub) {
+      __syncthreads();                                   // (A) main wave has published root, q, qd of this substep
+      // torque-independent share of the dynamics: this leg's kinematics, then the leg bias (wave 1) or the contact
+      // detection of half of the slots (waves 2, 3), straight into the LDS the main wave reads after barrier (A2)
+      {
+        float r13[13], qq[3], qdd[3];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) r13[i] = xroot[i][lane];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { qq[i] = xq[i][lane]; qdd[i] = xqd[i][lane]; }
+        const M3 Rb = quat_to_mat(r13 + 3);
+        const V3 pb = v3(r13[0], r13[1], r13[2]), vb = v3(r13[7], r13[8], r13[9]), wb = v3(r13[10], r13[11], r13[12]);
+        LegKin k;
+        leg_kinematics(lm_, Rb, pb, vb, wb, qq, qdd, k);
+        if (wv == 1) {
+          float bk[3]; V3 Fs, Ns;
+          leg_bias(lm_, k, pb, wb, qdd, P.grav, bk, Fs, Ns);
+          xbias[0][lane] = bk[0]; xbias[1][lane] = bk[1]; xbias[2][lane] = bk[2];
+          xbias[3][lane] = Fs.x; xbias[4][lane] = Fs.y; xbias[5][lane] = Fs.z;
+          xbias[6][lane] = Ns.x; xbias[7][lane] = Ns.y; xbias[8][lane] = Ns.z;
+        } else if (wv == 2) {
+          contact_detect<0, LG_MAX_CP / 2>(lm_, T, P, k, Rb, pb, cst, lane);
+        } else {
+          contact_detect<LG_MAX_CP / 2, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
+        }
+      }
+      __syncthreads();                                   // (A2) bias + contact detection visible to the main wave
+      const float x0 = (tgt - xq[j][lane]) * g.actuator_in_scale[0], x1 = xqd[j][lane] * g.actuator_in_scale[1];
+      xtau[j][lane] = lstm_actuator1(wlstm, x0, x1, h0, c0, h1, c1, g.actuator_out_scale);
+      __syncthreads();                                   // (B) torques ready
+    }
+    if (valid) {
+      float4* p = (float4*)(C->sea_h + row * 8);
+      p[0] = make_float4(h0[0], h0[1], h0[2], h0[3]); p[1] = make_float4(h0[4], h0[5], h0[6], h0[7]);
+      p = (float4*)(C->sea_c + row * 8);
+      p[0] = make_float4(c0[0], c0[1], c0[2], c0[3]); p[1] = make_float4(c0[4], c0[5], c0[6], c0[7]);
+      p = (float4*)(C->sea_h + (N12 + row) * 8);
+      p[0] = make_float4(h1[0], h1[1], h1[2], h1[3]); p[1] = make_float4(h1[4], h1[5], h1[6], h1[7]);
+      p = (float4*)(C->sea_c + (N12 + row) * 8);
+      p[0] = make_float4(c1[0], c1[1], c1[2], c1[3]); p[1] = make_float4(c1[4], c1[5], c1[6], c1[7]);
+      C->actions[(size_t)e * 12 + d] = a;
+      C->torques[(size_t)e * 12 + d] = xtau[j][lane];
+    }
+    return;
+  }
+  const bool split = MODE == 0 && nact == 3;             // actuator waves present
 
   QuadState s;
 #pragma unroll
@@ -186,7 +363,7 @@ __global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ 
     last_qd[j] = C->last_dof_vel[(size_t)e * 12 + 3 * l + j];
   }
   float act[3] = {0, 0, 0};
-  if (MODE != 1) {
+  if (MODE != 1 && !split) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       float a = actions_in ? actions_in[(size_t)e * 12 + 3 * l + j] : C->actions[(size_t)e * 12 + 3 * l + j];
@@ -196,12 +373,11 @@ __global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ 
     }
   }
   LegActuator A;
-  const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
-  if (MODE != 1 && net) load_lstm(C, e, l, A);
+  if (MODE != 1 && net && !split) load_lstm(C, e, l, A);
 
-  float tau[3];
+  float tau[3] = {0, 0, 0};
   if (MODE == 2) {
-    leg_torques(C, l, act, s.q, s.qd, last_qd, A, tau);
+    leg_torques(C, lm_, wlstm, act, s.q, s.qd, last_qd, A, tau);
     if (valid) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) C->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
@@ -218,10 +394,24 @@ __global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ 
   const float mu_robot = C->friction[e], madd = C->mass_added[e];
   V3 fbody[5];
   bool fault = false;
+#ifdef LG_STAMPS
+  unsigned long long* stamps = (blockIdx.x == 0 && lane == 0) ? C->stamps : nullptr;
+  unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#else
+  unsigned long long* stamps = nullptr;
+#endif
 #pragma unroll 1
   for (int sub = 0; sub < nsub; ++sub) {
-    if (MODE == 0) leg_torques(C, l, act, s.q, s.qd, last_qd, A, tau);
-    else {
+    STAMP(15);
+    if (split) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { xq[j][lane] = s.q[j]; xqd[j][lane] = s.qd[j]; }
+#pragma unroll
+      for (int i = 0; i < 13; ++i) xroot[i][lane] = s.root[i];
+      __syncthreads();                                   // (A) root, q, qd of this substep visible to the helper waves
+    } else if (MODE == 0) {
+      leg_torques(C, lm_, wlstm, act, s.q, s.qd, last_qd, A, tau);
+    } else {
 #pragma unroll
       for (int j = 0; j < 3; ++j) tau[j] = C->torques[(size_t)e * 12 + 3 * l + j];
     }
@@ -230,7 +420,27 @@ __global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ 
     for (int i = 0; i < 7; ++i) root0[i] = s.root[i];
 #pragma unroll
     for (int j = 0; j < 3; ++j) q0[j] = s.q[j];
-    physics_substep(m, T, P, l, lane, cst, s, tau, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr);
+    STAMP(0);
+    auto tau_fn = [&](float* t) {
+      if (split) {
+        __syncthreads();                                 // (B) actuator waves have written this substep's torques
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tau[j] = xtau[j][lane];
+      }
+      t[0] = tau[0]; t[1] = tau[1]; t[2] = tau[2];
+    };
+    auto prep_fn = [&](float* bk, V3& Fs, V3& Ns) -> bool {
+      if (!split) return false;
+      __syncthreads();                                   // (A2) helper waves have written the leg bias and the slot table
+      bk[0] = xbias[0][lane]; bk[1] = xbias[1][lane]; bk[2] = xbias[2][lane];
+      Fs = v3(xbias[3][lane], xbias[4][lane], xbias[5][lane]);
+      Ns = v3(xbias[6][lane], xbias[7][lane], xbias[8][lane]);
+      return true;
+    };
+    physics_substep(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr, stamps);
+#ifdef LG_STAMPS
+    stamp_t = __builtin_amdgcn_s_memtime();
+#endif
     // fault guard: a non-finite state is rolled back to the pre-step pose at rest and flagged for termination
     float acc = 0.f, acc0 = 0.f;
 #pragma unroll
@@ -247,11 +457,12 @@ __global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ 
       for (int i = 0; i < 13; ++i)
         s.root[i] = ok0 ? (i < 7 ? root0[i] : 0.f) : g.base_init_state[i] + (i < 3 ? C->origins[(size_t)e * 3 + i] : 0.f);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { s.q[j] = ok0 ? q0[j] : g.default_dof_pos[3 * l + j]; s.qd[j] = 0.f; }
+      for (int j = 0; j < 3; ++j) { s.q[j] = ok0 ? q0[j] : lm_.f(LM_DEFAULT_POS + j); s.qd[j] = 0.f; }
 #pragma unroll
       for (int b = 0; b < 5; ++b) fbody[b] = v3(0, 0, 0);
     }
   }
+  STAMP(9);
   if (!valid) return;
   if (fault && l == 0) C->reset_buf[e] = 2;
 
@@ -264,9 +475,9 @@ __global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ 
   for (int j = 0; j < 3; ++j) {
     C->dof[((size_t)e * 12 + 3 * l + j) * 2] = s.q[j];
     C->dof[((size_t)e * 12 + 3 * l + j) * 2 + 1] = s.qd[j];
-    if (MODE == 0) C->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
+    if (MODE == 0 && !split) C->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
   }
-  if (MODE == 0 && net) store_lstm(C, e, l, A);
+  if (MODE == 0 && net && !split) store_lstm(C, e, l, A);
   const int per_leg = C->per_leg, B = C->B;
   {
     float* cf = C->cforce + (size_t)e * B * 3;
@@ -284,7 +495,7 @@ __global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ 
     const M3 Rb = quat_to_mat(s.root + 3);
     const V3 pb = v3(s.root[0], s.root[1], s.root[2]), vb = v3(s.root[7], s.root[8], s.root[9]), wb = v3(s.root[10], s.root[11], s.root[12]);
     LegKin k;
-    leg_kinematics(m, l, Rb, pb, vb, wb, s.q, s.qd, k);
+    leg_kinematics(lm_, Rb, pb, vb, wb, s.q, s.qd, k);
     float* rb = C->rigid + (size_t)e * B * 13;
     if (l == 0) {
 #pragma unroll
@@ -299,13 +510,17 @@ __global__ __launch_bounds__(64) void physics_kernel(const DevCtx* __restrict__ 
     }
     if (per_leg == 4) {
       float* o = rb + (size_t)(1 + per_leg * l + 3) * 13;
-      V3 r = mul(k.R[2], ld3(m->foot_pos[l]));
+      V3 r = mul(k.R[2], lm_.v(LM_FOOT_POS));
       V3 p = k.O[2] + r, v = k.vO[2] + cross(k.w[2], r);
-      float qq[4]; mat_to_quat(mul(k.R[2], ldm3(m->foot_rot[l])), qq);
+      M3 fr;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) fr.m[i] = lm_.f(LM_FOOT_ROT + i);
+      float qq[4]; mat_to_quat(mul(k.R[2], fr), qq);
       o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
       o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = k.w[2].x; o[11] = k.w[2].y; o[12] = k.w[2].z;
     }
   }
+  STAMP(10);
 }
 
 // ============================================================================================ post-physics helpers
@@ -317,11 +532,30 @@ LG_DEV float wrap_to_pi(float a) {   // math_utils.py:55-58
   return r;
 }
 
-LG_DEV void resample_commands(const DevCtx* __restrict__ C, int e, int slot0, int64_t step, uint32_t stream) {  // LR:405-423
-  const lg_config& g = C->cfg; float* cmd = C->commands + (size_t)e * 4;
-  float c0 = rand_float(g.cmd_lin_vel_x[0], g.cmd_lin_vel_x[1], uniform_draw(C, e, slot0, step, stream));
-  float c1 = rand_float(g.cmd_lin_vel_y[0], g.cmd_lin_vel_y[1], uniform_draw(C, e, slot0 + 1, step, stream));
-  float u2 = uniform_draw(C, e, slot0 + 2, step, stream);
+// Where one env's data lives while the post-physics logic runs: LDS copies inside post_kernel (staged with coalesced
+// loads, so the one-lane-per-env phase never waits on global memory), plain global rows for lg_reset_idx.
+struct EnvView {
+  float *root, *dof, *cmd, *air, *ctime, *blv, *bav, *pg;
+  const float *tq, *act, *lact, *ldv, *cf, *rb;
+  uint8_t* lastc;
+};
+LG_DEV EnvView global_view(const DevCtx* __restrict__ C, int e) {
+  EnvView V;
+  V.root = C->root + (size_t)e * 13; V.dof = C->dof + (size_t)e * 24; V.cmd = C->commands + (size_t)e * 4;
+  V.air = C->feet_air + (size_t)e * 4; V.ctime = C->feet_ctime + (size_t)e * 4;
+  V.blv = C->base_lin_vel + (size_t)e * 3; V.bav = C->base_ang_vel + (size_t)e * 3; V.pg = C->proj_grav + (size_t)e * 3;
+  V.tq = C->torques + (size_t)e * 12; V.act = C->actions + (size_t)e * 12; V.lact = C->last_actions + (size_t)e * 12;
+  V.ldv = C->last_dof_vel + (size_t)e * 12; V.cf = C->cforce + (size_t)e * C->B * 3; V.rb = C->rigid + (size_t)e * C->B * 13;
+  V.lastc = C->last_contacts + (size_t)e * 4;
+  return V;
+}
+
+LG_DEV void resample_commands(const DevCtx* __restrict__ C, float* cmd, int e, int slot0, int64_t step, uint32_t stream) {  // LR:405-423
+  const lg_config& g = C->cfg;
+  float u[4]; uniform_draw4(C, e, slot0 >> 2, step, stream, u);      // slot0 is 4-aligned (LG_RS_CMD_CB, LG_RS_CMD_RESET)
+  float c0 = rand_float(g.cmd_lin_vel_x[0], g.cmd_lin_vel_x[1], u[0]);
+  float c1 = rand_float(g.cmd_lin_vel_y[0], g.cmd_lin_vel_y[1], u[1]);
+  float u2 = u[2];
   if (g.heading_command) cmd[3] = rand_float(g.cmd_heading[0], g.cmd_heading[1], u2);
   else cmd[2] = rand_float(g.cmd_ang_vel_yaw[0], g.cmd_ang_vel_yaw[1], u2);
   float keep = sqrtf(c0 * c0 + c1 * c1) > 0.2f ? 1.f : 0.f;
@@ -346,13 +580,14 @@ LG_DEV float terrain_height_at(const DevCtx* __restrict__ C, float qz, float qw,
 }
 #pragma clang fp contract(fast)
 
-LG_DEV void reset_env(const DevCtx* __restrict__ C, int e, int update_curriculum, int64_t step, uint32_t stream) {  // LR:162-213
+LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int update_curriculum, int64_t step, uint32_t stream) {  // LR:162-213
   const lg_config& g = C->cfg;
-  float* root = C->root + (size_t)e * 13; float* dof = C->dof + (size_t)e * 24;
-  float* org = C->origins + (size_t)e * 3; float* cmd = C->commands + (size_t)e * 4;
+  float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
+  float* org = C->origins + (size_t)e * 3;
+  float o0 = org[0], o1 = org[1], o2 = org[2];
   if (g.curriculum && update_curriculum) {   // LR:498-518
     int64_t typ = C->types[e];
-    float dx = root[0] - org[0], dy = root[1] - org[1];
+    float dx = root[0] - o0, dy = root[1] - o1;
     float dist = sqrtf(dx * dx + dy * dy);
     bool up = dist > C->env_length / 2;
     bool down = (dist < sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) * g.max_episode_length_s * 0.5f) && !up;
@@ -361,47 +596,50 @@ LG_DEV void reset_env(const DevCtx* __restrict__ C, int e, int update_curriculum
     else if (L < 0) L = 0;
     C->levels[e] = L;
     const float* to = C->terrain_origins + ((size_t)L * C->num_types + typ) * 3;
-    org[0] = to[0]; org[1] = to[1]; org[2] = to[2];
+    o0 = to[0]; o1 = to[1]; o2 = to[2];
+    org[0] = o0; org[1] = o1; org[2] = o2;
   }
-  for (int d = 0; d < 12; ++d) {   // LR:450-465
-    dof[2 * d] = g.default_dof_pos[d] * rand_float(0.5f, 1.5f, uniform_draw(C, e, LG_RS_DOF + d, step, stream));
-    dof[2 * d + 1] = 0.f;
+#pragma unroll
+  for (int gq = 0; gq < 3; ++gq) {   // LR:450-465 — slots LG_RS_DOF .. +11 = groups 2, 3, 4
+    float u[4]; uniform_draw4(C, e, (LG_RS_DOF >> 2) + gq, step, stream, u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { int d = 4 * gq + i; dof[2 * d] = g.default_dof_pos[d] * rand_float(0.5f, 1.5f, u[i]); dof[2 * d + 1] = 0.f; }
   }
   float r[13];
   for (int i = 0; i < 13; ++i) r[i] = g.base_init_state[i];   // LR:467-489
-  r[0] += org[0]; r[1] += org[1]; r[2] += org[2];
-  if (g.custom_origins) {
-    r[0] += rand_float(-0.5f, 0.5f, uniform_draw(C, e, LG_RS_ROOT_XY, step, stream));
-    r[1] += rand_float(-0.5f, 0.5f, uniform_draw(C, e, LG_RS_ROOT_XY + 1, step, stream));
-  }
-  for (int i = 0; i < 6; ++i) r[7 + i] = rand_float(-0.5f, 0.5f, uniform_draw(C, e, LG_RS_ROOT_VEL + i, step, stream));
+  r[0] += o0; r[1] += o1; r[2] += o2;
+  float ua[4], ub[4];                 // slots 20..23 and 24..27: root xy (2) then root velocity (6)
+  uniform_draw4(C, e, LG_RS_ROOT_XY >> 2, step, stream, ua);
+  uniform_draw4(C, e, (LG_RS_ROOT_XY >> 2) + 1, step, stream, ub);
+  if (g.custom_origins) { r[0] += rand_float(-0.5f, 0.5f, ua[0]); r[1] += rand_float(-0.5f, 0.5f, ua[1]); }
+  r[7] = rand_float(-0.5f, 0.5f, ua[2]); r[8] = rand_float(-0.5f, 0.5f, ua[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[9 + i] = rand_float(-0.5f, 0.5f, ub[i]);
   for (int i = 0; i < 13; ++i) root[i] = r[i];
-  resample_commands(C, e, LG_RS_CMD_RESET, step, stream);
+  resample_commands(C, cmd, e, LG_RS_CMD_RESET, step, stream);
   for (int d = 0; d < 12; ++d) { C->last_actions[(size_t)e * 12 + d] = 0.f; C->last_dof_vel[(size_t)e * 12 + d] = 0.f; }
-  for (int f = 0; f < 4; ++f) { C->feet_air[(size_t)e * 4 + f] = 0.f; C->feet_ctime[(size_t)e * 4 + f] = 0.f; }
+  for (int f = 0; f < 4; ++f) { V.air[f] = 0.f; V.ctime[f] = 0.f; }
   C->ep_len[e] = 0;
   C->reset_buf[e] = 1;
   if (g.control_type == LG_CTRL_ACTUATOR_NET) {   // anymal.py:78-82
     const size_t N12 = (size_t)C->N * 12;
-    for (int lay = 0; lay < 2; ++lay)
-      for (int k = 0; k < 96; ++k) {
-        C->sea_h[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
-        C->sea_c[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
-      }
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int lay = 0; lay < 2; ++lay) {
+      float4* ph = (float4*)(C->sea_h + (lay * N12 + (size_t)e * 12) * 8);
+      float4* pc = (float4*)(C->sea_c + (lay * N12 + (size_t)e * 12) * 8);
+      for (int k = 0; k < 24; ++k) { ph[k] = z4; pc[k] = z4; }
+    }
   }
 }
 
 // every _reward_* of RM:41-234 (+ anymal.py:112-114), selected by id
-LG_DEV float reward_term(const DevCtx* __restrict__ C, int e, int id, const float* s_h, int64_t step) {
+LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, int id, const float* s_h, int64_t step) {
   const lg_config& g = C->cfg; const lg_robot_model& m = C->model; const float dt = g.sim_dt * g.decimation;
-  const float* root = C->root + (size_t)e * 13; const float* dof = C->dof + (size_t)e * 24;
-  const float* blv = C->base_lin_vel + (size_t)e * 3; const float* bav = C->base_ang_vel + (size_t)e * 3;
-  const float* pg = C->proj_grav + (size_t)e * 3; const float* cmd = C->commands + (size_t)e * 4;
-  const float* tq = C->torques + (size_t)e * 12; const float* act = C->actions + (size_t)e * 12;
-  const float* lact = C->last_actions + (size_t)e * 12; const float* ldv = C->last_dof_vel + (size_t)e * 12;
-  const float* cf = C->cforce + (size_t)e * C->B * 3; const float* rb = C->rigid + (size_t)e * C->B * 13;
-  float* air = C->feet_air + (size_t)e * 4; float* ctime = C->feet_ctime + (size_t)e * 4;
-  uint8_t* lastc = C->last_contacts + (size_t)e * 4;
+  const float* root = V.root; const float* dof = V.dof;
+  const float* blv = V.blv; const float* bav = V.bav; const float* pg = V.pg; const float* cmd = V.cmd;
+  const float* tq = V.tq; const float* act = V.act; const float* lact = V.lact; const float* ldv = V.ldv;
+  const float* cf = V.cf; const float* rb = V.rb;
+  float* air = V.air; float* ctime = V.ctime; uint8_t* lastc = V.lastc;
   const float cmdn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
 #define SQ(x) ((x) * (x))
 #define FNORM(b) sqrtf(SQ(cf[3 * (b)]) + SQ(cf[3 * (b) + 1]) + SQ(cf[3 * (b) + 2]))
@@ -494,45 +732,95 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, int e, int id, const floa
 }
 
 // ============================================================================================ post-physics kernel
+// LDS staging area per env (floats)
+enum { S_ROOT = 0, S_DOF = 13, S_CF = 37, S_RB = S_CF + LG_MAX_BODIES * 3, S_ACT = S_RB + LG_MAX_BODIES * 13, S_LACT = S_ACT + 12,
+       S_LDV = S_LACT + 12, S_TQ = S_LDV + 12, S_LRV = S_TQ + 12, S_CMD = S_LRV + 6, S_BLA = S_CMD + 4, S_BAA = S_BLA + 3,
+       S_AIR = S_BAA + 3, S_CT = S_AIR + 4, S_BLV = S_CT + 4, S_BAV = S_BLV + 3, S_PG = S_BAV + 3, S_SUMS = S_PG + 3,
+       S_GAIT = S_SUMS + LG_MAX_REWARD_TERMS, S_STRIDE = S_GAIT + 1 + 2 };
+
 __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C) {
-  __shared__ float s_h[EPB][MAX_P];
-  __shared__ float s_prop[EPB][48];
-  __shared__ float s_rootz[EPB];
-  __shared__ float s_part[EPB][PART_STRIDE];
+  __shared__ float s_h[EPBP][MAX_P];
+  __shared__ float s_env[EPBP][S_STRIDE];
+  __shared__ float s_prop[EPBP][48];
+  __shared__ float s_rootz[EPBP];
+  __shared__ float s_part[EPBP][PART_STRIDE];
+  __shared__ uint8_t s_lastc[EPBP][4];
+  __shared__ int64_t s_eplen[EPBP];
+  __shared__ uint8_t s_flag[EPBP];
   const lg_config& g = C->cfg; const lg_robot_model& m = C->model;
-  const int tid = threadIdx.x, e0 = blockIdx.x * EPB;
-  const int nenv = min(EPB, C->N - e0);
+  const int tid = threadIdx.x, e0 = blockIdx.x * EPBP;
+  const int nenv = min(EPBP, C->N - e0);
   const int P = g.measure_heights ? C->P : 0;
   const int64_t step = C->counters[0] + 1;   // LR:123 (finalize_kernel stores it)
   const float dt = g.sim_dt * g.decimation;
+  const int B = C->B;
+#ifdef LG_STAMPS
+  unsigned long long* stamps = (blockIdx.x == 0 && tid == 0) ? C->stamps : nullptr;
+  unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
+
+  // ---- (0) stage this workgroup's env rows in LDS: every global row block is contiguous over the 16 envs
+#define STAGE(OFF, SRC, LEN)                                                                   \
+  for (int idx = tid; idx < nenv * (LEN); idx += 256) {                                         \
+    int el = idx / (LEN), k = idx - el * (LEN);                                                 \
+    s_env[el][(OFF) + k] = (SRC)[(size_t)e0 * (LEN) + idx];                                     \
+  }
+  STAGE(S_ROOT, C->root, 13) STAGE(S_DOF, C->dof, 24) STAGE(S_CF, C->cforce, B * 3) STAGE(S_RB, C->rigid, B * 13)
+  STAGE(S_ACT, C->actions, 12) STAGE(S_LACT, C->last_actions, 12) STAGE(S_LDV, C->last_dof_vel, 12) STAGE(S_TQ, C->torques, 12)
+  STAGE(S_LRV, C->last_root_vel, 6) STAGE(S_CMD, C->commands, 4) STAGE(S_BLA, C->base_lin_acc, 3) STAGE(S_BAA, C->base_ang_acc, 3)
+  STAGE(S_AIR, C->feet_air, 4) STAGE(S_CT, C->feet_ctime, 4) STAGE(S_GAIT, C->gait_idx, 1)
+#undef STAGE
+  for (int idx = tid; idx < nenv * g.num_reward_terms; idx += 256) {     // episode sums are (K, N): row k, envs contiguous
+    int k = idx / nenv, el = idx - k * nenv;
+    s_env[el][S_SUMS + k] = C->ep_sums[(size_t)k * C->N + e0 + el];
+  }
+  if (tid < nenv * 4) s_lastc[tid >> 2][tid & 3] = C->last_contacts[(size_t)e0 * 4 + tid];
+  if (tid < nenv) { s_eplen[tid] = C->ep_len[e0 + tid]; s_flag[tid] = C->reset_buf[e0 + tid]; }
+  __syncthreads();
+  STAMP(11);
 
   // ---- (1) height scan from the post-physics root pose (LR:400-401), all lanes, row-contiguous stores
   if (P > 0) {
-    for (int idx = tid; idx < nenv * P; idx += 256) {
-      int el = idx / P, p = idx - el * P, e = e0 + el;
-      float hgt = 0.f;
-      if (C->ter.mesh_type != LG_MESH_PLANE) {
-        const float* root = C->root + (size_t)e * 13;
-        float qz = root[5], qw = root[6];
-        float nrm = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
-        hgt = terrain_height_at(C, qz / nrm, qw / nrm, root[0], root[1], C->height_points[2 * p], C->height_points[2 * p + 1]);
+    const bool plane = C->ter.mesh_type == LG_MESH_PLANE;
+    for (int base = tid; base < nenv * P; base += 4 * 256) {
+      float hgt[4]; int els[4], ps[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {          // four independent gathers in flight per lane
+        int idx = base + u * 256;
+        bool ok = idx < nenv * P;
+        int el = ok ? idx / P : 0, p = ok ? idx - el * P : 0;
+        els[u] = el; ps[u] = ok ? p : -1;
+        hgt[u] = 0.f;
+        if (ok && !plane) {
+          const float* root = s_env[el] + S_ROOT;
+          float qz = root[5], qw = root[6];
+          float nrm = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
+          hgt[u] = terrain_height_at(C, qz / nrm, qw / nrm, root[0], root[1], C->height_points[2 * p], C->height_points[2 * p + 1]);
+        }
       }
-      s_h[el][p] = hgt;
-      C->heights[(size_t)e * C->P + p] = hgt;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (ps[u] >= 0) {
+        s_h[els[u]][ps[u]] = hgt[u];
+        C->heights[(size_t)(e0 + els[u]) * C->P + ps[u]] = hgt[u];
+      }
     }
   }
   __syncthreads();
+  STAMP(12);
 
-  // ---- (2) one lane per env: everything scalar, in the reference's order
+  // ---- (2) one lane per env: everything scalar, in the reference's order, on the LDS copies
   if (tid < nenv) {
     const int el = tid, e = e0 + el;
-    float* root = C->root + (size_t)e * 13; float* dof = C->dof + (size_t)e * 24;
-    float* blv = C->base_lin_vel + (size_t)e * 3; float* bav = C->base_ang_vel + (size_t)e * 3; float* pg = C->proj_grav + (size_t)e * 3;
-    float* bla = C->base_lin_acc + (size_t)e * 3; float* baa = C->base_ang_acc + (size_t)e * 3;
-    float* lrv = C->last_root_vel + (size_t)e * 6; float* cmd = C->commands + (size_t)e * 4;
-    const float* cf = C->cforce + (size_t)e * C->B * 3; const float* act = C->actions + (size_t)e * 12;
-    int64_t eplen = C->ep_len[e] + 1;                                             // LR:122
-    C->ep_len[e] = eplen;
+    float* S = s_env[el];
+    EnvView V;
+    V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
+    V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT;
+    V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = s_lastc[el];
+    float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
+    float* bla = S + S_BLA; float* baa = S + S_BAA; const float* lrv = S + S_LRV;
+    const float* cf = V.cf; const float* act = V.act;
+    bool root_dirty = false;
+    int64_t eplen = s_eplen[el] + 1;                                              // LR:122
     float q[4] = {root[3], root[4], root[5], root[6]};
     V3 lin = v3(root[7], root[8], root[9]), ang = v3(root[10], root[11], root[12]);
     V3 v = quat_rotate_inverse(q, lin);                                           // LR:128-134
@@ -543,9 +831,9 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     V3 da = quat_rotate_inverse(q, ang - v3(lrv[3], lrv[4], lrv[5]));
     baa[0] = baa[0] * ema + oma * da.x / dt; baa[1] = baa[1] * ema + oma * da.y / dt; baa[2] = baa[2] * ema + oma * da.z / dt;
     V3 gv = quat_rotate_inverse(q, v3(0, 0, -1));
-    blv[0] = v.x; blv[1] = v.y; blv[2] = v.z; bav[0] = w.x; bav[1] = w.y; bav[2] = w.z; pg[0] = gv.x; pg[1] = gv.y; pg[2] = gv.z;
+    V.blv[0] = v.x; V.blv[1] = v.y; V.blv[2] = v.z; V.bav[0] = w.x; V.bav[1] = w.y; V.bav[2] = w.z; V.pg[0] = gv.x; V.pg[1] = gv.y; V.pg[2] = gv.z;
     // _post_physics_step_callback (LR:386-403)
-    if (eplen % g.resampling_steps == 0) resample_commands(C, e, LG_RS_CMD_CB, step, 0);
+    if (eplen % g.resampling_steps == 0) resample_commands(C, cmd, e, LG_RS_CMD_CB, step, 0);
     if (g.heading_command) {
       V3 f = quat_apply(q, v3(1, 0, 0));
       float x = 0.5f * wrap_to_pi(cmd[3] - atan2f(f.y, f.x));
@@ -554,42 +842,46 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     if (g.push_robots && (step % g.push_interval == 0)) {                           // LR:402-403, 491-496
       root[7] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, uniform_draw(C, e, LG_RS_PUSH, step, 0));
       root[8] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, uniform_draw(C, e, LG_RS_PUSH + 1, step, 0));
+      root_dirty = true;
     }
     // check_termination (LR:155-160)
     bool term = false;
     for (int i = 0; i < m.num_termination; ++i) { int b = m.termination_contact_indices[i]; term |= FNORM(b) > 1.f; }
-    term |= C->reset_buf[e] == 2;   // physics fault flagged by physics_kernel
+    term |= s_flag[el] == 2;        // physics fault flagged by physics_kernel
     bool tout = (float)eplen > g.max_episode_length;
     C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0;
     // compute_reward (LR:215-232)
     float rew = 0.f;
+    float rk[LG_MAX_REWARD_TERMS];
     for (int k = 0; k < g.num_reward_terms; ++k) {
-      int id = g.reward_term_ids[k]; if (id == LG_REW_TERMINATION) continue;
-      float r = reward_term(C, e, id, s_h[el], step) * g.reward_scales[k];
-      rew += r; C->ep_sums[(size_t)k * C->N + e] += r;
+      int id = g.reward_term_ids[k];
+      float r = 0.f;
+      if (id != LG_REW_TERMINATION) { r = reward_term(C, V, e, id, s_h[el], step) * g.reward_scales[k]; rew += r; }
+      rk[k] = r;
     }
     if (g.only_positive_rewards) rew = fmaxf(rew, 0.f);
     for (int k = 0; k < g.num_reward_terms; ++k) if (g.reward_term_ids[k] == LG_REW_TERMINATION) {
-      float r = reward_term(C, e, LG_REW_TERMINATION, s_h[el], step) * g.reward_scales[k];
-      rew += r; C->ep_sums[(size_t)k * C->N + e] += r;
+      float r = ((term || tout) && !tout ? 1.f : 0.f) * g.reward_scales[k];
+      rew += r; rk[k] = r;
     }
     C->rew[e] = rew;
     // reset (LR:144-145) and the episode statistics of LR:200-206
     const bool do_reset = term || tout;
     s_part[el][g.num_reward_terms + 2] = do_reset ? (float)eplen : 0.f;
-    if (do_reset) reset_env(C, e, 1, step, 0);
+    C->ep_len[e] = eplen;
+    if (do_reset) { reset_env(C, V, e, 1, step, 0); root_dirty = true; }
     for (int k = 0; k < g.num_reward_terms; ++k) {
-      float sv = 0.f;
-      if (do_reset) { sv = C->ep_sums[(size_t)k * C->N + e]; C->ep_sums[(size_t)k * C->N + e] = 0.f; }
-      s_part[el][k] = sv;
+      float tot = S[S_SUMS + k] + rk[k];
+      s_part[el][k] = do_reset ? tot : 0.f;
+      S[S_SUMS + k] = do_reset ? 0.f : tot;          // written back to (K, N) cooperatively below
     }
     s_part[el][g.num_reward_terms] = do_reset ? 1.f : 0.f;
     s_part[el][g.num_reward_terms + 1] = g.curriculum ? (float)C->levels[e] : 0.f;
     // proprioceptive part of the observation (LR:237-244), from the post-reset state
     float* sp = s_prop[el];
-    sp[0] = blv[0] * g.obs_scale_lin_vel; sp[1] = blv[1] * g.obs_scale_lin_vel; sp[2] = blv[2] * g.obs_scale_lin_vel;
-    sp[3] = bav[0] * g.obs_scale_ang_vel; sp[4] = bav[1] * g.obs_scale_ang_vel; sp[5] = bav[2] * g.obs_scale_ang_vel;
-    sp[6] = pg[0]; sp[7] = pg[1]; sp[8] = pg[2];
+    sp[0] = V.blv[0] * g.obs_scale_lin_vel; sp[1] = V.blv[1] * g.obs_scale_lin_vel; sp[2] = V.blv[2] * g.obs_scale_lin_vel;
+    sp[3] = V.bav[0] * g.obs_scale_ang_vel; sp[4] = V.bav[1] * g.obs_scale_ang_vel; sp[5] = V.bav[2] * g.obs_scale_ang_vel;
+    sp[6] = V.pg[0]; sp[7] = V.pg[1]; sp[8] = V.pg[2];
     sp[9] = cmd[0] * g.obs_scale_lin_vel; sp[10] = cmd[1] * g.obs_scale_lin_vel; sp[11] = cmd[2] * g.obs_scale_ang_vel;
     for (int d = 0; d < 12; ++d) {
       sp[12 + d] = (dof[2 * d] - g.default_dof_pos[d]) * g.obs_scale_dof_pos;
@@ -597,20 +889,35 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
       sp[36 + d] = act[d];
     }
     s_rootz[el] = root[2];
+    // write back what this lane changed (rows it did not touch stay as the physics kernel left them)
+    if (root_dirty) for (int i = 0; i < 13; ++i) C->root[(size_t)e * 13 + i] = root[i];
+    if (do_reset) for (int d = 0; d < 24; ++d) C->dof[(size_t)e * 24 + d] = dof[d];
+    for (int i = 0; i < 4; ++i) {
+      C->commands[(size_t)e * 4 + i] = cmd[i]; C->feet_air[(size_t)e * 4 + i] = V.air[i]; C->feet_ctime[(size_t)e * 4 + i] = V.ctime[i];
+      C->last_contacts[(size_t)e * 4 + i] = V.lastc[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+      C->base_lin_vel[(size_t)e * 3 + i] = V.blv[i]; C->base_ang_vel[(size_t)e * 3 + i] = V.bav[i]; C->proj_grav[(size_t)e * 3 + i] = V.pg[i];
+      C->base_lin_acc[(size_t)e * 3 + i] = bla[i]; C->base_ang_acc[(size_t)e * 3 + i] = baa[i];
+    }
     // history buffers (LR:148-150)
     for (int d = 0; d < 12; ++d) { C->last_actions[(size_t)e * 12 + d] = act[d]; C->last_dof_vel[(size_t)e * 12 + d] = dof[2 * d + 1]; }
-    for (int i = 0; i < 6; ++i) lrv[i] = root[7 + i];
+    for (int i = 0; i < 6; ++i) C->last_root_vel[(size_t)e * 6 + i] = root[7 + i];
     // Anymal.post_physics_step: gait scheduler (anymal.py:107-110)
     if (g.gait_enabled) {
-      float x = fmodf(C->gait_idx[e] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
+      float x = fmodf(S[S_GAIT] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
       C->gait_idx[e] = x;
-      const float* rb = C->rigid + (size_t)e * C->B * 13;
-      for (int f = 0; f < 4; ++f) C->gait_foot_z[(size_t)e * 4 + f] = rb[(size_t)m.feet_indices[f] * 13 + 2];
+      for (int f = 0; f < 4; ++f) C->gait_foot_z[(size_t)e * 4 + f] = V.rb[(size_t)m.feet_indices[f] * 13 + 2];
     }
   }
   __syncthreads();
+  STAMP(13);
 
   // ---- per-workgroup episode statistics, summed in fixed env order (deterministic)
+  for (int idx = tid; idx < nenv * g.num_reward_terms; idx += 256) {     // episode sums back to their (K, N) rows
+    int k = idx / nenv, el = idx - k * nenv;
+    C->ep_sums[(size_t)k * C->N + e0 + el] = s_env[el][S_SUMS + k];
+  }
   const int KP = g.num_reward_terms + 3;
   if (tid < KP) {
     float s = 0.f;
@@ -646,20 +953,21 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
       C->obs[(size_t)e * O + idx] = o;
     }
   }
+  STAMP(14);
 }
 
-// one wave: fixed-order reduction of the per-workgroup partials -> extras (LR:200-206), step counters, running stats.
-// Column c is summed by all 64 lanes (lane i takes workgroups i, i+64, ...) and folded with a fixed xor butterfly, so
-// the result does not depend on scheduling.
-__global__ __launch_bounds__(64) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step) {
-  const int K = C->cfg.num_reward_terms, tid = threadIdx.x;
+// one workgroup of 16 waves: fixed-order reduction of the per-workgroup partials -> extras (LR:200-206), step counters,
+// running stats.  Wave w sums columns w, w+16, ...: lane i takes workgroups i, i+64, ... and the 64 partial sums are
+// folded with a fixed xor butterfly, so the result does not depend on scheduling.
+__global__ __launch_bounds__(1024) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step) {
+  const int K = C->cfg.num_reward_terms, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   __shared__ float tot[PART_STRIDE];
-  for (int c = 0; c < K + 3; ++c) {
+  for (int c = wv; c < K + 3; c += 16) {
     float s = 0.f;
-    for (int b = tid; b < nblocks; b += 64) s += C->partials[(size_t)b * PART_STRIDE + c];
+    for (int b = lane; b < nblocks; b += 64) s += C->partials[(size_t)b * PART_STRIDE + c];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (tid == 0) tot[c] = s;
+    if (lane == 0) tot[c] = s;
   }
   __syncthreads();
   const float cnt = tot[K];
@@ -687,7 +995,7 @@ __global__ __launch_bounds__(256) void reset_idx_kernel(const DevCtx* __restrict
     C->partials[K + 2] = s;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += 256) reset_env(C, ids[i], update_curriculum, step, 1);
+  for (int i = tid; i < n; i += 256) { const EnvView V = global_view(C, ids[i]); reset_env(C, V, ids[i], update_curriculum, step, 1); }
   __syncthreads();
   __threadfence_block();
   if (tid < K) {
@@ -778,6 +1086,13 @@ size_t lg_arena_bytes(const lg_config* cfg, const lg_robot_model* model, const l
 
 const char* lg_last_error(lg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
+// diagnostic builds only: copy out the 16 phase counters (not part of the public ABI)
+int lg_debug_read_stamps(lg_ctx* c, unsigned long long out[32]) {
+  if (!c) return LG_ERR_INVALID;
+  if (hipDeviceSynchronize() != hipSuccess) return LG_ERR_HIP;
+  return hipMemcpy(out, c->h.stamps, 256, hipMemcpyDeviceToHost) == hipSuccess ? LG_OK : LG_ERR_HIP;
+}
+
 void lg_destroy(lg_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -827,16 +1142,17 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.ter.mesh_type = ter->mesh_type; h.ter.rows = ter->rows; h.ter.cols = ter->cols;
   h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
   h.ter.H = (const int16_t*)P(LG_T_HEIGHT_SAMPLES);
-  h.nblocks_post = (h.N + EPB - 1) / EPB;
+  h.nblocks_post = (h.N + EPBP - 1) / EPBP;
 
   // aux buffer: noise_vec | height_points | partials
   size_t n_noise = (size_t)cfg->num_obs, n_hp = (size_t)2 * cfg->num_height_points;
   size_t n_part = (size_t)h.nblocks_post * PART_STRIDE;
-  size_t aux_floats = n_noise + n_hp + n_part;
+  size_t aux_floats = n_noise + n_hp + n_part + 66;   // + 32 x u64 stamp counters
   if (hipMalloc(&c->aux, aux_floats * 4) != hipSuccess) return fail("hipMalloc(aux) failed");
   if (hipMemset(c->aux, 0, aux_floats * 4) != hipSuccess) return fail("hipMemset(aux) failed");
   float* aux = (float*)c->aux;
   h.noise_vec = aux; h.height_points = aux + n_noise; h.partials = aux + n_noise + n_hp;
+  h.stamps = (unsigned long long*)(aux + ((n_noise + n_hp + n_part + 1) & ~(size_t)1));
   if (hipMemcpy(aux, cfg->noise_scale_vec, n_noise * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy noise_scale_vec failed");
   if (n_hp && hipMemcpy(aux + n_noise, cfg->height_points, n_hp * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy height_points failed");
   if (ter->mesh_type == LG_MESH_HEIGHTFIELD &&
@@ -855,6 +1171,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   if (hipMalloc((void**)&c->d, sizeof(DevCtx)) != hipSuccess) return fail("hipMalloc(ctx) failed");
   if (hipMemcpy(c->d, &h, sizeof(DevCtx), hipMemcpyHostToDevice) != hipSuccess) return fail("copy ctx failed");
   if (hipDeviceSynchronize() != hipSuccess) return fail("device sync failed");
+  if (const char* ev = getenv("LG_SPLIT")) c->split = atoi(ev) != 0;
   return c;
 }
 
@@ -870,7 +1187,7 @@ int lg_get_tensor(lg_ctx* c, int id, void** dptr, int64_t shape[4], int32_t* ndi
 static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev) {
   hipLaunchKernelGGL(post_kernel, dim3(c->h.nblocks_post), dim3(256), 0, st, c->d);
   if (ev) (void)hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, c->d, c->h.nblocks_post, 1);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, c->d, c->h.nblocks_post, 1);
   if (ev) (void)hipEventRecord(ev[3], st);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
@@ -881,13 +1198,14 @@ int lg_step(lg_ctx* c, const float* actions, void* stream) {
   if (!actions) { c->err = "actions is null"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   const int nb = (c->h.N + EPB - 1) / EPB;
+  const int nact = (c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET && c->split) ? 3 : 0;
   hipEvent_t* ev = nullptr;
   if (c->prof_max > 0) {
     if (c->prof_n < c->prof_max && (c->prof_calls % c->prof_stride) == 0) ev = &c->ev[(size_t)4 * c->prof_n++];
     c->prof_calls++;
   }
   if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(physics_kernel<0>, dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation);
+  hipLaunchKernelGGL(physics_kernel<0>, dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact);
   if (ev) (void)hipEventRecord(ev[1], st);
   return launch_post(c, st, ev);
 }
@@ -919,7 +1237,7 @@ int lg_profile_end(lg_ctx* c, float mean_ms[3], int32_t* nsamples) {
 int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
   const int nb = (c->h.N + EPB - 1) / EPB;
-  hipLaunchKernelGGL(physics_kernel<2>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0);
+  hipLaunchKernelGGL(physics_kernel<2>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -927,7 +1245,7 @@ int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
 int lg_simulate(lg_ctx* c, void* stream) {
   if (!c) return LG_ERR_INVALID;
   const int nb = (c->h.N + EPB - 1) / EPB;
-  hipLaunchKernelGGL(physics_kernel<1>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1);
+  hipLaunchKernelGGL(physics_kernel<1>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -943,7 +1261,7 @@ int lg_reset_idx(lg_ctx* c, const int32_t* env_ids, int32_t n, int32_t update_cu
   if (n == 0) return LG_OK;                         // LR:172-173
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(reset_idx_kernel, dim3(1), dim3(256), 0, st, c->d, env_ids, n, update_curriculum);
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, c->d, 1, 0);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, c->d, 1, 0);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }

@@ -12,7 +12,7 @@ import torch
 
 from extended_legged_gym_amd import abi
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblgstep.so")
+LIB_PATH = os.environ.get("LGSTEP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblgstep.so")
 _TORCH_DTYPE = {abi.LG_F32: torch.float32, abi.LG_I64: torch.int64, abi.LG_U8: torch.uint8, abi.LG_I16: torch.int16,
                 abi.LG_I32: torch.int32, abi.LG_F64: torch.float64}
 _lib = None

@@ -1,0 +1,30 @@
+"""Diagnostic: run the bench workload on the -DLG_STAMPS build and print the share of shader cycles per phase of
+physics_kernel (lane 0 of workgroup 0).  Shares only — never quote this build's run time."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["LGSTEP_LIB"] = os.path.join(ROOT, "extended_legged_gym_amd", "csrc", "liblgstep_stamps.so")
+sys.path.insert(0, ROOT)
+import torch
+import bench
+pd = "--pd" in sys.argv
+env, cfg = bench.build_env(0, 1, 4096, pd)
+env.reset()
+g = torch.Generator().manual_seed(0)
+pool = [torch.randn(4096, 12, generator=g).cuda() for _ in range(16)]
+for i in range(300):
+    env.step(pool[i % 16])
+lib = env.core.lib
+out = (C.c_ulonglong * 32)()
+lib.lg_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+rc = lib.lg_debug_read_stamps(env.core.ctx, out)
+import extended_legged_gym_amd.native as nat
+print('lib', nat.LIB_PATH, 'rc', rc)
+names = {15: "substep prologue", 0: "publish q/qd | inline actuator", 1: "kinematics", 2: "bias (RNEA)", 3: "CRBA+Schur+chol",
+         5: "contact pass A (detect)", 6: "contact pass B (setup)", 4: "wait for torques (barrier B)", 7: "unconstrained + PGS",
+         8: "limits+forces+integrate", 9: "fault guard", 10: "write-back + final FK",
+         11: "POST: stage rows in LDS", 12: "POST: height scan", 13: "POST: per-env scalar phase", 14: "POST: partials + obs rows"}
+tot = sum(out[:16])
+print('active slots per wave-substep', out[16] / max(out[17], 1), ' active contacts per wave-substep', out[18] / max(out[17], 1), '(of', 64 * 7, 'lane-slots)')
+for k, n in names.items():
+    print(f"{n:28s} {out[k]:14d} cycles  {100.0 * out[k] / max(tot, 1):5.1f} %   per substep-call {out[k] / (301 * 4):9.0f}")
+print("total cycles per step", tot / 301)
