@@ -550,12 +550,12 @@ LG_DEV EnvView global_view(const DevCtx* __restrict__ C, int e) {
   return V;
 }
 
-LG_DEV void resample_commands(const DevCtx* __restrict__ C, float* cmd, int e, int slot0, int64_t step, uint32_t stream) {  // LR:405-423
+// `U` = this env's uniforms for slots 0 .. LG_RS_NOISE-1 (drawn up front, one Philox call per group of four)
+LG_DEV void resample_commands(const DevCtx* __restrict__ C, float* cmd, const float* U, int slot0) {  // LR:405-423
   const lg_config& g = C->cfg;
-  float u[4]; uniform_draw4(C, e, slot0 >> 2, step, stream, u);      // slot0 is 4-aligned (LG_RS_CMD_CB, LG_RS_CMD_RESET)
-  float c0 = rand_float(g.cmd_lin_vel_x[0], g.cmd_lin_vel_x[1], u[0]);
-  float c1 = rand_float(g.cmd_lin_vel_y[0], g.cmd_lin_vel_y[1], u[1]);
-  float u2 = u[2];
+  float c0 = rand_float(g.cmd_lin_vel_x[0], g.cmd_lin_vel_x[1], U[slot0]);
+  float c1 = rand_float(g.cmd_lin_vel_y[0], g.cmd_lin_vel_y[1], U[slot0 + 1]);
+  float u2 = U[slot0 + 2];
   if (g.heading_command) cmd[3] = rand_float(g.cmd_heading[0], g.cmd_heading[1], u2);
   else cmd[2] = rand_float(g.cmd_ang_vel_yaw[0], g.cmd_ang_vel_yaw[1], u2);
   float keep = sqrtf(c0 * c0 + c1 * c1) > 0.2f ? 1.f : 0.f;
@@ -580,7 +580,8 @@ LG_DEV float terrain_height_at(const DevCtx* __restrict__ C, float qz, float qw,
 }
 #pragma clang fp contract(fast)
 
-LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int update_curriculum, int64_t step, uint32_t stream) {  // LR:162-213
+// zero_sea: also clear the LSTM actuator state rows here (the post kernel does it cooperatively instead)
+LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int update_curriculum, const float* U, bool zero_sea) {  // LR:162-213
   const lg_config& g = C->cfg;
   float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
   float* org = C->origins + (size_t)e * 3;
@@ -592,36 +593,29 @@ LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int
     bool up = dist > C->env_length / 2;
     bool down = (dist < sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) * g.max_episode_length_s * 0.5f) && !up;
     int64_t L = C->levels[e] + (up ? 1 : 0) - (down ? 1 : 0);
-    if (L >= g.max_terrain_level) L = (int64_t)floorf(uniform_draw(C, e, LG_RS_LEVEL, step, stream) * (float)g.max_terrain_level);
+    if (L >= g.max_terrain_level) L = (int64_t)floorf(U[LG_RS_LEVEL] * (float)g.max_terrain_level);
     else if (L < 0) L = 0;
     C->levels[e] = L;
     const float* to = C->terrain_origins + ((size_t)L * C->num_types + typ) * 3;
     o0 = to[0]; o1 = to[1]; o2 = to[2];
     org[0] = o0; org[1] = o1; org[2] = o2;
   }
-#pragma unroll
-  for (int gq = 0; gq < 3; ++gq) {   // LR:450-465 — slots LG_RS_DOF .. +11 = groups 2, 3, 4
-    float u[4]; uniform_draw4(C, e, (LG_RS_DOF >> 2) + gq, step, stream, u);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { int d = 4 * gq + i; dof[2 * d] = g.default_dof_pos[d] * rand_float(0.5f, 1.5f, u[i]); dof[2 * d + 1] = 0.f; }
+  for (int d = 0; d < 12; ++d) {   // LR:450-465
+    dof[2 * d] = g.default_dof_pos[d] * rand_float(0.5f, 1.5f, U[LG_RS_DOF + d]);
+    dof[2 * d + 1] = 0.f;
   }
   float r[13];
   for (int i = 0; i < 13; ++i) r[i] = g.base_init_state[i];   // LR:467-489
   r[0] += o0; r[1] += o1; r[2] += o2;
-  float ua[4], ub[4];                 // slots 20..23 and 24..27: root xy (2) then root velocity (6)
-  uniform_draw4(C, e, LG_RS_ROOT_XY >> 2, step, stream, ua);
-  uniform_draw4(C, e, (LG_RS_ROOT_XY >> 2) + 1, step, stream, ub);
-  if (g.custom_origins) { r[0] += rand_float(-0.5f, 0.5f, ua[0]); r[1] += rand_float(-0.5f, 0.5f, ua[1]); }
-  r[7] = rand_float(-0.5f, 0.5f, ua[2]); r[8] = rand_float(-0.5f, 0.5f, ua[3]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[9 + i] = rand_float(-0.5f, 0.5f, ub[i]);
+  if (g.custom_origins) { r[0] += rand_float(-0.5f, 0.5f, U[LG_RS_ROOT_XY]); r[1] += rand_float(-0.5f, 0.5f, U[LG_RS_ROOT_XY + 1]); }
+  for (int i = 0; i < 6; ++i) r[7 + i] = rand_float(-0.5f, 0.5f, U[LG_RS_ROOT_VEL + i]);
   for (int i = 0; i < 13; ++i) root[i] = r[i];
-  resample_commands(C, cmd, e, LG_RS_CMD_RESET, step, stream);
+  resample_commands(C, cmd, U, LG_RS_CMD_RESET);
   for (int d = 0; d < 12; ++d) { C->last_actions[(size_t)e * 12 + d] = 0.f; C->last_dof_vel[(size_t)e * 12 + d] = 0.f; }
   for (int f = 0; f < 4; ++f) { V.air[f] = 0.f; V.ctime[f] = 0.f; }
   C->ep_len[e] = 0;
   C->reset_buf[e] = 1;
-  if (g.control_type == LG_CTRL_ACTUATOR_NET) {   // anymal.py:78-82
+  if (zero_sea && g.control_type == LG_CTRL_ACTUATOR_NET) {   // anymal.py:78-82
     const size_t N12 = (size_t)C->N * 12;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int lay = 0; lay < 2; ++lay) {
@@ -747,6 +741,8 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
   __shared__ uint8_t s_lastc[EPBP][4];
   __shared__ int64_t s_eplen[EPBP];
   __shared__ uint8_t s_flag[EPBP];
+  __shared__ float s_u[EPBP][LG_RS_NOISE];      // uniforms of slots 0..31 (commands, push, curriculum, reset)
+  __shared__ uint8_t s_did_reset[EPBP], s_root_dirty[EPBP];
   const lg_config& g = C->cfg; const lg_robot_model& m = C->model;
   const int tid = threadIdx.x, e0 = blockIdx.x * EPBP;
   const int nenv = min(EPBP, C->N - e0);
@@ -776,6 +772,10 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
   }
   if (tid < nenv * 4) s_lastc[tid >> 2][tid & 3] = C->last_contacts[(size_t)e0 * 4 + tid];
   if (tid < nenv) { s_eplen[tid] = C->ep_len[e0 + tid]; s_flag[tid] = C->reset_buf[e0 + tid]; }
+  if (tid < nenv * (LG_RS_NOISE / 4)) {          // one Philox call per (env, slot group): 8 lanes per env
+    int el = tid / (LG_RS_NOISE / 4), gq = tid - el * (LG_RS_NOISE / 4);
+    uniform_draw4(C, e0 + el, gq, step, 0, &s_u[el][4 * gq]);
+  }
   __syncthreads();
   STAMP(11);
 
@@ -833,15 +833,15 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     V3 gv = quat_rotate_inverse(q, v3(0, 0, -1));
     V.blv[0] = v.x; V.blv[1] = v.y; V.blv[2] = v.z; V.bav[0] = w.x; V.bav[1] = w.y; V.bav[2] = w.z; V.pg[0] = gv.x; V.pg[1] = gv.y; V.pg[2] = gv.z;
     // _post_physics_step_callback (LR:386-403)
-    if (eplen % g.resampling_steps == 0) resample_commands(C, cmd, e, LG_RS_CMD_CB, step, 0);
+    if ((int)eplen % g.resampling_steps == 0) resample_commands(C, cmd, s_u[el], LG_RS_CMD_CB);
     if (g.heading_command) {
       V3 f = quat_apply(q, v3(1, 0, 0));
       float x = 0.5f * wrap_to_pi(cmd[3] - atan2f(f.y, f.x));
       cmd[2] = fminf(fmaxf(x, -1.f), 1.f);
     }
     if (g.push_robots && (step % g.push_interval == 0)) {                           // LR:402-403, 491-496
-      root[7] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, uniform_draw(C, e, LG_RS_PUSH, step, 0));
-      root[8] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, uniform_draw(C, e, LG_RS_PUSH + 1, step, 0));
+      root[7] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, s_u[el][LG_RS_PUSH]);
+      root[8] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, s_u[el][LG_RS_PUSH + 1]);
       root_dirty = true;
     }
     // check_termination (LR:155-160)
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     const bool do_reset = term || tout;
     s_part[el][g.num_reward_terms + 2] = do_reset ? (float)eplen : 0.f;
     C->ep_len[e] = eplen;
-    if (do_reset) { reset_env(C, V, e, 1, step, 0); root_dirty = true; }
+    if (do_reset) { reset_env(C, V, e, 1, s_u[el], false); root_dirty = true; }
     for (int k = 0; k < g.num_reward_terms; ++k) {
       float tot = S[S_SUMS + k] + rk[k];
       s_part[el][k] = do_reset ? tot : 0.f;
@@ -889,29 +889,47 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
       sp[36 + d] = act[d];
     }
     s_rootz[el] = root[2];
-    // write back what this lane changed (rows it did not touch stay as the physics kernel left them)
-    if (root_dirty) for (int i = 0; i < 13; ++i) C->root[(size_t)e * 13 + i] = root[i];
-    if (do_reset) for (int d = 0; d < 24; ++d) C->dof[(size_t)e * 24 + d] = dof[d];
-    for (int i = 0; i < 4; ++i) {
-      C->commands[(size_t)e * 4 + i] = cmd[i]; C->feet_air[(size_t)e * 4 + i] = V.air[i]; C->feet_ctime[(size_t)e * 4 + i] = V.ctime[i];
-      C->last_contacts[(size_t)e * 4 + i] = V.lastc[i];
-    }
-    for (int i = 0; i < 3; ++i) {
-      C->base_lin_vel[(size_t)e * 3 + i] = V.blv[i]; C->base_ang_vel[(size_t)e * 3 + i] = V.bav[i]; C->proj_grav[(size_t)e * 3 + i] = V.pg[i];
-      C->base_lin_acc[(size_t)e * 3 + i] = bla[i]; C->base_ang_acc[(size_t)e * 3 + i] = baa[i];
-    }
-    // history buffers (LR:148-150)
-    for (int d = 0; d < 12; ++d) { C->last_actions[(size_t)e * 12 + d] = act[d]; C->last_dof_vel[(size_t)e * 12 + d] = dof[2 * d + 1]; }
-    for (int i = 0; i < 6; ++i) C->last_root_vel[(size_t)e * 6 + i] = root[7 + i];
+    s_did_reset[el] = do_reset ? 1 : 0; s_root_dirty[el] = root_dirty ? 1 : 0;
+    // (rows are written back to global memory cooperatively after this phase)
     // Anymal.post_physics_step: gait scheduler (anymal.py:107-110)
     if (g.gait_enabled) {
       float x = fmodf(S[S_GAIT] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
-      C->gait_idx[e] = x;
-      for (int f = 0; f < 4; ++f) C->gait_foot_z[(size_t)e * 4 + f] = V.rb[(size_t)m.feet_indices[f] * 13 + 2];
+      S[S_GAIT] = x;
     }
   }
   __syncthreads();
   STAMP(13);
+
+  // ---- (2b) cooperative write-back of everything phase (2) produced or changed; history buffers (LR:148-150)
+#define UNSTAGE(DST, OFF, LEN)                                                                 \
+  for (int idx = tid; idx < nenv * (LEN); idx += 256) {                                         \
+    int el = idx / (LEN), k = idx - el * (LEN);                                                 \
+    (DST)[(size_t)e0 * (LEN) + idx] = s_env[el][(OFF) + k];                                     \
+  }
+  UNSTAGE(C->commands, S_CMD, 4) UNSTAGE(C->feet_air, S_AIR, 4) UNSTAGE(C->feet_ctime, S_CT, 4)
+  UNSTAGE(C->base_lin_vel, S_BLV, 3) UNSTAGE(C->base_ang_vel, S_BAV, 3) UNSTAGE(C->proj_grav, S_PG, 3)
+  UNSTAGE(C->base_lin_acc, S_BLA, 3) UNSTAGE(C->base_ang_acc, S_BAA, 3) UNSTAGE(C->gait_idx, S_GAIT, 1)
+#undef UNSTAGE
+  if (tid < nenv * 4) C->last_contacts[(size_t)e0 * 4 + tid] = s_lastc[tid >> 2][tid & 3];
+  for (int idx = tid; idx < nenv * 13; idx += 256) { int el = idx / 13, k = idx - el * 13; if (s_root_dirty[el]) C->root[(size_t)(e0 + el) * 13 + k] = s_env[el][S_ROOT + k]; }
+  for (int idx = tid; idx < nenv * 24; idx += 256) { int el = idx / 24, k = idx - el * 24; if (s_did_reset[el]) C->dof[(size_t)(e0 + el) * 24 + k] = s_env[el][S_DOF + k]; }
+  for (int idx = tid; idx < nenv * 12; idx += 256) {
+    int el = idx / 12, d = idx - el * 12;
+    C->last_actions[(size_t)(e0 + el) * 12 + d] = s_env[el][S_ACT + d];
+    C->last_dof_vel[(size_t)(e0 + el) * 12 + d] = s_env[el][S_DOF + 2 * d + 1];
+  }
+  for (int idx = tid; idx < nenv * 6; idx += 256) { int el = idx / 6, k = idx - el * 6; C->last_root_vel[(size_t)(e0 + el) * 6 + k] = s_env[el][S_ROOT + 7 + k]; }
+  if (g.gait_enabled && tid < nenv * 4) { int el = tid >> 2, f = tid & 3; C->gait_foot_z[(size_t)(e0 + el) * 4 + f] = s_env[el][S_RB + m.feet_indices[f] * 13 + 2]; }
+  if (g.control_type == LG_CTRL_ACTUATOR_NET) {      // anymal.py:78-82: clear the LSTM state of the envs that were reset
+    const size_t N12 = (size_t)C->N * 12;
+    for (int idx = tid; idx < nenv * 2 * 96; idx += 256) {
+      int el = idx / 192, r = idx - el * 192, lay = r / 96, k = r - lay * 96;
+      if (s_did_reset[el]) {
+        C->sea_h[(lay * N12 + (size_t)(e0 + el) * 12) * 8 + k] = 0.f;
+        C->sea_c[(lay * N12 + (size_t)(e0 + el) * 12) * 8 + k] = 0.f;
+      }
+    }
+  }
 
   // ---- per-workgroup episode statistics, summed in fixed env order (deterministic)
   for (int idx = tid; idx < nenv * g.num_reward_terms; idx += 256) {     // episode sums back to their (K, N) rows
@@ -995,7 +1013,13 @@ __global__ __launch_bounds__(256) void reset_idx_kernel(const DevCtx* __restrict
     C->partials[K + 2] = s;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += 256) { const EnvView V = global_view(C, ids[i]); reset_env(C, V, ids[i], update_curriculum, step, 1); }
+  for (int i = tid; i < n; i += 256) {
+    const EnvView V = global_view(C, ids[i]);
+    float U[LG_RS_NOISE];
+#pragma unroll
+    for (int gq = 0; gq < LG_RS_NOISE / 4; ++gq) uniform_draw4(C, ids[i], gq, step, 1, U + 4 * gq);
+    reset_env(C, V, ids[i], update_curriculum, U, true);
+  }
   __syncthreads();
   __threadfence_block();
   if (tid < K) {
