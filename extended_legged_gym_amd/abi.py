@@ -70,7 +70,7 @@ class lg_terrain(C.Structure):
 
 class lg_config(C.Structure):
     _fields_ = [
-        ("abi_version", i32), ("num_envs", i32), ("num_obs", i32), ("num_height_points", i32),
+        ("abi_version", i32), ("num_envs", i32), ("num_obs", i32), ("num_height_points", i32), ("num_extra_obs", i32),
         ("sim_dt", f32), ("decimation", i32), ("gravity", f32 * 3),
         ("control_type", i32), ("action_scale", f32),
         ("p_gains", f32 * 12), ("d_gains", f32 * 12), ("default_dof_pos", f32 * 12),
@@ -98,6 +98,11 @@ class lg_config(C.Structure):
     ]
 
 
+class lg_depth_params(C.Structure):
+    _fields_ = [("width", i32), ("height", i32), ("resized_width", i32), ("resized_height", i32), ("buffer_len", i32),
+                ("near_clip", f32), ("far_clip", f32), ("position", f32 * 3), ("quat_offset", f32 * 4)]
+
+
 def declare_product(lib):
     """Prototypes of liblgstep.so (include/lgstep.h)."""
     vp = C.c_void_p
@@ -111,6 +116,8 @@ def declare_product(lib):
     lib.lg_get_tensor.restype = C.c_int
     lib.lg_step.argtypes = [vp, vp, vp]
     lib.lg_step.restype = C.c_int
+    lib.lg_step_physics.argtypes = [vp, vp, vp]
+    lib.lg_step_physics.restype = C.c_int
     lib.lg_compute_torques.argtypes = [vp, vp, vp]
     lib.lg_compute_torques.restype = C.c_int
     lib.lg_simulate.argtypes = [vp, vp]
@@ -119,6 +126,24 @@ def declare_product(lib):
     lib.lg_post_physics_step.restype = C.c_int
     lib.lg_reset_idx.argtypes = [vp, vp, i32, i32, vp]
     lib.lg_reset_idx.restype = C.c_int
+    lib.lg_set_extra_obs.argtypes = [vp, vp]
+    lib.lg_set_extra_obs.restype = C.c_int
+    lib.lg_mesh_create.argtypes = [C.POINTER(f32), C.c_int64, C.POINTER(i32), C.c_int64, C.c_int]
+    lib.lg_mesh_create.restype = vp
+    lib.lg_mesh_destroy.argtypes = [vp]
+    lib.lg_mesh_destroy.restype = None
+    lib.lg_mesh_info.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.lg_mesh_info.restype = C.c_int
+    lib.lg_mesh_last_error.argtypes = [vp]
+    lib.lg_mesh_last_error.restype = C.c_char_p
+    lib.lg_raycast_mesh.argtypes = [vp, vp, vp, C.c_int64, f32, vp, vp, vp]
+    lib.lg_raycast_mesh.restype = C.c_int
+    lib.lg_mesh_query_sdf.argtypes = [vp, vp, C.c_int64, f32, vp, vp, vp]
+    lib.lg_mesh_query_sdf.restype = C.c_int
+    lib.lg_raycaster_update.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp, vp, vp, vp]
+    lib.lg_raycaster_update.restype = C.c_int
+    lib.lg_depth_camera_update.argtypes = [vp, C.POINTER(lg_depth_params), vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.lg_depth_camera_update.restype = C.c_int
     lib.lg_profile_begin.argtypes = [vp, i32, i32]
     lib.lg_profile_begin.restype = C.c_int
     lib.lg_profile_end.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
@@ -130,6 +155,7 @@ def declare_product(lib):
     return lib
 
 
-PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_compute_torques",
+PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_step_physics", "lg_compute_torques",
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
-                   "lg_destroy"]
+                   "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_last_error",
+                   "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update"]

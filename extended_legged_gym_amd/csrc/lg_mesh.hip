@@ -1,0 +1,453 @@
+// lg_mesh.hip — triangle-mesh queries on gfx950: BVH build (host), ray casting, closest point / signed distance,
+// and the two fused sensor kernels built on them (RayCaster, depth camera).
+//
+// Replaces NVIDIA Warp in the reference: wp.Mesh(points, indices) BVH (utils/ray_caster.py:39-42, utils/mesh_sdf.py:32-35),
+// wp.mesh_query_ray in raycast_mesh_kernel (ray_caster.py:45-92) and wp.mesh_query_point_sign_normal in
+// query_sdf_kernel (mesh_sdf.py:38-116).  Warp itself is closed-source-adjacent third party code that is not in the
+// reference tree; semantics restated: closest two-sided hit with 0 <= t <= max_dist; closest point on the surface with
+// the sign taken from the normal of the closest feature's face.
+//
+// Layout: 32-byte BVH nodes (bounds + child / triangle range), triangles re-ordered by leaf and stored as three float4
+// (48 B) so one leaf is a short contiguous burst; everything stays resident in HBM/L2 (rough terrain: 1.6 M triangles =
+// 78 MB + 26 MB of nodes).  One ray / point per lane, ordered traversal with a small per-lane stack.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "lg_device.h"
+#include "../../include/lgstep.h"
+
+struct BvhNode {          // 32 B
+  float bmin[3]; int32_t left_first;   // inner: index of left child (right = left + 1); leaf: first triangle
+  float bmax[3]; int32_t count;        // 0 = inner node, > 0 = number of triangles in the leaf
+};
+
+struct lg_mesh {
+  int device = 0;
+  int64_t n_tris = 0, n_nodes = 0;
+  BvhNode* d_nodes = nullptr;
+  float4* d_tris = nullptr;            // 3 float4 per triangle: v0, v1, v2 (w unused)
+  std::string err;
+};
+
+static thread_local std::string g_mesh_err;
+
+// ------------------------------------------------------------------------------------------------ host: BVH build
+namespace {
+struct BuildTri { float v[9]; float c[3]; };
+struct Builder {
+  std::vector<BuildTri>& t; std::vector<BvhNode>& nodes;
+  void bounds(int first, int count, float* mn, float* mx) {
+    for (int k = 0; k < 3; ++k) { mn[k] = 1e30f; mx[k] = -1e30f; }
+    for (int i = first; i < first + count; ++i)
+      for (int v = 0; v < 3; ++v)
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], t[i].v[3 * v + k]); mx[k] = std::max(mx[k], t[i].v[3 * v + k]); }
+  }
+  void build(int node, int first, int count) {
+    BvhNode& n = nodes[node];
+    bounds(first, count, n.bmin, n.bmax);
+    if (count <= 4) { n.left_first = first; n.count = count; return; }
+    // binned SAH on centroids, 8 bins per axis
+    float cmin[3] = {1e30f, 1e30f, 1e30f}, cmax[3] = {-1e30f, -1e30f, -1e30f};
+    for (int i = first; i < first + count; ++i) for (int k = 0; k < 3; ++k) { cmin[k] = std::min(cmin[k], t[i].c[k]); cmax[k] = std::max(cmax[k], t[i].c[k]); }
+    int best_axis = -1; float best_cost = 1e30f, best_split = 0.f;
+    const int NB = 8;
+    for (int ax = 0; ax < 3; ++ax) {
+      float ext = cmax[ax] - cmin[ax];
+      if (!(ext > 1e-9f)) continue;
+      int cnt[NB] = {0}; float bmn[NB][3], bmx[NB][3];
+      for (int b = 0; b < NB; ++b) for (int k = 0; k < 3; ++k) { bmn[b][k] = 1e30f; bmx[b][k] = -1e30f; }
+      for (int i = first; i < first + count; ++i) {
+        int b = std::min(NB - 1, (int)((t[i].c[ax] - cmin[ax]) / ext * NB));
+        cnt[b]++;
+        for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) { bmn[b][k] = std::min(bmn[b][k], t[i].v[3 * v + k]); bmx[b][k] = std::max(bmx[b][k], t[i].v[3 * v + k]); }
+      }
+      float lmn[3], lmx[3], area_l[NB], area_r[NB]; int nl[NB], nr[NB];
+      auto area = [](const float* a, const float* b) { float x = b[0] - a[0], y = b[1] - a[1], z = b[2] - a[2]; return x * y + y * z + z * x; };
+      for (int k = 0; k < 3; ++k) { lmn[k] = 1e30f; lmx[k] = -1e30f; }
+      int acc = 0;
+      for (int b = 0; b < NB - 1; ++b) {
+        for (int k = 0; k < 3; ++k) { lmn[k] = std::min(lmn[k], bmn[b][k]); lmx[k] = std::max(lmx[k], bmx[b][k]); }
+        acc += cnt[b]; nl[b] = acc; area_l[b] = acc ? area(lmn, lmx) : 0.f;
+      }
+      for (int k = 0; k < 3; ++k) { lmn[k] = 1e30f; lmx[k] = -1e30f; }
+      acc = 0;
+      for (int b = NB - 1; b > 0; --b) {
+        for (int k = 0; k < 3; ++k) { lmn[k] = std::min(lmn[k], bmn[b][k]); lmx[k] = std::max(lmx[k], bmx[b][k]); }
+        acc += cnt[b]; nr[b - 1] = acc; area_r[b - 1] = acc ? area(lmn, lmx) : 0.f;
+      }
+      for (int b = 0; b < NB - 1; ++b) {
+        if (nl[b] == 0 || nr[b] == 0) continue;
+        float cost = area_l[b] * nl[b] + area_r[b] * nr[b];
+        if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = cmin[ax] + ext * (b + 1) / NB; }
+      }
+    }
+    int mid;
+    if (best_axis < 0) {      // all centroids coincide: split in the middle
+      mid = first + count / 2;
+    } else {
+      auto it = std::partition(t.begin() + first, t.begin() + first + count, [&](const BuildTri& a) { return a.c[best_axis] < best_split; });
+      mid = (int)(it - t.begin());
+      if (mid == first || mid == first + count) mid = first + count / 2;
+    }
+    int left = (int)nodes.size();
+    nodes.push_back(BvhNode()); nodes.push_back(BvhNode());
+    nodes[node].left_first = left; nodes[node].count = 0;
+    build(left, first, mid - first);
+    build(left + 1, mid, first + count - mid);
+  }
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ device: traversal
+struct MeshView { const BvhNode* __restrict__ nodes; const float4* __restrict__ tris; };
+
+LG_DEV bool slab(const BvhNode& n, V3 o, V3 inv, float tmax, float* tnear) {
+  float tx1 = (n.bmin[0] - o.x) * inv.x, tx2 = (n.bmax[0] - o.x) * inv.x;
+  float ty1 = (n.bmin[1] - o.y) * inv.y, ty2 = (n.bmax[1] - o.y) * inv.y;
+  float tz1 = (n.bmin[2] - o.z) * inv.z, tz2 = (n.bmax[2] - o.z) * inv.z;
+  float tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fmaxf(fminf(tz1, tz2), 0.f));
+  float tmx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fminf(fmaxf(tz1, tz2), tmax));
+  *tnear = tmin;
+  return tmin <= tmx;
+}
+
+// closest two-sided hit with 0 <= t <= max_dist (Moller-Trumbore); returns t or -1
+LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
+  const V3 inv = v3(1.f / (fabsf(d.x) > 1e-12f ? d.x : copysignf(1e-12f, d.x)), 1.f / (fabsf(d.y) > 1e-12f ? d.y : copysignf(1e-12f, d.y)),
+                    1.f / (fabsf(d.z) > 1e-12f ? d.z : copysignf(1e-12f, d.z)));
+  float best = max_dist; bool hit = false;
+  int stack[48]; int sp = 0;
+  int cur = 0; float tn;
+  if (!slab(M.nodes[0], o, inv, best, &tn)) return -1.f;
+  while (true) {
+    const BvhNode n = M.nodes[cur];
+    if (n.count > 0) {
+      for (int i = 0; i < n.count; ++i) {
+        const float4* T = M.tris + (size_t)(n.left_first + i) * 3;
+        float4 a = T[0], b = T[1], c = T[2];
+        V3 v0 = v3(a.x, a.y, a.z), e1 = v3(b.x - a.x, b.y - a.y, b.z - a.z), e2 = v3(c.x - a.x, c.y - a.y, c.z - a.z);
+        V3 p = cross(d, e2);
+        float det = dot(e1, p);
+        if (fabsf(det) < 1e-20f) continue;
+        float idet = 1.f / det;
+        V3 s = o - v0;
+        float u = dot(s, p) * idet;
+        if (u < 0.f || u > 1.f) continue;
+        V3 q = cross(s, e1);
+        float v = dot(d, q) * idet;
+        if (v < 0.f || u + v > 1.f) continue;
+        float t = dot(e2, q) * idet;
+        if (t >= 0.f && t <= best) { best = t; hit = true; }
+      }
+      if (sp == 0) break;
+      cur = stack[--sp];
+      continue;
+    }
+    const int l = n.left_first, r = l + 1;
+    float tl, tr;
+    bool hl = slab(M.nodes[l], o, inv, best, &tl), hr = slab(M.nodes[r], o, inv, best, &tr);
+    if (hl && hr) {
+      int nearc = tl <= tr ? l : r, farc = tl <= tr ? r : l;
+      if (sp < 48) stack[sp++] = farc;
+      cur = nearc;
+    } else if (hl) cur = l;
+    else if (hr) cur = r;
+    else { if (sp == 0) break; cur = stack[--sp]; }
+  }
+  return hit ? best : -1.f;
+}
+
+// closest point on triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5)
+LG_DEV V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
+  V3 ab = b - a, ac = c - a, ap = p - a;
+  float d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0.f && d2 <= 0.f) return a;
+  V3 bp = p - b; float d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0.f && d4 <= d3) return b;
+  float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { float v = d1 / (d1 - d3); return a + v * ab; }
+  V3 cp = p - c; float d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0.f && d5 <= d6) return c;
+  float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { float w = d2 / (d2 - d6); return a + w * ac; }
+  float va = d3 * d6 - d5 * d4;
+  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) { float w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); return b + w * (c - b); }
+  float denom = 1.f / (va + vb + vc);
+  return a + (vb * denom) * ab + (vc * denom) * ac;
+}
+
+LG_DEV float box_dist2(const BvhNode& n, V3 p) {
+  float dx = fmaxf(fmaxf(n.bmin[0] - p.x, 0.f), p.x - n.bmax[0]);
+  float dy = fmaxf(fmaxf(n.bmin[1] - p.y, 0.f), p.y - n.bmax[1]);
+  float dz = fmaxf(fmaxf(n.bmin[2] - p.z, 0.f), p.z - n.bmax[2]);
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// closest point within max_dist; outputs the point and the (unnormalised) normal of the face it lies on
+LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V3* fn_out) {
+  float best2 = max_dist * max_dist; bool found = false;
+  V3 bestp = p, bestn = v3(0, 0, 1);
+  int stack[48]; int sp = 0; int cur = 0;
+  if (box_dist2(M.nodes[0], p) > best2) return false;
+  while (true) {
+    const BvhNode n = M.nodes[cur];
+    if (n.count > 0) {
+      for (int i = 0; i < n.count; ++i) {
+        const float4* T = M.tris + (size_t)(n.left_first + i) * 3;
+        float4 a4 = T[0], b4 = T[1], c4 = T[2];
+        V3 a = v3(a4.x, a4.y, a4.z), b = v3(b4.x, b4.y, b4.z), c = v3(c4.x, c4.y, c4.z);
+        V3 q = closest_on_triangle(p, a, b, c);
+        V3 dq = p - q; float d2 = dot(dq, dq);
+        if (d2 < best2) { best2 = d2; bestp = q; bestn = cross(b - a, c - a); found = true; }
+      }
+      if (sp == 0) break;
+      cur = stack[--sp];
+      continue;
+    }
+    const int l = n.left_first, r = l + 1;
+    float dl = box_dist2(M.nodes[l], p), dr = box_dist2(M.nodes[r], p);
+    bool hl = dl < best2, hr = dr < best2;
+    if (hl && hr) { int nearc = dl <= dr ? l : r, farc = dl <= dr ? r : l; if (sp < 48) stack[sp++] = farc; cur = nearc; }
+    else if (hl) cur = l;
+    else if (hr) cur = r;
+    else { if (sp == 0) break; cur = stack[--sp]; }
+  }
+  *cp_out = bestp; *fn_out = bestn;
+  return found;
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+// raycast_mesh (ray_caster.py:95-167): hit point o + t d, or the ray end point o + d max_dist and found = 0
+__global__ __launch_bounds__(256) void raycast_kernel(MeshView M, const float* __restrict__ o, const float* __restrict__ d, int64_t n,
+                                                      float max_dist, float* __restrict__ hits, uint8_t* __restrict__ found) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  V3 ro = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+  float t = trace_ray(M, ro, rd, max_dist);
+  bool hit = t >= 0.f;
+  V3 h = ro + (hit ? t : max_dist) * rd;
+  hits[3 * i] = h.x; hits[3 * i + 1] = h.y; hits[3 * i + 2] = h.z;
+  found[i] = hit ? 1 : 0;
+}
+
+// query_sdf_kernel (mesh_sdf.py:38-116): signed distance, unit gradient (pointing away from the surface outside, flipped
+// inside), face-normal fallback on the surface, max_distance / zero gradient when nothing is within range
+__global__ __launch_bounds__(256) void sdf_kernel(MeshView M, const float* __restrict__ pts, int64_t n, float max_dist,
+                                                  float* __restrict__ sdf, float* __restrict__ grad) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  V3 p = v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+  V3 cp, fn;
+  if (!closest_point(M, p, max_dist, &cp, &fn)) {
+    sdf[i] = max_dist; grad[3 * i] = 0.f; grad[3 * i + 1] = 0.f; grad[3 * i + 2] = 0.f;
+    return;
+  }
+  V3 diff = p - cp; float dist = norm(diff);
+  float fl = norm(fn); V3 nrm = fl > 0.f ? (1.f / fl) * fn : v3(0, 0, 1);
+  float sign = dot(diff, nrm) < 0.f ? -1.f : 1.f;
+  V3 g;
+  if (dist > 1e-6f) g = (sign / dist) * diff; else g = sign * nrm;
+  sdf[i] = sign * dist;
+  grad[3 * i] = g.x; grad[3 * i + 1] = g.y; grad[3 * i + 2] = g.z;
+}
+
+// RayCaster._update_ray_casting + LeggedRobotRayCast._get_raycast_distances (ray_caster.py:558-594,
+// legged_robot_raycast.py:262-297): one lane per (env, ray)
+__global__ __launch_bounds__(256) void raycaster_kernel(MeshView M, const float* __restrict__ root /* (N,13) */, const float* __restrict__ ray_o,
+                                                        const float* __restrict__ ray_d, int N, int R, float max_dist, int yaw_only,
+                                                        float* __restrict__ hits, uint8_t* __restrict__ found, float* __restrict__ dist) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)N * R) return;
+  int e = (int)(i / R), r = (int)(i - (int64_t)e * R);
+  const float* rs = root + (size_t)e * 13;
+  float q[4] = {rs[3], rs[4], rs[5], rs[6]};
+  if (yaw_only) {   // math_utils.quat_apply_yaw: zero x, y and renormalise
+    float nrm = fmaxf(sqrtf(q[2] * q[2] + q[3] * q[3]), 1e-9f);
+    q[0] = 0.f; q[1] = 0.f; q[2] /= nrm; q[3] /= nrm;
+  }
+  V3 pos = v3(rs[0], rs[1], rs[2]);
+  V3 o = quat_apply(q, v3(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2])) + pos;
+  V3 d = quat_apply(q, v3(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
+  float t = trace_ray(M, o, d, max_dist);
+  bool hit = t >= 0.f;
+  V3 h = o + (hit ? t : max_dist) * d;
+  hits[3 * i] = h.x; hits[3 * i + 1] = h.y; hits[3 * i + 2] = h.z;
+  found[i] = hit ? 1 : 0;
+  // distance from the ROBOT BASE position, not from the ray origin (legged_robot_raycast.py:278-285)
+  float dd = norm(h - pos);
+  float nd = 1.f - fminf(fmaxf(dd / max_dist, 0.f), 1.f);
+  dist[i] = hit ? nd : 0.f;
+}
+
+LG_DEV float cubic_w(float x) {   // Keys kernel, a = -0.75 (torch / torchvision bicubic)
+  const float a = -0.75f; x = fabsf(x);
+  if (x <= 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+  if (x < 2.f) return ((a * x - 5.f * a) * x + 8.f * a) * x - 4.f * a;
+  return 0.f;
+}
+
+// DepthCameraWarp.update + update_depth_buffer + process_depth_image (depth_camera.py:402-566, 84-138, 56-69):
+// one workgroup per env; the raw H x W depth image lives in LDS between the ray pass and the resize pass.
+__global__ __launch_bounds__(256) void depth_kernel(MeshView M, const float* __restrict__ root, const float* __restrict__ ray_d /* (H*W,3) */,
+                                                    const int64_t* __restrict__ ep_len, int W, int H, int RW, int RH, int buffer_len,
+                                                    float near_clip, float far_clip, float px, float py, float pz,
+                                                    float qx, float qy, float qz, float qw, const float* __restrict__ env_noise,
+                                                    float* __restrict__ cam_pos, float* __restrict__ cam_rot, float* __restrict__ depth_buffer) {
+  extern __shared__ float img[];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const float* rs = root + (size_t)e * 13;
+  const float bq[4] = {rs[3], rs[4], rs[5], rs[6]};
+  // camera pose: position = base + R(base) offset; rotation = quat_mul(base, offset) in Isaac Gym's xyzw convention
+  V3 cpos = v3(rs[0], rs[1], rs[2]) + quat_apply(bq, v3(px, py, pz));
+  float cq[4];
+  {
+    float x1 = bq[0], y1 = bq[1], z1 = bq[2], w1 = bq[3], x2 = qx, y2 = qy, z2 = qz, w2 = qw;
+    float ww = (z1 + x1) * (x2 + y2), yy = (w1 - y1) * (w2 + z2), zz = (w1 + y1) * (w2 - z2);
+    float xx = ww + yy + zz, qq = 0.5f * (xx + (z1 - x1) * (x2 - y2));
+    cq[3] = qq - ww + (z1 - y1) * (y2 - z2); cq[0] = qq - xx + (x1 + w1) * (x2 + w2);
+    cq[1] = qq - yy + (w1 - x1) * (y2 + z2); cq[2] = qq - zz + (z1 + y1) * (w2 - x2);
+  }
+  if (tid == 0) {
+    cam_pos[3 * e] = cpos.x; cam_pos[3 * e + 1] = cpos.y; cam_pos[3 * e + 2] = cpos.z;
+    cam_rot[4 * e] = cq[0]; cam_rot[4 * e + 1] = cq[1]; cam_rot[4 * e + 2] = cq[2]; cam_rot[4 * e + 3] = cq[3];
+  }
+  const float noise = env_noise ? env_noise[e] : 0.f;
+  for (int p = tid; p < W * H; p += 256) {
+    V3 d = quat_apply(cq, v3(ray_d[3 * p], ray_d[3 * p + 1], ray_d[3 * p + 2]));
+    float t = trace_ray(M, cpos, d, far_clip);
+    float depth = t >= 0.f ? -(t * norm(d)) : -far_clip;
+    depth += noise;
+    img[p] = fminf(fmaxf(depth, -far_clip), -near_clip);
+  }
+  __syncthreads();
+  const bool init = ep_len[e] <= 1;
+  const float sx = (float)W / (float)RW, sy = (float)H / (float)RH;
+  float* buf = depth_buffer + (size_t)e * buffer_len * RW * RH;
+  for (int p = tid; p < RW * RH; p += 256) {
+    int oy = p / RW, ox = p - oy * RW;
+    float v;
+    if (RW == W && RH == H) v = img[p];
+    else {   // bicubic, align_corners = False, no antialias
+      float fx = (ox + 0.5f) * sx - 0.5f, fy = (oy + 0.5f) * sy - 0.5f;
+      int ix = (int)floorf(fx), iy = (int)floorf(fy);
+      float tx = fx - ix, ty = fy - iy, acc = 0.f;
+#pragma unroll
+      for (int m = -1; m <= 2; ++m) {
+        int yy = min(max(iy + m, 0), H - 1); float wy = cubic_w(ty - m);
+        float row = 0.f;
+#pragma unroll
+        for (int k = -1; k <= 2; ++k) { int xx = min(max(ix + k, 0), W - 1); row += cubic_w(tx - k) * img[yy * W + xx]; }
+        acc += wy * row;
+      }
+      v = acc;
+    }
+    v = (v * -1.f - near_clip) / (far_clip - near_clip) - 0.5f;   // normalize_depth_image
+    if (init) { for (int k = 0; k < buffer_len; ++k) buf[(size_t)k * RW * RH + p] = v; }
+    else {
+      for (int k = 0; k + 1 < buffer_len; ++k) buf[(size_t)k * RW * RH + p] = buf[(size_t)(k + 1) * RW * RH + p];
+      buf[(size_t)(buffer_len - 1) * RW * RH + p] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char* lg_mesh_last_error(lg_mesh* m) { return m ? m->err.c_str() : g_mesh_err.c_str(); }
+
+void lg_mesh_destroy(lg_mesh* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->d_nodes) (void)hipFree(m->d_nodes);
+  if (m->d_tris) (void)hipFree(m->d_tris);
+  delete m;
+}
+
+lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t* triangles, int64_t n_triangles, int device_id) {
+  if (!vertices || !triangles || n_vertices <= 0 || n_triangles <= 0) { g_mesh_err = "empty mesh"; return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_mesh_err = "no HIP device: mesh queries have no CPU path"; return nullptr; }
+  if (device_id < 0 || device_id >= ndev || hipSetDevice(device_id) != hipSuccess) { g_mesh_err = "bad device"; return nullptr; }
+  std::vector<BuildTri> t((size_t)n_triangles);
+  for (int64_t i = 0; i < n_triangles; ++i) {
+    for (int v = 0; v < 3; ++v) {
+      int32_t idx = triangles[3 * i + v];
+      if (idx < 0 || idx >= n_vertices) { g_mesh_err = "triangle index out of range"; return nullptr; }
+      for (int k = 0; k < 3; ++k) t[i].v[3 * v + k] = vertices[3 * (int64_t)idx + k];
+    }
+    for (int k = 0; k < 3; ++k) t[i].c[k] = (t[i].v[k] + t[i].v[3 + k] + t[i].v[6 + k]) / 3.f;
+  }
+  std::vector<BvhNode> nodes; nodes.reserve((size_t)n_triangles); nodes.push_back(BvhNode());
+  Builder b{t, nodes};
+  b.build(0, 0, (int)n_triangles);
+  std::vector<float4> packed((size_t)n_triangles * 3);
+  for (int64_t i = 0; i < n_triangles; ++i)
+    for (int v = 0; v < 3; ++v) packed[3 * i + v] = make_float4(t[i].v[3 * v], t[i].v[3 * v + 1], t[i].v[3 * v + 2], 0.f);
+  lg_mesh* m = new lg_mesh();
+  m->device = device_id; m->n_tris = n_triangles; m->n_nodes = (int64_t)nodes.size();
+  if (hipMalloc((void**)&m->d_nodes, nodes.size() * sizeof(BvhNode)) != hipSuccess ||
+      hipMalloc((void**)&m->d_tris, packed.size() * sizeof(float4)) != hipSuccess ||
+      hipMemcpy(m->d_nodes, nodes.data(), nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(m->d_tris, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
+    g_mesh_err = "device allocation / upload of the BVH failed"; lg_mesh_destroy(m); return nullptr;
+  }
+  return m;
+}
+
+int lg_mesh_info(lg_mesh* m, int64_t out[2]) { if (!m) return LG_ERR_INVALID; out[0] = m->n_tris; out[1] = m->n_nodes; return LG_OK; }
+
+#define MESH_TRY(m, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (m)->err = std::string(#expr) + ": " + hipGetErrorString(_e); return LG_ERR_HIP; } } while (0)
+
+int lg_raycast_mesh(lg_mesh* m, const float* origins, const float* dirs, int64_t n_rays, float max_dist, float* hits, uint8_t* found, void* stream) {
+  if (!m || !origins || !dirs || !hits || !found || n_rays < 0) return LG_ERR_INVALID;
+  if (n_rays == 0) return LG_OK;
+  MeshView M{m->d_nodes, m->d_tris};
+  hipLaunchKernelGGL(raycast_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, origins, dirs, n_rays, max_dist, hits, found);
+  MESH_TRY(m, hipGetLastError());
+  return LG_OK;
+}
+
+int lg_mesh_query_sdf(lg_mesh* m, const float* points, int64_t n, float max_dist, float* sdf, float* grad, void* stream) {
+  if (!m || !points || !sdf || !grad || n < 0) return LG_ERR_INVALID;
+  if (n == 0) return LG_OK;
+  MeshView M{m->d_nodes, m->d_tris};
+  hipLaunchKernelGGL(sdf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, points, n, max_dist, sdf, grad);
+  MESH_TRY(m, hipGetLastError());
+  return LG_OK;
+}
+
+int lg_raycaster_update(lg_mesh* m, const float* root_states, const float* ray_origins, const float* ray_dirs, int32_t num_envs,
+                        int32_t num_rays, float max_dist, int32_t attach_yaw_only, float* ray_hits, uint8_t* hits_found,
+                        float* raycast_distances, void* stream) {
+  if (!m || !root_states || !ray_origins || !ray_dirs || !ray_hits || !hits_found || !raycast_distances || num_envs <= 0 || num_rays <= 0)
+    return LG_ERR_INVALID;
+  MeshView M{m->d_nodes, m->d_tris};
+  int64_t n = (int64_t)num_envs * num_rays;
+  hipLaunchKernelGGL(raycaster_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, root_states, ray_origins,
+                     ray_dirs, num_envs, num_rays, max_dist, attach_yaw_only, ray_hits, hits_found, raycast_distances);
+  MESH_TRY(m, hipGetLastError());
+  return LG_OK;
+}
+
+int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* root_states, const float* ray_dirs, const int64_t* episode_length_buf,
+                           int32_t num_envs, const float* env_noise, float* camera_pos, float* camera_rot, float* depth_buffer, void* stream) {
+  if (!m || !p || !root_states || !ray_dirs || !episode_length_buf || !camera_pos || !camera_rot || !depth_buffer || num_envs <= 0)
+    return LG_ERR_INVALID;
+  if (p->width <= 0 || p->height <= 0 || p->resized_width <= 0 || p->resized_height <= 0 || p->buffer_len <= 0) return LG_ERR_INVALID;
+  size_t lds = (size_t)p->width * p->height * sizeof(float);
+  if (lds > 64 * 1024) { m->err = "depth image too large for the LDS-staged resize"; return LG_ERR_UNSUPPORTED; }
+  MeshView M{m->d_nodes, m->d_tris};
+  hipLaunchKernelGGL(depth_kernel, dim3(num_envs), dim3(256), lds, (hipStream_t)stream, M, root_states, ray_dirs, episode_length_buf,
+                     p->width, p->height, p->resized_width, p->resized_height, p->buffer_len, p->near_clip, p->far_clip,
+                     p->position[0], p->position[1], p->position[2], p->quat_offset[0], p->quat_offset[1], p->quat_offset[2],
+                     p->quat_offset[3], env_noise, camera_pos, camera_rot, depth_buffer);
+  MESH_TRY(m, hipGetLastError());
+  return LG_OK;
+}
+
+}  // extern "C"

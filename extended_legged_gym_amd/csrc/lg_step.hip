@@ -44,6 +44,7 @@ struct DevCtx {
   double* ep_stats;
   const float* terrain_origins;
   const float *noise_vec, *height_points;
+  const float* extra_obs;   // (N, cfg.num_extra_obs) caller-owned rows appended to the observation
   float* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
   int nblocks_post;
   unsigned long long* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
@@ -965,6 +966,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
       if (idx >= O) break;
       float o;
       if (idx < 48) o = s_prop[el][idx];
+      else if (idx >= 48 + P) o = C->extra_obs ? C->extra_obs[(size_t)e * g.num_extra_obs + (idx - 48 - P)] : 0.f;
       else { float h = (s_rootz[el] - 0.5f) - s_h[el][idx - 48]; o = fminf(fmaxf(h, -1.f), 1.f) * g.obs_scale_height; }
       if (g.add_noise) o += (2.f * u[i] - 1.f) * C->noise_vec[idx];
       o = fminf(fmaxf(o, -g.clip_observations), g.clip_observations);
@@ -1078,7 +1080,8 @@ static const char* validate(const lg_config* cfg, const lg_robot_model* model, c
   if (cfg->num_envs <= 0) return "num_envs must be positive";
   if (cfg->num_reward_terms < 0 || cfg->num_reward_terms > LG_MAX_REWARD_TERMS) return "too many reward terms";
   if (cfg->num_height_points > MAX_P) return "num_height_points exceeds the 192 points the post kernel stages in LDS";
-  if (cfg->num_obs != 48 + (cfg->measure_heights ? cfg->num_height_points : 0)) return "num_obs does not match the observation layout";
+  if (cfg->num_extra_obs < 0) return "num_extra_obs is negative";
+  if (cfg->num_obs != 48 + (cfg->measure_heights ? cfg->num_height_points : 0) + cfg->num_extra_obs) return "num_obs does not match the observation layout";
   if (model->num_bodies != 1 + 4 * (3 + model->has_foot_body) || model->num_bodies > LG_MAX_BODIES) return "unsupported body count";
   if (cfg->decimation <= 0 || cfg->sim_dt <= 0.f) return "bad dt / decimation";
   if (cfg->resampling_steps <= 0) return "resampling_steps must be positive";
@@ -1232,6 +1235,24 @@ int lg_step(lg_ctx* c, const float* actions, void* stream) {
   hipLaunchKernelGGL(physics_kernel<0>, dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact);
   if (ev) (void)hipEventRecord(ev[1], st);
   return launch_post(c, st, ev);
+}
+
+int lg_set_extra_obs(lg_ctx* c, const float* dptr) {
+  if (!c) return LG_ERR_INVALID;
+  if (c->h.cfg.num_extra_obs > 0 && !dptr) { c->err = "extra obs buffer is null"; return LG_ERR_INVALID; }
+  c->h.extra_obs = dptr;
+  HIP_TRY(c, hipMemcpy(c->d, &c->h, sizeof(DevCtx), hipMemcpyHostToDevice));
+  return LG_OK;
+}
+
+int lg_step_physics(lg_ctx* c, const float* actions, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (!actions) { c->err = "actions is null"; return LG_ERR_INVALID; }
+  const int nb = (c->h.N + EPB - 1) / EPB;
+  const int nact = (c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET && c->split) ? 3 : 0;
+  hipLaunchKernelGGL(physics_kernel<0>, dim3(nb), dim3(64 * (1 + nact)), 0, (hipStream_t)stream, c->d, actions, c->h.cfg.decimation, nact);
+  HIP_TRY(c, hipGetLastError());
+  return LG_OK;
 }
 
 int lg_profile_begin(lg_ctx* c, int32_t max_samples, int32_t stride) {

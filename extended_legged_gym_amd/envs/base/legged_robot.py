@@ -83,7 +83,7 @@ class LeggedRobot(BaseTask):
         # env shards of a multi-GPU job draw from disjoint Philox streams
         seed += 1000003 * int(getattr(self.cfg, "rng_stream_offset", 0))
         self.setup = NativeSetup(self.cfg, self.sim_params, self.robot_model, terrain=self.terrain, seed=seed,
-                                 gait=self._gait_config())
+                                 gait=self._gait_config(), num_extra_obs=self._num_extra_obs())
         self.core = NativeCore(self.setup, self.device)
         t = self.core.t
 
@@ -119,6 +119,9 @@ class LeggedRobot(BaseTask):
 
     def _gait_config(self):
         return None
+
+    def _num_extra_obs(self):
+        return 0
 
     def _get_env_origins(self):
         """Terrain platforms on rough terrain, a grid otherwise (`legged_robot.py:817-844`)."""

@@ -122,7 +122,7 @@ class NativeSetup:
     """Owns the structs plus the numpy buffers their pointers refer to (keeps them alive)."""
 
     def __init__(self, cfg, sim_params, model, terrain=None, seed=0, rng_mode=abi.LG_RNG_PHILOX, gait=None,
-                 reward_stage=None):
+                 reward_stage=None, num_extra_obs=0):
         self.model_dict = model
         self.model = model_struct(model)
         dt = cfg.control.decimation * sim_params.dt
@@ -176,7 +176,8 @@ class NativeSetup:
         self.height_points = height_points(cfg) if cfg.terrain.measure_heights else np.zeros((0, 2), np.float32)
         c.num_height_points = self.height_points.shape[0]
         c.height_points = self.height_points.ctypes.data_as(C.POINTER(C.c_float))
-        expect = 48 + (c.num_height_points if cfg.terrain.measure_heights else 0)
+        c.num_extra_obs = int(num_extra_obs)
+        expect = 48 + (c.num_height_points if cfg.terrain.measure_heights else 0) + c.num_extra_obs
         if num_obs != expect:
             raise ValueError(f"num_observations={num_obs} but the observation layout has {expect} entries")
 

@@ -92,6 +92,17 @@ class NativeCore:
         a = self._f32(actions)
         self._check(self.lib.lg_step(self.ctx, C.c_void_p(a.data_ptr()), self._stream()))
 
+    def set_extra_obs(self, rows):
+        """Bind the (N, num_extra_obs) float32 device tensor appended to every observation row."""
+        assert rows.is_contiguous() and rows.dtype == torch.float32
+        self._extra_obs = rows
+        self._check(self.lib.lg_set_extra_obs(self.ctx, C.c_void_p(rows.data_ptr())))
+
+    def compute_torques_and_simulate(self, actions):
+        """The physics half of `lg_step` (clip actions, `decimation` x (actuators + one dt)), without post-physics."""
+        a = self._f32(actions)
+        self._check(self.lib.lg_step_physics(self.ctx, C.c_void_p(a.data_ptr()), self._stream()))
+
     def compute_torques(self, actions=None):
         if actions is None:
             self._check(self.lib.lg_compute_torques(self.ctx, None, self._stream()))

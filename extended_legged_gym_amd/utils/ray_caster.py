@@ -1,0 +1,208 @@
+"""Ray-casting sensor with the reference's interface (`utils/ray_caster.py`): `PatternType`, `RayCasterPatternCfg`,
+`RayCasterCfg`, `RayCasterData`, `RayCaster`, `raycast_mesh`.  The Warp kernel + numpy round trip
+(`ray_caster.py:95-167`) is replaced by `lg_raycast_mesh`; the sensor update (`:518-594`) plus the distance observation of
+`LeggedRobotRayCast._get_raycast_distances` is ONE kernel (`lg_raycaster_update`) with device-resident inputs/outputs."""
+import ctypes as C
+from dataclasses import dataclass, field
+from enum import Enum
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+from extended_legged_gym_amd.utils.isaac_torch_utils import quat_apply
+from extended_legged_gym_amd.utils.mesh import DeviceMesh, convert_to_warp_mesh  # noqa: F401
+
+
+def raycast_mesh(ray_origins: torch.Tensor, ray_directions: torch.Tensor, max_dist: float = 100.0,
+                 mesh: DeviceMesh = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Cast rays of shape (B, R, 3) or (R, 3) against `mesh`: hit points (ray end points on a miss) and a bool mask."""
+    if mesh is None:
+        raise ValueError("Mesh cannot be None")
+    if ray_origins.dim() not in (2, 3):
+        raise ValueError(f"Expected ray_origins to have rank 2 or 3, got {ray_origins.dim()}")
+    shape = ray_origins.shape
+    o = ray_origins.reshape(-1, 3).to(device=mesh.device, dtype=torch.float32).contiguous()
+    d = ray_directions.reshape(-1, 3).to(device=mesh.device, dtype=torch.float32).contiguous()
+    hits = torch.empty_like(o)
+    found = torch.empty(o.shape[0], dtype=torch.uint8, device=mesh.device)
+    mesh._check(mesh.lib.lg_raycast_mesh(mesh.handle, C.c_void_p(o.data_ptr()), C.c_void_p(d.data_ptr()), o.shape[0],
+                                         float(max_dist), C.c_void_p(hits.data_ptr()), C.c_void_p(found.data_ptr()),
+                                         mesh._stream()))
+    return hits.reshape(shape), found.view(torch.bool).reshape(shape[:-1])
+
+
+class PatternType(Enum):
+    SINGLE_RAY = "single_ray"
+    GRID = "grid"
+    CONE = "cone"
+    SPHERICAL = "spherical"
+    SPHERICAL2 = "spherical2"
+
+
+@dataclass
+class RayCasterPatternCfg:
+    pattern_type: PatternType = PatternType.SINGLE_RAY
+    single_ray_direction: List[float] = field(default_factory=lambda: [1.0, 0.0, 0.0])
+    grid_dims: Tuple[int, int] = (5, 5)
+    grid_width: float = 1.0
+    grid_height: float = 1.0
+    cone_num_rays: int = 16
+    cone_angle: float = 30.0                       # degrees
+    spherical_num_azimuth: int = 8
+    spherical_num_elevation: int = 4
+    spherical2_num_points: int = 32
+    spherical2_polar_axis: List[float] = field(default_factory=lambda: [0.0, 0.0, 1.0])
+    ellipsoid_axes: List[float] = field(default_factory=lambda: [1.0, 1.0, 0.3])
+
+    def create_pattern(self, device: str = "cuda:0") -> Tuple[torch.Tensor, torch.Tensor]:
+        """Ray origins (all zero) and unit directions, (n_rays, 3) each (`ray_caster.py:205-363`), forward = +x."""
+        pt = self.pattern_type
+        if pt == PatternType.SINGLE_RAY:
+            dirs = torch.tensor([self.single_ray_direction])
+        elif pt == PatternType.GRID:
+            rows, cols = self.grid_dims
+            xs = torch.linspace(-self.grid_width / 2, self.grid_width / 2, cols)
+            ys = torch.linspace(-self.grid_height / 2, self.grid_height / 2, rows)
+            yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+            dirs = torch.stack([torch.ones_like(xx), xx, yy], dim=-1).reshape(-1, 3)
+            dirs = dirs / torch.norm(dirs, dim=1, keepdim=True)
+        elif pt == PatternType.CONE:
+            half = self.cone_angle * (np.pi / 180)
+            ang = torch.linspace(0, 2 * np.pi * (1.0 - 1.0 / self.cone_num_rays), self.cone_num_rays)
+            spread = torch.sin(torch.tensor(half))
+            fwd = torch.cos(torch.tensor(half))
+            dirs = torch.stack([fwd.expand_as(ang), torch.cos(ang) * spread, torch.sin(ang) * spread], dim=-1)
+            dirs = torch.tensor(dirs.tolist())         # the reference goes through Python floats (.item())
+            dirs = dirs / torch.norm(dirs, dim=1, keepdim=True)
+        elif pt == PatternType.SPHERICAL:
+            az = torch.linspace(0, 2 * np.pi * (1.0 - 1.0 / self.spherical_num_azimuth), self.spherical_num_azimuth)
+            el = torch.linspace(-np.pi / 2, np.pi / 2, self.spherical_num_elevation)
+            ee, aa = torch.meshgrid(el, az, indexing="ij")
+            dirs = torch.stack([torch.cos(ee) * torch.cos(aa), torch.cos(ee) * torch.sin(aa), torch.sin(ee)], dim=-1)
+            dirs = torch.tensor(dirs.reshape(-1, 3).tolist())
+        elif pt == PatternType.SPHERICAL2:
+            n = self.spherical2_num_points
+            golden = (1 + 5 ** 0.5) / 2
+            d = torch.zeros((n, 3))
+            for i in range(n):                          # Fibonacci lattice, y runs from 1 to -1
+                y = 1 - (2 * i) / (n - 1)
+                radius = (1 - y * y) ** 0.5
+                theta = 2 * np.pi * i / golden
+                d[i, 0], d[i, 1], d[i, 2] = radius * np.cos(theta), y, radius * np.sin(theta)
+            d = d * torch.tensor(self.ellipsoid_axes)
+            dirs = d / torch.norm(d, dim=1, keepdim=True)
+            if not np.allclose(self.spherical2_polar_axis, [0.0, 0.0, 1.0]):
+                axis = torch.tensor(self.spherical2_polar_axis)
+                axis = axis / torch.norm(axis)
+                z = torch.tensor([0.0, 0.0, 1.0])
+                rot_axis = torch.cross(z, axis, dim=0)
+                angle = None
+                if torch.norm(rot_axis) < 1e-6:
+                    if torch.dot(z, axis) <= 0:
+                        rot_axis, angle = torch.tensor([1.0, 0.0, 0.0]), torch.tensor(np.pi)
+                else:
+                    rot_axis = rot_axis / torch.norm(rot_axis)
+                    angle = torch.acos(torch.clamp(torch.dot(z, axis), -1.0, 1.0))
+                if angle is not None:
+                    s, c = torch.sin(angle / 2), torch.cos(angle / 2)
+                    # reference quirk (`ray_caster.py:355-358`): built as [w, x, y, z], consumed as (x, y, z, w)
+                    q = torch.stack([c, rot_axis[0] * s, rot_axis[1] * s, rot_axis[2] * s]).float()
+                    dirs = quat_apply(q.repeat(n, 1), dirs)
+        else:
+            raise ValueError(f"Unknown pattern type: {self.pattern_type}")
+        dirs = dirs.to(torch.float32)
+        return torch.zeros_like(dirs).to(device), dirs.to(device)
+
+
+@dataclass
+class RayCasterCfg:
+    pattern_cfg: RayCasterPatternCfg = field(default_factory=RayCasterPatternCfg)
+    mesh_paths: List[str] = field(default_factory=list)
+    vertices: torch.Tensor = None
+    triangles: torch.Tensor = None
+    max_distance: float = 100.0
+    attach_yaw_only: bool = True
+    offset_pos: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0])
+    offset_rot: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0, 1.0])
+    update_period: float = 0.0
+
+
+@dataclass
+class RayCasterData:
+    ray_hits: torch.Tensor = None          # (num_envs, num_rays, 3)
+    ray_hits_found: torch.Tensor = None    # (num_envs, num_rays) bool
+    pos: torch.Tensor = None
+    rot: torch.Tensor = None
+
+
+class RayCaster:
+    """Ray-casting sensor attached to each robot base (`ray_caster.py:402-617`)."""
+
+    def __init__(self, cfg: RayCasterCfg, num_envs: int, device: str = "cuda:0", mesh: DeviceMesh = None):
+        self.cfg, self.num_envs, self.device = cfg, num_envs, device
+        self._timestamp = torch.zeros(num_envs, device=device)
+        self._timestamp_last_update = torch.zeros(num_envs, device=device)
+        self._is_outdated = torch.ones(num_envs, dtype=torch.bool, device=device)
+        self.meshes = {}
+        if mesh is not None:
+            self.meshes["custom_mesh"] = mesh
+        elif cfg.vertices is not None and cfg.triangles is not None:
+            self.meshes["custom_mesh"] = DeviceMesh(torch.as_tensor(cfg.vertices).cpu().numpy(),
+                                                    torch.as_tensor(cfg.triangles).cpu().numpy(), device)
+        elif cfg.mesh_paths:
+            from extended_legged_gym_amd.utils.obj_io import load_obj
+            for path in cfg.mesh_paths:
+                v, t = load_obj(path)
+                self.meshes[path] = DeviceMesh(v, t, device)
+        else:
+            raise ValueError("No mesh or vertices/triangles provided for ray casting.")
+        origins, dirs = cfg.pattern_cfg.create_pattern(device)
+        self.num_rays = len(dirs)
+        self._pattern_origins = (origins + torch.tensor(cfg.offset_pos, device=device)).contiguous()
+        self._pattern_dirs = dirs.contiguous()
+        self.ray_origins = self._pattern_origins.repeat(num_envs, 1, 1)
+        self.ray_directions = self._pattern_dirs.repeat(num_envs, 1, 1)
+        self._data = RayCasterData()
+        self._data.pos = torch.zeros(num_envs, 3, device=device)
+        self._data.rot = torch.zeros(num_envs, 4, device=device)
+        self._data.rot[:, 3] = 1.0
+        self._data.ray_hits = torch.zeros(num_envs, self.num_rays, 3, device=device)
+        self._hits_found_u8 = torch.zeros(num_envs, self.num_rays, dtype=torch.uint8, device=device)
+        self._data.ray_hits_found = self._hits_found_u8.view(torch.bool)
+        self.raycast_distances = torch.zeros(num_envs, self.num_rays, device=device)
+        self._is_initialized = True
+
+    def update_from_root_states(self, dt: float, root_states: torch.Tensor):
+        """All envs, every call (`update_period == 0`, the only mode the reference's env classes use): rays follow
+        the base pose in `root_states` (N, 13); fills hits, found mask and the normalised distance observation."""
+        self._timestamp += dt
+        mesh = next(iter(self.meshes.values()))
+        rs = root_states if root_states.is_contiguous() else root_states.contiguous()
+        mesh._check(mesh.lib.lg_raycaster_update(
+            mesh.handle, C.c_void_p(rs.data_ptr()), C.c_void_p(self._pattern_origins.data_ptr()),
+            C.c_void_p(self._pattern_dirs.data_ptr()), self.num_envs, self.num_rays, float(self.cfg.max_distance),
+            int(bool(self.cfg.attach_yaw_only)), C.c_void_p(self._data.ray_hits.data_ptr()),
+            C.c_void_p(self._hits_found_u8.data_ptr()), C.c_void_p(self.raycast_distances.data_ptr()), mesh._stream()))
+        self._data.pos, self._data.rot = rs[:, 0:3], rs[:, 3:7]
+        self._timestamp_last_update[:] = self._timestamp
+        self._is_outdated[:] = False
+
+    def update(self, dt: float, sensor_pos: torch.Tensor, sensor_rot: torch.Tensor, env_ids: torch.Tensor = None):
+        """Reference signature (`ray_caster.py:518-556`); `sensor_rot` is xyzw like every caller passes it."""
+        if env_ids is not None or self.cfg.update_period > 0.0:
+            raise NotImplementedError("partial / periodic ray-caster updates are not part of the native path")
+        rs = torch.zeros(self.num_envs, 13, device=self.device)
+        rs[:, 0:3], rs[:, 3:7] = sensor_pos, sensor_rot
+        self.update_from_root_states(dt, rs)
+
+    def reset(self, env_ids=None):
+        if env_ids is None:
+            env_ids = torch.arange(self.num_envs, device=self.device)
+        self._timestamp[env_ids] = 0.0
+        self._timestamp_last_update[env_ids] = 0.0
+        self._is_outdated[env_ids] = True
+
+    @property
+    def data(self) -> RayCasterData:
+        return self._data

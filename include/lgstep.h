@@ -56,7 +56,7 @@ enum lg_dtype { LG_F32 = 0, LG_I64 = 1, LG_U8 = 2, LG_I16 = 3, LG_I32 = 4, LG_F6
 enum lg_control { LG_CTRL_P = 0, LG_CTRL_V = 1, LG_CTRL_T = 2, LG_CTRL_ACTUATOR_NET = 3 };
 
 /* terrain mesh type (legged_robot.py:259-274).  LG_MESH_HEIGHTFIELD collides against the int16 grid itself. */
-enum lg_mesh { LG_MESH_PLANE = 0, LG_MESH_HEIGHTFIELD = 1 };
+enum lg_mesh_type { LG_MESH_PLANE = 0, LG_MESH_HEIGHTFIELD = 1 };
 
 /* rng_mode: counter-based Philox4x32-10 in-kernel, or uniforms injected by the host (parity / golden tests) */
 enum lg_rng { LG_RNG_PHILOX = 0, LG_RNG_INJECT = 1 };
@@ -161,7 +161,7 @@ typedef struct lg_robot_model {
 } lg_robot_model;
 
 typedef struct lg_terrain {
-  int32_t mesh_type;                  /* lg_mesh */
+  int32_t mesh_type;                  /* lg_mesh_type */
   int32_t rows, cols;                 /* height_samples shape (tot_rows, tot_cols); 0 for plane */
   float horizontal_scale, vertical_scale, border_size;
   float static_friction;
@@ -174,6 +174,8 @@ typedef struct lg_terrain {
 typedef struct lg_config {
   int32_t abi_version;
   int32_t num_envs, num_obs, num_height_points;
+  int32_t num_extra_obs;              /* observation columns appended after the height scan from a caller-owned device
+                                         buffer (lg_set_extra_obs): LeggedRobotRayCast's raycast_distances */
   float sim_dt; int32_t decimation; float gravity[3];
   /* control */
   int32_t control_type; float action_scale;
@@ -232,6 +234,10 @@ int lg_get_tensor(lg_ctx* ctx, int tensor_id, void** dptr, int64_t shape[4], int
  * fused post-physics step.  `actions` is a device pointer to (N,12) f32.  Replaces legged_robot.py:93-110. */
 int lg_step(lg_ctx* ctx, const float* actions, void* stream);
 
+/* The physics half of lg_step only (LR:93-103): used when a sensor update (ray caster, LR raycast :219-230) must run
+ * between the last substep and post_physics_step. */
+int lg_step_physics(lg_ctx* ctx, const float* actions, void* stream);
+
 /* Pieces of lg_step, exposed because the reference exposes them as overridable methods / gym calls. */
 int lg_compute_torques(lg_ctx* ctx, const float* actions, void* stream);  /* -> LG_T_TORQUES (and LSTM state) */
 int lg_simulate(lg_ctx* ctx, void* stream);                               /* one dt with LG_T_TORQUES applied */
@@ -239,6 +245,48 @@ int lg_post_physics_step(lg_ctx* ctx, void* stream);
 
 /* Reset the listed envs (device pointer to n int32 ids).  `update_curriculum` = the reference's init_done. */
 int lg_reset_idx(lg_ctx* ctx, const int32_t* env_ids, int32_t n, int32_t update_curriculum, void* stream);
+
+/* Bind the (N, num_extra_obs) f32 device buffer whose rows are appended to the observation (legged_robot_raycast.py:252-254). */
+int lg_set_extra_obs(lg_ctx* ctx, const float* dptr);
+
+/* ---- triangle-mesh queries (replace NVIDIA Warp: utils/ray_caster.py:39-167, utils/mesh_sdf.py:32-116, utils/depth_camera.py) ---- */
+typedef struct lg_mesh lg_mesh;
+
+/* Build a BVH over (vertices (n,3) f32, triangles (m,3) i32) — HOST pointers — and upload it to `device_id`
+ * (wp.Mesh(points, indices), ray_caster.py:23-42). */
+lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t* triangles, int64_t n_triangles, int device_id);
+void lg_mesh_destroy(lg_mesh* mesh);
+int lg_mesh_info(lg_mesh* mesh, int64_t out[2]);            /* {#triangles, #bvh nodes} */
+const char* lg_mesh_last_error(lg_mesh* mesh);
+
+/* raycast_mesh (ray_caster.py:95-167): device pointers, n rays; hits (n,3) = o + t d or o + d max_dist, found (n) u8. */
+int lg_raycast_mesh(lg_mesh* mesh, const float* origins, const float* dirs, int64_t n_rays, float max_dist,
+                    float* hits, uint8_t* found, void* stream);
+
+/* MeshSDF.query (mesh_sdf.py:230-336, kernel :38-116): signed distance (n) and unit gradient (n,3); max_dist / 0 when out of range. */
+int lg_mesh_query_sdf(lg_mesh* mesh, const float* points, int64_t n_points, float max_dist, float* sdf, float* grad, void* stream);
+
+/* RayCaster._update_ray_casting + LeggedRobotRayCast._get_raycast_distances (ray_caster.py:558-594,
+ * legged_robot_raycast.py:262-297) for all envs: rays = pattern rotated by the base (yaw-only or full) + base position. */
+int lg_raycaster_update(lg_mesh* mesh, const float* root_states, const float* ray_origins, const float* ray_dirs,
+                        int32_t num_envs, int32_t num_rays, float max_dist, int32_t attach_yaw_only,
+                        float* ray_hits, uint8_t* hits_found, float* raycast_distances, void* stream);
+
+typedef struct lg_depth_params {
+  int32_t width, height;                 /* cfg.depth.original */
+  int32_t resized_width, resized_height; /* cfg.depth.resized */
+  int32_t buffer_len;
+  float near_clip, far_clip;
+  float position[3];                     /* camera mount in the base frame */
+  float quat_offset[4];                  /* mount rotation exactly as the reference hands it to quat_mul (depth_camera.py:546-562) */
+} lg_depth_params;
+
+/* DepthCameraWarp.update + update_depth_buffer (depth_camera.py:402-566): camera pose from the base pose, one ray per
+ * pixel, depth = -distance (or -far_clip), + per-env noise, clip, bicubic resize, normalise to [-0.5, 0.5], FIFO of
+ * buffer_len frames (all frames = newest when episode_length_buf <= 1).  env_noise may be NULL. */
+int lg_depth_camera_update(lg_mesh* mesh, const lg_depth_params* params, const float* root_states, const float* ray_dirs,
+                           const int64_t* episode_length_buf, int32_t num_envs, const float* env_noise,
+                           float* camera_pos, float* camera_rot, float* depth_buffer, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the caller's stream around the kernels of lg_step.
  * lg_profile_begin arms up to `max_samples` instrumented steps (every `stride`-th lg_step call is sampled);

@@ -42,6 +42,9 @@ def lib():
         L.lgo_set_threads.argtypes = [C.c_int]
         L.lgo_max_threads.restype = C.c_int
         L.lgo_debug_terrain.argtypes = [vp, C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.lgo_set_extra_obs.argtypes = [vp, vp]
+        L.lgo_raycast_bruteforce.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_float, vp, vp]
+        L.lgo_sdf_bruteforce.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_float, vp, vp]
         _lib = L
     return _lib
 
@@ -102,3 +105,22 @@ class OracleEnv:
             self.close()
         except Exception:
             pass
+
+
+def raycast_bruteforce(vertices, triangles, origins, dirs, max_dist):
+    """O(rays x triangles) closest two-sided hit; returns (hits (n,3), found (n,) bool)."""
+    v = np.ascontiguousarray(vertices, np.float32); t = np.ascontiguousarray(triangles, np.int32)
+    o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3); d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+    hits = np.zeros_like(o); found = np.zeros(len(o), np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().lgo_raycast_bruteforce(p(v), p(t), len(t), p(o), p(d), len(o), float(max_dist), p(hits), p(found))
+    return hits, found.astype(bool)
+
+
+def sdf_bruteforce(vertices, triangles, points, max_dist):
+    v = np.ascontiguousarray(vertices, np.float32); t = np.ascontiguousarray(triangles, np.int32)
+    q = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+    sdf = np.zeros(len(q), np.float32); grad = np.zeros_like(q)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().lgo_sdf_bruteforce(p(v), p(t), len(t), p(q), len(q), float(max_dist), p(sdf), p(grad))
+    return sdf, grad
