@@ -188,9 +188,11 @@ LG_DEV float box_dist2(const BvhNode& n, V3 p) {
   return dx * dx + dy * dy + dz * dz;
 }
 
-// closest point within max_dist; outputs the point and the (unnormalised) normal of the face it lies on
+// closest point within max_dist; outputs the point and the unit normal of the face that decides the sign.  When several
+// faces are equally close (the closest feature is a shared edge or vertex) the face whose plane is farthest from the
+// query point decides: that rule is independent of traversal order, so the BVH and a brute-force scan agree.
 LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V3* fn_out) {
-  float best2 = max_dist * max_dist; bool found = false;
+  float best2 = max_dist * max_dist; bool found = false; float bestabs = -1.f;
   V3 bestp = p, bestn = v3(0, 0, 1);
   int stack[48]; int sp = 0; int cur = 0;
   if (box_dist2(M.nodes[0], p) > best2) return false;
@@ -203,7 +205,18 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
         V3 a = v3(a4.x, a4.y, a4.z), b = v3(b4.x, b4.y, b4.z), c = v3(c4.x, c4.y, c4.z);
         V3 q = closest_on_triangle(p, a, b, c);
         V3 dq = p - q; float d2 = dot(dq, dq);
-        if (d2 < best2) { best2 = d2; bestp = q; bestn = cross(b - a, c - a); found = true; }
+        if (d2 > best2 * (1.f + 1e-5f) + 1e-12f) continue;
+        V3 fn = cross(b - a, c - a); float fl = norm(fn);
+        const bool strictly = !found || d2 < best2 * (1.f - 1e-5f) - 1e-12f;
+        if (strictly) { bestabs = -1.f; bestn = v3(0, 0, 1); }
+        if (fl > 1e-10f) {                     // degenerate (zero-area) faces never decide the sign
+          V3 nh = (1.f / fl) * fn;
+          float sd = dot(dq, nh);
+          float ab = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f);   // coincident faces of opposite orientation: outside wins
+          if (ab > bestabs) { bestn = nh; bestabs = ab; }
+        }
+        if (!found || d2 < best2) { best2 = d2; bestp = q; }
+        found = true;
       }
       if (sp == 0) break;
       cur = stack[--sp];
@@ -211,7 +224,8 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
     }
     const int l = n.left_first, r = l + 1;
     float dl = box_dist2(M.nodes[l], p), dr = box_dist2(M.nodes[r], p);
-    bool hl = dl < best2, hr = dr < best2;
+    const float lim = best2 * (1.f + 1e-5f) + 1e-12f;
+    bool hl = dl <= lim, hr = dr <= lim;
     if (hl && hr) { int nearc = dl <= dr ? l : r, farc = dl <= dr ? r : l; if (sp < 48) stack[sp++] = farc; cur = nearc; }
     else if (hl) cur = l;
     else if (hr) cur = r;
