@@ -47,6 +47,7 @@ struct DevCtx {
   const float* extra_obs;   // (N, cfg.num_extra_obs) caller-owned rows appended to the observation
   float* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
   int nblocks_post;
+  int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
   unsigned long long* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
 };
 
@@ -59,6 +60,7 @@ struct lg_ctx {
   void* aux = nullptr; // noise_vec, height_points, partials
   TensorInfo t[LG_T_COUNT];
   int device = 0;
+  unsigned long sync_calls = 0;
   int split = 1;       // fused step: run the LSTM actuators on three extra waves (LG_SPLIT=0 disables, diagnostic)
   std::string err;
   // optional per-kernel timing (lg_profile_begin / lg_profile_end)
@@ -260,7 +262,8 @@ LG_DEV void leg_torques(const DevCtx* __restrict__ C, const LegModel& lm_, const
 // MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
 // MODE 2: lg_compute_torques only.
 template <int MODE>
-__global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, int nact) {
+__global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, int nact,
+                                                      const int32_t* __restrict__ ids, int n) {
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
@@ -269,10 +272,12 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ __attribute__((aligned(16))) float wlstm[LG_LSTM_NPARAM + 3];
   __shared__ float xq[3][64], xqd[3][64], xtau[3][64], xroot[13][64], xbias[9][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int e = blockIdx.x * EPB + (lane >> 2);
+  // row kq of the launch <-> env e (identity, or ids[kq] for subset stepping: main-only / rollout-only steps)
+  const int kq = blockIdx.x * EPB + (lane >> 2);
   const int l = lane & 3;
-  const bool valid = e < C->N;
-  if (!valid) e = C->N - 1;          // whole quads are (in)valid together; invalid quads compute on a copy and store nothing
+  const bool valid = kq < n;
+  const int krow = valid ? kq : n - 1;   // whole quads are (in)valid together; invalid quads compute on a copy and store nothing
+  const int e = ids ? ids[krow] : krow;
   const lg_robot_model* __restrict__ m = &C->model;
   const lg_config& g = C->cfg;
   const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   if (MODE == 0 && wv > 0) {
     // ---------------------------------------------------------------- actuator wave: joint j of leg l of env e
     const int j = wv - 1, d = 3 * l + j;
-    float a = actions_in[(size_t)e * 12 + d];
+    float a = actions_in[(size_t)krow * 12 + d];
     a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);
     const float tgt = a * g.action_scale + lm_.f(LM_DEFAULT_POS + j);
     const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + d;
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   if (MODE != 1 && !split) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      float a = actions_in ? actions_in[(size_t)e * 12 + 3 * l + j] : C->actions[(size_t)e * 12 + 3 * l + j];
+      float a = actions_in ? actions_in[(size_t)krow * 12 + 3 * l + j] : C->actions[(size_t)e * 12 + 3 * l + j];
       a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);        // LR:93-94
       act[j] = a;
       if (valid && actions_in) C->actions[(size_t)e * 12 + 3 * l + j] = a;
@@ -733,7 +738,10 @@ enum { S_ROOT = 0, S_DOF = 13, S_CF = 37, S_RB = S_CF + LG_MAX_BODIES * 3, S_ACT
        S_AIR = S_BAA + 3, S_CT = S_AIR + 4, S_BLV = S_CT + 4, S_BAV = S_BLV + 3, S_PG = S_BAV + 3, S_SUMS = S_PG + 3,
        S_GAIT = S_SUMS + LG_MAX_REWARD_TERMS, S_STRIDE = S_GAIT + 1 + 2 };
 
-__global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C) {
+// ids/n: optional env subset (row k of the launch <-> env ids[k]); mode 0 = LeggedRobot.post_physics_step,
+// mode 1 = RobotBatchRollout.post_physics_step_rollout (robot_batch_rollout.py:763-817: no callback, no termination,
+// no reset, rewards without episode sums).
+__global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int mode) {
   __shared__ float s_h[EPBP][MAX_P];
   __shared__ float s_env[EPBP][S_STRIDE];
   __shared__ float s_prop[EPBP][48];
@@ -746,9 +754,14 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
   __shared__ uint8_t s_did_reset[EPBP], s_root_dirty[EPBP];
   const lg_config& g = C->cfg; const lg_robot_model& m = C->model;
   const int tid = threadIdx.x, e0 = blockIdx.x * EPBP;
-  const int nenv = min(EPBP, C->N - e0);
+  const int nenv = min(EPBP, n - e0);
+  const bool ro = mode == 1;
+  __shared__ int s_e[EPBP];
+  if (tid < EPBP) s_e[tid] = tid < nenv ? (ids ? ids[e0 + tid] : e0 + tid) : 0;
+  __syncthreads();
   const int P = g.measure_heights ? C->P : 0;
-  const int64_t step = C->counters[0] + 1;   // LR:123 (finalize_kernel stores it)
+  const int64_t step = ro ? C->counters[3] + 1 : C->counters[0] + 1;   // LR:123 (finalize_kernel stores it)
+  const uint32_t rstream = ro ? 2u : 0u;
   const float dt = g.sim_dt * g.decimation;
   const int B = C->B;
 #ifdef LG_STAMPS
@@ -760,7 +773,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
 #define STAGE(OFF, SRC, LEN)                                                                   \
   for (int idx = tid; idx < nenv * (LEN); idx += 256) {                                         \
     int el = idx / (LEN), k = idx - el * (LEN);                                                 \
-    s_env[el][(OFF) + k] = (SRC)[(size_t)e0 * (LEN) + idx];                                     \
+    s_env[el][(OFF) + k] = (SRC)[(size_t)s_e[el] * (LEN) + k];                                     \
   }
   STAGE(S_ROOT, C->root, 13) STAGE(S_DOF, C->dof, 24) STAGE(S_CF, C->cforce, B * 3) STAGE(S_RB, C->rigid, B * 13)
   STAGE(S_ACT, C->actions, 12) STAGE(S_LACT, C->last_actions, 12) STAGE(S_LDV, C->last_dof_vel, 12) STAGE(S_TQ, C->torques, 12)
@@ -769,19 +782,21 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
 #undef STAGE
   for (int idx = tid; idx < nenv * g.num_reward_terms; idx += 256) {     // episode sums are (K, N): row k, envs contiguous
     int k = idx / nenv, el = idx - k * nenv;
-    s_env[el][S_SUMS + k] = C->ep_sums[(size_t)k * C->N + e0 + el];
+    s_env[el][S_SUMS + k] = C->ep_sums[(size_t)k * C->N + s_e[el]];
   }
-  if (tid < nenv * 4) s_lastc[tid >> 2][tid & 3] = C->last_contacts[(size_t)e0 * 4 + tid];
-  if (tid < nenv) { s_eplen[tid] = C->ep_len[e0 + tid]; s_flag[tid] = C->reset_buf[e0 + tid]; }
+  if (tid < nenv * 4) s_lastc[tid >> 2][tid & 3] = C->last_contacts[(size_t)s_e[tid >> 2] * 4 + (tid & 3)];
+  if (tid < nenv) { s_eplen[tid] = C->ep_len[s_e[tid]]; s_flag[tid] = C->reset_buf[s_e[tid]]; }
   if (tid < nenv * (LG_RS_NOISE / 4)) {          // one Philox call per (env, slot group): 8 lanes per env
     int el = tid / (LG_RS_NOISE / 4), gq = tid - el * (LG_RS_NOISE / 4);
-    uniform_draw4(C, e0 + el, gq, step, 0, &s_u[el][4 * gq]);
+    uniform_draw4(C, s_e[el], gq, step, rstream, &s_u[el][4 * gq]);
   }
   __syncthreads();
   STAMP(11);
 
   // ---- (1) height scan from the post-physics root pose (LR:400-401), all lanes, row-contiguous stores
-  if (P > 0) {
+  if (P > 0 && ro) {      // rollout steps keep the heights measured by the last main step (callback_rollout is a no-op)
+    for (int idx = tid; idx < nenv * P; idx += 256) { int el = idx / P, p = idx - el * P; s_h[el][p] = C->heights[(size_t)s_e[el] * C->P + p]; }
+  } else if (P > 0) {
     const bool plane = C->ter.mesh_type == LG_MESH_PLANE;
     for (int base = tid; base < nenv * P; base += 4 * 256) {
       float hgt[4]; int els[4], ps[4];
@@ -802,7 +817,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
 #pragma unroll
       for (int u = 0; u < 4; ++u) if (ps[u] >= 0) {
         s_h[els[u]][ps[u]] = hgt[u];
-        C->heights[(size_t)(e0 + els[u]) * C->P + ps[u]] = hgt[u];
+        C->heights[(size_t)s_e[els[u]] * C->P + ps[u]] = hgt[u];
       }
     }
   }
@@ -811,7 +826,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
 
   // ---- (2) one lane per env: everything scalar, in the reference's order, on the LDS copies
   if (tid < nenv) {
-    const int el = tid, e = e0 + el;
+    const int el = tid, e = s_e[el];
     float* S = s_env[el];
     EnvView V;
     V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
@@ -821,7 +836,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     float* bla = S + S_BLA; float* baa = S + S_BAA; const float* lrv = S + S_LRV;
     const float* cf = V.cf; const float* act = V.act;
     bool root_dirty = false;
-    int64_t eplen = s_eplen[el] + 1;                                              // LR:122
+    int64_t eplen = s_eplen[el] + (ro ? 0 : 1);                                   // LR:122 (not in rollout steps)
     float q[4] = {root[3], root[4], root[5], root[6]};
     V3 lin = v3(root[7], root[8], root[9]), ang = v3(root[10], root[11], root[12]);
     V3 v = quat_rotate_inverse(q, lin);                                           // LR:128-134
@@ -834,13 +849,13 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     V3 gv = quat_rotate_inverse(q, v3(0, 0, -1));
     V.blv[0] = v.x; V.blv[1] = v.y; V.blv[2] = v.z; V.bav[0] = w.x; V.bav[1] = w.y; V.bav[2] = w.z; V.pg[0] = gv.x; V.pg[1] = gv.y; V.pg[2] = gv.z;
     // _post_physics_step_callback (LR:386-403)
-    if ((int)eplen % g.resampling_steps == 0) resample_commands(C, cmd, s_u[el], LG_RS_CMD_CB);
-    if (g.heading_command) {
+    if (!ro && (int)eplen % g.resampling_steps == 0) resample_commands(C, cmd, s_u[el], LG_RS_CMD_CB);
+    if (!ro && g.heading_command) {
       V3 f = quat_apply(q, v3(1, 0, 0));
       float x = 0.5f * wrap_to_pi(cmd[3] - atan2f(f.y, f.x));
       cmd[2] = fminf(fmaxf(x, -1.f), 1.f);
     }
-    if (g.push_robots && (step % g.push_interval == 0)) {                           // LR:402-403, 491-496
+    if (!ro && g.push_robots && (step % g.push_interval == 0)) {                    // LR:402-403, 491-496
       root[7] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, s_u[el][LG_RS_PUSH]);
       root[8] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, s_u[el][LG_RS_PUSH + 1]);
       root_dirty = true;
@@ -850,7 +865,10 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     for (int i = 0; i < m.num_termination; ++i) { int b = m.termination_contact_indices[i]; term |= FNORM(b) > 1.f; }
     term |= s_flag[el] == 2;        // physics fault flagged by physics_kernel
     bool tout = (float)eplen > g.max_episode_length;
-    C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0;
+    if (ro) {                       // rollout envs never terminate on their own: flags keep their last values
+      tout = C->time_out[e] != 0; term = (s_flag[el] != 0) && !tout;
+      if (s_flag[el] == 2) C->reset_buf[e] = 1;
+    } else { C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0; }
     // compute_reward (LR:215-232)
     float rew = 0.f;
     float rk[LG_MAX_REWARD_TERMS];
@@ -867,17 +885,17 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     }
     C->rew[e] = rew;
     // reset (LR:144-145) and the episode statistics of LR:200-206
-    const bool do_reset = term || tout;
+    const bool do_reset = !ro && (term || tout);
     s_part[el][g.num_reward_terms + 2] = do_reset ? (float)eplen : 0.f;
     C->ep_len[e] = eplen;
     if (do_reset) { reset_env(C, V, e, 1, s_u[el], false); root_dirty = true; }
     for (int k = 0; k < g.num_reward_terms; ++k) {
-      float tot = S[S_SUMS + k] + rk[k];
+      float tot = S[S_SUMS + k] + (ro ? 0.f : rk[k]);        // compute_reward_rollout does not touch the episode sums
       s_part[el][k] = do_reset ? tot : 0.f;
       S[S_SUMS + k] = do_reset ? 0.f : tot;          // written back to (K, N) cooperatively below
     }
     s_part[el][g.num_reward_terms] = do_reset ? 1.f : 0.f;
-    s_part[el][g.num_reward_terms + 1] = g.curriculum ? (float)C->levels[e] : 0.f;
+    s_part[el][g.num_reward_terms + 1] = (g.curriculum && !ro) ? (float)C->levels[e] : 0.f;
     // proprioceptive part of the observation (LR:237-244), from the post-reset state
     float* sp = s_prop[el];
     sp[0] = V.blv[0] * g.obs_scale_lin_vel; sp[1] = V.blv[1] * g.obs_scale_lin_vel; sp[2] = V.blv[2] * g.obs_scale_lin_vel;
@@ -893,7 +911,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
     s_did_reset[el] = do_reset ? 1 : 0; s_root_dirty[el] = root_dirty ? 1 : 0;
     // (rows are written back to global memory cooperatively after this phase)
     // Anymal.post_physics_step: gait scheduler (anymal.py:107-110)
-    if (g.gait_enabled) {
+    if (g.gait_enabled && !ro) {
       float x = fmodf(S[S_GAIT] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
       S[S_GAIT] = x;
     }
@@ -905,29 +923,29 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
 #define UNSTAGE(DST, OFF, LEN)                                                                 \
   for (int idx = tid; idx < nenv * (LEN); idx += 256) {                                         \
     int el = idx / (LEN), k = idx - el * (LEN);                                                 \
-    (DST)[(size_t)e0 * (LEN) + idx] = s_env[el][(OFF) + k];                                     \
+    (DST)[(size_t)s_e[el] * (LEN) + k] = s_env[el][(OFF) + k];                                     \
   }
   UNSTAGE(C->commands, S_CMD, 4) UNSTAGE(C->feet_air, S_AIR, 4) UNSTAGE(C->feet_ctime, S_CT, 4)
   UNSTAGE(C->base_lin_vel, S_BLV, 3) UNSTAGE(C->base_ang_vel, S_BAV, 3) UNSTAGE(C->proj_grav, S_PG, 3)
   UNSTAGE(C->base_lin_acc, S_BLA, 3) UNSTAGE(C->base_ang_acc, S_BAA, 3) UNSTAGE(C->gait_idx, S_GAIT, 1)
 #undef UNSTAGE
-  if (tid < nenv * 4) C->last_contacts[(size_t)e0 * 4 + tid] = s_lastc[tid >> 2][tid & 3];
-  for (int idx = tid; idx < nenv * 13; idx += 256) { int el = idx / 13, k = idx - el * 13; if (s_root_dirty[el]) C->root[(size_t)(e0 + el) * 13 + k] = s_env[el][S_ROOT + k]; }
-  for (int idx = tid; idx < nenv * 24; idx += 256) { int el = idx / 24, k = idx - el * 24; if (s_did_reset[el]) C->dof[(size_t)(e0 + el) * 24 + k] = s_env[el][S_DOF + k]; }
+  if (tid < nenv * 4) C->last_contacts[(size_t)s_e[tid >> 2] * 4 + (tid & 3)] = s_lastc[tid >> 2][tid & 3];
+  for (int idx = tid; idx < nenv * 13; idx += 256) { int el = idx / 13, k = idx - el * 13; if (s_root_dirty[el]) C->root[(size_t)s_e[el] * 13 + k] = s_env[el][S_ROOT + k]; }
+  for (int idx = tid; idx < nenv * 24; idx += 256) { int el = idx / 24, k = idx - el * 24; if (s_did_reset[el]) C->dof[(size_t)s_e[el] * 24 + k] = s_env[el][S_DOF + k]; }
   for (int idx = tid; idx < nenv * 12; idx += 256) {
     int el = idx / 12, d = idx - el * 12;
-    C->last_actions[(size_t)(e0 + el) * 12 + d] = s_env[el][S_ACT + d];
-    C->last_dof_vel[(size_t)(e0 + el) * 12 + d] = s_env[el][S_DOF + 2 * d + 1];
+    C->last_actions[(size_t)s_e[el] * 12 + d] = s_env[el][S_ACT + d];
+    C->last_dof_vel[(size_t)s_e[el] * 12 + d] = s_env[el][S_DOF + 2 * d + 1];
   }
-  for (int idx = tid; idx < nenv * 6; idx += 256) { int el = idx / 6, k = idx - el * 6; C->last_root_vel[(size_t)(e0 + el) * 6 + k] = s_env[el][S_ROOT + 7 + k]; }
-  if (g.gait_enabled && tid < nenv * 4) { int el = tid >> 2, f = tid & 3; C->gait_foot_z[(size_t)(e0 + el) * 4 + f] = s_env[el][S_RB + m.feet_indices[f] * 13 + 2]; }
+  for (int idx = tid; idx < nenv * 6; idx += 256) { int el = idx / 6, k = idx - el * 6; C->last_root_vel[(size_t)s_e[el] * 6 + k] = s_env[el][S_ROOT + 7 + k]; }
+  if (g.gait_enabled && !ro && tid < nenv * 4) { int el = tid >> 2, f = tid & 3; C->gait_foot_z[(size_t)s_e[el] * 4 + f] = s_env[el][S_RB + m.feet_indices[f] * 13 + 2]; }
   if (g.control_type == LG_CTRL_ACTUATOR_NET) {      // anymal.py:78-82: clear the LSTM state of the envs that were reset
     const size_t N12 = (size_t)C->N * 12;
     for (int idx = tid; idx < nenv * 2 * 96; idx += 256) {
       int el = idx / 192, r = idx - el * 192, lay = r / 96, k = r - lay * 96;
       if (s_did_reset[el]) {
-        C->sea_h[(lay * N12 + (size_t)(e0 + el) * 12) * 8 + k] = 0.f;
-        C->sea_c[(lay * N12 + (size_t)(e0 + el) * 12) * 8 + k] = 0.f;
+        C->sea_h[(lay * N12 + (size_t)s_e[el] * 12) * 8 + k] = 0.f;
+        C->sea_c[(lay * N12 + (size_t)s_e[el] * 12) * 8 + k] = 0.f;
       }
     }
   }
@@ -935,7 +953,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
   // ---- per-workgroup episode statistics, summed in fixed env order (deterministic)
   for (int idx = tid; idx < nenv * g.num_reward_terms; idx += 256) {     // episode sums back to their (K, N) rows
     int k = idx / nenv, el = idx - k * nenv;
-    C->ep_sums[(size_t)k * C->N + e0 + el] = s_env[el][S_SUMS + k];
+    C->ep_sums[(size_t)k * C->N + s_e[el]] = s_env[el][S_SUMS + k];
   }
   const int KP = g.num_reward_terms + 3;
   if (tid < KP) {
@@ -947,7 +965,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
   // ---- (3) observation rows: proprio | heights, + uniform noise, clipped (LR:245-252, :107-108); 4 entries per lane
   const int O = g.num_obs, G4 = (O + 3) >> 2;
   for (int gi = tid; gi < nenv * G4; gi += 256) {
-    int el = gi / G4, gq = gi - el * G4, e = e0 + el;
+    int el = gi / G4, gq = gi - el * G4, e = s_e[el];
     float u[4] = {0.5f, 0.5f, 0.5f, 0.5f};
     if (g.add_noise) {
       if (g.rng_mode == LG_RNG_INJECT) {
@@ -955,7 +973,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C)
         for (int i = 0; i < 4; ++i) if (4 * gq + i < O) u[i] = C->rand_inject[(size_t)e * (LG_RS_NOISE + O) + LG_RS_NOISE + 4 * gq + i];
       } else {
         uint32_t o4[4];
-        philox4((uint32_t)e, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), 0u, (uint32_t)g.seed, (uint32_t)(g.seed >> 32), o4);
+        philox4((uint32_t)e, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), rstream, (uint32_t)g.seed, (uint32_t)(g.seed >> 32), o4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) u[i] = u01(o4[i]);
       }
@@ -996,12 +1014,12 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const DevCtx* __restrict
     if (tid == K && C->cfg.curriculum) C->extras[K] = tot[K + 1] / (float)C->N;
   }
   if (tid == 0) {
-    if (bump_step) C->counters[0] += 1; else C->counters[2] += 1;
+    if (bump_step == 1) C->counters[0] += 1; else if (bump_step == 0) C->counters[2] += 1;
     C->counters[1] = (int64_t)cnt;
     double ret = 0.0;
     for (int k = 0; k < K; ++k) ret += (double)tot[k];
     C->ep_stats[0] += ret; C->ep_stats[1] += (double)tot[K + 2]; C->ep_stats[2] += (double)cnt;
-    if (bump_step) C->ep_stats[3] += (double)C->N;
+    if (bump_step == 1) C->ep_stats[3] += (double)C->n_stepped;
   }
 }
 
@@ -1170,6 +1188,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
   h.ter.H = (const int16_t*)P(LG_T_HEIGHT_SAMPLES);
   h.nblocks_post = (h.N + EPBP - 1) / EPBP;
+  h.n_stepped = h.N;
 
   // aux buffer: noise_vec | height_points | partials
   size_t n_noise = (size_t)cfg->num_obs, n_hp = (size_t)2 * cfg->num_height_points;
@@ -1211,30 +1230,99 @@ int lg_get_tensor(lg_ctx* c, int id, void** dptr, int64_t shape[4], int32_t* ndi
   return LG_OK;
 }
 
-static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev) {
-  hipLaunchKernelGGL(post_kernel, dim3(c->h.nblocks_post), dim3(256), 0, st, c->d);
+__global__ void bump_rollout_counter(const DevCtx* __restrict__ C) { C->counters[3] += 1; }
+__global__ void set_n_stepped(DevCtx* C, int n) { C->n_stepped = n; }
+
+static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t* ids, int n, int mode) {
+  const int nb = (n + EPBP - 1) / EPBP;
+  hipLaunchKernelGGL(post_kernel, dim3(nb), dim3(256), 0, st, c->d, ids, n, mode);
   if (ev) (void)hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, c->d, c->h.nblocks_post, 1);
+  if (mode == 0) hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, c->d, nb, 1);
+  else hipLaunchKernelGGL(bump_rollout_counter, dim3(1), dim3(1), 0, st, c->d);
   if (ev) (void)hipEventRecord(ev[3], st);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
+}
+
+static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n) {
+  const int nb = (n + EPB - 1) / EPB;
+  const int nact = (c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET && c->split) ? 3 : 0;
+  if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
+  hipLaunchKernelGGL(physics_kernel<0>, dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n);
 }
 
 int lg_step(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
   if (!actions) { c->err = "actions is null"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
-  const int nb = (c->h.N + EPB - 1) / EPB;
-  const int nact = (c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET && c->split) ? 3 : 0;
   hipEvent_t* ev = nullptr;
   if (c->prof_max > 0) {
     if (c->prof_n < c->prof_max && (c->prof_calls % c->prof_stride) == 0) ev = &c->ev[(size_t)4 * c->prof_n++];
     c->prof_calls++;
   }
   if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(physics_kernel<0>, dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact);
+  launch_physics(c, st, actions, nullptr, c->h.N);
   if (ev) (void)hipEventRecord(ev[1], st);
-  return launch_post(c, st, ev);
+  return launch_post(c, st, ev, nullptr, c->h.N, 0);
+}
+
+int lg_step_subset(lg_ctx* c, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (!actions || !env_ids || n <= 0 || n > c->h.N) { c->err = "bad subset step arguments"; return LG_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  launch_physics(c, st, actions, env_ids, n);
+  return launch_post(c, st, nullptr, env_ids, n, rollout_mode ? 1 : 0);
+}
+
+int lg_step_physics(lg_ctx* c, const float* actions, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (!actions) { c->err = "actions is null"; return LG_ERR_INVALID; }
+  launch_physics(c, (hipStream_t)stream, actions, nullptr, c->h.N);
+  HIP_TRY(c, hipGetLastError());
+  return LG_OK;
+}
+
+// RobotBatchRollout._sync_main_to_rollout (robot_batch_rollout.py:1447-1535): env i*(1+R) is main i, the next R envs are
+// its rollouts; one lane per (rollout env, float) copies the 12 state tensors the reference copies.
+__global__ __launch_bounds__(256) void sync_kernel(const DevCtx* __restrict__ C, int R, float drift, uint32_t seed_lo, uint32_t call) {
+  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1;   // floats (+ one slot for the 4 contact bytes)
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)C->N * per;
+  if (gid >= total) return;
+  const int e = (int)(gid / per), k = (int)(gid - (int64_t)e * per);
+  const int src = e - e % (1 + R);
+  if (src == e) return;
+  int o = k;
+  if (o < 13) {
+    float v = C->root[(size_t)src * 13 + o];
+    if (drift > 0.f && o < 3) {   // domain_rand.rollout_envs_sync_pos_drift (:1493-1497)
+      uint32_t r4[4]; philox4((uint32_t)e, call, (uint32_t)o, 7u, seed_lo, 0x5a5au, r4);
+      v += (u01(r4[0]) - 0.5f) * drift;
+    }
+    C->root[(size_t)e * 13 + o] = v; return;
+  }
+  o -= 13; if (o < 24) { C->dof[(size_t)e * 24 + o] = C->dof[(size_t)src * 24 + o]; return; }
+  o -= 24; if (o < 12) { C->actions[(size_t)e * 12 + o] = C->actions[(size_t)src * 12 + o]; return; }
+  o -= 12; if (o < 12) { C->last_actions[(size_t)e * 12 + o] = C->last_actions[(size_t)src * 12 + o]; return; }
+  o -= 12; if (o < 12) { C->last_dof_vel[(size_t)e * 12 + o] = C->last_dof_vel[(size_t)src * 12 + o]; return; }
+  o -= 12; if (o < 6) { C->last_root_vel[(size_t)e * 6 + o] = C->last_root_vel[(size_t)src * 6 + o]; return; }
+  o -= 6; if (o < 3) { C->base_lin_vel[(size_t)e * 3 + o] = C->base_lin_vel[(size_t)src * 3 + o]; return; }
+  o -= 3; if (o < 3) { C->base_ang_vel[(size_t)e * 3 + o] = C->base_ang_vel[(size_t)src * 3 + o]; return; }
+  o -= 3; if (o < 3) { C->proj_grav[(size_t)e * 3 + o] = C->proj_grav[(size_t)src * 3 + o]; return; }
+  o -= 3; if (o < 4) { C->feet_air[(size_t)e * 4 + o] = C->feet_air[(size_t)src * 4 + o]; return; }
+  o -= 4; if (o < 4) { C->feet_ctime[(size_t)e * 4 + o] = C->feet_ctime[(size_t)src * 4 + o]; return; }
+  for (int f = 0; f < 4; ++f) C->last_contacts[(size_t)e * 4 + f] = C->last_contacts[(size_t)src * 4 + f];
+}
+
+int lg_sync_main_to_rollout(lg_ctx* c, int32_t rollouts_per_main, float pos_drift, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (rollouts_per_main <= 0 || c->h.N % (1 + rollouts_per_main) != 0) { c->err = "num_envs is not num_main * (1 + rollouts_per_main)"; return LG_ERR_INVALID; }
+  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1;
+  int64_t total = (int64_t)c->h.N * per;
+  hipLaunchKernelGGL(sync_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c->d, rollouts_per_main, pos_drift,
+                     (uint32_t)c->h.cfg.seed, (uint32_t)(c->sync_calls++));
+  HIP_TRY(c, hipGetLastError());
+  return LG_OK;
 }
 
 int lg_set_extra_obs(lg_ctx* c, const float* dptr) {
@@ -1242,16 +1330,6 @@ int lg_set_extra_obs(lg_ctx* c, const float* dptr) {
   if (c->h.cfg.num_extra_obs > 0 && !dptr) { c->err = "extra obs buffer is null"; return LG_ERR_INVALID; }
   c->h.extra_obs = dptr;
   HIP_TRY(c, hipMemcpy(c->d, &c->h, sizeof(DevCtx), hipMemcpyHostToDevice));
-  return LG_OK;
-}
-
-int lg_step_physics(lg_ctx* c, const float* actions, void* stream) {
-  if (!c) return LG_ERR_INVALID;
-  if (!actions) { c->err = "actions is null"; return LG_ERR_INVALID; }
-  const int nb = (c->h.N + EPB - 1) / EPB;
-  const int nact = (c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET && c->split) ? 3 : 0;
-  hipLaunchKernelGGL(physics_kernel<0>, dim3(nb), dim3(64 * (1 + nact)), 0, (hipStream_t)stream, c->d, actions, c->h.cfg.decimation, nact);
-  HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
 
@@ -1282,7 +1360,7 @@ int lg_profile_end(lg_ctx* c, float mean_ms[3], int32_t* nsamples) {
 int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
   const int nb = (c->h.N + EPB - 1) / EPB;
-  hipLaunchKernelGGL(physics_kernel<2>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0);
+  hipLaunchKernelGGL(physics_kernel<2>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -1290,14 +1368,14 @@ int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
 int lg_simulate(lg_ctx* c, void* stream) {
   if (!c) return LG_ERR_INVALID;
   const int nb = (c->h.N + EPB - 1) / EPB;
-  hipLaunchKernelGGL(physics_kernel<1>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0);
+  hipLaunchKernelGGL(physics_kernel<1>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
 
 int lg_post_physics_step(lg_ctx* c, void* stream) {
   if (!c) return LG_ERR_INVALID;
-  return launch_post(c, (hipStream_t)stream, nullptr);
+  return launch_post(c, (hipStream_t)stream, nullptr, nullptr, c->h.N, 0);
 }
 
 int lg_reset_idx(lg_ctx* c, const int32_t* env_ids, int32_t n, int32_t update_curriculum, void* stream) {

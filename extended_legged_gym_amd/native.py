@@ -103,6 +103,14 @@ class NativeCore:
         a = self._f32(actions)
         self._check(self.lib.lg_step_physics(self.ctx, C.c_void_p(a.data_ptr()), self._stream()))
 
+    def step_subset(self, actions, env_ids_i32, rollout_mode):
+        a = self._f32(actions)
+        self._check(self.lib.lg_step_subset(self.ctx, C.c_void_p(a.data_ptr()), C.c_void_p(env_ids_i32.data_ptr()),
+                                            int(env_ids_i32.numel()), int(rollout_mode), self._stream()))
+
+    def sync_main_to_rollout(self, rollouts_per_main, pos_drift=0.0):
+        self._check(self.lib.lg_sync_main_to_rollout(self.ctx, int(rollouts_per_main), float(pos_drift), self._stream()))
+
     def compute_torques(self, actions=None):
         if actions is None:
             self._check(self.lib.lg_compute_torques(self.ctx, None, self._stream()))

@@ -238,6 +238,18 @@ int lg_step(lg_ctx* ctx, const float* actions, void* stream);
  * between the last substep and post_physics_step. */
 int lg_step_physics(lg_ctx* ctx, const float* actions, void* stream);
 
+/* Main-rollout stepping (envs/batch_rollout/robot_batch_rollout.py): advance only the n listed envs; row k of `actions`
+ * (n,12) belongs to env_ids[k] (device pointers).  rollout_mode = 0: the listed envs take a full LeggedRobot step
+ * (RobotBatchRollout.step :535-600 for the main envs); rollout_mode = 1: post_physics_step_rollout semantics (:763-817) —
+ * no command resampling / pushes / termination / reset, rewards computed but not added to the episode sums, the other
+ * envs are not touched (the reference simulates and then restores them, :687, :1585-1640). */
+int lg_step_subset(lg_ctx* ctx, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream);
+
+/* _sync_main_to_rollout (:1447-1535): with env i*(1+R) the i-th main env and the next R envs its rollouts, copy root /
+ * DOF state, actions, history, base velocities, projected gravity and the feet contact state from every main env to its
+ * rollouts; pos_drift > 0 adds U(-drift/2, drift/2) to the copied base positions (:1493-1497). */
+int lg_sync_main_to_rollout(lg_ctx* ctx, int32_t rollouts_per_main, float pos_drift, void* stream);
+
 /* Pieces of lg_step, exposed because the reference exposes them as overridable methods / gym calls. */
 int lg_compute_torques(lg_ctx* ctx, const float* actions, void* stream);  /* -> LG_T_TORQUES (and LSTM state) */
 int lg_simulate(lg_ctx* ctx, void* stream);                               /* one dt with LG_T_TORQUES applied */
