@@ -28,7 +28,8 @@ def test_subset_step_and_sync_match_oracle():
     o.reset_idx(np.arange(T))
     for _ in range(15):
         o.step(rng.normal(size=(T, 12)).astype(np.float32))
-    for name in COPY + ["friction_coeffs"]:
+    for name in COPY + ["friction_coeffs", "actions", "rigid_body_state", "contact_forces", "torques", "obs_buf", "rew_buf",
+                        "base_lin_vel", "base_ang_vel", "projected_gravity", "reset_buf", "time_out_buf"]:
         core.t[name].copy_(torch.from_numpy(o.t[name].copy()))
     main = np.arange(0, T, 1 + R, dtype=np.int32)
     roll = np.array([e for e in range(T) if e % (1 + R)], dtype=np.int32)
