@@ -1,0 +1,91 @@
+"""Secondary measurements for BASELINE.json configs other than the headline (which is bench.py): env-steps/s through the
+public Python API, synthetic N(0,1) actions, after a warm-up.  Informational; one JSON line per config.
+
+  config 1  ANYmal-C flat, 64 envs                      (plumbing case; here on the GPU, the product has no CPU path)
+  config 4  ANYmal-C rough + 60x30 ray-cast depth camera, 4096 envs on this GPU (of 8192 over 2 GPUs)
+  config 5  ANYmal-C main-rollout sampler: 128 main x 32 rollouts on this GPU (of 1024 x 32 over 8 GPUs): step_rollout
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params  # noqa: E402
+
+
+def sim_params(cfg):
+    return parse_sim_params(get_args([]), {"sim": class_to_dict(cfg.sim)})
+
+
+def timeit(fn, warm, steps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def config1():
+    from extended_legged_gym_amd.envs import Anymal, AnymalCFlatCfg
+    cfg = AnymalCFlatCfg(); cfg.env.num_envs = 64; cfg.seed = 1
+    env = Anymal(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
+    env.reset()
+    a = torch.randn(64, 12, device="cuda")
+    dt = timeit(lambda: env.step(a), 200, 200)
+    return dict(config="1: ANYmal-C flat, 64 envs", env_steps_per_s=64 / dt, ms_per_step=dt * 1e3)
+
+
+def config4():
+    from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
+    from extended_legged_gym_amd.envs.base.legged_robot_depthcam import LeggedRobotDepth
+
+    class Env(LeggedRobotDepth):
+        def _gait_config(self):
+            return dict(period=0.6, swing_height=0.15, foot_phases=[0.0, 0.5, 0.5, 0.0])
+    cfg = AnymalCRoughCfg(); cfg.env.num_envs = 4096; cfg.seed = 1
+    np.random.seed(1)
+    env = Env(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
+    env.reset()
+    a = torch.randn(4096, 12, device="cuda")
+    dt = timeit(lambda: env.step(a), 50, 100)
+    mesh = env.terrain_mesh()
+    return dict(config="4: ANYmal-C rough (trimesh, 1.6M triangles) + 60x30 depth camera every step, 4096 envs on 1 GPU",
+                env_steps_per_s=4096 / dt, ms_per_step=dt * 1e3, rays_per_s=4096 * 1800 / dt,
+                mesh_triangles=mesh.num_triangles, bvh_nodes=mesh.num_bvh_nodes)
+
+
+def config5():
+    from extended_legged_gym_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+    from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout import RobotBatchRollout
+    from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout_config import RobotBatchRolloutCfg
+    base = AnymalCFlatCfg(); cfg = RobotBatchRolloutCfg()
+    for sec in ("init_state", "control", "asset", "rewards", "commands", "terrain"):
+        setattr(cfg, sec, getattr(base, sec))
+    cfg.env.num_envs, cfg.env.rollout_envs, cfg.env.num_observations = 128, 32, 48
+    cfg.control.use_actuator_network = False          # anymal_c_batch_rollout_config.py:181-183
+    cfg.rewards.only_positive_rewards = False
+    cfg.seed = 1
+    env = RobotBatchRollout(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
+    env.reset()
+    a = torch.randn(128 * 32, 12, device="cuda")
+    dt = timeit(lambda: env.step_rollout(a), 50, 200)
+    us = torch.randn(128 * 32, 16, 12, device="cuda")
+    t0 = time.perf_counter(); env.rollout_batch(us); torch.cuda.synchronize(); tb = time.perf_counter() - t0
+    am = torch.randn(128, 12, device="cuda")
+    dm = timeit(lambda: env.step(am), 20, 50)
+    return dict(config="5: ANYmal-C main-rollout, 128 main x 32 rollouts on 1 GPU (PD actuators, plane)",
+                rollout_env_steps_per_s=128 * 32 / dt, step_rollout_ms=dt * 1e3, rollout_batch_H16_ms=tb * 1e3, main_step_ms=dm * 1e3)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["1", "4", "5"]
+    for w in which:
+        print(json.dumps({"1": config1, "4": config4, "5": config5}[w]()))
