@@ -18,7 +18,7 @@
 // dwords per field (broadcast, conflict-free) instead of issuing ~100 dependent global loads per substep.
 enum { LM_JPOS = 0, LM_JROT = 9, LM_JAXIS = 36, LM_MASS = 45, LM_COM = 48, LM_INERTIA = 57, LM_FOOT_POS = 75, LM_FOOT_ROT = 78,
        LM_VEL_LIMIT = 87, LM_TORQUE_LIMIT = 90, LM_DEFAULT_POS = 93, LM_PGAIN = 96, LM_DGAIN = 99, LM_CP_COUNT = 102,
-       LM_CP_LINK = 103, LM_CP_POS = 111, LM_CP_RADIUS = 135, LM_FIELDS = 143 };
+       LM_CP_LINK = 103, LM_CP_POS = 111, LM_CP_RADIUS = 135, LM_LOWER = 143, LM_UPPER = 146, LM_FIELDS = 149 };
 struct LegModel {
   const float* t; int l;
   LG_DEV float f(int field) const { return t[field * 4 + l]; }
@@ -46,7 +46,9 @@ LG_DEV void fill_leg_model(float* t, const lg_robot_model* __restrict__ m, const
     else if (field < LM_CP_LINK) val = __int_as_float(m->cp_count[l]);
     else if (field < LM_CP_POS) val = __int_as_float(m->cp_link[l][field - LM_CP_LINK]);
     else if (field < LM_CP_RADIUS) { int k = field - LM_CP_POS; val = m->cp_pos[l][k / 3][k % 3]; }
-    else val = m->cp_radius[l][field - LM_CP_RADIUS];
+    else if (field < LM_LOWER) val = m->cp_radius[l][field - LM_CP_RADIUS];
+    else if (field < LM_UPPER) val = m->dof_lower[3 * l + field - LM_LOWER];
+    else val = m->dof_upper[3 * l + field - LM_UPPER];
     t[idx] = val;
   }
 }
@@ -453,8 +455,40 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     }
   }
 
+  // ---------------------------------------------------------------- joint position limits as unilateral rows on qd
+  // (URDF lower/upper; lower >= upper = unlimited).  Whole block is skipped unless some lane of the wave is near a limit.
+  float jl_sgn[3], jl_bn[3], jl_iA[3], jl_lam[3] = {0.f, 0.f, 0.f}, jl_Wb[3][6], jl_y[3][3];
+  bool jl_act[3];
+  bool jl_any = false;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float lo = lm_.f(LM_LOWER + j), hi = lm_.f(LM_UPPER + j);
+    const float glo = s.q[j] - lo, ghi = hi - s.q[j];
+    const float gap = glo <= ghi ? glo : ghi;
+    jl_sgn[j] = glo <= ghi ? 1.f : -1.f;
+    jl_act[j] = (lo < hi) && (gap + fminf(0.f, dt * jl_sgn[j] * vK[j]) < 0.05f);   // near the limit, or about to cross it this step
+    jl_bn[j] = gap >= 0.f ? -gap * idt_ : fminf(-gap * P.erp * idt_, 10.f);
+    jl_any |= jl_act[j];
+  }
+  const bool jl_wave = __ballot(jl_any) != 0ull;
+  if (jl_wave) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float ej[3] = {j == 0 ? jl_sgn[j] : 0.f, j == 1 ? jl_sgn[j] : 0.f, j == 2 ? jl_sgn[j] : 0.f};
+      sym3_mul(Mi, ej, jl_y[j]);
+      float gvec[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) gvec[a] = -(Mbk[a][0] * jl_y[j][0] + Mbk[a][1] * jl_y[j][1] + Mbk[a][2] * jl_y[j][2]);
+      symv6(Si, gvec, jl_Wb[j]);
+      float wj = jl_y[j][j];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) wj -= Y[j][a] * jl_Wb[j][a];
+      jl_iA[j] = frcp(jl_sgn[j] * wj + P.cfm);
+    }
+  }
+
   // ---------------------------------------------------------------- projected Gauss-Seidel
-  if (slot_mask) {
+  if (slot_mask || jl_wave) {
 #pragma unroll 1
     for (int it = 0; it < P.iters; ++it) {
 #pragma unroll 1
@@ -493,6 +527,27 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
 #pragma unroll
           for (int a = 0; a < 6; ++a) w -= Y[j][a] * g[a];
           vK[j] += w;
+        }
+      }
+      if (jl_wave) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {           // joint j of the four legs together, like a contact slot
+          const float u = jl_sgn[j] * vK[j];
+          const float ln = fmaxf(jl_lam[j] - (u - jl_bn[j]) * jl_iA[j], 0.f);
+          const float dl = jl_act[j] ? ln - jl_lam[j] : 0.f;
+          if (jl_act[j]) jl_lam[j] = ln;
+          float gq[6];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) gq[a] = quad_sum(dl * jl_Wb[j][a]);
+#pragma unroll
+          for (int a = 0; a < 6; ++a) vB[a] += gq[a];
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj) {
+            float w = dl * jl_y[j][jj];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) w -= Y[jj][a] * gq[a];
+            vK[jj] += w;
+          }
         }
       }
     }

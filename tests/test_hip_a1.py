@@ -1,0 +1,74 @@
+"""GPU: Unitree A1 (reference envs/a1/a1_config.py:33-79): PD torques, hard joint limits from the URDF, box-corner
+collision points.  Parity with the oracle and behavioural checks of the joint-limit rows."""
+import numpy as np
+import pytest
+import torch
+
+from extended_legged_gym_amd.envs.a1.a1_config import A1RoughCfg
+from extended_legged_gym_amd.envs.base.native_config import NativeSetup, load_robot_model
+from extended_legged_gym_amd.utils.terrain import Terrain
+from tests.helpers import sim_params_for
+from tests.test_hip_vs_oracle import COPY, STATE, compare
+
+pytestmark = pytest.mark.gpu
+
+
+def test_a1_single_step_parity_and_joint_limits():
+    from extended_legged_gym_amd.native import NativeCore
+    from oracle.oracle_lib import OracleEnv
+    n = 128
+    cfg = A1RoughCfg()
+    cfg.env.num_envs = n
+    cfg.terrain.mesh_type = "heightfield"
+    cfg.terrain.num_rows = cfg.terrain.num_cols = 3
+    cfg.terrain.max_init_terrain_level = 2
+    cfg.terrain.border_size = 5
+    np.random.seed(4)
+    terrain = Terrain(cfg.terrain, n)
+    model = load_robot_model(cfg.asset)
+    assert abs(model["base_mass"] + sum(map(sum, model["link_mass"])) - 12.454) < 1e-3
+    lo, hi = np.array(model["dof_lower"]), np.array(model["dof_upper"])
+    assert (lo < hi).all()                                     # A1 has real joint limits
+    s = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=4)
+    o, core = OracleEnv(s), NativeCore(s, "cuda:0")
+    rng = np.random.default_rng(4)
+    o.t["friction_coeffs"][:] = rng.uniform(0.5, 1.25, n)
+    lv = rng.integers(0, 3, n); ty = np.floor(np.arange(n) / (n / 3)).astype(np.int64)
+    o.t["terrain_levels"][:] = lv; o.t["terrain_types"][:] = ty; o.t["env_origins"][:] = terrain.env_origins[lv, ty]
+    o.reset_idx(np.arange(n))
+    worst = 0.0
+    for it in range(60):
+        act = 4.0 * rng.normal(size=(n, 12)).astype(np.float32)            # big actions: drive joints into their limits
+        if it % 20 == 19:
+            for name in COPY:
+                core.t[name].copy_(torch.from_numpy(o.t[name].copy()))
+            o.step(act); core.step(torch.from_numpy(act).cuda())
+            compare(core, o, [x for x in STATE if x not in ("sea_hidden_state", "sea_cell_state")])
+        else:
+            o.step(act)
+        # a reset draws q = default * U(0.5, 1.5) (LR:458-459), which may start outside the limits: look at settled envs
+        old = o.t["episode_length_buf"] >= 10
+        q = o.t["dof_state"][:, :, 0][old]
+        if len(q):
+            worst = max(worst, float(np.max(np.maximum(lo - q, q - hi))))
+    assert worst < 0.08, worst                                 # limits hold up to a small, bounded overshoot
+    core.close(); o.close()
+
+
+def test_a1_env_stands_and_stays_finite():
+    from tests.test_env_api import make
+    env = make("a1", 256, **{"terrain.mesh_type": "plane", "terrain.measure_heights": False, "env.num_observations": 48})
+    env.reset()
+    for _ in range(150):
+        env.step(torch.zeros(256, 12, device=env.device))
+    assert int(env.reset_buf.sum()) == 0
+    assert torch.allclose(env.contact_forces[:, :, 2].sum(1), torch.full((256,), 12.454 * 9.81, device=env.device), rtol=0.05)
+    assert float(env.root_states[:, 2].min()) > 0.2
+    g = torch.Generator().manual_seed(0)
+    for _ in range(300):
+        env.step(3.0 * torch.randn(256, 12, generator=g).cuda())
+    for name in ["obs_buf", "root_states", "dof_state", "rew_buf"]:
+        assert torch.isfinite(env.core.t[name]).all()
+    lo = torch.tensor(env.robot_model["dof_lower"], device=env.device); hi = torch.tensor(env.robot_model["dof_upper"], device=env.device)
+    old = env.episode_length_buf >= 10
+    assert float(torch.maximum(lo - env.dof_pos, env.dof_pos - hi)[old].max()) < 0.08
