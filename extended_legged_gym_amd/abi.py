@@ -13,7 +13,7 @@ LG_LSTM_NPARAM = 969
 LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_UNSUPPORTED, LG_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 LG_F32, LG_I64, LG_U8, LG_I16, LG_I32, LG_F64 = 0, 1, 2, 3, 4, 5
 LG_CTRL_P, LG_CTRL_V, LG_CTRL_T, LG_CTRL_ACTUATOR_NET = 0, 1, 2, 3
-LG_MESH_PLANE, LG_MESH_HEIGHTFIELD = 0, 1
+LG_MESH_PLANE, LG_MESH_HEIGHTFIELD, LG_MESH_TRIMESH = 0, 1, 2
 LG_RNG_PHILOX, LG_RNG_INJECT = 0, 1
 
 RAND_SLOTS = dict(LG_RS_CMD_CB=0, LG_RS_PUSH=4, LG_RS_LEVEL=6, LG_RS_DOF=8, LG_RS_ROOT_XY=20, LG_RS_ROOT_VEL=22,
@@ -65,6 +65,7 @@ class lg_terrain(C.Structure):
         ("num_levels", i32), ("num_types", i32),
         ("terrain_origins", C.POINTER(f32)),
         ("env_length", f32),
+        ("collision_mesh", C.c_void_p),
     ]
 
 

@@ -13,6 +13,7 @@
 // one slot relax simultaneously, slots sequentially), Coulomb friction disc, semi-implicit Euler.
 #pragma once
 #include "lg_device.h"
+#include "lg_bvh.h"
 
 // Per-leg model constants staged in LDS as [field][leg]: lane l reads field*4 + l, i.e. a wave touches 4 consecutive
 // dwords per field (broadcast, conflict-free) instead of issuing ~100 dependent global loads per substep.
@@ -168,7 +169,7 @@ LG_DEV void symv6(const float* Si, const float* x, float* y) {
 }
 
 // terrain surface under (x, y): height and unit normal of the regular-grid triangulation (diagonal v(i,j)->v(i+1,j+1))
-struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t* __restrict__ H; };
+struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t* __restrict__ H; MeshView M; };
 LG_DEV void terrain_query(const TerrainView& T, float x, float y, float* h, V3* n) {
   if (T.mesh_type == LG_MESH_PLANE) { *h = 0.f; *n = v3(0, 0, 1); return; }
   const float ihs = frcp(T.hscale);
@@ -270,12 +271,45 @@ LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const Phys
   }
 }
 
+// Triangle-mesh terrain (LG_MESH_TRIMESH): the surface under a sphere is the closest point of the collision mesh within
+// radius + contact_offset + LG_MESH_CONTACT_MARGIN; normal = direction from that point to the sphere centre (flipped
+// when the centre is behind the deciding face), gap = signed distance - radius.  Same slot-table outputs as above.
+#define LG_MESH_CONTACT_MARGIN 0.02f
+LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k,
+                                const M3& Rb, V3 pb, float* cst, int lane) {
+  const int ncp = lm_.i(LM_CP_COUNT);
+  const float idt_ = frcp(P.dt);
+#pragma unroll 1
+  for (int sl = s0; sl < s1; ++sl) {
+    CS(sl, CF_L0) = 0.f; CS(sl, CF_L1) = 0.f; CS(sl, CF_L2) = 0.f;
+    bool active = false; V3 n = v3(0, 0, 1), x = pb; float phi = 1.f, rad = 0.f;
+    if (sl < ncp) {
+      const int link = lm_.i(LM_CP_LINK + sl);
+      const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
+      rad = lm_.f(LM_CP_RADIUS + sl);
+      x = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
+      V3 cp, fn;
+      if (closest_point(T.M, x, rad + P.contact_offset + LG_MESH_CONTACT_MARGIN, &cp, &fn)) {
+        const V3 diff = x - cp; const float dist = norm(diff);
+        const float sign = dot(diff, fn) < 0.f ? -1.f : 1.f;
+        n = dist > 1e-6f ? (sign / dist) * diff : fn;
+        phi = sign * dist - rad;
+        active = phi < P.contact_offset;
+      }
+    }
+    CS(sl, CF_ACTIVE) = active ? 1.f : 0.f;
+    sts3(cst, sl, CF_N, lane, n);
+    sts3(cst, sl, CF_R, lane, (x - rad * n) - pb);
+    CS(sl, CF_BN) = phi >= 0.f ? -phi * idt_ : fminf(-phi * P.erp * idt_, P.max_depen);
+  }
+}
+
 // One physics step of length P.dt for the env this quad owns.  tau_fn(tau[3]) delivers this leg's joint torques; it is
 // called after everything that does not depend on them (kinematics, bias, mass matrix, contact set-up).
 // fbody[5] (optional) receives the net contact force on {base (already quad-summed), link0, link1, link2, foot}.
 // prep_fn(bk, Fs, Ns) returns true when helper waves have produced the leg bias and the contact detection (it then
 // holds the rendezvous and fills the three outputs); false means this wave computes them itself.
-template <class TauFn, class PrepFn>
+template <bool TMESH, class TauFn, class PrepFn>
 LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel& lm_, const TerrainView& T, const PhysParams& P,
                             int lane, float* cst, QuadState& s, TauFn tau_fn, PrepFn prep_fn, float mu_robot, float madd, V3* fbody,
                             unsigned long long* stamps = nullptr) {
@@ -350,7 +384,8 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   float bk[3]; V3 Fs, Ns;
   if (!prep_fn(bk, Fs, Ns)) {
     leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);
-    contact_detect<0, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
+    if (TMESH) contact_detect_mesh(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);
+    else contact_detect<0, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
   }
   float bb[6];
   {

@@ -261,7 +261,7 @@ LG_DEV void leg_torques(const DevCtx* __restrict__ C, const LegModel& lm_, const
 // ============================================================================================ physics kernel
 // MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
 // MODE 2: lg_compute_torques only.
-template <int MODE>
+template <int MODE, bool TMESH>
 __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, int nact,
                                                       const int32_t* __restrict__ ids, int n) {
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
@@ -331,6 +331,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           xbias[0][lane] = bk[0]; xbias[1][lane] = bk[1]; xbias[2][lane] = bk[2];
           xbias[3][lane] = Fs.x; xbias[4][lane] = Fs.y; xbias[5][lane] = Fs.z;
           xbias[6][lane] = Ns.x; xbias[7][lane] = Ns.y; xbias[8][lane] = Ns.z;
+        } else if (TMESH) {
+          contact_detect_mesh(wv == 2 ? 0 : LG_MAX_CP / 2, wv == 2 ? LG_MAX_CP / 2 : LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);
         } else if (wv == 2) {
           contact_detect<0, LG_MAX_CP / 2>(lm_, T, P, k, Rb, pb, cst, lane);
         } else {
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       Ns = v3(xbias[6][lane], xbias[7][lane], xbias[8][lane]);
       return true;
     };
-    physics_substep(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr, stamps);
+    physics_substep<TMESH>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr, stamps);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -1104,7 +1106,9 @@ static const char* validate(const lg_config* cfg, const lg_robot_model* model, c
   if (cfg->decimation <= 0 || cfg->sim_dt <= 0.f) return "bad dt / decimation";
   if (cfg->resampling_steps <= 0) return "resampling_steps must be positive";
   if (cfg->push_robots && cfg->push_interval <= 0) return "push_interval must be positive";
-  if (ter->mesh_type == LG_MESH_HEIGHTFIELD && (ter->rows < 2 || ter->cols < 2 || !ter->height_samples)) return "heightfield terrain without samples";
+  if (ter->mesh_type < LG_MESH_PLANE || ter->mesh_type > LG_MESH_TRIMESH) return "unknown terrain mesh_type";
+  if (ter->mesh_type != LG_MESH_PLANE && (ter->rows < 2 || ter->cols < 2 || !ter->height_samples)) return "rough terrain without height samples";
+  if (ter->mesh_type == LG_MESH_TRIMESH && !ter->collision_mesh) return "trimesh terrain without a collision mesh (lg_mesh_create)";
   if (cfg->curriculum && (ter->num_levels <= 0 || ter->num_types <= 0 || !ter->terrain_origins)) return "curriculum needs terrain_origins";
   for (int l = 0; l < 4; ++l) if (model->cp_count[l] < 0 || model->cp_count[l] > LG_MAX_CP) return "bad cp_count";
   for (int k = 0; k < cfg->num_reward_terms; ++k) if (cfg->reward_term_ids[k] < 0 || cfg->reward_term_ids[k] >= LG_REW_COUNT) return "unknown reward term id";
@@ -1187,6 +1191,11 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.ter.mesh_type = ter->mesh_type; h.ter.rows = ter->rows; h.ter.cols = ter->cols;
   h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
   h.ter.H = (const int16_t*)P(LG_T_HEIGHT_SAMPLES);
+  h.ter.M = MeshView{nullptr, nullptr};
+  if (ter->mesh_type == LG_MESH_TRIMESH) {
+    if (ter->collision_mesh->device != device_id) return fail("collision mesh lives on another device");
+    h.ter.M = MeshView{ter->collision_mesh->d_nodes, ter->collision_mesh->d_tris};
+  }
   h.nblocks_post = (h.N + EPBP - 1) / EPBP;
   h.n_stepped = h.N;
 
@@ -1201,7 +1210,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.stamps = (unsigned long long*)(aux + ((n_noise + n_hp + n_part + 1) & ~(size_t)1));
   if (hipMemcpy(aux, cfg->noise_scale_vec, n_noise * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy noise_scale_vec failed");
   if (n_hp && hipMemcpy(aux + n_noise, cfg->height_points, n_hp * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy height_points failed");
-  if (ter->mesh_type == LG_MESH_HEIGHTFIELD &&
+  if (ter->mesh_type != LG_MESH_PLANE &&
       hipMemcpy(P(LG_T_HEIGHT_SAMPLES), ter->height_samples, (size_t)ter->rows * ter->cols * 2, hipMemcpyHostToDevice) != hipSuccess)
     return fail("copy height_samples failed");
   if (ter->num_levels > 0 && ter->terrain_origins &&
@@ -1248,7 +1257,10 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
   const int nb = (n + EPB - 1) / EPB;
   const int nact = (c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET && c->split) ? 3 : 0;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
-  hipLaunchKernelGGL(physics_kernel<0>, dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n);
+  if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
+    hipLaunchKernelGGL((physics_kernel<0, true>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n);
+  else
+    hipLaunchKernelGGL((physics_kernel<0, false>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n);
 }
 
 int lg_step(lg_ctx* c, const float* actions, void* stream) {
@@ -1360,7 +1372,7 @@ int lg_profile_end(lg_ctx* c, float mean_ms[3], int32_t* nsamples) {
 int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
   const int nb = (c->h.N + EPB - 1) / EPB;
-  hipLaunchKernelGGL(physics_kernel<2>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N);
+  hipLaunchKernelGGL((physics_kernel<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -1368,7 +1380,10 @@ int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
 int lg_simulate(lg_ctx* c, void* stream) {
   if (!c) return LG_ERR_INVALID;
   const int nb = (c->h.N + EPB - 1) / EPB;
-  hipLaunchKernelGGL(physics_kernel<1>, dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N);
+  if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
+    hipLaunchKernelGGL((physics_kernel<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N);
+  else
+    hipLaunchKernelGGL((physics_kernel<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }

@@ -16,6 +16,8 @@ from extended_legged_gym_amd.native import NativeCore
 from extended_legged_gym_amd.utils.helpers import class_to_dict
 from extended_legged_gym_amd.utils.isaac_torch_utils import get_axis_params, to_torch, torch_rand_float
 from extended_legged_gym_amd.utils.terrain import Terrain
+from extended_legged_gym_amd.utils.terrain_obj import TerrainObj
+from extended_legged_gym_amd.utils.terrain_confine import TerrainConfined
 from .base_task import BaseTask
 from .legged_robot_config import LeggedRobotCfg
 from .native_config import NativeSetup, load_robot_model
@@ -64,10 +66,11 @@ class LeggedRobot(BaseTask):
         mesh_type = self.cfg.terrain.mesh_type
         if mesh_type in ['heightfield', 'trimesh']:
             if self.cfg.terrain.use_terrain_obj:
-                raise NotImplementedError("TerrainObj (OBJ mesh terrain) is not part of the native step yet")
-            self.terrain = Terrain(self.cfg.terrain, self.num_envs)
+                self.terrain = TerrainObj(self.cfg.terrain)
+            else:
+                self.terrain = Terrain(self.cfg.terrain, self.num_envs)
         elif mesh_type == 'confined_trimesh':
-            raise NotImplementedError("confined_trimesh terrain is not part of the native step yet")
+            self.terrain = TerrainConfined(self.cfg.terrain, self.num_envs)
         elif mesh_type == 'plane':
             self.terrain = None
         else:
@@ -127,7 +130,10 @@ class LeggedRobot(BaseTask):
         """Terrain platforms on rough terrain, a grid otherwise (`legged_robot.py:817-844`)."""
         t = self.core.t
         self.env_origins = t["env_origins"]
-        if self.cfg.terrain.mesh_type in ["heightfield", "trimesh", "confined_trimesh"]:
+        if self.cfg.terrain.mesh_type in ["trimesh", "confined_trimesh"] and getattr(self.cfg.terrain, "random_origins", False):
+            self.custom_origins = False
+            self._sample_random_origins()
+        elif self.cfg.terrain.mesh_type in ["heightfield", "trimesh", "confined_trimesh"]:
             self.custom_origins = True
             max_init_level = self.cfg.terrain.max_init_terrain_level
             if not self.cfg.terrain.curriculum:
@@ -153,6 +159,38 @@ class LeggedRobot(BaseTask):
             self.env_origins[:, 0] = (spacing * xx.flatten()[:self.num_envs]).to(self.device)
             self.env_origins[:, 1] = (spacing * yy.flatten()[:self.num_envs]).to(self.device)
             self.env_origins[:, 2] = 0.
+
+    def _sample_random_origins(self):
+        """Origins for multi-layer mesh terrains (`robot_batch_rollout.py:1105-1218`): uniform XY samples in
+        `origins_x_range` x `origins_y_range`, kept where the gap between the lowest surface seen from below ("ground",
+        cast_dir=+1) and the highest seen from above ("ceiling", cast_dir=-1) exceeds `base_height_target x
+        height_clearance_factor`, or where there is a single layer; z = ground height.  The vertical ray casts run on the
+        GPU BVH (`Terrain*.get_heights_batch`)."""
+        tc = self.cfg.terrain
+        need = self.cfg.rewards.base_height_target * tc.height_clearance_factor
+        (x0, x1), (y0, y1) = tc.origins_x_range, tc.origins_y_range
+        kept, attempts = [], 0
+        n_kept = 0
+        while n_kept < self.num_envs and attempts < tc.origin_generation_max_attempts:
+            b = min(1000, tc.origin_generation_max_attempts - attempts)
+            xy = torch.rand(b, 2, device=self.device) * torch.tensor([x1 - x0, y1 - y0], device=self.device) \
+                + torch.tensor([x0, y0], device=self.device)
+            attempts += b
+            ground = torch.from_numpy(self.terrain.get_heights_batch(xy.cpu(), max_height=20.0, cast_dir=1)).to(self.device)
+            ceil = torch.from_numpy(self.terrain.get_heights_batch(xy.cpu(), max_height=20.0, cast_dir=-1)).to(self.device)
+            clearance = ceil - ground
+            ok = (clearance > need) | (clearance < 1e-6)
+            sel = torch.cat([xy[ok], ground[ok].unsqueeze(1).to(xy.dtype)], 1)
+            kept.append(sel)
+            n_kept += sel.shape[0]
+        pos = torch.cat(kept, 0)[:self.num_envs] if kept else torch.zeros(0, 3, device=self.device)
+        if pos.shape[0] == 0:       # nothing valid: fallback grid at nominal height (`:1204-1211`)
+            i = torch.arange(self.num_envs, device=self.device)
+            pos = torch.stack([(i % 10) * 3.0, torch.div(i, 10, rounding_mode='floor') * 3.0,
+                               torch.full_like(i, self.cfg.rewards.base_height_target, dtype=torch.float)], 1)
+        elif pos.shape[0] < self.num_envs:   # reuse valid positions cyclically (`:1198-1202`)
+            pos = pos[torch.arange(self.num_envs, device=self.device) % pos.shape[0]]
+        self.env_origins[:] = pos.to(torch.float32)
 
     def _parse_cfg(self, cfg):
         self.dt = self.cfg.control.decimation * self.sim_params.dt

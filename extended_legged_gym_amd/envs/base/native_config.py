@@ -218,6 +218,8 @@ class NativeSetup:
         rough = cfg.terrain.mesh_type in ['heightfield', 'trimesh', 'confined_trimesh']
         c.curriculum = int(cfg.terrain.curriculum and rough)
         c.custom_origins = int(rough)
+        if cfg.terrain.mesh_type in ['trimesh', 'confined_trimesh'] and getattr(cfg.terrain, "random_origins", False):
+            c.custom_origins, c.curriculum = 0, 0     # origins sampled by ray casts (robot_batch_rollout.py:1105-1107)
         c.max_terrain_level = cfg.terrain.num_rows
         init = cfg.init_state
         _fill(c.base_init_state, list(init.pos) + list(init.rot) + list(init.lin_vel) + list(init.ang_vel))
@@ -245,6 +247,14 @@ class NativeSetup:
             self.height_samples = np.ascontiguousarray(terrain.heightsamples, dtype=np.int16)
             self.terrain_origins = np.ascontiguousarray(terrain.env_origins, dtype=np.float32)
             t.mesh_type = abi.LG_MESH_HEIGHTFIELD
+            if getattr(terrain, "collide_as_mesh", False):
+                # TerrainObj / TerrainConfined: overhangs, ceilings and walls cannot be a height grid; contacts run against
+                # the triangle mesh itself, placed like gym.add_triangle_mesh does (transform.p = -border_size,
+                # robot_batch_rollout.py:376-394).  NativeCore builds the BVH and fills terrain.collision_mesh.
+                t.mesh_type = abi.LG_MESH_TRIMESH
+                shift = np.array([cfg.terrain.border_size, cfg.terrain.border_size, 0.0], dtype=np.float32)
+                self.collision_vertices = np.ascontiguousarray(np.asarray(terrain.vertices, dtype=np.float32) - shift)
+                self.collision_triangles = np.ascontiguousarray(np.asarray(terrain.triangles).astype(np.int32))
             t.rows, t.cols = self.height_samples.shape
             t.horizontal_scale, t.vertical_scale = cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale
             t.border_size = cfg.terrain.border_size

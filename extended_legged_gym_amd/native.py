@@ -49,6 +49,12 @@ class NativeCore:
         self.setup = setup
         self.device = dev
         self.device_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.collision_mesh = None
+        if setup.terrain.mesh_type == abi.LG_MESH_TRIMESH:
+            # the triangle soup the reference hands to gym.add_triangle_mesh; BVH built once, owned by this core
+            from extended_legged_gym_amd.utils.mesh import DeviceMesh
+            self.collision_mesh = DeviceMesh(setup.collision_vertices, setup.collision_triangles, device=dev)
+            setup.terrain.collision_mesh = self.collision_mesh.handle
         nbytes = self.lib.lg_arena_bytes(C.byref(setup.cfg), C.byref(setup.model), C.byref(setup.terrain))
         if nbytes == 0:
             raise ValueError("lg_arena_bytes rejected the configuration: " + self._err(None))

@@ -55,8 +55,11 @@ enum lg_dtype { LG_F32 = 0, LG_I64 = 1, LG_U8 = 2, LG_I16 = 3, LG_I32 = 4, LG_F6
 /* control_type (legged_robot.py:438-447; anymal.py:93-105) */
 enum lg_control { LG_CTRL_P = 0, LG_CTRL_V = 1, LG_CTRL_T = 2, LG_CTRL_ACTUATOR_NET = 3 };
 
-/* terrain mesh type (legged_robot.py:259-274).  LG_MESH_HEIGHTFIELD collides against the int16 grid itself. */
-enum lg_mesh_type { LG_MESH_PLANE = 0, LG_MESH_HEIGHTFIELD = 1 };
+/* terrain mesh type (legged_robot.py:259-274).  LG_MESH_HEIGHTFIELD collides against the int16 grid itself;
+ * LG_MESH_TRIMESH collides against an arbitrary triangle mesh (gym.add_triangle_mesh, legged_robot.py:652-672, with
+ * TerrainObj / TerrainConfined vertices) through closest-point queries on lg_terrain.collision_mesh, while the height
+ * scan keeps reading height_samples (all zero for TerrainObj, terrain_obj.py:116). */
+enum lg_mesh_type { LG_MESH_PLANE = 0, LG_MESH_HEIGHTFIELD = 1, LG_MESH_TRIMESH = 2 };
 
 /* rng_mode: counter-based Philox4x32-10 in-kernel, or uniforms injected by the host (parity / golden tests) */
 enum lg_rng { LG_RNG_PHILOX = 0, LG_RNG_INJECT = 1 };
@@ -169,6 +172,7 @@ typedef struct lg_terrain {
   int32_t num_levels, num_types;      /* terrain_origins shape (num_levels, num_types, 3) */
   const float* terrain_origins;       /* HOST pointer, copied at lg_create */
   float env_length;                   /* terrain.env_length, curriculum distance threshold (:510) */
+  const struct lg_mesh* collision_mesh; /* LG_MESH_TRIMESH: handle from lg_mesh_create (same device), must outlive the ctx */
 } lg_terrain;
 
 typedef struct lg_config {

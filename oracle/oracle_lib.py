@@ -46,6 +46,7 @@ def lib():
         L.lgo_step_subset.argtypes = [vp, vp, vp, C.c_int32, C.c_int32]
         L.lgo_sync_main_to_rollout.argtypes = [vp, C.c_int32, C.c_float, C.c_uint32]
         L.lgo_raycast_bruteforce.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_float, vp, vp]
+        L.lgo_set_collision_mesh.argtypes = [vp, vp, C.c_int64, vp, C.c_int64]
         L.lgo_sdf_bruteforce.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_float, vp, vp]
         _lib = L
     return _lib
@@ -56,6 +57,10 @@ class OracleEnv:
         self.setup = setup
         self.L = lib()
         self.ctx = self.L.lgo_create(C.byref(setup.cfg), C.byref(setup.model), C.byref(setup.terrain))
+        if setup.terrain.mesh_type == abi.LG_MESH_TRIMESH:
+            v = np.ascontiguousarray(setup.collision_vertices, dtype=np.float32)
+            t = np.ascontiguousarray(setup.collision_triangles, dtype=np.int32)
+            self.L.lgo_set_collision_mesh(self.ctx, v.ctypes.data_as(C.c_void_p), len(v), t.ctypes.data_as(C.c_void_p), len(t))
         self.t = {}
         for name, tid in abi.TENSOR_ID.items():
             p, shp, nd, dt = C.c_void_p(), (C.c_int64 * 4)(), C.c_int32(), C.c_int32()
