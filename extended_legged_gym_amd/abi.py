@@ -121,6 +121,10 @@ def declare_product(lib):
     lib.lg_step_physics.restype = C.c_int
     lib.lg_step_subset.argtypes = [vp, vp, vp, i32, i32, vp]
     lib.lg_step_subset.restype = C.c_int
+    lib.lg_step_subset_physics.argtypes = [vp, vp, vp, i32, vp]
+    lib.lg_step_subset_physics.restype = C.c_int
+    lib.lg_post_physics_subset.argtypes = [vp, vp, i32, i32, vp]
+    lib.lg_post_physics_subset.restype = C.c_int
     lib.lg_sync_main_to_rollout.argtypes = [vp, i32, f32, vp]
     lib.lg_sync_main_to_rollout.restype = C.c_int
     lib.lg_compute_torques.argtypes = [vp, vp, vp]
@@ -147,6 +151,10 @@ def declare_product(lib):
     lib.lg_mesh_query_sdf.restype = C.c_int
     lib.lg_raycaster_update.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp, vp, vp, vp]
     lib.lg_raycaster_update.restype = C.c_int
+    lib.lg_raycaster_update_subset.argtypes = [vp, vp, vp, vp, i32, f32, i32, vp, i32, vp, vp, vp, i32, vp]
+    lib.lg_raycaster_update_subset.restype = C.c_int
+    lib.lg_sdf_bodies_update.argtypes = [vp, vp, i32, vp, vp, i32, vp, i32, f32, vp, i32, vp, vp, vp]
+    lib.lg_sdf_bodies_update.restype = C.c_int
     lib.lg_depth_camera_update.argtypes = [vp, C.POINTER(lg_depth_params), vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.lg_depth_camera_update.restype = C.c_int
     lib.lg_profile_begin.argtypes = [vp, i32, i32]
@@ -163,4 +171,5 @@ def declare_product(lib):
 PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_step_physics", "lg_step_subset", "lg_sync_main_to_rollout", "lg_compute_torques",
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
                    "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_last_error",
-                   "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update"]
+                   "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update",
+                   "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update"]

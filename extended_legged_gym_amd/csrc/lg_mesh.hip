@@ -130,13 +130,17 @@ __global__ __launch_bounds__(256) void sdf_kernel(MeshView M, const float* __res
 }
 
 // RayCaster._update_ray_casting + LeggedRobotRayCast._get_raycast_distances (ray_caster.py:558-594,
-// legged_robot_raycast.py:262-297): one lane per (env, ray)
+// legged_robot_raycast.py:262-297): one lane per (listed env, ray); outputs are indexed by env id, the distance
+// observation with a row stride so that it can live inside a wider extra-observation row
 __global__ __launch_bounds__(256) void raycaster_kernel(MeshView M, const float* __restrict__ root /* (N,13) */, const float* __restrict__ ray_o,
-                                                        const float* __restrict__ ray_d, int N, int R, float max_dist, int yaw_only,
-                                                        float* __restrict__ hits, uint8_t* __restrict__ found, float* __restrict__ dist) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)N * R) return;
-  int e = (int)(i / R), r = (int)(i - (int64_t)e * R);
+                                                        const float* __restrict__ ray_d, const int32_t* __restrict__ ids, int n_ids, int R,
+                                                        float max_dist, int yaw_only, float* __restrict__ hits, uint8_t* __restrict__ found,
+                                                        float* __restrict__ dist, int dist_stride) {
+  int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gi >= (int64_t)n_ids * R) return;
+  const int kq = (int)(gi / R), r = (int)(gi - (int64_t)kq * R);
+  const int e = ids ? ids[kq] : kq;
+  const int64_t i = (int64_t)e * R + r;
   const float* rs = root + (size_t)e * 13;
   float q[4] = {rs[3], rs[4], rs[5], rs[6]};
   if (yaw_only) {   // math_utils.quat_apply_yaw: zero x, y and renormalise
@@ -154,7 +158,37 @@ __global__ __launch_bounds__(256) void raycaster_kernel(MeshView M, const float*
   // distance from the ROBOT BASE position, not from the ray origin (legged_robot_raycast.py:278-285)
   float dd = norm(h - pos);
   float nd = 1.f - fminf(fmaxf(dd / max_dist, 0.f), 1.f);
-  dist[i] = hit ? nd : 0.f;
+  dist[(size_t)e * dist_stride + r] = hit ? nd : 0.f;
+}
+
+// RobotBatchRolloutPercept._update_sdf_values (robot_batch_rollout_percept.py:384-440): for every listed env and every query
+// body, the collision-sphere centre = body position + body rotation * offset, then signed distance, unit gradient and the
+// nearest surface point p - sdf * grad (mesh_sdf.py:295-336) — all bodies of all envs in one launch (the reference runs
+// two Warp queries per body).  sdf rows have a stride so they can be the tail of the extra-observation row.
+__global__ __launch_bounds__(256) void sdf_bodies_kernel(MeshView M, const float* __restrict__ rb /* (N,B,13) */, int B,
+                                                         const int32_t* __restrict__ body_idx, const float* __restrict__ offsets, int nb,
+                                                         const int32_t* __restrict__ ids, int n_ids, float max_dist,
+                                                         float* __restrict__ sdf, int sdf_stride, float* __restrict__ grad,
+                                                         float* __restrict__ nearest) {
+  int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gi >= (int64_t)n_ids * nb) return;
+  const int kq = (int)(gi / nb), b = (int)(gi - (int64_t)kq * nb);
+  const int e = ids ? ids[kq] : kq;
+  const float* s = rb + ((size_t)e * B + body_idx[b]) * 13;
+  const float q[4] = {s[3], s[4], s[5], s[6]};
+  V3 p = v3(s[0], s[1], s[2]);
+  if (offsets) p = p + quat_apply(q, v3(offsets[3 * b], offsets[3 * b + 1], offsets[3 * b + 2]));
+  V3 cp, fn; float sd = max_dist; V3 g = v3(0, 0, 0);
+  if (closest_point(M, p, max_dist, &cp, &fn)) {
+    V3 diff = p - cp; float dist = norm(diff);
+    float sign = dot(diff, fn) < 0.f ? -1.f : 1.f;
+    g = dist > 1e-6f ? (sign / dist) * diff : sign * fn;
+    sd = sign * dist;
+  }
+  const size_t o = (size_t)e * nb + b;
+  sdf[(size_t)e * sdf_stride + b] = sd;
+  if (grad) { grad[3 * o] = g.x; grad[3 * o + 1] = g.y; grad[3 * o + 2] = g.z; }
+  if (nearest) { V3 np_ = p - sd * g; nearest[3 * o] = np_.x; nearest[3 * o + 1] = np_.y; nearest[3 * o + 2] = np_.z; }
 }
 
 LG_DEV float cubic_w(float x) {   // Keys kernel, a = -0.75 (torch / torchvision bicubic)
@@ -294,15 +328,37 @@ int lg_mesh_query_sdf(lg_mesh* m, const float* points, int64_t n, float max_dist
   return LG_OK;
 }
 
+int lg_raycaster_update_subset(lg_mesh* m, const float* root_states, const float* ray_origins, const float* ray_dirs, int32_t num_rays,
+                               float max_dist, int32_t attach_yaw_only, const int32_t* env_ids, int32_t n, float* ray_hits,
+                               uint8_t* hits_found, float* raycast_distances, int32_t distance_stride, void* stream) {
+  if (!m || !root_states || !ray_origins || !ray_dirs || !ray_hits || !hits_found || !raycast_distances || n <= 0 || num_rays <= 0 ||
+      distance_stride < num_rays)
+    return LG_ERR_INVALID;
+  MeshView M{m->d_nodes, m->d_tris};
+  int64_t tot = (int64_t)n * num_rays;
+  hipLaunchKernelGGL(raycaster_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, root_states, ray_origins,
+                     ray_dirs, env_ids, n, num_rays, max_dist, attach_yaw_only, ray_hits, hits_found, raycast_distances, distance_stride);
+  MESH_TRY(m, hipGetLastError());
+  return LG_OK;
+}
+
 int lg_raycaster_update(lg_mesh* m, const float* root_states, const float* ray_origins, const float* ray_dirs, int32_t num_envs,
                         int32_t num_rays, float max_dist, int32_t attach_yaw_only, float* ray_hits, uint8_t* hits_found,
                         float* raycast_distances, void* stream) {
-  if (!m || !root_states || !ray_origins || !ray_dirs || !ray_hits || !hits_found || !raycast_distances || num_envs <= 0 || num_rays <= 0)
+  return lg_raycaster_update_subset(m, root_states, ray_origins, ray_dirs, num_rays, max_dist, attach_yaw_only, nullptr, num_envs,
+                                    ray_hits, hits_found, raycast_distances, num_rays, stream);
+}
+
+int lg_sdf_bodies_update(lg_mesh* m, const float* rigid_body_state, int32_t num_bodies, const int32_t* body_indices,
+                         const float* sphere_offsets, int32_t num_query_bodies, const int32_t* env_ids, int32_t n, float max_dist,
+                         float* sdf_values, int32_t sdf_stride, float* sdf_gradients, float* nearest_points, void* stream) {
+  if (!m || !rigid_body_state || !body_indices || !sdf_values || num_bodies <= 0 || num_query_bodies <= 0 || n <= 0 ||
+      sdf_stride < num_query_bodies)
     return LG_ERR_INVALID;
   MeshView M{m->d_nodes, m->d_tris};
-  int64_t n = (int64_t)num_envs * num_rays;
-  hipLaunchKernelGGL(raycaster_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, root_states, ray_origins,
-                     ray_dirs, num_envs, num_rays, max_dist, attach_yaw_only, ray_hits, hits_found, raycast_distances);
+  int64_t tot = (int64_t)n * num_query_bodies;
+  hipLaunchKernelGGL(sdf_bodies_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, rigid_body_state, num_bodies,
+                     body_indices, sphere_offsets, num_query_bodies, env_ids, n, max_dist, sdf_values, sdf_stride, sdf_gradients, nearest_points);
   MESH_TRY(m, hipGetLastError());
   return LG_OK;
 }

@@ -1286,6 +1286,20 @@ int lg_step_subset(lg_ctx* c, const float* actions, const int32_t* env_ids, int3
   return launch_post(c, st, nullptr, env_ids, n, rollout_mode ? 1 : 0);
 }
 
+int lg_step_subset_physics(lg_ctx* c, const float* actions, const int32_t* env_ids, int32_t n, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (!actions || !env_ids || n <= 0 || n > c->h.N) { c->err = "bad subset step arguments"; return LG_ERR_INVALID; }
+  launch_physics(c, (hipStream_t)stream, actions, env_ids, n);
+  HIP_TRY(c, hipGetLastError());
+  return LG_OK;
+}
+
+int lg_post_physics_subset(lg_ctx* c, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (!env_ids || n <= 0 || n > c->h.N) { c->err = "bad subset step arguments"; return LG_ERR_INVALID; }
+  return launch_post(c, (hipStream_t)stream, nullptr, env_ids, n, rollout_mode ? 1 : 0);
+}
+
 int lg_step_physics(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
   if (!actions) { c->err = "actions is null"; return LG_ERR_INVALID; }

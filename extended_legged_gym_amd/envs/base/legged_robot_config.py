@@ -49,6 +49,12 @@ class LeggedRobotCfg(BaseConfig):
         terrain_proportions = [0.1, 0.1, 0.35, 0.25, 0.2]   # smooth slope, rough slope, stairs up, stairs down, discrete
         confined_terrain_proportions = [0.25, 0.5, 0.75, 1.0]
         slope_treshold = 0.75
+        # origins for multi-layer mesh terrains (values of base_pose_adapt_config.py:77-81; off by default)
+        random_origins = False
+        origin_generation_max_attempts = 10000
+        origins_x_range = [-20.0, 20.0]
+        origins_y_range = [-20.0, 20.0]
+        height_clearance_factor = 2.0
 
     class raycaster:
         enable_raycast = False

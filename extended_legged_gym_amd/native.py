@@ -109,6 +109,15 @@ class NativeCore:
         a = self._f32(actions)
         self._check(self.lib.lg_step_physics(self.ctx, C.c_void_p(a.data_ptr()), self._stream()))
 
+    def step_subset_physics(self, actions, env_ids_i32):
+        a = self._f32(actions)
+        self._check(self.lib.lg_step_subset_physics(self.ctx, C.c_void_p(a.data_ptr()), C.c_void_p(env_ids_i32.data_ptr()),
+                                                    int(env_ids_i32.numel()), self._stream()))
+
+    def post_physics_subset(self, env_ids_i32, rollout_mode):
+        self._check(self.lib.lg_post_physics_subset(self.ctx, C.c_void_p(env_ids_i32.data_ptr()), int(env_ids_i32.numel()),
+                                                    int(rollout_mode), self._stream()))
+
     def step_subset(self, actions, env_ids_i32, rollout_mode):
         a = self._f32(actions)
         self._check(self.lib.lg_step_subset(self.ctx, C.c_void_p(a.data_ptr()), C.c_void_p(env_ids_i32.data_ptr()),
@@ -148,6 +157,9 @@ class NativeCore:
             torch.cuda.synchronize(self.device)
             self.lib.lg_destroy(self.ctx)
             self.ctx = None
+        if getattr(self, "collision_mesh", None) is not None:
+            self.collision_mesh.close()
+            self.collision_mesh = None
 
     def __del__(self):
         try:

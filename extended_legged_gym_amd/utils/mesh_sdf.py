@@ -59,6 +59,24 @@ class MeshSDF:
         self._data.sdf_values, self._data.sdf_gradients = sdf.reshape(shape[:-1]), grad.reshape(shape)
         return self._data.sdf_values, self._data.sdf_gradients
 
+    def query_bodies(self, rigid_body_state, num_bodies, body_indices_i32, sphere_offsets, sdf_rows, gradients=None,
+                     nearest=None, env_ids_i32=None):
+        """Fused `_update_sdf_values` (`robot_batch_rollout_percept.py:384-440`): for the listed envs (all when None) and
+        every query body, point = body position + body rotation * offset; writes `sdf_rows[e, b]` (a strided
+        (N, n_query) view is fine) and optionally `gradients` / `nearest` (N, n_query, 3).  One launch, no host sync."""
+        mesh = next(iter(self.meshes.values()))
+        rb = rigid_body_state if rigid_body_state.is_contiguous() else rigid_body_state.contiguous()
+        nq = int(body_indices_i32.numel())
+        assert sdf_rows.dtype == torch.float32 and sdf_rows.stride(1) == 1 and sdf_rows.shape[1] == nq
+        N = sdf_rows.shape[0]
+        n = N if env_ids_i32 is None else int(env_ids_i32.numel())
+
+        def ptr(t):
+            return C.c_void_p(None) if t is None else C.c_void_p(t.data_ptr())
+        mesh._check(mesh.lib.lg_sdf_bodies_update(mesh.handle, ptr(rb), int(num_bodies), ptr(body_indices_i32), ptr(sphere_offsets),
+                                                  nq, ptr(env_ids_i32), n, float(self.cfg.max_distance), ptr(sdf_rows),
+                                                  int(sdf_rows.stride(0)), ptr(gradients), ptr(nearest), mesh._stream()))
+
     def nearest_points(self, query_points: torch.Tensor) -> torch.Tensor:
         sdf, grad = self.query(query_points)
         return query_points - sdf.unsqueeze(-1) * grad

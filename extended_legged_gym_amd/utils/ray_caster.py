@@ -164,37 +164,79 @@ class RayCaster:
         self.ray_origins = self._pattern_origins.repeat(num_envs, 1, 1)
         self.ray_directions = self._pattern_dirs.repeat(num_envs, 1, 1)
         self._data = RayCasterData()
-        self._data.pos = torch.zeros(num_envs, 3, device=device)
-        self._data.rot = torch.zeros(num_envs, 4, device=device)
-        self._data.rot[:, 3] = 1.0
+        self._pos_own = torch.zeros(num_envs, 3, device=device)
+        self._rot_own = torch.zeros(num_envs, 4, device=device)
+        self._rot_own[:, 3] = 1.0
+        self._data.pos, self._data.rot = self._pos_own, self._rot_own
         self._data.ray_hits = torch.zeros(num_envs, self.num_rays, 3, device=device)
         self._hits_found_u8 = torch.zeros(num_envs, self.num_rays, dtype=torch.uint8, device=device)
         self._data.ray_hits_found = self._hits_found_u8.view(torch.bool)
         self.raycast_distances = torch.zeros(num_envs, self.num_rays, device=device)
         self._is_initialized = True
 
-    def update_from_root_states(self, dt: float, root_states: torch.Tensor):
-        """All envs, every call (`update_period == 0`, the only mode the reference's env classes use): rays follow
-        the base pose in `root_states` (N, 13); fills hits, found mask and the normalised distance observation."""
-        self._timestamp += dt
+    def bind_distance_rows(self, rows: torch.Tensor):
+        """Write the distance observation into columns [0, num_rays) of a wider (N, >= num_rays) float32 row buffer
+        (the env's extra-observation rows) instead of the sensor's own (N, num_rays) tensor."""
+        assert rows.dtype == torch.float32 and rows.dim() == 2 and rows.shape[0] == self.num_envs
+        assert rows.stride(1) == 1 and rows.stride(0) >= self.num_rays
+        self.raycast_distances = rows[:, :self.num_rays]
+
+    def _cast(self, root_states: torch.Tensor, env_ids_i32: torch.Tensor = None):
+        """One launch: rays of all envs (or of the listed ones) from the base poses in `root_states` (N, 13)."""
         mesh = next(iter(self.meshes.values()))
         rs = root_states if root_states.is_contiguous() else root_states.contiguous()
-        mesh._check(mesh.lib.lg_raycaster_update(
+        n = self.num_envs if env_ids_i32 is None else int(env_ids_i32.numel())
+        ids = C.c_void_p(None) if env_ids_i32 is None else C.c_void_p(env_ids_i32.data_ptr())
+        mesh._check(mesh.lib.lg_raycaster_update_subset(
             mesh.handle, C.c_void_p(rs.data_ptr()), C.c_void_p(self._pattern_origins.data_ptr()),
-            C.c_void_p(self._pattern_dirs.data_ptr()), self.num_envs, self.num_rays, float(self.cfg.max_distance),
-            int(bool(self.cfg.attach_yaw_only)), C.c_void_p(self._data.ray_hits.data_ptr()),
-            C.c_void_p(self._hits_found_u8.data_ptr()), C.c_void_p(self.raycast_distances.data_ptr()), mesh._stream()))
-        self._data.pos, self._data.rot = rs[:, 0:3], rs[:, 3:7]
-        self._timestamp_last_update[:] = self._timestamp
-        self._is_outdated[:] = False
+            C.c_void_p(self._pattern_dirs.data_ptr()), self.num_rays, float(self.cfg.max_distance),
+            int(bool(self.cfg.attach_yaw_only)), ids, n, C.c_void_p(self._data.ray_hits.data_ptr()),
+            C.c_void_p(self._hits_found_u8.data_ptr()), C.c_void_p(self.raycast_distances.data_ptr()),
+            int(self.raycast_distances.stride(0)), mesh._stream()))
+
+    def update_from_root_states(self, dt: float, root_states: torch.Tensor, env_ids_i32: torch.Tensor = None):
+        """The env classes' path (`update_period == 0`): rays follow the base pose in `root_states` (N, 13); fills hits,
+        found mask and the normalised distance observation of all envs, or of the envs in `env_ids_i32` (int32, device)."""
+        self._timestamp += dt
+        self._cast(root_states, env_ids_i32)
+        self._data.pos, self._data.rot = root_states[:, 0:3], root_states[:, 3:7]
+        if env_ids_i32 is None:
+            self._timestamp_last_update[:] = self._timestamp
+            self._is_outdated[:] = False
+        else:
+            idx = env_ids_i32.long()
+            self._timestamp_last_update[idx] = self._timestamp[idx]
+            self._is_outdated[idx] = False
 
     def update(self, dt: float, sensor_pos: torch.Tensor, sensor_rot: torch.Tensor, env_ids: torch.Tensor = None):
-        """Reference signature (`ray_caster.py:518-556`); `sensor_rot` is xyzw like every caller passes it."""
-        if env_ids is not None or self.cfg.update_period > 0.0:
-            raise NotImplementedError("partial / periodic ray-caster updates are not part of the native path")
+        """Reference signature and scheduling (`ray_caster.py:518-556`): every env's clock advances by `dt`; without
+        `env_ids` the envs whose last cast is at least `cfg.update_period` old are re-cast (all of them when the period
+        is 0), with `env_ids` exactly those are.  `sensor_rot` is xyzw like every caller passes it."""
+        self._timestamp += dt
+        if env_ids is None:
+            self._is_outdated |= (self._timestamp - self._timestamp_last_update + 1e-6 >= self.cfg.update_period)
+            if self.cfg.update_period > 0.0:
+                env_ids = self._is_outdated.nonzero().squeeze(-1)
+        else:
+            env_ids = torch.as_tensor(env_ids, device=self.device)
+            self._is_outdated[env_ids] = True
+        if env_ids is not None and len(env_ids) == 0:
+            return
         rs = torch.zeros(self.num_envs, 13, device=self.device)
         rs[:, 0:3], rs[:, 3:7] = sensor_pos, sensor_rot
-        self.update_from_root_states(dt, rs)
+        if env_ids is None:
+            self._cast(rs)
+            self._data.pos, self._data.rot = rs[:, 0:3], rs[:, 3:7]
+            self._timestamp_last_update[:] = self._timestamp
+            self._is_outdated[:] = False
+        else:
+            self._cast(rs, env_ids.to(torch.int32).contiguous())
+            if not self._data.pos.is_contiguous() or self._data.pos.data_ptr() != self._pos_own.data_ptr():
+                self._data.pos, self._data.rot = self._pos_own, self._rot_own
+            self._data.pos[env_ids] = rs[env_ids, 0:3]
+            self._data.rot[env_ids] = rs[env_ids, 3:7]
+            self._timestamp_last_update[env_ids] = self._timestamp[env_ids]
+            self._is_outdated[env_ids] = False
 
     def reset(self, env_ids=None):
         if env_ids is None:

@@ -249,6 +249,11 @@ int lg_step_physics(lg_ctx* ctx, const float* actions, void* stream);
  * envs are not touched (the reference simulates and then restores them, :687, :1585-1640). */
 int lg_step_subset(lg_ctx* ctx, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream);
 
+/* The two halves of lg_step_subset, so that sensor kernels (ray caster, body SDF) can run on the post-physics, pre-reset state
+ * in between (RobotBatchRolloutPercept._post_physics_step_callback, robot_batch_rollout_percept.py:301-331). */
+int lg_step_subset_physics(lg_ctx* ctx, const float* actions, const int32_t* env_ids, int32_t n, void* stream);
+int lg_post_physics_subset(lg_ctx* ctx, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream);
+
 /* _sync_main_to_rollout (:1447-1535): with env i*(1+R) the i-th main env and the next R envs its rollouts, copy root /
  * DOF state, actions, history, base velocities, projected gravity and the feet contact state from every main env to its
  * rollouts; pos_drift > 0 adds U(-drift/2, drift/2) to the copied base positions (:1493-1497). */
@@ -287,6 +292,21 @@ int lg_mesh_query_sdf(lg_mesh* mesh, const float* points, int64_t n_points, floa
 int lg_raycaster_update(lg_mesh* mesh, const float* root_states, const float* ray_origins, const float* ray_dirs,
                         int32_t num_envs, int32_t num_rays, float max_dist, int32_t attach_yaw_only,
                         float* ray_hits, uint8_t* hits_found, float* raycast_distances, void* stream);
+
+/* The same for the n listed envs only (env_ids: device pointer, NULL = envs 0..n-1; RayCaster.update(env_ids=...),
+ * ray_caster.py:518-556): outputs stay indexed by env id; row e of the distance observation starts at
+ * raycast_distances + e * distance_stride (>= num_rays), so it can sit inside a wider extra-observation row. */
+int lg_raycaster_update_subset(lg_mesh* mesh, const float* root_states, const float* ray_origins, const float* ray_dirs,
+                               int32_t num_rays, float max_dist, int32_t attach_yaw_only, const int32_t* env_ids, int32_t n,
+                               float* ray_hits, uint8_t* hits_found, float* raycast_distances, int32_t distance_stride, void* stream);
+
+/* RobotBatchRolloutPercept._update_sdf_values (robot_batch_rollout_percept.py:384-440): for the n listed envs (NULL = all)
+ * and the num_query_bodies bodies body_indices[] (device), query point = body position + body rotation * sphere_offsets[b]
+ * (device (nq,3) or NULL) read from rigid_body_state (N, num_bodies, 13); writes sdf_values[e * sdf_stride + b] and, when not
+ * NULL, sdf_gradients (N,nq,3) and nearest_points (N,nq,3) = p - sdf * grad.  One launch for all bodies. */
+int lg_sdf_bodies_update(lg_mesh* mesh, const float* rigid_body_state, int32_t num_bodies, const int32_t* body_indices,
+                         const float* sphere_offsets, int32_t num_query_bodies, const int32_t* env_ids, int32_t n, float max_dist,
+                         float* sdf_values, int32_t sdf_stride, float* sdf_gradients, float* nearest_points, void* stream);
 
 typedef struct lg_depth_params {
   int32_t width, height;                 /* cfg.depth.original */

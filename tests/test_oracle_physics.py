@@ -225,3 +225,86 @@ def test_terrain_surface_is_the_grid_triangulation():
     assert abs(o2.terrain(x0 - 0.05, y0 - 0.05)[0] - 0.25) < 1e-6      # diagonal of cell (9,9) ends at the raised vertex
     assert abs(o2.terrain(x0 - 0.05, y0 + 0.05)[0] - 0.0) < 1e-6       # off-diagonal corner pair is flat
     o.close(); o2.close()
+
+
+# ------------------------------------------------------------------------------------------------ triangle-mesh terrain
+class MeshFixtureTerrain(FixtureTerrain):
+    """A terrain object that asks for triangle contacts (what TerrainObj / TerrainConfined do)."""
+    collide_as_mesh = True
+
+    def __init__(self, vertices, triangles, heightsamples, env_origins, env_length):
+        super().__init__(heightsamples, env_origins, env_length)
+        self.vertices, self.triangles = vertices, triangles
+
+
+def _mesh_cfg(cfg):
+    cfg.terrain.mesh_type = "trimesh"; cfg.terrain.border_size = 0.0
+    cfg.terrain.num_rows = cfg.terrain.num_cols = 1; cfg.terrain.curriculum = False
+    cfg.terrain.random_origins = True            # grid origins, no random XY at reset: same layout as the plane run
+    cfg.terrain.measure_heights = False
+
+
+def test_mesh_terrain_two_triangle_plane_equals_the_plane():
+    """Contacts against a triangle mesh that happens to be the plane z = 0 reproduce the plane terrain: same normals
+    (0, 0, 1), same gaps, hence the same trajectory up to fp32 rounding of the closest-point arithmetic."""
+    v = np.array([[-50, -50, 0], [50, -50, 0], [50, 50, 0], [-50, 50, 0]], np.float32)
+    t = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    ter = MeshFixtureTerrain(v, t, np.zeros((4, 4), np.int16), np.zeros((1, 1, 3), np.float32), 5.0)
+    n = 4
+    cfg, s, model, om = make(n=n, control="P", terrain=ter, mutate=_mesh_cfg)
+    assert s.terrain.mesh_type == abi.LG_MESH_TRIMESH and s.cfg.custom_origins == 0
+    _, _, _, op = make(n=n, control="P")
+    rng = np.random.default_rng(2)
+    for o in (om, op):
+        o.reset_idx(np.arange(n))
+    np.testing.assert_allclose(om.t["root_states"], op.t["root_states"], atol=1e-6)
+    for it in range(60):
+        a = rng.normal(size=(n, 12)).astype(np.float32)
+        om.step(a); op.step(a)
+        if it == 9:          # before contact switching amplifies the rounding differences
+            for name in ["root_states", "dof_state", "contact_forces"]:
+                a_, b_ = om.t[name], op.t[name]
+                assert np.abs(a_ - b_).max() <= 1e-3 * max(1.0, np.abs(b_).max()), name
+    for name in ["root_states", "dof_state"]:
+        a, b = om.t[name], op.t[name]
+        assert np.abs(a - b).max() <= 5e-2 * max(1.0, np.abs(b).max()), name
+    assert om.t["contact_forces"][:, model["feet_indices"], 2].max() > 50.0
+    om.close(); op.close()
+
+
+def test_mesh_terrain_supports_the_robot_on_a_raised_box_and_under_a_ceiling():
+    """A robot reset above a 0.3 m box stands on the box top, not on the floor; one started under a low ceiling slab
+    is pushed back down by it (the ceiling faces look down, the normal comes from the closest point, not from +z)."""
+    def box(x0, x1, y0, y1, z0, z1, base):
+        c = np.array([[x0, y0, z0], [x1, y0, z0], [x1, y1, z0], [x0, y1, z0], [x0, y0, z1], [x1, y0, z1], [x1, y1, z1], [x0, y1, z1]], np.float32)
+        f = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6], [3, 0, 4], [3, 4, 7]], np.int32)
+        return c, f + base
+    floor_v = np.array([[-30, -30, 0], [30, -30, 0], [30, 30, 0], [-30, 30, 0]], np.float32)
+    floor_t = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    bv, bt = box(-1.5, 1.5, -1.5, 1.5, 0.0, 0.3, 4)            # env 0 (origin 0, 0) stands on this
+    cv, ct = box(1.5, 4.5, -1.5, 1.5, 0.62, 0.8, 12)           # slab over env 1 at (3, 0): underside at 0.62
+    v = np.concatenate([floor_v, bv, cv]); t = np.concatenate([floor_t, bt, ct])
+    ter = MeshFixtureTerrain(v, t, np.zeros((4, 4), np.int16), np.zeros((1, 1, 3), np.float32), 5.0)
+    cfg, s, model, o = make(n=2, control="P", terrain=ter, mutate=_mesh_cfg)
+    o.t["env_origins"][1] = [3.0, 0.0, 0.0]                     # (the env layer writes the grid; here by hand)
+    o.reset_idx(np.arange(2))
+    o.t["root_states"][0, 2] += 0.3
+    o.t["root_states"][:, 7:13] = 0
+    o.t["root_states"][1, 9] = 3.0                              # env 1 jumps into the slab
+    top = []
+    for _ in range(50):
+        o.step(np.zeros((2, 12), np.float32))
+        top.append(o.t["root_states"][1, 2])
+    feet = model["feet_indices"]
+    assert np.all(o.t["rigid_body_state"][0, feet, 2] > 0.3 - 0.01)          # on the box
+    assert 0.3 + 0.35 < o.t["root_states"][0, 2] < 0.3 + 0.65
+    # the trunk's collision spheres (radius >= 5 cm) stop at the slab underside: the base origin never passes it
+    assert max(top) < 0.62 + 0.02
+    _, _, _, free = make(n=2, control="P")
+    free.reset_idx(np.arange(2)); free.t["root_states"][:, 7:13] = 0; free.t["root_states"][1, 9] = 3.0
+    peak = 0
+    for _ in range(50):
+        free.step(np.zeros((2, 12), np.float32)); peak = max(peak, free.t["root_states"][1, 2])
+    assert peak > 0.62 + 0.1                                                 # without the slab the same jump goes higher
+    assert not np.isnan(o.t["root_states"]).any()
+    o.close(); free.close()
