@@ -1311,7 +1311,8 @@ int lg_step_physics(lg_ctx* c, const float* actions, void* stream) {
 // RobotBatchRollout._sync_main_to_rollout (robot_batch_rollout.py:1447-1535): env i*(1+R) is main i, the next R envs are
 // its rollouts; one lane per (rollout env, float) copies the 12 state tensors the reference copies.
 __global__ __launch_bounds__(256) void sync_kernel(const DevCtx* __restrict__ C, int R, float drift, uint32_t seed_lo, uint32_t call) {
-  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1;   // floats (+ one slot for the 4 contact bytes)
+  const int B = C->B;
+  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1 + B * 16;   // floats (+ one slot for the 4 contact bytes)
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)C->N * per;
   if (gid >= total) return;
@@ -1337,13 +1338,25 @@ __global__ __launch_bounds__(256) void sync_kernel(const DevCtx* __restrict__ C,
   o -= 3; if (o < 3) { C->proj_grav[(size_t)e * 3 + o] = C->proj_grav[(size_t)src * 3 + o]; return; }
   o -= 3; if (o < 4) { C->feet_air[(size_t)e * 4 + o] = C->feet_air[(size_t)src * 4 + o]; return; }
   o -= 4; if (o < 4) { C->feet_ctime[(size_t)e * 4 + o] = C->feet_ctime[(size_t)src * 4 + o]; return; }
-  for (int f = 0; f < 4; ++f) C->last_contacts[(size_t)e * 4 + f] = C->last_contacts[(size_t)src * 4 + f];
+  o -= 4; if (o < 1) { for (int f = 0; f < 4; ++f) C->last_contacts[(size_t)e * 4 + f] = C->last_contacts[(size_t)src * 4 + f]; return; }
+  // body states and contact forces: what the rollouts would hold had they been stepped along with their main (the
+  // reference steps every env with the main's action, :554-594); the position drift moves all bodies alike
+  o -= 1; if (o < B * 13) {
+    float v = C->rigid[(size_t)src * B * 13 + o];
+    const int comp = o % 13;
+    if (drift > 0.f && comp < 3) {
+      uint32_t r4[4]; philox4((uint32_t)e, call, (uint32_t)comp, 7u, seed_lo, 0x5a5au, r4);
+      v += (u01(r4[0]) - 0.5f) * drift;
+    }
+    C->rigid[(size_t)e * B * 13 + o] = v; return;
+  }
+  o -= B * 13; C->cforce[(size_t)e * B * 3 + o] = C->cforce[(size_t)src * B * 3 + o];
 }
 
 int lg_sync_main_to_rollout(lg_ctx* c, int32_t rollouts_per_main, float pos_drift, void* stream) {
   if (!c) return LG_ERR_INVALID;
   if (rollouts_per_main <= 0 || c->h.N % (1 + rollouts_per_main) != 0) { c->err = "num_envs is not num_main * (1 + rollouts_per_main)"; return LG_ERR_INVALID; }
-  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1;
+  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1 + c->h.B * 16;
   int64_t total = (int64_t)c->h.N * per;
   hipLaunchKernelGGL(sync_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c->d, rollouts_per_main, pos_drift,
                      (uint32_t)c->h.cfg.seed, (uint32_t)(c->sync_calls++));

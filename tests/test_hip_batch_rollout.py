@@ -37,7 +37,8 @@ def test_subset_step_and_sync_match_oracle():
     # sync (with position drift from the shared Philox stream), then a rollout-mode step of the rollout envs only
     o.sync_main_to_rollout(R, 0.05, 0); core.sync_main_to_rollout(R, 0.05)
     torch.cuda.synchronize()
-    for name in ["root_states", "dof_state", "actions", "last_actions", "last_dof_vel", "last_root_vel", "feet_air_time"]:
+    for name in ["root_states", "dof_state", "actions", "last_actions", "last_dof_vel", "last_root_vel", "feet_air_time",
+                 "rigid_body_state", "contact_forces"]:
         np.testing.assert_allclose(core.t[name].cpu().numpy(), o.t[name], rtol=1e-6, atol=1e-7, err_msg=name)
     assert np.array_equal(core.t["last_contacts"].cpu().numpy(), o.t["last_contacts"])
     before_main = {n: core.t[n][torch.from_numpy(main).long().cuda()].clone() for n in ("root_states", "dof_state", "episode_length_buf", "episode_sums" if False else "rew_buf")}
