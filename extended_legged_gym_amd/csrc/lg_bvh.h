@@ -120,13 +120,16 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
         const float4* T = M.tris + (size_t)(n.left_first + i) * 3;
         float4 a4 = T[0], b4 = T[1], c4 = T[2];
         V3 a = v3(a4.x, a4.y, a4.z), b = v3(b4.x, b4.y, b4.z), c = v3(c4.x, c4.y, c4.z);
+        // zero-area faces (slope-corrected height-field meshes are full of them) are skipped: their points belong to
+        // the edges of their neighbours, and the barycentric arithmetic below is 0/0 on them
+        V3 fn = cross(b - a, c - a); float fl = norm(fn);
+        if (!(fl > 1e-10f)) continue;
         V3 q = closest_on_triangle(p, a, b, c);
         V3 dq = p - q; float d2 = dot(dq, dq);
-        if (d2 > best2 * (1.f + 1e-5f) + 1e-12f) continue;
-        V3 fn = cross(b - a, c - a); float fl = norm(fn);
+        if (!(d2 <= best2 * (1.f + 1e-5f) + 1e-12f)) continue;
         const bool strictly = !found || d2 < best2 * (1.f - 1e-5f) - 1e-12f;
         if (strictly) { bestabs = -1.f; bestn = v3(0, 0, 1); }
-        if (fl > 1e-10f) {                     // degenerate (zero-area) faces never decide the sign
+        {
           V3 nh = (1.f / fl) * fn;
           float sd = dot(dq, nh);
           float ab = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f);   // coincident faces of opposite orientation: outside wins

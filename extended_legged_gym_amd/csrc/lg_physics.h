@@ -272,11 +272,19 @@ LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const Phys
 }
 
 // Triangle-mesh terrain (LG_MESH_TRIMESH): the surface under a sphere is the closest point of the collision mesh within
-// radius + contact_offset + LG_MESH_CONTACT_MARGIN; normal = direction from that point to the sphere centre (flipped
-// when the centre is behind the deciding face), gap = signed distance - radius.  Same slot-table outputs as above.
-#define LG_MESH_CONTACT_MARGIN 0.02f
+// range = radius + contact_offset + LG_MESH_CONTACT_MARGIN (the margin lets a sphere whose centre has sunk below the surface
+// still find it); normal = direction from that point to the sphere centre (flipped when the centre is behind the deciding
+// face), gap = signed distance - radius.  Same slot-table outputs as above.
+//
+// `cq` (optional, LDS, [slot][4][lane]) caches per sphere the position and the unsigned surface distance of its last
+// query, which looked LG_MESH_CACHE_REACH further than `range`.  While the sphere has moved less than that distance minus
+// `range` since, no triangle can be within `range` and the traversal is skipped — an exact cull, the result is what
+// the query would have returned (nothing).  Most spheres of a walking robot (trunk, hips, thighs) ride on it.
+#define LG_MESH_CONTACT_MARGIN 0.1f
+#define LG_MESH_CACHE_REACH 0.15f
+#define CQ(slot, f) cq[((slot) * 4 + (f)) * 64 + lane]
 LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k,
-                                const M3& Rb, V3 pb, float* cst, int lane) {
+                                const M3& Rb, V3 pb, float* cst, int lane, float* cq = nullptr, bool first = true) {
   const int ncp = lm_.i(LM_CP_COUNT);
   const float idt_ = frcp(P.dt);
 #pragma unroll 1
@@ -288,13 +296,21 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
       rad = lm_.f(LM_CP_RADIUS + sl);
       x = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
-      V3 cp, fn;
-      if (closest_point(T.M, x, rad + P.contact_offset + LG_MESH_CONTACT_MARGIN, &cp, &fn)) {
-        const V3 diff = x - cp; const float dist = norm(diff);
-        const float sign = dot(diff, fn) < 0.f ? -1.f : 1.f;
-        n = dist > 1e-6f ? (sign / dist) * diff : fn;
-        phi = sign * dist - rad;
-        active = phi < P.contact_offset;
+      const float range = rad + P.contact_offset + LG_MESH_CONTACT_MARGIN;
+      bool query = true;
+      if (cq && !first) query = !(norm(x - v3(CQ(sl, 0), CQ(sl, 1), CQ(sl, 2))) < CQ(sl, 3) - range);
+      if (query) {
+        V3 cp, fn;
+        const float reach = cq ? range + LG_MESH_CACHE_REACH : range;
+        const bool found = closest_point(T.M, x, reach, &cp, &fn);
+        const V3 diff = x - cp; const float dist = found ? norm(diff) : reach;
+        if (cq) { CQ(sl, 0) = x.x; CQ(sl, 1) = x.y; CQ(sl, 2) = x.z; CQ(sl, 3) = dist; }
+        if (found && dist <= range) {
+          const float sign = dot(diff, fn) < 0.f ? -1.f : 1.f;
+          n = dist > 1e-6f ? (sign / dist) * diff : fn;
+          phi = sign * dist - rad;
+          active = phi < P.contact_offset;
+        }
       }
     }
     CS(sl, CF_ACTIVE) = active ? 1.f : 0.f;

