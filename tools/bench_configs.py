@@ -51,28 +51,43 @@ def config3():
     from extended_legged_gym_amd.envs.base.legged_robot import LeggedRobot
     from extended_legged_gym_amd.utils.obj_io import save_obj
     from extended_legged_gym_amd.utils.terrain_confine import TerrainConfined
-    gen = A1RoughCfg().terrain
-    gen.mesh_type, gen.curriculum, gen.border_size = "confined_trimesh", True, 5.0
-    gen.confined_terrain_proportions = [0.25, 0.25, 0.25, 0.25]        # tunnel, barrier, timber piles, gaps
-    np.random.seed(1)
+    from extended_legged_gym_amd.utils.terrain_confine import convert_2layer_heightfield_to_trimesh
+    gen = A1RoughCfg().terrain                                          # timber-pile + barrier mix,
+    gen.mesh_type, gen.curriculum, gen.border_size = "confined_trimesh", True, 5.0      # 8 m tiles, seed 2, two layers
+    gen.num_rows, gen.num_cols, gen.terrain_length, gen.terrain_width = 4, 4, 8.0, 8.0
+    gen.confined_terrain_proportions = [0.0, 0.5, 0.5, 0.0, 0.0, 0.0]
+    np.random.seed(2)
     tc = TerrainConfined(gen, 4096)
+    v, tri = convert_2layer_heightfield_to_trimesh(tc.ground_height_field_raw, tc.ceiling_height_field_raw, gen.horizontal_scale,
+                                                   gen.vertical_scale, gen.slope_treshold, enable_ceiling=True)
     path = os.path.join(tempfile.mkdtemp(), "confined.obj")
-    save_obj(path, tc.vertices, tc.triangles)
+    save_obj(path, v, tri)
     cfg = A1RoughCfg(); cfg.env.num_envs = 4096; cfg.seed = 1
     t = cfg.terrain
     t.mesh_type, t.use_terrain_obj, t.terrain_file, t.curriculum = "trimesh", True, path, False
-    t.random_origins, t.origins_x_range, t.origins_y_range = True, [-19.0, 19.0], [-19.0, 19.0]
+    t.random_origins, t.origins_x_range, t.origins_y_range = True, [-15.0, 15.0], [-15.0, 15.0]
     t.height_clearance_factor = 2.0
     env = LeggedRobot(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
     env.reset()
     a = torch.randn(4096, 12, device="cuda")
-    dt = timeit(lambda: env.step(a), 100, 200)
-    ok = bool(torch.isfinite(env.root_states).all())
+    # SDF of 5 bodies per env per step (trunk + 4 feet), as RobotBatchRolloutPercept does it: one fused launch
+    from extended_legged_gym_amd.utils.mesh_sdf import MeshSDF, MeshSDFCfg
+    sdf = MeshSDF(MeshSDFCfg(max_distance=10.0), device="cuda:0", mesh=env.core.collision_mesh)
+    bodies = torch.tensor([0] + env.feet_indices.tolist(), dtype=torch.int32, device="cuda")
+    vals, grads, near = torch.zeros(4096, 5, device="cuda"), torch.zeros(4096, 5, 3, device="cuda"), torch.zeros(4096, 5, 3, device="cuda")
+
+    def one():
+        env.step(a)
+        sdf.query_bodies(env.rigid_body_state.view(4096, env.num_bodies, 13), env.num_bodies, bodies, None, vals, grads, near)
+    dt = timeit(one, 100, 200)
+    dt_sdf = timeit(lambda: sdf.query_bodies(env.rigid_body_state.view(4096, env.num_bodies, 13), env.num_bodies, bodies, None,
+                                             vals, grads, near), 20, 200)
+    ok = bool(torch.isfinite(env.root_states).all() and torch.isfinite(vals).all())
     mesh = env.core.collision_mesh
     z = env.root_states[:, 2]
-    return dict(config="3: Unitree A1, confined-space OBJ mesh (TerrainObj), SDF contacts on the BVH, 4096 envs on 1 GPU",
-                env_steps_per_s=4096 / dt, ms_per_step=dt * 1e3, mesh_triangles=mesh.num_triangles, bvh_nodes=mesh.num_bvh_nodes,
-                finite=ok, base_z_min=float(z.min()), base_z_median=float(z.median()),
+    return dict(config="3: Unitree A1, confined-space OBJ mesh (TerrainObj), SDF contacts on the BVH + SDF of 5 bodies/env/step, 4096 envs on 1 GPU",
+                env_steps_per_s=4096 / dt, ms_per_step=dt * 1e3, sdf_5_bodies_ms=dt_sdf * 1e3,
+                mesh_triangles=mesh.num_triangles, bvh_nodes=mesh.num_bvh_nodes, finite=ok, base_z_min=float(z.min()), base_z_median=float(z.median()),
                 mean_episode_len=float(env.episode_length_buf.float().mean()))
 
 
