@@ -6,10 +6,11 @@
 //   physics_kernel   one DPP quad (4 lanes) per env, one leg per lane, 16 envs per wave64; clip actions, then
 //                    `decimation` x (actuator torques [PD | LSTM] + articulated dynamics + contact) entirely in
 //                    registers/LDS; state is read once and written once per policy step.
-//   post_kernel      16 envs per 256-thread workgroup: (1) cooperative terrain height scan, (2) one lane per env for the
-//                    scalar logic (commands, termination, rewards, reset, curriculum), (3) cooperative observation
-//                    assembly + noise with coalesced row stores.
-//   finalize_kernel  one workgroup: fixed-order reduction of the per-workgroup episode statistics (deterministic).
+//   post_kernel      4 envs per 256-thread workgroup, one wave per env: rows staged in LDS with one round of loads,
+//                    cooperative terrain height scan, the post-physics logic in lane-parallel stages that keep the
+//                    reference's order of side effects, observation rows with noise.
+//   finalize_kernel  one workgroup: episode statistics of the step, rows of the workgroups that reset an env added in
+//                    fixed order (deterministic); also closes lg_reset_idx.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -46,6 +47,8 @@ struct DevCtx {
   const float *noise_vec, *height_points;
   const float* extra_obs;   // (N, cfg.num_extra_obs) caller-owned rows appended to the observation
   float* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
+  float* lvl_part;     // [nblocks] : per-workgroup sum of terrain levels
+  unsigned* part_flag; // [nblocks] : 1 when some env of the workgroup was reset in this step (its partials row is valid)
   int nblocks_post;
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
   unsigned long long* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
@@ -648,11 +651,14 @@ LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int
 }
 
 // every _reward_* of RM:41-234 (+ anymal.py:112-114), selected by id
-LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, int id, const float* s_h, int64_t step) {
+// `feat` = the eight per-DOF sums (F_* below), `fn` = contact-force norm of every body, `bh` = sum over the height points
+// of (base z - height): computed lane-parallel by the post kernel before the terms are evaluated in config order.
+enum { F_TQ2 = 0, F_QD2, F_ACC2, F_ARATE2, F_POSLIM, F_VELLIM, F_TQLIM, F_STILL, F_COUNT };
+LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, int id, const float* feat, const float* fn, float bh,
+                         int64_t step) {
   const lg_config& g = C->cfg; const lg_robot_model& m = C->model; const float dt = g.sim_dt * g.decimation;
-  const float* root = V.root; const float* dof = V.dof;
+  const float* root = V.root;
   const float* blv = V.blv; const float* bav = V.bav; const float* pg = V.pg; const float* cmd = V.cmd;
-  const float* tq = V.tq; const float* act = V.act; const float* lact = V.lact; const float* ldv = V.ldv;
   const float* cf = V.cf; const float* rb = V.rb;
   float* air = V.air; float* ctime = V.ctime; uint8_t* lastc = V.lastc;
   const float cmdn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
@@ -664,7 +670,7 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     case LG_REW_ORIENTATION: return SQ(pg[0]) + SQ(pg[1]);
     case LG_REW_BASE_HEIGHT: {
       float s = root[2];
-      if (g.measure_heights) { s = 0.f; for (int p = 0; p < C->P; ++p) s += root[2] - s_h[p]; s /= (float)C->P; }
+      if (g.measure_heights) s = bh / (float)C->P;
       return SQ(s - g.base_height_target);
     }
     case LG_REW_BASE_FOOT_HEIGHT: {
@@ -673,18 +679,14 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
       float est = n > 0 ? s / (float)n : root[2] - g.base_height_target;
       return SQ((root[2] - est) - g.base_height_target);
     }
-    case LG_REW_TORQUES: { float s = 0.f; for (int d = 0; d < 12; ++d) s += SQ(tq[d]); return s; }
-    case LG_REW_DOF_VEL: { float s = 0.f; for (int d = 0; d < 12; ++d) s += SQ(dof[2 * d + 1]); return s; }
-    case LG_REW_DOF_ACC: { float s = 0.f; for (int d = 0; d < 12; ++d) s += SQ((ldv[d] - dof[2 * d + 1]) / dt); return s; }
-    case LG_REW_ACTION_RATE: { float s = 0.f; for (int d = 0; d < 12; ++d) s += SQ(lact[d] - act[d]); return s; }
-    case LG_REW_DOF_POS_LIMITS: {
-      float s = 0.f;
-      for (int d = 0; d < 12; ++d) { float lo = dof[2 * d] - g.dof_pos_limits[d][0], hi = dof[2 * d] - g.dof_pos_limits[d][1]; s += -fminf(lo, 0.f) + fmaxf(hi, 0.f); }
-      return s;
-    }
-    case LG_REW_DOF_VEL_LIMITS: { float s = 0.f; for (int d = 0; d < 12; ++d) s += fminf(fmaxf(fabsf(dof[2 * d + 1]) - m.dof_vel_limit[d] * g.soft_dof_vel_limit, 0.f), 1.f); return s; }
-    case LG_REW_TORQUE_LIMITS: { float s = 0.f; for (int d = 0; d < 12; ++d) s += fmaxf(fabsf(tq[d]) - m.torque_limit[d] * g.soft_torque_limit, 0.f); return s; }
-    case LG_REW_COLLISION: { float s = 0.f; for (int i = 0; i < m.num_penalised; ++i) s += FNORM(m.penalised_contact_indices[i]) > 0.1f ? 1.f : 0.f; return s; }
+    case LG_REW_TORQUES: return feat[F_TQ2];
+    case LG_REW_DOF_VEL: return feat[F_QD2];
+    case LG_REW_DOF_ACC: return feat[F_ACC2];
+    case LG_REW_ACTION_RATE: return feat[F_ARATE2];
+    case LG_REW_DOF_POS_LIMITS: return feat[F_POSLIM];
+    case LG_REW_DOF_VEL_LIMITS: return feat[F_VELLIM];
+    case LG_REW_TORQUE_LIMITS: return feat[F_TQLIM];
+    case LG_REW_COLLISION: { float s = 0.f; for (int i = 0; i < m.num_penalised; ++i) s += fn[m.penalised_contact_indices[i]] > 0.1f ? 1.f : 0.f; return s; }
     case LG_REW_FEET_STUMBLE: {
       bool any = false;
       for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; any |= sqrtf(SQ(cf[3 * b]) + SQ(cf[3 * b + 1])) > 5.f * fabsf(cf[3 * b + 2]); }
@@ -717,7 +719,7 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
       }
       return s * (cmdn > 0.1f ? 1.f : 0.f);
     }
-    case LG_REW_FEET_CONTACT_FORCES: { float s = 0.f; for (int f = 0; f < 4; ++f) s += fmaxf(FNORM(m.feet_indices[f]) - g.max_contact_force, 0.f); return s; }
+    case LG_REW_FEET_CONTACT_FORCES: { float s = 0.f; for (int f = 0; f < 4; ++f) s += fmaxf(fn[m.feet_indices[f]] - g.max_contact_force, 0.f); return s; }
     case LG_REW_GAIT_2_STEP: {
 #define SYNC(a, b) (fminf(SQ(air[a] - air[b]), 4.f) + fminf(SQ(ctime[a] - ctime[b]), 4.f))
 #define ASYN(a, b) (fminf(SQ(air[a] - ctime[b]), 4.f) + fminf(SQ(ctime[a] - air[b]), 4.f))
@@ -729,7 +731,7 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     }
     case LG_REW_FOUR_FOOTUP: { bool all = true; for (int f = 0; f < 4; ++f) all &= cf[3 * m.feet_indices[f] + 2] < 1.f; return 0.1f * (all ? 1.f : 0.f); }
     case LG_REW_TERMINATION: return (C->reset_buf[e] && !C->time_out[e]) ? 1.f : 0.f;
-    case LG_REW_STAND_STILL: { float s = 0.f; for (int d = 0; d < 12; ++d) s += fabsf(dof[2 * d] - g.default_dof_pos[d]); return s * (cmdn < 0.1f ? 1.f : 0.f); }
+    case LG_REW_STAND_STILL: return feat[F_STILL] * (cmdn < 0.1f ? 1.f : 0.f);
     case LG_REW_TRACKING_LIN_VEL: return expf(-(SQ(cmd[0] - blv[0]) + SQ(cmd[1] - blv[1])) / g.tracking_sigma);
     case LG_REW_TRACKING_ANG_VEL: return expf(-SQ(cmd[2] - bav[2]) / g.tracking_sigma);
     case LG_REW_GAIT_SCHEDULER: {   // gait_scheduler.py:74-81 on the foot heights / phase stored by the previous step
@@ -744,6 +746,89 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     }
   }
   return 0.f;
+}
+
+// Episode statistics of one step: fixed-order (ascending workgroup) sums of the per-workgroup partial rows -> extras
+// (LR:200-206), step counters, running stats.  Only workgroups that reset an env have a row to add (flags), so the usual
+// step touches a handful of rows; the order of the additions never depends on scheduling.  One 256-thread workgroup,
+// launched after post_kernel (use_flags) and after reset_idx_kernel (its single row).
+//   bump: 1 = policy step (counters[0]), 0 = explicit reset (counters[2]), 2 = rollout step (counters[3], nothing else)
+#define FIN_CHUNK 1024
+// (A single launch with a "last workgroup finishes the step" ticket was measured and lost: on this multi-XCD part the
+// cross-workgroup hand-over needs device-scope atomics on one address plus L2-bypassing accesses, which cost more than
+// the ~2 us launch of this small second kernel.)
+LG_DEV void st_dev(float* p, float v) { *p = v; }
+LG_DEV float ld_dev(const float* p) { return *p; }
+LG_DEV void st_dev(unsigned* p, unsigned v) { *p = v; }
+LG_DEV unsigned ld_dev(const unsigned* p) { return *p; }
+LG_DEV void finalize_step(const DevCtx* __restrict__ C, int nblocks, int bump, int tid, bool use_flags) {
+  const int K = C->cfg.num_reward_terms, KP = K + 3, lane = tid & 63, wv = tid >> 6;
+  __shared__ float tot[PART_STRIDE];
+  __shared__ int f_list[FIN_CHUNK];
+  __shared__ int f_n;
+  __shared__ float f_buf[8][32];
+  __shared__ float f_lvl[256];
+  if (bump == 2) { if (tid == 0) C->counters[3] += 1; return; }
+  __shared__ unsigned char f_flag[FIN_CHUNK];
+  if (tid < PART_STRIDE) tot[tid] = 0.f;
+  float lvl_acc = 0.f;                     // this thread's share of the terrain-level sum (fixed assignment of rows)
+  const bool want_lvl = C->cfg.curriculum != 0;
+  for (int c0 = 0; c0 < nblocks; c0 += FIN_CHUNK) {
+    const int cn = min(FIN_CHUNK, nblocks - c0);
+    {                                      // flags and level sums of the chunk: independent loads, one latency
+      unsigned fl[FIN_CHUNK / 256]; float lv[FIN_CHUNK / 256];
+#pragma unroll
+      for (int i = 0; i < FIN_CHUNK / 256; ++i) {
+        const int b = tid + 256 * i;
+        fl[i] = (b < cn && use_flags) ? ld_dev(C->part_flag + c0 + b) : (b < cn ? 1u : 0u);
+        lv[i] = (b < cn && use_flags && want_lvl) ? ld_dev(C->lvl_part + c0 + b) : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < FIN_CHUNK / 256; ++i) { f_flag[tid + 256 * i] = fl[i] ? 1 : 0; lvl_acc += lv[i]; }
+    }
+    __syncthreads();
+    if (wv == 0) {                       // ascending list of the workgroups of this chunk that hold a row
+      int cnt = 0;
+      for (int base = 0; base < cn; base += 64) {
+        const int b = base + lane;
+        const bool f = b < cn && f_flag[b] != 0;
+        const unsigned long long mk = __ballot(f);
+        if (f) f_list[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = c0 + b;
+        cnt += __popcll(mk);
+      }
+      if (lane == 0) f_n = cnt;
+    }
+    __syncthreads();
+    const int nl = f_n;
+    for (int j0 = 0; j0 < nl; j0 += 8) {       // 8 rows per pass: loads in parallel, additions in row order
+      const int j = j0 + (tid >> 5), c = tid & 31;
+      f_buf[tid >> 5][c] = (j < nl && c < KP) ? ld_dev(C->partials + (size_t)f_list[j] * PART_STRIDE + c) : 0.f;
+      __syncthreads();
+      if (tid < KP) { float sacc = tot[tid]; for (int jj = 0; jj < 8; ++jj) sacc += f_buf[jj][tid]; tot[tid] = sacc; }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  const float cnt = tot[K];
+  if (cnt > 0.f && want_lvl) {            // mean terrain level over all envs (LR:205-206): only reported with a reset
+    if (!use_flags) lvl_acc = tid == 0 ? ld_dev(C->partials + K + 1) : 0.f;
+    f_lvl[tid] = lvl_acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) f_lvl[tid] += f_lvl[tid + off]; __syncthreads(); }
+  }
+  if (cnt > 0.f) {
+    if (tid < K) C->extras[tid] = tot[tid] / cnt / C->cfg.max_episode_length_s;
+    if (tid == K && C->cfg.curriculum) C->extras[K] = f_lvl[0] / (float)C->N;
+  }
+  if (tid == 0) {
+    if (bump == 1) C->counters[0] += 1; else if (bump == 0) C->counters[2] += 1;
+    C->counters[1] = (int64_t)cnt;
+    double ret = 0.0;
+    for (int k = 0; k < K; ++k) ret += (double)tot[k];
+    C->ep_stats[0] += ret; C->ep_stats[1] += (double)tot[K + 2]; C->ep_stats[2] += (double)cnt;
+    if (bump == 1) C->ep_stats[3] += (double)C->n_stepped;
+  }
 }
 
 // ============================================================================================ post-physics kernel
@@ -767,6 +852,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   __shared__ uint8_t s_flag[EPBP];
   __shared__ float s_u[EPBP][LG_RS_NOISE];      // uniforms of slots 0..31 (commands, push, curriculum, reset)
   __shared__ uint8_t s_did_reset[EPBP], s_root_dirty[EPBP];
+  __shared__ float s_level[EPBP];               // terrain level at the start of the step (re-read after a reset)
   const lg_config& g = C->cfg; const lg_robot_model& m = C->model;
   const int tid = threadIdx.x, e0 = blockIdx.x * EPBP;
   const int nenv = min(EPBP, n - e0);
@@ -784,27 +870,45 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
 
-  // ---- (0) stage this workgroup's env rows in LDS: every global row block is contiguous over the 16 envs
-#define STAGE(OFF, SRC, LEN)                                                                   \
-  for (int idx = tid; idx < nenv * (LEN); idx += 256) {                                         \
-    int el = idx / (LEN), k = idx - el * (LEN);                                                 \
-    s_env[el][(OFF) + k] = (SRC)[(size_t)s_e[el] * (LEN) + k];                                     \
+  // ---- (0) stage this workgroup's env rows in LDS.  Every global load is issued before the first LDS store, so the
+  // phase costs one memory latency instead of one per tensor.
+  static_assert(LG_MAX_BODIES * 13 * EPBP <= 1024 && 64 * EPBP <= 256, "staging assumes <= 4 row chunks of 256 lanes");
+#define LDV(name, SRC, LEN) float name = 0.f; if (tid < nenv * (LEN)) { int el_ = tid / (LEN), k_ = tid - el_ * (LEN); name = (SRC)[(size_t)s_e[el_] * (LEN) + k_]; }
+#define STV(name, OFF, LEN) if (tid < nenv * (LEN)) { int el_ = tid / (LEN), k_ = tid - el_ * (LEN); s_env[el_][(OFF) + k_] = name; }
+  const int LRB = B * 13;
+  float v_rb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int idx = tid + j * 256; v_rb[j] = 0.f;
+    if (idx < nenv * LRB) { int el_ = idx / LRB, k_ = idx - el_ * LRB; v_rb[j] = C->rigid[(size_t)s_e[el_] * LRB + k_]; }
   }
-  STAGE(S_ROOT, C->root, 13) STAGE(S_DOF, C->dof, 24) STAGE(S_CF, C->cforce, B * 3) STAGE(S_RB, C->rigid, B * 13)
-  STAGE(S_ACT, C->actions, 12) STAGE(S_LACT, C->last_actions, 12) STAGE(S_LDV, C->last_dof_vel, 12) STAGE(S_TQ, C->torques, 12)
-  STAGE(S_LRV, C->last_root_vel, 6) STAGE(S_CMD, C->commands, 4) STAGE(S_BLA, C->base_lin_acc, 3) STAGE(S_BAA, C->base_ang_acc, 3)
-  STAGE(S_AIR, C->feet_air, 4) STAGE(S_CT, C->feet_ctime, 4) STAGE(S_GAIT, C->gait_idx, 1)
-#undef STAGE
-  for (int idx = tid; idx < nenv * g.num_reward_terms; idx += 256) {     // episode sums are (K, N): row k, envs contiguous
-    int k = idx / nenv, el = idx - k * nenv;
-    s_env[el][S_SUMS + k] = C->ep_sums[(size_t)k * C->N + s_e[el]];
-  }
-  if (tid < nenv * 4) s_lastc[tid >> 2][tid & 3] = C->last_contacts[(size_t)s_e[tid >> 2] * 4 + (tid & 3)];
-  if (tid < nenv) { s_eplen[tid] = C->ep_len[s_e[tid]]; s_flag[tid] = C->reset_buf[s_e[tid]]; }
+  LDV(v_root, C->root, 13) LDV(v_dof, C->dof, 24) LDV(v_cf, C->cforce, B * 3)
+  LDV(v_act, C->actions, 12) LDV(v_lact, C->last_actions, 12) LDV(v_ldv, C->last_dof_vel, 12) LDV(v_tq, C->torques, 12)
+  LDV(v_lrv, C->last_root_vel, 6) LDV(v_cmd, C->commands, 4) LDV(v_bla, C->base_lin_acc, 3) LDV(v_baa, C->base_ang_acc, 3)
+  LDV(v_air, C->feet_air, 4) LDV(v_ct, C->feet_ctime, 4) LDV(v_gait, C->gait_idx, 1)
+  float v_sum = 0.f;                                   // episode sums are (K, N): row k, envs contiguous
+  if (tid < nenv * g.num_reward_terms) { int k = tid / nenv, el_ = tid - k * nenv; v_sum = C->ep_sums[(size_t)k * C->N + s_e[el_]]; }
+  uint8_t v_lc = 0; if (tid < nenv * 4) v_lc = C->last_contacts[(size_t)s_e[tid >> 2] * 4 + (tid & 3)];
+  int64_t v_len = 0; uint8_t v_flag = 0; int64_t v_lvl = 0;
+  if (tid < nenv) { v_len = C->ep_len[s_e[tid]]; v_flag = C->reset_buf[s_e[tid]]; if (g.curriculum && !ro) v_lvl = C->levels[s_e[tid]]; }
   if (tid < nenv * (LG_RS_NOISE / 4)) {          // one Philox call per (env, slot group): 8 lanes per env
-    int el = tid / (LG_RS_NOISE / 4), gq = tid - el * (LG_RS_NOISE / 4);
-    uniform_draw4(C, s_e[el], gq, step, rstream, &s_u[el][4 * gq]);
+    int el_ = tid / (LG_RS_NOISE / 4), gq = tid - el_ * (LG_RS_NOISE / 4);
+    uniform_draw4(C, s_e[el_], gq, step, rstream, &s_u[el_][4 * gq]);
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int idx = tid + j * 256;
+    if (idx < nenv * LRB) { int el_ = idx / LRB, k_ = idx - el_ * LRB; s_env[el_][S_RB + k_] = v_rb[j]; }
+  }
+  STV(v_root, S_ROOT, 13) STV(v_dof, S_DOF, 24) STV(v_cf, S_CF, B * 3)
+  STV(v_act, S_ACT, 12) STV(v_lact, S_LACT, 12) STV(v_ldv, S_LDV, 12) STV(v_tq, S_TQ, 12)
+  STV(v_lrv, S_LRV, 6) STV(v_cmd, S_CMD, 4) STV(v_bla, S_BLA, 3) STV(v_baa, S_BAA, 3)
+  STV(v_air, S_AIR, 4) STV(v_ct, S_CT, 4) STV(v_gait, S_GAIT, 1)
+#undef LDV
+#undef STV
+  if (tid < nenv * g.num_reward_terms) { int k = tid / nenv, el_ = tid - k * nenv; s_env[el_][S_SUMS + k] = v_sum; }
+  if (tid < nenv * 4) s_lastc[tid >> 2][tid & 3] = v_lc;
+  if (tid < nenv) { s_eplen[tid] = v_len; s_flag[tid] = v_flag; s_level[tid] = (float)v_lvl; }
   __syncthreads();
   STAMP(11);
 
@@ -839,33 +943,83 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   __syncthreads();
   STAMP(12);
 
-  // ---- (2) one lane per env: everything scalar, in the reference's order, on the LDS copies
-  if (tid < nenv) {
-    const int el = tid, e = s_e[el];
-    float* S = s_env[el];
-    EnvView V;
-    V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
-    V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT;
-    V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = s_lastc[el];
-    float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
-    float* bla = S + S_BLA; float* baa = S + S_BAA; const float* lrv = S + S_LRV;
-    const float* cf = V.cf; const float* act = V.act;
-    bool root_dirty = false;
-    int64_t eplen = s_eplen[el] + (ro ? 0 : 1);                                   // LR:122 (not in rollout steps)
+  // ---- (2) one wave per env.  The reference's order of side effects is kept by stages separated by barriers:
+  //   (2.1) base-frame velocities / accelerations / gravity (five rotations on five lanes), per-DOF reward features
+  //         (one lane per DOF), contact-force norms (one lane per body), base-height partial sums;
+  //   (2.2) feature sums (one lane per feature, DOF order = the serial order), callback + termination (one lane);
+  //   (2.3) reward terms in config order, episode sums, reset (one lane: O(1) per term now);
+  //   (2.4) proprioceptive observation entries (one lane per entry), gait phase.
+  __shared__ float s_feat[EPBP][F_COUNT][12];
+  __shared__ float s_fsum[EPBP][F_COUNT];
+  __shared__ float s_fn[EPBP][LG_MAX_BODIES];
+  __shared__ float s_bh[EPBP];
+  __shared__ uint8_t s_term[EPBP], s_tout[EPBP];
+  const int wv = tid >> 6, ln = tid & 63;
+  const bool have = wv < nenv;
+  const int el = have ? wv : 0, e = s_e[el];
+  float* S = s_env[el];
+  EnvView V;
+  V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
+  V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT;
+  V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = s_lastc[el];
+  float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
+  __shared__ float s_rk[EPBP][LG_MAX_REWARD_TERMS];
+  __shared__ float s_old[EPBP][8];
+  __shared__ uint8_t s_oldc[EPBP][4];
+  unsigned term_mask = 0;                       // which reward terms are switched on (wave-uniform)
+  int kfat = g.num_reward_terms;                // position of feet_air_time in the evaluation order (K = absent)
+  for (int k = 0; k < g.num_reward_terms; ++k) {
+    const int id = g.reward_term_ids[k];
+    term_mask |= 1u << id;
+    if (id == LG_REW_FEET_AIR_TIME) kfat = k;
+  }
+
+  // (2.1)
+  if (have && ln < 5) {                                                           // LR:128-134
+    const float* lrv = S + S_LRV;
     float q[4] = {root[3], root[4], root[5], root[6]};
     V3 lin = v3(root[7], root[8], root[9]), ang = v3(root[10], root[11], root[12]);
-    V3 v = quat_rotate_inverse(q, lin);                                           // LR:128-134
-    V3 dl = quat_rotate_inverse(q, lin - v3(lrv[0], lrv[1], lrv[2]));
+    V3 x = ln == 0 ? lin : ln == 1 ? lin - v3(lrv[0], lrv[1], lrv[2]) : ln == 2 ? ang : ln == 3 ? ang - v3(lrv[3], lrv[4], lrv[5]) : v3(0, 0, -1);
+    V3 r = quat_rotate_inverse(q, x);
     const float ema = 0.9f, oma = (float)(1 - 0.9);
-    bla[0] = bla[0] * ema + oma * dl.x / dt; bla[1] = bla[1] * ema + oma * dl.y / dt; bla[2] = bla[2] * ema + oma * dl.z / dt;
-    V3 w = quat_rotate_inverse(q, ang);
-    V3 da = quat_rotate_inverse(q, ang - v3(lrv[3], lrv[4], lrv[5]));
-    baa[0] = baa[0] * ema + oma * da.x / dt; baa[1] = baa[1] * ema + oma * da.y / dt; baa[2] = baa[2] * ema + oma * da.z / dt;
-    V3 gv = quat_rotate_inverse(q, v3(0, 0, -1));
-    V.blv[0] = v.x; V.blv[1] = v.y; V.blv[2] = v.z; V.bav[0] = w.x; V.bav[1] = w.y; V.bav[2] = w.z; V.pg[0] = gv.x; V.pg[1] = gv.y; V.pg[2] = gv.z;
+    float* dst = ln == 0 ? V.blv : ln == 1 ? S + S_BLA : ln == 2 ? V.bav : ln == 3 ? S + S_BAA : V.pg;
+    if (ln == 1 || ln == 3) { dst[0] = dst[0] * ema + oma * r.x / dt; dst[1] = dst[1] * ema + oma * r.y / dt; dst[2] = dst[2] * ema + oma * r.z / dt; }
+    else { dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; }
+  } else if (have && ln >= 16 && ln < 28) {
+    const int d = ln - 16;
+    const float q_ = dof[2 * d], qd = dof[2 * d + 1], tq = V.tq[d];
+    float (*F)[12] = s_feat[el];
+    F[F_TQ2][d] = tq * tq;
+    F[F_QD2][d] = qd * qd;
+    { float a = (V.ldv[d] - qd) / dt; F[F_ACC2][d] = a * a; }
+    { float a = V.lact[d] - V.act[d]; F[F_ARATE2][d] = a * a; }
+    { float lo = q_ - g.dof_pos_limits[d][0], hi = q_ - g.dof_pos_limits[d][1]; F[F_POSLIM][d] = -fminf(lo, 0.f) + fmaxf(hi, 0.f); }
+    F[F_VELLIM][d] = fminf(fmaxf(fabsf(qd) - m.dof_vel_limit[d] * g.soft_dof_vel_limit, 0.f), 1.f);
+    F[F_TQLIM][d] = fmaxf(fabsf(tq) - m.torque_limit[d] * g.soft_torque_limit, 0.f);
+    F[F_STILL][d] = fabsf(q_ - g.default_dof_pos[d]);
+  } else if (have && ln >= 32 && ln < 32 + B) {
+    const float* cf = V.cf + 3 * (ln - 32);
+    s_fn[el][ln - 32] = sqrtf(cf[0] * cf[0] + cf[1] * cf[1] + cf[2] * cf[2]);
+  }
+  __syncthreads();
+  STAMP(19);
+
+  // (2.2)
+  if (have && ln < F_COUNT) {
+    float sacc = 0.f;
+    for (int d = 0; d < 12; ++d) sacc += s_feat[el][ln][d];
+    s_fsum[el][ln] = sacc;
+  } else if (have && ln == 8) {
+    float sacc = 0.f;
+    if ((term_mask >> LG_REW_BASE_HEIGHT) & 1u) for (int p = 0; p < P; ++p) sacc += root[2] - s_h[el][p];
+    s_bh[el] = sacc;
+  } else if (have && ln == 9) {
+    const int64_t eplen = s_eplen[el] + (ro ? 0 : 1);                             // LR:122 (not in rollout steps)
+    bool root_dirty = false;
     // _post_physics_step_callback (LR:386-403)
     if (!ro && (int)eplen % g.resampling_steps == 0) resample_commands(C, cmd, s_u[el], LG_RS_CMD_CB);
     if (!ro && g.heading_command) {
+      float q[4] = {root[3], root[4], root[5], root[6]};
       V3 f = quat_apply(q, v3(1, 0, 0));
       float x = 0.5f * wrap_to_pi(cmd[3] - atan2f(f.y, f.x));
       cmd[2] = fminf(fmaxf(x, -1.f), 1.f);
@@ -877,59 +1031,82 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     }
     // check_termination (LR:155-160)
     bool term = false;
-    for (int i = 0; i < m.num_termination; ++i) { int b = m.termination_contact_indices[i]; term |= FNORM(b) > 1.f; }
+    for (int i = 0; i < m.num_termination; ++i) term |= s_fn[el][m.termination_contact_indices[i]] > 1.f;
     term |= s_flag[el] == 2;        // physics fault flagged by physics_kernel
     bool tout = (float)eplen > g.max_episode_length;
     if (ro) {                       // rollout envs never terminate on their own: flags keep their last values
       tout = C->time_out[e] != 0; term = (s_flag[el] != 0) && !tout;
       if (s_flag[el] == 2) C->reset_buf[e] = 1;
     } else { C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0; }
-    // compute_reward (LR:215-232)
+    s_term[el] = term ? 1 : 0; s_tout[el] = tout ? 1 : 0;
+    s_root_dirty[el] = root_dirty ? 1 : 0;
+    s_eplen[el] = eplen;
+    C->ep_len[e] = eplen;
+  }
+  __syncthreads();
+  STAMP(20);
+
+  // (2.3a) the one stateful term: _reward_feet_air_time rewrites air / contact times and last_contacts (RM:150-163).
+  // Terms that come before it in the config order must still see the old values: keep a copy.
+  if (have && ln == 0 && kfat < g.num_reward_terms) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { s_old[el][f] = V.air[f]; s_old[el][4 + f] = V.ctime[f]; s_oldc[el][f] = V.lastc[f]; }
+    s_rk[el][kfat] = reward_term(C, V, e, LG_REW_FEET_AIR_TIME, s_fsum[el], s_fn[el], s_bh[el], step) * g.reward_scales[kfat];
+  }
+  __syncthreads();
+  // (2.3b) every other term on its own lane (they only read)
+  if (have && ln < g.num_reward_terms && ln != kfat) {
+    const int id = g.reward_term_ids[ln];
+    EnvView Vk = V;
+    if (ln < kfat && kfat < g.num_reward_terms) { Vk.air = s_old[el]; Vk.ctime = s_old[el] + 4; Vk.lastc = s_oldc[el]; }
+    s_rk[el][ln] = id != LG_REW_TERMINATION ? reward_term(C, Vk, e, id, s_fsum[el], s_fn[el], s_bh[el], step) * g.reward_scales[ln] : 0.f;
+  }
+  __syncthreads();
+  STAMP(21);
+  // (2.3c) total in config order, clip, termination term, reset (LR:215-232, 144-145)
+  if (have && ln == 0) {
+    const bool term = s_term[el] != 0, tout = s_tout[el] != 0;
     float rew = 0.f;
-    float rk[LG_MAX_REWARD_TERMS];
-    for (int k = 0; k < g.num_reward_terms; ++k) {
-      int id = g.reward_term_ids[k];
-      float r = 0.f;
-      if (id != LG_REW_TERMINATION) { r = reward_term(C, V, e, id, s_h[el], step) * g.reward_scales[k]; rew += r; }
-      rk[k] = r;
-    }
+    for (int k = 0; k < g.num_reward_terms; ++k) rew += s_rk[el][k];
     if (g.only_positive_rewards) rew = fmaxf(rew, 0.f);
     for (int k = 0; k < g.num_reward_terms; ++k) if (g.reward_term_ids[k] == LG_REW_TERMINATION) {
       float r = ((term || tout) && !tout ? 1.f : 0.f) * g.reward_scales[k];
-      rew += r; rk[k] = r;
+      rew += r; s_rk[el][k] = r;
     }
     C->rew[e] = rew;
-    // reset (LR:144-145) and the episode statistics of LR:200-206
     const bool do_reset = !ro && (term || tout);
-    s_part[el][g.num_reward_terms + 2] = do_reset ? (float)eplen : 0.f;
-    C->ep_len[e] = eplen;
-    if (do_reset) { reset_env(C, V, e, 1, s_u[el], false); root_dirty = true; }
-    for (int k = 0; k < g.num_reward_terms; ++k) {
-      float tot = S[S_SUMS + k] + (ro ? 0.f : rk[k]);        // compute_reward_rollout does not touch the episode sums
-      s_part[el][k] = do_reset ? tot : 0.f;
-      S[S_SUMS + k] = do_reset ? 0.f : tot;          // written back to (K, N) cooperatively below
-    }
-    s_part[el][g.num_reward_terms] = do_reset ? 1.f : 0.f;
-    s_part[el][g.num_reward_terms + 1] = (g.curriculum && !ro) ? (float)C->levels[e] : 0.f;
-    // proprioceptive part of the observation (LR:237-244), from the post-reset state
-    float* sp = s_prop[el];
-    sp[0] = V.blv[0] * g.obs_scale_lin_vel; sp[1] = V.blv[1] * g.obs_scale_lin_vel; sp[2] = V.blv[2] * g.obs_scale_lin_vel;
-    sp[3] = V.bav[0] * g.obs_scale_ang_vel; sp[4] = V.bav[1] * g.obs_scale_ang_vel; sp[5] = V.bav[2] * g.obs_scale_ang_vel;
-    sp[6] = V.pg[0]; sp[7] = V.pg[1]; sp[8] = V.pg[2];
-    sp[9] = cmd[0] * g.obs_scale_lin_vel; sp[10] = cmd[1] * g.obs_scale_lin_vel; sp[11] = cmd[2] * g.obs_scale_ang_vel;
-    for (int d = 0; d < 12; ++d) {
-      sp[12 + d] = (dof[2 * d] - g.default_dof_pos[d]) * g.obs_scale_dof_pos;
-      sp[24 + d] = dof[2 * d + 1] * g.obs_scale_dof_vel;
-      sp[36 + d] = act[d];
-    }
+    if (do_reset) { reset_env(C, V, e, 1, s_u[el], false); s_root_dirty[el] = 1; if (g.curriculum) s_level[el] = (float)C->levels[e]; }
     s_rootz[el] = root[2];
-    s_did_reset[el] = do_reset ? 1 : 0; s_root_dirty[el] = root_dirty ? 1 : 0;
-    // (rows are written back to global memory cooperatively after this phase)
-    // Anymal.post_physics_step: gait scheduler (anymal.py:107-110)
-    if (g.gait_enabled && !ro) {
-      float x = fmodf(S[S_GAIT] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
-      S[S_GAIT] = x;
-    }
+    s_did_reset[el] = do_reset ? 1 : 0;
+  }
+  __syncthreads();
+
+  // (2.4) proprioceptive part of the observation (LR:237-244), from the post-reset state; gait scheduler (anymal.py:107-110)
+  if (have && ln < 48) {
+    float* sp = s_prop[el];
+    float o;
+    if (ln < 3) o = V.blv[ln] * g.obs_scale_lin_vel;
+    else if (ln < 6) o = V.bav[ln - 3] * g.obs_scale_ang_vel;
+    else if (ln < 9) o = V.pg[ln - 6];
+    else if (ln < 12) o = cmd[ln - 9] * (ln < 11 ? g.obs_scale_lin_vel : g.obs_scale_ang_vel);
+    else if (ln < 24) o = (dof[2 * (ln - 12)] - g.default_dof_pos[ln - 12]) * g.obs_scale_dof_pos;
+    else if (ln < 36) o = dof[2 * (ln - 24) + 1] * g.obs_scale_dof_vel;
+    else o = V.act[ln - 36];
+    sp[ln] = o;
+  } else if (have && ln == 48 && g.gait_enabled && !ro) {
+    float x = fmodf(S[S_GAIT] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
+    S[S_GAIT] = x;
+  }
+  if (have) {                                   // episode sums and the statistics of LR:200-206, one lane per term
+    const bool do_reset = s_did_reset[el] != 0;
+    const int K_ = g.num_reward_terms;
+    if (ln < K_) {
+      float tot = S[S_SUMS + ln] + (ro ? 0.f : s_rk[el][ln]);  // compute_reward_rollout does not touch the episode sums
+      s_part[el][ln] = do_reset ? tot : 0.f;
+      S[S_SUMS + ln] = do_reset ? 0.f : tot;        // written back to (K, N) cooperatively below
+    } else if (ln == K_) s_part[el][K_] = do_reset ? 1.f : 0.f;
+    else if (ln == K_ + 1) s_part[el][K_ + 1] = s_level[el];
+    else if (ln == K_ + 2) s_part[el][K_ + 2] = do_reset ? (float)s_eplen[el] : 0.f;
   }
   __syncthreads();
   STAMP(13);
@@ -971,71 +1148,60 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     C->ep_sums[(size_t)k * C->N + s_e[el]] = s_env[el][S_SUMS + k];
   }
   const int KP = g.num_reward_terms + 3;
-  if (tid < KP) {
-    float s = 0.f;
-    for (int el = 0; el < nenv; ++el) s += s_part[el][tid];
-    C->partials[(size_t)blockIdx.x * PART_STRIDE + tid] = s;
+  bool any_reset = false;
+  for (int el2 = 0; el2 < nenv; ++el2) any_reset |= s_did_reset[el2] != 0;
+  if (tid < KP && any_reset) {              // the row is only read when the flag says so
+    float sacc = 0.f;
+    for (int el2 = 0; el2 < nenv; ++el2) sacc += s_part[el2][tid];
+    st_dev(C->partials + (size_t)blockIdx.x * PART_STRIDE + tid, sacc);
+  }
+  if (tid == KP) st_dev(C->part_flag + blockIdx.x, any_reset ? 1u : 0u);
+  if (tid == KP + 1) {
+    float sacc = 0.f;
+    for (int el2 = 0; el2 < nenv; ++el2) sacc += s_part[el2][g.num_reward_terms + 1];
+    st_dev(C->lvl_part + blockIdx.x, sacc);
   }
 
-  // ---- (3) observation rows: proprio | heights, + uniform noise, clipped (LR:245-252, :107-108); 4 entries per lane
+  // ---- (3) observation rows: proprio | heights | extra, + uniform noise, clipped (LR:245-252, :107-108); 4 entries per
+  // lane, loads first (noise scales, caller's extra rows, injected uniforms), then arithmetic, then the row stores
   const int O = g.num_obs, G4 = (O + 3) >> 2;
+  const bool inject = g.rng_mode == LG_RNG_INJECT;
   for (int gi = tid; gi < nenv * G4; gi += 256) {
-    int el = gi / G4, gq = gi - el * G4, e = s_e[el];
-    float u[4] = {0.5f, 0.5f, 0.5f, 0.5f};
-    if (g.add_noise) {
-      if (g.rng_mode == LG_RNG_INJECT) {
+    const int el3 = gi / G4, gq = gi - el3 * G4, e3 = s_e[el3];
+    float u[4] = {0.5f, 0.5f, 0.5f, 0.5f}, nv[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (4 * gq + i < O) u[i] = C->rand_inject[(size_t)e * (LG_RS_NOISE + O) + LG_RS_NOISE + 4 * gq + i];
-      } else {
-        uint32_t o4[4];
-        philox4((uint32_t)e, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), rstream, (uint32_t)g.seed, (uint32_t)(g.seed >> 32), o4);
+    for (int i = 0; i < 4; ++i) {
+      const int idx = 4 * gq + i;
+      const bool in = idx < O;
+      if (g.add_noise && in) nv[i] = C->noise_vec[idx];
+      if (g.add_noise && inject && in) u[i] = C->rand_inject[(size_t)e3 * (LG_RS_NOISE + O) + LG_RS_NOISE + idx];
+      if (in && idx >= 48 + P && C->extra_obs) ex[i] = C->extra_obs[(size_t)e3 * g.num_extra_obs + (idx - 48 - P)];
+    }
+    if (g.add_noise && !inject) {
+      uint32_t o4[4];
+      philox4((uint32_t)e3, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), rstream, (uint32_t)g.seed, (uint32_t)(g.seed >> 32), o4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = u01(o4[i]);
-      }
+      for (int i = 0; i < 4; ++i) u[i] = u01(o4[i]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int idx = 4 * gq + i;
-      if (idx >= O) break;
-      float o;
-      if (idx < 48) o = s_prop[el][idx];
-      else if (idx >= 48 + P) o = C->extra_obs ? C->extra_obs[(size_t)e * g.num_extra_obs + (idx - 48 - P)] : 0.f;
-      else { float h = (s_rootz[el] - 0.5f) - s_h[el][idx - 48]; o = fminf(fmaxf(h, -1.f), 1.f) * g.obs_scale_height; }
-      if (g.add_noise) o += (2.f * u[i] - 1.f) * C->noise_vec[idx];
-      o = fminf(fmaxf(o, -g.clip_observations), g.clip_observations);
-      C->obs[(size_t)e * O + idx] = o;
+      const int idx = 4 * gq + i;
+      if (idx < O) {
+        float o;
+        if (idx < 48) o = s_prop[el3][idx];
+        else if (idx >= 48 + P) o = ex[i];
+        else { float h = (s_rootz[el3] - 0.5f) - s_h[el3][idx - 48]; o = fminf(fmaxf(h, -1.f), 1.f) * g.obs_scale_height; }
+        if (g.add_noise) o += (2.f * u[i] - 1.f) * nv[i];
+        o = fminf(fmaxf(o, -g.clip_observations), g.clip_observations);
+        C->obs[(size_t)e3 * O + idx] = o;
+      }
     }
   }
   STAMP(14);
 }
 
-// one workgroup of 16 waves: fixed-order reduction of the per-workgroup partials -> extras (LR:200-206), step counters,
-// running stats.  Wave w sums columns w, w+16, ...: lane i takes workgroups i, i+64, ... and the 64 partial sums are
-// folded with a fixed xor butterfly, so the result does not depend on scheduling.
-__global__ __launch_bounds__(1024) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step) {
-  const int K = C->cfg.num_reward_terms, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  __shared__ float tot[PART_STRIDE];
-  for (int c = wv; c < K + 3; c += 16) {
-    float s = 0.f;
-    for (int b = lane; b < nblocks; b += 64) s += C->partials[(size_t)b * PART_STRIDE + c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) tot[c] = s;
-  }
-  __syncthreads();
-  const float cnt = tot[K];
-  if (cnt > 0.f) {
-    if (tid < K) C->extras[tid] = tot[tid] / cnt / C->cfg.max_episode_length_s;
-    if (tid == K && C->cfg.curriculum) C->extras[K] = tot[K + 1] / (float)C->N;
-  }
-  if (tid == 0) {
-    if (bump_step == 1) C->counters[0] += 1; else if (bump_step == 0) C->counters[2] += 1;
-    C->counters[1] = (int64_t)cnt;
-    double ret = 0.0;
-    for (int k = 0; k < K; ++k) ret += (double)tot[k];
-    C->ep_stats[0] += ret; C->ep_stats[1] += (double)tot[K + 2]; C->ep_stats[2] += (double)cnt;
-    if (bump_step == 1) C->ep_stats[3] += (double)C->n_stepped;
-  }
+__global__ __launch_bounds__(256) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step, int use_flags) {
+  finalize_step(C, nblocks, bump_step, threadIdx.x, use_flags != 0);
 }
 
 // lg_reset_idx: one workgroup, loops over the id list; statistics summed in list order
@@ -1215,12 +1381,17 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   // aux buffer: noise_vec | height_points | partials
   size_t n_noise = (size_t)cfg->num_obs, n_hp = (size_t)2 * cfg->num_height_points;
   size_t n_part = (size_t)h.nblocks_post * PART_STRIDE;
-  size_t aux_floats = n_noise + n_hp + n_part + 66;   // + 32 x u64 stamp counters
+  size_t n_fin = (size_t)2 * h.nblocks_post + 4;   // level sums | reset flags | ticket
+  size_t aux_floats = n_noise + n_hp + n_part + 66 + n_fin;   // + 32 x u64 stamp counters
   if (hipMalloc(&c->aux, aux_floats * 4) != hipSuccess) return fail("hipMalloc(aux) failed");
   if (hipMemset(c->aux, 0, aux_floats * 4) != hipSuccess) return fail("hipMemset(aux) failed");
   float* aux = (float*)c->aux;
   h.noise_vec = aux; h.height_points = aux + n_noise; h.partials = aux + n_noise + n_hp;
   h.stamps = (unsigned long long*)(aux + ((n_noise + n_hp + n_part + 1) & ~(size_t)1));
+  {
+    float* fin = aux + n_noise + n_hp + n_part + 66;
+    h.lvl_part = fin; h.part_flag = (unsigned*)(fin + h.nblocks_post);
+  }
   if (hipMemcpy(aux, cfg->noise_scale_vec, n_noise * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy noise_scale_vec failed");
   if (n_hp && hipMemcpy(aux + n_noise, cfg->height_points, n_hp * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy height_points failed");
   if (ter->mesh_type != LG_MESH_PLANE &&
@@ -1252,15 +1423,13 @@ int lg_get_tensor(lg_ctx* c, int id, void** dptr, int64_t shape[4], int32_t* ndi
   return LG_OK;
 }
 
-__global__ void bump_rollout_counter(const DevCtx* __restrict__ C) { C->counters[3] += 1; }
 __global__ void set_n_stepped(DevCtx* C, int n) { C->n_stepped = n; }
 
 static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t* ids, int n, int mode) {
   const int nb = (n + EPBP - 1) / EPBP;
   hipLaunchKernelGGL(post_kernel, dim3(nb), dim3(256), 0, st, c->d, ids, n, mode);
   if (ev) (void)hipEventRecord(ev[2], st);
-  if (mode == 0) hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, c->d, nb, 1);
-  else hipLaunchKernelGGL(bump_rollout_counter, dim3(1), dim3(1), 0, st, c->d);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, c->d, nb, mode == 0 ? 1 : 2, 1);
   if (ev) (void)hipEventRecord(ev[3], st);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
@@ -1441,7 +1610,7 @@ int lg_reset_idx(lg_ctx* c, const int32_t* env_ids, int32_t n, int32_t update_cu
   if (n == 0) return LG_OK;                         // LR:172-173
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(reset_idx_kernel, dim3(1), dim3(256), 0, st, c->d, env_ids, n, update_curriculum);
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, c->d, 1, 0);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, c->d, 1, 0, 0);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }

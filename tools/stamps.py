@@ -22,8 +22,9 @@ print('lib', nat.LIB_PATH, 'rc', rc)
 names = {15: "substep prologue", 0: "publish q/qd | inline actuator", 1: "kinematics", 2: "bias (RNEA)", 3: "CRBA+Schur+chol",
          5: "contact pass A (detect)", 6: "contact pass B (setup)", 4: "wait for torques (barrier B)", 7: "unconstrained + PGS",
          8: "limits+forces+integrate", 9: "fault guard", 10: "write-back + final FK",
-         11: "POST: stage rows in LDS", 12: "POST: height scan", 13: "POST: per-env scalar phase", 14: "POST: partials + obs rows"}
-tot = sum(out[:16])
+         11: "POST: stage rows in LDS", 12: "POST: height scan", 19: "POST 2.1: rotations + per-DOF features", 20: "POST 2.2: feature sums + callback + termination",
+         21: "POST 2.3: reward terms + sums (+ reset)", 13: "POST 2.4: proprio obs entries", 14: "POST: partials + obs rows"}
+tot = sum(out[:16]) + sum(out[19:22])
 print('active slots per wave-substep', out[16] / max(out[17], 1), ' active contacts per wave-substep', out[18] / max(out[17], 1), '(of', 64 * 7, 'lane-slots)')
 for k, n in names.items():
     print(f"{n:28s} {out[k]:14d} cycles  {100.0 * out[k] / max(tot, 1):5.1f} %   per substep-call {out[k] / (301 * 4):9.0f}")
