@@ -168,22 +168,35 @@ LG_DEV void symv6(const float* Si, const float* x, float* y) {
   }
 }
 
-// terrain surface under (x, y): height and unit normal of the regular-grid triangulation (diagonal v(i,j)->v(i+1,j+1))
+// terrain surface under (x, y): height and unit normal of the regular-grid triangulation (diagonal v(i,j)->v(i+1,j+1)).
+// Split in two so that callers can put other work between the four sample loads and their first use.
 struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t* __restrict__ H; MeshView M; };
-LG_DEV void terrain_query(const TerrainView& T, float x, float y, float* h, V3* n) {
-  if (T.mesh_type == LG_MESH_PLANE) { *h = 0.f; *n = v3(0, 0, 1); return; }
+struct TerrainCell { float u, v; int16_t h0, h1, h2, h3; };
+LG_DEV TerrainCell terrain_fetch(const TerrainView& T, float x, float y) {
+  TerrainCell c;
+  if (T.mesh_type == LG_MESH_PLANE) { c.u = 0.f; c.v = 0.f; c.h0 = c.h1 = c.h2 = c.h3 = 0; return c; }
   const float ihs = frcp(T.hscale);
   float fx = (x + T.border) * ihs, fy = (y + T.border) * ihs;
   int i = (int)floorf(fx), j = (int)floorf(fy);
   i = max(0, min(i, T.rows - 2)); j = max(0, min(j, T.cols - 2));
-  float u = fminf(fmaxf(fx - (float)i, 0.f), 1.f), v = fminf(fmaxf(fy - (float)j, 0.f), 1.f);
+  c.u = fminf(fmaxf(fx - (float)i, 0.f), 1.f); c.v = fminf(fmaxf(fy - (float)j, 0.f), 1.f);
   const int16_t* r0 = T.H + (size_t)i * T.cols + j;
-  float h0 = T.vscale * r0[0], h1 = T.vscale * r0[1], h2 = T.vscale * r0[T.cols], h3 = T.vscale * r0[T.cols + 1];
+  c.h0 = r0[0]; c.h1 = r0[1]; c.h2 = r0[T.cols]; c.h3 = r0[T.cols + 1];
+  return c;
+}
+LG_DEV void terrain_eval(const TerrainView& T, const TerrainCell& c, float* h, V3* n) {
+  if (T.mesh_type == LG_MESH_PLANE) { *h = 0.f; *n = v3(0, 0, 1); return; }
+  const float ihs = frcp(T.hscale);
+  float h0 = T.vscale * c.h0, h1 = T.vscale * c.h1, h2 = T.vscale * c.h2, h3 = T.vscale * c.h3;
   float dhdu, dhdv;
-  if (v >= u) { dhdu = h3 - h1; dhdv = h1 - h0; } else { dhdu = h2 - h0; dhdv = h3 - h2; }
-  *h = h0 + u * dhdu + v * dhdv;
+  if (c.v >= c.u) { dhdu = h3 - h1; dhdv = h1 - h0; } else { dhdu = h2 - h0; dhdv = h3 - h2; }
+  *h = h0 + c.u * dhdu + c.v * dhdv;
   V3 g = v3(-dhdu * ihs, -dhdv * ihs, 1.f);
   *n = __builtin_amdgcn_rsqf(dot(g, g)) * g;
+}
+LG_DEV void terrain_query(const TerrainView& T, float x, float y, float* h, V3* n) {
+  const TerrainCell c = terrain_fetch(T, x, y);
+  terrain_eval(T, c, h, n);
 }
 
 // per-contact-slot scratch in LDS, laid out [slot][field][lane] (lane-contiguous: conflict-free ds_read_b32)
@@ -241,34 +254,48 @@ LG_DEV void leg_bias(const LegModel& lm_, const LegKin& k, V3 pb, V3 wb, const f
 
 // Contact detection for slots [S0, S1): sphere centre, terrain surface under it, gap, activation; results go to the
 // LDS slot table (CF_ACTIVE, CF_N, CF_R, CF_BN, zeroed impulses).  Unrolled and branch-free so the lookups overlap.
+// Two halves: `begin` computes the sphere centres and issues the height-sample loads, `finish` consumes them — the
+// helper waves run their actuator network in between, which hides the memory latency of the lookups.
 template <int S0, int S1>
-LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k, const M3& Rb, V3 pb,
-                           float* cst, int lane) {
-  const int ncp = lm_.i(LM_CP_COUNT);
-  const float idt_ = frcp(P.dt);
-  V3 xs[S1 - S0]; float rads[S1 - S0];
+struct ContactProbe { V3 xs[S1 - S0]; float rads[S1 - S0]; TerrainCell cell[S1 - S0]; };
+template <int S0, int S1>
+LG_DEV void contact_detect_begin(const LegModel& lm_, const TerrainView& T, const LegKin& k, const M3& Rb, V3 pb, ContactProbe<S0, S1>& pr) {
 #pragma unroll
   for (int sl = S0; sl < S1; ++sl) {
     const int link = lm_.i(LM_CP_LINK + sl);
     const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
-    rads[sl - S0] = lm_.f(LM_CP_RADIUS + sl);
+    pr.rads[sl - S0] = lm_.f(LM_CP_RADIUS + sl);
     const V3 xb = pb + mul(Rb, lp), x0 = k.O[0] + mul(k.R[0], lp), x1 = k.O[1] + mul(k.R[1], lp), x2 = k.O[2] + mul(k.R[2], lp);
-    xs[sl - S0] = link < 0 ? xb : (link == 0 ? x0 : (link == 1 ? x1 : x2));
+    pr.xs[sl - S0] = link < 0 ? xb : (link == 0 ? x0 : (link == 1 ? x1 : x2));
   }
-  float hh[S1 - S0]; V3 nn[S1 - S0];
 #pragma unroll
-  for (int i = 0; i < S1 - S0; ++i) terrain_query(T, xs[i].x, xs[i].y, &hh[i], &nn[i]);
+  for (int i = 0; i < S1 - S0; ++i) pr.cell[i] = terrain_fetch(T, pr.xs[i].x, pr.xs[i].y);
+}
+template <int S0, int S1>
+LG_DEV void contact_detect_finish(const LegModel& lm_, const TerrainView& T, const PhysParams& P, V3 pb, const ContactProbe<S0, S1>& pr,
+                                  float* cst, int lane) {
+  const int ncp = lm_.i(LM_CP_COUNT);
+  const float idt_ = frcp(P.dt);
 #pragma unroll
   for (int sl = S0; sl < S1; ++sl) {
-    const V3 n = nn[sl - S0], x = xs[sl - S0];
-    const float phi = (x.z - hh[sl - S0]) * n.z - rads[sl - S0];
+    float hh; V3 n;
+    terrain_eval(T, pr.cell[sl - S0], &hh, &n);
+    const V3 x = pr.xs[sl - S0];
+    const float phi = (x.z - hh) * n.z - pr.rads[sl - S0];
     const bool active = (sl < ncp) && (phi < P.contact_offset);
     CS(sl, CF_ACTIVE) = active ? 1.f : 0.f;
     CS(sl, CF_L0) = 0.f; CS(sl, CF_L1) = 0.f; CS(sl, CF_L2) = 0.f;
     sts3(cst, sl, CF_N, lane, n);
-    sts3(cst, sl, CF_R, lane, (x - rads[sl - S0] * n) - pb);
+    sts3(cst, sl, CF_R, lane, (x - pr.rads[sl - S0] * n) - pb);
     CS(sl, CF_BN) = phi >= 0.f ? -phi * idt_ : fminf(-phi * P.erp * idt_, P.max_depen);
   }
+}
+template <int S0, int S1>
+LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k, const M3& Rb, V3 pb,
+                           float* cst, int lane) {
+  ContactProbe<S0, S1> pr;
+  contact_detect_begin<S0, S1>(lm_, T, k, Rb, pb, pr);
+  contact_detect_finish<S0, S1>(lm_, T, P, pb, pr, cst, lane);
 }
 
 // Triangle-mesh terrain (LG_MESH_TRIMESH): the surface under a sphere is the closest point of the collision mesh within
@@ -320,15 +347,110 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
   }
 }
 
+// Solver data of contact slot `sl` (contact frame, Jacobian pieces, A = J M^-1 J^T, the M^-1 J^T columns), from the
+// detection results in the slot table and this leg's share of the factorised mass matrix.  Any wave of the workgroup
+// that holds the leg kinematics and (Mi, Mbk, Y, Si) can run it: the slots of one substep are dealt to all four waves.
+LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 pb, const float Mi[6], const float Mbk[6][3],
+                               const float Y[3][6], const float Si[21], float cfm, float* cst, int lane) {
+  const int ncp = lm_.i(LM_CP_COUNT);
+  int lk = -1;
+  if (sl < ncp) { int link = lm_.i(LM_CP_LINK + sl); lk = link < 0 ? -1 : (link > 2 ? 2 : link); }
+  const V3 n = lds3(cst, sl, CF_N, lane), r = lds3(cst, sl, CF_R, lane);
+  const V3 p = r + pb;
+  // contact frame and Jacobian pieces (computed on every lane of the wave; inactive lanes carry harmless values)
+  V3 a0 = fabsf(n.x) < 0.57735f ? v3(1, 0, 0) : v3(0, 1, 0);
+  V3 t1 = cross(a0, n); t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
+  V3 t2 = cross(n, t1);
+  V3 jk[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) jk[j] = j <= lk ? cross(k.ax[j], p - k.O[j]) : v3(0, 0, 0);
+  // A = J M^-1 J^T in the contact frame (rows n, t1, t2)
+  V3 dirs[3] = {n, t1, t2};
+  float Wb[3][6], Wk[3][3];   // M^-1 J^T columns: base part and own-leg part
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    V3 d = dirs[c];
+    V3 rd = cross(r, d);
+    float jkv[3] = {dot(jk[0], d), dot(jk[1], d), dot(jk[2], d)}, z[3];
+    sym3_mul(Mi, jkv, z);
+    float g[6] = {d.x, d.y, d.z, rd.x, rd.y, rd.z};
+#pragma unroll
+    for (int a = 0; a < 6; ++a) g[a] -= Mbk[a][0] * z[0] + Mbk[a][1] * z[1] + Mbk[a][2] * z[2];
+    symv6(Si, g, Wb[c]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) CS(sl, CF_WB + 6 * c + a) = Wb[c][a];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float w = z[j];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) w -= Y[j][a] * Wb[c][a];
+      Wk[c][j] = w;
+      CS(sl, CF_ZC + 3 * c + j) = z[j];
+    }
+  }
+  float A[3][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    V3 d = dirs[b]; V3 rd = cross(r, d);
+    float jb[6] = {d.x, d.y, d.z, rd.x, rd.y, rd.z};
+    float jkv[3] = {dot(jk[0], d), dot(jk[1], d), dot(jk[2], d)};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float sacc = jkv[0] * Wk[c][0] + jkv[1] * Wk[c][1] + jkv[2] * Wk[c][2];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) sacc += jb[a] * Wb[c][a];
+      A[b][c] = sacc;
+    }
+  }
+  sts3(cst, sl, CF_T1, lane, t1); sts3(cst, sl, CF_T2, lane, t2);
+  sts3(cst, sl, CF_JK0, lane, jk[0]); sts3(cst, sl, CF_JK1, lane, jk[1]); sts3(cst, sl, CF_JK2, lane, jk[2]);
+  CS(sl, CF_ANN) = A[0][0] + cfm; CS(sl, CF_AN1) = A[1][0]; CS(sl, CF_AN2) = A[2][0];
+  CS(sl, CF_A11) = A[1][1] + cfm; CS(sl, CF_A12) = A[1][2]; CS(sl, CF_A22) = A[2][2] + cfm;
+}
+
+// wave-uniform: slots with at least one active contact in this wave
+LG_DEV unsigned active_slot_mask(const float* cst, int lane) {
+  unsigned slot_mask = 0;
+#pragma unroll
+  for (int sl = 0; sl < LG_MAX_CP; ++sl)
+    if (__ballot(CS(sl, CF_ACTIVE) != 0.f) != 0ull) slot_mask |= 1u << sl;
+  return slot_mask;
+}
+
+// How the contact set-up of one substep is shared between the waves of a workgroup: this wave takes every n-th active slot.
+struct SlotShare { int n, me; };
+// (Mi 6 | Mbk 18 | Y 18 | Si 21) of every lane, published by the main wave for the helper waves: [field][lane]
+#define XS_FIELDS 63
+LG_DEV void publish_mass_factors(float* xs, int lane, const float Mi[6], const float Mbk[6][3], const float Y[3][6], const float Si[21]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) xs[i * 64 + lane] = Mi[i];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { xs[(6 + a * 3 + j) * 64 + lane] = Mbk[a][j]; xs[(24 + j * 6 + a) * 64 + lane] = Y[j][a]; }
+#pragma unroll
+  for (int i = 0; i < 21; ++i) xs[(42 + i) * 64 + lane] = Si[i];
+}
+LG_DEV void fetch_mass_factors(const float* xs, int lane, float Mi[6], float Mbk[6][3], float Y[3][6], float Si[21]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Mi[i] = xs[i * 64 + lane];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { Mbk[a][j] = xs[(6 + a * 3 + j) * 64 + lane]; Y[j][a] = xs[(24 + j * 6 + a) * 64 + lane]; }
+#pragma unroll
+  for (int i = 0; i < 21; ++i) Si[i] = xs[(42 + i) * 64 + lane];
+}
+
 // One physics step of length P.dt for the env this quad owns.  tau_fn(tau[3]) delivers this leg's joint torques; it is
 // called after everything that does not depend on them (kinematics, bias, mass matrix, contact set-up).
 // fbody[5] (optional) receives the net contact force on {base (already quad-summed), link0, link1, link2, foot}.
 // prep_fn(bk, Fs, Ns) returns true when helper waves have produced the leg bias and the contact detection (it then
 // holds the rendezvous and fills the three outputs); false means this wave computes them itself.
-template <bool TMESH, class TauFn, class PrepFn>
+template <bool TMESH, class TauFn, class PrepFn, class ShareFn>
 LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel& lm_, const TerrainView& T, const PhysParams& P,
-                            int lane, float* cst, QuadState& s, TauFn tau_fn, PrepFn prep_fn, float mu_robot, float madd, V3* fbody,
-                            unsigned long long* stamps = nullptr) {
+                            int lane, float* cst, QuadState& s, TauFn tau_fn, PrepFn prep_fn, ShareFn share_fn, SlotShare share,
+                            float* xs, float mu_robot, float madd, V3* fbody, unsigned long long* stamps = nullptr) {
   STAMP_DECL
   const float dt = P.dt;
   const V3 pb = v3(s.root[0], s.root[1], s.root[2]);
@@ -394,6 +516,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   }
   float Si[21];
   spd6_inverse_from_chol(L, Si);
+  if (share.n > 1) publish_mass_factors(xs, lane, Mi, Mbk, Y, Si);
 
   STAMP(3);
   // ---------------------------------------------------------------- leg bias + contact detection: helper waves or inline
@@ -413,73 +536,23 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   }
   const float mu = 0.5f * (mu_robot + P.terrain_mu);   // PhysX default friction combine mode: average
   const float idt_ = frcp(dt);
-  const int ncp = lm_.i(LM_CP_COUNT);
-  unsigned slot_mask = 0;    // wave-uniform: slots with at least one active contact in this wave
-#pragma unroll
-  for (int sl = 0; sl < LG_MAX_CP; ++sl)
-    if (__ballot(CS(sl, CF_ACTIVE) != 0.f) != 0ull) slot_mask |= 1u << sl;
+  const unsigned slot_mask = active_slot_mask(cst, lane);
 #ifdef LG_STAMPS
   if (stamps) { stamps[16] += __popc(slot_mask); stamps[17] += 1; unsigned long long am = 0; for (int sl = 0; sl < LG_MAX_CP; ++sl) am += __popcll(__ballot(CS(sl, CF_ACTIVE) != 0.f)); stamps[18] += am; }
 #endif
   STAMP(5);
-  // pass B: per-contact solver data, only for slots some lane of the wave needs
+  // pass B: per-contact solver data, only for slots some lane of the wave needs.  With helper waves the active slots are
+  // dealt round-robin to the `share.n` waves of the workgroup (this wave is share.me); share_fn is the rendezvous after it.
+  {
+    int seen = 0;
 #pragma unroll 1
-  for (int sl = 0; sl < LG_MAX_CP; ++sl) {
-    if (!((slot_mask >> sl) & 1u)) continue;
-    int lk = -1;
-    if (sl < ncp) { int link = lm_.i(LM_CP_LINK + sl); lk = link < 0 ? -1 : (link > 2 ? 2 : link); }
-    const V3 n = lds3(cst, sl, CF_N, lane), r = lds3(cst, sl, CF_R, lane);
-    const V3 p = r + pb;
-    // contact frame and Jacobian pieces (computed on every lane of the wave; inactive lanes carry harmless values)
-    V3 a0 = fabsf(n.x) < 0.57735f ? v3(1, 0, 0) : v3(0, 1, 0);
-    V3 t1 = cross(a0, n); t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
-    V3 t2 = cross(n, t1);
-    V3 jk[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) jk[j] = j <= lk ? cross(k.ax[j], p - k.O[j]) : v3(0, 0, 0);
-    // A = J M^-1 J^T in the contact frame (rows n, t1, t2)
-    V3 dirs[3] = {n, t1, t2};
-    float Wb[3][6], Wk[3][3];   // M^-1 J^T columns: base part and own-leg part
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      V3 d = dirs[c];
-      V3 rd = cross(r, d);
-      float jkv[3] = {dot(jk[0], d), dot(jk[1], d), dot(jk[2], d)}, z[3];
-      sym3_mul(Mi, jkv, z);
-      float g[6] = {d.x, d.y, d.z, rd.x, rd.y, rd.z};
-#pragma unroll
-      for (int a = 0; a < 6; ++a) g[a] -= Mbk[a][0] * z[0] + Mbk[a][1] * z[1] + Mbk[a][2] * z[2];
-      symv6(Si, g, Wb[c]);
-#pragma unroll
-      for (int a = 0; a < 6; ++a) CS(sl, CF_WB + 6 * c + a) = Wb[c][a];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        float w = z[j];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) w -= Y[j][a] * Wb[c][a];
-        Wk[c][j] = w;
-        CS(sl, CF_ZC + 3 * c + j) = z[j];
-      }
+    for (int sl = 0; sl < LG_MAX_CP; ++sl) {
+      if (!((slot_mask >> sl) & 1u)) continue;
+      if ((seen++ % share.n) != share.me) continue;
+      contact_setup_slot(sl, lm_, k, pb, Mi, Mbk, Y, Si, P.cfm, cst, lane);
     }
-    float A[3][3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      V3 d = dirs[b]; V3 rd = cross(r, d);
-      float jb[6] = {d.x, d.y, d.z, rd.x, rd.y, rd.z};
-      float jkv[3] = {dot(jk[0], d), dot(jk[1], d), dot(jk[2], d)};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float sacc = jkv[0] * Wk[c][0] + jkv[1] * Wk[c][1] + jkv[2] * Wk[c][2];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) sacc += jb[a] * Wb[c][a];
-        A[b][c] = sacc;
-      }
-    }
-    sts3(cst, sl, CF_T1, lane, t1); sts3(cst, sl, CF_T2, lane, t2);
-    sts3(cst, sl, CF_JK0, lane, jk[0]); sts3(cst, sl, CF_JK1, lane, jk[1]); sts3(cst, sl, CF_JK2, lane, jk[2]);
-    CS(sl, CF_ANN) = A[0][0] + P.cfm; CS(sl, CF_AN1) = A[1][0]; CS(sl, CF_AN2) = A[2][0];
-    CS(sl, CF_A11) = A[1][1] + P.cfm; CS(sl, CF_A12) = A[1][2]; CS(sl, CF_A22) = A[2][2] + P.cfm;
   }
+  share_fn();
 
   STAMP(6);
   // ---------------------------------------------------------------- unconstrained velocity v* = v + dt M^-1 (tau - c)

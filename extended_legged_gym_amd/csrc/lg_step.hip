@@ -49,6 +49,7 @@ struct DevCtx {
   float* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
   float* lvl_part;     // [nblocks] : per-workgroup sum of terrain levels
   unsigned* part_flag; // [nblocks] : 1 when some env of the workgroup was reset in this step (its partials row is valid)
+  float lstm_w[912];   // actuator network weights, gate-interleaved (pack_lstm_weights): read with scalar loads
   int nblocks_post;
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
   unsigned long long* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
@@ -94,115 +95,88 @@ LG_DEV void uniform_draw4(const DevCtx* __restrict__ C, int e, int grp, int64_t 
 }
 
 // ============================================================================================ device: actuators
-LG_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-LG_DEV float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
-
 struct LegActuator { float h[2][3][8], c[2][3][8]; };   // LSTM state of this lane's three joints
 
-// The ANYdrive LSTM actuator for this lane's three joints at once (anymal.py:93-105): 2-layer LSTM(2->8->8) + Linear(8->1).
-// W = the 969 weights staged in LDS (every lane reads the same address: broadcast); each weight row is read once and
-// used for all three joints.  Torch gate order i, f, g, o.
-LG_DEV void lstm_actuator3(const float* __restrict__ W, const float x0[3], const float x1[3], LegActuator& A, float out_scale,
-                           float tau[3]) {
-  const float *wih0 = W, *whh0 = W + 64, *bih0 = W + 320, *bhh0 = W + 352, *wih1 = W + 384, *whh1 = W + 640,
-              *bih1 = W + 896, *bhh1 = W + 928, *lw = W + 960, *lb = W + 968;
-  float hn0[3][8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float gt[4][3];
-#pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
-      const int r = 8 * gi + k;
-      const float b = bih0[r] + bhh0[r], w0 = wih0[2 * r], w1 = wih0[2 * r + 1];
-      float wh[8];
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) wh[kk] = whh0[8 * r + kk];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        float s = b + w0 * x0[j] + w1 * x1[j];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) s += wh[kk] * A.h[0][j][kk];
-        gt[gi][j] = s;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float cn = fast_sigmoid(gt[1][j]) * A.c[0][j][k] + fast_sigmoid(gt[0][j]) * fast_tanh(gt[2][j]);
-      A.c[0][j][k] = cn; hn0[j][k] = fast_sigmoid(gt[3][j]) * fast_tanh(cn);
-    }
+// The ANYdrive LSTM actuator (anymal.py:93-105): 2-layer LSTM(2->8->8) + Linear(8->1), torch gate order i, f, g, o.
+//
+// The 969 weights are the same for every lane: they stay in global memory in a gate-interleaved order (DevCtx::lstm_w,
+// pack_lstm_weights) and are fetched with scalar loads (s_load_dwordx4..x16 through the scalar cache) straight into
+// SGPRs; for every unit k and input kk the four gate weights (i, f, g, o) are adjacent, so one SGPR pair feeds a packed
+// FMA (v_pk_fma_f32: gates i,f and g,o) — half the instructions of a scalar dot product, no LDS traffic, and the scalar
+// unit runs ahead of the vector ALU.  Offsets in floats:
+enum { LW_B0 = 0, LW_X0 = 32, LW_H0 = 96, LW_B1 = 352, LW_I1 = 384, LW_H1 = 640, LW_OUT = 896, LW_COUNT = 905 };
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// torch layout (lg_config.actuator_net) -> gate-interleaved layout, once, on the host at lg_create
+static void pack_lstm_weights(float* W, const float* net) {
+  for (int i = 0; i < LW_COUNT; ++i) W[i] = 0.f;
+  for (int i = 0; i < LG_LSTM_NPARAM; ++i) {
+    int d = -1;
+    if (i < 64) { int r = i >> 1, j = i & 1; d = LW_X0 + ((r & 7) * 2 + j) * 4 + (r >> 3); }
+    else if (i < 320) { int r = (i - 64) >> 3, kk = (i - 64) & 7; d = LW_H0 + ((r & 7) * 8 + kk) * 4 + (r >> 3); }
+    else if (i < 384) d = -1;                              // biases: below
+    else if (i < 640) { int r = (i - 384) >> 3, kk = (i - 384) & 7; d = LW_I1 + ((r & 7) * 8 + kk) * 4 + (r >> 3); }
+    else if (i < 896) { int r = (i - 640) >> 3, kk = (i - 640) & 7; d = LW_H1 + ((r & 7) * 8 + kk) * 4 + (r >> 3); }
+    else if (i < 960) d = -1;
+    else d = LW_OUT + (i - 960);
+    if (d >= 0) W[d] = net[i];
   }
-  float hn1[3][8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float gt[4][3];
-#pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
-      const int r = 8 * gi + k;
-      const float b = bih1[r] + bhh1[r];
-      float wi[8], wh[8];
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) { wi[kk] = wih1[8 * r + kk]; wh[kk] = whh1[8 * r + kk]; }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        float s = b;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) s += wi[kk] * hn0[j][kk] + wh[kk] * A.h[1][j][kk];
-        gt[gi][j] = s;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float cn = fast_sigmoid(gt[1][j]) * A.c[1][j][k] + fast_sigmoid(gt[0][j]) * fast_tanh(gt[2][j]);
-      A.c[1][j][k] = cn; hn1[j][k] = fast_sigmoid(gt[3][j]) * fast_tanh(cn);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    float o = lb[0];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { o += lw[k] * hn1[j][k]; A.h[0][j][k] = hn0[j][k]; A.h[1][j][k] = hn1[j][k]; }
-    tau[j] = out_scale * o;     // no torque clip on this path (anymal.py:101-102)
+  for (int i = 0; i < 64; ++i) {                           // (b_ih + b_hh) of both layers, gate-interleaved
+    const int lay = i >> 5, r = i & 31, base = lay ? 896 : 320;
+    W[(lay ? LW_B1 : LW_B0) + (r & 7) * 4 + (r >> 3)] = net[base + r] + net[base + 32 + r];
   }
 }
 
-// One joint per lane (actuator waves of the 4-wave step): same arithmetic as lstm_actuator3, state h0,c0,h1,c1 of 8 each.
+LG_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+LG_DEV float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+LG_DEV v2f splat2(float x) { v2f r = {x, x}; return r; }
+
+// one joint: inputs x0 (scaled position error), x1 (scaled velocity); state h0, c0, h1, c1 of 8 each, updated in place
 LG_DEV float lstm_actuator1(const float* __restrict__ W, float x0, float x1, float* h0, float* c0, float* h1, float* c1,
                             float out_scale) {
-  const float *wih0 = W, *whh0 = W + 64, *bih0 = W + 320, *bhh0 = W + 352, *wih1 = W + 384, *whh1 = W + 640,
-              *bih1 = W + 896, *bhh1 = W + 928, *lw = W + 960, *lb = W + 968;
+  const v4f* B0 = (const v4f*)(W + LW_B0); const v4f* X0 = (const v4f*)(W + LW_X0); const v4f* H0 = (const v4f*)(W + LW_H0);
+  const v4f* B1 = (const v4f*)(W + LW_B1); const v4f* I1 = (const v4f*)(W + LW_I1); const v4f* H1 = (const v4f*)(W + LW_H1);
   float hn0[8], hn1[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float gt[4];
+    v4f w = B0[k];
+    v2f a_if = w.xy, a_go = w.zw;
+    w = X0[2 * k];     a_if = __builtin_elementwise_fma(w.xy, splat2(x0), a_if); a_go = __builtin_elementwise_fma(w.zw, splat2(x0), a_go);
+    w = X0[2 * k + 1]; a_if = __builtin_elementwise_fma(w.xy, splat2(x1), a_if); a_go = __builtin_elementwise_fma(w.zw, splat2(x1), a_go);
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
-      const int r = 8 * gi + k;
-      float s = (bih0[r] + bhh0[r]) + wih0[2 * r] * x0 + wih0[2 * r + 1] * x1;
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) s += whh0[8 * r + kk] * h0[kk];
-      gt[gi] = s;
+    for (int kk = 0; kk < 8; ++kk) {
+      w = H0[8 * k + kk];
+      a_if = __builtin_elementwise_fma(w.xy, splat2(h0[kk]), a_if); a_go = __builtin_elementwise_fma(w.zw, splat2(h0[kk]), a_go);
     }
-    float cn = fast_sigmoid(gt[1]) * c0[k] + fast_sigmoid(gt[0]) * fast_tanh(gt[2]);
-    c0[k] = cn; hn0[k] = fast_sigmoid(gt[3]) * fast_tanh(cn);
+    float cn = fast_sigmoid(a_if.y) * c0[k] + fast_sigmoid(a_if.x) * fast_tanh(a_go.x);
+    c0[k] = cn; hn0[k] = fast_sigmoid(a_go.y) * fast_tanh(cn);
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float gt[4];
+    v4f w = B1[k];
+    v2f a_if = w.xy, a_go = w.zw;
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
-      const int r = 8 * gi + k;
-      float s = bih1[r] + bhh1[r];
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) s += wih1[8 * r + kk] * hn0[kk] + whh1[8 * r + kk] * h1[kk];
-      gt[gi] = s;
+    for (int kk = 0; kk < 8; ++kk) {
+      w = I1[8 * k + kk];
+      a_if = __builtin_elementwise_fma(w.xy, splat2(hn0[kk]), a_if); a_go = __builtin_elementwise_fma(w.zw, splat2(hn0[kk]), a_go);
+      w = H1[8 * k + kk];
+      a_if = __builtin_elementwise_fma(w.xy, splat2(h1[kk]), a_if); a_go = __builtin_elementwise_fma(w.zw, splat2(h1[kk]), a_go);
     }
-    float cn = fast_sigmoid(gt[1]) * c1[k] + fast_sigmoid(gt[0]) * fast_tanh(gt[2]);
-    c1[k] = cn; hn1[k] = fast_sigmoid(gt[3]) * fast_tanh(cn);
+    float cn = fast_sigmoid(a_if.y) * c1[k] + fast_sigmoid(a_if.x) * fast_tanh(a_go.x);
+    c1[k] = cn; hn1[k] = fast_sigmoid(a_go.y) * fast_tanh(cn);
   }
-  float o = lb[0];
+  float o = W[LW_OUT + 8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { o += lw[k] * hn1[k]; h0[k] = hn0[k]; h1[k] = hn1[k]; }
-  return out_scale * o;
+  for (int k = 0; k < 8; ++k) { o += W[LW_OUT + k] * hn1[k]; h0[k] = hn0[k]; h1[k] = hn1[k]; }
+  return out_scale * o;       // no torque clip on this path (anymal.py:101-102)
+}
+
+// the three joints of this lane's leg (single-wave builds: lg_compute_torques, LG_SPLIT=0)
+LG_DEV void lstm_actuator3(const float* __restrict__ W, const float x0[3], const float x1[3], LegActuator& A, float out_scale,
+                           float tau[3]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) tau[j] = lstm_actuator1(W, x0[j], x1[j], A.h[0][j], A.c[0][j], A.h[1][j], A.c[1][j], out_scale);
 }
 
 LG_DEV void load_lstm(const DevCtx* __restrict__ C, int e, int l, LegActuator& A) {
@@ -272,8 +246,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
   __shared__ float cst[LG_MAX_CP * CF_FIELDS * 64];
   __shared__ float lmod[LM_FIELDS * 4];
-  __shared__ __attribute__((aligned(16))) float wlstm[LG_LSTM_NPARAM + 3];
+  const float* __restrict__ wlstm = C->lstm_w;
   __shared__ float xq[3][64], xqd[3][64], xtau[3][64], xroot[13][64], xbias[9][64];
+  __shared__ float xs[XS_FIELDS * 64];              // main wave's mass-matrix factors for the helpers' share of the contact set-up
   __shared__ float cqc[TMESH ? LG_MAX_CP * 4 * 64 : 1];   // mesh terrains: last closest-point query of every collision sphere
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // row kq of the launch <-> env e (identity, or ids[kq] for subset stepping: main-only / rollout-only steps)
@@ -286,8 +261,6 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const lg_config& g = C->cfg;
   const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
   if (wv == 0) fill_leg_model(lmod, m, &C->cfg, lane);
-  if (MODE != 1 && net)
-    for (int i = threadIdx.x; i < LG_LSTM_NPARAM; i += blockDim.x) wlstm[i] = g.actuator_net[i];
   __syncthreads();
   const LegModel lm_{lmod, l};
 
@@ -319,41 +292,72 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm;
     P.terrain_mu = C->terrain_mu;
     const TerrainView T = C->ter;
+#ifdef LG_STAMPS
+    unsigned long long* stamps = (blockIdx.x == 0 && lane == 0 && wv == 2) ? C->stamps : nullptr;
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
     for (int sub = 0; sub < nsub; ++sub) {
       __syncthreads();                                   // (A) main wave has published root, q, qd of this substep
+      STAMP(22);
       // torque-independent share of the dynamics: this leg's kinematics, then the leg bias (wave 1) or the contact
-      // detection of half of the slots (waves 2, 3), straight into the LDS the main wave reads after barrier (A2)
+      // detection of half of the slots (waves 2, 3), straight into the LDS the main wave reads after barrier (A2);
+      // then this wave's joint of the actuator network, all while the main wave factorises the mass matrix
+      float r13[13], qq[3], qdd[3];
+#pragma unroll
+      for (int i = 0; i < 13; ++i) r13[i] = xroot[i][lane];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { qq[i] = xq[i][lane]; qdd[i] = xqd[i][lane]; }
+      const M3 Rb = quat_to_mat(r13 + 3);
+      const V3 pb = v3(r13[0], r13[1], r13[2]), vb = v3(r13[7], r13[8], r13[9]), wb = v3(r13[10], r13[11], r13[12]);
+      LegKin k;
+      leg_kinematics(lm_, Rb, pb, vb, wb, qq, qdd, k);
+      STAMP(23);
+      // heightfield terrains: issue this wave's height-sample loads now, use them after the actuator network
+      ContactProbe<0, LG_MAX_CP / 2> pr2; ContactProbe<LG_MAX_CP / 2, LG_MAX_CP> pr3;
+      if (wv == 1) {
+        float bk[3]; V3 Fs, Ns;
+        leg_bias(lm_, k, pb, wb, qdd, P.grav, bk, Fs, Ns);
+        xbias[0][lane] = bk[0]; xbias[1][lane] = bk[1]; xbias[2][lane] = bk[2];
+        xbias[3][lane] = Fs.x; xbias[4][lane] = Fs.y; xbias[5][lane] = Fs.z;
+        xbias[6][lane] = Ns.x; xbias[7][lane] = Ns.y; xbias[8][lane] = Ns.z;
+      } else if (TMESH) {
+        contact_detect_mesh(wv == 2 ? 0 : LG_MAX_CP / 2, wv == 2 ? LG_MAX_CP / 2 : LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane, cqc, sub == 0);
+      } else if (wv == 2) {
+        contact_detect_begin<0, LG_MAX_CP / 2>(lm_, T, k, Rb, pb, pr2);
+      } else {
+        contact_detect_begin<LG_MAX_CP / 2, LG_MAX_CP>(lm_, T, k, Rb, pb, pr3);
+      }
+      STAMP(24);
+      if (net) {
+        const float x0 = (tgt - qq[j]) * g.actuator_in_scale[0], x1 = qdd[j] * g.actuator_in_scale[1];
+        // an opaque zero keeps the ~60 weight addresses from being hoisted out of the substep loop as loop invariants
+        // (they would fill the SGPR file and spill): inside the loop they fold into the s_load immediate offsets
+        int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+        xtau[j][lane] = lstm_actuator1(wlstm + zero, x0, x1, h0, c0, h1, c1, g.actuator_out_scale);
+      }
+      if (!TMESH && wv == 2) contact_detect_finish<0, LG_MAX_CP / 2>(lm_, T, P, pb, pr2, cst, lane);
+      else if (!TMESH && wv == 3) contact_detect_finish<LG_MAX_CP / 2, LG_MAX_CP>(lm_, T, P, pb, pr3, cst, lane);
+      STAMP(25);
+      __syncthreads();                                   // (A2) bias, contact detection, torques | mass-matrix factors
+      STAMP(26);
+      // this wave's share of the contact set-up (every fourth active slot)
       {
-        float r13[13], qq[3], qdd[3];
-#pragma unroll
-        for (int i = 0; i < 13; ++i) r13[i] = xroot[i][lane];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { qq[i] = xq[i][lane]; qdd[i] = xqd[i][lane]; }
-        const M3 Rb = quat_to_mat(r13 + 3);
-        const V3 pb = v3(r13[0], r13[1], r13[2]), vb = v3(r13[7], r13[8], r13[9]), wb = v3(r13[10], r13[11], r13[12]);
-        LegKin k;
-        leg_kinematics(lm_, Rb, pb, vb, wb, qq, qdd, k);
-        if (wv == 1) {
-          float bk[3]; V3 Fs, Ns;
-          leg_bias(lm_, k, pb, wb, qdd, P.grav, bk, Fs, Ns);
-          xbias[0][lane] = bk[0]; xbias[1][lane] = bk[1]; xbias[2][lane] = bk[2];
-          xbias[3][lane] = Fs.x; xbias[4][lane] = Fs.y; xbias[5][lane] = Fs.z;
-          xbias[6][lane] = Ns.x; xbias[7][lane] = Ns.y; xbias[8][lane] = Ns.z;
-        } else if (TMESH) {
-          contact_detect_mesh(wv == 2 ? 0 : LG_MAX_CP / 2, wv == 2 ? LG_MAX_CP / 2 : LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane, cqc, sub == 0);
-        } else if (wv == 2) {
-          contact_detect<0, LG_MAX_CP / 2>(lm_, T, P, k, Rb, pb, cst, lane);
-        } else {
-          contact_detect<LG_MAX_CP / 2, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
+        float Mi[6], Mbk[6][3], Y[3][6], Si[21];
+        const unsigned slot_mask = active_slot_mask(cst, lane);
+        if (slot_mask) {
+          fetch_mass_factors(xs, lane, Mi, Mbk, Y, Si);
+          int seen = 0;
+#pragma unroll 1
+          for (int sl = 0; sl < LG_MAX_CP; ++sl) {
+            if (!((slot_mask >> sl) & 1u)) continue;
+            if ((seen++ & 3) != wv) continue;
+            contact_setup_slot(sl, lm_, k, pb, Mi, Mbk, Y, Si, P.cfm, cst, lane);
+          }
         }
       }
-      __syncthreads();                                   // (A2) bias + contact detection visible to the main wave
-      if (net) {
-        const float x0 = (tgt - xq[j][lane]) * g.actuator_in_scale[0], x1 = xqd[j][lane] * g.actuator_in_scale[1];
-        xtau[j][lane] = lstm_actuator1(wlstm, x0, x1, h0, c0, h1, c1, g.actuator_out_scale);
-        __syncthreads();                                 // (B) torques ready
-      }
+      STAMP(27);
+      __syncthreads();                                   // (A3) slot table complete
     }
     if (valid && net) {
       float4* p = (float4*)(C->sea_h + row * 8);
@@ -444,8 +448,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     for (int j = 0; j < 3; ++j) q0[j] = s.q[j];
     STAMP(0);
     auto tau_fn = [&](float* t) {
-      if (split) {
-        __syncthreads();                                 // (B) actuator waves have written this substep's torques
+      if (split) {                                       // written by the helper waves before barrier (A2)
 #pragma unroll
         for (int j = 0; j < 3; ++j) tau[j] = xtau[j][lane];
       }
@@ -459,7 +462,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       Ns = v3(xbias[6][lane], xbias[7][lane], xbias[8][lane]);
       return true;
     };
-    physics_substep<TMESH>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr, stamps);
+    auto share_fn = [&]() { if (helpers) __syncthreads(); };   // (A3) every wave has finished its slots
+    const SlotShare share{helpers ? 4 : 1, 0};
+    physics_substep<TMESH>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
+                           sub == nsub - 1 ? fbody : nullptr, stamps);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -1351,6 +1357,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.cfg.noise_scale_vec = nullptr; h.cfg.height_points = nullptr;
   h.N = cfg->num_envs; h.B = model->num_bodies; h.K = cfg->num_reward_terms; h.P = cfg->num_height_points;
   h.per_leg = 3 + model->has_foot_body;
+  pack_lstm_weights(h.lstm_w, cfg->actuator_net);
   h.terrain_mu = ter->static_friction; h.env_length = ter->env_length; h.num_levels = ter->num_levels; h.num_types = ter->num_types;
   char* base = (char*)c->arena;
   auto P = [&](int id) { return (void*)(base + c->t[id].off); };
