@@ -618,17 +618,25 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
 #pragma unroll 1
       for (int sl = 0; sl < LG_MAX_CP; ++sl) {
         if (!((slot_mask >> sl) & 1u)) continue;
+        // the whole slot record first (59 LDS reads in flight, one wait), then arithmetic only: read-next-to-use costs
+        // an LDS round trip at every step of this dependent chain
         const bool active = CS(sl, CF_ACTIVE) != 0.f;
-        V3 n = lds3(cst, sl, CF_N, lane), t1 = lds3(cst, sl, CF_T1, lane), t2 = lds3(cst, sl, CF_T2, lane);
-        V3 r = lds3(cst, sl, CF_R, lane);
-        V3 jk0 = lds3(cst, sl, CF_JK0, lane), jk1 = lds3(cst, sl, CF_JK1, lane), jk2 = lds3(cst, sl, CF_JK2, lane);
+        const V3 n = lds3(cst, sl, CF_N, lane), t1 = lds3(cst, sl, CF_T1, lane), t2 = lds3(cst, sl, CF_T2, lane);
+        const V3 r = lds3(cst, sl, CF_R, lane);
+        const V3 jk0 = lds3(cst, sl, CF_JK0, lane), jk1 = lds3(cst, sl, CF_JK1, lane), jk2 = lds3(cst, sl, CF_JK2, lane);
+        const float l0 = CS(sl, CF_L0), l1 = CS(sl, CF_L1), l2 = CS(sl, CF_L2), bn = CS(sl, CF_BN);
+        const float Ann = CS(sl, CF_ANN), An1 = CS(sl, CF_AN1), An2 = CS(sl, CF_AN2);
+        const float A11 = CS(sl, CF_A11), A12 = CS(sl, CF_A12), A22 = CS(sl, CF_A22);
+        float wbv[18], zcv[9];
+#pragma unroll
+        for (int a = 0; a < 18; ++a) wbv[a] = CS(sl, CF_WB + a);
+#pragma unroll
+        for (int a = 0; a < 9; ++a) zcv[a] = CS(sl, CF_ZC + a);
+        __builtin_amdgcn_sched_barrier(0);
         // velocity of the contact point
         V3 vp = v3(vB[0], vB[1], vB[2]) + cross(v3(vB[3], vB[4], vB[5]), r) + vK[0] * jk0 + vK[1] * jk1 + vK[2] * jk2;
         float u0 = dot(n, vp), u1 = dot(t1, vp), u2 = dot(t2, vp);
-        float l0 = CS(sl, CF_L0), l1 = CS(sl, CF_L1), l2 = CS(sl, CF_L2);
-        float Ann = CS(sl, CF_ANN), An1 = CS(sl, CF_AN1), An2 = CS(sl, CF_AN2);
-        float A11 = CS(sl, CF_A11), A12 = CS(sl, CF_A12), A22 = CS(sl, CF_A22);
-        float ln = fmaxf(l0 - (u0 - CS(sl, CF_BN)) * frcp(Ann), 0.f);
+        float ln = fmaxf(l0 - (u0 - bn) * frcp(Ann), 0.f);
         float dn = ln - l0;
         float w1 = u1 + An1 * dn, w2 = u2 + An2 * dn;
         float idet = frcp(A11 * A22 - A12 * A12);
@@ -642,12 +650,12 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
         float g[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a)
-          g[a] = quad_sum(d0 * CS(sl, CF_WB + a) + d1 * CS(sl, CF_WB + 6 + a) + d2 * CS(sl, CF_WB + 12 + a));
+          g[a] = quad_sum(d0 * wbv[a] + d1 * wbv[6 + a] + d2 * wbv[12 + a]);
 #pragma unroll
         for (int a = 0; a < 6; ++a) vB[a] += g[a];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          float w = d0 * CS(sl, CF_ZC + j) + d1 * CS(sl, CF_ZC + 3 + j) + d2 * CS(sl, CF_ZC + 6 + j);
+          float w = d0 * zcv[j] + d1 * zcv[3 + j] + d2 * zcv[6 + j];
 #pragma unroll
           for (int a = 0; a < 6; ++a) w -= Y[j][a] * g[a];
           vK[j] += w;
