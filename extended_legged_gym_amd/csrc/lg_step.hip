@@ -235,6 +235,42 @@ LG_DEV void leg_torques(const DevCtx* __restrict__ C, const LegModel& lm_, const
   }
 }
 
+// Body states of one leg (+ the base from leg 0) from the generalised state: forward kinematics once more, then the
+// (N, B, 13) rows [pos3, quat xyzw4, lin vel3, ang vel3] the reference reads from refresh_rigid_body_state_tensor.
+// `part` selects what this caller stores: -1 everything; 0 / 1 / 2 = link 0 (+ base) / link 1 / link 2 (+ foot body).
+LG_DEV void write_rigid_body_state(const DevCtx* __restrict__ C, const LegModel& lm_, int e, int l, const float* root, const float* q,
+                                   const float* qd, int part = -1) {
+  const int per_leg = C->per_leg, B = C->B;
+  const M3 Rb = quat_to_mat(root + 3);
+  const V3 pb = v3(root[0], root[1], root[2]), vb = v3(root[7], root[8], root[9]), wb = v3(root[10], root[11], root[12]);
+  LegKin k;
+  leg_kinematics(lm_, Rb, pb, vb, wb, q, qd, k);
+  float* rb = C->rigid + (size_t)e * B * 13;
+  if (l == 0 && part <= 0) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) rb[i] = root[i];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (part >= 0 && part != j) continue;
+    float* o = rb + (size_t)(1 + per_leg * l + j) * 13;
+    float qq[4]; mat_to_quat(k.R[j], qq);
+    o[0] = k.O[j].x; o[1] = k.O[j].y; o[2] = k.O[j].z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
+    o[7] = k.vO[j].x; o[8] = k.vO[j].y; o[9] = k.vO[j].z; o[10] = k.w[j].x; o[11] = k.w[j].y; o[12] = k.w[j].z;
+  }
+  if (per_leg == 4 && (part < 0 || part == 2)) {
+    float* o = rb + (size_t)(1 + per_leg * l + 3) * 13;
+    V3 r = mul(k.R[2], lm_.v(LM_FOOT_POS));
+    V3 p = k.O[2] + r, v = k.vO[2] + cross(k.w[2], r);
+    M3 fr;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fr.m[i] = lm_.f(LM_FOOT_ROT + i);
+    float qq[4]; mat_to_quat(mul(k.R[2], fr), qq);
+    o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
+    o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = k.w[2].x; o[11] = k.w[2].y; o[12] = k.w[2].z;
+  }
+}
+
 // ============================================================================================ physics kernel
 // MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
 // MODE 2: lg_compute_torques only.
@@ -358,6 +394,15 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       }
       STAMP(27);
       __syncthreads();                                   // (A3) slot table complete
+    }
+    __syncthreads();                                     // (F) main wave has published the final state of the step
+    if (valid) {                                         // wave w stores link w-1 of every leg (+ base / + foot body)
+      float r13[13], qq[3], qdd[3];
+#pragma unroll
+      for (int i = 0; i < 13; ++i) r13[i] = xroot[i][lane];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { qq[i] = xq[i][lane]; qdd[i] = xqd[i][lane]; }
+      write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, wv - 1);
     }
     if (valid && net) {
       float4* p = (float4*)(C->sea_h + row * 8);
@@ -493,6 +538,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
   }
   STAMP(9);
+  if (helpers) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { xq[j][lane] = s.q[j]; xqd[j][lane] = s.qd[j]; }
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xroot[i][lane] = s.root[i];
+    __syncthreads();                                     // (F) final state visible to the helper waves, which write the body states
+  }
   if (!valid) return;
   if (fault && l == 0) C->reset_buf[e] = 2;
 
@@ -520,36 +572,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     cl[6] = last.x; cl[7] = last.y; cl[8] = last.z;
     if (per_leg == 4) { cl[9] = fbody[4].x; cl[10] = fbody[4].y; cl[11] = fbody[4].z; }
   }
-  // ---- rigid-body state of the post-step configuration (LR:118-120 refresh_rigid_body_state_tensor)
-  {
-    const M3 Rb = quat_to_mat(s.root + 3);
-    const V3 pb = v3(s.root[0], s.root[1], s.root[2]), vb = v3(s.root[7], s.root[8], s.root[9]), wb = v3(s.root[10], s.root[11], s.root[12]);
-    LegKin k;
-    leg_kinematics(lm_, Rb, pb, vb, wb, s.q, s.qd, k);
-    float* rb = C->rigid + (size_t)e * B * 13;
-    if (l == 0) {
-#pragma unroll
-      for (int i = 0; i < 13; ++i) rb[i] = s.root[i];
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float* o = rb + (size_t)(1 + per_leg * l + j) * 13;
-      float qq[4]; mat_to_quat(k.R[j], qq);
-      o[0] = k.O[j].x; o[1] = k.O[j].y; o[2] = k.O[j].z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
-      o[7] = k.vO[j].x; o[8] = k.vO[j].y; o[9] = k.vO[j].z; o[10] = k.w[j].x; o[11] = k.w[j].y; o[12] = k.w[j].z;
-    }
-    if (per_leg == 4) {
-      float* o = rb + (size_t)(1 + per_leg * l + 3) * 13;
-      V3 r = mul(k.R[2], lm_.v(LM_FOOT_POS));
-      V3 p = k.O[2] + r, v = k.vO[2] + cross(k.w[2], r);
-      M3 fr;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) fr.m[i] = lm_.f(LM_FOOT_ROT + i);
-      float qq[4]; mat_to_quat(mul(k.R[2], fr), qq);
-      o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
-      o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = k.w[2].x; o[11] = k.w[2].y; o[12] = k.w[2].z;
-    }
-  }
+  // ---- rigid-body state of the post-step configuration (LR:118-120 refresh_rigid_body_state_tensor); with helper
+  // waves, they write it (one link each) from the published final state while this wave stores the rest
+  if (!helpers) write_rigid_body_state(C, lm_, e, l, s.root, s.q, s.qd);
   STAMP(10);
 }
 
