@@ -173,15 +173,17 @@ LG_DEV void symv6(const float* Si, const float* x, float* y) {
 struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t* __restrict__ H; MeshView M; };
 struct TerrainCell { float u, v; int16_t h0, h1, h2, h3; };
 LG_DEV TerrainCell terrain_fetch(const TerrainView& T, float x, float y) {
+  // branch-free on purpose (the plane reads its 1 x 1 dummy grid): a conditional around the loads would make the
+  // compiler wait for them at the end of the branch, and the point of the split is to leave them in flight
   TerrainCell c;
-  if (T.mesh_type == LG_MESH_PLANE) { c.u = 0.f; c.v = 0.f; c.h0 = c.h1 = c.h2 = c.h3 = 0; return c; }
-  const float ihs = frcp(T.hscale);
+  const float ihs = T.hscale > 0.f ? frcp(T.hscale) : 0.f;
   float fx = (x + T.border) * ihs, fy = (y + T.border) * ihs;
   int i = (int)floorf(fx), j = (int)floorf(fy);
   i = max(0, min(i, T.rows - 2)); j = max(0, min(j, T.cols - 2));
   c.u = fminf(fmaxf(fx - (float)i, 0.f), 1.f); c.v = fminf(fmaxf(fy - (float)j, 0.f), 1.f);
+  const int dc = T.cols > 1 ? 1 : 0, dr = T.rows > 1 ? T.cols : 0;
   const int16_t* r0 = T.H + (size_t)i * T.cols + j;
-  c.h0 = r0[0]; c.h1 = r0[1]; c.h2 = r0[T.cols]; c.h3 = r0[T.cols + 1];
+  c.h0 = r0[0]; c.h1 = r0[dc]; c.h2 = r0[dr]; c.h3 = r0[dr + dc];
   return c;
 }
 LG_DEV void terrain_eval(const TerrainView& T, const TerrainCell& c, float* h, V3* n) {
@@ -447,7 +449,9 @@ LG_DEV void fetch_mass_factors(const float* xs, int lane, float Mi[6], float Mbk
 // fbody[5] (optional) receives the net contact force on {base (already quad-summed), link0, link1, link2, foot}.
 // prep_fn(bk, Fs, Ns) returns true when helper waves have produced the leg bias and the contact detection (it then
 // holds the rendezvous and fills the three outputs); false means this wave computes them itself.
-template <bool TMESH, class TauFn, class PrepFn, class ShareFn>
+// With helper waves on a heightfield the contact detection is dealt two slots per wave; this wave takes slots
+// [0, MAIN_DETECT) before the rendezvous (0: the helpers, or the inline path, detect everything).
+template <bool TMESH, int MAIN_DETECT, class TauFn, class PrepFn, class ShareFn>
 LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel& lm_, const TerrainView& T, const PhysParams& P,
                             int lane, float* cst, QuadState& s, TauFn tau_fn, PrepFn prep_fn, ShareFn share_fn, SlotShare share,
                             float* xs, float mu_robot, float madd, V3* fbody, unsigned long long* stamps = nullptr) {
@@ -521,6 +525,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   STAMP(3);
   // ---------------------------------------------------------------- leg bias + contact detection: helper waves or inline
   float bk[3]; V3 Fs, Ns;
+  if (MAIN_DETECT > 0 && share.n > 1) contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
   if (!prep_fn(bk, Fs, Ns)) {
     leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);
     if (TMESH) contact_detect_mesh(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);

@@ -349,20 +349,23 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       LegKin k;
       leg_kinematics(lm_, Rb, pb, vb, wb, qq, qdd, k);
       STAMP(23);
-      // heightfield terrains: issue this wave's height-sample loads now, use them after the actuator network
-      ContactProbe<0, LG_MAX_CP / 2> pr2; ContactProbe<LG_MAX_CP / 2, LG_MAX_CP> pr3;
+      // heightfield terrains: two slots per wave (the main wave takes slots 0, 1); this wave issues its height-sample
+      // loads now and uses them after the actuator network
+      ContactProbe<2, 4> pr1; ContactProbe<4, 6> pr2; ContactProbe<6, 8> pr3;
+      static_assert(LG_MAX_CP == 8, "slot split assumes 8 contact slots");
       if (wv == 1) {
         float bk[3]; V3 Fs, Ns;
         leg_bias(lm_, k, pb, wb, qdd, P.grav, bk, Fs, Ns);
         xbias[0][lane] = bk[0]; xbias[1][lane] = bk[1]; xbias[2][lane] = bk[2];
         xbias[3][lane] = Fs.x; xbias[4][lane] = Fs.y; xbias[5][lane] = Fs.z;
         xbias[6][lane] = Ns.x; xbias[7][lane] = Ns.y; xbias[8][lane] = Ns.z;
+        if (!TMESH) contact_detect_begin<2, 4>(lm_, T, k, Rb, pb, pr1);
       } else if (TMESH) {
         contact_detect_mesh(wv == 2 ? 0 : LG_MAX_CP / 2, wv == 2 ? LG_MAX_CP / 2 : LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane, cqc, sub == 0);
       } else if (wv == 2) {
-        contact_detect_begin<0, LG_MAX_CP / 2>(lm_, T, k, Rb, pb, pr2);
+        contact_detect_begin<4, 6>(lm_, T, k, Rb, pb, pr2);
       } else {
-        contact_detect_begin<LG_MAX_CP / 2, LG_MAX_CP>(lm_, T, k, Rb, pb, pr3);
+        contact_detect_begin<6, 8>(lm_, T, k, Rb, pb, pr3);
       }
       STAMP(24);
       if (net) {
@@ -372,8 +375,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
         xtau[j][lane] = lstm_actuator1(wlstm + zero, x0, x1, h0, c0, h1, c1, g.actuator_out_scale);
       }
-      if (!TMESH && wv == 2) contact_detect_finish<0, LG_MAX_CP / 2>(lm_, T, P, pb, pr2, cst, lane);
-      else if (!TMESH && wv == 3) contact_detect_finish<LG_MAX_CP / 2, LG_MAX_CP>(lm_, T, P, pb, pr3, cst, lane);
+      if (!TMESH && wv == 1) contact_detect_finish<2, 4>(lm_, T, P, pb, pr1, cst, lane);
+      else if (!TMESH && wv == 2) contact_detect_finish<4, 6>(lm_, T, P, pb, pr2, cst, lane);
+      else if (!TMESH && wv == 3) contact_detect_finish<6, 8>(lm_, T, P, pb, pr3, cst, lane);
       STAMP(25);
       __syncthreads();                                   // (A2) bias, contact detection, torques | mass-matrix factors
       STAMP(26);
@@ -509,8 +513,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     };
     auto share_fn = [&]() { if (helpers) __syncthreads(); };   // (A3) every wave has finished its slots
     const SlotShare share{helpers ? 4 : 1, 0};
-    physics_substep<TMESH>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
-                           sub == nsub - 1 ? fbody : nullptr, stamps);
+    physics_substep<TMESH, TMESH ? 0 : 2>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
+                                          sub == nsub - 1 ? fbody : nullptr, stamps);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
