@@ -114,3 +114,13 @@ LG_DEV void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 LG_DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains every
+// outstanding global load and store (vmcnt(0)); the kernels here exchange data between waves through LDS alone, and
+// keeping gathers in flight across a barrier is how they overlap memory latency with the next stage.
+LG_DEV void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const lg_config& g = C->cfg;
   const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
   if (wv == 0) fill_leg_model(lmod, m, &C->cfg, lane);
-  __syncthreads();
+  lds_barrier();
   const LegModel lm_{lmod, l};
 
   if (MODE == 0 && wv > 0) {
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #endif
 #pragma unroll 1
     for (int sub = 0; sub < nsub; ++sub) {
-      __syncthreads();                                   // (A) main wave has published root, q, qd of this substep
+      lds_barrier();                                   // (A) main wave has published root, q, qd of this substep
       STAMP(22);
       // torque-independent share of the dynamics: this leg's kinematics, then the leg bias (wave 1) or the contact
       // detection of half of the slots (waves 2, 3), straight into the LDS the main wave reads after barrier (A2);
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       else if (!TMESH && wv == 2) contact_detect_finish<4, 6>(lm_, T, P, pb, pr2, cst, lane);
       else if (!TMESH && wv == 3) contact_detect_finish<6, 8>(lm_, T, P, pb, pr3, cst, lane);
       STAMP(25);
-      __syncthreads();                                   // (A2) bias, contact detection, torques | mass-matrix factors
+      lds_barrier();                                   // (A2) bias, contact detection, torques | mass-matrix factors
       STAMP(26);
       // this wave's share of the contact set-up (every fourth active slot)
       {
@@ -397,9 +397,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         }
       }
       STAMP(27);
-      __syncthreads();                                   // (A3) slot table complete
+      lds_barrier();                                   // (A3) slot table complete
     }
-    __syncthreads();                                     // (F) main wave has published the final state of the step
+    lds_barrier();                                     // (F) main wave has published the final state of the step
     if (valid) {                                         // wave w stores link w-1 of every leg (+ base / + foot body)
       float r13[13], qq[3], qdd[3];
 #pragma unroll
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       for (int j = 0; j < 3; ++j) { xq[j][lane] = s.q[j]; xqd[j][lane] = s.qd[j]; }
 #pragma unroll
       for (int i = 0; i < 13; ++i) xroot[i][lane] = s.root[i];
-      __syncthreads();                                   // (A) root, q, qd of this substep visible to the helper waves
+      lds_barrier();                                   // (A) root, q, qd of this substep visible to the helper waves
     }
     if (split) {
     } else if (MODE == 0) {
@@ -505,13 +505,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     };
     auto prep_fn = [&](float* bk, V3& Fs, V3& Ns) -> bool {
       if (!helpers) return false;
-      __syncthreads();                                   // (A2) helper waves have written the leg bias and the slot table
+      lds_barrier();                                   // (A2) helper waves have written the leg bias and the slot table
       bk[0] = xbias[0][lane]; bk[1] = xbias[1][lane]; bk[2] = xbias[2][lane];
       Fs = v3(xbias[3][lane], xbias[4][lane], xbias[5][lane]);
       Ns = v3(xbias[6][lane], xbias[7][lane], xbias[8][lane]);
       return true;
     };
-    auto share_fn = [&]() { if (helpers) __syncthreads(); };   // (A3) every wave has finished its slots
+    auto share_fn = [&]() { if (helpers) lds_barrier(); };   // (A3) every wave has finished its slots
     const SlotShare share{helpers ? 4 : 1, 0};
     physics_substep<TMESH, TMESH ? 0 : 2>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
                                           sub == nsub - 1 ? fbody : nullptr, stamps);
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     for (int j = 0; j < 3; ++j) { xq[j][lane] = s.q[j]; xqd[j][lane] = s.qd[j]; }
 #pragma unroll
     for (int i = 0; i < 13; ++i) xroot[i][lane] = s.root[i];
-    __syncthreads();                                     // (F) final state visible to the helper waves, which write the body states
+    lds_barrier();                                     // (F) final state visible to the helper waves, which write the body states
   }
   if (!valid) return;
   if (fault && l == 0) C->reset_buf[e] = 2;
@@ -624,7 +624,8 @@ LG_DEV void resample_commands(const DevCtx* __restrict__ C, float* cmd, const fl
 // LR:900-938 + math_utils.quat_apply_yaw: the index arithmetic must round exactly like the reference's separate
 // fp32 torch kernels, so contraction into FMAs is disabled for this function.
 #pragma clang fp contract(off)
-LG_DEV float terrain_height_at(const DevCtx* __restrict__ C, float qz, float qw, float px0, float py0, float bx, float by) {
+struct HeightProbe { int16_t h1, h2, h3; };
+LG_DEV HeightProbe terrain_height_probe(const DevCtx* __restrict__ C, float qz, float qw, float px0, float py0, float bx, float by) {
   float tx = (0.f - qz * by) * 2.f, ty = (qz * bx - 0.f) * 2.f;
   float rx = (bx + qw * tx) + (0.f - qz * ty);
   float ry = (by + qw * ty) + (qz * tx - 0.f);
@@ -633,9 +634,16 @@ LG_DEV float terrain_height_at(const DevCtx* __restrict__ C, float qz, float qw,
   int ix = (int)px, iy = (int)py;                       // trunc toward zero (tensor.long())
   ix = max(0, min(ix, C->ter.rows - 2)); iy = max(0, min(iy, C->ter.cols - 2));
   const int16_t* H = C->ter.H + (size_t)ix * C->ter.cols + iy;
-  int16_t h1 = H[0], h2 = H[C->ter.cols], h3 = H[1];
-  int16_t h = h1 < h2 ? h1 : h2; h = h < h3 ? h : h3;
+  const int dr = C->ter.rows > 1 ? C->ter.cols : 0, dc = C->ter.cols > 1 ? 1 : 0;    // plane: the 1 x 1 dummy grid
+  HeightProbe r; r.h1 = H[0]; r.h2 = H[dr]; r.h3 = H[dc];
+  return r;
+}
+LG_DEV float terrain_height_value(const DevCtx* __restrict__ C, const HeightProbe& r) {
+  int16_t h = r.h1 < r.h2 ? r.h1 : r.h2; h = h < r.h3 ? h : r.h3;
   return (float)h * C->ter.vscale;
+}
+LG_DEV float terrain_height_at(const DevCtx* __restrict__ C, float qz, float qw, float px0, float py0, float bx, float by) {
+  return terrain_height_value(C, terrain_height_probe(C, qz, qw, px0, py0, bx, by));
 }
 #pragma clang fp contract(fast)
 
@@ -818,11 +826,11 @@ LG_DEV void finalize_step(const DevCtx* __restrict__ C, int nblocks, int bump, i
         fl[i] = (b < cn && use_flags) ? ld_dev(C->part_flag + c0 + b) : (b < cn ? 1u : 0u);
         lv[i] = (b < cn && use_flags && want_lvl) ? ld_dev(C->lvl_part + c0 + b) : 0.f;
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int i = 0; i < FIN_CHUNK / 256; ++i) { f_flag[tid + 256 * i] = fl[i] ? 1 : 0; lvl_acc += lv[i]; }
     }
-    __syncthreads();
+    lds_barrier();
     if (wv == 0) {                       // ascending list of the workgroups of this chunk that hold a row
       int cnt = 0;
       for (int base = 0; base < cn; base += 64) {
@@ -834,23 +842,23 @@ LG_DEV void finalize_step(const DevCtx* __restrict__ C, int nblocks, int bump, i
       }
       if (lane == 0) f_n = cnt;
     }
-    __syncthreads();
+    lds_barrier();
     const int nl = f_n;
     for (int j0 = 0; j0 < nl; j0 += 8) {       // 8 rows per pass: loads in parallel, additions in row order
       const int j = j0 + (tid >> 5), c = tid & 31;
       f_buf[tid >> 5][c] = (j < nl && c < KP) ? ld_dev(C->partials + (size_t)f_list[j] * PART_STRIDE + c) : 0.f;
-      __syncthreads();
+      lds_barrier();
       if (tid < KP) { float sacc = tot[tid]; for (int jj = 0; jj < 8; ++jj) sacc += f_buf[jj][tid]; tot[tid] = sacc; }
-      __syncthreads();
+      lds_barrier();
     }
   }
-  __syncthreads();
+  lds_barrier();
   const float cnt = tot[K];
   if (cnt > 0.f && want_lvl) {            // mean terrain level over all envs (LR:205-206): only reported with a reset
     if (!use_flags) lvl_acc = tid == 0 ? ld_dev(C->partials + K + 1) : 0.f;
     f_lvl[tid] = lvl_acc;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if (tid < off) f_lvl[tid] += f_lvl[tid + off]; __syncthreads(); }
+    lds_barrier();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) f_lvl[tid] += f_lvl[tid + off]; lds_barrier(); }
   }
   if (cnt > 0.f) {
     if (tid < K) C->extras[tid] = tot[tid] / cnt / C->cfg.max_episode_length_s;
@@ -894,7 +902,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   const bool ro = mode == 1;
   __shared__ int s_e[EPBP];
   if (tid < EPBP) s_e[tid] = tid < nenv ? (ids ? ids[e0 + tid] : e0 + tid) : 0;
-  __syncthreads();
+  lds_barrier();
   const int P = g.measure_heights ? C->P : 0;
   const int64_t step = ro ? C->counters[3] + 1 : C->counters[0] + 1;   // LR:123 (finalize_kernel stores it)
   const uint32_t rstream = ro ? 2u : 0u;
@@ -904,6 +912,38 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   unsigned long long* stamps = (blockIdx.x == 0 && tid == 0) ? C->stamps : nullptr;
   unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
+
+  // ---- (1a) height scan from the post-physics root pose (LR:400-401).  Order of the memory traffic of this kernel's
+  // first stage: [scan inputs: base pose + scan points] -> [all staging loads] -> wait for the scan inputs only ->
+  // [height gathers] -> LDS stores of the staged rows -> barrier; the gathers are consumed after stage (2.1).
+  // No branch around any of these loads: lanes without a point, and the plane, read a valid dummy address (a
+  // conditional load makes the compiler drain the memory pipeline at the end of the branch).
+  static_assert(EPBP * MAX_P <= 4 * 256, "height scan assumes one pass of four points per lane");
+  const bool scan = P > 0 && !ro;
+  const bool plane = C->ter.mesh_type == LG_MESH_PLANE;
+  HeightProbe hp_[4]; int hel[4], hpi[4];
+  float rq[4][4], hxy[4][2];
+  {
+    const float* hpts = scan ? C->height_points : C->root;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + u * 256;
+      const bool ok = scan && idx < nenv * P;
+      const int el_ = ok ? idx / P : 0, p = ok ? idx - el_ * P : 0;
+      hel[u] = el_; hpi[u] = ok ? p : -1;
+      const float* rt = C->root + (size_t)s_e[el_] * 13;
+      rq[u][0] = rt[0]; rq[u][1] = rt[1]; rq[u][2] = rt[5]; rq[u][3] = rt[6];
+      hxy[u][0] = hpts[2 * p]; hxy[u][1] = hpts[2 * p + 1];
+    }
+  }
+  float h_keep[4] = {0.f, 0.f, 0.f, 0.f};     // rollout steps keep the heights measured by the last main step
+  if (P > 0 && ro) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + u * 256;
+      if (idx < nenv * P) { const int el_ = idx / P, p = idx - el_ * P; hel[u] = el_; hpi[u] = p; h_keep[u] = C->heights[(size_t)s_e[el_] * C->P + p]; }
+    }
+  }
 
   // ---- (0) stage this workgroup's env rows in LDS.  Every global load is issued before the first LDS store, so the
   // phase costs one memory latency instead of one per tensor.
@@ -925,10 +965,21 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   if (tid < nenv * g.num_reward_terms) { int k = tid / nenv, el_ = tid - k * nenv; v_sum = C->ep_sums[(size_t)k * C->N + s_e[el_]]; }
   uint8_t v_lc = 0; if (tid < nenv * 4) v_lc = C->last_contacts[(size_t)s_e[tid >> 2] * 4 + (tid & 3)];
   int64_t v_len = 0; uint8_t v_flag = 0; int64_t v_lvl = 0;
-  if (tid < nenv) { v_len = C->ep_len[s_e[tid]]; v_flag = C->reset_buf[s_e[tid]]; if (g.curriculum && !ro) v_lvl = C->levels[s_e[tid]]; }
+  {
+    const int e_ = s_e[tid < nenv ? tid : 0];
+    v_len = C->ep_len[e_]; v_flag = C->reset_buf[e_]; v_lvl = C->levels[e_];
+    if (!(g.curriculum && !ro)) v_lvl = 0;
+  }
   if (tid < nenv * (LG_RS_NOISE / 4)) {          // one Philox call per (env, slot group): 8 lanes per env
     int el_ = tid / (LG_RS_NOISE / 4), gq = tid - el_ * (LG_RS_NOISE / 4);
     uniform_draw4(C, s_e[el_], gq, step, rstream, &s_u[el_][4 * gq]);
+  }
+  // (1a, continued) the scan inputs are here: issue the height gathers
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float qz = rq[u][2], qw = rq[u][3];
+    const float nrm = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
+    hp_[u] = terrain_height_probe(C, qz / nrm, qw / nrm, rq[u][0], rq[u][1], hxy[u][0], hxy[u][1]);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -944,39 +995,8 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   if (tid < nenv * g.num_reward_terms) { int k = tid / nenv, el_ = tid - k * nenv; s_env[el_][S_SUMS + k] = v_sum; }
   if (tid < nenv * 4) s_lastc[tid >> 2][tid & 3] = v_lc;
   if (tid < nenv) { s_eplen[tid] = v_len; s_flag[tid] = v_flag; s_level[tid] = (float)v_lvl; }
-  __syncthreads();
+  lds_barrier();
   STAMP(11);
-
-  // ---- (1) height scan from the post-physics root pose (LR:400-401), all lanes, row-contiguous stores
-  if (P > 0 && ro) {      // rollout steps keep the heights measured by the last main step (callback_rollout is a no-op)
-    for (int idx = tid; idx < nenv * P; idx += 256) { int el = idx / P, p = idx - el * P; s_h[el][p] = C->heights[(size_t)s_e[el] * C->P + p]; }
-  } else if (P > 0) {
-    const bool plane = C->ter.mesh_type == LG_MESH_PLANE;
-    for (int base = tid; base < nenv * P; base += 4 * 256) {
-      float hgt[4]; int els[4], ps[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {          // four independent gathers in flight per lane
-        int idx = base + u * 256;
-        bool ok = idx < nenv * P;
-        int el = ok ? idx / P : 0, p = ok ? idx - el * P : 0;
-        els[u] = el; ps[u] = ok ? p : -1;
-        hgt[u] = 0.f;
-        if (ok && !plane) {
-          const float* root = s_env[el] + S_ROOT;
-          float qz = root[5], qw = root[6];
-          float nrm = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
-          hgt[u] = terrain_height_at(C, qz / nrm, qw / nrm, root[0], root[1], C->height_points[2 * p], C->height_points[2 * p + 1]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) if (ps[u] >= 0) {
-        s_h[els[u]][ps[u]] = hgt[u];
-        C->heights[(size_t)s_e[els[u]] * C->P + ps[u]] = hgt[u];
-      }
-    }
-  }
-  __syncthreads();
-  STAMP(12);
 
   // ---- (2) one wave per env.  The reference's order of side effects is kept by stages separated by barriers:
   //   (2.1) base-frame velocities / accelerations / gravity (five rotations on five lanes), per-DOF reward features
@@ -1036,7 +1056,14 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     const float* cf = V.cf + 3 * (ln - 32);
     s_fn[el][ln - 32] = sqrtf(cf[0] * cf[0] + cf[1] * cf[1] + cf[2] * cf[2]);
   }
-  __syncthreads();
+  // (1b) the height samples have arrived by now: rows into LDS (and to the measured_heights tensor on main steps)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) if (hpi[u] >= 0) {
+    const float hv = ro ? h_keep[u] : (plane ? 0.f : terrain_height_value(C, hp_[u]));
+    s_h[hel[u]][hpi[u]] = hv;
+    if (!ro) C->heights[(size_t)s_e[hel[u]] * C->P + hpi[u]] = hv;
+  }
+  lds_barrier();
   STAMP(19);
 
   // (2.2)
@@ -1078,7 +1105,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     s_eplen[el] = eplen;
     C->ep_len[e] = eplen;
   }
-  __syncthreads();
+  lds_barrier();
   STAMP(20);
 
   // (2.3a) the one stateful term: _reward_feet_air_time rewrites air / contact times and last_contacts (RM:150-163).
@@ -1088,7 +1115,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     for (int f = 0; f < 4; ++f) { s_old[el][f] = V.air[f]; s_old[el][4 + f] = V.ctime[f]; s_oldc[el][f] = V.lastc[f]; }
     s_rk[el][kfat] = reward_term(C, V, e, LG_REW_FEET_AIR_TIME, s_fsum[el], s_fn[el], s_bh[el], step) * g.reward_scales[kfat];
   }
-  __syncthreads();
+  lds_barrier();
   // (2.3b) every other term on its own lane (they only read)
   if (have && ln < g.num_reward_terms && ln != kfat) {
     const int id = g.reward_term_ids[ln];
@@ -1096,7 +1123,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     if (ln < kfat && kfat < g.num_reward_terms) { Vk.air = s_old[el]; Vk.ctime = s_old[el] + 4; Vk.lastc = s_oldc[el]; }
     s_rk[el][ln] = id != LG_REW_TERMINATION ? reward_term(C, Vk, e, id, s_fsum[el], s_fn[el], s_bh[el], step) * g.reward_scales[ln] : 0.f;
   }
-  __syncthreads();
+  lds_barrier();
   STAMP(21);
   // (2.3c) total in config order, clip, termination term, reset (LR:215-232, 144-145)
   if (have && ln == 0) {
@@ -1114,7 +1141,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     s_rootz[el] = root[2];
     s_did_reset[el] = do_reset ? 1 : 0;
   }
-  __syncthreads();
+  lds_barrier();
 
   // (2.4) proprioceptive part of the observation (LR:237-244), from the post-reset state; gait scheduler (anymal.py:107-110)
   if (have && ln < 48) {
@@ -1143,7 +1170,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     else if (ln == K_ + 1) s_part[el][K_ + 1] = s_level[el];
     else if (ln == K_ + 2) s_part[el][K_ + 2] = do_reset ? (float)s_eplen[el] : 0.f;
   }
-  __syncthreads();
+  lds_barrier();
   STAMP(13);
 
   // ---- (2b) cooperative write-back of everything phase (2) produced or changed; history buffers (LR:148-150)
@@ -1248,7 +1275,7 @@ __global__ __launch_bounds__(256) void reset_idx_kernel(const DevCtx* __restrict
     for (int i = 0; i < n; ++i) s += (float)C->ep_len[ids[i]];
     C->partials[K + 2] = s;
   }
-  __syncthreads();
+  __syncthreads();   // global data crosses these barriers
   for (int i = tid; i < n; i += 256) {
     const EnvView V = global_view(C, ids[i]);
     float U[LG_RS_NOISE];
@@ -1256,7 +1283,7 @@ __global__ __launch_bounds__(256) void reset_idx_kernel(const DevCtx* __restrict
     for (int gq = 0; gq < LG_RS_NOISE / 4; ++gq) uniform_draw4(C, ids[i], gq, step, 1, U + 4 * gq);
     reset_env(C, V, ids[i], update_curriculum, U, true);
   }
-  __syncthreads();
+  __syncthreads();   // global data crosses these barriers
   __threadfence_block();
   if (tid < K) {
     float s = 0.f;
