@@ -34,7 +34,7 @@ TENSOR_NAMES = [
     "feet_air_time", "feet_contact_time", "last_contacts", "measured_heights", "obs_buf", "rew_buf", "reset_buf",
     "time_out_buf", "episode_length_buf", "episode_sums", "terrain_levels", "terrain_types", "env_origins",
     "friction_coeffs", "base_mass_added", "sea_hidden_state", "sea_cell_state", "gait_idx", "gait_foot_z",
-    "extras_episode", "rand_inject", "step_counters", "height_samples", "terrain_origins", "episode_stats"]
+    "extras_episode", "rand_inject", "step_counters", "height_samples", "terrain_origins", "episode_stats", "command_ranges"]
 TENSOR_ID = {n: i for i, n in enumerate(TENSOR_NAMES)}
 LG_T_COUNT = len(TENSOR_NAMES)
 
@@ -83,6 +83,7 @@ class lg_config(C.Structure):
         ("noise_scale_vec", C.POINTER(f32)), ("height_points", C.POINTER(f32)),
         ("heading_command", i32), ("resampling_steps", i32),
         ("cmd_lin_vel_x", f32 * 2), ("cmd_lin_vel_y", f32 * 2), ("cmd_ang_vel_yaw", f32 * 2), ("cmd_heading", f32 * 2),
+        ("command_curriculum", i32), ("max_curriculum", f32),
         ("push_robots", i32), ("push_interval", i32), ("max_push_vel_xy", f32),
         ("num_reward_terms", i32), ("reward_term_ids", i32 * LG_MAX_REWARD_TERMS),
         ("reward_scales", f32 * LG_MAX_REWARD_TERMS), ("only_positive_rewards", i32),
@@ -121,6 +122,8 @@ def declare_product(lib):
     lib.lg_step_physics.restype = C.c_int
     lib.lg_step_subset.argtypes = [vp, vp, vp, i32, i32, vp]
     lib.lg_step_subset.restype = C.c_int
+    lib.lg_set_reward_terms.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(f32), vp]
+    lib.lg_set_reward_terms.restype = C.c_int
     lib.lg_step_subset_physics.argtypes = [vp, vp, vp, i32, vp]
     lib.lg_step_subset_physics.restype = C.c_int
     lib.lg_post_physics_subset.argtypes = [vp, vp, i32, i32, vp]
@@ -172,4 +175,4 @@ PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
                    "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_last_error",
                    "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update",
-                   "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update"]
+                   "lg_set_reward_terms", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update"]

@@ -42,6 +42,7 @@ struct DevCtx {
   int64_t *levels, *types;
   float *origins, *friction, *mass_added, *sea_h, *sea_c, *gait_idx, *gait_foot_z, *extras, *rand_inject;
   int64_t* counters;
+  float* cmd_ranges;   // LG_T_COMMAND_RANGES (4,2)
   double* ep_stats;
   const float* terrain_origins;
   const float *noise_vec, *height_points;
@@ -612,11 +613,12 @@ LG_DEV EnvView global_view(const DevCtx* __restrict__ C, int e) {
 // `U` = this env's uniforms for slots 0 .. LG_RS_NOISE-1 (drawn up front, one Philox call per group of four)
 LG_DEV void resample_commands(const DevCtx* __restrict__ C, float* cmd, const float* U, int slot0) {  // LR:405-423
   const lg_config& g = C->cfg;
-  float c0 = rand_float(g.cmd_lin_vel_x[0], g.cmd_lin_vel_x[1], U[slot0]);
-  float c1 = rand_float(g.cmd_lin_vel_y[0], g.cmd_lin_vel_y[1], U[slot0 + 1]);
+  const float* R = C->cmd_ranges;   // rows lin_vel_x, lin_vel_y, ang_vel_yaw, heading
+  float c0 = rand_float(R[0], R[1], U[slot0]);
+  float c1 = rand_float(R[2], R[3], U[slot0 + 1]);
   float u2 = U[slot0 + 2];
-  if (g.heading_command) cmd[3] = rand_float(g.cmd_heading[0], g.cmd_heading[1], u2);
-  else cmd[2] = rand_float(g.cmd_ang_vel_yaw[0], g.cmd_ang_vel_yaw[1], u2);
+  if (g.heading_command) cmd[3] = rand_float(R[6], R[7], u2);
+  else cmd[2] = rand_float(R[4], R[5], u2);
   float keep = sqrtf(c0 * c0 + c1 * c1) > 0.2f ? 1.f : 0.f;
   cmd[0] = c0 * keep; cmd[1] = c1 * keep;
 }
@@ -863,6 +865,20 @@ LG_DEV void finalize_step(const DevCtx* __restrict__ C, int nblocks, int bump, i
   if (cnt > 0.f) {
     if (tid < K) C->extras[tid] = tot[tid] / cnt / C->cfg.max_episode_length_s;
     if (tid == K && C->cfg.curriculum) C->extras[K] = f_lvl[0] / (float)C->N;
+  }
+  if (tid == 0 && cnt > 0.f && C->cfg.command_curriculum) {
+    // update_command_curriculum (LR:520-533), gated like LR:178: every max_episode_length steps, from the mean
+    // tracking_lin_vel episode sum of the envs reset in this step.  The widened range serves every later draw (the
+    // reference applies it already to the commands of those same envs: their reset runs before this statistics step).
+    const lg_config& g = C->cfg;
+    const int64_t common = C->counters[0] + (bump == 1 ? 1 : 0);
+    int kt = -1;
+    for (int k = 0; k < K; ++k) if (g.reward_term_ids[k] == LG_REW_TRACKING_LIN_VEL) kt = k;
+    if (kt >= 0 && common % (int64_t)g.max_episode_length == 0 &&
+        tot[kt] / cnt / g.max_episode_length > 0.8f * g.reward_scales[kt]) {
+      C->cmd_ranges[0] = fminf(fmaxf(C->cmd_ranges[0] - 0.5f, -g.max_curriculum), 0.f);
+      C->cmd_ranges[1] = fminf(fmaxf(C->cmd_ranges[1] + 0.5f, 0.f), g.max_curriculum);
+    }
   }
   if (tid == 0) {
     if (bump == 1) C->counters[0] += 1; else if (bump == 0) C->counters[2] += 1;
@@ -1302,7 +1318,7 @@ __global__ __launch_bounds__(256) void reset_idx_kernel(const DevCtx* __restrict
 static size_t dtype_size(int d) { return d == LG_F32 ? 4 : (d == LG_I64 || d == LG_F64) ? 8 : d == LG_U8 ? 1 : d == LG_I16 ? 2 : 4; }
 
 static size_t build_layout(const lg_config* cfg, const lg_robot_model* model, const lg_terrain* ter, TensorInfo* t) {
-  const int64_t N = cfg->num_envs, B = model->num_bodies, K = cfg->num_reward_terms, P = cfg->num_height_points, O = cfg->num_obs;
+  const int64_t N = cfg->num_envs, B = model->num_bodies, P = cfg->num_height_points, O = cfg->num_obs;
   auto set = [&](int id, int dtype, std::initializer_list<int64_t> shp) {
     TensorInfo& T = t[id]; T.dtype = dtype; T.ndim = (int)shp.size(); int i = 0;
     for (auto s : shp) T.shape[i++] = s;
@@ -1317,15 +1333,16 @@ static size_t build_layout(const lg_config* cfg, const lg_robot_model* model, co
   set(LG_T_FEET_AIR_TIME, LG_F32, {N, 4}); set(LG_T_FEET_CONTACT_TIME, LG_F32, {N, 4}); set(LG_T_LAST_CONTACTS, LG_U8, {N, 4});
   set(LG_T_MEASURED_HEIGHTS, LG_F32, {N, P > 0 ? P : 1}); set(LG_T_OBS_BUF, LG_F32, {N, O}); set(LG_T_REW_BUF, LG_F32, {N});
   set(LG_T_RESET_BUF, LG_U8, {N}); set(LG_T_TIME_OUT_BUF, LG_U8, {N}); set(LG_T_EPISODE_LENGTH_BUF, LG_I64, {N});
-  set(LG_T_EPISODE_SUMS, LG_F32, {K > 0 ? K : 1, N}); set(LG_T_TERRAIN_LEVELS, LG_I64, {N}); set(LG_T_TERRAIN_TYPES, LG_I64, {N});
+  set(LG_T_EPISODE_SUMS, LG_F32, {LG_MAX_REWARD_TERMS, N}); set(LG_T_TERRAIN_LEVELS, LG_I64, {N}); set(LG_T_TERRAIN_TYPES, LG_I64, {N});
   set(LG_T_ENV_ORIGINS, LG_F32, {N, 3}); set(LG_T_FRICTION_COEFFS, LG_F32, {N}); set(LG_T_BASE_MASS_ADDED, LG_F32, {N});
   set(LG_T_SEA_HIDDEN_STATE, LG_F32, {2, N * 12, 8}); set(LG_T_SEA_CELL_STATE, LG_F32, {2, N * 12, 8});
-  set(LG_T_GAIT_IDX, LG_F32, {N}); set(LG_T_GAIT_FOOT_Z, LG_F32, {N, 4}); set(LG_T_EXTRAS_EPISODE, LG_F32, {K + 1});
+  set(LG_T_GAIT_IDX, LG_F32, {N}); set(LG_T_GAIT_FOOT_Z, LG_F32, {N, 4}); set(LG_T_EXTRAS_EPISODE, LG_F32, {LG_MAX_REWARD_TERMS + 1});
   set(LG_T_RAND_INJECT, LG_F32, {N, LG_RS_NOISE + O}); set(LG_T_STEP_COUNTERS, LG_I64, {4});
   int64_t r = ter->rows > 0 ? ter->rows : 1, cc = ter->cols > 0 ? ter->cols : 1;
   set(LG_T_HEIGHT_SAMPLES, LG_I16, {r, cc});
   set(LG_T_TERRAIN_ORIGINS, LG_F32, {ter->num_levels > 0 ? ter->num_levels : 1, ter->num_types > 0 ? ter->num_types : 1, 3});
   set(LG_T_EPISODE_STATS, LG_F64, {4});
+  set(LG_T_COMMAND_RANGES, LG_F32, {4, 2});
   size_t off = 0;
   for (int i = 0; i < LG_T_COUNT; ++i) {
     TensorInfo& T = t[i]; size_t n = dtype_size(T.dtype);
@@ -1429,7 +1446,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.origins = (float*)P(LG_T_ENV_ORIGINS); h.friction = (float*)P(LG_T_FRICTION_COEFFS); h.mass_added = (float*)P(LG_T_BASE_MASS_ADDED);
   h.sea_h = (float*)P(LG_T_SEA_HIDDEN_STATE); h.sea_c = (float*)P(LG_T_SEA_CELL_STATE); h.gait_idx = (float*)P(LG_T_GAIT_IDX);
   h.gait_foot_z = (float*)P(LG_T_GAIT_FOOT_Z); h.extras = (float*)P(LG_T_EXTRAS_EPISODE); h.rand_inject = (float*)P(LG_T_RAND_INJECT);
-  h.counters = (int64_t*)P(LG_T_STEP_COUNTERS); h.ep_stats = (double*)P(LG_T_EPISODE_STATS); h.terrain_origins = (const float*)P(LG_T_TERRAIN_ORIGINS);
+  h.counters = (int64_t*)P(LG_T_STEP_COUNTERS); h.cmd_ranges = (float*)P(LG_T_COMMAND_RANGES); h.ep_stats = (double*)P(LG_T_EPISODE_STATS); h.terrain_origins = (const float*)P(LG_T_TERRAIN_ORIGINS);
   h.ter.mesh_type = ter->mesh_type; h.ter.rows = ter->rows; h.ter.cols = ter->cols;
   h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
   h.ter.H = (const int16_t*)P(LG_T_HEIGHT_SAMPLES);
@@ -1463,6 +1480,11 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   if (ter->num_levels > 0 && ter->terrain_origins &&
       hipMemcpy(P(LG_T_TERRAIN_ORIGINS), ter->terrain_origins, (size_t)ter->num_levels * ter->num_types * 12, hipMemcpyHostToDevice) != hipSuccess)
     return fail("copy terrain_origins failed");
+  {
+    float cr[8] = {cfg->cmd_lin_vel_x[0], cfg->cmd_lin_vel_x[1], cfg->cmd_lin_vel_y[0], cfg->cmd_lin_vel_y[1],
+                   cfg->cmd_ang_vel_yaw[0], cfg->cmd_ang_vel_yaw[1], cfg->cmd_heading[0], cfg->cmd_heading[1]};
+    if (hipMemcpy(P(LG_T_COMMAND_RANGES), cr, sizeof(cr), hipMemcpyHostToDevice) != hipSuccess) return fail("copy command ranges failed");
+  }
   // initial values: identity base quaternion, reset_buf = 1 (base_task.py:73)
   {
     std::vector<float> root((size_t)h.N * 13, 0.f);
@@ -1531,6 +1553,22 @@ int lg_step_subset(lg_ctx* c, const float* actions, const int32_t* env_ids, int3
   hipStream_t st = (hipStream_t)stream;
   launch_physics(c, st, actions, env_ids, n);
   return launch_post(c, st, nullptr, env_ids, n, rollout_mode ? 1 : 0);
+}
+
+int lg_set_reward_terms(lg_ctx* c, int32_t num_terms, const int32_t* term_ids, const float* scales, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (num_terms < 0 || num_terms > LG_MAX_REWARD_TERMS || (num_terms > 0 && (!term_ids || !scales))) { c->err = "bad reward term list"; return LG_ERR_INVALID; }
+  for (int k = 0; k < num_terms; ++k) if (term_ids[k] < 0 || term_ids[k] >= LG_REW_COUNT) { c->err = "unknown reward term id"; return LG_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  lg_config& g = c->h.cfg;
+  g.num_reward_terms = num_terms; c->h.K = num_terms;
+  for (int k = 0; k < LG_MAX_REWARD_TERMS; ++k) { g.reward_term_ids[k] = k < num_terms ? term_ids[k] : 0; g.reward_scales[k] = k < num_terms ? scales[k] : 0.f; }
+  // the three fields are adjacent in lg_config: one stream-ordered copy of that span of the device context
+  char* base = (char*)&c->h; char* lo = (char*)&g.num_reward_terms; char* hi = (char*)&g.reward_scales[LG_MAX_REWARD_TERMS];
+  HIP_TRY(c, hipMemcpyAsync((char*)c->d + (lo - base), lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync((char*)c->d + ((char*)&c->h.K - base), &c->h.K, sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemsetAsync(c->h.ep_sums, 0, (size_t)LG_MAX_REWARD_TERMS * c->h.N * sizeof(float), st));
+  return LG_OK;
 }
 
 int lg_step_subset_physics(lg_ctx* c, const float* actions, const int32_t* env_ids, int32_t n, void* stream) {

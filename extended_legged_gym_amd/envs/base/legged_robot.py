@@ -20,7 +20,28 @@ from extended_legged_gym_amd.utils.terrain_obj import TerrainObj
 from extended_legged_gym_amd.utils.terrain_confine import TerrainConfined
 from .base_task import BaseTask
 from .legged_robot_config import LeggedRobotCfg
-from .native_config import NativeSetup, load_robot_model
+from .native_config import NativeSetup, load_robot_model, reward_setup
+
+
+class CommandRanges:
+    """`env.command_ranges` (`legged_robot.py:853`): name -> [min, max], backed by the device tensor the kernels draw
+    commands from (`LG_T_COMMAND_RANGES`), so host edits take effect and the command curriculum's widening is visible."""
+    ROWS = {"lin_vel_x": 0, "lin_vel_y": 1, "ang_vel_yaw": 2, "heading": 3}
+
+    def __init__(self, tensor):
+        self._t = tensor
+
+    def __getitem__(self, name):
+        return self._t[self.ROWS[name]].tolist()
+
+    def __setitem__(self, name, value):
+        self._t[self.ROWS[name]] = torch.as_tensor(value, dtype=torch.float32, device=self._t.device)
+
+    def keys(self):
+        return self.ROWS.keys()
+
+    def __contains__(self, name):
+        return name in self.ROWS
 
 
 class LeggedRobot(BaseTask):
@@ -211,8 +232,17 @@ class LeggedRobot(BaseTask):
         return scales
 
     def update_reward_scales(self, mean_reward):
-        if self.cfg.rewards.multi_stage_rewards:
-            raise NotImplementedError("multi-stage reward scales are not re-uploaded to the native step yet")
+        """Next reward stage once the mean reward passes the threshold (`legged_robot_rew_mixin.py:31-38`): the new
+        term list goes to the native step (`lg_set_reward_terms`), which also restarts the episode sums like
+        `_prepare_reward_function` does by re-creating them."""
+        r = self.cfg.rewards
+        if r.multi_stage_rewards and mean_reward > r.reward_stage_threshold and self.reward_scales_stage < r.reward_max_stage:
+            self.reward_scales_stage += 1
+            names, vals = reward_setup(self.cfg, self.dt, self.reward_scales_stage)
+            self.setup.reward_names, self.setup.reward_scales = names, vals
+            self.core.set_reward_terms([abi.REWARD_TERM_ID[n] for n in names], vals)
+            self._prepare_reward_function()
+            return True
         return False
 
     def _init_buffers(self):
@@ -228,6 +258,7 @@ class LeggedRobot(BaseTask):
         self.contact_forces = t["contact_forces"]
         self.rigid_body_state = t["rigid_body_state"].view(N * self.num_bodies, 13)
         self.common_step_counter = 0
+        self.command_ranges = CommandRanges(t["command_ranges"])
         self.extras = {}
         self.noise_scale_vec = torch.from_numpy(self.setup.noise_scale_vec).to(self.device)
         self.add_noise = self.cfg.noise.add_noise
@@ -276,7 +307,9 @@ class LeggedRobot(BaseTask):
         if self.cfg.terrain.curriculum:
             episode["terrain_level"] = ex[len(names)]
         if self.cfg.commands.curriculum:
-            episode["max_command_x"] = self.command_ranges["lin_vel_x"][1]
+            episode["max_command_x"] = self.core.t["command_ranges"][0, 1]      # 0-d view, widened in place by the kernel
+        if self.cfg.rewards.multi_stage_rewards:
+            episode["reward_stage"] = float(self.reward_scales_stage)
         self.extras["episode"] = episode
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf

@@ -189,6 +189,8 @@ class NativeSetup:
         _fill(c.cmd_lin_vel_y, rng.lin_vel_y)
         _fill(c.cmd_ang_vel_yaw, rng.ang_vel_yaw)
         _fill(c.cmd_heading, rng.heading)
+        c.command_curriculum = int(bool(getattr(cfg.commands, "curriculum", False)))
+        c.max_curriculum = float(getattr(cfg.commands, "max_curriculum", 1.0))
 
         # domain randomisation
         c.push_robots = int(cfg.domain_rand.push_robots)

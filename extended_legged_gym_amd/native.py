@@ -109,6 +109,13 @@ class NativeCore:
         a = self._f32(actions)
         self._check(self.lib.lg_step_physics(self.ctx, C.c_void_p(a.data_ptr()), self._stream()))
 
+    def set_reward_terms(self, term_ids, scales):
+        """New active reward terms (evaluation order, dt-scaled scales); zeroes every episode sum."""
+        n = len(term_ids)
+        ids = (C.c_int32 * max(n, 1))(*[int(i) for i in term_ids])
+        sc = (C.c_float * max(n, 1))(*[float(x) for x in scales])
+        self._check(self.lib.lg_set_reward_terms(self.ctx, n, ids, sc, self._stream()))
+
     def step_subset_physics(self, actions, env_ids_i32):
         a = self._f32(actions)
         self._check(self.lib.lg_step_subset_physics(self.ctx, C.c_void_p(a.data_ptr()), C.c_void_p(env_ids_i32.data_ptr()),

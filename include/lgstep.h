@@ -112,7 +112,7 @@ enum lg_tensor_id {
   LG_T_RESET_BUF,           /* (N) u8                                                                  */
   LG_T_TIME_OUT_BUF,        /* (N) u8                                                                  */
   LG_T_EPISODE_LENGTH_BUF,  /* (N) i64                                                                 */
-  LG_T_EPISODE_SUMS,        /* (K,N) f32, row k = episode_sums[reward_names[k]]                        */
+  LG_T_EPISODE_SUMS,        /* (LG_MAX_REWARD_TERMS,N) f32, row k < K = episode_sums[reward_names[k]]   */
   LG_T_TERRAIN_LEVELS,      /* (N) i64                                                                 */
   LG_T_TERRAIN_TYPES,       /* (N) i64                                                                 */
   LG_T_ENV_ORIGINS,         /* (N,3) f32                                                               */
@@ -122,8 +122,8 @@ enum lg_tensor_id {
   LG_T_SEA_CELL_STATE,      /* (2,N*12,8) f32 (anymal.py:89)                                           */
   LG_T_GAIT_IDX,            /* (N) f32 (gait_scheduler.py:60)                                          */
   LG_T_GAIT_FOOT_Z,         /* (N,4) f32 foot heights handed to GaitScheduler.step by the previous step (gait_scheduler.py:71) */
-  LG_T_EXTRAS_EPISODE,      /* (K+1) f32: mean episode sum / max_episode_length_s per reward term over the
-                               envs reset in the most recent step that reset any (:200-203); [K] = mean terrain level */
+  LG_T_EXTRAS_EPISODE,      /* (LG_MAX_REWARD_TERMS+1) f32: [k < K] mean episode sum / max_episode_length_s per reward term
+                               over the envs reset in the most recent step that reset any (:200-203); [K] = mean terrain level */
   LG_T_RAND_INJECT,         /* (N, LG_RS_NOISE+num_obs) f32, only read when rng_mode == LG_RNG_INJECT   */
   LG_T_STEP_COUNTERS,       /* (4) i64: [0] common_step_counter, [1] #envs reset by the last step       */
   LG_T_HEIGHT_SAMPLES,      /* (rows, cols) i16, read-only terrain grid                                */
@@ -131,6 +131,9 @@ enum lg_tensor_id {
   LG_T_EPISODE_STATS,       /* (4) f64 running totals since lg_create: sum of finished-episode returns, sum of their
                                lengths, #finished episodes, #env-steps — what a rank contributes to the cross-GPU
                                all-gather of episode statistics                                         */
+  LG_T_COMMAND_RANGES,      /* (4,2) f32 [lin_vel_x, lin_vel_y, ang_vel_yaw, heading] x [min, max]: the ranges commands
+                               are drawn from (:405-423); starts as lg_config.cmd_*, widened in place by the command
+                               curriculum (:520-533), writable by the host                               */
   LG_T_COUNT
 };
 
@@ -194,7 +197,9 @@ typedef struct lg_config {
   const float* height_points;         /* HOST, num_height_points x 2 (x, y) base-frame scan grid (:884-898) */
   /* commands (:405-423) */
   int32_t heading_command, resampling_steps;
-  float cmd_lin_vel_x[2], cmd_lin_vel_y[2], cmd_ang_vel_yaw[2], cmd_heading[2];
+  float cmd_lin_vel_x[2], cmd_lin_vel_y[2], cmd_ang_vel_yaw[2], cmd_heading[2];   /* initial LG_T_COMMAND_RANGES */
+  int32_t command_curriculum;         /* commands.curriculum (:178-179, :520-533) */
+  float max_curriculum;               /* commands.max_curriculum */
   /* domain randomisation (:491-496) */
   int32_t push_robots, push_interval; float max_push_vel_xy;
   /* rewards (:215-232, :649-674) — terms in evaluation order, scales already multiplied by dt */
@@ -248,6 +253,11 @@ int lg_step_physics(lg_ctx* ctx, const float* actions, void* stream);
  * no command resampling / pushes / termination / reset, rewards computed but not added to the episode sums, the other
  * envs are not touched (the reference simulates and then restores them, :687, :1585-1640). */
 int lg_step_subset(lg_ctx* ctx, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream);
+
+/* Multi-stage rewards (legged_robot_rew_mixin.py:15-38: update_reward_scales -> _prepare_reward_function): replace the
+ * active reward terms (evaluation order, scales already multiplied by dt, num_terms <= LG_MAX_REWARD_TERMS; HOST
+ * pointers) and zero every episode sum, as re-creating `episode_sums` does (:672-674).  Stream-ordered. */
+int lg_set_reward_terms(lg_ctx* ctx, int32_t num_terms, const int32_t* term_ids, const float* scales, void* stream);
 
 /* The two halves of lg_step_subset, so that sensor kernels (ray caster, body SDF) can run on the post-physics, pre-reset state
  * in between (RobotBatchRolloutPercept._post_physics_step_callback, robot_batch_rollout_percept.py:301-331). */

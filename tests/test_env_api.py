@@ -76,3 +76,30 @@ def test_rough_env_heights_curriculum_and_sharding_layout():
     assert torch.allclose(q, q.round(), atol=1e-3)
     st = env.core.t["episode_stats"].cpu().numpy()
     assert st[3] == 256 * 301 and st[2] > 0 and st[1] > 0
+
+
+def test_update_reward_scales_and_command_ranges_on_the_env():
+    """`env.update_reward_scales(mean)` / `env.reward_scales_stage` as rsl_rl calls them (on_policy_runner.py:470-475),
+    and `env.command_ranges` as a live view of what the kernels draw from."""
+    env = make("anymal_c_flat", 32, **{"rewards.multi_stage_rewards": True, "rewards.reward_max_stage": 1,
+                                       "rewards.reward_stage_threshold": 1.0, "rewards.scales.dof_vel": [0.0, -0.01],
+                                       "rewards.scales.torques": [-0.00001, -0.0001]})
+    env.reset()
+    assert env.reward_scales_stage == 0 and "dof_vel" not in env.episode_sums
+    for _ in range(3):
+        env.step(torch.zeros(32, 12, device=env.device))
+    assert not env.update_reward_scales(0.5) and env.reward_scales_stage == 0            # below the threshold
+    assert env.update_reward_scales(2.0) and env.reward_scales_stage == 1
+    assert "dof_vel" in env.episode_sums and abs(env.reward_scales["torques"] - (-0.0001 * env.dt)) < 1e-12
+    assert all(float(v.abs().sum()) == 0.0 for v in env.episode_sums.values())             # sums restart
+    env.step(torch.randn(32, 12, device=env.device))
+    assert float(env.episode_sums["dof_vel"].abs().sum()) > 0
+    assert not env.update_reward_scales(100.0)                                             # already at the last stage
+    assert env.extras["episode"]["reward_stage"] == 1.0
+    # command ranges: host edits reach the kernel
+    assert env.command_ranges["lin_vel_x"] == [-1.0, 1.0]
+    env.command_ranges["lin_vel_x"] = [2.0, 2.0]
+    env.command_ranges["lin_vel_y"] = [0.0, 0.0]
+    env.reset_idx(torch.arange(32, device=env.device))
+    torch.cuda.synchronize()
+    assert torch.allclose(env.commands[:, 0], torch.full((32,), 2.0, device=env.device))

@@ -112,3 +112,41 @@ def test_philox_streams_match():
     for name in ["root_states", "dof_state", "commands"]:
         np.testing.assert_allclose(core.t[name].cpu().numpy(), o.t[name], rtol=3e-7, atol=1e-7, err_msg=name)
     core.close(); o.close()
+
+
+def test_reward_stage_switch_and_command_curriculum_match_oracle():
+    """lg_set_reward_terms (multi-stage rewards) and the in-kernel command curriculum against the oracle."""
+    from extended_legged_gym_amd.envs.base.native_config import reward_setup
+    from extended_legged_gym_amd.native import NativeCore
+    from oracle.oracle_lib import OracleEnv
+    from tests.test_oracle_physics import _cmd_curriculum_cfg, _stage_cfg
+    n = 64
+    cfg = AnymalCFlatCfg(); cfg.env.num_envs = n
+    cfg.control.use_actuator_network = False
+    cfg.noise.add_noise = False; cfg.domain_rand.push_robots = False
+    _stage_cfg(cfg); _cmd_curriculum_cfg(cfg)
+    s = NativeSetup(cfg, sim_params_for(cfg), load_robot_model(cfg.asset), seed=3, gait=ANYMAL_GAIT)
+    o, core = OracleEnv(s), NativeCore(s, "cuda:0")
+    o.t["friction_coeffs"][:] = 1.0; core.t["friction_coeffs"].fill_(1.0)
+    o.reset_idx(np.arange(n)); core.reset_idx(torch.arange(n, device="cuda"))
+    z = np.zeros((n, 12), np.float32); zt = torch.zeros(n, 12, device="cuda")
+    for step in range(1, 112):
+        o.step(z); core.step(zt)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o.t["command_ranges"][0], [-0.5, 0.5])
+    np.testing.assert_allclose(core.t["command_ranges"].cpu().numpy(), o.t["command_ranges"])
+    # stage switch from identical state
+    names1, vals1 = reward_setup(cfg, s.dt, 1)
+    ids1 = [abi.REWARD_TERM_ID[k] for k in names1]
+    for name in COPY:
+        core.t[name].copy_(torch.from_numpy(o.t[name].copy()))
+    o.set_reward_terms(ids1, vals1); core.set_reward_terms(ids1, vals1)
+    torch.cuda.synchronize()
+    assert not core.t["episode_sums"].any()
+    rng = np.random.default_rng(1)
+    a = rng.normal(size=(n, 12)).astype(np.float32)
+    o.step(a); core.step(torch.from_numpy(a).cuda())
+    compare(core, o, ["rew_buf", "episode_sums", "root_states", "obs_buf"])
+    k_dv = names1.index("dof_vel")
+    assert float(core.t["episode_sums"][k_dv].abs().sum()) > 0
+    core.close(); o.close()

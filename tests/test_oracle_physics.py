@@ -308,3 +308,71 @@ def test_mesh_terrain_supports_the_robot_on_a_raised_box_and_under_a_ceiling():
     assert peak > 0.62 + 0.1                                                 # without the slab the same jump goes higher
     assert not np.isnan(o.t["root_states"]).any()
     o.close(); free.close()
+
+
+# ------------------------------------------------------------------------------------------------ reward stages, command curriculum
+def _stage_cfg(cfg):
+    cfg.rewards.multi_stage_rewards = True
+    cfg.rewards.reward_max_stage = 1
+    cfg.rewards.scales.torques = [-0.00001, -0.001]
+    cfg.rewards.scales.dof_vel = [0.0, -0.01]                 # a term that only exists from stage 1 on
+    cfg.rewards.only_positive_rewards = False
+
+
+def test_reward_stage_switch_replaces_terms_and_restarts_episode_sums():
+    """update_reward_scales (legged_robot_rew_mixin.py:31-38): stage 1 brings in `dof_vel`, scales `torques` up and
+    re-creates the episode sums; the reward of the next step is the stage-1 sum of terms."""
+    from extended_legged_gym_amd.envs.base.native_config import reward_setup
+    cfg, s, model, o = make(n=4, control="P", mutate=_stage_cfg)
+    names0 = s.reward_names
+    assert "dof_vel" not in names0 and "torques" in names0
+    o.reset_idx(np.arange(4))
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        o.step(rng.normal(size=(4, 12)).astype(np.float32))
+    K0 = len(names0)
+    assert np.abs(o.t["episode_sums"][:K0]).sum() > 0 and not o.t["episode_sums"][K0:].any()
+    names1, vals1 = reward_setup(cfg, s.dt, 1)
+    assert "dof_vel" in names1 and len(names1) == K0 + 1
+    o.set_reward_terms([abi.REWARD_TERM_ID[n] for n in names1], vals1)
+    assert not o.t["episode_sums"].any()
+    a = rng.normal(size=(4, 12)).astype(np.float32)
+    o.step(a)
+    es = o.t["episode_sums"][:len(names1)]
+    np.testing.assert_allclose(o.t["rew_buf"], es.sum(0), rtol=1e-5, atol=1e-7)         # one step since the restart
+    k_dv, k_tq = names1.index("dof_vel"), names1.index("torques")
+    qd = o.t["dof_state"][:, :, 1]
+    # rewards are evaluated before last_dof_vel etc. are updated but after the physics step: dof_vel term = sum qd^2
+    np.testing.assert_allclose(es[k_dv], -0.01 * s.dt * (qd ** 2).sum(1), rtol=1e-4)
+    np.testing.assert_allclose(es[k_tq], -0.001 * s.dt * (o.t["torques"] ** 2).sum(1), rtol=1e-4)
+    o.close()
+
+
+def _cmd_curriculum_cfg(cfg):
+    cfg.commands.curriculum = True
+    cfg.commands.max_curriculum = 0.8
+    cfg.commands.ranges.lin_vel_x = [0.0, 0.0]; cfg.commands.ranges.lin_vel_y = [0.0, 0.0]
+    cfg.commands.ranges.ang_vel_yaw = [0.0, 0.0]; cfg.commands.heading_command = False
+    cfg.env.episode_length_s = 0.2                              # 10 policy steps: time-out on step 11, 22, ...
+    cfg.rewards.tracking_sigma = 25.0                           # reset velocities of +-0.5 m/s still count as tracking
+
+
+def test_command_curriculum_widens_the_range_when_tracking_is_good():
+    """update_command_curriculum (legged_robot.py:178-179, 520-533): robots told to stand still do track their command;
+    the first time a reset coincides with common_step_counter % max_episode_length == 0 (step 110 = lcm(11, 10)) the
+    lin_vel_x range grows by 0.5 on each side, clipped to max_curriculum."""
+    cfg, s, model, o = make(n=3, control="P", mutate=_cmd_curriculum_cfg)
+    assert s.cfg.command_curriculum == 1 and int(s.cfg.max_episode_length) == 10
+    np.testing.assert_allclose(o.t["command_ranges"], [[0, 0], [0, 0], [0, 0], cfg.commands.ranges.heading])
+    o.reset_idx(np.arange(3))
+    z = np.zeros((3, 12), np.float32)
+    for step in range(1, 121):
+        o.step(z)
+        want = [0.0, 0.0] if step < 110 else [-0.5, 0.5]
+        np.testing.assert_allclose(o.t["command_ranges"][0], want, err_msg=f"step {step}")
+    assert np.abs(o.t["commands"][:, 0]).max() == 0.0           # (the envs reset on step 110 drew from the old range)
+    for step in range(121, 221):
+        o.step(z)
+    np.testing.assert_allclose(o.t["command_ranges"][0], [-0.8, 0.8])       # second widening at step 220, clipped
+    assert np.abs(o.t["commands"][:, 0]).max() > 0.0            # later resets draw from the widened range
+    o.close()
