@@ -1,11 +1,18 @@
-"""Registered tasks (subset of the reference's `envs/__init__.py:114-198` that the native step covers)."""
+"""Registered tasks (subset of the reference's `envs/__init__.py:114-198` that the native step covers); the batch-rollout env
+classes are importable from here for task-specific configs."""
 from extended_legged_gym_amd.utils.task_registry import task_registry
 from .base.legged_robot import LeggedRobot
 from .anymal_c.anymal import Anymal
 from .anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg, AnymalCRoughCfgPPO
 from .anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg, AnymalCFlatCfgPPO
 from .a1.a1_config import A1RoughCfg, A1RoughCfgPPO
+from .go2.go2 import Go2
+from .go2.go2_config import Go2RoughCfg, Go2RoughCfgPPO, Go2FlatCfg, Go2FlatCfgPPO
+from .batch_rollout.robot_batch_rollout import RobotBatchRollout
+from .batch_rollout.robot_batch_rollout_percept import RobotBatchRolloutPercept
 
 task_registry.register("anymal_c_rough", Anymal, AnymalCRoughCfg(), AnymalCRoughCfgPPO())
 task_registry.register("anymal_c_flat", Anymal, AnymalCFlatCfg(), AnymalCFlatCfgPPO())
 task_registry.register("a1", LeggedRobot, A1RoughCfg(), A1RoughCfgPPO())
+task_registry.register("go2_rough", Go2, Go2RoughCfg(), Go2RoughCfgPPO())
+task_registry.register("go2_flat", Go2, Go2FlatCfg(), Go2FlatCfgPPO())

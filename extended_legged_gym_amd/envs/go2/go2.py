@@ -1,0 +1,8 @@
+"""`Go2(LeggedRobot)` (reference `envs/go2/go2.py:19-93`): like `Anymal` — optional LSTM actuator network and a gait
+scheduler stepped once per policy step, both inside the native kernels."""
+from extended_legged_gym_amd.envs.anymal_c.anymal import Anymal
+
+
+class Go2(Anymal):
+    def _gait_config(self):
+        return dict(period=0.6, swing_height=0.15, foot_phases=[0.0, 0.5, 0.5, 0.0])     # go2.py:30-34

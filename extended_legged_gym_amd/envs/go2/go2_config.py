@@ -1,0 +1,116 @@
+"""Unitree Go2 task configs (values of the reference's `envs/go2/flat/go2_rough_config.py:33-174` and
+`go2_flat_config.py:33-97`)."""
+from extended_legged_gym_amd.envs.base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgPPO
+
+
+class Go2RoughCfg(LeggedRobotCfg):
+    class env(LeggedRobotCfg.env):
+        num_envs = 4096
+        num_observations = 235
+        num_actions = 12
+
+    class terrain(LeggedRobotCfg.terrain):
+        curriculum = True
+        mesh_type = 'trimesh'
+        measure_heights = True
+
+    class commands(LeggedRobotCfg.commands):
+        curriculum = False
+        max_curriculum = 1.
+        resampling_time = 10.
+        heading_command = True
+
+        class ranges:
+            lin_vel_x = [-1.0, 1.0]
+            lin_vel_y = [-1.0, 1.0]
+            ang_vel_yaw = [-1, 1]
+            heading = [-3.14, 3.14]
+
+    class init_state(LeggedRobotCfg.init_state):
+        pos = [0.0, 0.0, 0.33]
+        default_joint_angles = {
+            'FL_hip_joint': 0.1, 'RL_hip_joint': 0.1, 'FR_hip_joint': -0.1, 'RR_hip_joint': -0.1,
+            'FL_thigh_joint': 0.8, 'RL_thigh_joint': 0.8, 'FR_thigh_joint': 0.8, 'RR_thigh_joint': 0.8,
+            'FL_calf_joint': -1.5, 'RL_calf_joint': -1.5, 'FR_calf_joint': -1.5, 'RR_calf_joint': -1.5,
+        }
+
+    class control(LeggedRobotCfg.control):
+        stiffness = {'joint': 30.0}
+        damping = {'joint': 0.8}
+        action_scale = 0.3
+        decimation = 4
+        use_actuator_network = False
+
+    class asset(LeggedRobotCfg.asset):
+        file = "{LEGGED_GYM_ROOT_DIR}/resources/robots/go2/urdf/go2_description.urdf"
+        name = "go2"
+        foot_name = "foot"
+        penalize_contacts_on = ["thigh", "calf"]
+        terminate_after_contacts_on = ["base", "Head_upper"]
+        self_collisions = 1
+
+    class rewards(LeggedRobotCfg.rewards):
+        soft_dof_pos_limit = 0.9
+        max_contact_force = 350.0
+        base_height_target = 0.25
+
+        class scales(LeggedRobotCfg.rewards.scales):
+            orientation = -0.5
+            torques = -0.00001
+            action_rate = -0.001
+
+    class domain_rand(LeggedRobotCfg.domain_rand):
+        randomize_base_mass = True
+        added_mass_range = [-1., 1.]
+
+
+class Go2RoughCfgPPO(LeggedRobotCfgPPO):
+    class algorithm(LeggedRobotCfgPPO.algorithm):
+        entropy_coef = 0.01
+
+    class runner(LeggedRobotCfgPPO.runner):
+        run_name = ''
+        experiment_name = 'rough_go2'
+        max_iterations = 1000
+
+
+class Go2FlatCfg(Go2RoughCfg):
+    class env(Go2RoughCfg.env):
+        num_observations = 48
+
+    class terrain(Go2RoughCfg.terrain):
+        mesh_type = 'plane'
+        measure_heights = False
+
+    class asset(Go2RoughCfg.asset):
+        self_collisions = 0
+
+    class rewards(Go2RoughCfg.rewards):
+        max_contact_force = 350.
+
+        class scales(Go2RoughCfg.rewards.scales):
+            orientation = -5.0
+            torques = -0.000025
+            action_rate = -0.01
+            feet_air_time = 1.0
+
+    class commands(Go2RoughCfg.commands):
+        heading_command = False
+        resampling_time = 4.
+
+        class ranges(Go2RoughCfg.commands.ranges):
+            ang_vel_yaw = [-1.5, 1.5]
+
+    class domain_rand(Go2RoughCfg.domain_rand):
+        friction_range = [0.5, 1.5]
+
+
+class Go2FlatCfgPPO(Go2RoughCfgPPO):
+    class policy(Go2RoughCfgPPO.policy):
+        actor_hidden_dims = [128, 64, 32]
+        critic_hidden_dims = [128, 64, 32]
+        activation = 'elu'
+
+    class runner(Go2RoughCfgPPO.runner):
+        experiment_name = 'flat_go2'
+        max_iterations = 300

@@ -105,6 +105,19 @@ def _link_spheres(link, compact=False):
     return out
 
 
+def _two_extremes(spheres):
+    """At most two primitives of a link in the reduced set: the pair that is farthest apart (its two ends)."""
+    if len(spheres) <= 2:
+        return list(spheres)
+    best, pair = -1.0, (0, 1)
+    for i in range(len(spheres)):
+        for j in range(i + 1, len(spheres)):
+            d = float(np.linalg.norm(np.asarray(spheres[i][0]) - np.asarray(spheres[j][0])))
+            if d > best:
+                best, pair = d, (i, j)
+    return [spheres[pair[0]], spheres[pair[1]]]
+
+
 def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on, collapse_fixed_joints=True):
     """Returns a plain-dict robot model with the fields of `lg_robot_model` (include/lgstep.h)."""
     root = ET.parse(path).getroot()
@@ -190,7 +203,7 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
             dof_names.append(jj["name"])
             mass, com, ine = bb.mass, bb.com.copy(), bb.inertia.copy()
             spheres = [(k, body_index, sp, sr) for (sp, sr) in bb.spheres]
-            spheres_c = [(k, body_index, sp, sr) for (sp, sr) in bb.spheres_compact]
+            spheres_c = [(k, body_index, sp, sr) for (sp, sr) in _two_extremes(bb.spheres_compact)]
             if k == 2:
                 if foot is not None:
                     fj, fb = foot

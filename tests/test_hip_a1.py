@@ -72,3 +72,32 @@ def test_a1_env_stands_and_stays_finite():
     lo = torch.tensor(env.robot_model["dof_lower"], device=env.device); hi = torch.tensor(env.robot_model["dof_upper"], device=env.device)
     old = env.episode_length_buf >= 10
     assert float(torch.maximum(lo - env.dof_pos, env.dof_pos - hi)[old].max()) < 0.08
+
+
+def test_go2_flat_and_rough_tasks():
+    """Unitree Go2: same kernels, table-driven robot model from the shipped JSON."""
+    from tests.test_env_api import make
+    env = make("go2_flat", 128)
+    assert (env.num_obs, env.num_actions, env.num_bodies) == (48, 12, 17)
+    env.reset()
+    for _ in range(150):
+        env.step(torch.zeros(128, 12, device=env.device))
+    assert int(env.reset_buf.sum()) == 0
+    mass = 15.017 + env.core.t["base_mass_added"]
+    assert torch.allclose(env.contact_forces[:, :, 2].sum(1), mass * 9.81, rtol=0.05)
+    assert 0.2 < float(env.root_states[:, 2].min()) and float(env.root_states[:, 2].max()) < 0.4
+    g = torch.Generator().manual_seed(0)
+    resets = 0
+    for _ in range(300):
+        _, _, _, d, _ = env.step(3.0 * torch.randn(128, 12, generator=g).cuda())
+        resets += int(d.sum())
+    assert resets > 0                                            # trunk contacts terminate episodes
+    for name in ["obs_buf", "root_states", "dof_state", "rew_buf"]:
+        assert torch.isfinite(env.core.t[name]).all()
+    np.random.seed(3)
+    env = make("go2_rough", 64, **{"terrain.num_rows": 2, "terrain.num_cols": 2, "terrain.max_init_terrain_level": 1})
+    obs, _ = env.reset()
+    assert obs.shape == (64, 235)
+    for _ in range(50):
+        obs, _, rew, d, info = env.step(torch.randn(64, 12, generator=g).cuda())
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()

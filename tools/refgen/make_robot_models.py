@@ -21,6 +21,10 @@ m = load_urdf(f"{REF}/robots/a1/urdf/a1.urdf", "foot", ["thigh", "calf"], ["base
 save_model(m, f"{OUT}/robots/a1.json")
 print("a1", m["num_bodies"], m["body_names"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"])
 
+m = load_urdf(f"{REF}/robots/go2/urdf/go2_description.urdf", "foot", ["thigh", "calf"], ["base", "Head_upper"])
+save_model(m, f"{OUT}/robots/go2_description.json")
+print("go2", m["num_bodies"], m["body_names"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"])
+
 import torch
 net = torch.jit.load(f"{REF}/actuator_nets/anydrive_v3_lstm.pt")
 sd = {k: v.detach().numpy() for k, v in net.state_dict().items()}
