@@ -7,30 +7,70 @@
 
 #include "lg_device.h"
 
+// Host-side binary node (builder only) ...
 struct BvhNode {          // 32 B
   float bmin[3]; int32_t left_first;   // inner: index of left child (right = left + 1); leaf: first triangle
   float bmax[3]; int32_t count;        // 0 = inner node, > 0 = number of triangles in the leaf
 };
 
+// ... collapsed for the device into 4-wide nodes that carry their CHILDREN's boxes: one 128-byte fetch per visited
+// node decides all four children, so a traversal pays one dependent memory round trip per level of a tree half as
+// deep (the binary layout paid two: the node, then its two children).
+//   child[k] >= 0            inner node index
+//   child[k] == BVH4_EMPTY   no child
+//   otherwise                leaf: ~child[k] = (first_triangle << 3) | (count - 1), count <= 8
+#define BVH4_EMPTY ((int32_t)0x80000000)
+struct BvhNode4 {         // 128 B, structure of arrays over the four children
+  float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
+  int32_t child[4];
+  int32_t pad[4];
+};
+
 struct lg_mesh {
   int device = 0;
   int64_t n_tris = 0, n_nodes = 0;
-  BvhNode* d_nodes = nullptr;
+  BvhNode4* d_nodes = nullptr;
   float4* d_tris = nullptr;            // 3 float4 per triangle: v0, v1, v2 (w unused)
   std::string err;
 };
 
 // ------------------------------------------------------------------------------------------------ device: traversal
-struct MeshView { const BvhNode* __restrict__ nodes; const float4* __restrict__ tris; };
+struct MeshView { const BvhNode4* __restrict__ nodes; const float4* __restrict__ tris; };
+#define BVH_STACK 40      // <= 3 pushes per level of a 4-wide tree
 
-LG_DEV bool slab(const BvhNode& n, V3 o, V3 inv, float tmax, float* tnear) {
-  float tx1 = (n.bmin[0] - o.x) * inv.x, tx2 = (n.bmax[0] - o.x) * inv.x;
-  float ty1 = (n.bmin[1] - o.y) * inv.y, ty2 = (n.bmax[1] - o.y) * inv.y;
-  float tz1 = (n.bmin[2] - o.z) * inv.z, tz2 = (n.bmax[2] - o.z) * inv.z;
-  float tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fmaxf(fminf(tz1, tz2), 0.f));
-  float tmx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fminf(fmaxf(tz1, tz2), tmax));
-  *tnear = tmin;
-  return tmin <= tmx;
+struct Node4Regs { float4 minx, miny, minz, maxx, maxy, maxz; int4 child; };
+LG_DEV Node4Regs load_node4(const BvhNode4* __restrict__ nodes, int idx) {
+  const float4* p = (const float4*)(nodes + idx);
+  Node4Regs n;
+  n.minx = p[0]; n.miny = p[1]; n.minz = p[2]; n.maxx = p[3]; n.maxy = p[4]; n.maxz = p[5];
+  n.child = *(const int4*)(p + 6);
+  return n;
+}
+#define F4(v, k) ((k) == 0 ? (v).x : (k) == 1 ? (v).y : (k) == 2 ? (v).z : (v).w)
+
+// Nearest of up to four candidates (inner node indices or leaf codes; BVH4_EMPTY = none) becomes `cur`; the others go
+// on the stack farthest first, so they pop nearest first.  Leaves travel through the stack like inner nodes: strict
+// nearest-first order is what keeps the search radius (or the ray interval) shrinking as early as possible.
+LG_DEV bool descend4(int cand[4], float key[4], int* stack_i, float* stack_k, int& sp, int& cur) {
+  int nvalid = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) nvalid += cand[k] != BVH4_EMPTY ? 1 : 0;
+  if (nvalid == 0) return false;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {                 // push the largest key while more than one candidate is left
+    if (nvalid > 1) {
+      int bk = -1, bi = BVH4_EMPTY; float bv = -1.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (cand[k] != BVH4_EMPTY && key[k] > bv) { bv = key[k]; bk = k; bi = cand[k]; }
+      if (sp < BVH_STACK) { stack_i[sp] = bi; stack_k[sp] = bv; ++sp; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (k == bk) cand[k] = BVH4_EMPTY;
+      --nvalid;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (cand[k] != BVH4_EMPTY) cur = cand[k];
+  return true;
 }
 
 // closest two-sided hit with 0 <= t <= max_dist (Moller-Trumbore); returns t or -1
@@ -38,16 +78,31 @@ LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
   const V3 inv = v3(1.f / (fabsf(d.x) > 1e-12f ? d.x : copysignf(1e-12f, d.x)), 1.f / (fabsf(d.y) > 1e-12f ? d.y : copysignf(1e-12f, d.y)),
                     1.f / (fabsf(d.z) > 1e-12f ? d.z : copysignf(1e-12f, d.z)));
   float best = max_dist; bool hit = false;
-  int stack[48]; int sp = 0;
-  int cur = 0; float tn;
-  if (!slab(M.nodes[0], o, inv, best, &tn)) return -1.f;
+  int stack_i[BVH_STACK]; float stack_k[BVH_STACK]; int sp = 0;
+  int cur = 0;
   while (true) {
-    const BvhNode n = M.nodes[cur];
-    if (n.count > 0) {
-      for (int i = 0; i < n.count; ++i) {
-        const float4* T = M.tris + (size_t)(n.left_first + i) * 3;
-        float4 a = T[0], b = T[1], c = T[2];
-        V3 v0 = v3(a.x, a.y, a.z), e1 = v3(b.x - a.x, b.y - a.y, b.z - a.z), e2 = v3(c.x - a.x, c.y - a.y, c.z - a.z);
+    bool go = false;
+    if (cur >= 0) {
+      const Node4Regs n = load_node4(M.nodes, cur);
+      int cand[4]; float key[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = F4(n.child, k);
+        float tx1 = (F4(n.minx, k) - o.x) * inv.x, tx2 = (F4(n.maxx, k) - o.x) * inv.x;
+        float ty1 = (F4(n.miny, k) - o.y) * inv.y, ty2 = (F4(n.maxy, k) - o.y) * inv.y;
+        float tz1 = (F4(n.minz, k) - o.z) * inv.z, tz2 = (F4(n.maxz, k) - o.z) * inv.z;
+        float tmin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fmaxf(fminf(tz1, tz2), 0.f));
+        float tmx = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fminf(fmaxf(tz1, tz2), best));
+        key[k] = tmin;
+        cand[k] = (c != BVH4_EMPTY && tmin <= tmx) ? c : BVH4_EMPTY;
+      }
+      go = descend4(cand, key, stack_i, stack_k, sp, cur);
+    } else {
+      const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
+      for (int i = 0; i < cnt; ++i) {
+        const float4* T = M.tris + (size_t)(first + i) * 3;
+        float4 a = T[0], b = T[1], cc = T[2];
+        V3 v0 = v3(a.x, a.y, a.z), e1 = v3(b.x - a.x, b.y - a.y, b.z - a.z), e2 = v3(cc.x - a.x, cc.y - a.y, cc.z - a.z);
         V3 p = cross(d, e2);
         float det = dot(e1, p);
         if (fabsf(det) < 1e-20f) continue;
@@ -61,20 +116,11 @@ LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
         float t = dot(e2, q) * idet;
         if (t >= 0.f && t <= best) { best = t; hit = true; }
       }
-      if (sp == 0) break;
-      cur = stack[--sp];
-      continue;
     }
-    const int l = n.left_first, r = l + 1;
-    float tl, tr;
-    bool hl = slab(M.nodes[l], o, inv, best, &tl), hr = slab(M.nodes[r], o, inv, best, &tr);
-    if (hl && hr) {
-      int nearc = tl <= tr ? l : r, farc = tl <= tr ? r : l;
-      if (sp < 48) stack[sp++] = farc;
-      cur = nearc;
-    } else if (hl) cur = l;
-    else if (hr) cur = r;
-    else { if (sp == 0) break; cur = stack[--sp]; }
+    if (go) continue;
+    bool popped = false;
+    while (sp > 0) { --sp; if (stack_k[sp] <= best) { cur = stack_i[sp]; popped = true; break; } }
+    if (!popped) break;
   }
   return hit ? best : -1.f;
 }
@@ -98,33 +144,40 @@ LG_DEV V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
   return a + (vb * denom) * ab + (vc * denom) * ac;
 }
 
-LG_DEV float box_dist2(const BvhNode& n, V3 p) {
-  float dx = fmaxf(fmaxf(n.bmin[0] - p.x, 0.f), p.x - n.bmax[0]);
-  float dy = fmaxf(fmaxf(n.bmin[1] - p.y, 0.f), p.y - n.bmax[1]);
-  float dz = fmaxf(fmaxf(n.bmin[2] - p.z, 0.f), p.z - n.bmax[2]);
-  return dx * dx + dy * dy + dz * dz;
-}
-
 // closest point within max_dist; outputs the point and the unit normal of the face that decides the sign.  When several
 // faces are equally close (the closest feature is a shared edge or vertex) the face whose plane is farthest from the
 // query point decides: that rule is independent of traversal order, so the BVH and a brute-force scan agree.
 LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V3* fn_out) {
   float best2 = max_dist * max_dist; bool found = false; float bestabs = -1.f;
   V3 bestp = p, bestn = v3(0, 0, 1);
-  int stack[48]; int sp = 0; int cur = 0;
-  if (box_dist2(M.nodes[0], p) > best2) return false;
+  int stack_i[BVH_STACK]; float stack_k[BVH_STACK]; int sp = 0; int cur = 0;
   while (true) {
-    const BvhNode n = M.nodes[cur];
-    if (n.count > 0) {
-      for (int i = 0; i < n.count; ++i) {
-        const float4* T = M.tris + (size_t)(n.left_first + i) * 3;
+    bool go = false;
+    if (cur >= 0) {
+      const Node4Regs n = load_node4(M.nodes, cur);
+      int cand[4]; float key[4];
+      const float lim = best2 * (1.f + 1e-5f) + 1e-12f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = F4(n.child, k);
+        float dx = fmaxf(fmaxf(F4(n.minx, k) - p.x, 0.f), p.x - F4(n.maxx, k));
+        float dy = fmaxf(fmaxf(F4(n.miny, k) - p.y, 0.f), p.y - F4(n.maxy, k));
+        float dz = fmaxf(fmaxf(F4(n.minz, k) - p.z, 0.f), p.z - F4(n.maxz, k));
+        key[k] = dx * dx + dy * dy + dz * dz;
+        cand[k] = (c != BVH4_EMPTY && key[k] <= lim) ? c : BVH4_EMPTY;
+      }
+      go = descend4(cand, key, stack_i, stack_k, sp, cur);
+    } else {
+      const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
+      for (int i = 0; i < cnt; ++i) {
+        const float4* T = M.tris + (size_t)(first + i) * 3;
         float4 a4 = T[0], b4 = T[1], c4 = T[2];
-        V3 a = v3(a4.x, a4.y, a4.z), b = v3(b4.x, b4.y, b4.z), c = v3(c4.x, c4.y, c4.z);
+        V3 a = v3(a4.x, a4.y, a4.z), b = v3(b4.x, b4.y, b4.z), cc = v3(c4.x, c4.y, c4.z);
         // zero-area faces (slope-corrected height-field meshes are full of them) are skipped: their points belong to
         // the edges of their neighbours, and the barycentric arithmetic below is 0/0 on them
-        V3 fn = cross(b - a, c - a); float fl = norm(fn);
+        V3 fn = cross(b - a, cc - a); float fl = norm(fn);
         if (!(fl > 1e-10f)) continue;
-        V3 q = closest_on_triangle(p, a, b, c);
+        V3 q = closest_on_triangle(p, a, b, cc);
         V3 dq = p - q; float d2 = dot(dq, dq);
         if (!(d2 <= best2 * (1.f + 1e-5f) + 1e-12f)) continue;
         const bool strictly = !found || d2 < best2 * (1.f - 1e-5f) - 1e-12f;
@@ -138,18 +191,11 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
         if (!found || d2 < best2) { best2 = d2; bestp = q; }
         found = true;
       }
-      if (sp == 0) break;
-      cur = stack[--sp];
-      continue;
     }
-    const int l = n.left_first, r = l + 1;
-    float dl = box_dist2(M.nodes[l], p), dr = box_dist2(M.nodes[r], p);
-    const float lim = best2 * (1.f + 1e-5f) + 1e-12f;
-    bool hl = dl <= lim, hr = dr <= lim;
-    if (hl && hr) { int nearc = dl <= dr ? l : r, farc = dl <= dr ? r : l; if (sp < 48) stack[sp++] = farc; cur = nearc; }
-    else if (hl) cur = l;
-    else if (hr) cur = r;
-    else { if (sp == 0) break; cur = stack[--sp]; }
+    if (go) continue;
+    bool popped = false;
+    while (sp > 0) { --sp; if (stack_k[sp] <= best2 * (1.f + 1e-5f) + 1e-12f) { cur = stack_i[sp]; popped = true; break; } }
+    if (!popped) break;
   }
   *cp_out = bestp; *fn_out = bestn;
   return found;

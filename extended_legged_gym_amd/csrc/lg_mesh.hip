@@ -7,9 +7,9 @@
 // reference tree; semantics restated: closest two-sided hit with 0 <= t <= max_dist; closest point on the surface with
 // the sign taken from the normal of the closest feature's face.
 //
-// Layout: 32-byte BVH nodes (bounds + child / triangle range), triangles re-ordered by leaf and stored as three float4
-// (48 B) so one leaf is a short contiguous burst; everything stays resident in HBM/L2 (rough terrain: 1.6 M triangles =
-// 78 MB + 26 MB of nodes).  One ray / point per lane, ordered traversal with a small per-lane stack.
+// Layout: a binned-SAH binary tree built on the host, collapsed into 128-byte 4-wide nodes that carry their children's
+// boxes (lg_bvh.h); triangles re-ordered by leaf and stored as three float4 (48 B) so one leaf is a short contiguous
+// burst; everything stays resident in HBM/L2.  One ray / point per lane, nearest-first traversal with a per-lane stack.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -89,6 +89,36 @@ struct Builder {
     nodes[node].left_first = left; nodes[node].count = 0;
     build(left, first, mid - first);
     build(left + 1, mid, first + count - mid);
+  }
+};
+// binary tree -> 4-wide nodes that hold their children's boxes (see lg_bvh.h)
+struct Collapser {
+  const std::vector<BvhNode>& n2; std::vector<BvhNode4>& n4;
+  static float area(const BvhNode& n) { float x = n.bmax[0] - n.bmin[0], y = n.bmax[1] - n.bmin[1], z = n.bmax[2] - n.bmin[2]; return x * y + y * z + z * x; }
+  int emit(int root2) {
+    int kids[4]; int nk = 0;
+    if (n2[root2].count > 0) kids[nk++] = root2;                       // the whole mesh is one leaf
+    else { kids[nk++] = n2[root2].left_first; kids[nk++] = n2[root2].left_first + 1; }
+    while (nk < 4) {                                                   // open the inner child with the largest box
+      int best = -1; float ba = -1.f;
+      for (int i = 0; i < nk; ++i) if (n2[kids[i]].count == 0 && area(n2[kids[i]]) > ba) { ba = area(n2[kids[i]]); best = i; }
+      if (best < 0) break;
+      const int c = kids[best];
+      kids[best] = n2[c].left_first; kids[nk++] = n2[c].left_first + 1;
+    }
+    const int me = (int)n4.size();
+    n4.push_back(BvhNode4());
+    for (int k = 0; k < 4; ++k) {
+      BvhNode4& N = n4[me];
+      if (k >= nk) { N.minx[k] = N.miny[k] = N.minz[k] = 1e30f; N.maxx[k] = N.maxy[k] = N.maxz[k] = -1e30f; N.child[k] = BVH4_EMPTY; N.pad[k] = 0; continue; }
+      const BvhNode& c = n2[kids[k]];
+      N.minx[k] = c.bmin[0]; N.miny[k] = c.bmin[1]; N.minz[k] = c.bmin[2];
+      N.maxx[k] = c.bmax[0]; N.maxy[k] = c.bmax[1]; N.maxz[k] = c.bmax[2];
+      N.pad[k] = 0;
+      if (c.count > 0) N.child[k] = ~((c.left_first << 3) | (c.count - 1));
+      else { const int idx = emit(kids[k]); n4[me].child[k] = idx; }   // (n4 may have been reallocated: index, not reference)
+    }
+    return me;
   }
 };
 }  // namespace
@@ -295,11 +325,15 @@ lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t
   std::vector<float4> packed((size_t)n_triangles * 3);
   for (int64_t i = 0; i < n_triangles; ++i)
     for (int v = 0; v < 3; ++v) packed[3 * i + v] = make_float4(t[i].v[3 * v], t[i].v[3 * v + 1], t[i].v[3 * v + 2], 0.f);
+  if (n_triangles >= (1ll << 28)) { g_mesh_err = "mesh too large for the leaf encoding (2^28 triangles)"; return nullptr; }
+  std::vector<BvhNode4> nodes4; nodes4.reserve(nodes.size() / 2 + 1);
+  Collapser col{nodes, nodes4};
+  col.emit(0);
   lg_mesh* m = new lg_mesh();
-  m->device = device_id; m->n_tris = n_triangles; m->n_nodes = (int64_t)nodes.size();
-  if (hipMalloc((void**)&m->d_nodes, nodes.size() * sizeof(BvhNode)) != hipSuccess ||
+  m->device = device_id; m->n_tris = n_triangles; m->n_nodes = (int64_t)nodes4.size();
+  if (hipMalloc((void**)&m->d_nodes, nodes4.size() * sizeof(BvhNode4)) != hipSuccess ||
       hipMalloc((void**)&m->d_tris, packed.size() * sizeof(float4)) != hipSuccess ||
-      hipMemcpy(m->d_nodes, nodes.data(), nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(m->d_nodes, nodes4.data(), nodes4.size() * sizeof(BvhNode4), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(m->d_tris, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
     g_mesh_err = "device allocation / upload of the BVH failed"; lg_mesh_destroy(m); return nullptr;
   }
