@@ -312,8 +312,15 @@ LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const Phys
 #define LG_MESH_CONTACT_MARGIN 0.1f
 #define LG_MESH_CACHE_REACH 0.15f
 #define CQ(slot, f) cq[((slot) * 4 + (f)) * 64 + lane]
+// `cq` (optional, LDS, [slot][4][lane], persisted per env between steps) caches per sphere the position and the unsigned
+// surface distance of its last query (distance < 0: no entry).  Two exact uses of it:
+//   * cull: the query looked LG_MESH_CACHE_REACH further than `range`; while the sphere has moved less than that distance
+//     minus `range` since, no triangle can be within `range` and the traversal is skipped;
+//   * bound: the surface cannot be farther than the cached distance plus the distance travelled, so the search starts
+//     with that radius instead of the full reach - a foot in stance tests a handful of triangles, not the ~60 within
+//     reach.  A reset teleports the sphere; the travel term then exceeds the reach and the bound falls back to it.
 LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k,
-                                const M3& Rb, V3 pb, float* cst, int lane, float* cq = nullptr, bool first = true) {
+                                const M3& Rb, V3 pb, float* cst, int lane, float* cq = nullptr) {
   const int ncp = lm_.i(LM_CP_COUNT);
   const float idt_ = frcp(P.dt);
 #pragma unroll 1
@@ -326,12 +333,19 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       rad = lm_.f(LM_CP_RADIUS + sl);
       x = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
       const float range = rad + P.contact_offset + LG_MESH_CONTACT_MARGIN;
-      bool query = true;
-      if (cq && !first) query = !(norm(x - v3(CQ(sl, 0), CQ(sl, 1), CQ(sl, 2))) < CQ(sl, 3) - range);
+      const float reach = cq ? range + LG_MESH_CACHE_REACH : range;
+      bool query = true; float bound = reach;
+      if (cq) {
+        const float dq = CQ(sl, 3);
+        if (dq >= 0.f) {
+          const float travel = norm(x - v3(CQ(sl, 0), CQ(sl, 1), CQ(sl, 2)));
+          query = !(travel < dq - range);
+          bound = fminf(reach, dq + travel * 1.0001f + 1e-4f);
+        }
+      }
       if (query) {
         V3 cp, fn;
-        const float reach = cq ? range + LG_MESH_CACHE_REACH : range;
-        const bool found = closest_point(T.M, x, reach, &cp, &fn);
+        const bool found = closest_point(T.M, x, bound, &cp, &fn);
         const V3 diff = x - cp; const float dist = found ? norm(diff) : reach;
         if (cq) { CQ(sl, 0) = x.x; CQ(sl, 1) = x.y; CQ(sl, 2) = x.z; CQ(sl, 3) = dist; }
         if (found && dist <= range) {
@@ -454,7 +468,8 @@ LG_DEV void fetch_mass_factors(const float* xs, int lane, float Mi[6], float Mbk
 template <bool TMESH, int MAIN_DETECT, class TauFn, class PrepFn, class ShareFn>
 LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel& lm_, const TerrainView& T, const PhysParams& P,
                             int lane, float* cst, QuadState& s, TauFn tau_fn, PrepFn prep_fn, ShareFn share_fn, SlotShare share,
-                            float* xs, float mu_robot, float madd, V3* fbody, unsigned long long* stamps = nullptr) {
+                            float* xs, float mu_robot, float madd, V3* fbody, unsigned long long* stamps = nullptr,
+                            float* cq = nullptr) {
   STAMP_DECL
   const float dt = P.dt;
   const V3 pb = v3(s.root[0], s.root[1], s.root[2]);
@@ -525,7 +540,10 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   STAMP(3);
   // ---------------------------------------------------------------- leg bias + contact detection: helper waves or inline
   float bk[3]; V3 Fs, Ns;
-  if (MAIN_DETECT > 0 && share.n > 1) contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
+  if (MAIN_DETECT > 0 && share.n > 1) {
+    if (TMESH) contact_detect_mesh(0, MAIN_DETECT, lm_, T, P, k, Rb, pb, cst, lane, cq);
+    else contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
+  }
   if (!prep_fn(bk, Fs, Ns)) {
     leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);
     if (TMESH) contact_detect_mesh(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);

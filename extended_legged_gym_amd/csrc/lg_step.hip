@@ -50,6 +50,7 @@ struct DevCtx {
   float* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
   float* lvl_part;     // [nblocks] : per-workgroup sum of terrain levels
   unsigned* part_flag; // [nblocks] : 1 when some env of the workgroup was reset in this step (its partials row is valid)
+  float* mesh_cache;   // [N][4 legs][LG_MAX_CP][4]: last closest-point query of every collision sphere (mesh terrains)
   float lstm_w[912];   // actuator network weights, gate-interleaved (pack_lstm_weights): read with scalar loads
   int nblocks_post;
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
@@ -63,6 +64,7 @@ struct lg_ctx {
   DevCtx* d = nullptr; // device copy
   void* arena = nullptr; bool own_arena = false; size_t arena_bytes = 0;
   void* aux = nullptr; // noise_vec, height_points, partials
+  void* mesh_cache = nullptr;
   TensorInfo t[LG_T_COUNT];
   int device = 0;
   unsigned long sync_calls = 0;
@@ -272,6 +274,22 @@ LG_DEV void write_rigid_body_state(const DevCtx* __restrict__ C, const LegModel&
   }
 }
 
+// persisted closest-point cache of one lane's slots [s0, s0 + 2): global [env][leg][slot][4] <-> LDS [slot][4][lane]
+template <bool LOAD>
+LG_DEV void mesh_cache_io(const DevCtx* __restrict__ C, float* cqc, int e, int l, int lane, int s0) {
+  float4* g = (float4*)(C->mesh_cache + ((size_t)e * 4 + l) * LG_MAX_CP * 4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int sl = s0 + i;
+    if (LOAD) {
+      const float4 v = g[sl];
+      cqc[(sl * 4 + 0) * 64 + lane] = v.x; cqc[(sl * 4 + 1) * 64 + lane] = v.y; cqc[(sl * 4 + 2) * 64 + lane] = v.z; cqc[(sl * 4 + 3) * 64 + lane] = v.w;
+    } else {
+      g[sl] = make_float4(cqc[(sl * 4 + 0) * 64 + lane], cqc[(sl * 4 + 1) * 64 + lane], cqc[(sl * 4 + 2) * 64 + lane], cqc[(sl * 4 + 3) * 64 + lane]);
+    }
+  }
+}
+
 // ============================================================================================ physics kernel
 // MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
 // MODE 2: lg_compute_torques only.
@@ -329,6 +347,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm;
     P.terrain_mu = C->terrain_mu;
     const TerrainView T = C->ter;
+    if (TMESH) mesh_cache_io<true>(C, cqc, e, l, lane, 2 * wv);   // this wave's two slots of the persisted query cache -> LDS
 #ifdef LG_STAMPS
     unsigned long long* stamps = (blockIdx.x == 0 && lane == 0 && wv == 2) ? C->stamps : nullptr;
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
@@ -361,8 +380,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         xbias[3][lane] = Fs.x; xbias[4][lane] = Fs.y; xbias[5][lane] = Fs.z;
         xbias[6][lane] = Ns.x; xbias[7][lane] = Ns.y; xbias[8][lane] = Ns.z;
         if (!TMESH) contact_detect_begin<2, 4>(lm_, T, k, Rb, pb, pr1);
+        else contact_detect_mesh(2, 4, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (TMESH) {
-        contact_detect_mesh(wv == 2 ? 0 : LG_MAX_CP / 2, wv == 2 ? LG_MAX_CP / 2 : LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane, cqc, sub == 0);
+        contact_detect_mesh(2 * wv, 2 * wv + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (wv == 2) {
         contact_detect_begin<4, 6>(lm_, T, k, Rb, pb, pr2);
       } else {
@@ -401,6 +421,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       lds_barrier();                                   // (A3) slot table complete
     }
     lds_barrier();                                     // (F) main wave has published the final state of the step
+    if (TMESH && valid) mesh_cache_io<false>(C, cqc, e, l, lane, 2 * wv);
     if (valid) {                                         // wave w stores link w-1 of every leg (+ base / + foot body)
       float r13[13], qq[3], qdd[3];
 #pragma unroll
@@ -468,6 +489,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const float mu_robot = C->friction[e], madd = C->mass_added[e];
   V3 fbody[5];
   bool fault = false;
+  if (TMESH && helpers) mesh_cache_io<true>(C, cqc, e, l, lane, 0);
 #ifdef LG_STAMPS
   unsigned long long* stamps = (blockIdx.x == 0 && lane == 0) ? C->stamps : nullptr;
   unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
@@ -514,8 +536,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     };
     auto share_fn = [&]() { if (helpers) lds_barrier(); };   // (A3) every wave has finished its slots
     const SlotShare share{helpers ? 4 : 1, 0};
-    physics_substep<TMESH, TMESH ? 0 : 2>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
-                                          sub == nsub - 1 ? fbody : nullptr, stamps);
+    physics_substep<TMESH, 2>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
+                              sub == nsub - 1 ? fbody : nullptr, stamps, (TMESH && helpers) ? cqc : nullptr);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -551,6 +573,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     lds_barrier();                                     // (F) final state visible to the helper waves, which write the body states
   }
   if (!valid) return;
+  if (TMESH && helpers) mesh_cache_io<false>(C, cqc, e, l, lane, 0);
   if (fault && l == 0) C->reset_buf[e] = 2;
 
   // ---- write back state, torques, contact forces
@@ -1405,6 +1428,7 @@ void lg_destroy(lg_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->d) (void)hipFree(c->d);
   if (c->aux) (void)hipFree(c->aux);
+  if (c->mesh_cache) (void)hipFree(c->mesh_cache);
   if (c->own_arena && c->arena) (void)hipFree(c->arena);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   delete c;
@@ -1431,6 +1455,14 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.N = cfg->num_envs; h.B = model->num_bodies; h.K = cfg->num_reward_terms; h.P = cfg->num_height_points;
   h.per_leg = 3 + model->has_foot_body;
   pack_lstm_weights(h.lstm_w, cfg->actuator_net);
+  h.mesh_cache = nullptr;
+  if (ter->mesh_type == LG_MESH_TRIMESH) {
+    const size_t nf = (size_t)cfg->num_envs * 4 * LG_MAX_CP * 4;
+    std::vector<float> init(nf, -1.f);                   // distance < 0: no entry
+    if (hipMalloc((void**)&c->mesh_cache, nf * 4) != hipSuccess ||
+        hipMemcpy(c->mesh_cache, init.data(), nf * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("mesh contact cache allocation failed");
+    h.mesh_cache = (float*)c->mesh_cache;
+  }
   h.terrain_mu = ter->static_friction; h.env_length = ter->env_length; h.num_levels = ter->num_levels; h.num_types = ter->num_types;
   char* base = (char*)c->arena;
   auto P = [&](int id) { return (void*)(base + c->t[id].off); };
