@@ -96,6 +96,25 @@ def cpu_baseline(env, actions_pool, budget_s=15.0):
                        f"(best of the probed team sizes; {avail} CPUs visible), {dt:.1f} s")
 
 
+def pmc_traffic(N):
+    """HBM bytes per launch of the physics kernel from the committed rocprofv3 PMC passes (`tools/profile_round.sh`,
+    separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command).  bench.py cannot collect counters
+    itself; the figure is only reported when the committed passes were taken at the same env count."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files or N != 4096:
+        return {"traffic": None}
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"]
+        name = [n for n in k if "physics_kernel" in n][0]
+        rd, wr = k[name]["FETCH_SIZE_KiB_per_launch"] * 1024.0, k[name]["WRITE_SIZE_KiB_per_launch"] * 1024.0
+        return {"traffic": rd + wr, "traffic_read_bytes_as_reported": rd, "traffic_write_bytes": wr,
+                "traffic_source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,7 +187,7 @@ def main():
                                    "actions N(0,1), one step = 4 physics substeps + post-physics",
                        "num_envs_per_gpu": N, "decimation": 4, "sim_dt": 0.005, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "physics_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(N),
                          "algorithmic_bytes_per_env_step": phys_bytes, "kernel_ms": prof["physics_ms"],
                          "post_kernel_ms": prof["post_ms"], "finalize_kernel_ms": prof["finalize_ms"],
                          "hip_event_samples": prof["samples"],
