@@ -150,3 +150,33 @@ def test_reward_stage_switch_and_command_curriculum_match_oracle():
     k_dv = names1.index("dof_vel")
     assert float(core.t["episode_sums"][k_dv].abs().sum()) > 0
     core.close(); o.close()
+
+
+@pytest.mark.parametrize("n", [1, 5, 37])
+def test_ragged_env_counts_match_oracle(n):
+    """Env counts that fill neither a 16-env physics workgroup nor a 4-env post workgroup: partial quads / waves /
+    workgroups compute on copies and store nothing outside their rows."""
+    from extended_legged_gym_amd.native import NativeCore
+    from oracle.oracle_lib import OracleEnv
+    cfg, s, terrain = build("rough_lstm", n, seed=2)
+    o, core = OracleEnv(s), NativeCore(s, "cuda:0")
+    rng = init_oracle(o, cfg, s, terrain, n, 2)
+    for it in range(12):
+        act = rng.normal(size=(n, 12)).astype(np.float32)
+        if it % 4 == 3:
+            for name in COPY:
+                core.t[name].copy_(torch.from_numpy(o.t[name].copy()))
+            o.step(act); core.step(torch.from_numpy(act).cuda())
+            torch.cuda.synchronize()
+            for name in STATE:
+                a = core.t[name].cpu().numpy().astype(np.float64).reshape(-1); b = o.t[name].astype(np.float64).reshape(-1)
+                err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+                assert np.isfinite(a).all() and (err <= 5e-3).mean() >= 0.98, (name, err.max())
+        else:
+            o.step(act)
+    # an empty reset list and a single-env subset step are legal
+    core.reset_idx(torch.zeros(0, dtype=torch.long, device="cuda"))
+    core.step_subset(torch.zeros(1, 12, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda"), 0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(core.t["obs_buf"]).all()
+    core.close(); o.close()
