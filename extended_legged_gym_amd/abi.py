@@ -171,6 +171,27 @@ def declare_product(lib):
     return lib
 
 
+def declare_policy(lib):
+    """Prototypes of the rollout-collection entry points (include/lgpolicy.h), same library."""
+    vp = C.c_void_p
+    lib.lg_mlp_create.argtypes = [i32, C.POINTER(i32), C.POINTER(C.POINTER(f32)), C.POINTER(C.POINTER(f32)), i32, C.c_int]
+    lib.lg_mlp_create.restype = vp
+    lib.lg_mlp_destroy.argtypes = [vp]
+    lib.lg_mlp_destroy.restype = None
+    lib.lg_mlp_last_error.argtypes = [vp]
+    lib.lg_mlp_last_error.restype = C.c_char_p
+    lib.lg_mlp_forward.argtypes = [vp, vp, C.c_int64, vp, vp]
+    lib.lg_mlp_forward.restype = C.c_int
+    lib.lg_policy_act.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_uint64, C.c_uint64, i32, vp, vp, vp, vp, vp]
+    lib.lg_policy_act.restype = C.c_int
+    lib.lg_compute_returns.argtypes = [vp, vp, vp, vp, i32, C.c_int64, f32, f32, i32, vp, vp, vp]
+    lib.lg_compute_returns.restype = C.c_int
+    return lib
+
+
+POLICY_SYMBOLS = ["lg_mlp_create", "lg_mlp_destroy", "lg_mlp_last_error", "lg_mlp_forward", "lg_policy_act", "lg_compute_returns"]
+ACTIVATIONS = {"elu": 0, "relu": 1, "tanh": 2, "lrelu": 3, "selu": 4}
+
 PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_step_physics", "lg_step_subset", "lg_sync_main_to_rollout", "lg_compute_torques",
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
                    "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_last_error",

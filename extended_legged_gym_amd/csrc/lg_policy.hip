@@ -1,0 +1,278 @@
+// lg_policy.hip — gfx950 kernels for the rollout-collection side of PPO (include/lgpolicy.h): fused MLP forward on the
+// fp32 matrix cores, PPO.act (both networks + Gaussian sampling + log-prob) in one launch, GAE returns.
+//
+// MLP kernel.  Workgroup = 4 waves = 32 rows of the batch through ALL layers; the activations of the current layer live in
+// LDS in the operand order of v_mfma_f32_16x16x4_f32 ([k/4][row][k%4], row stride 33: the A-fragment read of a wave is 64
+// consecutive words, conflict-free), the next layer's activations are written to a second LDS buffer by the epilogue
+// (bias + activation on the accumulator fragments).  Weights are re-tiled once on the host into B-fragment order
+// ([16-column chunk][k/4][lane]), so a wave's B operand is one coalesced 256-byte load per MFMA pair; each wave owns every
+// fourth 16-column chunk of the layer and keeps two independent accumulators (rows 0-15 and 16-31), which is what the
+// 16x16x4 instruction needs to issue back to back.  Exact fp32: the MFMA is a k-ordered fmaf chain.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "lg_device.h"
+#include "../../include/lgpolicy.h"
+
+#define MLP_ROWS 32          // batch rows per workgroup
+#define MLP_RS 33            // LDS row stride (rows) of the [k/4][row][4] activation image
+#define MLP_MAXW 512         // widest layer
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpDev {
+  int L, act;
+  int dims[LG_MLP_MAX_LAYERS + 1];
+  int kpad[LG_MLP_MAX_LAYERS];       // input width rounded up to 4
+  int nchunks[LG_MLP_MAX_LAYERS];    // output width rounded up to 16, / 16
+  const float* w[LG_MLP_MAX_LAYERS]; // tiled weights [chunk][k/4][64]
+  const float* b[LG_MLP_MAX_LAYERS]; // bias, padded to 16 * nchunks
+};
+
+struct lg_mlp {
+  MlpDev h;
+  int device = 0;
+  std::vector<void*> allocs;
+  std::string err;
+};
+
+static thread_local std::string g_pol_err;
+
+LG_DEV float apply_act(float x, int act) {
+  switch (act) {
+    case LG_ACT_ELU: return x > 0.f ? x : expm1f(x);
+    case LG_ACT_RELU: return fmaxf(x, 0.f);
+    case LG_ACT_TANH: return tanhf(x);
+    case LG_ACT_LRELU: return x > 0.f ? x : 0.01f * x;
+    case LG_ACT_SELU: return 1.0507009873554805f * (x > 0.f ? x : 1.6732632423543772f * expm1f(x));
+  }
+  return x;
+}
+
+// 32 rows of x through the whole network; result rows (width dims[L], <= 16 * nchunks) left in `out` (LDS image)
+LG_DEV void mlp_tile(const MlpDev& M, const float* __restrict__ x, int64_t row0, int64_t n, float* buf0, float* buf1, float* yrows /* [32][16*?] */,
+                     float* __restrict__ y_global) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // stage the input tile: x (n, K0) row-major -> [k/4][row][k%4]
+  const int K0 = M.dims[0], K0p = M.kpad[0];
+  for (int idx = tid; idx < MLP_ROWS * K0p; idx += 256) {
+    const int r = idx / K0p, k = idx - r * K0p;
+    const int64_t row = row0 + r;
+    const float v = (row < n && k < K0) ? x[row * K0 + k] : 0.f;
+    buf0[((k >> 2) * MLP_RS + r) * 4 + (k & 3)] = v;
+  }
+  lds_barrier();
+  float* in = buf0; float* out = buf1;
+  for (int l = 0; l < M.L; ++l) {
+    const int ksteps = M.kpad[l] >> 2, nch = M.nchunks[l];
+    const bool last = l == M.L - 1;
+    const int nout = M.dims[l + 1];
+    for (int c = wv; c < nch; c += 4) {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const float* __restrict__ wt = M.w[l] + (size_t)c * ksteps * 64 + lane;
+      const float* a0p = in + (lane & 15) * 4 + (lane >> 4);
+      const float* a1p = a0p + 16 * 4;
+#pragma unroll 4
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const float b = wt[(size_t)ks * 64];
+        const float a0 = a0p[ks * MLP_RS * 4], a1 = a1p[ks * MLP_RS * 4];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+      }
+      // epilogue: C[m = 4 * (lane >> 4) + i][col = lane & 15]
+      const int col = c * 16 + (lane & 15);
+      const float bias = M.b[l][col];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 4 * (lane >> 4) + i;
+        float v0 = acc0[i] + bias, v1 = acc1[i] + bias;
+        if (!last) {
+          v0 = apply_act(v0, M.act); v1 = apply_act(v1, M.act);
+          if (col >= nout) { v0 = 0.f; v1 = 0.f; }                 // padded columns feed zeros to the next layer
+          out[((col >> 2) * MLP_RS + m) * 4 + (col & 3)] = v0;
+          out[((col >> 2) * MLP_RS + m + 16) * 4 + (col & 3)] = v1;
+        } else if (col < nout) {
+          if (yrows) { yrows[m * 16 * nch + col] = v0; yrows[(m + 16) * 16 * nch + col] = v1; }
+          if (y_global) {
+            if (row0 + m < n) y_global[(row0 + m) * nout + col] = v0;
+            if (row0 + m + 16 < n) y_global[(row0 + m + 16) * nout + col] = v1;
+          }
+        }
+      }
+    }
+    lds_barrier();
+    float* t = in; in = out; out = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDev M, const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+  __shared__ float buf0[(MLP_MAXW / 4) * MLP_RS * 4];
+  __shared__ float buf1[(MLP_MAXW / 4) * MLP_RS * 4];
+  mlp_tile(M, x, (int64_t)blockIdx.x * MLP_ROWS, n, buf0, buf1, nullptr, y);
+}
+
+// PPO.act: blockIdx.y = 0 actor (+ sampling, log-prob), 1 critic
+__global__ __launch_bounds__(256) void policy_act_kernel(MlpDev A, MlpDev Cr, const float* __restrict__ obs, const float* __restrict__ cobs,
+                                                         int64_t n, const float* __restrict__ stdv, uint32_t seed_lo, uint32_t seed_hi,
+                                                         uint32_t call_lo, uint32_t call_hi, int deterministic, float* __restrict__ actions,
+                                                         float* __restrict__ mean, float* __restrict__ logp, float* __restrict__ values) {
+  __shared__ float buf0[(MLP_MAXW / 4) * MLP_RS * 4];
+  __shared__ float buf1[(MLP_MAXW / 4) * MLP_RS * 4];
+  __shared__ float yrows[MLP_ROWS * 16 * 2];       // output rows of the actor (<= 32 actions)
+  __shared__ float lp[MLP_ROWS][32];
+  const int64_t row0 = (int64_t)blockIdx.x * MLP_ROWS;
+  if (blockIdx.y == 1) { mlp_tile(Cr, cobs, row0, n, buf0, buf1, nullptr, values); return; }
+  const int na = A.dims[A.L], stride = 16 * A.nchunks[A.L - 1];
+  mlp_tile(A, obs, row0, n, buf0, buf1, yrows, mean);
+  // one lane per (row, action): z from Philox + Box-Muller, two normals per counter word pair
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < MLP_ROWS * 32; idx += 256) {
+    const int r = idx >> 5, a = idx & 31;
+    float term = 0.f;
+    if (a < na && row0 + r < n) {
+      const float mu = yrows[r * stride + a], sd = stdv[a];
+      float act = mu;
+      if (!deterministic) {
+        uint32_t o[4];
+        philox4((uint32_t)(row0 + r), (uint32_t)((uint64_t)(row0 + r) >> 32), (uint32_t)(a >> 1), call_lo ^ (call_hi * 0x9E3779B9u), seed_lo, seed_hi, o);
+        const float u1 = fmaxf(u01(o[0]), 5.9604645e-8f), u2 = u01(o[1]);
+        const float rad = sqrtf(-2.f * logf(u1));
+        const float z = (a & 1) ? rad * sinf(6.28318530717958647692f * u2) : rad * cosf(6.28318530717958647692f * u2);
+        act = mu + sd * z;
+      }
+      actions[(row0 + r) * na + a] = act;
+      const float d = act - mu;
+      term = -(d * d) / (2.f * sd * sd) - logf(sd) - 0.91893853320467274178f;      // Normal.log_prob
+    }
+    lp[r][a] = term;
+  }
+  lds_barrier();
+  if (tid < MLP_ROWS && row0 + tid < n) {
+    float sacc = 0.f;
+    for (int a = 0; a < na; ++a) sacc += lp[tid][a];
+    logp[row0 + tid] = sacc;
+  }
+}
+
+// GAE (rollout_storage.py:145-160): one lane per env, the T-step recursion in registers
+__global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rew, const float* __restrict__ dones, const float* __restrict__ val,
+                                                  const float* __restrict__ last, int T, int64_t n, float gamma, float lam,
+                                                  float* __restrict__ ret, float* __restrict__ adv) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float a = 0.f, next = last[e];
+  for (int t = T - 1; t >= 0; --t) {
+    const float v = val[(size_t)t * n + e];
+    const float nt = 1.f - dones[(size_t)t * n + e];
+    const float delta = rew[(size_t)t * n + e] + nt * gamma * next - v;
+    a = delta + nt * gamma * lam * a;
+    ret[(size_t)t * n + e] = a + v;
+    adv[(size_t)t * n + e] = (a + v) - v;          // self.returns - self.values, as the reference computes it
+    next = v;
+  }
+}
+
+// mean / unbiased std over all entries, then (x - mean) / (std + 1e-8): one workgroup, fixed-order tree (deterministic)
+__global__ __launch_bounds__(1024) void normalize_kernel(float* __restrict__ adv, int64_t count) {
+  __shared__ double s1[1024], s2[1024];
+  const int tid = threadIdx.x;
+  double a = 0.0;
+  for (int64_t i = tid; i < count; i += 1024) a += (double)adv[i];
+  s1[tid] = a;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) { if (tid < off) s1[tid] += s1[tid + off]; __syncthreads(); }
+  const double mean = s1[0] / (double)count;
+  double q = 0.0;
+  for (int64_t i = tid; i < count; i += 1024) { const double d = (double)adv[i] - mean; q += d * d; }
+  s2[tid] = q;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) { if (tid < off) s2[tid] += s2[tid + off]; __syncthreads(); }
+  const double sd = count > 1 ? sqrt(s2[0] / (double)(count - 1)) : 0.0;
+  const float m = (float)mean, inv = 1.f / ((float)sd + 1e-8f);
+  for (int64_t i = tid; i < count; i += 1024) adv[i] = (adv[i] - m) * inv;
+}
+
+extern "C" {
+
+const char* lg_mlp_last_error(lg_mlp* m) { return m ? m->err.c_str() : g_pol_err.c_str(); }
+
+void lg_mlp_destroy(lg_mlp* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  for (void* p : m->allocs) (void)hipFree(p);
+  delete m;
+}
+
+lg_mlp* lg_mlp_create(int32_t L, const int32_t* dims, const float* const* weights, const float* const* biases, int32_t activation,
+                      int device_id) {
+  if (L <= 0 || L > LG_MLP_MAX_LAYERS || !dims || !weights || !biases) { g_pol_err = "bad layer list"; return nullptr; }
+  if (activation < LG_ACT_ELU || activation > LG_ACT_SELU) { g_pol_err = "unknown activation"; return nullptr; }
+  for (int l = 0; l <= L; ++l) if (dims[l] <= 0 || dims[l] > MLP_MAXW) { g_pol_err = "layer width out of range (1..512)"; return nullptr; }
+  if (dims[L] > 32) { /* fine for lg_mlp_forward; lg_policy_act checks its own limit */ }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_pol_err = "no HIP device: the policy kernels have no CPU path"; return nullptr; }
+  if (device_id < 0 || device_id >= ndev || hipSetDevice(device_id) != hipSuccess) { g_pol_err = "bad device"; return nullptr; }
+  lg_mlp* m = new lg_mlp();
+  m->device = device_id; m->h.L = L; m->h.act = activation;
+  for (int l = 0; l <= L; ++l) m->h.dims[l] = dims[l];
+  for (int l = 0; l < L; ++l) {
+    const int K = dims[l], N = dims[l + 1], Kp = (K + 3) & ~3, nch = (N + 15) / 16, ks = Kp / 4;
+    m->h.kpad[l] = Kp; m->h.nchunks[l] = nch;
+    // B fragment of v_mfma_f32_16x16x4_f32: lane holds B[k = lane >> 4][n = lane & 15] = W[n][k]
+    std::vector<float> tw((size_t)nch * ks * 64, 0.f), tb((size_t)nch * 16, 0.f);
+    for (int c = 0; c < nch; ++c)
+      for (int s = 0; s < ks; ++s)
+        for (int ln = 0; ln < 64; ++ln) {
+          const int nn = c * 16 + (ln & 15), kk = s * 4 + (ln >> 4);
+          if (nn < N && kk < K) tw[((size_t)c * ks + s) * 64 + ln] = weights[l][(size_t)nn * K + kk];
+        }
+    for (int i = 0; i < N; ++i) tb[i] = biases[l][i];
+    void *dw = nullptr, *db = nullptr;
+    if (hipMalloc(&dw, tw.size() * 4) != hipSuccess || hipMalloc(&db, tb.size() * 4) != hipSuccess ||
+        hipMemcpy(dw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(db, tb.data(), tb.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      if (dw) m->allocs.push_back(dw);
+      if (db) m->allocs.push_back(db);
+      g_pol_err = "weight upload failed"; lg_mlp_destroy(m); return nullptr;
+    }
+    m->allocs.push_back(dw); m->allocs.push_back(db);
+    m->h.w[l] = (const float*)dw; m->h.b[l] = (const float*)db;
+  }
+  return m;
+}
+
+#define POL_TRY(m, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (m)->err = std::string(#expr) + ": " + hipGetErrorString(_e); return LG_ERR_HIP; } } while (0)
+
+int lg_mlp_forward(lg_mlp* m, const float* x, int64_t n, float* y, void* stream) {
+  if (!m || !x || !y || n < 0) return LG_ERR_INVALID;
+  if (n == 0) return LG_OK;
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS)), dim3(256), 0, (hipStream_t)stream, m->h, x, n, y);
+  POL_TRY(m, hipGetLastError());
+  return LG_OK;
+}
+
+int lg_policy_act(lg_mlp* actor, lg_mlp* critic, const float* obs, const float* critic_obs, int64_t n, const float* std_, uint64_t seed,
+                  uint64_t call, int32_t deterministic, float* actions, float* action_mean, float* logp, float* values, void* stream) {
+  if (!actor || !critic || !obs || !critic_obs || !std_ || !actions || !action_mean || !logp || !values || n < 0) return LG_ERR_INVALID;
+  if (actor->h.dims[actor->h.L] > 32) { actor->err = "lg_policy_act supports up to 32 actions"; return LG_ERR_UNSUPPORTED; }
+  if (n == 0) return LG_OK;
+  hipLaunchKernelGGL(policy_act_kernel, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS), 2), dim3(256), 0, (hipStream_t)stream, actor->h, critic->h,
+                     obs, critic_obs, n, std_, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)call, (uint32_t)(call >> 32), deterministic,
+                     actions, action_mean, logp, values);
+  POL_TRY(actor, hipGetLastError());
+  return LG_OK;
+}
+
+int lg_compute_returns(const float* rewards, const float* dones, const float* values, const float* last_values, int32_t T, int64_t n,
+                       float gamma, float lam, int32_t normalize, float* returns, float* advantages, void* stream) {
+  if (!rewards || !dones || !values || !last_values || !returns || !advantages || T <= 0 || n <= 0) return LG_ERR_INVALID;
+  hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, dones, values, last_values, T, n,
+                     gamma, lam, returns, advantages);
+  if (normalize) hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, advantages, (int64_t)T * n);
+  return hipGetLastError() == hipSuccess ? LG_OK : LG_ERR_HIP;
+}
+
+}  // extern "C"

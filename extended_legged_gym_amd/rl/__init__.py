@@ -1,0 +1,3 @@
+"""Rollout-collection side of PPO on the GPU: `NativeActorCritic`, `compute_returns`."""
+from .policy import NativeActorCritic, NativeMLP          # noqa: F401
+from .storage import compute_returns                      # noqa: F401

@@ -1,0 +1,55 @@
+"""CPU restatement (numpy, float64 accumulation) of the rollout-collection arithmetic — TEST INFRASTRUCTURE ONLY, pinned by
+tests/golden/policy.npz (generated from the reference's vendored rsl_rl by tools/refgen/make_policy_golden.py).
+
+Follows rsl_rl/modules/actor_critic.py:42-66 (Sequential of Linear + activation), :96-136 (Normal(mean, std): log_prob,
+entropy), rsl_rl/storage/rollout_storage.py:145-167 (compute_returns)."""
+import numpy as np
+
+_ACT = {
+    "elu": lambda x: np.where(x > 0, x, np.expm1(np.minimum(x, 0))),
+    "relu": lambda x: np.maximum(x, 0),
+    "tanh": np.tanh,
+    "lrelu": lambda x: np.where(x > 0, x, 0.01 * x),
+    "selu": lambda x: 1.0507009873554805 * np.where(x > 0, x, 1.6732632423543772 * np.expm1(np.minimum(x, 0))),
+}
+
+
+def sequential_layers(state, prefix):
+    idx = sorted({int(k[len(prefix) + 1:].split(".")[0]) for k in state if k.startswith(prefix + ".") and k.endswith(".weight")})
+    return [(np.asarray(state[f"{prefix}.{i}.weight"], np.float64), np.asarray(state[f"{prefix}.{i}.bias"], np.float64)) for i in idx]
+
+
+def mlp_forward(layers, x, activation="elu"):
+    h = np.asarray(x, np.float64)
+    for i, (w, b) in enumerate(layers):
+        h = h @ w.T + b
+        if i < len(layers) - 1:
+            h = _ACT[activation](h)
+    return h
+
+
+def normal_log_prob(actions, mean, std):
+    a, m, s = (np.asarray(v, np.float64) for v in (actions, mean, std))
+    return (-((a - m) ** 2) / (2 * s * s) - np.log(s) - 0.5 * np.log(2 * np.pi)).sum(-1)
+
+
+def normal_entropy(std, n):
+    s = np.asarray(std, np.float64)
+    return np.full(n, (0.5 + 0.5 * np.log(2 * np.pi) + np.log(s)).sum())
+
+
+def compute_returns(rewards, dones, values, last_values, gamma, lam, normalize=True):
+    r, d, v = (np.asarray(x, np.float64).reshape(x.shape[0], -1) for x in (rewards, dones, values))
+    T = r.shape[0]
+    ret = np.zeros_like(v)
+    adv = 0.0
+    for t in reversed(range(T)):
+        nxt = np.asarray(last_values, np.float64).reshape(-1) if t == T - 1 else v[t + 1]
+        nt = 1.0 - d[t]
+        delta = r[t] + nt * gamma * nxt - v[t]
+        adv = delta + nt * gamma * lam * adv
+        ret[t] = adv + v[t]
+    advs = ret - v
+    if normalize:
+        advs = (advs - advs.mean()) / (advs.std(ddof=1) + 1e-8)
+    return ret, advs

@@ -61,6 +61,20 @@ def test_library_exports_every_declared_symbol_and_struct_sizes_agree():
                            ctypes.sizeof(abi.lg_terrain)]
 
 
+def test_policy_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "lgpolicy.h")).read()
+    declared = sorted(set(re.findall(r"\b(lg_[a-z_]+)\s*\(", hdr)))
+    assert sorted(abi.POLICY_SYMBOLS) == declared
+    lib = ctypes.CDLL(LIB)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    abi.declare_policy(lib)
+    body = re.search(r"enum\s+lg_activation\s*\{(.*?)\};", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    vals = {k.strip(): int(v) for k, v in (item.split("=") for item in body.split(",") if "=" in item)}
+    assert {k[len("LG_ACT_"):].lower(): v for k, v in vals.items()} == abi.ACTIVATIONS
+
+
 def test_product_has_no_path_through_the_oracle():
     """The package must never import or link the checker."""
     pkg = os.path.join(ROOT, "extended_legged_gym_amd")
