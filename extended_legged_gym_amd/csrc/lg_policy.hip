@@ -26,7 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct MlpDev {
   int L, act;
   int dims[LG_MLP_MAX_LAYERS + 1];
-  int kpad[LG_MLP_MAX_LAYERS];       // input width rounded up to 4
+  int kpad[LG_MLP_MAX_LAYERS];       // input width rounded up to 32 (eight k-steps of 4)
   int nchunks[LG_MLP_MAX_LAYERS];    // output width rounded up to 16, / 16
   const float* w[LG_MLP_MAX_LAYERS]; // tiled weights [chunk][k/4][64]
   const float* b[LG_MLP_MAX_LAYERS]; // bias, padded to 16 * nchunks
@@ -75,13 +75,32 @@ LG_DEV void mlp_tile(const MlpDev& M, const float* __restrict__ x, int64_t row0,
       const float* __restrict__ wt = M.w[l] + (size_t)c * ksteps * 64 + lane;
       const float* a0p = in + (lane & 15) * 4 + (lane >> 4);
       const float* a1p = a0p + 16 * 4;
-#pragma unroll 4
-      for (int ks = 0; ks < ksteps; ++ks) {
-        const float b = wt[(size_t)ks * 64];
-        const float a0 = a0p[ks * MLP_RS * 4], a1 = a1p[ks * MLP_RS * 4];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+      // k-steps in blocks of 8 (widths are padded to 32), two register buffers in ping-pong: the next block's eight weight
+      // fragments and sixteen activation fragments are requested BEFORE the current block's sixteen MFMAs issue (sched_barrier keeps the compiler from
+      // sinking the loads to their first use), so the L2 latency of the weight stream hides behind 512 cycles of MFMA
+      // work.  Loads are unconditional (the tail re-reads the last block): a load inside a branch is waited for at its end.
+#define MLP_BLOCK(BUF, A0, A1, NXT, NA0, NA1, KB)                                                             \
+      {                                                                                                       \
+        const int kn_ = min((KB) + 8, ksteps - 8);                                                            \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) NXT[j] = wt[(size_t)(kn_ + j) * 64];                  \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) { NA0[j] = a0p[(kn_ + j) * MLP_RS * 4]; NA1[j] = a1p[(kn_ + j) * MLP_RS * 4]; } \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], BUF[j], acc0, 0, 0, 0);                          \
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], BUF[j], acc1, 0, 0, 0);                          \
+        }                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
       }
+      float bA[8], bB[8], pA0[8], pA1[8], qA0[8], qA1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { bA[j] = wt[(size_t)j * 64]; pA0[j] = a0p[j * MLP_RS * 4]; pA1[j] = a1p[j * MLP_RS * 4]; }
+      int kb = 0;
+      for (; kb + 16 <= ksteps; kb += 16) {
+        MLP_BLOCK(bA, pA0, pA1, bB, qA0, qA1, kb)
+        MLP_BLOCK(bB, qA0, qA1, bA, pA0, pA1, kb + 8)
+      }
+      if (kb < ksteps) MLP_BLOCK(bA, pA0, pA1, bB, qA0, qA1, kb)      // odd number of blocks
+#undef MLP_BLOCK
       // epilogue: C[m = 4 * (lane >> 4) + i][col = lane & 15]
       const int col = c * 16 + (lane & 15);
       const float bias = M.b[l][col];
@@ -219,7 +238,9 @@ lg_mlp* lg_mlp_create(int32_t L, const int32_t* dims, const float* const* weight
   m->device = device_id; m->h.L = L; m->h.act = activation;
   for (int l = 0; l <= L; ++l) m->h.dims[l] = dims[l];
   for (int l = 0; l < L; ++l) {
-    const int K = dims[l], N = dims[l + 1], Kp = (K + 3) & ~3, nch = (N + 15) / 16, ks = Kp / 4;
+    const int K = dims[l], N = dims[l + 1], Kp = (K + 31) & ~31, ks = Kp / 4;
+    // hidden layers produce the next layer's whole padded input (zero weights and bias -> act(0) = 0 in the padding)
+    const int nch = l == L - 1 ? (N + 15) / 16 : ((N + 31) & ~31) / 16;
     m->h.kpad[l] = Kp; m->h.nchunks[l] = nch;
     // B fragment of v_mfma_f32_16x16x4_f32: lane holds B[k = lane >> 4][n = lane & 15] = W[n][k]
     std::vector<float> tw((size_t)nch * ks * 64, 0.f), tb((size_t)nch * 16, 0.f);
