@@ -79,6 +79,9 @@ LG_DEV void mlp_tile(const MlpDev& M, const float* __restrict__ x, int64_t row0,
       // fragments and sixteen activation fragments are requested BEFORE the current block's sixteen MFMAs issue (sched_barrier keeps the compiler from
       // sinking the loads to their first use), so the L2 latency of the weight stream hides behind 512 cycles of MFMA
       // work.  Loads are unconditional (the tail re-reads the last block): a load inside a branch is waited for at its end.
+// volatile asm keeps the two accumulator chains interleaved as written (the compiler otherwise issues eight dependent
+// MFMAs on one accumulator, then eight on the other: 40-cycle dependent latency instead of the 32-cycle issue rate)
+#define MFMA_IN_ORDER(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 #define MLP_BLOCK(BUF, A0, A1, NXT, NA0, NA1, KB)                                                             \
       {                                                                                                       \
         const int kn_ = min((KB) + 8, ksteps - 8);                                                            \
@@ -86,8 +89,8 @@ LG_DEV void mlp_tile(const MlpDev& M, const float* __restrict__ x, int64_t row0,
         _Pragma("unroll") for (int j = 0; j < 8; ++j) { NA0[j] = a0p[(kn_ + j) * MLP_RS * 4]; NA1[j] = a1p[(kn_ + j) * MLP_RS * 4]; } \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[j], BUF[j], acc0, 0, 0, 0);                          \
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[j], BUF[j], acc1, 0, 0, 0);                          \
+          MFMA_IN_ORDER(acc0, A0[j], BUF[j]);                                                                 \
+          MFMA_IN_ORDER(acc1, A1[j], BUF[j]);                                                                 \
         }                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
       }
@@ -101,6 +104,9 @@ LG_DEV void mlp_tile(const MlpDev& M, const float* __restrict__ x, int64_t row0,
       }
       if (kb < ksteps) MLP_BLOCK(bA, pA0, pA1, bB, qA0, qA1, kb)      // odd number of blocks
 #undef MLP_BLOCK
+      // the MFMAs above are opaque to the compiler's hazard recogniser: give the last one its result latency before the
+      // accumulators are read by the epilogue
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
       // epilogue: C[m = 4 * (lane >> 4) + i][col = lane & 15]
       const int col = c * 16 + (lane & 15);
       const float bias = M.b[l][col];
