@@ -420,8 +420,12 @@ LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 
   }
   sts3(cst, sl, CF_T1, lane, t1); sts3(cst, sl, CF_T2, lane, t2);
   sts3(cst, sl, CF_JK0, lane, jk[0]); sts3(cst, sl, CF_JK1, lane, jk[1]); sts3(cst, sl, CF_JK2, lane, jk[2]);
-  CS(sl, CF_ANN) = A[0][0] + cfm; CS(sl, CF_AN1) = A[1][0]; CS(sl, CF_AN2) = A[2][0];
-  CS(sl, CF_A11) = A[1][1] + cfm; CS(sl, CF_A12) = A[1][2]; CS(sl, CF_A22) = A[2][2] + cfm;
+  // the sweeps only ever divide by these: store the reciprocal of the normal row and the inverse of the 2x2 tangential
+  // block (computed once here, by whichever wave sets the slot up, instead of in each of the four sweeps)
+  const float a11 = A[1][1] + cfm, a12 = A[1][2], a22 = A[2][2] + cfm;
+  const float idet = frcp(a11 * a22 - a12 * a12);
+  CS(sl, CF_ANN) = frcp(A[0][0] + cfm); CS(sl, CF_AN1) = A[1][0]; CS(sl, CF_AN2) = A[2][0];
+  CS(sl, CF_A11) = a22 * idet; CS(sl, CF_A12) = -a12 * idet; CS(sl, CF_A22) = a11 * idet;
 }
 
 // wave-uniform: slots with at least one active contact in this wave
@@ -648,8 +652,8 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
         const V3 r = lds3(cst, sl, CF_R, lane);
         const V3 jk0 = lds3(cst, sl, CF_JK0, lane), jk1 = lds3(cst, sl, CF_JK1, lane), jk2 = lds3(cst, sl, CF_JK2, lane);
         const float l0 = CS(sl, CF_L0), l1 = CS(sl, CF_L1), l2 = CS(sl, CF_L2), bn = CS(sl, CF_BN);
-        const float Ann = CS(sl, CF_ANN), An1 = CS(sl, CF_AN1), An2 = CS(sl, CF_AN2);
-        const float A11 = CS(sl, CF_A11), A12 = CS(sl, CF_A12), A22 = CS(sl, CF_A22);
+        const float iAnn = CS(sl, CF_ANN), An1 = CS(sl, CF_AN1), An2 = CS(sl, CF_AN2);      // 1 / Ann
+        const float B11 = CS(sl, CF_A11), B12 = CS(sl, CF_A12), B22 = CS(sl, CF_A22);         // inverse of the tangential block
         float wbv[18], zcv[9];
 #pragma unroll
         for (int a = 0; a < 18; ++a) wbv[a] = CS(sl, CF_WB + a);
@@ -659,12 +663,11 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
         // velocity of the contact point
         V3 vp = v3(vB[0], vB[1], vB[2]) + cross(v3(vB[3], vB[4], vB[5]), r) + vK[0] * jk0 + vK[1] * jk1 + vK[2] * jk2;
         float u0 = dot(n, vp), u1 = dot(t1, vp), u2 = dot(t2, vp);
-        float ln = fmaxf(l0 - (u0 - bn) * frcp(Ann), 0.f);
+        float ln = fmaxf(l0 - (u0 - bn) * iAnn, 0.f);
         float dn = ln - l0;
         float w1 = u1 + An1 * dn, w2 = u2 + An2 * dn;
-        float idet = frcp(A11 * A22 - A12 * A12);
-        float n1 = l1 - (A22 * w1 - A12 * w2) * idet;
-        float n2 = l2 - (-A12 * w1 + A11 * w2) * idet;
+        float n1 = l1 - (B11 * w1 + B12 * w2);
+        float n2 = l2 - (B12 * w1 + B22 * w2);
         float lim = mu * ln, m2 = n1 * n1 + n2 * n2;
         if (m2 > lim * lim) { float sc = m2 > 0.f ? lim * __builtin_amdgcn_rsqf(m2) : 0.f; n1 *= sc; n2 *= sc; }
         float d0 = active ? dn : 0.f, d1 = active ? n1 - l1 : 0.f, d2 = active ? n2 - l2 : 0.f;
