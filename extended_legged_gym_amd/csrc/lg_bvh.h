@@ -200,3 +200,82 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
   *cp_out = bestp; *fn_out = bestn;
   return found;
 }
+
+// Two closest-point queries in ONE traversal (the collision spheres a wave tests in a substep come in neighbouring
+// pairs - two spheres of one link, or of adjacent links - whose searches visit almost the same nodes): a child is opened
+// when either query still needs it, each leaf triangle is tested against both, and each query keeps its own radius and
+// result exactly as `closest_point` would have (same tolerances, same tie rule), so the outcome per query is the
+// solo outcome.  A query with on = false is skipped.
+struct ClosestQuery { V3 p; float max_dist; bool on; bool found; V3 cp, fn; };
+LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery& B, int* visits = nullptr) {
+  float bestA = A.max_dist * A.max_dist, bestB = B.max_dist * B.max_dist, absA = -1.f, absB = -1.f;
+  bool fA = false, fB = false;
+  V3 pA = A.p, pB = B.p, cA = A.p, cB = B.p, nA = v3(0, 0, 1), nB = v3(0, 0, 1);
+  const bool onA = A.on, onB = B.on;
+  int stack_i[BVH_STACK]; float stack_k[BVH_STACK]; int sp = 0; int cur = 0;
+  if (onA || onB) while (true) {
+    bool go = false;
+    if (visits) ++*visits;
+    const float limA = onA ? bestA * (1.f + 1e-5f) + 1e-12f : -1.f, limB = onB ? bestB * (1.f + 1e-5f) + 1e-12f : -1.f;
+    if (cur >= 0) {
+      const Node4Regs n = load_node4(M.nodes, cur);
+      int cand[4]; float key[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = F4(n.child, k);
+        const float x0 = F4(n.minx, k), x1 = F4(n.maxx, k), y0 = F4(n.miny, k), y1 = F4(n.maxy, k), z0 = F4(n.minz, k), z1 = F4(n.maxz, k);
+        float dx = fmaxf(fmaxf(x0 - pA.x, 0.f), pA.x - x1), dy = fmaxf(fmaxf(y0 - pA.y, 0.f), pA.y - y1), dz = fmaxf(fmaxf(z0 - pA.z, 0.f), pA.z - z1);
+        const float kA = dx * dx + dy * dy + dz * dz;
+        dx = fmaxf(fmaxf(x0 - pB.x, 0.f), pB.x - x1); dy = fmaxf(fmaxf(y0 - pB.y, 0.f), pB.y - y1); dz = fmaxf(fmaxf(z0 - pB.z, 0.f), pB.z - z1);
+        const float kB = dx * dx + dy * dy + dz * dz;
+        const bool wantA = kA <= limA, wantB = kB <= limB;
+        key[k] = wantA && wantB ? fminf(kA, kB) : (wantA ? kA : kB);
+        cand[k] = (c != BVH4_EMPTY && (wantA || wantB)) ? c : BVH4_EMPTY;
+      }
+      go = descend4(cand, key, stack_i, stack_k, sp, cur);
+    } else {
+      const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
+      for (int i = 0; i < cnt; ++i) {
+        const float4* T = M.tris + (size_t)(first + i) * 3;
+        float4 a4 = T[0], b4 = T[1], c4 = T[2];
+        V3 a = v3(a4.x, a4.y, a4.z), b = v3(b4.x, b4.y, b4.z), cc = v3(c4.x, c4.y, c4.z);
+        V3 fn = cross(b - a, cc - a); float fl = norm(fn);
+        if (!(fl > 1e-10f)) continue;                      // zero-area faces are skipped (see closest_point)
+        const V3 nh = (1.f / fl) * fn;
+        if (onA) {
+          V3 q = closest_on_triangle(pA, a, b, cc);
+          V3 dq = pA - q; float d2 = dot(dq, dq);
+          if (d2 <= bestA * (1.f + 1e-5f) + 1e-12f) {
+            const bool strictly = !fA || d2 < bestA * (1.f - 1e-5f) - 1e-12f;
+            if (strictly) { absA = -1.f; nA = v3(0, 0, 1); }
+            float sd = dot(dq, nh);
+            float ab = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f);
+            if (ab > absA) { nA = nh; absA = ab; }
+            if (!fA || d2 < bestA) { bestA = d2; cA = q; }
+            fA = true;
+          }
+        }
+        if (onB) {
+          V3 q = closest_on_triangle(pB, a, b, cc);
+          V3 dq = pB - q; float d2 = dot(dq, dq);
+          if (d2 <= bestB * (1.f + 1e-5f) + 1e-12f) {
+            const bool strictly = !fB || d2 < bestB * (1.f - 1e-5f) - 1e-12f;
+            if (strictly) { absB = -1.f; nB = v3(0, 0, 1); }
+            float sd = dot(dq, nh);
+            float ab = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f);
+            if (ab > absB) { nB = nh; absB = ab; }
+            if (!fB || d2 < bestB) { bestB = d2; cB = q; }
+            fB = true;
+          }
+        }
+      }
+    }
+    if (go) continue;
+    bool popped = false;
+    const float lim = fmaxf(onA ? bestA * (1.f + 1e-5f) + 1e-12f : -1.f, onB ? bestB * (1.f + 1e-5f) + 1e-12f : -1.f);
+    while (sp > 0) { --sp; if (stack_k[sp] <= lim) { cur = stack_i[sp]; popped = true; break; } }
+    if (!popped) break;
+  }
+  A.found = fA; A.cp = cA; A.fn = nA; B.found = fB; B.cp = cB; B.fn = nB;
+}
+

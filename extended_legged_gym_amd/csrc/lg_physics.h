@@ -320,46 +320,74 @@ LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const Phys
 //     with that radius instead of the full reach - a foot in stance tests a handful of triangles, not the ~60 within
 //     reach.  A reset teleports the sphere; the travel term then exceeds the reach and the bound falls back to it.
 LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k,
-                                const M3& Rb, V3 pb, float* cst, int lane, float* cq = nullptr) {
+                                const M3& Rb, V3 pb, float* cst, int lane, float* cq = nullptr, unsigned long long* dbg = nullptr) {
   const int ncp = lm_.i(LM_CP_COUNT);
   const float idt_ = frcp(P.dt);
+  // slots in pairs: one BVH traversal serves two neighbouring spheres (closest_point_pair)
 #pragma unroll 1
-  for (int sl = s0; sl < s1; ++sl) {
-    CS(sl, CF_L0) = 0.f; CS(sl, CF_L1) = 0.f; CS(sl, CF_L2) = 0.f;
-    bool active = false; V3 n = v3(0, 0, 1), x = pb; float phi = 1.f, rad = 0.f;
-    if (sl < ncp) {
-      const int link = lm_.i(LM_CP_LINK + sl);
-      const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
-      rad = lm_.f(LM_CP_RADIUS + sl);
-      x = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
-      const float range = rad + P.contact_offset + LG_MESH_CONTACT_MARGIN;
-      const float reach = cq ? range + LG_MESH_CACHE_REACH : range;
-      bool query = true; float bound = reach;
-      if (cq) {
-        const float dq = CQ(sl, 3);
-        if (dq >= 0.f) {
-          const float travel = norm(x - v3(CQ(sl, 0), CQ(sl, 1), CQ(sl, 2)));
-          query = !(travel < dq - range);
-          bound = fminf(reach, dq + travel * 1.0001f + 1e-4f);
+  for (int sp0 = s0; sp0 < s1; sp0 += 2) {
+    V3 xs[2]; float rads[2], ranges[2], reaches[2]; ClosestQuery Q[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int sl = sp0 + h;
+      xs[h] = pb; rads[h] = 0.f; ranges[h] = 0.f; reaches[h] = 0.f;
+      Q[h].p = pb; Q[h].max_dist = 0.f; Q[h].on = false; Q[h].found = false; Q[h].cp = pb; Q[h].fn = v3(0, 0, 1);
+      if (sl < s1 && sl < ncp) {
+        const int link = lm_.i(LM_CP_LINK + sl);
+        const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
+        rads[h] = lm_.f(LM_CP_RADIUS + sl);
+        const V3 x = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
+        xs[h] = x;
+        const float range = rads[h] + P.contact_offset + LG_MESH_CONTACT_MARGIN;
+        const float reach = cq ? range + LG_MESH_CACHE_REACH : range;
+        ranges[h] = range; reaches[h] = reach;
+        bool query = true; float bound = reach;
+        if (cq) {
+          const float dq = CQ(sl, 3);
+          if (dq >= 0.f) {
+            const float travel = norm(x - v3(CQ(sl, 0), CQ(sl, 1), CQ(sl, 2)));
+            query = !(travel < dq - range);
+            bound = fminf(reach, dq + travel * 1.0001f + 1e-4f);
+          }
         }
+        Q[h].p = x; Q[h].max_dist = bound; Q[h].on = query;
       }
-      if (query) {
-        V3 cp, fn;
-        const bool found = closest_point(T.M, x, bound, &cp, &fn);
-        const V3 diff = x - cp; const float dist = found ? norm(diff) : reach;
+    }
+#ifdef LG_STAMPS
+    {
+      int visits = 0;
+      closest_point_pair(T.M, Q[0], Q[1], &visits);
+      // diagnostic: queries issued / traversal steps (sum and max over the wave) of workgroup 0, wave 2
+      int vmax = visits, vsum = visits;
+      for (int off = 32; off > 0; off >>= 1) { vmax = max(vmax, __shfl_xor(vmax, off)); vsum += __shfl_xor(vsum, off); }
+      const int nq = __popcll(__ballot(Q[0].on)) + __popcll(__ballot(Q[1].on));
+      if (dbg && lane == 0) { dbg[28] += nq; dbg[29] += vsum; dbg[30] += vmax; dbg[31] += 1; }
+    }
+#else
+    closest_point_pair(T.M, Q[0], Q[1]);
+#endif
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int sl = sp0 + h;
+      if (sl >= s1) continue;
+      CS(sl, CF_L0) = 0.f; CS(sl, CF_L1) = 0.f; CS(sl, CF_L2) = 0.f;
+      bool active = false; V3 n = v3(0, 0, 1); float phi = 1.f;
+      const V3 x = xs[h]; const float rad = rads[h];
+      if (Q[h].on) {
+        const V3 diff = x - Q[h].cp; const float dist = Q[h].found ? norm(diff) : reaches[h];
         if (cq) { CQ(sl, 0) = x.x; CQ(sl, 1) = x.y; CQ(sl, 2) = x.z; CQ(sl, 3) = dist; }
-        if (found && dist <= range) {
-          const float sign = dot(diff, fn) < 0.f ? -1.f : 1.f;
-          n = dist > 1e-6f ? (sign / dist) * diff : fn;
+        if (Q[h].found && dist <= ranges[h]) {
+          const float sign = dot(diff, Q[h].fn) < 0.f ? -1.f : 1.f;
+          n = dist > 1e-6f ? (sign / dist) * diff : Q[h].fn;
           phi = sign * dist - rad;
           active = phi < P.contact_offset;
         }
       }
+      CS(sl, CF_ACTIVE) = active ? 1.f : 0.f;
+      sts3(cst, sl, CF_N, lane, n);
+      sts3(cst, sl, CF_R, lane, (x - rad * n) - pb);
+      CS(sl, CF_BN) = phi >= 0.f ? -phi * idt_ : fminf(-phi * P.erp * idt_, P.max_depen);
     }
-    CS(sl, CF_ACTIVE) = active ? 1.f : 0.f;
-    sts3(cst, sl, CF_N, lane, n);
-    sts3(cst, sl, CF_R, lane, (x - rad * n) - pb);
-    CS(sl, CF_BN) = phi >= 0.f ? -phi * idt_ : fminf(-phi * P.erp * idt_, P.max_depen);
   }
 }
 

@@ -382,7 +382,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         if (!TMESH) contact_detect_begin<2, 4>(lm_, T, k, Rb, pb, pr1);
         else contact_detect_mesh(2, 4, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (TMESH) {
+#ifdef LG_STAMPS
+        contact_detect_mesh(2 * wv, 2 * wv + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc, (blockIdx.x == 0 && wv == 2) ? C->stamps : nullptr);
+#else
         contact_detect_mesh(2 * wv, 2 * wv + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
+#endif
       } else if (wv == 2) {
         contact_detect_begin<4, 6>(lm_, T, k, Rb, pb, pr2);
       } else {

@@ -41,3 +41,6 @@ calls = max(out[17], 1)
 for k, n in names.items():
     print(f"{n:40s} per substep {out[k] / calls:10.0f} cycles")
 print("active slots per wave-substep", out[16] / calls)
+pairs = max(out[31], 1)
+print(f"wave 2 of workgroup 0, per paired query: {out[28] / pairs:.1f} of 128 lane-queries issued, traversal steps: sum over lanes "
+      f"{out[29] / pairs:.0f}, max over lanes {out[30] / pairs:.1f}")
