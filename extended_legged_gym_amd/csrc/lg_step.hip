@@ -703,7 +703,19 @@ LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int
   float r[13];
   for (int i = 0; i < 13; ++i) r[i] = g.base_init_state[i];   // LR:467-489
   r[0] += o0; r[1] += o1; r[2] += o2;
-  if (g.custom_origins) { r[0] += rand_float(-0.5f, 0.5f, U[LG_RS_ROOT_XY]); r[1] += rand_float(-0.5f, 0.5f, U[LG_RS_ROOT_XY + 1]); }
+  if (g.custom_origins) {
+    r[0] += rand_float(-0.5f, 0.5f, U[LG_RS_ROOT_XY]); r[1] += rand_float(-0.5f, 0.5f, U[LG_RS_ROOT_XY + 1]);
+    if (g.reset_z_from_terrain && C->ter.mesh_type != LG_MESH_PLANE) {   // robot_batch_rollout.py:1379-1391
+      const TerrainView& T = C->ter;
+      int ix = (int)((r[0] + T.border) / T.hscale), iy = (int)((r[1] + T.border) / T.hscale);   // trunc, as .long()
+      ix = max(0, min(ix, T.rows - 2)); iy = max(0, min(iy, T.cols - 2));
+      {
+#pragma clang fp contract(off)   // two roundings, as torch (heights * vertical_scale, then + init z)
+        const float hz = (float)T.H[(size_t)ix * T.cols + iy] * T.vscale;
+        r[2] = hz + g.base_init_state[2];
+      }
+    }
+  }
   for (int i = 0; i < 6; ++i) r[7 + i] = rand_float(-0.5f, 0.5f, U[LG_RS_ROOT_VEL + i]);
   for (int i = 0; i < 13; ++i) root[i] = r[i];
   resample_commands(C, cmd, U, LG_RS_CMD_RESET);
@@ -1659,7 +1671,13 @@ __global__ __launch_bounds__(256) void sync_kernel(const DevCtx* __restrict__ C,
   o -= 3; if (o < 3) { C->proj_grav[(size_t)e * 3 + o] = C->proj_grav[(size_t)src * 3 + o]; return; }
   o -= 3; if (o < 4) { C->feet_air[(size_t)e * 4 + o] = C->feet_air[(size_t)src * 4 + o]; return; }
   o -= 4; if (o < 4) { C->feet_ctime[(size_t)e * 4 + o] = C->feet_ctime[(size_t)src * 4 + o]; return; }
-  o -= 4; if (o < 1) { for (int f = 0; f < 4; ++f) C->last_contacts[(size_t)e * 4 + f] = C->last_contacts[(size_t)src * 4 + f]; return; }
+  o -= 4; if (o < 1) {
+    for (int f = 0; f < 4; ++f) C->last_contacts[(size_t)e * 4 + f] = C->last_contacts[(size_t)src * 4 + f];
+    // termination flags: the reference's rollouts are stepped with their main (:554-594) and so raise the same contact
+    // termination; their stale flags then feed `_reward_termination` of the rollout steps (:806-809)
+    C->reset_buf[e] = C->reset_buf[src]; C->time_out[e] = C->time_out[src];
+    return;
+  }
   // body states and contact forces: what the rollouts would hold had they been stepped along with their main (the
   // reference steps every env with the main's action, :554-594); the position drift moves all bodies alike
   o -= 1; if (o < B * 13) {

@@ -107,7 +107,9 @@ class LeggedRobot(BaseTask):
         # env shards of a multi-GPU job draw from disjoint Philox streams
         seed += 1000003 * int(getattr(self.cfg, "rng_stream_offset", 0))
         self.setup = NativeSetup(self.cfg, self.sim_params, self.robot_model, terrain=self.terrain, seed=seed,
-                                 gait=self._gait_config(), num_extra_obs=self._num_extra_obs())
+                                 gait=self._gait_config(), num_extra_obs=self._num_extra_obs(),
+                                 reset_z_from_terrain=self._reset_z_from_terrain,
+                                 custom_origins=self._custom_origins_rule())
         self.core = NativeCore(self.setup, self.device)
         t = self.core.t
 
@@ -141,7 +143,13 @@ class LeggedRobot(BaseTask):
         if self.terrain is not None:
             self.height_samples = t["height_samples"]
 
+    _reset_z_from_terrain = False    # RobotBatchRollout: root z from the height sample under the reset position
+
     def _gait_config(self):
+        return None
+
+    def _custom_origins_rule(self):
+        """None: `LeggedRobot`'s rule (terrain platforms on every non-flat terrain, `:817-844`)."""
         return None
 
     def _num_extra_obs(self):

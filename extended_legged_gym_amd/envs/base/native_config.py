@@ -122,7 +122,8 @@ class NativeSetup:
     """Owns the structs plus the numpy buffers their pointers refer to (keeps them alive)."""
 
     def __init__(self, cfg, sim_params, model, terrain=None, seed=0, rng_mode=abi.LG_RNG_PHILOX, gait=None,
-                 reward_stage=None, num_extra_obs=0):
+                 reward_stage=None, num_extra_obs=0, reset_z_from_terrain=False,
+                 custom_origins=None):
         self.model_dict = model
         self.model = model_struct(model)
         dt = cfg.control.decimation * sim_params.dt
@@ -222,7 +223,11 @@ class NativeSetup:
         c.custom_origins = int(rough)
         if cfg.terrain.mesh_type in ['trimesh', 'confined_trimesh'] and getattr(cfg.terrain, "random_origins", False):
             c.custom_origins, c.curriculum = 0, 0     # origins sampled by ray casts (robot_batch_rollout.py:1105-1107)
+        if custom_origins is not None:                # env classes with their own origin rule (RobotBatchRollout)
+            c.custom_origins = int(bool(custom_origins))
+            c.curriculum = int(c.curriculum and c.custom_origins)
         c.max_terrain_level = cfg.terrain.num_rows
+        c.reset_z_from_terrain = int(bool(reset_z_from_terrain))
         init = cfg.init_state
         _fill(c.base_init_state, list(init.pos) + list(init.rot) + list(init.lin_vel) + list(init.ang_vel))
 

@@ -17,7 +17,22 @@ import torch
 from extended_legged_gym_amd.envs.base.legged_robot import LeggedRobot
 
 
+def centered_grid_origins(num_envs, spacing):
+    """Env origins on a flat ground: a grid centred on the world origin (`robot_batch_rollout.py:1264-1286`; unlike
+    `LeggedRobot`'s grid, which starts at the origin)."""
+    num_cols = int(np.floor(np.sqrt(num_envs)))
+    num_rows = int(np.ceil(num_envs / num_cols))
+    rows = (np.arange(num_rows, dtype=np.float32) - np.float32((num_rows - 1) / 2)) * np.float32(spacing)
+    cols = (np.arange(num_cols, dtype=np.float32) - np.float32((num_cols - 1) / 2)) * np.float32(spacing)
+    xx, yy = np.meshgrid(rows, cols, indexing="ij")
+    out = np.zeros((num_envs, 3), np.float32)
+    out[:, 0], out[:, 1] = xx.ravel()[:num_envs], yy.ravel()[:num_envs]
+    return out
+
+
 class RobotBatchRollout(LeggedRobot):
+    _reset_z_from_terrain = True     # `_reset_root_states` (`:1366-1405`)
+
     def __init__(self, cfg, sim_params, physics_engine, sim_device, headless):
         self.num_main_envs = cfg.env.num_envs
         self.num_rollout_per_main = cfg.env.rollout_envs
@@ -50,6 +65,36 @@ class RobotBatchRollout(LeggedRobot):
     def _init_buffers(self):
         super()._init_buffers()
         self._init_env_indices()
+
+    def _custom_origins_rule(self):
+        """Terrain cells only on mesh terrains without random origins; a height field gets the flat grid (`:1102-1264`)."""
+        t = self.cfg.terrain
+        return t.mesh_type in ["trimesh", "confined_trimesh"] and not getattr(t, "random_origins", False)
+
+    def _get_env_origins(self):
+        """Origins of all `total_num_envs` envs (`:1095-1286`): on a mesh terrain every main env draws a terrain cell
+        and its rollouts share it; on flat ground (and, as in the reference, on a height field) a centred grid."""
+        t = self.core.t
+        self.env_origins = t["env_origins"]
+        mesh = self.cfg.terrain.mesh_type in ["trimesh", "confined_trimesh"]
+        if mesh and getattr(self.cfg.terrain, "random_origins", False):
+            self.custom_origins = False
+            self._sample_random_origins()
+        elif mesh:
+            self.custom_origins = True
+            R, T = self.cfg.env.rollout_envs, self.num_envs
+            self.terrain_levels, self.terrain_types = t["terrain_levels"], t["terrain_types"]
+            lv = torch.randint(0, min(self.cfg.terrain.max_init_terrain_level + 1, self.cfg.terrain.num_rows), (T,))
+            ty = torch.randint(0, self.cfg.terrain.num_cols, (T,))
+            main_of = torch.arange(T) - torch.arange(T) % (1 + R)
+            self.terrain_levels.copy_(lv[main_of].to(self.device))
+            self.terrain_types.copy_(ty[main_of].to(self.device))
+            self.max_terrain_level = self.cfg.terrain.num_rows
+            self.terrain_origins = t["terrain_origins"]
+            self.env_origins[:] = self.terrain_origins[self.terrain_levels, self.terrain_types]
+        else:
+            self.custom_origins = False
+            self.env_origins.copy_(torch.from_numpy(centered_grid_origins(self.num_envs, self.cfg.env.env_spacing)))
 
     # ------------------------------------------------------------------ stepping
     def step(self, actions):

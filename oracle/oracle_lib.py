@@ -44,6 +44,8 @@ def lib():
         L.lgo_debug_terrain.argtypes = [vp, C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.lgo_set_extra_obs.argtypes = [vp, vp]
         L.lgo_step_subset.argtypes = [vp, vp, vp, C.c_int32, C.c_int32]
+        L.lgo_step_subset_physics.argtypes = [vp, vp, vp, C.c_int32]
+        L.lgo_post_physics_subset.argtypes = [vp, vp, C.c_int32, C.c_int32]
         L.lgo_sync_main_to_rollout.argtypes = [vp, C.c_int32, C.c_float, C.c_uint32]
         L.lgo_raycast_bruteforce.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_float, vp, vp]
         L.lgo_set_reward_terms.argtypes = [vp, C.c_int32, vp, vp]
@@ -98,6 +100,10 @@ class OracleEnv:
         a, p = self._f(actions)
         ids = np.ascontiguousarray(env_ids, dtype=np.int32)
         return self.L.lgo_step_subset(self.ctx, p, ids.ctypes.data_as(C.c_void_p), len(ids), int(rollout_mode))
+
+    def post_physics_subset(self, env_ids, rollout_mode):
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        return self.L.lgo_post_physics_subset(self.ctx, ids.ctypes.data_as(C.c_void_p), len(ids), int(rollout_mode))
 
     def sync_main_to_rollout(self, rollouts_per_main, drift=0.0, call=0):
         return self.L.lgo_sync_main_to_rollout(self.ctx, int(rollouts_per_main), float(drift), int(call))

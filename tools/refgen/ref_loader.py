@@ -21,6 +21,9 @@ from unittest.mock import MagicMock
 import numpy as np
 import torch
 
+# /root/reference must stay untouched: importing from it must not drop __pycache__ directories next to its sources.
+sys.dont_write_bytecode = True
+
 REF_ROOT = "/root/reference"
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -145,6 +148,7 @@ class FakeGym:
     def refresh_net_contact_force_tensor(self, sim): pass
     def refresh_rigid_body_state_tensor(self, sim): pass
     def set_dof_actuation_force_tensor(self, sim, t): self.last_torques = t.clone()
+    def set_dof_actuation_force_tensor_indexed(self, sim, t, ids, n): self.last_torques = t.clone()
     def set_dof_state_tensor_indexed(self, *a): pass
     def set_actor_root_state_tensor_indexed(self, *a): pass
     def set_actor_root_state_tensor(self, *a): pass
