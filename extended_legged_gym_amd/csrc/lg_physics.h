@@ -9,9 +9,12 @@
 //
 // Replaces gym.simulate (reference legged_robot.py:100; PhysX, closed): same tensor contract (:564-584), own model:
 // composite-rigid-body mass matrix + recursive Newton-Euler bias (spatial quantities about the base origin P, world
-// axes), sphere-vs-heightfield contacts solved at velocity level by projected Gauss-Seidel (the four lanes' contacts of
-// one slot relax simultaneously, slots sequentially), Coulomb friction disc, semi-implicit Euler.
+// axes), sphere-vs-heightfield contacts solved at velocity level by projected Gauss-Seidel (every leg walks the list of
+// its active contacts; the four legs' j-th entries relax simultaneously), Coulomb friction disc, semi-implicit Euler.
 #pragma once
+#ifndef LG_AB
+#define LG_AB 0
+#endif
 #include "lg_device.h"
 #include "lg_bvh.h"
 
@@ -201,11 +204,24 @@ LG_DEV void terrain_query(const TerrainView& T, float x, float y, float* h, V3* 
   terrain_eval(T, c, h, n);
 }
 
-// per-contact-slot scratch in LDS, laid out [slot][field][lane] (lane-contiguous: conflict-free ds_read_b32)
-enum { CF_N = 0, CF_T1 = 3, CF_T2 = 6, CF_R = 9, CF_JK0 = 12, CF_JK1 = 15, CF_JK2 = 18,
-       CF_ANN = 21, CF_AN1, CF_AN2, CF_A11, CF_A12, CF_A22, CF_BN, CF_L0, CF_L1, CF_L2, CF_ACTIVE,
-       CF_WB = 32 /* 3 x 6: base response per unit contact-frame impulse */, CF_ZC = 50 /* 3 x 3: Mkk^-1 J_k^T */, CF_FIELDS = 60 };
-#define CS(slot, f) cst[((slot) * CF_FIELDS + (f)) * 64 + lane]
+// per-contact-slot scratch in LDS, laid out [slot][lane][field]: one lane's record of a slot is 60 contiguous floats
+// (240 B, 16-B aligned), so the sweeps fetch it with 15 ds_read_b128 instead of 59 ds_read_b32 -- a lone wave on a SIMD
+// gets a fifth of the LDS rate on 4-byte reads and the full rate on 16-byte ones (MI355X_MICROARCH.md, LDS).  Rows of
+// 60 dwords put the 16 lanes of every ds_read_b128 lane group on 16 distinct 4-bank sets: conflict-free.
+// fields 0..11 are written by the contact detection (and the multipliers by the sweeps), 12..59 by the set-up: each block
+// is a whole number of 16-B units
+enum { CF_N = 0, CF_R = 3, CF_BN = 6, CF_ACTIVE = 7, CF_L0 = 8, CF_L1 = 9, CF_L2 = 10, /* 11: pad */
+       CF_SETUP = 12, CF_T1 = 12, CF_T2 = 15, CF_JK0 = 18, CF_JK1 = 21, CF_JK2 = 24,
+       CF_ANN = 27, CF_AN1 = 28, CF_AN2 = 29, CF_A11 = 30, CF_A12 = 31, CF_A22 = 32,
+       CF_WB = 33 /* 3 x 6: base response per unit contact-frame impulse */, CF_ZC = 51 /* 3 x 3: Mkk^-1 J_k^T */, CF_FIELDS = 60 };
+#define CS(slot, f) cst[((slot) * 64 + lane) * CF_FIELDS + (f)]
+static_assert(CF_FIELDS % 4 == 0 && (CF_FIELDS / 4) % 2 == 1, "slot rows: 16-B aligned, odd number of 16-B units (bank spread)");
+// the whole record of one slot, 15 x 16 B
+LG_DEV void load_slot_record(const float* cst, int slot, int lane, float rec[CF_FIELDS]) {
+  const float4* p = reinterpret_cast<const float4*>(&CS(slot, 0));
+#pragma unroll
+  for (int i = 0; i < CF_FIELDS / 4; ++i) { float4 v = p[i]; rec[4 * i] = v.x; rec[4 * i + 1] = v.y; rec[4 * i + 2] = v.z; rec[4 * i + 3] = v.w; }
+}
 LG_DEV V3 lds3(const float* cst, int slot, int f, int lane) { return v3(CS(slot, f), CS(slot, f + 1), CS(slot, f + 2)); }
 LG_DEV void sts3(float* cst, int slot, int f, int lane, V3 a) { CS(slot, f) = a.x; CS(slot, f + 1) = a.y; CS(slot, f + 2) = a.z; }
 
@@ -401,6 +417,8 @@ LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 
   if (sl < ncp) { int link = lm_.i(LM_CP_LINK + sl); lk = link < 0 ? -1 : (link > 2 ? 2 : link); }
   const V3 n = lds3(cst, sl, CF_N, lane), r = lds3(cst, sl, CF_R, lane);
   const V3 p = r + pb;
+  float out[CF_FIELDS - CF_SETUP];   // the set-up block of the slot record, stored below as 12 x 16 B
+#define OUT(f) out[(f) - CF_SETUP]
   // contact frame and Jacobian pieces (computed on every lane of the wave; inactive lanes carry harmless values)
   V3 a0 = fabsf(n.x) < 0.57735f ? v3(1, 0, 0) : v3(0, 1, 0);
   V3 t1 = cross(a0, n); t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
@@ -422,14 +440,14 @@ LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 
     for (int a = 0; a < 6; ++a) g[a] -= Mbk[a][0] * z[0] + Mbk[a][1] * z[1] + Mbk[a][2] * z[2];
     symv6(Si, g, Wb[c]);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) CS(sl, CF_WB + 6 * c + a) = Wb[c][a];
+    for (int a = 0; a < 6; ++a) OUT(CF_WB + 6 * c + a) = Wb[c][a];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       float w = z[j];
 #pragma unroll
       for (int a = 0; a < 6; ++a) w -= Y[j][a] * Wb[c][a];
       Wk[c][j] = w;
-      CS(sl, CF_ZC + 3 * c + j) = z[j];
+      OUT(CF_ZC + 3 * c + j) = z[j];
     }
   }
   float A[3][3];
@@ -446,14 +464,33 @@ LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 
       A[b][c] = sacc;
     }
   }
-  sts3(cst, sl, CF_T1, lane, t1); sts3(cst, sl, CF_T2, lane, t2);
-  sts3(cst, sl, CF_JK0, lane, jk[0]); sts3(cst, sl, CF_JK1, lane, jk[1]); sts3(cst, sl, CF_JK2, lane, jk[2]);
+  OUT(CF_T1) = t1.x; OUT(CF_T1 + 1) = t1.y; OUT(CF_T1 + 2) = t1.z; OUT(CF_T2) = t2.x; OUT(CF_T2 + 1) = t2.y; OUT(CF_T2 + 2) = t2.z;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { OUT(CF_JK0 + 3 * j) = jk[j].x; OUT(CF_JK0 + 3 * j + 1) = jk[j].y; OUT(CF_JK0 + 3 * j + 2) = jk[j].z; }
   // the sweeps only ever divide by these: store the reciprocal of the normal row and the inverse of the 2x2 tangential
   // block (computed once here, by whichever wave sets the slot up, instead of in each of the four sweeps)
   const float a11 = A[1][1] + cfm, a12 = A[1][2], a22 = A[2][2] + cfm;
   const float idet = frcp(a11 * a22 - a12 * a12);
-  CS(sl, CF_ANN) = frcp(A[0][0] + cfm); CS(sl, CF_AN1) = A[1][0]; CS(sl, CF_AN2) = A[2][0];
-  CS(sl, CF_A11) = a22 * idet; CS(sl, CF_A12) = -a12 * idet; CS(sl, CF_A22) = a11 * idet;
+  OUT(CF_ANN) = frcp(A[0][0] + cfm); OUT(CF_AN1) = A[1][0]; OUT(CF_AN2) = A[2][0];
+  OUT(CF_A11) = a22 * idet; OUT(CF_A12) = -a12 * idet; OUT(CF_A22) = a11 * idet;
+#undef OUT
+  float4* dst = reinterpret_cast<float4*>(&CS(sl, CF_SETUP));
+#pragma unroll
+  for (int i = 0; i < (CF_FIELDS - CF_SETUP) / 4; ++i) dst[i] = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+}
+
+// per lane: its active slots packed four bits each, lowest first; *count = how many.  The sweeps walk these lists, so a
+// sweep takes max-over-lanes(count) steps instead of one step per slot that is active anywhere in the wave.
+LG_DEV unsigned active_slot_list(const float* cst, int lane, int* count) {
+  unsigned list = 0; int n = 0;
+#pragma unroll
+  for (int sl = 0; sl < LG_MAX_CP; ++sl) {
+    const bool a = CS(sl, CF_ACTIVE) != 0.f;
+    list |= a ? (unsigned)sl << (4 * n) : 0u;
+    n += a ? 1 : 0;
+  }
+  *count = n;
+  return list;
 }
 
 // wave-uniform: slots with at least one active contact in this wave
@@ -469,25 +506,35 @@ LG_DEV unsigned active_slot_mask(const float* cst, int lane) {
 struct SlotShare { int n, me; };
 // (Mi 6 | Mbk 18 | Y 18 | Si 21) of every lane, published by the main wave for the helper waves: [field][lane]
 #define XS_FIELDS 63
+#define XS_STRIDE 68   // dwords per lane: 16-B aligned rows, 17 (odd) 16-B units -> conflict-free ds_read/write_b128
 LG_DEV void publish_mass_factors(float* xs, int lane, const float Mi[6], const float Mbk[6][3], const float Y[3][6], const float Si[21]) {
+  float rec[64];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) xs[i * 64 + lane] = Mi[i];
+  for (int i = 0; i < 6; ++i) rec[i] = Mi[i];
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { xs[(6 + a * 3 + j) * 64 + lane] = Mbk[a][j]; xs[(24 + j * 6 + a) * 64 + lane] = Y[j][a]; }
+    for (int j = 0; j < 3; ++j) { rec[6 + a * 3 + j] = Mbk[a][j]; rec[24 + j * 6 + a] = Y[j][a]; }
 #pragma unroll
-  for (int i = 0; i < 21; ++i) xs[(42 + i) * 64 + lane] = Si[i];
+  for (int i = 0; i < 21; ++i) rec[42 + i] = Si[i];
+  rec[63] = 0.f;
+  float4* p = reinterpret_cast<float4*>(xs + lane * XS_STRIDE);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) p[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
 }
 LG_DEV void fetch_mass_factors(const float* xs, int lane, float Mi[6], float Mbk[6][3], float Y[3][6], float Si[21]) {
+  float rec[64];
+  const float4* p = reinterpret_cast<const float4*>(xs + lane * XS_STRIDE);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) Mi[i] = xs[i * 64 + lane];
+  for (int i = 0; i < 16; ++i) { float4 v = p[i]; rec[4 * i] = v.x; rec[4 * i + 1] = v.y; rec[4 * i + 2] = v.z; rec[4 * i + 3] = v.w; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Mi[i] = rec[i];
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { Mbk[a][j] = xs[(6 + a * 3 + j) * 64 + lane]; Y[j][a] = xs[(24 + j * 6 + a) * 64 + lane]; }
+    for (int j = 0; j < 3; ++j) { Mbk[a][j] = rec[6 + a * 3 + j]; Y[j][a] = rec[24 + j * 6 + a]; }
 #pragma unroll
-  for (int i = 0; i < 21; ++i) Si[i] = xs[(42 + i) * 64 + lane];
+  for (int i = 0; i < 21; ++i) Si[i] = rec[42 + i];
 }
 
 // One physics step of length P.dt for the env this quad owns.  tau_fn(tau[3]) delivers this leg's joint torques; it is
@@ -593,7 +640,15 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   const float idt_ = frcp(dt);
   const unsigned slot_mask = active_slot_mask(cst, lane);
 #ifdef LG_STAMPS
-  if (stamps) { stamps[16] += __popc(slot_mask); stamps[17] += 1; unsigned long long am = 0; for (int sl = 0; sl < LG_MAX_CP; ++sl) am += __popcll(__ballot(CS(sl, CF_ACTIVE) != 0.f)); stamps[18] += am; }
+  {  // ballots by the whole wave, accumulation by the stamping lane
+    unsigned long long am = 0, g4 = 0;
+    for (int sl = 0; sl < LG_MAX_CP; ++sl) {
+      const unsigned long long b = __ballot(CS(sl, CF_ACTIVE) != 0.f);
+      am += __popcll(b);
+      for (int w = 0; w < 4; ++w) g4 += ((b >> (16 * w)) & 0xffffull) ? 1 : 0;
+    }
+    if (stamps) { stamps[16] += __popc(slot_mask); stamps[17] += 1; stamps[18] += am; stamps[28] += g4; }
+  }
 #endif
   STAMP(5);
   // pass B: per-contact solver data, only for slots some lane of the wave needs.  With helper waves the active slots are
@@ -650,6 +705,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     jl_any |= jl_act[j];
   }
   const bool jl_wave = __ballot(jl_any) != 0ull;
+  // (skipping, wave-uniformly, the rows no lane needs was measured: +2 us on the kernel -- the branches cost more than the rows)
   if (jl_wave) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -667,26 +723,32 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   }
 
   // ---------------------------------------------------------------- projected Gauss-Seidel
+  int my_count; const unsigned my_list = active_slot_list(cst, lane, &my_count);
+  int my_steps = 0;                                   // wave-uniform: the longest list
+#pragma unroll
+  for (int j = 0; j < LG_MAX_CP; ++j) my_steps += __ballot(my_count > j) != 0ull ? 1 : 0;
   if (slot_mask || jl_wave) {
 #pragma unroll 1
     for (int it = 0; it < P.iters; ++it) {
+      // every lane walks the list of its own active slots; step j relaxes the j-th active contact of each of the four
+      // legs together (Jacobi across the quad, Gauss-Seidel along the lists).  A sweep takes max-over-lanes(list length)
+      // steps -- measured 2.3 on the headline workload against 3.0 slots that are active somewhere in the wave.
 #pragma unroll 1
-      for (int sl = 0; sl < LG_MAX_CP; ++sl) {
-        if (!((slot_mask >> sl) & 1u)) continue;
-        // the whole slot record first (59 LDS reads in flight, one wait), then arithmetic only: read-next-to-use costs
-        // an LDS round trip at every step of this dependent chain
-        const bool active = CS(sl, CF_ACTIVE) != 0.f;
-        const V3 n = lds3(cst, sl, CF_N, lane), t1 = lds3(cst, sl, CF_T1, lane), t2 = lds3(cst, sl, CF_T2, lane);
-        const V3 r = lds3(cst, sl, CF_R, lane);
-        const V3 jk0 = lds3(cst, sl, CF_JK0, lane), jk1 = lds3(cst, sl, CF_JK1, lane), jk2 = lds3(cst, sl, CF_JK2, lane);
-        const float l0 = CS(sl, CF_L0), l1 = CS(sl, CF_L1), l2 = CS(sl, CF_L2), bn = CS(sl, CF_BN);
-        const float iAnn = CS(sl, CF_ANN), An1 = CS(sl, CF_AN1), An2 = CS(sl, CF_AN2);      // 1 / Ann
-        const float B11 = CS(sl, CF_A11), B12 = CS(sl, CF_A12), B22 = CS(sl, CF_A22);         // inverse of the tangential block
-        float wbv[18], zcv[9];
-#pragma unroll
-        for (int a = 0; a < 18; ++a) wbv[a] = CS(sl, CF_WB + a);
-#pragma unroll
-        for (int a = 0; a < 9; ++a) zcv[a] = CS(sl, CF_ZC + a);
+      for (int step = 0; step < my_steps; ++step) {
+        const bool active = step < my_count;
+        const int sl = active ? (int)((my_list >> (4 * step)) & 0xfu) : 0;   // idle lanes read slot 0 and apply nothing
+        // the whole slot record first (15 x 16-B LDS reads in flight, one wait), then arithmetic only: read-next-to-use
+        // costs an LDS round trip at every step of this dependent chain
+        float rec[CF_FIELDS];
+        load_slot_record(cst, sl, lane, rec);
+        const V3 n = v3(rec[CF_N], rec[CF_N + 1], rec[CF_N + 2]), t1 = v3(rec[CF_T1], rec[CF_T1 + 1], rec[CF_T1 + 2]);
+        const V3 t2 = v3(rec[CF_T2], rec[CF_T2 + 1], rec[CF_T2 + 2]), r = v3(rec[CF_R], rec[CF_R + 1], rec[CF_R + 2]);
+        const V3 jk0 = v3(rec[CF_JK0], rec[CF_JK0 + 1], rec[CF_JK0 + 2]), jk1 = v3(rec[CF_JK1], rec[CF_JK1 + 1], rec[CF_JK1 + 2]);
+        const V3 jk2 = v3(rec[CF_JK2], rec[CF_JK2 + 1], rec[CF_JK2 + 2]);
+        const float l0 = rec[CF_L0], l1 = rec[CF_L1], l2 = rec[CF_L2], bn = rec[CF_BN];
+        const float iAnn = rec[CF_ANN], An1 = rec[CF_AN1], An2 = rec[CF_AN2];      // 1 / Ann
+        const float B11 = rec[CF_A11], B12 = rec[CF_A12], B22 = rec[CF_A22];         // inverse of the tangential block
+        const float* wbv = rec + CF_WB; const float* zcv = rec + CF_ZC;
         __builtin_amdgcn_sched_barrier(0);
         // velocity of the contact point
         V3 vp = v3(vB[0], vB[1], vB[2]) + cross(v3(vB[3], vB[4], vB[5]), r) + vK[0] * jk0 + vK[1] * jk1 + vK[2] * jk2;

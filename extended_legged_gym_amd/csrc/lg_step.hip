@@ -299,11 +299,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
-  __shared__ float cst[LG_MAX_CP * CF_FIELDS * 64];
+  __shared__ __attribute__((aligned(16))) float cst[LG_MAX_CP * CF_FIELDS * 64];
   __shared__ float lmod[LM_FIELDS * 4];
   const float* __restrict__ wlstm = C->lstm_w;
   __shared__ float xq[3][64], xqd[3][64], xtau[3][64], xroot[13][64], xbias[9][64];
-  __shared__ float xs[XS_FIELDS * 64];              // main wave's mass-matrix factors for the helpers' share of the contact set-up
+  __shared__ __attribute__((aligned(16))) float xs[XS_STRIDE * 64];              // main wave's mass-matrix factors for the helpers' share of the contact set-up
   __shared__ float cqc[TMESH ? LG_MAX_CP * 4 * 64 : 1];   // mesh terrains: last closest-point query of every collision sphere
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // row kq of the launch <-> env e (identity, or ids[kq] for subset stepping: main-only / rollout-only steps)
