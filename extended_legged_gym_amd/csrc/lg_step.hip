@@ -175,6 +175,63 @@ LG_DEV float lstm_actuator1(const float* __restrict__ W, float x0, float x1, flo
   return out_scale * o;       // no torque clip on this path (anymal.py:101-102)
 }
 
+// The same network in two halves for the actuator waves of the multi-wave kernel.  The recurrent terms of BOTH layers
+// (bias + W_hh h) depend only on the hidden state left by the previous substep, so they are evaluated while the main
+// wave runs its Gauss-Seidel sweeps (the actuator waves have nothing else to do then); what stays on the critical path
+// in front of the rendezvous is the input part: 2 of 10 columns of layer 0 and 8 of 16 of layer 1, plus the gates.
+struct LstmPre { v4f a0[8], a1[8]; };
+LG_DEV void lstm_recurrent_part(const float* __restrict__ W, const float* h0, const float* h1, LstmPre& pre) {
+  const v4f* B0 = (const v4f*)(W + LW_B0); const v4f* H0 = (const v4f*)(W + LW_H0);
+  const v4f* B1 = (const v4f*)(W + LW_B1); const v4f* H1 = (const v4f*)(W + LW_H1);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v4f w = B0[k];
+    v2f a_if = w.xy, a_go = w.zw;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      w = H0[8 * k + kk];
+      a_if = __builtin_elementwise_fma(w.xy, splat2(h0[kk]), a_if); a_go = __builtin_elementwise_fma(w.zw, splat2(h0[kk]), a_go);
+    }
+    pre.a0[k] = (v4f){a_if.x, a_if.y, a_go.x, a_go.y};
+    w = B1[k];
+    a_if = w.xy; a_go = w.zw;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      w = H1[8 * k + kk];
+      a_if = __builtin_elementwise_fma(w.xy, splat2(h1[kk]), a_if); a_go = __builtin_elementwise_fma(w.zw, splat2(h1[kk]), a_go);
+    }
+    pre.a1[k] = (v4f){a_if.x, a_if.y, a_go.x, a_go.y};
+  }
+}
+LG_DEV float lstm_input_part(const float* __restrict__ W, float x0, float x1, const LstmPre& pre, float* h0, float* c0, float* h1,
+                             float* c1, float out_scale) {
+  const v4f* X0 = (const v4f*)(W + LW_X0); const v4f* I1 = (const v4f*)(W + LW_I1);
+  float hn0[8], hn1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v2f a_if = pre.a0[k].xy, a_go = pre.a0[k].zw;
+    v4f w = X0[2 * k]; a_if = __builtin_elementwise_fma(w.xy, splat2(x0), a_if); a_go = __builtin_elementwise_fma(w.zw, splat2(x0), a_go);
+    w = X0[2 * k + 1]; a_if = __builtin_elementwise_fma(w.xy, splat2(x1), a_if); a_go = __builtin_elementwise_fma(w.zw, splat2(x1), a_go);
+    float cn = fast_sigmoid(a_if.y) * c0[k] + fast_sigmoid(a_if.x) * fast_tanh(a_go.x);
+    c0[k] = cn; hn0[k] = fast_sigmoid(a_go.y) * fast_tanh(cn);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v2f a_if = pre.a1[k].xy, a_go = pre.a1[k].zw;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      v4f w = I1[8 * k + kk];
+      a_if = __builtin_elementwise_fma(w.xy, splat2(hn0[kk]), a_if); a_go = __builtin_elementwise_fma(w.zw, splat2(hn0[kk]), a_go);
+    }
+    float cn = fast_sigmoid(a_if.y) * c1[k] + fast_sigmoid(a_if.x) * fast_tanh(a_go.x);
+    c1[k] = cn; hn1[k] = fast_sigmoid(a_go.y) * fast_tanh(cn);
+  }
+  float o = W[LW_OUT + 8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { o += W[LW_OUT + k] * hn1[k]; h0[k] = hn0[k]; h1[k] = hn1[k]; }
+  return out_scale * o;
+}
+
 // the three joints of this lane's leg (single-wave builds: lg_compute_torques, LG_SPLIT=0)
 LG_DEV void lstm_actuator3(const float* __restrict__ W, const float x0[3], const float x1[3], LegActuator& A, float out_scale,
                            float tau[3]) {
@@ -296,6 +353,8 @@ LG_DEV void mesh_cache_io(const DevCtx* __restrict__ C, float* cqc, int e, int l
 template <int MODE, bool TMESH>
 __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, int nact,
                                                       const int32_t* __restrict__ ids, int n) {
+  // contact-detection split of a heightfield step with actuator waves (see the helper loop); mesh terrains: two slots a wave
+  constexpr int DS0 = 2, DS1 = 4, DS2 = 6;   // (1/2/2/3 and 0/2/3/3 splits measured after the network was halved: no change)
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
@@ -352,6 +411,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     unsigned long long* stamps = (blockIdx.x == 0 && lane == 0 && wv == 2) ? C->stamps : nullptr;
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
+    LstmPre lpre;
+    if (net) { int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); lstm_recurrent_part(wlstm + zero, h0, h1, lpre); }
 #pragma unroll 1
     for (int sub = 0; sub < nsub; ++sub) {
       lds_barrier();                                   // (A) main wave has published root, q, qd of this substep
@@ -371,7 +432,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       STAMP(23);
       // heightfield terrains: two slots per wave (the main wave takes slots 0, 1); this wave issues its height-sample
       // loads now and uses them after the actuator network
-      ContactProbe<2, 4> pr1; ContactProbe<4, 6> pr2; ContactProbe<6, 8> pr3;
+      // slot ranges [DS0, DS1) wave 1 (which also has the leg bias), [DS1, DS2) wave 2, [DS2, 8) wave 3; the main wave
+      // takes [0, DS0) while it waits for nothing else
+      ContactProbe<DS0, DS1> pr1; ContactProbe<DS1, DS2> pr2; ContactProbe<DS2, 8> pr3;
       static_assert(LG_MAX_CP == 8, "slot split assumes 8 contact slots");
       if (wv == 1) {
         float bk[3]; V3 Fs, Ns;
@@ -379,7 +442,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         xbias[0][lane] = bk[0]; xbias[1][lane] = bk[1]; xbias[2][lane] = bk[2];
         xbias[3][lane] = Fs.x; xbias[4][lane] = Fs.y; xbias[5][lane] = Fs.z;
         xbias[6][lane] = Ns.x; xbias[7][lane] = Ns.y; xbias[8][lane] = Ns.z;
-        if (!TMESH) contact_detect_begin<2, 4>(lm_, T, k, Rb, pb, pr1);
+        if (!TMESH) contact_detect_begin<DS0, DS1>(lm_, T, k, Rb, pb, pr1);
         else contact_detect_mesh(2, 4, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (TMESH) {
 #ifdef LG_STAMPS
@@ -388,9 +451,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         contact_detect_mesh(2 * wv, 2 * wv + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
 #endif
       } else if (wv == 2) {
-        contact_detect_begin<4, 6>(lm_, T, k, Rb, pb, pr2);
+        contact_detect_begin<DS1, DS2>(lm_, T, k, Rb, pb, pr2);
       } else {
-        contact_detect_begin<6, 8>(lm_, T, k, Rb, pb, pr3);
+        contact_detect_begin<DS2, 8>(lm_, T, k, Rb, pb, pr3);
       }
       STAMP(24);
       if (net) {
@@ -398,11 +461,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         // an opaque zero keeps the ~60 weight addresses from being hoisted out of the substep loop as loop invariants
         // (they would fill the SGPR file and spill): inside the loop they fold into the s_load immediate offsets
         int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-        xtau[j][lane] = lstm_actuator1(wlstm + zero, x0, x1, h0, c0, h1, c1, g.actuator_out_scale);
+        xtau[j][lane] = lstm_input_part(wlstm + zero, x0, x1, lpre, h0, c0, h1, c1, g.actuator_out_scale);
       }
-      if (!TMESH && wv == 1) contact_detect_finish<2, 4>(lm_, T, P, pb, pr1, cst, lane);
-      else if (!TMESH && wv == 2) contact_detect_finish<4, 6>(lm_, T, P, pb, pr2, cst, lane);
-      else if (!TMESH && wv == 3) contact_detect_finish<6, 8>(lm_, T, P, pb, pr3, cst, lane);
+      if (!TMESH && wv == 1) contact_detect_finish<DS0, DS1>(lm_, T, P, pb, pr1, cst, lane);
+      else if (!TMESH && wv == 2) contact_detect_finish<DS1, DS2>(lm_, T, P, pb, pr2, cst, lane);
+      else if (!TMESH && wv == 3) contact_detect_finish<DS2, 8>(lm_, T, P, pb, pr3, cst, lane);
       STAMP(25);
       lds_barrier();                                   // (A2) bias, contact detection, torques | mass-matrix factors
       STAMP(26);
@@ -423,6 +486,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       }
       STAMP(27);
       lds_barrier();                                   // (A3) slot table complete
+      if (net && sub + 1 < nsub) {                     // while the main wave sweeps: recurrent half of the next substep's network
+        int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+        lstm_recurrent_part(wlstm + zero, h0, h1, lpre);
+      }
     }
     lds_barrier();                                     // (F) main wave has published the final state of the step
     if (TMESH && valid) mesh_cache_io<false>(C, cqc, e, l, lane, 2 * wv);
@@ -540,7 +607,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     };
     auto share_fn = [&]() { if (helpers) lds_barrier(); };   // (A3) every wave has finished its slots
     const SlotShare share{helpers ? 4 : 1, 0};
-    physics_substep<TMESH, 2>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
+    physics_substep<TMESH, DS0>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
                               sub == nsub - 1 ? fbody : nullptr, stamps, (TMESH && helpers) ? cqc : nullptr);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();

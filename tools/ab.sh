@@ -3,7 +3,7 @@
 n=${1:-3}
 root=$(cd "$(dirname "$0")/.." && pwd)
 for i in $(seq $n); do
-  for v in 0 1; do
+  for v in ${AB_VARIANTS:-0 1}; do
     LGSTEP_LIB=$root/extended_legged_gym_amd/csrc/liblgstep_ab$v.so python $root/bench.py 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
