@@ -8,9 +8,10 @@
 //                    registers/LDS; state is read once and written once per policy step.
 //   post_kernel      4 envs per 256-thread workgroup, one wave per env: rows staged in LDS with one round of loads,
 //                    cooperative terrain height scan, the post-physics logic in lane-parallel stages that keep the
-//                    reference's order of side effects, observation rows with noise.
-//   finalize_kernel  one workgroup: episode statistics of the step, rows of the workgroups that reset an env added in
-//                    fixed order (deterministic); also closes lg_reset_idx.
+//                    reference's order of side effects, observation rows with noise; the last workgroup to arrive
+//                    (sharded device-scope arrival counters) publishes the episode statistics of the step, summed
+//                    with integer atomics (deterministic).
+//   finalize_kernel  one workgroup: the same statistics step behind lg_reset_idx.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,6 +51,8 @@ struct DevCtx {
   float* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
   float* lvl_part;     // [nblocks] : per-workgroup sum of terrain levels
   unsigned* part_flag; // [nblocks] : 1 when some env of the workgroup was reset in this step (its partials row is valid)
+  long long* acc;      // [PART_STRIDE] fixed-point (x 2^24) sums of the reset envs' rows of one post-kernel launch
+  unsigned* tickets;   // 9 counters, one per 128-B line: per-shard arrivals of the post kernel's workgroups + the shards' own
   float* mesh_cache;   // [N][4 legs][LG_MAX_CP][4]: last closest-point query of every collision sphere (mesh terrains)
   float lstm_w[912];   // actuator network weights, gate-interleaved (pack_lstm_weights): read with scalar loads
   int nblocks_post;
@@ -902,16 +905,59 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
 // Episode statistics of one step: fixed-order (ascending workgroup) sums of the per-workgroup partial rows -> extras
 // (LR:200-206), step counters, running stats.  Only workgroups that reset an env have a row to add (flags), so the usual
 // step touches a handful of rows; the order of the additions never depends on scheduling.  One 256-thread workgroup,
-// launched after post_kernel (use_flags) and after reset_idx_kernel (its single row).
+// launched after reset_idx_kernel (its single row); a policy step runs finalize_from_acc inside the post kernel instead.
 //   bump: 1 = policy step (counters[0]), 0 = explicit reset (counters[2]), 2 = rollout step (counters[3], nothing else)
 #define FIN_CHUNK 1024
-// (A single launch with a "last workgroup finishes the step" ticket was measured and lost: on this multi-XCD part the
-// cross-workgroup hand-over needs device-scope atomics on one address plus L2-bypassing accesses, which cost more than
-// the ~2 us launch of this small second kernel.)
-LG_DEV void st_dev(float* p, float v) { *p = v; }
-LG_DEV float ld_dev(const float* p) { return *p; }
-LG_DEV void st_dev(unsigned* p, unsigned v) { *p = v; }
-LG_DEV unsigned ld_dev(const unsigned* p) { return *p; }
+// A policy step has no second launch for its statistics: the post kernel's workgroups count their arrival on sharded
+// device-scope counters and the last one runs finalize_from_acc (a single counter for 1024 workgroups cost 12 us, a
+// list walk over per-workgroup rows 6 us; sharded counters + integer accumulators 4.4 us, against 5.8 us + a kernel
+// boundary for the separate launch).  finalize_kernel remains for lg_reset_idx (one row, no arrival counting).
+// written by one workgroup, read by another (possibly on another XCD, behind another L2) within ONE launch: relaxed
+// device-scope accesses (sc1: write-through / L2-bypassing), ordered by the arrival counters below
+LG_DEV void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+LG_DEV float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+LG_DEV void st_dev(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+LG_DEV unsigned ld_dev(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the published half of the statistics step: extras, command curriculum, counters, running totals
+LG_DEV void finalize_publish(const DevCtx* __restrict__ C, const float* tot, float* f_lvl, float lvl_acc, int bump, int tid, bool use_flags) {
+  const int K = C->cfg.num_reward_terms;
+  const bool want_lvl = C->cfg.curriculum != 0;
+  lds_barrier();
+  const float cnt = tot[K];
+  if (cnt > 0.f && want_lvl) {            // mean terrain level over all envs (LR:205-206): only reported with a reset
+    if (!use_flags) lvl_acc = tid == 0 ? ld_dev(C->partials + K + 1) : 0.f;
+    f_lvl[tid] = lvl_acc;
+    lds_barrier();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) f_lvl[tid] += f_lvl[tid + off]; lds_barrier(); }
+  }
+  if (cnt > 0.f) {
+    if (tid < K) C->extras[tid] = tot[tid] / cnt / C->cfg.max_episode_length_s;
+    if (tid == K && C->cfg.curriculum) C->extras[K] = f_lvl[0] / (float)C->N;
+  }
+  if (tid == 0 && cnt > 0.f && C->cfg.command_curriculum) {
+    // update_command_curriculum (LR:520-533), gated like LR:178: every max_episode_length steps, from the mean
+    // tracking_lin_vel episode sum of the envs reset in this step.  The widened range serves every later draw (the
+    // reference applies it already to the commands of those same envs: their reset runs before this statistics step).
+    const lg_config& g = C->cfg;
+    const int64_t common = C->counters[0] + (bump == 1 ? 1 : 0);
+    int kt = -1;
+    for (int k = 0; k < K; ++k) if (g.reward_term_ids[k] == LG_REW_TRACKING_LIN_VEL) kt = k;
+    if (kt >= 0 && common % (int64_t)g.max_episode_length == 0 &&
+        tot[kt] / cnt / g.max_episode_length > 0.8f * g.reward_scales[kt]) {
+      C->cmd_ranges[0] = fminf(fmaxf(C->cmd_ranges[0] - 0.5f, -g.max_curriculum), 0.f);
+      C->cmd_ranges[1] = fminf(fmaxf(C->cmd_ranges[1] + 0.5f, 0.f), g.max_curriculum);
+    }
+  }
+  if (tid == 0) {
+    if (bump == 1) C->counters[0] += 1; else if (bump == 0) C->counters[2] += 1;
+    C->counters[1] = (int64_t)cnt;
+    double ret = 0.0;
+    for (int k = 0; k < K; ++k) ret += (double)tot[k];
+    C->ep_stats[0] += ret; C->ep_stats[1] += (double)tot[K + 2]; C->ep_stats[2] += (double)cnt;
+    if (bump == 1) C->ep_stats[3] += (double)C->n_stepped;
+  }
+}
+
 LG_DEV void finalize_step(const DevCtx* __restrict__ C, int nblocks, int bump, int tid, bool use_flags) {
   const int K = C->cfg.num_reward_terms, KP = K + 3, lane = tid & 63, wv = tid >> 6;
   __shared__ float tot[PART_STRIDE];
@@ -960,40 +1006,29 @@ LG_DEV void finalize_step(const DevCtx* __restrict__ C, int nblocks, int bump, i
       lds_barrier();
     }
   }
-  lds_barrier();
-  const float cnt = tot[K];
-  if (cnt > 0.f && want_lvl) {            // mean terrain level over all envs (LR:205-206): only reported with a reset
-    if (!use_flags) lvl_acc = tid == 0 ? ld_dev(C->partials + K + 1) : 0.f;
-    f_lvl[tid] = lvl_acc;
-    lds_barrier();
-    for (int off = 128; off > 0; off >>= 1) { if (tid < off) f_lvl[tid] += f_lvl[tid + off]; lds_barrier(); }
-  }
-  if (cnt > 0.f) {
-    if (tid < K) C->extras[tid] = tot[tid] / cnt / C->cfg.max_episode_length_s;
-    if (tid == K && C->cfg.curriculum) C->extras[K] = f_lvl[0] / (float)C->N;
-  }
-  if (tid == 0 && cnt > 0.f && C->cfg.command_curriculum) {
-    // update_command_curriculum (LR:520-533), gated like LR:178: every max_episode_length steps, from the mean
-    // tracking_lin_vel episode sum of the envs reset in this step.  The widened range serves every later draw (the
-    // reference applies it already to the commands of those same envs: their reset runs before this statistics step).
-    const lg_config& g = C->cfg;
-    const int64_t common = C->counters[0] + (bump == 1 ? 1 : 0);
-    int kt = -1;
-    for (int k = 0; k < K; ++k) if (g.reward_term_ids[k] == LG_REW_TRACKING_LIN_VEL) kt = k;
-    if (kt >= 0 && common % (int64_t)g.max_episode_length == 0 &&
-        tot[kt] / cnt / g.max_episode_length > 0.8f * g.reward_scales[kt]) {
-      C->cmd_ranges[0] = fminf(fmaxf(C->cmd_ranges[0] - 0.5f, -g.max_curriculum), 0.f);
-      C->cmd_ranges[1] = fminf(fmaxf(C->cmd_ranges[1] + 0.5f, 0.f), g.max_curriculum);
+  finalize_publish(C, tot, f_lvl, lvl_acc, bump, tid, use_flags);
+}
+
+// Statistics step of a policy step, run by the last workgroup of the post kernel: the workgroups that reset an env have
+// added their rows to 64-bit fixed-point accumulators (integer atomics: the sum does not depend on arrival order), so
+// this is one round trip (the accumulators and the per-workgroup level sums together) instead of a list walk.
+#define ACC_SCALE 16777216.0
+LG_DEV void finalize_from_acc(const DevCtx* __restrict__ C, int nblocks, int bump, int tid) {
+  const int K = C->cfg.num_reward_terms, KP = K + 3;
+  __shared__ float tot[PART_STRIDE];
+  __shared__ float f_lvl[256];
+  if (bump == 2) { if (tid == 0) C->counters[3] += 1; return; }
+  float lvl_acc = 0.f;
+  if (C->cfg.curriculum != 0) for (int b = tid; b < nblocks; b += 256) lvl_acc += ld_dev(C->lvl_part + b);
+  if (tid < PART_STRIDE) {
+    long long a = 0;
+    if (tid < KP) {
+      a = __hip_atomic_load(C->acc + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a != 0) __hip_atomic_store(C->acc + tid, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    tot[tid] = (float)((double)a * (1.0 / ACC_SCALE));
   }
-  if (tid == 0) {
-    if (bump == 1) C->counters[0] += 1; else if (bump == 0) C->counters[2] += 1;
-    C->counters[1] = (int64_t)cnt;
-    double ret = 0.0;
-    for (int k = 0; k < K; ++k) ret += (double)tot[k];
-    C->ep_stats[0] += ret; C->ep_stats[1] += (double)tot[K + 2]; C->ep_stats[2] += (double)cnt;
-    if (bump == 1) C->ep_stats[3] += (double)C->n_stepped;
-  }
+  finalize_publish(C, tot, f_lvl, lvl_acc, bump, tid, true);
 }
 
 // ============================================================================================ post-physics kernel
@@ -1334,12 +1369,12 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   const int KP = g.num_reward_terms + 3;
   bool any_reset = false;
   for (int el2 = 0; el2 < nenv; ++el2) any_reset |= s_did_reset[el2] != 0;
-  if (tid < KP && any_reset) {              // the row is only read when the flag says so
+  // rows of the reset envs: 64-bit fixed-point integer atomics (order-independent, hence deterministic)
+  if (tid < KP && any_reset) {
     float sacc = 0.f;
     for (int el2 = 0; el2 < nenv; ++el2) sacc += s_part[el2][tid];
-    st_dev(C->partials + (size_t)blockIdx.x * PART_STRIDE + tid, sacc);
+    __hip_atomic_fetch_add(C->acc + tid, __double2ll_rn((double)sacc * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (tid == KP) st_dev(C->part_flag + blockIdx.x, any_reset ? 1u : 0u);
   if (tid == KP + 1) {
     float sacc = 0.f;
     for (int el2 = 0; el2 < nenv; ++el2) sacc += s_part[el2][g.num_reward_terms + 1];
@@ -1382,6 +1417,26 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     }
   }
   STAMP(14);
+  // ---- the last workgroup to arrive finishes the step (statistics, extras, counters): arrivals are counted per shard
+  // (blockIdx & 7: eight counters on eight cache lines, ~1/8 of the contention of one), the shard that fills up counts
+  // itself on a ninth.  The partial rows above went out as device-scope stores; __syncthreads() drains them
+  // (s_waitcnt vmcnt(0)) before the arrival is counted.
+  __shared__ int s_last;
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned shard = blockIdx.x & 7u, nsh = min(8u, gridDim.x);
+    const unsigned want = (gridDim.x + 7u - shard) >> 3;
+    int last = 0;
+    if (__hip_atomic_fetch_add(C->tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want - 1u) {
+      if (__hip_atomic_fetch_add(C->tickets + 32 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1u) {
+        last = 1;
+        for (int i = 0; i < 9; ++i) __hip_atomic_store(C->tickets + 32 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last) finalize_from_acc(C, (int)gridDim.x, mode == 0 ? 1 : 2, tid);
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step, int use_flags) {
@@ -1576,7 +1631,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   // aux buffer: noise_vec | height_points | partials
   size_t n_noise = (size_t)cfg->num_obs, n_hp = (size_t)2 * cfg->num_height_points;
   size_t n_part = (size_t)h.nblocks_post * PART_STRIDE;
-  size_t n_fin = (size_t)2 * h.nblocks_post + 4;   // level sums | reset flags | ticket
+  size_t n_fin = (size_t)2 * h.nblocks_post + 4 + 32 + 9 * 32 + 2 * PART_STRIDE + 2;   // level sums | reset flags | (pad to a 128-B line) | arrival counters | accumulators
   size_t aux_floats = n_noise + n_hp + n_part + 66 + n_fin;   // + 32 x u64 stamp counters
   if (hipMalloc(&c->aux, aux_floats * 4) != hipSuccess) return fail("hipMalloc(aux) failed");
   if (hipMemset(c->aux, 0, aux_floats * 4) != hipSuccess) return fail("hipMemset(aux) failed");
@@ -1586,6 +1641,8 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   {
     float* fin = aux + n_noise + n_hp + n_part + 66;
     h.lvl_part = fin; h.part_flag = (unsigned*)(fin + h.nblocks_post);
+    h.tickets = (unsigned*)(((uintptr_t)(fin + 2 * h.nblocks_post + 4) + 127) & ~(uintptr_t)127);
+    h.acc = (long long*)(h.tickets + 9 * 32);
   }
   if (hipMemcpy(aux, cfg->noise_scale_vec, n_noise * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy noise_scale_vec failed");
   if (n_hp && hipMemcpy(aux + n_noise, cfg->height_points, n_hp * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy height_points failed");
@@ -1629,7 +1686,6 @@ static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t*
   const int nb = (n + EPBP - 1) / EPBP;
   hipLaunchKernelGGL(post_kernel, dim3(nb), dim3(256), 0, st, c->d, ids, n, mode);
   if (ev) (void)hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, c->d, nb, mode == 0 ? 1 : 2, 1);
   if (ev) (void)hipEventRecord(ev[3], st);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
