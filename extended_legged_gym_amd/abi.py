@@ -93,6 +93,7 @@ class lg_config(C.Structure):
         ("max_episode_length", f32), ("max_episode_length_s", f32),
         ("curriculum", i32), ("custom_origins", i32), ("max_terrain_level", i32),
         ("reset_z_from_terrain", i32),
+        ("terminate_on_flip", i32),
         ("base_init_state", f32 * 13),
         ("gait_enabled", i32), ("gait_period", f32), ("gait_swing_height", f32), ("gait_foot_phases", f32 * 4),
         ("solver_iterations", i32), ("contact_offset", f32), ("max_depenetration_velocity", f32), ("erp", f32),

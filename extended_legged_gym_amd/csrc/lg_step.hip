@@ -1251,6 +1251,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     // check_termination (LR:155-160)
     bool term = false;
     for (int i = 0; i < m.num_termination; ++i) term |= s_fn[el][m.termination_contact_indices[i]] > 1.f;
+    term |= g.terminate_on_flip && V.pg[2] > 0.f;   // anymal_c_batch_rollout.py:192-198 (stage 2.1 left the new vector in LDS)
     term |= s_flag[el] == 2;        // physics fault flagged by physics_kernel
     bool tout = (float)eplen > g.max_episode_length;
     if (ro) {                       // rollout envs never terminate on their own: flags keep their last values

@@ -10,9 +10,14 @@ from .go2.go2 import Go2
 from .go2.go2_config import Go2RoughCfg, Go2RoughCfgPPO, Go2FlatCfg, Go2FlatCfgPPO
 from .batch_rollout.robot_batch_rollout import RobotBatchRollout
 from .batch_rollout.robot_batch_rollout_percept import RobotBatchRolloutPercept
+from .anymal_c.batch_rollout.anymal_c_batch_rollout import AnymalCBatchRollout
+from .anymal_c.batch_rollout.anymal_c_batch_rollout_config import (AnymalCBatchRolloutCfg, AnymalCBatchRolloutCfgPPO,
+                                                                   AnymalCBatchRolloutFlatCfg, AnymalCBatchRolloutFlatCfgPPO)
 
 task_registry.register("anymal_c_rough", Anymal, AnymalCRoughCfg(), AnymalCRoughCfgPPO())
 task_registry.register("anymal_c_flat", Anymal, AnymalCFlatCfg(), AnymalCFlatCfgPPO())
 task_registry.register("a1", LeggedRobot, A1RoughCfg(), A1RoughCfgPPO())
 task_registry.register("go2_rough", Go2, Go2RoughCfg(), Go2RoughCfgPPO())
 task_registry.register("go2_flat", Go2, Go2FlatCfg(), Go2FlatCfgPPO())
+task_registry.register("anymal_c_batch_rollout", AnymalCBatchRollout, AnymalCBatchRolloutCfg(), AnymalCBatchRolloutCfgPPO())
+task_registry.register("anymal_c_batch_rollout_flat", AnymalCBatchRollout, AnymalCBatchRolloutFlatCfg(), AnymalCBatchRolloutFlatCfgPPO())

@@ -109,7 +109,7 @@ class LeggedRobot(BaseTask):
         self.setup = NativeSetup(self.cfg, self.sim_params, self.robot_model, terrain=self.terrain, seed=seed,
                                  gait=self._gait_config(), num_extra_obs=self._num_extra_obs(),
                                  reset_z_from_terrain=self._reset_z_from_terrain,
-                                 custom_origins=self._custom_origins_rule())
+                                 custom_origins=self._custom_origins_rule(), terminate_on_flip=self._terminate_on_flip)
         self.core = NativeCore(self.setup, self.device)
         t = self.core.t
 
@@ -143,6 +143,7 @@ class LeggedRobot(BaseTask):
         if self.terrain is not None:
             self.height_samples = t["height_samples"]
 
+    _terminate_on_flip = False       # AnymalCBatchRollout: an upside-down robot ends the episode
     _reset_z_from_terrain = False    # RobotBatchRollout: root z from the height sample under the reset position
 
     def _gait_config(self):

@@ -123,7 +123,7 @@ class NativeSetup:
 
     def __init__(self, cfg, sim_params, model, terrain=None, seed=0, rng_mode=abi.LG_RNG_PHILOX, gait=None,
                  reward_stage=None, num_extra_obs=0, reset_z_from_terrain=False,
-                 custom_origins=None):
+                 custom_origins=None, terminate_on_flip=False):
         self.model_dict = model
         self.model = model_struct(model)
         dt = cfg.control.decimation * sim_params.dt
@@ -228,6 +228,7 @@ class NativeSetup:
             c.curriculum = int(c.curriculum and c.custom_origins)
         c.max_terrain_level = cfg.terrain.num_rows
         c.reset_z_from_terrain = int(bool(reset_z_from_terrain))
+        c.terminate_on_flip = int(bool(terminate_on_flip))
         init = cfg.init_state
         _fill(c.base_init_state, list(init.pos) + list(init.rot) + list(init.lin_vel) + list(init.ang_vel))
 

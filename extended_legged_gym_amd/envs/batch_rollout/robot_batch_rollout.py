@@ -151,7 +151,8 @@ class RobotBatchRollout(LeggedRobot):
     def _sync_main_to_rollout(self):
         """Copy every main env's state onto its rollouts (`:1447-1535`), one kernel."""
         drift = float(getattr(self.cfg.domain_rand, "rollout_envs_sync_pos_drift", 0.0))
-        self.core.sync_main_to_rollout(self.num_rollout_per_main, drift)
+        if self.num_rollout_per_main > 0:                      # `:1452-1453`: nothing to sync without rollout envs
+            self.core.sync_main_to_rollout(self.num_rollout_per_main, drift)
         self.t_rollout = self.t_main
 
     def _cache_main_env_states(self):

@@ -214,6 +214,8 @@ typedef struct lg_config {
   int32_t curriculum, custom_origins, max_terrain_level;
   int32_t reset_z_from_terrain;       /* RobotBatchRollout._reset_root_states (robot_batch_rollout.py:1379-1391): with custom
                                        * origins, root z = height sample under the drawn (x, y) + init z */
+  int32_t terminate_on_flip;          /* AnymalCBatchRollout.check_termination (anymal_c_batch_rollout.py:192-198): also reset
+                                       * when projected_gravity.z > 0 (robot upside down) */
   float base_init_state[13];
   /* gait scheduler (anymal.py:59-63, gait_scheduler.py:63-81) */
   int32_t gait_enabled; float gait_period, gait_swing_height, gait_foot_phases[LG_NUM_LEGS];

@@ -202,3 +202,45 @@ def test_reset_root_height_from_terrain_matches_oracle():
     np.testing.assert_allclose(want[:, 2], z, rtol=0, atol=1e-6)
     assert np.ptp(want[:, 2]) > 0.05                              # the terrain is not flat under the spawn points
     core.close(); o.close()
+
+
+def test_anymal_c_batch_rollout_tasks_and_flip_termination():
+    """The registered `anymal_c_batch_rollout*` tasks (reference envs/__init__.py:124-126): no contact termination, an
+    upside-down base ends a main env's episode (anymal_c_batch_rollout.py:192-198); HIP and oracle agree on the flag."""
+    from tests.test_env_api import make
+    from oracle.oracle_lib import OracleEnv
+    env = make("anymal_c_batch_rollout", 8, **{"env.rollout_envs": 3, "noise.add_noise": False,
+                                               "domain_rand.push_robots": False})
+    assert (env.num_envs, env.total_num_envs, env.num_obs) == (8, 32, 48)
+    assert env.setup.cfg.terminate_on_flip == 1 and env.setup.model.num_termination == 0
+    obs, _ = env.reset()
+    assert obs.shape == (8, 48)
+    for _ in range(5):
+        _, _, _, done, _ = env.step(torch.zeros(8, 12, device=env.device))
+    assert int(done.sum()) == 0
+    # turn main env 2 onto its back, in the air: no contact, yet the episode ends
+    m = int(env.main_env_indices[2])
+    env.root_states[m, 3:7] = torch.tensor([1.0, 0.0, 0.0, 0.0], device=env.device)
+    env.root_states[m, 2] = 2.0
+    o = OracleEnv(env.setup)
+    for name in ("root_states", "dof_state", "commands", "last_actions", "last_dof_vel", "last_root_vel", "episode_length_buf",
+                 "feet_air_time", "feet_contact_time", "last_contacts", "friction_coeffs", "base_mass_added", "env_origins",
+                 "base_lin_acc", "base_ang_acc", "step_counters", "episode_sums", "rigid_body_state", "contact_forces"):
+        o.t[name][...] = env.core.t[name].cpu().numpy()
+    a = torch.zeros(8, 12, device=env.device)
+    _, _, _, done, _ = env.step(a)
+    assert done.tolist() == [False, False, True, False, False, False, False, False]
+    o.sync_main_to_rollout(3, 0.0, 0)
+    o.step_subset(np.zeros((8, 12), np.float32), env.main_env_indices.cpu().numpy().astype(np.int32), 0)
+    assert np.array_equal(o.t["reset_buf"][env.main_env_indices.cpu().numpy()] != 0, done.cpu().numpy())
+    o.close()
+    # the flat training variant: no rollout envs at all, two-stage reward scales
+    env = make("anymal_c_batch_rollout_flat", 16)
+    assert (env.num_envs, env.total_num_envs, env.num_rollout_per_main) == (16, 16, 0)
+    env.reset()
+    for _ in range(20):
+        obs, _, rew, done, info = env.step(torch.zeros(16, 12, device=env.device))
+    assert torch.isfinite(obs).all() and (rew >= 0).all()            # only_positive_rewards
+    assert env.reward_scales_stage == 0
+    env.update_reward_scales(100.0)
+    assert env.reward_scales_stage == 1

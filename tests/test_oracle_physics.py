@@ -376,3 +376,26 @@ def test_command_curriculum_widens_the_range_when_tracking_is_good():
     np.testing.assert_allclose(o.t["command_ranges"][0], [-0.8, 0.8])       # second widening at step 220, clipped
     assert np.abs(o.t["commands"][:, 0]).max() > 0.0            # later resets draw from the widened range
     o.close()
+
+
+def test_flip_termination_without_contact_termination():
+    """AnymalCBatchRollout.check_termination (anymal_c_batch_rollout.py:192-198): with `terminate_on_flip` an upside-down
+    base (projected_gravity.z > 0) ends the episode even though no body is listed for contact termination."""
+    from extended_legged_gym_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+    from extended_legged_gym_amd.envs.base.native_config import NativeSetup, load_robot_model
+    from oracle.oracle_lib import OracleEnv
+    from tests.helpers import sim_params_for
+    for flag in (False, True):
+        cfg = AnymalCFlatCfg()
+        cfg.env.num_envs = 4
+        cfg.control.use_actuator_network = False
+        cfg.asset.terminate_after_contacts_on = []
+        s = NativeSetup(cfg, sim_params_for(cfg), load_robot_model(cfg.asset), seed=1, terminate_on_flip=flag)
+        assert s.model.num_termination == 0
+        o = OracleEnv(s)
+        o.reset_idx(np.arange(4))
+        o.t["root_states"][1, 3:7] = [1, 0, 0, 0]      # half a turn about x: belly up
+        o.t["root_states"][1, 2] = 2.0                  # in the air: no contact anywhere
+        o.step(np.zeros((4, 12), np.float32))
+        assert o.t["reset_buf"].tolist() == ([0, 1, 0, 0] if flag else [0, 0, 0, 0])
+        o.close()
