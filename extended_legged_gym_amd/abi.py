@@ -25,7 +25,9 @@ REWARD_TERMS = [
     "action_rate", "ang_vel_xy", "base_foot_height", "base_height", "collision", "dof_acc", "dof_pos_limits", "dof_vel",
     "dof_vel_limits", "feet_air_time", "feet_contact_forces", "feet_slip", "feet_stumble", "feet_stumble_liftup",
     "four_footup", "gait_2_step", "gait_scheduler", "jump_air", "lin_vel_z", "orientation", "stand_still", "termination",
-    "torque_limits", "torques", "tracking_ang_vel", "tracking_lin_vel"]
+    "torque_limits", "torques", "tracking_ang_vel", "tracking_lin_vel",
+    # class-specific variants: selected through an env class's `reward_term_variants`, never named in a config
+    "orientation_load_adapt"]
 REWARD_TERM_ID = {n: i for i, n in enumerate(REWARD_TERMS)}
 
 TENSOR_NAMES = [

@@ -693,7 +693,7 @@ LG_DEV float wrap_to_pi(float a) {   // math_utils.py:55-58
 // loads, so the one-lane-per-env phase never waits on global memory), plain global rows for lg_reset_idx.
 struct EnvView {
   float *root, *dof, *cmd, *air, *ctime, *blv, *bav, *pg;
-  const float *tq, *act, *lact, *ldv, *cf, *rb;
+  const float *tq, *act, *lact, *ldv, *cf, *rb, *bla;
   uint8_t* lastc;
 };
 LG_DEV EnvView global_view(const DevCtx* __restrict__ C, int e) {
@@ -703,7 +703,7 @@ LG_DEV EnvView global_view(const DevCtx* __restrict__ C, int e) {
   V.blv = C->base_lin_vel + (size_t)e * 3; V.bav = C->base_ang_vel + (size_t)e * 3; V.pg = C->proj_grav + (size_t)e * 3;
   V.tq = C->torques + (size_t)e * 12; V.act = C->actions + (size_t)e * 12; V.lact = C->last_actions + (size_t)e * 12;
   V.ldv = C->last_dof_vel + (size_t)e * 12; V.cf = C->cforce + (size_t)e * C->B * 3; V.rb = C->rigid + (size_t)e * C->B * 13;
-  V.lastc = C->last_contacts + (size_t)e * 4;
+  V.lastc = C->last_contacts + (size_t)e * 4; V.bla = C->base_lin_acc + (size_t)e * 3;
   return V;
 }
 
@@ -822,6 +822,8 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     case LG_REW_LIN_VEL_Z: return SQ(blv[2]);
     case LG_REW_ANG_VEL_XY: return SQ(bav[0]) + SQ(bav[1]);
     case LG_REW_ORIENTATION: return SQ(pg[0]) + SQ(pg[1]);
+    case LG_REW_ORIENTATION_LOAD_ADAPT:   // base perpendicular to gravity + acceleration (anymal.py:140-143)
+      return SQ(pg[0] - V.bla[0] / 9.81f) + SQ(pg[1] - V.bla[1] / 9.81f);
     case LG_REW_BASE_HEIGHT: {
       float s = root[2];
       if (g.measure_heights) s = bh / (float)C->P;
@@ -1172,7 +1174,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   float* S = s_env[el];
   EnvView V;
   V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
-  V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT;
+  V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT; V.bla = S + S_BLA;
   V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = s_lastc[el];
   float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
   __shared__ float s_rk[EPBP][LG_MAX_REWARD_TERMS];

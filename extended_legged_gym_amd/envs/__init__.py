@@ -2,12 +2,14 @@
 classes are importable from here for task-specific configs."""
 from extended_legged_gym_amd.utils.task_registry import task_registry
 from .base.legged_robot import LeggedRobot
-from .anymal_c.anymal import Anymal
+from .anymal_c.anymal import Anymal, LoadAdaptAnymal
 from .anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg, AnymalCRoughCfgPPO
 from .anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg, AnymalCFlatCfgPPO
+from .anymal_c.flat.load_adapt_anymal_c_flat_config import LoadAdaptAnymalCFlatCfg, LoadAdaptAnymalCFlatCfgPPO
 from .a1.a1_config import A1RoughCfg, A1RoughCfgPPO
-from .go2.go2 import Go2
-from .go2.go2_config import Go2RoughCfg, Go2RoughCfgPPO, Go2FlatCfg, Go2FlatCfgPPO
+from .go2.go2 import Go2, LoadAdaptGo2
+from .go2.go2_config import (Go2RoughCfg, Go2RoughCfgPPO, Go2FlatCfg, Go2FlatCfgPPO, LoadAdaptGo2FlatCfg,
+                             LoadAdaptGo2FlatCfgPPO)
 from .batch_rollout.robot_batch_rollout import RobotBatchRollout
 from .batch_rollout.robot_batch_rollout_percept import RobotBatchRolloutPercept
 from .anymal_c.batch_rollout.anymal_c_batch_rollout import AnymalCBatchRollout
@@ -21,3 +23,5 @@ task_registry.register("go2_rough", Go2, Go2RoughCfg(), Go2RoughCfgPPO())
 task_registry.register("go2_flat", Go2, Go2FlatCfg(), Go2FlatCfgPPO())
 task_registry.register("anymal_c_batch_rollout", AnymalCBatchRollout, AnymalCBatchRolloutCfg(), AnymalCBatchRolloutCfgPPO())
 task_registry.register("anymal_c_batch_rollout_flat", AnymalCBatchRollout, AnymalCBatchRolloutFlatCfg(), AnymalCBatchRolloutFlatCfgPPO())
+task_registry.register("load_adapt_anymal_c_flat", LoadAdaptAnymal, LoadAdaptAnymalCFlatCfg(), LoadAdaptAnymalCFlatCfgPPO())
+task_registry.register("load_adapt_go2_flat", LoadAdaptGo2, LoadAdaptGo2FlatCfg(), LoadAdaptGo2FlatCfgPPO())

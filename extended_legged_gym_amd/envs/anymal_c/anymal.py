@@ -17,3 +17,11 @@ class Anymal(LeggedRobot):
         self.sea_hidden_state_per_env = self.sea_hidden_state.view(2, self.num_envs, self.num_actions, 8)
         self.sea_cell_state_per_env = self.sea_cell_state.view(2, self.num_envs, self.num_actions, 8)
         self.gait_idx = t["gait_idx"]
+
+
+class LoadAdaptAnymal(Anymal):
+    """`LoadAdaptAnymal` (reference `anymal.py:117-143`): `_reward_orientation` penalises the base not being
+    perpendicular to gravity + acceleration, `sum((projected_gravity[:2] - base_lin_acc[:2] / 9.81)^2)`; `_reward_ang_vel_xy`
+    is the base term.  The variant is a native reward term, selected here by name."""
+    reward_term_variants = {"orientation": "orientation_load_adapt"}
+

@@ -109,7 +109,8 @@ class LeggedRobot(BaseTask):
         self.setup = NativeSetup(self.cfg, self.sim_params, self.robot_model, terrain=self.terrain, seed=seed,
                                  gait=self._gait_config(), num_extra_obs=self._num_extra_obs(),
                                  reset_z_from_terrain=self._reset_z_from_terrain,
-                                 custom_origins=self._custom_origins_rule(), terminate_on_flip=self._terminate_on_flip)
+                                 custom_origins=self._custom_origins_rule(), terminate_on_flip=self._terminate_on_flip,
+                                 reward_term_variants=self.reward_term_variants)
         self.core = NativeCore(self.setup, self.device)
         t = self.core.t
 
@@ -143,6 +144,7 @@ class LeggedRobot(BaseTask):
         if self.terrain is not None:
             self.height_samples = t["height_samples"]
 
+    reward_term_variants = {}        # cfg.rewards.scales name -> native term for classes that override a `_reward_*`
     _terminate_on_flip = False       # AnymalCBatchRollout: an upside-down robot ends the episode
     _reset_z_from_terrain = False    # RobotBatchRollout: root z from the height sample under the reset position
 
@@ -249,7 +251,7 @@ class LeggedRobot(BaseTask):
             self.reward_scales_stage += 1
             names, vals = reward_setup(self.cfg, self.dt, self.reward_scales_stage)
             self.setup.reward_names, self.setup.reward_scales = names, vals
-            self.core.set_reward_terms([abi.REWARD_TERM_ID[n] for n in names], vals)
+            self.core.set_reward_terms([abi.REWARD_TERM_ID[self.reward_term_variants.get(n, n)] for n in names], vals)
             self._prepare_reward_function()
             return True
         return False

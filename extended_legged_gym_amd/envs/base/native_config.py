@@ -123,7 +123,7 @@ class NativeSetup:
 
     def __init__(self, cfg, sim_params, model, terrain=None, seed=0, rng_mode=abi.LG_RNG_PHILOX, gait=None,
                  reward_stage=None, num_extra_obs=0, reset_z_from_terrain=False,
-                 custom_origins=None, terminate_on_flip=False):
+                 custom_origins=None, terminate_on_flip=False, reward_term_variants=None):
         self.model_dict = model
         self.model = model_struct(model)
         dt = cfg.control.decimation * sim_params.dt
@@ -203,7 +203,7 @@ class NativeSetup:
         self.reward_names, self.reward_scales = reward_setup(cfg, dt, reward_stage)
         c.num_reward_terms = len(self.reward_names)
         for k, (n, v) in enumerate(zip(self.reward_names, self.reward_scales)):
-            c.reward_term_ids[k] = abi.REWARD_TERM_ID[n]
+            c.reward_term_ids[k] = abi.REWARD_TERM_ID[(reward_term_variants or {}).get(n, n)]
             c.reward_scales[k] = v
         r = cfg.rewards
         c.only_positive_rewards = int(r.only_positive_rewards)

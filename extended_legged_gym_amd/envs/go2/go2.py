@@ -6,3 +6,9 @@ from extended_legged_gym_amd.envs.anymal_c.anymal import Anymal
 class Go2(Anymal):
     def _gait_config(self):
         return dict(period=0.6, swing_height=0.15, foot_phases=[0.0, 0.5, 0.5, 0.0])     # go2.py:30-34
+
+
+class LoadAdaptGo2(Go2):
+    """`LoadAdaptGo2` (reference `go2.py:118-144`): same orientation term as `LoadAdaptAnymal`."""
+    reward_term_variants = {"orientation": "orientation_load_adapt"}
+

@@ -114,3 +114,56 @@ class Go2FlatCfgPPO(Go2RoughCfgPPO):
     class runner(Go2RoughCfgPPO.runner):
         experiment_name = 'flat_go2'
         max_iterations = 300
+
+
+class LoadAdaptGo2FlatCfg(Go2FlatCfg):
+    """`load_adapt_go2_flat` (values of the reference's `envs/go2/flat/load_adapt_go2_flat_config.py:4-60`)."""
+    class env(Go2FlatCfg.env):
+        num_observations = 48
+        num_actions = 12
+
+    class commands(Go2FlatCfg.commands):
+        resampling_time = 10.
+
+        class ranges:
+            lin_vel_x = [-0.5, 0.5]
+            lin_vel_y = [-0.5, 0.5]
+            ang_vel_yaw = [-0.5, 0.5]
+            heading = [-3.14, 3.14]
+
+    class rewards(Go2FlatCfg.rewards):
+        class scales(Go2FlatCfg.rewards.scales):
+            termination = -0.0
+            tracking_lin_vel = 1.0
+            tracking_ang_vel = 0.5
+            lin_vel_z = -2.0
+            ang_vel_xy = -0.05
+            orientation = -5.0
+            torques = -0.00001
+            dof_vel = -0.
+            dof_acc = -2.5e-7
+            base_height = -0.
+            collision = -1.
+            action_rate = -0.01
+            stumble = -0.0
+            stand_still = -0.
+
+    class domain_rand(Go2FlatCfg.domain_rand):
+        randomize_friction = True
+        friction_range = [0.2, 1.25]
+        randomize_base_mass = True
+        added_mass_range = [-3., 3.]
+        push_robots = True
+        push_interval_s = 3
+        max_push_vel_xy = 1.
+
+
+class LoadAdaptGo2FlatCfgPPO(Go2FlatCfgPPO):
+    class algorithm(Go2FlatCfgPPO.algorithm):
+        entropy_coef = 0.01
+
+    class runner(Go2FlatCfgPPO.runner):
+        run_name = ''
+        experiment_name = 'load_adapt_go2'
+        max_iterations = 300
+

@@ -83,7 +83,10 @@ enum lg_reward_term {
   LG_REW_FEET_CONTACT_FORCES, LG_REW_FEET_SLIP, LG_REW_FEET_STUMBLE, LG_REW_FEET_STUMBLE_LIFTUP, LG_REW_FOUR_FOOTUP,
   LG_REW_GAIT_2_STEP, LG_REW_GAIT_SCHEDULER, LG_REW_JUMP_AIR, LG_REW_LIN_VEL_Z, LG_REW_ORIENTATION,
   LG_REW_STAND_STILL, LG_REW_TERMINATION, LG_REW_TORQUE_LIMITS, LG_REW_TORQUES, LG_REW_TRACKING_ANG_VEL,
-  LG_REW_TRACKING_LIN_VEL, LG_REW_COUNT
+  LG_REW_TRACKING_LIN_VEL,
+  /* class-specific variants of a term (same name in cfg.rewards.scales, chosen by the env class) */
+  LG_REW_ORIENTATION_LOAD_ADAPT,     /* LoadAdaptAnymal / LoadAdaptGo2._reward_orientation (anymal.py:140-143, go2.py:141-144) */
+  LG_REW_COUNT
 };
 
 /* arena tensors (names follow the reference's attribute names, legged_robot.py:559-647, base_task.py:71-79) */

@@ -12,7 +12,8 @@ from extended_legged_gym_amd.envs.base.native_config import NativeSetup, load_ro
 from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_CASES = ["flat_pd", "flat_lstm", "rough_lstm", "rough_allrew"]
+GOLDEN_CASES = ["flat_pd", "flat_lstm", "rough_lstm", "rough_allrew", "flat_loadadapt"]
+CLASS_VARIANTS = {"LoadAdaptAnymal": {"orientation": "orientation_load_adapt"}}   # = LoadAdaptAnymal.reward_term_variants
 ANYMAL_GAIT = dict(period=0.6, swing_height=0.15, foot_phases=[0.0, 0.5, 0.5, 0.0])   # anymal.py:59-63
 
 
@@ -55,7 +56,8 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
     # the harness robot (tools/refgen/ref_loader.py:anymal_robot_description) carries these DOF limits
     model["dof_lower"], model["dof_upper"] = [-9.42] * 12, [9.42] * 12
     model["dof_vel_limit"], model["torque_limit"] = [20.0] * 12, [80.0] * 12
-    setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ANYMAL_GAIT)
+    setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ANYMAL_GAIT,
+                        reward_term_variants=CLASS_VARIANTS.get(case.get("cls", "Anymal")))
     return cfg, setup
 
 

@@ -101,3 +101,27 @@ def test_go2_flat_and_rough_tasks():
     for _ in range(50):
         obs, _, rew, d, info = env.step(torch.randn(64, 12, generator=g).cuda())
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+
+
+def test_load_adapt_tasks_use_the_acceleration_aware_orientation_term():
+    """`load_adapt_anymal_c_flat` / `load_adapt_go2_flat` (reference envs/__init__.py:120,140): the classes swap
+    `_reward_orientation` for the gravity + acceleration variant (anymal.py:140-143, go2.py:141-144)."""
+    from extended_legged_gym_amd import abi
+    from tests.test_env_api import make
+    for task in ("load_adapt_anymal_c_flat", "load_adapt_go2_flat"):
+        env = make(task, 64, **{"noise.add_noise": False})
+        k = env.setup.reward_names.index("orientation")
+        assert env.setup.cfg.reward_term_ids[k] == abi.REWARD_TERM_ID["orientation_load_adapt"]
+        env.reset()
+        g = torch.Generator().manual_seed(1)
+        for _ in range(30):
+            env.step(0.5 * torch.randn(64, 12, generator=g).cuda())
+        before = env.episode_sums["orientation"].clone() if isinstance(env.episode_sums, dict) else env.core.t["episode_sums"][k].clone()
+        pg, acc = env.projected_gravity.clone(), None
+        env.step(torch.zeros(64, 12, device=env.device))
+        after = env.episode_sums["orientation"] if isinstance(env.episode_sums, dict) else env.core.t["episode_sums"][k]
+        pg, acc = env.projected_gravity, env.base_lin_acc
+        want = ((pg[:, :2] - acc[:, :2] / 9.81) ** 2).sum(1) * env.setup.reward_scales[k]
+        alive = ~env.reset_buf.bool()
+        assert torch.allclose((after - before)[alive], want[alive], rtol=1e-4, atol=1e-6)
+        assert torch.isfinite(env.obs_buf).all()

@@ -33,6 +33,8 @@ def build(case):
     ref_loader.load_reference()
     from isaacgym import gymapi
     from legged_gym.envs import Anymal, AnymalCFlatCfg, AnymalCRoughCfg
+    from legged_gym.envs.anymal_c.anymal import LoadAdaptAnymal
+    Base = {"Anymal": Anymal, "LoadAdaptAnymal": LoadAdaptAnymal}[case.get("cls", "Anymal")]
     import legged_gym.envs.base.legged_robot as LR
 
     ref_loader.FakeGym.robot = ref_loader.anymal_robot_description()
@@ -76,7 +78,7 @@ def build(case):
         rec["log"].append((rec.get("ctx"), "level", rec.get("ids"), u.clone()))
         return torch.floor(u * high).to(t.dtype)
 
-    class Rec(Anymal):
+    class Rec(Base):
         def _post_physics_step_callback(self):
             rec["ctx"] = "cb"
             super()._post_physics_step_callback()
@@ -313,8 +315,14 @@ CASES = [
     dict(name="rough_allrew", base="rough", num_envs=32, steps=6, seed=3, actuator_net=False, push_interval_s=0.06,
          resampling_time=0.1, heading_command=True, episode_length_s=20, num_rows=3, num_cols=4, border_size=5,
          scales=ALL_SCALES, only_positive_rewards=False),
+    # LoadAdaptAnymal (anymal.py:117-143): orientation measured against gravity + acceleration
+    dict(name="flat_loadadapt", base="flat", cls="LoadAdaptAnymal", num_envs=24, steps=4, seed=4, actuator_net=False,
+         push_interval_s=0.06, resampling_time=0.1, heading_command=False, episode_length_s=20,
+         scales=dict(orientation=-80.0), only_positive_rewards=False),
 ]
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
     for c in CASES:
-        run_case(c)
+        if not only or c["name"] in only:
+            run_case(c)
