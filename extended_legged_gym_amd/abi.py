@@ -175,6 +175,12 @@ def declare_product(lib):
     return lib
 
 
+class lg_rollout(C.Structure):
+    """include/lgpolicy.h: device pointers to the (T, n, .) rows of one collected rollout."""
+    _fields_ = [(k, C.c_void_p) for k in ("observations", "actions", "rewards", "dones", "values", "actions_log_prob", "mu", "sigma",
+                                          "last_values", "returns", "advantages")]
+
+
 def declare_policy(lib):
     """Prototypes of the rollout-collection entry points (include/lgpolicy.h), same library."""
     vp = C.c_void_p
@@ -190,10 +196,13 @@ def declare_policy(lib):
     lib.lg_policy_act.restype = C.c_int
     lib.lg_compute_returns.argtypes = [vp, vp, vp, vp, i32, C.c_int64, f32, f32, i32, vp, vp, vp]
     lib.lg_compute_returns.restype = C.c_int
+    lib.lg_collect_rollout.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64, i32, f32, f32, i32, C.POINTER(lg_rollout), vp]
+    lib.lg_collect_rollout.restype = C.c_int
     return lib
 
 
-POLICY_SYMBOLS = ["lg_mlp_create", "lg_mlp_destroy", "lg_mlp_last_error", "lg_mlp_forward", "lg_policy_act", "lg_compute_returns"]
+POLICY_SYMBOLS = ["lg_mlp_create", "lg_mlp_destroy", "lg_mlp_last_error", "lg_mlp_forward", "lg_policy_act", "lg_compute_returns",
+                  "lg_collect_rollout"]
 ACTIVATIONS = {"elu": 0, "relu": 1, "tanh": 2, "lrelu": 3, "selu": 4}
 
 PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_step_physics", "lg_step_subset", "lg_sync_main_to_rollout", "lg_compute_torques",

@@ -45,6 +45,33 @@ int lg_policy_act(lg_mlp* actor, lg_mlp* critic, const float* obs, const float* 
 int lg_compute_returns(const float* rewards, const float* dones, const float* values, const float* last_values, int32_t T,
                        int64_t n, float gamma, float lam, int32_t normalize, float* returns, float* advantages, void* stream);
 
+/* The collection loop of OnPolicyRunner.learn (runners/on_policy_runner.py:395-445) for a feed-forward policy, without
+ * returning to the host between steps: for t in [0, T):
+ *     observations[t] = env obs;  PPO.act (ppo.py:147-159) -> actions[t], values[t], actions_log_prob[t], mu[t], sigma[t];
+ *     one lg_step of the env with actions[t];   PPO.process_env_step (ppo.py:161-183): rewards[t] = rew + gamma * values[t] * time_outs,
+ *     dones[t] = reset_buf
+ * then last_values = critic(env obs) (ppo.py:186-190) and, when returns / advantages are given, compute_returns.
+ * Rows are laid out as RolloutStorage holds them (rollout_storage.py:47-76), (T, n, .) row-major f32 (dones as 0 / 1).
+ * Sampling call t uses Philox call number first_call + t, so the loop draws exactly what T separate lg_policy_act calls
+ * with calls first_call .. first_call + T - 1 draw.  The policy sees the env's obs_buf as both actor and critic input
+ * (no privileged observations).  Everything is enqueued on `stream`; nothing is synchronised. */
+struct lg_ctx;
+typedef struct lg_rollout {
+  float* observations;       /* (T, n, num_obs) */
+  float* actions;            /* (T, n, A) */
+  float* rewards;            /* (T, n) */
+  float* dones;              /* (T, n) */
+  float* values;             /* (T, n) */
+  float* actions_log_prob;   /* (T, n) */
+  float* mu;                 /* (T, n, A) */
+  float* sigma;              /* (T, n, A) */
+  float* last_values;        /* (n) */
+  float* returns;            /* (T, n) or NULL */
+  float* advantages;         /* (T, n) or NULL */
+} lg_rollout;
+int lg_collect_rollout(struct lg_ctx* env, lg_mlp* actor, lg_mlp* critic, const float* std, uint64_t seed, uint64_t first_call,
+                       int32_t T, float gamma, float lam, int32_t normalize_advantage, const lg_rollout* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,3 +81,49 @@ def test_compute_returns_matches_rsl_rl_golden_and_oracle():
     wr, wa = po.compute_returns(r.numpy(), d.numpy(), v.numpy(), last.numpy(), 0.99, 0.95, True)
     np.testing.assert_allclose(ret.cpu().numpy()[..., 0], wr, rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(adv.cpu().numpy()[..., 0], wa, rtol=1e-4, atol=2e-5)
+
+
+def test_collect_rollout_matches_the_python_loop():
+    """`lg_collect_rollout` (runner loop on_policy_runner.py:395-445 + ppo.py:147-190 + rollout_storage.py:91-167 in one
+    call) against the same steps driven from Python through the separate entry points, on two identically seeded envs:
+    the rows must be identical (same kernels, same Philox calls, same order)."""
+    from extended_legged_gym_amd.rl import NativeActorCritic, collect_rollout, compute_returns
+    from tests.test_env_api import make
+    T, N = 6, 256
+    torch.manual_seed(3)
+    dims = [48, 64, 32, 12]
+    actor = torch.nn.Sequential(torch.nn.Linear(48, 64), torch.nn.ELU(), torch.nn.Linear(64, 32), torch.nn.ELU(), torch.nn.Linear(32, 12))
+    critic = torch.nn.Sequential(torch.nn.Linear(48, 64), torch.nn.ELU(), torch.nn.Linear(64, 32), torch.nn.ELU(), torch.nn.Linear(32, 1))
+    sd = {"actor." + k: v for k, v in actor.state_dict().items()}
+    sd.update({"critic." + k: v for k, v in critic.state_dict().items()})
+    sd["std"] = 0.7 * torch.ones(12)
+    over = {"env.episode_length_s": 0.08, "seed": 5}       # max_episode_length = 4 policy steps: time-outs inside the rollout
+    envs = [make("anymal_c_flat", N, **over) for _ in range(2)]
+    acs = [NativeActorCritic(sd, "elu", device="cuda:0", seed=11) for _ in range(2)]
+    for e in envs:
+        e.reset()
+    assert torch.equal(envs[0].obs_buf, envs[1].obs_buf)
+    # (a) Python loop
+    env, ac = envs[0], acs[0]
+    rows = {k: [] for k in ("observations", "actions", "rewards", "dones", "values", "actions_log_prob", "mu", "sigma")}
+    obs = env.get_observations()
+    for t in range(T):
+        a, v, lp, mu, sig = ac.act_and_evaluate(obs)
+        rows["observations"].append(obs.clone()); rows["actions"].append(a.clone()); rows["values"].append(v.clone())
+        rows["actions_log_prob"].append(lp.clone().view(-1, 1)); rows["mu"].append(mu.clone()); rows["sigma"].append(sig.clone())
+        obs, _, rew, dones, infos = env.step(a)
+        r = rew.clone()
+        r += 0.99 * torch.squeeze(v * infos["time_outs"].unsqueeze(1), 1)            # ppo.py:179-183
+        rows["rewards"].append(r.view(-1, 1)); rows["dones"].append(dones.float().view(-1, 1))
+    ref = {k: torch.stack(v) for k, v in rows.items()}
+    last = ac.evaluate(obs)
+    ret, adv = compute_returns(ref["rewards"], ref["dones"], ref["values"], last, 0.99, 0.95, True)
+    # (b) one native call
+    out = collect_rollout(envs[1], acs[1], T, 0.99, 0.95, True)
+    torch.cuda.synchronize()
+    assert float(ref["dones"].sum()) > 0 and float((ref["rewards"] - torch.stack([x for x in rows["rewards"]])).abs().max()) == 0
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.equal(out["last_values"], last) and torch.equal(out["returns"], ret) and torch.equal(out["advantages"], adv)
+    assert torch.equal(envs[0].obs_buf, envs[1].obs_buf) and acs[0]._call == acs[1]._call == T
+    assert envs[0].common_step_counter == envs[1].common_step_counter

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from extended_legged_gym_amd.rl import NativeActorCritic, compute_returns  # noqa: E402
+from extended_legged_gym_amd.rl import NativeActorCritic, collect_rollout, compute_returns  # noqa: E402
 
 
 def timeit(fn, warm=20, steps=100):
@@ -95,10 +95,13 @@ def main():
             a = dist.sample(); critic(ob); dist.log_prob(a).sum(-1)
         return a
     t_loop_eager = timeit(lambda: collect(eager_policy), 3, 10)
+    # the whole runner loop (act, step, bootstrapped rewards, storage rows, last values, GAE) as one library call
+    t_loop_one_call = timeit(lambda: collect_rollout(env, ac, T, 0.99, 0.95, True), 3, 10)
     print(json.dumps({
         "policy_act_ms": t_native * 1e3, "policy_act_tflops": flops / t_native / 1e12, "policy_act_eager_torch_ms": t_eager * 1e3,
         "compute_returns_ms": t_gae * 1e3, "compute_returns_eager_torch_ms": t_gae_eager * 1e3,
         "collect_24_steps_ms": t_loop_native * 1e3, "collect_24_steps_env_steps_per_s": N * T / t_loop_native,
+        "collect_24_steps_one_call_ms": t_loop_one_call * 1e3, "collect_24_steps_one_call_env_steps_per_s": N * T / t_loop_one_call,
         "collect_24_steps_eager_policy_ms": t_loop_eager * 1e3, "collect_24_steps_eager_policy_env_steps_per_s": N * T / t_loop_eager,
         "shape": "actor 235-512-256-128-12 + critic 235-512-256-128-1, ELU, 4096 envs, fp32"}))
 
