@@ -1072,78 +1072,87 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
 
+  // One wave per env from the first load to the last store: wave w of the workgroup owns env e0 + w, lane ln owns entry
+  // ln (+ 64 j) of each of its rows.  No index of this kernel needs an integer division (rows used to be dealt to the 256
+  // threads of the workgroup by flat index: ~25 instructions per division by a run-time row length, a dozen of them).
+  const int wv = tid >> 6, ln = tid & 63;
+  const bool have = wv < nenv;
+  const int el = have ? wv : 0, e = s_e[el];       // waves without an env shadow env 0 of the workgroup and store nothing
+  float* S = s_env[el];
+
   // ---- (1a) height scan from the post-physics root pose (LR:400-401).  Order of the memory traffic of this kernel's
   // first stage: [scan inputs: base pose + scan points] -> [all staging loads] -> wait for the scan inputs only ->
   // [height gathers] -> LDS stores of the staged rows -> barrier; the gathers are consumed after stage (2.1).
   // No branch around any of these loads: lanes without a point, and the plane, read a valid dummy address (a
   // conditional load makes the compiler drain the memory pipeline at the end of the branch).
-  static_assert(EPBP * MAX_P <= 4 * 256, "height scan assumes one pass of four points per lane");
+  static_assert(MAX_P <= 3 * 64, "height scan assumes three points per lane");
   const bool scan = P > 0 && !ro;
   const bool plane = C->ter.mesh_type == LG_MESH_PLANE;
-  HeightProbe hp_[4]; int hel[4], hpi[4];
-  float rq[4][4], hxy[4][2];
+  HeightProbe hp_[3]; int hpi[3];
+  float rq[4], hxy[3][2];
   {
     const float* hpts = scan ? C->height_points : C->root;
+    const float* rt = C->root + (size_t)e * 13;
+    rq[0] = rt[0]; rq[1] = rt[1]; rq[2] = rt[5]; rq[3] = rt[6];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * 256;
-      const bool ok = scan && idx < nenv * P;
-      const int el_ = ok ? idx / P : 0, p = ok ? idx - el_ * P : 0;
-      hel[u] = el_; hpi[u] = ok ? p : -1;
-      const float* rt = C->root + (size_t)s_e[el_] * 13;
-      rq[u][0] = rt[0]; rq[u][1] = rt[1]; rq[u][2] = rt[5]; rq[u][3] = rt[6];
-      hxy[u][0] = hpts[2 * p]; hxy[u][1] = hpts[2 * p + 1];
+    for (int u = 0; u < 3; ++u) {
+      const int p = ln + 64 * u;
+      const bool ok = scan && have && p < P;
+      hpi[u] = ok ? p : -1;
+      const int pp = ok ? p : 0;
+      hxy[u][0] = hpts[2 * pp]; hxy[u][1] = hpts[2 * pp + 1];
     }
   }
-  float h_keep[4] = {0.f, 0.f, 0.f, 0.f};     // rollout steps keep the heights measured by the last main step
+  float h_keep[3] = {0.f, 0.f, 0.f};          // rollout steps keep the heights measured by the last main step
   if (P > 0 && ro) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * 256;
-      if (idx < nenv * P) { const int el_ = idx / P, p = idx - el_ * P; hel[u] = el_; hpi[u] = p; h_keep[u] = C->heights[(size_t)s_e[el_] * C->P + p]; }
+    for (int u = 0; u < 3; ++u) {
+      const int p = ln + 64 * u;
+      if (have && p < P) { hpi[u] = p; h_keep[u] = C->heights[(size_t)e * C->P + p]; }
     }
   }
 
-  // ---- (0) stage this workgroup's env rows in LDS.  Every global load is issued before the first LDS store, so the
+  // ---- (0) stage this wave's env rows in LDS.  Every global load is issued before the first LDS store, so the
   // phase costs one memory latency instead of one per tensor.
-  static_assert(LG_MAX_BODIES * 13 * EPBP <= 1024 && 64 * EPBP <= 256, "staging assumes <= 4 row chunks of 256 lanes");
-#define LDV(name, SRC, LEN) float name = 0.f; if (tid < nenv * (LEN)) { int el_ = tid / (LEN), k_ = tid - el_ * (LEN); name = (SRC)[(size_t)s_e[el_] * (LEN) + k_]; }
-#define STV(name, OFF, LEN) if (tid < nenv * (LEN)) { int el_ = tid / (LEN), k_ = tid - el_ * (LEN); s_env[el_][(OFF) + k_] = name; }
+  static_assert(LG_MAX_BODIES * 13 <= 256 && LG_MAX_BODIES * 3 <= 64 && LG_MAX_REWARD_TERMS <= 64 && LG_RS_NOISE / 4 <= 64,
+                "staging assumes <= 4 row chunks of 64 lanes for the body states and one for every other row");
+#define LDV(name, SRC, LEN) float name = 0.f; if (ln < (LEN)) name = (SRC)[(size_t)e * (LEN) + ln];
+#define STV(name, OFF, LEN) if (have && ln < (LEN)) S[(OFF) + ln] = name;
   const int LRB = B * 13;
   float v_rb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    int idx = tid + j * 256; v_rb[j] = 0.f;
-    if (idx < nenv * LRB) { int el_ = idx / LRB, k_ = idx - el_ * LRB; v_rb[j] = C->rigid[(size_t)s_e[el_] * LRB + k_]; }
+    const int k_ = ln + j * 64; v_rb[j] = 0.f;
+    if (k_ < LRB) v_rb[j] = C->rigid[(size_t)e * LRB + k_];
   }
   LDV(v_root, C->root, 13) LDV(v_dof, C->dof, 24) LDV(v_cf, C->cforce, B * 3)
   LDV(v_act, C->actions, 12) LDV(v_lact, C->last_actions, 12) LDV(v_ldv, C->last_dof_vel, 12) LDV(v_tq, C->torques, 12)
   LDV(v_lrv, C->last_root_vel, 6) LDV(v_cmd, C->commands, 4) LDV(v_bla, C->base_lin_acc, 3) LDV(v_baa, C->base_ang_acc, 3)
   LDV(v_air, C->feet_air, 4) LDV(v_ct, C->feet_ctime, 4) LDV(v_gait, C->gait_idx, 1)
   float v_sum = 0.f;                                   // episode sums are (K, N): row k, envs contiguous
-  if (tid < nenv * g.num_reward_terms) { int k = tid / nenv, el_ = tid - k * nenv; v_sum = C->ep_sums[(size_t)k * C->N + s_e[el_]]; }
-  uint8_t v_lc = 0; if (tid < nenv * 4) v_lc = C->last_contacts[(size_t)s_e[tid >> 2] * 4 + (tid & 3)];
-  int64_t v_len = 0; uint8_t v_flag = 0; int64_t v_lvl = 0;
-  {
-    const int e_ = s_e[tid < nenv ? tid : 0];
-    v_len = C->ep_len[e_]; v_flag = C->reset_buf[e_]; v_lvl = C->levels[e_];
-    if (!(g.curriculum && !ro)) v_lvl = 0;
-  }
-  if (tid < nenv * (LG_RS_NOISE / 4)) {          // one Philox call per (env, slot group): 8 lanes per env
-    int el_ = tid / (LG_RS_NOISE / 4), gq = tid - el_ * (LG_RS_NOISE / 4);
-    uniform_draw4(C, s_e[el_], gq, step, rstream, &s_u[el_][4 * gq]);
-  }
-  // (1a, continued) the scan inputs are here: issue the height gathers
+  if (ln < g.num_reward_terms) v_sum = C->ep_sums[(size_t)ln * C->N + e];
+  uint8_t v_lc = 0; if (ln < 4) v_lc = C->last_contacts[(size_t)e * 4 + ln];
+  int64_t v_len = C->ep_len[e]; uint8_t v_flag = C->reset_buf[e]; int64_t v_lvl = C->levels[e];
+  if (!(g.curriculum && !ro)) v_lvl = 0;
+  float nv_pre[4] = {0.f, 0.f, 0.f, 0.f};            // noise scales of this lane's first four observation entries (stage 3)
+  if (g.add_noise) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const float qz = rq[u][2], qw = rq[u][3];
+    for (int i = 0; i < 4; ++i) if (4 * ln + i < g.num_obs) nv_pre[i] = C->noise_vec[4 * ln + i];
+  }
+  if (have && ln < LG_RS_NOISE / 4)                   // one Philox call per (env, slot group): 8 lanes
+    uniform_draw4(C, e, ln, step, rstream, &s_u[el][4 * ln]);
+  // (1a, continued) the scan inputs are here: issue the height gathers
+  {
+    const float qz = rq[2], qw = rq[3];
     const float nrm = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
-    hp_[u] = terrain_height_probe(C, qz / nrm, qw / nrm, rq[u][0], rq[u][1], hxy[u][0], hxy[u][1]);
+    const float qzn = qz / nrm, qwn = qw / nrm;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) hp_[u] = terrain_height_probe(C, qzn, qwn, rq[0], rq[1], hxy[u][0], hxy[u][1]);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    int idx = tid + j * 256;
-    if (idx < nenv * LRB) { int el_ = idx / LRB, k_ = idx - el_ * LRB; s_env[el_][S_RB + k_] = v_rb[j]; }
+    const int k_ = ln + j * 64;
+    if (have && k_ < LRB) S[S_RB + k_] = v_rb[j];
   }
   STV(v_root, S_ROOT, 13) STV(v_dof, S_DOF, 24) STV(v_cf, S_CF, B * 3)
   STV(v_act, S_ACT, 12) STV(v_lact, S_LACT, 12) STV(v_ldv, S_LDV, 12) STV(v_tq, S_TQ, 12)
@@ -1151,35 +1160,33 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   STV(v_air, S_AIR, 4) STV(v_ct, S_CT, 4) STV(v_gait, S_GAIT, 1)
 #undef LDV
 #undef STV
-  if (tid < nenv * g.num_reward_terms) { int k = tid / nenv, el_ = tid - k * nenv; s_env[el_][S_SUMS + k] = v_sum; }
-  if (tid < nenv * 4) s_lastc[tid >> 2][tid & 3] = v_lc;
-  if (tid < nenv) { s_eplen[tid] = v_len; s_flag[tid] = v_flag; s_level[tid] = (float)v_lvl; }
+  if (have && ln < g.num_reward_terms) S[S_SUMS + ln] = v_sum;
+  if (have && ln < 4) s_lastc[el][ln] = v_lc;
+  if (have && ln == 0) { s_eplen[el] = v_len; s_flag[el] = v_flag; s_level[el] = (float)v_lvl; }
   lds_barrier();
   STAMP(11);
 
-  // ---- (2) one wave per env.  The reference's order of side effects is kept by stages separated by barriers:
+  // (1b) the height samples have usually arrived by the end of stage (2.1): they are consumed after it (see below)
+  // ---- (2) the post-physics logic of the workgroup's four envs on ONE wave, sixteen lanes per env.  The stages below are
+  // a few lanes wide (five rotations, twelve DOFs, one lane per reward term ...), and their cost is instruction issue:
+  // a wave per env made every SIMD issue each stage four times (four workgroups per CU, one wave of each per SIMD) with
+  // at most a quarter of the lanes in use; now one wave per workgroup issues it once for all four envs, and which wave
+  // that is rotates with the workgroup index so that the four workgroups of a CU load its four SIMDs evenly.
+  // The reference's order of side effects is kept by stages separated by barriers:
   //   (2.1) base-frame velocities / accelerations / gravity (five rotations on five lanes), per-DOF reward features
-  //         (one lane per DOF), contact-force norms (one lane per body), base-height partial sums;
+  //         (one lane per DOF), contact-force norms (one lane per body);
   //   (2.2) feature sums (one lane per feature, DOF order = the serial order), callback + termination (one lane);
-  //   (2.3) reward terms in config order, episode sums, reset (one lane: O(1) per term now);
-  //   (2.4) proprioceptive observation entries (one lane per entry), gait phase.
+  //   (2.3) reward terms in config order, episode sums, reset;
+  //   (2.4) proprioceptive observation entries, gait phase.
   __shared__ float s_feat[EPBP][F_COUNT][12];
   __shared__ float s_fsum[EPBP][F_COUNT];
   __shared__ float s_fn[EPBP][LG_MAX_BODIES];
   __shared__ float s_bh[EPBP];
   __shared__ uint8_t s_term[EPBP], s_tout[EPBP];
-  const int wv = tid >> 6, ln = tid & 63;
-  const bool have = wv < nenv;
-  const int el = have ? wv : 0, e = s_e[el];
-  float* S = s_env[el];
-  EnvView V;
-  V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
-  V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT; V.bla = S + S_BLA;
-  V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = s_lastc[el];
-  float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
   __shared__ float s_rk[EPBP][LG_MAX_REWARD_TERMS];
   __shared__ float s_old[EPBP][8];
   __shared__ uint8_t s_oldc[EPBP][4];
+  static_assert(EPBP * 16 == 64 && F_COUNT <= 8, "phase 2: sixteen lanes per env on one wave");
   unsigned term_mask = 0;                       // which reward terms are switched on (wave-uniform)
   int kfat = g.num_reward_terms;                // position of feet_air_time in the evaluation order (K = absent)
   for (int k = 0; k < g.num_reward_terms; ++k) {
@@ -1187,188 +1194,210 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     term_mask |= 1u << id;
     if (id == LG_REW_FEET_AIR_TIME) kfat = k;
   }
+  {
+    const bool mine = wv == (int)((blockIdx.x >> 8) & 3u);   // (workgroups 256 apart share a CU when all 1024 are resident)
+    const int el = ln >> 4, sl = ln & 15;                   // env of the workgroup, lane within the env (shadow the wave-per-env names)
+    const bool have = mine && el < nenv;
+    float* S = s_env[have ? el : 0];
+    EnvView V;
+    V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
+    V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT; V.bla = S + S_BLA;
+    V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = s_lastc[have ? el : 0];
+    float* root = V.root; float* dof = V.dof;
 
-  // (2.1)
-  if (have && ln < 5) {                                                           // LR:128-134
-    const float* lrv = S + S_LRV;
-    float q[4] = {root[3], root[4], root[5], root[6]};
-    V3 lin = v3(root[7], root[8], root[9]), ang = v3(root[10], root[11], root[12]);
-    V3 x = ln == 0 ? lin : ln == 1 ? lin - v3(lrv[0], lrv[1], lrv[2]) : ln == 2 ? ang : ln == 3 ? ang - v3(lrv[3], lrv[4], lrv[5]) : v3(0, 0, -1);
-    V3 r = quat_rotate_inverse(q, x);
-    const float ema = 0.9f, oma = (float)(1 - 0.9);
-    float* dst = ln == 0 ? V.blv : ln == 1 ? S + S_BLA : ln == 2 ? V.bav : ln == 3 ? S + S_BAA : V.pg;
-    if (ln == 1 || ln == 3) { dst[0] = dst[0] * ema + oma * r.x / dt; dst[1] = dst[1] * ema + oma * r.y / dt; dst[2] = dst[2] * ema + oma * r.z / dt; }
-    else { dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; }
-  } else if (have && ln >= 16 && ln < 28) {
-    const int d = ln - 16;
-    const float q_ = dof[2 * d], qd = dof[2 * d + 1], tq = V.tq[d];
-    float (*F)[12] = s_feat[el];
-    F[F_TQ2][d] = tq * tq;
-    F[F_QD2][d] = qd * qd;
-    { float a = (V.ldv[d] - qd) / dt; F[F_ACC2][d] = a * a; }
-    { float a = V.lact[d] - V.act[d]; F[F_ARATE2][d] = a * a; }
-    { float lo = q_ - g.dof_pos_limits[d][0], hi = q_ - g.dof_pos_limits[d][1]; F[F_POSLIM][d] = -fminf(lo, 0.f) + fmaxf(hi, 0.f); }
-    F[F_VELLIM][d] = fminf(fmaxf(fabsf(qd) - m.dof_vel_limit[d] * g.soft_dof_vel_limit, 0.f), 1.f);
-    F[F_TQLIM][d] = fmaxf(fabsf(tq) - m.torque_limit[d] * g.soft_torque_limit, 0.f);
-    F[F_STILL][d] = fabsf(q_ - g.default_dof_pos[d]);
-  } else if (have && ln >= 32 && ln < 32 + B) {
-    const float* cf = V.cf + 3 * (ln - 32);
-    s_fn[el][ln - 32] = sqrtf(cf[0] * cf[0] + cf[1] * cf[1] + cf[2] * cf[2]);
+    // (2.1)
+    if (have && sl < 5) {                                                           // LR:128-134
+      const float* lrv = S + S_LRV;
+      float q[4] = {root[3], root[4], root[5], root[6]};
+      V3 lin = v3(root[7], root[8], root[9]), ang = v3(root[10], root[11], root[12]);
+      V3 x = sl == 0 ? lin : sl == 1 ? lin - v3(lrv[0], lrv[1], lrv[2]) : sl == 2 ? ang : sl == 3 ? ang - v3(lrv[3], lrv[4], lrv[5]) : v3(0, 0, -1);
+      V3 r = quat_rotate_inverse(q, x);
+      const float ema = 0.9f, oma = (float)(1 - 0.9);
+      float* dst = sl == 0 ? V.blv : sl == 1 ? S + S_BLA : sl == 2 ? V.bav : sl == 3 ? S + S_BAA : V.pg;
+      if (sl == 1 || sl == 3) { dst[0] = dst[0] * ema + oma * r.x / dt; dst[1] = dst[1] * ema + oma * r.y / dt; dst[2] = dst[2] * ema + oma * r.z / dt; }
+      else { dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; }
+    }
+    if (have && sl < 12) {
+      const int d = sl;
+      const float q_ = dof[2 * d], qd = dof[2 * d + 1], tq = V.tq[d];
+      float (*F)[12] = s_feat[el];
+      F[F_TQ2][d] = tq * tq;
+      F[F_QD2][d] = qd * qd;
+      { float a = (V.ldv[d] - qd) / dt; F[F_ACC2][d] = a * a; }
+      { float a = V.lact[d] - V.act[d]; F[F_ARATE2][d] = a * a; }
+      { float lo = q_ - g.dof_pos_limits[d][0], hi = q_ - g.dof_pos_limits[d][1]; F[F_POSLIM][d] = -fminf(lo, 0.f) + fmaxf(hi, 0.f); }
+      F[F_VELLIM][d] = fminf(fmaxf(fabsf(qd) - m.dof_vel_limit[d] * g.soft_dof_vel_limit, 0.f), 1.f);
+      F[F_TQLIM][d] = fmaxf(fabsf(tq) - m.torque_limit[d] * g.soft_torque_limit, 0.f);
+      F[F_STILL][d] = fabsf(q_ - g.default_dof_pos[d]);
+    }
+    if (have) {
+      for (int b = sl; b < B; b += 16) {
+        const float* cf = V.cf + 3 * b;
+        s_fn[el][b] = sqrtf(cf[0] * cf[0] + cf[1] * cf[1] + cf[2] * cf[2]);
+      }
+    }
   }
-  // (1b) the height samples have arrived by now: rows into LDS (and to the measured_heights tensor on main steps)
+  // (1b) the height samples: rows into LDS (and to the measured_heights tensor on main steps), every wave for its own env
 #pragma unroll
-  for (int u = 0; u < 4; ++u) if (hpi[u] >= 0) {
+  for (int u = 0; u < 3; ++u) if (hpi[u] >= 0) {
     const float hv = ro ? h_keep[u] : (plane ? 0.f : terrain_height_value(C, hp_[u]));
-    s_h[hel[u]][hpi[u]] = hv;
-    if (!ro) C->heights[(size_t)s_e[hel[u]] * C->P + hpi[u]] = hv;
+    s_h[el][hpi[u]] = hv;
+    if (!ro) C->heights[(size_t)e * C->P + hpi[u]] = hv;
   }
   lds_barrier();
   STAMP(19);
+  {
+    const bool mine = wv == (int)((blockIdx.x >> 8) & 3u);
+    const int el = ln >> 4, sl = ln & 15;
+    const bool have = mine && el < nenv;
+    const int e = s_e[have ? el : 0];
+    float* S = s_env[have ? el : 0];
+    EnvView V;
+    V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
+    V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT; V.bla = S + S_BLA;
+    V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = s_lastc[have ? el : 0];
+    float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
 
-  // (2.2)
-  if (have && ln < F_COUNT) {
-    float sacc = 0.f;
-    for (int d = 0; d < 12; ++d) sacc += s_feat[el][ln][d];
-    s_fsum[el][ln] = sacc;
-  } else if (have && ln == 8) {
-    float sacc = 0.f;
-    if ((term_mask >> LG_REW_BASE_HEIGHT) & 1u) for (int p = 0; p < P; ++p) sacc += root[2] - s_h[el][p];
-    s_bh[el] = sacc;
-  } else if (have && ln == 9) {
-    const int64_t eplen = s_eplen[el] + (ro ? 0 : 1);                             // LR:122 (not in rollout steps)
-    bool root_dirty = false;
-    // _post_physics_step_callback (LR:386-403)
-    if (!ro && (int)eplen % g.resampling_steps == 0) resample_commands(C, cmd, s_u[el], LG_RS_CMD_CB);
-    if (!ro && g.heading_command) {
-      float q[4] = {root[3], root[4], root[5], root[6]};
-      V3 f = quat_apply(q, v3(1, 0, 0));
-      float x = 0.5f * wrap_to_pi(cmd[3] - atan2f(f.y, f.x));
-      cmd[2] = fminf(fmaxf(x, -1.f), 1.f);
+    // (2.2)
+    if (have && sl < F_COUNT) {
+      float sacc = 0.f;
+      for (int d = 0; d < 12; ++d) sacc += s_feat[el][sl][d];
+      s_fsum[el][sl] = sacc;
+    } else if (have && sl == 8) {
+      float sacc = 0.f;
+      if ((term_mask >> LG_REW_BASE_HEIGHT) & 1u) for (int p = 0; p < P; ++p) sacc += root[2] - s_h[el][p];
+      s_bh[el] = sacc;
+    } else if (have && sl == 9) {
+      const int64_t eplen = s_eplen[el] + (ro ? 0 : 1);                             // LR:122 (not in rollout steps)
+      bool root_dirty = false;
+      // _post_physics_step_callback (LR:386-403)
+      if (!ro && (int)eplen % g.resampling_steps == 0) resample_commands(C, cmd, s_u[el], LG_RS_CMD_CB);
+      if (!ro && g.heading_command) {
+        float q[4] = {root[3], root[4], root[5], root[6]};
+        V3 f = quat_apply(q, v3(1, 0, 0));
+        float x = 0.5f * wrap_to_pi(cmd[3] - atan2f(f.y, f.x));
+        cmd[2] = fminf(fmaxf(x, -1.f), 1.f);
+      }
+      if (!ro && g.push_robots && (step % g.push_interval == 0)) {                    // LR:402-403, 491-496
+        root[7] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, s_u[el][LG_RS_PUSH]);
+        root[8] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, s_u[el][LG_RS_PUSH + 1]);
+        root_dirty = true;
+      }
+      // check_termination (LR:155-160)
+      bool term = false;
+      for (int i = 0; i < m.num_termination; ++i) term |= s_fn[el][m.termination_contact_indices[i]] > 1.f;
+      term |= g.terminate_on_flip && V.pg[2] > 0.f;   // anymal_c_batch_rollout.py:192-198 (stage 2.1 left the new vector in LDS)
+      term |= s_flag[el] == 2;        // physics fault flagged by physics_kernel
+      bool tout = (float)eplen > g.max_episode_length;
+      if (ro) {                       // rollout envs never terminate on their own: flags keep their last values
+        tout = C->time_out[e] != 0; term = (s_flag[el] != 0) && !tout;
+        if (s_flag[el] == 2) C->reset_buf[e] = 1;
+      } else { C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0; }
+      s_term[el] = term ? 1 : 0; s_tout[el] = tout ? 1 : 0;
+      s_root_dirty[el] = root_dirty ? 1 : 0;
+      s_eplen[el] = eplen;
+      C->ep_len[e] = eplen;
     }
-    if (!ro && g.push_robots && (step % g.push_interval == 0)) {                    // LR:402-403, 491-496
-      root[7] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, s_u[el][LG_RS_PUSH]);
-      root[8] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, s_u[el][LG_RS_PUSH + 1]);
-      root_dirty = true;
-    }
-    // check_termination (LR:155-160)
-    bool term = false;
-    for (int i = 0; i < m.num_termination; ++i) term |= s_fn[el][m.termination_contact_indices[i]] > 1.f;
-    term |= g.terminate_on_flip && V.pg[2] > 0.f;   // anymal_c_batch_rollout.py:192-198 (stage 2.1 left the new vector in LDS)
-    term |= s_flag[el] == 2;        // physics fault flagged by physics_kernel
-    bool tout = (float)eplen > g.max_episode_length;
-    if (ro) {                       // rollout envs never terminate on their own: flags keep their last values
-      tout = C->time_out[e] != 0; term = (s_flag[el] != 0) && !tout;
-      if (s_flag[el] == 2) C->reset_buf[e] = 1;
-    } else { C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0; }
-    s_term[el] = term ? 1 : 0; s_tout[el] = tout ? 1 : 0;
-    s_root_dirty[el] = root_dirty ? 1 : 0;
-    s_eplen[el] = eplen;
-    C->ep_len[e] = eplen;
-  }
-  lds_barrier();
-  STAMP(20);
+    lds_barrier();
+    STAMP(20);
 
-  // (2.3a) the one stateful term: _reward_feet_air_time rewrites air / contact times and last_contacts (RM:150-163).
-  // Terms that come before it in the config order must still see the old values: keep a copy.
-  if (have && ln == 0 && kfat < g.num_reward_terms) {
+    // (2.3a) the one stateful term: _reward_feet_air_time rewrites air / contact times and last_contacts (RM:150-163).
+    // Terms that come before it in the config order must still see the old values: keep a copy.
+    if (have && sl == 0 && kfat < g.num_reward_terms) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { s_old[el][f] = V.air[f]; s_old[el][4 + f] = V.ctime[f]; s_oldc[el][f] = V.lastc[f]; }
-    s_rk[el][kfat] = reward_term(C, V, e, LG_REW_FEET_AIR_TIME, s_fsum[el], s_fn[el], s_bh[el], step) * g.reward_scales[kfat];
-  }
-  lds_barrier();
-  // (2.3b) every other term on its own lane (they only read)
-  if (have && ln < g.num_reward_terms && ln != kfat) {
-    const int id = g.reward_term_ids[ln];
-    EnvView Vk = V;
-    if (ln < kfat && kfat < g.num_reward_terms) { Vk.air = s_old[el]; Vk.ctime = s_old[el] + 4; Vk.lastc = s_oldc[el]; }
-    s_rk[el][ln] = id != LG_REW_TERMINATION ? reward_term(C, Vk, e, id, s_fsum[el], s_fn[el], s_bh[el], step) * g.reward_scales[ln] : 0.f;
-  }
-  lds_barrier();
-  STAMP(21);
-  // (2.3c) total in config order, clip, termination term, reset (LR:215-232, 144-145)
-  if (have && ln == 0) {
-    const bool term = s_term[el] != 0, tout = s_tout[el] != 0;
-    float rew = 0.f;
-    for (int k = 0; k < g.num_reward_terms; ++k) rew += s_rk[el][k];
-    if (g.only_positive_rewards) rew = fmaxf(rew, 0.f);
-    for (int k = 0; k < g.num_reward_terms; ++k) if (g.reward_term_ids[k] == LG_REW_TERMINATION) {
-      float r = ((term || tout) && !tout ? 1.f : 0.f) * g.reward_scales[k];
-      rew += r; s_rk[el][k] = r;
+      for (int f = 0; f < 4; ++f) { s_old[el][f] = V.air[f]; s_old[el][4 + f] = V.ctime[f]; s_oldc[el][f] = V.lastc[f]; }
+      s_rk[el][kfat] = reward_term(C, V, e, LG_REW_FEET_AIR_TIME, s_fsum[el], s_fn[el], s_bh[el], step) * g.reward_scales[kfat];
     }
-    C->rew[e] = rew;
-    const bool do_reset = !ro && (term || tout);
-    if (do_reset) { reset_env(C, V, e, 1, s_u[el], false); s_root_dirty[el] = 1; if (g.curriculum) s_level[el] = (float)C->levels[e]; }
-    s_rootz[el] = root[2];
-    s_did_reset[el] = do_reset ? 1 : 0;
-  }
-  lds_barrier();
+    lds_barrier();
+    // (2.3b) every other term on its own lane (they only read); more than sixteen terms take a second round
+    for (int k = sl; have && k < g.num_reward_terms; k += 16) {
+      if (k == kfat) continue;
+      const int id = g.reward_term_ids[k];
+      EnvView Vk = V;
+      if (k < kfat && kfat < g.num_reward_terms) { Vk.air = s_old[el]; Vk.ctime = s_old[el] + 4; Vk.lastc = s_oldc[el]; }
+      s_rk[el][k] = id != LG_REW_TERMINATION ? reward_term(C, Vk, e, id, s_fsum[el], s_fn[el], s_bh[el], step) * g.reward_scales[k] : 0.f;
+    }
+    lds_barrier();
+    STAMP(21);
+    // (2.3c) total in config order, clip, termination term, reset (LR:215-232, 144-145)
+    if (have && sl == 0) {
+      const bool term = s_term[el] != 0, tout = s_tout[el] != 0;
+      float rew = 0.f;
+      for (int k = 0; k < g.num_reward_terms; ++k) rew += s_rk[el][k];
+      if (g.only_positive_rewards) rew = fmaxf(rew, 0.f);
+      for (int k = 0; k < g.num_reward_terms; ++k) if (g.reward_term_ids[k] == LG_REW_TERMINATION) {
+        float r = ((term || tout) && !tout ? 1.f : 0.f) * g.reward_scales[k];
+        rew += r; s_rk[el][k] = r;
+      }
+      C->rew[e] = rew;
+      const bool do_reset = !ro && (term || tout);
+      if (do_reset) { reset_env(C, V, e, 1, s_u[el], false); s_root_dirty[el] = 1; if (g.curriculum) s_level[el] = (float)C->levels[e]; }
+      s_rootz[el] = root[2];
+      s_did_reset[el] = do_reset ? 1 : 0;
+    }
+    lds_barrier();
 
-  // (2.4) proprioceptive part of the observation (LR:237-244), from the post-reset state; gait scheduler (anymal.py:107-110)
-  if (have && ln < 48) {
-    float* sp = s_prop[el];
-    float o;
-    if (ln < 3) o = V.blv[ln] * g.obs_scale_lin_vel;
-    else if (ln < 6) o = V.bav[ln - 3] * g.obs_scale_ang_vel;
-    else if (ln < 9) o = V.pg[ln - 6];
-    else if (ln < 12) o = cmd[ln - 9] * (ln < 11 ? g.obs_scale_lin_vel : g.obs_scale_ang_vel);
-    else if (ln < 24) o = (dof[2 * (ln - 12)] - g.default_dof_pos[ln - 12]) * g.obs_scale_dof_pos;
-    else if (ln < 36) o = dof[2 * (ln - 24) + 1] * g.obs_scale_dof_vel;
-    else o = V.act[ln - 36];
-    sp[ln] = o;
-  } else if (have && ln == 48 && g.gait_enabled && !ro) {
-    float x = fmodf(S[S_GAIT] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
-    S[S_GAIT] = x;
-  }
-  if (have) {                                   // episode sums and the statistics of LR:200-206, one lane per term
-    const bool do_reset = s_did_reset[el] != 0;
-    const int K_ = g.num_reward_terms;
-    if (ln < K_) {
-      float tot = S[S_SUMS + ln] + (ro ? 0.f : s_rk[el][ln]);  // compute_reward_rollout does not touch the episode sums
-      s_part[el][ln] = do_reset ? tot : 0.f;
-      S[S_SUMS + ln] = do_reset ? 0.f : tot;        // written back to (K, N) cooperatively below
-    } else if (ln == K_) s_part[el][K_] = do_reset ? 1.f : 0.f;
-    else if (ln == K_ + 1) s_part[el][K_ + 1] = s_level[el];
-    else if (ln == K_ + 2) s_part[el][K_ + 2] = do_reset ? (float)s_eplen[el] : 0.f;
+    // (2.4) proprioceptive part of the observation (LR:237-244), from the post-reset state; gait scheduler (anymal.py:107-110)
+    if (have) {
+      float* sp = s_prop[el];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int i = sl + 16 * r;
+        float o;
+        if (i < 3) o = V.blv[i] * g.obs_scale_lin_vel;
+        else if (i < 6) o = V.bav[i - 3] * g.obs_scale_ang_vel;
+        else if (i < 9) o = V.pg[i - 6];
+        else if (i < 12) o = cmd[i - 9] * (i < 11 ? g.obs_scale_lin_vel : g.obs_scale_ang_vel);
+        else if (i < 24) o = (dof[2 * (i - 12)] - g.default_dof_pos[i - 12]) * g.obs_scale_dof_pos;
+        else if (i < 36) o = dof[2 * (i - 24) + 1] * g.obs_scale_dof_vel;
+        else o = V.act[i - 36];
+        sp[i] = o;
+      }
+      if (sl == 15 && g.gait_enabled && !ro) {
+        float x = fmodf(S[S_GAIT] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
+        S[S_GAIT] = x;
+      }
+      // episode sums and the statistics of LR:200-206, one lane per term
+      const bool do_reset = s_did_reset[el] != 0;
+      const int K_ = g.num_reward_terms;
+      for (int k = sl; k < K_ + 3; k += 16) {
+        if (k < K_) {
+          float tot = S[S_SUMS + k] + (ro ? 0.f : s_rk[el][k]);  // compute_reward_rollout does not touch the episode sums
+          s_part[el][k] = do_reset ? tot : 0.f;
+          S[S_SUMS + k] = do_reset ? 0.f : tot;        // written back to (K, N) by the env's own wave below
+        } else if (k == K_) s_part[el][K_] = do_reset ? 1.f : 0.f;
+        else if (k == K_ + 1) s_part[el][K_ + 1] = s_level[el];
+        else s_part[el][K_ + 2] = do_reset ? (float)s_eplen[el] : 0.f;
+      }
+    }
   }
   lds_barrier();
   STAMP(13);
 
   // ---- (2b) cooperative write-back of everything phase (2) produced or changed; history buffers (LR:148-150)
-#define UNSTAGE(DST, OFF, LEN)                                                                 \
-  for (int idx = tid; idx < nenv * (LEN); idx += 256) {                                         \
-    int el = idx / (LEN), k = idx - el * (LEN);                                                 \
-    (DST)[(size_t)s_e[el] * (LEN) + k] = s_env[el][(OFF) + k];                                     \
-  }
+#define UNSTAGE(DST, OFF, LEN) if (have && ln < (LEN)) (DST)[(size_t)e * (LEN) + ln] = S[(OFF) + ln];
   UNSTAGE(C->commands, S_CMD, 4) UNSTAGE(C->feet_air, S_AIR, 4) UNSTAGE(C->feet_ctime, S_CT, 4)
   UNSTAGE(C->base_lin_vel, S_BLV, 3) UNSTAGE(C->base_ang_vel, S_BAV, 3) UNSTAGE(C->proj_grav, S_PG, 3)
   UNSTAGE(C->base_lin_acc, S_BLA, 3) UNSTAGE(C->base_ang_acc, S_BAA, 3) UNSTAGE(C->gait_idx, S_GAIT, 1)
+  UNSTAGE(C->last_actions, S_ACT, 12) UNSTAGE(C->last_root_vel, S_ROOT + 7, 6)
 #undef UNSTAGE
-  if (tid < nenv * 4) C->last_contacts[(size_t)s_e[tid >> 2] * 4 + (tid & 3)] = s_lastc[tid >> 2][tid & 3];
-  for (int idx = tid; idx < nenv * 13; idx += 256) { int el = idx / 13, k = idx - el * 13; if (s_root_dirty[el]) C->root[(size_t)s_e[el] * 13 + k] = s_env[el][S_ROOT + k]; }
-  for (int idx = tid; idx < nenv * 24; idx += 256) { int el = idx / 24, k = idx - el * 24; if (s_did_reset[el]) C->dof[(size_t)s_e[el] * 24 + k] = s_env[el][S_DOF + k]; }
-  for (int idx = tid; idx < nenv * 12; idx += 256) {
-    int el = idx / 12, d = idx - el * 12;
-    C->last_actions[(size_t)s_e[el] * 12 + d] = s_env[el][S_ACT + d];
-    C->last_dof_vel[(size_t)s_e[el] * 12 + d] = s_env[el][S_DOF + 2 * d + 1];
-  }
-  for (int idx = tid; idx < nenv * 6; idx += 256) { int el = idx / 6, k = idx - el * 6; C->last_root_vel[(size_t)s_e[el] * 6 + k] = s_env[el][S_ROOT + 7 + k]; }
-  if (g.gait_enabled && !ro && tid < nenv * 4) { int el = tid >> 2, f = tid & 3; C->gait_foot_z[(size_t)s_e[el] * 4 + f] = s_env[el][S_RB + m.feet_indices[f] * 13 + 2]; }
-  if (g.control_type == LG_CTRL_ACTUATOR_NET) {      // anymal.py:78-82: clear the LSTM state of the envs that were reset
+  if (have && ln < 4) C->last_contacts[(size_t)e * 4 + ln] = s_lastc[el][ln];
+  if (have && ln < 13 && s_root_dirty[el]) C->root[(size_t)e * 13 + ln] = S[S_ROOT + ln];
+  if (have && ln < 24 && s_did_reset[el]) C->dof[(size_t)e * 24 + ln] = S[S_DOF + ln];
+  if (have && ln < 12) C->last_dof_vel[(size_t)e * 12 + ln] = S[S_DOF + 2 * ln + 1];
+  if (g.gait_enabled && !ro && have && ln < 4) C->gait_foot_z[(size_t)e * 4 + ln] = S[S_RB + m.feet_indices[ln] * 13 + 2];
+  if (g.control_type == LG_CTRL_ACTUATOR_NET && have && s_did_reset[el]) {   // anymal.py:78-82: clear the LSTM state of a reset env
     const size_t N12 = (size_t)C->N * 12;
-    for (int idx = tid; idx < nenv * 2 * 96; idx += 256) {
-      int el = idx / 192, r = idx - el * 192, lay = r / 96, k = r - lay * 96;
-      if (s_did_reset[el]) {
-        C->sea_h[(lay * N12 + (size_t)s_e[el] * 12) * 8 + k] = 0.f;
-        C->sea_c[(lay * N12 + (size_t)s_e[el] * 12) * 8 + k] = 0.f;
-      }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = ln + 64 * j, lay = idx >= 96 ? 1 : 0, k = idx - 96 * lay;
+      C->sea_h[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
+      C->sea_c[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
     }
   }
 
   // ---- per-workgroup episode statistics, summed in fixed env order (deterministic)
-  for (int idx = tid; idx < nenv * g.num_reward_terms; idx += 256) {     // episode sums back to their (K, N) rows
-    int k = idx / nenv, el = idx - k * nenv;
-    C->ep_sums[(size_t)k * C->N + s_e[el]] = s_env[el][S_SUMS + k];
-  }
+  if (have && ln < g.num_reward_terms) C->ep_sums[(size_t)ln * C->N + e] = S[S_SUMS + ln];   // back to the (K, N) rows
   const int KP = g.num_reward_terms + 3;
   bool any_reset = false;
   for (int el2 = 0; el2 < nenv; ++el2) any_reset |= s_did_reset[el2] != 0;
@@ -1383,19 +1412,32 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     for (int el2 = 0; el2 < nenv; ++el2) sacc += s_part[el2][g.num_reward_terms + 1];
     st_dev(C->lvl_part + blockIdx.x, sacc);
   }
+  // ---- arrival: the last workgroup to arrive finishes the step (statistics, extras, counters).  Arrivals are counted per
+  // shard (blockIdx & 7: eight counters on eight cache lines, ~1/8 of the contention of one), the shard that fills up
+  // counts itself on a ninth.  Everything the finishing workgroup reads (the accumulators, the level sums) was written
+  // above by THIS wave as device-scope accesses; the wave waits for them to be acknowledged (vmcnt(0)) and then counts
+  // its arrival.  The counter's reply is only looked at after the observation rows, which hide its round trip.
+  static_assert(LG_MAX_REWARD_TERMS + 3 + 2 <= 64, "statistics rows and the arrival counter are written by wave 0");
+  unsigned arrival = 0;
+  const unsigned shard = blockIdx.x & 7u, nsh = min(8u, gridDim.x);
+  const unsigned want = (gridDim.x + 7u - shard) >> 3;
+  if (wv == 0) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's stores and atomics have completed
+    if (tid == 0) arrival = __hip_atomic_fetch_add(C->tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // ---- (3) observation rows: proprio | heights | extra, + uniform noise, clipped (LR:245-252, :107-108); 4 entries per
   // lane, loads first (noise scales, caller's extra rows, injected uniforms), then arithmetic, then the row stores
   const int O = g.num_obs, G4 = (O + 3) >> 2;
   const bool inject = g.rng_mode == LG_RNG_INJECT;
-  for (int gi = tid; gi < nenv * G4; gi += 256) {
-    const int el3 = gi / G4, gq = gi - el3 * G4, e3 = s_e[el3];
+  for (int gq = ln; have && gq < G4; gq += 64) {
+    const int el3 = el, e3 = e;
     float u[4] = {0.5f, 0.5f, 0.5f, 0.5f}, nv[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = 4 * gq + i;
       const bool in = idx < O;
-      if (g.add_noise && in) nv[i] = C->noise_vec[idx];
+      if (g.add_noise && in) nv[i] = gq == ln ? nv_pre[i] : C->noise_vec[idx];
       if (g.add_noise && inject && in) u[i] = C->rand_inject[(size_t)e3 * (LG_RS_NOISE + O) + LG_RS_NOISE + idx];
       if (in && idx >= 48 + P && C->extra_obs) ex[i] = C->extra_obs[(size_t)e3 * g.num_extra_obs + (idx - 48 - P)];
     }
@@ -1420,17 +1462,10 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     }
   }
   STAMP(14);
-  // ---- the last workgroup to arrive finishes the step (statistics, extras, counters): arrivals are counted per shard
-  // (blockIdx & 7: eight counters on eight cache lines, ~1/8 of the contention of one), the shard that fills up counts
-  // itself on a ninth.  The partial rows above went out as device-scope stores; __syncthreads() drains them
-  // (s_waitcnt vmcnt(0)) before the arrival is counted.
   __shared__ int s_last;
-  __syncthreads();
   if (tid == 0) {
-    const unsigned shard = blockIdx.x & 7u, nsh = min(8u, gridDim.x);
-    const unsigned want = (gridDim.x + 7u - shard) >> 3;
     int last = 0;
-    if (__hip_atomic_fetch_add(C->tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want - 1u) {
+    if (arrival == want - 1u) {
       if (__hip_atomic_fetch_add(C->tickets + 32 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1u) {
         last = 1;
         for (int i = 0; i < 9; ++i) __hip_atomic_store(C->tickets + 32 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
