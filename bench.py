@@ -96,13 +96,15 @@ def cpu_baseline(env, actions_pool, budget_s=15.0):
                        f"(best of the probed team sizes; {avail} CPUs visible), {dt:.1f} s")
 
 
+PMC_PASSES = "r01_post16_pmc.json"
+
+
 def pmc_traffic(N):
     """HBM bytes per launch of the physics kernel from the committed rocprofv3 PMC passes (`tools/profile_round.sh`,
     separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command).  bench.py cannot collect counters
     itself; the figure is only reported when the committed passes were taken at the same env count."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files or N != 4096:
+    files = [os.path.join(ROOT, "profiles", PMC_PASSES)]     # the passes taken on the current build of the kernels
+    if not os.path.exists(files[0]) or N != 4096:
         return {"traffic": None}
     try:
         with open(files[-1]) as f:
