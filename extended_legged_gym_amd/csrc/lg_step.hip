@@ -355,7 +355,8 @@ LG_DEV void mesh_cache_io(const DevCtx* __restrict__ C, float* cqc, int e, int l
 // MODE 2: lg_compute_torques only.
 template <int MODE, bool TMESH>
 __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, int nact,
-                                                      const int32_t* __restrict__ ids, int n) {
+                                                      const int32_t* __restrict__ ids, int n, int act_stride) {
+  // act_stride: floats between consecutive action rows (12, or horizon * 12 when the rows are one step of a (n, horizon, 12) plan)
   // contact-detection split of a heightfield step with actuator waves (see the helper loop); mesh terrains: two slots a wave
   constexpr int DS0 = 2, DS1 = 4, DS2 = 6;   // (1/2/2/3 and 0/2/3/3 splits measured after the network was halved: no change)
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     const int j = wv - 1, d = 3 * l + j;
     // with the actuator network this wave also evaluates joint j of every leg; with PD control (helpers are then only
     // present for triangle-mesh terrains) the main wave keeps the torques and barrier (B) does not exist
-    float a = net ? actions_in[(size_t)krow * 12 + d] : 0.f;
+    float a = net ? actions_in[(size_t)krow * act_stride + d] : 0.f;
     a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);
     const float tgt = a * g.action_scale + lm_.f(LM_DEFAULT_POS + j);
     const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + d;
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   if (MODE != 1 && !split) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      float a = actions_in ? actions_in[(size_t)krow * 12 + 3 * l + j] : C->actions[(size_t)e * 12 + 3 * l + j];
+      float a = actions_in ? actions_in[(size_t)krow * act_stride + 3 * l + j] : C->actions[(size_t)e * 12 + 3 * l + j];
       a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);        // LR:93-94
       act[j] = a;
       if (valid && actions_in) C->actions[(size_t)e * 12 + 3 * l + j] = a;
@@ -1043,7 +1044,9 @@ enum { S_ROOT = 0, S_DOF = 13, S_CF = 37, S_RB = S_CF + LG_MAX_BODIES * 3, S_ACT
 // ids/n: optional env subset (row k of the launch <-> env ids[k]); mode 0 = LeggedRobot.post_physics_step,
 // mode 1 = RobotBatchRollout.post_physics_step_rollout (robot_batch_rollout.py:763-817: no callback, no termination,
 // no reset, rewards without episode sums).
-__global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int mode) {
+// rew_out (optional): the reward of launch row k also goes to rew_out[k * rew_stride] (lg_rollout_batch: column i of (n, horizon)).
+__global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int mode,
+                                                   float* __restrict__ rew_out, int rew_stride) {
   __shared__ float s_h[EPBP][MAX_P];
   __shared__ float s_env[EPBP][S_STRIDE];
   __shared__ float s_prop[EPBP][48];
@@ -1330,6 +1333,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
         rew += r; s_rk[el][k] = r;
       }
       C->rew[e] = rew;
+      if (rew_out) rew_out[(size_t)(e0 + el) * rew_stride] = rew;
       const bool do_reset = !ro && (term || tout);
       if (do_reset) { reset_env(C, V, e, 1, s_u[el], false); s_root_dirty[el] = 1; if (g.curriculum) s_level[el] = (float)C->levels[e]; }
       s_rootz[el] = root[2];
@@ -1720,25 +1724,25 @@ int lg_get_tensor(lg_ctx* c, int id, void** dptr, int64_t shape[4], int32_t* ndi
 
 __global__ void set_n_stepped(DevCtx* C, int n) { C->n_stepped = n; }
 
-static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t* ids, int n, int mode) {
+static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t* ids, int n, int mode, float* rew_out = nullptr, int rew_stride = 0) {
   const int nb = (n + EPBP - 1) / EPBP;
-  hipLaunchKernelGGL(post_kernel, dim3(nb), dim3(256), 0, st, c->d, ids, n, mode);
+  hipLaunchKernelGGL(post_kernel, dim3(nb), dim3(256), 0, st, c->d, ids, n, mode, rew_out, rew_stride);
   if (ev) (void)hipEventRecord(ev[2], st);
   if (ev) (void)hipEventRecord(ev[3], st);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
 
-static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n) {
+static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = 12) {
   const int nb = (n + EPB - 1) / EPB;
   // helper waves: with the actuator network (unless LG_SPLIT=0), and always on triangle-mesh terrains, whose contact
   // detection is a BVH traversal per collision sphere that should not sit on the main wave
   const int nact = ((c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET && c->split) || c->h.ter.mesh_type == LG_MESH_TRIMESH) ? 3 : 0;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
-    hipLaunchKernelGGL((physics_kernel<0, true>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n);
+    hipLaunchKernelGGL((physics_kernel<0, true>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride);
   else
-    hipLaunchKernelGGL((physics_kernel<0, false>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n);
+    hipLaunchKernelGGL((physics_kernel<0, false>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride);
 }
 
 int lg_step(lg_ctx* c, const float* actions, void* stream) {
@@ -1864,6 +1868,23 @@ int lg_sync_main_to_rollout(lg_ctx* c, int32_t rollouts_per_main, float pos_drif
   return LG_OK;
 }
 
+// rollout_batch (robot_traj_grad_sampling.py:249-280): sync, `horizon` rollout steps, sync -- enqueued by one call.  Step i
+// reads its action rows in place from the (n, horizon, 12) plan and the post kernel writes column i of `rewards`.
+int lg_rollout_batch(lg_ctx* c, const float* all_us, int32_t horizon, const int32_t* env_ids, int32_t n, int32_t rollouts_per_main,
+                     float pos_drift, float* rewards, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (!all_us || !env_ids || !rewards || horizon <= 0 || n <= 0 || n > c->h.N) { c->err = "bad rollout_batch arguments"; return LG_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = lg_sync_main_to_rollout(c, rollouts_per_main, pos_drift, stream);
+  if (rc != LG_OK) return rc;
+  for (int i = 0; i < horizon; ++i) {
+    launch_physics(c, st, all_us + (size_t)i * 12, env_ids, n, horizon * 12);
+    rc = launch_post(c, st, nullptr, env_ids, n, 1, rewards + i, horizon);
+    if (rc != LG_OK) return rc;
+  }
+  return lg_sync_main_to_rollout(c, rollouts_per_main, pos_drift, stream);
+}
+
 int lg_set_extra_obs(lg_ctx* c, const float* dptr) {
   if (!c) return LG_ERR_INVALID;
   if (c->h.cfg.num_extra_obs > 0 && !dptr) { c->err = "extra obs buffer is null"; return LG_ERR_INVALID; }
@@ -1899,7 +1920,7 @@ int lg_profile_end(lg_ctx* c, float mean_ms[3], int32_t* nsamples) {
 int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
   const int nb = (c->h.N + EPB - 1) / EPB;
-  hipLaunchKernelGGL((physics_kernel<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N);
+  hipLaunchKernelGGL((physics_kernel<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N, 12);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -1908,9 +1929,9 @@ int lg_simulate(lg_ctx* c, void* stream) {
   if (!c) return LG_ERR_INVALID;
   const int nb = (c->h.N + EPB - 1) / EPB;
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
-    hipLaunchKernelGGL((physics_kernel<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N);
+    hipLaunchKernelGGL((physics_kernel<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, 12);
   else
-    hipLaunchKernelGGL((physics_kernel<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N);
+    hipLaunchKernelGGL((physics_kernel<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, 12);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }

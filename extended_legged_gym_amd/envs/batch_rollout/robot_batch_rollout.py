@@ -187,6 +187,14 @@ class RobotBatchRollout(LeggedRobot):
     def rollout_batch(self, all_us):
         """Horizon loop of the sampling planners (`robot_traj_grad_sampling.py:249-280`): `all_us` (num_main * R, H,
         num_actions) → per-step rewards (num_main * R, H)."""
+        if type(self).step_rollout is RobotBatchRollout.step_rollout or getattr(self, "_plain_rollout_steps", False):
+            # no sensor update between physics and post-physics: the whole loop is one library call (lg_rollout_batch)
+            if all_us.shape[0] != len(self.rollout_env_indices):
+                raise ValueError(f"Expected a plan for {len(self.rollout_env_indices)} rollout envs, got {all_us.shape[0]}")
+            drift = float(getattr(self.cfg.domain_rand, "rollout_envs_sync_pos_drift", 0.0))
+            rews = self.core.rollout_batch(all_us.to(self.device), self._rollout_ids_i32, self.num_rollout_per_main, drift)
+            self.t_rollout = self.t_main
+            return rews
         self._sync_main_to_rollout()
         H = all_us.shape[1]
         rews = torch.zeros(all_us.shape[0], H, device=self.device)

@@ -162,6 +162,11 @@ class RobotBatchRolloutPercept(RobotBatchRollout):
         self.t_rollout = self.t_main
         return out
 
+    @property
+    def _plain_rollout_steps(self):
+        """No sensor runs between physics and post-physics: `rollout_batch` may take the one-call path."""
+        return self.ray_caster is None and self.mesh_sdf is None
+
     def step_rollout(self, rollout_actions, noise_scales=None):
         if self.ray_caster is None and self.mesh_sdf is None:
             return super().step_rollout(rollout_actions, noise_scales)

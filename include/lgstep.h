@@ -276,6 +276,14 @@ int lg_post_physics_subset(lg_ctx* ctx, const int32_t* env_ids, int32_t n, int32
  * rollouts; pos_drift > 0 adds U(-drift/2, drift/2) to the copied base positions (:1493-1497). */
 int lg_sync_main_to_rollout(lg_ctx* ctx, int32_t rollouts_per_main, float pos_drift, void* stream);
 
+/* rollout_batch (envs/batch_rollout/robot_traj_grad_sampling.py:249-280, the horizon loop every sampling planner drives):
+ * _sync_main_to_rollout, then `horizon` times step_rollout with all_us[:, i, :] (row k of the (n, horizon, 12) plan belongs
+ * to env_ids[k]; read in place, no per-step copy) while rewards[k, i] receives the reward of that step, then
+ * _sync_main_to_rollout again.  Device pointers; 2 + 2 * horizon launches enqueued by one call.  Envs without perception
+ * sensors between physics and post-physics only (RobotBatchRollout; the percept env keeps its per-step calls). */
+int lg_rollout_batch(lg_ctx* ctx, const float* all_us, int32_t horizon, const int32_t* env_ids, int32_t n, int32_t rollouts_per_main,
+                     float pos_drift, float* rewards, void* stream);
+
 /* Pieces of lg_step, exposed because the reference exposes them as overridable methods / gym calls. */
 int lg_compute_torques(lg_ctx* ctx, const float* actions, void* stream);  /* -> LG_T_TORQUES (and LSTM state) */
 int lg_simulate(lg_ctx* ctx, void* stream);                               /* one dt with LG_T_TORQUES applied */

@@ -68,6 +68,7 @@ def test_robot_batch_rollout_contract():
     cfg.noise.add_noise = False
     cfg.domain_rand.randomize_friction = False
     cfg.domain_rand.push_robots = False
+    cfg.rewards.only_positive_rewards = False       # random actions earn negative totals: keep them visible
     cfg.seed = 2
     env = RobotBatchRollout(cfg, sim_params_for(cfg), "native_hip", "cuda:0", True)
     assert (env.num_envs, env.total_num_envs, env.num_rollout_per_main) == (16, 144, 8)
@@ -95,10 +96,23 @@ def test_robot_batch_rollout_contract():
     assert torch.equal(env.episode_length_buf, ep_before)            # rollout steps do not age episodes
     assert not torch.allclose(ro[:, 0, :3], main_before[:, :3])      # but the rollouts did move
     # different actions → rollouts diverge; a horizon of rollout steps returns per-step rewards
-    rews = env.rollout_batch(torch.randn(128, 4, 12, generator=g).cuda())
+    plan = torch.randn(128, 4, 12, generator=g).cuda()
+    rews = env.rollout_batch(plan)                                    # lg_rollout_batch: the whole loop in one call
     assert rews.shape == (128, 4) and torch.isfinite(rews).all()
     ro = env.root_states[env.rollout_env_indices].view(16, 8, 13)
     assert torch.allclose(ro, ro[:, :1].expand_as(ro))               # rollout_batch ends with a re-sync
+    obs_native = env.obs_buf.clone()
+    # ... bit for bit what the reference's horizon loop returns (robot_traj_grad_sampling.py:249-280) when driven step by step
+    env._sync_main_to_rollout()
+    loop = torch.zeros_like(rews)
+    for i in range(4):
+        loop[:, i] = env.step_rollout(plan[:, i])[2]
+    assert torch.equal(env.obs_buf[env.rollout_env_indices], obs_native[env.rollout_env_indices])   # obs of the last step
+    env._sync_main_to_rollout()
+    assert torch.equal(rews, loop)
+    assert rews.std() > 0
+    with pytest.raises(ValueError):
+        env.rollout_batch(plan[:100])
     # legacy interface: mean action per main env + noise scales
     o2, _, r2, _, _ = env.step_rollout(torch.zeros(16, 12).cuda(), noise_scales=0.1 * torch.ones(12))
     assert o2.shape == (128, 48)
