@@ -6,9 +6,10 @@
 //   physics_kernel   one DPP quad (4 lanes) per env, one leg per lane, 16 envs per wave64; clip actions, then
 //                    `decimation` x (actuator torques [PD | LSTM] + articulated dynamics + contact) entirely in
 //                    registers/LDS; state is read once and written once per policy step.
-//   post_kernel      4 envs per 256-thread workgroup, one wave per env: rows staged in LDS with one round of loads,
-//                    cooperative terrain height scan, the post-physics logic in lane-parallel stages that keep the
-//                    reference's order of side effects, observation rows with noise; the last workgroup to arrive
+//   post_kernel      4 envs per 256-thread workgroup.  Wide stages one wave per env: rows staged in LDS with one round of
+//                    loads, terrain height scan, observation rows with noise.  Narrow stages (the post-physics logic in
+//                    lane-parallel stages that keep the reference's order of side effects) for all four envs on one
+//                    wave, sixteen lanes per env; the last workgroup to arrive
 //                    (sharded device-scope arrival counters) publishes the episode statistics of the step, summed
 //                    with integer atomics (deterministic).
 //   finalize_kernel  one workgroup: the same statistics step behind lg_reset_idx.
@@ -22,7 +23,7 @@
 #include "lg_physics.h"
 
 #define EPB 16          // envs per workgroup (= per main wave) in physics_kernel
-#define EPBP 4          // envs per 256-thread workgroup in post_kernel: short per-phase loops, 4 workgroups per CU at N = 4096
+#define EPBP 4          // envs per 256-thread workgroup in post_kernel (a wave per env in the wide stages, 16 lanes per env in the narrow ones); 4 workgroups per CU at N = 4096
 #define MAX_P 192       // height-scan points per env held in LDS
 #define PART_STRIDE (LG_MAX_REWARD_TERMS + 3)
 
