@@ -1042,29 +1042,48 @@ enum { S_ROOT = 0, S_DOF = 13, S_CF = 37, S_RB = S_CF + LG_MAX_BODIES * 3, S_ACT
        S_AIR = S_BAA + 3, S_CT = S_AIR + 4, S_BLV = S_CT + 4, S_BAV = S_BLV + 3, S_PG = S_BAV + 3, S_SUMS = S_PG + 3,
        S_GAIT = S_SUMS + LG_MAX_REWARD_TERMS, S_STRIDE = S_GAIT + 1 + 2 };
 
+// LDS of one post-physics instance (EPBP envs): a workgroup of post_kernel, or one wave of the fused step kernel
+struct alignas(16) PostLds {
+  int64_t s_eplen[EPBP];
+  float s_h[EPBP][MAX_P];
+  float s_env[EPBP][S_STRIDE];
+  float s_prop[EPBP][48];
+  float s_part[EPBP][PART_STRIDE];
+  float s_u[EPBP][LG_RS_NOISE];      // uniforms of slots 0..31 (commands, push, curriculum, reset)
+  float s_feat[EPBP][F_COUNT][12];
+  float s_fsum[EPBP][F_COUNT];
+  float s_fn[EPBP][LG_MAX_BODIES];
+  float s_rk[EPBP][LG_MAX_REWARD_TERMS];
+  float s_old[EPBP][8];
+  float s_rootz[EPBP], s_bh[EPBP];
+  float s_level[EPBP];               // terrain level at the start of the step (re-read after a reset)
+  int s_e[EPBP];
+  uint8_t s_lastc[EPBP][4], s_oldc[EPBP][4];
+  uint8_t s_flag[EPBP], s_did_reset[EPBP], s_root_dirty[EPBP], s_term[EPBP], s_tout[EPBP];
+};
+
+// The post-physics step of one instance = EPBP (4) envs: rows [inst * 4, inst * 4 + 4) of the launch.
+//   FUSED = false: the instance is a 256-thread workgroup of post_kernel; in the wide stages wave w owns env w.
+//   FUSED = true:  the instance is ONE wave of the fused step kernel (physics_kernel's tail: the four waves of a physics
+//                  workgroup take four envs each of its sixteen); the wave owns all four envs in the wide stages (NQ = 4
+//                  rounds of the same lane mapping) and runs the narrow stages for them as below.  The workgroup barriers
+//                  stay (every wave passes the same ones); the instances never exchange data.
 // ids/n: optional env subset (row k of the launch <-> env ids[k]); mode 0 = LeggedRobot.post_physics_step,
 // mode 1 = RobotBatchRollout.post_physics_step_rollout (robot_batch_rollout.py:763-817: no callback, no termination,
 // no reset, rewards without episode sums).
 // rew_out (optional): the reward of launch row k also goes to rew_out[k * rew_stride] (lg_rollout_batch: column i of (n, horizon)).
-__global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int mode,
-                                                   float* __restrict__ rew_out, int rew_stride) {
-  __shared__ float s_h[EPBP][MAX_P];
-  __shared__ float s_env[EPBP][S_STRIDE];
-  __shared__ float s_prop[EPBP][48];
-  __shared__ float s_rootz[EPBP];
-  __shared__ float s_part[EPBP][PART_STRIDE];
-  __shared__ uint8_t s_lastc[EPBP][4];
-  __shared__ int64_t s_eplen[EPBP];
-  __shared__ uint8_t s_flag[EPBP];
-  __shared__ float s_u[EPBP][LG_RS_NOISE];      // uniforms of slots 0..31 (commands, push, curriculum, reset)
-  __shared__ uint8_t s_did_reset[EPBP], s_root_dirty[EPBP];
-  __shared__ float s_level[EPBP];               // terrain level at the start of the step (re-read after a reset)
+// ninst: instances of the launch (rows of the per-instance statistics the finishing workgroup adds up).
+template <bool FUSED>
+LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int mode, float* __restrict__ rew_out,
+                          int rew_stride, PostLds& L, int inst, int ninst) {
+  constexpr int NQ = FUSED ? EPBP : 1;          // envs a wave owns in the wide stages
   const lg_config& g = C->cfg; const lg_robot_model& m = C->model;
-  const int tid = threadIdx.x, e0 = blockIdx.x * EPBP;
-  const int nenv = min(EPBP, n - e0);
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  const int itid = FUSED ? ln : tid;            // thread index within the instance
+  const int e0 = inst * EPBP;
+  const int nenv = max(0, min(EPBP, n - e0));
   const bool ro = mode == 1;
-  __shared__ int s_e[EPBP];
-  if (tid < EPBP) s_e[tid] = tid < nenv ? (ids ? ids[e0 + tid] : e0 + tid) : 0;
+  if (itid < EPBP) L.s_e[itid] = itid < nenv ? (ids ? ids[e0 + itid] : e0 + itid) : 0;
   lds_barrier();
   const int P = g.measure_heights ? C->P : 0;
   const int64_t step = ro ? C->counters[3] + 1 : C->counters[0] + 1;   // LR:123 (finalize_kernel stores it)
@@ -1072,17 +1091,21 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   const float dt = g.sim_dt * g.decimation;
   const int B = C->B;
 #ifdef LG_STAMPS
-  unsigned long long* stamps = (blockIdx.x == 0 && tid == 0) ? C->stamps : nullptr;
+  unsigned long long* stamps = (inst == 0 && itid == 0) ? C->stamps : nullptr;
   unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
 
-  // One wave per env from the first load to the last store: wave w of the workgroup owns env e0 + w, lane ln owns entry
-  // ln (+ 64 j) of each of its rows.  No index of this kernel needs an integer division (rows used to be dealt to the 256
-  // threads of the workgroup by flat index: ~25 instructions per division by a run-time row length, a dozen of them).
-  const int wv = tid >> 6, ln = tid & 63;
-  const bool have = wv < nenv;
-  const int el = have ? wv : 0, e = s_e[el];       // waves without an env shadow env 0 of the workgroup and store nothing
-  float* S = s_env[el];
+  // Wide stages: a wave owns an env from the first load to the last store, lane ln owns entry ln (+ 64 j) of each of its
+  // rows.  No index needs an integer division (rows used to be dealt to the 256 threads of the workgroup by flat index:
+  // ~25 instructions per division by a run-time row length, a dozen of them).
+  const int wv_el = wv < nenv ? wv : 0;          // FUSED = false: this wave's env (waves without one shadow env 0 and store nothing)
+  bool hv_[NQ]; int eq[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int el = FUSED ? q : wv_el;
+    hv_[q] = FUSED ? q < nenv : wv < nenv;
+    eq[q] = L.s_e[el];
+  }
 
   // ---- (1a) height scan from the post-physics root pose (LR:400-401).  Order of the memory traffic of this kernel's
   // first stage: [scan inputs: base pose + scan points] -> [all staging loads] -> wait for the scan inputs only ->
@@ -1092,81 +1115,106 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   static_assert(MAX_P <= 3 * 64, "height scan assumes three points per lane");
   const bool scan = P > 0 && !ro;
   const bool plane = C->ter.mesh_type == LG_MESH_PLANE;
-  HeightProbe hp_[3]; int hpi[3];
-  float rq[4], hxy[3][2];
+  HeightProbe hp_[NQ][3]; int hpi[NQ][3];
+  float rq[NQ][4], hxy[3][2];
   {
     const float* hpts = scan ? C->height_points : C->root;
-    const float* rt = C->root + (size_t)e * 13;
-    rq[0] = rt[0]; rq[1] = rt[1]; rq[2] = rt[5]; rq[3] = rt[6];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float* rt = C->root + (size_t)eq[q] * 13;
+      rq[q][0] = rt[0]; rq[q][1] = rt[1]; rq[q][2] = rt[5]; rq[q][3] = rt[6];
+    }
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int p = ln + 64 * u;
-      const bool ok = scan && have && p < P;
-      hpi[u] = ok ? p : -1;
-      const int pp = ok ? p : 0;
+      const bool okp = scan && p < P;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) hpi[q][u] = (okp && hv_[q]) ? p : -1;
+      const int pp = okp ? p : 0;
       hxy[u][0] = hpts[2 * pp]; hxy[u][1] = hpts[2 * pp + 1];
     }
   }
-  float h_keep[3] = {0.f, 0.f, 0.f};          // rollout steps keep the heights measured by the last main step
+  float h_keep[NQ][3];                         // rollout steps keep the heights measured by the last main step
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) h_keep[q][u] = 0.f;
   if (P > 0 && ro) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int p = ln + 64 * u;
-      if (have && p < P) { hpi[u] = p; h_keep[u] = C->heights[(size_t)e * C->P + p]; }
-    }
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int p = ln + 64 * u;
+        if (hv_[q] && p < P) { hpi[q][u] = p; h_keep[q][u] = C->heights[(size_t)eq[q] * C->P + p]; }
+      }
   }
 
-  // ---- (0) stage this wave's env rows in LDS.  Every global load is issued before the first LDS store, so the
-  // phase costs one memory latency instead of one per tensor.
+  // ---- (0) stage the env rows in LDS.  Every global load is issued before the first LDS store, so the phase costs one
+  // memory latency instead of one per tensor.
   static_assert(LG_MAX_BODIES * 13 <= 256 && LG_MAX_BODIES * 3 <= 64 && LG_MAX_REWARD_TERMS <= 64 && LG_RS_NOISE / 4 <= 64,
                 "staging assumes <= 4 row chunks of 64 lanes for the body states and one for every other row");
-#define LDV(name, SRC, LEN) float name = 0.f; if (ln < (LEN)) name = (SRC)[(size_t)e * (LEN) + ln];
-#define STV(name, OFF, LEN) if (have && ln < (LEN)) S[(OFF) + ln] = name;
   const int LRB = B * 13;
-  float v_rb[4];
+  float v_rb[NQ][4], v_row[NQ][14], v_sum[NQ];
+  uint8_t v_lc[NQ], v_flag[NQ]; int64_t v_len[NQ], v_lvl[NQ];
+#define LDV(i, SRC, LEN) v_row[q][i] = 0.f; if (ln < (LEN)) v_row[q][i] = (SRC)[(size_t)e * (LEN) + ln];
+#define STV(i, OFF, LEN) if (hv_[q] && ln < (LEN)) S[(OFF) + ln] = v_row[q][i];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k_ = ln + j * 64; v_rb[j] = 0.f;
-    if (k_ < LRB) v_rb[j] = C->rigid[(size_t)e * LRB + k_];
+  for (int q = 0; q < NQ; ++q) {
+    const int e = eq[q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k_ = ln + j * 64; v_rb[q][j] = 0.f;
+      if (k_ < LRB) v_rb[q][j] = C->rigid[(size_t)e * LRB + k_];
+    }
+    LDV(0, C->root, 13) LDV(1, C->dof, 24) LDV(2, C->cforce, B * 3)
+    LDV(3, C->actions, 12) LDV(4, C->last_actions, 12) LDV(5, C->last_dof_vel, 12) LDV(6, C->torques, 12)
+    LDV(7, C->last_root_vel, 6) LDV(8, C->commands, 4) LDV(9, C->base_lin_acc, 3) LDV(10, C->base_ang_acc, 3)
+    LDV(11, C->feet_air, 4) LDV(12, C->feet_ctime, 4) LDV(13, C->gait_idx, 1)
+    v_sum[q] = 0.f;                                    // episode sums are (K, N): row k, envs contiguous
+    if (ln < g.num_reward_terms) v_sum[q] = C->ep_sums[(size_t)ln * C->N + e];
+    v_lc[q] = 0; if (ln < 4) v_lc[q] = C->last_contacts[(size_t)e * 4 + ln];
+    v_len[q] = C->ep_len[e]; v_flag[q] = C->reset_buf[e]; v_lvl[q] = C->levels[e];
+    if (!(g.curriculum && !ro)) v_lvl[q] = 0;
   }
-  LDV(v_root, C->root, 13) LDV(v_dof, C->dof, 24) LDV(v_cf, C->cforce, B * 3)
-  LDV(v_act, C->actions, 12) LDV(v_lact, C->last_actions, 12) LDV(v_ldv, C->last_dof_vel, 12) LDV(v_tq, C->torques, 12)
-  LDV(v_lrv, C->last_root_vel, 6) LDV(v_cmd, C->commands, 4) LDV(v_bla, C->base_lin_acc, 3) LDV(v_baa, C->base_ang_acc, 3)
-  LDV(v_air, C->feet_air, 4) LDV(v_ct, C->feet_ctime, 4) LDV(v_gait, C->gait_idx, 1)
-  float v_sum = 0.f;                                   // episode sums are (K, N): row k, envs contiguous
-  if (ln < g.num_reward_terms) v_sum = C->ep_sums[(size_t)ln * C->N + e];
-  uint8_t v_lc = 0; if (ln < 4) v_lc = C->last_contacts[(size_t)e * 4 + ln];
-  int64_t v_len = C->ep_len[e]; uint8_t v_flag = C->reset_buf[e]; int64_t v_lvl = C->levels[e];
-  if (!(g.curriculum && !ro)) v_lvl = 0;
   float nv_pre[4] = {0.f, 0.f, 0.f, 0.f};            // noise scales of this lane's first four observation entries (stage 3)
   if (g.add_noise) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (4 * ln + i < g.num_obs) nv_pre[i] = C->noise_vec[4 * ln + i];
   }
-  if (have && ln < LG_RS_NOISE / 4)                   // one Philox call per (env, slot group): 8 lanes
-    uniform_draw4(C, e, ln, step, rstream, &s_u[el][4 * ln]);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int el = FUSED ? q : wv_el;
+    if (hv_[q] && ln < LG_RS_NOISE / 4)               // one Philox call per (env, slot group): 8 lanes
+      uniform_draw4(C, eq[q], ln, step, rstream, &L.s_u[el][4 * ln]);
+  }
   // (1a, continued) the scan inputs are here: issue the height gathers
-  {
-    const float qz = rq[2], qw = rq[3];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float qz = rq[q][2], qw = rq[q][3];
     const float nrm = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
     const float qzn = qz / nrm, qwn = qw / nrm;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) hp_[u] = terrain_height_probe(C, qzn, qwn, rq[0], rq[1], hxy[u][0], hxy[u][1]);
+    for (int u = 0; u < 3; ++u) hp_[q][u] = terrain_height_probe(C, qzn, qwn, rq[q][0], rq[q][1], hxy[u][0], hxy[u][1]);
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k_ = ln + j * 64;
-    if (have && k_ < LRB) S[S_RB + k_] = v_rb[j];
+  for (int q = 0; q < NQ; ++q) {
+    const int el = FUSED ? q : wv_el;
+    float* S = L.s_env[el];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k_ = ln + j * 64;
+      if (hv_[q] && k_ < LRB) S[S_RB + k_] = v_rb[q][j];
+    }
+    STV(0, S_ROOT, 13) STV(1, S_DOF, 24) STV(2, S_CF, B * 3)
+    STV(3, S_ACT, 12) STV(4, S_LACT, 12) STV(5, S_LDV, 12) STV(6, S_TQ, 12)
+    STV(7, S_LRV, 6) STV(8, S_CMD, 4) STV(9, S_BLA, 3) STV(10, S_BAA, 3)
+    STV(11, S_AIR, 4) STV(12, S_CT, 4) STV(13, S_GAIT, 1)
+    if (hv_[q] && ln < g.num_reward_terms) S[S_SUMS + ln] = v_sum[q];
+    if (hv_[q] && ln < 4) L.s_lastc[el][ln] = v_lc[q];
+    if (hv_[q] && ln == 0) { L.s_eplen[el] = v_len[q]; L.s_flag[el] = v_flag[q]; L.s_level[el] = (float)v_lvl[q]; }
   }
-  STV(v_root, S_ROOT, 13) STV(v_dof, S_DOF, 24) STV(v_cf, S_CF, B * 3)
-  STV(v_act, S_ACT, 12) STV(v_lact, S_LACT, 12) STV(v_ldv, S_LDV, 12) STV(v_tq, S_TQ, 12)
-  STV(v_lrv, S_LRV, 6) STV(v_cmd, S_CMD, 4) STV(v_bla, S_BLA, 3) STV(v_baa, S_BAA, 3)
-  STV(v_air, S_AIR, 4) STV(v_ct, S_CT, 4) STV(v_gait, S_GAIT, 1)
 #undef LDV
 #undef STV
-  if (have && ln < g.num_reward_terms) S[S_SUMS + ln] = v_sum;
-  if (have && ln < 4) s_lastc[el][ln] = v_lc;
-  if (have && ln == 0) { s_eplen[el] = v_len; s_flag[el] = v_flag; s_level[el] = (float)v_lvl; }
   lds_barrier();
   STAMP(11);
 
@@ -1182,14 +1230,6 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   //   (2.2) feature sums (one lane per feature, DOF order = the serial order), callback + termination (one lane);
   //   (2.3) reward terms in config order, episode sums, reset;
   //   (2.4) proprioceptive observation entries, gait phase.
-  __shared__ float s_feat[EPBP][F_COUNT][12];
-  __shared__ float s_fsum[EPBP][F_COUNT];
-  __shared__ float s_fn[EPBP][LG_MAX_BODIES];
-  __shared__ float s_bh[EPBP];
-  __shared__ uint8_t s_term[EPBP], s_tout[EPBP];
-  __shared__ float s_rk[EPBP][LG_MAX_REWARD_TERMS];
-  __shared__ float s_old[EPBP][8];
-  __shared__ uint8_t s_oldc[EPBP][4];
   static_assert(EPBP * 16 == 64 && F_COUNT <= 8, "phase 2: sixteen lanes per env on one wave");
   unsigned term_mask = 0;                       // which reward terms are switched on (wave-uniform)
   int kfat = g.num_reward_terms;                // position of feet_air_time in the evaluation order (K = absent)
@@ -1199,14 +1239,14 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     if (id == LG_REW_FEET_AIR_TIME) kfat = k;
   }
   {
-    const bool mine = wv == (int)((blockIdx.x >> 8) & 3u);   // (workgroups 256 apart share a CU when all 1024 are resident)
+    const bool mine = FUSED || wv == (int)((blockIdx.x >> 8) & 3u);   // (workgroups 256 apart share a CU when all 1024 are resident)
     const int el = ln >> 4, sl = ln & 15;                   // env of the workgroup, lane within the env (shadow the wave-per-env names)
     const bool have = mine && el < nenv;
-    float* S = s_env[have ? el : 0];
+    float* S = L.s_env[have ? el : 0];
     EnvView V;
     V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
     V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT; V.bla = S + S_BLA;
-    V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = s_lastc[have ? el : 0];
+    V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = L.s_lastc[have ? el : 0];
     float* root = V.root; float* dof = V.dof;
 
     // (2.1)
@@ -1224,7 +1264,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     if (have && sl < 12) {
       const int d = sl;
       const float q_ = dof[2 * d], qd = dof[2 * d + 1], tq = V.tq[d];
-      float (*F)[12] = s_feat[el];
+      float (*F)[12] = L.s_feat[el];
       F[F_TQ2][d] = tq * tq;
       F[F_QD2][d] = qd * qd;
       { float a = (V.ldv[d] - qd) / dt; F[F_ACC2][d] = a * a; }
@@ -1237,45 +1277,49 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     if (have) {
       for (int b = sl; b < B; b += 16) {
         const float* cf = V.cf + 3 * b;
-        s_fn[el][b] = sqrtf(cf[0] * cf[0] + cf[1] * cf[1] + cf[2] * cf[2]);
+        L.s_fn[el][b] = sqrtf(cf[0] * cf[0] + cf[1] * cf[1] + cf[2] * cf[2]);
       }
     }
   }
-  // (1b) the height samples: rows into LDS (and to the measured_heights tensor on main steps), every wave for its own env
+  // (1b) the height samples: rows into LDS (and to the measured_heights tensor on main steps), every wave for its own envs
 #pragma unroll
-  for (int u = 0; u < 3; ++u) if (hpi[u] >= 0) {
-    const float hv = ro ? h_keep[u] : (plane ? 0.f : terrain_height_value(C, hp_[u]));
-    s_h[el][hpi[u]] = hv;
-    if (!ro) C->heights[(size_t)e * C->P + hpi[u]] = hv;
+  for (int q = 0; q < NQ; ++q) {
+    const int el = FUSED ? q : wv_el;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) if (hpi[q][u] >= 0) {
+      const float hv = ro ? h_keep[q][u] : (plane ? 0.f : terrain_height_value(C, hp_[q][u]));
+      L.s_h[el][hpi[q][u]] = hv;
+      if (!ro) C->heights[(size_t)eq[q] * C->P + hpi[q][u]] = hv;
+    }
   }
   lds_barrier();
   STAMP(19);
   {
-    const bool mine = wv == (int)((blockIdx.x >> 8) & 3u);
+    const bool mine = FUSED || wv == (int)((blockIdx.x >> 8) & 3u);
     const int el = ln >> 4, sl = ln & 15;
     const bool have = mine && el < nenv;
-    const int e = s_e[have ? el : 0];
-    float* S = s_env[have ? el : 0];
+    const int e = L.s_e[have ? el : 0];
+    float* S = L.s_env[have ? el : 0];
     EnvView V;
     V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
     V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT; V.bla = S + S_BLA;
-    V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = s_lastc[have ? el : 0];
+    V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = L.s_lastc[have ? el : 0];
     float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
 
     // (2.2)
     if (have && sl < F_COUNT) {
       float sacc = 0.f;
-      for (int d = 0; d < 12; ++d) sacc += s_feat[el][sl][d];
-      s_fsum[el][sl] = sacc;
+      for (int d = 0; d < 12; ++d) sacc += L.s_feat[el][sl][d];
+      L.s_fsum[el][sl] = sacc;
     } else if (have && sl == 8) {
       float sacc = 0.f;
-      if ((term_mask >> LG_REW_BASE_HEIGHT) & 1u) for (int p = 0; p < P; ++p) sacc += root[2] - s_h[el][p];
-      s_bh[el] = sacc;
+      if ((term_mask >> LG_REW_BASE_HEIGHT) & 1u) for (int p = 0; p < P; ++p) sacc += root[2] - L.s_h[el][p];
+      L.s_bh[el] = sacc;
     } else if (have && sl == 9) {
-      const int64_t eplen = s_eplen[el] + (ro ? 0 : 1);                             // LR:122 (not in rollout steps)
+      const int64_t eplen = L.s_eplen[el] + (ro ? 0 : 1);                             // LR:122 (not in rollout steps)
       bool root_dirty = false;
       // _post_physics_step_callback (LR:386-403)
-      if (!ro && (int)eplen % g.resampling_steps == 0) resample_commands(C, cmd, s_u[el], LG_RS_CMD_CB);
+      if (!ro && (int)eplen % g.resampling_steps == 0) resample_commands(C, cmd, L.s_u[el], LG_RS_CMD_CB);
       if (!ro && g.heading_command) {
         float q[4] = {root[3], root[4], root[5], root[6]};
         V3 f = quat_apply(q, v3(1, 0, 0));
@@ -1283,23 +1327,23 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
         cmd[2] = fminf(fmaxf(x, -1.f), 1.f);
       }
       if (!ro && g.push_robots && (step % g.push_interval == 0)) {                    // LR:402-403, 491-496
-        root[7] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, s_u[el][LG_RS_PUSH]);
-        root[8] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, s_u[el][LG_RS_PUSH + 1]);
+        root[7] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, L.s_u[el][LG_RS_PUSH]);
+        root[8] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, L.s_u[el][LG_RS_PUSH + 1]);
         root_dirty = true;
       }
       // check_termination (LR:155-160)
       bool term = false;
-      for (int i = 0; i < m.num_termination; ++i) term |= s_fn[el][m.termination_contact_indices[i]] > 1.f;
+      for (int i = 0; i < m.num_termination; ++i) term |= L.s_fn[el][m.termination_contact_indices[i]] > 1.f;
       term |= g.terminate_on_flip && V.pg[2] > 0.f;   // anymal_c_batch_rollout.py:192-198 (stage 2.1 left the new vector in LDS)
-      term |= s_flag[el] == 2;        // physics fault flagged by physics_kernel
+      term |= L.s_flag[el] == 2;        // physics fault flagged by physics_kernel
       bool tout = (float)eplen > g.max_episode_length;
       if (ro) {                       // rollout envs never terminate on their own: flags keep their last values
-        tout = C->time_out[e] != 0; term = (s_flag[el] != 0) && !tout;
-        if (s_flag[el] == 2) C->reset_buf[e] = 1;
+        tout = C->time_out[e] != 0; term = (L.s_flag[el] != 0) && !tout;
+        if (L.s_flag[el] == 2) C->reset_buf[e] = 1;
       } else { C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0; }
-      s_term[el] = term ? 1 : 0; s_tout[el] = tout ? 1 : 0;
-      s_root_dirty[el] = root_dirty ? 1 : 0;
-      s_eplen[el] = eplen;
+      L.s_term[el] = term ? 1 : 0; L.s_tout[el] = tout ? 1 : 0;
+      L.s_root_dirty[el] = root_dirty ? 1 : 0;
+      L.s_eplen[el] = eplen;
       C->ep_len[e] = eplen;
     }
     lds_barrier();
@@ -1309,8 +1353,8 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     // Terms that come before it in the config order must still see the old values: keep a copy.
     if (have && sl == 0 && kfat < g.num_reward_terms) {
 #pragma unroll
-      for (int f = 0; f < 4; ++f) { s_old[el][f] = V.air[f]; s_old[el][4 + f] = V.ctime[f]; s_oldc[el][f] = V.lastc[f]; }
-      s_rk[el][kfat] = reward_term(C, V, e, LG_REW_FEET_AIR_TIME, s_fsum[el], s_fn[el], s_bh[el], step) * g.reward_scales[kfat];
+      for (int f = 0; f < 4; ++f) { L.s_old[el][f] = V.air[f]; L.s_old[el][4 + f] = V.ctime[f]; L.s_oldc[el][f] = V.lastc[f]; }
+      L.s_rk[el][kfat] = reward_term(C, V, e, LG_REW_FEET_AIR_TIME, L.s_fsum[el], L.s_fn[el], L.s_bh[el], step) * g.reward_scales[kfat];
     }
     lds_barrier();
     // (2.3b) every other term on its own lane (they only read); more than sixteen terms take a second round
@@ -1318,33 +1362,33 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
       if (k == kfat) continue;
       const int id = g.reward_term_ids[k];
       EnvView Vk = V;
-      if (k < kfat && kfat < g.num_reward_terms) { Vk.air = s_old[el]; Vk.ctime = s_old[el] + 4; Vk.lastc = s_oldc[el]; }
-      s_rk[el][k] = id != LG_REW_TERMINATION ? reward_term(C, Vk, e, id, s_fsum[el], s_fn[el], s_bh[el], step) * g.reward_scales[k] : 0.f;
+      if (k < kfat && kfat < g.num_reward_terms) { Vk.air = L.s_old[el]; Vk.ctime = L.s_old[el] + 4; Vk.lastc = L.s_oldc[el]; }
+      L.s_rk[el][k] = id != LG_REW_TERMINATION ? reward_term(C, Vk, e, id, L.s_fsum[el], L.s_fn[el], L.s_bh[el], step) * g.reward_scales[k] : 0.f;
     }
     lds_barrier();
     STAMP(21);
     // (2.3c) total in config order, clip, termination term, reset (LR:215-232, 144-145)
     if (have && sl == 0) {
-      const bool term = s_term[el] != 0, tout = s_tout[el] != 0;
+      const bool term = L.s_term[el] != 0, tout = L.s_tout[el] != 0;
       float rew = 0.f;
-      for (int k = 0; k < g.num_reward_terms; ++k) rew += s_rk[el][k];
+      for (int k = 0; k < g.num_reward_terms; ++k) rew += L.s_rk[el][k];
       if (g.only_positive_rewards) rew = fmaxf(rew, 0.f);
       for (int k = 0; k < g.num_reward_terms; ++k) if (g.reward_term_ids[k] == LG_REW_TERMINATION) {
         float r = ((term || tout) && !tout ? 1.f : 0.f) * g.reward_scales[k];
-        rew += r; s_rk[el][k] = r;
+        rew += r; L.s_rk[el][k] = r;
       }
       C->rew[e] = rew;
       if (rew_out) rew_out[(size_t)(e0 + el) * rew_stride] = rew;
       const bool do_reset = !ro && (term || tout);
-      if (do_reset) { reset_env(C, V, e, 1, s_u[el], false); s_root_dirty[el] = 1; if (g.curriculum) s_level[el] = (float)C->levels[e]; }
-      s_rootz[el] = root[2];
-      s_did_reset[el] = do_reset ? 1 : 0;
+      if (do_reset) { reset_env(C, V, e, 1, L.s_u[el], false); L.s_root_dirty[el] = 1; if (g.curriculum) L.s_level[el] = (float)C->levels[e]; }
+      L.s_rootz[el] = root[2];
+      L.s_did_reset[el] = do_reset ? 1 : 0;
     }
     lds_barrier();
 
     // (2.4) proprioceptive part of the observation (LR:237-244), from the post-reset state; gait scheduler (anymal.py:107-110)
     if (have) {
-      float* sp = s_prop[el];
+      float* sp = L.s_prop[el];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int i = sl + 16 * r;
@@ -1363,106 +1407,115 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
         S[S_GAIT] = x;
       }
       // episode sums and the statistics of LR:200-206, one lane per term
-      const bool do_reset = s_did_reset[el] != 0;
+      const bool do_reset = L.s_did_reset[el] != 0;
       const int K_ = g.num_reward_terms;
       for (int k = sl; k < K_ + 3; k += 16) {
         if (k < K_) {
-          float tot = S[S_SUMS + k] + (ro ? 0.f : s_rk[el][k]);  // compute_reward_rollout does not touch the episode sums
-          s_part[el][k] = do_reset ? tot : 0.f;
+          float tot = S[S_SUMS + k] + (ro ? 0.f : L.s_rk[el][k]);  // compute_reward_rollout does not touch the episode sums
+          L.s_part[el][k] = do_reset ? tot : 0.f;
           S[S_SUMS + k] = do_reset ? 0.f : tot;        // written back to (K, N) by the env's own wave below
-        } else if (k == K_) s_part[el][K_] = do_reset ? 1.f : 0.f;
-        else if (k == K_ + 1) s_part[el][K_ + 1] = s_level[el];
-        else s_part[el][K_ + 2] = do_reset ? (float)s_eplen[el] : 0.f;
+        } else if (k == K_) L.s_part[el][K_] = do_reset ? 1.f : 0.f;
+        else if (k == K_ + 1) L.s_part[el][K_ + 1] = L.s_level[el];
+        else L.s_part[el][K_ + 2] = do_reset ? (float)L.s_eplen[el] : 0.f;
       }
     }
   }
   lds_barrier();
   STAMP(13);
 
-  // ---- (2b) cooperative write-back of everything phase (2) produced or changed; history buffers (LR:148-150)
-#define UNSTAGE(DST, OFF, LEN) if (have && ln < (LEN)) (DST)[(size_t)e * (LEN) + ln] = S[(OFF) + ln];
-  UNSTAGE(C->commands, S_CMD, 4) UNSTAGE(C->feet_air, S_AIR, 4) UNSTAGE(C->feet_ctime, S_CT, 4)
-  UNSTAGE(C->base_lin_vel, S_BLV, 3) UNSTAGE(C->base_ang_vel, S_BAV, 3) UNSTAGE(C->proj_grav, S_PG, 3)
-  UNSTAGE(C->base_lin_acc, S_BLA, 3) UNSTAGE(C->base_ang_acc, S_BAA, 3) UNSTAGE(C->gait_idx, S_GAIT, 1)
-  UNSTAGE(C->last_actions, S_ACT, 12) UNSTAGE(C->last_root_vel, S_ROOT + 7, 6)
-#undef UNSTAGE
-  if (have && ln < 4) C->last_contacts[(size_t)e * 4 + ln] = s_lastc[el][ln];
-  if (have && ln < 13 && s_root_dirty[el]) C->root[(size_t)e * 13 + ln] = S[S_ROOT + ln];
-  if (have && ln < 24 && s_did_reset[el]) C->dof[(size_t)e * 24 + ln] = S[S_DOF + ln];
-  if (have && ln < 12) C->last_dof_vel[(size_t)e * 12 + ln] = S[S_DOF + 2 * ln + 1];
-  if (g.gait_enabled && !ro && have && ln < 4) C->gait_foot_z[(size_t)e * 4 + ln] = S[S_RB + m.feet_indices[ln] * 13 + 2];
-  if (g.control_type == LG_CTRL_ACTUATOR_NET && have && s_did_reset[el]) {   // anymal.py:78-82: clear the LSTM state of a reset env
-    const size_t N12 = (size_t)C->N * 12;
+  // ---- (2b) write-back of everything phase (2) produced or changed; history buffers (LR:148-150)
+#define UNSTAGE(DST, OFF, LEN) if (hv_[q] && ln < (LEN)) (DST)[(size_t)e * (LEN) + ln] = S[(OFF) + ln];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = ln + 64 * j, lay = idx >= 96 ? 1 : 0, k = idx - 96 * lay;
-      C->sea_h[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
-      C->sea_c[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
+  for (int q = 0; q < NQ; ++q) {
+    const int el = FUSED ? q : wv_el, e = eq[q];
+    const float* S = L.s_env[el];
+    UNSTAGE(C->commands, S_CMD, 4) UNSTAGE(C->feet_air, S_AIR, 4) UNSTAGE(C->feet_ctime, S_CT, 4)
+    UNSTAGE(C->base_lin_vel, S_BLV, 3) UNSTAGE(C->base_ang_vel, S_BAV, 3) UNSTAGE(C->proj_grav, S_PG, 3)
+    UNSTAGE(C->base_lin_acc, S_BLA, 3) UNSTAGE(C->base_ang_acc, S_BAA, 3) UNSTAGE(C->gait_idx, S_GAIT, 1)
+    UNSTAGE(C->last_actions, S_ACT, 12) UNSTAGE(C->last_root_vel, S_ROOT + 7, 6)
+    if (hv_[q] && ln < 4) C->last_contacts[(size_t)e * 4 + ln] = L.s_lastc[el][ln];
+    if (hv_[q] && ln < 13 && L.s_root_dirty[el]) C->root[(size_t)e * 13 + ln] = S[S_ROOT + ln];
+    if (hv_[q] && ln < 24 && L.s_did_reset[el]) C->dof[(size_t)e * 24 + ln] = S[S_DOF + ln];
+    if (hv_[q] && ln < 12) C->last_dof_vel[(size_t)e * 12 + ln] = S[S_DOF + 2 * ln + 1];
+    if (g.gait_enabled && !ro && hv_[q] && ln < 4) C->gait_foot_z[(size_t)e * 4 + ln] = S[S_RB + m.feet_indices[ln] * 13 + 2];
+    if (g.control_type == LG_CTRL_ACTUATOR_NET && hv_[q] && L.s_did_reset[el]) {   // anymal.py:78-82: clear the LSTM state of a reset env
+      const size_t N12 = (size_t)C->N * 12;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int idx = ln + 64 * j, lay = idx >= 96 ? 1 : 0, k = idx - 96 * lay;
+        C->sea_h[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
+        C->sea_c[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
+      }
     }
+    if (hv_[q] && ln < g.num_reward_terms) C->ep_sums[(size_t)ln * C->N + e] = S[S_SUMS + ln];   // back to the (K, N) rows
   }
+#undef UNSTAGE
 
-  // ---- per-workgroup episode statistics, summed in fixed env order (deterministic)
-  if (have && ln < g.num_reward_terms) C->ep_sums[(size_t)ln * C->N + e] = S[S_SUMS + ln];   // back to the (K, N) rows
+  // ---- per-instance episode statistics, summed in fixed env order (deterministic); written by the instance's first wave
   const int KP = g.num_reward_terms + 3;
+  const bool stat_wave = FUSED || wv == 0;
   bool any_reset = false;
-  for (int el2 = 0; el2 < nenv; ++el2) any_reset |= s_did_reset[el2] != 0;
+  for (int el2 = 0; el2 < nenv; ++el2) any_reset |= L.s_did_reset[el2] != 0;
   // rows of the reset envs: 64-bit fixed-point integer atomics (order-independent, hence deterministic)
-  if (tid < KP && any_reset) {
+  if (stat_wave && ln < KP && any_reset) {
     float sacc = 0.f;
-    for (int el2 = 0; el2 < nenv; ++el2) sacc += s_part[el2][tid];
-    __hip_atomic_fetch_add(C->acc + tid, __double2ll_rn((double)sacc * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int el2 = 0; el2 < nenv; ++el2) sacc += L.s_part[el2][ln];
+    __hip_atomic_fetch_add(C->acc + ln, __double2ll_rn((double)sacc * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (tid == KP + 1) {
+  if (stat_wave && ln == KP + 1) {
     float sacc = 0.f;
-    for (int el2 = 0; el2 < nenv; ++el2) sacc += s_part[el2][g.num_reward_terms + 1];
-    st_dev(C->lvl_part + blockIdx.x, sacc);
+    for (int el2 = 0; el2 < nenv; ++el2) sacc += L.s_part[el2][g.num_reward_terms + 1];
+    st_dev(C->lvl_part + inst, sacc);
   }
   // ---- arrival: the last workgroup to arrive finishes the step (statistics, extras, counters).  Arrivals are counted per
   // shard (blockIdx & 7: eight counters on eight cache lines, ~1/8 of the contention of one), the shard that fills up
   // counts itself on a ninth.  Everything the finishing workgroup reads (the accumulators, the level sums) was written
-  // above by THIS wave as device-scope accesses; the wave waits for them to be acknowledged (vmcnt(0)) and then counts
-  // its arrival.  The counter's reply is only looked at after the observation rows, which hide its round trip.
-  static_assert(LG_MAX_REWARD_TERMS + 3 + 2 <= 64, "statistics rows and the arrival counter are written by wave 0");
+  // above as device-scope accesses by the statistics wave(s); each waits for them to be acknowledged (vmcnt(0)), and then
+  // the workgroup counts its arrival.  The counter's reply is only looked at after the observation rows, which hide its
+  // round trip.
+  static_assert(LG_MAX_REWARD_TERMS + 3 + 2 <= 64, "statistics rows are written by one wave");
   unsigned arrival = 0;
   const unsigned shard = blockIdx.x & 7u, nsh = min(8u, gridDim.x);
   const unsigned want = (gridDim.x + 7u - shard) >> 3;
-  if (wv == 0) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's stores and atomics have completed
-    if (tid == 0) arrival = __hip_atomic_fetch_add(C->tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (stat_wave) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's stores and atomics have completed
+  if (FUSED) lds_barrier();                              // ... those of all four instances of the workgroup
+  if (tid == 0) arrival = __hip_atomic_fetch_add(C->tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // ---- (3) observation rows: proprio | heights | extra, + uniform noise, clipped (LR:245-252, :107-108); 4 entries per
   // lane, loads first (noise scales, caller's extra rows, injected uniforms), then arithmetic, then the row stores
   const int O = g.num_obs, G4 = (O + 3) >> 2;
   const bool inject = g.rng_mode == LG_RNG_INJECT;
-  for (int gq = ln; have && gq < G4; gq += 64) {
-    const int el3 = el, e3 = e;
-    float u[4] = {0.5f, 0.5f, 0.5f, 0.5f}, nv[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = 4 * gq + i;
-      const bool in = idx < O;
-      if (g.add_noise && in) nv[i] = gq == ln ? nv_pre[i] : C->noise_vec[idx];
-      if (g.add_noise && inject && in) u[i] = C->rand_inject[(size_t)e3 * (LG_RS_NOISE + O) + LG_RS_NOISE + idx];
-      if (in && idx >= 48 + P && C->extra_obs) ex[i] = C->extra_obs[(size_t)e3 * g.num_extra_obs + (idx - 48 - P)];
-    }
-    if (g.add_noise && !inject) {
-      uint32_t o4[4];
-      philox4((uint32_t)e3, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), rstream, (uint32_t)g.seed, (uint32_t)(g.seed >> 32), o4);
+  for (int q = 0; q < NQ; ++q) {
+    const int el3 = FUSED ? q : wv_el, e3 = eq[q];
+    for (int gq = ln; hv_[q] && gq < G4; gq += 64) {
+      float u[4] = {0.5f, 0.5f, 0.5f, 0.5f}, nv[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) u[i] = u01(o4[i]);
-    }
+      for (int i = 0; i < 4; ++i) {
+        const int idx = 4 * gq + i;
+        const bool in = idx < O;
+        if (g.add_noise && in) nv[i] = gq == ln ? nv_pre[i] : C->noise_vec[idx];
+        if (g.add_noise && inject && in) u[i] = C->rand_inject[(size_t)e3 * (LG_RS_NOISE + O) + LG_RS_NOISE + idx];
+        if (in && idx >= 48 + P && C->extra_obs) ex[i] = C->extra_obs[(size_t)e3 * g.num_extra_obs + (idx - 48 - P)];
+      }
+      if (g.add_noise && !inject) {
+        uint32_t o4[4];
+        philox4((uint32_t)e3, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), rstream, (uint32_t)g.seed, (uint32_t)(g.seed >> 32), o4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = 4 * gq + i;
-      if (idx < O) {
-        float o;
-        if (idx < 48) o = s_prop[el3][idx];
-        else if (idx >= 48 + P) o = ex[i];
-        else { float h = (s_rootz[el3] - 0.5f) - s_h[el3][idx - 48]; o = fminf(fmaxf(h, -1.f), 1.f) * g.obs_scale_height; }
-        if (g.add_noise) o += (2.f * u[i] - 1.f) * nv[i];
-        o = fminf(fmaxf(o, -g.clip_observations), g.clip_observations);
-        C->obs[(size_t)e3 * O + idx] = o;
+        for (int i = 0; i < 4; ++i) u[i] = u01(o4[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = 4 * gq + i;
+        if (idx < O) {
+          float o;
+          if (idx < 48) o = L.s_prop[el3][idx];
+          else if (idx >= 48 + P) o = ex[i];
+          else { float h = (L.s_rootz[el3] - 0.5f) - L.s_h[el3][idx - 48]; o = fminf(fmaxf(h, -1.f), 1.f) * g.obs_scale_height; }
+          if (g.add_noise) o += (2.f * u[i] - 1.f) * nv[i];
+          o = fminf(fmaxf(o, -g.clip_observations), g.clip_observations);
+          C->obs[(size_t)e3 * O + idx] = o;
+        }
       }
     }
   }
@@ -1479,7 +1532,13 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
     s_last = last;
   }
   __syncthreads();
-  if (s_last) finalize_from_acc(C, (int)gridDim.x, mode == 0 ? 1 : 2, tid);
+  if (s_last) finalize_from_acc(C, ninst, mode == 0 ? 1 : 2, tid);
+}
+
+__global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int mode,
+                                                   float* __restrict__ rew_out, int rew_stride) {
+  __shared__ PostLds L;
+  post_instance<false>(C, ids, n, mode, rew_out, rew_stride, L, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step, int use_flags) {
