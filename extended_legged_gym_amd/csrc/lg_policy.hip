@@ -310,7 +310,13 @@ __global__ __launch_bounds__(256) void store_transition_kernel(int64_t n, int A,
                                                                float* __restrict__ dones, float* __restrict__ sigma) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  rewards[i] = rew[i] + gamma * (values[i] * (time_out[i] ? 1.f : 0.f));     // bootstrapping on time outs
+  // bootstrapping on time outs: three separately rounded operations, as the reference's tensor expression
+  // `rewards += gamma * (values * time_outs)` (a contracted FMA differs from it by an ulp now and then)
+  {
+#pragma clang fp contract(off)
+    const float boot = gamma * (values[i] * (time_out[i] ? 1.f : 0.f));
+    rewards[i] = rew[i] + boot;
+  }
   dones[i] = reset[i] ? 1.f : 0.f;
   for (int a = 0; a < A; ++a) sigma[i * A + a] = std[a];
 }

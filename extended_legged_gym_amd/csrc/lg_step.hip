@@ -748,7 +748,10 @@ LG_DEV float terrain_height_at(const DevCtx* __restrict__ C, float qz, float qw,
 }
 #pragma clang fp contract(fast)
 
-// zero_sea: also clear the LSTM actuator state rows here (the post kernel does it cooperatively instead)
+// zero_sea: the caller is lg_reset_idx's kernel, which has no write-back stage of its own: clear the LSTM actuator state rows
+// and the history rows (last_actions, last_dof_vel) in global memory here.  The post kernel passes false: its write-back
+// stage stores both rows for every env (LR:148-150 runs after reset_idx) and clears the LSTM rows cooperatively; storing
+// them here as well would race with those stores, which another wave of the workgroup issues.
 LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int update_curriculum, const float* U, bool zero_sea) {  // LR:162-213
   const lg_config& g = C->cfg;
   float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
@@ -791,7 +794,7 @@ LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int
   for (int i = 0; i < 6; ++i) r[7 + i] = rand_float(-0.5f, 0.5f, U[LG_RS_ROOT_VEL + i]);
   for (int i = 0; i < 13; ++i) root[i] = r[i];
   resample_commands(C, cmd, U, LG_RS_CMD_RESET);
-  for (int d = 0; d < 12; ++d) { C->last_actions[(size_t)e * 12 + d] = 0.f; C->last_dof_vel[(size_t)e * 12 + d] = 0.f; }
+  if (zero_sea) for (int d = 0; d < 12; ++d) { C->last_actions[(size_t)e * 12 + d] = 0.f; C->last_dof_vel[(size_t)e * 12 + d] = 0.f; }
   for (int f = 0; f < 4; ++f) { V.air[f] = 0.f; V.ctime[f] = 0.f; }
   C->ep_len[e] = 0;
   C->reset_buf[e] = 1;

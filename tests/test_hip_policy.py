@@ -123,7 +123,11 @@ def test_collect_rollout_matches_the_python_loop():
     torch.cuda.synchronize()
     assert float(ref["dones"].sum()) > 0 and float((ref["rewards"] - torch.stack([x for x in rows["rewards"]])).abs().max()) == 0
     for k in ref:
-        assert torch.equal(out[k], ref[k]), k
+        if not torch.equal(out[k], ref[k]):
+            d = (out[k].float() - ref[k].float()).abs().flatten(1)
+            bad = (d > 0).nonzero()
+            raise AssertionError(f"{k}: {len(bad)} entries differ (max {float(d.max()):.3e}); first (step, flat index) = {bad[0].tolist()}; "
+                                 f"steps with a difference: {sorted(set(bad[:, 0].tolist()))}; dones per step: {ref['dones'].sum((1, 2)).tolist()}")
     assert torch.equal(out["last_values"], last) and torch.equal(out["returns"], ret) and torch.equal(out["advantages"], adv)
     assert torch.equal(envs[0].obs_buf, envs[1].obs_buf) and acs[0]._call == acs[1]._call == T
     assert envs[0].common_step_counter == envs[1].common_step_counter
