@@ -351,6 +351,20 @@ LG_DEV void mesh_cache_io(const DevCtx* __restrict__ C, float* cqc, int e, int l
   }
 }
 
+LG_DEV void publish_state(float* rec, const float root[13], const float q[3], const float qd[3]) {
+  float4* p = reinterpret_cast<float4*>(rec);
+  p[0] = make_float4(root[0], root[1], root[2], root[3]); p[1] = make_float4(root[4], root[5], root[6], root[7]);
+  p[2] = make_float4(root[8], root[9], root[10], root[11]); p[3] = make_float4(root[12], q[0], q[1], q[2]);
+  p[4] = make_float4(qd[0], qd[1], qd[2], 0.f);
+}
+LG_DEV void fetch_state(const float* rec, float root[13], float q[3], float qd[3]) {
+  const float4* p = reinterpret_cast<const float4*>(rec);
+  const float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+  root[0] = a.x; root[1] = a.y; root[2] = a.z; root[3] = a.w; root[4] = b.x; root[5] = b.y; root[6] = b.z; root[7] = b.w;
+  root[8] = c.x; root[9] = c.y; root[10] = c.z; root[11] = c.w; root[12] = d.x; q[0] = d.y; q[1] = d.z; q[2] = d.w;
+  qd[0] = e.x; qd[1] = e.y; qd[2] = e.z;
+}
+
 // ============================================================================================ physics kernel
 // MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
 // MODE 2: lg_compute_torques only.
@@ -366,7 +380,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ __attribute__((aligned(16))) float cst[LG_MAX_CP * CF_FIELDS * 64];
   __shared__ float lmod[LM_FIELDS * 4];
   const float* __restrict__ wlstm = C->lstm_w;
-  __shared__ float xq[3][64], xqd[3][64], xtau[3][64], xroot[13][64], xbias[9][64];
+  // state of the substep published by the main wave for the helpers: [lane][root 13 | q 3 | qd 3 | pad] = five 16-byte units per
+  // lane (odd: conflict-free), written / read with ds_*_b128 -- a lone wave gets the full LDS rate only on 16-byte accesses
+  __shared__ __attribute__((aligned(16))) float xst[64][20];
+  __shared__ float xtau[3][64];
+  __shared__ __attribute__((aligned(16))) float xbias[64][12];   // leg bias of wave 1: [lane][bk 3 | Fs 3 | Ns 3 | pad], three 16-byte units
   __shared__ __attribute__((aligned(16))) float xs[XS_STRIDE * 64];              // main wave's mass-matrix factors for the helpers' share of the contact set-up
   __shared__ float cqc[TMESH ? LG_MAX_CP * 4 * 64 : 1];   // mesh terrains: last closest-point query of every collision sphere
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -426,10 +444,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       // detection of half of the slots (waves 2, 3), straight into the LDS the main wave reads after barrier (A2);
       // then this wave's joint of the actuator network, all while the main wave factorises the mass matrix
       float r13[13], qq[3], qdd[3];
-#pragma unroll
-      for (int i = 0; i < 13; ++i) r13[i] = xroot[i][lane];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { qq[i] = xq[i][lane]; qdd[i] = xqd[i][lane]; }
+      fetch_state(xst[lane], r13, qq, qdd);
       const M3 Rb = quat_to_mat(r13 + 3);
       const V3 pb = v3(r13[0], r13[1], r13[2]), vb = v3(r13[7], r13[8], r13[9]), wb = v3(r13[10], r13[11], r13[12]);
       LegKin k;
@@ -444,9 +459,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (wv == 1) {
         float bk[3]; V3 Fs, Ns;
         leg_bias(lm_, k, pb, wb, qdd, P.grav, bk, Fs, Ns);
-        xbias[0][lane] = bk[0]; xbias[1][lane] = bk[1]; xbias[2][lane] = bk[2];
-        xbias[3][lane] = Fs.x; xbias[4][lane] = Fs.y; xbias[5][lane] = Fs.z;
-        xbias[6][lane] = Ns.x; xbias[7][lane] = Ns.y; xbias[8][lane] = Ns.z;
+        {
+          float4* pb4 = reinterpret_cast<float4*>(xbias[lane]);
+          pb4[0] = make_float4(bk[0], bk[1], bk[2], Fs.x); pb4[1] = make_float4(Fs.y, Fs.z, Ns.x, Ns.y); pb4[2] = make_float4(Ns.z, 0.f, 0.f, 0.f);
+        }
         if (!TMESH) contact_detect_begin<DS0, DS1>(lm_, T, k, Rb, pb, pr1);
         else contact_detect_mesh(2, 4, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (TMESH) {
@@ -500,10 +516,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     if (TMESH && valid) mesh_cache_io<false>(C, cqc, e, l, lane, 2 * wv);
     if (valid) {                                         // wave w stores link w-1 of every leg (+ base / + foot body)
       float r13[13], qq[3], qdd[3];
-#pragma unroll
-      for (int i = 0; i < 13; ++i) r13[i] = xroot[i][lane];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { qq[i] = xq[i][lane]; qdd[i] = xqd[i][lane]; }
+      fetch_state(xst[lane], r13, qq, qdd);
       write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, wv - 1);
     }
     if (valid && net) {
@@ -576,10 +589,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   for (int sub = 0; sub < nsub; ++sub) {
     STAMP(15);
     if (helpers) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) { xq[j][lane] = s.q[j]; xqd[j][lane] = s.qd[j]; }
-#pragma unroll
-      for (int i = 0; i < 13; ++i) xroot[i][lane] = s.root[i];
+    publish_state(xst[lane], s.root, s.q, s.qd);
       lds_barrier();                                   // (A) root, q, qd of this substep visible to the helper waves
     }
     if (split) {
@@ -605,9 +615,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     auto prep_fn = [&](float* bk, V3& Fs, V3& Ns) -> bool {
       if (!helpers) return false;
       lds_barrier();                                   // (A2) helper waves have written the leg bias and the slot table
-      bk[0] = xbias[0][lane]; bk[1] = xbias[1][lane]; bk[2] = xbias[2][lane];
-      Fs = v3(xbias[3][lane], xbias[4][lane], xbias[5][lane]);
-      Ns = v3(xbias[6][lane], xbias[7][lane], xbias[8][lane]);
+      const float4* pb4 = reinterpret_cast<const float4*>(xbias[lane]);
+      const float4 b0 = pb4[0], b1 = pb4[1], b2 = pb4[2];
+      bk[0] = b0.x; bk[1] = b0.y; bk[2] = b0.z;
+      Fs = v3(b0.w, b1.x, b1.y);
+      Ns = v3(b1.z, b1.w, b2.x);
       return true;
     };
     auto share_fn = [&]() { if (helpers) lds_barrier(); };   // (A3) every wave has finished its slots
@@ -642,10 +654,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   }
   STAMP(9);
   if (helpers) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { xq[j][lane] = s.q[j]; xqd[j][lane] = s.qd[j]; }
-#pragma unroll
-    for (int i = 0; i < 13; ++i) xroot[i][lane] = s.root[i];
+    publish_state(xst[lane], s.root, s.q, s.qd);
     lds_barrier();                                     // (F) final state visible to the helper waves, which write the body states
   }
   if (!valid) return;
