@@ -1119,6 +1119,15 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
     eq[q] = L.s_e[el];
   }
 
+  // Per-DOF constants of the narrow stages (lane sl of an env's sixteen owns DOF sl there), requested now so that their
+  // latency overlaps the staging loads instead of standing in the dependent chain of stage (2.1) / (2.4); likewise the
+  // 64-bit modulo of the push schedule.
+  const int sl_pf = ln & 15, d_pf = min(sl_pf, 11);
+  const float pf_lim0 = g.dof_pos_limits[d_pf][0], pf_lim1 = g.dof_pos_limits[d_pf][1];
+  const float pf_vlim = m.dof_vel_limit[d_pf], pf_tlim = m.torque_limit[d_pf], pf_dflt = g.default_dof_pos[d_pf];
+  const float pf_dflt_r0 = g.default_dof_pos[max(sl_pf - 12, 0)], pf_dflt_r1 = g.default_dof_pos[min(sl_pf + 4, 11)];   // entries 12..23 of the observation
+  const bool push_now = !ro && g.push_robots && (step % g.push_interval == 0);                                          // LR:402-403
+
   // ---- (1a) height scan from the post-physics root pose (LR:400-401).  Order of the memory traffic of this kernel's
   // first stage: [scan inputs: base pose + scan points] -> [all staging loads] -> wait for the scan inputs only ->
   // [height gathers] -> LDS stores of the staged rows -> barrier; the gathers are consumed after stage (2.1).
@@ -1281,10 +1290,10 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
       F[F_QD2][d] = qd * qd;
       { float a = (V.ldv[d] - qd) / dt; F[F_ACC2][d] = a * a; }
       { float a = V.lact[d] - V.act[d]; F[F_ARATE2][d] = a * a; }
-      { float lo = q_ - g.dof_pos_limits[d][0], hi = q_ - g.dof_pos_limits[d][1]; F[F_POSLIM][d] = -fminf(lo, 0.f) + fmaxf(hi, 0.f); }
-      F[F_VELLIM][d] = fminf(fmaxf(fabsf(qd) - m.dof_vel_limit[d] * g.soft_dof_vel_limit, 0.f), 1.f);
-      F[F_TQLIM][d] = fmaxf(fabsf(tq) - m.torque_limit[d] * g.soft_torque_limit, 0.f);
-      F[F_STILL][d] = fabsf(q_ - g.default_dof_pos[d]);
+      { float lo = q_ - pf_lim0, hi = q_ - pf_lim1; F[F_POSLIM][d] = -fminf(lo, 0.f) + fmaxf(hi, 0.f); }
+      F[F_VELLIM][d] = fminf(fmaxf(fabsf(qd) - pf_vlim * g.soft_dof_vel_limit, 0.f), 1.f);
+      F[F_TQLIM][d] = fmaxf(fabsf(tq) - pf_tlim * g.soft_torque_limit, 0.f);
+      F[F_STILL][d] = fabsf(q_ - pf_dflt);
     }
     if (have) {
       for (int b = sl; b < B; b += 16) {
@@ -1316,7 +1325,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
     V.root = S + S_ROOT; V.dof = S + S_DOF; V.cmd = S + S_CMD; V.air = S + S_AIR; V.ctime = S + S_CT;
     V.blv = S + S_BLV; V.bav = S + S_BAV; V.pg = S + S_PG; V.tq = S + S_TQ; V.act = S + S_ACT; V.lact = S + S_LACT; V.bla = S + S_BLA;
     V.ldv = S + S_LDV; V.cf = S + S_CF; V.rb = S + S_RB; V.lastc = L.s_lastc[have ? el : 0];
-    float* root = V.root; float* dof = V.dof; float* cmd = V.cmd;
+    float* root = V.root; float* cmd = V.cmd;
 
     // (2.2)
     if (have && sl < F_COUNT) {
@@ -1338,7 +1347,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
         float x = 0.5f * wrap_to_pi(cmd[3] - atan2f(f.y, f.x));
         cmd[2] = fminf(fmaxf(x, -1.f), 1.f);
       }
-      if (!ro && g.push_robots && (step % g.push_interval == 0)) {                    // LR:402-403, 491-496
+      if (push_now) {                                                                // LR:402-403, 491-496
         root[7] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, L.s_u[el][LG_RS_PUSH]);
         root[8] = rand_float(-g.max_push_vel_xy, g.max_push_vel_xy, L.s_u[el][LG_RS_PUSH + 1]);
         root_dirty = true;
@@ -1401,18 +1410,17 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
     // (2.4) proprioceptive part of the observation (LR:237-244), from the post-reset state; gait scheduler (anymal.py:107-110)
     if (have) {
       float* sp = L.s_prop[el];
+      // entry i = (S[off_i] - sub_i) * scale_i, branch-free (sub is the default DOF position for entries 12..23, else 0;
+      // x - 0 and x * 1 are exact, so this is the reference's arithmetic entry by entry)
+      const float ls = g.obs_scale_lin_vel, as = g.obs_scale_ang_vel, ps = g.obs_scale_dof_pos, vs = g.obs_scale_dof_vel;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int i = sl + 16 * r;
-        float o;
-        if (i < 3) o = V.blv[i] * g.obs_scale_lin_vel;
-        else if (i < 6) o = V.bav[i - 3] * g.obs_scale_ang_vel;
-        else if (i < 9) o = V.pg[i - 6];
-        else if (i < 12) o = cmd[i - 9] * (i < 11 ? g.obs_scale_lin_vel : g.obs_scale_ang_vel);
-        else if (i < 24) o = (dof[2 * (i - 12)] - g.default_dof_pos[i - 12]) * g.obs_scale_dof_pos;
-        else if (i < 36) o = dof[2 * (i - 24) + 1] * g.obs_scale_dof_vel;
-        else o = V.act[i - 36];
-        sp[i] = o;
+        const int off = i < 3 ? S_BLV + i : i < 6 ? S_BAV + i - 3 : i < 9 ? S_PG + i - 6 : i < 12 ? S_CMD + i - 9
+                      : i < 24 ? S_DOF + 2 * (i - 12) : i < 36 ? S_DOF + 2 * (i - 24) + 1 : S_ACT + i - 36;
+        const float scale = i < 3 ? ls : i < 6 ? as : i < 9 ? 1.f : i < 11 ? ls : i < 12 ? as : i < 24 ? ps : i < 36 ? vs : 1.f;
+        const float sub = (i >= 12 && i < 24) ? (r == 0 ? pf_dflt_r0 : pf_dflt_r1) : 0.f;
+        sp[i] = (S[off] - sub) * scale;
       }
       if (sl == 15 && g.gait_enabled && !ro) {
         float x = fmodf(S[S_GAIT] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
