@@ -623,6 +623,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     if (TMESH) contact_detect_mesh(0, MAIN_DETECT, lm_, T, P, k, Rb, pb, cst, lane, cq);
     else contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
   }
+  STAMP(29);   // (diagnostic: this wave's own detection ends here; what follows in stamp 5 is the wait at the rendezvous)
   if (!prep_fn(bk, Fs, Ns)) {
     leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);
     if (TMESH) contact_detect_mesh(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);

@@ -431,7 +431,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     const TerrainView T = C->ter;
     if (TMESH) mesh_cache_io<true>(C, cqc, e, l, lane, 2 * wv);   // this wave's two slots of the persisted query cache -> LDS
 #ifdef LG_STAMPS
-    unsigned long long* stamps = (blockIdx.x == 0 && lane == 0 && wv == 2) ? C->stamps : nullptr;
+#ifndef LG_STAMP_WAVE
+#define LG_STAMP_WAVE 2          // which helper wave the diagnostic build watches
+#endif
+    unsigned long long* stamps = (blockIdx.x == 0 && lane == 0 && wv == LG_STAMP_WAVE) ? C->stamps : nullptr;
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     LstmPre lpre;

@@ -2,7 +2,7 @@
 physics_kernel (lane 0 of workgroup 0).  Shares only — never quote this build's run time."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["LGSTEP_LIB"] = os.path.join(ROOT, "extended_legged_gym_amd", "csrc", "liblgstep_stamps.so")
+os.environ["LGSTEP_LIB"] = os.path.join(ROOT, "extended_legged_gym_amd", "csrc", os.environ.get("LG_STAMPS_LIB", "liblgstep_stamps.so"))
 sys.path.insert(0, ROOT)
 import torch
 import bench
@@ -20,11 +20,11 @@ rc = lib.lg_debug_read_stamps(env.core.ctx, out)
 import extended_legged_gym_amd.native as nat
 print('lib', nat.LIB_PATH, 'rc', rc)
 names = {15: "substep prologue", 0: "publish q/qd | inline actuator", 1: "kinematics", 2: "bias (RNEA)", 3: "CRBA+Schur+chol",
-         5: "contact pass A (detect)", 6: "contact pass B (setup)", 4: "wait for torques (barrier B)", 7: "unconstrained + PGS",
+         29: "own contact detection", 5: "wait at rendezvous (A2) + slot mask", 6: "contact pass B (setup)", 4: "wait for torques (barrier B)", 7: "unconstrained + PGS",
          8: "limits+forces+integrate", 9: "fault guard", 10: "write-back + final FK",
          11: "POST: stage rows in LDS", 12: "POST: height scan", 19: "POST 2.1: rotations + per-DOF features", 20: "POST 2.2: feature sums + callback + termination",
          21: "POST 2.3: reward terms + sums (+ reset)", 13: "POST 2.4: proprio obs entries", 14: "POST: partials + obs rows"}
-tot = sum(out[:16]) + sum(out[19:22])
+tot = sum(out[:16]) + sum(out[19:22]) + out[29]
 hn = {22: "HELPER w2: wait at (A)", 23: "HELPER: kinematics", 24: "HELPER: contact detect (4 slots)", 25: "HELPER: LSTM joint", 26: "HELPER: wait at (A2)", 27: "HELPER: contact set-up share"}
 for k, n in hn.items():
     print(f"{n:34s} per substep {out[k] / (301 * 4):9.0f} cycles")
