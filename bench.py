@@ -96,7 +96,7 @@ def cpu_baseline(env, actions_pool, budget_s=15.0):
                        f"(best of the probed team sizes; {avail} CPUs visible), {dt:.1f} s")
 
 
-PMC_PASSES = "r01_post16_pmc.json"
+PMC_PASSES = "r01_end_pmc.json"
 
 
 def pmc_traffic(N):
