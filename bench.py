@@ -97,6 +97,27 @@ def cpu_baseline(env, actions_pool, budget_s=15.0):
 
 
 PMC_PASSES = "r01_end_pmc.json"
+SQ_PASSES = "r01_end_sq_counters.txt"
+
+
+def sq_issue(N):
+    """VALU busy fraction of the physics kernel's waves from the committed SQ counter passes (`tools/pmc_sq.sh`): the kernel
+    is bound by instruction issue of one wave per SIMD, not by bytes, so this is the utilisation figure that moves."""
+    path = os.path.join(ROOT, "profiles", SQ_PASSES)
+    if not os.path.exists(path) or N != 4096:
+        return {}
+    try:
+        vals, on = {}, False
+        for line in open(path):
+            if line.startswith("=="):
+                on = "physics_kernel" in line
+            elif on and "per launch" in line:
+                k, v = line.split()[:2]
+                vals[k] = float(v)
+        return {"valu_busy_frac": vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_WAVE_CYCLES"], "valu_insts_per_launch": vals["SQ_INSTS_VALU"],
+                "issue_source": os.path.relpath(path, ROOT)}
+    except Exception:
+        return {}
 
 
 def pmc_traffic(N):
@@ -189,7 +210,7 @@ def main():
                                    "actions N(0,1), one step = 4 physics substeps + post-physics",
                        "num_envs_per_gpu": N, "decimation": 4, "sim_dt": 0.005, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "physics_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(N),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(N), **sq_issue(N),
                          "algorithmic_bytes_per_env_step": phys_bytes, "kernel_ms": prof["physics_ms"],
                          "post_kernel_ms": prof["post_ms"], "finalize_kernel_ms": prof["finalize_ms"],
                          "hip_event_samples": prof["samples"],
