@@ -208,12 +208,22 @@ LG_DEV void terrain_query(const TerrainView& T, float x, float y, float* h, V3* 
 // (240 B, 16-B aligned), so the sweeps fetch it with 15 ds_read_b128 instead of 59 ds_read_b32 -- a lone wave on a SIMD
 // gets a fifth of the LDS rate on 4-byte reads and the full rate on 16-byte ones (MI355X_MICROARCH.md, LDS).  Rows of
 // 60 dwords put the 16 lanes of every ds_read_b128 lane group on 16 distinct 4-bank sets: conflict-free.
-// fields 0..11 are written by the contact detection (and the multipliers by the sweeps), 12..59 by the set-up: each block
-// is a whole number of 16-B units
-enum { CF_N = 0, CF_R = 3, CF_BN = 6, CF_ACTIVE = 7, CF_L0 = 8, CF_L1 = 9, CF_L2 = 10, /* 11: pad */
-       CF_SETUP = 12, CF_T1 = 12, CF_T2 = 15, CF_JK0 = 18, CF_JK1 = 21, CF_JK2 = 24,
-       CF_ANN = 27, CF_AN1 = 28, CF_AN2 = 29, CF_A11 = 30, CF_A12 = 31, CF_A22 = 32,
-       CF_WB = 33 /* 3 x 6: base response per unit contact-frame impulse */, CF_ZC = 51 /* 3 x 3: Mkk^-1 J_k^T */, CF_FIELDS = 60 };
+// fields 0..11 are written by the contact detection (the multipliers then by the sweeps; field 9 by the set-up), 12..59 by the
+// set-up: each block is a whole number of 16-B units
+// The sweeps run on packed fp32 (v_pk_fma_f32: two lanes of a 64-bit register pair per instruction), so everything they
+// combine pairwise sits at an EVEN offset of the record, next to its partner: the two tangential multipliers, the
+// (t1, t2) components interleaved, (An1, An2), the rows of the inverse tangential block, the base-response columns in
+// pairs of base coordinates, the joint responses of joints (0, 1) of the three contact-frame axes.
+// The blocks are laid out in the order a sweep step needs them (contact frame and gap, Jacobian pieces, tangents, the
+// tangential block, then the responses), because the step starts computing as soon as the first 16-byte reads land.
+enum { CF_N = 0, CF_BN = 3, CF_R = 4, CF_ACTIVE = 7, CF_L0 = 8, CF_ANN = 9 /* 1 / (Ann + cfm), written by the set-up */, CF_L1 = 10, CF_L2 = 11,
+       CF_SETUP = 12, CF_JK0 = 12, CF_JK1 = 15, CF_JK2 = 18, CF_ZC2 = 21 /* 3: (Mkk^-1 J_k^T)[c][joint 2] */,
+       CF_T12 = 24 /* t1.x t2.x t1.y t2.y t1.z t2.z */, CF_AN12 = 30 /* An1 An2 */, CF_B = 32 /* inverse tangential block, rows (B11 B12) (B12 B22) */,
+       CF_WB = 36 /* 3 x 6: base response per unit contact-frame impulse */, CF_ZCP = 54 /* 3 x 2: (Mkk^-1 J_k^T)[c][joint 0, 1] */, CF_FIELDS = 60 };
+static_assert(CF_T12 % 2 == 0 && CF_AN12 % 2 == 0 && CF_B % 2 == 0 && CF_WB % 2 == 0 && CF_ZCP % 2 == 0 && CF_L1 % 2 == 0, "packed operands sit at even offsets");
+typedef float pk2 __attribute__((ext_vector_type(2)));
+LG_DEV pk2 pk_splat(float x) { pk2 r = {x, x}; return r; }
+LG_DEV pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
 #define CS(slot, f) cst[((slot) * 64 + lane) * CF_FIELDS + (f)]
 static_assert(CF_FIELDS % 4 == 0 && (CF_FIELDS / 4) % 2 == 1, "slot rows: 16-B aligned, odd number of 16-B units (bank spread)");
 // the whole record of one slot, 15 x 16 B
@@ -447,8 +457,8 @@ LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 
 #pragma unroll
       for (int a = 0; a < 6; ++a) w -= Y[j][a] * Wb[c][a];
       Wk[c][j] = w;
-      OUT(CF_ZC + 3 * c + j) = z[j];
     }
+    OUT(CF_ZCP + 2 * c) = z[0]; OUT(CF_ZCP + 2 * c + 1) = z[1]; OUT(CF_ZC2 + c) = z[2];
   }
   float A[3][3];
 #pragma unroll
@@ -464,15 +474,15 @@ LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 
       A[b][c] = sacc;
     }
   }
-  OUT(CF_T1) = t1.x; OUT(CF_T1 + 1) = t1.y; OUT(CF_T1 + 2) = t1.z; OUT(CF_T2) = t2.x; OUT(CF_T2 + 1) = t2.y; OUT(CF_T2 + 2) = t2.z;
+  OUT(CF_T12) = t1.x; OUT(CF_T12 + 1) = t2.x; OUT(CF_T12 + 2) = t1.y; OUT(CF_T12 + 3) = t2.y; OUT(CF_T12 + 4) = t1.z; OUT(CF_T12 + 5) = t2.z;
 #pragma unroll
   for (int j = 0; j < 3; ++j) { OUT(CF_JK0 + 3 * j) = jk[j].x; OUT(CF_JK0 + 3 * j + 1) = jk[j].y; OUT(CF_JK0 + 3 * j + 2) = jk[j].z; }
   // the sweeps only ever divide by these: store the reciprocal of the normal row and the inverse of the 2x2 tangential
   // block (computed once here, by whichever wave sets the slot up, instead of in each of the four sweeps)
   const float a11 = A[1][1] + cfm, a12 = A[1][2], a22 = A[2][2] + cfm;
   const float idet = frcp(a11 * a22 - a12 * a12);
-  OUT(CF_ANN) = frcp(A[0][0] + cfm); OUT(CF_AN1) = A[1][0]; OUT(CF_AN2) = A[2][0];
-  OUT(CF_A11) = a22 * idet; OUT(CF_A12) = -a12 * idet; OUT(CF_A22) = a11 * idet;
+  CS(sl, CF_ANN) = frcp(A[0][0] + cfm); OUT(CF_AN12) = A[1][0]; OUT(CF_AN12 + 1) = A[2][0];
+  OUT(CF_B) = a22 * idet; OUT(CF_B + 1) = -a12 * idet; OUT(CF_B + 2) = -a12 * idet; OUT(CF_B + 3) = a11 * idet;
 #undef OUT
   float4* dst = reinterpret_cast<float4*>(&CS(sl, CF_SETUP));
 #pragma unroll
@@ -729,6 +739,12 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
 #pragma unroll
   for (int j = 0; j < LG_MAX_CP; ++j) my_steps += __ballot(my_count > j) != 0ull ? 1 : 0;
   if (slot_mask || jl_wave) {
+    // packed state of the sweeps: base velocity in three pairs, joints (0, 1) as a pair and joint 2 alone, Y by joint pair
+    pk2 vBp[3] = {{vB[0], vB[1]}, {vB[2], vB[3]}, {vB[4], vB[5]}};
+    pk2 vK01 = {vK[0], vK[1]}; float vK2 = vK[2];
+    pk2 Y01[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { Y01[a].x = Y[0][a]; Y01[a].y = Y[1][a]; }
 #pragma unroll 1
     for (int it = 0; it < P.iters; ++it) {
       // every lane walks the list of its own active slots; step j relaxes the j-th active contact of each of the four
@@ -742,46 +758,61 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
         // costs an LDS round trip at every step of this dependent chain
         float rec[CF_FIELDS];
         load_slot_record(cst, sl, lane, rec);
-        const V3 n = v3(rec[CF_N], rec[CF_N + 1], rec[CF_N + 2]), t1 = v3(rec[CF_T1], rec[CF_T1 + 1], rec[CF_T1 + 2]);
-        const V3 t2 = v3(rec[CF_T2], rec[CF_T2 + 1], rec[CF_T2 + 2]), r = v3(rec[CF_R], rec[CF_R + 1], rec[CF_R + 2]);
+        const V3 n = v3(rec[CF_N], rec[CF_N + 1], rec[CF_N + 2]), r = v3(rec[CF_R], rec[CF_R + 1], rec[CF_R + 2]);
         const V3 jk0 = v3(rec[CF_JK0], rec[CF_JK0 + 1], rec[CF_JK0 + 2]), jk1 = v3(rec[CF_JK1], rec[CF_JK1 + 1], rec[CF_JK1 + 2]);
         const V3 jk2 = v3(rec[CF_JK2], rec[CF_JK2 + 1], rec[CF_JK2 + 2]);
-        const float l0 = rec[CF_L0], l1 = rec[CF_L1], l2 = rec[CF_L2], bn = rec[CF_BN];
-        const float iAnn = rec[CF_ANN], An1 = rec[CF_AN1], An2 = rec[CF_AN2];      // 1 / Ann
-        const float B11 = rec[CF_A11], B12 = rec[CF_A12], B22 = rec[CF_A22];         // inverse of the tangential block
-        const float* wbv = rec + CF_WB; const float* zcv = rec + CF_ZC;
+        const float l0 = rec[CF_L0], bn = rec[CF_BN], iAnn = rec[CF_ANN];           // 1 / Ann
+        const pk2 l12 = {rec[CF_L1], rec[CF_L2]}, an12 = {rec[CF_AN12], rec[CF_AN12 + 1]};
+        const pk2 b_r0 = {rec[CF_B], rec[CF_B + 1]}, b_r1 = {rec[CF_B + 2], rec[CF_B + 3]};   // inverse of the tangential block
         __builtin_amdgcn_sched_barrier(0);
         // velocity of the contact point
-        V3 vp = v3(vB[0], vB[1], vB[2]) + cross(v3(vB[3], vB[4], vB[5]), r) + vK[0] * jk0 + vK[1] * jk1 + vK[2] * jk2;
-        float u0 = dot(n, vp), u1 = dot(t1, vp), u2 = dot(t2, vp);
-        float ln = fmaxf(l0 - (u0 - bn) * iAnn, 0.f);
-        float dn = ln - l0;
-        float w1 = u1 + An1 * dn, w2 = u2 + An2 * dn;
-        float n1 = l1 - (B11 * w1 + B12 * w2);
-        float n2 = l2 - (B12 * w1 + B22 * w2);
-        float lim = mu * ln, m2 = n1 * n1 + n2 * n2;
-        if (m2 > lim * lim) { float sc = m2 > 0.f ? lim * __builtin_amdgcn_rsqf(m2) : 0.f; n1 *= sc; n2 *= sc; }
-        float d0 = active ? dn : 0.f, d1 = active ? n1 - l1 : 0.f, d2 = active ? n2 - l2 : 0.f;
-        if (active) { CS(sl, CF_L0) = ln; CS(sl, CF_L1) = n1; CS(sl, CF_L2) = n2; }
+        V3 vp = v3(vBp[0].x, vBp[0].y, vBp[1].x) + cross(v3(vBp[1].y, vBp[2].x, vBp[2].y), r) + vK01.x * jk0 + vK01.y * jk1 + vK2 * jk2;
+        const float u0 = dot(n, vp);
+        pk2 u12 = pk_splat(vp.x) * (pk2){rec[CF_T12], rec[CF_T12 + 1]};
+        u12 = pk_fma(pk_splat(vp.y), (pk2){rec[CF_T12 + 2], rec[CF_T12 + 3]}, u12);
+        u12 = pk_fma(pk_splat(vp.z), (pk2){rec[CF_T12 + 4], rec[CF_T12 + 5]}, u12);
+        const float ln = fmaxf(l0 - (u0 - bn) * iAnn, 0.f);
+        const float dn = ln - l0;
+        const pk2 w12 = pk_fma(an12, pk_splat(dn), u12);
+        pk2 t12 = b_r0 * pk_splat(w12.x);
+        t12 = pk_fma(b_r1, pk_splat(w12.y), t12);
+        pk2 n12 = l12 - t12;
+        const float lim = mu * ln, m2 = n12.x * n12.x + n12.y * n12.y;
+        if (m2 > lim * lim) { const float sc = m2 > 0.f ? lim * __builtin_amdgcn_rsqf(m2) : 0.f; n12 = n12 * pk_splat(sc); }
+        const float d0 = active ? dn : 0.f;
+        pk2 d12 = n12 - l12;
+        d12.x = active ? d12.x : 0.f; d12.y = active ? d12.y : 0.f;
+        if (active) *reinterpret_cast<float4*>(&CS(sl, CF_L0)) = make_float4(ln, iAnn, n12.x, n12.y);
         // apply: base response of this lane's impulse from the stored M^-1 J^T columns, summed over the quad
-        float g[6];
+        pk2 g[3];
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
-          g[a] = quad_sum(d0 * wbv[a] + d1 * wbv[6 + a] + d2 * wbv[12 + a]);
+        for (int p = 0; p < 3; ++p) {
+          pk2 acc = pk_splat(d0) * (pk2){rec[CF_WB + 2 * p], rec[CF_WB + 2 * p + 1]};
+          acc = pk_fma(pk_splat(d12.x), (pk2){rec[CF_WB + 6 + 2 * p], rec[CF_WB + 6 + 2 * p + 1]}, acc);
+          acc = pk_fma(pk_splat(d12.y), (pk2){rec[CF_WB + 12 + 2 * p], rec[CF_WB + 12 + 2 * p + 1]}, acc);
+          g[p].x = quad_sum(acc.x); g[p].y = quad_sum(acc.y);
+        }
 #pragma unroll
-        for (int a = 0; a < 6; ++a) vB[a] += g[a];
+        for (int p = 0; p < 3; ++p) vBp[p] = vBp[p] + g[p];
+        {
+          pk2 w01 = pk_splat(d0) * (pk2){rec[CF_ZCP], rec[CF_ZCP + 1]};
+          w01 = pk_fma(pk_splat(d12.x), (pk2){rec[CF_ZCP + 2], rec[CF_ZCP + 3]}, w01);
+          w01 = pk_fma(pk_splat(d12.y), (pk2){rec[CF_ZCP + 4], rec[CF_ZCP + 5]}, w01);
+          float w2 = d0 * rec[CF_ZC2] + d12.x * rec[CF_ZC2 + 1] + d12.y * rec[CF_ZC2 + 2];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          float w = d0 * zcv[j] + d1 * zcv[3 + j] + d2 * zcv[6 + j];
-#pragma unroll
-          for (int a = 0; a < 6; ++a) w -= Y[j][a] * g[a];
-          vK[j] += w;
+          for (int a = 0; a < 6; ++a) {
+            const float ga = (a & 1) ? g[a >> 1].y : g[a >> 1].x;
+            w01 = pk_fma(-Y01[a], pk_splat(ga), w01);
+            w2 -= Y[2][a] * ga;
+          }
+          vK01 = vK01 + w01; vK2 += w2;
         }
       }
       if (jl_wave) {
+        float vBs[6] = {vBp[0].x, vBp[0].y, vBp[1].x, vBp[1].y, vBp[2].x, vBp[2].y}, vKs[3] = {vK01.x, vK01.y, vK2};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {           // joint j of the four legs together, like a contact slot
-          const float u = jl_sgn[j] * vK[j];
+          const float u = jl_sgn[j] * vKs[j];
           const float ln = fmaxf(jl_lam[j] - (u - jl_bn[j]) * jl_iA[j], 0.f);
           const float dl = jl_act[j] ? ln - jl_lam[j] : 0.f;
           if (jl_act[j]) jl_lam[j] = ln;
@@ -789,17 +820,23 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
 #pragma unroll
           for (int a = 0; a < 6; ++a) gq[a] = quad_sum(dl * jl_Wb[j][a]);
 #pragma unroll
-          for (int a = 0; a < 6; ++a) vB[a] += gq[a];
+          for (int a = 0; a < 6; ++a) vBs[a] += gq[a];
 #pragma unroll
           for (int jj = 0; jj < 3; ++jj) {
             float w = dl * jl_y[j][jj];
 #pragma unroll
             for (int a = 0; a < 6; ++a) w -= Y[jj][a] * gq[a];
-            vK[jj] += w;
+            vKs[jj] += w;
           }
         }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { vBp[p].x = vBs[2 * p]; vBp[p].y = vBs[2 * p + 1]; }
+        vK01.x = vKs[0]; vK01.y = vKs[1]; vK2 = vKs[2];
       }
     }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { vB[2 * p] = vBp[p].x; vB[2 * p + 1] = vBp[p].y; }
+    vK[0] = vK01.x; vK[1] = vK01.y; vK[2] = vK2;
   }
 
   STAMP(7);
@@ -818,7 +855,8 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     for (int sl = 0; sl < LG_MAX_CP; ++sl) {
       if (!((slot_mask >> sl) & 1u)) continue;
       if (CS(sl, CF_ACTIVE) == 0.f) continue;
-      V3 f = idt * (CS(sl, CF_L0) * lds3(cst, sl, CF_N, lane) + CS(sl, CF_L1) * lds3(cst, sl, CF_T1, lane) + CS(sl, CF_L2) * lds3(cst, sl, CF_T2, lane));
+      const V3 t1 = v3(CS(sl, CF_T12), CS(sl, CF_T12 + 2), CS(sl, CF_T12 + 4)), t2 = v3(CS(sl, CF_T12 + 1), CS(sl, CF_T12 + 3), CS(sl, CF_T12 + 5));
+      V3 f = idt * (CS(sl, CF_L0) * lds3(cst, sl, CF_N, lane) + CS(sl, CF_L1) * t1 + CS(sl, CF_L2) * t2);
       int link = lm_.i(LM_CP_LINK + sl);
       int slotb = link < 0 ? 0 : (link > 3 ? 4 : link + 1);
 #pragma unroll
