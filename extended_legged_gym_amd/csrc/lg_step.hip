@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
                                                       const int32_t* __restrict__ ids, int n, int act_stride) {
   // act_stride: floats between consecutive action rows (12, or horizon * 12 when the rows are one step of a (n, horizon, 12) plan)
   // contact-detection split of a heightfield step with actuator waves (see the helper loop); mesh terrains: two slots a wave
-  constexpr int DS0 = 2, DS1 = 4, DS2 = 6;   // (1/2/2/3 and 0/2/3/3 splits measured after the network was halved: no change)
+  constexpr int DS0 = 3, DS1 = 4, DS2 = 6;   //   // main 3 / wave 1 (which also has the leg bias) 1 / 2 / 2: the helpers are the last to arrive at (A2), the main wave has ~3 k cycles of slack there (A/B in one session: 2/2/2/2 +1.4 us, 4/0/2/2 +0.3 us; 1/2/2/3 and 0/2/3/3: worse still)
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
@@ -457,7 +457,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       // loads now and uses them after the actuator network
       // slot ranges [DS0, DS1) wave 1 (which also has the leg bias), [DS1, DS2) wave 2, [DS2, 8) wave 3; the main wave
       // takes [0, DS0) while it waits for nothing else
-      ContactProbe<DS0, DS1> pr1; ContactProbe<DS1, DS2> pr2; ContactProbe<DS2, 8> pr3;
+      constexpr int DS1P = DS1 > DS0 ? DS1 : DS0 + 1;   // (wave 1 may have no slot at all: its probe type still needs a size)
+      ContactProbe<DS0, DS1P> pr1; ContactProbe<DS1, DS2> pr2; ContactProbe<DS2, 8> pr3;
       static_assert(LG_MAX_CP == 8, "slot split assumes 8 contact slots");
       if (wv == 1) {
         float bk[3]; V3 Fs, Ns;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           float4* pb4 = reinterpret_cast<float4*>(xbias[lane]);
           pb4[0] = make_float4(bk[0], bk[1], bk[2], Fs.x); pb4[1] = make_float4(Fs.y, Fs.z, Ns.x, Ns.y); pb4[2] = make_float4(Ns.z, 0.f, 0.f, 0.f);
         }
-        if (!TMESH) contact_detect_begin<DS0, DS1>(lm_, T, k, Rb, pb, pr1);
+        if (!TMESH) { if (DS0 < DS1) contact_detect_begin<DS0, DS1P>(lm_, T, k, Rb, pb, pr1); }
         else contact_detect_mesh(2, 4, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (TMESH) {
 #ifdef LG_STAMPS
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
         xtau[j][lane] = lstm_input_part(wlstm + zero, x0, x1, lpre, h0, c0, h1, c1, g.actuator_out_scale);
       }
-      if (!TMESH && wv == 1) contact_detect_finish<DS0, DS1>(lm_, T, P, pb, pr1, cst, lane);
+      if (!TMESH && wv == 1) { if (DS0 < DS1) contact_detect_finish<DS0, DS1P>(lm_, T, P, pb, pr1, cst, lane); }
       else if (!TMESH && wv == 2) contact_detect_finish<DS1, DS2>(lm_, T, P, pb, pr2, cst, lane);
       else if (!TMESH && wv == 3) contact_detect_finish<DS2, 8>(lm_, T, P, pb, pr3, cst, lane);
       STAMP(25);
