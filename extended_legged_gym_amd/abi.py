@@ -134,6 +134,8 @@ def declare_product(lib):
     lib.lg_post_physics_subset.restype = C.c_int
     lib.lg_sync_main_to_rollout.argtypes = [vp, i32, f32, vp]
     lib.lg_sync_main_to_rollout.restype = C.c_int
+    lib.lg_step_transition.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp]
+    lib.lg_step_transition.restype = C.c_int
     lib.lg_rollout_batch.argtypes = [vp, vp, i32, vp, i32, i32, f32, vp, vp]
     lib.lg_rollout_batch.restype = C.c_int
     lib.lg_compute_torques.argtypes = [vp, vp, vp]
@@ -207,7 +209,7 @@ POLICY_SYMBOLS = ["lg_mlp_create", "lg_mlp_destroy", "lg_mlp_last_error", "lg_ml
                   "lg_collect_rollout"]
 ACTIVATIONS = {"elu": 0, "relu": 1, "tanh": 2, "lrelu": 3, "selu": 4}
 
-PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_step_physics", "lg_step_subset", "lg_sync_main_to_rollout", "lg_rollout_batch", "lg_compute_torques",
+PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_step_physics", "lg_step_subset", "lg_step_transition", "lg_sync_main_to_rollout", "lg_rollout_batch", "lg_compute_torques",
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
                    "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_last_error",
                    "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update",

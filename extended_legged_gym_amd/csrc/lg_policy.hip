@@ -303,23 +303,15 @@ int lg_compute_returns(const float* rewards, const float* dones, const float* va
   return hipGetLastError() == hipSuccess ? LG_OK : LG_ERR_HIP;
 }
 
-// PPO.process_env_step (ppo.py:161-183) + the sigma row of the transition (ppo.py:155): one lane per env
-__global__ __launch_bounds__(256) void store_transition_kernel(int64_t n, int A, const float* __restrict__ rew, const uint8_t* __restrict__ reset,
-                                                               const uint8_t* __restrict__ time_out, const float* __restrict__ values,
-                                                               const float* __restrict__ std, float gamma, float* __restrict__ rewards,
-                                                               float* __restrict__ dones, float* __restrict__ sigma) {
+// the sigma rows of all T transitions (ppo.py:155: action_std broadcast over the envs): one launch for the whole rollout
+__global__ __launch_bounds__(256) void fill_sigma_kernel(int64_t rows, int A, const float* __restrict__ std, float* __restrict__ sigma) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  // bootstrapping on time outs: three separately rounded operations, as the reference's tensor expression
-  // `rewards += gamma * (values * time_outs)` (a contracted FMA differs from it by an ulp now and then)
-  {
-#pragma clang fp contract(off)
-    const float boot = gamma * (values[i] * (time_out[i] ? 1.f : 0.f));
-    rewards[i] = rew[i] + boot;
-  }
-  dones[i] = reset[i] ? 1.f : 0.f;
-  for (int a = 0; a < A; ++a) sigma[i * A + a] = std[a];
+  if (i >= rows * A) return;
+  sigma[i] = std[i % A];
 }
+
+extern "C" int lg_step_transition(lg_ctx* ctx, const float* actions, float* next_observations, const float* values, float gamma,
+                                  float* rewards, float* dones, void* stream);
 
 int lg_collect_rollout(lg_ctx* env, lg_mlp* actor, lg_mlp* critic, const float* std, uint64_t seed, uint64_t first_call, int32_t T,
                        float gamma, float lam, int32_t normalize_advantage, const lg_rollout* out, void* stream) {
@@ -329,29 +321,24 @@ int lg_collect_rollout(lg_ctx* env, lg_mlp* actor, lg_mlp* critic, const float* 
   void* p; int64_t shp[4]; int32_t nd, dt;
   if (lg_get_tensor(env, LG_T_OBS_BUF, &p, shp, &nd, &dt) != LG_OK) return LG_ERR_INVALID;
   const float* obs = (const float*)p; const int64_t n = shp[0], O = shp[1];
-  if (lg_get_tensor(env, LG_T_REW_BUF, &p, shp, &nd, &dt) != LG_OK) return LG_ERR_INVALID;
-  const float* rew = (const float*)p;
-  if (lg_get_tensor(env, LG_T_RESET_BUF, &p, shp, &nd, &dt) != LG_OK) return LG_ERR_INVALID;
-  const uint8_t* reset = (const uint8_t*)p;
-  if (lg_get_tensor(env, LG_T_TIME_OUT_BUF, &p, shp, &nd, &dt) != LG_OK) return LG_ERR_INVALID;
-  const uint8_t* tout = (const uint8_t*)p;
   const int A = actor->h.dims[actor->h.L];
   if (actor->h.dims[0] != O || critic->h.dims[0] != O || critic->h.dims[critic->h.L] != 1 || A != LG_NUM_DOF) {
     actor->err = "lg_collect_rollout: network widths do not match the env (obs width, 12 actions, scalar value)"; return LG_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
+  // the first observation row is copied from the env; every later one is written by the step itself (lg_step_transition),
+  // as are the reward (with the time-out bootstrap) and done rows: three launches per step (act, physics, post-physics)
+  POL_TRY(actor, hipMemcpyAsync(out->observations, obs, (size_t)n * O * 4, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(fill_sigma_kernel, dim3((unsigned)(((int64_t)T * n * A + 255) / 256)), dim3(256), 0, st, (int64_t)T * n, A, std, out->sigma);
   for (int t = 0; t < T; ++t) {
     float* obs_t = out->observations + (size_t)t * n * O;
     float* act_t = out->actions + (size_t)t * n * A;
-    POL_TRY(actor, hipMemcpyAsync(obs_t, obs, (size_t)n * O * 4, hipMemcpyDeviceToDevice, st));
     int rc = lg_policy_act(actor, critic, obs_t, obs_t, n, std, seed, first_call + (uint64_t)t, 0, act_t, out->mu + (size_t)t * n * A,
                            out->actions_log_prob + (size_t)t * n, out->values + (size_t)t * n, stream);
     if (rc != LG_OK) return rc;
-    rc = lg_step(env, act_t, stream);
-    if (rc != LG_OK) { actor->err = std::string("lg_collect_rollout: lg_step failed: ") + lg_last_error(env); return rc; }
-    hipLaunchKernelGGL(store_transition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, A, rew, reset, tout,
-                       out->values + (size_t)t * n, std, gamma, out->rewards + (size_t)t * n, out->dones + (size_t)t * n,
-                       out->sigma + (size_t)t * n * A);
+    rc = lg_step_transition(env, act_t, t + 1 < T ? out->observations + (size_t)(t + 1) * n * O : nullptr, out->values + (size_t)t * n, gamma,
+                            out->rewards + (size_t)t * n, out->dones + (size_t)t * n, stream);
+    if (rc != LG_OK) { actor->err = std::string("lg_collect_rollout: lg_step_transition failed: ") + lg_last_error(env); return rc; }
   }
   int rc = lg_mlp_forward(critic, obs, n, out->last_values, stream);
   if (rc != LG_OK) return rc;

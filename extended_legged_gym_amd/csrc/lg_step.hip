@@ -1097,9 +1097,15 @@ struct alignas(16) PostLds {
 // no reset, rewards without episode sums).
 // rew_out (optional): the reward of launch row k also goes to rew_out[k * rew_stride] (lg_rollout_batch: column i of (n, horizon)).
 // ninst: instances of the launch (rows of the per-instance statistics the finishing workgroup adds up).
+// Optional second destinations of a step that feeds a rollout storage directly (lg_step_transition): row k of the launch
+//   obs_out[k, :]  = the observation row (RolloutStorage.observations[t + 1]: what the policy acts on next),
+//   rewards[k]     = rew + gamma * (values[k] * time_out)   (PPO.process_env_step, ppo.py:179-183: three roundings),
+//   dones[k]       = reset flag as float (ppo.py:165).
+struct PostSink { float* obs_out; const float* values; float* rewards; float* dones; float gamma; };
+
 template <bool FUSED>
 LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int mode, float* __restrict__ rew_out,
-                          int rew_stride, PostLds& L, int inst, int ninst) {
+                          int rew_stride, PostLds& L, int inst, int ninst, const PostSink K) {
   constexpr int NQ = FUSED ? EPBP : 1;          // envs a wave owns in the wide stages
   const lg_config& g = C->cfg; const lg_robot_model& m = C->model;
   const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
@@ -1139,6 +1145,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   const float pf_vlim = m.dof_vel_limit[d_pf], pf_tlim = m.torque_limit[d_pf], pf_dflt = g.default_dof_pos[d_pf];
   const float pf_dflt_r0 = g.default_dof_pos[max(sl_pf - 12, 0)], pf_dflt_r1 = g.default_dof_pos[min(sl_pf + 4, 11)];   // entries 12..23 of the observation
   const bool push_now = !ro && g.push_robots && (step % g.push_interval == 0);                                          // LR:402-403
+  const float pf_value = K.values ? K.values[min(inst * EPBP + (ln >> 4), n - 1)] : 0.f;   // critic value of the narrow-stage lane's env (time-out bootstrap)
 
   // ---- (1a) height scan from the post-physics root pose (LR:400-401).  Order of the memory traffic of this kernel's
   // first stage: [scan inputs: base pose + scan points] -> [all staging loads] -> wait for the scan inputs only ->
@@ -1412,6 +1419,12 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
       }
       C->rew[e] = rew;
       if (rew_out) rew_out[(size_t)(e0 + el) * rew_stride] = rew;
+      if (K.rewards) {
+#pragma clang fp contract(off)
+        const float boot = K.gamma * (pf_value * (tout ? 1.f : 0.f));
+        K.rewards[e0 + el] = rew + boot;
+        K.dones[e0 + el] = (term || tout) ? 1.f : 0.f;
+      }
       const bool do_reset = !ro && (term || tout);
       if (do_reset) { reset_env(C, V, e, 1, L.s_u[el], false); L.s_root_dirty[el] = 1; if (g.curriculum) L.s_level[el] = (float)C->levels[e]; }
       L.s_rootz[el] = root[2];
@@ -1547,6 +1560,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
           if (g.add_noise) o += (2.f * u[i] - 1.f) * nv[i];
           o = fminf(fmaxf(o, -g.clip_observations), g.clip_observations);
           C->obs[(size_t)e3 * O + idx] = o;
+          if (K.obs_out) K.obs_out[(size_t)(e0 + el3) * O + idx] = o;
         }
       }
     }
@@ -1568,9 +1582,9 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
 }
 
 __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int mode,
-                                                   float* __restrict__ rew_out, int rew_stride) {
+                                                   float* __restrict__ rew_out, int rew_stride, PostSink sink) {
   __shared__ PostLds L;
-  post_instance<false>(C, ids, n, mode, rew_out, rew_stride, L, (int)blockIdx.x, (int)gridDim.x);
+  post_instance<false>(C, ids, n, mode, rew_out, rew_stride, L, (int)blockIdx.x, (int)gridDim.x, sink);
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step, int use_flags) {
@@ -1816,9 +1830,10 @@ int lg_get_tensor(lg_ctx* c, int id, void** dptr, int64_t shape[4], int32_t* ndi
 
 __global__ void set_n_stepped(DevCtx* C, int n) { C->n_stepped = n; }
 
-static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t* ids, int n, int mode, float* rew_out = nullptr, int rew_stride = 0) {
+static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t* ids, int n, int mode, float* rew_out = nullptr, int rew_stride = 0,
+                       PostSink sink = PostSink{nullptr, nullptr, nullptr, nullptr, 0.f}) {
   const int nb = (n + EPBP - 1) / EPBP;
-  hipLaunchKernelGGL(post_kernel, dim3(nb), dim3(256), 0, st, c->d, ids, n, mode, rew_out, rew_stride);
+  hipLaunchKernelGGL(post_kernel, dim3(nb), dim3(256), 0, st, c->d, ids, n, mode, rew_out, rew_stride, sink);
   if (ev) (void)hipEventRecord(ev[2], st);
   if (ev) (void)hipEventRecord(ev[3], st);
   HIP_TRY(c, hipGetLastError());
@@ -1852,6 +1867,17 @@ int lg_step(lg_ctx* c, const float* actions, void* stream) {
   launch_physics(c, st, actions, nullptr, c->h.N);
   if (ev) (void)hipEventRecord(ev[1], st);
   return launch_post(c, st, ev, nullptr, c->h.N, 0);
+}
+
+// lg_step whose post-physics kernel also fills one transition of a rollout storage (see PostSink): what
+// RolloutStorage.add_transitions / PPO.process_env_step copy and compute after env.step in the reference's runner.
+int lg_step_transition(lg_ctx* c, const float* actions, float* next_observations, const float* values, float gamma, float* rewards,
+                       float* dones, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  if (!actions || !values || !rewards || !dones) { c->err = "lg_step_transition: null row"; return LG_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  launch_physics(c, st, actions, nullptr, c->h.N);
+  return launch_post(c, st, nullptr, nullptr, c->h.N, 0, nullptr, 0, PostSink{next_observations, values, rewards, dones, gamma});
 }
 
 int lg_step_subset(lg_ctx* c, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream) {

@@ -254,6 +254,13 @@ int lg_step(lg_ctx* ctx, const float* actions, void* stream);
  * between the last substep and post_physics_step. */
 int lg_step_physics(lg_ctx* ctx, const float* actions, void* stream);
 
+/* lg_step for a caller that keeps a rollout storage (rsl_rl's runner loop, on_policy_runner.py:401-445): the post-physics
+ * kernel also writes the new observation rows to `next_observations` (num_envs, num_obs; RolloutStorage.observations[t + 1],
+ * may be NULL), rewards[k] = rew + gamma * values[k] * time_out (PPO.process_env_step, ppo.py:179-183) and dones[k]
+ * (ppo.py:165) -- no copy / transition kernels after the step.  Device pointers. */
+int lg_step_transition(lg_ctx* ctx, const float* actions, float* next_observations, const float* values, float gamma,
+                       float* rewards, float* dones, void* stream);
+
 /* Main-rollout stepping (envs/batch_rollout/robot_batch_rollout.py): advance only the n listed envs; row k of `actions`
  * (n,12) belongs to env_ids[k] (device pointers).  rollout_mode = 0: the listed envs take a full LeggedRobot step
  * (RobotBatchRollout.step :535-600 for the main envs); rollout_mode = 1: post_physics_step_rollout semantics (:763-817) —
