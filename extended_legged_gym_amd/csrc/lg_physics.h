@@ -782,7 +782,8 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
         const float d0 = active ? dn : 0.f;
         pk2 d12 = n12 - l12;
         d12.x = active ? d12.x : 0.f; d12.y = active ? d12.y : 0.f;
-        if (active) *reinterpret_cast<float4*>(&CS(sl, CF_L0)) = make_float4(ln, iAnn, n12.x, n12.y);
+        // multipliers back to the record, without a branch: an idle lane rewrites what it has just read from its slot 0
+        *reinterpret_cast<float4*>(&CS(sl, CF_L0)) = make_float4(active ? ln : l0, iAnn, active ? n12.x : l12.x, active ? n12.y : l12.y);
         // apply: base response of this lane's impulse from the stored M^-1 J^T columns, summed over the quad
         pk2 g[3];
 #pragma unroll
