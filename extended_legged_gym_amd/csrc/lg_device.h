@@ -66,8 +66,24 @@ LG_DEV M3 quat_to_mat(const float* q) {
              2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
              2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
 }
+// sin and cos together, branch-free: Cody-Waite reduction to [-pi/4, pi/4] (two-term pi/2, exact products through FMA; good
+// for |x| up to ~1e4, far beyond any joint angle or half rotation per substep here), cephes minimax polynomials, quadrant by
+// selects.  ~25 instructions and no branch against ~80 and two exec-mask branches of the library sincosf: the three joint
+// rotations of the leg kinematics sit on the critical path of every wave of the physics workgroup.  Within 1-2 ulp of libm.
+LG_DEV void sincos_fast(float x, float* sn, float* cs) {
+  const float k = rintf(x * 0.636619772367581343f);
+  float r = fmaf(-k, 1.57079637050628662109375f, x);
+  r = fmaf(-k, -4.37113900018624283e-8f, r);
+  const float r2 = r * r;
+  const float sp = r + r * r2 * (-1.6666654611e-1f + r2 * (8.3321608736e-3f + r2 * -1.9515295891e-4f));
+  const float cp = 1.f - 0.5f * r2 + r2 * r2 * (4.166664568298827e-2f + r2 * (-1.388731625493765e-3f + r2 * 2.443315711809948e-5f));
+  const int n = (int)k & 3;
+  const float s0 = (n & 1) ? cp : sp, c0 = (n & 1) ? sp : cp;
+  *sn = (n & 2) ? -s0 : s0;
+  *cs = ((n + 1) & 2) ? -c0 : c0;
+}
 LG_DEV M3 axis_angle(V3 a, float q) {
-  float s, c; sincosf(q, &s, &c); float t = 1 - c;
+  float s, c; sincos_fast(q, &s, &c); float t = 1 - c;
   return M3{{t * a.x * a.x + c, t * a.x * a.y - s * a.z, t * a.x * a.z + s * a.y,
              t * a.x * a.y + s * a.z, t * a.y * a.y + c, t * a.y * a.z - s * a.x,
              t * a.x * a.z - s * a.y, t * a.y * a.z + s * a.x, t * a.z * a.z + c}};

@@ -873,7 +873,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   s.root[0] += dt * vB[0]; s.root[1] += dt * vB[1]; s.root[2] += dt * vB[2];
   {
     V3 w = v3(vB[3], vB[4], vB[5]); float wn = norm(w), ang = wn * dt;
-    float sh, ch; sincosf(0.5f * ang, &sh, &ch);
+    float sh, ch; sincos_fast(0.5f * ang, &sh, &ch);
     sh = wn > 1e-9f ? sh * frcp(wn) : 0.5f * dt;
     float dq0 = sh * w.x, dq1 = sh * w.y, dq2 = sh * w.z, dq3 = ch;
     float* qq = s.root + 3;
