@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
                                                       const int32_t* __restrict__ ids, int n, int act_stride) {
   // act_stride: floats between consecutive action rows (12, or horizon * 12 when the rows are one step of a (n, horizon, 12) plan)
   // contact-detection split of a heightfield step with actuator waves (see the helper loop); mesh terrains: two slots a wave
+  // (heightfield / plane steps; on triangle-mesh terrains every wave takes the slot pair [2 w, 2 w + 2), the main wave [0, 2))
   constexpr int DS0 = 3, DS1 = 4, DS2 = 6;   // main 3 / wave 1 (which also has the leg bias) 1 / 2 / 2: the helpers are the last to arrive at (A2), the main wave has ~3 k cycles of slack there (A/B in one session: 2/2/2/2 +1.4 us, 4/0/2/2 +0.3 us; 1/2/2/3 and 0/2/3/3: worse still)
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     };
     auto share_fn = [&]() { if (helpers) lds_barrier(); };   // (A3) every wave has finished its slots
     const SlotShare share{helpers ? 4 : 1, 0};
-    physics_substep<TMESH, DS0>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
+    physics_substep<TMESH, TMESH ? 2 : DS0>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
                               sub == nsub - 1 ? fbody : nullptr, stamps, (TMESH && helpers) ? cqc : nullptr);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
