@@ -855,9 +855,10 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
 #pragma unroll 1
     for (int sl = 0; sl < LG_MAX_CP; ++sl) {
       if (!((slot_mask >> sl) & 1u)) continue;
-      if (CS(sl, CF_ACTIVE) == 0.f) continue;
+      const bool on = CS(sl, CF_ACTIVE) != 0.f;       // selected, not branched on: a lane without this contact adds zero
       const V3 t1 = v3(CS(sl, CF_T12), CS(sl, CF_T12 + 2), CS(sl, CF_T12 + 4)), t2 = v3(CS(sl, CF_T12 + 1), CS(sl, CF_T12 + 3), CS(sl, CF_T12 + 5));
       V3 f = idt * (CS(sl, CF_L0) * lds3(cst, sl, CF_N, lane) + CS(sl, CF_L1) * t1 + CS(sl, CF_L2) * t2);
+      f = v3(on ? f.x : 0.f, on ? f.y : 0.f, on ? f.z : 0.f);
       int link = lm_.i(LM_CP_LINK + sl);
       int slotb = link < 0 ? 0 : (link > 3 ? 4 : link + 1);
 #pragma unroll
