@@ -745,6 +745,10 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     pk2 Y01[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a) { Y01[a].x = Y[0][a]; Y01[a].y = Y[1][a]; }
+    // A lane with nothing to relax at a step still reads a record (and multiplies it by zero impulses): it must be one the
+    // set-up has written in THIS launch for every lane -- any slot of the wave's mask -- not a slot nobody uses, whose LDS
+    // may hold another kernel's bits (0 x NaN would poison the base velocity of the quad).
+    const int idle_sl = slot_mask ? __builtin_ctz(slot_mask) : 0;
 #pragma unroll 1
     for (int it = 0; it < P.iters; ++it) {
       // every lane walks the list of its own active slots; step j relaxes the j-th active contact of each of the four
@@ -753,7 +757,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
 #pragma unroll 1
       for (int step = 0; step < my_steps; ++step) {
         const bool active = step < my_count;
-        const int sl = active ? (int)((my_list >> (4 * step)) & 0xfu) : 0;   // idle lanes read slot 0 and apply nothing
+        const int sl = active ? (int)((my_list >> (4 * step)) & 0xfu) : idle_sl;   // idle lanes read a slot every lane has a record for and apply nothing
         // the whole slot record first (15 x 16-B LDS reads in flight, one wait), then arithmetic only: read-next-to-use
         // costs an LDS round trip at every step of this dependent chain
         float rec[CF_FIELDS];
