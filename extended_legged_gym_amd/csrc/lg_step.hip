@@ -1145,7 +1145,9 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   const float pf_lim0 = g.dof_pos_limits[d_pf][0], pf_lim1 = g.dof_pos_limits[d_pf][1];
   const float pf_vlim = m.dof_vel_limit[d_pf], pf_tlim = m.torque_limit[d_pf], pf_dflt = g.default_dof_pos[d_pf];
   const float pf_dflt_r0 = g.default_dof_pos[max(sl_pf - 12, 0)], pf_dflt_r1 = g.default_dof_pos[min(sl_pf + 4, 11)];   // entries 12..23 of the observation
-  const bool push_now = !ro && g.push_robots && (step % g.push_interval == 0);                                          // LR:402-403
+  // (the step counter is 64-bit; its modulo is a ~150-instruction emulation, a 32-bit one a fifth of that: taken whenever it fits)
+  const bool push_hit = (step >> 32) == 0 ? ((uint32_t)step % (uint32_t)g.push_interval == 0u) : (step % g.push_interval == 0);
+  const bool push_now = !ro && g.push_robots && push_hit;                                                               // LR:402-403
   const float pf_value = K.values ? K.values[min(inst * EPBP + (ln >> 4), n - 1)] : 0.f;   // critic value of the narrow-stage lane's env (time-out bootstrap)
 
   // ---- (1a) height scan from the post-physics root pose (LR:400-401).  Order of the memory traffic of this kernel's
