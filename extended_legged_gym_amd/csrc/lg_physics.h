@@ -513,7 +513,7 @@ LG_DEV unsigned active_slot_mask(const float* cst, int lane) {
 }
 
 // How the contact set-up of one substep is shared between the waves of a workgroup: this wave takes every n-th active slot.
-struct SlotShare { int n, me; };
+struct SlotShare { int n, me; bool late; };   // late: the rendezvous after the set-up is held right in front of the sweeps
 // (Mi 6 | Mbk 18 | Y 18 | Si 21) of every lane, published by the main wave for the helper waves: [field][lane]
 #define XS_FIELDS 63
 #define XS_STRIDE 68   // dwords per lane: 16-B aligned rows, 17 (odd) 16-B units -> conflict-free ds_read/write_b128
@@ -673,7 +673,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
       contact_setup_slot(sl, lm_, k, pb, Mi, Mbk, Y, Si, P.cfm, cst, lane);
     }
   }
-  share_fn();
+  if (!share.late) share_fn();
 
   STAMP(6);
   // ---------------------------------------------------------------- unconstrained velocity v* = v + dt M^-1 (tau - c)
@@ -738,6 +738,10 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   int my_steps = 0;                                   // wave-uniform: the longest list
 #pragma unroll
   for (int j = 0; j < LG_MAX_CP; ++j) my_steps += __ballot(my_count > j) != 0ull ? 1 : 0;
+  // With helper waves this wave is the last to be dealt a slot of the set-up (share.late): the unconstrained velocity, the
+  // joint-limit rows and the slot lists above need nothing from the slot records, so they ran while the other waves set
+  // their slots up; the rendezvous that closes the set-up comes only now.
+  if (share.late) share_fn();
   if (slot_mask || jl_wave) {
     // packed state of the sweeps: base velocity in three pairs, joints (0, 1) as a pair and joint 2 alone, Y by joint pair
     pk2 vBp[3] = {{vB[0], vB[1]}, {vB[2], vB[3]}, {vB[4], vB[5]}};
