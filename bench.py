@@ -96,8 +96,8 @@ def cpu_baseline(env, actions_pool, budget_s=15.0):
                        f"(best of the probed team sizes; {avail} CPUs visible), {dt:.1f} s")
 
 
-PMC_PASSES = "r01_fin_pmc.json"
-SQ_PASSES = "r01_fin_sq_counters.txt"
+PMC_PASSES = "r01_z_pmc.json"
+SQ_PASSES = "r01_z_sq_counters.txt"
 
 
 def sq_issue(N):
