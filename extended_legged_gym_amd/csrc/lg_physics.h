@@ -658,7 +658,8 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
       am += __popcll(b);
       for (int w = 0; w < 4; ++w) g4 += ((b >> (16 * w)) & 0xffffull) ? 1 : 0;
     }
-    if (stamps) { stamps[16] += __popc(slot_mask); stamps[17] += 1; stamps[18] += am; stamps[28] += g4; }
+    if (stamps) { stamps[16] += __popc(slot_mask); stamps[17] += 1; stamps[18] += am; stamps[28] += g4;
+                  stamps[30] += __popc(slot_mask) >= 4 ? 1 : 0; stamps[31] += __popc(slot_mask) >= 5 ? 1 : 0; }   // (heightfield runs: 30 / 31 are free)
   }
 #endif
   STAMP(5);

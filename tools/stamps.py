@@ -29,6 +29,7 @@ hn = {22: "HELPER w2: wait at (A)", 23: "HELPER: kinematics", 24: "HELPER: conta
 for k, n in hn.items():
     print(f"{n:34s} per substep {out[k] / (301 * 4):9.0f} cycles")
 print('active slots per 16-lane group (4 envs) per substep', out[28] / max(out[17], 1) / 4)
+print('wave-substeps with >= 4 active slots: %.1f %%, >= 5: %.1f %%' % (100.0 * out[30] / max(out[17], 1), 100.0 * out[31] / max(out[17], 1)))
 print('active slots per wave-substep', out[16] / max(out[17], 1), ' active contacts per wave-substep', out[18] / max(out[17], 1), '(of', 64 * 7, 'lane-slots)')
 for k, n in names.items():
     print(f"{n:28s} {out[k]:14d} cycles  {100.0 * out[k] / max(tot, 1):5.1f} %   per substep-call {out[k] / (301 * 4):9.0f}")
