@@ -1276,10 +1276,12 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   static_assert(EPBP * 16 == 64 && F_COUNT <= 8, "phase 2: sixteen lanes per env on one wave");
   unsigned term_mask = 0;                       // which reward terms are switched on (wave-uniform)
   int kfat = g.num_reward_terms;                // position of feet_air_time in the evaluation order (K = absent)
+  int kterm = -1; float term_scale = 0.f;       // position and scale of the termination term (added after the clip, LR:226-232)
   for (int k = 0; k < g.num_reward_terms; ++k) {
     const int id = g.reward_term_ids[k];
     term_mask |= 1u << id;
     if (id == LG_REW_FEET_AIR_TIME) kfat = k;
+    if (id == LG_REW_TERMINATION) { kterm = k; term_scale = g.reward_scales[k]; }
   }
   {
     const bool mine = FUSED || wv == (int)((blockIdx.x >> 8) & 3u);   // (workgroups 256 apart share a CU when all 1024 are resident)
@@ -1416,9 +1418,9 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
       float rew = 0.f;
       for (int k = 0; k < g.num_reward_terms; ++k) rew += L.s_rk[el][k];
       if (g.only_positive_rewards) rew = fmaxf(rew, 0.f);
-      for (int k = 0; k < g.num_reward_terms; ++k) if (g.reward_term_ids[k] == LG_REW_TERMINATION) {
-        float r = ((term || tout) && !tout ? 1.f : 0.f) * g.reward_scales[k];
-        rew += r; L.s_rk[el][k] = r;
+      if (kterm >= 0) {                                  // (found once at the top: no walk over the term list on this lane's chain)
+        float r = ((term || tout) && !tout ? 1.f : 0.f) * term_scale;
+        rew += r; L.s_rk[el][kterm] = r;
       }
       C->rew[e] = rew;
       if (rew_out) rew_out[(size_t)(e0 + el) * rew_stride] = rew;
