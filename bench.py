@@ -212,7 +212,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "physics_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(N), **sq_issue(N),
                          "algorithmic_bytes_per_env_step": phys_bytes, "kernel_ms": prof["physics_ms"],
-                         "post_kernel_ms": prof["post_ms"], "finalize_kernel_ms": prof["finalize_ms"],
+                         "post_kernel_ms": prof["post_ms"], "hip_event_pair_overhead_ms": prof["finalize_ms"],   # two events back to back: what every event interval above carries on top of its kernel
                          "hip_event_samples": prof["samples"],
                          "whole_step_bytes_per_env_step": phys_bytes + POST_BYTES["read"] + POST_BYTES["write"]},
             "episode_stats": {"sum_return": float(stats_all[0]), "sum_length": float(stats_all[1]),
