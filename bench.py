@@ -96,14 +96,21 @@ def cpu_baseline(env, actions_pool, budget_s=15.0):
                        f"(best of the probed team sizes; {avail} CPUs visible), {dt:.1f} s")
 
 
-PMC_PASSES = "r01_z_pmc.json"
-SQ_PASSES = "r01_z_sq_counters.txt"
+def _latest_profile(suffix):
+    """Counter summary `profiles/<tag>_<suffix>` of the build named in `profiles/LATEST` (written by tools/profile_round.sh
+    when the summaries of a build are committed)."""
+    tag = "r01_z"
+    try:
+        tag = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip() or tag
+    except OSError:
+        pass
+    return os.path.join(ROOT, "profiles", f"{tag}_{suffix}")
 
 
 def sq_issue(N):
     """VALU busy fraction of the physics kernel's waves from the committed SQ counter passes (`tools/pmc_sq.sh`): the kernel
     is bound by instruction issue of one wave per SIMD, not by bytes, so this is the utilisation figure that moves."""
-    path = os.path.join(ROOT, "profiles", SQ_PASSES)
+    path = _latest_profile("sq_counters.txt")
     if not os.path.exists(path) or N != 4096:
         return {}
     try:
@@ -124,7 +131,7 @@ def pmc_traffic(N):
     """HBM bytes per launch of the physics kernel from the committed rocprofv3 PMC passes (`tools/profile_round.sh`,
     separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command).  bench.py cannot collect counters
     itself; the figure is only reported when the committed passes were taken at the same env count."""
-    files = [os.path.join(ROOT, "profiles", PMC_PASSES)]     # the passes taken on the current build of the kernels
+    files = [_latest_profile("pmc.json")]     # the passes taken on the most recent build of the kernels
     if not os.path.exists(files[0]) or N != 4096:
         return {"traffic": None}
     try:
@@ -147,6 +154,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pd-control", action="store_true", help="diagnostic: PD actuators instead of the LSTM net")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process has not touched the GPU yet, so it may start the N ranks as
+        # children (one process per GPU, rendezvous on the loopback address) and hand their exit code on.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
@@ -175,8 +195,8 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    samples = min(256, a.steps)
-    env.core.profile_begin(samples, max(1, a.steps // samples))
+    # the timed region: exactly --steps calls of env.step, nothing else (no events, no profiler)
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(a.steps):
         env.step(pool[i % len(pool)])
@@ -185,6 +205,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+
+    # a separate, untimed pass for the per-kernel durations of the roofline block: HIP events on the stream the kernels
+    # run on, every 4th step sampled, at least 64 samples whatever --steps was
+    samples = 128
+    env.core.profile_begin(samples, 4)
+    for i in range(4 * samples):
+        env.step(pool[i % len(pool)])
+    torch.cuda.synchronize(dev)
     prof = env.core.profile_end()
 
     # episode statistics of every shard: one all-gather (RCCL over xGMI when world > 1)
@@ -209,7 +237,8 @@ def main():
                                    f"{N} envs/GPU, LSTM actuator net, 235-dim obs, noise+pushes+curriculum on, "
                                    "actions N(0,1), one step = 4 physics substeps + post-physics",
                        "num_envs_per_gpu": N, "decimation": 4, "sim_dt": 0.005, "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "physics_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "limited_by": "instruction issue / dependent latency of one heavy wave per SIMD (see valu_busy_frac), not bytes",
+                         "kernel": "physics_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(N), **sq_issue(N),
                          "algorithmic_bytes_per_env_step": phys_bytes, "kernel_ms": prof["physics_ms"],
                          "kernel_ms_net_of_event_overhead": max(prof["physics_ms"] - prof["finalize_ms"], 0.0),   # what rocprofv3 reports (profiles/)

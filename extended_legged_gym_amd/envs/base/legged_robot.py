@@ -97,13 +97,18 @@ class LeggedRobot(BaseTask):
         else:
             raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh, confined_trimesh]")
 
+        # env shards of a multi-GPU job: same terrain (common seed, generated above), own per-env randomisation
+        from extended_legged_gym_amd.utils.sharding import draw_env_randomisation, seed_shard_rngs
+        seed = getattr(self.cfg, "seed", 1)
+        seed = int(seed) if seed is not None and seed >= 0 else 0
+        seed_shard_rngs(seed, int(getattr(self.cfg, "rng_stream_offset", 0)))
+        self._env_draws = draw_env_randomisation(self.cfg, self.num_envs)
+
         self.robot_model = load_robot_model(self.cfg.asset)
         self.body_names = self.robot_model["body_names"]
         self.dof_names = self.robot_model["dof_names"]
         self.num_bodies = len(self.body_names)
         self.num_dof = self.num_dofs = len(self.dof_names)
-        seed = getattr(self.cfg, "seed", 1)
-        seed = int(seed) if seed is not None and seed >= 0 else 0
         # env shards of a multi-GPU job draw from disjoint Philox streams
         seed += 1000003 * int(getattr(self.cfg, "rng_stream_offset", 0))
         self.setup = NativeSetup(self.cfg, self.sim_params, self.robot_model, terrain=self.terrain, seed=seed,
@@ -124,17 +129,13 @@ class LeggedRobot(BaseTask):
 
         self._get_env_origins()
         # per-env friction: 64 buckets (`:332-343`); base payload (`:381-383`)
-        if self.cfg.domain_rand.randomize_friction:
-            fr = self.cfg.domain_rand.friction_range
-            bucket_ids = torch.randint(0, 64, (self.num_envs, 1))
-            buckets = torch_rand_float(fr[0], fr[1], (64, 1), device='cpu')
-            self.friction_coeffs = buckets[bucket_ids]
-            t["friction_coeffs"].copy_(self.friction_coeffs.view(-1))
+        if self._env_draws["friction"] is not None:
+            self.friction_coeffs = self._env_draws["friction"].view(-1, 1, 1)
+            t["friction_coeffs"].copy_(self._env_draws["friction"])
         else:
             t["friction_coeffs"].fill_(1.0)
-        if self.cfg.domain_rand.randomize_base_mass:
-            rng = self.cfg.domain_rand.added_mass_range
-            t["base_mass_added"].copy_(torch.from_numpy(np.random.uniform(rng[0], rng[1], self.num_envs).astype(np.float32)))
+        if self._env_draws["payload"] is not None:
+            t["base_mass_added"].copy_(self._env_draws["payload"])
 
         # DOF limits (`:357-371`)
         m = self.robot_model
@@ -167,12 +168,9 @@ class LeggedRobot(BaseTask):
             self._sample_random_origins()
         elif self.cfg.terrain.mesh_type in ["heightfield", "trimesh", "confined_trimesh"]:
             self.custom_origins = True
-            max_init_level = self.cfg.terrain.max_init_terrain_level
-            if not self.cfg.terrain.curriculum:
-                max_init_level = self.cfg.terrain.num_rows - 1
             self.terrain_levels = t["terrain_levels"]
             self.terrain_types = t["terrain_types"]
-            self.terrain_levels.copy_(torch.randint(0, max_init_level + 1, (self.num_envs,), device=self.device))
+            self.terrain_levels.copy_(self._env_draws["levels"])
             # a shard of a multi-GPU job indexes terrain columns by GLOBAL env id, so the union of the shards has the
             # single-GPU layout (`legged_robot.py:829-830` with num_envs = the job's total)
             offset = int(getattr(self.cfg.env, "global_env_offset", 0))

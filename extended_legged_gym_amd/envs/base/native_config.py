@@ -242,7 +242,10 @@ class NativeSetup:
         c.solver_iterations = int(getattr(px, "num_position_iterations", 4))
         c.contact_offset = float(getattr(px, "contact_offset", 0.01))
         c.max_depenetration_velocity = float(getattr(px, "max_depenetration_velocity", 1.0))
-        c.erp, c.cfm = 0.2, 1e-6
+        # penetration recovery per substep: PhysX scales the penetration bias of a contact row by 0.8 / dt and clamps it
+        # at max_depenetration_velocity (contact preparation of its solver).  Pinned at task level: with 0.8 the reference's
+        # PhysX-trained walking policy stays up (tests/test_walk_policy.py; 0.2 let feet sink and cost ~0.4 falls / 20 s).
+        c.erp, c.cfm = 0.8, 1e-6
         c.seed, c.rng_mode = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_mode)
         self.cfg = c
 

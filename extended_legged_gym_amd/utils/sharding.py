@@ -14,6 +14,43 @@ def shard_env_cfg(cfg, rank, world, envs_per_rank):
     return cfg
 
 
+def seed_shard_rngs(seed, shard):
+    """Per-shard seed of the global torch / numpy generators for the per-env draws made at creation (friction buckets,
+    payload, initial terrain level: `legged_robot.py:332-343,381-383,823`).  Called AFTER the terrain has been generated
+    from the common seed, so every rank holds the same terrain but env i of two shards is not the same sample of the
+    domain randomisation.  Shard 0 keeps the single-GPU stream."""
+    import numpy as np
+    if not shard:
+        return int(seed)
+    s = (int(seed) + 1000003 * int(shard)) & 0x7FFFFFFF
+    np.random.seed(s)
+    torch.manual_seed(s)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(s)
+    return s
+
+
+def draw_env_randomisation(cfg, num_envs):
+    """The per-env draws of `_create_envs` / `_get_env_origins` from the global generators, on the host: friction
+    coefficients through 64 buckets (`legged_robot.py:332-343`), base payload (`:381-383`), initial terrain level
+    (`:823`).  Returns float32 / int64 CPU tensors (None where the config does not randomise)."""
+    import numpy as np
+    from extended_legged_gym_amd.utils.isaac_torch_utils import torch_rand_float
+    out = dict(friction=None, payload=None, levels=None)
+    if cfg.domain_rand.randomize_friction:
+        fr = cfg.domain_rand.friction_range
+        bucket_ids = torch.randint(0, 64, (num_envs, 1))
+        buckets = torch_rand_float(fr[0], fr[1], (64, 1), device='cpu')
+        out["friction"] = buckets[bucket_ids].view(-1)
+    if cfg.domain_rand.randomize_base_mass:
+        rng = cfg.domain_rand.added_mass_range
+        out["payload"] = torch.from_numpy(np.random.uniform(rng[0], rng[1], num_envs).astype(np.float32))
+    if cfg.terrain.mesh_type in ["heightfield", "trimesh", "confined_trimesh"]:
+        max_init_level = cfg.terrain.max_init_terrain_level if cfg.terrain.curriculum else cfg.terrain.num_rows - 1
+        out["levels"] = torch.randint(0, max_init_level + 1, (num_envs,))
+    return out
+
+
 def terrain_types_for_shard(num_cols, rank, world, envs_per_rank):
     idx = rank * envs_per_rank + torch.arange(envs_per_rank)
     return torch.div(idx, (world * envs_per_rank / num_cols), rounding_mode='floor').to(torch.long)

@@ -1,0 +1,53 @@
+"""bench.py's output contract, and its distributed code path on one GPU.
+
+The multi-GPU scaling run belongs to the driver (N = 2, 4, 8 on a whole node); what can be checked on a one-GPU box is
+that the SAME code path works: under `torch.distributed.run` a 1-rank `nccl` (= RCCL) process group is formed, the
+barriers and the episode-statistics all-gather run on it, and rank 0 prints one JSON line with the required keys.  The
+timed region must carry no instrumentation: `hip_event_samples` comes from the separate pass and does not depend on --steps."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json_line(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_source_keeps_the_profiler_out_of_the_timed_region():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    timed = src[src.index("t0 = time.perf_counter()\n    for i in range(a.steps)"):src.index("elapsed = time.perf_counter() - t0")]
+    assert "profile_begin" not in timed and "Event" not in timed
+    assert src.index("profile_begin") > src.index("elapsed = time.perf_counter() - t0")
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_forms_a_one_rank_rccl_group():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "20",
+           "--envs-per-gpu", "1024", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json_line(r.stdout)
+    for k in REQUIRED:
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["finite"] is True
+    assert out["roofline"]["hip_event_samples"] >= 64            # the instrumented pass is separate from the 20 timed steps
+    assert out["episode_stats"]["env_steps"] > 0                 # went through the all-gather of the 1-rank group
+    assert out["value"] > 0 and abs(out["ms_per_step"] * 1e-3 * out["value"] - 1024) < 1.0

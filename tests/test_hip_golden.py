@@ -59,3 +59,46 @@ def test_hip_step_matches_reference(case):
             np.testing.assert_allclose(core.t["extras_episode"][:K].cpu().numpy(), z["extras_episode"][t], rtol=1e-4, atol=1e-6)
         assert int(core.t["step_counters"][1]) == int(z["reset"][t].sum())
     core.close()
+
+
+@pytest.mark.parametrize("case", ["flat_lstm", "rough_lstm"])
+def test_fused_step_actuator_matches_reference_torques(case):
+    """The actuator as the HEADLINE path runs it: inside the fused physics kernel (`lg_step` / `lg_step_physics`), where the
+    LSTM is split over helper waves into a recurrent and an input half with fast gate functions — not the stand-alone
+    `lg_compute_torques` kernel of the test above.  A context with `decimation = 1` makes one library call = one substep, so
+    the golden DOF state of each substep (recorded from the reference's `Anymal.step()`) can be injected in front of it
+    exactly as the FakeGym harness injected it in front of the reference's `_compute_torques` (`anymal.py:93-105`); the
+    LSTM state is carried by the kernel from call to call.  Same bar as the stand-alone path: torques atol 5e-5."""
+    from extended_legged_gym_amd.native import NativeCore
+    z, meta = load_golden(case)
+    cfg, _ = golden_setup(z, meta)
+    dec = cfg.control.decimation
+    meta1 = dict(meta)
+    cfg1, s1 = golden_setup(z, meta1)
+    s1.cfg.decimation = 1
+    core = NativeCore(s1, "cuda:0")
+    T = z["actions"].shape[0]
+
+    def write(name, arr):
+        tt = core.t[name]
+        if name == "episode_sums":
+            tt = tt[:np.asarray(arr).shape[0]]
+        tt.copy_(torch.from_numpy(np.ascontiguousarray(arr).reshape(tuple(tt.shape))).to(tt.dtype))
+
+    for t in range(T):
+        load_pre_state(core.t, z, t, write)
+        act = torch.from_numpy(z["actions"][t]).cuda()
+        for sub in range(dec):
+            if sub > 0:
+                write("dof_state", z["sim_dof"][t, sub - 1])       # what refresh_dof_state_tensor showed the reference
+            write("root_states", z["pre_root_states"][t])         # keep the robots where the fixture has them (free fall otherwise)
+            core.compute_torques_and_simulate(act)                # fused: clip actions, actuator, one dt of physics
+            check("torques", core.t["torques"], z["torques"][t, sub], t)
+        check("actions", core.t["actions"], z["clipped_actions"][t], t)
+        # LSTM state after the four substeps = the reference's, for the envs its post-physics step did not reset
+        keep = torch.from_numpy(z["reset"][t] == 0).cuda().repeat_interleave(12)
+        for name, key in (("sea_hidden_state", "post_sea_hidden"), ("sea_cell_state", "post_sea_cell")):
+            got = core.t[name][:, keep].cpu().numpy()
+            want = z[key][t][:, keep.cpu().numpy()]
+            np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL_BY_NAME[name], err_msg=f"step {t}: {name}")
+    core.close()

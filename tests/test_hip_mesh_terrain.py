@@ -98,7 +98,8 @@ def test_two_triangle_plane_mesh_equals_plane_on_the_gpu():
     for name in ["root_states", "dof_state", "contact_forces", "obs_buf", "rew_buf"]:
         a, b = cores[0].t[name].cpu().numpy(), cores[1].t[name].cpu().numpy()
         err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
-        assert (err <= 2e-3).mean() >= 0.99, (name, err.max())
+        # (penetration recovery at PhysX's 0.8 / dt makes first touch-downs stiffer than the former 0.2: 98.6 % measured)
+        assert (err <= 2e-3).mean() >= 0.98 and np.median(err) <= 2e-5, (name, err.max())
     assert cores[0].t["contact_forces"][:, :, 2].max() > 50.0
     for c in cores:
         c.close()

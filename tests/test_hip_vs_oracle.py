@@ -55,18 +55,53 @@ def init_oracle(o, cfg, s, terrain, n, seed):
     return rng
 
 
+def env_rows(name, arr, n):
+    """(n, k) view of a state tensor with one row per env."""
+    a = np.asarray(arr, dtype=np.float64)
+    if name in ("sea_hidden_state", "sea_cell_state"):       # (2, n * 12, 8)
+        return a.reshape(2, n, -1).transpose(1, 0, 2).reshape(n, -1)
+    if name == "episode_sums":                                # (K, n)
+        return a.reshape(-1, n).T
+    return a.reshape(n, -1)
+
+
+def contact_pattern(t, n):
+    cf = np.asarray(t, dtype=np.float64).reshape(n, -1, 3)
+    return np.linalg.norm(cf, axis=2) > 1e-3                  # which bodies carry a contact force in the last substep
+
+
+MAX_DIFFERENT_CONTACT_ENVS = 0.03      # fraction of envs whose set of loaded bodies differs between HIP and oracle
+TOL_SAME_CONTACTS = 5e-2               # max error of ANY entry of an env whose contact set agrees ...
+TOL_SAME_CONTACTS_BY_NAME = {"contact_forces": 0.25}   # ... except the multipliers of the last 4-sweep Gauss-Seidel solve themselves:
+# a contact that switched on one substep earlier in one implementation shows up as a force difference (11 % measured) while the
+# state it produces stays within the bar above
+REPORT = []
+
+
 def compare(core, o, names, frac_ok=0.995, tol=2e-3, med=2e-5):
+    """The bar of the module docstring, made explicit about its outliers: envs in which a contact within rounding of its
+    activation threshold is on in one implementation and off in the other are COUNTED (at most 3 % of the envs) and are
+    the only place an entry may be far off; everywhere else every entry is within 5e-2 * max(1, |x|), 99.5 % of the entries
+    of each tensor within 2e-3 and the median within 2e-5."""
     torch.cuda.synchronize()
+    n = int(core.t["root_states"].shape[0])
+    differ = (contact_pattern(core.t["contact_forces"].detach().cpu().numpy(), n) != contact_pattern(o.t["contact_forces"], n)).any(1)
+    assert differ.mean() <= MAX_DIFFERENT_CONTACT_ENVS, f"{differ.sum()} of {n} envs load different bodies"
     worst = {}
     for name in names:
-        a = core.t[name].detach().cpu().numpy().astype(np.float64).reshape(-1)
-        b = o.t[name].astype(np.float64).reshape(-1)
+        a = env_rows(name, core.t[name].detach().cpu().numpy(), n)
+        b = env_rows(name, o.t[name], n)
         err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
         assert np.isfinite(a).all(), f"{name}: non-finite values on the GPU"
         ok = (err <= tol).mean()
-        worst[name] = (float(np.median(err)), float(err.max()), float(ok))
+        same = err[~differ]
+        worst[name] = (float(np.median(err)), float(same.max()) if same.size else 0.0, float(err.max()), float(ok))
         assert ok >= frac_ok, f"{name}: only {ok:.4f} of entries within {tol} (max {err.max():.3g})"
         assert np.median(err) <= med, f"{name}: median error {np.median(err):.3g}"
+        assert same.size == 0 or same.max() <= TOL_SAME_CONTACTS_BY_NAME.get(name, TOL_SAME_CONTACTS), \
+            f"{name}: error {same.max():.3g} in env {int(np.argmax(err.max(1) * ~differ))} whose contact set agrees"
+    REPORT.append(dict(envs=n, envs_with_different_contacts=int(differ.sum()),
+                       max_err_same_contacts=max(v[1] for v in worst.values()), max_err_any=max(v[2] for v in worst.values())))
     return worst
 
 
@@ -91,6 +126,7 @@ def test_single_step_parity_from_identical_state(kind):
             # integer outputs: identical wherever the float state agrees
             ra, rb = core.t["reset_buf"].cpu().numpy(), o.t["reset_buf"]
             assert (ra != rb).mean() <= 0.01
+            print("parity report:", REPORT[-1])
             assert np.array_equal(core.t["episode_length_buf"].cpu().numpy()[ra == rb], o.t["episode_length_buf"][ra == rb])
         else:
             o.step(act)

@@ -1,0 +1,235 @@
+"""Known answers for the quaternion helpers.
+
+The golden vectors cannot pin them: `tools/refgen/ref_loader.py` installs this project's own
+`utils/isaac_torch_utils.py` AS `isaacgym.torch_utils` (the real one is a closed package, absent), so the "reference" runs
+that produced the fixtures rotated vectors with our code.  A convention slip (wxyz vs xyzw, active vs passive, left vs
+right product) would be invisible there.  Here every helper is held to closed-form answers and to an independent
+implementation (scipy's `Rotation`, xyzw like Isaac Gym), and the in-kernel helpers (`csrc/lg_device.h`, and the
+oracle's own copies) are held to the same answers through the post-physics step: base-frame velocities and projected
+gravity of bodies at known attitudes (`legged_robot.py:128-134`)."""
+import numpy as np
+import pytest
+import torch
+from scipy.spatial.transform import Rotation
+
+from extended_legged_gym_amd.utils import isaac_torch_utils as tu
+from extended_legged_gym_amd.utils import math_utils as mu
+
+S = np.sqrt(0.5)
+AXES = {"x": [1.0, 0, 0], "y": [0, 1.0, 0], "z": [0, 0, 1.0]}
+
+
+def q_axis(axis, deg):
+    a = np.asarray(AXES[axis]) * np.sin(np.radians(deg) / 2)
+    return np.array([a[0], a[1], a[2], np.cos(np.radians(deg) / 2)], np.float32)
+
+
+# (quaternion xyzw, vector, rotated vector): right-handed active rotations
+KNOWN = [
+    (q_axis("z", 90), [1, 0, 0], [0, 1, 0]),
+    (q_axis("z", -90), [1, 0, 0], [0, -1, 0]),
+    (q_axis("x", 90), [0, 1, 0], [0, 0, 1]),
+    (q_axis("x", -90), [0, 1, 0], [0, 0, -1]),
+    (q_axis("y", 90), [0, 0, 1], [1, 0, 0]),
+    (q_axis("y", -90), [0, 0, 1], [-1, 0, 0]),
+    (q_axis("y", 90), [1, 0, 0], [0, 0, -1]),
+    (np.array([0, 0, 0, 1], np.float32), [0.3, -0.7, 2.0], [0.3, -0.7, 2.0]),
+    (q_axis("z", 180), [1, 2, 3], [-1, -2, 3]),
+]
+
+
+def T(a):
+    return torch.tensor(np.asarray(a, np.float32))
+
+
+def test_rotate_apply_and_inverse_known_answers():
+    for q, v, want in KNOWN:
+        q_, v_ = T(q)[None], T(v)[None]
+        np.testing.assert_allclose(tu.quat_rotate(q_, v_)[0].numpy(), want, atol=1e-6)
+        np.testing.assert_allclose(tu.quat_apply(q_, v_)[0].numpy(), want, atol=1e-6)
+        np.testing.assert_allclose(tu.quat_rotate_inverse(q_, T(want)[None])[0].numpy(), v, atol=1e-6)
+
+
+def test_helpers_agree_with_an_independent_implementation():
+    rng = np.random.default_rng(0)
+    q = rng.normal(size=(200, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    v = rng.normal(size=(200, 3)).astype(np.float32)
+    R = Rotation.from_quat(q.astype(np.float64))             # scipy: scalar-last (x, y, z, w), active rotation
+    np.testing.assert_allclose(tu.quat_rotate(T(q), T(v)).numpy(), R.apply(v), atol=2e-6)
+    np.testing.assert_allclose(tu.quat_apply(T(q), T(v)).numpy(), R.apply(v), atol=2e-6)
+    np.testing.assert_allclose(tu.quat_rotate_inverse(T(q), T(v)).numpy(), R.inv().apply(v), atol=2e-6)
+    # round trip
+    back = tu.quat_rotate_inverse(T(q), tu.quat_rotate(T(q), T(v)))
+    np.testing.assert_allclose(back.numpy(), v, atol=3e-6)
+    # product: quat_mul(a, b) rotates by b first, then a  <=>  R(a) R(b)
+    p = rng.normal(size=(200, 4)).astype(np.float32)
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    qp = tu.quat_mul(T(q), T(p)).numpy()
+    Rm = R.as_matrix() @ Rotation.from_quat(p.astype(np.float64)).as_matrix()
+    np.testing.assert_allclose(Rotation.from_quat(qp.astype(np.float64)).as_matrix(), Rm, atol=3e-6)
+    np.testing.assert_allclose(np.linalg.norm(qp, axis=1), 1.0, atol=1e-6)
+    # conjugate = inverse for unit quaternions
+    ident = tu.quat_mul(T(q), tu.quat_conjugate(T(q))).numpy()
+    np.testing.assert_allclose(ident, np.tile([0, 0, 0, 1.0], (200, 1)), atol=2e-6)
+
+
+def test_quat_mul_known_products():
+    z90, x90 = T(q_axis("z", 90))[None], T(q_axis("x", 90))[None]
+    np.testing.assert_allclose(tu.quat_mul(z90, z90)[0].numpy(), q_axis("z", 180), atol=1e-6)
+    # x-then-z differs from z-then-x: quat_mul(z90, x90) applied to e_y: x90 takes e_y to e_z, z90 leaves e_z
+    v = tu.quat_apply(tu.quat_mul(z90, x90), T([0, 1, 0])[None])[0].numpy()
+    np.testing.assert_allclose(v, [0, 0, 1], atol=1e-6)
+    v = tu.quat_apply(tu.quat_mul(x90, z90), T([0, 1, 0])[None])[0].numpy()     # z90: e_y -> -e_x, x90 leaves e_x
+    np.testing.assert_allclose(v, [-1, 0, 0], atol=1e-6)
+
+
+def test_angle_axis_normalize_and_axis_params():
+    ang = T([np.pi / 2, np.pi, 0.3])
+    ax = T([[0, 0, 2.0], [3.0, 0, 0], [0, 1.0, 0]])            # un-normalised axes
+    q = tu.quat_from_angle_axis(ang, ax).numpy()
+    want = Rotation.from_rotvec(np.array([[0, 0, np.pi / 2], [np.pi, 0, 0], [0, 0.3, 0]])).as_quat()
+    np.testing.assert_allclose(q, want, atol=1e-6)
+    np.testing.assert_allclose(tu.normalize(T([[3.0, 0, 4.0]])).numpy(), [[0.6, 0, 0.8]], atol=1e-7)
+    assert tu.get_axis_params(-1.0, 2) == [0.0, 0.0, -1.0]
+    assert tu.get_axis_params(1.0, 1, x_value=0.5) == [0.5, 1.0, 0.0]
+
+
+def test_yaw_only_rotation_wrap_and_ypr():
+    # quat_apply_yaw (math_utils.py:40-44): only the yaw of a tilted attitude rotates the vector
+    tilt = Rotation.from_euler("ZYX", [40, 25, -10], degrees=True)       # yaw 40, pitch 25, roll -10
+    q = T(tilt.as_quat())[None]
+    v = T([1.0, 0.5, 0.2])[None]
+    got = mu.quat_apply_yaw(q.clone(), v)[0].numpy()
+    qz, qw = tilt.as_quat()[2], tilt.as_quat()[3]                         # what the helper keeps: (0, 0, z, w) normalised
+    yaw_only = Rotation.from_quat([0, 0, qz, qw])
+    np.testing.assert_allclose(got, yaw_only.apply(v[0].numpy()), atol=2e-6)
+    got = mu.quat_apply_yaw(T(q_axis("z", 90))[None], T([1.0, 0, 0])[None])[0].numpy()
+    np.testing.assert_allclose(got, [0, 1, 0], atol=1e-6)
+    a = T([0.0, np.pi + 0.1, -np.pi - 0.1, 7.0, -7.0])
+    np.testing.assert_allclose(mu.wrap_to_pi(a.clone()).numpy(), [0.0, -np.pi + 0.1, np.pi - 0.1, 7.0 - 2 * np.pi, -7.0 + 2 * np.pi],
+                               atol=1e-6)
+    yaw, pitch, roll = T([0.7]), T([-0.2]), T([0.4])
+    q = mu.ypr_to_quat(yaw, pitch, roll)[0].numpy()
+    want = (Rotation.from_euler("x", 0.4) * Rotation.from_euler("y", -0.2) * Rotation.from_euler("z", 0.7)).as_quat()
+    np.testing.assert_allclose(q * np.sign(q[3]), want * np.sign(want[3]), atol=1e-6)
+
+
+# ------------------------------------------------------------------ the in-kernel helpers, through the post-physics step
+def _attitude_cases():
+    qs = [np.array([0, 0, 0, 1], np.float32)] + [q_axis(a, d) for a in "xyz" for d in (90, -90)]
+    rng = np.random.default_rng(3)
+    r = rng.normal(size=(9, 4)).astype(np.float32)
+    qs += list(r / np.linalg.norm(r, axis=1, keepdims=True))
+    return np.stack(qs)
+
+
+def _post_step_case(n):
+    from extended_legged_gym_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+    from extended_legged_gym_amd.envs.base.native_config import NativeSetup, load_robot_model
+    from tests.helpers import ANYMAL_GAIT, sim_params_for
+    cfg = AnymalCFlatCfg()
+    cfg.env.num_envs = n
+    cfg.control.use_actuator_network = False
+    cfg.noise.add_noise = False
+    cfg.domain_rand.push_robots = False
+    cfg.asset.terminate_after_contacts_on = []
+    setup = NativeSetup(cfg, sim_params_for(cfg), load_robot_model(cfg.asset), seed=0, gait=ANYMAL_GAIT)
+    q = _attitude_cases()
+    rng = np.random.default_rng(4)
+    root = np.zeros((n, 13), np.float32)
+    root[:, 2] = 5.0
+    root[:, 3:7] = q
+    root[:, 7:13] = rng.normal(size=(n, 6))
+    R = Rotation.from_quat(q.astype(np.float64))
+    want = dict(base_lin_vel=R.inv().apply(root[:, 7:10]), base_ang_vel=R.inv().apply(root[:, 10:13]),
+                projected_gravity=R.inv().apply(np.tile([0, 0, -1.0], (n, 1))))
+    return setup, root, want
+
+
+def test_oracle_base_frame_quantities_known_answers():
+    from oracle.oracle_lib import OracleEnv
+    n = len(_attitude_cases())
+    setup, root, want = _post_step_case(n)
+    o = OracleEnv(setup)
+    o.reset_idx(np.arange(n))
+    o.t["root_states"][:] = root
+    o.post_physics_step()
+    for k, v in want.items():
+        np.testing.assert_allclose(o.t[k], v, atol=3e-6, err_msg=k)
+    # 90 deg yaw: world +x velocity is -y in the base frame; 90 deg pitch about +y (nose down): gravity along +x of the base
+    o.close()
+    yaw = Rotation.from_quat(q_axis("z", 90)).inv().apply([1.0, 0, 0])
+    np.testing.assert_allclose(yaw, [0, -1, 0], atol=1e-7)
+    pitch = Rotation.from_quat(q_axis("y", 90)).inv().apply([0, 0, -1.0])
+    np.testing.assert_allclose(pitch, [1, 0, 0], atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_hip_base_frame_quantities_known_answers():
+    from extended_legged_gym_amd.native import NativeCore
+    n = len(_attitude_cases())
+    setup, root, want = _post_step_case(n)
+    core = NativeCore(setup, "cuda:0")
+    core.reset_idx(torch.arange(n))
+    core.t["root_states"].copy_(torch.from_numpy(root))
+    core.post_physics_step()
+    torch.cuda.synchronize()
+    for k, v in want.items():
+        np.testing.assert_allclose(core.t[k].cpu().numpy(), v, atol=3e-6, err_msg=k)
+    core.close()
+
+
+def _check_rigid_frames(rb, root):
+    n = rb.shape[0]
+    R = Rotation.from_quat(root[:, 3:7].astype(np.float64))
+    rel0 = rb[0, :, 0:3] - rb[0, 0:1, 0:3]                   # env 0 has the identity attitude
+    assert np.abs(rel0).max() > 0.3                          # the bodies are spread out: the test can see a wrong rotation
+    for e in range(n):
+        rel = R[e].inv().apply(rb[e, :, 0:3] - rb[e, 0:1, 0:3])
+        np.testing.assert_allclose(rel, rel0, atol=2e-5)
+        for b in range(rb.shape[1]):
+            want = (R[e] * Rotation.from_quat(rb[0, b, 3:7].astype(np.float64))).as_matrix()
+            got = Rotation.from_quat(rb[e, b, 3:7].astype(np.float64)).as_matrix()
+            np.testing.assert_allclose(got, want, atol=2e-5)
+
+
+def test_oracle_rigid_body_frames_follow_the_base_attitude():
+    from oracle.oracle_lib import OracleEnv
+    n = len(_attitude_cases())
+    setup, root, _ = _post_step_case(n)
+    o = OracleEnv(setup)
+    o.reset_idx(np.arange(n))
+    root[:, 7:13] = 0
+    o.t["root_states"][:] = root
+    o.t["dof_state"][..., 0] = np.asarray(setup.default_dof_pos, np.float32) + 0.3
+    o.t["dof_state"][..., 1] = 0
+    o.refresh_rigid_body_state()
+    _check_rigid_frames(o.t["rigid_body_state"].reshape(n, -1, 13).copy(), root)
+    o.close()
+
+
+@pytest.mark.gpu
+def test_hip_rigid_body_frames_follow_the_base_attitude():
+    """`quat_to_mat` / `mat_to_quat` / `axis_angle` of csrc/lg_device.h through the physics kernel: with zero gravity and
+    zero velocities one `lg_simulate` leaves the pose unchanged and refreshes `rigid_body_state`; body positions relative
+    to the base, expressed in the base frame, must not depend on the attitude, and every body quaternion must be the base
+    rotation times the attitude-independent relative rotation."""
+    from extended_legged_gym_amd.native import NativeCore
+    n = len(_attitude_cases())
+    setup, root, _ = _post_step_case(n)
+    setup.cfg.gravity[0] = setup.cfg.gravity[1] = setup.cfg.gravity[2] = 0.0
+    core = NativeCore(setup, "cuda:0")
+    core.reset_idx(torch.arange(n))
+    root[:, 7:13] = 0
+    core.t["root_states"].copy_(torch.from_numpy(root))
+    dof = core.t["dof_state"].clone()
+    dof[..., 0] = torch.tensor(setup.default_dof_pos, device="cuda") + 0.3
+    dof[..., 1] = 0
+    core.t["dof_state"].copy_(dof)
+    core.t["torques"].zero_()
+    core.simulate()
+    torch.cuda.synchronize()
+    rb = core.t["rigid_body_state"].cpu().numpy().reshape(n, -1, 13)
+    _check_rigid_frames(rb, root)
+    core.close()

@@ -38,11 +38,27 @@ def _worker(rank, world, port, out):
         env.step(3.0 * rng.normal(size=(16, 12)).astype(np.float32))
     mine = torch.from_numpy(env.t["episode_stats"].copy())
     table, totals = gather_episode_stats(mine, dist)
+    # per-env randomisation at creation: terrain from the common seed first (as LeggedRobot.create_sim does), then the
+    # shard's own draws of friction buckets, payload and initial terrain level
+    from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
+    from extended_legged_gym_amd.utils.helpers import set_seed
+    from extended_legged_gym_amd.utils.sharding import draw_env_randomisation, seed_shard_rngs
+    from extended_legged_gym_amd.utils.terrain import Terrain
+    rcfg = shard_env_cfg(AnymalCRoughCfg(), rank, world, 64)
+    rcfg.terrain.num_rows, rcfg.terrain.num_cols, rcfg.terrain.border_size = 3, 3, 5
+    set_seed(1)
+    terrain = Terrain(rcfg.terrain, 64)
+    seed_shard_rngs(1, rcfg.rng_stream_offset)
+    draws = draw_env_randomisation(rcfg, 64)
+    packed = torch.cat([draws["friction"].float(), draws["payload"].float(), draws["levels"].float(),
+                        torch.tensor([float(terrain.heightsamples.astype(np.int64).sum())])])
+    rand_all = [torch.zeros_like(packed) for _ in range(world)]
+    dist.all_gather(rand_all, packed)
     first_cmd = torch.from_numpy(env.t["commands"][0].copy())
     cmds = [torch.zeros_like(first_cmd) for _ in range(world)]
     dist.all_gather(cmds, first_cmd)
     if rank == 0:
-        out.put((table.numpy(), totals.numpy(), torch.stack(cmds).numpy()))
+        out.put((table.numpy(), totals.numpy(), torch.stack(cmds).numpy(), torch.stack(rand_all).numpy()))
     dist.barrier()
     dist.destroy_process_group()
     env.close()
@@ -55,7 +71,7 @@ def test_two_rank_gloo_shards_and_stat_allgather():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    table, totals, cmds = out.get(timeout=300)
+    table, totals, cmds, rand_all = out.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -64,6 +80,11 @@ def test_two_rank_gloo_shards_and_stat_allgather():
     assert table[0, 3] == 16 * 30 and table[1, 3] == 16 * 30 and totals[3] == 2 * 16 * 30     # env-steps per shard
     assert totals[2] >= 32                                   # every env finished >= 1 episode (the initial reset_idx)
     assert not np.allclose(cmds[0], cmds[1])                 # shards draw from different Philox streams
+    # same terrain on both ranks, different domain-randomisation samples (friction, payload, initial terrain level)
+    assert rand_all[0, -1] == rand_all[1, -1]
+    fr, pay, lv = rand_all[:, :64], rand_all[:, 64:128], rand_all[:, 128:192]
+    assert not np.allclose(fr[0], fr[1]) and not np.allclose(pay[0], pay[1]) and not np.array_equal(lv[0], lv[1])
+    assert fr.min() >= 0.5 and fr.max() <= 1.25 and pay.min() >= -5 and pay.max() <= 5
 
 
 def test_terrain_types_of_shards_tile_the_single_gpu_layout():
