@@ -31,6 +31,7 @@ struct lg_mesh {
   int64_t n_tris = 0, n_nodes = 0;
   BvhNode4* d_nodes = nullptr;
   float4* d_tris = nullptr;            // 3 float4 per triangle: v0, v1, v2 (w unused)
+  float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};   // bounding box of the mesh
   std::string err;
 };
 

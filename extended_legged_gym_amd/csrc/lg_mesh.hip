@@ -331,6 +331,7 @@ lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t
   col.emit(0);
   lg_mesh* m = new lg_mesh();
   m->device = device_id; m->n_tris = n_triangles; m->n_nodes = (int64_t)nodes4.size();
+  for (int k = 0; k < 3; ++k) { m->bmin[k] = nodes[0].bmin[k]; m->bmax[k] = nodes[0].bmax[k]; }
   if (hipMalloc((void**)&m->d_nodes, nodes4.size() * sizeof(BvhNode4)) != hipSuccess ||
       hipMalloc((void**)&m->d_tris, packed.size() * sizeof(float4)) != hipSuccess ||
       hipMemcpy(m->d_nodes, nodes4.data(), nodes4.size() * sizeof(BvhNode4), hipMemcpyHostToDevice) != hipSuccess ||

@@ -15,6 +15,9 @@
 #ifndef LG_AB
 #define LG_AB 0
 #endif
+#ifndef LG_PGS_REG
+#define LG_PGS_REG 1     // slot records a lane keeps in registers through the Gauss-Seidel sweeps (0: all from LDS)
+#endif
 #include "lg_device.h"
 #include "lg_bvh.h"
 
@@ -754,8 +757,85 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     // set-up has written in THIS launch for every lane -- any slot of the wave's mask -- not a slot nobody uses, whose LDS
     // may hold another kernel's bits (0 x NaN would poison the base velocity of the quad).
     const int idle_sl = slot_mask ? __builtin_ctz(slot_mask) : 0;
+#if LG_PGS_REG > 0
+    // One sweep step on a slot record held in REGISTERS.  The records of a lane's first PGS_REG active slots are fetched
+    // once (15 ds_read_b128 each) in front of the sweeps and stay in VGPRs through all `iters` sweeps, multipliers included:
+    // the lone main wave pays an LDS round trip per record per sweep otherwise (the sweeps are a dependent chain, nothing
+    // hides it).  Steps beyond PGS_REG take the LDS path below.  Measured (A/B in one session, physics kernel at 4096 envs):
+    // PGS_REG 1: -1.0 us; 2: +-0; 4: +2.5 us -- a wave has 256 architectural VGPRs, what lives beyond them sits in AGPRs and
+    // costs a v_accvgpr_read per use, so only the first record (most legs have one contact, the foot) pays.
+    constexpr int PGS_REG = LG_PGS_REG;
+    float regs[PGS_REG][CF_FIELDS];
+#pragma unroll
+    for (int st_ = 0; st_ < PGS_REG; ++st_) {
+      if (st_ < my_steps) {                              // wave-uniform
+        const int sl = st_ < my_count ? (int)((my_list >> (4 * st_)) & 0xfu) : idle_sl;
+        load_slot_record(cst, sl, lane, regs[st_]);
+      }
+    }
+    auto relax = [&](float* rec, const bool active) {
+      const V3 n = v3(rec[CF_N], rec[CF_N + 1], rec[CF_N + 2]), r = v3(rec[CF_R], rec[CF_R + 1], rec[CF_R + 2]);
+      const V3 jk0 = v3(rec[CF_JK0], rec[CF_JK0 + 1], rec[CF_JK0 + 2]), jk1 = v3(rec[CF_JK1], rec[CF_JK1 + 1], rec[CF_JK1 + 2]);
+      const V3 jk2 = v3(rec[CF_JK2], rec[CF_JK2 + 1], rec[CF_JK2 + 2]);
+      const float l0 = rec[CF_L0], bn = rec[CF_BN], iAnn = rec[CF_ANN];
+      const pk2 l12 = {rec[CF_L1], rec[CF_L2]}, an12 = {rec[CF_AN12], rec[CF_AN12 + 1]};
+      const pk2 b_r0 = {rec[CF_B], rec[CF_B + 1]}, b_r1 = {rec[CF_B + 2], rec[CF_B + 3]};
+      V3 vp = v3(vBp[0].x, vBp[0].y, vBp[1].x) + cross(v3(vBp[1].y, vBp[2].x, vBp[2].y), r) + vK01.x * jk0 + vK01.y * jk1 + vK2 * jk2;
+      const float u0 = dot(n, vp);
+      pk2 u12 = pk_splat(vp.x) * (pk2){rec[CF_T12], rec[CF_T12 + 1]};
+      u12 = pk_fma(pk_splat(vp.y), (pk2){rec[CF_T12 + 2], rec[CF_T12 + 3]}, u12);
+      u12 = pk_fma(pk_splat(vp.z), (pk2){rec[CF_T12 + 4], rec[CF_T12 + 5]}, u12);
+      const float ln = fmaxf(l0 - (u0 - bn) * iAnn, 0.f);
+      const float dn = ln - l0;
+      const pk2 w12 = pk_fma(an12, pk_splat(dn), u12);
+      pk2 t12 = b_r0 * pk_splat(w12.x);
+      t12 = pk_fma(b_r1, pk_splat(w12.y), t12);
+      pk2 n12 = l12 - t12;
+      const float lim = mu * ln, m2 = n12.x * n12.x + n12.y * n12.y;
+      if (m2 > lim * lim) { const float sc = m2 > 0.f ? lim * __builtin_amdgcn_rsqf(m2) : 0.f; n12 = n12 * pk_splat(sc); }
+      const float d0 = active ? dn : 0.f;
+      pk2 d12 = n12 - l12;
+      d12.x = active ? d12.x : 0.f; d12.y = active ? d12.y : 0.f;
+      rec[CF_L0] = active ? ln : l0; rec[CF_L1] = active ? n12.x : l12.x; rec[CF_L2] = active ? n12.y : l12.y;
+      pk2 g[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        pk2 acc = pk_splat(d0) * (pk2){rec[CF_WB + 2 * p], rec[CF_WB + 2 * p + 1]};
+        acc = pk_fma(pk_splat(d12.x), (pk2){rec[CF_WB + 6 + 2 * p], rec[CF_WB + 6 + 2 * p + 1]}, acc);
+        acc = pk_fma(pk_splat(d12.y), (pk2){rec[CF_WB + 12 + 2 * p], rec[CF_WB + 12 + 2 * p + 1]}, acc);
+        g[p].x = quad_sum(acc.x); g[p].y = quad_sum(acc.y);
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) vBp[p] = vBp[p] + g[p];
+      pk2 w01 = pk_splat(d0) * (pk2){rec[CF_ZCP], rec[CF_ZCP + 1]};
+      w01 = pk_fma(pk_splat(d12.x), (pk2){rec[CF_ZCP + 2], rec[CF_ZCP + 3]}, w01);
+      w01 = pk_fma(pk_splat(d12.y), (pk2){rec[CF_ZCP + 4], rec[CF_ZCP + 5]}, w01);
+      float w2 = d0 * rec[CF_ZC2] + d12.x * rec[CF_ZC2 + 1] + d12.y * rec[CF_ZC2 + 2];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const float ga = (a & 1) ? g[a >> 1].y : g[a >> 1].x;
+        w01 = pk_fma(-Y01[a], pk_splat(ga), w01);
+        w2 -= Y[2][a] * ga;
+      }
+      vK01 = vK01 + w01; vK2 += w2;
+    };
+#endif
 #pragma unroll 1
     for (int it = 0; it < P.iters; ++it) {
+#if LG_PGS_REG > 0
+#pragma unroll
+      for (int st_ = 0; st_ < PGS_REG; ++st_)
+        if (st_ < my_steps) relax(regs[st_], st_ < my_count);
+#pragma unroll 1
+      for (int step = PGS_REG; step < my_steps; ++step) {
+        const bool active = step < my_count;
+        const int sl = active ? (int)((my_list >> (4 * step)) & 0xfu) : idle_sl;
+        float rec[CF_FIELDS];
+        load_slot_record(cst, sl, lane, rec);
+        relax(rec, active);
+        *reinterpret_cast<float4*>(&CS(sl, CF_L0)) = make_float4(rec[CF_L0], rec[CF_ANN], rec[CF_L1], rec[CF_L2]);
+      }
+#else
       // every lane walks the list of its own active slots; step j relaxes the j-th active contact of each of the four
       // legs together (Jacobi across the quad, Gauss-Seidel along the lists).  A sweep takes max-over-lanes(list length)
       // steps -- measured 2.3 on the headline workload against 3.0 slots that are active somewhere in the wave.
@@ -818,6 +898,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
           vK01 = vK01 + w01; vK2 += w2;
         }
       }
+#endif
       if (jl_wave) {
         float vBs[6] = {vBp[0].x, vBp[0].y, vBp[1].x, vBp[1].y, vBp[2].x, vBp[2].y}, vKs[3] = {vK01.x, vK01.y, vK2};
 #pragma unroll
@@ -844,6 +925,15 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
         vK01.x = vKs[0]; vK01.y = vKs[1]; vK2 = vKs[2];
       }
     }
+#if LG_PGS_REG > 0
+#pragma unroll
+    for (int st_ = 0; st_ < LG_PGS_REG; ++st_) {
+      if (st_ < my_steps && st_ < my_count) {            // (an idle lane has nothing to store: its record was only read)
+        const int sl = (int)((my_list >> (4 * st_)) & 0xfu);
+        *reinterpret_cast<float4*>(&CS(sl, CF_L0)) = make_float4(regs[st_][CF_L0], regs[st_][CF_ANN], regs[st_][CF_L1], regs[st_][CF_L2]);
+      }
+    }
+#endif
 #pragma unroll
     for (int p = 0; p < 3; ++p) { vB[2 * p] = vBp[p].x; vB[2 * p + 1] = vBp[p].y; }
     vK[0] = vK01.x; vK[1] = vK01.y; vK[2] = vK2;

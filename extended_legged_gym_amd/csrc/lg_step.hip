@@ -22,6 +22,7 @@
 
 #include "lg_physics.h"
 
+#define LG_MESH_OOB_MARGIN 1.0f   // metres beyond the collision mesh's bounding box before an env counts as lost
 #define EPB 16          // envs per workgroup (= per main wave) in physics_kernel
 #define EPBP 4          // envs per 256-thread workgroup in post_kernel (a wave per env in the wide stages, 16 lanes per env in the narrow ones); 4 workgroups per CU at N = 4096
 #define MAX_P 192       // height-scan points per env held in LDS
@@ -54,9 +55,13 @@ struct DevCtx {
   unsigned* part_flag; // [nblocks] : 1 when some env of the workgroup was reset in this step (its partials row is valid)
   long long* acc;      // [PART_STRIDE] fixed-point (x 2^24) sums of the reset envs' rows of one post-kernel launch
   unsigned* tickets;   // 9 counters, one per 128-B line: per-shard arrivals of the post kernel's workgroups + the shards' own
+  float mesh_lo[3], mesh_hi[3];   // bounding box of the collision mesh (LG_MESH_TRIMESH): a base that leaves it by more than LG_MESH_OOB_MARGIN ends the episode
   float* mesh_cache;   // [N][4 legs][LG_MAX_CP][4]: last closest-point query of every collision sphere (mesh terrains)
   float lstm_w[912];   // actuator network weights, gate-interleaved (pack_lstm_weights): read with scalar loads
   int nblocks_post;
+  // reward-term bookkeeping of the post kernel, derived from cfg.reward_term_ids on the host (reward_meta): a walk over the
+  // term list in the kernel is one dependent scalar load per term on the narrow-stage chain
+  unsigned rew_term_mask; int rew_kfat, rew_kterm; float rew_term_scale;
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
   unsigned long long* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
 };
@@ -79,6 +84,17 @@ struct lg_ctx {
 };
 
 static thread_local std::string g_err;
+
+static void reward_meta(DevCtx& h) {
+  const lg_config& g = h.cfg;
+  h.rew_term_mask = 0; h.rew_kfat = g.num_reward_terms; h.rew_kterm = -1; h.rew_term_scale = 0.f;
+  for (int k = 0; k < g.num_reward_terms; ++k) {
+    const int id = g.reward_term_ids[k];
+    h.rew_term_mask |= 1u << id;
+    if (id == LG_REW_FEET_AIR_TIME) h.rew_kfat = k;       // position of feet_air_time in the evaluation order (K = absent)
+    if (id == LG_REW_TERMINATION) { h.rew_kterm = k; h.rew_term_scale = g.reward_scales[k]; }   // added after the clip, LR:226-232
+  }
+}
 
 // ============================================================================================ device: RNG
 LG_DEV float uniform_draw(const DevCtx* __restrict__ C, int e, int slot, int64_t step, uint32_t stream) {
@@ -648,6 +664,14 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     for (int i = 0; i < 13; ++i) acc += s.root[i] * 0.f;
 #pragma unroll
     for (int i = 7; i < 13; ++i) acc += fabsf(s.root[i]) < 1e3f ? 0.f : 1.f;   // finite but diverged (> 1 km/s, > 1000 rad/s)
+    if (TMESH) {
+      // a base that has left the collision mesh (walked off its edge, or got through a surface and is in free fall below it)
+      // can never come back: same treatment as a fault -- back to the pre-step pose at rest, episode terminated.  PhysX has
+      // no such rule (its bodies fall forever); the reference's tasks never leave their terrain because it is bordered.
+      acc += (s.root[0] < C->mesh_lo[0] - LG_MESH_OOB_MARGIN || s.root[0] > C->mesh_hi[0] + LG_MESH_OOB_MARGIN ||
+              s.root[1] < C->mesh_lo[1] - LG_MESH_OOB_MARGIN || s.root[1] > C->mesh_hi[1] + LG_MESH_OOB_MARGIN ||
+              s.root[2] < C->mesh_lo[2] - LG_MESH_OOB_MARGIN) ? 1.f : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { acc += s.q[j] * 0.f + s.qd[j] * 0.f; acc0 += q0[j] * 0.f; }
 #pragma unroll
@@ -1274,15 +1298,8 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   //   (2.3) reward terms in config order, episode sums, reset;
   //   (2.4) proprioceptive observation entries, gait phase.
   static_assert(EPBP * 16 == 64 && F_COUNT <= 8, "phase 2: sixteen lanes per env on one wave");
-  unsigned term_mask = 0;                       // which reward terms are switched on (wave-uniform)
-  int kfat = g.num_reward_terms;                // position of feet_air_time in the evaluation order (K = absent)
-  int kterm = -1; float term_scale = 0.f;       // position and scale of the termination term (added after the clip, LR:226-232)
-  for (int k = 0; k < g.num_reward_terms; ++k) {
-    const int id = g.reward_term_ids[k];
-    term_mask |= 1u << id;
-    if (id == LG_REW_FEET_AIR_TIME) kfat = k;
-    if (id == LG_REW_TERMINATION) { kterm = k; term_scale = g.reward_scales[k]; }
-  }
+  const unsigned term_mask = C->rew_term_mask;  // which reward terms are switched on (wave-uniform)
+  const int kfat = C->rew_kfat, kterm = C->rew_kterm; const float term_scale = C->rew_term_scale;   // see reward_meta()
   {
     const bool mine = FUSED || wv == (int)((blockIdx.x >> 8) & 3u);   // (workgroups 256 apart share a CU when all 1024 are resident)
     const int el = ln >> 4, sl = ln & 15;                   // env of the workgroup, lane within the env (shadow the wave-per-env names)
@@ -1746,6 +1763,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.N = cfg->num_envs; h.B = model->num_bodies; h.K = cfg->num_reward_terms; h.P = cfg->num_height_points;
   h.per_leg = 3 + model->has_foot_body;
   pack_lstm_weights(h.lstm_w, cfg->actuator_net);
+  reward_meta(h);
   h.mesh_cache = nullptr;
   if (ter->mesh_type == LG_MESH_TRIMESH) {
     const size_t nf = (size_t)cfg->num_envs * 4 * LG_MAX_CP * 4;
@@ -1777,6 +1795,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   if (ter->mesh_type == LG_MESH_TRIMESH) {
     if (ter->collision_mesh->device != device_id) return fail("collision mesh lives on another device");
     h.ter.M = MeshView{ter->collision_mesh->d_nodes, ter->collision_mesh->d_tris};
+    for (int k = 0; k < 3; ++k) { h.mesh_lo[k] = ter->collision_mesh->bmin[k]; h.mesh_hi[k] = ter->collision_mesh->bmax[k]; }
   }
   h.nblocks_post = (h.N + EPBP - 1) / EPBP;
   h.n_stepped = h.N;
@@ -1905,6 +1924,8 @@ int lg_set_reward_terms(lg_ctx* c, int32_t num_terms, const int32_t* term_ids, c
   char* base = (char*)&c->h; char* lo = (char*)&g.num_reward_terms; char* hi = (char*)&g.reward_scales[LG_MAX_REWARD_TERMS];
   HIP_TRY(c, hipMemcpyAsync((char*)c->d + (lo - base), lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpyAsync((char*)c->d + ((char*)&c->h.K - base), &c->h.K, sizeof(int), hipMemcpyHostToDevice, st));
+  reward_meta(c->h);
+  HIP_TRY(c, hipMemcpyAsync((char*)c->d + ((char*)&c->h.rew_term_mask - base), &c->h.rew_term_mask, 4 * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemsetAsync(c->h.ep_sums, 0, (size_t)LG_MAX_REWARD_TERMS * c->h.N * sizeof(float), st));
   return LG_OK;
 }

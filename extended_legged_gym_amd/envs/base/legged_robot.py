@@ -206,10 +206,20 @@ class LeggedRobot(BaseTask):
             xy = torch.rand(b, 2, device=self.device) * torch.tensor([x1 - x0, y1 - y0], device=self.device) \
                 + torch.tensor([x0, y0], device=self.device)
             attempts += b
-            ground = torch.from_numpy(self.terrain.get_heights_batch(xy.cpu(), max_height=20.0, cast_dir=1)).to(self.device)
-            ceil = torch.from_numpy(self.terrain.get_heights_batch(xy.cpu(), max_height=20.0, cast_dir=-1)).to(self.device)
-            clearance = ceil - ground
-            ok = (clearance > need) | (clearance < 1e-6)
+            # the reference probes the single point (x, y); here the probe covers the robot's footprint (`origin_footprint`,
+            # half extents in m, default 0.35 x 0.25): the origin's height is the HIGHEST ground under it and the clearance the
+            # lowest ceiling above it, so that no foot or hip is spawned inside a pile, a wall or the slab next to the sampled
+            # point (a PhysX body spawned in penetration is pushed out; a sphere deeper than the contact margin here is lost)
+            fx, fy = getattr(tc, "origin_footprint", [0.35, 0.25])
+            lin = torch.linspace(-1.0, 1.0, 5, device=self.device)
+            offs = torch.stack(torch.meshgrid(fx * lin, fy * lin, indexing="ij"), -1).reshape(-1, 2)      # 5 x 5 probe grid, centre included
+            pts = (xy[:, None, :] + offs[None, :, :]).reshape(-1, 2)
+            g_all = torch.from_numpy(self.terrain.get_heights_batch(pts.cpu(), max_height=20.0, cast_dir=1)).to(self.device).view(b, -1)
+            c_all = torch.from_numpy(self.terrain.get_heights_batch(pts.cpu(), max_height=20.0, cast_dir=-1)).to(self.device).view(b, -1)
+            ground = g_all.max(dim=1).values
+            # per probe: a single layer there (the ray from above meets the same surface as the ray from below), or enough
+            # room between the highest ground of the footprint and the ceiling over this probe
+            ok = ((c_all - g_all < 1e-6) | (c_all - ground[:, None] > need)).all(dim=1)
             sel = torch.cat([xy[ok], ground[ok].unsqueeze(1).to(xy.dtype)], 1)
             kept.append(sel)
             n_kept += sel.shape[0]

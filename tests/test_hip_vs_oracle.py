@@ -78,29 +78,30 @@ TOL_SAME_CONTACTS_BY_NAME = {"contact_forces": 0.25}   # ... except the multipli
 REPORT = []
 
 
-def compare(core, o, names, frac_ok=0.995, tol=2e-3, med=2e-5):
+def compare(core, o, names, frac_ok=0.995, tol=2e-3, med=2e-5, rows=None):
     """The bar of the module docstring, made explicit about its outliers: envs in which a contact within rounding of its
-    activation threshold is on in one implementation and off in the other are COUNTED (at most 3 % of the envs) and are
-    the only place an entry may be far off; everywhere else every entry is within 5e-2 * max(1, |x|), 99.5 % of the entries
-    of each tensor within 2e-3 and the median within 2e-5."""
+    activation threshold is on in one implementation and off in the other (different bodies loaded in the last substep) are
+    COUNTED -- at most 3 % of the envs -- and left out of the entry-wise bar; in every other env every entry is within
+    5e-2 * max(1, |x|), 99.5 % of the entries of each tensor within 2e-3 and the median within 2e-5."""
     torch.cuda.synchronize()
     n = int(core.t["root_states"].shape[0])
-    differ = (contact_pattern(core.t["contact_forces"].detach().cpu().numpy(), n) != contact_pattern(o.t["contact_forces"], n)).any(1)
-    assert differ.mean() <= MAX_DIFFERENT_CONTACT_ENVS, f"{differ.sum()} of {n} envs load different bodies"
+    rows = np.ones(n, bool) if rows is None else np.asarray(rows, bool)      # envs to compare (callers exclude envs whose reset decision differs)
+    differ = (contact_pattern(core.t["contact_forces"].detach().cpu().numpy(), n) != contact_pattern(o.t["contact_forces"], n)).any(1)[rows]
+    assert differ.mean() <= MAX_DIFFERENT_CONTACT_ENVS, f"{differ.sum()} of {rows.sum()} envs load different bodies"
     worst = {}
     for name in names:
-        a = env_rows(name, core.t[name].detach().cpu().numpy(), n)
-        b = env_rows(name, o.t[name], n)
+        a = env_rows(name, core.t[name].detach().cpu().numpy(), n)[rows]
+        b = env_rows(name, o.t[name], n)[rows]
         err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
         assert np.isfinite(a).all(), f"{name}: non-finite values on the GPU"
-        ok = (err <= tol).mean()
-        same = err[~differ]
-        worst[name] = (float(np.median(err)), float(same.max()) if same.size else 0.0, float(err.max()), float(ok))
-        assert ok >= frac_ok, f"{name}: only {ok:.4f} of entries within {tol} (max {err.max():.3g})"
-        assert np.median(err) <= med, f"{name}: median error {np.median(err):.3g}"
+        same = err[~differ]                     # the bar applies to the envs whose contact sets agree; the others are counted above
+        ok = (same <= tol).mean() if same.size else 1.0
+        worst[name] = (float(np.median(same)) if same.size else 0.0, float(same.max()) if same.size else 0.0, float(err.max()), float(ok))
+        assert ok >= frac_ok, f"{name}: only {ok:.4f} of entries within {tol} (max {same.max():.3g})"
+        assert same.size == 0 or np.median(same) <= med, f"{name}: median error {np.median(same):.3g}"
         assert same.size == 0 or same.max() <= TOL_SAME_CONTACTS_BY_NAME.get(name, TOL_SAME_CONTACTS), \
-            f"{name}: error {same.max():.3g} in env {int(np.argmax(err.max(1) * ~differ))} whose contact set agrees"
-    REPORT.append(dict(envs=n, envs_with_different_contacts=int(differ.sum()),
+            f"{name}: error {same.max():.3g} in an env whose contact set agrees"
+    REPORT.append(dict(envs=int(rows.sum()), envs_with_different_contacts=int(differ.sum()),
                        max_err_same_contacts=max(v[1] for v in worst.values()), max_err_any=max(v[2] for v in worst.values())))
     return worst
 
