@@ -7,6 +7,19 @@
 
 #define LG_DEV __device__ __forceinline__
 
+// Host side: every ABI entry point runs on the device its context / mesh / network lives on, whatever device is current in
+// the calling thread (an env on cuda:1 driven from a thread whose current device is cuda:0), and leaves the caller's current
+// device as it found it.
+struct DeviceScope {
+  int prev = -1; bool ok = true;
+  explicit DeviceScope(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; }
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete; DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 struct V3 { float x, y, z; };
 LG_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 LG_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }

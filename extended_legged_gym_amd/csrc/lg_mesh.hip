@@ -299,7 +299,7 @@ const char* lg_mesh_last_error(lg_mesh* m) { return m ? m->err.c_str() : g_mesh_
 
 void lg_mesh_destroy(lg_mesh* m) {
   if (!m) return;
-  (void)hipSetDevice(m->device);
+  DeviceScope ds_(m->device);
   if (m->d_nodes) (void)hipFree(m->d_nodes);
   if (m->d_tris) (void)hipFree(m->d_tris);
   delete m;
@@ -309,7 +309,9 @@ lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t
   if (!vertices || !triangles || n_vertices <= 0 || n_triangles <= 0) { g_mesh_err = "empty mesh"; return nullptr; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_mesh_err = "no HIP device: mesh queries have no CPU path"; return nullptr; }
-  if (device_id < 0 || device_id >= ndev || hipSetDevice(device_id) != hipSuccess) { g_mesh_err = "bad device"; return nullptr; }
+  if (device_id < 0 || device_id >= ndev) { g_mesh_err = "bad device"; return nullptr; }
+  DeviceScope ds_(device_id);
+  if (!ds_.ok) { g_mesh_err = "bad device"; return nullptr; }
   std::vector<BuildTri> t((size_t)n_triangles);
   for (int64_t i = 0; i < n_triangles; ++i) {
     for (int v = 0; v < 3; ++v) {
@@ -347,6 +349,7 @@ int lg_mesh_info(lg_mesh* m, int64_t out[2]) { if (!m) return LG_ERR_INVALID; ou
 
 int lg_raycast_mesh(lg_mesh* m, const float* origins, const float* dirs, int64_t n_rays, float max_dist, float* hits, uint8_t* found, void* stream) {
   if (!m || !origins || !dirs || !hits || !found || n_rays < 0) return LG_ERR_INVALID;
+  DeviceScope ds_(m->device);
   if (n_rays == 0) return LG_OK;
   MeshView M{m->d_nodes, m->d_tris};
   hipLaunchKernelGGL(raycast_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, origins, dirs, n_rays, max_dist, hits, found);
@@ -356,6 +359,7 @@ int lg_raycast_mesh(lg_mesh* m, const float* origins, const float* dirs, int64_t
 
 int lg_mesh_query_sdf(lg_mesh* m, const float* points, int64_t n, float max_dist, float* sdf, float* grad, void* stream) {
   if (!m || !points || !sdf || !grad || n < 0) return LG_ERR_INVALID;
+  DeviceScope ds_(m->device);
   if (n == 0) return LG_OK;
   MeshView M{m->d_nodes, m->d_tris};
   hipLaunchKernelGGL(sdf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, points, n, max_dist, sdf, grad);
@@ -369,6 +373,7 @@ int lg_raycaster_update_subset(lg_mesh* m, const float* root_states, const float
   if (!m || !root_states || !ray_origins || !ray_dirs || !ray_hits || !hits_found || !raycast_distances || n <= 0 || num_rays <= 0 ||
       distance_stride < num_rays)
     return LG_ERR_INVALID;
+  DeviceScope ds_(m->device);
   MeshView M{m->d_nodes, m->d_tris};
   int64_t tot = (int64_t)n * num_rays;
   hipLaunchKernelGGL(raycaster_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, root_states, ray_origins,
@@ -390,6 +395,7 @@ int lg_sdf_bodies_update(lg_mesh* m, const float* rigid_body_state, int32_t num_
   if (!m || !rigid_body_state || !body_indices || !sdf_values || num_bodies <= 0 || num_query_bodies <= 0 || n <= 0 ||
       sdf_stride < num_query_bodies)
     return LG_ERR_INVALID;
+  DeviceScope ds_(m->device);
   MeshView M{m->d_nodes, m->d_tris};
   int64_t tot = (int64_t)n * num_query_bodies;
   hipLaunchKernelGGL(sdf_bodies_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, rigid_body_state, num_bodies,
@@ -402,6 +408,7 @@ int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* ro
                            int32_t num_envs, const float* env_noise, float* camera_pos, float* camera_rot, float* depth_buffer, void* stream) {
   if (!m || !p || !root_states || !ray_dirs || !episode_length_buf || !camera_pos || !camera_rot || !depth_buffer || num_envs <= 0)
     return LG_ERR_INVALID;
+  DeviceScope ds_(m->device);
   if (p->width <= 0 || p->height <= 0 || p->resized_width <= 0 || p->resized_height <= 0 || p->buffer_len <= 0) return LG_ERR_INVALID;
   size_t lds = (size_t)p->width * p->height * sizeof(float);
   if (lds > 64 * 1024) { m->err = "depth image too large for the LDS-staged resize"; return LG_ERR_UNSUPPORTED; }

@@ -227,7 +227,7 @@ const char* lg_mlp_last_error(lg_mlp* m) { return m ? m->err.c_str() : g_pol_err
 
 void lg_mlp_destroy(lg_mlp* m) {
   if (!m) return;
-  (void)hipSetDevice(m->device);
+  DeviceScope ds_(m->device);
   for (void* p : m->allocs) (void)hipFree(p);
   delete m;
 }
@@ -240,7 +240,9 @@ lg_mlp* lg_mlp_create(int32_t L, const int32_t* dims, const float* const* weight
   if (dims[L] > 32) { /* fine for lg_mlp_forward; lg_policy_act checks its own limit */ }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_pol_err = "no HIP device: the policy kernels have no CPU path"; return nullptr; }
-  if (device_id < 0 || device_id >= ndev || hipSetDevice(device_id) != hipSuccess) { g_pol_err = "bad device"; return nullptr; }
+  if (device_id < 0 || device_id >= ndev) { g_pol_err = "bad device"; return nullptr; }
+  DeviceScope ds_(device_id);
+  if (!ds_.ok) { g_pol_err = "bad device"; return nullptr; }
   lg_mlp* m = new lg_mlp();
   m->device = device_id; m->h.L = L; m->h.act = activation;
   for (int l = 0; l <= L; ++l) m->h.dims[l] = dims[l];
@@ -276,6 +278,7 @@ lg_mlp* lg_mlp_create(int32_t L, const int32_t* dims, const float* const* weight
 
 int lg_mlp_forward(lg_mlp* m, const float* x, int64_t n, float* y, void* stream) {
   if (!m || !x || !y || n < 0) return LG_ERR_INVALID;
+  DeviceScope ds_(m->device);
   if (n == 0) return LG_OK;
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS)), dim3(256), 0, (hipStream_t)stream, m->h, x, n, y);
   POL_TRY(m, hipGetLastError());
@@ -285,6 +288,7 @@ int lg_mlp_forward(lg_mlp* m, const float* x, int64_t n, float* y, void* stream)
 int lg_policy_act(lg_mlp* actor, lg_mlp* critic, const float* obs, const float* critic_obs, int64_t n, const float* std_, uint64_t seed,
                   uint64_t call, int32_t deterministic, float* actions, float* action_mean, float* logp, float* values, void* stream) {
   if (!actor || !critic || !obs || !critic_obs || !std_ || !actions || !action_mean || !logp || !values || n < 0) return LG_ERR_INVALID;
+  DeviceScope ds_(actor->device);
   if (actor->h.dims[actor->h.L] > 32) { actor->err = "lg_policy_act supports up to 32 actions"; return LG_ERR_UNSUPPORTED; }
   if (n == 0) return LG_OK;
   hipLaunchKernelGGL(policy_act_kernel, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS), 2), dim3(256), 0, (hipStream_t)stream, actor->h, critic->h,
@@ -297,6 +301,9 @@ int lg_policy_act(lg_mlp* actor, lg_mlp* critic, const float* obs, const float* 
 int lg_compute_returns(const float* rewards, const float* dones, const float* values, const float* last_values, int32_t T, int64_t n,
                        float gamma, float lam, int32_t normalize, float* returns, float* advantages, void* stream) {
   if (!rewards || !dones || !values || !last_values || !returns || !advantages || T <= 0 || n <= 0) return LG_ERR_INVALID;
+  hipPointerAttribute_t pa;                        // no context in this call: run where the rows live
+  if (hipPointerGetAttributes(&pa, rewards) != hipSuccess) return LG_ERR_INVALID;
+  DeviceScope ds_(pa.device);
   hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, dones, values, last_values, T, n,
                      gamma, lam, returns, advantages);
   if (normalize) hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, advantages, (int64_t)T * n);
@@ -316,6 +323,7 @@ extern "C" int lg_step_transition(lg_ctx* ctx, const float* actions, float* next
 int lg_collect_rollout(lg_ctx* env, lg_mlp* actor, lg_mlp* critic, const float* std, uint64_t seed, uint64_t first_call, int32_t T,
                        float gamma, float lam, int32_t normalize_advantage, const lg_rollout* out, void* stream) {
   if (!env || !actor || !critic || !std || !out || T <= 0) return LG_ERR_INVALID;
+  DeviceScope ds_(actor->device);
   if (!out->observations || !out->actions || !out->rewards || !out->dones || !out->values || !out->actions_log_prob || !out->mu ||
       !out->sigma || !out->last_values) { actor->err = "lg_collect_rollout: null output row"; return LG_ERR_INVALID; }
   void* p; int64_t shp[4]; int32_t nd, dt;

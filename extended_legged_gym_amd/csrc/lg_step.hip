@@ -63,6 +63,7 @@ struct DevCtx {
   // term list in the kernel is one dependent scalar load per term on the narrow-stage chain
   unsigned rew_term_mask; int rew_kfat, rew_kterm; float rew_term_scale;
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
+  float lvl_total_before;       // subset steps with a terrain curriculum: sum of ALL terrain levels before the launch (level_total_kernel)
   unsigned long long* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
 };
 
@@ -1066,13 +1067,17 @@ LG_DEV void finalize_step(const DevCtx* __restrict__ C, int nblocks, int bump, i
 // added their rows to 64-bit fixed-point accumulators (integer atomics: the sum does not depend on arrival order), so
 // this is one round trip (the accumulators and the per-workgroup level sums together) instead of a list walk.
 #define ACC_SCALE 16777216.0
-LG_DEV void finalize_from_acc(const DevCtx* __restrict__ C, int nblocks, int bump, int tid) {
+LG_DEV void finalize_from_acc(const DevCtx* __restrict__ C, int nblocks, int bump, int tid, bool subset) {
   const int K = C->cfg.num_reward_terms, KP = K + 3;
   __shared__ float tot[PART_STRIDE];
   __shared__ float f_lvl[256];
   if (bump == 2) { if (tid == 0) C->counters[3] += 1; return; }
   float lvl_acc = 0.f;
   if (C->cfg.curriculum != 0) for (int b = tid; b < nblocks; b += 256) lvl_acc += ld_dev(C->lvl_part + b);
+  if (C->cfg.curriculum != 0 && subset) {
+    for (int b = tid; b < nblocks; b += 256) lvl_acc -= ld_dev(reinterpret_cast<const float*>(C->part_flag) + b);
+    if (tid == 0) lvl_acc += C->lvl_total_before;
+  }
   if (tid < PART_STRIDE) {
     long long a = 0;
     if (tid < KP) {
@@ -1106,6 +1111,7 @@ struct alignas(16) PostLds {
   float s_old[EPBP][8];
   float s_rootz[EPBP], s_bh[EPBP];
   float s_level[EPBP];               // terrain level at the start of the step (re-read after a reset)
+  float s_level0[EPBP];              // ... and a copy that stays (subset steps: the finisher needs the sum before and after)
   int s_e[EPBP];
   uint8_t s_lastc[EPBP][4], s_oldc[EPBP][4];
   uint8_t s_flag[EPBP], s_did_reset[EPBP], s_root_dirty[EPBP], s_term[EPBP], s_tout[EPBP];
@@ -1278,7 +1284,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
     STV(11, S_AIR, 4) STV(12, S_CT, 4) STV(13, S_GAIT, 1)
     if (hv_[q] && ln < g.num_reward_terms) S[S_SUMS + ln] = v_sum[q];
     if (hv_[q] && ln < 4) L.s_lastc[el][ln] = v_lc[q];
-    if (hv_[q] && ln == 0) { L.s_eplen[el] = v_len[q]; L.s_flag[el] = v_flag[q]; L.s_level[el] = (float)v_lvl[q]; }
+    if (hv_[q] && ln == 0) { L.s_eplen[el] = v_len[q]; L.s_flag[el] = v_flag[q]; L.s_level[el] = (float)v_lvl[q]; L.s_level0[el] = (float)v_lvl[q]; }
   }
 #undef LDV
 #undef STV
@@ -1533,6 +1539,11 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
     float sacc = 0.f;
     for (int el2 = 0; el2 < nenv; ++el2) sacc += L.s_part[el2][g.num_reward_terms + 1];
     st_dev(C->lvl_part + inst, sacc);
+    if (ids) {      // subset step: the mean level is over ALL envs (LR:205-206, robot_batch_rollout.py:932) = total before - ours before + ours after
+      float s0 = 0.f;
+      for (int el2 = 0; el2 < nenv; ++el2) s0 += L.s_level0[el2];
+      st_dev(reinterpret_cast<float*>(C->part_flag) + inst, s0);       // (the flag rows are only used by lg_reset_idx's finalize_kernel)
+    }
   }
   // ---- arrival: the last workgroup to arrive finishes the step (statistics, extras, counters).  Arrivals are counted per
   // shard (blockIdx & 7: eight counters on eight cache lines, ~1/8 of the contention of one), the shard that fills up
@@ -1600,7 +1611,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
     s_last = last;
   }
   __syncthreads();
-  if (s_last) finalize_from_acc(C, ninst, mode == 0 ? 1 : 2, tid);
+  if (s_last) finalize_from_acc(C, ninst, mode == 0 ? 1 : 2, tid, ids != nullptr);
 }
 
 __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int mode,
@@ -1611,6 +1622,41 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
 
 __global__ __launch_bounds__(256) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step, int use_flags) {
   finalize_step(C, nblocks, bump_step, threadIdx.x, use_flags != 0);
+}
+
+// lg_set_state_indexed: one quad per listed env (lane = leg): rows of the caller's full tensors -> simulation state, then the
+// rigid-body rows of the new pose
+__global__ __launch_bounds__(64) void set_state_kernel(const DevCtx* __restrict__ C, const float* __restrict__ root_src, const float* __restrict__ dof_src,
+                                                       const int32_t* __restrict__ ids, int n) {
+  __shared__ float lmod[LM_FIELDS * 4];
+  const int lane = threadIdx.x, l = lane & 3;
+  fill_leg_model(lmod, &C->model, &C->cfg, lane);
+  lds_barrier();
+  const int kq = blockIdx.x * 16 + (lane >> 2);
+  if (kq >= n) return;
+  const int e = ids[kq];
+  if (e < 0 || e >= C->N) return;
+  const LegModel lm_{lmod, l};
+  const float* rs = (root_src ? root_src : C->root) + (size_t)e * 13;
+  const float* ds = (dof_src ? dof_src : C->dof) + ((size_t)e * 12 + 3 * l) * 2;
+  float r13[13], q[3], qd[3];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) r13[i] = rs[i];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { q[j] = ds[2 * j]; qd[j] = ds[2 * j + 1]; }
+  if (root_src && root_src != C->root && l == 0) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) C->root[(size_t)e * 13 + i] = r13[i];
+  }
+  if (dof_src && dof_src != C->dof) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { C->dof[((size_t)e * 12 + 3 * l + j) * 2] = q[j]; C->dof[((size_t)e * 12 + 3 * l + j) * 2 + 1] = qd[j]; }
+  }
+  write_rigid_body_state(C, lm_, e, l, r13, q, qd);
+  const int B = C->B, per_leg = C->per_leg;
+  float* cf = C->cforce + (size_t)e * B * 3;
+  if (l == 0) { cf[0] = 0.f; cf[1] = 0.f; cf[2] = 0.f; }
+  for (int i = 0; i < per_leg * 3; ++i) cf[(1 + per_leg * l) * 3 + i] = 0.f;
 }
 
 // lg_reset_idx: one workgroup, loops over the id list; statistics summed in list order
@@ -1733,7 +1779,7 @@ int lg_debug_read_stamps(lg_ctx* c, unsigned long long out[32]) {
 
 void lg_destroy(lg_ctx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  DeviceScope ds_(c->device);
   if (c->d) (void)hipFree(c->d);
   if (c->aux) (void)hipFree(c->aux);
   if (c->mesh_cache) (void)hipFree(c->mesh_cache);
@@ -1747,7 +1793,8 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device: the env step has no CPU path"; return nullptr; }
   if (device_id < 0 || device_id >= ndev) { g_err = "device_id out of range"; return nullptr; }
-  if (hipSetDevice(device_id) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+  DeviceScope ds_(device_id);                      // (restores the caller's current device on every return path)
+  if (!ds_.ok) { g_err = "hipSetDevice failed"; return nullptr; }
   lg_ctx* c = new lg_ctx();
   c->device = device_id;
   c->arena_bytes = build_layout(cfg, model, ter, c->t);
@@ -1853,10 +1900,22 @@ int lg_get_tensor(lg_ctx* c, int id, void** dptr, int64_t shape[4], int32_t* ndi
 }
 
 __global__ void set_n_stepped(DevCtx* C, int n) { C->n_stepped = n; }
+// sum of all terrain levels before a subset step (exact in float up to 2^24)
+__global__ __launch_bounds__(256) void level_total_kernel(DevCtx* C) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int e = threadIdx.x; e < C->N; e += 256) s += (float)C->levels[e];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) C->lvl_total_before = red[0];
+}
 
 static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t* ids, int n, int mode, float* rew_out = nullptr, int rew_stride = 0,
                        PostSink sink = PostSink{nullptr, nullptr, nullptr, nullptr, 0.f}) {
   const int nb = (n + EPBP - 1) / EPBP;
+  if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }   // (a post step without its physics launch)
+  if (ids && mode == 0 && c->h.cfg.curriculum) hipLaunchKernelGGL(level_total_kernel, dim3(1), dim3(256), 0, st, c->d);
   hipLaunchKernelGGL(post_kernel, dim3(nb), dim3(256), 0, st, c->d, ids, n, mode, rew_out, rew_stride, sink);
   if (ev) (void)hipEventRecord(ev[2], st);
   if (ev) (void)hipEventRecord(ev[3], st);
@@ -1880,6 +1939,7 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
 
 int lg_step(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   if (!actions) { c->err = "actions is null"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t* ev = nullptr;
@@ -1898,6 +1958,7 @@ int lg_step(lg_ctx* c, const float* actions, void* stream) {
 int lg_step_transition(lg_ctx* c, const float* actions, float* next_observations, const float* values, float gamma, float* rewards,
                        float* dones, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   if (!actions || !values || !rewards || !dones) { c->err = "lg_step_transition: null row"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   launch_physics(c, st, actions, nullptr, c->h.N);
@@ -1906,6 +1967,7 @@ int lg_step_transition(lg_ctx* c, const float* actions, float* next_observations
 
 int lg_step_subset(lg_ctx* c, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   if (!actions || !env_ids || n <= 0 || n > c->h.N) { c->err = "bad subset step arguments"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   launch_physics(c, st, actions, env_ids, n);
@@ -1914,6 +1976,7 @@ int lg_step_subset(lg_ctx* c, const float* actions, const int32_t* env_ids, int3
 
 int lg_set_reward_terms(lg_ctx* c, int32_t num_terms, const int32_t* term_ids, const float* scales, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   if (num_terms < 0 || num_terms > LG_MAX_REWARD_TERMS || (num_terms > 0 && (!term_ids || !scales))) { c->err = "bad reward term list"; return LG_ERR_INVALID; }
   for (int k = 0; k < num_terms; ++k) if (term_ids[k] < 0 || term_ids[k] >= LG_REW_COUNT) { c->err = "unknown reward term id"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
@@ -1932,6 +1995,7 @@ int lg_set_reward_terms(lg_ctx* c, int32_t num_terms, const int32_t* term_ids, c
 
 int lg_step_subset_physics(lg_ctx* c, const float* actions, const int32_t* env_ids, int32_t n, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   if (!actions || !env_ids || n <= 0 || n > c->h.N) { c->err = "bad subset step arguments"; return LG_ERR_INVALID; }
   launch_physics(c, (hipStream_t)stream, actions, env_ids, n);
   HIP_TRY(c, hipGetLastError());
@@ -1940,12 +2004,14 @@ int lg_step_subset_physics(lg_ctx* c, const float* actions, const int32_t* env_i
 
 int lg_post_physics_subset(lg_ctx* c, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   if (!env_ids || n <= 0 || n > c->h.N) { c->err = "bad subset step arguments"; return LG_ERR_INVALID; }
   return launch_post(c, (hipStream_t)stream, nullptr, env_ids, n, rollout_mode ? 1 : 0);
 }
 
 int lg_step_physics(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   if (!actions) { c->err = "actions is null"; return LG_ERR_INVALID; }
   launch_physics(c, (hipStream_t)stream, actions, nullptr, c->h.N);
   HIP_TRY(c, hipGetLastError());
@@ -1956,7 +2022,8 @@ int lg_step_physics(lg_ctx* c, const float* actions, void* stream) {
 // its rollouts; one lane per (rollout env, float) copies the 12 state tensors the reference copies.
 __global__ __launch_bounds__(256) void sync_kernel(const DevCtx* __restrict__ C, int R, float drift, uint32_t seed_lo, uint32_t call) {
   const int B = C->B;
-  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1 + B * 16;   // floats (+ one slot for the 4 contact bytes)
+  const bool net = C->cfg.control_type == LG_CTRL_ACTUATOR_NET;
+  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1 + B * 16 + (net ? 12 + 4 * 96 : 0);   // floats (+ one slot for the 4 contact bytes)
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)C->N * per;
   if (gid >= total) return;
@@ -2000,13 +2067,25 @@ __global__ __launch_bounds__(256) void sync_kernel(const DevCtx* __restrict__ C,
     }
     C->rigid[(size_t)e * B * 13 + o] = v; return;
   }
-  o -= B * 13; C->cforce[(size_t)e * B * 3 + o] = C->cforce[(size_t)src * B * 3 + o];
+  o -= B * 13; if (o < B * 3) { C->cforce[(size_t)e * B * 3 + o] = C->cforce[(size_t)src * B * 3 + o]; return; }
+  // actuator network (control.use_actuator_network in a batch-rollout task): the reference steps the rollouts along with their
+  // main, with the main's action (anymal_c_batch_rollout.py:157-182), so their LSTM state and torques equal the main's at
+  // every sync; here the mains are stepped alone and the state is copied
+  o -= B * 3; if (o < 12) { C->torques[(size_t)e * 12 + o] = C->torques[(size_t)src * 12 + o]; return; }
+  o -= 12;
+  {
+    const size_t N12 = (size_t)C->N * 12;
+    const int which = o / 192, r = o - 192 * which, lay = r / 96, i = r - 96 * lay;      // [h | c] x [layer 0 | layer 1] x (12 x 8)
+    float* T = which == 0 ? C->sea_h : C->sea_c;
+    T[(lay * N12 + (size_t)e * 12) * 8 + i] = T[(lay * N12 + (size_t)src * 12) * 8 + i];
+  }
 }
 
 int lg_sync_main_to_rollout(lg_ctx* c, int32_t rollouts_per_main, float pos_drift, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   if (rollouts_per_main <= 0 || c->h.N % (1 + rollouts_per_main) != 0) { c->err = "num_envs is not num_main * (1 + rollouts_per_main)"; return LG_ERR_INVALID; }
-  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1 + c->h.B * 16;
+  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1 + c->h.B * 16 + (c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET ? 12 + 4 * 96 : 0);
   int64_t total = (int64_t)c->h.N * per;
   hipLaunchKernelGGL(sync_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c->d, rollouts_per_main, pos_drift,
                      (uint32_t)c->h.cfg.seed, (uint32_t)(c->sync_calls++));
@@ -2019,6 +2098,7 @@ int lg_sync_main_to_rollout(lg_ctx* c, int32_t rollouts_per_main, float pos_drif
 int lg_rollout_batch(lg_ctx* c, const float* all_us, int32_t horizon, const int32_t* env_ids, int32_t n, int32_t rollouts_per_main,
                      float pos_drift, float* rewards, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   if (!all_us || !env_ids || !rewards || horizon <= 0 || n <= 0 || n > c->h.N) { c->err = "bad rollout_batch arguments"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   int rc = lg_sync_main_to_rollout(c, rollouts_per_main, pos_drift, stream);
@@ -2031,6 +2111,16 @@ int lg_rollout_batch(lg_ctx* c, const float* all_us, int32_t horizon, const int3
   return lg_sync_main_to_rollout(c, rollouts_per_main, pos_drift, stream);
 }
 
+int lg_set_state_indexed(lg_ctx* c, const float* root_states, const float* dof_state, const int32_t* env_ids, int32_t n, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
+  if (n < 0 || (n > 0 && !env_ids)) { c->err = "lg_set_state_indexed: bad id list"; return LG_ERR_INVALID; }
+  if (n == 0) return LG_OK;
+  hipLaunchKernelGGL(set_state_kernel, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, (hipStream_t)stream, c->d, root_states, dof_state, env_ids, n);
+  HIP_TRY(c, hipGetLastError());
+  return LG_OK;
+}
+
 int lg_set_extra_obs(lg_ctx* c, const float* dptr) {
   if (!c) return LG_ERR_INVALID;
   if (c->h.cfg.num_extra_obs > 0 && !dptr) { c->err = "extra obs buffer is null"; return LG_ERR_INVALID; }
@@ -2041,6 +2131,7 @@ int lg_set_extra_obs(lg_ctx* c, const float* dptr) {
 
 int lg_profile_begin(lg_ctx* c, int32_t max_samples, int32_t stride) {
   if (!c || max_samples <= 0 || stride <= 0) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   c->ev.assign((size_t)4 * max_samples, nullptr);
   for (auto& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
@@ -2050,6 +2141,7 @@ int lg_profile_begin(lg_ctx* c, int32_t max_samples, int32_t stride) {
 
 int lg_profile_end(lg_ctx* c, float mean_ms[3], int32_t* nsamples) {
   if (!c || !mean_ms || !nsamples) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   double acc[3] = {0, 0, 0};
   for (int i = 0; i < c->prof_n; ++i) {
     hipEvent_t* ev = &c->ev[(size_t)4 * i];
@@ -2065,6 +2157,7 @@ int lg_profile_end(lg_ctx* c, float mean_ms[3], int32_t* nsamples) {
 
 int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
   hipLaunchKernelGGL((physics_kernel<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N, 12);
   HIP_TRY(c, hipGetLastError());
@@ -2073,6 +2166,7 @@ int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
 
 int lg_simulate(lg_ctx* c, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
     hipLaunchKernelGGL((physics_kernel<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, 12);
@@ -2084,11 +2178,13 @@ int lg_simulate(lg_ctx* c, void* stream) {
 
 int lg_post_physics_step(lg_ctx* c, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   return launch_post(c, (hipStream_t)stream, nullptr, nullptr, c->h.N, 0);
 }
 
 int lg_reset_idx(lg_ctx* c, const int32_t* env_ids, int32_t n, int32_t update_curriculum, void* stream) {
   if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
   if (n < 0 || (n > 0 && !env_ids)) { c->err = "bad env id list"; return LG_ERR_INVALID; }
   if (n == 0) return LG_OK;                         // LR:172-173
   hipStream_t st = (hipStream_t)stream;

@@ -258,7 +258,16 @@ class NativeSetup:
             self.height_samples = np.ascontiguousarray(terrain.heightsamples, dtype=np.int16)
             self.terrain_origins = np.ascontiguousarray(terrain.env_origins, dtype=np.float32)
             t.mesh_type = abi.LG_MESH_HEIGHTFIELD
-            if getattr(terrain, "collide_as_mesh", False):
+            # mesh_type = 'trimesh' on a procedural Terrain: the reference collides against convert_heightfield_to_trimesh(...,
+            # slope_treshold) (terrain.py:77-80, legged_robot.py:_create_trimesh), whose vertices are shifted so that cells steeper
+            # than the threshold become vertical walls -- a surface the height grid cannot hold (and the one the ray-cast sensors
+            # see, legged_robot_raycast.py:187-196).  Contacts therefore run against those triangles, like TerrainObj /
+            # TerrainConfined; `terrain.collide_height_grid = True` keeps the (faster) unshifted grid, which is what
+            # mesh_type = 'heightfield' always uses (gym.add_heightfield, legged_robot.py:_create_heightfield).
+            shifted = (cfg.terrain.mesh_type == "trimesh" and getattr(terrain, "vertices", None) is not None
+                       and getattr(cfg.terrain, "slope_treshold", None) is not None
+                       and not getattr(cfg.terrain, "collide_height_grid", False))
+            if getattr(terrain, "collide_as_mesh", False) or shifted:
                 # TerrainObj / TerrainConfined: overhangs, ceilings and walls cannot be a height grid; contacts run against
                 # the triangle mesh itself, placed like gym.add_triangle_mesh does (transform.p = -border_size,
                 # robot_batch_rollout.py:376-394).  NativeCore builds the BVH and fills terrain.collision_mesh.

@@ -162,6 +162,17 @@ class NativeCore:
         self._check(self.lib.lg_reset_idx(self.ctx, C.c_void_p(ids.data_ptr()), int(ids.numel()), int(update_curriculum),
                                           self._stream()))
 
+    def set_state_indexed(self, env_ids, root_states=None, dof_state=None):
+        """Teleport the listed envs (`gym.set_actor_root_state_tensor_indexed` / `set_dof_state_tensor_indexed`): rows of the
+        given FULL tensors (default: the library's own, i.e. whatever the caller wrote into the views) become the state, and
+        the rigid-body states of those envs are recomputed from it."""
+        ids = env_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        r = None if root_states is None else self._f32(root_states)
+        d = None if dof_state is None else self._f32(dof_state)
+        self._check(self.lib.lg_set_state_indexed(self.ctx, C.c_void_p(r.data_ptr()) if r is not None else None,
+                                                  C.c_void_p(d.data_ptr()) if d is not None else None,
+                                                  C.c_void_p(ids.data_ptr()), int(ids.numel()), self._stream()))
+
     def profile_begin(self, max_samples=256, stride=1):
         self._check(self.lib.lg_profile_begin(self.ctx, int(max_samples), int(stride)))
 

@@ -299,6 +299,14 @@ int lg_post_physics_step(lg_ctx* ctx, void* stream);
 /* Reset the listed envs (device pointer to n int32 ids).  `update_curriculum` = the reference's init_done. */
 int lg_reset_idx(lg_ctx* ctx, const int32_t* env_ids, int32_t n, int32_t update_curriculum, void* stream);
 
+/* gym.set_actor_root_state_tensor_indexed / set_dof_state_tensor_indexed (legged_robot.py:463-465, 487-489, 496): teleport the n
+ * listed envs.  `root_states` (N,13) and `dof_state` (N,12,2) are FULL tensors (device pointers, either may be NULL), of which the
+ * rows of env_ids (device pointer to n int32) are copied into the simulation state, exactly the calling convention of the gym
+ * functions.  The library's own LG_T_ROOT_STATES / LG_T_DOF_STATE are the simulation state (edits through their zero-copy views
+ * need no call at all: passing them here is accepted and copies nothing); the rigid-body states of the listed envs are refreshed
+ * from the new pose either way and their contact forces zeroed. */
+int lg_set_state_indexed(lg_ctx* ctx, const float* root_states, const float* dof_state, const int32_t* env_ids, int32_t n, void* stream);
+
 /* Bind the (N, num_extra_obs) f32 device buffer whose rows are appended to the observation (legged_robot_raycast.py:252-254). */
 int lg_set_extra_obs(lg_ctx* ctx, const float* dptr);
 

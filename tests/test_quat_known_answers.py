@@ -233,3 +233,36 @@ def test_hip_rigid_body_frames_follow_the_base_attitude():
     rb = core.t["rigid_body_state"].cpu().numpy().reshape(n, -1, 13)
     _check_rigid_frames(rb, root)
     core.close()
+
+
+@pytest.mark.gpu
+def test_set_state_indexed_teleports_and_refreshes_body_states():
+    """`lg_set_state_indexed` = gym.set_actor_root_state_tensor_indexed + set_dof_state_tensor_indexed (legged_robot.py:463-465,
+    487-489): rows of the caller's full tensors become the state of the listed envs, the others are untouched, and the body
+    states of the listed envs follow the new pose at once (the same frames test as above)."""
+    from extended_legged_gym_amd.native import NativeCore
+    n = len(_attitude_cases())
+    setup, root, _ = _post_step_case(n)
+    core = NativeCore(setup, "cuda:0")
+    core.reset_idx(torch.arange(n))
+    before_root, before_rb = core.t["root_states"].clone(), core.t["rigid_body_state"].clone()
+    root[:, 7:13] = 0
+    new_root = torch.from_numpy(root).cuda()
+    new_dof = torch.zeros(n, 12, 2, device="cuda")
+    new_dof[..., 0] = torch.tensor(setup.default_dof_pos, device="cuda") + 0.3
+    ids = torch.tensor([0, 3, 4, 7, n - 1], device="cuda")
+    core.set_state_indexed(ids, new_root, new_dof)
+    torch.cuda.synchronize()
+    rest = torch.ones(n, dtype=torch.bool, device="cuda"); rest[ids] = False
+    assert torch.equal(core.t["root_states"][rest], before_root[rest]) and torch.equal(core.t["rigid_body_state"][rest], before_rb[rest])
+    assert torch.equal(core.t["root_states"][ids], new_root[ids]) and torch.equal(core.t["dof_state"][ids], new_dof[ids])
+    assert not core.t["contact_forces"][ids].any()
+    rb = core.t["rigid_body_state"].cpu().numpy().reshape(n, -1, 13)
+    sel = ids.cpu().numpy()
+    _check_rigid_frames(rb[sel], root[sel])                      # (env 0 of the selection has the identity attitude)
+    # editing the library's own views and passing nothing: the body states catch up
+    core.t["root_states"][5] = new_root[5]
+    core.set_state_indexed(torch.tensor([5], device="cuda"))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(core.t["rigid_body_state"].view(n, -1, 13)[5, 0].cpu().numpy(), root[5], atol=1e-6)
+    core.close()
