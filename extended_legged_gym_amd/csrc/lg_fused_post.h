@@ -1,0 +1,557 @@
+// lg_fused_post.h — the post-physics step as the TAIL of the physics kernel (lg_step's fused path).
+//
+// Included by lg_step.hip after the post-physics helpers (reward_term, reset_env, resample_commands, the height probe, the
+// statistics step).  The stand-alone post_kernel stays for every split entry point (lg_post_physics_step, subset / rollout
+// steps, lg_step_transition); a full policy step of all envs (`lg_step`) instead ends inside physics_kernel:
+//
+//   * a physics workgroup already holds the final state of its 16 envs in the main wave's registers (root, q, qd, torques,
+//     contact forces): nothing is re-read from HBM, the history rows the post step needs (last actions, commands, feet
+//     timers, episode sums ...) and its uniform draws are fetched by the three helper waves while the main wave runs the
+//     last Gauss-Seidel sweeps (they are idle then);
+//   * the per-DOF / per-body reductions run on the main wave in its quad layout (lane = leg, DPP quad sums);
+//   * the serial part (callback, termination, reward terms in config order, reset, episode sums) runs once per env on the
+//     quad's first lane, on LDS rows, with the SAME functions the post kernel uses (reward_term, reset_env, ...);
+//   * meanwhile the helper waves write the rigid-body rows and run the 187-point height scan;
+//   * then all four waves write the env rows back and assemble the observation rows (4 envs per wave).
+//
+// The stand-alone post kernel costs ~21 us per step at 4096 envs (1024 workgroups, a chain of eight barrier-separated narrow
+// stages behind a staging pass) plus a kernel boundary; this tail replaces it.  Same arithmetic, same Philox counters, same
+// order of side effects (LR:113-153): the two paths agree to summation order (tests/test_hip_fused_step.py).
+#pragma once
+#define HF(i) (hot[(i)])
+#define HI(i) (__float_as_int(hot[(i)]))
+
+// LDS row of one env during the tail (floats); lives in the memory of `xs` (dead after the last contact set-up)
+enum { FS_ROOT = 0, FS_DOF = 13, FS_CF = 37, FS_FRB = FS_CF + LG_MAX_BODIES * 3 /* four feet rows x 13 */, FS_ACT = FS_FRB + 52, FS_LACT = FS_ACT + 12,
+       FS_LRV = FS_LACT + 12, FS_CMD = FS_LRV + 6, FS_BLA = FS_CMD + 4, FS_BAA = FS_BLA + 3, FS_AIR = FS_BAA + 3, FS_CT = FS_AIR + 4, FS_BLV = FS_CT + 4,
+       FS_BAV = FS_BLV + 3, FS_PG = FS_BAV + 3, FS_SUMS = FS_PG + 3, FS_GAIT = FS_SUMS + LG_MAX_REWARD_TERMS, FS_FN = FS_GAIT + 1,
+       FS_GFZ = FS_FN + LG_MAX_BODIES /* gait_foot_z of the previous step */, FS_VAL = FS_GFZ + 4 /* critic value (lg_step_transition) */,
+       FS_END = FS_VAL + 1, FS_STRIDE = FS_END + (FS_END % 2 == 0 ? 1 : 0) };
+static_assert(EPB * FS_STRIDE <= XS_STRIDE * 64, "the env rows of the fused tail must fit the memory of the mass-factor table");
+// uniforms + small integers of one env (fetched before the final barrier): in the memory of `xbias` (64 x 12 floats)
+enum { FU_U = 0, FU_PRE = EPB * LG_RS_NOISE, FU_PRE_STRIDE = 16 };   // pre: [0,1] episode length (int64) | [2] level | [3] last_contacts (4 bytes)
+static_assert(FU_PRE + EPB * FU_PRE_STRIDE <= 64 * 12, "uniforms + pre-step integers must fit the leg-bias table");
+// results of the serial part + heights: in the memory of the contact-slot table (dead after the last force read-out)
+enum { FM_RK = 0, FM_PART = LG_MAX_REWARD_TERMS, FM_ROOTZ = FM_PART + PART_STRIDE, FM_DID_RESET, FM_ROOT_DIRTY, FM_LASTC /* 4 */, FM_RAW = FM_LASTC + 4 /* 2 x LG_REW_COUNT */,
+       FM_STRIDE = FM_RAW + 2 * LG_REW_COUNT + 1 };
+enum { FO_STRIDE = 256, FH_HEIGHTS = 0, FH_MISC = EPB * MAX_P, FH_OBS = FH_MISC + EPB * FM_STRIDE + 3 - (FH_MISC + EPB * FM_STRIDE + 3) % 4 /* 16-B aligned */ };
+
+// ---- helper waves, while the main wave runs the last sweeps: history rows, uniforms, pre-step integers -> LDS
+LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid /* 0..191 */, int64_t step, const float* values) {
+  const lg_config& g = C->cfg;
+  const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
+  const int K = g.num_reward_terms, per = 12 + 6 + 4 + 3 + 3 + 4 + 4 + 1 + 4 + K;
+  for (int idx = htid; idx < nenv * per; idx += 192) {
+    const int el = idx / per; int o = idx - el * per;
+    const int e = e0 + el;
+    float* S = SR + el * FS_STRIDE;
+    if (o < 12) { S[FS_LACT + o] = C->last_actions[(size_t)e * 12 + o]; continue; }
+    o -= 12; if (o < 6) { S[FS_LRV + o] = C->last_root_vel[(size_t)e * 6 + o]; continue; }
+    o -= 6; if (o < 4) { S[FS_CMD + o] = C->commands[(size_t)e * 4 + o]; continue; }
+    o -= 4; if (o < 3) { S[FS_BLA + o] = C->base_lin_acc[(size_t)e * 3 + o]; continue; }
+    o -= 3; if (o < 3) { S[FS_BAA + o] = C->base_ang_acc[(size_t)e * 3 + o]; continue; }
+    o -= 3; if (o < 4) { S[FS_AIR + o] = C->feet_air[(size_t)e * 4 + o]; continue; }
+    o -= 4; if (o < 4) { S[FS_CT + o] = C->feet_ctime[(size_t)e * 4 + o]; continue; }
+    o -= 4; if (o < 1) { S[FS_GAIT] = C->gait_idx[e]; continue; }
+    o -= 1; if (o < 4) { S[FS_GFZ + o] = C->gait_foot_z[(size_t)e * 4 + o]; continue; }
+    o -= 4; S[FS_SUMS + o] = C->ep_sums[(size_t)o * C->N + e];
+  }
+  // one Philox call per (env, slot group): 8 groups of the 32 control slots
+  for (int idx = htid; idx < nenv * (LG_RS_NOISE / 4); idx += 192) {
+    const int el = idx / (LG_RS_NOISE / 4), grp = idx - el * (LG_RS_NOISE / 4);
+    uniform_draw4(C, e0 + el, grp, step, 0u, UB + FU_U + el * LG_RS_NOISE + 4 * grp);
+  }
+  if (htid < nenv) {
+    const int e = e0 + htid;
+    float* pre = UB + FU_PRE + htid * FU_PRE_STRIDE;
+    *reinterpret_cast<int64_t*>(pre) = C->ep_len[e];
+    pre[2] = g.curriculum ? (float)C->levels[e] : 0.f;
+    SR[htid * FS_STRIDE + FS_VAL] = values ? values[e] : 0.f;
+    uint8_t* lc = reinterpret_cast<uint8_t*>(pre + 3);
+    const uint8_t* src = C->last_contacts + (size_t)e * 4;
+    lc[0] = src[0]; lc[1] = src[1]; lc[2] = src[2]; lc[3] = src[3];
+  }
+}
+
+// ---- helper waves, after the final state is published: the height scan of the workgroup's envs (LR:400-401), one point per lane
+LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid) {
+  const int P = C->cfg.measure_heights ? C->P : 0;
+  if (P <= 0) return;
+  const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
+  const bool plane = C->ter.mesh_type == LG_MESH_PLANE;
+  const int p = htid;
+  const bool okp = p < P;
+  const float bx = C->height_points[2 * (okp ? p : 0)], by = C->height_points[2 * (okp ? p : 0) + 1];
+  HeightProbe hp[EPB];
+#pragma unroll
+  for (int el = 0; el < EPB; ++el) {
+    const float* r = xst[4 * el];          // the quad's published root: pos 0..2; slot 19 of its first two rows: the normalised yaw-only quaternion (z, w)
+    hp[el] = terrain_height_probe(C, r[19], xst[4 * el + 1][19], r[0], r[1], bx, by);
+  }
+#pragma unroll
+  for (int el = 0; el < EPB; ++el) {
+    if (okp && el < nenv) {
+      const float hv = plane ? 0.f : terrain_height_value(C, hp[el]);
+      HB[FH_HEIGHTS + el * MAX_P + p] = hv;
+      C->heights[(size_t)(e0 + el) * C->P + p] = hv;
+    }
+  }
+}
+
+// ---- main wave, quad layout: per-DOF reward features (sums over the 12 DOFs), contact-force norms, base-frame quantities
+struct FusedMainIn {
+  const float* root; const float* q; const float* qd; const float* tau; const float* last_qd; const V3* fbody; bool fault;
+};
+LG_DEV void fused_main_part1(const DevCtx* __restrict__ C, const float* hot, const LegModel& lm_, float* S, int l, const FusedMainIn& in, float feat[F_COUNT]) {
+  const float dt = HF(HC_DT);
+  const int per_leg = C->per_leg;
+  // state rows
+  if (l == 0) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) S[FS_ROOT + i] = in.root[i];
+    S[FS_CF] = in.fbody[0].x; S[FS_CF + 1] = in.fbody[0].y; S[FS_CF + 2] = in.fbody[0].z;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { S[FS_DOF + 2 * (3 * l + j)] = in.q[j]; S[FS_DOF + 2 * (3 * l + j) + 1] = in.qd[j]; }
+  V3 last = in.fbody[3];
+  if (per_leg == 3) last = last + in.fbody[4];
+  {
+    float* cl = S + FS_CF + (1 + per_leg * l) * 3;
+    cl[0] = in.fbody[1].x; cl[1] = in.fbody[1].y; cl[2] = in.fbody[1].z;
+    cl[3] = in.fbody[2].x; cl[4] = in.fbody[2].y; cl[5] = in.fbody[2].z;
+    cl[6] = last.x; cl[7] = last.y; cl[8] = last.z;
+    if (per_leg == 4) { cl[9] = in.fbody[4].x; cl[10] = in.fbody[4].y; cl[11] = in.fbody[4].z; }
+    float* fn = S + FS_FN + 1 + per_leg * l;
+    fn[0] = norm(in.fbody[1]); fn[1] = norm(in.fbody[2]); fn[2] = norm(last);
+    if (per_leg == 4) fn[3] = norm(in.fbody[4]);
+    if (l == 0) S[FS_FN] = norm(in.fbody[0]);
+  }
+  // per-DOF features (RM: torques, dof_vel, dof_acc, action_rate, dof_pos_limits, dof_vel_limits, torque_limits, stand_still)
+  float f[F_COUNT];
+#pragma unroll
+  for (int k = 0; k < F_COUNT; ++k) f[k] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int d = 3 * l + j;
+    const float q_ = in.q[j], qd = in.qd[j], tq = in.tau[j];
+    f[F_TQ2] += tq * tq;
+    f[F_QD2] += qd * qd;
+    { const float a = (in.last_qd[j] - qd) / dt; f[F_ACC2] += a * a; }
+    { const float a = S[FS_LACT + d] - S[FS_ACT + d]; f[F_ARATE2] += a * a; }
+    { const float lo = q_ - lm_.f(LM_SOFT_LO + j), hi = q_ - lm_.f(LM_SOFT_HI + j); f[F_POSLIM] += -fminf(lo, 0.f) + fmaxf(hi, 0.f); }
+    f[F_VELLIM] += fminf(fmaxf(fabsf(qd) - lm_.f(LM_VEL_LIMIT + j) * HF(HC_SOFT_VEL), 0.f), 1.f);
+    f[F_TQLIM] += fmaxf(fabsf(tq) - lm_.f(LM_TORQUE_LIMIT + j) * HF(HC_SOFT_TQ), 0.f);
+    f[F_STILL] += fabsf(q_ - lm_.f(LM_DEFAULT_POS + j));
+  }
+#pragma unroll
+  for (int k = 0; k < F_COUNT; ++k) feat[k] = quad_sum(f[k]);
+  // base-frame quantities (LR:128-134): lane 0 lin vel, 1 lin acc, 2 ang vel, 3 ang acc; projected gravity on lane 0
+  {
+    const float* root = in.root; const float* lrv = S + FS_LRV;
+    const V3 lin = v3(root[7], root[8], root[9]), ang = v3(root[10], root[11], root[12]);
+    const V3 x = l == 0 ? lin : l == 1 ? lin - v3(lrv[0], lrv[1], lrv[2]) : l == 2 ? ang : ang - v3(lrv[3], lrv[4], lrv[5]);
+    const V3 r = quat_rotate_inverse(root + 3, x);
+    const float ema = 0.9f, oma = (float)(1 - 0.9);
+    float* dst = S + (l == 0 ? FS_BLV : l == 1 ? FS_BLA : l == 2 ? FS_BAV : FS_BAA);
+    if (l == 1 || l == 3) { dst[0] = dst[0] * ema + oma * r.x / dt; dst[1] = dst[1] * ema + oma * r.y / dt; dst[2] = dst[2] * ema + oma * r.z / dt; }
+    else { dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; }
+    const V3 gr = quat_rotate_inverse(root + 3, v3(0, 0, -1));
+    if (l == 0) { S[FS_PG] = gr.x; S[FS_PG + 1] = gr.y; S[FS_PG + 2] = gr.z; }
+  }
+}
+
+// ---- the serial part of one env, on ONE lane (LR:113-153 in the reference's order): callback, termination, rewards, reset,
+// episode sums.  `S` = the env's LDS row, `U` = its 32 uniforms, `pre` = pre-step integers, `M` = result row, `H` = its heights.
+//
+// Everything the reward terms read is fetched into registers in ONE batch of LDS / scalar loads first (the feet's contact
+// forces and timers, the base-frame vectors, the index lists of the model); the terms themselves (RM:41-234, restated from
+// reward_term() above, which stays the reference for the post kernel and is what tests/test_hip_fused_step.py compares this
+// with) are then arithmetic on registers.  Evaluated through reward_term() -- pointer-chasing through LDS with a dependent
+// scalar load per model index -- this part was a ~12 k-cycle latency chain per step on a lane with nothing else to run.
+struct FusedRewardRegs {
+  float blv[3], bav[3], pg[3], cmd[4], bla[2], rootz;
+  float air[4], ct[4]; bool lastc[4];
+  float cfx[4], cfy[4], cfz[4], fnf[4];        // feet: contact force, its norm
+  float fz[4], fvx[4], fvy[4], fvz[4];         // feet rows: height, velocity (valid when a term needs them)
+  float ncoll, bh;
+  float gait_idx, gait_fz[4];
+};
+// Raw values of every enabled reward term (before its scale), straight-line: RAW0[id] = what a term sees when it is evaluated
+// BEFORE _reward_feet_air_time in the config order, RAW1[id] = at / after it (that term rewrites the feet timers and
+// last_contacts, RM:150-163, and five terms read them).  No loop, no switch: the terms' inputs are in registers and every
+// branch is on the kernel-uniform term mask, so nothing waits on a dependent load.
+LG_DEV void fused_reward_all(const DevCtx* __restrict__ C, const float* hot, unsigned mask, FusedRewardRegs& R, const float feat[F_COUNT], int64_t step,
+                             float* RAW0, float* RAW1) {
+  const float dt = HF(HC_DT);
+  const float cmdn = sqrtf(R.cmd[0] * R.cmd[0] + R.cmd[1] * R.cmd[1]);
+#define ON(ID) (((mask >> (ID)) & 1u) != 0u)
+#define PUT(ID, expr) if (ON(ID)) { const float v_ = (expr); RAW0[ID] = v_; RAW1[ID] = v_; }
+  PUT(LG_REW_LIN_VEL_Z, SQ(R.blv[2]))
+  PUT(LG_REW_ANG_VEL_XY, SQ(R.bav[0]) + SQ(R.bav[1]))
+  PUT(LG_REW_ORIENTATION, SQ(R.pg[0]) + SQ(R.pg[1]))
+  PUT(LG_REW_ORIENTATION_LOAD_ADAPT, SQ(R.pg[0] - R.bla[0] / 9.81f) + SQ(R.pg[1] - R.bla[1] / 9.81f))
+  if (ON(LG_REW_BASE_HEIGHT)) {
+    float s = R.rootz;
+    if (HI(HC_MEASURE_H)) s = R.bh / (float)HI(HC_P);
+    const float v_ = SQ(s - HF(HC_BH_TARGET)); RAW0[LG_REW_BASE_HEIGHT] = v_; RAW1[LG_REW_BASE_HEIGHT] = v_;
+  }
+  PUT(LG_REW_TORQUES, feat[F_TQ2]) PUT(LG_REW_DOF_VEL, feat[F_QD2]) PUT(LG_REW_DOF_ACC, feat[F_ACC2]) PUT(LG_REW_ACTION_RATE, feat[F_ARATE2])
+  PUT(LG_REW_DOF_POS_LIMITS, feat[F_POSLIM]) PUT(LG_REW_DOF_VEL_LIMITS, feat[F_VELLIM]) PUT(LG_REW_TORQUE_LIMITS, feat[F_TQLIM])
+  PUT(LG_REW_COLLISION, R.ncoll)
+  PUT(LG_REW_STAND_STILL, feat[F_STILL] * (cmdn < 0.1f ? 1.f : 0.f))
+  PUT(LG_REW_TRACKING_LIN_VEL, expf(-(SQ(R.cmd[0] - R.blv[0]) + SQ(R.cmd[1] - R.blv[1])) / HF(HC_SIGMA)))
+  PUT(LG_REW_TRACKING_ANG_VEL, expf(-SQ(R.cmd[2] - R.bav[2]) / HF(HC_SIGMA)))
+  if (ON(LG_REW_FEET_STUMBLE) || ON(LG_REW_FEET_STUMBLE_LIFTUP)) {
+    bool any = false; float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { const bool st = sqrtf(SQ(R.cfx[f]) + SQ(R.cfy[f])) > 5.f * fabsf(R.cfz[f]); any |= st; s += (st ? 1.f : 0.f) * R.fvz[f]; }
+    RAW0[LG_REW_FEET_STUMBLE] = RAW1[LG_REW_FEET_STUMBLE] = any ? 1.f : 0.f;
+    RAW0[LG_REW_FEET_STUMBLE_LIFTUP] = RAW1[LG_REW_FEET_STUMBLE_LIFTUP] = s;
+  }
+  if (ON(LG_REW_FEET_CONTACT_FORCES)) {
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) s += fmaxf(R.fnf[f] - HF(HC_MAX_CF), 0.f);
+    RAW0[LG_REW_FEET_CONTACT_FORCES] = RAW1[LG_REW_FEET_CONTACT_FORCES] = s;
+  }
+  if (ON(LG_REW_FOUR_FOOTUP)) {
+    bool all = true;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) all &= R.cfz[f] < 1.f;
+    RAW0[LG_REW_FOUR_FOOTUP] = RAW1[LG_REW_FOUR_FOOTUP] = 0.1f * (all ? 1.f : 0.f);
+  }
+  if (ON(LG_REW_GAIT_SCHEDULER)) {   // gait_scheduler.py:74-81 on the foot heights / phase stored by the previous step
+    float s = 0.f;
+    if (HI(HC_GAIT_ON) && step > 1) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const float ph = fmodf(R.gait_idx + HF(HC_GAIT_PHASE + f), 1.0f);
+        const float tgt = ph < 0.5f ? HF(HC_GAIT_SWING) * sinf(6.28318530717958647692f * ph) : 0.f;
+        s += SQ(tgt - R.gait_fz[f]);
+      }
+    }
+    RAW0[LG_REW_GAIT_SCHEDULER] = RAW1[LG_REW_GAIT_SCHEDULER] = s;
+  }
+  // ---- the terms that read the feet timers / last_contacts: once on the old values, once on what feet_air_time leaves
+#define FSYNC(a, b) (fminf(SQ(R.air[a] - R.air[b]), 4.f) + fminf(SQ(R.ct[a] - R.ct[b]), 4.f))
+#define FASYN(a, b) (fminf(SQ(R.air[a] - R.ct[b]), 4.f) + fminf(SQ(R.ct[a] - R.air[b]), 4.f))
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    float* RAW = pass == 0 ? RAW0 : RAW1;
+    if (ON(LG_REW_BASE_FOOT_HEIGHT)) {
+      float s = 0.f; int n = 0;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) if (R.ct[f] > 1e-3f) { s += R.fz[f]; ++n; }
+      const float est = n > 0 ? s / (float)n : R.rootz - HF(HC_BH_TARGET);
+      RAW[LG_REW_BASE_FOOT_HEIGHT] = SQ((R.rootz - est) - HF(HC_BH_TARGET));
+    }
+    if (ON(LG_REW_FEET_SLIP)) {
+      float s = 0.f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) { const bool cfl = (R.cfz[f] > 1.f) || R.lastc[f]; const float vn = sqrtf(SQ(R.fvx[f]) + SQ(R.fvy[f])); s += (cfl ? 1.f : 0.f) * SQ(vn); }
+      RAW[LG_REW_FEET_SLIP] = s;
+    }
+    if (ON(LG_REW_JUMP_AIR)) {
+      float s = 0.f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) { const bool cfl = (R.cfz[f] > 1.f) || R.lastc[f]; s += (cfl ? 0.f : 1.f) * (R.air[f] - 0.5f); }
+      RAW[LG_REW_JUMP_AIR] = fmaxf(s - 2.f, 0.f);
+    }
+    if (ON(LG_REW_GAIT_2_STEP)) {
+      const float sr = (FSYNC(0, 3) + FSYNC(1, 2)) / 2;
+      const float ar = (FASYN(0, 1) + FASYN(0, 2) + FASYN(3, 2) + FASYN(3, 1)) / 4;
+      const float other = HI(HC_HEADING) ? R.cmd[3] : R.cmd[2];
+      const bool on = cmdn > 0.1f || fabsf(other) >= 0.05f;
+      RAW[LG_REW_GAIT_2_STEP] = (sr + ar) * (on ? 1.f : 0.f);
+    }
+    if (pass == 0 && ON(LG_REW_FEET_AIR_TIME)) {   // RM:150-163, stateful
+      float s = 0.f;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const bool contact = R.cfz[f] > 1.f; const bool cfl = contact || R.lastc[f];
+        R.lastc[f] = contact;
+        const float first = (R.air[f] > 0.f && cfl) ? 1.f : 0.f;
+        const float a = R.air[f] + dt, ct = R.ct[f] + dt;
+        s += (a - 0.5f) * first;
+        R.air[f] = a * (cfl ? 0.f : 1.f); R.ct[f] = ct * (cfl ? 1.f : 0.f);
+      }
+      RAW0[LG_REW_FEET_AIR_TIME] = RAW1[LG_REW_FEET_AIR_TIME] = s * (cmdn > 0.1f ? 1.f : 0.f);
+    }
+  }
+#undef FSYNC
+#undef FASYN
+#undef PUT
+#undef ON
+}
+
+LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int e, float* S, const float* U, const float* pre, float* M, const float* H,
+                             const float feat[F_COUNT], bool fault, int64_t step, const PostSink& K) {
+  const float dt = HF(HC_DT);
+  const int P = HI(HC_P);
+  const unsigned term_mask = (unsigned)HI(HC_TERM_MASK);
+  const int kterm = HI(HC_KTERM); const float term_scale = HF(HC_TERM_SCALE);
+  float* root = S + FS_ROOT; float* cmd = S + FS_CMD;
+  const float* fn = S + FS_FN; const float* cf = S + FS_CF;
+  // ---- one batch of loads: model index lists, feet quantities, base-frame vectors, counters
+  FusedRewardRegs R;
+  int fidx[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) fidx[f] = HI(HC_FEET + f);
+  float ncoll = 0.f; bool term = false;
+#pragma unroll
+  for (int i = 0; i < LG_MAX_INDEX_LIST; ++i) {          // fixed bounds: the index loads and the LDS reads behind them go out together
+    const bool pen = i < HI(HC_NPEN), trm = i < HI(HC_NTERM);
+    const float fp = fn[HI(HC_PEN + i)], ft = fn[HI(HC_TERMB + i)];
+    ncoll += (pen && fp > 0.1f) ? 1.f : 0.f;
+    term |= trm && ft > 1.f;
+  }
+  R.ncoll = ncoll;
+  { const uint8_t* lc = reinterpret_cast<const uint8_t*>(pre + 3);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) R.lastc[f] = lc[f] != 0; }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    R.cfx[f] = cf[3 * fidx[f]]; R.cfy[f] = cf[3 * fidx[f] + 1]; R.cfz[f] = cf[3 * fidx[f] + 2]; R.fnf[f] = fn[fidx[f]];
+    R.air[f] = S[FS_AIR + f]; R.ct[f] = S[FS_CT + f];
+    R.fz[f] = S[FS_FRB + 13 * f + 2]; R.fvx[f] = S[FS_FRB + 13 * f + 7]; R.fvy[f] = S[FS_FRB + 13 * f + 8]; R.fvz[f] = S[FS_FRB + 13 * f + 9];
+    R.gait_fz[f] = S[FS_GFZ + f];
+  }
+  R.gait_idx = S[FS_GAIT];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { R.blv[i] = S[FS_BLV + i]; R.bav[i] = S[FS_BAV + i]; R.pg[i] = S[FS_PG + i]; }
+  R.bla[0] = S[FS_BLA]; R.bla[1] = S[FS_BLA + 1];
+  R.rootz = root[2];
+  const int64_t eplen = *reinterpret_cast<const int64_t*>(pre) + 1;                   // LR:122
+  bool root_dirty = false;
+  // ---- _post_physics_step_callback (LR:386-403)
+  if ((int)eplen % HI(HC_RESAMPLING_STEPS) == 0) resample_commands(C, cmd, U, LG_RS_CMD_CB);
+  if (HI(HC_HEADING)) {
+    float q[4] = {root[3], root[4], root[5], root[6]};
+    V3 f = quat_apply(q, v3(1, 0, 0));
+    float x = 0.5f * wrap_to_pi(cmd[3] - atan2f(f.y, f.x));
+    cmd[2] = fminf(fmaxf(x, -1.f), 1.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) R.cmd[i] = cmd[i];
+  const bool push_hit = (step >> 32) == 0 ? ((uint32_t)step % (uint32_t)HI(HC_PUSH_INTERVAL) == 0u) : (step % HI(HC_PUSH_INTERVAL) == 0);
+  if (HI(HC_PUSH) && push_hit) {                                                     // LR:402-403, 491-496
+    root[7] = rand_float(-HF(HC_MAX_PUSH), HF(HC_MAX_PUSH), U[LG_RS_PUSH]);
+    root[8] = rand_float(-HF(HC_MAX_PUSH), HF(HC_MAX_PUSH), U[LG_RS_PUSH + 1]);
+    root_dirty = true;
+  }
+  // ---- check_termination (LR:155-160)
+  term |= HI(HC_FLIP) && R.pg[2] > 0.f;
+  term |= fault;                                   // physics fault / lost env flagged by this launch
+  const bool tout = (float)eplen > HF(HC_MAX_EPLEN);
+  C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0;
+  C->ep_len[e] = eplen;
+  // ---- compute_reward (LR:215-232): terms in config order; _reward_feet_air_time rewrites the feet timers where it stands in
+  // that order (RM:150-163), so earlier terms see the old values and later ones the new, as in the reference
+  R.bh = 0.f;
+  if ((term_mask >> LG_REW_BASE_HEIGHT) & 1u) for (int p = 0; p < P; ++p) R.bh += root[2] - H[p];
+  float rew = 0.f;
+  const int K_ = HI(HC_K), kfat = HI(HC_KFAT);
+  float* RAW0 = M + FM_RAW; float* RAW1 = RAW0 + LG_REW_COUNT;
+  fused_reward_all(C, hot, term_mask, R, feat, step, RAW0, RAW1);
+#pragma unroll 4
+  for (int k = 0; k < K_; ++k) {                 // the reference's sum, in config order (LR:218-224)
+    const int id = HI(HC_IDS + k);
+    const float raw = k < kfat ? RAW0[id] : RAW1[id];
+    const float r = id != LG_REW_TERMINATION ? raw * HF(HC_SCALES + k) : 0.f;
+    M[FM_RK + k] = r;
+    rew += r;
+  }
+  if (HI(HC_ONLY_POS)) rew = fmaxf(rew, 0.f);
+  if (kterm >= 0) {
+    const float r = ((term || tout) && !tout ? 1.f : 0.f) * term_scale;
+    rew += r; M[FM_RK + kterm] = r;
+  }
+  C->rew[e] = rew;
+  if (K.rewards) {                               // PPO.process_env_step (ppo.py:165, 179-183): three roundings
+#pragma clang fp contract(off)
+    const float boot = K.gamma * (S[FS_VAL] * (tout ? 1.f : 0.f));
+    K.rewards[e] = rew + boot;
+    K.dones[e] = (term || tout) ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) { S[FS_AIR + f] = R.air[f]; S[FS_CT + f] = R.ct[f]; }       // what _reward_feet_air_time left (reset_env zeroes them)
+  float level = pre[2];
+  const bool do_reset = term || tout;
+  if (do_reset) {
+    EnvView V;
+    uint8_t lastc_unused[4] = {0, 0, 0, 0};
+    V.root = root; V.dof = S + FS_DOF; V.cmd = cmd; V.air = S + FS_AIR; V.ctime = S + FS_CT;
+    V.blv = S + FS_BLV; V.bav = S + FS_BAV; V.pg = S + FS_PG; V.tq = nullptr; V.act = S + FS_ACT; V.lact = S + FS_LACT; V.bla = S + FS_BLA;
+    V.ldv = nullptr; V.cf = cf; V.rb = S + FS_FRB; V.lastc = lastc_unused; V.feet_rows = 1;
+    reset_env(C, V, e, 1, U, false);
+    root_dirty = true;
+    if (HI(HC_CURRICULUM)) level = (float)C->levels[e];
+  }
+  M[FM_ROOTZ] = root[2];
+  M[FM_DID_RESET] = do_reset ? 1.f : 0.f;
+  M[FM_ROOT_DIRTY] = root_dirty ? 1.f : 0.f;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) M[FM_LASTC + f] = R.lastc[f] ? 1.f : 0.f;
+  if (HI(HC_GAIT_ON)) {                                                                 // anymal.py:107-110
+    float x = fmodf(S[FS_GAIT] + dt / HF(HC_GAIT_PERIOD), 1.0f); if (x < 0.f) x += 1.0f;
+    S[FS_GAIT] = x;
+  }
+  // ---- episode sums and the statistics of LR:200-206
+#pragma unroll 4
+  for (int k = 0; k < K_; ++k) {
+    const float tot = S[FS_SUMS + k] + M[FM_RK + k];
+    M[FM_PART + k] = do_reset ? tot : 0.f;
+    S[FS_SUMS + k] = do_reset ? 0.f : tot;
+  }
+  M[FM_PART + K_] = do_reset ? 1.f : 0.f;
+  M[FM_PART + K_ + 1] = level;
+  M[FM_PART + K_ + 2] = do_reset ? (float)eplen : 0.f;
+}
+
+// ---- all four waves: write-back of the env rows + observation rows, 4 envs per wave; statistics + arrival by wave 0
+// Returns true on the LAST workgroup of the launch to arrive (it then runs finalize_from_acc).
+LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out) {
+  STAMP_DECL
+  const int wv = tid >> 6, ln = tid & 63;
+  const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
+  const int P = HI(HC_P);
+  const float* MB = HB + FH_MISC;
+  // Row stores, 4 envs per wave.  All LDS reads of the four envs are issued first (one round trip), then the predicated global
+  // stores: a read-then-store chain per row costs an LDS latency each, 70 times over, on a wave that is alone on its SIMD.
+  {
+    enum { NR = 16 };
+    const int off[NR] = {FS_ROOT, FS_DOF, FS_CMD, FS_AIR, FS_CT, FS_BLV, FS_BAV, FS_PG, FS_BLA, FS_BAA, FS_GAIT, FS_ACT, FS_ROOT + 7, FS_SUMS, FS_FRB, FS_DOF};
+    const int len[NR] = {13, 24, 4, 4, 4, 3, 3, 3, 3, 3, 1, 12, 6, HI(HC_K), 0 /* gait_foot_z: stored with the foot's rigid-body row */, 12};
+    float v[4][NR]; float lc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* S = SR + (4 * wv + q) * FS_STRIDE;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int i = max(min(ln, len[r] - 1), 0);
+        v[q][r] = S[off[r] + (r == 15 ? 2 * i + 1 : i)];   // 14: foot heights (gait_foot_z), 15: DOF velocities
+      }
+      lc[q] = MB[(4 * wv + q) * FM_STRIDE + FM_LASTC + min(ln, 3)];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int el = 4 * wv + q;
+      if (el < nenv) {
+        const size_t e = (size_t)(e0 + el);
+        float* dst[NR] = {C->root + e * 13, C->dof + e * 24, C->commands + e * 4, C->feet_air + e * 4, C->feet_ctime + e * 4, C->base_lin_vel + e * 3,
+                          C->base_ang_vel + e * 3, C->proj_grav + e * 3, C->base_lin_acc + e * 3, C->base_ang_acc + e * 3, C->gait_idx + e,
+                          C->last_actions + e * 12, C->last_root_vel + e * 6, nullptr, C->gait_foot_z + e * 4, C->last_dof_vel + e * 12};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          if (r == 13) { if (ln < len[r]) C->ep_sums[(size_t)ln * C->N + e] = v[q][r]; }       // (K, N) rows
+          else if (r == 14) { }
+          else if (ln < len[r]) dst[r][ln] = v[q][r];
+        }
+        if (ln < 4) C->last_contacts[e * 4 + ln] = lc[q] != 0.f ? 1 : 0;
+      }
+    }
+  }
+  STAMP(22);
+  // statistics of the workgroup's envs (fixed env order), arrival
+  const int KP = HI(HC_K) + 3;
+  bool any_reset = false;
+  for (int el = 0; el < nenv; ++el) any_reset |= MB[el * FM_STRIDE + FM_DID_RESET] != 0.f;
+  if (wv == 0 && ln < KP && any_reset) {
+    float sacc = 0.f;
+    for (int el = 0; el < nenv; ++el) sacc += MB[el * FM_STRIDE + FM_PART + ln];
+    __hip_atomic_fetch_add(C->acc + ln, __double2ll_rn((double)sacc * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (wv == 0 && ln == KP + 1) {
+    float sacc = 0.f;
+    for (int el = 0; el < nenv; ++el) sacc += MB[el * FM_STRIDE + FM_PART + HI(HC_K) + 1];
+    st_dev(C->lvl_part + blk, sacc);
+  }
+  unsigned arrival = 0;
+  const unsigned shard = (unsigned)blk & 7u, nsh = min(8u, gridDim.x);
+  const unsigned want = (gridDim.x + 7u - shard) >> 3;
+  if (wv == 0) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the statistics stores / atomics of this wave have completed
+  if (tid == 0) arrival = __hip_atomic_fetch_add(C->tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  STAMP(23);
+
+  // observation rows (LR:234-252, :107-108): proprio | heights | extra, + uniform noise, clipped.  A lane forms the 4 entries of
+  // ONE Philox call (entries 4 gq .. 4 gq + 3, the post kernel's mapping, so the noise is the same draw for draw); what does not
+  // depend on the env (noise scales, source offsets, scales) is formed once per lane in front of the env loop.  The entries go
+  // through an LDS row so that the global stores are dense (lane = entry): four 16-byte-strided dword stores per env were the
+  // most expensive part of this phase (the memory pipeline handles 4 lanes per 64-byte segment).
+  const int O = HI(HC_NUM_OBS), G4 = (O + 3) >> 2;
+  const bool inject = HI(HC_INJECT) != 0, add_noise = HI(HC_ADD_NOISE) != 0;
+  const float ls = HF(HC_OS_LIN), as = HF(HC_OS_ANG), ps = HF(HC_OS_POS), vs = HF(HC_OS_VEL), hs = HF(HC_OS_H), clip = HF(HC_CLIP_OBS);
+  float* OB = const_cast<float*>(HB) + FH_OBS + wv * FO_STRIDE;      // this wave's staging row
+  for (int g0 = 0; g0 < G4; g0 += 64) {
+    const int gq = g0 + ln;
+    float nv[4], scale[4], sub[4]; int off[4], hix[4], kind[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = 4 * gq + i;
+      nv[i] = (add_noise && idx < O) ? C->noise_vec[idx] : 0.f;
+      off[i] = idx < 3 ? FS_BLV + idx : idx < 6 ? FS_BAV + idx - 3 : idx < 9 ? FS_PG + idx - 6 : idx < 12 ? FS_CMD + idx - 9
+             : idx < 24 ? FS_DOF + 2 * (idx - 12) : idx < 36 ? FS_DOF + 2 * (idx - 24) + 1 : idx < 48 ? FS_ACT + idx - 36 : 0;
+      scale[i] = idx < 3 ? ls : idx < 6 ? as : idx < 9 ? 1.f : idx < 11 ? ls : idx < 12 ? as : idx < 24 ? ps : idx < 36 ? vs : 1.f;
+      sub[i] = (idx >= 12 && idx < 24) ? HF(HC_DEFAULT_POS + min(max(idx - 12, 0), 11)) : 0.f;
+      kind[i] = idx < 48 ? 0 : (idx < 48 + P ? 1 : 2);
+      hix[i] = min(max(idx - 48, 0), MAX_P - 1);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                 // (unrolled: the four envs' Philox chains and LDS reads interleave)
+      const int el = 4 * wv + q;
+      if (el >= nenv) continue;
+      const int e = e0 + el;
+      const float* S = SR + el * FS_STRIDE; const float* H = HB + FH_HEIGHTS + el * MAX_P;
+      const float rootz = MB[el * FM_STRIDE + FM_ROOTZ];
+      float u[4] = {0.5f, 0.5f, 0.5f, 0.5f}, ex[4] = {0.f, 0.f, 0.f, 0.f}, sv[4], hv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sv[i] = S[off[i]]; hv[i] = H[hix[i]]; }
+      if (add_noise && inject) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (4 * gq + i < O) u[i] = C->rand_inject[(size_t)e * (LG_RS_NOISE + O) + LG_RS_NOISE + 4 * gq + i];
+      }
+      if (C->extra_obs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int idx = 4 * gq + i; if (idx < O && idx >= 48 + P) ex[i] = C->extra_obs[(size_t)e * HI(HC_NUM_EXTRA) + (idx - 48 - P)]; }
+      }
+      if (add_noise && !inject) {
+        uint32_t o4[4];
+        philox4((uint32_t)e, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), 0u, (uint32_t)HI(HC_SEED_LO), (uint32_t)HI(HC_SEED_HI), o4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = u01(o4[i]);
+      }
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float op = (sv[i] - sub[i]) * scale[i];                                           // proprioceptive entry (LR:237-244), post-reset rows
+        const float oh = fminf(fmaxf((rootz - 0.5f) - hv[i], -1.f), 1.f) * hs;  // height entry (LR:245-247)
+        float v = kind[i] == 0 ? op : (kind[i] == 1 ? oh : ex[i]);
+        if (add_noise) v += (2.f * u[i] - 1.f) * nv[i];
+        o[i] = fminf(fmaxf(v, -clip), clip);
+      }
+      *reinterpret_cast<float4*>(OB + 4 * ln) = make_float4(o[0], o[1], o[2], o[3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): the row is in LDS (same wave: the LDS pipeline is in order)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = 4 * g0 + ln + 64 * j;
+        if (idx < O && idx < 4 * g0 + 256) {
+          const float v = OB[idx - 4 * g0];
+          C->obs[(size_t)e * O + idx] = v;
+          if (obs_out) obs_out[(size_t)e * O + idx] = v;     // RolloutStorage.observations[t + 1]
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  STAMP(24);
+  bool last = false;
+  if (tid == 0 && arrival == want - 1u) {
+    if (__hip_atomic_fetch_add(C->tickets + 32 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1u) {
+      last = true;
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(C->tickets + 32 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  return last;
+}

@@ -25,7 +25,8 @@
 // dwords per field (broadcast, conflict-free) instead of issuing ~100 dependent global loads per substep.
 enum { LM_JPOS = 0, LM_JROT = 9, LM_JAXIS = 36, LM_MASS = 45, LM_COM = 48, LM_INERTIA = 57, LM_FOOT_POS = 75, LM_FOOT_ROT = 78,
        LM_VEL_LIMIT = 87, LM_TORQUE_LIMIT = 90, LM_DEFAULT_POS = 93, LM_PGAIN = 96, LM_DGAIN = 99, LM_CP_COUNT = 102,
-       LM_CP_LINK = 103, LM_CP_POS = 111, LM_CP_RADIUS = 135, LM_LOWER = 143, LM_UPPER = 146, LM_FIELDS = 149 };
+       LM_CP_LINK = 103, LM_CP_POS = 111, LM_CP_RADIUS = 135, LM_LOWER = 143, LM_UPPER = 146,
+       LM_SOFT_LO = 149, LM_SOFT_HI = 152 /* cfg.dof_pos_limits: the soft limits of _reward_dof_pos_limits */, LM_FIELDS = 155 };
 struct LegModel {
   const float* t; int l;
   LG_DEV float f(int field) const { return t[field * 4 + l]; }
@@ -55,7 +56,9 @@ LG_DEV void fill_leg_model(float* t, const lg_robot_model* __restrict__ m, const
     else if (field < LM_CP_RADIUS) { int k = field - LM_CP_POS; val = m->cp_pos[l][k / 3][k % 3]; }
     else if (field < LM_LOWER) val = m->cp_radius[l][field - LM_CP_RADIUS];
     else if (field < LM_UPPER) val = m->dof_lower[3 * l + field - LM_LOWER];
-    else val = m->dof_upper[3 * l + field - LM_UPPER];
+    else if (field < LM_SOFT_LO) val = m->dof_upper[3 * l + field - LM_UPPER];
+    else if (field < LM_SOFT_HI) val = g->dof_pos_limits[3 * l + field - LM_SOFT_LO][0];
+    else val = g->dof_pos_limits[3 * l + field - LM_SOFT_HI][1];
     t[idx] = val;
   }
 }

@@ -28,6 +28,16 @@
 #define MAX_P 192       // height-scan points per env held in LDS
 #define PART_STRIDE (LG_MAX_REWARD_TERMS + 3)
 
+// The scalars the post-physics tail of the fused step reads, packed into one contiguous block (built on the host, copied into
+// LDS at kernel start): lg_config is 8 KB (the actuator weights sit in the middle of it) and the tail touches ~20 different
+// 64-byte lines of it, each a scalar-cache miss on first touch, serialised by the tail's dependent chain.
+enum { HC_DT = 0, HC_K, HC_KFAT, HC_KTERM, HC_TERM_SCALE, HC_TERM_MASK, HC_RESAMPLING_STEPS, HC_HEADING, HC_PUSH, HC_PUSH_INTERVAL, HC_MAX_PUSH,
+       HC_FLIP, HC_MAX_EPLEN, HC_ONLY_POS, HC_CURRICULUM, HC_GAIT_ON, HC_GAIT_PERIOD, HC_GAIT_SWING, HC_GAIT_PHASE /* 4 */, HC_SIGMA = HC_GAIT_PHASE + 4,
+       HC_BH_TARGET, HC_MAX_CF, HC_MEASURE_H, HC_P, HC_FEET /* 4 */, HC_NPEN = HC_FEET + 4, HC_PEN /* 16 */, HC_NTERM = HC_PEN + LG_MAX_INDEX_LIST,
+       HC_TERMB /* 16 */, HC_SOFT_VEL = HC_TERMB + LG_MAX_INDEX_LIST, HC_SOFT_TQ, HC_NUM_OBS, HC_ADD_NOISE, HC_INJECT, HC_OS_LIN, HC_OS_ANG, HC_OS_POS,
+       HC_OS_VEL, HC_OS_H, HC_CLIP_OBS, HC_SEED_LO, HC_SEED_HI, HC_NUM_EXTRA, HC_IDS /* 32 */, HC_SCALES = HC_IDS + LG_MAX_REWARD_TERMS /* 32 */,
+       HC_DEFAULT_POS = HC_SCALES + LG_MAX_REWARD_TERMS /* 12 */, HC_COUNT = HC_DEFAULT_POS + 12 };
+
 struct DevCtx {
   lg_config cfg;
   lg_robot_model model;
@@ -62,6 +72,7 @@ struct DevCtx {
   // reward-term bookkeeping of the post kernel, derived from cfg.reward_term_ids on the host (reward_meta): a walk over the
   // term list in the kernel is one dependent scalar load per term on the narrow-stage chain
   unsigned rew_term_mask; int rew_kfat, rew_kterm; float rew_term_scale;
+  float hot[HC_COUNT];          // see the HC_* enum (ints stored as bit patterns)
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
   float lvl_total_before;       // subset steps with a terrain curriculum: sum of ALL terrain levels before the launch (level_total_kernel)
   unsigned long long* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
@@ -79,12 +90,36 @@ struct lg_ctx {
   int device = 0;
   unsigned long sync_calls = 0;
   int split = 1;       // fused step: run the LSTM actuators on three extra waves (LG_SPLIT=0 disables, diagnostic)
+  int fuse = 1;        // lg_step ends inside the physics kernel (LG_FUSE=0: separate post kernel, diagnostic / A-B)
   std::string err;
   // optional per-kernel timing (lg_profile_begin / lg_profile_end)
   std::vector<hipEvent_t> ev; int prof_max = 0, prof_stride = 1, prof_n = 0; long prof_calls = 0;
 };
 
 static thread_local std::string g_err;
+
+static void hot_config(DevCtx& h) {
+  const lg_config& g = h.cfg; const lg_robot_model& m = h.model;
+  auto I = [&](int i, int v) { memcpy(&h.hot[i], &v, 4); };
+  auto U = [&](int i, unsigned v) { memcpy(&h.hot[i], &v, 4); };
+  auto F = [&](int i, float v) { h.hot[i] = v; };
+  F(HC_DT, g.sim_dt * g.decimation); I(HC_K, g.num_reward_terms); I(HC_KFAT, h.rew_kfat); I(HC_KTERM, h.rew_kterm); F(HC_TERM_SCALE, h.rew_term_scale);
+  U(HC_TERM_MASK, h.rew_term_mask); I(HC_RESAMPLING_STEPS, g.resampling_steps); I(HC_HEADING, g.heading_command); I(HC_PUSH, g.push_robots);
+  I(HC_PUSH_INTERVAL, g.push_interval); F(HC_MAX_PUSH, g.max_push_vel_xy); I(HC_FLIP, g.terminate_on_flip); F(HC_MAX_EPLEN, g.max_episode_length);
+  I(HC_ONLY_POS, g.only_positive_rewards); I(HC_CURRICULUM, g.curriculum); I(HC_GAIT_ON, g.gait_enabled); F(HC_GAIT_PERIOD, g.gait_period);
+  F(HC_GAIT_SWING, g.gait_swing_height);
+  for (int f = 0; f < 4; ++f) { F(HC_GAIT_PHASE + f, g.gait_foot_phases[f]); I(HC_FEET + f, m.feet_indices[f]); }
+  F(HC_SIGMA, g.tracking_sigma); F(HC_BH_TARGET, g.base_height_target); F(HC_MAX_CF, g.max_contact_force); I(HC_MEASURE_H, g.measure_heights);
+  I(HC_P, g.measure_heights ? h.P : 0);
+  I(HC_NPEN, m.num_penalised); I(HC_NTERM, m.num_termination);
+  for (int i = 0; i < LG_MAX_INDEX_LIST; ++i) { I(HC_PEN + i, i < m.num_penalised ? m.penalised_contact_indices[i] : 0); I(HC_TERMB + i, i < m.num_termination ? m.termination_contact_indices[i] : 0); }
+  F(HC_SOFT_VEL, g.soft_dof_vel_limit); F(HC_SOFT_TQ, g.soft_torque_limit); I(HC_NUM_OBS, g.num_obs); I(HC_ADD_NOISE, g.add_noise);
+  I(HC_INJECT, g.rng_mode == LG_RNG_INJECT); F(HC_OS_LIN, g.obs_scale_lin_vel); F(HC_OS_ANG, g.obs_scale_ang_vel); F(HC_OS_POS, g.obs_scale_dof_pos);
+  F(HC_OS_VEL, g.obs_scale_dof_vel); F(HC_OS_H, g.obs_scale_height); F(HC_CLIP_OBS, g.clip_observations);
+  U(HC_SEED_LO, (unsigned)g.seed); U(HC_SEED_HI, (unsigned)(g.seed >> 32)); I(HC_NUM_EXTRA, g.num_extra_obs);
+  for (int k = 0; k < LG_MAX_REWARD_TERMS; ++k) { I(HC_IDS + k, g.reward_term_ids[k]); F(HC_SCALES + k, g.reward_scales[k]); }
+  for (int d = 0; d < 12; ++d) F(HC_DEFAULT_POS + d, g.default_dof_pos[d]);
+}
 
 static void reward_meta(DevCtx& h) {
   const lg_config& g = h.cfg;
@@ -328,7 +363,7 @@ LG_DEV void leg_torques(const DevCtx* __restrict__ C, const LegModel& lm_, const
 // (N, B, 13) rows [pos3, quat xyzw4, lin vel3, ang vel3] the reference reads from refresh_rigid_body_state_tensor.
 // `part` selects what this caller stores: -1 everything; 0 / 1 / 2 = link 0 (+ base) / link 1 / link 2 (+ foot body).
 LG_DEV void write_rigid_body_state(const DevCtx* __restrict__ C, const LegModel& lm_, int e, int l, const float* root, const float* q,
-                                   const float* qd, int part = -1) {
+                                   const float* qd, int part = -1, float* foot_row_lds = nullptr, float* foot_z_dst = nullptr) {
   const int per_leg = C->per_leg, B = C->B;
   const M3 Rb = quat_to_mat(root + 3);
   const V3 pb = v3(root[0], root[1], root[2]), vb = v3(root[7], root[8], root[9]), wb = v3(root[10], root[11], root[12]);
@@ -357,6 +392,18 @@ LG_DEV void write_rigid_body_state(const DevCtx* __restrict__ C, const LegModel&
     float qq[4]; mat_to_quat(mul(k.R[2], fr), qq);
     o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
     o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = k.w[2].x; o[11] = k.w[2].y; o[12] = k.w[2].z;
+    if (foot_row_lds) {       // the fused step's reward terms read the feet rows from LDS
+#pragma unroll
+      for (int i = 0; i < 13; ++i) foot_row_lds[i] = o[i];
+    }
+    if (foot_z_dst) *foot_z_dst = p.z;                  // gait_foot_z: the heights handed to GaitScheduler.step (anymal.py:107-110)
+  } else if (per_leg == 3 && (part < 0 || part == 2)) {   // no separate foot body: "the foot" is the last link
+    const float* o = rb + (size_t)(1 + per_leg * l + 2) * 13;
+    if (foot_row_lds) {
+#pragma unroll
+      for (int i = 0; i < 13; ++i) foot_row_lds[i] = o[i];
+    }
+    if (foot_z_dst) *foot_z_dst = k.O[2].z;
   }
 }
 
@@ -376,11 +423,11 @@ LG_DEV void mesh_cache_io(const DevCtx* __restrict__ C, float* cqc, int e, int l
   }
 }
 
-LG_DEV void publish_state(float* rec, const float root[13], const float q[3], const float qd[3]) {
+LG_DEV void publish_state(float* rec, const float root[13], const float q[3], const float qd[3], float extra = 0.f) {
   float4* p = reinterpret_cast<float4*>(rec);
   p[0] = make_float4(root[0], root[1], root[2], root[3]); p[1] = make_float4(root[4], root[5], root[6], root[7]);
   p[2] = make_float4(root[8], root[9], root[10], root[11]); p[3] = make_float4(root[12], q[0], q[1], q[2]);
-  p[4] = make_float4(qd[0], qd[1], qd[2], 0.f);
+  p[4] = make_float4(qd[0], qd[1], qd[2], extra);      // (slot 19: free for the caller)
 }
 LG_DEV void fetch_state(const float* rec, float root[13], float q[3], float qd[3]) {
   const float4* p = reinterpret_cast<const float4*>(rec);
@@ -393,9 +440,27 @@ LG_DEV void fetch_state(const float* rec, float root[13], float q[3], float qd[3
 // ============================================================================================ physics kernel
 // MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
 // MODE 2: lg_compute_torques only.
+// Optional second destinations of a step that feeds a rollout storage directly (lg_step_transition), see post_instance
+struct PostSink { float* obs_out; const float* values; float* rewards; float* dones; float gamma; };
+
+// the post-physics step as the tail of this kernel (lg_fused_post.h, defined below the post-physics helpers)
+struct FusedMainIn;
+LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid, int64_t step, const float* values);
+LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid);
+LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot, const LegModel& lm_, float* xs, float* UB, float* HB, int lane, int e, bool valid,
+                                  const float* root, const float* q, const float* qd, const float* tau, const float* last_qd, const V3* fbody,
+                                  const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K);
+LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out);
+LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid);
+LG_DEV bool fused_did_reset(const float* HB, int el);
+LG_DEV float* fused_foot_row(float* xs, int lane);
+LG_DEV float* fused_act_slot(float* xs, int lane, int d);
+LG_DEV bool fused_needs_heights_early(const DevCtx* __restrict__ C);
+LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__ C);
+
 template <int MODE, bool TMESH>
 __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, int nact,
-                                                      const int32_t* __restrict__ ids, int n, int act_stride) {
+                                                      const int32_t* __restrict__ ids, int n, int act_stride, int fuse, PostSink sink) {
   // act_stride: floats between consecutive action rows (12, or horizon * 12 when the rows are one step of a (n, horizon, 12) plan)
   // contact-detection split of a heightfield step with actuator waves (see the helper loop); mesh terrains: two slots a wave
   // (heightfield / plane steps; on triangle-mesh terrains every wave takes the slot pair [2 w, 2 w + 2), the main wave [0, 2))
@@ -413,6 +478,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ __attribute__((aligned(16))) float xbias[64][12];   // leg bias of wave 1: [lane][bk 3 | Fs 3 | Ns 3 | pad], three 16-byte units
   __shared__ __attribute__((aligned(16))) float xs[XS_STRIDE * 64];              // main wave's mass-matrix factors for the helpers' share of the contact set-up
   __shared__ float cqc[TMESH ? LG_MAX_CP * 4 * 64 : 1];   // mesh terrains: last closest-point query of every collision sphere
+  __shared__ int s_last_f;                                 // fused step: this workgroup is the last of the launch to arrive
+  __shared__ float hot[HC_COUNT];                          // fused step: the scalars of the post-physics tail (HC_*)
+  const int64_t fstep = C->counters[0] + 1;               // LR:123 (the statistics step of the previous launch stored it)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // row kq of the launch <-> env e (identity, or ids[kq] for subset stepping: main-only / rollout-only steps)
   const int kq = blockIdx.x * EPB + (lane >> 2);
@@ -424,6 +492,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const lg_config& g = C->cfg;
   const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
   if (wv == 0) fill_leg_model(lmod, m, &C->cfg, lane);
+  if (fuse && wv == 1) for (int i = lane; i < HC_COUNT; i += 64) hot[i] = C->hot[i];
   lds_barrier();
   const LegModel lm_{lmod, l};
 
@@ -541,15 +610,39 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
         lstm_recurrent_part(wlstm + zero, h0, h1, lpre);
       }
+      if (fuse && sub + 1 == nsub) {                   // ... in the last substep: what the post-physics tail needs from HBM
+        if (net) *fused_act_slot(xs, lane, d) = a;     // (the mass-factor table is dead after (A3): the env rows live there)
+        fused_prefetch(C, xs, &xbias[0][0], blockIdx.x, n, (wv - 1) * 64 + lane, fstep, sink.values);
+      }
     }
     lds_barrier();                                     // (F) main wave has published the final state of the step
     if (TMESH && valid) mesh_cache_io<false>(C, cqc, e, l, lane, 2 * wv);
-    if (valid) {                                         // wave w stores link w-1 of every leg (+ base / + foot body)
-      float r13[13], qq[3], qdd[3];
-      fetch_state(xst[lane], r13, qq, qdd);
-      write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, wv - 1);
+    bool zero_state = false;
+    if (!fuse) {
+      if (valid) {                                       // wave w stores link w-1 of every leg (+ base / + foot body)
+        float r13[13], qq[3], qdd[3];
+        fetch_state(xst[lane], r13, qq, qdd);
+        write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, wv - 1);
+      }
+    } else {
+      // fused step: first what the rest of the tail waits for (the height scan; the feet rows when a reward term reads them),
+      // the rigid-body rows -- stores nobody in this launch reads -- come last
+      const bool feet_early = fused_needs_feet_rows(C);  // (kernel-uniform)
+      if (feet_early && wv == 3 && valid) {
+        float r13[13], qq[3], qdd[3];
+        fetch_state(xst[lane], r13, qq, qdd);
+        write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane));   // (gait_foot_z is stored late: the serial part still reads the old one)
+      }
+      fused_height_scan(C, xst, cst, blockIdx.x, n, (wv - 1) * 64 + lane);
+      if (feet_early || fused_needs_heights_early(C)) lds_barrier();   // (G1) only when the serial part reads a helper's product
+      lds_barrier();                                   // (G2) serial part + height scan done
+      zero_state = fused_did_reset(cst, lane >> 2);     // anymal.py:78-82: a reset env starts from the zero LSTM state
     }
     if (valid && net) {
+      if (zero_state) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { h0[i] = 0.f; c0[i] = 0.f; h1[i] = 0.f; c1[i] = 0.f; }
+      }
       float4* p = (float4*)(C->sea_h + row * 8);
       p[0] = make_float4(h0[0], h0[1], h0[2], h0[3]); p[1] = make_float4(h0[4], h0[5], h0[6], h0[7]);
       p = (float4*)(C->sea_c + row * 8);
@@ -560,6 +653,19 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       p[0] = make_float4(c1[0], c1[1], c1[2], c1[3]); p[1] = make_float4(c1[4], c1[5], c1[6], c1[7]);
       C->actions[(size_t)e * 12 + d] = a;
       C->torques[(size_t)e * 12 + d] = xtau[j][lane];
+    }
+    if (fuse) {
+      const bool last = fused_writeback_obs(C, hot, xs, cst, blockIdx.x, n, threadIdx.x, fstep, nullptr, sink.obs_out);
+      if (valid && !(fused_needs_feet_rows(C) && wv == 3)) {     // rigid-body rows of the post-physics (pre-reset) pose, LR:118-120
+        float r13[13], qq[3], qdd[3];
+        fetch_state(xst[lane], r13, qq, qdd);
+        write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled) ? C->gait_foot_z + (size_t)e * 4 + l : nullptr);
+      } else if (valid && g.gait_enabled) {
+        C->gait_foot_z[(size_t)e * 4 + l] = fused_foot_row(xs, lane)[2];
+      }
+      if (threadIdx.x == 0) s_last_f = last ? 1 : 0;
+      __syncthreads();
+      if (s_last_f) fused_finalize(C, gridDim.x, threadIdx.x);
     }
     return;
   }
@@ -692,8 +798,47 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   }
   STAMP(9);
   if (helpers) {
-    publish_state(xst[lane], s.root, s.q, s.qd);
+    float qn = 0.f;
+    if (fuse) {      // the height scan's yaw-only quaternion (math_utils.quat_apply_yaw), normalised here once per env instead of once per scan point
+      const float qz = s.root[5], qw = s.root[6];
+      const float nrm = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
+      qn = (l == 0 ? qz : qw) / nrm;
+    }
+    publish_state(xst[lane], s.root, s.q, s.qd, qn);
     lds_barrier();                                     // (F) final state visible to the helper waves, which write the body states
+  }
+  if (fuse) {
+    // ---- fused step: the post-physics step of the workgroup's envs, from the registers of this wave (lg_fused_post.h)
+    fused_main_and_serial(C, hot, lm_, xs, &xbias[0][0], cst, lane, e, valid, s.root, s.q, s.qd, tau, last_qd, fbody, split ? nullptr : act, fault, fstep, stamps, sink);
+#ifdef LG_STAMPS
+    stamp_t = __builtin_amdgcn_s_memtime();
+#endif
+    if (valid) {
+      if (TMESH && helpers) mesh_cache_io<false>(C, cqc, e, l, lane, 0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) if (!split) C->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
+      const int per_leg = C->per_leg, B = C->B;
+      float* cf = C->cforce + (size_t)e * B * 3;
+      if (l == 0) { cf[0] = fbody[0].x; cf[1] = fbody[0].y; cf[2] = fbody[0].z; }
+      float* cl = cf + (size_t)(1 + per_leg * l) * 3;
+      V3 last = fbody[3];
+      if (per_leg == 3) last = last + fbody[4];
+      cl[0] = fbody[1].x; cl[1] = fbody[1].y; cl[2] = fbody[1].z;
+      cl[3] = fbody[2].x; cl[4] = fbody[2].y; cl[5] = fbody[2].z;
+      cl[6] = last.x; cl[7] = last.y; cl[8] = last.z;
+      if (per_leg == 4) { cl[9] = fbody[4].x; cl[10] = fbody[4].y; cl[11] = fbody[4].z; }
+    }
+    STAMP(12);
+    const bool last_wg = fused_writeback_obs(C, hot, xs, cst, blockIdx.x, n, threadIdx.x, fstep, stamps, sink.obs_out);
+#ifdef LG_STAMPS
+    stamp_t = __builtin_amdgcn_s_memtime();
+#endif
+    STAMP(13);
+    if (threadIdx.x == 0) s_last_f = last_wg ? 1 : 0;
+    __syncthreads();
+    if (s_last_f) fused_finalize(C, gridDim.x, threadIdx.x);
+    STAMP(14);
+    return;
   }
   if (!valid) return;
   if (TMESH && helpers) mesh_cache_io<false>(C, cqc, e, l, lane, 0);
@@ -744,6 +889,7 @@ struct EnvView {
   float *root, *dof, *cmd, *air, *ctime, *blv, *bav, *pg;
   const float *tq, *act, *lact, *ldv, *cf, *rb, *bla;
   uint8_t* lastc;
+  int feet_rows = 0;      // rb holds only the four feet rows (foot f at rb + 13 f) instead of all bodies: the fused step's rows
 };
 LG_DEV EnvView global_view(const DevCtx* __restrict__ C, int e) {
   EnvView V;
@@ -870,6 +1016,7 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
   const float cmdn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
 #define SQ(x) ((x) * (x))
 #define FNORM(b) sqrtf(SQ(cf[3 * (b)]) + SQ(cf[3 * (b) + 1]) + SQ(cf[3 * (b) + 2]))
+#define FRB(f, k) rb[(size_t)(V.feet_rows ? (f) : m.feet_indices[f]) * 13 + (k)]      /* component k of foot f's rigid-body row */
   switch (id) {
     case LG_REW_LIN_VEL_Z: return SQ(blv[2]);
     case LG_REW_ANG_VEL_XY: return SQ(bav[0]) + SQ(bav[1]);
@@ -883,7 +1030,7 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     }
     case LG_REW_BASE_FOOT_HEIGHT: {
       float s = 0.f; int n = 0;
-      for (int f = 0; f < 4; ++f) if (ctime[f] > 1e-3f) { s += rb[(size_t)m.feet_indices[f] * 13 + 2]; ++n; }
+      for (int f = 0; f < 4; ++f) if (ctime[f] > 1e-3f) { s += FRB(f, 2); ++n; }
       float est = n > 0 ? s / (float)n : root[2] - g.base_height_target;
       return SQ((root[2] - est) - g.base_height_target);
     }
@@ -902,12 +1049,12 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     }
     case LG_REW_FEET_STUMBLE_LIFTUP: {
       float s = 0.f;
-      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool st = sqrtf(SQ(cf[3 * b]) + SQ(cf[3 * b + 1])) > 5.f * fabsf(cf[3 * b + 2]); s += (st ? 1.f : 0.f) * rb[(size_t)b * 13 + 9]; }
+      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool st = sqrtf(SQ(cf[3 * b]) + SQ(cf[3 * b + 1])) > 5.f * fabsf(cf[3 * b + 2]); s += (st ? 1.f : 0.f) * FRB(f, 9); }
       return s;
     }
     case LG_REW_FEET_SLIP: {
       float s = 0.f;
-      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool cfl = (cf[3 * b + 2] > 1.f) || lastc[f]; float vn = sqrtf(SQ(rb[(size_t)b * 13 + 7]) + SQ(rb[(size_t)b * 13 + 8])); s += (cfl ? 1.f : 0.f) * SQ(vn); }
+      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool cfl = (cf[3 * b + 2] > 1.f) || lastc[f]; float vn = sqrtf(SQ(FRB(f, 7)) + SQ(FRB(f, 8))); s += (cfl ? 1.f : 0.f) * SQ(vn); }
       return s;
     }
     case LG_REW_JUMP_AIR: {
@@ -1132,8 +1279,6 @@ struct alignas(16) PostLds {
 //   obs_out[k, :]  = the observation row (RolloutStorage.observations[t + 1]: what the policy acts on next),
 //   rewards[k]     = rew + gamma * (values[k] * time_out)   (PPO.process_env_step, ppo.py:179-183: three roundings),
 //   dones[k]       = reset flag as float (ppo.py:165).
-struct PostSink { float* obs_out; const float* values; float* rewards; float* dones; float gamma; };
-
 template <bool FUSED>
 LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restrict__ ids, int n, int mode, float* __restrict__ rew_out,
                           int rew_stride, PostLds& L, int inst, int ninst, const PostSink K) {
@@ -1620,6 +1765,42 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   post_instance<false>(C, ids, n, mode, rew_out, rew_stride, L, (int)blockIdx.x, (int)gridDim.x, sink);
 }
 
+#include "lg_fused_post.h"
+// glue between physics_kernel (which only sees declarations) and the tail
+LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid) { finalize_from_acc(C, nblocks, 1, tid, false); }
+LG_DEV bool fused_did_reset(const float* HB, int el) { return HB[FH_MISC + el * FM_STRIDE + FM_DID_RESET] != 0.f; }
+LG_DEV float* fused_foot_row(float* xs, int lane) { return xs + (lane >> 2) * FS_STRIDE + FS_FRB + 13 * (lane & 3); }
+LG_DEV float* fused_act_slot(float* xs, int lane, int d) { return xs + (lane >> 2) * FS_STRIDE + FS_ACT + d; }
+LG_DEV bool fused_needs_heights_early(const DevCtx* __restrict__ C) {
+  return ((C->rew_term_mask >> LG_REW_BASE_HEIGHT) & 1u) != 0u && C->cfg.measure_heights && C->P > 0;
+}
+LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__ C) {    // reward terms that read the feet's rigid-body rows
+  return (C->rew_term_mask & ((1u << LG_REW_BASE_FOOT_HEIGHT) | (1u << LG_REW_FEET_STUMBLE_LIFTUP) | (1u << LG_REW_FEET_SLIP))) != 0u;
+}
+LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot, const LegModel& lm_, float* xs, float* UB, float* HB, int lane, int e, bool valid,
+                                  const float* root, const float* q, const float* qd, const float* tau, const float* last_qd, const V3* fbody,
+                                  const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K) {
+  STAMP_DECL
+  const int l = lane & 3, el = lane >> 2;
+  float* S = xs + el * FS_STRIDE;
+  if (act_or_null) {        // PD-controlled robot with helper waves: the clipped actions are in this wave's registers
+#pragma unroll
+    for (int j = 0; j < 3; ++j) S[FS_ACT + 3 * l + j] = act_or_null[j];
+  }
+  float feat[F_COUNT];
+  const FusedMainIn in{root, q, qd, tau, last_qd, fbody, fault};
+  fused_main_part1(C, hot, lm_, S, l, in, feat);
+  STAMP(11);
+  if (fused_needs_feet_rows(C) || fused_needs_heights_early(C)) lds_barrier();   // (G1) only when the serial part reads a helper's product
+  STAMP(19);
+  if (l == 0 && valid)
+    fused_env_serial(C, hot, e, S, UB + FU_U + el * LG_RS_NOISE, UB + FU_PRE + el * FU_PRE_STRIDE, HB + FH_MISC + el * FM_STRIDE,
+                     HB + FH_HEIGHTS + el * MAX_P, feat, fault, step, K);
+  STAMP(20);
+  lds_barrier();                                         // (G2) serial part + height scan done
+  STAMP(21);
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step, int use_flags) {
   finalize_step(C, nblocks, bump_step, threadIdx.x, use_flags != 0);
 }
@@ -1811,6 +1992,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.per_leg = 3 + model->has_foot_body;
   pack_lstm_weights(h.lstm_w, cfg->actuator_net);
   reward_meta(h);
+  hot_config(h);
   h.mesh_cache = nullptr;
   if (ter->mesh_type == LG_MESH_TRIMESH) {
     const size_t nf = (size_t)cfg->num_envs * 4 * LG_MAX_CP * 4;
@@ -1887,6 +2069,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   if (hipMemcpy(c->d, &h, sizeof(DevCtx), hipMemcpyHostToDevice) != hipSuccess) return fail("copy ctx failed");
   if (hipDeviceSynchronize() != hipSuccess) return fail("device sync failed");
   if (const char* ev = getenv("LG_SPLIT")) c->split = atoi(ev) != 0;
+  if (const char* ev = getenv("LG_FUSE")) c->fuse = atoi(ev) != 0;
   return c;
 }
 
@@ -1923,7 +2106,11 @@ static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t*
   return LG_OK;
 }
 
-static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = 12) {
+// fuse: the post-physics step runs as the tail of the physics kernel (full steps of all envs with helper waves; LG_FUSE=0 keeps
+// the two-launch path, which every split / subset / rollout entry point uses anyway)
+static bool can_fuse(const lg_ctx* c) { return c->fuse && (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) && c->h.P <= MAX_P; }
+static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = 12, bool fuse = false,
+                           PostSink sink = PostSink{nullptr, nullptr, nullptr, nullptr, 0.f}) {
   const int nb = (n + EPB - 1) / EPB;
   // helper waves (leg bias, contact detection, a share of the contact set-up; with the actuator network also its three
   // joints per leg): always, unless LG_SPLIT=0 (diagnostic) -- and even then on triangle-mesh terrains, whose contact
@@ -1932,9 +2119,9 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
   const int nact = (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) ? 3 : 0;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
-    hipLaunchKernelGGL((physics_kernel<0, true>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride);
+    hipLaunchKernelGGL((physics_kernel<0, true>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
   else
-    hipLaunchKernelGGL((physics_kernel<0, false>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride);
+    hipLaunchKernelGGL((physics_kernel<0, false>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
 }
 
 int lg_step(lg_ctx* c, const float* actions, void* stream) {
@@ -1948,8 +2135,14 @@ int lg_step(lg_ctx* c, const float* actions, void* stream) {
     c->prof_calls++;
   }
   if (ev) (void)hipEventRecord(ev[0], st);
-  launch_physics(c, st, actions, nullptr, c->h.N);
+  const bool fuse = can_fuse(c);
+  launch_physics(c, st, actions, nullptr, c->h.N, 12, fuse);
   if (ev) (void)hipEventRecord(ev[1], st);
+  if (fuse) {                                            // one launch per policy step
+    if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
+    HIP_TRY(c, hipGetLastError());
+    return LG_OK;
+  }
   return launch_post(c, st, ev, nullptr, c->h.N, 0);
 }
 
@@ -1961,8 +2154,14 @@ int lg_step_transition(lg_ctx* c, const float* actions, float* next_observations
   DeviceScope ds_(c->device);
   if (!actions || !values || !rewards || !dones) { c->err = "lg_step_transition: null row"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
+  const PostSink sink{next_observations, values, rewards, dones, gamma};
+  if (can_fuse(c)) {
+    launch_physics(c, st, actions, nullptr, c->h.N, 12, true, sink);
+    HIP_TRY(c, hipGetLastError());
+    return LG_OK;
+  }
   launch_physics(c, st, actions, nullptr, c->h.N);
-  return launch_post(c, st, nullptr, nullptr, c->h.N, 0, nullptr, 0, PostSink{next_observations, values, rewards, dones, gamma});
+  return launch_post(c, st, nullptr, nullptr, c->h.N, 0, nullptr, 0, sink);
 }
 
 int lg_step_subset(lg_ctx* c, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream) {
@@ -1988,7 +2187,8 @@ int lg_set_reward_terms(lg_ctx* c, int32_t num_terms, const int32_t* term_ids, c
   HIP_TRY(c, hipMemcpyAsync((char*)c->d + (lo - base), lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemcpyAsync((char*)c->d + ((char*)&c->h.K - base), &c->h.K, sizeof(int), hipMemcpyHostToDevice, st));
   reward_meta(c->h);
-  HIP_TRY(c, hipMemcpyAsync((char*)c->d + ((char*)&c->h.rew_term_mask - base), &c->h.rew_term_mask, 4 * sizeof(int), hipMemcpyHostToDevice, st));
+  hot_config(c->h);
+  HIP_TRY(c, hipMemcpyAsync((char*)c->d + ((char*)&c->h.rew_term_mask - base), &c->h.rew_term_mask, 4 * sizeof(int) + sizeof(c->h.hot), hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemsetAsync(c->h.ep_sums, 0, (size_t)LG_MAX_REWARD_TERMS * c->h.N * sizeof(float), st));
   return LG_OK;
 }
@@ -2159,7 +2359,7 @@ int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
   DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
-  hipLaunchKernelGGL((physics_kernel<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N, 12);
+  hipLaunchKernelGGL((physics_kernel<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N, 12, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -2169,9 +2369,9 @@ int lg_simulate(lg_ctx* c, void* stream) {
   DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
-    hipLaunchKernelGGL((physics_kernel<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, 12);
+    hipLaunchKernelGGL((physics_kernel<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, 12, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
   else
-    hipLaunchKernelGGL((physics_kernel<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, 12);
+    hipLaunchKernelGGL((physics_kernel<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, 12, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }

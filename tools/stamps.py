@@ -22,10 +22,10 @@ print('lib', nat.LIB_PATH, 'rc', rc)
 names = {15: "substep prologue", 0: "publish q/qd | inline actuator", 1: "kinematics", 2: "bias (RNEA)", 3: "CRBA+Schur+chol",
          29: "own contact detection", 5: "wait at rendezvous (A2) + slot mask", 6: "contact pass B (setup)", 4: "wait for torques (barrier B)", 7: "unconstrained + PGS",
          8: "limits+forces+integrate", 9: "fault guard", 10: "write-back + final FK",
-         11: "POST: stage rows in LDS", 12: "POST: height scan", 19: "POST 2.1: rotations + per-DOF features", 20: "POST 2.2: feature sums + callback + termination",
-         21: "POST 2.3: reward terms + sums (+ reset)", 13: "POST 2.4: proprio obs entries", 14: "POST: partials + obs rows"}
+         11: "TAIL: main part 1 (rows, features, rotations)", 19: "TAIL: wait at (G1)", 20: "TAIL: serial part (callback, rewards, reset)",
+         21: "TAIL: wait at (G2)", 12: "TAIL: state stores", 13: "TAIL: write-back + obs rows", 14: "TAIL: arrival + finalize"}
 tot = sum(out[:16]) + sum(out[19:22]) + out[29]
-hn = {22: "HELPER w2: wait at (A)", 23: "HELPER: kinematics", 24: "HELPER: contact detect (4 slots)", 25: "HELPER: LSTM joint", 26: "HELPER: wait at (A2)", 27: "HELPER: contact set-up share"}
+hn = {22: "TAIL wb: row stores (main wave; helper stamp 22-24 unused in this build)", 23: "TAIL wb: stats + store drain + ticket", 24: "TAIL wb: obs rows", 25: "HELPER: LSTM joint", 26: "HELPER: wait at (A2)", 27: "HELPER: contact set-up share"}
 for k, n in hn.items():
     print(f"{n:34s} per substep {out[k] / (301 * 4):9.0f} cycles")
 print('active slots per 16-lane group (4 envs) per substep', out[28] / max(out[17], 1) / 4)
