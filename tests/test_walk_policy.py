@@ -159,3 +159,19 @@ def test_reference_policy_walks_on_the_hip_env(payload):
         json.dump(stats, f)
     env.core.close()
     check(stats, payload)
+
+
+@pytest.mark.gpu
+def test_play_script_runs_the_reference_checkpoint(tmp_path):
+    """`scripts/play.py` (reference scripts/play.py:42-117) end to end: registry -> play overrides -> env -> checkpoint in rsl_rl's
+    save format -> `NativeActorCritic.act_inference` -> stepping loop."""
+    import torch
+    from extended_legged_gym_amd.scripts.play import play
+    from extended_legged_gym_amd.utils.helpers import get_args
+    z = load_policy_fixture()
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    path = str(tmp_path / "model_200.pt")
+    torch.save({"model_state_dict": sd, "iter": 200, "infos": None}, path)
+    stats = play(get_args(["--task", "anymal_c_flat", "--headless", "--sim_device", "cuda:0"]), policy_path=path, num_steps=150)
+    assert stats["steps"] == 150 and np.isfinite(stats["mean_reward"]) and stats["mean_reward"] > 0.0
+    assert stats["mean_tracking_error"] < 0.6            # commands up to 1 m/s are followed, resampled every 4 s
