@@ -5,7 +5,7 @@ header and checks every enum value and struct size against this file so the two 
 """
 import ctypes as C
 
-LG_ABI_VERSION = 1
+LG_ABI_VERSION = 2
 LG_NUM_LEGS, LG_JOINTS_PER_LEG, LG_NUM_DOF = 4, 3, 12
 LG_MAX_CP, LG_MAX_BODIES, LG_MAX_REWARD_TERMS, LG_MAX_INDEX_LIST = 8, 17, 32, 16
 LG_LSTM_NPARAM = 969
@@ -27,7 +27,10 @@ REWARD_TERMS = [
     "four_footup", "gait_2_step", "gait_scheduler", "jump_air", "lin_vel_z", "orientation", "stand_still", "termination",
     "torque_limits", "torques", "tracking_ang_vel", "tracking_lin_vel",
     # class-specific variants: selected through an env class's `reward_term_variants`, never named in a config
-    "orientation_load_adapt"]
+    "orientation_load_adapt",
+    # StandAnymal / StandGo2 only (anymal.py:301-308); the other overrides of those classes come with lg_config.reward_class
+    "penalty_in_the_air"]
+REWARD_CLASSES = {"base": 0, "stand": 1}                   # enum lg_reward_class
 REWARD_TERM_ID = {n: i for i, n in enumerate(REWARD_TERMS)}
 
 TENSOR_NAMES = [
@@ -88,7 +91,7 @@ class lg_config(C.Structure):
         ("command_curriculum", i32), ("max_curriculum", f32),
         ("push_robots", i32), ("push_interval", i32), ("max_push_vel_xy", f32),
         ("num_reward_terms", i32), ("reward_term_ids", i32 * LG_MAX_REWARD_TERMS),
-        ("reward_scales", f32 * LG_MAX_REWARD_TERMS), ("only_positive_rewards", i32),
+        ("reward_scales", f32 * LG_MAX_REWARD_TERMS), ("only_positive_rewards", i32), ("reward_class", i32),
         ("tracking_sigma", f32), ("base_height_target", f32), ("max_contact_force", f32), ("soft_dof_vel_limit", f32),
         ("soft_torque_limit", f32),
         ("dof_pos_limits", (f32 * 2) * 12),

@@ -187,8 +187,9 @@ LG_DEV void fused_reward_all(const DevCtx* __restrict__ C, const float* hot, uns
 #define ON(ID) (((mask >> (ID)) & 1u) != 0u)
 #define PUT(ID, expr) if (ON(ID)) { const float v_ = (expr); RAW0[ID] = v_; RAW1[ID] = v_; }
   PUT(LG_REW_LIN_VEL_Z, SQ(R.blv[2]))
-  PUT(LG_REW_ANG_VEL_XY, SQ(R.bav[0]) + SQ(R.bav[1]))
-  PUT(LG_REW_ORIENTATION, SQ(R.pg[0]) + SQ(R.pg[1]))
+  const bool stand = HI(HC_STAND) != 0;     // StandAnymal / StandGo2 overrides (anymal.py:264-308), see enum lg_reward_class
+  PUT(LG_REW_ANG_VEL_XY, stand ? SQ(R.bav[1]) + SQ(R.bav[2]) : SQ(R.bav[0]) + SQ(R.bav[1]))
+  PUT(LG_REW_ORIENTATION, stand ? SQ(R.pg[1]) + SQ(R.pg[2]) : SQ(R.pg[0]) + SQ(R.pg[1]))
   PUT(LG_REW_ORIENTATION_LOAD_ADAPT, SQ(R.pg[0] - R.bla[0] / 9.81f) + SQ(R.pg[1] - R.bla[1] / 9.81f))
   if (ON(LG_REW_BASE_HEIGHT)) {
     float s = R.rootz;
@@ -199,8 +200,8 @@ LG_DEV void fused_reward_all(const DevCtx* __restrict__ C, const float* hot, uns
   PUT(LG_REW_DOF_POS_LIMITS, feat[F_POSLIM]) PUT(LG_REW_DOF_VEL_LIMITS, feat[F_VELLIM]) PUT(LG_REW_TORQUE_LIMITS, feat[F_TQLIM])
   PUT(LG_REW_COLLISION, R.ncoll)
   PUT(LG_REW_STAND_STILL, feat[F_STILL] * (cmdn < 0.1f ? 1.f : 0.f))
-  PUT(LG_REW_TRACKING_LIN_VEL, expf(-(SQ(R.cmd[0] - R.blv[0]) + SQ(R.cmd[1] - R.blv[1])) / HF(HC_SIGMA)))
-  PUT(LG_REW_TRACKING_ANG_VEL, expf(-SQ(R.cmd[2] - R.bav[2]) / HF(HC_SIGMA)))
+  PUT(LG_REW_TRACKING_LIN_VEL, expf(-(stand ? SQ(R.cmd[0] + R.blv[1]) + SQ(R.cmd[1] + R.blv[2]) : SQ(R.cmd[0] - R.blv[0]) + SQ(R.cmd[1] - R.blv[1])) / HF(HC_SIGMA)))
+  PUT(LG_REW_TRACKING_ANG_VEL, expf(-SQ(R.cmd[2] - (stand ? R.bav[0] : R.bav[2])) / HF(HC_SIGMA)))
   if (ON(LG_REW_FEET_STUMBLE) || ON(LG_REW_FEET_STUMBLE_LIFTUP)) {
     bool any = false; float s = 0.f;
 #pragma unroll
@@ -264,16 +265,19 @@ LG_DEV void fused_reward_all(const DevCtx* __restrict__ C, const float* hot, uns
       const bool on = cmdn > 0.1f || fabsf(other) >= 0.05f;
       RAW[LG_REW_GAIT_2_STEP] = (sr + ar) * (on ? 1.f : 0.f);
     }
-    if (pass == 0 && ON(LG_REW_FEET_AIR_TIME)) {   // RM:150-163, stateful
+    if (ON(LG_REW_PENALTY_IN_THE_AIR))             // anymal.py:301-308
+      RAW[LG_REW_PENALTY_IN_THE_AIR] = ((R.cfz[1] > 1.f) || R.lastc[1] || (R.cfz[3] > 1.f) || R.lastc[3]) ? 0.f : 1.f;
+    if (pass == 0 && ON(LG_REW_FEET_AIR_TIME)) {   // RM:150-163, stateful; stand classes: feet 1 and 3, feet_contact_time untouched
       float s = 0.f;
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
+        if (stand && (f & 1) == 0) continue;
         const bool contact = R.cfz[f] > 1.f; const bool cfl = contact || R.lastc[f];
         R.lastc[f] = contact;
         const float first = (R.air[f] > 0.f && cfl) ? 1.f : 0.f;
         const float a = R.air[f] + dt, ct = R.ct[f] + dt;
         s += (a - 0.5f) * first;
-        R.air[f] = a * (cfl ? 0.f : 1.f); R.ct[f] = ct * (cfl ? 1.f : 0.f);
+        R.air[f] = a * (cfl ? 0.f : 1.f); if (!stand) R.ct[f] = ct * (cfl ? 1.f : 0.f);
       }
       RAW0[LG_REW_FEET_AIR_TIME] = RAW1[LG_REW_FEET_AIR_TIME] = s * (cmdn > 0.1f ? 1.f : 0.f);
     }

@@ -32,7 +32,7 @@
 // LDS at kernel start): lg_config is 8 KB (the actuator weights sit in the middle of it) and the tail touches ~20 different
 // 64-byte lines of it, each a scalar-cache miss on first touch, serialised by the tail's dependent chain.
 enum { HC_DT = 0, HC_K, HC_KFAT, HC_KTERM, HC_TERM_SCALE, HC_TERM_MASK, HC_RESAMPLING_STEPS, HC_HEADING, HC_PUSH, HC_PUSH_INTERVAL, HC_MAX_PUSH,
-       HC_FLIP, HC_MAX_EPLEN, HC_ONLY_POS, HC_CURRICULUM, HC_GAIT_ON, HC_GAIT_PERIOD, HC_GAIT_SWING, HC_GAIT_PHASE /* 4 */, HC_SIGMA = HC_GAIT_PHASE + 4,
+       HC_FLIP, HC_MAX_EPLEN, HC_ONLY_POS, HC_STAND, HC_CURRICULUM, HC_GAIT_ON, HC_GAIT_PERIOD, HC_GAIT_SWING, HC_GAIT_PHASE /* 4 */, HC_SIGMA = HC_GAIT_PHASE + 4,
        HC_BH_TARGET, HC_MAX_CF, HC_MEASURE_H, HC_P, HC_FEET /* 4 */, HC_NPEN = HC_FEET + 4, HC_PEN /* 16 */, HC_NTERM = HC_PEN + LG_MAX_INDEX_LIST,
        HC_TERMB /* 16 */, HC_SOFT_VEL = HC_TERMB + LG_MAX_INDEX_LIST, HC_SOFT_TQ, HC_NUM_OBS, HC_ADD_NOISE, HC_INJECT, HC_OS_LIN, HC_OS_ANG, HC_OS_POS,
        HC_OS_VEL, HC_OS_H, HC_CLIP_OBS, HC_SEED_LO, HC_SEED_HI, HC_NUM_EXTRA, HC_IDS /* 32 */, HC_SCALES = HC_IDS + LG_MAX_REWARD_TERMS /* 32 */,
@@ -106,7 +106,7 @@ static void hot_config(DevCtx& h) {
   F(HC_DT, g.sim_dt * g.decimation); I(HC_K, g.num_reward_terms); I(HC_KFAT, h.rew_kfat); I(HC_KTERM, h.rew_kterm); F(HC_TERM_SCALE, h.rew_term_scale);
   U(HC_TERM_MASK, h.rew_term_mask); I(HC_RESAMPLING_STEPS, g.resampling_steps); I(HC_HEADING, g.heading_command); I(HC_PUSH, g.push_robots);
   I(HC_PUSH_INTERVAL, g.push_interval); F(HC_MAX_PUSH, g.max_push_vel_xy); I(HC_FLIP, g.terminate_on_flip); F(HC_MAX_EPLEN, g.max_episode_length);
-  I(HC_ONLY_POS, g.only_positive_rewards); I(HC_CURRICULUM, g.curriculum); I(HC_GAIT_ON, g.gait_enabled); F(HC_GAIT_PERIOD, g.gait_period);
+  I(HC_ONLY_POS, g.only_positive_rewards); I(HC_STAND, g.reward_class == LG_RC_STAND); I(HC_CURRICULUM, g.curriculum); I(HC_GAIT_ON, g.gait_enabled); F(HC_GAIT_PERIOD, g.gait_period);
   F(HC_GAIT_SWING, g.gait_swing_height);
   for (int f = 0; f < 4; ++f) { F(HC_GAIT_PHASE + f, g.gait_foot_phases[f]); I(HC_FEET + f, m.feet_indices[f]); }
   F(HC_SIGMA, g.tracking_sigma); F(HC_BH_TARGET, g.base_height_target); F(HC_MAX_CF, g.max_contact_force); I(HC_MEASURE_H, g.measure_heights);
@@ -1014,13 +1014,14 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
   const float* cf = V.cf; const float* rb = V.rb;
   float* air = V.air; float* ctime = V.ctime; uint8_t* lastc = V.lastc;
   const float cmdn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
+  const bool stand = g.reward_class == LG_RC_STAND;
 #define SQ(x) ((x) * (x))
 #define FNORM(b) sqrtf(SQ(cf[3 * (b)]) + SQ(cf[3 * (b) + 1]) + SQ(cf[3 * (b) + 2]))
 #define FRB(f, k) rb[(size_t)(V.feet_rows ? (f) : m.feet_indices[f]) * 13 + (k)]      /* component k of foot f's rigid-body row */
   switch (id) {
     case LG_REW_LIN_VEL_Z: return SQ(blv[2]);
-    case LG_REW_ANG_VEL_XY: return SQ(bav[0]) + SQ(bav[1]);
-    case LG_REW_ORIENTATION: return SQ(pg[0]) + SQ(pg[1]);
+    case LG_REW_ANG_VEL_XY: return stand ? SQ(bav[1]) + SQ(bav[2]) : SQ(bav[0]) + SQ(bav[1]);        // anymal.py:264-266
+    case LG_REW_ORIENTATION: return stand ? SQ(pg[1]) + SQ(pg[2]) : SQ(pg[0]) + SQ(pg[1]);             // anymal.py:268-271
     case LG_REW_ORIENTATION_LOAD_ADAPT:   // base perpendicular to gravity + acceleration (anymal.py:140-143)
       return SQ(pg[0] - V.bla[0] / 9.81f) + SQ(pg[1] - V.bla[1] / 9.81f);
     case LG_REW_BASE_HEIGHT: {
@@ -1062,17 +1063,22 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
       for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool cfl = (cf[3 * b + 2] > 1.f) || lastc[f]; s += (cfl ? 0.f : 1.f) * (air[f] - 0.5f); }
       return fmaxf(s - 2.f, 0.f);
     }
-    case LG_REW_FEET_AIR_TIME: {   // RM:150-163, stateful
+    case LG_REW_FEET_AIR_TIME: {   // RM:150-163, stateful; the stand classes run it on feet 1 and 3 only and leave feet_contact_time alone (anymal.py:287-299)
       float s = 0.f;
-      for (int f = 0; f < 4; ++f) {
+      for (int f = stand ? 1 : 0; f < 4; f += stand ? 2 : 1) {
         int b = m.feet_indices[f]; bool contact = cf[3 * b + 2] > 1.f; bool cfl = contact || lastc[f];
         lastc[f] = contact ? 1 : 0;
         float first = (air[f] > 0.f && cfl) ? 1.f : 0.f;
         float a = air[f] + dt, ct = ctime[f] + dt;
         s += (a - 0.5f) * first;
-        air[f] = a * (cfl ? 0.f : 1.f); ctime[f] = ct * (cfl ? 1.f : 0.f);
+        air[f] = a * (cfl ? 0.f : 1.f); if (!stand) ctime[f] = ct * (cfl ? 1.f : 0.f);
       }
       return s * (cmdn > 0.1f ? 1.f : 0.f);
+    }
+    case LG_REW_PENALTY_IN_THE_AIR: {   // anymal.py:301-308
+      bool any = false;
+      for (int f = 1; f < 4; f += 2) any |= (cf[3 * m.feet_indices[f] + 2] > 1.f) || lastc[f];
+      return any ? 0.f : 1.f;
     }
     case LG_REW_FEET_CONTACT_FORCES: { float s = 0.f; for (int f = 0; f < 4; ++f) s += fmaxf(fn[m.feet_indices[f]] - g.max_contact_force, 0.f); return s; }
     case LG_REW_GAIT_2_STEP: {
@@ -1087,8 +1093,9 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     case LG_REW_FOUR_FOOTUP: { bool all = true; for (int f = 0; f < 4; ++f) all &= cf[3 * m.feet_indices[f] + 2] < 1.f; return 0.1f * (all ? 1.f : 0.f); }
     case LG_REW_TERMINATION: return (C->reset_buf[e] && !C->time_out[e]) ? 1.f : 0.f;
     case LG_REW_STAND_STILL: return feat[F_STILL] * (cmdn < 0.1f ? 1.f : 0.f);
-    case LG_REW_TRACKING_LIN_VEL: return expf(-(SQ(cmd[0] - blv[0]) + SQ(cmd[1] - blv[1])) / g.tracking_sigma);
-    case LG_REW_TRACKING_ANG_VEL: return expf(-SQ(cmd[2] - bav[2]) / g.tracking_sigma);
+    case LG_REW_TRACKING_LIN_VEL:       // stand: commands against -base_lin_vel[1:] (anymal.py:277-281)
+      return expf(-(stand ? SQ(cmd[0] + blv[1]) + SQ(cmd[1] + blv[2]) : SQ(cmd[0] - blv[0]) + SQ(cmd[1] - blv[1])) / g.tracking_sigma);
+    case LG_REW_TRACKING_ANG_VEL: return expf(-SQ(cmd[2] - (stand ? bav[0] : bav[2])) / g.tracking_sigma);   // anymal.py:283-286
     case LG_REW_GAIT_SCHEDULER: {   // gait_scheduler.py:74-81 on the foot heights / phase stored by the previous step
       if (!g.gait_enabled || step <= 1) return 0.f;
       float gi = C->gait_idx[e]; const float* fz = C->gait_foot_z + (size_t)e * 4; float s = 0.f;

@@ -2,14 +2,16 @@
 classes are importable from here for task-specific configs."""
 from extended_legged_gym_amd.utils.task_registry import task_registry
 from .base.legged_robot import LeggedRobot
-from .anymal_c.anymal import Anymal, LoadAdaptAnymal
+from .anymal_c.anymal import Anymal, AnymalStudent, LoadAdaptAnymal, StandAnymal
 from .anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg, AnymalCRoughCfgPPO
 from .anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg, AnymalCFlatCfgPPO
 from .anymal_c.flat.load_adapt_anymal_c_flat_config import LoadAdaptAnymalCFlatCfg, LoadAdaptAnymalCFlatCfgPPO
+from .anymal_c.flat.stand_anymal_c_flat_config import StandAnymalCFlatCfg, StandAnymalCFlatCfgPPO
+from .anymal_c.mixed_terrains.anymal_c_rough_student_config import AnymalCRoughStudentCfg, AnymalCRoughStudentCfgPPO
 from .a1.a1_config import A1RoughCfg, A1RoughCfgPPO
-from .go2.go2 import Go2, LoadAdaptGo2
+from .go2.go2 import Go2, LoadAdaptGo2, StandGo2
 from .go2.go2_config import (Go2RoughCfg, Go2RoughCfgPPO, Go2FlatCfg, Go2FlatCfgPPO, LoadAdaptGo2FlatCfg,
-                             LoadAdaptGo2FlatCfgPPO)
+                             LoadAdaptGo2FlatCfgPPO, StandGo2FlatCfg, StandGo2FlatCfgPPO)
 from .batch_rollout.robot_batch_rollout import RobotBatchRollout
 from .batch_rollout.robot_batch_rollout_percept import RobotBatchRolloutPercept
 from .anymal_c.batch_rollout.anymal_c_batch_rollout import AnymalCBatchRollout
@@ -25,3 +27,6 @@ task_registry.register("anymal_c_batch_rollout", AnymalCBatchRollout, AnymalCBat
 task_registry.register("anymal_c_batch_rollout_flat", AnymalCBatchRollout, AnymalCBatchRolloutFlatCfg(), AnymalCBatchRolloutFlatCfgPPO())
 task_registry.register("load_adapt_anymal_c_flat", LoadAdaptAnymal, LoadAdaptAnymalCFlatCfg(), LoadAdaptAnymalCFlatCfgPPO())
 task_registry.register("load_adapt_go2_flat", LoadAdaptGo2, LoadAdaptGo2FlatCfg(), LoadAdaptGo2FlatCfgPPO())
+task_registry.register("stand_anymal_c_flat", StandAnymal, StandAnymalCFlatCfg(), StandAnymalCFlatCfgPPO())
+task_registry.register("stand_go2_flat", StandGo2, StandGo2FlatCfg(), StandGo2FlatCfgPPO())
+task_registry.register("anymal_c_rough_student", AnymalStudent, AnymalCRoughStudentCfg(), AnymalCRoughStudentCfgPPO())

@@ -54,6 +54,7 @@ class LeggedRobot(BaseTask):
         self._parse_cfg(self.cfg)
         super().__init__(self.cfg, sim_params, physics_engine, sim_device, headless)
         self._init_buffers()
+        self._spawn_state()
         self._prepare_reward_function()
         self.init_done = True
         self.acc_ema = 0.9
@@ -115,7 +116,7 @@ class LeggedRobot(BaseTask):
                                  gait=self._gait_config(), num_extra_obs=self._num_extra_obs(),
                                  reset_z_from_terrain=self._reset_z_from_terrain,
                                  custom_origins=self._custom_origins_rule(), terminate_on_flip=self._terminate_on_flip,
-                                 reward_term_variants=self.reward_term_variants)
+                                 reward_term_variants=self.reward_term_variants, reward_class=self.reward_class)
         self.core = NativeCore(self.setup, self.device)
         t = self.core.t
 
@@ -145,6 +146,7 @@ class LeggedRobot(BaseTask):
         if self.terrain is not None:
             self.height_samples = t["height_samples"]
 
+    reward_class = "base"           # "stand": the StandAnymal / StandGo2 overrides (enum lg_reward_class)
     reward_term_variants = {}        # cfg.rewards.scales name -> native term for classes that override a `_reward_*`
     _terminate_on_flip = False       # AnymalCBatchRollout: an upside-down robot ends the episode
     _reset_z_from_terrain = False    # RobotBatchRollout: root z from the height sample under the reset position
@@ -313,6 +315,16 @@ class LeggedRobot(BaseTask):
         else:
             self.measured_heights = 0
         self.default_dof_pos = torch.tensor(self.setup.default_dof_pos, dtype=torch.float, device=self.device).unsqueeze(0)
+
+    def _spawn_state(self):
+        """State of a freshly created env, before any reset: every robot at its origin in the initial base state, where
+        `_create_envs` spawns the actors (`legged_robot.py:786-793`, without its +-1 m xy jitter), joints at the default angles
+        (the reference's actors start at the asset's zero pose and rely on PhysX to resolve the ground penetration that causes).
+        `scripts/play.py` steps such an env without calling `reset()` first."""
+        self.root_states[:] = self.base_init_state
+        self.root_states[:, :3] += self.env_origins
+        self.dof_pos[:] = self.default_dof_pos
+        self.dof_vel[:] = 0.
 
     def _prepare_reward_function(self):
         """Names / dt-scaled scales of the active terms and their episode sums (`legged_robot.py:649-674`)."""

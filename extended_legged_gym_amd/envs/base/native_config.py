@@ -90,6 +90,9 @@ def reward_setup(cfg, dt, stage=None):
     for k, v in scales.items():
         if v == 0:
             continue
+        if k == "standing":
+            raise IndexError("_reward_standing sums a 1-D tensor over dim 1 (anymal.py:273-275, go2.py:268-270): the reference raises "
+                             "on the first step of any config that scales it (stand_go2_flat); set rewards.scales.standing = 0")
         if k not in abi.REWARD_TERM_ID:
             raise AttributeError(f"'_reward_{k}' is not a reward term of the native step")
         names.append(k)
@@ -123,7 +126,7 @@ class NativeSetup:
 
     def __init__(self, cfg, sim_params, model, terrain=None, seed=0, rng_mode=abi.LG_RNG_PHILOX, gait=None,
                  reward_stage=None, num_extra_obs=0, reset_z_from_terrain=False,
-                 custom_origins=None, terminate_on_flip=False, reward_term_variants=None):
+                 custom_origins=None, terminate_on_flip=False, reward_term_variants=None, reward_class="base"):
         self.model_dict = model
         self.model = model_struct(model)
         dt = cfg.control.decimation * sim_params.dt
@@ -207,6 +210,13 @@ class NativeSetup:
             c.reward_scales[k] = v
         r = cfg.rewards
         c.only_positive_rewards = int(r.only_positive_rewards)
+        c.reward_class = abi.REWARD_CLASSES[reward_class]
+        if reward_class == "stand":        # StandAnymal's (N, 2) feet buffers: the four-footed timer terms cannot run on them
+            bad = {"four_footup", "jump_air", "gait_2_step", "feet_slip"} & set(self.reward_names)
+            if bad:
+                raise ValueError(f"reward terms {sorted(bad)} read four-wide feet buffers; the stand classes keep two (anymal.py:256-260)")
+        elif "penalty_in_the_air" in self.reward_names:
+            raise AttributeError("_reward_penalty_in_the_air is defined by the stand classes only (anymal.py:301-308)")
         c.tracking_sigma, c.base_height_target, c.max_contact_force = r.tracking_sigma, r.base_height_target, r.max_contact_force
         c.soft_dof_vel_limit, c.soft_torque_limit = r.soft_dof_vel_limit, r.soft_torque_limit
         lo, hi = np.asarray(model["dof_lower"], np.float32), np.asarray(model["dof_upper"], np.float32)

@@ -12,3 +12,13 @@ class LoadAdaptGo2(Go2):
     """`LoadAdaptGo2` (reference `go2.py:118-144`): same orientation term as `LoadAdaptAnymal`."""
     reward_term_variants = {"orientation": "orientation_load_adapt"}
 
+
+
+class StandGo2(Go2):
+    """`StandGo2` (reference `go2.py:248-305`): the same overrides as `StandAnymal`."""
+    reward_class = "stand"
+
+    def _init_buffers(self):
+        super()._init_buffers()
+        self.feet_air_time = self.feet_air_time[:, 1::2]
+        self.last_contacts = self.last_contacts[:, 1::2]

@@ -167,3 +167,51 @@ class LoadAdaptGo2FlatCfgPPO(Go2FlatCfgPPO):
         experiment_name = 'load_adapt_go2'
         max_iterations = 300
 
+
+
+class StandGo2FlatCfg(Go2FlatCfg):
+    """`stand_go2_flat` (values of the reference's `envs/go2/flat/stand_go2_flat_config.py:33-86`).  The reference scales
+    `standing = -10`, a term whose function raises on its first evaluation (`go2.py:268-270`: `torch.sum(..., dim=1)` of a 1-D
+    tensor), so the registered task cannot step there; the value is kept and `NativeSetup` raises the same `IndexError` until
+    the scale is set to 0."""
+    class env(Go2FlatCfg.env):
+        num_observations = 48
+        num_actions = 12
+        episode_length_s = 5.
+
+    class commands(Go2FlatCfg.commands):
+        num_commands = 4
+        resampling_time = 5.
+
+        class ranges:
+            lin_vel_x = [-0.1, 0.1]
+            lin_vel_y = [-0.1, 0.1]
+            ang_vel_yaw = [-0.2, 0.2]
+            heading = [-0.0, 0.0]
+
+    class rewards(Go2FlatCfg.rewards):
+        class scales(Go2FlatCfg.rewards.scales):
+            tracking_lin_vel = 1.0
+            tracking_ang_vel = 1.0
+            lin_vel_z = -2.0
+            ang_vel_xy = -0.5
+            orientation = -10.0
+            torques = -0.000025
+            action_rate = -0.01
+            standing = -10.0
+            penalty_in_the_air = -5.0
+
+    class init_state(Go2FlatCfg.init_state):
+        pos = [0.0, 0.0, 0.43]
+        default_joint_angles = {
+            'FL_hip_joint': 0.0, 'RL_hip_joint': 0.0, 'FR_hip_joint': 0.0, 'RR_hip_joint': 0.0,
+            'FL_thigh_joint': 0.9, 'RL_thigh_joint': 0.9, 'FR_thigh_joint': 0.9, 'RR_thigh_joint': 0.9,
+            'FL_calf_joint': -1.8, 'RL_calf_joint': -1.8, 'FR_calf_joint': -1.8, 'RR_calf_joint': -1.8,
+        }
+
+
+class StandGo2FlatCfgPPO(Go2FlatCfgPPO):
+    class runner(Go2FlatCfgPPO.runner):
+        run_name = ''
+        experiment_name = 'stand_go2'
+        max_iterations = 300

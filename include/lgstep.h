@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION 1
+#define LG_ABI_VERSION 2
 
 #define LG_NUM_LEGS 4
 #define LG_JOINTS_PER_LEG 3
@@ -86,8 +86,16 @@ enum lg_reward_term {
   LG_REW_TRACKING_LIN_VEL,
   /* class-specific variants of a term (same name in cfg.rewards.scales, chosen by the env class) */
   LG_REW_ORIENTATION_LOAD_ADAPT,     /* LoadAdaptAnymal / LoadAdaptGo2._reward_orientation (anymal.py:140-143, go2.py:141-144) */
+  LG_REW_PENALTY_IN_THE_AIR,         /* StandAnymal / StandGo2._reward_penalty_in_the_air (anymal.py:301-308): neither of feet 1, 3 in (filtered) contact */
   LG_REW_COUNT
 };
+
+/* lg_config.reward_class: the env class whose overrides of the shared term names apply.  LG_RC_STAND = StandAnymal / StandGo2
+ * (anymal.py:253-308, go2.py): the robot stands on feet_indices[1] and [3] with its x axis up, so
+ *   ang_vel_xy        sums base_ang_vel[1:]^2,            orientation      sums projected_gravity[1:]^2,
+ *   tracking_lin_vel  tracks commands[:2] against -base_lin_vel[1:],   tracking_ang_vel tracks commands[2] against base_ang_vel[0],
+ *   feet_air_time     runs on feet 1 and 3 only (columns 1, 3 of feet_air_time / last_contacts; feet_contact_time untouched). */
+enum lg_reward_class { LG_RC_BASE = 0, LG_RC_STAND = 1 };
 
 /* arena tensors (names follow the reference's attribute names, legged_robot.py:559-647, base_task.py:71-79) */
 enum lg_tensor_id {
@@ -210,6 +218,7 @@ typedef struct lg_config {
   int32_t reward_term_ids[LG_MAX_REWARD_TERMS];
   float reward_scales[LG_MAX_REWARD_TERMS];
   int32_t only_positive_rewards;
+  int32_t reward_class;               /* enum lg_reward_class */
   float tracking_sigma, base_height_target, max_contact_force, soft_dof_vel_limit, soft_torque_limit;
   float dof_pos_limits[LG_NUM_DOF][2];/* soft limits (:366-370) */
   /* episode / curriculum */

@@ -1,5 +1,6 @@
 """Shared test plumbing: build configs / native setups for the golden cases, and drive an env core (the CPU oracle or
 the HIP library, both expose the same tensor names) through one golden step."""
+import contextlib
 import json
 import os
 
@@ -7,13 +8,16 @@ import numpy as np
 
 from extended_legged_gym_amd import abi
 from extended_legged_gym_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+from extended_legged_gym_amd.envs.anymal_c.anymal import teacher_row_cfg
 from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
+from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_student_config import AnymalCRoughStudentCfg
 from extended_legged_gym_amd.envs.base.native_config import NativeSetup, load_robot_model
 from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_CASES = ["flat_pd", "flat_lstm", "rough_lstm", "rough_allrew", "flat_loadadapt"]
+GOLDEN_CASES = ["flat_pd", "flat_lstm", "rough_lstm", "rough_allrew", "flat_loadadapt", "flat_stand", "rough_student"]
 CLASS_VARIANTS = {"LoadAdaptAnymal": {"orientation": "orientation_load_adapt"}}   # = LoadAdaptAnymal.reward_term_variants
+CLASS_REWARD_CLASS = {"StandAnymal": "stand"}                                        # = StandAnymal.reward_class
 ANYMAL_GAIT = dict(period=0.6, swing_height=0.15, foot_phases=[0.0, 0.5, 0.5, 0.0])   # anymal.py:59-63
 
 
@@ -36,6 +40,9 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
     """Our own config classes, edited exactly as tools/refgen/make_golden.py edited the reference's."""
     case = meta["case"]
     cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
+    student = case.get("cls") == "AnymalStudent"
+    if student:
+        cfg = AnymalCRoughStudentCfg()
     cfg.env.num_envs = case["num_envs"]
     cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]
@@ -51,13 +58,18 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
         terrain = FixtureTerrain(z["height_samples"], z["terrain_origins"], cfg.terrain.terrain_length)
     for k, v in case.get("scales", {}).items():
         setattr(cfg.rewards.scales, k, v)
+    if "max_contact_force" in case:
+        cfg.rewards.max_contact_force = case["max_contact_force"]
     cfg.rewards.only_positive_rewards = case.get("only_positive_rewards", True)
     model = load_robot_model(cfg.asset)
     # the harness robot (tools/refgen/ref_loader.py:anymal_robot_description) carries these DOF limits
     model["dof_lower"], model["dof_upper"] = [-9.42] * 12, [9.42] * 12
     model["dof_vel_limit"], model["torque_limit"] = [20.0] * 12, [80.0] * 12
-    setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ANYMAL_GAIT,
-                        reward_term_variants=CLASS_VARIANTS.get(case.get("cls", "Anymal")))
+    # AnymalStudent: the native step produces the teacher's row (what the class asks of it, anymal.py:AnymalStudent.__init__)
+    with (teacher_row_cfg(cfg) if student else contextlib.nullcontext()):
+        setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ANYMAL_GAIT,
+                            reward_term_variants=CLASS_VARIANTS.get(case.get("cls", "Anymal")),
+                            reward_class=CLASS_REWARD_CLASS.get(case.get("cls", "Anymal"), "base"))
     return cfg, setup
 
 
@@ -79,7 +91,9 @@ def load_pre_state(core_t, z, t, write):
     sc[0] = int(z["pre_common_step_counter"][t])
     write("step_counters", sc)
     write("reset_buf", z["pre_reset_buf"][t])
-    write("rand_inject", np.nan_to_num(z["rand"][t], nan=0.0))
+    rand = np.nan_to_num(z["rand"][t], nan=0.0)
+    width = core_t["rand_inject"].shape[1]               # AnymalStudent: 144 noise draws recorded, the native row is 235 wide (noise off)
+    write("rand_inject", np.pad(rand, ((0, 0), (0, max(0, width - rand.shape[1]))))[:, :width])
 
 
 # name of the env-core tensor -> golden key, compared after a step
@@ -92,3 +106,10 @@ POST_KEYS = {"root_states": "post_root_states", "dof_state": "post_dof_state", "
              "episode_sums": "post_episode_sums", "env_origins": "post_env_origins", "gait_idx": "post_gait_idx",
              "sea_hidden_state": "post_sea_hidden", "sea_cell_state": "post_sea_cell",
              "obs_buf": "obs", "rew_buf": "rew", "reset_buf": "reset", "time_out_buf": "time_out", "actions": "clipped_actions"}
+
+
+def post_keys(meta):
+    """POST_KEYS for a golden case: the native observation of `AnymalStudent` is the reference's privileged row."""
+    if meta["case"].get("cls") == "AnymalStudent":
+        return {**POST_KEYS, "obs_buf": "privileged_obs"}
+    return POST_KEYS

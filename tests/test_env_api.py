@@ -1,5 +1,7 @@
 """GPU: the drop-in `LeggedRobot` / VecEnv surface (reference `rsl_rl/env/vec_env_old.py:35-59`, what
 `on_policy_runner.py:43-76,326-331,358-361,401-412` and `scripts/play.py:93-107` touch)."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,7 @@ def make(task, n, **over):
     from extended_legged_gym_amd.utils.helpers import get_args
     args = get_args(["--num_envs", str(n)])
     env_cfg, _ = task_registry.get_cfgs(task)
+    env_cfg = copy.deepcopy(env_cfg)          # get_cfgs hands out the registered instance (task_registry.py, as the reference): keep tests independent
     for k, v in over.items():
         obj = env_cfg
         parts = k.split(".")

@@ -46,7 +46,12 @@ def make(kind, n, fuse):
                   "feet_contact_forces", "feet_slip", "jump_air", "gait_2_step", "base_foot_height", "termination"):
             setattr(cfg.rewards.scales, k, -0.01)
         cfg.rewards.only_positive_rewards = False
-    setup = NativeSetup(cfg, sim_params_for(cfg), load_robot_model(cfg.asset), terrain=terrain, seed=7, gait=ANYMAL_GAIT)
+    if kind == "flat_stand":            # StandAnymal's reward class (anymal.py:253-308) with the scales of its task config
+        for k, v in dict(orientation=-4.0, feet_air_time=1.0, base_height=-4.0, collision=-2.0, penalty_in_the_air=-4.0, ang_vel_xy=-0.05).items():
+            setattr(cfg.rewards.scales, k, v)
+        cfg.rewards.only_positive_rewards = False
+    setup = NativeSetup(cfg, sim_params_for(cfg), load_robot_model(cfg.asset), terrain=terrain, seed=7, gait=ANYMAL_GAIT,
+                        reward_class="stand" if kind == "flat_stand" else "base")
     from extended_legged_gym_amd.native import NativeCore
     old = os.environ.get("LG_FUSE")
     os.environ["LG_FUSE"] = "1" if fuse else "0"
@@ -60,7 +65,7 @@ def make(kind, n, fuse):
     return cfg, setup, terrain, core
 
 
-@pytest.mark.parametrize("kind,n", [("rough_lstm", 200), ("flat_pd_mesh", 0), ("flat_allrew", 96), ("rough_lstm", 5)])
+@pytest.mark.parametrize("kind,n", [("rough_lstm", 200), ("flat_pd_mesh", 0), ("flat_allrew", 96), ("rough_lstm", 5), ("flat_stand", 64)])
 def test_fused_step_equals_physics_plus_post_kernel(kind, n):
     if kind == "flat_pd_mesh":
         pytest.skip("PD robots run helper waves only on mesh terrains: covered by tests/test_hip_config3.py (fused) against the oracle")

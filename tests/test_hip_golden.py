@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import GOLDEN_CASES, POST_KEYS, golden_setup, load_golden, load_pre_state
+from tests.helpers import GOLDEN_CASES, golden_setup, load_golden, load_pre_state, post_keys
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 2e-5, 2e-6
@@ -51,7 +51,7 @@ def test_hip_step_matches_reference(case):
             assert np.array_equal(core.t["measured_heights"].cpu().numpy(), z["measured_heights"][t]), f"step {t}: heights"
         if "post_terrain_levels" in z.files:
             assert np.array_equal(core.t["terrain_levels"].cpu().numpy(), z["post_terrain_levels"][t])
-        for name, key in POST_KEYS.items():
+        for name, key in post_keys(meta).items():
             got = core.t[name][:z[key][t].shape[0]] if name == "episode_sums" else core.t[name]
             check(name, got, z[key][t], t)
         if z["extras_fresh"][t]:

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -92,3 +93,66 @@ def test_terrain_types_of_shards_tile_the_single_gpu_layout():
     union = torch.cat([terrain_types_for_shard(num_cols, r, world, per) for r in range(world)])
     single = torch.div(torch.arange(world * per), (world * per / num_cols), rounding_mode='floor').to(torch.long)
     assert torch.equal(union, single)
+
+
+# ------------------------------------------------------------------------------------------------ two ranks of the HIP path on one GPU
+def _hip_worker(rank, world, port, out):
+    """One shard of a 2-rank job, both on cuda:0 (the GPU box has one card; RCCL refuses two ranks on one device, so the rehearsal's
+    collective runs over gloo -- the env path is the product's: `shard_env_cfg` + `LeggedRobot.create_sim` + `lg_step`)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contextlib
+    import io
+    from extended_legged_gym_amd.envs import Anymal, AnymalCRoughCfg
+    from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params, set_seed
+    n = 256
+    cfg = AnymalCRoughCfg()
+    cfg.terrain.mesh_type = "heightfield"
+    cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = 4, 4, 5
+    cfg.terrain.max_init_terrain_level = 3
+    cfg.seed = 1
+    shard_env_cfg(cfg, rank, world, n)
+    args = get_args([]); args.sim_device = "cuda:0"
+    with contextlib.redirect_stdout(io.StringIO()):
+        set_seed(1)                                  # identical terrain on both ranks
+    env = Anymal(cfg, parse_sim_params(args, {"sim": class_to_dict(cfg.sim)}), args.physics_engine, args.sim_device, True)
+    env.reset()
+    g = torch.Generator().manual_seed(100 + rank)
+    for _ in range(60):
+        env.step(torch.randn(n, 12, generator=g).cuda())
+    torch.cuda.synchronize()
+    table, totals = gather_episode_stats(env.core.t["episode_stats"].cpu().clone(), dist)
+    packed = torch.cat([env.core.t["friction_coeffs"].cpu(), env.core.t["terrain_types"].cpu().float(),
+                        torch.tensor([float(env.core.t["height_samples"].long().sum()), float(torch.isfinite(env.obs_buf).all())])])
+    allp = [torch.zeros_like(packed) for _ in range(world)]
+    dist.all_gather(allp, packed)
+    if rank == 0:
+        out.put((table.numpy(), totals.numpy(), torch.stack(allp).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_hip_shards_on_one_gpu():
+    """N > 1 of the HIP path itself (the driver's scaling run needs a whole node): two processes, 256 envs each on cuda:0, global
+    terrain-column indexing, per-shard domain randomisation, the episode-statistics all-gather."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hip_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    table, totals, packed = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = 256
+    steps = 61                                   # env.reset() takes one zero-action step (base_task.py:115-119)
+    assert table.shape == (2, 4) and table[0, 3] == n * steps and table[1, 3] == n * steps and totals[3] == 2 * n * steps
+    np.testing.assert_allclose(totals, table.sum(0))
+    fr, ty = packed[:, :n], packed[:, n:2 * n]
+    assert packed[0, -2] == packed[1, -2] and packed[0, -1] == 1.0 and packed[1, -1] == 1.0      # same terrain, finite observations
+    assert not np.allclose(fr[0], fr[1])                                                           # shards draw their own friction buckets
+    union = np.concatenate([ty[0], ty[1]])
+    single = np.floor(np.arange(2 * n) / (2 * n / 4))
+    assert np.array_equal(union, single)                                                           # terrain columns by GLOBAL env index

@@ -33,13 +33,17 @@ def build(case):
     ref_loader.load_reference()
     from isaacgym import gymapi
     from legged_gym.envs import Anymal, AnymalCFlatCfg, AnymalCRoughCfg
-    from legged_gym.envs.anymal_c.anymal import LoadAdaptAnymal
-    Base = {"Anymal": Anymal, "LoadAdaptAnymal": LoadAdaptAnymal}[case.get("cls", "Anymal")]
+    from legged_gym.envs.anymal_c.anymal import AnymalStudent, LoadAdaptAnymal, StandAnymal
+    from legged_gym.envs import AnymalCRoughStudentCfg
+    Base = {"Anymal": Anymal, "LoadAdaptAnymal": LoadAdaptAnymal, "StandAnymal": StandAnymal,
+            "AnymalStudent": AnymalStudent}[case.get("cls", "Anymal")]
     import legged_gym.envs.base.legged_robot as LR
 
     ref_loader.FakeGym.robot = ref_loader.anymal_robot_description()
     N = case["num_envs"]
     cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
+    if case.get("cls") == "AnymalStudent":
+        cfg = AnymalCRoughStudentCfg()
     cfg.env.num_envs = N
     cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]
@@ -54,6 +58,8 @@ def build(case):
         cfg.terrain.border_size = case["border_size"]
     for k, v in case.get("scales", {}).items():
         setattr(cfg.rewards.scales, k, v)
+    if "max_contact_force" in case:
+        cfg.rewards.max_contact_force = case["max_contact_force"]
     cfg.rewards.only_positive_rewards = case.get("only_positive_rewards", True)
     sp = gymapi.SimParams()
     sp.dt = cfg.sim.dt
@@ -171,6 +177,11 @@ def persistent(env):
     )
     if hasattr(env, "terrain_levels"):
         d["terrain_levels"] = env.terrain_levels
+    if env.feet_air_time.shape[1] == 2:       # StandAnymal's two-wide buffers (anymal.py:256-260) = feet 1 and 3 of four
+        for k in ("feet_air_time", "last_contacts"):
+            wide = torch.zeros(env.num_envs, 4, dtype=d[k].dtype)
+            wide[:, 1::2] = d[k]
+            d[k] = wide
     return {k: v.detach().clone().numpy() for k, v in d.items()}
 
 
@@ -262,6 +273,9 @@ def run_case(case):
                   obs=obs.clone().numpy(), rew=rew.clone().numpy(), reset=reset.clone().numpy().astype(np.uint8),
                   time_out=env.time_out_buf.clone().numpy().astype(np.uint8),
                   clipped_actions=env.actions.clone().numpy())
+        if env.privileged_obs_buf is not None:
+            st["privileged_obs"] = env.privileged_obs_buf.clone().numpy()
+            st["obs_history"] = env.obs_history.clone().numpy()
         mh = env.measured_heights
         st["measured_heights"] = mh.clone().numpy() if torch.is_tensor(mh) else np.zeros((N, 0), np.float32)
         ep = extras.get("episode", {})
@@ -319,6 +333,16 @@ CASES = [
     dict(name="flat_loadadapt", base="flat", cls="LoadAdaptAnymal", num_envs=24, steps=4, seed=4, actuator_net=False,
          push_interval_s=0.06, resampling_time=0.1, heading_command=False, episode_length_s=20,
          scales=dict(orientation=-80.0), only_positive_rewards=False),
+    # AnymalStudent (anymal.py:311-391): history observations (in-place noise on the stored rows included) + the teacher's row
+    dict(name="rough_student", base="rough", cls="AnymalStudent", num_envs=32, steps=8, seed=6, actuator_net=False,
+         push_interval_s=15, resampling_time=4.0, heading_command=True, episode_length_s=20, num_rows=3, num_cols=4, border_size=5),
+    # StandAnymal (anymal.py:253-308): five overridden terms on the hind feet / rotated axes + penalty_in_the_air, with the
+    # scales of stand_anymal_c_flat_config.py:73-80 (+ ang_vel_xy, which that config inherits as -0.05 already)
+    dict(name="flat_stand", base="flat", cls="StandAnymal", num_envs=24, steps=6, seed=5, actuator_net=False,
+         push_interval_s=0.06, resampling_time=0.1, heading_command=False, episode_length_s=20,
+         scales=dict(orientation=-4.0, torques=-0.000025, feet_air_time=1.0, base_height=-4.0, collision=-2.0,
+                     penalty_in_the_air=-4.0, feet_contact_forces=-0.01),
+         max_contact_force=100.0, only_positive_rewards=False),
 ]
 
 if __name__ == "__main__":
