@@ -2,10 +2,11 @@
 classes are importable from here for task-specific configs."""
 from extended_legged_gym_amd.utils.task_registry import task_registry
 from .base.legged_robot import LeggedRobot
-from .anymal_c.anymal import Anymal, AnymalStudent, LoadAdaptAnymal, StandAnymal
+from .anymal_c.anymal import Anymal, AnymalStudent, LoadAdaptAnymal, PoseAnymal, StandAnymal
 from .anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg, AnymalCRoughCfgPPO
 from .anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg, AnymalCFlatCfgPPO
 from .anymal_c.flat.load_adapt_anymal_c_flat_config import LoadAdaptAnymalCFlatCfg, LoadAdaptAnymalCFlatCfgPPO
+from .anymal_c.flat.pose_anymal_c_flat_config import PoseAnymalCFlatCfg, PoseAnymalCFlatCfgPPO
 from .anymal_c.flat.stand_anymal_c_flat_config import StandAnymalCFlatCfg, StandAnymalCFlatCfgPPO
 from .anymal_c.mixed_terrains.anymal_c_rough_student_config import AnymalCRoughStudentCfg, AnymalCRoughStudentCfgPPO
 from .a1.a1_config import A1RoughCfg, A1RoughCfgPPO
@@ -30,3 +31,4 @@ task_registry.register("load_adapt_go2_flat", LoadAdaptGo2, LoadAdaptGo2FlatCfg(
 task_registry.register("stand_anymal_c_flat", StandAnymal, StandAnymalCFlatCfg(), StandAnymalCFlatCfgPPO())
 task_registry.register("stand_go2_flat", StandGo2, StandGo2FlatCfg(), StandGo2FlatCfgPPO())
 task_registry.register("anymal_c_rough_student", AnymalStudent, AnymalCRoughStudentCfg(), AnymalCRoughStudentCfgPPO())
+task_registry.register("pose_anymal_c_flat", PoseAnymal, PoseAnymalCFlatCfg(), PoseAnymalCFlatCfgPPO())

@@ -8,7 +8,8 @@ import numpy as np
 
 from extended_legged_gym_amd import abi
 from extended_legged_gym_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
-from extended_legged_gym_amd.envs.anymal_c.anymal import teacher_row_cfg
+from extended_legged_gym_amd.envs.anymal_c.anymal import pose_native_cfg, teacher_row_cfg
+from extended_legged_gym_amd.envs.anymal_c.flat.pose_anymal_c_flat_config import PoseAnymalCFlatCfg
 from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
 from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_student_config import AnymalCRoughStudentCfg
 from extended_legged_gym_amd.envs.base.native_config import NativeSetup, load_robot_model
@@ -40,9 +41,11 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
     """Our own config classes, edited exactly as tools/refgen/make_golden.py edited the reference's."""
     case = meta["case"]
     cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
-    student = case.get("cls") == "AnymalStudent"
+    student, pose = case.get("cls") == "AnymalStudent", case.get("cls") == "PoseAnymal"
     if student:
         cfg = AnymalCRoughStudentCfg()
+    if pose:
+        cfg = PoseAnymalCFlatCfg()
     cfg.env.num_envs = case["num_envs"]
     cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]
@@ -66,7 +69,8 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
     model["dof_lower"], model["dof_upper"] = [-9.42] * 12, [9.42] * 12
     model["dof_vel_limit"], model["torque_limit"] = [20.0] * 12, [80.0] * 12
     # AnymalStudent: the native step produces the teacher's row (what the class asks of it, anymal.py:AnymalStudent.__init__)
-    with (teacher_row_cfg(cfg) if student else contextlib.nullcontext()):
+    # PoseAnymal: the native step runs without the two pose terms, the clip and the noise (anymal.py:pose_native_cfg)
+    with (teacher_row_cfg(cfg) if student else pose_native_cfg(cfg) if pose else contextlib.nullcontext()):
         setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ANYMAL_GAIT,
                             reward_term_variants=CLASS_VARIANTS.get(case.get("cls", "Anymal")),
                             reward_class=CLASS_REWARD_CLASS.get(case.get("cls", "Anymal"), "base"))

@@ -33,10 +33,10 @@ def build(case):
     ref_loader.load_reference()
     from isaacgym import gymapi
     from legged_gym.envs import Anymal, AnymalCFlatCfg, AnymalCRoughCfg
-    from legged_gym.envs.anymal_c.anymal import AnymalStudent, LoadAdaptAnymal, StandAnymal
-    from legged_gym.envs import AnymalCRoughStudentCfg
+    from legged_gym.envs.anymal_c.anymal import AnymalStudent, LoadAdaptAnymal, PoseAnymal, StandAnymal
+    from legged_gym.envs import AnymalCRoughStudentCfg, PoseAnymalCFlatCfg
     Base = {"Anymal": Anymal, "LoadAdaptAnymal": LoadAdaptAnymal, "StandAnymal": StandAnymal,
-            "AnymalStudent": AnymalStudent}[case.get("cls", "Anymal")]
+            "AnymalStudent": AnymalStudent, "PoseAnymal": PoseAnymal}[case.get("cls", "Anymal")]
     import legged_gym.envs.base.legged_robot as LR
 
     ref_loader.FakeGym.robot = ref_loader.anymal_robot_description()
@@ -44,6 +44,8 @@ def build(case):
     cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
     if case.get("cls") == "AnymalStudent":
         cfg = AnymalCRoughStudentCfg()
+    if case.get("cls") == "PoseAnymal":
+        cfg = PoseAnymalCFlatCfg()
     cfg.env.num_envs = N
     cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]
@@ -71,6 +73,8 @@ def build(case):
         rec["log"].append((rec.get("ctx"), rec.get("sub"), rec.get("ids"), u.clone()))
         return (upper - lower) * u + lower
     LR.torch_rand_float = rand_float
+    import legged_gym.envs.anymal_c.anymal as AM
+    AM.torch_rand_float = rand_float          # PoseAnymal._resample_commands draws through its own module's name
 
     orig_rand_like, orig_randint_like = torch.rand_like, torch.randint_like
 
@@ -130,8 +134,9 @@ def build(case):
     return env, cfg, rec
 
 
-def slots_from_log(log, N, nslots):
-    """Scatter the recorded draws into a dense (N, nslots) table, NaN = not drawn."""
+def slots_from_log(log, N, nslots, pose=None):
+    """Scatter the recorded draws into a dense (N, nslots) table, NaN = not drawn.  `pose` (N, 8): the four extra draws of
+    PoseAnymal._resample_commands (anymal.py:213-220), columns 0-3 from the callback, 4-7 from reset_idx."""
     tab = np.full((N, nslots), np.nan, dtype=np.float32)
     counters = {}
     for ctx, sub, ids, u in log:
@@ -143,7 +148,9 @@ def slots_from_log(log, N, nslots):
         counters[key] = k + 1
         ids = ids.numpy()
         u = u.numpy()
-        if sub == "cmd":
+        if sub == "cmd" and k >= 3:
+            pose[ids, (0 if ctx == "cb" else 4) + k - 3] = u[:, 0]
+        elif sub == "cmd":
             base = RS_CMD_CB if ctx == "cb" else RS_CMD_RESET
             tab[ids, base + k] = u[:, 0]
         elif sub == "push":
@@ -267,15 +274,19 @@ def run_case(case):
         post = persistent(env)
         st = {f"pre_{k}": v for k, v in pre.items()}
         st.update({f"post_{k}": v for k, v in post.items()})
+        pose_u = np.full((N, 8), np.nan, dtype=np.float32)
         st.update(actions=actions.numpy(), sim_dof=cur["sim_dof"].numpy(), sim_root=root.numpy(),
                   sim_rigid=rigid.numpy(), sim_contact=contact.numpy(),
-                  rand=slots_from_log(rec["log"], N, nslots), torques=torch.stack(torq).numpy(),
+                  rand=slots_from_log(rec["log"], N, nslots, pose_u), torques=torch.stack(torq).numpy(),
                   obs=obs.clone().numpy(), rew=rew.clone().numpy(), reset=reset.clone().numpy().astype(np.uint8),
                   time_out=env.time_out_buf.clone().numpy().astype(np.uint8),
                   clipped_actions=env.actions.clone().numpy())
         if env.privileged_obs_buf is not None:
             st["privileged_obs"] = env.privileged_obs_buf.clone().numpy()
             st["obs_history"] = env.obs_history.clone().numpy()
+        if hasattr(env, "exp_quat"):
+            st["rand_pose"] = pose_u
+            st["exp_quat"] = env.exp_quat.clone().numpy()
         mh = env.measured_heights
         st["measured_heights"] = mh.clone().numpy() if torch.is_tensor(mh) else np.zeros((N, 0), np.float32)
         ep = extras.get("episode", {})
@@ -336,6 +347,12 @@ CASES = [
     # AnymalStudent (anymal.py:311-391): history observations (in-place noise on the stored rows included) + the teacher's row
     dict(name="rough_student", base="rough", cls="AnymalStudent", num_envs=32, steps=8, seed=6, actuator_net=False,
          push_interval_s=15, resampling_time=4.0, heading_command=True, episode_length_s=20, num_rows=3, num_cols=4, border_size=5),
+    # PoseAnymal (anymal.py:146-250): eight command channels, 52 observations, orientation / base-height terms against the commanded pose
+    dict(name="flat_pose", base="flat", cls="PoseAnymal", num_envs=24, steps=8, seed=7, actuator_net=False, push_interval_s=0.06,
+         resampling_time=0.1, heading_command=False, episode_length_s=20,
+         # milder penalties than the task's, so that on the scripted states the clip of only_positive_rewards (left on) bites on some envs only
+         scales=dict(base_height=-1.0, orientation=-0.2, lin_vel_z=-0.1, collision=-0.05, tracking_lin_vel=2.0, tracking_ang_vel=1.0,
+                     action_rate=-0.0005, dof_acc=-2.5e-8)),
     # StandAnymal (anymal.py:253-308): five overridden terms on the hind feet / rotated axes + penalty_in_the_air, with the
     # scales of stand_anymal_c_flat_config.py:73-80 (+ ang_vel_xy, which that config inherits as -0.05 already)
     dict(name="flat_stand", base="flat", cls="StandAnymal", num_envs=24, steps=6, seed=5, actuator_net=False,
