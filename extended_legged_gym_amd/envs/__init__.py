@@ -10,9 +10,9 @@ from .anymal_c.flat.pose_anymal_c_flat_config import PoseAnymalCFlatCfg, PoseAny
 from .anymal_c.flat.stand_anymal_c_flat_config import StandAnymalCFlatCfg, StandAnymalCFlatCfgPPO
 from .anymal_c.mixed_terrains.anymal_c_rough_student_config import AnymalCRoughStudentCfg, AnymalCRoughStudentCfgPPO
 from .a1.a1_config import A1RoughCfg, A1RoughCfgPPO
-from .go2.go2 import Go2, LoadAdaptGo2, StandGo2
+from .go2.go2 import Go2, LoadAdaptGo2, PoseGo2, StandGo2
 from .go2.go2_config import (Go2RoughCfg, Go2RoughCfgPPO, Go2FlatCfg, Go2FlatCfgPPO, LoadAdaptGo2FlatCfg,
-                             LoadAdaptGo2FlatCfgPPO, StandGo2FlatCfg, StandGo2FlatCfgPPO)
+                             LoadAdaptGo2FlatCfgPPO, PoseGo2FlatCfg, PoseGo2FlatCfgPPO, StandGo2FlatCfg, StandGo2FlatCfgPPO)
 from .batch_rollout.robot_batch_rollout import RobotBatchRollout
 from .batch_rollout.robot_batch_rollout_percept import RobotBatchRolloutPercept
 from .anymal_c.batch_rollout.anymal_c_batch_rollout import AnymalCBatchRollout
@@ -32,3 +32,4 @@ task_registry.register("stand_anymal_c_flat", StandAnymal, StandAnymalCFlatCfg()
 task_registry.register("stand_go2_flat", StandGo2, StandGo2FlatCfg(), StandGo2FlatCfgPPO())
 task_registry.register("anymal_c_rough_student", AnymalStudent, AnymalCRoughStudentCfg(), AnymalCRoughStudentCfgPPO())
 task_registry.register("pose_anymal_c_flat", PoseAnymal, PoseAnymalCFlatCfg(), PoseAnymalCFlatCfgPPO())
+task_registry.register("pose_go2_flat", PoseGo2, PoseGo2FlatCfg(), PoseGo2FlatCfgPPO())

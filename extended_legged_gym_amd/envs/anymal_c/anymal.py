@@ -231,8 +231,8 @@ def pose_layer_params(cfg, dt, noise_scale_vec52, device):
                 noise_scale_vec=torch.as_tensor(noise_scale_vec52, dtype=torch.float, device=device))
 
 
-class PoseAnymal(Anymal):
-    """`PoseAnymal` (reference `anymal.py:146-250`, task `pose_anymal_c_flat`): four extra command channels (yaw / pitch / roll
+class PoseCommandsMixin:
+    """`PoseAnymal` / `PoseGo2` (reference `anymal.py:146-250`, `go2.py:146-246`, identical bodies): four extra command channels (yaw / pitch / roll
     shift of the base, base height), a 52-entry observation, and `orientation` / `base_height` rewards measured against the
     commanded pose.
 
@@ -299,6 +299,10 @@ class PoseAnymal(Anymal):
         self.commands[env_ids, 4:8] = r[:, 0] + (r[:, 1] - r[:, 0]) * torch.rand(len(env_ids), 4, device=self.device)
         self.commands[:, :4] = self._native_commands
         self._pose["sums"][:, env_ids] = 0.
+
+
+class PoseAnymal(PoseCommandsMixin, Anymal):
+    """Task `pose_anymal_c_flat` (reference `envs/__init__.py:119`)."""
 
 
 class _PoseCommandRanges:

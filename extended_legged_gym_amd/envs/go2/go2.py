@@ -1,6 +1,6 @@
 """`Go2(LeggedRobot)` (reference `envs/go2/go2.py:19-93`): like `Anymal` — optional LSTM actuator network and a gait
 scheduler stepped once per policy step, both inside the native kernels."""
-from extended_legged_gym_amd.envs.anymal_c.anymal import Anymal
+from extended_legged_gym_amd.envs.anymal_c.anymal import Anymal, PoseCommandsMixin
 
 
 class Go2(Anymal):
@@ -22,3 +22,9 @@ class StandGo2(Go2):
         super()._init_buffers()
         self.feet_air_time = self.feet_air_time[:, 1::2]
         self.last_contacts = self.last_contacts[:, 1::2]
+
+
+class PoseGo2(PoseCommandsMixin, Go2):
+    """`PoseGo2` (reference `go2.py:146-246`, the body of `PoseAnymal`).  Its registered config `pose_go2_flat` declares 60
+    observations for a 52-entry row (`pose_go2_flat_config.py:35`): the reference fails on the first noisy step (52 + a 60-wide noise
+    vector), `NativeSetup` refuses the config up front; with `env.num_observations = 52` the class runs."""

@@ -215,3 +215,42 @@ class StandGo2FlatCfgPPO(Go2FlatCfgPPO):
         run_name = ''
         experiment_name = 'stand_go2'
         max_iterations = 300
+
+
+class PoseGo2FlatCfg(Go2FlatCfg):
+    """`pose_go2_flat` (values of the reference's `envs/go2/flat/pose_go2_flat_config.py:33-70`, including its `num_observations
+    = 60` for a row of 52 entries: see `PoseGo2`)."""
+    class env(Go2FlatCfg.env):
+        num_observations = 60
+        num_actions = 12
+
+    class commands(Go2FlatCfg.commands):
+        num_commands = 8
+        resampling_time = 5.
+
+        class ranges:
+            lin_vel_x = [-0.5, 0.5]
+            lin_vel_y = [-0.5, 0.5]
+            ang_vel_yaw = [-0.5, 0.5]
+            heading = [-0.0, 0.0]
+            base_yaw_shift = [-0.0, 0.0]
+            base_pitch_shift = [-0.3, 0.3]
+            base_roll_shift = [-0.3, 0.3]
+            base_height = [0.25, 0.42]
+
+    class rewards(Go2FlatCfg.rewards):
+        class scales(Go2FlatCfg.rewards.scales):
+            orientation = -5.0
+            base_height = -5.0
+
+    class init_state(Go2FlatCfg.init_state):
+        reset_mode = 'reset_to_range'
+        pos = [0.0, 0.0, 0.52]
+
+
+class PoseGo2FlatCfgPPO(Go2FlatCfgPPO):
+    class runner(Go2FlatCfgPPO.runner):
+        run_name = ''
+        experiment_name = 'pose_go2'
+        load_run = -1
+        max_iterations = 300

@@ -113,6 +113,19 @@ def test_exp_quat_heading_drops_out_of_the_expected_gravity():
 
 
 @pytest.mark.gpu
+def test_pose_go2_runs_with_the_observation_count_corrected():
+    """`pose_go2_flat` declares 60 observations for a 52-entry row (pose_go2_flat_config.py:35): refused as registered, runs at 52."""
+    from tests.test_env_api import make
+    with pytest.raises(ValueError):
+        make("pose_go2_flat", 32)
+    env = make("pose_go2_flat", 32, **{"env.num_observations": 52})
+    obs, _ = env.reset()
+    for _ in range(10):
+        obs, _, rew, done, _ = env.step(torch.zeros(32, 12, device=env.device))
+    assert obs.shape == (32, 52) and torch.isfinite(obs).all() and torch.equal(obs[:, 12:16], env.commands[:, 4:8])
+
+
+@pytest.mark.gpu
 def test_pose_env_on_the_device():
     """Task `pose_anymal_c_flat` through the registry: shapes, the pose channels in the observation, host writes to `commands`
     reach the kernel, the base row of `rigid_body_state` is the pre-reset root position the base-height term needs."""
