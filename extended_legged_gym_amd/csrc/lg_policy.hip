@@ -1,13 +1,20 @@
 // lg_policy.hip — gfx950 kernels for the rollout-collection side of PPO (include/lgpolicy.h): fused MLP forward on the
 // fp32 matrix cores, PPO.act (both networks + Gaussian sampling + log-prob) in one launch, GAE returns.
 //
-// MLP kernel.  Workgroup = 4 waves = 32 rows of the batch through ALL layers; the activations of the current layer live in
-// LDS in the operand order of v_mfma_f32_16x16x4_f32 ([k/4][row][k%4], row stride 33: the A-fragment read of a wave is 64
-// consecutive words, conflict-free), the next layer's activations are written to a second LDS buffer by the epilogue
-// (bias + activation on the accumulator fragments).  Weights are re-tiled once on the host into B-fragment order
-// ([16-column chunk][k/4][lane]), so a wave's B operand is one coalesced 256-byte load per MFMA pair; each wave owns every
-// fourth 16-column chunk of the layer and keeps two independent accumulators (rows 0-15 and 16-31), which is what the
-// 16x16x4 instruction needs to issue back to back.  Exact fp32: the MFMA is a k-ordered fmaf chain.
+// MLP kernel.  Workgroup = 8 waves = 32 rows of the batch through ALL layers.  The activations of the current layer live in LDS
+// in an image a lane reads with ONE ds_read_b128 per four k-steps: [k/16][row][k%4][(k/4)%4] -- the four values a lane feeds to
+// four successive v_mfma_f32_16x16x4_f32 (A operand: lane = (row, k%4)) are adjacent, and the 64 lanes of a wave read 1 KB
+// contiguous (conflict-free).  The next layer's image is written to a second LDS buffer by the epilogue (bias + activation on the
+// accumulator fragments).  Weights are re-tiled once on the host the same way ([16-column chunk][k/16][lane][(k/4)%4]): one
+// coalesced global_load_dwordx4 per wave and eight MFMAs.  Each wave owns every eighth 16-column chunk of a layer and keeps two
+// independent accumulators (rows 0-15 and 16-31), which is what the 16x16x4 instruction needs to issue back to back.
+// Exact fp32: the MFMA is a k-ordered fmaf chain.
+//
+// Why 16-byte operand loads and two waves per SIMD (tools/micro/mfma_loop.hip, measured on MI355X): data returning from a global
+// load holds the matrix pipe of that SIMD for ~16 cycles per VGPR written and a ds_read for ~4-14, whatever the wave does
+// meanwhile -- a two-chain MFMA loop at 36 cycles per MFMA runs at 54 with one global_load_dword + one ds_read2_b32 per MFMA pair
+// (the round-1 loop: 80 us for the 235-512-256-128 pair at 4096 rows), at 46 with one dwordx4 + two b128 per eight MFMAs, and at
+// 41 with a second wave on the SIMD to fill the gaps.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -18,18 +25,24 @@
 #include "../../include/lgpolicy.h"
 #include "../../include/lgstep.h"
 
+#ifndef LG_AB
+#define LG_AB 0
+#endif
 #define MLP_ROWS 32          // batch rows per workgroup
-#define MLP_RS 33            // LDS row stride (rows) of the [k/4][row][4] activation image
+#define MLP_THREADS 512      // eight waves: two per SIMD
 #define MLP_MAXW 512         // widest layer
+#define MLP_IMG (MLP_MAXW * MLP_ROWS)          // floats of one activation image
+// element (row m, input k) of the activation image
+#define IMG(m, k) (((((k) >> 4) * MLP_ROWS + (m)) * 4 + ((k) & 3)) * 4 + (((k) >> 2) & 3))
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct MlpDev {
   int L, act;
   int dims[LG_MLP_MAX_LAYERS + 1];
-  int kpad[LG_MLP_MAX_LAYERS];       // input width rounded up to 32 (eight k-steps of 4)
+  int kpad[LG_MLP_MAX_LAYERS];       // input width rounded up to 64 (four blocks of four k-steps of 4)
   int nchunks[LG_MLP_MAX_LAYERS];    // output width rounded up to 16, / 16
-  const float* w[LG_MLP_MAX_LAYERS]; // tiled weights [chunk][k/4][64]
+  const float* w[LG_MLP_MAX_LAYERS]; // tiled weights [chunk][k/16][lane][4]
   const float* b[LG_MLP_MAX_LAYERS]; // bias, padded to 16 * nchunks
 };
 
@@ -44,7 +57,11 @@ static thread_local std::string g_pol_err;
 
 LG_DEV float apply_act(float x, int act) {
   switch (act) {
-    case LG_ACT_ELU: return x > 0.f ? x : expm1f(x);
+    case LG_ACT_ELU: {   // x > 0 ? x : expm1(x): the degree-6 Taylor polynomial for |x| < 0.25 (truncation < 5e-8 relative), exp(x) - 1
+                         // below that (fast exp: ~1e-7 absolute on a result of magnitude >= 0.22); libm's expm1f is ~30 instructions
+      const float p = x * (1.f + x * (0.5f + x * (1.f / 6 + x * (1.f / 24 + x * (1.f / 120 + x * (1.f / 720))))));
+      return x > 0.f ? x : (x > -0.25f ? p : __expf(x) - 1.f);
+    }
     case LG_ACT_RELU: return fmaxf(x, 0.f);
     case LG_ACT_TANH: return tanhf(x);
     case LG_ACT_LRELU: return x > 0.f ? x : 0.01f * x;
@@ -53,64 +70,85 @@ LG_DEV float apply_act(float x, int act) {
   return x;
 }
 
-// 32 rows of x through the whole network; result rows (width dims[L], <= 16 * nchunks) left in `out` (LDS image)
+// 32 rows of x through the whole network; result rows (width dims[L], <= 16 * nchunks) left in `yrows` / written to `y_global`
 LG_DEV void mlp_tile(const MlpDev& M, const float* __restrict__ x, int64_t row0, int64_t n, float* buf0, float* buf1, float* yrows /* [32][16*?] */,
                      float* __restrict__ y_global) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // stage the input tile: x (n, K0) row-major -> [k/4][row][k%4]
+#if LG_AB == 8      // diagnostic build: phase times of one workgroup (100 MHz wall clock), printed from the kernel
+  unsigned long long tstamp[8]; int ts_n = 0;
+#define TS() do { __builtin_amdgcn_s_waitcnt(0); tstamp[ts_n++] = wall_clock64(); } while (0)
+#else
+#define TS()
+#endif
+  TS();
+  // stage the input tile: x (n, K0) row-major -> activation image.  Eight independent loads in flight per lane.
   const int K0 = M.dims[0], K0p = M.kpad[0];
-  for (int idx = tid; idx < MLP_ROWS * K0p; idx += 256) {
-    const int r = idx / K0p, k = idx - r * K0p;
-    const int64_t row = row0 + r;
-    const float v = (row < n && k < K0) ? x[row * K0 + k] : 0.f;
-    buf0[((k >> 2) * MLP_RS + r) * 4 + (k & 3)] = v;
+  for (int base = 0; base < MLP_ROWS * K0p; base += 8 * MLP_THREADS) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * MLP_THREADS + tid, r = idx / K0p, k = idx - r * K0p;
+      const int64_t row = row0 + r;
+      v[u] = (idx < MLP_ROWS * K0p && row < n && k < K0) ? x[row * K0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * MLP_THREADS + tid, r = idx / K0p, k = idx - r * K0p;
+      if (idx < MLP_ROWS * K0p) buf0[IMG(r, k)] = v[u];
+    }
   }
   lds_barrier();
+  TS();
   float* in = buf0; float* out = buf1;
+// volatile asm keeps the two accumulator chains interleaved as written (the compiler otherwise issues the dependent MFMAs of one
+// accumulator back to back: 40-cycle dependent latency instead of the 32-cycle issue rate)
+#define MFMA_IN_ORDER(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+// One block = 16 inputs = four k-steps = eight MFMAs on the fragments (W, A0, A1), in ascending k.  The fragments of the block
+// TWO ahead (of this chunk, or of the wave's next chunk) are requested in the middle of the block: sched_barrier pins the order,
+// the compiler's s_waitcnt before a block's first MFMA then only waits for loads issued sixteen MFMAs earlier.
+#define MLP_BLOCK(W, A0, A1, NW, NA0, NA1, WN, AN)                                                            \
+      {                                                                                                       \
+        MFMA_IN_ORDER(acc0, A0.x, W.x); MFMA_IN_ORDER(acc1, A1.x, W.x);                                       \
+        MFMA_IN_ORDER(acc0, A0.y, W.y); MFMA_IN_ORDER(acc1, A1.y, W.y);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        NW = *(WN); NA0 = *(AN); NA1 = (AN)[64];                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        MFMA_IN_ORDER(acc0, A0.z, W.z); MFMA_IN_ORDER(acc1, A1.z, W.z);                                       \
+        MFMA_IN_ORDER(acc0, A0.w, W.w); MFMA_IN_ORDER(acc1, A1.w, W.w);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+      }
   for (int l = 0; l < M.L; ++l) {
-    const int ksteps = M.kpad[l] >> 2, nch = M.nchunks[l];
+    const int nblk = M.kpad[l] >> 4, nch = M.nchunks[l];          // blocks of 16 inputs per chunk: a multiple of 4
     const bool last = l == M.L - 1;
     const int nout = M.dims[l + 1];
-    for (int c = wv; c < nch; c += 4) {
+    // A fragments: lane (row = lane & 15, k%4 = lane >> 4) reads float4 (block * 32 + row) * 4 + k%4: the wave covers 64 consecutive
+    // float4 of the block; rows 16-31 sit 64 float4 further
+    const float4* ap = reinterpret_cast<const float4*>(in) + (lane & 15) * 4 + (lane >> 4);
+    const float4* wl = reinterpret_cast<const float4*>(M.w[l]) + lane;
+    float4 w0, w1, w2, w3, p0, p1, p2, p3, q0, q1, q2, q3;     // four rotating fragment sets (weights, rows 0-15, rows 16-31)
+    if (wv < nch) {
+      const float4* wc = wl + (size_t)wv * nblk * 64;
+      w0 = wc[0]; p0 = ap[0]; q0 = ap[64];
+      w1 = wc[64]; p1 = ap[128]; q1 = ap[128 + 64];
+    }
+    for (int c = wv; c < nch; c += MLP_THREADS / 64) {
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const float* __restrict__ wt = M.w[l] + (size_t)c * ksteps * 64 + lane;
-      const float* a0p = in + (lane & 15) * 4 + (lane >> 4);
-      const float* a1p = a0p + 16 * 4;
-      // k-steps in blocks of 8 (widths are padded to 32), two register buffers in ping-pong: the next block's eight weight
-      // fragments and sixteen activation fragments are requested BEFORE the current block's sixteen MFMAs issue (sched_barrier keeps the compiler from
-      // sinking the loads to their first use), so the L2 latency of the weight stream hides behind 512 cycles of MFMA
-      // work.  Loads are unconditional (the tail re-reads the last block): a load inside a branch is waited for at its end.
-// volatile asm keeps the two accumulator chains interleaved as written (the compiler otherwise issues eight dependent
-// MFMAs on one accumulator, then eight on the other: 40-cycle dependent latency instead of the 32-cycle issue rate)
-#define MFMA_IN_ORDER(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
-#define MLP_BLOCK(BUF, A0, A1, NXT, NA0, NA1, KB)                                                             \
-      {                                                                                                       \
-        const int kn_ = min((KB) + 8, ksteps - 8);                                                            \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) NXT[j] = wt[(size_t)(kn_ + j) * 64];                  \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) { NA0[j] = a0p[(kn_ + j) * MLP_RS * 4]; NA1[j] = a1p[(kn_ + j) * MLP_RS * 4]; } \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
-          MFMA_IN_ORDER(acc0, A0[j], BUF[j]);                                                                 \
-          MFMA_IN_ORDER(acc1, A1[j], BUF[j]);                                                                 \
-        }                                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
+      const float4* wc = wl + (size_t)c * nblk * 64;
+      const int cn = c + MLP_THREADS / 64 < nch ? c + MLP_THREADS / 64 : c;           // the wave's last chunk re-reads its own first blocks
+      const float4* wnext = wl + (size_t)cn * nblk * 64;
+      const int col = c * 16 + (lane & 15);
+      const float bias = M.b[l][col];
+      for (int kb = 0; kb < nblk; kb += 4) {
+        const bool more = kb + 4 < nblk;
+        MLP_BLOCK(w0, p0, q0, w2, p2, q2, wc + (size_t)(kb + 2) * 64, ap + (kb + 2) * 128)
+        MLP_BLOCK(w1, p1, q1, w3, p3, q3, wc + (size_t)(kb + 3) * 64, ap + (kb + 3) * 128)
+        MLP_BLOCK(w2, p2, q2, w0, p0, q0, more ? wc + (size_t)(kb + 4) * 64 : wnext, more ? ap + (kb + 4) * 128 : ap)
+        MLP_BLOCK(w3, p3, q3, w1, p1, q1, more ? wc + (size_t)(kb + 5) * 64 : wnext + 64, more ? ap + (kb + 5) * 128 : ap + 128)
       }
-      float bA[8], bB[8], pA0[8], pA1[8], qA0[8], qA1[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { bA[j] = wt[(size_t)j * 64]; pA0[j] = a0p[j * MLP_RS * 4]; pA1[j] = a1p[j * MLP_RS * 4]; }
-      int kb = 0;
-      for (; kb + 16 <= ksteps; kb += 16) {
-        MLP_BLOCK(bA, pA0, pA1, bB, qA0, qA1, kb)
-        MLP_BLOCK(bB, qA0, qA1, bA, pA0, pA1, kb + 8)
-      }
-      if (kb < ksteps) MLP_BLOCK(bA, pA0, pA1, bB, qA0, qA1, kb)      // odd number of blocks
-#undef MLP_BLOCK
       // the MFMAs above are opaque to the compiler's hazard recogniser: give the last one its result latency before the
       // accumulators are read by the epilogue
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
       // epilogue: C[m = 4 * (lane >> 4) + i][col = lane & 15]
-      const int col = c * 16 + (lane & 15);
-      const float bias = M.b[l][col];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = 4 * (lane >> 4) + i;
@@ -118,8 +156,8 @@ LG_DEV void mlp_tile(const MlpDev& M, const float* __restrict__ x, int64_t row0,
         if (!last) {
           v0 = apply_act(v0, M.act); v1 = apply_act(v1, M.act);
           if (col >= nout) { v0 = 0.f; v1 = 0.f; }                 // padded columns feed zeros to the next layer
-          out[((col >> 2) * MLP_RS + m) * 4 + (col & 3)] = v0;
-          out[((col >> 2) * MLP_RS + m + 16) * 4 + (col & 3)] = v1;
+          out[IMG(m, col)] = v0;
+          out[IMG(m + 16, col)] = v1;
         } else if (col < nout) {
           if (yrows) { yrows[m * 16 * nch + col] = v0; yrows[(m + 16) * 16 * nch + col] = v1; }
           if (y_global) {
@@ -129,24 +167,30 @@ LG_DEV void mlp_tile(const MlpDev& M, const float* __restrict__ x, int64_t row0,
         }
       }
     }
+    TS();
     lds_barrier();
     float* t = in; in = out; out = t;
   }
+#if LG_AB == 8
+  if (blockIdx.x == 5 && lane == 0 && M.L == 4) printf("wg %d,%d wave %d: stage %llu  L0 %llu  L1 %llu  L2 %llu  L3 %llu  (10 ns ticks)\n", blockIdx.x, blockIdx.y, wv,
+      tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4]);
+#endif
+#undef MLP_BLOCK
 }
 
-__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDev M, const float* __restrict__ x, int64_t n, float* __restrict__ y) {
-  __shared__ float buf0[(MLP_MAXW / 4) * MLP_RS * 4];
-  __shared__ float buf1[(MLP_MAXW / 4) * MLP_RS * 4];
+__global__ __launch_bounds__(MLP_THREADS) void mlp_forward_kernel(MlpDev M, const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) float buf0[MLP_IMG];
+  __shared__ __attribute__((aligned(16))) float buf1[MLP_IMG];
   mlp_tile(M, x, (int64_t)blockIdx.x * MLP_ROWS, n, buf0, buf1, nullptr, y);
 }
 
 // PPO.act: blockIdx.y = 0 actor (+ sampling, log-prob), 1 critic
-__global__ __launch_bounds__(256) void policy_act_kernel(MlpDev A, MlpDev Cr, const float* __restrict__ obs, const float* __restrict__ cobs,
+__global__ __launch_bounds__(MLP_THREADS) void policy_act_kernel(MlpDev A, MlpDev Cr, const float* __restrict__ obs, const float* __restrict__ cobs,
                                                          int64_t n, const float* __restrict__ stdv, uint32_t seed_lo, uint32_t seed_hi,
                                                          uint32_t call_lo, uint32_t call_hi, int deterministic, float* __restrict__ actions,
                                                          float* __restrict__ mean, float* __restrict__ logp, float* __restrict__ values) {
-  __shared__ float buf0[(MLP_MAXW / 4) * MLP_RS * 4];
-  __shared__ float buf1[(MLP_MAXW / 4) * MLP_RS * 4];
+  __shared__ __attribute__((aligned(16))) float buf0[MLP_IMG];
+  __shared__ __attribute__((aligned(16))) float buf1[MLP_IMG];
   __shared__ float yrows[MLP_ROWS * 16 * 2];       // output rows of the actor (<= 32 actions)
   __shared__ float lp[MLP_ROWS][32];
   const int64_t row0 = (int64_t)blockIdx.x * MLP_ROWS;
@@ -155,7 +199,7 @@ __global__ __launch_bounds__(256) void policy_act_kernel(MlpDev A, MlpDev Cr, co
   mlp_tile(A, obs, row0, n, buf0, buf1, yrows, mean);
   // one lane per (row, action): z from Philox + Box-Muller, two normals per counter word pair
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < MLP_ROWS * 32; idx += 256) {
+  for (int idx = tid; idx < MLP_ROWS * 32; idx += MLP_THREADS) {
     const int r = idx >> 5, a = idx & 31;
     float term = 0.f;
     if (a < na && row0 + r < n) {
@@ -247,18 +291,20 @@ lg_mlp* lg_mlp_create(int32_t L, const int32_t* dims, const float* const* weight
   m->device = device_id; m->h.L = L; m->h.act = activation;
   for (int l = 0; l <= L; ++l) m->h.dims[l] = dims[l];
   for (int l = 0; l < L; ++l) {
-    const int K = dims[l], N = dims[l + 1], Kp = (K + 31) & ~31, ks = Kp / 4;
+    const int K = dims[l], N = dims[l + 1], Kp = (K + 63) & ~63, nb = Kp / 16;
     // hidden layers produce the next layer's whole padded input (zero weights and bias -> act(0) = 0 in the padding)
-    const int nch = l == L - 1 ? (N + 15) / 16 : ((N + 31) & ~31) / 16;
+    const int nch = l == L - 1 ? (N + 15) / 16 : ((N + 63) & ~63) / 16;
     m->h.kpad[l] = Kp; m->h.nchunks[l] = nch;
-    // B fragment of v_mfma_f32_16x16x4_f32: lane holds B[k = lane >> 4][n = lane & 15] = W[n][k]
-    std::vector<float> tw((size_t)nch * ks * 64, 0.f), tb((size_t)nch * 16, 0.f);
+    // B fragment of v_mfma_f32_16x16x4_f32: lane holds B[k = lane >> 4][n = lane & 15] = W[n][k]; the fragments of the four
+    // k-steps of a 16-input block sit in one float4 per lane
+    std::vector<float> tw((size_t)nch * nb * 64 * 4, 0.f), tb((size_t)nch * 16, 0.f);
     for (int c = 0; c < nch; ++c)
-      for (int s = 0; s < ks; ++s)
-        for (int ln = 0; ln < 64; ++ln) {
-          const int nn = c * 16 + (ln & 15), kk = s * 4 + (ln >> 4);
-          if (nn < N && kk < K) tw[((size_t)c * ks + s) * 64 + ln] = weights[l][(size_t)nn * K + kk];
-        }
+      for (int b = 0; b < nb; ++b)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int s = 0; s < 4; ++s) {
+            const int nn = c * 16 + (ln & 15), kk = b * 16 + s * 4 + (ln >> 4);
+            if (nn < N && kk < K) tw[(((size_t)c * nb + b) * 64 + ln) * 4 + s] = weights[l][(size_t)nn * K + kk];
+          }
     for (int i = 0; i < N; ++i) tb[i] = biases[l][i];
     void *dw = nullptr, *db = nullptr;
     if (hipMalloc(&dw, tw.size() * 4) != hipSuccess || hipMalloc(&db, tb.size() * 4) != hipSuccess ||
@@ -280,7 +326,7 @@ int lg_mlp_forward(lg_mlp* m, const float* x, int64_t n, float* y, void* stream)
   if (!m || !x || !y || n < 0) return LG_ERR_INVALID;
   DeviceScope ds_(m->device);
   if (n == 0) return LG_OK;
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS)), dim3(256), 0, (hipStream_t)stream, m->h, x, n, y);
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS)), dim3(MLP_THREADS), 0, (hipStream_t)stream, m->h, x, n, y);
   POL_TRY(m, hipGetLastError());
   return LG_OK;
 }
@@ -291,7 +337,7 @@ int lg_policy_act(lg_mlp* actor, lg_mlp* critic, const float* obs, const float* 
   DeviceScope ds_(actor->device);
   if (actor->h.dims[actor->h.L] > 32) { actor->err = "lg_policy_act supports up to 32 actions"; return LG_ERR_UNSUPPORTED; }
   if (n == 0) return LG_OK;
-  hipLaunchKernelGGL(policy_act_kernel, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS), 2), dim3(256), 0, (hipStream_t)stream, actor->h, critic->h,
+  hipLaunchKernelGGL(policy_act_kernel, dim3((unsigned)((n + MLP_ROWS - 1) / MLP_ROWS), 2), dim3(MLP_THREADS), 0, (hipStream_t)stream, actor->h, critic->h,
                      obs, critic_obs, n, std_, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)call, (uint32_t)(call >> 32), deterministic,
                      actions, action_mean, logp, values);
   POL_TRY(actor, hipGetLastError());
