@@ -459,6 +459,9 @@ LG_DEV bool fused_needs_heights_early(const DevCtx* __restrict__ C);
 LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__ C);
 
 template <int MODE, bool TMESH>
+#if LG_AB == 9      // timing probe: cap the kernel at the 256 registers per wave that two workgroups per CU would leave (spills go to scratch)
+__attribute__((amdgpu_num_vgpr(120)))
+#endif
 __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, int nact,
                                                       const int32_t* __restrict__ ids, int n, int act_stride, int fuse, PostSink sink) {
   // act_stride: floats between consecutive action rows (12, or horizon * 12 when the rows are one step of a (n, horizon, 12) plan)
