@@ -71,6 +71,7 @@ class lg_terrain(C.Structure):
         ("terrain_origins", C.POINTER(f32)),
         ("env_length", f32),
         ("collision_mesh", C.c_void_p),
+        ("grid_vertices", C.POINTER(f32)),
     ]
 
 

@@ -207,7 +207,8 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
 // when either query still needs it, each leaf triangle is tested against both, and each query keeps its own radius and
 // result exactly as `closest_point` would have (same tolerances, same tie rule), so the outcome per query is the
 // solo outcome.  A query with on = false is skipped.
-struct ClosestQuery { V3 p; float max_dist; bool on; bool found; V3 cp, fn; };
+struct ClosestQuery { V3 p; float max_dist; bool on; bool found; V3 cp, fn;
+                      float range, lb; };   // grid meshes: `range` = beyond this distance only a lower bound is wanted, returned in `lb` when nothing is found
 LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery& B, int* visits = nullptr) {
   float bestA = A.max_dist * A.max_dist, bestB = B.max_dist * B.max_dist, absA = -1.f, absB = -1.f;
   bool fA = false, fB = false;

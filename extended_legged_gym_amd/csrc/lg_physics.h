@@ -179,7 +179,9 @@ LG_DEV void symv6(const float* Si, const float* x, float* y) {
 
 // terrain surface under (x, y): height and unit normal of the regular-grid triangulation (diagonal v(i,j)->v(i+1,j+1)).
 // Split in two so that callers can put other work between the four sample loads and their first use.
-struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t* __restrict__ H; MeshView M; };
+struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t* __restrict__ H; MeshView M;
+                     const float* __restrict__ GV; /* grid-mesh vertices (rows x cols x 3, world frame) or null */
+                     const float* __restrict__ GM; int mcols; /* max vertex z per 8 x 8 block of vertices */ };
 struct TerrainCell { float u, v; int16_t h0, h1, h2, h3; };
 LG_DEV TerrainCell terrain_fetch(const TerrainView& T, float x, float y) {
   // branch-free on purpose (the plane reads its 1 x 1 dummy grid): a conditional around the loads would make the
@@ -332,6 +334,103 @@ LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const Phys
   contact_detect_finish<S0, S1>(lm_, T, P, pb, pr, cst, lane);
 }
 
+// Closest point on a GRID mesh (lg_terrain.grid_vertices): the triangles of cell (i, j) are (v0, v3, v1) and (v0, v2, v3) with
+// v0 = (i, j), v1 = (i, j+1), v2 = (i+1, j), v3 = (i+1, j+1), and the slope correction moved every vertex by at most one cell in x and
+// y, so a cell's triangles lie inside [(i-1) hs, (i+2) hs] x [(j-1) hs, (j+2) hs]: the cells that can hold a point within R of p are
+// an index range around p, scanned row by row (two new vertices per cell) with a box test per cell in front of the two triangle
+// tests.  Same per-triangle arithmetic, tolerances and tie rule as `closest_point` (lg_bvh.h), which is independent of the order
+// the triangles are met in: the result is the BVH's.  ~10-30 triangle tests for a foot on the ground instead of a tree walk with
+// dependent 128-byte node fetches.
+LG_DEV void closest_grid_triangle(V3 p, V3 a, V3 b, V3 cc, float& best2, bool& found, float& bestabs, V3& bestp, V3& bestn) {
+  V3 fn = cross(b - a, cc - a); float fl = norm(fn);
+  if (!(fl > 1e-10f)) return;                                 // zero-area faces of the slope correction
+  V3 q = closest_on_triangle(p, a, b, cc);
+  V3 dq = p - q; float d2 = dot(dq, dq);
+  if (!(d2 <= best2 * (1.f + 1e-5f) + 1e-12f)) return;
+  const bool strictly = !found || d2 < best2 * (1.f - 1e-5f) - 1e-12f;
+  if (strictly) { bestabs = -1.f; bestn = v3(0, 0, 1); }
+  V3 nh = (1.f / fl) * fn;
+  float sd = dot(dq, nh);
+  float ab = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f);
+  if (ab > bestabs) { bestn = nh; bestabs = ab; }
+  if (!found || d2 < best2) { best2 = d2; bestp = q; }
+  found = true;
+}
+LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visits = nullptr) {
+  if (!A.on) return;
+#if LG_AB == 1      // timing probe: no query at all (nothing is ever found)
+  A.found = false; A.cp = A.p; A.fn = v3(0, 0, 1); return;
+#endif
+  const float R = A.max_dist, ihs = frcp(T.hscale);
+  float best2 = R * R, bestabs = -1.f; bool found = false;
+  V3 bestp = A.p, bestn = v3(0, 0, 1);
+  const V3 p = A.p;
+  const float gx = (p.x + T.border) * ihs, gy = (p.y + T.border) * ihs;
+  float gr = R * ihs + 1e-3f;
+  int i0 = (int)floorf(gx - gr) - 1, i1 = (int)floorf(gx + gr) + 1, j0 = (int)floorf(gy - gr) - 1, j1 = (int)floorf(gy + gr) + 1;
+  i0 = max(i0, 0); j0 = max(j0, 0); i1 = min(i1, T.rows - 2); j1 = min(j1, T.cols - 2);
+  A.found = false; A.cp = p; A.fn = v3(0, 0, 1);
+  if (i0 > i1 || j0 > j1) return;
+  {  // nothing of the window reaches up to the sphere: the highest vertex of the 8 x 8 blocks that cover it is more than R below p
+    float top = -1e30f;
+    for (int bi = i0 >> 3; bi <= (i1 + 1) >> 3; ++bi)
+      for (int bj = j0 >> 3; bj <= (j1 + 1) >> 3; ++bj) top = fmaxf(top, T.GM[bi * T.mcols + bj]);
+    if (p.z - top > R) return;
+  }
+  {  // the window's own highest vertex (the height samples ARE the vertex heights; the slope correction moves x and y only): when
+     // the sphere is more than the contact range above it, no contact is possible and the exact closest point is not needed --
+     // the caller's distance cache gets the proven lower bound.  A pass of 2-byte loads instead of a box test per cell.
+    int hmax = -32768;
+    for (int i = i0; i <= i1 + 1; ++i) {
+      const int16_t* hr = T.H + (size_t)i * T.cols;
+      for (int j = j0; j <= j1 + 1; ++j) hmax = max(hmax, (int)hr[j]);
+    }
+    const float clear = p.z - ((float)hmax * T.vscale + 1e-4f);
+    if (clear > A.range) { A.lb = fminf(R, clear); return; }
+  }
+  auto cell = [&](int i, int j, V3 v0, V3 v1, V3 v2, V3 v3_) {
+    if (visits) ++*visits;
+    const float lox = fminf(fminf(v0.x, v1.x), fminf(v2.x, v3_.x)), hix = fmaxf(fmaxf(v0.x, v1.x), fmaxf(v2.x, v3_.x));
+    const float loy = fminf(fminf(v0.y, v1.y), fminf(v2.y, v3_.y)), hiy = fmaxf(fmaxf(v0.y, v1.y), fmaxf(v2.y, v3_.y));
+    const float loz = fminf(fminf(v0.z, v1.z), fminf(v2.z, v3_.z)), hiz = fmaxf(fmaxf(v0.z, v1.z), fmaxf(v2.z, v3_.z));
+    const float dx = fmaxf(fmaxf(lox - p.x, 0.f), p.x - hix), dy = fmaxf(fmaxf(loy - p.y, 0.f), p.y - hiy), dz = fmaxf(fmaxf(loz - p.z, 0.f), p.z - hiz);
+    if (dx * dx + dy * dy + dz * dz <= best2 * (1.f + 1e-5f) + 1e-12f) {
+      closest_grid_triangle(p, v0, v3_, v1, best2, found, bestabs, bestp, bestn);
+      closest_grid_triangle(p, v0, v2, v3_, best2, found, bestabs, bestp, bestn);
+    }
+  };
+#if LG_AB == 2      // timing probe: the cell under the sphere only
+  { const int ci = max(i0, min((int)floorf(gx), i1)), cj = max(j0, min((int)floorf(gy), j1));
+    const float* r0 = T.GV + ((size_t)ci * T.cols + cj) * 3; const float* r1 = r0 + (size_t)T.cols * 3;
+    cell(ci, cj, v3(r0[0], r0[1], r0[2]), v3(r0[3], r0[4], r0[5]), v3(r1[0], r1[1], r1[2]), v3(r1[3], r1[4], r1[5]));
+    A.found = found; A.cp = bestp; A.fn = bestn; return; }
+#endif
+  {  // the cell under the sphere first: on most ground its triangles are the closest ones or nearly so, and whatever distance they
+     // give bounds the search -- the window shrinks to the cells that can hold something closer (they are met again by the scan:
+     // a triangle met twice changes nothing, the update rules are idempotent)
+    const int ci = max(i0, min((int)floorf(gx), i1)), cj = max(j0, min((int)floorf(gy), j1));
+    const float* r0 = T.GV + ((size_t)ci * T.cols + cj) * 3; const float* r1 = r0 + (size_t)T.cols * 3;
+    cell(ci, cj, v3(r0[0], r0[1], r0[2]), v3(r0[3], r0[4], r0[5]), v3(r1[0], r1[1], r1[2]), v3(r1[3], r1[4], r1[5]));
+    if (found) {
+      gr = sqrtf(best2) * ihs * (1.f + 1e-4f) + 1e-3f;
+      i0 = max(i0, (int)floorf(gx - gr) - 1); i1 = min(i1, (int)floorf(gx + gr) + 1);
+      j0 = max(j0, (int)floorf(gy - gr) - 1); j1 = min(j1, (int)floorf(gy + gr) + 1);
+    }
+  }
+  for (int i = i0; i <= i1; ++i) {
+    const float* r0 = T.GV + ((size_t)i * T.cols + j0) * 3;
+    const float* r1 = r0 + (size_t)T.cols * 3;
+    V3 v0 = v3(r0[0], r0[1], r0[2]), v2 = v3(r1[0], r1[1], r1[2]);
+    for (int j = j0; j <= j1; ++j) {
+      r0 += 3; r1 += 3;
+      const V3 v1 = v3(r0[0], r0[1], r0[2]), v3_ = v3(r1[0], r1[1], r1[2]);
+      cell(i, j, v0, v1, v2, v3_);
+      v0 = v1; v2 = v3_;
+    }
+  }
+  A.found = found; A.cp = bestp; A.fn = bestn;
+}
+
 // Triangle-mesh terrain (LG_MESH_TRIMESH): the surface under a sphere is the closest point of the collision mesh within
 // range = radius + contact_offset + LG_MESH_CONTACT_MARGIN (the margin lets a sphere whose centre has sunk below the surface
 // still find it); normal = direction from that point to the sphere centre (flipped when the centre is behind the deciding
@@ -363,7 +462,7 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
     for (int h = 0; h < 2; ++h) {
       const int sl = sp0 + h;
       xs[h] = pb; rads[h] = 0.f; ranges[h] = 0.f; reaches[h] = 0.f;
-      Q[h].p = pb; Q[h].max_dist = 0.f; Q[h].on = false; Q[h].found = false; Q[h].cp = pb; Q[h].fn = v3(0, 0, 1);
+      Q[h].p = pb; Q[h].max_dist = 0.f; Q[h].on = false; Q[h].found = false; Q[h].cp = pb; Q[h].fn = v3(0, 0, 1); Q[h].range = 0.f; Q[h].lb = 0.f;
       if (sl < s1 && sl < ncp) {
         const int link = lm_.i(LM_CP_LINK + sl);
         const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
@@ -382,13 +481,14 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
             bound = fminf(reach, dq + travel * 1.0001f + 1e-4f);
           }
         }
-        Q[h].p = x; Q[h].max_dist = bound; Q[h].on = query;
+        Q[h].p = x; Q[h].max_dist = bound; Q[h].on = query; Q[h].range = range; Q[h].lb = bound;
       }
     }
 #ifdef LG_STAMPS
     {
       int visits = 0;
-      closest_point_pair(T.M, Q[0], Q[1], &visits);
+      if (T.GV) { closest_point_grid(T, Q[0], &visits); closest_point_grid(T, Q[1], &visits); }
+      else closest_point_pair(T.M, Q[0], Q[1], &visits);
       // diagnostic: queries issued / traversal steps (sum and max over the wave) of workgroup 0, wave 2
       int vmax = visits, vsum = visits;
       for (int off = 32; off > 0; off >>= 1) { vmax = max(vmax, __shfl_xor(vmax, off)); vsum += __shfl_xor(vsum, off); }
@@ -396,7 +496,8 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       if (dbg && lane == 0) { dbg[28] += nq; dbg[29] += vsum; dbg[30] += vmax; dbg[31] += 1; }
     }
 #else
-    closest_point_pair(T.M, Q[0], Q[1]);
+    if (T.GV) { closest_point_grid(T, Q[0]); closest_point_grid(T, Q[1]); }
+    else closest_point_pair(T.M, Q[0], Q[1]);
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -406,7 +507,9 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       bool active = false; V3 n = v3(0, 0, 1); float phi = 1.f;
       const V3 x = xs[h]; const float rad = rads[h];
       if (Q[h].on) {
-        const V3 diff = x - Q[h].cp; const float dist = Q[h].found ? norm(diff) : reaches[h];
+        // nothing found: nothing lies within the radius that was searched (= `reach` whenever the cached distance was exact; a grid
+        // mesh may return a smaller proven bound)
+        const V3 diff = x - Q[h].cp; const float dist = Q[h].found ? norm(diff) : (T.GV ? Q[h].lb : reaches[h]);
         if (cq) { CQ(sl, 0) = x.x; CQ(sl, 1) = x.y; CQ(sl, 2) = x.z; CQ(sl, 3) = dist; }
         if (Q[h].found && dist <= ranges[h]) {
           const float sign = dot(diff, Q[h].fn) < 0.f ? -1.f : 1.f;

@@ -86,6 +86,8 @@ struct lg_ctx {
   void* arena = nullptr; bool own_arena = false; size_t arena_bytes = 0;
   void* aux = nullptr; // noise_vec, height_points, partials
   void* mesh_cache = nullptr;
+  void* grid_verts = nullptr;   // device copy of lg_terrain.grid_vertices
+  int grid_mesh = 1;           // LG_GRID_MESH=0: walk the BVH for grid meshes too (diagnostic / A-B)
   TensorInfo t[LG_T_COUNT];
   int device = 0;
   unsigned long sync_calls = 0;
@@ -1974,6 +1976,7 @@ void lg_destroy(lg_ctx* c) {
   if (c->d) (void)hipFree(c->d);
   if (c->aux) (void)hipFree(c->aux);
   if (c->mesh_cache) (void)hipFree(c->mesh_cache);
+  if (c->grid_verts) (void)hipFree(c->grid_verts);
   if (c->own_arena && c->arena) (void)hipFree(c->arena);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   delete c;
@@ -2030,7 +2033,24 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.ter.mesh_type = ter->mesh_type; h.ter.rows = ter->rows; h.ter.cols = ter->cols;
   h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
   h.ter.H = (const int16_t*)P(LG_T_HEIGHT_SAMPLES);
-  h.ter.M = MeshView{nullptr, nullptr};
+  h.ter.M = MeshView{nullptr, nullptr}; h.ter.GV = nullptr; h.ter.GM = nullptr; h.ter.mcols = 0;
+  if (const char* ev = getenv("LG_GRID_MESH")) c->grid_mesh = atoi(ev) != 0;
+  if (ter->mesh_type == LG_MESH_TRIMESH && ter->grid_vertices && c->grid_mesh) {      // grid mesh: contact queries by cell index
+    // vertices, then the max z of every 8 x 8 block of vertices (the cull in closest_point_grid)
+    const size_t nv = (size_t)ter->rows * ter->cols * 3;
+    const int mr = (ter->rows + 7) / 8, mc = (ter->cols + 7) / 8;
+    std::vector<float> top((size_t)mr * mc, -1e30f);
+    for (int i = 0; i < ter->rows; ++i)
+      for (int j = 0; j < ter->cols; ++j) {
+        float& t = top[(size_t)(i >> 3) * mc + (j >> 3)];
+        t = std::max(t, ter->grid_vertices[((size_t)i * ter->cols + j) * 3 + 2]);
+      }
+    if (hipMalloc((void**)&c->grid_verts, (nv + top.size()) * sizeof(float)) != hipSuccess ||
+        hipMemcpy(c->grid_verts, ter->grid_vertices, nv * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy((float*)c->grid_verts + nv, top.data(), top.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+      return fail("grid-mesh vertex upload failed");
+    h.ter.GV = (const float*)c->grid_verts; h.ter.GM = (const float*)c->grid_verts + nv; h.ter.mcols = mc;
+  }
   if (ter->mesh_type == LG_MESH_TRIMESH) {
     if (ter->collision_mesh->device != device_id) return fail("collision mesh lives on another device");
     h.ter.M = MeshView{ter->collision_mesh->d_nodes, ter->collision_mesh->d_tris};

@@ -285,6 +285,11 @@ class NativeSetup:
                 shift = np.array([cfg.terrain.border_size, cfg.terrain.border_size, 0.0], dtype=np.float32)
                 self.collision_vertices = np.ascontiguousarray(np.asarray(terrain.vertices, dtype=np.float32) - shift)
                 self.collision_triangles = np.ascontiguousarray(np.asarray(terrain.triangles).astype(np.int32))
+                # a procedural Terrain's mesh is the regular triangulation of its height grid: the kernel can index the cells
+                # around a collision sphere directly (lg_terrain.grid_vertices) instead of walking the BVH
+                nr, nc = self.height_samples.shape
+                if shifted and self.collision_vertices.shape[0] == nr * nc and self.collision_triangles.shape[0] == 2 * (nr - 1) * (nc - 1):
+                    t.grid_vertices = self.collision_vertices.ctypes.data_as(C.POINTER(C.c_float))
             t.rows, t.cols = self.height_samples.shape
             t.horizontal_scale, t.vertical_scale = cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale
             t.border_size = cfg.terrain.border_size

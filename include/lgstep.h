@@ -187,6 +187,11 @@ typedef struct lg_terrain {
   const float* terrain_origins;       /* HOST pointer, copied at lg_create */
   float env_length;                   /* terrain.env_length, curriculum distance threshold (:510) */
   const struct lg_mesh* collision_mesh; /* LG_MESH_TRIMESH: handle from lg_mesh_create (same device), must outlive the ctx */
+  const float* grid_vertices;         /* HOST pointer or NULL, rows*cols*3, copied at lg_create.  Set when the collision mesh is the
+                                       * regular triangulation of a height grid (convert_heightfield_to_trimesh, terrain.py:77-80: cell
+                                       * (i, j) -> triangles (v0, v3, v1), (v0, v2, v3); vertices moved by at most one cell in x / y by the
+                                       * slope correction), in world coordinates: contact queries then index the cells around a sphere
+                                       * directly instead of walking the BVH -- same triangles, same closest points, same tie rule */
 } lg_terrain;
 
 typedef struct lg_config {

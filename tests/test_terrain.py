@@ -205,3 +205,71 @@ def test_trimesh_wall_stops_a_robot_pushed_against_it():
     assert x_max < xw + 0.02                                                # no body got past the face at ground level ...
     assert float(core.t["root_states"][:, 2].max()) < 0.75                  # ... nor was the robot lifted onto the 0.6 m step
     core.close()
+
+
+@pytest.mark.gpu
+def test_grid_mesh_queries_equal_the_bvh_walk():
+    """A procedural `Terrain` mesh is the regular triangulation of its height grid, so the contact path indexes the cells around a
+    sphere (lg_terrain.grid_vertices) instead of walking the BVH (`LG_GRID_MESH=0`).  Both visit every triangle that can hold the
+    closest point and share the per-triangle arithmetic and the order-independent tie rule: same contacts, same trajectories
+    (the closest POINT on an edge shared by two faces may come from either, a last-bit difference)."""
+    import os
+    import torch
+    from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
+    from extended_legged_gym_amd.envs.base.native_config import NativeSetup, load_robot_model
+    from extended_legged_gym_amd.native import NativeCore
+    from extended_legged_gym_amd.utils.terrain import Terrain
+    from tests.helpers import ANYMAL_GAIT, sim_params_for
+    n = 128
+    cfg = AnymalCRoughCfg()
+    cfg.env.num_envs = n
+    cfg.control.use_actuator_network = False
+    t = cfg.terrain
+    t.num_rows, t.num_cols, t.border_size, t.max_init_terrain_level = 3, 4, 5, 2
+    np.random.seed(3)
+    ter = Terrain(t, n)
+    cores = []
+    for flag in ("1", "0"):
+        setup = NativeSetup(cfg, sim_params_for(cfg), load_robot_model(cfg.asset), terrain=ter, seed=5, gait=ANYMAL_GAIT)
+        assert bool(setup.terrain.grid_vertices)
+        old = os.environ.get("LG_GRID_MESH")
+        os.environ["LG_GRID_MESH"] = flag
+        try:
+            cores.append(NativeCore(setup, "cuda:0"))
+        finally:
+            if old is None:
+                del os.environ["LG_GRID_MESH"]
+            else:
+                os.environ["LG_GRID_MESH"] = old
+    rng = np.random.default_rng(0)
+    lv = torch.from_numpy(rng.integers(0, 3, n)); ty = torch.from_numpy(rng.integers(0, 4, n))
+    org = torch.from_numpy(ter.env_origins[lv.numpy(), ty.numpy()].astype(np.float32))
+    for c in cores:
+        c.t["terrain_levels"].copy_(lv); c.t["terrain_types"].copy_(ty); c.t["env_origins"].copy_(org)
+        c.reset_idx(torch.arange(n))
+    g = torch.Generator().manual_seed(1)
+    contacts = mismatched = 0
+    from tests.test_hip_fused_step import SYNC
+    for it in range(40):
+        for name in SYNC:                                   # same state in front of every compared step (contacts are chaotic:
+            cores[1].t[name].copy_(cores[0].t[name])        # a last-bit difference grows to 1e-4 within a dozen steps)
+        a = torch.randn(n, 12, generator=g).cuda()
+        for c in cores:
+            c.step(a)
+        torch.cuda.synchronize()
+        for name in ("root_states", "dof_state", "contact_forces", "rew_buf"):
+            x, y = cores[0].t[name].cpu().numpy().reshape(n, -1), cores[1].t[name].cpu().numpy().reshape(n, -1)
+            tol = 1e-3 if name == "contact_forces" else 1e-5
+            bad = (np.abs(x - y) > tol + 1e-4 * np.abs(y)).any(axis=1)
+            # a sphere whose gap sits within rounding of the activation distance can be a contact on one path and not yet on the
+            # other: such an env differs for that step by a small force (both are valid)
+            assert bad.sum() <= 2, (it, name, int(bad.sum()))
+            worst = float(np.abs(x - y).max()) if name != "contact_forces" else 0.0
+            assert worst < 5e-3, (it, name, worst)
+            mismatched += int(bad.sum())
+        assert torch.equal(cores[0].t["reset_buf"], cores[1].t["reset_buf"])
+        contacts += int((cores[0].t["contact_forces"].view(n, -1, 3)[:, :, 2] > 1.0).sum())
+    assert contacts > 40 * n                                                # the robots were standing on the mesh all along
+    assert mismatched <= 12                                                 # of 40 steps x 128 envs x 4 tensors
+    for c in cores:
+        c.close()
