@@ -180,8 +180,8 @@ LG_DEV void symv6(const float* Si, const float* x, float* y) {
 // terrain surface under (x, y): height and unit normal of the regular-grid triangulation (diagonal v(i,j)->v(i+1,j+1)).
 // Split in two so that callers can put other work between the four sample loads and their first use.
 struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t* __restrict__ H; MeshView M;
-                     const float* __restrict__ GV; /* grid-mesh vertices (rows x cols x 3, world frame) or null */
-                     const float* __restrict__ GM; int mcols; /* max vertex z per 8 x 8 block of vertices */ };
+                     const float* __restrict__ GV; /* non-null: grid mesh */ const float4* __restrict__ GV4; /* its vertices (rows x cols) x (x, y, z, 0), world frame */
+                     const float* __restrict__ GM; int mcols; /* max vertex z per 2 x 2 block of vertices */ };
 struct TerrainCell { float u, v; int16_t h0, h1, h2, h3; };
 LG_DEV TerrainCell terrain_fetch(const TerrainView& T, float x, float y) {
   // branch-free on purpose (the plane reads its 1 x 1 dummy grid): a conditional around the loads would make the
@@ -356,6 +356,9 @@ LG_DEV void closest_grid_triangle(V3 p, V3 a, V3 b, V3 cc, float& best2, bool& f
   if (!found || d2 < best2) { best2 = d2; bestp = q; }
   found = true;
 }
+// Every stage below is a few ROUNDS of independent loads (indices clamped, loads unconditional) followed by arithmetic: a wave pays
+// one L2 latency per round whatever its lanes need, and the first version's one-cell-at-a-time loop spent 36 k cycles per pair of
+// queries on ~20 dependent rounds each.
 LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visits = nullptr) {
   if (!A.on) return;
 #if LG_AB == 1      // timing probe: no query at all (nothing is ever found)
@@ -371,25 +374,27 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
   i0 = max(i0, 0); j0 = max(j0, 0); i1 = min(i1, T.rows - 2); j1 = min(j1, T.cols - 2);
   A.found = false; A.cp = p; A.fn = v3(0, 0, 1);
   if (i0 > i1 || j0 > j1) return;
-  {  // nothing of the window reaches up to the sphere: the highest vertex of the 8 x 8 blocks that cover it is more than R below p
+  {  // how far the sphere is above everything around it: the highest vertex of the 2 x 2 blocks that cover the window's vertices
+     // (a vertex's height is its height sample; the slope correction moves x and y only).  More than radius + contact_offset: no
+     // contact is possible, the exact closest point is not needed, and the caller's distance cache gets the proven lower bound.
+    const int bi0 = i0 >> 1, bi1 = (i1 + 1) >> 1, bj0 = j0 >> 1, bj1 = (j1 + 1) >> 1;
     float top = -1e30f;
-    for (int bi = i0 >> 3; bi <= (i1 + 1) >> 3; ++bi)
-      for (int bj = j0 >> 3; bj <= (j1 + 1) >> 3; ++bj) top = fmaxf(top, T.GM[bi * T.mcols + bj]);
-    if (p.z - top > R) return;
-  }
-  {  // the window's own highest vertex (the height samples ARE the vertex heights; the slope correction moves x and y only): when
-     // the sphere is more than the contact range above it, no contact is possible and the exact closest point is not needed --
-     // the caller's distance cache gets the proven lower bound.  A pass of 2-byte loads instead of a box test per cell.
-    int hmax = -32768;
-    for (int i = i0; i <= i1 + 1; ++i) {
-      const int16_t* hr = T.H + (size_t)i * T.cols;
-      for (int j = j0; j <= j1 + 1; ++j) hmax = max(hmax, (int)hr[j]);
-    }
-    const float clear = p.z - ((float)hmax * T.vscale + 1e-4f);
+    for (int bi = bi0; bi <= bi1; bi += 4)
+      for (int bj = bj0; bj <= bj1; bj += 8) {
+        float tv[32];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 8; ++t) tv[8 * u + t] = T.GM[(size_t)min(bi + u, bi1) * T.mcols + min(bj + t, bj1)];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) top = fmaxf(top, tv[t]);
+      }
+    const float clear = p.z - top;
     if (clear > A.range) { A.lb = fminf(R, clear); return; }
   }
-  auto cell = [&](int i, int j, V3 v0, V3 v1, V3 v2, V3 v3_) {
+  auto cell = [&](float4 a0, float4 a1, float4 b0, float4 b1) {
     if (visits) ++*visits;
+    const V3 v0 = v3(a0.x, a0.y, a0.z), v1 = v3(a1.x, a1.y, a1.z), v2 = v3(b0.x, b0.y, b0.z), v3_ = v3(b1.x, b1.y, b1.z);
     const float lox = fminf(fminf(v0.x, v1.x), fminf(v2.x, v3_.x)), hix = fmaxf(fmaxf(v0.x, v1.x), fmaxf(v2.x, v3_.x));
     const float loy = fminf(fminf(v0.y, v1.y), fminf(v2.y, v3_.y)), hiy = fmaxf(fmaxf(v0.y, v1.y), fmaxf(v2.y, v3_.y));
     const float loz = fminf(fminf(v0.z, v1.z), fminf(v2.z, v3_.z)), hiz = fmaxf(fmaxf(v0.z, v1.z), fmaxf(v2.z, v3_.z));
@@ -399,33 +404,35 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
       closest_grid_triangle(p, v0, v2, v3_, best2, found, bestabs, bestp, bestn);
     }
   };
-#if LG_AB == 2      // timing probe: the cell under the sphere only
-  { const int ci = max(i0, min((int)floorf(gx), i1)), cj = max(j0, min((int)floorf(gy), j1));
-    const float* r0 = T.GV + ((size_t)ci * T.cols + cj) * 3; const float* r1 = r0 + (size_t)T.cols * 3;
-    cell(ci, cj, v3(r0[0], r0[1], r0[2]), v3(r0[3], r0[4], r0[5]), v3(r1[0], r1[1], r1[2]), v3(r1[3], r1[4], r1[5]));
-    A.found = found; A.cp = bestp; A.fn = bestn; return; }
-#endif
   {  // the cell under the sphere first: on most ground its triangles are the closest ones or nearly so, and whatever distance they
      // give bounds the search -- the window shrinks to the cells that can hold something closer (they are met again by the scan:
      // a triangle met twice changes nothing, the update rules are idempotent)
     const int ci = max(i0, min((int)floorf(gx), i1)), cj = max(j0, min((int)floorf(gy), j1));
-    const float* r0 = T.GV + ((size_t)ci * T.cols + cj) * 3; const float* r1 = r0 + (size_t)T.cols * 3;
-    cell(ci, cj, v3(r0[0], r0[1], r0[2]), v3(r0[3], r0[4], r0[5]), v3(r1[0], r1[1], r1[2]), v3(r1[3], r1[4], r1[5]));
+    const float4* ra = T.GV4 + (size_t)ci * T.cols + cj; const float4* rb = ra + T.cols;
+    const float4 a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1];
+    cell(a0, a1, b0, b1);
+#if LG_AB == 2      // timing probe: the cell under the sphere only
+    A.found = found; A.cp = bestp; A.fn = bestn; return;
+#endif
     if (found) {
       gr = sqrtf(best2) * ihs * (1.f + 1e-4f) + 1e-3f;
       i0 = max(i0, (int)floorf(gx - gr) - 1); i1 = min(i1, (int)floorf(gx + gr) + 1);
       j0 = max(j0, (int)floorf(gy - gr) - 1); j1 = min(j1, (int)floorf(gy + gr) + 1);
     }
   }
-  for (int i = i0; i <= i1; ++i) {
-    const float* r0 = T.GV + ((size_t)i * T.cols + j0) * 3;
-    const float* r1 = r0 + (size_t)T.cols * 3;
-    V3 v0 = v3(r0[0], r0[1], r0[2]), v2 = v3(r1[0], r1[1], r1[2]);
-    for (int j = j0; j <= j1; ++j) {
-      r0 += 3; r1 += 3;
-      const V3 v1 = v3(r0[0], r0[1], r0[2]), v3_ = v3(r1[0], r1[1], r1[2]);
-      cell(i, j, v0, v1, v2, v3_);
-      v0 = v1; v2 = v3_;
+  for (int i = i0; i <= i1; i += 2) {                       // two rows of four cells per round: 3 x 5 vertices, fifteen 16-byte loads
+    const int ib = min(i + 1, T.rows - 2);                  // second cell row (clamped: re-reads the first when the window ends)
+    const float4* r0 = T.GV4 + (size_t)i * T.cols; const float4* r1 = r0 + T.cols; const float4* r2 = T.GV4 + (size_t)(ib + 1) * T.cols;
+    for (int jb = j0; jb <= j1; jb += 4) {
+      float4 a[5], b[5], c[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) { const int j = min(jb + t, T.cols - 1); a[t] = r0[j]; b[t] = r1[j]; c[t] = r2[j]; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (jb + t <= j1) {
+          cell(a[t], a[t + 1], b[t], b[t + 1]);
+          if (i + 1 <= i1) cell(b[t], b[t + 1], c[t], c[t + 1]);
+        }
     }
   }
   A.found = found; A.cp = bestp; A.fn = bestn;
@@ -481,14 +488,19 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
             bound = fminf(reach, dq + travel * 1.0001f + 1e-4f);
           }
         }
-        Q[h].p = x; Q[h].max_dist = bound; Q[h].on = query; Q[h].range = range; Q[h].lb = bound;
+        // grid meshes: a sphere higher above everything around it than radius + contact_offset cannot touch (the margin in `range`
+        // is for centres that have sunk BELOW the surface)
+        Q[h].p = x; Q[h].max_dist = bound; Q[h].on = query; Q[h].range = rads[h] + P.contact_offset; Q[h].lb = bound;
       }
     }
 #ifdef LG_STAMPS
     {
       int visits = 0;
+      const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
       if (T.GV) { closest_point_grid(T, Q[0], &visits); closest_point_grid(T, Q[1], &visits); }
       else closest_point_pair(T.M, Q[0], Q[1], &visits);
+      __builtin_amdgcn_s_waitcnt(0);
+      if (dbg && lane == 0) dbg[27] += __builtin_amdgcn_s_memtime() - tq0;
       // diagnostic: queries issued / traversal steps (sum and max over the wave) of workgroup 0, wave 2
       int vmax = visits, vsum = visits;
       for (int off = 32; off > 0; off >>= 1) { vmax = max(vmax, __shfl_xor(vmax, off)); vsum += __shfl_xor(vsum, off); }

@@ -2033,23 +2033,25 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.ter.mesh_type = ter->mesh_type; h.ter.rows = ter->rows; h.ter.cols = ter->cols;
   h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
   h.ter.H = (const int16_t*)P(LG_T_HEIGHT_SAMPLES);
-  h.ter.M = MeshView{nullptr, nullptr}; h.ter.GV = nullptr; h.ter.GM = nullptr; h.ter.mcols = 0;
+  h.ter.M = MeshView{nullptr, nullptr}; h.ter.GV = nullptr; h.ter.GV4 = nullptr; h.ter.GM = nullptr; h.ter.mcols = 0;
   if (const char* ev = getenv("LG_GRID_MESH")) c->grid_mesh = atoi(ev) != 0;
   if (ter->mesh_type == LG_MESH_TRIMESH && ter->grid_vertices && c->grid_mesh) {      // grid mesh: contact queries by cell index
-    // vertices, then the max z of every 8 x 8 block of vertices (the cull in closest_point_grid)
-    const size_t nv = (size_t)ter->rows * ter->cols * 3;
-    const int mr = (ter->rows + 7) / 8, mc = (ter->cols + 7) / 8;
-    std::vector<float> top((size_t)mr * mc, -1e30f);
+    // vertices as (x, y, z, 0) -- one 16-byte load each --, then the max z of every 2 x 2 block of vertices (the clearance test in closest_point_grid)
+    const size_t nvert = (size_t)ter->rows * ter->cols, nv = nvert * 4;
+    const int mr = (ter->rows + 1) / 2, mc = (ter->cols + 1) / 2;
+    std::vector<float> v4(nv, 0.f), top((size_t)mr * mc, -1e30f);
     for (int i = 0; i < ter->rows; ++i)
       for (int j = 0; j < ter->cols; ++j) {
-        float& t = top[(size_t)(i >> 3) * mc + (j >> 3)];
-        t = std::max(t, ter->grid_vertices[((size_t)i * ter->cols + j) * 3 + 2]);
+        const size_t k = (size_t)i * ter->cols + j;
+        for (int a = 0; a < 3; ++a) v4[4 * k + a] = ter->grid_vertices[3 * k + a];
+        float& t = top[(size_t)(i >> 1) * mc + (j >> 1)];
+        t = std::max(t, ter->grid_vertices[3 * k + 2]);
       }
     if (hipMalloc((void**)&c->grid_verts, (nv + top.size()) * sizeof(float)) != hipSuccess ||
-        hipMemcpy(c->grid_verts, ter->grid_vertices, nv * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->grid_verts, v4.data(), nv * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy((float*)c->grid_verts + nv, top.data(), top.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
       return fail("grid-mesh vertex upload failed");
-    h.ter.GV = (const float*)c->grid_verts; h.ter.GM = (const float*)c->grid_verts + nv; h.ter.mcols = mc;
+    h.ter.GV = (const float*)c->grid_verts; h.ter.GV4 = (const float4*)c->grid_verts; h.ter.GM = (const float*)c->grid_verts + nv; h.ter.mcols = mc;
   }
   if (ter->mesh_type == LG_MESH_TRIMESH) {
     if (ter->collision_mesh->device != device_id) return fail("collision mesh lives on another device");
