@@ -359,13 +359,19 @@ LG_DEV void closest_grid_triangle(V3 p, V3 a, V3 b, V3 cc, float& best2, bool& f
 // Every stage below is a few ROUNDS of independent loads (indices clamped, loads unconditional) followed by arithmetic: a wave pays
 // one L2 latency per round whatever its lanes need, and the first version's one-cell-at-a-time loop spent 36 k cycles per pair of
 // queries on ~20 dependent rounds each.
-LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visits = nullptr) {
+LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visits = nullptr, unsigned long long* tdbg = nullptr) {
+#ifdef LG_STAMPS
+  unsigned long long tg0 = __builtin_amdgcn_s_memtime();
+#define GSTAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (tdbg) tdbg[k] += t_ - tg0; tg0 = t_; } while (0)
+#else
+#define GSTAMP(k)
+#endif
   if (!A.on) return;
 #if LG_AB == 1      // timing probe: no query at all (nothing is ever found)
   A.found = false; A.cp = A.p; A.fn = v3(0, 0, 1); return;
 #endif
-  const float R = A.max_dist, ihs = frcp(T.hscale);
-  float best2 = R * R, bestabs = -1.f; bool found = false;
+  float R = A.max_dist; const float ihs = frcp(T.hscale);
+  float bestabs = -1.f; bool found = false;
   V3 bestp = A.p, bestn = v3(0, 0, 1);
   const V3 p = A.p;
   const float gx = (p.x + T.border) * ihs, gy = (p.y + T.border) * ihs;
@@ -374,11 +380,15 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
   i0 = max(i0, 0); j0 = max(j0, 0); i1 = min(i1, T.rows - 2); j1 = min(j1, T.cols - 2);
   A.found = false; A.cp = p; A.fn = v3(0, 0, 1);
   if (i0 > i1 || j0 > j1) return;
+  // the window that matters for a sphere whose centre is ABOVE the ground: only what lies within radius + contact_offset can touch it
+  const float Rs = fminf(R, A.range + 1e-3f), grs = Rs * ihs + 1e-3f;
+  const int si0 = max((int)floorf(gx - grs) - 1, 0), si1 = min((int)floorf(gx + grs) + 1, T.rows - 2);
+  const int sj0 = max((int)floorf(gy - grs) - 1, 0), sj1 = min((int)floorf(gy + grs) + 1, T.cols - 2);
   {  // how far the sphere is above everything around it: the highest vertex of the 2 x 2 blocks that cover the window's vertices
      // (a vertex's height is its height sample; the slope correction moves x and y only).  More than radius + contact_offset: no
      // contact is possible, the exact closest point is not needed, and the caller's distance cache gets the proven lower bound.
     const int bi0 = i0 >> 1, bi1 = (i1 + 1) >> 1, bj0 = j0 >> 1, bj1 = (j1 + 1) >> 1;
-    float top = -1e30f;
+    float top = -1e30f, top_s = -1e30f;
     for (int bi = bi0; bi <= bi1; bi += 4)
       for (int bj = bj0; bj <= bj1; bj += 8) {
         float tv[32];
@@ -387,30 +397,49 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 #pragma unroll
           for (int t = 0; t < 8; ++t) tv[8 * u + t] = T.GM[(size_t)min(bi + u, bi1) * T.mcols + min(bj + t, bj1)];
 #pragma unroll
-        for (int t = 0; t < 32; ++t) top = fmaxf(top, tv[t]);
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            top = fmaxf(top, tv[8 * u + t]);
+            const int b_i = min(bi + u, bi1), b_j = min(bj + t, bj1);
+            const bool near = b_i >= (si0 >> 1) && b_i <= ((si1 + 1) >> 1) && b_j >= (sj0 >> 1) && b_j <= ((sj1 + 1) >> 1);
+            top_s = fmaxf(top_s, near ? tv[8 * u + t] : -1e30f);
+          }
       }
     const float clear = p.z - top;
+    GSTAMP(22);
     if (clear > A.range) { A.lb = fminf(R, clear); return; }
+    // the centre is above every vertex near it: the sphere is not sunk into the ground (the margin in the caller's range is for
+    // that case), so a contact needs a triangle within radius + contact_offset -- search that far only.  Nothing there: the cache
+    // gets that radius as its lower bound.
+    if (p.z > top_s + 1e-4f) { R = Rs; A.lb = Rs; i0 = si0; i1 = si1; j0 = sj0; j1 = sj1; }
   }
-  auto cell = [&](float4 a0, float4 a1, float4 b0, float4 b1) {
-    if (visits) ++*visits;
-    const V3 v0 = v3(a0.x, a0.y, a0.z), v1 = v3(a1.x, a1.y, a1.z), v2 = v3(b0.x, b0.y, b0.z), v3_ = v3(b1.x, b1.y, b1.z);
-    const float lox = fminf(fminf(v0.x, v1.x), fminf(v2.x, v3_.x)), hix = fmaxf(fmaxf(v0.x, v1.x), fmaxf(v2.x, v3_.x));
-    const float loy = fminf(fminf(v0.y, v1.y), fminf(v2.y, v3_.y)), hiy = fmaxf(fmaxf(v0.y, v1.y), fmaxf(v2.y, v3_.y));
-    const float loz = fminf(fminf(v0.z, v1.z), fminf(v2.z, v3_.z)), hiz = fmaxf(fmaxf(v0.z, v1.z), fmaxf(v2.z, v3_.z));
+  float best2 = R * R;
+  // box of a cell's four vertices against the current best distance (cheap, unrolled over a round's cells) ...
+  auto box_ok = [&](float4 a0, float4 a1, float4 b0, float4 b1) -> bool {
+    const float lox = fminf(fminf(a0.x, a1.x), fminf(b0.x, b1.x)), hix = fmaxf(fmaxf(a0.x, a1.x), fmaxf(b0.x, b1.x));
+    const float loy = fminf(fminf(a0.y, a1.y), fminf(b0.y, b1.y)), hiy = fmaxf(fmaxf(a0.y, a1.y), fmaxf(b0.y, b1.y));
+    const float loz = fminf(fminf(a0.z, a1.z), fminf(b0.z, b1.z)), hiz = fmaxf(fmaxf(a0.z, a1.z), fmaxf(b0.z, b1.z));
     const float dx = fmaxf(fmaxf(lox - p.x, 0.f), p.x - hix), dy = fmaxf(fmaxf(loy - p.y, 0.f), p.y - hiy), dz = fmaxf(fmaxf(loz - p.z, 0.f), p.z - hiz);
-    if (dx * dx + dy * dy + dz * dz <= best2 * (1.f + 1e-5f) + 1e-12f) {
-      closest_grid_triangle(p, v0, v3_, v1, best2, found, bestabs, bestp, bestn);
-      closest_grid_triangle(p, v0, v2, v3_, best2, found, bestabs, bestp, bestn);
-    }
+    return dx * dx + dy * dy + dz * dz <= best2 * (1.f + 1e-5f) + 1e-12f;
   };
-  {  // the cell under the sphere first: on most ground its triangles are the closest ones or nearly so, and whatever distance they
-     // give bounds the search -- the window shrinks to the cells that can hold something closer (they are met again by the scan:
-     // a triangle met twice changes nothing, the update rules are idempotent)
-    const int ci = max(i0, min((int)floorf(gx), i1)), cj = max(j0, min((int)floorf(gy), j1));
-    const float4* ra = T.GV4 + (size_t)ci * T.cols + cj; const float4* rb = ra + T.cols;
+  // ... and the two exact triangle tests of a cell that passed: ONE instance of this code, run in a loop over the cells a round
+  // selected (their vertices are re-read, now cache hits).  Inlined at every cell of the unrolled rounds it was ~3.6 k instructions.
+  auto exact = [&](int i, int j) {
+    if (visits) ++*visits;
+    const float4* ra = T.GV4 + (size_t)i * T.cols + j; const float4* rb = ra + T.cols;
     const float4 a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1];
-    cell(a0, a1, b0, b1);
+    const V3 v0 = v3(a0.x, a0.y, a0.z), v1 = v3(a1.x, a1.y, a1.z), v2 = v3(b0.x, b0.y, b0.z), v3_ = v3(b1.x, b1.y, b1.z);
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) closest_grid_triangle(p, v0, h == 0 ? v3_ : v2, h == 0 ? v1 : v3_, best2, found, bestabs, bestp, bestn);
+  };
+  if (i1 - i0 >= 4 || j1 - j0 >= 4) {
+    // a window wider than one round: the cell under the sphere first.  On most ground its triangles are the closest ones or nearly
+    // so, and whatever distance they give bounds the search -- the window shrinks to the cells that can hold something closer (they
+    // are met again by the scan: a triangle met twice changes nothing, the update rules are idempotent)
+    const int ci = max(i0, min((int)floorf(gx), i1)), cj = max(j0, min((int)floorf(gy), j1));
+    exact(ci, cj);
+    GSTAMP(23);
 #if LG_AB == 2      // timing probe: the cell under the sphere only
     A.found = found; A.cp = bestp; A.fn = bestn; return;
 #endif
@@ -420,21 +449,38 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
       j0 = max(j0, (int)floorf(gy - gr) - 1); j1 = min(j1, (int)floorf(gy + gr) + 1);
     }
   }
-  for (int i = i0; i <= i1; i += 2) {                       // two rows of four cells per round: 3 x 5 vertices, fifteen 16-byte loads
-    const int ib = min(i + 1, T.rows - 2);                  // second cell row (clamped: re-reads the first when the window ends)
-    const float4* r0 = T.GV4 + (size_t)i * T.cols; const float4* r1 = r0 + T.cols; const float4* r2 = T.GV4 + (size_t)(ib + 1) * T.cols;
+  // rounds of 4 x 4 cells = 5 x 5 vertices, twenty-five 16-byte loads in flight: the usual window (a foot on the ground, a sphere
+  // a few centimetres above it) is one round
+#pragma unroll 1
+  for (int i = i0; i <= i1; i += 4) {
+#pragma unroll 1
     for (int jb = j0; jb <= j1; jb += 4) {
-      float4 a[5], b[5], c[5];
+      float4 v[5][5];
+#ifdef LG_STAMPS
+      if (visits) *visits += 1000;        // diagnostic: thousands = rounds of this lane
+#endif
 #pragma unroll
-      for (int t = 0; t < 5; ++t) { const int j = min(jb + t, T.cols - 1); a[t] = r0[j]; b[t] = r1[j]; c[t] = r2[j]; }
+      for (int u = 0; u < 5; ++u) {
+        const float4* rr = T.GV4 + (size_t)min(i + u, T.rows - 1) * T.cols;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (jb + t <= j1) {
-          cell(a[t], a[t + 1], b[t], b[t + 1]);
-          if (i + 1 <= i1) cell(b[t], b[t + 1], c[t], c[t + 1]);
-        }
+        for (int t = 0; t < 5; ++t) v[u][t] = rr[min(jb + t, T.cols - 1)];
+      }
+      GSTAMP(25);
+      unsigned pass = 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (i + u <= i1 && jb + t <= j1 && box_ok(v[u][t], v[u][t + 1], v[u + 1][t], v[u + 1][t + 1])) pass |= 1u << (4 * u + t);
+      GSTAMP(26);
+#pragma unroll 1
+      while (pass) {
+        const int bit = __ffs(pass) - 1; pass &= pass - 1u;
+        exact(i + (bit >> 2), jb + (bit & 3));
+      }
     }
   }
+  GSTAMP(24);
   A.found = found; A.cp = bestp; A.fn = bestn;
 }
 
@@ -497,7 +543,7 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
     {
       int visits = 0;
       const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
-      if (T.GV) { closest_point_grid(T, Q[0], &visits); closest_point_grid(T, Q[1], &visits); }
+      if (T.GV) { closest_point_grid(T, Q[0], &visits, (dbg && lane == 0) ? dbg : nullptr); closest_point_grid(T, Q[1], &visits, (dbg && lane == 0) ? dbg : nullptr); }
       else closest_point_pair(T.M, Q[0], Q[1], &visits);
       __builtin_amdgcn_s_waitcnt(0);
       if (dbg && lane == 0) dbg[27] += __builtin_amdgcn_s_memtime() - tq0;

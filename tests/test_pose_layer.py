@@ -118,7 +118,7 @@ def test_pose_go2_runs_with_the_observation_count_corrected():
     from tests.test_env_api import make
     with pytest.raises(ValueError):
         make("pose_go2_flat", 32)
-    env = make("pose_go2_flat", 32, **{"env.num_observations": 52})
+    env = make("pose_go2_flat", 32, **{"env.num_observations": 52, "noise.add_noise": False})
     obs, _ = env.reset()
     for _ in range(10):
         obs, _, rew, done, _ = env.step(torch.zeros(32, 12, device=env.device))
