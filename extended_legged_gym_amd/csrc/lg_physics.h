@@ -370,6 +370,12 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 #if LG_AB == 1      // timing probe: no query at all (nothing is ever found)
   A.found = false; A.cp = A.p; A.fn = v3(0, 0, 1); return;
 #endif
+  // pointers read out of a struct are generic to the compiler (flat_load: counted on both wait counters, drained with vmcnt(0) and
+  // lgkmcnt(0) together); these three are device-global by construction
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef const f4v __attribute__((address_space(1)))* gf4; typedef const float __attribute__((address_space(1)))* gf1;
+  const gf4 GV4 = (gf4)T.GV4; const gf1 GM = (gf1)T.GM;
+  auto ld4 = [](gf4 q) -> float4 { const f4v v = *q; return make_float4(v.x, v.y, v.z, v.w); };
   float R = A.max_dist; const float ihs = frcp(T.hscale);
   float bestabs = -1.f; bool found = false;
   V3 bestp = A.p, bestn = v3(0, 0, 1);
@@ -395,7 +401,7 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int t = 0; t < 8; ++t) tv[8 * u + t] = T.GM[(size_t)min(bi + u, bi1) * T.mcols + min(bj + t, bj1)];
+          for (int t = 0; t < 8; ++t) tv[8 * u + t] = GM[(size_t)min(bi + u, bi1) * T.mcols + min(bj + t, bj1)];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -427,8 +433,8 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
   // selected (their vertices are re-read, now cache hits).  Inlined at every cell of the unrolled rounds it was ~3.6 k instructions.
   auto exact = [&](int i, int j) {
     if (visits) ++*visits;
-    const float4* ra = T.GV4 + (size_t)i * T.cols + j; const float4* rb = ra + T.cols;
-    const float4 a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1];
+    const gf4 ra = GV4 + (size_t)i * T.cols + j; const gf4 rb = ra + T.cols;
+    const float4 a0 = ld4(ra), a1 = ld4(ra + 1), b0 = ld4(rb), b1 = ld4(rb + 1);
     const V3 v0 = v3(a0.x, a0.y, a0.z), v1 = v3(a1.x, a1.y, a1.z), v2 = v3(b0.x, b0.y, b0.z), v3_ = v3(b1.x, b1.y, b1.z);
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) closest_grid_triangle(p, v0, h == 0 ? v3_ : v2, h == 0 ? v1 : v3_, best2, found, bestabs, bestp, bestn);
@@ -461,9 +467,9 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 #endif
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
-        const float4* rr = T.GV4 + (size_t)min(i + u, T.rows - 1) * T.cols;
+        const gf4 rr = GV4 + (size_t)min(i + u, T.rows - 1) * T.cols;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) v[u][t] = rr[min(jb + t, T.cols - 1)];
+        for (int t = 0; t < 5; ++t) v[u][t] = ld4(rr + min(jb + t, T.cols - 1));
       }
       GSTAMP(25);
       unsigned pass = 0u;
@@ -735,6 +741,10 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   leg_kinematics(lm_, Rb, pb, vb, wb, s.q, s.qd, k);
 
   STAMP(1);
+  // mesh terrains: this wave's share of the contact detection goes HERE, where only the state and the kinematics are live; after the
+  // mass matrix and its factors it sat in the middle of ~500 live registers and the inlined closest-point scan spilled them
+  // (~800 scratch loads in the substep of the main wave)
+  if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh(0, MAIN_DETECT, lm_, T, P, k, Rb, pb, cst, lane, cq);
   // ---------------------------------------------------------------- bias forces (RNEA, zero generalised acceleration)
   const float m0 = m->base_mass + madd, iscale = m0 * frcp(m->base_mass);
   const V3 rc0 = mul(Rb, ld3(m->base_com));
@@ -796,10 +806,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   STAMP(3);
   // ---------------------------------------------------------------- leg bias + contact detection: helper waves or inline
   float bk[3]; V3 Fs, Ns;
-  if (MAIN_DETECT > 0 && share.n > 1) {
-    if (TMESH) contact_detect_mesh(0, MAIN_DETECT, lm_, T, P, k, Rb, pb, cst, lane, cq);
-    else contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
-  }
+  if (!TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
   STAMP(29);   // (diagnostic: this wave's own detection ends here; what follows in stamp 5 is the wait at the rendezvous)
   if (!prep_fn(bk, Fs, Ns)) {
     leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);

@@ -24,5 +24,5 @@ calls = max(out[31], 1)
 print("wave 2 of workgroup 0: %d detection calls; per call: %.1f queries issued (of 128), %.1f cells or nodes visited summed over lanes, %.1f by the busiest lane"
       % (calls, out[28] / calls, out[29] / calls, out[30] / calls))
 print("cycles inside the queries per call (wave 2):", out[27] / calls, " clearance stage", out[22] / calls, " centre cell", out[23] / calls, " window scan: loads", out[25] / calls, " box tests", out[26] / calls, " exact tests + loop ends", out[24] / calls)
-for k in range(16):
+for k in list(range(16)) + [29]:
     print(k, out[k] // (n + 1) // 4, "cycles per substep")
