@@ -6,6 +6,12 @@
 #include "../../include/lgstep.h"
 
 #define LG_DEV __device__ __forceinline__
+// global address space on pointer members of device-side structs (device compilation only; same layout on the host): see DevCtx
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LG_G __attribute__((address_space(1)))
+#else
+#define LG_G
+#endif
 
 // Host side: every ABI entry point runs on the device its context / mesh / network lives on, whatever device is current in
 // the calling thread (an env on cuda:1 driven from a thread whose current device is cuda:0), and leaves the caller's current

@@ -38,6 +38,10 @@ enum { HC_DT = 0, HC_K, HC_KFAT, HC_KTERM, HC_TERM_SCALE, HC_TERM_MASK, HC_RESAM
        HC_OS_VEL, HC_OS_H, HC_CLIP_OBS, HC_SEED_LO, HC_SEED_HI, HC_NUM_EXTRA, HC_IDS /* 32 */, HC_SCALES = HC_IDS + LG_MAX_REWARD_TERMS /* 32 */,
        HC_DEFAULT_POS = HC_SCALES + LG_MAX_REWARD_TERMS /* 12 */, HC_COUNT = HC_DEFAULT_POS + 12 };
 
+// Device-side view of every pointer member: the global address space.  A pointer read out of a struct is generic to the compiler and
+// every access through it a flat_load / flat_store, which counts on BOTH wait counters and returns out of order, so that any wait for
+// LDS data with one of them in flight becomes a full drain; with the members typed as global pointers (device compilation only: the
+// layout is the same) the accesses are global_load / global_store (LG_G, lg_device.h).
 struct DevCtx {
   lg_config cfg;
   lg_robot_model model;
@@ -45,28 +49,28 @@ struct DevCtx {
   TerrainView ter;
   float terrain_mu, env_length; int num_levels, num_types;
   // tensors (device pointers into the arena)
-  float *root, *dof, *rigid, *cforce, *torques, *actions, *last_actions, *last_dof_vel, *last_root_vel, *commands;
-  float *base_lin_vel, *base_ang_vel, *proj_grav, *base_lin_acc, *base_ang_acc, *feet_air, *feet_ctime;
-  uint8_t* last_contacts;
-  float *heights, *obs, *rew;
-  uint8_t *reset_buf, *time_out;
-  int64_t* ep_len;
-  float* ep_sums;
-  int64_t *levels, *types;
-  float *origins, *friction, *mass_added, *sea_h, *sea_c, *gait_idx, *gait_foot_z, *extras, *rand_inject;
-  int64_t* counters;
-  float* cmd_ranges;   // LG_T_COMMAND_RANGES (4,2)
-  double* ep_stats;
-  const float* terrain_origins;
-  const float *noise_vec, *height_points;
-  const float* extra_obs;   // (N, cfg.num_extra_obs) caller-owned rows appended to the observation
-  float* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
-  float* lvl_part;     // [nblocks] : per-workgroup sum of terrain levels
-  unsigned* part_flag; // [nblocks] : 1 when some env of the workgroup was reset in this step (its partials row is valid)
-  long long* acc;      // [PART_STRIDE] fixed-point (x 2^24) sums of the reset envs' rows of one post-kernel launch
-  unsigned* tickets;   // 9 counters, one per 128-B line: per-shard arrivals of the post kernel's workgroups + the shards' own
+  float LG_G *root, *dof, *rigid, *cforce, *torques, *actions, *last_actions, *last_dof_vel, *last_root_vel, *commands;
+  float LG_G *base_lin_vel, *base_ang_vel, *proj_grav, *base_lin_acc, *base_ang_acc, *feet_air, *feet_ctime;
+  uint8_t LG_G* last_contacts;
+  float LG_G *heights, *obs, *rew;
+  uint8_t LG_G *reset_buf, *time_out;
+  int64_t LG_G* ep_len;
+  float LG_G* ep_sums;
+  int64_t LG_G *levels, *types;
+  float LG_G *origins, *friction, *mass_added, *sea_h, *sea_c, *gait_idx, *gait_foot_z, *extras, *rand_inject;
+  int64_t LG_G* counters;
+  float LG_G* cmd_ranges;   // LG_T_COMMAND_RANGES (4,2)
+  double LG_G* ep_stats;
+  const float LG_G* terrain_origins;
+  const float LG_G *noise_vec, *height_points;
+  const float LG_G* extra_obs;   // (N, cfg.num_extra_obs) caller-owned rows appended to the observation
+  float LG_G* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
+  float LG_G* lvl_part;     // [nblocks] : per-workgroup sum of terrain levels
+  unsigned LG_G* part_flag; // [nblocks] : 1 when some env of the workgroup was reset in this step (its partials row is valid)
+  long long LG_G* acc;      // [PART_STRIDE] fixed-point (x 2^24) sums of the reset envs' rows of one post-kernel launch
+  unsigned LG_G* tickets;   // 9 counters, one per 128-B line: per-shard arrivals of the post kernel's workgroups + the shards' own
   float mesh_lo[3], mesh_hi[3];   // bounding box of the collision mesh (LG_MESH_TRIMESH): a base that leaves it by more than LG_MESH_OOB_MARGIN ends the episode
-  float* mesh_cache;   // [N][4 legs][LG_MAX_CP][4]: last closest-point query of every collision sphere (mesh terrains)
+  float LG_G* mesh_cache;   // [N][4 legs][LG_MAX_CP][4]: last closest-point query of every collision sphere (mesh terrains)
   float lstm_w[912];   // actuator network weights, gate-interleaved (pack_lstm_weights): read with scalar loads
   int nblocks_post;
   // reward-term bookkeeping of the post kernel, derived from cfg.reward_term_ids on the host (reward_meta): a walk over the
@@ -75,7 +79,7 @@ struct DevCtx {
   float hot[HC_COUNT];          // see the HC_* enum (ints stored as bit patterns)
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
   float lvl_total_before;       // subset steps with a terrain curriculum: sum of ALL terrain levels before the launch (level_total_kernel)
-  unsigned long long* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
+  unsigned long long LG_G* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
 };
 
 struct TensorInfo { size_t off; int64_t shape[4]; int ndim; int dtype; };
@@ -2012,27 +2016,27 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
     std::vector<float> init(nf, -1.f);                   // distance < 0: no entry
     if (hipMalloc((void**)&c->mesh_cache, nf * 4) != hipSuccess ||
         hipMemcpy(c->mesh_cache, init.data(), nf * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("mesh contact cache allocation failed");
-    h.mesh_cache = (float*)c->mesh_cache;
+    h.mesh_cache = (float LG_G*)c->mesh_cache;
   }
   h.terrain_mu = ter->static_friction; h.env_length = ter->env_length; h.num_levels = ter->num_levels; h.num_types = ter->num_types;
   char* base = (char*)c->arena;
   auto P = [&](int id) { return (void*)(base + c->t[id].off); };
-  h.root = (float*)P(LG_T_ROOT_STATES); h.dof = (float*)P(LG_T_DOF_STATE); h.rigid = (float*)P(LG_T_RIGID_BODY_STATE);
-  h.cforce = (float*)P(LG_T_CONTACT_FORCES); h.torques = (float*)P(LG_T_TORQUES); h.actions = (float*)P(LG_T_ACTIONS);
-  h.last_actions = (float*)P(LG_T_LAST_ACTIONS); h.last_dof_vel = (float*)P(LG_T_LAST_DOF_VEL); h.last_root_vel = (float*)P(LG_T_LAST_ROOT_VEL);
-  h.commands = (float*)P(LG_T_COMMANDS); h.base_lin_vel = (float*)P(LG_T_BASE_LIN_VEL); h.base_ang_vel = (float*)P(LG_T_BASE_ANG_VEL);
-  h.proj_grav = (float*)P(LG_T_PROJECTED_GRAVITY); h.base_lin_acc = (float*)P(LG_T_BASE_LIN_ACC); h.base_ang_acc = (float*)P(LG_T_BASE_ANG_ACC);
-  h.feet_air = (float*)P(LG_T_FEET_AIR_TIME); h.feet_ctime = (float*)P(LG_T_FEET_CONTACT_TIME); h.last_contacts = (uint8_t*)P(LG_T_LAST_CONTACTS);
-  h.heights = (float*)P(LG_T_MEASURED_HEIGHTS); h.obs = (float*)P(LG_T_OBS_BUF); h.rew = (float*)P(LG_T_REW_BUF);
-  h.reset_buf = (uint8_t*)P(LG_T_RESET_BUF); h.time_out = (uint8_t*)P(LG_T_TIME_OUT_BUF); h.ep_len = (int64_t*)P(LG_T_EPISODE_LENGTH_BUF);
-  h.ep_sums = (float*)P(LG_T_EPISODE_SUMS); h.levels = (int64_t*)P(LG_T_TERRAIN_LEVELS); h.types = (int64_t*)P(LG_T_TERRAIN_TYPES);
-  h.origins = (float*)P(LG_T_ENV_ORIGINS); h.friction = (float*)P(LG_T_FRICTION_COEFFS); h.mass_added = (float*)P(LG_T_BASE_MASS_ADDED);
-  h.sea_h = (float*)P(LG_T_SEA_HIDDEN_STATE); h.sea_c = (float*)P(LG_T_SEA_CELL_STATE); h.gait_idx = (float*)P(LG_T_GAIT_IDX);
-  h.gait_foot_z = (float*)P(LG_T_GAIT_FOOT_Z); h.extras = (float*)P(LG_T_EXTRAS_EPISODE); h.rand_inject = (float*)P(LG_T_RAND_INJECT);
-  h.counters = (int64_t*)P(LG_T_STEP_COUNTERS); h.cmd_ranges = (float*)P(LG_T_COMMAND_RANGES); h.ep_stats = (double*)P(LG_T_EPISODE_STATS); h.terrain_origins = (const float*)P(LG_T_TERRAIN_ORIGINS);
+  h.root = (float LG_G*)P(LG_T_ROOT_STATES); h.dof = (float LG_G*)P(LG_T_DOF_STATE); h.rigid = (float LG_G*)P(LG_T_RIGID_BODY_STATE);
+  h.cforce = (float LG_G*)P(LG_T_CONTACT_FORCES); h.torques = (float LG_G*)P(LG_T_TORQUES); h.actions = (float LG_G*)P(LG_T_ACTIONS);
+  h.last_actions = (float LG_G*)P(LG_T_LAST_ACTIONS); h.last_dof_vel = (float LG_G*)P(LG_T_LAST_DOF_VEL); h.last_root_vel = (float LG_G*)P(LG_T_LAST_ROOT_VEL);
+  h.commands = (float LG_G*)P(LG_T_COMMANDS); h.base_lin_vel = (float LG_G*)P(LG_T_BASE_LIN_VEL); h.base_ang_vel = (float LG_G*)P(LG_T_BASE_ANG_VEL);
+  h.proj_grav = (float LG_G*)P(LG_T_PROJECTED_GRAVITY); h.base_lin_acc = (float LG_G*)P(LG_T_BASE_LIN_ACC); h.base_ang_acc = (float LG_G*)P(LG_T_BASE_ANG_ACC);
+  h.feet_air = (float LG_G*)P(LG_T_FEET_AIR_TIME); h.feet_ctime = (float LG_G*)P(LG_T_FEET_CONTACT_TIME); h.last_contacts = (uint8_t LG_G*)P(LG_T_LAST_CONTACTS);
+  h.heights = (float LG_G*)P(LG_T_MEASURED_HEIGHTS); h.obs = (float LG_G*)P(LG_T_OBS_BUF); h.rew = (float LG_G*)P(LG_T_REW_BUF);
+  h.reset_buf = (uint8_t LG_G*)P(LG_T_RESET_BUF); h.time_out = (uint8_t LG_G*)P(LG_T_TIME_OUT_BUF); h.ep_len = (int64_t LG_G*)P(LG_T_EPISODE_LENGTH_BUF);
+  h.ep_sums = (float LG_G*)P(LG_T_EPISODE_SUMS); h.levels = (int64_t LG_G*)P(LG_T_TERRAIN_LEVELS); h.types = (int64_t LG_G*)P(LG_T_TERRAIN_TYPES);
+  h.origins = (float LG_G*)P(LG_T_ENV_ORIGINS); h.friction = (float LG_G*)P(LG_T_FRICTION_COEFFS); h.mass_added = (float LG_G*)P(LG_T_BASE_MASS_ADDED);
+  h.sea_h = (float LG_G*)P(LG_T_SEA_HIDDEN_STATE); h.sea_c = (float LG_G*)P(LG_T_SEA_CELL_STATE); h.gait_idx = (float LG_G*)P(LG_T_GAIT_IDX);
+  h.gait_foot_z = (float LG_G*)P(LG_T_GAIT_FOOT_Z); h.extras = (float LG_G*)P(LG_T_EXTRAS_EPISODE); h.rand_inject = (float LG_G*)P(LG_T_RAND_INJECT);
+  h.counters = (int64_t LG_G*)P(LG_T_STEP_COUNTERS); h.cmd_ranges = (float LG_G*)P(LG_T_COMMAND_RANGES); h.ep_stats = (double LG_G*)P(LG_T_EPISODE_STATS); h.terrain_origins = (const float LG_G*)P(LG_T_TERRAIN_ORIGINS);
   h.ter.mesh_type = ter->mesh_type; h.ter.rows = ter->rows; h.ter.cols = ter->cols;
   h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
-  h.ter.H = (const int16_t*)P(LG_T_HEIGHT_SAMPLES);
+  h.ter.H = (const int16_t LG_G*)P(LG_T_HEIGHT_SAMPLES);
   h.ter.M = MeshView{nullptr, nullptr}; h.ter.GV = nullptr; h.ter.GV4 = nullptr; h.ter.GM = nullptr; h.ter.mcols = 0;
   if (const char* ev = getenv("LG_GRID_MESH")) c->grid_mesh = atoi(ev) != 0;
   if (ter->mesh_type == LG_MESH_TRIMESH && ter->grid_vertices && c->grid_mesh) {      // grid mesh: contact queries by cell index
@@ -2069,13 +2073,13 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   if (hipMalloc(&c->aux, aux_floats * 4) != hipSuccess) return fail("hipMalloc(aux) failed");
   if (hipMemset(c->aux, 0, aux_floats * 4) != hipSuccess) return fail("hipMemset(aux) failed");
   float* aux = (float*)c->aux;
-  h.noise_vec = aux; h.height_points = aux + n_noise; h.partials = aux + n_noise + n_hp;
-  h.stamps = (unsigned long long*)(aux + ((n_noise + n_hp + n_part + 1) & ~(size_t)1));
+  h.noise_vec = (const float LG_G*)aux; h.height_points = (const float LG_G*)(aux + n_noise); h.partials = (float LG_G*)(aux + n_noise + n_hp);
+  h.stamps = (unsigned long long LG_G*)(aux + ((n_noise + n_hp + n_part + 1) & ~(size_t)1));
   {
     float* fin = aux + n_noise + n_hp + n_part + 66;
-    h.lvl_part = fin; h.part_flag = (unsigned*)(fin + h.nblocks_post);
-    h.tickets = (unsigned*)(((uintptr_t)(fin + 2 * h.nblocks_post + 4) + 127) & ~(uintptr_t)127);
-    h.acc = (long long*)(h.tickets + 9 * 32);
+    h.lvl_part = (float LG_G*)fin; h.part_flag = (unsigned LG_G*)(fin + h.nblocks_post);
+    h.tickets = (unsigned LG_G*)(((uintptr_t)(fin + 2 * h.nblocks_post + 4) + 127) & ~(uintptr_t)127);
+    h.acc = (long long LG_G*)(h.tickets + 9 * 32);
   }
   if (hipMemcpy(aux, cfg->noise_scale_vec, n_noise * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy noise_scale_vec failed");
   if (n_hp && hipMemcpy(aux + n_noise, cfg->height_points, n_hp * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy height_points failed");
@@ -2356,7 +2360,7 @@ int lg_set_state_indexed(lg_ctx* c, const float* root_states, const float* dof_s
 int lg_set_extra_obs(lg_ctx* c, const float* dptr) {
   if (!c) return LG_ERR_INVALID;
   if (c->h.cfg.num_extra_obs > 0 && !dptr) { c->err = "extra obs buffer is null"; return LG_ERR_INVALID; }
-  c->h.extra_obs = dptr;
+  c->h.extra_obs = (const float LG_G*)dptr;
   HIP_TRY(c, hipMemcpy(c->d, &c->h, sizeof(DevCtx), hipMemcpyHostToDevice));
   return LG_OK;
 }
