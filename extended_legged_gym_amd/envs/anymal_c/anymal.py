@@ -279,7 +279,8 @@ class PoseCommandsMixin:
                    base_z=t["rigid_body_state"][:, 0, 2], projected_gravity=self.projected_gravity,
                    measured_heights=self.measured_heights if self.cfg.terrain.measure_heights else None)
         noise_u = torch.rand(n, self.num_obs, device=self.device) if self.add_noise else None
-        self.obs_buf, self.rew_buf = pose_layer_step(self._pose, nat, u[:, :4], u[:, 4:], noise_u, self._pose_par)
+        self.obs_buf, rew = pose_layer_step(self._pose, nat, u[:, :4], u[:, 4:], noise_u, self._pose_par)
+        self.rew_buf.copy_(rew)            # in place, as `compute_reward` writes it (`legged_robot.py:222`); obs_buf is rebound there too
         self.commands[:, :4] = self._native_commands
 
     def step(self, actions):
