@@ -439,10 +439,12 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) closest_grid_triangle(p, v0, h == 0 ? v3_ : v2, h == 0 ? v1 : v3_, best2, found, bestabs, bestp, bestn);
   };
-  if (i1 - i0 >= 4 || j1 - j0 >= 4) {
-    // a window wider than one round: the cell under the sphere first.  On most ground its triangles are the closest ones or nearly
-    // so, and whatever distance they give bounds the search -- the window shrinks to the cells that can hold something closer (they
-    // are met again by the scan: a triangle met twice changes nothing, the update rules are idempotent)
+  {
+    // the cell under the sphere first.  On most ground its triangles are the closest ones or nearly so, and whatever distance they
+    // give bounds the search: the window shrinks to the cells that can hold something closer, and the box tests of the round(s)
+    // below pass fewer neighbours (each passing cell costs two exact triangle tests, ~2 k cycles of a wave whose busiest lane
+    // decides; with the radius-sized initial bound a foot near a cell border passed 4-6 cells).  The cell is met again by the scan:
+    // a triangle met twice changes nothing, the update rules are idempotent.
     const int ci = max(i0, min((int)floorf(gx), i1)), cj = max(j0, min((int)floorf(gy), j1));
     exact(ci, cj);
     GSTAMP(23);
@@ -727,7 +729,7 @@ LG_DEV void fetch_mass_factors(const float* xs, int lane, float Mi[6], float Mbk
 // holds the rendezvous and fills the three outputs); false means this wave computes them itself.
 // With helper waves on a heightfield the contact detection is dealt two slots per wave; this wave takes slots
 // [0, MAIN_DETECT) before the rendezvous (0: the helpers, or the inline path, detect everything).
-template <bool TMESH, int MAIN_DETECT, class TauFn, class PrepFn, class ShareFn>
+template <bool TMESH, int MAIN_DETECT, bool ALLOW_INLINE, class TauFn, class PrepFn, class ShareFn>
 LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel& lm_, const TerrainView& T, const PhysParams& P,
                             int lane, float* cst, QuadState& s, TauFn tau_fn, PrepFn prep_fn, ShareFn share_fn, SlotShare share,
                             float* xs, float mu_robot, float madd, V3* fbody, unsigned long long* stamps = nullptr,
@@ -744,7 +746,11 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   // mesh terrains: this wave's share of the contact detection goes HERE, where only the state and the kinematics are live; after the
   // mass matrix and its factors it sat in the middle of ~500 live registers and the inlined closest-point scan spilled them
   // (~800 scratch loads in the substep of the main wave)
+#if defined(LG_STAMPS) && defined(LG_STAMP_MAIN_MESH)
+  if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh(0, MAIN_DETECT, lm_, T, P, k, Rb, pb, cst, lane, cq, stamps);   // diagnostic: the query counters watch this wave
+#else
   if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh(0, MAIN_DETECT, lm_, T, P, k, Rb, pb, cst, lane, cq);
+#endif
   // ---------------------------------------------------------------- bias forces (RNEA, zero generalised acceleration)
   const float m0 = m->base_mass + madd, iscale = m0 * frcp(m->base_mass);
   const V3 rc0 = mul(Rb, ld3(m->base_com));
@@ -810,7 +816,9 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   STAMP(29);   // (diagnostic: this wave's own detection ends here; what follows in stamp 5 is the wait at the rendezvous)
   if (!prep_fn(bk, Fs, Ns)) {
     leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);
-    if (TMESH) contact_detect_mesh(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);
+    // (ALLOW_INLINE = false: the fused step on a mesh terrain always runs with helper waves; an inlined mesh query here, unreachable,
+    //  still costs the main wave registers)
+    if (TMESH) { if (ALLOW_INLINE) contact_detect_mesh(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane); }
     else contact_detect<0, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
   }
   float bb[6];

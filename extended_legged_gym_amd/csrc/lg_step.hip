@@ -575,7 +575,12 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         else contact_detect_mesh(2, 4, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (TMESH) {
 #ifdef LG_STAMPS
-        contact_detect_mesh(2 * wv, 2 * wv + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc, (blockIdx.x == 0 && wv == 2) ? C->stamps : nullptr);
+        contact_detect_mesh(2 * wv, 2 * wv + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc,
+#ifdef LG_STAMP_MAIN_MESH
+                            nullptr);
+#else
+                            (blockIdx.x == 0 && wv == 2) ? C->stamps : nullptr);
+#endif
 #else
         contact_detect_mesh(2 * wv, 2 * wv + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
 #endif
@@ -769,7 +774,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     };
     auto share_fn = [&]() { if (helpers) lds_barrier(); };   // (A3) every wave has finished its slots
     const SlotShare share{helpers ? 4 : 1, helpers ? 3 : 0, helpers};     // set-up order: wave 1, 2, 3, then this wave
-    physics_substep<TMESH, TMESH ? 2 : DS0>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
+    physics_substep<TMESH, TMESH ? 2 : DS0, !(MODE == 0 && TMESH)>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
                               sub == nsub - 1 ? fbody : nullptr, stamps, (TMESH && helpers) ? cqc : nullptr);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
