@@ -5,7 +5,7 @@ header and checks every enum value and struct size against this file so the two 
 """
 import ctypes as C
 
-LG_ABI_VERSION = 2
+LG_ABI_VERSION = 3
 LG_NUM_LEGS, LG_JOINTS_PER_LEG, LG_NUM_DOF = 4, 3, 12
 LG_MAX_CP, LG_MAX_BODIES, LG_MAX_REWARD_TERMS, LG_MAX_INDEX_LIST = 8, 17, 32, 16
 LG_LSTM_NPARAM = 969
@@ -15,6 +15,8 @@ LG_F32, LG_I64, LG_U8, LG_I16, LG_I32, LG_F64 = 0, 1, 2, 3, 4, 5
 LG_CTRL_P, LG_CTRL_V, LG_CTRL_T, LG_CTRL_ACTUATOR_NET = 0, 1, 2, 3
 LG_MESH_PLANE, LG_MESH_HEIGHTFIELD, LG_MESH_TRIMESH = 0, 1, 2
 LG_RNG_PHILOX, LG_RNG_INJECT = 0, 1
+LG_SOLVER_PGS, LG_SOLVER_TGS = 0, 1
+LG_FRICTION_CONE, LG_FRICTION_PYRAMID = 0, 1
 
 RAND_SLOTS = dict(LG_RS_CMD_CB=0, LG_RS_PUSH=4, LG_RS_LEVEL=6, LG_RS_DOF=8, LG_RS_ROOT_XY=20, LG_RS_ROOT_VEL=22,
                   LG_RS_CMD_RESET=28, LG_RS_NOISE=32)
@@ -103,7 +105,7 @@ class lg_config(C.Structure):
         ("base_init_state", f32 * 13),
         ("gait_enabled", i32), ("gait_period", f32), ("gait_swing_height", f32), ("gait_foot_phases", f32 * 4),
         ("solver_iterations", i32), ("contact_offset", f32), ("max_depenetration_velocity", f32), ("erp", f32),
-        ("cfm", f32),
+        ("cfm", f32), ("solver_type", i32), ("friction_model", i32), ("self_collisions", i32),
         ("seed", C.c_uint64), ("rng_mode", i32),
     ]
 

@@ -9,8 +9,14 @@
 //
 // Replaces gym.simulate (reference legged_robot.py:100; PhysX, closed): same tensor contract (:564-584), own model:
 // composite-rigid-body mass matrix + recursive Newton-Euler bias (spatial quantities about the base origin P, world
-// axes), sphere-vs-heightfield contacts solved at velocity level by projected Gauss-Seidel (every leg walks the list of
-// its active contacts; the four legs' j-th entries relax simultaneously), Coulomb friction disc, semi-implicit Euler.
+// axes), sphere-vs-heightfield contacts solved at velocity level (every leg walks the list of its active contacts; the four
+// legs' j-th entries relax simultaneously) by the solver sim.physx.solver_type names (legged_robot_config.py:256-267):
+//   LG_SOLVER_TGS (the reference's setting): temporal Gauss-Seidel -- `iters` sub-intervals of h = dt / iters, each ONE pass over
+//     the rows with the separation re-evaluated from the displacement accumulated so far (sep = gap + J_n . dq, bias over h),
+//     then dq += h v; the pose advances once, by dq, at the end of the step;
+//   LG_SOLVER_PGS: `iters` sweeps at the frozen pose (bias over dt), then dq = dt v.
+// Friction rows: PhysX's two scalar rows along the tangents, each clamped to +-mu f_n (LG_FRICTION_PYRAMID), or the exact 2x2
+// tangential block projected on the disc (LG_FRICTION_CONE).  Semi-implicit Euler.
 #pragma once
 #ifndef LG_AB
 #define LG_AB 0
@@ -224,9 +230,9 @@ LG_DEV void terrain_query(const TerrainView& T, float x, float y, float* h, V3* 
 // pairs of base coordinates, the joint responses of joints (0, 1) of the three contact-frame axes.
 // The blocks are laid out in the order a sweep step needs them (contact frame and gap, Jacobian pieces, tangents, the
 // tangential block, then the responses), because the step starts computing as soon as the first 16-byte reads land.
-enum { CF_N = 0, CF_BN = 3, CF_R = 4, CF_ACTIVE = 7, CF_L0 = 8, CF_ANN = 9 /* 1 / (Ann + cfm), written by the set-up */, CF_L1 = 10, CF_L2 = 11,
+enum { CF_N = 0, CF_GAP = 3 /* signed gap at the start of the step */, CF_R = 4, CF_ACTIVE = 7, CF_L0 = 8, CF_ANN = 9 /* 1 / (Ann + cfm), written by the set-up */, CF_L1 = 10, CF_L2 = 11,
        CF_SETUP = 12, CF_JK0 = 12, CF_JK1 = 15, CF_JK2 = 18, CF_ZC2 = 21 /* 3: (Mkk^-1 J_k^T)[c][joint 2] */,
-       CF_T12 = 24 /* t1.x t2.x t1.y t2.y t1.z t2.z */, CF_AN12 = 30 /* An1 An2 */, CF_B = 32 /* inverse tangential block, rows (B11 B12) (B12 B22) */,
+       CF_T12 = 24 /* t1.x t2.x t1.y t2.y t1.z t2.z */, CF_AN12 = 30 /* An1 An2 */, CF_B = 32 /* cone: inverse tangential block, rows (B11 B12) (B12 B22); pyramid: 1/A11, A12, A12, 1/A22 */,
        CF_WB = 36 /* 3 x 6: base response per unit contact-frame impulse */, CF_ZCP = 54 /* 3 x 2: (Mkk^-1 J_k^T)[c][joint 0, 1] */, CF_FIELDS = 60 };
 static_assert(CF_T12 % 2 == 0 && CF_AN12 % 2 == 0 && CF_B % 2 == 0 && CF_WB % 2 == 0 && CF_ZCP % 2 == 0 && CF_L1 % 2 == 0, "packed operands sit at even offsets");
 typedef float pk2 __attribute__((ext_vector_type(2)));
@@ -254,7 +260,7 @@ LG_DEV void sts3(float* cst, int slot, int f, int lane, V3 a) { CS(slot, f) = a.
 #endif
 
 struct PhysParams {
-  float dt; V3 grav; int iters; float contact_offset, max_depen, erp, cfm, terrain_mu;
+  float dt; V3 grav; int iters; float contact_offset, max_depen, erp, cfm, terrain_mu; int solver, fric;
 };
 
 struct QuadState {           // per lane: replicated base + own leg
@@ -289,7 +295,7 @@ LG_DEV void leg_bias(const LegModel& lm_, const LegKin& k, V3 pb, V3 wb, const f
 }
 
 // Contact detection for slots [S0, S1): sphere centre, terrain surface under it, gap, activation; results go to the
-// LDS slot table (CF_ACTIVE, CF_N, CF_R, CF_BN, zeroed impulses).  Unrolled and branch-free so the lookups overlap.
+// LDS slot table (CF_ACTIVE, CF_N, CF_R, CF_GAP, zeroed impulses).  Unrolled and branch-free so the lookups overlap.
 // Two halves: `begin` computes the sphere centres and issues the height-sample loads, `finish` consumes them — the
 // helper waves run their actuator network in between, which hides the memory latency of the lookups.
 template <int S0, int S1>
@@ -311,7 +317,6 @@ template <int S0, int S1>
 LG_DEV void contact_detect_finish(const LegModel& lm_, const TerrainView& T, const PhysParams& P, V3 pb, const ContactProbe<S0, S1>& pr,
                                   float* cst, int lane) {
   const int ncp = lm_.i(LM_CP_COUNT);
-  const float idt_ = frcp(P.dt);
 #pragma unroll
   for (int sl = S0; sl < S1; ++sl) {
     float hh; V3 n;
@@ -323,7 +328,7 @@ LG_DEV void contact_detect_finish(const LegModel& lm_, const TerrainView& T, con
     CS(sl, CF_L0) = 0.f; CS(sl, CF_L1) = 0.f; CS(sl, CF_L2) = 0.f;
     sts3(cst, sl, CF_N, lane, n);
     sts3(cst, sl, CF_R, lane, (x - pr.rads[sl - S0] * n) - pb);
-    CS(sl, CF_BN) = phi >= 0.f ? -phi * idt_ : fminf(-phi * P.erp * idt_, P.max_depen);
+    CS(sl, CF_GAP) = phi;
   }
 }
 template <int S0, int S1>
@@ -587,7 +592,7 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       CS(sl, CF_ACTIVE) = active ? 1.f : 0.f;
       sts3(cst, sl, CF_N, lane, n);
       sts3(cst, sl, CF_R, lane, (x - rad * n) - pb);
-      CS(sl, CF_BN) = phi >= 0.f ? -phi * idt_ : fminf(-phi * P.erp * idt_, P.max_depen);
+      CS(sl, CF_GAP) = phi;
     }
   }
 }
@@ -596,7 +601,7 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
 // detection results in the slot table and this leg's share of the factorised mass matrix.  Any wave of the workgroup
 // that holds the leg kinematics and (Mi, Mbk, Y, Si) can run it: the slots of one substep are dealt to all four waves.
 LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 pb, const float Mi[6], const float Mbk[6][3],
-                               const float Y[3][6], const float Si[21], float cfm, float* cst, int lane) {
+                               const float Y[3][6], const float Si[21], float cfm, int fric, float* cst, int lane) {
   const int ncp = lm_.i(LM_CP_COUNT);
   int lk = -1;
   if (sl < ncp) { int link = lm_.i(LM_CP_LINK + sl); lk = link < 0 ? -1 : (link > 2 ? 2 : link); }
@@ -657,7 +662,8 @@ LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 
   const float a11 = A[1][1] + cfm, a12 = A[1][2], a22 = A[2][2] + cfm;
   const float idet = frcp(a11 * a22 - a12 * a12);
   CS(sl, CF_ANN) = frcp(A[0][0] + cfm); OUT(CF_AN12) = A[1][0]; OUT(CF_AN12 + 1) = A[2][0];
-  OUT(CF_B) = a22 * idet; OUT(CF_B + 1) = -a12 * idet; OUT(CF_B + 2) = -a12 * idet; OUT(CF_B + 3) = a11 * idet;
+  const bool pyr = fric != LG_FRICTION_CONE;
+  OUT(CF_B) = pyr ? frcp(a11) : a22 * idet; OUT(CF_B + 1) = pyr ? a12 : -a12 * idet; OUT(CF_B + 2) = pyr ? a12 : -a12 * idet; OUT(CF_B + 3) = pyr ? frcp(a22) : a11 * idet;
 #undef OUT
   float4* dst = reinterpret_cast<float4*>(&CS(sl, CF_SETUP));
 #pragma unroll
@@ -853,7 +859,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     for (int sl = 0; sl < LG_MAX_CP; ++sl) {
       if (!((slot_mask >> sl) & 1u)) continue;
       if ((seen++ % share.n) != share.me) continue;
-      contact_setup_slot(sl, lm_, k, pb, Mi, Mbk, Y, Si, P.cfm, cst, lane);
+      contact_setup_slot(sl, lm_, k, pb, Mi, Mbk, Y, Si, P.cfm, P.fric, cst, lane);
     }
   }
   if (!share.late) share_fn();
@@ -885,7 +891,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
 
   // ---------------------------------------------------------------- joint position limits as unilateral rows on qd
   // (URDF lower/upper; lower >= upper = unlimited).  Whole block is skipped unless some lane of the wave is near a limit.
-  float jl_sgn[3], jl_bn[3], jl_iA[3], jl_lam[3] = {0.f, 0.f, 0.f}, jl_Wb[3][6], jl_y[3][3];
+  float jl_sgn[3], jl_gap[3], jl_iA[3], jl_lam[3] = {0.f, 0.f, 0.f}, jl_Wb[3][6], jl_y[3][3];
   bool jl_act[3];
   bool jl_any = false;
 #pragma unroll
@@ -895,7 +901,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     const float gap = glo <= ghi ? glo : ghi;
     jl_sgn[j] = glo <= ghi ? 1.f : -1.f;
     jl_act[j] = (lo < hi) && (gap + fminf(0.f, dt * jl_sgn[j] * vK[j]) < 0.05f);   // near the limit, or about to cross it this step
-    jl_bn[j] = gap >= 0.f ? -gap * idt_ : fminf(-gap * P.erp * idt_, 10.f);
+    jl_gap[j] = gap;
     jl_any |= jl_act[j];
   }
   const bool jl_wave = __ballot(jl_any) != 0ull;
@@ -916,7 +922,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     }
   }
 
-  // ---------------------------------------------------------------- projected Gauss-Seidel
+  // ---------------------------------------------------------------- contact / limit rows: TGS sub-intervals or PGS sweeps
   int my_count; const unsigned my_list = active_slot_list(cst, lane, &my_count);
   int my_steps = 0;                                   // wave-uniform: the longest list
 #pragma unroll
@@ -925,6 +931,13 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   // joint-limit rows and the slot lists above need nothing from the slot records, so they ran while the other waves set
   // their slots up; the rendezvous that closes the set-up comes only now.
   if (share.late) share_fn();
+  // the step's generalised displacement: dq = sum over the sub-intervals of h * v (TGS), dt * v of the last sweep (PGS)
+  pk2 dqB[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}; pk2 dqK01 = {0.f, 0.f}; float dqK2 = 0.f;
+  const bool tgs = P.solver == LG_SOLVER_TGS;
+  const int iters = P.iters > 0 ? P.iters : 1;
+  const float h = tgs ? dt * frcp((float)iters) : dt, ih = frcp(h);
+  const float tgsf = tgs ? 1.f : 0.f;
+  const float vlim[3] = {lm_.f(LM_VEL_LIMIT), lm_.f(LM_VEL_LIMIT + 1), lm_.f(LM_VEL_LIMIT + 2)};
   if (slot_mask || jl_wave) {
     // packed state of the sweeps: base velocity in three pairs, joints (0, 1) as a pair and joint 2 alone, Y by joint pair
     pk2 vBp[3] = {{vB[0], vB[1]}, {vB[2], vB[3]}, {vB[4], vB[5]}};
@@ -932,19 +945,20 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     pk2 Y01[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a) { Y01[a].x = Y[0][a]; Y01[a].y = Y[1][a]; }
+    const bool pyr = P.fric != LG_FRICTION_CONE;
+    const float erp_ih = P.erp * ih;
     // A lane with nothing to relax at a step still reads a record (and multiplies it by zero impulses): it must be one the
     // set-up has written in THIS launch for every lane -- any slot of the wave's mask -- not a slot nobody uses, whose LDS
     // may hold another kernel's bits (0 x NaN would poison the base velocity of the quad).
     const int idle_sl = slot_mask ? __builtin_ctz(slot_mask) : 0;
-#if LG_PGS_REG > 0
-    // One sweep step on a slot record held in REGISTERS.  The records of a lane's first PGS_REG active slots are fetched
-    // once (15 ds_read_b128 each) in front of the sweeps and stay in VGPRs through all `iters` sweeps, multipliers included:
-    // the lone main wave pays an LDS round trip per record per sweep otherwise (the sweeps are a dependent chain, nothing
-    // hides it).  Steps beyond PGS_REG take the LDS path below.  Measured (A/B in one session, physics kernel at 4096 envs):
+    // One relaxation of a slot record held in registers.  The records of a lane's first PGS_REG active slots are fetched
+    // once (15 ds_read_b128 each) in front of the sweeps and stay in VGPRs through all `iters` passes, multipliers included:
+    // the lone main wave pays an LDS round trip per record per pass otherwise (the passes are a dependent chain, nothing
+    // hides it).  Steps beyond PGS_REG fetch their record per pass.  Measured (A/B in one session, physics kernel at 4096 envs):
     // PGS_REG 1: -1.0 us; 2: +-0; 4: +2.5 us -- a wave has 256 architectural VGPRs, what lives beyond them sits in AGPRs and
     // costs a v_accvgpr_read per use, so only the first record (most legs have one contact, the foot) pays.
     constexpr int PGS_REG = LG_PGS_REG;
-    float regs[PGS_REG][CF_FIELDS];
+    float regs[PGS_REG > 0 ? PGS_REG : 1][CF_FIELDS];
 #pragma unroll
     for (int st_ = 0; st_ < PGS_REG; ++st_) {
       if (st_ < my_steps) {                              // wave-uniform
@@ -956,9 +970,14 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
       const V3 n = v3(rec[CF_N], rec[CF_N + 1], rec[CF_N + 2]), r = v3(rec[CF_R], rec[CF_R + 1], rec[CF_R + 2]);
       const V3 jk0 = v3(rec[CF_JK0], rec[CF_JK0 + 1], rec[CF_JK0 + 2]), jk1 = v3(rec[CF_JK1], rec[CF_JK1 + 1], rec[CF_JK1 + 2]);
       const V3 jk2 = v3(rec[CF_JK2], rec[CF_JK2 + 1], rec[CF_JK2 + 2]);
-      const float l0 = rec[CF_L0], bn = rec[CF_BN], iAnn = rec[CF_ANN];
+      const float l0 = rec[CF_L0], iAnn = rec[CF_ANN];
       const pk2 l12 = {rec[CF_L1], rec[CF_L2]}, an12 = {rec[CF_AN12], rec[CF_AN12 + 1]};
       const pk2 b_r0 = {rec[CF_B], rec[CF_B + 1]}, b_r1 = {rec[CF_B + 2], rec[CF_B + 3]};
+      // separation now: the gap of the start of the step plus the displacement of the contact point along the normal so far
+      // (TGS; PGS keeps the gap) and the bias velocity over the (sub-)interval
+      const V3 dp = v3(dqB[0].x, dqB[0].y, dqB[1].x) + cross(v3(dqB[1].y, dqB[2].x, dqB[2].y), r) + dqK01.x * jk0 + dqK01.y * jk1 + dqK2 * jk2;
+      const float sep = fmaf(tgsf, dot(n, dp), rec[CF_GAP]);
+      const float bn = sep >= 0.f ? -sep * ih : fminf(-sep * erp_ih, P.max_depen);
       V3 vp = v3(vBp[0].x, vBp[0].y, vBp[1].x) + cross(v3(vBp[1].y, vBp[2].x, vBp[2].y), r) + vK01.x * jk0 + vK01.y * jk1 + vK2 * jk2;
       const float u0 = dot(n, vp);
       pk2 u12 = pk_splat(vp.x) * (pk2){rec[CF_T12], rec[CF_T12 + 1]};
@@ -967,11 +986,17 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
       const float ln = fmaxf(l0 - (u0 - bn) * iAnn, 0.f);
       const float dn = ln - l0;
       const pk2 w12 = pk_fma(an12, pk_splat(dn), u12);
+      const float lim = mu * ln;
+      // cone: exact 2x2 tangential block, projected on the disc
       pk2 t12 = b_r0 * pk_splat(w12.x);
       t12 = pk_fma(b_r1, pk_splat(w12.y), t12);
-      pk2 n12 = l12 - t12;
-      const float lim = mu * ln, m2 = n12.x * n12.x + n12.y * n12.y;
-      if (m2 > lim * lim) { const float sc = m2 > 0.f ? lim * __builtin_amdgcn_rsqf(m2) : 0.f; n12 = n12 * pk_splat(sc); }
+      pk2 c12 = l12 - t12;
+      const float m2 = c12.x * c12.x + c12.y * c12.y;
+      if (m2 > lim * lim) { const float sc = m2 > 0.f ? lim * __builtin_amdgcn_rsqf(m2) : 0.f; c12 = c12 * pk_splat(sc); }
+      // pyramid: two scalar rows, each clamped on its own (b_r0 = (1/A11, A12), b_r1 = (A12, 1/A22))
+      const float p1 = fminf(fmaxf(l12.x - w12.x * b_r0.x, -lim), lim);
+      const float p2 = fminf(fmaxf(l12.y - fmaf(b_r0.y, p1 - l12.x, w12.y) * b_r1.y, -lim), lim);
+      pk2 n12; n12.x = pyr ? p1 : c12.x; n12.y = pyr ? p2 : c12.y;
       const float d0 = active ? dn : 0.f;
       pk2 d12 = n12 - l12;
       d12.x = active ? d12.x : 0.f; d12.y = active ? d12.y : 0.f;
@@ -998,92 +1023,33 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
       }
       vK01 = vK01 + w01; vK2 += w2;
     };
-#endif
 #pragma unroll 1
-    for (int it = 0; it < P.iters; ++it) {
-#if LG_PGS_REG > 0
+    for (int it = 0; it < iters; ++it) {
+      // every lane walks the list of its own active slots; step j relaxes the j-th active contact of each of the four
+      // legs together (Jacobi across the quad, Gauss-Seidel along the lists).  A pass takes max-over-lanes(list length)
+      // steps -- measured 2.3 on the headline workload against 3.0 slots that are active somewhere in the wave.
 #pragma unroll
       for (int st_ = 0; st_ < PGS_REG; ++st_)
         if (st_ < my_steps) relax(regs[st_], st_ < my_count);
 #pragma unroll 1
       for (int step = PGS_REG; step < my_steps; ++step) {
         const bool active = step < my_count;
-        const int sl = active ? (int)((my_list >> (4 * step)) & 0xfu) : idle_sl;
+        const int sl = active ? (int)((my_list >> (4 * step)) & 0xfu) : idle_sl;   // idle lanes read a slot every lane has a record for and apply nothing
         float rec[CF_FIELDS];
         load_slot_record(cst, sl, lane, rec);
         relax(rec, active);
+        // multipliers back to the record, without a branch: an idle lane rewrites what it has just read
         *reinterpret_cast<float4*>(&CS(sl, CF_L0)) = make_float4(rec[CF_L0], rec[CF_ANN], rec[CF_L1], rec[CF_L2]);
       }
-#else
-      // every lane walks the list of its own active slots; step j relaxes the j-th active contact of each of the four
-      // legs together (Jacobi across the quad, Gauss-Seidel along the lists).  A sweep takes max-over-lanes(list length)
-      // steps -- measured 2.3 on the headline workload against 3.0 slots that are active somewhere in the wave.
-#pragma unroll 1
-      for (int step = 0; step < my_steps; ++step) {
-        const bool active = step < my_count;
-        const int sl = active ? (int)((my_list >> (4 * step)) & 0xfu) : idle_sl;   // idle lanes read a slot every lane has a record for and apply nothing
-        // the whole slot record first (15 x 16-B LDS reads in flight, one wait), then arithmetic only: read-next-to-use
-        // costs an LDS round trip at every step of this dependent chain
-        float rec[CF_FIELDS];
-        load_slot_record(cst, sl, lane, rec);
-        const V3 n = v3(rec[CF_N], rec[CF_N + 1], rec[CF_N + 2]), r = v3(rec[CF_R], rec[CF_R + 1], rec[CF_R + 2]);
-        const V3 jk0 = v3(rec[CF_JK0], rec[CF_JK0 + 1], rec[CF_JK0 + 2]), jk1 = v3(rec[CF_JK1], rec[CF_JK1 + 1], rec[CF_JK1 + 2]);
-        const V3 jk2 = v3(rec[CF_JK2], rec[CF_JK2 + 1], rec[CF_JK2 + 2]);
-        const float l0 = rec[CF_L0], bn = rec[CF_BN], iAnn = rec[CF_ANN];           // 1 / Ann
-        const pk2 l12 = {rec[CF_L1], rec[CF_L2]}, an12 = {rec[CF_AN12], rec[CF_AN12 + 1]};
-        const pk2 b_r0 = {rec[CF_B], rec[CF_B + 1]}, b_r1 = {rec[CF_B + 2], rec[CF_B + 3]};   // inverse of the tangential block
-        __builtin_amdgcn_sched_barrier(0);
-        // velocity of the contact point
-        V3 vp = v3(vBp[0].x, vBp[0].y, vBp[1].x) + cross(v3(vBp[1].y, vBp[2].x, vBp[2].y), r) + vK01.x * jk0 + vK01.y * jk1 + vK2 * jk2;
-        const float u0 = dot(n, vp);
-        pk2 u12 = pk_splat(vp.x) * (pk2){rec[CF_T12], rec[CF_T12 + 1]};
-        u12 = pk_fma(pk_splat(vp.y), (pk2){rec[CF_T12 + 2], rec[CF_T12 + 3]}, u12);
-        u12 = pk_fma(pk_splat(vp.z), (pk2){rec[CF_T12 + 4], rec[CF_T12 + 5]}, u12);
-        const float ln = fmaxf(l0 - (u0 - bn) * iAnn, 0.f);
-        const float dn = ln - l0;
-        const pk2 w12 = pk_fma(an12, pk_splat(dn), u12);
-        pk2 t12 = b_r0 * pk_splat(w12.x);
-        t12 = pk_fma(b_r1, pk_splat(w12.y), t12);
-        pk2 n12 = l12 - t12;
-        const float lim = mu * ln, m2 = n12.x * n12.x + n12.y * n12.y;
-        if (m2 > lim * lim) { const float sc = m2 > 0.f ? lim * __builtin_amdgcn_rsqf(m2) : 0.f; n12 = n12 * pk_splat(sc); }
-        const float d0 = active ? dn : 0.f;
-        pk2 d12 = n12 - l12;
-        d12.x = active ? d12.x : 0.f; d12.y = active ? d12.y : 0.f;
-        // multipliers back to the record, without a branch: an idle lane rewrites what it has just read from its slot 0
-        *reinterpret_cast<float4*>(&CS(sl, CF_L0)) = make_float4(active ? ln : l0, iAnn, active ? n12.x : l12.x, active ? n12.y : l12.y);
-        // apply: base response of this lane's impulse from the stored M^-1 J^T columns, summed over the quad
-        pk2 g[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          pk2 acc = pk_splat(d0) * (pk2){rec[CF_WB + 2 * p], rec[CF_WB + 2 * p + 1]};
-          acc = pk_fma(pk_splat(d12.x), (pk2){rec[CF_WB + 6 + 2 * p], rec[CF_WB + 6 + 2 * p + 1]}, acc);
-          acc = pk_fma(pk_splat(d12.y), (pk2){rec[CF_WB + 12 + 2 * p], rec[CF_WB + 12 + 2 * p + 1]}, acc);
-          g[p].x = quad_sum(acc.x); g[p].y = quad_sum(acc.y);
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p) vBp[p] = vBp[p] + g[p];
-        {
-          pk2 w01 = pk_splat(d0) * (pk2){rec[CF_ZCP], rec[CF_ZCP + 1]};
-          w01 = pk_fma(pk_splat(d12.x), (pk2){rec[CF_ZCP + 2], rec[CF_ZCP + 3]}, w01);
-          w01 = pk_fma(pk_splat(d12.y), (pk2){rec[CF_ZCP + 4], rec[CF_ZCP + 5]}, w01);
-          float w2 = d0 * rec[CF_ZC2] + d12.x * rec[CF_ZC2 + 1] + d12.y * rec[CF_ZC2 + 2];
-#pragma unroll
-          for (int a = 0; a < 6; ++a) {
-            const float ga = (a & 1) ? g[a >> 1].y : g[a >> 1].x;
-            w01 = pk_fma(-Y01[a], pk_splat(ga), w01);
-            w2 -= Y[2][a] * ga;
-          }
-          vK01 = vK01 + w01; vK2 += w2;
-        }
-      }
-#endif
       if (jl_wave) {
         float vBs[6] = {vBp[0].x, vBp[0].y, vBp[1].x, vBp[1].y, vBp[2].x, vBp[2].y}, vKs[3] = {vK01.x, vK01.y, vK2};
+        const float dqs[3] = {dqK01.x, dqK01.y, dqK2};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {           // joint j of the four legs together, like a contact slot
           const float u = jl_sgn[j] * vKs[j];
-          const float ln = fmaxf(jl_lam[j] - (u - jl_bn[j]) * jl_iA[j], 0.f);
+          const float gap = fmaf(tgsf * jl_sgn[j], dqs[j], jl_gap[j]);
+          const float bn = gap >= 0.f ? -gap * ih : fminf(-gap * erp_ih, 10.f);
+          const float ln = fmaxf(jl_lam[j] - (u - bn) * jl_iA[j], 0.f);
           const float dl = jl_act[j] ? ln - jl_lam[j] : 0.f;
           if (jl_act[j]) jl_lam[j] = ln;
           float gq[6];
@@ -1103,30 +1069,41 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
         for (int p = 0; p < 3; ++p) { vBp[p].x = vBs[2 * p]; vBp[p].y = vBs[2 * p + 1]; }
         vK01.x = vKs[0]; vK01.y = vKs[1]; vK2 = vKs[2];
       }
-    }
-#if LG_PGS_REG > 0
+      // end of the sub-interval (TGS) / of the last sweep (PGS): joint speed limit (URDF <limit velocity>, a hard cap on |qd|),
+      // then the displacement of the interval
+      const bool close = tgs || it == iters - 1;
+      {
+        const float c0 = vlim[0] > 0.f ? fminf(fmaxf(vK01.x, -vlim[0]), vlim[0]) : vK01.x;
+        const float c1 = vlim[1] > 0.f ? fminf(fmaxf(vK01.y, -vlim[1]), vlim[1]) : vK01.y;
+        const float c2 = vlim[2] > 0.f ? fminf(fmaxf(vK2, -vlim[2]), vlim[2]) : vK2;
+        vK01.x = close ? c0 : vK01.x; vK01.y = close ? c1 : vK01.y; vK2 = close ? c2 : vK2;
+      }
+      const pk2 hh = pk_splat(close ? h : 0.f);
 #pragma unroll
-    for (int st_ = 0; st_ < LG_PGS_REG; ++st_) {
+      for (int p = 0; p < 3; ++p) dqB[p] = pk_fma(hh, vBp[p], dqB[p]);
+      dqK01 = pk_fma(hh, vK01, dqK01); dqK2 = fmaf(hh.x, vK2, dqK2);
+    }
+#pragma unroll
+    for (int st_ = 0; st_ < PGS_REG; ++st_) {
       if (st_ < my_steps && st_ < my_count) {            // (an idle lane has nothing to store: its record was only read)
         const int sl = (int)((my_list >> (4 * st_)) & 0xfu);
         *reinterpret_cast<float4*>(&CS(sl, CF_L0)) = make_float4(regs[st_][CF_L0], regs[st_][CF_ANN], regs[st_][CF_L1], regs[st_][CF_L2]);
       }
     }
-#endif
 #pragma unroll
     for (int p = 0; p < 3; ++p) { vB[2 * p] = vBp[p].x; vB[2 * p + 1] = vBp[p].y; }
     vK[0] = vK01.x; vK[1] = vK01.y; vK[2] = vK2;
+  } else {
+    // no row anywhere in the wave: the velocity is the unconstrained one over the whole step
+#pragma unroll
+    for (int j = 0; j < 3; ++j) if (vlim[j] > 0.f) vK[j] = fminf(fmaxf(vK[j], -vlim[j]), vlim[j]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { dqB[p].x = dt * vB[2 * p]; dqB[p].y = dt * vB[2 * p + 1]; }
+    dqK01.x = dt * vK[0]; dqK01.y = dt * vK[1]; dqK2 = dt * vK[2];
   }
 
   STAMP(7);
-  // ---------------------------------------------------------------- joint speed limit (URDF <limit velocity>)
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    float lim = lm_.f(LM_VEL_LIMIT + j);
-    if (lim > 0.f) vK[j] = fminf(fmaxf(vK[j], -lim), lim);
-  }
-
-  // ---------------------------------------------------------------- net contact force per body (world frame)
+  // ---------------------------------------------------------------- net contact force per body (world frame): the step's impulse / dt
   if (fbody) {
     V3 fb[5] = {v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0)};
     const float idt = idt_;
@@ -1147,13 +1124,13 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     for (int b = 1; b < 5; ++b) fbody[b] = fb[b];
   }
 
-  // ---------------------------------------------------------------- semi-implicit Euler
+  // ---------------------------------------------------------------- pose advance by the step's displacement (semi-implicit Euler)
   s.root[7] = vB[0]; s.root[8] = vB[1]; s.root[9] = vB[2]; s.root[10] = vB[3]; s.root[11] = vB[4]; s.root[12] = vB[5];
-  s.root[0] += dt * vB[0]; s.root[1] += dt * vB[1]; s.root[2] += dt * vB[2];
+  s.root[0] += dqB[0].x; s.root[1] += dqB[0].y; s.root[2] += dqB[1].x;
   {
-    V3 w = v3(vB[3], vB[4], vB[5]); float wn = norm(w), ang = wn * dt;
+    V3 w = v3(dqB[1].y, dqB[2].x, dqB[2].y); float ang = norm(w);
     float sh, ch; sincos_fast(0.5f * ang, &sh, &ch);
-    sh = wn > 1e-9f ? sh * frcp(wn) : 0.5f * dt;
+    sh = ang > 1e-12f ? sh * frcp(ang) : 0.5f;
     float dq0 = sh * w.x, dq1 = sh * w.y, dq2 = sh * w.z, dq3 = ch;
     float* qq = s.root + 3;
     float x = dq3 * qq[0] + dq0 * qq[3] + dq1 * qq[2] - dq2 * qq[1];
@@ -1163,7 +1140,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     float inv = __builtin_amdgcn_rsqf(x * x + y * y + z * z + w4 * w4);
     qq[0] = x * inv; qq[1] = y * inv; qq[2] = z * inv; qq[3] = w4 * inv;
   }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) { s.qd[j] = vK[j]; s.q[j] += dt * vK[j]; }
+  s.qd[0] = vK[0]; s.qd[1] = vK[1]; s.qd[2] = vK[2];
+  s.q[0] += dqK01.x; s.q[1] += dqK01.y; s.q[2] += dqK2;
   STAMP(8);
 }

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     PhysParams P;
     P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
-    P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm;
+    P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
     P.terrain_mu = C->terrain_mu;
     const TerrainView T = C->ter;
     if (TMESH) mesh_cache_io<true>(C, cqc, e, l, lane, 2 * wv);   // this wave's two slots of the persisted query cache -> LDS
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           for (int sl = 0; sl < LG_MAX_CP; ++sl) {
             if (!((slot_mask >> sl) & 1u)) continue;
             if ((seen++ & 3) != wv - 1) continue;       // set-up order: waves 1, 2, 3, then the main wave (A/B: -1.9 us on the kernel)
-            contact_setup_slot(sl, lm_, k, pb, Mi, Mbk, Y, Si, P.cfm, cst, lane);
+            contact_setup_slot(sl, lm_, k, pb, Mi, Mbk, Y, Si, P.cfm, P.fric, cst, lane);
           }
         }
       }
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 
   PhysParams P;
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
-  P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm;
+  P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
   P.terrain_mu = C->terrain_mu;
   const TerrainView T = C->ter;
   const float mu_robot = C->friction[e], madd = C->mass_added[e];

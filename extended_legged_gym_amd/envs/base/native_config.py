@@ -252,10 +252,25 @@ class NativeSetup:
         c.solver_iterations = int(getattr(px, "num_position_iterations", 4))
         c.contact_offset = float(getattr(px, "contact_offset", 0.01))
         c.max_depenetration_velocity = float(getattr(px, "max_depenetration_velocity", 1.0))
-        # penetration recovery per substep: PhysX scales the penetration bias of a contact row by 0.8 / dt and clamps it
-        # at max_depenetration_velocity (contact preparation of its solver).  Pinned at task level: with 0.8 the reference's
-        # PhysX-trained walking policy stays up (tests/test_walk_policy.py; 0.2 let feet sink and cost ~0.4 falls / 20 s).
-        c.erp, c.cfm = 0.8, 1e-6
+        # sim.physx.solver_type (legged_robot_config.py:262: "0: pgs, 1: tgs"): the reference runs PhysX's temporal Gauss-Seidel.
+        st = int(getattr(px, "solver_type", 1))
+        if st not in (0, 1):
+            raise ValueError(f"sim.physx.solver_type must be 0 (pgs) or 1 (tgs), got {st}")
+        c.solver_type = abi.LG_SOLVER_TGS if st == 1 else abi.LG_SOLVER_PGS
+        # friction rows of a contact: PhysX's two scalar rows per contact ("pyramid", the default) or the exact Coulomb disc ("cone")
+        fm = str(getattr(px, "friction_model", "pyramid"))
+        if fm not in ("pyramid", "cone"):
+            raise ValueError(f"sim.physx.friction_model must be 'pyramid' or 'cone', got {fm!r}")
+        c.friction_model = abi.LG_FRICTION_PYRAMID if fm == "pyramid" else abi.LG_FRICTION_CONE
+        # share of a contact's penetration recovered per solver (sub-)interval, clamped at max_depenetration_velocity.  Not a PhysX
+        # parameter name: 0.8 is the factor PhysX's contact preparation applies to the penetration bias; what it does to the
+        # reference's walking policy is measured in DESIGN.md s2a (tools/physics/walk_matrix.py), not claimed as an equivalence.
+        erp = float(getattr(px, "penetration_recovery", 0.8))
+        if not 0.0 < erp <= 1.0:
+            raise ValueError(f"sim.physx.penetration_recovery must be in (0, 1], got {erp}")
+        c.erp, c.cfm = erp, 1e-6
+        # asset.self_collisions is a collision-filter bitmask: 0 = the actor's shapes collide with each other (legged_robot_config.py:176)
+        c.self_collisions = 0
         c.seed, c.rng_mode = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_mode)
         self.cfg = c
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION 2
+#define LG_ABI_VERSION 3
 
 #define LG_NUM_LEGS 4
 #define LG_JOINTS_PER_LEG 3
@@ -60,6 +60,17 @@ enum lg_control { LG_CTRL_P = 0, LG_CTRL_V = 1, LG_CTRL_T = 2, LG_CTRL_ACTUATOR_
  * TerrainObj / TerrainConfined vertices) through closest-point queries on lg_terrain.collision_mesh, while the height
  * scan keeps reading height_samples (all zero for TerrainObj, terrain_obj.py:116). */
 enum lg_mesh_type { LG_MESH_PLANE = 0, LG_MESH_HEIGHTFIELD = 1, LG_MESH_TRIMESH = 2 };
+
+/* sim.physx.solver_type (legged_robot_config.py:262: "0: pgs, 1: tgs").  LG_SOLVER_PGS: num_position_iterations projected
+ * Gauss-Seidel sweeps over the contact / limit rows at the frozen pose of the start of sim.dt, then one pose update.
+ * LG_SOLVER_TGS (what the reference configures): temporal Gauss-Seidel -- num_position_iterations sub-intervals of
+ * dt / iterations, each one pass over the rows with the separation re-evaluated from the pose advanced so far, then the pose
+ * advances by the sub-interval. */
+enum lg_solver { LG_SOLVER_PGS = 0, LG_SOLVER_TGS = 1 };
+
+/* friction rows of a contact: LG_FRICTION_CONE = exact 2x2 tangential block projected on the disc |f_t| <= mu f_n;
+ * LG_FRICTION_PYRAMID = PhysX's two scalar rows along the tangents, each clamped to +-mu f_n on its own */
+enum lg_friction { LG_FRICTION_CONE = 0, LG_FRICTION_PYRAMID = 1 };
 
 /* rng_mode: counter-based Philox4x32-10 in-kernel, or uniforms injected by the host (parity / golden tests) */
 enum lg_rng { LG_RNG_PHILOX = 0, LG_RNG_INJECT = 1 };
@@ -239,6 +250,10 @@ typedef struct lg_config {
   /* contact solver (legged_robot_config.py:250-267) */
   int32_t solver_iterations;          /* physx.num_position_iterations */
   float contact_offset, max_depenetration_velocity, erp, cfm;
+  int32_t solver_type;                /* enum lg_solver: physx.solver_type */
+  int32_t friction_model;             /* enum lg_friction */
+  int32_t self_collisions;            /* 1 = the robot's own collision spheres collide with each other (asset.self_collisions == 0,
+                                       * legged_robot_config.py:176, passed to create_actor at legged_robot.py:792) */
   /* rng */
   uint64_t seed; int32_t rng_mode;
 } lg_config;
