@@ -17,7 +17,7 @@ import torch
 
 from extended_legged_gym_amd import abi
 from tests.helpers import sim_params_for
-from tests.test_hip_vs_oracle import COPY, STATE, compare
+from tests.test_hip_vs_oracle import COPY, STATE, compare, step_bars
 
 pytestmark = pytest.mark.gpu
 
@@ -72,7 +72,7 @@ def test_a1_on_confined_obj_mesh_matches_oracle_for_one_step(tmp_path):
     # reset on one side only and cannot be compared entry by entry; such envs are counted, not hidden
     ra, rb = env.core.t["reset_buf"].cpu().numpy(), o.t["reset_buf"]
     assert (ra != rb).mean() <= 0.02
-    rep = compare(env.core, o, [s for s in STATE if s not in ("measured_heights", "sea_hidden_state", "sea_cell_state")], rows=ra == rb)
+    rep = compare(env.core, o, [s for s in STATE if s not in ("measured_heights", "sea_hidden_state", "sea_cell_state")], rows=ra == rb, bars=step_bars(env.setup))
     cf = o.t["contact_forces"].reshape(n, -1, 3)
     assert (np.linalg.norm(cf, axis=2) > 1.0).any(axis=1).mean() > 0.8          # the robots are in contact with the mesh
     assert (np.abs(cf[..., :2]).max() > 5.0), rep                                 # ... and not only with horizontal faces
