@@ -106,7 +106,7 @@ class lg_config(C.Structure):
         ("gait_enabled", i32), ("gait_period", f32), ("gait_swing_height", f32), ("gait_foot_phases", f32 * 4),
         ("solver_iterations", i32), ("contact_offset", f32), ("max_depenetration_velocity", f32), ("erp", f32),
         ("cfm", f32), ("solver_type", i32), ("friction_model", i32), ("self_collisions", i32),
-        ("seed", C.c_uint64), ("rng_mode", i32),
+        ("seed", C.c_uint64), ("rng_mode", i32), ("inject_sim_state", i32),
     ]
 
 

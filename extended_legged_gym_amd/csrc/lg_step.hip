@@ -643,9 +643,16 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       // the rigid-body rows -- stores nobody in this launch reads -- come last
       const bool feet_early = fused_needs_feet_rows(C);  // (kernel-uniform)
       if (feet_early && wv == 3 && valid) {
-        float r13[13], qq[3], qdd[3];
-        fetch_state(xst[lane], r13, qq, qdd);
-        write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane));   // (gait_foot_z is stored late: the serial part still reads the old one)
+        if (g.inject_sim_state) {                        // parity tests: the feet rows the caller injected
+          const float* o = C->rigid + ((size_t)e * C->B + 1 + C->per_leg * l + (C->per_leg == 4 ? 3 : 2)) * 13;
+          float* fr = fused_foot_row(xs, lane);
+#pragma unroll
+          for (int i = 0; i < 13; ++i) fr[i] = o[i];
+        } else {
+          float r13[13], qq[3], qdd[3];
+          fetch_state(xst[lane], r13, qq, qdd);
+          write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane));   // (gait_foot_z is stored late: the serial part still reads the old one)
+        }
       }
       fused_height_scan(C, xst, cst, blockIdx.x, n, (wv - 1) * 64 + lane);
       if (feet_early || fused_needs_heights_early(C)) lds_barrier();   // (G1) only when the serial part reads a helper's product
@@ -666,11 +673,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       p = (float4*)(C->sea_c + (N12 + row) * 8);
       p[0] = make_float4(c1[0], c1[1], c1[2], c1[3]); p[1] = make_float4(c1[4], c1[5], c1[6], c1[7]);
       C->actions[(size_t)e * 12 + d] = a;
-      C->torques[(size_t)e * 12 + d] = xtau[j][lane];
+      if (!(fuse && g.inject_sim_state)) C->torques[(size_t)e * 12 + d] = xtau[j][lane];
     }
     if (fuse) {
       const bool last = fused_writeback_obs(C, hot, xs, cst, blockIdx.x, n, threadIdx.x, fstep, nullptr, sink.obs_out);
-      if (valid && !(fused_needs_feet_rows(C) && wv == 3)) {     // rigid-body rows of the post-physics (pre-reset) pose, LR:118-120
+      if (valid && g.inject_sim_state) {                         // parity tests: the injected rows stay; gait_foot_z from the injected foot row
+        if (wv == 3 && g.gait_enabled) C->gait_foot_z[(size_t)e * 4 + l] = C->rigid[((size_t)e * C->B + 1 + C->per_leg * l + (C->per_leg == 4 ? 3 : 2)) * 13 + 2];
+      } else if (valid && !(fused_needs_feet_rows(C) && wv == 3)) {     // rigid-body rows of the post-physics (pre-reset) pose, LR:118-120
         float r13[13], qq[3], qdd[3];
         fetch_state(xst[lane], r13, qq, qdd);
         write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled) ? C->gait_foot_z + (size_t)e * 4 + l : nullptr);
@@ -811,6 +820,25 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
   }
   STAMP(9);
+  if (fuse && g.inject_sim_state) {
+    // parity tests (lg_config.inject_sim_state): the post-physics half starts from the post-simulation state the caller left in the
+    // tensors -- this workgroup's rows still hold it, nothing of this launch has stored to them yet
+    const int per_leg = C->per_leg, B = C->B;
+    const int ee = valid ? e : 0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) s.root[i] = C->root[(size_t)ee * 13 + i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      s.q[j] = C->dof[((size_t)ee * 12 + 3 * l + j) * 2]; s.qd[j] = C->dof[((size_t)ee * 12 + 3 * l + j) * 2 + 1];
+      tau[j] = C->torques[(size_t)ee * 12 + 3 * l + j];
+    }
+    const float* cf = C->cforce + (size_t)ee * B * 3;
+    fbody[0] = v3(cf[0], cf[1], cf[2]);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { const float* cl = cf + (size_t)(1 + per_leg * l + b) * 3; fbody[1 + b] = v3(cl[0], cl[1], cl[2]); }
+    if (per_leg == 4) { const float* cl = cf + (size_t)(1 + per_leg * l + 3) * 3; fbody[4] = v3(cl[0], cl[1], cl[2]); } else fbody[4] = v3(0, 0, 0);
+    fault = false;
+  }
   if (helpers) {
     float qn = 0.f;
     if (fuse) {      // the height scan's yaw-only quaternion (math_utils.quat_apply_yaw), normalised here once per env instead of once per scan point

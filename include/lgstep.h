@@ -256,6 +256,10 @@ typedef struct lg_config {
                                        * legged_robot_config.py:176, passed to create_actor at legged_robot.py:792) */
   /* rng */
   uint64_t seed; int32_t rng_mode;
+  int32_t inject_sim_state;           /* parity tests only (like LG_RNG_INJECT): lg_step's post-physics half takes the post-simulation state
+                                       * from what the caller put into LG_T_ROOT_STATES / DOF_STATE / TORQUES / CONTACT_FORCES / RIGID_BODY_STATE
+                                       * before the call -- the way the recording harness injected it under the reference's step() -- and
+                                       * leaves those tensors as they are; what the substeps computed from it is discarded */
 } lg_config;
 
 typedef struct lg_ctx lg_ctx;

@@ -61,6 +61,54 @@ def test_hip_step_matches_reference(case):
     core.close()
 
 
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_fused_step_matches_reference(case):
+    """The golden steps through `lg_step` itself -- ONE launch, the post-physics step as the tail of the physics kernel
+    (`csrc/lg_fused_post.h`: the code the headline number runs), not the stand-alone `lg_post_physics_step` of the test above.
+    `lg_config.inject_sim_state` is the FakeGym of this path: the kernel's tail starts from the post-simulation state the fixture
+    recorded (root, DOF state and torques of the last substep, rigid-body rows, contact forces), placed in the tensors before the
+    call, instead of from what its own substeps computed.  Everything the reference's `post_physics_step` produces is then held to
+    the golden vectors at the bar of the split path.  (The LSTM state is the kernel's own across its substeps: covered by
+    `test_fused_step_actuator_matches_reference_torques`.)"""
+    from extended_legged_gym_amd.native import NativeCore
+    z, meta = load_golden(case)
+    cfg, s = golden_setup(z, meta)
+    s.cfg.inject_sim_state = 1
+    core = NativeCore(s, "cuda:0")
+    T, dec = z["actions"].shape[0], cfg.control.decimation
+
+    def write(name, arr):
+        tt = core.t[name]
+        if name == "episode_sums":
+            tt = tt[:np.asarray(arr).shape[0]]
+        tt.copy_(torch.from_numpy(np.ascontiguousarray(arr).reshape(tuple(tt.shape))).to(tt.dtype))
+
+    skip = {"sea_hidden_state", "sea_cell_state"}
+    for t in range(T):
+        load_pre_state(core.t, z, t, write)
+        write("dof_state", z["sim_dof"][t, dec - 1])
+        write("torques", z["torques"][t, dec - 1])
+        write("root_states", z["sim_root"][t])
+        write("rigid_body_state", z["sim_rigid"][t])
+        write("contact_forces", z["sim_contact"][t])
+        core.step(torch.from_numpy(z["actions"][t]).cuda())
+        torch.cuda.synchronize()
+        if cfg.terrain.measure_heights:
+            assert np.array_equal(core.t["measured_heights"].cpu().numpy(), z["measured_heights"][t]), f"step {t}: heights"
+        if "post_terrain_levels" in z.files:
+            assert np.array_equal(core.t["terrain_levels"].cpu().numpy(), z["post_terrain_levels"][t])
+        for name, key in post_keys(meta).items():
+            if name in skip:
+                continue
+            got = core.t[name][:z[key][t].shape[0]] if name == "episode_sums" else core.t[name]
+            check(name, got, z[key][t], t)
+        if z["extras_fresh"][t]:
+            K = len(meta["reward_names"])
+            np.testing.assert_allclose(core.t["extras_episode"][:K].cpu().numpy(), z["extras_episode"][t], rtol=1e-4, atol=1e-6)
+        assert int(core.t["step_counters"][1]) == int(z["reset"][t].sum())
+    core.close()
+
+
 @pytest.mark.parametrize("case", ["flat_lstm", "rough_lstm"])
 def test_fused_step_actuator_matches_reference_torques(case):
     """The actuator as the HEADLINE path runs it: inside the fused physics kernel (`lg_step` / `lg_step_physics`), where the
