@@ -96,22 +96,48 @@ def cpu_baseline(env, actions_pool, budget_s=15.0):
                        f"(best of the probed team sizes; {avail} CPUs visible), {dt:.1f} s")
 
 
-def _latest_profile(suffix):
-    """Counter summary `profiles/<tag>_<suffix>` of the build named in `profiles/LATEST` (written by tools/profile_round.sh
-    when the summaries of a build are committed)."""
-    tag = "r01_z"
+def kernel_source_sha256():
+    """Hash of the kernel sources the library is built from: counter summaries are only quoted next to timings of the same code."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "extended_legged_gym_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "lgstep.h"), "rb").read())
+    return h.hexdigest()
+
+
+def _profile_tag():
     try:
-        tag = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip() or tag
+        return open(os.path.join(ROOT, "profiles", "LATEST")).read().strip() or "r01_z"
     except OSError:
-        pass
-    return os.path.join(ROOT, "profiles", f"{tag}_{suffix}")
+        return "r01_z"
+
+
+def _latest_profile(suffix):
+    """Counter summary `profiles/<tag>_<suffix>` of the build named in `profiles/LATEST` (written by tools/collect_profiles.py
+    when the summaries of a build are committed)."""
+    return os.path.join(ROOT, "profiles", f"{_profile_tag()}_{suffix}")
+
+
+def committed_counters_match_this_build():
+    """True when `profiles/<tag>_build.json` (tools/collect_profiles.py) names the sources this library was built from and the
+    run uses the default one-launch step: PMC / SQ figures of another build, or of the split path, are not quoted."""
+    if os.environ.get("LG_FUSE", "1") == "0" or os.environ.get("LG_SPLIT") or os.environ.get("LG_GRID_MESH"):
+        return False
+    try:
+        with open(_latest_profile("build.json")) as f:
+            return json.load(f)["kernel_source_sha256"] == kernel_source_sha256()
+    except Exception:
+        return False
 
 
 def sq_issue(N):
     """VALU busy fraction of the physics kernel's waves from the committed SQ counter passes (`tools/pmc_sq.sh`): the kernel
     is bound by instruction issue of one wave per SIMD, not by bytes, so this is the utilisation figure that moves."""
     path = _latest_profile("sq_counters.txt")
-    if not os.path.exists(path) or N != 4096:
+    if not os.path.exists(path) or N != 4096 or not committed_counters_match_this_build():
         return {}
     try:
         vals, on = {}, False
@@ -134,13 +160,17 @@ def pmc_traffic(N):
     files = [_latest_profile("pmc.json")]     # the passes taken on the most recent build of the kernels
     if not os.path.exists(files[0]) or N != 4096:
         return {"traffic": None}
+    if not committed_counters_match_this_build():
+        sys.stderr.write("bench.py: profiles/%s_* were taken on other kernel sources (or another launch mode): roofline.traffic = null\n" % _profile_tag())
+        return {"traffic": None, "traffic_note": "committed counter passes belong to another build"}
     try:
         with open(files[-1]) as f:
             k = json.load(f)["kernels"]
         name = [n for n in k if "physics_kernel" in n][0]
         rd, wr = k[name]["FETCH_SIZE_KiB_per_launch"] * 1024.0, k[name]["WRITE_SIZE_KiB_per_launch"] * 1024.0
         return {"traffic": rd + wr, "traffic_read_bytes_as_reported": rd, "traffic_write_bytes": wr,
-                "traffic_source": os.path.relpath(files[-1], ROOT)}
+                "traffic_source": os.path.relpath(files[-1], ROOT) + " (committed profile of this build, not measured by this run)",
+                "profile_tag": _profile_tag()}
     except Exception:
         return {"traffic": None}
 

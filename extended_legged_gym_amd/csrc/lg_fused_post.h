@@ -35,6 +35,8 @@ static_assert(FU_PRE + EPB * FU_PRE_STRIDE <= 64 * 12, "uniforms + pre-step inte
 enum { FM_RK = 0, FM_PART = LG_MAX_REWARD_TERMS, FM_ROOTZ = FM_PART + PART_STRIDE, FM_DID_RESET, FM_ROOT_DIRTY, FM_LASTC /* 4 */, FM_RAW = FM_LASTC + 4 /* 2 x LG_REW_COUNT */,
        FM_STRIDE = FM_RAW + 2 * LG_REW_COUNT + 1 };
 enum { FO_STRIDE = 256, FH_HEIGHTS = 0, FH_MISC = EPB * MAX_P, FH_OBS = FH_MISC + EPB * FM_STRIDE + 3 - (FH_MISC + EPB * FM_STRIDE + 3) % 4 /* 16-B aligned */ };
+static_assert(FH_OBS + 4 * FO_STRIDE <= LG_MAX_CP * CF_FIELDS * 64, "heights + per-env results + four observation staging rows must fit the memory of the contact-slot table");
+static_assert(LG_REW_COUNT <= 32, "reward-term masks (rew_term_mask, 1u << id) are 32 bits wide");
 
 // ---- helper waves, while the main wave runs the last sweeps: history rows, uniforms, pre-step integers -> LDS
 LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid /* 0..191 */, int64_t step, const float* values) {

@@ -40,6 +40,30 @@ def test_noise_scale_vec_of_the_student_is_the_head_of_the_teacher_rows():
     np.testing.assert_array_equal(s.noise_scale_vec[:144], z["noise_scale_vec"])
 
 
+def test_noise_scale_vec_for_a_history_longer_than_the_teacher_row():
+    """The class default `history_length = 5` gives 240 observations, more than the teacher row's 235: the noise vector is built on the
+    student's buffer (`legged_robot.py:533-556`), and the history update must broadcast against it."""
+    from extended_legged_gym_amd.envs.anymal_c.anymal import student_history_update
+    from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_student_config import AnymalCRoughStudentCfg
+    from extended_legged_gym_amd.envs.base.native_config import noise_scale_vec
+    cfg = AnymalCRoughStudentCfg()
+    v = noise_scale_vec(cfg, 48 * 5)
+    assert v.shape == (240,) and np.all(v[48:235] == v[48]) and v[48] > 0 and np.all(v[235:] == 0)
+    hist, obs = student_history_update(torch.zeros(4, 5, 48), torch.ones(4, 48), torch.zeros(4, dtype=torch.bool), torch.rand(4, 240), torch.from_numpy(v))
+    assert obs.shape == (4, 240) and torch.isfinite(obs).all()
+
+
+@pytest.mark.gpu
+def test_student_env_with_the_default_history_length():
+    from tests.test_env_api import make
+    env = make("anymal_c_rough_student", 16, **{"env.history_length": 5, "env.num_observations": 240, "terrain.mesh_type": "heightfield",
+                                                "terrain.num_rows": 2, "terrain.num_cols": 2, "terrain.border_size": 5, "terrain.max_init_terrain_level": 1})
+    assert env.num_obs == 240 and env.noise_scale_vec.shape == (240,) and env.add_noise
+    env.reset()
+    obs, priv, *_ = env.step(torch.zeros(16, 12, device=env.device))
+    assert obs.shape == (16, 240) and torch.isfinite(obs).all()
+
+
 @pytest.mark.gpu
 def test_student_env_on_the_device():
     """Task `anymal_c_rough_student` through the registry: shapes, history shifting, zeroing at reset, privileged row = native row."""

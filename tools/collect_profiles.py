@@ -49,5 +49,13 @@ if os.path.exists(sq):
 for src, name in ((f"bench_{tag}.json", "bench.json"), (f"configs_{tag}.jsonl", "other_configs.jsonl"), (f"rollout_{tag}.json", "rollout_collection.json")):
     if os.path.exists(os.path.join(ROOT, "gpurun_out", src)):
         shutil.copy(os.path.join(ROOT, "gpurun_out", src), out(name))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_sha256: bench.py quotes these counters only next to timings of the same sources)
+try:
+    import subprocess
+    head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
+except Exception:
+    head = None
+json.dump({"kernel_source_sha256": bench.kernel_source_sha256(), "git_head_at_collection": head}, open(out("build.json"), "w"), indent=1)
 open(os.path.join(dst, "LATEST"), "w").write(tag + "\n")
 print("profiles/%s_* written:" % tag, sorted(os.path.basename(f) for f in glob.glob(out("*"))))
