@@ -1,0 +1,20 @@
+"""The other half of "a policy trained on one simulator walks on the other" (SURVEY s7): PPO with the reference's hyper-parameters
+(`LeggedRobotCfgPPO`, `anymal_c_flat_config.py:84-97`) learns to walk on this physics from scratch, through the native rollout
+collection (`lg_collect_rollout`).  The full 300-iteration run and its play-back next to the PhysX-trained policy are recorded in
+profiles/r03_train_acceptance.json (tools/train_acceptance.py); this is its 150-iteration regression (~10 s on the GPU)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_ppo_learns_to_walk_on_the_native_env(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train_acceptance
+    s = train_acceptance.main(["--iters", "150", "--envs", "4096", "--seed", "1", "--no-play", "--out", str(tmp_path / "run.json")])
+    # the reference's README: "basic locomotion (~200 epochs)" (legged_gym/README.md:18); measured here: 0.85 at iteration 150
+    assert s["final_rew_tracking_lin_vel"] >= 0.6, s
+    assert s["final_mean_episode_length"] >= 800, s
