@@ -9,6 +9,8 @@ from .anymal_c.flat.load_adapt_anymal_c_flat_config import LoadAdaptAnymalCFlatC
 from .anymal_c.flat.pose_anymal_c_flat_config import PoseAnymalCFlatCfg, PoseAnymalCFlatCfgPPO
 from .anymal_c.flat.stand_anymal_c_flat_config import StandAnymalCFlatCfg, StandAnymalCFlatCfgPPO
 from .anymal_c.mixed_terrains.anymal_c_rough_student_config import AnymalCRoughStudentCfg, AnymalCRoughStudentCfgPPO
+from .anymal_c.mixed_terrains.anymal_c_rough_teacher_config import AnymalCRoughTeacherCfg, AnymalCRoughTeacherCfgPPO
+from .anymal_b.anymal_b_config import AnymalBRoughCfg, AnymalBRoughCfgPPO
 from .a1.a1_config import A1RoughCfg, A1RoughCfgPPO
 from .go2.go2 import Go2, LoadAdaptGo2, PoseGo2, StandGo2
 from .go2.go2_config import (Go2RoughCfg, Go2RoughCfgPPO, Go2FlatCfg, Go2FlatCfgPPO, LoadAdaptGo2FlatCfg,
@@ -26,6 +28,13 @@ task_registry.register("go2_rough", Go2, Go2RoughCfg(), Go2RoughCfgPPO())
 task_registry.register("go2_flat", Go2, Go2FlatCfg(), Go2FlatCfgPPO())
 task_registry.register("anymal_c_batch_rollout", AnymalCBatchRollout, AnymalCBatchRolloutCfg(), AnymalCBatchRolloutCfgPPO())
 task_registry.register("anymal_c_batch_rollout_flat", AnymalCBatchRollout, AnymalCBatchRolloutFlatCfg(), AnymalCBatchRolloutFlatCfgPPO())
+from .go2.batch_rollout.go2_batch_rollout import Go2BatchRollout  # noqa: E402
+from .go2.batch_rollout.go2_batch_rollout_config import (Go2BatchRolloutCfg, Go2BatchRolloutCfgPPO,  # noqa: E402
+                                                         Go2BatchRolloutFlatCfg, Go2BatchRolloutFlatCfgPPO)
+task_registry.register("anymal_b", Anymal, AnymalBRoughCfg(), AnymalBRoughCfgPPO())
+task_registry.register("anymal_c_rough_teacher", Anymal, AnymalCRoughTeacherCfg(), AnymalCRoughTeacherCfgPPO())
+task_registry.register("go2_batch_rollout", Go2BatchRollout, Go2BatchRolloutCfg(), Go2BatchRolloutCfgPPO())
+task_registry.register("go2_batch_rollout_flat", Go2BatchRollout, Go2BatchRolloutFlatCfg(), Go2BatchRolloutFlatCfgPPO())
 task_registry.register("load_adapt_anymal_c_flat", LoadAdaptAnymal, LoadAdaptAnymalCFlatCfg(), LoadAdaptAnymalCFlatCfgPPO())
 task_registry.register("load_adapt_go2_flat", LoadAdaptGo2, LoadAdaptGo2FlatCfg(), LoadAdaptGo2FlatCfgPPO())
 task_registry.register("stand_anymal_c_flat", StandAnymal, StandAnymalCFlatCfg(), StandAnymalCFlatCfgPPO())

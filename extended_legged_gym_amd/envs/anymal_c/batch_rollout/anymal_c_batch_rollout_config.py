@@ -3,9 +3,26 @@
 termination (an upside-down base ends the episode instead), `only_positive_rewards` off."""
 from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout_percept_config import (
     RobotBatchRolloutPerceptCfg, RobotBatchRolloutPerceptCfgPPO)
+from extended_legged_gym_amd.utils.gait_scheduler import AsyncGaitSchedulerCfg
 
 
 class AnymalCBatchRolloutCfg(RobotBatchRolloutPerceptCfg):
+    class gait_scheduler:            # time-driven gait shaping of the class (zero-scaled in the shipped configs)
+        period = 1.0
+        duty = 0.5
+        foot_phases = [0.0, 0.5, 0.0, 0.5]
+        dt = 0.02
+        swing_height = 0.04
+        track_sigma = 0.25
+
+    class async_gait_scheduler(AsyncGaitSchedulerCfg):
+        dof_names = ['LF_HAA', 'LF_HFE', 'LF_KFE', 'RF_HAA', 'RF_HFE', 'RF_KFE',
+                     'LH_HAA', 'LH_HFE', 'LH_KFE', 'RH_HAA', 'RH_HFE', 'RH_KFE']
+        dof_align_sets = [['LF_HFE', 'RH_HFE'], ['RF_HFE', 'LH_HFE'], ['LF_KFE', 'RH_KFE'], ['RF_KFE', 'LH_KFE']]
+        dof_nominal_pos = [0.0, 0.4, -0.8, 0.0, 0.4, -0.8, 0.0, -0.4, 0.8, 0.0, -0.4, 0.8]
+        foot_names = ['LF_FOOT', 'RF_FOOT', 'LH_FOOT', 'RH_FOOT']
+        foot_z_align_sets = [['LF_FOOT', 'RH_FOOT'], ['RF_FOOT', 'LH_FOOT']]
+
     class env(RobotBatchRolloutPerceptCfg.env):
         num_envs = 32            # main envs
         rollout_envs = 1
@@ -120,6 +137,11 @@ class AnymalCBatchRolloutCfg(RobotBatchRolloutPerceptCfg):
             action_rate = -0.001
             stand_still = -0.
 
+        class async_gait_scheduler:  # weights of the three alignment terms per reward stage
+            dof_align = 1.0
+            dof_nominal_pos = [0.05, 0.2]
+            reward_foot_z_align = [0.1, 0.6]
+
     class domain_rand(RobotBatchRolloutPerceptCfg.domain_rand):
         randomize_base_mass = True
         added_mass_range = [-5., 5.]
@@ -143,6 +165,7 @@ class AnymalCBatchRolloutCfgPPO(RobotBatchRolloutPerceptCfgPPO):
         run_name = ''
         experiment_name = 'anymal_c_batch_rollout'
         load_run = -1
+        max_iterations = 3000
 
 
 class AnymalCBatchRolloutFlatCfg(AnymalCBatchRolloutCfg):
@@ -162,6 +185,10 @@ class AnymalCBatchRolloutFlatCfg(AnymalCBatchRolloutCfg):
             'LH_HAA': 0.0, 'LH_HFE': -0.4, 'LH_KFE': 0.8,
             'RH_HAA': 0.0, 'RH_HFE': -0.4, 'RH_KFE': 0.8,
         }
+
+    class asset(AnymalCBatchRolloutCfg.asset):
+        penalize_contacts_on = ["SHANK", "THIGH"]
+        terminate_after_contacts_on = ["base"]
 
     class rewards(AnymalCBatchRolloutCfg.rewards):
         max_contact_force = 500.
@@ -192,4 +219,5 @@ class AnymalCBatchRolloutFlatCfg(AnymalCBatchRolloutCfg):
 
 class AnymalCBatchRolloutFlatCfgPPO(AnymalCBatchRolloutCfgPPO):
     class runner(AnymalCBatchRolloutCfgPPO.runner):
-        experiment_name = 'anymal_c_batch_rollout_flat'
+        experiment_name = 'anymal_c_batch_rollout'      # (the reference's flat task logs under the same name)
+        multi_stage_rewards = True

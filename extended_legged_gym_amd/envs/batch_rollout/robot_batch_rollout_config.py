@@ -15,6 +15,10 @@ class RobotBatchRolloutCfg(LeggedRobotCfg):
     class domain_rand(LeggedRobotCfg.domain_rand):
         rollout_envs_sync_pos_drift = 0.0
 
+    class sim(LeggedRobotCfg.sim):
+        class physx(LeggedRobotCfg.sim.physx):
+            max_gpu_contact_pairs = 2**24    # (a PhysX buffer size: carried for config parity, nothing native reads it)
+
 
 class RobotBatchRolloutCfgPPO(LeggedRobotCfgPPO):
     class runner(LeggedRobotCfgPPO.runner):

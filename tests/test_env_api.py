@@ -106,3 +106,37 @@ def test_update_reward_scales_and_command_ranges_on_the_env():
     env.reset_idx(torch.arange(32, device=env.device))
     torch.cuda.synchronize()
     assert torch.allclose(env.commands[:, 0], torch.full((32,), 2.0, device=env.device))
+
+
+def test_round3_tasks_construct_and_step():
+    """`anymal_b`, `anymal_c_rough_teacher`, `go2_batch_rollout`, `go2_batch_rollout_flat` (reference envs/__init__.py:134, 194, 142-143)
+    through the registry; their config trees are held to the reference's in tests/test_task_configs.py, their post-physics step (class
+    `Anymal` on those trees) to golden vectors in tests/test_hip_golden.py."""
+    small = {"terrain.mesh_type": "heightfield", "terrain.num_rows": 2, "terrain.num_cols": 2, "terrain.border_size": 5, "terrain.max_init_terrain_level": 1}
+    env = make("anymal_b", 32, **small)
+    assert (env.num_obs, env.num_actions, env.num_bodies) == (235, 12, 17) and abs(env.setup.model.base_mass + 4 * 3.35 - 30.62) < 1.5
+    env.reset()
+    for _ in range(30):
+        obs, priv, rew, done, info = env.step(torch.zeros(32, 12, device=env.device))
+    assert priv is None and torch.isfinite(obs).all() and float(env.root_states[:, 2].min()) > 0.2      # the 30.6 kg robot stands on its actuator net
+    env = make("anymal_c_rough_teacher", 32, **small)
+    assert env.num_obs == 235 and env.cfg.control.use_actuator_network
+    env.reset()
+    for _ in range(10):
+        obs, _, rew, done, info = env.step(torch.randn(32, 12, device=env.device))
+    assert torch.isfinite(obs).all() and "rew_tracking_lin_vel" in info["episode"]
+    flat = make("go2_batch_rollout_flat", 16)
+    assert (flat.num_envs, flat.total_num_envs, flat.num_obs) == (16, 16, 48) and flat.setup.cfg.terminate_on_flip == 1
+    flat.reset()
+    for _ in range(20):
+        obs, _, rew, done, info = flat.step(torch.zeros(16, 12, device=flat.device))
+    assert torch.isfinite(obs).all() and (rew >= 0).all() and flat.update_reward_scales(100.0) and flat.reward_scales_stage == 1
+    # the percept variant needs a terrain mesh (the reference names an OBJ of its author's machine): on the plane with its sensors on
+    env = make("go2_batch_rollout", 4, **{"env.rollout_envs": 3, "terrain.use_terrain_obj": False, "terrain.mesh_type": "plane", "terrain.random_origins": False})
+    assert (env.num_envs, env.total_num_envs, env.num_obs) == (4, 16, 181)
+    obs, _ = env.reset()
+    for _ in range(5):
+        obs, _, rew, done, info = env.step(torch.zeros(4, 12, device=env.device))
+    assert obs.shape == (4, 181) and torch.isfinite(obs).all() and float(obs[:, 48:176].max()) > 0.0     # some of the 128 rays hit the ground
+    ro = env.step_rollout(torch.zeros(12, 12, device=env.device))
+    assert ro[0].shape == (12, 181)

@@ -42,6 +42,12 @@ def build(case):
     ref_loader.FakeGym.robot = ref_loader.anymal_robot_description()
     N = case["num_envs"]
     cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
+    if case.get("cfg") == "teacher":        # task anymal_c_rough_teacher
+        from legged_gym.envs import AnymalCRoughTeacherCfg
+        cfg = AnymalCRoughTeacherCfg()
+    if case.get("cfg") == "anymal_b":       # task anymal_b (the harness robot keeps ANYmal's body / DOF names, which ANYmal-B shares)
+        from legged_gym.envs import AnymalBRoughCfg
+        cfg = AnymalBRoughCfg()
     if case.get("cls") == "AnymalStudent":
         cfg = AnymalCRoughStudentCfg()
     if case.get("cls") == "PoseAnymal":
@@ -360,6 +366,14 @@ CASES = [
          scales=dict(orientation=-4.0, torques=-0.000025, feet_air_time=1.0, base_height=-4.0, collision=-2.0,
                      penalty_in_the_air=-4.0, feet_contact_forces=-0.01),
          max_contact_force=100.0, only_positive_rewards=False),
+]
+
+CASES += [
+    # tasks anymal_c_rough_teacher / anymal_b (envs/__init__.py:194, :134): class Anymal on their own config trees
+    dict(name="rough_teacher", base="rough", cfg="teacher", num_envs=32, steps=4, seed=8, actuator_net=True, push_interval_s=0.08,
+         resampling_time=0.1, heading_command=True, episode_length_s=20, num_rows=3, num_cols=4, border_size=5),
+    dict(name="rough_anymal_b", base="rough", cfg="anymal_b", num_envs=32, steps=4, seed=9, actuator_net=True, push_interval_s=0.08,
+         resampling_time=0.1, heading_command=False, episode_length_s=20, num_rows=3, num_cols=4, border_size=5),
 ]
 
 if __name__ == "__main__":

@@ -138,6 +138,8 @@ def main(argv=None):
     a = ap.parse_args(argv)
     torch.manual_seed(a.seed); np.random.seed(a.seed)
     env_cfg, train_cfg = task_registry.get_cfgs("anymal_c_flat")
+    import copy
+    env_cfg = copy.deepcopy(env_cfg)                 # (the registry's instance stays untouched)
     env_cfg.env.num_envs = a.envs
     env_cfg.seed = a.seed
     env, env_cfg = task_registry.make_env("anymal_c_flat", args=get_args(["--headless", "--sim_device", "cuda:0"]), env_cfg=env_cfg)
