@@ -87,7 +87,7 @@ def ppo_update(ac, opt, data, cfg, lr):
             loss.backward()
             torch.nn.utils.clip_grad_norm_(ac.parameters(), cfg["max_grad_norm"])
             opt.step()
-            stats["value"] += float(value_loss); stats["surrogate"] += float(surrogate); stats["kl"] += float(kl); stats["n"] += 1
+            stats["value"] += float(value_loss.detach()); stats["surrogate"] += float(surrogate.detach()); stats["kl"] += float(kl); stats["n"] += 1
     n = max(stats.pop("n"), 1)
     return lr, {k: v / n for k, v in stats.items()}
 
