@@ -24,9 +24,11 @@ class BaseTask:
         self.num_obs = cfg.env.num_observations
         self.num_privileged_obs = cfg.env.num_privileged_obs
         self.num_actions = cfg.env.num_actions
-        if self.num_privileged_obs is not None:
-            raise NotImplementedError("privileged observations are not produced by the native step")
-        self.privileged_obs_buf = None
+        # `base_task.py:76-79`: a zero tensor of that width when the config asks for one.  The reference's `LeggedRobot` never writes it
+        # (`compute_observations`, `legged_robot.py:234-252`, fills `obs_buf` only; `step` clips it, `:109-110`) -- env classes that do
+        # (`AnymalStudent`) bind their own tensor after construction
+        self.privileged_obs_buf = None if self.num_privileged_obs is None else \
+            torch.zeros(self.num_envs, self.num_privileged_obs, device=self.device, dtype=torch.float)
         self.extras = {}
 
         self.create_sim()      # builds terrain, robot model and the native context; binds the buffers below

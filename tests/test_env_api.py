@@ -108,6 +108,16 @@ def test_update_reward_scales_and_command_ranges_on_the_env():
     assert torch.allclose(env.commands[:, 0], torch.full((32,), 2.0, device=env.device))
 
 
+def test_privileged_obs_buffer_as_base_task_allocates_it():
+    """`env.num_privileged_obs` set on a plain `LeggedRobot` task (`base_task.py:76-79, 109`): a zero tensor of that width comes back from
+    `step` and `get_privileged_observations`, as in the reference, whose `compute_observations` leaves it untouched."""
+    env = make("anymal_c_flat", 16, **{"env.num_privileged_obs": 7})
+    obs, priv = env.reset()
+    assert priv.shape == (16, 7) and priv.is_cuda and not priv.any() and env.get_privileged_observations() is priv
+    _, priv2, *_ = env.step(torch.zeros(16, 12, device=env.device))
+    assert priv2 is priv
+
+
 def test_round3_tasks_construct_and_step():
     """`anymal_b`, `anymal_c_rough_teacher`, `go2_batch_rollout`, `go2_batch_rollout_flat` (reference envs/__init__.py:134, 194, 142-143)
     through the registry; their config trees are held to the reference's in tests/test_task_configs.py, their post-physics step (class
