@@ -821,11 +821,13 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   if (!TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
   STAMP(29);   // (diagnostic: this wave's own detection ends here; what follows in stamp 5 is the wait at the rendezvous)
   if (!prep_fn(bk, Fs, Ns)) {
-    leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);
-    // (ALLOW_INLINE = false: the fused step on a mesh terrain always runs with helper waves; an inlined mesh query here, unreachable,
-    //  still costs the main wave registers)
-    if (TMESH) { if (ALLOW_INLINE) contact_detect_mesh(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane); }
-    else contact_detect<0, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
+    // (ALLOW_INLINE = false: a launch with helper waves never gets here; the inlined fallback, unreachable, still costs the main wave
+    //  registers and code)
+    if (ALLOW_INLINE) {
+      leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);
+      if (TMESH) contact_detect_mesh(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);
+      else contact_detect<0, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
+    }
   }
   float bb[6];
   {

@@ -250,6 +250,9 @@ LG_DEV float lstm_actuator1(const float* __restrict__ W, float x0, float x1, flo
 // wave runs its Gauss-Seidel sweeps (the actuator waves have nothing else to do then); what stays on the critical path
 // in front of the rendezvous is the input part: 2 of 10 columns of layer 0 and 8 of 16 of layer 1, plus the gates.
 struct LstmPre { v4f a0[8], a1[8]; };
+#ifndef LG_LSTM_LDS
+#define LG_LSTM_LDS (LG_AB == 1)     // A/B build 1: the actuator waves read the LSTM weights from LDS instead of through scalar loads
+#endif
 LG_DEV void lstm_recurrent_part(const float* __restrict__ W, const float* h0, const float* h1, LstmPre& pre) {
   const v4f* B0 = (const v4f*)(W + LW_B0); const v4f* H0 = (const v4f*)(W + LW_H0);
   const v4f* B1 = (const v4f*)(W + LW_B1); const v4f* H1 = (const v4f*)(W + LW_H1);
@@ -339,11 +342,13 @@ LG_DEV void store_lstm(const DevCtx* __restrict__ C, int e, int l, const LegActu
     }
 }
 
-// torques of this lane's three joints (LR:425-448 / anymal.py:93-105)
+// torques of this lane's three joints (LR:425-448 / anymal.py:93-105).  ALLOW_NET = false: the caller's launch evaluates the actuator
+// network on its helper waves; only the PD / velocity / torque modes are compiled in
+template <bool ALLOW_NET = true>
 LG_DEV void leg_torques(const DevCtx* __restrict__ C, const LegModel& lm_, const float* __restrict__ Wlds, const float act[3],
                         const float q[3], const float qd[3], const float last_qd[3], LegActuator& A, float tau[3]) {
   const lg_config& g = C->cfg;
-  if (g.control_type == LG_CTRL_ACTUATOR_NET) {
+  if (ALLOW_NET && g.control_type == LG_CTRL_ACTUATOR_NET) {
     float x0[3], x1[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -464,7 +469,10 @@ LG_DEV float* fused_act_slot(float* xs, int lane, int d);
 LG_DEV bool fused_needs_heights_early(const DevCtx* __restrict__ C);
 LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__ C);
 
-template <int MODE, bool TMESH>
+// HELPERS: the launch has the three helper waves (every policy step unless LG_SPLIT=0).  A separate instance, so that the kernel the
+// headline runs does not carry the single-wave fallback (the whole LSTM inlined in the main wave, inline leg bias and contact
+// detection): that dead code accounted for most of the register spills the compiler reported for the kernel.
+template <int MODE, bool TMESH, bool HELPERS = false>
 #if LG_AB == 9      // timing probe: cap the kernel at the 256 registers per wave that two workgroups per CU would leave (spills go to scratch)
 __attribute__((amdgpu_num_vgpr(120)))
 #endif
@@ -489,6 +497,12 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ float cqc[TMESH ? LG_MAX_CP * 4 * 64 : 1];   // mesh terrains: last closest-point query of every collision sphere
   __shared__ int s_last_f;                                 // fused step: this workgroup is the last of the launch to arrive
   __shared__ float hot[HC_COUNT];                          // fused step: the scalars of the post-physics tail (HC_*)
+  // A/B build 1 only: an LDS copy of the 905 gate-interleaved LSTM weights for the actuator waves (one ds_read_b128 at a wave-uniform
+  // address = four weights).  Measured against the scalar loads (s_load_dwordx16 -> SGPR pairs feeding the packed FMAs) in one session:
+  // 0.0897 ms per step from LDS, 0.0818 ms through SGPRs -- the scalar unit fetches the weights beside the vector ALU, while LDS
+  // reads take issue slots of the wave whose chain of gate evaluations is the critical path in front of rendezvous (A2).
+  constexpr bool LSTM_LDS = !TMESH && LG_LSTM_LDS;
+  __shared__ __attribute__((aligned(16))) float wlds[LSTM_LDS ? LW_COUNT + 3 : 4];
   const int64_t fstep = C->counters[0] + 1;               // LR:123 (the statistics step of the previous launch stored it)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // row kq of the launch <-> env e (identity, or ids[kq] for subset stepping: main-only / rollout-only steps)
@@ -502,10 +516,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
   if (wv == 0) fill_leg_model(lmod, m, &C->cfg, lane);
   if (fuse && wv == 1) for (int i = lane; i < HC_COUNT; i += 64) hot[i] = C->hot[i];
+  if (LSTM_LDS && MODE == 0 && net && wv >= 2) for (int i = (wv - 2) * 64 + lane; i < LW_COUNT; i += 128) wlds[i] = wlstm[i];
   lds_barrier();
   const LegModel lm_{lmod, l};
 
-  if (MODE == 0 && wv > 0) {
+  if (MODE == 0 && HELPERS && wv > 0) {
     // ---------------------------------------------------------------- actuator wave: joint j of leg l of env e
     const int j = wv - 1, d = 3 * l + j;
     // with the actuator network this wave also evaluates joint j of every leg; with PD control (helpers are then only
@@ -542,7 +557,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     LstmPre lpre;
-    if (net) { int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); lstm_recurrent_part(wlstm + zero, h0, h1, lpre); }
+    if (net) {
+      if (LSTM_LDS) lstm_recurrent_part(wlds, h0, h1, lpre);
+      else { int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); lstm_recurrent_part(wlstm + zero, h0, h1, lpre); }
+    }
 #pragma unroll 1
     for (int sub = 0; sub < nsub; ++sub) {
       lds_barrier();                                   // (A) main wave has published root, q, qd of this substep
@@ -594,8 +612,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         const float x0 = (tgt - qq[j]) * g.actuator_in_scale[0], x1 = qdd[j] * g.actuator_in_scale[1];
         // an opaque zero keeps the ~60 weight addresses from being hoisted out of the substep loop as loop invariants
         // (they would fill the SGPR file and spill): inside the loop they fold into the s_load immediate offsets
-        int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-        xtau[j][lane] = lstm_input_part(wlstm + zero, x0, x1, lpre, h0, c0, h1, c1, g.actuator_out_scale);
+        if (LSTM_LDS) xtau[j][lane] = lstm_input_part(wlds, x0, x1, lpre, h0, c0, h1, c1, g.actuator_out_scale);
+        else {
+          int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+          xtau[j][lane] = lstm_input_part(wlstm + zero, x0, x1, lpre, h0, c0, h1, c1, g.actuator_out_scale);
+        }
       }
       if (!TMESH && wv == 1) { if (DS0 < DS1) contact_detect_finish<DS0, DS1P>(lm_, T, P, pb, pr1, cst, lane); }
       else if (!TMESH && wv == 2) contact_detect_finish<DS1, DS2>(lm_, T, P, pb, pr2, cst, lane);
@@ -621,8 +642,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       STAMP(27);
       lds_barrier();                                   // (A3) slot table complete
       if (net && sub + 1 < nsub) {                     // while the main wave sweeps: recurrent half of the next substep's network
-        int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-        lstm_recurrent_part(wlstm + zero, h0, h1, lpre);
+        if (LSTM_LDS) lstm_recurrent_part(wlds, h0, h1, lpre);
+        else { int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); lstm_recurrent_part(wlstm + zero, h0, h1, lpre); }
       }
       if (fuse && sub + 1 == nsub) {                   // ... in the last substep: what the post-physics tail needs from HBM
         if (net) *fused_act_slot(xs, lane, d) = a;     // (the mass-factor table is dead after (A3): the env rows live there)
@@ -692,7 +713,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     return;
   }
-  const bool helpers = MODE == 0 && nact == 3;           // helper waves present (leg bias + contact detection)
+  const bool helpers = MODE == 0 && HELPERS;             // helper waves present (leg bias + contact detection); the host launches this instance with nact == 3
   const bool split = helpers && net;                     // ... and they evaluate the actuator network too
 
   QuadState s;
@@ -753,7 +774,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     if (split) {
     } else if (MODE == 0) {
-      leg_torques(C, lm_, wlstm, act, s.q, s.qd, last_qd, A, tau);
+      leg_torques<!HELPERS>(C, lm_, wlstm, act, s.q, s.qd, last_qd, A, tau);
     } else {
 #pragma unroll
       for (int j = 0; j < 3; ++j) tau[j] = C->torques[(size_t)e * 12 + 3 * l + j];
@@ -783,7 +804,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     };
     auto share_fn = [&]() { if (helpers) lds_barrier(); };   // (A3) every wave has finished its slots
     const SlotShare share{helpers ? 4 : 1, helpers ? 3 : 0, helpers};     // set-up order: wave 1, 2, 3, then this wave
-    physics_substep<TMESH, TMESH ? 2 : DS0, !(MODE == 0 && TMESH)>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
+    physics_substep<TMESH, TMESH ? 2 : DS0, !(MODE == 0 && HELPERS)>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
                               sub == nsub - 1 ? fbody : nullptr, stamps, (TMESH && helpers) ? cqc : nullptr);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
@@ -2188,9 +2209,10 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
   const int nact = (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) ? 3 : 0;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
-    hipLaunchKernelGGL((physics_kernel<0, true>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
+    hipLaunchKernelGGL((physics_kernel<0, true, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
   else
-    hipLaunchKernelGGL((physics_kernel<0, false>), dim3(nb), dim3(64 * (1 + nact)), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
+    if (nact == 3) hipLaunchKernelGGL((physics_kernel<0, false, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
+    else hipLaunchKernelGGL((physics_kernel<0, false, false>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
 }
 
 int lg_step(lg_ctx* c, const float* actions, void* stream) {
