@@ -234,11 +234,18 @@ enum { CF_N = 0, CF_GAP = 3 /* signed gap at the start of the step */, CF_R = 4,
        CF_SETUP = 12, CF_JK0 = 12, CF_JK1 = 15, CF_JK2 = 18, CF_ZC2 = 21 /* 3: (Mkk^-1 J_k^T)[c][joint 2] */,
        CF_T12 = 24 /* t1.x t2.x t1.y t2.y t1.z t2.z */, CF_AN12 = 30 /* An1 An2 */, CF_B = 32 /* cone: inverse tangential block, rows (B11 B12) (B12 B22); pyramid: 1/A11, A12, A12, 1/A22 */,
        CF_WB = 36 /* 3 x 6: base response per unit contact-frame impulse */, CF_ZCP = 54 /* 3 x 2: (Mkk^-1 J_k^T)[c][joint 0, 1] */, CF_FIELDS = 60 };
+static_assert(CF_T12 % 4 == 0 && CF_L0 == 8 && CF_ANN == 9 && CF_L1 == 10 && CF_L2 == 11 && CF_GAP == 3 && CF_ACTIVE == 7, "16-byte units of the record as CS4 reads them");
 static_assert(CF_T12 % 2 == 0 && CF_AN12 % 2 == 0 && CF_B % 2 == 0 && CF_WB % 2 == 0 && CF_ZCP % 2 == 0 && CF_L1 % 2 == 0, "packed operands sit at even offsets");
 typedef float pk2 __attribute__((ext_vector_type(2)));
 LG_DEV pk2 pk_splat(float x) { pk2 r = {x, x}; return r; }
 LG_DEV pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
 #define CS(slot, f) cst[((slot) * 64 + lane) * CF_FIELDS + (f)]
+// 16-byte unit u of a lane's slot record: record fields are only ever touched four at a time -- a 4-byte access at a stride of 60 dwords
+// across the lanes lands on 16 of the 64 banks (4-way conflict); a ds_*_b128 of the same record does not conflict (odd number of units)
+#define CS4(slot, u) (reinterpret_cast<float4*>(cst + ((slot) * 64 + lane) * CF_FIELDS)[u])
+// which lanes have an active contact in a slot: one 64-bit ballot per slot behind the records, written by the wave that detects the slot
+#define LG_CST_FLOATS (LG_MAX_CP * CF_FIELDS * 64 + 2 * LG_MAX_CP)
+#define AMASK(slot) (reinterpret_cast<unsigned long long*>(const_cast<float*>(cst) + LG_MAX_CP * CF_FIELDS * 64)[slot])
 static_assert(CF_FIELDS % 4 == 0 && (CF_FIELDS / 4) % 2 == 1, "slot rows: 16-B aligned, odd number of 16-B units (bank spread)");
 // the whole record of one slot, 15 x 16 B
 LG_DEV void load_slot_record(const float* cst, int slot, int lane, float rec[CF_FIELDS]) {
@@ -324,11 +331,12 @@ LG_DEV void contact_detect_finish(const LegModel& lm_, const TerrainView& T, con
     const V3 x = pr.xs[sl - S0];
     const float phi = (x.z - hh) * n.z - pr.rads[sl - S0];
     const bool active = (sl < ncp) && (phi < P.contact_offset);
-    CS(sl, CF_ACTIVE) = active ? 1.f : 0.f;
-    CS(sl, CF_L0) = 0.f; CS(sl, CF_L1) = 0.f; CS(sl, CF_L2) = 0.f;
-    sts3(cst, sl, CF_N, lane, n);
-    sts3(cst, sl, CF_R, lane, (x - pr.rads[sl - S0] * n) - pb);
-    CS(sl, CF_GAP) = phi;
+    const V3 r = (x - pr.rads[sl - S0] * n) - pb;
+    CS4(sl, 0) = make_float4(n.x, n.y, n.z, phi);
+    CS4(sl, 1) = make_float4(r.x, r.y, r.z, active ? 1.f : 0.f);
+    CS4(sl, 2) = make_float4(0.f, 0.f, 0.f, 0.f);                // multipliers (field 9, 1 / Ann, comes from the set-up)
+    const unsigned long long am = __ballot(active);
+    if (lane == 0) AMASK(sl) = am;
   }
 }
 template <int S0, int S1>
@@ -519,7 +527,6 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k,
                                 const M3& Rb, V3 pb, float* cst, int lane, float* cq = nullptr, unsigned long long* dbg = nullptr) {
   const int ncp = lm_.i(LM_CP_COUNT);
-  const float idt_ = frcp(P.dt);
   // slots in pairs: one BVH traversal serves two neighbouring spheres (closest_point_pair)
 #pragma unroll 1
   for (int sp0 = s0; sp0 < s1; sp0 += 2) {
@@ -574,7 +581,6 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
     for (int h = 0; h < 2; ++h) {
       const int sl = sp0 + h;
       if (sl >= s1) continue;
-      CS(sl, CF_L0) = 0.f; CS(sl, CF_L1) = 0.f; CS(sl, CF_L2) = 0.f;
       bool active = false; V3 n = v3(0, 0, 1); float phi = 1.f;
       const V3 x = xs[h]; const float rad = rads[h];
       if (Q[h].on) {
@@ -589,10 +595,12 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
           active = phi < P.contact_offset;
         }
       }
-      CS(sl, CF_ACTIVE) = active ? 1.f : 0.f;
-      sts3(cst, sl, CF_N, lane, n);
-      sts3(cst, sl, CF_R, lane, (x - rad * n) - pb);
-      CS(sl, CF_GAP) = phi;
+      const V3 r = (x - rad * n) - pb;
+      CS4(sl, 0) = make_float4(n.x, n.y, n.z, phi);
+      CS4(sl, 1) = make_float4(r.x, r.y, r.z, active ? 1.f : 0.f);
+      CS4(sl, 2) = make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned long long am = __ballot(active);
+      if (lane == 0) AMASK(sl) = am;
     }
   }
 }
@@ -605,7 +613,8 @@ LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 
   const int ncp = lm_.i(LM_CP_COUNT);
   int lk = -1;
   if (sl < ncp) { int link = lm_.i(LM_CP_LINK + sl); lk = link < 0 ? -1 : (link > 2 ? 2 : link); }
-  const V3 n = lds3(cst, sl, CF_N, lane), r = lds3(cst, sl, CF_R, lane);
+  const float4 n4 = CS4(sl, 0), r4 = CS4(sl, 1);
+  const V3 n = v3(n4.x, n4.y, n4.z), r = v3(r4.x, r4.y, r4.z);
   const V3 p = r + pb;
   float out[CF_FIELDS - CF_SETUP];   // the set-up block of the slot record, stored below as 12 x 16 B
 #define OUT(f) out[(f) - CF_SETUP]
@@ -661,7 +670,8 @@ LG_DEV void contact_setup_slot(int sl, const LegModel& lm_, const LegKin& k, V3 
   // block (computed once here, by whichever wave sets the slot up, instead of in each of the four sweeps)
   const float a11 = A[1][1] + cfm, a12 = A[1][2], a22 = A[2][2] + cfm;
   const float idet = frcp(a11 * a22 - a12 * a12);
-  CS(sl, CF_ANN) = frcp(A[0][0] + cfm); OUT(CF_AN12) = A[1][0]; OUT(CF_AN12 + 1) = A[2][0];
+  CS4(sl, 2) = make_float4(0.f, frcp(A[0][0] + cfm), 0.f, 0.f);       // (L0, 1 / Ann, L1, L2): the multipliers are still zero here
+  OUT(CF_AN12) = A[1][0]; OUT(CF_AN12 + 1) = A[2][0];
   const bool pyr = fric != LG_FRICTION_CONE;
   OUT(CF_B) = pyr ? frcp(a11) : a22 * idet; OUT(CF_B + 1) = pyr ? a12 : -a12 * idet; OUT(CF_B + 2) = pyr ? a12 : -a12 * idet; OUT(CF_B + 3) = pyr ? frcp(a22) : a11 * idet;
 #undef OUT
@@ -676,7 +686,7 @@ LG_DEV unsigned active_slot_list(const float* cst, int lane, int* count) {
   unsigned list = 0; int n = 0;
 #pragma unroll
   for (int sl = 0; sl < LG_MAX_CP; ++sl) {
-    const bool a = CS(sl, CF_ACTIVE) != 0.f;
+    const bool a = ((AMASK(sl) >> lane) & 1ull) != 0ull;
     list |= a ? (unsigned)sl << (4 * n) : 0u;
     n += a ? 1 : 0;
   }
@@ -689,7 +699,7 @@ LG_DEV unsigned active_slot_mask(const float* cst, int lane) {
   unsigned slot_mask = 0;
 #pragma unroll
   for (int sl = 0; sl < LG_MAX_CP; ++sl)
-    if (__ballot(CS(sl, CF_ACTIVE) != 0.f) != 0ull) slot_mask |= 1u << sl;
+    if (__builtin_amdgcn_readfirstlane(AMASK(sl) != 0ull ? 1 : 0)) slot_mask |= 1u << sl;
   return slot_mask;
 }
 
@@ -844,7 +854,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   {  // ballots by the whole wave, accumulation by the stamping lane
     unsigned long long am = 0, g4 = 0;
     for (int sl = 0; sl < LG_MAX_CP; ++sl) {
-      const unsigned long long b = __ballot(CS(sl, CF_ACTIVE) != 0.f);
+      const unsigned long long b = AMASK(sl);
       am += __popcll(b);
       for (int w = 0; w < 4; ++w) g4 += ((b >> (16 * w)) & 0xffffull) ? 1 : 0;
     }
@@ -1112,9 +1122,10 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
 #pragma unroll 1
     for (int sl = 0; sl < LG_MAX_CP; ++sl) {
       if (!((slot_mask >> sl) & 1u)) continue;
-      const bool on = CS(sl, CF_ACTIVE) != 0.f;       // selected, not branched on: a lane without this contact adds zero
-      const V3 t1 = v3(CS(sl, CF_T12), CS(sl, CF_T12 + 2), CS(sl, CF_T12 + 4)), t2 = v3(CS(sl, CF_T12 + 1), CS(sl, CF_T12 + 3), CS(sl, CF_T12 + 5));
-      V3 f = idt * (CS(sl, CF_L0) * lds3(cst, sl, CF_N, lane) + CS(sl, CF_L1) * t1 + CS(sl, CF_L2) * t2);
+      const bool on = ((AMASK(sl) >> lane) & 1ull) != 0ull;       // selected, not branched on: a lane without this contact adds zero
+      const float4 n4 = CS4(sl, 0), lam = CS4(sl, 2), ta = CS4(sl, CF_T12 / 4), tb = CS4(sl, CF_T12 / 4 + 1);   // T12 = t1.x t2.x t1.y t2.y | t1.z t2.z ..
+      const V3 t1 = v3(ta.x, ta.z, tb.x), t2 = v3(ta.y, ta.w, tb.y);
+      V3 f = idt * (lam.x * v3(n4.x, n4.y, n4.z) + lam.z * t1 + lam.w * t2);
       f = v3(on ? f.x : 0.f, on ? f.y : 0.f, on ? f.z : 0.f);
       int link = lm_.i(LM_CP_LINK + sl);
       int slotb = link < 0 ? 0 : (link > 3 ? 4 : link + 1);

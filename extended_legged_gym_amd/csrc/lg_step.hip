@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
-  __shared__ __attribute__((aligned(16))) float cst[LG_MAX_CP * CF_FIELDS * 64];
+  __shared__ __attribute__((aligned(16))) float cst[LG_CST_FLOATS];
   __shared__ float lmod[LM_FIELDS * 4];
   const float* __restrict__ wlstm = C->lstm_w;
   // state of the substep published by the main wave for the helpers: [lane][root 13 | q 3 | qd 3 | pad] = five 16-byte units per
