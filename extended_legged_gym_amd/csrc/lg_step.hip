@@ -251,7 +251,7 @@ LG_DEV float lstm_actuator1(const float* __restrict__ W, float x0, float x1, flo
 // in front of the rendezvous is the input part: 2 of 10 columns of layer 0 and 8 of 16 of layer 1, plus the gates.
 struct LstmPre { v4f a0[8], a1[8]; };
 #ifndef LG_LSTM_LDS
-#define LG_LSTM_LDS (LG_AB == 1)     // A/B build 1: the actuator waves read the LSTM weights from LDS instead of through scalar loads
+#define LG_LSTM_LDS (LG_AB == 7)     // A/B build 7: the actuator waves read the LSTM weights from LDS instead of through scalar loads
 #endif
 LG_DEV void lstm_recurrent_part(const float* __restrict__ W, const float* h0, const float* h1, LstmPre& pre) {
   const v4f* B0 = (const v4f*)(W + LW_B0); const v4f* H0 = (const v4f*)(W + LW_H0);
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ float cqc[TMESH ? LG_MAX_CP * 4 * 64 : 1];   // mesh terrains: last closest-point query of every collision sphere
   __shared__ int s_last_f;                                 // fused step: this workgroup is the last of the launch to arrive
   __shared__ float hot[HC_COUNT];                          // fused step: the scalars of the post-physics tail (HC_*)
-  // A/B build 1 only: an LDS copy of the 905 gate-interleaved LSTM weights for the actuator waves (one ds_read_b128 at a wave-uniform
+  // A/B build 7 only: an LDS copy of the 905 gate-interleaved LSTM weights for the actuator waves (one ds_read_b128 at a wave-uniform
   // address = four weights).  Measured against the scalar loads (s_load_dwordx16 -> SGPR pairs feeding the packed FMAs) in one session:
   // 0.0897 ms per step from LDS, 0.0818 ms through SGPRs -- the scalar unit fetches the weights beside the vector ALU, while LDS
   // reads take issue slots of the wave whose chain of gate evaluations is the critical path in front of rendezvous (A2).
