@@ -253,6 +253,15 @@ def main():
         elapsed = float(el.item())
     _, totals = gather_episode_stats(env.core.t["episode_stats"].clone(), dist)
     stats_all = totals.cpu().numpy()
+    # what each shard drew for itself (per-shard domain randomisation: disjoint Philox streams, shard-seeded host draws)
+    fr = env.core.t["friction_coeffs"].double()
+    mine = torch.stack([fr.mean(), fr[0], env.core.t["base_mass_added"].double().mean()])
+    if dist is not None:
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+    else:
+        every = [mine]
+    shards = [dict(rank=i, friction_mean=float(v[0]), friction_first=float(v[1]), payload_mean=float(v[2])) for i, v in enumerate(every)]
     finite = bool(torch.isfinite(env.obs_buf).all().item() and torch.isfinite(env.root_states).all().item())
 
     if rank == 0:
@@ -281,7 +290,7 @@ def main():
                          "whole_step_bytes_per_env_step": PHYSICS_BYTES["read"] + PHYSICS_BYTES["write"] + post_bytes, "launches_per_step": 1 if fused else 2},
             "episode_stats": {"sum_return": float(stats_all[0]), "sum_length": float(stats_all[1]),
                               "episodes": float(stats_all[2]), "env_steps": float(stats_all[3])},
-            "finite": finite,
+            "finite": finite, "shards": shards,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(env, pool)

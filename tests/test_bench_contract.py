@@ -51,3 +51,25 @@ def test_bench_under_torchrun_forms_a_one_rank_rccl_group():
     assert out["roofline"]["hip_event_samples"] >= 64            # the instrumented pass is separate from the 20 timed steps
     assert out["episode_stats"]["env_steps"] > 0                 # went through the all-gather of the 1-rank group
     assert out["value"] > 0 and abs(out["ms_per_step"] * 1e-3 * out["value"] - 1024) < 1.0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """The driver's scaling run, rehearsed at N = 2 through bench.py's own child-process launcher (`python bench.py --gpus 2`): one
+    process per GPU, RCCL group, per-shard randomisation, the episode-statistics all-gather.  Skipped on the one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "20", "--envs-per-gpu", "1024",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["finite"] is True
+    # every env-step of both shards arrived through the all-gather: reset() step + warm-up + timed + the instrumented pass, on 2 x 1024 envs
+    per_rank_steps = out["episode_stats"]["env_steps"] / (2 * 1024)
+    assert per_rank_steps == int(per_rank_steps) and per_rank_steps >= 70
+    assert abs(out["ms_per_step"] * 1e-3 * out["value"] - 2 * 1024) < 2.0
+    a, b = out["shards"]
+    assert a["rank"] == 0 and b["rank"] == 1 and a["friction_first"] != b["friction_first"] and a["friction_mean"] != b["friction_mean"]
