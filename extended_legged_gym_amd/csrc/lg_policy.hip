@@ -404,3 +404,80 @@ int lg_collect_rollout(lg_ctx* env, lg_mlp* actor, lg_mlp* critic, const float* 
 }
 
 }  // extern "C"
+
+
+// ============================================================================================ sampling planner arithmetic (lgpolicy.h)
+// plans[i, h, a] = sum_k phi[h, k] nodes[i, k, a]: one lane per output element, the K node rows of a sample are read coalesced along a
+__global__ __launch_bounds__(256) void plan_from_nodes_kernel(const float* __restrict__ nodes, const float* __restrict__ phi, int64_t n, int K, int H, int A,
+                                                              float* __restrict__ plans) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * H * A) return;
+  const int a = (int)(idx % A); const int64_t ih = idx / A; const int h = (int)(ih % H); const int64_t i = ih / H;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(phi[h * K + k], nodes[(i * K + k) * A + a], acc);
+  plans[idx] = acc;
+}
+
+// One wave per main env: its R samples' mean rewards, standardised, softmax at the given temperature, weighted mean of the node rows.
+// R, H, K * A are tens to hundreds: the whole problem of a main env is a few KB, read once.
+__global__ __launch_bounds__(64) void mppi_update_kernel(const float* __restrict__ rewards, const float* __restrict__ nodes, int R, int H, int KA, float temperature,
+                                                         float* __restrict__ new_nodes, float* __restrict__ weights) {
+  extern __shared__ float w_lds[];                 // R weights
+  const int m = blockIdx.x, lane = threadIdx.x;
+  const float* rw = rewards + (size_t)m * R * H;
+  auto wave_sum = [](float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; };
+  auto wave_max = [](float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; };
+  float s1 = 0.f;
+  for (int i = lane; i < R; i += 64) {
+    float r = 0.f;
+    for (int h = 0; h < H; ++h) r += rw[(size_t)i * H + h];
+    r /= (float)H;
+    w_lds[i] = r; s1 += r;
+  }
+  const float mean = wave_sum(s1) / (float)R;
+  float s2 = 0.f;
+  for (int i = lane; i < R; i += 64) { const float d = w_lds[i] - mean; s2 += d * d; }
+  const float sd = sqrtf(wave_sum(s2) / (float)R);
+  const float scale = sd > 1e-12f ? 1.f / (sd * temperature) : 0.f;
+  float mx = -3.0e38f;
+  for (int i = lane; i < R; i += 64) { const float z = (w_lds[i] - mean) * scale; w_lds[i] = z; mx = fmaxf(mx, z); }
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int i = lane; i < R; i += 64) { const float e = __expf(w_lds[i] - mx); w_lds[i] = e; se += e; }
+  const float inv = 1.f / wave_sum(se);
+  for (int i = lane; i < R; i += 64) { const float w = w_lds[i] * inv; w_lds[i] = w; weights[(size_t)m * R + i] = w; }
+  __syncthreads();
+  const float* nd = nodes + (size_t)m * R * KA;
+  for (int j = lane; j < KA; j += 64) {
+    float acc = 0.f;
+    for (int i = 0; i < R; ++i) acc = fmaf(w_lds[i], nd[(size_t)i * KA + j], acc);
+    new_nodes[(size_t)m * KA + j] = acc;
+  }
+}
+
+static int device_of(const void* p) {
+  hipPointerAttribute_t pa;
+  return hipPointerGetAttributes(&pa, p) == hipSuccess ? pa.device : -1;
+}
+
+int lg_plan_from_nodes(const float* nodes, const float* phi, int64_t n, int32_t K, int32_t H, int32_t A, float* plans, void* stream) {
+  if (!nodes || !phi || !plans || n <= 0 || K <= 0 || H <= 0 || A <= 0) return LG_ERR_INVALID;
+  const int dev = device_of(nodes);
+  if (dev < 0) return LG_ERR_INVALID;
+  DeviceScope ds_(dev);
+  const int64_t total = n * H * A;
+  hipLaunchKernelGGL(plan_from_nodes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nodes, phi, n, K, H, A, plans);
+  return hipGetLastError() == hipSuccess ? LG_OK : LG_ERR_HIP;
+}
+
+int lg_mppi_update(const float* rewards, const float* nodes, int32_t num_main, int32_t R, int32_t H, int32_t K, int32_t A, float temperature,
+                   float* new_nodes, float* weights, void* stream) {
+  if (!rewards || !nodes || !new_nodes || !weights || num_main <= 0 || R <= 0 || H <= 0 || K <= 0 || A <= 0 || !(temperature > 0.f)) return LG_ERR_INVALID;
+  if ((size_t)R * sizeof(float) > 60 * 1024) return LG_ERR_UNSUPPORTED;          // the weights of one main env live in LDS
+  const int dev = device_of(rewards);
+  if (dev < 0) return LG_ERR_INVALID;
+  DeviceScope ds_(dev);
+  hipLaunchKernelGGL(mppi_update_kernel, dim3((unsigned)num_main), dim3(64), (size_t)R * sizeof(float), (hipStream_t)stream, rewards, nodes, R, H, K * A, temperature,
+                     new_nodes, weights);
+  return hipGetLastError() == hipSuccess ? LG_OK : LG_ERR_HIP;
+}

@@ -1,0 +1,114 @@
+"""`NativeTrajSampler`: the optimiser the reference's planner envs drive through `rollout_batch`
+(`envs/batch_rollout/robot_traj_grad_sampling.py:210-280`).  In the reference it is the external package `traj_sampling`
+(imported at `:18`, absent from the tree); this restates the published algorithm that package implements -- DIAL-MPC (Xue et al.
+2024): a few annealed MPPI updates per control step over node trajectories, warm-started by shifting the last solution -- on the
+two native kernels of include/lgpolicy.h (`lg_plan_from_nodes`, `lg_mppi_update`) and the native `rollout_batch`.  Config names are
+the reference's `cfg.trajectory_opt` (`robot_traj_grad_sampling_config.py:44-71`).
+
+Per diffusion step i of a control step (num_diffuse_steps, or num_diffuse_steps_init after a reset):
+    sigma_k = noise_scaling * horizon_diffuse_factor ** (K - 1 - k) * traj_diffuse_factor ** i          (more noise far ahead, less each pass)
+    nodes[m, 0] = mean[m];  nodes[m, s] = mean[m] + sigma * N(0, 1), s = 1 .. R - 1                      (R = rollout_envs samples per main env)
+    plans = phi @ nodes  ->  rewards = env.rollout_batch(plans)  ->  mean[m] = sum_s softmax(z_s / temp_sample) nodes[m, s]
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from extended_legged_gym_amd import abi
+from extended_legged_gym_amd.rl.policy import _lib
+
+
+def interpolation_matrix(num_nodes, horizon, method="spline"):
+    """(H, K) weights of the node -> sample-time interpolation: nodes sit at K evenly spaced times over the horizon, the plan has one
+    action per sample time.  A spline is a linear operator on its node values, so column k is the interpolant of the k-th unit vector:
+    'linear' = piecewise linear, 'spline' = cubic (not-a-knot) through the nodes."""
+    tn = np.linspace(0.0, 1.0, num_nodes)
+    ts = np.linspace(0.0, 1.0, horizon)
+    phi = np.zeros((horizon, num_nodes))
+    for k in range(num_nodes):
+        e = np.zeros(num_nodes); e[k] = 1.0
+        if method == "linear" or num_nodes < 4:
+            phi[:, k] = np.interp(ts, tn, e)
+        elif method == "spline":
+            from scipy.interpolate import CubicSpline
+            phi[:, k] = CubicSpline(tn, e)(ts)
+        else:
+            raise ValueError(f"unknown interp_method {method!r} (linear | spline)")
+    return phi.astype(np.float32)
+
+
+class NativeTrajSampler:
+    def __init__(self, env, cfg, seed=0):
+        """env: a native `RobotBatchRollout` (rollout_envs samples per main env); cfg: `cfg.trajectory_opt`."""
+        if getattr(cfg, "update_method", "mppi") != "mppi":
+            raise NotImplementedError("update_method: only 'mppi' is built (wbfo / avwbfo live in the external traj_sampling package)")
+        self.env, self.cfg, self.lib = env, cfg, _lib()
+        self.device = torch.device(env.device)
+        self.M, self.R, self.A = env.num_envs, env.num_rollout_per_main, env.num_actions
+        if self.R < 2:
+            raise ValueError("trajectory optimisation needs at least 2 rollout envs per main env")
+        self.H, self.K = int(cfg.horizon_samples), int(cfg.horizon_nodes) + 1
+        self.phi = torch.from_numpy(interpolation_matrix(self.K, self.H, getattr(cfg, "interp_method", "spline"))).to(self.device).contiguous()
+        self.mean = torch.zeros(self.M, self.K, self.A, device=self.device)            # node trajectories of the main envs
+        self.gen = torch.Generator(device=self.device); self.gen.manual_seed(int(seed))
+        k = torch.arange(self.K, device=self.device, dtype=torch.float32)
+        self.sigma_nodes = float(getattr(cfg, "noise_scaling", 1.0)) * float(cfg.horizon_diffuse_factor) ** (self.K - 1 - k)
+        self.last_weights = None
+        self.last_rewards = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def plans_from_nodes(self, nodes):
+        """(n, K, A) -> (n, H, A)"""
+        nodes = nodes.contiguous()
+        n = nodes.shape[0]
+        plans = torch.empty(n, self.H, self.A, device=self.device)
+        rc = self.lib.lg_plan_from_nodes(C.c_void_p(nodes.data_ptr()), C.c_void_p(self.phi.data_ptr()), n, self.K, self.H, self.A,
+                                         C.c_void_p(plans.data_ptr()), self._stream())
+        if rc != abi.LG_OK:
+            raise RuntimeError(f"lg_plan_from_nodes failed ({rc})")
+        return plans
+
+    def mppi_update(self, rewards, nodes):
+        """rewards (M * R, H), nodes (M * R, K, A) -> (new mean (M, K, A), weights (M, R))"""
+        rewards, nodes = rewards.contiguous(), nodes.contiguous()
+        new = torch.empty(self.M, self.K, self.A, device=self.device)
+        w = torch.empty(self.M, self.R, device=self.device)
+        rc = self.lib.lg_mppi_update(C.c_void_p(rewards.data_ptr()), C.c_void_p(nodes.data_ptr()), self.M, self.R, self.H, self.K, self.A,
+                                     float(self.cfg.temp_sample), C.c_void_p(new.data_ptr()), C.c_void_p(w.data_ptr()), self._stream())
+        if rc != abi.LG_OK:
+            raise RuntimeError(f"lg_mppi_update failed ({rc})")
+        return new, w
+
+    def optimize(self, n_diffuse=None, initial=False):
+        """`optimize_all_trajectories` (`robot_traj_grad_sampling.py:226-247`): the annealed MPPI passes of one control step."""
+        n = int(n_diffuse if n_diffuse is not None else (self.cfg.num_diffuse_steps_init if initial else self.cfg.num_diffuse_steps))
+        for i in range(n):
+            sigma = self.sigma_nodes * float(self.cfg.traj_diffuse_factor) ** i
+            noise = torch.randn(self.M, self.R, self.K, self.A, device=self.device, generator=self.gen) * sigma.view(1, 1, -1, 1)
+            noise[:, 0] = 0.0                                             # sample 0 is the current mean itself
+            nodes = (self.mean.unsqueeze(1) + noise).view(self.M * self.R, self.K, self.A)
+            rewards = self.env.rollout_batch(self.plans_from_nodes(nodes))
+            self.mean, self.last_weights = self.mppi_update(rewards, nodes)
+            self.last_rewards = rewards
+        return self.mean
+
+    def action(self):
+        """First action of every main env's current plan."""
+        return self.plans_from_nodes(self.mean)[:, 0]
+
+    def shift(self):
+        """`shift_trajectory_batch` (`:200-209`): one control step has passed -- the plan advances by one sample time; re-sampled at
+        the node times (the last node repeats)."""
+        dense = self.plans_from_nodes(self.mean)                           # (M, H, A)
+        shifted = torch.cat([dense[:, 1:], dense[:, -1:]], dim=1)
+        idx = torch.linspace(0, self.H - 1, self.K, device=self.device).round().long()
+        self.mean = shifted[:, idx].contiguous()
+
+    def reset(self, env_ids=None):
+        if env_ids is None:
+            self.mean.zero_()
+        else:
+            self.mean[env_ids] = 0.0

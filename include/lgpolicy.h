@@ -72,6 +72,24 @@ typedef struct lg_rollout {
 int lg_collect_rollout(struct lg_ctx* env, lg_mlp* actor, lg_mlp* critic, const float* std, uint64_t seed, uint64_t first_call,
                        int32_t T, float gamma, float lam, int32_t normalize_advantage, const lg_rollout* out, void* stream);
 
+/* ---- the sampling planner's arithmetic around rollout_batch.
+ * The reference's planner envs (envs/batch_rollout/robot_traj_grad_sampling.py:210-280) hand `rollout_batch` as a callback to the
+ * optimiser of the external package `traj_sampling` (imported at :18, not in the reference tree, no pinned version): per diffusion step
+ * it perturbs the node trajectories, interpolates nodes -> dense plans, rolls the plans out, and re-weights the samples.  Restated here
+ * from the published algorithm that package implements (DIAL-MPC: Xue et al., "Full-Order Sampling-Based MPC for Torque-Level
+ * Locomotion Control via Diffusion-Style Annealing", 2024, with the MPPI update of its reference code; config names:
+ * robot_traj_grad_sampling_config.py:44-71 -- num_samples, temp_sample, horizon_samples, horizon_nodes, update_method "mppi"):
+ *
+ * lg_plan_from_nodes: plans[i, h, a] = sum_k phi[h, k] * nodes[i, k, a]     (n, K, A) -> (n, H, A); phi (H, K) holds the interpolation
+ *     weights of the node -> sample-time spline (a linear operator: the host builds it once, linear or cubic);
+ * lg_mppi_update: for main env m with sample rows i in [m R, (m + 1) R):
+ *     r_i = mean_h rewards[i, h];   z_i = (r_i - mean_i r) / std_i r   (population std; all-equal rewards: z = 0);
+ *     weights[i] = softmax_i(z_i / temperature);   new_nodes[m, k, a] = sum_i weights[i] nodes[i, k, a].
+ * All pointers are device pointers, row-major f32; asynchronous on `stream`. */
+int lg_plan_from_nodes(const float* nodes, const float* phi, int64_t n, int32_t K, int32_t H, int32_t A, float* plans, void* stream);
+int lg_mppi_update(const float* rewards, const float* nodes, int32_t num_main, int32_t R, int32_t H, int32_t K, int32_t A,
+                   float temperature, float* new_nodes, float* weights, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

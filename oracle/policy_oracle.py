@@ -53,3 +53,25 @@ def compute_returns(rewards, dones, values, last_values, gamma, lam, normalize=T
     if normalize:
         advs = (advs - advs.mean()) / (advs.std(ddof=1) + 1e-8)
     return ret, advs
+
+
+# ---------------------------------------------------------------------------------------------- sampling planner arithmetic (lgpolicy.h)
+def plan_from_nodes_oracle(nodes, phi):
+    """plans[i, h, a] = sum_k phi[h, k] nodes[i, k, a], float64 accumulation (include/lgpolicy.h: lg_plan_from_nodes)."""
+    return np.einsum("hk,nka->nha", np.asarray(phi, np.float64), np.asarray(nodes, np.float64)).astype(np.float32)
+
+
+def mppi_update_oracle(rewards, nodes, num_main, temperature):
+    """DIAL-MPC's MPPI update (Xue et al. 2024; the algorithm of the planner package the reference drives through rollout_batch,
+    robot_traj_grad_sampling.py:226-280), per main env over its R sample rows: standardised mean rewards (population std), softmax at
+    `temperature`, weighted mean of the node trajectories.  float64."""
+    rewards, nodes = np.asarray(rewards, np.float64), np.asarray(nodes, np.float64)
+    n, H = rewards.shape
+    R = n // num_main
+    r = rewards.mean(axis=1).reshape(num_main, R)
+    sd = r.std(axis=1, keepdims=True)
+    z = np.where(sd > 1e-12, (r - r.mean(axis=1, keepdims=True)) / np.maximum(sd, 1e-300) / temperature, 0.0)
+    z -= z.max(axis=1, keepdims=True)
+    w = np.exp(z); w /= w.sum(axis=1, keepdims=True)
+    new = np.einsum("mr,mrka->mka", w, nodes.reshape(num_main, R, *nodes.shape[1:]))
+    return new.astype(np.float32), w.astype(np.float32)

@@ -1,0 +1,99 @@
+"""The sampling planner's arithmetic around `rollout_batch` (include/lgpolicy.h: lg_plan_from_nodes, lg_mppi_update):
+numpy oracle known answers on the CPU, kernels vs oracle and the planner env end to end on the GPU."""
+import numpy as np
+import pytest
+
+from oracle.policy_oracle import mppi_update_oracle, plan_from_nodes_oracle
+
+
+def test_interpolation_matrix_is_an_interpolant():
+    from extended_legged_gym_amd.utils.traj_sampler import interpolation_matrix
+    for method in ("linear", "spline"):
+        phi = interpolation_matrix(5, 17, method)                 # nodes at sample times 0, 4, 8, 12, 16
+        assert phi.shape == (17, 5)
+        np.testing.assert_allclose(phi.sum(axis=1), 1.0, atol=1e-6)          # constants are reproduced
+        np.testing.assert_allclose(phi[::4], np.eye(5), atol=1e-6)           # the plan passes through the nodes
+        lin = np.linspace(0, 1, 5)
+        np.testing.assert_allclose(phi @ lin, np.linspace(0, 1, 17), atol=1e-6)   # ... and through straight lines
+
+
+def test_mppi_oracle_known_answers():
+    rng = np.random.default_rng(0)
+    M, R, H, K, A = 3, 16, 8, 5, 12
+    nodes = rng.normal(size=(M * R, K, A)).astype(np.float32)
+    # equal rewards: uniform weights, the new mean is the plain average
+    new, w = mppi_update_oracle(np.ones((M * R, H)), nodes, M, 0.05)
+    np.testing.assert_allclose(w, 1.0 / R, rtol=1e-6)
+    np.testing.assert_allclose(new, nodes.reshape(M, R, K, A).mean(axis=1), atol=1e-6)
+    # a cold temperature picks the best sample of each main env
+    rew = rng.normal(size=(M * R, H))
+    new, w = mppi_update_oracle(rew, nodes, M, 1e-4)
+    best = rew.mean(axis=1).reshape(M, R).argmax(axis=1)
+    for m in range(M):
+        assert w[m].argmax() == best[m] and w[m].max() > 0.999
+        np.testing.assert_allclose(new[m], nodes[m * R + best[m]], atol=1e-4)
+    # rewards are standardised per main env: an affine change of one env's rewards changes nothing
+    rew2 = rew.copy(); rew2[:R] = 7.0 * rew2[:R] - 3.0
+    np.testing.assert_allclose(mppi_update_oracle(rew2, nodes, M, 0.05)[1], mppi_update_oracle(rew, nodes, M, 0.05)[1], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 32, 16, 5, 12), (1, 128, 16, 5, 12), (3, 70, 7, 3, 5)])
+def test_sampler_kernels_match_the_oracle(shape):
+    import ctypes as C
+    import torch
+    from extended_legged_gym_amd.rl.policy import _lib
+    M, R, H, K, A = shape
+    lib = _lib()
+    g = torch.Generator().manual_seed(1)
+    nodes = torch.randn(M * R, K, A, generator=g).cuda()
+    phi = torch.rand(H, K, generator=g).cuda()
+    rew = torch.randn(M * R, H, generator=g).cuda()
+    plans = torch.empty(M * R, H, A, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.lg_plan_from_nodes(p(nodes), p(phi), M * R, K, H, A, p(plans), st) == 0
+    new = torch.empty(M, K, A, device="cuda"); w = torch.empty(M, R, device="cuda")
+    assert lib.lg_mppi_update(p(rew), p(nodes), M, R, H, K, A, 0.05, p(new), p(w), st) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(plans.cpu().numpy(), plan_from_nodes_oracle(nodes.cpu().numpy(), phi.cpu().numpy()), rtol=2e-5, atol=2e-6)
+    new_o, w_o = mppi_update_oracle(rew.cpu().numpy(), nodes.cpu().numpy(), M, 0.05)
+    np.testing.assert_allclose(w.cpu().numpy(), w_o, rtol=2e-3, atol=1e-7)          # exp of standardised rewards / 0.05: fp32 vs fp64
+    np.testing.assert_allclose(new.cpu().numpy(), new_o, rtol=2e-3, atol=2e-4)
+    assert abs(float(w.sum(dim=1).mean()) - 1.0) < 1e-5
+
+
+@pytest.mark.gpu
+def test_planner_env_improves_its_plan():
+    """`RobotTrajGradSampling` on the ANYmal-C plane: annealed MPPI over `lg_rollout_batch`.  The mean plan after ten passes earns more
+    than the plan it started from (all-zero nodes = stand still under a forward-velocity command), and stepping shifts the plan."""
+    import torch
+    from extended_legged_gym_amd.envs.anymal_c.batch_rollout.anymal_c_batch_rollout_config import AnymalCBatchRolloutCfg
+    from extended_legged_gym_amd.envs.batch_rollout.robot_traj_grad_sampling import RobotTrajGradSampling
+    from extended_legged_gym_amd.envs.batch_rollout.robot_traj_grad_sampling_config import RobotTrajGradSamplingCfg
+    from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
+    cfg = AnymalCBatchRolloutCfg()
+    cfg.trajectory_opt = RobotTrajGradSamplingCfg.trajectory_opt()
+    cfg.rl_warmstart = RobotTrajGradSamplingCfg.rl_warmstart()
+    cfg.env.num_envs, cfg.env.rollout_envs = 8, 64
+    cfg.noise.add_noise = False; cfg.domain_rand.push_robots = False; cfg.domain_rand.randomize_friction = False
+    cfg.seed = 3
+    env = RobotTrajGradSampling(cfg, parse_sim_params(get_args([]), {"sim": class_to_dict(cfg.sim)}), "native_hip", "cuda:0", True)
+    env.reset()
+    cmd = torch.zeros(8, 4, device=env.device); cmd[:, 0] = 0.5
+    for _ in range(15):
+        env.set_commands(cmd) if hasattr(env, "set_commands") else None
+        env.step(torch.zeros(8, 12, device=env.device))
+    s = env.traj_grad_sampler
+    assert (s.M, s.R, s.H, s.K) == (8, 64, 16, 5) and not s.mean.any()
+    env.set_commands(cmd)
+    zero_nodes = torch.zeros(8 * 64, 5, 12, device=env.device)
+    r0 = env.rollout_batch(s.plans_from_nodes(zero_nodes)).mean(dim=1).view(8, 64)[:, 0]
+    env.optimize_all_trajectories(initial=True)
+    assert s.last_weights.shape == (8, 64) and torch.allclose(s.last_weights.sum(dim=1), torch.ones(8, device=env.device), atol=1e-4)
+    nodes = s.mean.unsqueeze(1).expand(8, 64, 5, 12).reshape(8 * 64, 5, 12)
+    r1 = env.rollout_batch(s.plans_from_nodes(nodes)).mean(dim=1).view(8, 64)[:, 0]
+    assert float(r1.mean()) > float(r0.mean()), (r0.tolist(), r1.tolist())
+    first = env.planned_actions().clone()
+    env.step(first)
+    assert env.traj_grad_sampler.mean.shape == (8, 5, 12) and torch.isfinite(env.obs_buf).all()
