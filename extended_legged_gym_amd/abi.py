@@ -110,6 +110,15 @@ class lg_config(C.Structure):
     ]
 
 
+class lg_tile_spec(C.Structure):
+    _fields_ = [("kind", i32), ("max_height", i32), ("clip_lo", i32), ("clip_hi", i32), ("step_width", i32), ("step_height", i32),
+                ("num_steps", i32), ("noise_lo", i32), ("noise_step", i32), ("noise_levels", i32), ("noise_coarse", i32),
+                ("rect_min", i32), ("rect_max", i32), ("rect_count", i32), ("platform", i32), ("seed", C.c_uint32)]
+
+
+LG_TILE_FLAT, LG_TILE_PYRAMID_SLOPE, LG_TILE_PYRAMID_STAIRS, LG_TILE_DISCRETE_OBSTACLES = 0, 1, 2, 3
+
+
 class lg_depth_params(C.Structure):
     _fields_ = [("width", i32), ("height", i32), ("resized_width", i32), ("resized_height", i32), ("buffer_len", i32),
                 ("near_clip", f32), ("far_clip", f32), ("position", f32 * 3), ("quat_offset", f32 * 4)]
@@ -156,6 +165,10 @@ def declare_product(lib):
     lib.lg_set_state_indexed.restype = C.c_int
     lib.lg_set_extra_obs.argtypes = [vp, vp]
     lib.lg_set_extra_obs.restype = C.c_int
+    lib.lg_terrain_generate.argtypes = [C.POINTER(lg_tile_spec), i32, i32, i32, i32, i32, f32, f32, f32, f32, vp, vp, vp]
+    lib.lg_terrain_generate.restype = C.c_int
+    lib.lg_heightfield_to_trimesh.argtypes = [vp, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]
+    lib.lg_heightfield_to_trimesh.restype = C.c_int
     lib.lg_mesh_create.argtypes = [C.POINTER(f32), C.c_int64, C.POINTER(i32), C.c_int64, C.c_int]
     lib.lg_mesh_create.restype = vp
     lib.lg_mesh_destroy.argtypes = [vp]
@@ -225,4 +238,4 @@ PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
                    "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_last_error",
                    "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update",
-                   "lg_set_reward_terms", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed"]
+                   "lg_terrain_generate", "lg_heightfield_to_trimesh", "lg_set_reward_terms", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed"]

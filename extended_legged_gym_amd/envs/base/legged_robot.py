@@ -90,7 +90,7 @@ class LeggedRobot(BaseTask):
             if self.cfg.terrain.use_terrain_obj:
                 self.terrain = TerrainObj(self.cfg.terrain)
             else:
-                self.terrain = Terrain(self.cfg.terrain, self.num_envs)
+                self.terrain = Terrain(self.cfg.terrain, self.num_envs, device=self.device)
         elif mesh_type == 'confined_trimesh':
             self.terrain = TerrainConfined(self.cfg.terrain, self.num_envs)
         elif mesh_type == 'plane':

@@ -27,8 +27,18 @@ def pit_terrain(terrain, depth, platform_size=1.):
 
 
 class Terrain:
-    def __init__(self, cfg, num_robots) -> None:
+    def __init__(self, cfg, num_robots, device=None) -> None:
+        """`device` (e.g. "cuda:0", passed by the env): build on the GPU -- `cfg.device_generation` = "mesh" (default): tiles by the host
+        generators (numpy's stream, the reference's grids bit for bit), the heightfield -> triangle-mesh conversion as a kernel
+        (bit-exact); "all": the five curriculum tile types as a kernel too (Philox draws instead of numpy's: same distributions,
+        other samples); "off" or `device=None` (tools, CPU tests): host numpy throughout."""
         self.cfg = cfg
+        self._device = device
+        self._mode = getattr(cfg, "device_generation", "mesh") if device is not None else "off"
+        if self._mode not in ("off", "mesh", "all"):
+            raise ValueError(f"terrain.device_generation must be 'off', 'mesh' or 'all', got {self._mode!r}")
+        self._mesh_dev = None
+        self._mesh_host = None
         self.num_robots = num_robots
         self.type = cfg.mesh_type
         if self.type in ["none", "plane"]:
@@ -47,7 +57,9 @@ class Terrain:
         self.height_field_raw = np.zeros((self.tot_rows, self.tot_cols), dtype=np.int16)
 
         scale = getattr(cfg, "difficulty_scale", 1.0)
-        if cfg.curriculum:
+        if self._mode == "all" and not cfg.selected:
+            self._generate_on_device(scale)
+        elif cfg.curriculum:
             self.curiculum(scale)
         elif cfg.selected:
             self.selected_terrain()
@@ -56,8 +68,64 @@ class Terrain:
 
         self.heightsamples = self.height_field_raw
         if self.type == "trimesh":
-            self.vertices, self.triangles = terrain_utils.convert_heightfield_to_trimesh(
-                self.height_field_raw, cfg.horizontal_scale, cfg.vertical_scale, cfg.slope_treshold)
+            if self._mode == "off":
+                self._mesh_host = terrain_utils.convert_heightfield_to_trimesh(
+                    self.height_field_raw, cfg.horizontal_scale, cfg.vertical_scale, cfg.slope_treshold)
+            else:
+                from . import terrain_device
+                self._mesh_dev = terrain_device.heightfield_to_trimesh(self.height_field_raw, cfg.horizontal_scale, cfg.vertical_scale,
+                                                                       cfg.slope_treshold, device)
+
+    # the triangle mesh: device tensors when built on the GPU (`mesh_device`), host arrays on demand (the BVH builder and the
+    # reference's attribute names `vertices` / `triangles` want numpy)
+    @property
+    def mesh_device(self):
+        return self._mesh_dev
+
+    def _host_mesh(self):
+        if self._mesh_host is None:
+            if self._mesh_dev is None:
+                raise AttributeError("this terrain has no triangle mesh (mesh_type is not 'trimesh')")
+            v, t = self._mesh_dev
+            self._mesh_host = (v.cpu().numpy(), t.cpu().numpy().view(np.uint32))
+        return self._mesh_host
+
+    @property
+    def vertices(self):
+        return self._host_mesh()[0]
+
+    @vertices.setter
+    def vertices(self, v):
+        self._mesh_host = (v, self._mesh_host[1] if self._mesh_host is not None else None)
+        self._mesh_dev = None
+
+    @property
+    def triangles(self):
+        return self._host_mesh()[1]
+
+    @triangles.setter
+    def triangles(self, t):
+        self._mesh_host = (self._mesh_host[0] if self._mesh_host is not None else None, t)
+        self._mesh_dev = None
+
+    def _generate_on_device(self, difficulty_scale=1.0):
+        """The curriculum / random layouts (`terrain.py:82-101`) with the tiles written by `lg_terrain_generate`."""
+        from . import terrain_device
+        cfg = self.cfg
+        tiles = [[None] * cfg.num_cols for _ in range(cfg.num_rows)]
+        seed0 = int(np.random.randint(0, 2 ** 31 - 1))        # one draw from the seeded host stream keys every tile
+        for j in range(cfg.num_cols):
+            for i in range(cfg.num_rows):
+                if cfg.curriculum:
+                    difficulty, choice = i / cfg.num_rows * difficulty_scale, j / cfg.num_cols + 0.001
+                else:
+                    choice = np.random.uniform(0, 1)
+                    difficulty = np.random.choice([0.5, 0.75, 0.9]) * difficulty_scale
+                tiles[i][j] = terrain_device.tile_spec_for(choice, difficulty, self.proportions, self.width_per_env_pixels,
+                                                           cfg.horizontal_scale, cfg.vertical_scale, seed0 + 7919 * (i * cfg.num_cols + j))
+        H, org = terrain_device.generate(cfg, tiles, self._device)
+        self.height_field_raw = H.cpu().numpy()
+        self.env_origins = org.cpu().numpy().astype(np.float64)
 
     # ---- layouts
     def randomized_terrain(self, difficulty_scale=1.0):

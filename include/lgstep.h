@@ -264,6 +264,33 @@ typedef struct lg_config {
 
 typedef struct lg_ctx lg_ctx;
 
+/* ---- terrain construction on the device (reference utils/terrain.py:39-173 + isaacgym.terrain_utils, numpy on the host).
+ * lg_terrain_generate fills the (tot_rows, tot_cols) int16 height grid tile by tile -- the curriculum / random layouts of Terrain
+ * (`terrain.py:82-173`) hand it one lg_tile_spec per (row, col) -- and the (num_rows, num_cols, 3) tile origins
+ * [(row + 0.5) length, (col + 0.5) width, max height of the central 2 m x 2 m window] (`:156-173`).  The deterministic generators
+ * (pyramid slope, pyramid stairs, flat) produce the host generators' integers exactly; the random ones (uniform noise, discrete
+ * obstacles) draw from Philox4x32-10 keyed by the tile seed instead of numpy's global stream: same distributions, other samples.
+ * lg_heightfield_to_trimesh is convert_heightfield_to_trimesh (`terrain.py:77-80`) -- regular triangulation, cell (i, j) ->
+ * (v0, v3, v1), (v0, v2, v3), vertices next to a step steeper than slope_threshold moved by one cell -- bit for bit.
+ * Device pointers; asynchronous on `stream`. */
+enum lg_tile_kind { LG_TILE_FLAT = 0, LG_TILE_PYRAMID_SLOPE = 1, LG_TILE_PYRAMID_STAIRS = 2, LG_TILE_DISCRETE_OBSTACLES = 3 };
+typedef struct lg_tile_spec {
+  int32_t kind;               /* enum lg_tile_kind */
+  int32_t max_height;         /* PYRAMID_SLOPE: int(slope * hs / vs * width / 2) (may be negative); OBSTACLES: int(max_height / vs) */
+  int32_t clip_lo, clip_hi;   /* PYRAMID_SLOPE: the platform clip np.clip(h, min(edge, 0), max(edge, 0)) */
+  int32_t step_width, step_height, num_steps;   /* PYRAMID_STAIRS: pixels, height units, number of nested squares */
+  int32_t noise_lo, noise_step, noise_levels;   /* uniform noise added on top (0 levels = none): level k = noise_lo + k * noise_step */
+  int32_t noise_coarse;       /* pixels of the fine grid per coarse noise sample */
+  int32_t rect_min, rect_max, rect_count, platform;   /* OBSTACLES: sizes in pixels (step 4 as the host generator), flat platform in the middle */
+  uint32_t seed;
+} lg_tile_spec;
+int lg_terrain_generate(const lg_tile_spec* tiles_host, int32_t num_rows, int32_t num_cols, int32_t tile_len_px, int32_t tile_wid_px,
+                        int32_t border_px, float horizontal_scale, float vertical_scale, float env_length, float env_width,
+                        int16_t* heights, float* origins, void* stream);
+int lg_heightfield_to_trimesh(const int16_t* heights, int32_t rows, int32_t cols, double step_x, double step_y, double stop_x, double stop_y,
+                              double horizontal_scale, double vertical_scale, double slope_threshold_units /* < 0: none */,
+                              float* vertices, uint32_t* triangles, void* stream);
+
 /* sizes of the ABI structs as compiled into the library, for binding-side sanity checks */
 void lg_abi_sizes(int32_t out[4]); /* {LG_ABI_VERSION, sizeof(lg_config), sizeof(lg_robot_model), sizeof(lg_terrain)} */
 

@@ -81,12 +81,13 @@ def test_planner_env_improves_its_plan():
     env = RobotTrajGradSampling(cfg, parse_sim_params(get_args([]), {"sim": class_to_dict(cfg.sim)}), "native_hip", "cuda:0", True)
     env.reset()
     cmd = torch.zeros(8, 4, device=env.device); cmd[:, 0] = 0.5
+    mains = env.main_env_indices
     for _ in range(15):
-        env.set_commands(cmd) if hasattr(env, "set_commands") else None
+        env.set_commands(mains, cmd)
         env.step(torch.zeros(8, 12, device=env.device))
     s = env.traj_grad_sampler
     assert (s.M, s.R, s.H, s.K) == (8, 64, 16, 5) and not s.mean.any()
-    env.set_commands(cmd)
+    env.set_commands(mains, cmd)
     zero_nodes = torch.zeros(8 * 64, 5, 12, device=env.device)
     r0 = env.rollout_batch(s.plans_from_nodes(zero_nodes)).mean(dim=1).view(8, 64)[:, 0]
     env.optimize_all_trajectories(initial=True)
