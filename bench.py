@@ -36,7 +36,7 @@ POST_BYTES = dict(
 )
 
 
-def build_env(rank, world, num_envs, pd_control=False):
+def build_env(rank, world, num_envs, pd_control=False, solver=None):
     from extended_legged_gym_amd.envs import Anymal, AnymalCRoughCfg
     from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params, set_seed
     from extended_legged_gym_amd.utils.sharding import shard_env_cfg
@@ -46,6 +46,8 @@ def build_env(rank, world, num_envs, pd_control=False):
     shard_env_cfg(cfg, rank, world, num_envs)      # global terrain-column indexing + private Philox stream per shard
     if pd_control:                                 # diagnostic only (not the headline workload): PD law instead of the LSTM
         cfg.control.use_actuator_network = False
+    if solver == "pgs":                            # diagnostic only: round 2's solver (the headline runs sim.physx.solver_type = 1, TGS)
+        cfg.sim.physx.solver_type, cfg.sim.physx.friction_model = 0, "cone"
     args = get_args([])
     args.sim_device = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
     import contextlib
@@ -183,6 +185,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pd-control", action="store_true", help="diagnostic: PD actuators instead of the LSTM net")
+    ap.add_argument("--solver", choices=["tgs", "pgs"], default="tgs", help="diagnostic: pgs = round 2's solver instead of the configured TGS")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -213,7 +216,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
-    env, cfg = build_env(rank, world, a.envs_per_gpu, a.pd_control)
+    env, cfg = build_env(rank, world, a.envs_per_gpu, a.pd_control, a.solver)
     N = env.num_envs
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     pool = [torch.randn(N, 12, generator=gen).to(dev) for _ in range(64)]   # resident in HBM before timing starts
@@ -278,7 +281,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ANYmal-C rough heightfield terrain (8x8 tiles, 900x900 int16 grid, seed 1), "
                                    f"{N} envs/GPU, LSTM actuator net, 235-dim obs, noise+pushes+curriculum on, "
-                                   "actions N(0,1), one step = 4 physics substeps + post-physics",
+                                   "actions N(0,1), one step = 4 physics substeps (TGS contact solver, 4 sub-intervals each: sim.physx.solver_type = 1) + post-physics",
                        "num_envs_per_gpu": N, "decimation": 4, "sim_dt": 0.005, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "limited_by": "instruction issue / dependent latency of one heavy wave per SIMD (see valu_busy_frac), not bytes",
                          "kernel": "physics_kernel<0> (4 substeps + fused post-physics tail)" if fused else "physics_kernel<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
