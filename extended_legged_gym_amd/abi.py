@@ -31,7 +31,7 @@ REWARD_TERMS = [
     # class-specific variants: selected through an env class's `reward_term_variants`, never named in a config
     "orientation_load_adapt",
     # StandAnymal / StandGo2 only (anymal.py:301-308); the other overrides of those classes come with lg_config.reward_class
-    "penalty_in_the_air"]
+    "penalty_in_the_air", "async_gait_scheduler"]
 REWARD_CLASSES = {"base": 0, "stand": 1}                   # enum lg_reward_class
 REWARD_TERM_ID = {n: i for i, n in enumerate(REWARD_TERMS)}
 
@@ -106,7 +106,9 @@ class lg_config(C.Structure):
         ("gait_enabled", i32), ("gait_period", f32), ("gait_swing_height", f32), ("gait_foot_phases", f32 * 4),
         ("solver_iterations", i32), ("contact_offset", f32), ("max_depenetration_velocity", f32), ("erp", f32),
         ("cfm", f32), ("solver_type", i32), ("friction_model", i32), ("self_collisions", i32),
-        ("seed", C.c_uint64), ("rng_mode", i32), ("inject_sim_state", i32),
+        ("seed", C.c_uint64), ("rng_mode", i32),
+        ("async_num_dof_sets", i32), ("async_dof_sets", (i32 * 3) * 4), ("async_dof_nominal", f32 * 12), ("async_dof_weight", f32 * 12),
+        ("async_weights", f32 * 3), ("async_foot_z_align", f32), ("inject_sim_state", i32),
     ]
 
 
@@ -143,6 +145,8 @@ def declare_product(lib):
     lib.lg_step_subset.restype = C.c_int
     lib.lg_set_reward_terms.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(f32), vp]
     lib.lg_set_reward_terms.restype = C.c_int
+    lib.lg_set_async_gait.argtypes = [vp, C.POINTER(f32), f32, vp]
+    lib.lg_set_async_gait.restype = C.c_int
     lib.lg_step_subset_physics.argtypes = [vp, vp, vp, i32, vp]
     lib.lg_step_subset_physics.restype = C.c_int
     lib.lg_post_physics_subset.argtypes = [vp, vp, i32, i32, vp]
@@ -238,4 +242,4 @@ PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
                    "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_last_error",
                    "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update",
-                   "lg_terrain_generate", "lg_heightfield_to_trimesh", "lg_set_reward_terms", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed"]
+                   "lg_terrain_generate", "lg_heightfield_to_trimesh", "lg_set_reward_terms", "lg_set_async_gait", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed"]

@@ -359,6 +359,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
   const int K_ = HI(HC_K), kfat = HI(HC_KFAT);
   float* RAW0 = M + FM_RAW; float* RAW1 = RAW0 + LG_REW_COUNT;
   fused_reward_all(C, hot, term_mask, R, feat, step, RAW0, RAW1);
+  if ((term_mask >> LG_REW_ASYNC_GAIT_SCHEDULER) & 1u) RAW0[LG_REW_ASYNC_GAIT_SCHEDULER] = RAW1[LG_REW_ASYNC_GAIT_SCHEDULER] = async_gait_value(C->cfg, S + FS_DOF);
 #pragma unroll 4
   for (int k = 0; k < K_; ++k) {                 // the reference's sum, in config order (LR:218-224)
     const int id = HI(HC_IDS + k);

@@ -1069,6 +1069,23 @@ LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int
 // `feat` = the eight per-DOF sums (F_* below), `fn` = contact-force norm of every body, `bh` = sum over the height points
 // of (base z - height): computed lane-parallel by the post kernel before the terms are evaluated in config order.
 enum { F_TQ2 = 0, F_QD2, F_ACC2, F_ARATE2, F_POSLIM, F_VELLIM, F_TQLIM, F_STILL, F_COUNT };
+// AsyncGaitScheduler's three terms with the stage's weights (lg_config.async_*; anymal_c_batch_rollout.py:207-220 over
+// utils/gait_scheduler.py:151-175).  dof: (12, 2) rows [pos, vel].  A rare term: its parameters are read from the config in global memory.
+LG_DEV float async_gait_value(const lg_config& g, const float* dof) {
+  float align = 0.f;
+  for (int k = 0; k < g.async_num_dof_sets; ++k) {
+    int n = 0; float mean = 0.f;
+    for (int i = 0; i < 3; ++i) { const int d = g.async_dof_sets[k][i]; if (d >= 0) { mean += dof[2 * d]; ++n; } }
+    if (n < 2) continue;
+    mean /= (float)n;
+    float ss = 0.f;
+    for (int i = 0; i < 3; ++i) { const int d = g.async_dof_sets[k][i]; if (d >= 0) { const float x = dof[2 * d] - mean; ss += x * x; } }
+    align += sqrtf(ss / (float)(n - 1));
+  }
+  float nominal = 0.f;
+  for (int d = 0; d < LG_NUM_DOF; ++d) { const float x = dof[2 * d] - g.async_dof_nominal[d]; nominal += x * x * g.async_dof_weight[d]; }
+  return align * g.async_weights[0] + nominal * g.async_weights[1] + g.async_foot_z_align * g.async_weights[2];
+}
 LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, int id, const float* feat, const float* fn, float bh,
                          int64_t step) {
   const lg_config& g = C->cfg; const lg_robot_model& m = C->model; const float dt = g.sim_dt * g.decimation;
@@ -1156,6 +1173,7 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     case LG_REW_FOUR_FOOTUP: { bool all = true; for (int f = 0; f < 4; ++f) all &= cf[3 * m.feet_indices[f] + 2] < 1.f; return 0.1f * (all ? 1.f : 0.f); }
     case LG_REW_TERMINATION: return (C->reset_buf[e] && !C->time_out[e]) ? 1.f : 0.f;
     case LG_REW_STAND_STILL: return feat[F_STILL] * (cmdn < 0.1f ? 1.f : 0.f);
+    case LG_REW_ASYNC_GAIT_SCHEDULER: return async_gait_value(g, V.dof);
     case LG_REW_TRACKING_LIN_VEL:       // stand: commands against -base_lin_vel[1:] (anymal.py:277-281)
       return expf(-(stand ? SQ(cmd[0] + blv[1]) + SQ(cmd[1] + blv[2]) : SQ(cmd[0] - blv[0]) + SQ(cmd[1] - blv[1])) / g.tracking_sigma);
     case LG_REW_TRACKING_ANG_VEL: return expf(-SQ(cmd[2] - (stand ? bav[0] : bav[2])) / g.tracking_sigma);   // anymal.py:283-286
@@ -2281,6 +2299,17 @@ int lg_set_reward_terms(lg_ctx* c, int32_t num_terms, const int32_t* term_ids, c
   hot_config(c->h);
   HIP_TRY(c, hipMemcpyAsync((char*)c->d + ((char*)&c->h.rew_term_mask - base), &c->h.rew_term_mask, 4 * sizeof(int) + sizeof(c->h.hot), hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipMemsetAsync(c->h.ep_sums, 0, (size_t)LG_MAX_REWARD_TERMS * c->h.N * sizeof(float), st));
+  return LG_OK;
+}
+
+int lg_set_async_gait(lg_ctx* c, const float weights[3], float foot_z_align, void* stream) {
+  if (!c || !weights) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
+  lg_config& g = c->h.cfg;
+  for (int i = 0; i < 3; ++i) g.async_weights[i] = weights[i];
+  g.async_foot_z_align = foot_z_align;
+  char* base = (char*)&c->h; char* lo = (char*)&g.async_weights[0]; char* hi = (char*)(&g.async_foot_z_align + 1);
+  HIP_TRY(c, hipMemcpyAsync((char*)c->d + (lo - base), lo, (size_t)(hi - lo), hipMemcpyHostToDevice, (hipStream_t)stream));
   return LG_OK;
 }
 

@@ -31,6 +31,8 @@ task_registry.register("anymal_c_batch_rollout_flat", AnymalCBatchRollout, Anyma
 from .go2.batch_rollout.go2_batch_rollout import Go2BatchRollout  # noqa: E402
 from .go2.batch_rollout.go2_batch_rollout_config import (Go2BatchRolloutCfg, Go2BatchRolloutCfgPPO,  # noqa: E402
                                                          Go2BatchRolloutFlatCfg, Go2BatchRolloutFlatCfgPPO)
+from .anymal_c.batch_rollout.anymal_c_dialmpc_flat_config import AnymalCDialMPCFlatCfg, AnymalCDialMPCFlatCfgPPO  # noqa: E402
+task_registry.register("anymal_c_dialmpc_flat", AnymalCBatchRollout, AnymalCDialMPCFlatCfg(), AnymalCDialMPCFlatCfgPPO())
 task_registry.register("anymal_b", Anymal, AnymalBRoughCfg(), AnymalBRoughCfgPPO())
 task_registry.register("anymal_c_rough_teacher", Anymal, AnymalCRoughTeacherCfg(), AnymalCRoughTeacherCfgPPO())
 task_registry.register("go2_batch_rollout", Go2BatchRollout, Go2BatchRolloutCfg(), Go2BatchRolloutCfgPPO())

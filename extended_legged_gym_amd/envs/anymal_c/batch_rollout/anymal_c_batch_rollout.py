@@ -8,12 +8,19 @@ On top of `RobotBatchRolloutPercept`:
   picks the actuator from the config either way;
 * `_reward_orientation` (`:201-203`) is the base-class term.
 
-Not carried over: the time-driven `GaitScheduler` / `AsyncGaitScheduler` reward shaping (`:66-98, 207-225`; scales
-`gait_scheduler`, `async_gait_scheduler`, zero in the shipped task configs).  A config that turns them on is rejected
-instead of silently training on a different reward."""
-from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout_percept import RobotBatchRolloutPercept
+* `_reward_async_gait_scheduler` (`:207-220`): `AsyncGaitScheduler`'s joint-alignment / nominal-pose / foot-height-alignment terms with the
+  reward stage's weights are native term `LG_REW_ASYNC_GAIT_SCHEDULER` (`lg_config.async_*`).  Two things carried over as they are: the
+  scheduler object keeps the `foot_positions` tensor it was built with (the env re-binds that attribute every step), so its foot term is a
+  constant of the spawn pose; and the shipped quadruped configs inherit an 18-entry `dof_nominal_pos_weight`, with which the reference
+  raises on the first step of a task that scales the term (`anymal_c_dialmpc_flat`): `NativeSetup` raises the same error.
 
-_UNSUPPORTED = ("gait_scheduler", "async_gait_scheduler")
+Not carried over: the time-driven `GaitScheduler` foot-height tracking (`:66-98, 222-225`; scale `gait_scheduler`, zero in the shipped task
+configs).  A config that turns it on is rejected instead of silently training on a different reward."""
+from extended_legged_gym_amd.envs.base.native_config import async_gait_weights
+from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout_percept import RobotBatchRolloutPercept
+from extended_legged_gym_amd.utils.gait_scheduler import foot_z_align
+
+_UNSUPPORTED = ("gait_scheduler",)
 
 
 class AnymalCBatchRollout(RobotBatchRolloutPercept):
@@ -24,6 +31,22 @@ class AnymalCBatchRollout(RobotBatchRolloutPercept):
         for name in _UNSUPPORTED:
             v = getattr(scales, name, 0.0)
             if any(float(x) != 0.0 for x in (v if isinstance(v, (list, tuple)) else [v])):
-                raise NotImplementedError(f"rewards.scales.{name}: the time-driven gait-scheduler terms of AnymalCBatchRollout "
-                                          "are not part of the native step")
+                raise NotImplementedError(f"rewards.scales.{name}: the time-driven gait-scheduler term of AnymalCBatchRollout "
+                                          "is not part of the native step")
         super().__init__(cfg, sim_params, physics_engine, sim_device, headless)
+        self._async_foot_z_align = 0.0
+        if self.setup.cfg.async_num_dof_sets > 0:
+            # AsyncGaitScheduler.reward_foot_z_align on the feet positions of the freshly built env (what the scheduler object keeps)
+            # (every env is built in the same pose, so one value serves all of them)
+            feet = self.rigid_body_state.view(self.total_num_envs, self.num_bodies, 13)[:1, self.feet_indices, 0:3]
+            self._async_foot_z_align = float(foot_z_align(feet, self.cfg.async_gait_scheduler.foot_z_align_sets_idx)[0])
+            self._set_async_gait()
+
+    def _set_async_gait(self):
+        self.core.set_async_gait(async_gait_weights(self.cfg, self.reward_scales_stage), self._async_foot_z_align)
+
+    def update_reward_scales(self, mean_reward):
+        changed = super().update_reward_scales(mean_reward)
+        if changed and self.setup.cfg.async_num_dof_sets > 0:
+            self._set_async_gait()
+        return changed

@@ -100,6 +100,44 @@ def reward_setup(cfg, dt, stage=None):
     return names, vals
 
 
+def async_gait_weights(cfg, stage):
+    """`get_weight(key, reward_scales_stage)` of `_reward_async_gait_scheduler` (`anymal_c_batch_rollout.py:210-220`)."""
+    sc = class_to_dict(cfg.rewards.async_gait_scheduler)
+
+    def w(key):
+        v = sc[key]
+        return float(v[min(stage, len(v) - 1)]) if isinstance(v, list) else float(v)
+    return [w("dof_align"), w("dof_nominal_pos"), w("reward_foot_z_align")]
+
+
+def fill_async_gait(c, cfg, stage):
+    """`lg_config.async_*` from `cfg.async_gait_scheduler` (`utils/gait_scheduler.py:97-121`) and the stage's weights.  The index sets
+    are used as the reference uses them: positions in the section's own `dof_names` list applied to the simulator's DOF order."""
+    ag = getattr(cfg, "async_gait_scheduler", None)
+    if ag is None or not hasattr(ag, "dof_align_sets_idx"):
+        raise AttributeError("rewards.scales.async_gait_scheduler is set but the config has no async_gait_scheduler section")
+    nd = abi.LG_NUM_DOF
+    if len(ag.dof_names) != nd or len(ag.dof_nominal_pos) != nd:
+        raise ValueError(f"async_gait_scheduler: {len(ag.dof_names)} joints in a {nd}-DOF robot")
+    if len(ag.dof_nominal_pos_weight) != nd:
+        # the quadruped configs inherit AsyncGaitSchedulerCfg's 18-entry (hexapod) weight vector: `reward_dof_nominal_pos`
+        # (`utils/gait_scheduler.py:158-166`) multiplies a (N, 12) error by it and raises on the first step of any task that scales the term
+        raise RuntimeError(f"The size of tensor a ({nd}) must match the size of tensor b ({len(ag.dof_nominal_pos_weight)}) at non-singleton "
+                           "dimension 1 [AsyncGaitScheduler.reward_dof_nominal_pos: async_gait_scheduler.dof_nominal_pos_weight must have one "
+                           "entry per joint; the reference raises this on the first step of the task]")
+    sets = ag.dof_align_sets_idx
+    if len(sets) > 4 or any(len(x) > 3 for x in sets) or len(ag.foot_z_align_sets_idx) > 2:
+        raise ValueError("async_gait_scheduler: at most 4 joint sets of 3 and 2 foot sets")
+    c.async_num_dof_sets = len(sets)
+    for k in range(4):
+        for i in range(3):
+            c.async_dof_sets[k][i] = int(sets[k][i]) if k < len(sets) and i < len(sets[k]) else -1
+    _fill(c.async_dof_nominal, [float(x) for x in ag.dof_nominal_pos])
+    _fill(c.async_dof_weight, [float(x) for x in ag.dof_nominal_pos_weight])
+    _fill(c.async_weights, async_gait_weights(cfg, stage))
+    c.async_foot_z_align = 0.0          # set by the env once the spawn pose exists (lg_set_async_gait)
+
+
 def noise_scale_vec(cfg, num_obs):
     v = np.zeros(num_obs, dtype=np.float32)
     ns, lvl, os_ = cfg.noise.noise_scales, cfg.noise.noise_level, cfg.normalization.obs_scales
@@ -205,6 +243,10 @@ class NativeSetup:
         # rewards
         self.reward_names, self.reward_scales = reward_setup(cfg, dt, reward_stage)
         c.num_reward_terms = len(self.reward_names)
+        if "async_gait_scheduler" in self.reward_names or any(
+                any(float(x) != 0.0 for x in (v if isinstance(v, (list, tuple)) else [v]))
+                for k, v in class_to_dict(cfg.rewards.scales).items() if k == "async_gait_scheduler"):
+            fill_async_gait(c, cfg, cfg.rewards.reward_min_stage if (reward_stage is None and cfg.rewards.multi_stage_rewards) else (reward_stage or 0))
         for k, (n, v) in enumerate(zip(self.reward_names, self.reward_scales)):
             c.reward_term_ids[k] = abi.REWARD_TERM_ID[(reward_term_variants or {}).get(n, n)]
             c.reward_scales[k] = v

@@ -116,6 +116,11 @@ class NativeCore:
         sc = (C.c_float * max(n, 1))(*[float(x) for x in scales])
         self._check(self.lib.lg_set_reward_terms(self.ctx, n, ids, sc, self._stream()))
 
+    def set_async_gait(self, weights, foot_z_align):
+        """`AsyncGaitScheduler` term: stage weights (dof_align, dof_nominal_pos, reward_foot_z_align) and the spawn-pose constant."""
+        w = (C.c_float * 3)(*[float(x) for x in weights])
+        self._check(self.lib.lg_set_async_gait(self.ctx, w, float(foot_z_align), self._stream()))
+
     def step_subset_physics(self, actions, env_ids_i32):
         a = self._f32(actions)
         self._check(self.lib.lg_step_subset_physics(self.ctx, C.c_void_p(a.data_ptr()), C.c_void_p(env_ids_i32.data_ptr()),

@@ -1,7 +1,18 @@
 """`AsyncGaitSchedulerCfg` (reference `utils/gait_scheduler.py:97-121`): which joints / feet the alignment terms of
 `AsyncGaitScheduler` compare.  A config section; the index lists are derived from the names at instantiation, as in the reference.
-(The terms themselves -- `_reward_async_gait_scheduler`, `utils/gait_scheduler.py:151-175` -- are not part of the native step yet: a
-config that gives them a non-zero scale is rejected by the env classes.)"""
+The joint terms (`reward_dof_align`, `reward_dof_nominal_pos`, `utils/gait_scheduler.py:151-166`) are native reward term
+`LG_REW_ASYNC_GAIT_SCHEDULER`; the foot term (`:168-175`) is evaluated once by `foot_z_align` below, because the scheduler object keeps the
+feet tensor it was constructed with (see `envs/anymal_c/batch_rollout/anymal_c_batch_rollout.py`)."""
+import torch
+
+
+def foot_z_align(foot_pos, foot_z_align_sets_idx):
+    """`AsyncGaitScheduler.reward_foot_z_align` (`utils/gait_scheduler.py:168-175`): per env, the sum over the foot sets of the
+    (unbiased) standard deviation of the feet heights.  `foot_pos` is (N, feet, 3)."""
+    out = torch.zeros(foot_pos.shape[0], dtype=torch.float, device=foot_pos.device)
+    for s in foot_z_align_sets_idx:
+        out += torch.std(foot_pos[:, list(s), 2], dim=1)
+    return out
 
 
 class AsyncGaitSchedulerCfg(object):

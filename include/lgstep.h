@@ -98,6 +98,8 @@ enum lg_reward_term {
   /* class-specific variants of a term (same name in cfg.rewards.scales, chosen by the env class) */
   LG_REW_ORIENTATION_LOAD_ADAPT,     /* LoadAdaptAnymal / LoadAdaptGo2._reward_orientation (anymal.py:140-143, go2.py:141-144) */
   LG_REW_PENALTY_IN_THE_AIR,         /* StandAnymal / StandGo2._reward_penalty_in_the_air (anymal.py:301-308): neither of feet 1, 3 in (filtered) contact */
+  LG_REW_ASYNC_GAIT_SCHEDULER,       /* AnymalCBatchRollout / Go2BatchRollout._reward_async_gait_scheduler (anymal_c_batch_rollout.py:207-220) over
+                                      * AsyncGaitScheduler's three terms (utils/gait_scheduler.py:151-175), see lg_config.async_* */
   LG_REW_COUNT
 };
 
@@ -256,6 +258,16 @@ typedef struct lg_config {
                                        * legged_robot_config.py:176, passed to create_actor at legged_robot.py:792) */
   /* rng */
   uint64_t seed; int32_t rng_mode;
+  /* AsyncGaitScheduler (utils/gait_scheduler.py:97-175; sections cfg.async_gait_scheduler / cfg.rewards.async_gait_scheduler):
+   *   dof_align       = sum over sets of the unbiased std of dof_pos[set]            (sets of DOF indices, -1 padded)
+   *   dof_nominal_pos = sum_d weight[d] * (dof_pos[d] - nominal[d])^2
+   *   foot_z_align    = sum over foot sets of the unbiased std of foot z -- of the feet positions the scheduler object captured when
+   *                     the env was built (the reference's `foot_positions` attribute is re-bound every step, the scheduler keeps the
+   *                     first tensor): a constant of the spawn pose, async_foot_z_align
+   *   term = dof_align * w[0] + dof_nominal_pos * w[1] + foot_z_align * w[2]         (w: the stage's weights, lg_set_async_gait) */
+  int32_t async_num_dof_sets, async_dof_sets[4][3];
+  float async_dof_nominal[LG_NUM_DOF], async_dof_weight[LG_NUM_DOF];
+  float async_weights[3], async_foot_z_align;
   int32_t inject_sim_state;           /* parity tests only (like LG_RNG_INJECT): lg_step's post-physics half takes the post-simulation state
                                        * from what the caller put into LG_T_ROOT_STATES / DOF_STATE / TORQUES / CONTACT_FORCES / RIGID_BODY_STATE
                                        * before the call -- the way the recording harness injected it under the reference's step() -- and
@@ -332,6 +344,10 @@ int lg_step_subset(lg_ctx* ctx, const float* actions, const int32_t* env_ids, in
  * active reward terms (evaluation order, scales already multiplied by dt, num_terms <= LG_MAX_REWARD_TERMS; HOST
  * pointers) and zero every episode sum, as re-creating `episode_sums` does (:672-674).  Stream-ordered. */
 int lg_set_reward_terms(lg_ctx* ctx, int32_t num_terms, const int32_t* term_ids, const float* scales, void* stream);
+
+/* AsyncGaitScheduler term: the three weights of the current reward stage (`get_weight(key, reward_scales_stage)`,
+ * anymal_c_batch_rollout.py:212-216) and the foot_z_align constant of the spawn pose (see lg_config.async_*).  Stream-ordered. */
+int lg_set_async_gait(lg_ctx* ctx, const float weights[3], float foot_z_align, void* stream);
 
 /* The two halves of lg_step_subset, so that sensor kernels (ray caster, body SDF) can run on the post-physics, pre-reset state
  * in between (RobotBatchRolloutPercept._post_physics_step_callback, robot_batch_rollout_percept.py:301-331). */

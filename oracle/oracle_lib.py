@@ -49,6 +49,7 @@ def lib():
         L.lgo_sync_main_to_rollout.argtypes = [vp, C.c_int32, C.c_float, C.c_uint32]
         L.lgo_raycast_bruteforce.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_float, vp, vp]
         L.lgo_set_reward_terms.argtypes = [vp, C.c_int32, vp, vp]
+        L.lgo_set_async_gait.argtypes = [vp, vp, C.c_float]
         L.lgo_set_collision_mesh.argtypes = [vp, vp, C.c_int64, vp, C.c_int64]
         L.lgo_sdf_bruteforce.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_float, vp, vp]
         _lib = L
@@ -111,6 +112,10 @@ class OracleEnv:
     def set_reward_terms(self, term_ids, scales):
         ids = np.ascontiguousarray(term_ids, dtype=np.int32); sc = np.ascontiguousarray(scales, dtype=np.float32)
         assert self.L.lgo_set_reward_terms(self.ctx, len(ids), ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)) == 0
+
+    def set_async_gait(self, weights, foot_z_align):
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        assert self.L.lgo_set_async_gait(self.ctx, w.ctypes.data_as(C.c_void_p), float(foot_z_align)) == 0
 
     def reset_idx(self, env_ids, update_curriculum=0):
         ids = np.ascontiguousarray(env_ids, dtype=np.int32)
