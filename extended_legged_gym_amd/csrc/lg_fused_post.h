@@ -40,38 +40,71 @@ static_assert(LG_REW_COUNT <= 32, "reward-term masks (rew_term_mask, 1u << id) a
 
 // ---- helper waves, while the main wave runs the last sweeps: history rows, uniforms, pre-step integers -> LDS
 LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid /* 0..191 */, int64_t step, const float* values) {
+  // Every global load of this function is issued before the first LDS store: per element a load -> store chain inside a ten-way divergent
+  // branch (the former form) was five passes of ten memory round trips each, ~17 k cycles -- longer than the sweeps it was meant to hide
+  // behind, so the main wave waited 6.4 k cycles per step at barrier (F).
   const lg_config& g = C->cfg;
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
-  const int K = g.num_reward_terms, per = 12 + 6 + 4 + 3 + 3 + 4 + 4 + 1 + 4 + K;
-  for (int idx = htid; idx < nenv * per; idx += 192) {
-    const int el = idx / per; int o = idx - el * per;
-    const int e = e0 + el;
-    float* S = SR + el * FS_STRIDE;
-    if (o < 12) { S[FS_LACT + o] = C->last_actions[(size_t)e * 12 + o]; continue; }
-    o -= 12; if (o < 6) { S[FS_LRV + o] = C->last_root_vel[(size_t)e * 6 + o]; continue; }
-    o -= 6; if (o < 4) { S[FS_CMD + o] = C->commands[(size_t)e * 4 + o]; continue; }
-    o -= 4; if (o < 3) { S[FS_BLA + o] = C->base_lin_acc[(size_t)e * 3 + o]; continue; }
-    o -= 3; if (o < 3) { S[FS_BAA + o] = C->base_ang_acc[(size_t)e * 3 + o]; continue; }
-    o -= 3; if (o < 4) { S[FS_AIR + o] = C->feet_air[(size_t)e * 4 + o]; continue; }
-    o -= 4; if (o < 4) { S[FS_CT + o] = C->feet_ctime[(size_t)e * 4 + o]; continue; }
-    o -= 4; if (o < 1) { S[FS_GAIT] = C->gait_idx[e]; continue; }
-    o -= 1; if (o < 4) { S[FS_GFZ + o] = C->gait_foot_z[(size_t)e * 4 + o]; continue; }
-    o -= 4; S[FS_SUMS + o] = C->ep_sums[(size_t)o * C->N + e];
+  const int K = g.num_reward_terms;
+  enum { PER = 12 + 6 + 4 + 3 + 3 + 4 + 4 + 1 + 4, NF = (EPB * PER + 191) / 192, NS = (EPB * LG_MAX_REWARD_TERMS + 191) / 192 };
+  // fixed rows, flat index -> (env, entry): row base pointers are wave-uniform, the row is chosen by selects
+  const float LG_G* const b_lact = C->last_actions; const float LG_G* const b_lrv = C->last_root_vel; const float LG_G* const b_cmd = C->commands;
+  const float LG_G* const b_bla = C->base_lin_acc; const float LG_G* const b_baa = C->base_ang_acc; const float LG_G* const b_air = C->feet_air;
+  const float LG_G* const b_ct = C->feet_ctime; const float LG_G* const b_gait = C->gait_idx; const float LG_G* const b_gfz = C->gait_foot_z;
+  float fv[NF]; int fdst[NF];
+#pragma unroll
+  for (int it = 0; it < NF; ++it) {
+    const int idx = htid + 192 * it;
+    const int el = idx / PER, o = idx - el * PER;
+    const bool ok = el < nenv;
+    const size_t e = (size_t)(e0 + (ok ? el : 0));
+    const float LG_G* src; int dst;
+    if (o < 12) { src = b_lact + e * 12 + o; dst = FS_LACT + o; }
+    else if (o < 18) { src = b_lrv + e * 6 + (o - 12); dst = FS_LRV + (o - 12); }
+    else if (o < 22) { src = b_cmd + e * 4 + (o - 18); dst = FS_CMD + (o - 18); }
+    else if (o < 25) { src = b_bla + e * 3 + (o - 22); dst = FS_BLA + (o - 22); }
+    else if (o < 28) { src = b_baa + e * 3 + (o - 25); dst = FS_BAA + (o - 25); }
+    else if (o < 32) { src = b_air + e * 4 + (o - 28); dst = FS_AIR + (o - 28); }
+    else if (o < 36) { src = b_ct + e * 4 + (o - 32); dst = FS_CT + (o - 32); }
+    else if (o < 37) { src = b_gait + e; dst = FS_GAIT; }
+    else { src = b_gfz + e * 4 + (o - 37); dst = FS_GFZ + (o - 37); }
+    fdst[it] = ok ? el * FS_STRIDE + dst : -1;
+    fv[it] = *src;
   }
-  // one Philox call per (env, slot group): 8 groups of the 32 control slots
+  // episode sums, (K, N) rows: lane -> (term, env) with the env fastest (consecutive addresses)
+  float sv[NS]; int sdst[NS];
+#pragma unroll
+  for (int it = 0; it < NS; ++it) {
+    const int idx = htid + 192 * it;
+    const int el = idx & (EPB - 1), o = idx >> 4;
+    const bool ok = el < nenv && o < K;
+    sdst[it] = ok ? el * FS_STRIDE + FS_SUMS + o : -1;
+    sv[it] = C->ep_sums[(size_t)(ok ? o : 0) * C->N + e0 + (ok ? el : 0)];
+  }
+  static_assert(EPB == 16, "the (term, env) split of the episode sums assumes 16 envs per workgroup");
+  int64_t pl = 0; float plevel = 0.f, pval = 0.f; uint32_t plc = 0;
+  if (htid < nenv) {
+    const int e = e0 + htid;
+    pl = C->ep_len[e];
+    plevel = g.curriculum ? (float)C->levels[e] : 0.f;
+    pval = values ? values[e] : 0.f;
+    plc = *reinterpret_cast<const uint32_t*>(C->last_contacts + (size_t)e * 4);
+  }
+  // one Philox call per (env, slot group): 8 groups of the 32 control slots (computed while the loads are in flight)
   for (int idx = htid; idx < nenv * (LG_RS_NOISE / 4); idx += 192) {
     const int el = idx / (LG_RS_NOISE / 4), grp = idx - el * (LG_RS_NOISE / 4);
     uniform_draw4(C, e0 + el, grp, step, 0u, UB + FU_U + el * LG_RS_NOISE + 4 * grp);
   }
+#pragma unroll
+  for (int it = 0; it < NF; ++it) if (fdst[it] >= 0) SR[fdst[it]] = fv[it];
+#pragma unroll
+  for (int it = 0; it < NS; ++it) if (sdst[it] >= 0) SR[sdst[it]] = sv[it];
   if (htid < nenv) {
-    const int e = e0 + htid;
     float* pre = UB + FU_PRE + htid * FU_PRE_STRIDE;
-    *reinterpret_cast<int64_t*>(pre) = C->ep_len[e];
-    pre[2] = g.curriculum ? (float)C->levels[e] : 0.f;
-    SR[htid * FS_STRIDE + FS_VAL] = values ? values[e] : 0.f;
-    uint8_t* lc = reinterpret_cast<uint8_t*>(pre + 3);
-    const uint8_t* src = C->last_contacts + (size_t)e * 4;
-    lc[0] = src[0]; lc[1] = src[1]; lc[2] = src[2]; lc[3] = src[3];
+    *reinterpret_cast<int64_t*>(pre) = pl;
+    pre[2] = plevel;
+    SR[htid * FS_STRIDE + FS_VAL] = pval;
+    *reinterpret_cast<uint32_t*>(pre + 3) = plc;
   }
 }
 
@@ -458,7 +491,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
       }
     }
   }
-  STAMP(22);
+  STAMP(32);
   // statistics of the workgroup's envs (fixed env order), arrival
   const int KP = HI(HC_K) + 3;
   bool any_reset = false;
@@ -478,7 +511,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   const unsigned want = (gridDim.x + 7u - shard) >> 3;
   if (wv == 0) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the statistics stores / atomics of this wave have completed
   if (tid == 0) arrival = __hip_atomic_fetch_add(C->tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  STAMP(23);
+  STAMP(33);
 
   // observation rows (LR:234-252, :107-108): proprio | heights | extra, + uniform noise, clipped.  A lane forms the 4 entries of
   // ONE Philox call (entries 4 gq .. 4 gq + 3, the post kernel's mapping, so the noise is the same draw for draw); what does not
@@ -552,7 +585,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
       __builtin_amdgcn_wave_barrier();
     }
   }
-  STAMP(24);
+  STAMP(34);
   bool last = false;
   if (tid == 0 && arrival == want - 1u) {
     if (__hip_atomic_fetch_add(C->tickets + 32 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1u) {

@@ -40,33 +40,40 @@ struct LegModel {
   LG_DEV int i(int field) const { return __float_as_int(f(field)); }
 };
 // cooperative fill by one wave (64 lanes); call before any LegModel read, followed by a barrier
-LG_DEV void fill_leg_model(float* t, const lg_robot_model* __restrict__ m, const lg_config* __restrict__ g, int lane) {
-  for (int idx = lane; idx < LM_FIELDS * 4; idx += 64) {
-    const int field = idx >> 2, l = idx & 3;
-    float val;
-    if (field < LM_JROT) val = m->joint_pos[l][field / 3][field % 3];
-    else if (field < LM_JAXIS) { int k = field - LM_JROT; val = m->joint_rot[l][k / 9][k % 9]; }
-    else if (field < LM_MASS) { int k = field - LM_JAXIS; val = m->joint_axis[l][k / 3][k % 3]; }
-    else if (field < LM_COM) val = m->link_mass[l][field - LM_MASS];
-    else if (field < LM_INERTIA) { int k = field - LM_COM; val = m->link_com[l][k / 3][k % 3]; }
-    else if (field < LM_FOOT_POS) { int k = field - LM_INERTIA; val = m->link_inertia[l][k / 6][k % 6]; }
-    else if (field < LM_FOOT_ROT) val = m->foot_pos[l][field - LM_FOOT_POS];
-    else if (field < LM_VEL_LIMIT) val = m->foot_rot[l][field - LM_FOOT_ROT];
-    else if (field < LM_TORQUE_LIMIT) val = m->dof_vel_limit[3 * l + field - LM_VEL_LIMIT];
-    else if (field < LM_DEFAULT_POS) val = m->torque_limit[3 * l + field - LM_TORQUE_LIMIT];
-    else if (field < LM_PGAIN) val = g->default_dof_pos[3 * l + field - LM_DEFAULT_POS];
-    else if (field < LM_DGAIN) val = g->p_gains[3 * l + field - LM_PGAIN];
-    else if (field < LM_CP_COUNT) val = g->d_gains[3 * l + field - LM_DGAIN];
-    else if (field < LM_CP_LINK) val = __int_as_float(m->cp_count[l]);
-    else if (field < LM_CP_POS) val = __int_as_float(m->cp_link[l][field - LM_CP_LINK]);
-    else if (field < LM_CP_RADIUS) { int k = field - LM_CP_POS; val = m->cp_pos[l][k / 3][k % 3]; }
-    else if (field < LM_LOWER) val = m->cp_radius[l][field - LM_CP_RADIUS];
-    else if (field < LM_UPPER) val = m->dof_lower[3 * l + field - LM_LOWER];
-    else if (field < LM_SOFT_LO) val = m->dof_upper[3 * l + field - LM_UPPER];
-    else if (field < LM_SOFT_HI) val = g->dof_pos_limits[3 * l + field - LM_SOFT_LO][0];
-    else val = g->dof_pos_limits[3 * l + field - LM_SOFT_HI][1];
-    t[idx] = val;
-  }
+// entry idx = field * 4 + leg of the per-leg model table (LM_*); evaluated once on the host (pack_leg_model, at lg_create): the kernels
+// copy the packed table into LDS.  (Filled in the kernel it was ~25 divergent branches with a dependent load each, ten times over:
+// 6-8 k cycles in front of the first barrier of every launch.)
+__host__ __device__ inline float leg_model_entry(const lg_robot_model* m, const lg_config* g, int idx) {
+  const int field = idx >> 2, l = idx & 3;
+  if (field < LM_JROT) return m->joint_pos[l][field / 3][field % 3];
+  if (field < LM_JAXIS) { int k = field - LM_JROT; return m->joint_rot[l][k / 9][k % 9]; }
+  if (field < LM_MASS) { int k = field - LM_JAXIS; return m->joint_axis[l][k / 3][k % 3]; }
+  if (field < LM_COM) return m->link_mass[l][field - LM_MASS];
+  if (field < LM_INERTIA) { int k = field - LM_COM; return m->link_com[l][k / 3][k % 3]; }
+  if (field < LM_FOOT_POS) { int k = field - LM_INERTIA; return m->link_inertia[l][k / 6][k % 6]; }
+  if (field < LM_FOOT_ROT) return m->foot_pos[l][field - LM_FOOT_POS];
+  if (field < LM_VEL_LIMIT) return m->foot_rot[l][field - LM_FOOT_ROT];
+  if (field < LM_TORQUE_LIMIT) return m->dof_vel_limit[3 * l + field - LM_VEL_LIMIT];
+  if (field < LM_DEFAULT_POS) return m->torque_limit[3 * l + field - LM_TORQUE_LIMIT];
+  if (field < LM_PGAIN) return g->default_dof_pos[3 * l + field - LM_DEFAULT_POS];
+  if (field < LM_DGAIN) return g->p_gains[3 * l + field - LM_PGAIN];
+  if (field < LM_CP_COUNT) return g->d_gains[3 * l + field - LM_DGAIN];
+  float val; int iv;
+  if (field < LM_CP_LINK) { iv = m->cp_count[l]; memcpy(&val, &iv, 4); return val; }
+  if (field < LM_CP_POS) { iv = m->cp_link[l][field - LM_CP_LINK]; memcpy(&val, &iv, 4); return val; }
+  if (field < LM_CP_RADIUS) { int k = field - LM_CP_POS; return m->cp_pos[l][k / 3][k % 3]; }
+  if (field < LM_LOWER) return m->cp_radius[l][field - LM_CP_RADIUS];
+  if (field < LM_UPPER) return m->dof_lower[3 * l + field - LM_LOWER];
+  if (field < LM_SOFT_LO) return m->dof_upper[3 * l + field - LM_UPPER];
+  if (field < LM_SOFT_HI) return g->dof_pos_limits[3 * l + field - LM_SOFT_LO][0];
+  return g->dof_pos_limits[3 * l + field - LM_SOFT_HI][1];
+}
+inline void pack_leg_model(float* t, const lg_robot_model* m, const lg_config* g) {
+  for (int idx = 0; idx < LM_FIELDS * 4; ++idx) t[idx] = leg_model_entry(m, g, idx);
+}
+// LDS copy of the packed table by `nthreads` threads (tid 0 .. nthreads-1); the caller holds the barrier
+LG_DEV void fill_leg_model(float* t, const float* __restrict__ packed, int tid, int nthreads) {
+  for (int idx = tid; idx < LM_FIELDS * 4; idx += nthreads) t[idx] = packed[idx];
 }
 LG_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

@@ -77,6 +77,7 @@ struct DevCtx {
   // term list in the kernel is one dependent scalar load per term on the narrow-stage chain
   unsigned rew_term_mask; int rew_kfat, rew_kterm; float rew_term_scale;
   float hot[HC_COUNT];          // see the HC_* enum (ints stored as bit patterns)
+  float lmod[LM_FIELDS * 4];    // per-leg model table, packed on the host (pack_leg_model)
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
   float lvl_total_before;       // subset steps with a terrain curriculum: sum of ALL terrain levels before the launch (level_total_kernel)
   unsigned long long LG_G* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
@@ -106,6 +107,7 @@ static thread_local std::string g_err;
 
 static void hot_config(DevCtx& h) {
   const lg_config& g = h.cfg; const lg_robot_model& m = h.model;
+  pack_leg_model(h.lmod, &m, &g);
   auto I = [&](int i, int v) { memcpy(&h.hot[i], &v, 4); };
   auto U = [&](int i, unsigned v) { memcpy(&h.hot[i], &v, 4); };
   auto F = [&](int i, float v) { h.hot[i] = v; };
@@ -487,6 +489,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
   __shared__ __attribute__((aligned(16))) float cst[LG_CST_FLOATS];
   __shared__ float lmod[LM_FIELDS * 4];
+#ifdef LG_STAMPS
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
   const float* __restrict__ wlstm = C->lstm_w;
   // state of the substep published by the main wave for the helpers: [lane][root 13 | q 3 | qd 3 | pad] = five 16-byte units per
   // lane (odd: conflict-free), written / read with ds_*_b128 -- a lone wave gets the full LDS rate only on 16-byte accesses
@@ -514,10 +519,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const lg_robot_model* __restrict__ m = &C->model;
   const lg_config& g = C->cfg;
   const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
-  if (wv == 0) fill_leg_model(lmod, m, &C->cfg, lane);
+  fill_leg_model(lmod, C->lmod, threadIdx.x, blockDim.x);
   if (fuse && wv == 1) for (int i = lane; i < HC_COUNT; i += 64) hot[i] = C->hot[i];
   if (LSTM_LDS && MODE == 0 && net && wv >= 2) for (int i = (wv - 2) * 64 + lane; i < LW_COUNT; i += 128) wlds[i] = wlstm[i];
   lds_barrier();
+#ifdef LG_STAMPS
+  const unsigned long long t_bar0 = __builtin_amdgcn_s_memtime();
+#endif
   const LegModel lm_{lmod, l};
 
   if (MODE == 0 && HELPERS && wv > 0) {
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #pragma unroll 1
     for (int sub = 0; sub < nsub; ++sub) {
       lds_barrier();                                   // (A) main wave has published root, q, qd of this substep
-      STAMP(22);
+      STAMP(40);
       // torque-independent share of the dynamics: this leg's kinematics, then the leg bias (wave 1) or the contact
       // detection of half of the slots (waves 2, 3), straight into the LDS the main wave reads after barrier (A2);
       // then this wave's joint of the actuator network, all while the main wave factorises the mass matrix
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       const V3 pb = v3(r13[0], r13[1], r13[2]), vb = v3(r13[7], r13[8], r13[9]), wb = v3(r13[10], r13[11], r13[12]);
       LegKin k;
       leg_kinematics(lm_, Rb, pb, vb, wb, qq, qdd, k);
-      STAMP(23);
+      STAMP(41);
       // heightfield terrains: two slots per wave (the main wave takes slots 0, 1); this wave issues its height-sample
       // loads now and uses them after the actuator network
       // slot ranges [DS0, DS1) wave 1 (which also has the leg bias), [DS1, DS2) wave 2, [DS2, 8) wave 3; the main wave
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       } else {
         contact_detect_begin<DS2, 8>(lm_, T, k, Rb, pb, pr3);
       }
-      STAMP(24);
+      STAMP(42);
       if (net) {
         const float x0 = (tgt - qq[j]) * g.actuator_in_scale[0], x1 = qdd[j] * g.actuator_in_scale[1];
         // an opaque zero keeps the ~60 weight addresses from being hoisted out of the substep loop as loop invariants
@@ -621,9 +629,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (!TMESH && wv == 1) { if (DS0 < DS1) contact_detect_finish<DS0, DS1P>(lm_, T, P, pb, pr1, cst, lane); }
       else if (!TMESH && wv == 2) contact_detect_finish<DS1, DS2>(lm_, T, P, pb, pr2, cst, lane);
       else if (!TMESH && wv == 3) contact_detect_finish<DS2, 8>(lm_, T, P, pb, pr3, cst, lane);
-      STAMP(25);
+      STAMP(43);
       lds_barrier();                                   // (A2) bias, contact detection, torques | mass-matrix factors
-      STAMP(26);
+      STAMP(44);
       // this wave's share of the contact set-up (every fourth active slot)
       {
         float Mi[6], Mbk[6][3], Y[3][6], Si[21];
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           }
         }
       }
-      STAMP(27);
+      STAMP(45);
       lds_barrier();                                   // (A3) slot table complete
       if (net && sub + 1 < nsub) {                     // while the main wave sweeps: recurrent half of the next substep's network
         if (LSTM_LDS) lstm_recurrent_part(wlds, h0, h1, lpre);
@@ -647,10 +655,16 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       }
       if (fuse && sub + 1 == nsub) {                   // ... in the last substep: what the post-physics tail needs from HBM
         if (net) *fused_act_slot(xs, lane, d) = a;     // (the mass-factor table is dead after (A3): the env rows live there)
+        STAMP(46);                                     // (diagnostic: (A3) of the last substep)
         fused_prefetch(C, xs, &xbias[0][0], blockIdx.x, n, (wv - 1) * 64 + lane, fstep, sink.values);
+#ifdef LG_STAMPS
+        __builtin_amdgcn_s_waitcnt(0);
+#endif
+        STAMP(47);
       }
     }
     lds_barrier();                                     // (F) main wave has published the final state of the step
+    STAMP(48);
     if (TMESH && valid) mesh_cache_io<false>(C, cqc, e, l, lane, 2 * wv);
     bool zero_state = false;
     if (!fuse) {
@@ -761,7 +775,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   if (TMESH && helpers) mesh_cache_io<true>(C, cqc, e, l, lane, 0);
 #ifdef LG_STAMPS
   unsigned long long* stamps = (blockIdx.x == 0 && lane == 0) ? C->stamps : nullptr;
+  __builtin_amdgcn_s_waitcnt(0);                      // (diagnostic: the state loads have landed)
   unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+  if (stamps) { stamps[37] += t_bar0 - t_entry; stamps[38] += stamp_t - t_bar0; }
 #else
   unsigned long long* stamps = nullptr;
 #endif
@@ -870,6 +886,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     publish_state(xst[lane], s.root, s.q, s.qd, qn);
     lds_barrier();                                     // (F) final state visible to the helper waves, which write the body states
   }
+  STAMP(39);
   if (fuse) {
     // ---- fused step: the post-physics step of the workgroup's envs, from the registers of this wave (lg_fused_post.h)
     fused_main_and_serial(C, hot, lm_, xs, &xbias[0][0], cst, lane, e, valid, s.root, s.q, s.qd, tau, last_qd, fbody, split ? nullptr : act, fault, fstep, stamps, sink);
@@ -901,6 +918,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     __syncthreads();
     if (s_last_f) fused_finalize(C, gridDim.x, threadIdx.x);
     STAMP(14);
+#ifdef LG_STAMPS
+    if (stamps) stamps[36] += __builtin_amdgcn_s_memtime() - t_entry;      // the main wave's whole kernel
+#endif
     return;
   }
   if (!valid) return;
@@ -1899,7 +1919,7 @@ __global__ __launch_bounds__(64) void set_state_kernel(const DevCtx* __restrict_
                                                        const int32_t* __restrict__ ids, int n) {
   __shared__ float lmod[LM_FIELDS * 4];
   const int lane = threadIdx.x, l = lane & 3;
-  fill_leg_model(lmod, &C->model, &C->cfg, lane);
+  fill_leg_model(lmod, C->lmod, lane, 64);
   lds_barrier();
   const int kq = blockIdx.x * 16 + (lane >> 2);
   if (kq >= n) return;
@@ -2040,10 +2060,10 @@ size_t lg_arena_bytes(const lg_config* cfg, const lg_robot_model* model, const l
 const char* lg_last_error(lg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
 // diagnostic builds only: copy out the 16 phase counters (not part of the public ABI)
-int lg_debug_read_stamps(lg_ctx* c, unsigned long long out[32]) {
+int lg_debug_read_stamps(lg_ctx* c, unsigned long long out[64]) {
   if (!c) return LG_ERR_INVALID;
   if (hipDeviceSynchronize() != hipSuccess) return LG_ERR_HIP;
-  return hipMemcpy(out, c->h.stamps, 256, hipMemcpyDeviceToHost) == hipSuccess ? LG_OK : LG_ERR_HIP;
+  return hipMemcpy(out, c->h.stamps, 512, hipMemcpyDeviceToHost) == hipSuccess ? LG_OK : LG_ERR_HIP;
 }
 
 void lg_destroy(lg_ctx* c) {
@@ -2141,14 +2161,14 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   size_t n_noise = (size_t)cfg->num_obs, n_hp = (size_t)2 * cfg->num_height_points;
   size_t n_part = (size_t)h.nblocks_post * PART_STRIDE;
   size_t n_fin = (size_t)2 * h.nblocks_post + 4 + 32 + 9 * 32 + 2 * PART_STRIDE + 2;   // level sums | reset flags | (pad to a 128-B line) | arrival counters | accumulators
-  size_t aux_floats = n_noise + n_hp + n_part + 66 + n_fin;   // + 32 x u64 stamp counters
+  size_t aux_floats = n_noise + n_hp + n_part + 130 + n_fin;   // + 64 x u64 stamp counters
   if (hipMalloc(&c->aux, aux_floats * 4) != hipSuccess) return fail("hipMalloc(aux) failed");
   if (hipMemset(c->aux, 0, aux_floats * 4) != hipSuccess) return fail("hipMemset(aux) failed");
   float* aux = (float*)c->aux;
   h.noise_vec = (const float LG_G*)aux; h.height_points = (const float LG_G*)(aux + n_noise); h.partials = (float LG_G*)(aux + n_noise + n_hp);
   h.stamps = (unsigned long long LG_G*)(aux + ((n_noise + n_hp + n_part + 1) & ~(size_t)1));
   {
-    float* fin = aux + n_noise + n_hp + n_part + 66;
+    float* fin = aux + n_noise + n_hp + n_part + 130;
     h.lvl_part = (float LG_G*)fin; h.part_flag = (unsigned LG_G*)(fin + h.nblocks_post);
     h.tickets = (unsigned LG_G*)(((uintptr_t)(fin + 2 * h.nblocks_post + 4) + 127) & ~(uintptr_t)127);
     h.acc = (long long LG_G*)(h.tickets + 9 * 32);

@@ -14,23 +14,39 @@ pool = [torch.randn(4096, 12, generator=g).cuda() for _ in range(16)]
 for i in range(300):
     env.step(pool[i % 16])
 lib = env.core.lib
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 64)()
 lib.lg_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 rc = lib.lg_debug_read_stamps(env.core.ctx, out)
 import extended_legged_gym_amd.native as nat
 print('lib', nat.LIB_PATH, 'rc', rc)
-names = {15: "substep prologue", 0: "publish q/qd | inline actuator", 1: "kinematics", 2: "bias (RNEA)", 3: "CRBA+Schur+chol",
-         29: "own contact detection", 5: "wait at rendezvous (A2) + slot mask", 6: "contact pass B (setup)", 4: "wait for torques (barrier B)", 7: "unconstrained + PGS",
-         8: "limits+forces+integrate", 9: "fault guard", 10: "write-back + final FK",
-         11: "TAIL: main part 1 (rows, features, rotations)", 19: "TAIL: wait at (G1)", 20: "TAIL: serial part (callback, rewards, reset)",
-         21: "TAIL: wait at (G2)", 12: "TAIL: state stores", 13: "TAIL: write-back + obs rows", 14: "TAIL: arrival + finalize"}
-tot = sum(out[:16]) + sum(out[19:22]) + out[29]
-hn = {22: "TAIL wb: row stores (main wave; helper stamp 22-24 unused in this build)", 23: "TAIL wb: stats + store drain + ticket", 24: "TAIL wb: obs rows", 25: "HELPER: LSTM joint", 26: "HELPER: wait at (A2)", 27: "HELPER: contact set-up share"}
-for k, n in hn.items():
-    print(f"{n:34s} per substep {out[k] / (301 * 4):9.0f} cycles")
+STEPS = 301
+sub = {15: "substep prologue", 0: "publish q/qd | inline actuator", 1: "kinematics", 2: "bias (RNEA)", 3: "CRBA+Schur+chol",
+       29: "own contact detection", 5: "wait at rendezvous (A2) + slot mask", 6: "contact pass B (setup)", 4: "wait for torques (barrier B)",
+       7: "unconstrained + solver passes", 8: "limits+forces+integrate", 9: "fault guard", 10: "write-back + final FK"}
+tail = {39: "publish final state + wait at (F)", 11: "TAIL: main part 1 (rows, features, rotations)", 19: "TAIL: wait at (G1)", 20: "TAIL: serial part (callback, rewards, reset)",
+        21: "TAIL: wait at (G2)", 12: "TAIL: state stores", 32: "TAIL wb: row stores", 33: "TAIL wb: stats + ticket", 34: "TAIL wb: obs rows",
+        13: "TAIL: (call overhead)", 14: "TAIL: arrival + finalize"}
+helper = {40: "HELPER: wait at (A) [recurrent half + the main wave's sweeps]", 41: "HELPER: state fetch + kinematics", 42: "HELPER: bias / detection loads",
+          43: "HELPER: LSTM input half + detection finish", 44: "HELPER: wait at (A2)", 45: "HELPER: contact set-up share"}
+whole = out[36] / STEPS
+print(f"main wave, whole kernel: {whole:9.0f} cycles per step")
+ssum = 0
+for k, n in sub.items():
+    ssum += out[k]
+    print(f"  {n:48s} per substep {out[k] / (STEPS * 4):8.0f}   {100.0 * out[k] / max(out[36], 1):5.1f} %")
+print(f"  {'substeps, total':48s} per step    {ssum / STEPS:8.0f}   {100.0 * ssum / max(out[36], 1):5.1f} %")
+tsum = 0
+for k, n in tail.items():
+    tsum += out[k]
+    print(f"  {n:48s} per step    {out[k] / STEPS:8.0f}   {100.0 * out[k] / max(out[36], 1):5.1f} %")
+print(f"  {'tail, total':48s} per step    {tsum / STEPS:8.0f}   {100.0 * tsum / max(out[36], 1):5.1f} %")
+print(f"  entry -> first barrier (config / model block -> LDS)  per step {out[37] / STEPS:8.0f}")
+print(f"  first barrier -> state rows in registers             per step {out[38] / STEPS:8.0f}")
+print(f"  unaccounted (entry, loads, exit)                 per step    {(out[36] - ssum - tsum) / STEPS:8.0f}")
+for k, n in {46: "HELPER, last substep: set-up share end -> (A3) passed", 47: "HELPER, last substep: prefetch for the tail", 48: "HELPER: wait at (F)"}.items():
+    print(f"  {n:64s} per step    {out[k] / STEPS:8.0f}")
+for k, n in helper.items():
+    print(f"  {n:64s} per substep {out[k] / (STEPS * 4):8.0f}")
 print('active slots per 16-lane group (4 envs) per substep', out[28] / max(out[17], 1) / 4)
 print('wave-substeps with >= 4 active slots: %.1f %%, >= 5: %.1f %%' % (100.0 * out[30] / max(out[17], 1), 100.0 * out[31] / max(out[17], 1)))
 print('active slots per wave-substep', out[16] / max(out[17], 1), ' active contacts per wave-substep', out[18] / max(out[17], 1), '(of', 64 * 7, 'lane-slots)')
-for k, n in names.items():
-    print(f"{n:28s} {out[k]:14d} cycles  {100.0 * out[k] / max(tot, 1):5.1f} %   per substep-call {out[k] / (301 * 4):9.0f}")
-print("total cycles per step", tot / 301)
