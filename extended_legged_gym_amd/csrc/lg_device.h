@@ -141,8 +141,10 @@ LG_DEV S3 quad_sum(S3 a) { return S3{quad_sum(a.xx), quad_sum(a.xy), quad_sum(a.
 LG_DEV void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    // (64-bit products: one v_mad_u64_u32 each; as __umulhi + a 32-bit multiply the compiler emits v_mul_hi_u32 + v_mul_lo_u32, two
+    //  quarter-rate instructions per product)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
     uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
     c0 = n0; c1 = l1; c2 = n2; c3 = l0; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }

@@ -35,7 +35,7 @@ static_assert(FU_PRE + EPB * FU_PRE_STRIDE <= 64 * 12, "uniforms + pre-step inte
 enum { FM_RK = 0, FM_PART = LG_MAX_REWARD_TERMS, FM_ROOTZ = FM_PART + PART_STRIDE, FM_DID_RESET, FM_ROOT_DIRTY, FM_LASTC /* 4 */, FM_RAW = FM_LASTC + 4 /* 2 x LG_REW_COUNT */,
        FM_STRIDE = FM_RAW + 2 * LG_REW_COUNT + 1 };
 enum { FO_STRIDE = 256, FH_HEIGHTS = 0, FH_MISC = EPB * MAX_P, FH_OBS = FH_MISC + EPB * FM_STRIDE + 3 - (FH_MISC + EPB * FM_STRIDE + 3) % 4 /* 16-B aligned */ };
-static_assert(FH_OBS + 4 * FO_STRIDE <= LG_MAX_CP * CF_FIELDS * 64, "heights + per-env results + four observation staging rows must fit the memory of the contact-slot table");
+static_assert(FH_OBS + EPB * FO_STRIDE <= LG_MAX_CP * CF_FIELDS * 64, "heights + per-env results + one observation staging row per env must fit the memory of the contact-slot table");
 static_assert(LG_REW_COUNT <= 32, "reward-term masks (rew_term_mask, 1u << id) are 32 bits wide");
 
 // ---- helper waves, while the main wave runs the last sweeps: history rows, uniforms, pre-step integers -> LDS
@@ -456,40 +456,56 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
   const int P = HI(HC_P);
   const float* MB = HB + FH_MISC;
-  // Row stores, 4 envs per wave.  All LDS reads of the four envs are issued first (one round trip), then the predicated global
-  // stores: a read-then-store chain per row costs an LDS latency each, 70 times over, on a wave that is alone on its SIMD.
+  // Row stores, 4 envs per wave.  One store instruction covers a row of ALL FOUR envs of the wave (lane = (env q, entry i): rows are
+  // 1-24 entries long), small rows share an instruction (the destination is chosen by selects): 12 stores per wave where a store per
+  // (env, row) was 60, each with a handful of active lanes.  All LDS reads first (one round trip), then the stores.
   {
-    enum { NR = 16 };
-    const int off[NR] = {FS_ROOT, FS_DOF, FS_CMD, FS_AIR, FS_CT, FS_BLV, FS_BAV, FS_PG, FS_BLA, FS_BAA, FS_GAIT, FS_ACT, FS_ROOT + 7, FS_SUMS, FS_FRB, FS_DOF};
-    const int len[NR] = {13, 24, 4, 4, 4, 3, 3, 3, 3, 3, 1, 12, 6, HI(HC_K), 0 /* gait_foot_z: stored with the foot's rigid-body row */, 12};
-    float v[4][NR]; float lc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float* S = SR + (4 * wv + q) * FS_STRIDE;
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const int i = max(min(ln, len[r] - 1), 0);
-        v[q][r] = S[off[r] + (r == 15 ? 2 * i + 1 : i)];   // 14: foot heights (gait_foot_z), 15: DOF velocities
-      }
-      lc[q] = MB[(4 * wv + q) * FM_STRIDE + FM_LASTC + min(ln, 3)];
+    const int K_ = HI(HC_K);
+    const size_t eb = (size_t)(e0 + 4 * wv);                 // first env of this wave
+#define ROWI(LEN) const int q = ln / (LEN), i = ln - q * (LEN);
+#define ROWQ(LEN) ROWI(LEN) const bool ok = q < 4 && 4 * wv + q < nenv; const float* S = SR + (4 * wv + (ok ? q : 0)) * FS_STRIDE;
+    float v_root, v_d0, v_d1, v_a = 0.f, v_b = 0.f, v_act, v_lrv, v_ldv, v_s0 = 0.f, v_s1 = 0.f, v_lc;
+    bool k_root, k_d, k_a, k_b, k_lrv, k_s0, k_s1, k_lc;
+    float LG_G* p_a = nullptr; float LG_G* p_b = nullptr;
+    { ROWQ(13) v_root = S[FS_ROOT + i]; k_root = ok; }
+    { ROWQ(12) v_d0 = S[FS_DOF + i]; v_d1 = S[FS_DOF + 12 + i]; v_act = S[FS_ACT + i]; v_ldv = S[FS_DOF + 2 * i + 1]; k_d = ok; }
+    { ROWQ(6) v_lrv = S[FS_ROOT + 7 + i]; k_lrv = ok; }
+    {   // commands | feet_air_time | feet_contact_time | gait_idx: 13 lanes per env
+      ROWQ(13)
+      const int off = i < 4 ? FS_CMD + i : i < 8 ? FS_AIR + i - 4 : i < 12 ? FS_CT + i - 8 : FS_GAIT;
+      v_a = S[off]; k_a = ok;
+      const size_t e = eb + (ok ? q : 0);
+      p_a = i < 4 ? C->commands + e * 4 + i : i < 8 ? C->feet_air + e * 4 + (i - 4) : i < 12 ? C->feet_ctime + e * 4 + (i - 8) : C->gait_idx + e;
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int el = 4 * wv + q;
-      if (el < nenv) {
-        const size_t e = (size_t)(e0 + el);
-        float* dst[NR] = {C->root + e * 13, C->dof + e * 24, C->commands + e * 4, C->feet_air + e * 4, C->feet_ctime + e * 4, C->base_lin_vel + e * 3,
-                          C->base_ang_vel + e * 3, C->proj_grav + e * 3, C->base_lin_acc + e * 3, C->base_ang_acc + e * 3, C->gait_idx + e,
-                          C->last_actions + e * 12, C->last_root_vel + e * 6, nullptr, C->gait_foot_z + e * 4, C->last_dof_vel + e * 12};
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          if (r == 13) { if (ln < len[r]) C->ep_sums[(size_t)ln * C->N + e] = v[q][r]; }       // (K, N) rows
-          else if (r == 14) { }
-          else if (ln < len[r]) dst[r][ln] = v[q][r];
-        }
-        if (ln < 4) C->last_contacts[e * 4 + ln] = lc[q] != 0.f ? 1 : 0;
-      }
+    {   // base_lin_vel | base_ang_vel | projected_gravity | base_lin_acc | base_ang_acc: 15 lanes per env
+      ROWQ(15)
+      const int r = i / 3, c = i - 3 * r;
+      const int off = (r == 0 ? FS_BLV : r == 1 ? FS_BAV : r == 2 ? FS_PG : r == 3 ? FS_BLA : FS_BAA) + c;
+      v_b = S[off]; k_b = ok;
+      const size_t e = eb + (ok ? q : 0);
+      float LG_G* base = r == 0 ? C->base_lin_vel : r == 1 ? C->base_ang_vel : r == 2 ? C->proj_grav : r == 3 ? C->base_lin_acc : C->base_ang_acc;
+      p_b = base + e * 3 + c;
     }
+    {   // episode sums, (K, N) rows: lane = (term, env) with the env fastest
+      const int q = ln & 3, k0 = ln >> 2, k1 = k0 + 16;
+      const bool okq = 4 * wv + q < nenv;
+      const float* S = SR + (4 * wv + (okq ? q : 0)) * FS_STRIDE;
+      k_s0 = okq && k0 < K_; k_s1 = okq && k1 < K_;
+      v_s0 = S[FS_SUMS + (k_s0 ? k0 : 0)]; v_s1 = S[FS_SUMS + (k_s1 ? k1 : 0)];
+    }
+    { const int q = ln >> 2, f = ln & 3; k_lc = q < 4 && 4 * wv + q < nenv; v_lc = MB[(4 * wv + (k_lc ? q : 0)) * FM_STRIDE + FM_LASTC + f]; }
+    static_assert(LG_MAX_REWARD_TERMS <= 32, "two passes of 16 terms cover the episode sums");
+    { ROWI(13) if (k_root) C->root[(eb + q) * 13 + i] = v_root; }
+    { ROWI(12) if (k_d) { C->dof[(eb + q) * 24 + i] = v_d0; C->dof[(eb + q) * 24 + 12 + i] = v_d1; C->last_actions[(eb + q) * 12 + i] = v_act; C->last_dof_vel[(eb + q) * 12 + i] = v_ldv; } }
+    { ROWI(6) if (k_lrv) C->last_root_vel[(eb + q) * 6 + i] = v_lrv; }
+    if (k_a) *p_a = v_a;
+    if (k_b) *p_b = v_b;
+    { const int q = ln & 3, k0 = ln >> 2;
+      if (k_s0) C->ep_sums[(size_t)k0 * C->N + eb + q] = v_s0;
+      if (k_s1) C->ep_sums[(size_t)(k0 + 16) * C->N + eb + q] = v_s1; }
+    if (k_lc) C->last_contacts[(eb + (ln >> 2)) * 4 + (ln & 3)] = v_lc != 0.f ? 1 : 0;
+#undef ROWQ
+#undef ROWI
   }
   STAMP(32);
   // statistics of the workgroup's envs (fixed env order), arrival
@@ -521,7 +537,8 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   const int O = HI(HC_NUM_OBS), G4 = (O + 3) >> 2;
   const bool inject = HI(HC_INJECT) != 0, add_noise = HI(HC_ADD_NOISE) != 0;
   const float ls = HF(HC_OS_LIN), as = HF(HC_OS_ANG), ps = HF(HC_OS_POS), vs = HF(HC_OS_VEL), hs = HF(HC_OS_H), clip = HF(HC_CLIP_OBS);
-  float* OB = const_cast<float*>(HB) + FH_OBS + wv * FO_STRIDE;      // this wave's staging row
+  float* OB = const_cast<float*>(HB) + FH_OBS + 4 * wv * FO_STRIDE;  // this wave's staging rows, one per env: with ONE row the four envs of the wave
+                                                                      // ran one after the other (row write -> wait -> row reads -> stores, four times)
   for (int g0 = 0; g0 < G4; g0 += 64) {
     const int gq = g0 + ln;
     float nv[4], scale[4], sub[4]; int off[4], hix[4], kind[4];
@@ -536,6 +553,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
       kind[i] = idx < 48 ? 0 : (idx < 48 + P ? 1 : 2);
       hix[i] = min(max(idx - 48, 0), MAX_P - 1);
     }
+    STAMP(49);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                 // (unrolled: the four envs' Philox chains and LDS reads interleave)
       const int el = 4 * wv + q;
@@ -569,21 +587,32 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
         if (add_noise) v += (2.f * u[i] - 1.f) * nv[i];
         o[i] = fminf(fmaxf(v, -clip), clip);
       }
-      *reinterpret_cast<float4*>(OB + 4 * ln) = make_float4(o[0], o[1], o[2], o[3]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): the row is in LDS (same wave: the LDS pipeline is in order)
-      __builtin_amdgcn_wave_barrier();
+      *reinterpret_cast<float4*>(OB + q * FO_STRIDE + 4 * ln) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    STAMP(50);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the rows are in LDS (same wave: the LDS pipeline is in order)
+    __builtin_amdgcn_wave_barrier();
+    float ov[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ov[q][j] = OB[q * FO_STRIDE + ln + 64 * j];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int el = 4 * wv + q;
+      if (el >= nenv) continue;
+      const int e = e0 + el;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int idx = 4 * g0 + ln + 64 * j;
-        if (idx < O && idx < 4 * g0 + 256) {
-          const float v = OB[idx - 4 * g0];
-          C->obs[(size_t)e * O + idx] = v;
-          if (obs_out) obs_out[(size_t)e * O + idx] = v;     // RolloutStorage.observations[t + 1]
+        if (idx < O) {
+          C->obs[(size_t)e * O + idx] = ov[q][j];
+          if (obs_out) obs_out[(size_t)e * O + idx] = ov[q][j];     // RolloutStorage.observations[t + 1]
         }
       }
-      __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_wave_barrier();
   }
   STAMP(34);
   bool last = false;
