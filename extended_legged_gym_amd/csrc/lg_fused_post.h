@@ -512,12 +512,12 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   const int KP = HI(HC_K) + 3;
   bool any_reset = false;
   for (int el = 0; el < nenv; ++el) any_reset |= MB[el * FM_STRIDE + FM_DID_RESET] != 0.f;
-  if (wv == 0 && ln < KP && any_reset) {
+  if (wv == FUSED_STATS_WAVE && ln < KP && any_reset) {
     float sacc = 0.f;
     for (int el = 0; el < nenv; ++el) sacc += MB[el * FM_STRIDE + FM_PART + ln];
     __hip_atomic_fetch_add(C->acc + ln, __double2ll_rn((double)sacc * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (wv == 0 && ln == KP + 1) {
+  if (wv == FUSED_STATS_WAVE && ln == KP + 1) {
     float sacc = 0.f;
     for (int el = 0; el < nenv; ++el) sacc += MB[el * FM_STRIDE + FM_PART + HI(HC_K) + 1];
     st_dev(C->lvl_part + blk, sacc);
@@ -525,8 +525,8 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   unsigned arrival = 0;
   const unsigned shard = (unsigned)blk & 7u, nsh = min(8u, gridDim.x);
   const unsigned want = (gridDim.x + 7u - shard) >> 3;
-  if (wv == 0) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the statistics stores / atomics of this wave have completed
-  if (tid == 0) arrival = __hip_atomic_fetch_add(C->tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (wv == FUSED_STATS_WAVE) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the statistics stores / atomics of this wave have completed
+  if (tid == 64 * FUSED_STATS_WAVE) arrival = __hip_atomic_fetch_add(C->tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   STAMP(33);
 
   // observation rows (LR:234-252, :107-108): proprio | heights | extra, + uniform noise, clipped.  A lane forms the 4 entries of
@@ -616,7 +616,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   }
   STAMP(34);
   bool last = false;
-  if (tid == 0 && arrival == want - 1u) {
+  if (tid == 64 * FUSED_STATS_WAVE && arrival == want - 1u) {
     if (__hip_atomic_fetch_add(C->tickets + 32 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1u) {
       last = true;
       for (int i = 0; i < 9; ++i) __hip_atomic_store(C->tickets + 32 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

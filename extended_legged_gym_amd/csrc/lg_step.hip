@@ -463,6 +463,7 @@ LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[2
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot, const LegModel& lm_, float* xs, float* UB, float* HB, int lane, int e, bool valid,
                                   const float* root, const float* q, const float* qd, const float* tau, const float* last_qd, const V3* fbody,
                                   const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K);
+#define FUSED_STATS_WAVE 1   // which wave of a fused workgroup adds the statistics, draws the arrival ticket and tests for the last arrival (a helper wave: with the rigid-body rows moved in front of (G2) the helpers reach the write-back with less left to do than the main wave; A/B -0.5 %)
 LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out);
 LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid);
 LG_DEV bool fused_did_reset(const float* HB, int el);
@@ -690,8 +691,21 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         }
       }
       fused_height_scan(C, xst, cst, blockIdx.x, n, (wv - 1) * 64 + lane);
+      // the rigid-body rows (stores nobody in this launch reads) while the main wave runs the serial part: these waves wait ~6 k cycles for
+      // it at (G2); behind the write-back, where they used to be, they were on the tail of the launch
+      if (valid && g.inject_sim_state) {                         // parity tests: the injected rows stay; gait_foot_z from the injected foot row
+        if (wv == 3 && g.gait_enabled) C->gait_foot_z[(size_t)e * 4 + l] = C->rigid[((size_t)e * C->B + 1 + C->per_leg * l + (C->per_leg == 4 ? 3 : 2)) * 13 + 2];
+      } else if (valid && !(feet_early && wv == 3)) {            // rigid-body rows of the post-physics (pre-reset) pose, LR:118-120
+        float r13[13], qq[3], qdd[3];
+        fetch_state(xst[lane], r13, qq, qdd);
+        write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled) ? C->gait_foot_z + (size_t)e * 4 + l : nullptr);
+      } else if (valid && g.gait_enabled) {
+        C->gait_foot_z[(size_t)e * 4 + l] = fused_foot_row(xs, lane)[2];
+      }
+      STAMP(51);
       if (feet_early || fused_needs_heights_early(C)) lds_barrier();   // (G1) only when the serial part reads a helper's product
       lds_barrier();                                   // (G2) serial part + height scan done
+      STAMP(52);
       zero_state = fused_did_reset(cst, lane >> 2);     // anymal.py:78-82: a reset env starts from the zero LSTM state
     }
     if (valid && net) {
@@ -712,16 +726,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     if (fuse) {
       const bool last = fused_writeback_obs(C, hot, xs, cst, blockIdx.x, n, threadIdx.x, fstep, nullptr, sink.obs_out);
-      if (valid && g.inject_sim_state) {                         // parity tests: the injected rows stay; gait_foot_z from the injected foot row
-        if (wv == 3 && g.gait_enabled) C->gait_foot_z[(size_t)e * 4 + l] = C->rigid[((size_t)e * C->B + 1 + C->per_leg * l + (C->per_leg == 4 ? 3 : 2)) * 13 + 2];
-      } else if (valid && !(fused_needs_feet_rows(C) && wv == 3)) {     // rigid-body rows of the post-physics (pre-reset) pose, LR:118-120
-        float r13[13], qq[3], qdd[3];
-        fetch_state(xst[lane], r13, qq, qdd);
-        write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled) ? C->gait_foot_z + (size_t)e * 4 + l : nullptr);
-      } else if (valid && g.gait_enabled) {
-        C->gait_foot_z[(size_t)e * 4 + l] = fused_foot_row(xs, lane)[2];
-      }
-      if (threadIdx.x == 0) s_last_f = last ? 1 : 0;
+      if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last ? 1 : 0;
       __syncthreads();
       if (s_last_f) fused_finalize(C, gridDim.x, threadIdx.x);
     }
@@ -914,7 +919,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     STAMP(13);
-    if (threadIdx.x == 0) s_last_f = last_wg ? 1 : 0;
+    if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last_wg ? 1 : 0;
     __syncthreads();
     if (s_last_f) fused_finalize(C, gridDim.x, threadIdx.x);
     STAMP(14);

@@ -43,7 +43,7 @@ print(f"  {'tail, total':48s} per step    {tsum / STEPS:8.0f}   {100.0 * tsum / 
 print(f"  entry -> first barrier (config / model block -> LDS)  per step {out[37] / STEPS:8.0f}")
 print(f"  first barrier -> state rows in registers             per step {out[38] / STEPS:8.0f}")
 print(f"  unaccounted (entry, loads, exit)                 per step    {(out[36] - ssum - tsum) / STEPS:8.0f}")
-for k, n in {46: "HELPER, last substep: set-up share end -> (A3) passed", 47: "HELPER, last substep: prefetch for the tail", 48: "HELPER: wait at (F)"}.items():
+for k, n in {46: "HELPER, last substep: set-up share end -> (A3) passed", 47: "HELPER, last substep: prefetch for the tail", 48: "HELPER: wait at (F)", 51: "HELPER: feet rows + height scan", 52: "HELPER: wait at (G1) / (G2) for the serial part"}.items():
     print(f"  {n:64s} per step    {out[k] / STEPS:8.0f}")
 for k, n in helper.items():
     print(f"  {n:64s} per substep {out[k] / (STEPS * 4):8.0f}")
