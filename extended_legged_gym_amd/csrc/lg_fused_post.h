@@ -35,7 +35,8 @@ static_assert(FU_PRE + EPB * FU_PRE_STRIDE <= 64 * 12, "uniforms + pre-step inte
 enum { FM_RK = 0, FM_PART = LG_MAX_REWARD_TERMS, FM_ROOTZ = FM_PART + PART_STRIDE, FM_DID_RESET, FM_ROOT_DIRTY, FM_LASTC /* 4 */, FM_RAW = FM_LASTC + 4 /* 2 x LG_REW_COUNT */,
        FM_STRIDE = FM_RAW + 2 * LG_REW_COUNT + 1 };
 enum { FO_STRIDE = 256, FH_HEIGHTS = 0, FH_MISC = EPB * MAX_P, FH_OBS = FH_MISC + EPB * FM_STRIDE + 3 - (FH_MISC + EPB * FM_STRIDE + 3) % 4 /* 16-B aligned */ };
-static_assert(FH_OBS + EPB * FO_STRIDE <= LG_MAX_CP * CF_FIELDS * 64, "heights + per-env results + one observation staging row per env must fit the memory of the contact-slot table");
+enum { FH_NOISE = FH_OBS + EPB * FO_STRIDE /* observation-noise uniforms, one FO_STRIDE row per env, drawn by the helper waves (fused_noise_*) */ };
+static_assert(FH_NOISE + EPB * FO_STRIDE <= LG_MAX_CP * CF_FIELDS * 64, "heights + per-env results + observation staging and noise rows must fit the memory of the contact-slot table");
 static_assert(LG_REW_COUNT <= 32, "reward-term masks (rew_term_mask, 1u << id) are 32 bits wide");
 
 // ---- helper waves, while the main wave runs the last sweeps: history rows, uniforms, pre-step integers -> LDS
@@ -107,6 +108,39 @@ LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, i
     *reinterpret_cast<uint32_t*>(pre + 3) = plc;
   }
 }
+
+// ---- helper waves: the uniforms of the observation noise (LR:250-252), one Philox call per (env, group of 4 entries) with the post kernel's
+// counters.  They depend on nothing of this step, so they are drawn while these waves wait for the main wave at (F) -- into registers, the
+// LDS that will hold them is still the contact-slot table -- and parked in LDS behind the barrier; the write-back then reads its four
+// uniforms with one ds_read_b128 where every wave ran ~240 Philox calls (4 envs x 59 groups) on the tail of the launch.  A/B: -0.6 % on the
+// step; drawn behind the height scan instead (rolled loop, nothing held across the barrier) the main wave waits for them at (G2): +0.5 %.
+LG_DEV bool fused_noise_predrawn(const float* hot) {       // (kernel-uniform)
+  return HI(HC_ADD_NOISE) != 0 && HI(HC_INJECT) == 0 && HI(HC_NUM_OBS) <= FO_STRIDE;
+}
+LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid /* 0..191 */, int64_t step, float nz[NZ_IT][4]) {
+  const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
+  const int G4 = (HI(HC_NUM_OBS) + 3) >> 2;
+#pragma unroll
+  for (int it = 0; it < NZ_IT; ++it) {
+    const int idx = htid + 192 * it;
+    const int el = idx / G4, gq = idx - el * G4;
+    uint32_t o4[4] = {0u, 0u, 0u, 0u};
+    if (el < nenv) philox4((uint32_t)(e0 + el), (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), 0u, (uint32_t)HI(HC_SEED_LO), (uint32_t)HI(HC_SEED_HI), o4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nz[it][i] = u01(o4[i]);
+  }
+}
+LG_DEV void fused_noise_park(const float* hot, float* HB, int blk, int n, int htid, const float nz[NZ_IT][4]) {
+  const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
+  const int G4 = (HI(HC_NUM_OBS) + 3) >> 2;
+#pragma unroll
+  for (int it = 0; it < NZ_IT; ++it) {
+    const int idx = htid + 192 * it;
+    const int el = idx / G4, gq = idx - el * G4;
+    if (el < nenv) *reinterpret_cast<float4*>(HB + FH_NOISE + el * FO_STRIDE + 4 * gq) = make_float4(nz[it][0], nz[it][1], nz[it][2], nz[it][3]);
+  }
+}
+static_assert(NZ_IT * 192 >= EPB * (FO_STRIDE / 4), "the helper lanes cover every (env, Philox group) of rows up to FO_STRIDE entries");
 
 // ---- helper waves, after the final state is published: the height scan of the workgroup's envs (LR:400-401), one point per lane
 LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid) {
@@ -535,7 +569,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   // through an LDS row so that the global stores are dense (lane = entry): four 16-byte-strided dword stores per env were the
   // most expensive part of this phase (the memory pipeline handles 4 lanes per 64-byte segment).
   const int O = HI(HC_NUM_OBS), G4 = (O + 3) >> 2;
-  const bool inject = HI(HC_INJECT) != 0, add_noise = HI(HC_ADD_NOISE) != 0;
+  const bool inject = HI(HC_INJECT) != 0, add_noise = HI(HC_ADD_NOISE) != 0, predrawn = fused_noise_predrawn(hot);
   const float ls = HF(HC_OS_LIN), as = HF(HC_OS_ANG), ps = HF(HC_OS_POS), vs = HF(HC_OS_VEL), hs = HF(HC_OS_H), clip = HF(HC_CLIP_OBS);
   float* OB = const_cast<float*>(HB) + FH_OBS + 4 * wv * FO_STRIDE;  // this wave's staging rows, one per env: with ONE row the four envs of the wave
                                                                       // ran one after the other (row write -> wait -> row reads -> stores, four times)
@@ -573,10 +607,15 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
         for (int i = 0; i < 4; ++i) { const int idx = 4 * gq + i; if (idx < O && idx >= 48 + P) ex[i] = C->extra_obs[(size_t)e * HI(HC_NUM_EXTRA) + (idx - 48 - P)]; }
       }
       if (add_noise && !inject) {
-        uint32_t o4[4];
-        philox4((uint32_t)e, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), 0u, (uint32_t)HI(HC_SEED_LO), (uint32_t)HI(HC_SEED_HI), o4);
+        if (predrawn) {                            // (O <= FO_STRIDE: one pass, g0 == 0) drawn by the helper waves in front of (F)
+          const float4 t = *reinterpret_cast<const float4*>(HB + FH_NOISE + el * FO_STRIDE + 4 * min(gq, FO_STRIDE / 4 - 1));
+          u[0] = t.x; u[1] = t.y; u[2] = t.z; u[3] = t.w;
+        } else {
+          uint32_t o4[4];
+          philox4((uint32_t)e, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), 0u, (uint32_t)HI(HC_SEED_LO), (uint32_t)HI(HC_SEED_HI), o4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = u01(o4[i]);
+          for (int i = 0; i < 4; ++i) u[i] = u01(o4[i]);
+        }
       }
       float o[4];
 #pragma unroll

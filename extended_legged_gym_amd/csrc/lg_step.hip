@@ -460,6 +460,10 @@ struct PostSink { float* obs_out; const float* values; float* rewards; float* do
 struct FusedMainIn;
 LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid, int64_t step, const float* values);
 LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid);
+enum { NZ_IT = 6 };          // Philox calls per helper lane that cover the observation noise of the workgroup's 16 envs (rows of up to 256 entries)
+LG_DEV bool fused_noise_predrawn(const float* hot);
+LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid, int64_t step, float nz[NZ_IT][4]);
+LG_DEV void fused_noise_park(const float* hot, float* HB, int blk, int n, int htid, const float nz[NZ_IT][4]);
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot, const LegModel& lm_, float* xs, float* UB, float* HB, int lane, int e, bool valid,
                                   const float* root, const float* q, const float* qd, const float* tau, const float* last_qd, const V3* fbody,
                                   const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K);
@@ -664,8 +668,12 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         STAMP(47);
       }
     }
+    float nz[NZ_IT][4];
+    const bool predraw = fuse && fused_noise_predrawn(hot);
+    if (predraw) fused_noise_draw(hot, blockIdx.x, n, (wv - 1) * 64 + lane, fstep, nz);   // (these waves would wait for the main wave's last sweeps now)
     lds_barrier();                                     // (F) main wave has published the final state of the step
     STAMP(48);
+    if (predraw) fused_noise_park(hot, cst, blockIdx.x, n, (wv - 1) * 64 + lane, nz);
     if (TMESH && valid) mesh_cache_io<false>(C, cqc, e, l, lane, 2 * wv);
     bool zero_state = false;
     if (!fuse) {
