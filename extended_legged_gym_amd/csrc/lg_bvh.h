@@ -32,6 +32,8 @@ struct lg_mesh {
   BvhNode4* d_nodes = nullptr;
   float4* d_tris = nullptr;            // 3 float4 per triangle: v0, v1, v2 (w unused)
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};   // bounding box of the mesh
+  float4* d_sdf_cache = nullptr;       // lg_sdf_bodies_update: last closest surface point per query slot (xyz, w = 1 when set)
+  int64_t sdf_cache_n = 0;
   std::string err;
 };
 
@@ -145,6 +147,17 @@ LG_DEV V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
   return a + (vb * denom) * ab + (vc * denom) * ac;
 }
 
+// squared distance from p to the bounding box of triangle (a, b, c): a lower bound of the distance to the triangle.  A leaf holds up to 8
+// faces and every one of them used to get the full closest-point test (~150 instructions, twice in the pair traversal) although after the
+// first hit most lie beyond the current best distance: the box test (20 instructions) rejects those.  Exact: a face whose box is farther
+// than the acceptance limit holds no point within it.
+LG_DEV float tri_box_dist2(V3 p, V3 a, V3 b, V3 c) {
+  const float dx = fmaxf(fmaxf(fminf(fminf(a.x, b.x), c.x) - p.x, 0.f), p.x - fmaxf(fmaxf(a.x, b.x), c.x));
+  const float dy = fmaxf(fmaxf(fminf(fminf(a.y, b.y), c.y) - p.y, 0.f), p.y - fmaxf(fmaxf(a.y, b.y), c.y));
+  const float dz = fmaxf(fmaxf(fminf(fminf(a.z, b.z), c.z) - p.z, 0.f), p.z - fmaxf(fmaxf(a.z, b.z), c.z));
+  return dx * dx + dy * dy + dz * dz;
+}
+
 // closest point within max_dist; outputs the point and the unit normal of the face that decides the sign.  When several
 // faces are equally close (the closest feature is a shared edge or vertex) the face whose plane is farthest from the
 // query point decides: that rule is independent of traversal order, so the BVH and a brute-force scan agree.
@@ -170,27 +183,38 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
       go = descend4(cand, key, stack_i, stack_k, sp, cur);
     } else {
       const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
-      for (int i = 0; i < cnt; ++i) {
-        const float4* T = M.tris + (size_t)(first + i) * 3;
-        float4 a4 = T[0], b4 = T[1], c4 = T[2];
-        V3 a = v3(a4.x, a4.y, a4.z), b = v3(b4.x, b4.y, b4.z), cc = v3(c4.x, c4.y, c4.z);
-        // zero-area faces (slope-corrected height-field meshes are full of them) are skipped: their points belong to
-        // the edges of their neighbours, and the barycentric arithmetic below is 0/0 on them
-        V3 fn = cross(b - a, cc - a); float fl = norm(fn);
-        if (!(fl > 1e-10f)) continue;
-        V3 q = closest_on_triangle(p, a, b, cc);
-        V3 dq = p - q; float d2 = dot(dq, dq);
-        if (!(d2 <= best2 * (1.f + 1e-5f) + 1e-12f)) continue;
-        const bool strictly = !found || d2 < best2 * (1.f - 1e-5f) - 1e-12f;
-        if (strictly) { bestabs = -1.f; bestn = v3(0, 0, 1); }
-        {
-          V3 nh = (1.f / fl) * fn;
-          float sd = dot(dq, nh);
-          float ab = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f);   // coincident faces of opposite orientation: outside wins
-          if (ab > bestabs) { bestn = nh; bestabs = ab; }
+      // The triangles of a leaf (up to 8) are fetched four at a time, every load issued before the first test: one memory round trip per
+      // four faces instead of one per face (a lane tests its faces one after the other and the wave waits for its slowest lane).
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        float4 ta[4], tb[4], tc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4* T = M.tris + (size_t)(first + min(i0 + u, cnt - 1)) * 3;
+          ta[u] = T[0]; tb[u] = T[1]; tc[u] = T[2];
         }
-        if (!found || d2 < best2) { best2 = d2; bestp = q; }
-        found = true;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u >= cnt) continue;
+          V3 a = v3(ta[u].x, ta[u].y, ta[u].z), b = v3(tb[u].x, tb[u].y, tb[u].z), cc = v3(tc[u].x, tc[u].y, tc[u].z);
+          if (!(tri_box_dist2(p, a, b, cc) <= best2 * (1.f + 1e-5f) + 1e-12f)) continue;
+          // zero-area faces (slope-corrected height-field meshes are full of them) are skipped: their points belong to
+          // the edges of their neighbours, and the barycentric arithmetic below is 0/0 on them
+          V3 fn = cross(b - a, cc - a); float fl = norm(fn);
+          if (!(fl > 1e-10f)) continue;
+          V3 q = closest_on_triangle(p, a, b, cc);
+          V3 dq = p - q; float d2 = dot(dq, dq);
+          if (!(d2 <= best2 * (1.f + 1e-5f) + 1e-12f)) continue;
+          const bool strictly = !found || d2 < best2 * (1.f - 1e-5f) - 1e-12f;
+          if (strictly) { bestabs = -1.f; bestn = v3(0, 0, 1); }
+          {
+            V3 nh = (1.f / fl) * fn;
+            float sd = dot(dq, nh);
+            float ab = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f);   // coincident faces of opposite orientation: outside wins
+            if (ab > bestabs) { bestn = nh; bestabs = ab; }
+          }
+          if (!found || d2 < best2) { best2 = d2; bestp = q; }
+          found = true;
+        }
       }
     }
     if (go) continue;
@@ -215,11 +239,19 @@ LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery&
   V3 pA = A.p, pB = B.p, cA = A.p, cB = B.p, nA = v3(0, 0, 1), nB = v3(0, 0, 1);
   const bool onA = A.on, onB = B.on;
   int stack_i[BVH_STACK]; float stack_k[BVH_STACK]; int sp = 0; int cur = 0;
-  if (onA || onB) while (true) {
-    bool go = false;
-    if (visits) ++*visits;
+  // "while-while" form: every lane first walks inner nodes until it stands on a leaf (lanes that already do wait), then the whole wave
+  // tests leaf faces together.  As one loop whose body handled "inner node or leaf", each of the wave's ~26 iterations paid for the
+  // leaf branch (up to 8 faces, the expensive part) as soon as ANY lane stood on a leaf; now it is paid once per round of leaves.
+  bool done = !(onA || onB);
+  auto pop = [&]() -> bool {
+    const float lim = fmaxf(onA ? bestA * (1.f + 1e-5f) + 1e-12f : -1.f, onB ? bestB * (1.f + 1e-5f) + 1e-12f : -1.f);
+    while (sp > 0) { --sp; if (stack_k[sp] <= lim) { cur = stack_i[sp]; return true; } }
+    return false;
+  };
+  while (!done) {
     const float limA = onA ? bestA * (1.f + 1e-5f) + 1e-12f : -1.f, limB = onB ? bestB * (1.f + 1e-5f) + 1e-12f : -1.f;
-    if (cur >= 0) {
+    while (cur >= 0) {
+      if (visits) ++*visits;
       const Node4Regs n = load_node4(M.nodes, cur);
       int cand[4]; float key[4];
 #pragma unroll
@@ -234,17 +266,23 @@ LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery&
         key[k] = wantA && wantB ? fminf(kA, kB) : (wantA ? kA : kB);
         cand[k] = (c != BVH4_EMPTY && (wantA || wantB)) ? c : BVH4_EMPTY;
       }
-      go = descend4(cand, key, stack_i, stack_k, sp, cur);
-    } else {
+      if (!descend4(cand, key, stack_i, stack_k, sp, cur) && !pop()) { done = true; break; }
+    }
+    if (done) break;
+    {
+      if (visits) ++*visits;
       const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
       for (int i = 0; i < cnt; ++i) {
         const float4* T = M.tris + (size_t)(first + i) * 3;
         float4 a4 = T[0], b4 = T[1], c4 = T[2];
         V3 a = v3(a4.x, a4.y, a4.z), b = v3(b4.x, b4.y, b4.z), cc = v3(c4.x, c4.y, c4.z);
+        const bool nearA = onA && tri_box_dist2(pA, a, b, cc) <= bestA * (1.f + 1e-5f) + 1e-12f;
+        const bool nearB = onB && tri_box_dist2(pB, a, b, cc) <= bestB * (1.f + 1e-5f) + 1e-12f;
+        if (!(nearA || nearB)) continue;
         V3 fn = cross(b - a, cc - a); float fl = norm(fn);
         if (!(fl > 1e-10f)) continue;                      // zero-area faces are skipped (see closest_point)
         const V3 nh = (1.f / fl) * fn;
-        if (onA) {
+        if (nearA) {
           V3 q = closest_on_triangle(pA, a, b, cc);
           V3 dq = pA - q; float d2 = dot(dq, dq);
           if (d2 <= bestA * (1.f + 1e-5f) + 1e-12f) {
@@ -257,7 +295,7 @@ LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery&
             fA = true;
           }
         }
-        if (onB) {
+        if (nearB) {
           V3 q = closest_on_triangle(pB, a, b, cc);
           V3 dq = pB - q; float d2 = dot(dq, dq);
           if (d2 <= bestB * (1.f + 1e-5f) + 1e-12f) {
@@ -272,11 +310,7 @@ LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery&
         }
       }
     }
-    if (go) continue;
-    bool popped = false;
-    const float lim = fmaxf(onA ? bestA * (1.f + 1e-5f) + 1e-12f : -1.f, onB ? bestB * (1.f + 1e-5f) + 1e-12f : -1.f);
-    while (sp > 0) { --sp; if (stack_k[sp] <= lim) { cur = stack_i[sp]; popped = true; break; } }
-    if (!popped) break;
+    if (!pop()) done = true;
   }
   A.found = fA; A.cp = cA; A.fn = nA; B.found = fB; B.cp = cB; B.fn = nB;
 }

@@ -573,12 +573,12 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       if (T.GV) { closest_point_grid(T, Q[0], &visits, (dbg && lane == 0) ? dbg : nullptr); closest_point_grid(T, Q[1], &visits, (dbg && lane == 0) ? dbg : nullptr); }
       else closest_point_pair(T.M, Q[0], Q[1], &visits);
       __builtin_amdgcn_s_waitcnt(0);
-      if (dbg && lane == 0) dbg[27] += __builtin_amdgcn_s_memtime() - tq0;
+      if (dbg && lane == 0) dbg[53] += __builtin_amdgcn_s_memtime() - tq0;
       // diagnostic: queries issued / traversal steps (sum and max over the wave) of workgroup 0, wave 2
       int vmax = visits, vsum = visits;
       for (int off = 32; off > 0; off >>= 1) { vmax = max(vmax, __shfl_xor(vmax, off)); vsum += __shfl_xor(vsum, off); }
       const int nq = __popcll(__ballot(Q[0].on)) + __popcll(__ballot(Q[1].on));
-      if (dbg && lane == 0) { dbg[28] += nq; dbg[29] += vsum; dbg[30] += vmax; dbg[31] += 1; }
+      if (dbg && lane == 0) { dbg[54] += nq; dbg[55] += vsum; dbg[56] += vmax; dbg[57] += 1; }
     }
 #else
     if (T.GV) { closest_point_grid(T, Q[0]); closest_point_grid(T, Q[1]); }

@@ -467,6 +467,11 @@ LG_DEV void fused_noise_park(const float* hot, float* HB, int blk, int n, int ht
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot, const LegModel& lm_, float* xs, float* UB, float* HB, int lane, int e, bool valid,
                                   const float* root, const float* q, const float* qd, const float* tau, const float* last_qd, const V3* fbody,
                                   const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K);
+// blockIdx -> env block with the blocks of one XCD contiguous (blockIdx % 8 = XCD, round-robin dispatch): a bijection on [0, nb)
+LG_DEV int xcd_block(unsigned b, unsigned nb) {
+  const unsigned x = b & 7u, i = b >> 3, per = nb >> 3, rem = nb & 7u;
+  return (int)(x * per + min(x, rem) + i);
+}
 #define FUSED_STATS_WAVE 1   // which wave of a fused workgroup adds the statistics, draws the arrival ticket and tests for the last arrival (a helper wave: with the rigid-body rows moved in front of (G2) the helpers reach the write-back with less left to do than the main wave; A/B -0.5 %)
 LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out);
 LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid);
@@ -515,8 +520,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ __attribute__((aligned(16))) float wlds[LSTM_LDS ? LW_COUNT + 3 : 4];
   const int64_t fstep = C->counters[0] + 1;               // LR:123 (the statistics step of the previous launch stored it)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // Which block of 16 envs this workgroup steps.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own
+  // L2; on triangle-mesh terrains the BVH (13 MB of nodes + 34 MB of triangles on config 3) is what the contact queries read, and envs with
+  // neighbouring indices stand next to each other on the terrain -- so XCD x takes the x-th CONTIGUOUS eighth of the env blocks and its
+  // L2 sees one eighth of the map instead of all of it.
+  const int bid = TMESH ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   // row kq of the launch <-> env e (identity, or ids[kq] for subset stepping: main-only / rollout-only steps)
-  const int kq = blockIdx.x * EPB + (lane >> 2);
+  const int kq = bid * EPB + (lane >> 2);
   const int l = lane & 3;
   const bool valid = kq < n;
   const int krow = valid ? kq : n - 1;   // whole quads are (in)valid together; invalid quads compute on a copy and store nothing
@@ -661,7 +671,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (fuse && sub + 1 == nsub) {                   // ... in the last substep: what the post-physics tail needs from HBM
         if (net) *fused_act_slot(xs, lane, d) = a;     // (the mass-factor table is dead after (A3): the env rows live there)
         STAMP(46);                                     // (diagnostic: (A3) of the last substep)
-        fused_prefetch(C, xs, &xbias[0][0], blockIdx.x, n, (wv - 1) * 64 + lane, fstep, sink.values);
+        fused_prefetch(C, xs, &xbias[0][0], bid, n, (wv - 1) * 64 + lane, fstep, sink.values);
 #ifdef LG_STAMPS
         __builtin_amdgcn_s_waitcnt(0);
 #endif
@@ -670,10 +680,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     float nz[NZ_IT][4];
     const bool predraw = fuse && fused_noise_predrawn(hot);
-    if (predraw) fused_noise_draw(hot, blockIdx.x, n, (wv - 1) * 64 + lane, fstep, nz);   // (these waves would wait for the main wave's last sweeps now)
+    if (predraw) fused_noise_draw(hot, bid, n, (wv - 1) * 64 + lane, fstep, nz);   // (these waves would wait for the main wave's last sweeps now)
     lds_barrier();                                     // (F) main wave has published the final state of the step
     STAMP(48);
-    if (predraw) fused_noise_park(hot, cst, blockIdx.x, n, (wv - 1) * 64 + lane, nz);
+    if (predraw) fused_noise_park(hot, cst, bid, n, (wv - 1) * 64 + lane, nz);
     if (TMESH && valid) mesh_cache_io<false>(C, cqc, e, l, lane, 2 * wv);
     bool zero_state = false;
     if (!fuse) {
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane));   // (gait_foot_z is stored late: the serial part still reads the old one)
         }
       }
-      fused_height_scan(C, xst, cst, blockIdx.x, n, (wv - 1) * 64 + lane);
+      fused_height_scan(C, xst, cst, bid, n, (wv - 1) * 64 + lane);
       // the rigid-body rows (stores nobody in this launch reads) while the main wave runs the serial part: these waves wait ~6 k cycles for
       // it at (G2); behind the write-back, where they used to be, they were on the tail of the launch
       if (valid && g.inject_sim_state) {                         // parity tests: the injected rows stay; gait_foot_z from the injected foot row
@@ -733,7 +743,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (!(fuse && g.inject_sim_state)) C->torques[(size_t)e * 12 + d] = xtau[j][lane];
     }
     if (fuse) {
-      const bool last = fused_writeback_obs(C, hot, xs, cst, blockIdx.x, n, threadIdx.x, fstep, nullptr, sink.obs_out);
+      const bool last = fused_writeback_obs(C, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out);
       if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last ? 1 : 0;
       __syncthreads();
       if (s_last_f) fused_finalize(C, gridDim.x, threadIdx.x);
@@ -922,7 +932,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (per_leg == 4) { cl[9] = fbody[4].x; cl[10] = fbody[4].y; cl[11] = fbody[4].z; }
     }
     STAMP(12);
-    const bool last_wg = fused_writeback_obs(C, hot, xs, cst, blockIdx.x, n, threadIdx.x, fstep, stamps, sink.obs_out);
+    const bool last_wg = fused_writeback_obs(C, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif

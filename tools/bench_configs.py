@@ -45,7 +45,8 @@ def config1():
     return dict(config="1: ANYmal-C flat, 64 envs", env_steps_per_s=64 / dt, ms_per_step=dt * 1e3)
 
 
-def config3():
+def config3_env():
+    """The env of config 3 (also used by tools/stamps.py --config3)."""
     import tempfile
     from extended_legged_gym_amd.envs.a1.a1_config import A1RoughCfg
     from extended_legged_gym_amd.envs.base.legged_robot import LeggedRobot
@@ -69,6 +70,11 @@ def config3():
     t.height_clearance_factor = 2.0
     env = LeggedRobot(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
     env.reset()
+    return env
+
+
+def config3():
+    env = config3_env()
     a = torch.randn(4096, 12, device="cuda")
     # SDF of 5 bodies per env per step (trunk + 4 feet), as RobotBatchRolloutPercept does it: one fused launch
     from extended_legged_gym_amd.utils.mesh_sdf import MeshSDF, MeshSDFCfg

@@ -7,8 +7,13 @@ sys.path.insert(0, ROOT)
 import torch
 import bench
 pd = "--pd" in sys.argv
-env, cfg = bench.build_env(0, 1, 4096, pd)
-env.reset()
+if "--config3" in sys.argv:                       # A1 on the confined OBJ mesh (BVH contacts), tools/bench_configs.py config 3
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs
+    env = bench_configs.config3_env()
+else:
+    env, cfg = bench.build_env(0, 1, 4096, pd)
+    env.reset()
 g = torch.Generator().manual_seed(0)
 pool = [torch.randn(4096, 12, generator=g).cuda() for _ in range(16)]
 for i in range(300):
@@ -50,3 +55,7 @@ for k, n in helper.items():
 print('active slots per 16-lane group (4 envs) per substep', out[28] / max(out[17], 1) / 4)
 print('wave-substeps with >= 4 active slots: %.1f %%, >= 5: %.1f %%' % (100.0 * out[30] / max(out[17], 1), 100.0 * out[31] / max(out[17], 1)))
 print('active slots per wave-substep', out[16] / max(out[17], 1), ' active contacts per wave-substep', out[18] / max(out[17], 1), '(of', 64 * 7, 'lane-slots)')
+if "--config3" in sys.argv:
+    calls = max(out[57], 1)
+    print("mesh contact queries, wave 2 of workgroup 0: %d detection calls; per call: %.1f queries issued (of 128), %.1f BVH nodes visited summed over lanes, %.1f by the busiest lane; %.0f cycles inside the traversal"
+          % (calls, out[54] / calls, out[55] / calls, out[56] / calls, out[53] / calls))

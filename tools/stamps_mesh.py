@@ -17,12 +17,12 @@ n = 200
 for i in range(n):
     env.step(a)
 lib = env.core.lib
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 64)()
 lib.lg_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 lib.lg_debug_read_stamps(env.core.ctx, out)
-calls = max(out[31], 1)
+calls = max(out[57], 1)
 print("wave 2 of workgroup 0: %d detection calls; per call: %.1f queries issued (of 128), %.1f cells or nodes visited summed over lanes, %.1f by the busiest lane"
-      % (calls, out[28] / calls, out[29] / calls, out[30] / calls))
-print("cycles inside the queries per call (wave 2):", out[27] / calls, " clearance stage", out[22] / calls, " centre cell", out[23] / calls, " window scan: loads", out[25] / calls, " box tests", out[26] / calls, " exact tests + loop ends", out[24] / calls)
+      % (calls, out[54] / calls, out[55] / calls, out[56] / calls))
+print("cycles inside the queries per call (wave 2):", out[53] / calls, " clearance stage", out[22] / calls, " centre cell", out[23] / calls, " window scan: loads", out[25] / calls, " box tests", out[26] / calls, " exact tests + loop ends", out[24] / calls)
 for k in list(range(16)) + [29]:
     print(k, out[k] // (n + 1) // 4, "cycles per substep")
