@@ -83,9 +83,14 @@ LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
   float best = max_dist; bool hit = false;
   int stack_i[BVH_STACK]; float stack_k[BVH_STACK]; int sp = 0;
   int cur = 0;
-  while (true) {
-    bool go = false;
-    if (cur >= 0) {
+  // "while-while" form (see closest_point_pair): inner nodes until every lane of the wave stands on a leaf, then the leaf faces together
+  bool done = false;
+  auto pop = [&]() -> bool {
+    while (sp > 0) { --sp; if (stack_k[sp] <= best) { cur = stack_i[sp]; return true; } }
+    return false;
+  };
+  while (!done) {
+    while (cur >= 0) {
       const Node4Regs n = load_node4(M.nodes, cur);
       int cand[4]; float key[4];
 #pragma unroll
@@ -99,8 +104,10 @@ LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
         key[k] = tmin;
         cand[k] = (c != BVH4_EMPTY && tmin <= tmx) ? c : BVH4_EMPTY;
       }
-      go = descend4(cand, key, stack_i, stack_k, sp, cur);
-    } else {
+      if (!descend4(cand, key, stack_i, stack_k, sp, cur) && !pop()) { done = true; break; }
+    }
+    if (done) break;
+    {
       const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
       for (int i = 0; i < cnt; ++i) {
         const float4* T = M.tris + (size_t)(first + i) * 3;
@@ -120,10 +127,7 @@ LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
         if (t >= 0.f && t <= best) { best = t; hit = true; }
       }
     }
-    if (go) continue;
-    bool popped = false;
-    while (sp > 0) { --sp; if (stack_k[sp] <= best) { cur = stack_i[sp]; popped = true; break; } }
-    if (!popped) break;
+    if (!pop()) done = true;
   }
   return hit ? best : -1.f;
 }
@@ -165,9 +169,14 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
   float best2 = max_dist * max_dist; bool found = false; float bestabs = -1.f;
   V3 bestp = p, bestn = v3(0, 0, 1);
   int stack_i[BVH_STACK]; float stack_k[BVH_STACK]; int sp = 0; int cur = 0;
-  while (true) {
-    bool go = false;
-    if (cur >= 0) {
+  // "while-while" form (see closest_point_pair)
+  bool done = false;
+  auto pop = [&]() -> bool {
+    while (sp > 0) { --sp; if (stack_k[sp] <= best2 * (1.f + 1e-5f) + 1e-12f) { cur = stack_i[sp]; return true; } }
+    return false;
+  };
+  while (!done) {
+    while (cur >= 0) {
       const Node4Regs n = load_node4(M.nodes, cur);
       int cand[4]; float key[4];
       const float lim = best2 * (1.f + 1e-5f) + 1e-12f;
@@ -180,8 +189,10 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
         key[k] = dx * dx + dy * dy + dz * dz;
         cand[k] = (c != BVH4_EMPTY && key[k] <= lim) ? c : BVH4_EMPTY;
       }
-      go = descend4(cand, key, stack_i, stack_k, sp, cur);
-    } else {
+      if (!descend4(cand, key, stack_i, stack_k, sp, cur) && !pop()) { done = true; break; }
+    }
+    if (done) break;
+    {
       const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
       // The triangles of a leaf (up to 8) are fetched four at a time, every load issued before the first test: one memory round trip per
       // four faces instead of one per face (a lane tests its faces one after the other and the wave waits for its slowest lane).
@@ -217,10 +228,7 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
         }
       }
     }
-    if (go) continue;
-    bool popped = false;
-    while (sp > 0) { --sp; if (stack_k[sp] <= best2 * (1.f + 1e-5f) + 1e-12f) { cur = stack_i[sp]; popped = true; break; } }
-    if (!popped) break;
+    if (!pop()) done = true;
   }
   *cp_out = bestp; *fn_out = bestn;
   return found;
