@@ -241,12 +241,20 @@ LG_DEV bool closest_point(const MeshView& M, V3 p, float max_dist, V3* cp_out, V
 // solo outcome.  A query with on = false is skipped.
 struct ClosestQuery { V3 p; float max_dist; bool on; bool found; V3 cp, fn;
                       float range, lb; };   // grid meshes: `range` = beyond this distance only a lower bound is wanted, returned in `lb` when nothing is found
-LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery& B, int* visits = nullptr) {
+#ifndef LG_PAIR_CHUNK
+#define LG_PAIR_CHUNK 4
+#endif
+// EXT: the traversal stack lives in memory the caller provides (ext_k / ext_i, BVH_STACK entries each, per lane) -- LDS in the physics
+// kernel.  As private arrays the stacks are scratch memory (dynamic indexing): every pop was a dependent load through L1 / L2.
+template <bool EXT>
+LG_DEV void closest_point_pair_t(const MeshView& M, ClosestQuery& A, ClosestQuery& B, float* ext_k, int* ext_i, int* visits) {
   float bestA = A.max_dist * A.max_dist, bestB = B.max_dist * B.max_dist, absA = -1.f, absB = -1.f;
   bool fA = false, fB = false;
   V3 pA = A.p, pB = B.p, cA = A.p, cB = B.p, nA = v3(0, 0, 1), nB = v3(0, 0, 1);
   const bool onA = A.on, onB = B.on;
-  int stack_i[BVH_STACK]; float stack_k[BVH_STACK]; int sp = 0; int cur = 0;
+  int loc_i[EXT ? 1 : BVH_STACK]; float loc_k[EXT ? 1 : BVH_STACK];
+  int* const stack_i = EXT ? ext_i : loc_i; float* const stack_k = EXT ? ext_k : loc_k;
+  int sp = 0; int cur = 0;
   // "while-while" form: every lane first walks inner nodes until it stands on a leaf (lanes that already do wait), then the whole wave
   // tests leaf faces together.  As one loop whose body handled "inner node or leaf", each of the wave's ~26 iterations paid for the
   // leaf branch (up to 8 faces, the expensive part) as soon as ANY lane stood on a leaf; now it is paid once per round of leaves.
@@ -280,10 +288,17 @@ LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery&
     {
       if (visits) ++*visits;
       const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
-      for (int i = 0; i < cnt; ++i) {
-        const float4* T = M.tris + (size_t)(first + i) * 3;
-        float4 a4 = T[0], b4 = T[1], c4 = T[2];
-        V3 a = v3(a4.x, a4.y, a4.z), b = v3(b4.x, b4.y, b4.z), cc = v3(c4.x, c4.y, c4.z);
+      for (int i0 = 0; i0 < cnt; i0 += LG_PAIR_CHUNK) {
+      float4 ta[LG_PAIR_CHUNK], tb[LG_PAIR_CHUNK], tc[LG_PAIR_CHUNK];      // (the faces of a leaf are fetched LG_PAIR_CHUNK at a time, as in closest_point)
+#pragma unroll
+      for (int u = 0; u < LG_PAIR_CHUNK; ++u) {
+        const float4* T = M.tris + (size_t)(first + min(i0 + u, cnt - 1)) * 3;
+        ta[u] = T[0]; tb[u] = T[1]; tc[u] = T[2];
+      }
+#pragma unroll
+      for (int u = 0; u < LG_PAIR_CHUNK; ++u) {
+        if (i0 + u >= cnt) continue;
+        V3 a = v3(ta[u].x, ta[u].y, ta[u].z), b = v3(tb[u].x, tb[u].y, tb[u].z), cc = v3(tc[u].x, tc[u].y, tc[u].z);
         const bool nearA = onA && tri_box_dist2(pA, a, b, cc) <= bestA * (1.f + 1e-5f) + 1e-12f;
         const bool nearB = onB && tri_box_dist2(pB, a, b, cc) <= bestB * (1.f + 1e-5f) + 1e-12f;
         if (!(nearA || nearB)) continue;
@@ -317,9 +332,13 @@ LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery&
           }
         }
       }
+      }
     }
     if (!pop()) done = true;
   }
   A.found = fA; A.cp = cA; A.fn = nA; B.found = fB; B.cp = cB; B.fn = nB;
+}
+LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery& B, int* visits = nullptr) {
+  closest_point_pair_t<false>(M, A, B, nullptr, nullptr, visits);
 }
 

@@ -531,6 +531,12 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 //   * bound: the surface cannot be farther than the cached distance plus the distance travelled, so the search starts
 //     with that radius instead of the full reach - a foot in stance tests a handful of triangles, not the ~60 within
 //     reach.  A reset teleports the sphere; the travel term then exceeds the reach and the bound falls back to it.
+// The BVH traversal stack of a slot pair (sp0, sp0 + 1) lives in the SET-UP blocks of the two slots' records (dwords 12..59 of this lane's
+// record: 48 >= BVH_STACK): dead while the slots are being detected -- the previous substep's sweeps are over, the set-up of this one
+// comes after the rendezvous.  Keys in the even slot's block, node indices in the odd one's.
+static_assert(CF_FIELDS - CF_SETUP >= BVH_STACK && (LG_MAX_CP % 2) == 0, "a slot record's set-up block holds one traversal stack");
+LG_DEV float* mesh_stack_k(float* cst, int sp0, int lane) { return cst + ((sp0 * 64 + lane) * CF_FIELDS + CF_SETUP); }
+LG_DEV int* mesh_stack_i(float* cst, int sp0, int lane) { return reinterpret_cast<int*>(cst + (((sp0 + 1) * 64 + lane) * CF_FIELDS + CF_SETUP)); }
 LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k,
                                 const M3& Rb, V3 pb, float* cst, int lane, float* cq = nullptr, unsigned long long* dbg = nullptr) {
   const int ncp = lm_.i(LM_CP_COUNT);
@@ -571,7 +577,7 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       int visits = 0;
       const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
       if (T.GV) { closest_point_grid(T, Q[0], &visits, (dbg && lane == 0) ? dbg : nullptr); closest_point_grid(T, Q[1], &visits, (dbg && lane == 0) ? dbg : nullptr); }
-      else closest_point_pair(T.M, Q[0], Q[1], &visits);
+      else closest_point_pair_t<true>(T.M, Q[0], Q[1], mesh_stack_k(cst, sp0, lane), mesh_stack_i(cst, sp0, lane), &visits);
       __builtin_amdgcn_s_waitcnt(0);
       if (dbg && lane == 0) dbg[53] += __builtin_amdgcn_s_memtime() - tq0;
       // diagnostic: queries issued / traversal steps (sum and max over the wave) of workgroup 0, wave 2
@@ -582,7 +588,7 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
     }
 #else
     if (T.GV) { closest_point_grid(T, Q[0]); closest_point_grid(T, Q[1]); }
-    else closest_point_pair(T.M, Q[0], Q[1]);
+    else closest_point_pair_t<true>(T.M, Q[0], Q[1], mesh_stack_k(cst, sp0, lane), mesh_stack_i(cst, sp0, lane), nullptr);
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
