@@ -488,7 +488,6 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   STAMP_DECL
   const int wv = tid >> 6, ln = tid & 63;
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
-  const int P = HI(HC_P);
   const float* MB = HB + FH_MISC;
   // Row stores, 4 envs per wave.  One store instruction covers a row of ALL FOUR envs of the wave (lane = (env q, entry i): rows are
   // 1-24 entries long), small rows share an instruction (the destination is chosen by selects): 12 stores per wave where a store per
@@ -570,41 +569,37 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   // most expensive part of this phase (the memory pipeline handles 4 lanes per 64-byte segment).
   const int O = HI(HC_NUM_OBS), G4 = (O + 3) >> 2;
   const bool inject = HI(HC_INJECT) != 0, add_noise = HI(HC_ADD_NOISE) != 0, predrawn = fused_noise_predrawn(hot);
-  const float ls = HF(HC_OS_LIN), as = HF(HC_OS_ANG), ps = HF(HC_OS_POS), vs = HF(HC_OS_VEL), hs = HF(HC_OS_H), clip = HF(HC_CLIP_OBS);
+  const float clip = HF(HC_CLIP_OBS);
   float* OB = const_cast<float*>(HB) + FH_OBS + 4 * wv * FO_STRIDE;  // this wave's staging rows, one per env: with ONE row the four envs of the wave
                                                                       // ran one after the other (row write -> wait -> row reads -> stores, four times)
   for (int g0 = 0; g0 < G4; g0 += 64) {
     const int gq = g0 + ln;
-    float nv[4], scale[4], sub[4]; int off[4], hix[4], kind[4];
+    float4 tb[4];                                  // this lane's four entries of the host-packed table (pack_obs_table)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = 4 * gq + i;
-      nv[i] = (add_noise && idx < O) ? C->noise_vec[idx] : 0.f;
-      off[i] = idx < 3 ? FS_BLV + idx : idx < 6 ? FS_BAV + idx - 3 : idx < 9 ? FS_PG + idx - 6 : idx < 12 ? FS_CMD + idx - 9
-             : idx < 24 ? FS_DOF + 2 * (idx - 12) : idx < 36 ? FS_DOF + 2 * (idx - 24) + 1 : idx < 48 ? FS_ACT + idx - 36 : 0;
-      scale[i] = idx < 3 ? ls : idx < 6 ? as : idx < 9 ? 1.f : idx < 11 ? ls : idx < 12 ? as : idx < 24 ? ps : idx < 36 ? vs : 1.f;
-      sub[i] = (idx >= 12 && idx < 24) ? HF(HC_DEFAULT_POS + min(max(idx - 12, 0), 11)) : 0.f;
-      kind[i] = idx < 48 ? 0 : (idx < 48 + P ? 1 : 2);
-      hix[i] = min(max(idx - 48, 0), MAX_P - 1);
-    }
+    for (int i = 0; i < 4; ++i) tb[i] = C->obs_tab[4 * gq + i];
     STAMP(49);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {                 // (unrolled: the four envs' Philox chains and LDS reads interleave)
+    for (int q = 0; q < 4; ++q) {                 // (unrolled: the four envs' LDS reads interleave)
       const int el = 4 * wv + q;
       if (el >= nenv) continue;
       const int e = e0 + el;
       const float* S = SR + el * FS_STRIDE; const float* H = HB + FH_HEIGHTS + el * MAX_P;
       const float rootz = MB[el * FM_STRIDE + FM_ROOTZ];
-      float u[4] = {0.5f, 0.5f, 0.5f, 0.5f}, ex[4] = {0.f, 0.f, 0.f, 0.f}, sv[4], hv[4];
+      float u[4] = {0.5f, 0.5f, 0.5f, 0.5f}, ex[4] = {0.f, 0.f, 0.f, 0.f}, val[4];
+      int kind[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { sv[i] = S[off[i]]; hv[i] = H[hix[i]]; }
+      for (int i = 0; i < 4; ++i) {
+        const int code = __float_as_int(tb[i].x), off = code & 0xffff;
+        kind[i] = code >> 16;
+        val[i] = (kind[i] == 1 ? H : S)[kind[i] <= 1 ? off : 0];
+      }
       if (add_noise && inject) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (4 * gq + i < O) u[i] = C->rand_inject[(size_t)e * (LG_RS_NOISE + O) + LG_RS_NOISE + 4 * gq + i];
       }
       if (C->extra_obs) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int idx = 4 * gq + i; if (idx < O && idx >= 48 + P) ex[i] = C->extra_obs[(size_t)e * HI(HC_NUM_EXTRA) + (idx - 48 - P)]; }
+        for (int i = 0; i < 4; ++i) if (kind[i] == 2) ex[i] = C->extra_obs[(size_t)e * HI(HC_NUM_EXTRA) + (__float_as_int(tb[i].x) & 0xffff)];
       }
       if (add_noise && !inject) {
         if (predrawn) {                            // (O <= FO_STRIDE: one pass, g0 == 0) drawn by the helper waves in front of (F)
@@ -620,10 +615,10 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
       float o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float op = (sv[i] - sub[i]) * scale[i];                                           // proprioceptive entry (LR:237-244), post-reset rows
-        const float oh = fminf(fmaxf((rootz - 0.5f) - hv[i], -1.f), 1.f) * hs;  // height entry (LR:245-247)
+        const float op = (val[i] - tb[i].z) * tb[i].y;                                              // proprioceptive entry (LR:237-244), post-reset rows
+        const float oh = fminf(fmaxf((rootz - 0.5f) - val[i], -1.f), 1.f) * tb[i].y;      // height entry (LR:245-247)
         float v = kind[i] == 0 ? op : (kind[i] == 1 ? oh : ex[i]);
-        if (add_noise) v += (2.f * u[i] - 1.f) * nv[i];
+        if (add_noise) v += (2.f * u[i] - 1.f) * tb[i].w;
         o[i] = fminf(fmaxf(v, -clip), clip);
       }
       *reinterpret_cast<float4*>(OB + q * FO_STRIDE + 4 * ln) = make_float4(o[0], o[1], o[2], o[3]);

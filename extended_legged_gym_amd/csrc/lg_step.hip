@@ -64,6 +64,7 @@ struct DevCtx {
   const float LG_G* terrain_origins;
   const float LG_G *noise_vec, *height_points;
   const float LG_G* extra_obs;   // (N, cfg.num_extra_obs) caller-owned rows appended to the observation
+  const float4 LG_G* obs_tab;    // fused tail: per observation entry (source code, scale, offset, noise scale), packed on the host (pack_obs_table)
   float LG_G* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
   float LG_G* lvl_part;     // [nblocks] : per-workgroup sum of terrain levels
   unsigned LG_G* part_flag; // [nblocks] : 1 when some env of the workgroup was reset in this step (its partials row is valid)
@@ -90,6 +91,7 @@ struct lg_ctx {
   DevCtx* d = nullptr; // device copy
   void* arena = nullptr; bool own_arena = false; size_t arena_bytes = 0;
   void* aux = nullptr; // noise_vec, height_points, partials
+  void* obs_tab = nullptr;
   void* mesh_cache = nullptr;
   void* grid_verts = nullptr;   // device copy of lg_terrain.grid_vertices
   int grid_mesh = 1;           // LG_GRID_MESH=0: walk the BVH for grid meshes too (diagnostic / A-B)
@@ -1897,6 +1899,31 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
 }
 
 #include "lg_fused_post.h"
+
+// Observation entry idx of the fused tail as one float4: x = bits(source offset | kind << 16) (kind 0: float of the env's LDS row, 1: height
+// sample, 2: extra-observation column, 3: past the row), y = scale, z = subtracted offset, w = noise scale (0 without noise).  Per lane this
+// was ~100 instructions of selects and four dependent loads at the top of the write-back of every step; it depends on the config only.
+static std::vector<float> pack_obs_table(const lg_config& g, int P) {
+  const int O = g.num_obs, Opad = ((O + 3) / 4) * 4 + 256;            // (+ 256: lanes past the last group read entry codes of kind 3)
+  std::vector<float> t((size_t)Opad * 4, 0.f);
+  for (int idx = 0; idx < Opad; ++idx) {
+    int off = 0, kind = 3; float scale = 1.f, sub = 0.f, nv = 0.f;
+    if (idx < O) {
+      const float ls = g.obs_scale_lin_vel, as = g.obs_scale_ang_vel, ps = g.obs_scale_dof_pos, vs = g.obs_scale_dof_vel;
+      off = idx < 3 ? FS_BLV + idx : idx < 6 ? FS_BAV + idx - 3 : idx < 9 ? FS_PG + idx - 6 : idx < 12 ? FS_CMD + idx - 9
+          : idx < 24 ? FS_DOF + 2 * (idx - 12) : idx < 36 ? FS_DOF + 2 * (idx - 24) + 1 : idx < 48 ? FS_ACT + idx - 36 : 0;
+      scale = idx < 3 ? ls : idx < 6 ? as : idx < 9 ? 1.f : idx < 11 ? ls : idx < 12 ? as : idx < 24 ? ps : idx < 36 ? vs : 1.f;
+      sub = (idx >= 12 && idx < 24) ? g.default_dof_pos[idx - 12] : 0.f;
+      kind = idx < 48 ? 0 : (idx < 48 + P ? 1 : 2);
+      if (kind == 1) { off = std::min(std::max(idx - 48, 0), MAX_P - 1); scale = g.obs_scale_height; }
+      if (kind == 2) off = idx - 48 - P;
+      nv = g.add_noise ? g.noise_scale_vec[idx] : 0.f;
+    }
+    const int code = off | (kind << 16);
+    memcpy(&t[(size_t)idx * 4], &code, 4); t[(size_t)idx * 4 + 1] = scale; t[(size_t)idx * 4 + 2] = sub; t[(size_t)idx * 4 + 3] = nv;
+  }
+  return t;
+}
 // glue between physics_kernel (which only sees declarations) and the tail
 LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid) { finalize_from_acc(C, nblocks, 1, tid, false); }
 LG_DEV bool fused_did_reset(const float* HB, int el) { return HB[FH_MISC + el * FM_STRIDE + FM_DID_RESET] != 0.f; }
@@ -2094,6 +2121,7 @@ void lg_destroy(lg_ctx* c) {
   DeviceScope ds_(c->device);
   if (c->d) (void)hipFree(c->d);
   if (c->aux) (void)hipFree(c->aux);
+  if (c->obs_tab) (void)hipFree(c->obs_tab);
   if (c->mesh_cache) (void)hipFree(c->mesh_cache);
   if (c->grid_verts) (void)hipFree(c->grid_verts);
   if (c->own_arena && c->arena) (void)hipFree(c->arena);
@@ -2197,6 +2225,12 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
     h.acc = (long long LG_G*)(h.tickets + 9 * 32);
   }
   if (hipMemcpy(aux, cfg->noise_scale_vec, n_noise * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy noise_scale_vec failed");
+  {
+    std::vector<float> tab = pack_obs_table(*cfg, h.P);
+    if (hipMalloc(&c->obs_tab, tab.size() * 4) != hipSuccess) return fail("hipMalloc(obs_tab) failed");
+    if (hipMemcpy(c->obs_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy obs_tab failed");
+    h.obs_tab = (const float4 LG_G*)c->obs_tab;
+  }
   if (n_hp && hipMemcpy(aux + n_noise, cfg->height_points, n_hp * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("copy height_points failed");
   if (ter->mesh_type != LG_MESH_PLANE &&
       hipMemcpy(P(LG_T_HEIGHT_SAMPLES), ter->height_samples, (size_t)ter->rows * ter->cols * 2, hipMemcpyHostToDevice) != hipSuccess)
