@@ -134,15 +134,16 @@ def main(argv=None):
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-play", action="store_true", help="skip the play-back comparison with the PhysX-trained policy")
+    ap.add_argument("--task", default="anymal_c_flat", help="registered task (anymal_c_rough: terrain curriculum; use --no-play)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "train_acceptance.json"))
     a = ap.parse_args(argv)
     torch.manual_seed(a.seed); np.random.seed(a.seed)
-    env_cfg, train_cfg = task_registry.get_cfgs("anymal_c_flat")
+    env_cfg, train_cfg = task_registry.get_cfgs(a.task)
     import copy
     env_cfg = copy.deepcopy(env_cfg)                 # (the registry's instance stays untouched)
     env_cfg.env.num_envs = a.envs
     env_cfg.seed = a.seed
-    env, env_cfg = task_registry.make_env("anymal_c_flat", args=get_args(["--headless", "--sim_device", "cuda:0"]), env_cfg=env_cfg)
+    env, env_cfg = task_registry.make_env(a.task, args=get_args(["--headless", "--sim_device", "cuda:0"]), env_cfg=env_cfg)
     tc = class_to_dict(train_cfg)
     alg, pol, T = tc["algorithm"], tc["policy"], tc["runner"]["num_steps_per_env"]
     ac = ActorCritic(env.num_obs, env.num_actions, pol["actor_hidden_dims"], pol["critic_hidden_dims"], pol["init_noise_std"]).cuda()
@@ -173,9 +174,11 @@ def main(argv=None):
         row = dict(iter=it, mean_reward=float(np.mean(retbuf)) if retbuf else 0.0, mean_episode_length=float(np.mean(lenbuf)) if lenbuf else 0.0,
                    mean_step_reward=float(rew.mean()), dones_per_env_step=float(dones.float().mean()), lr=lr, action_std=float(ac.std.mean()),
                    **{"rew_" + n: float(v) for n, v in zip(names, ep)}, **st)
+        if env.cfg.terrain.curriculum:
+            row["terrain_level"] = float(env.terrain_levels.float().mean())
         curve.append(row)
         if it % 10 == 0 or it == a.iters - 1:
-            print(f"it {it:4d}  R {row['mean_reward']:7.2f}  len {row['mean_episode_length']:6.1f}  track {row.get('rew_tracking_lin_vel', 0):.3f}  "
+            print(f"it {it:4d}  R {row['mean_reward']:7.2f}  len {row['mean_episode_length']:6.1f}  track {row.get('rew_tracking_lin_vel', 0):.3f}  level {row.get('terrain_level', 0):.2f}  "
                   f"std {row['action_std']:.2f}  lr {lr:.1e}  kl {st['kl']:.4f}  {time.time() - t0:5.0f} s", flush=True)
     env_steps = a.iters * T * a.envs
     wall = time.time() - t0
@@ -191,7 +194,7 @@ def main(argv=None):
         ref = NativeActorCritic(sd, activation="elu", device="cuda:0")
         physx = gait_statistics(lambda o: ref.act_inference(o))
     last = curve[-10:]
-    summary = dict(task="anymal_c_flat", envs=a.envs, iterations=a.iters, env_steps=env_steps, wall_s=wall,
+    summary = dict(task=a.task, final_terrain_level=float(np.mean([r.get("terrain_level", 0.0) for r in last])), envs=a.envs, iterations=a.iters, env_steps=env_steps, wall_s=wall,
                    final_rew_tracking_lin_vel=float(np.mean([r.get("rew_tracking_lin_vel", 0.0) for r in last])),
                    final_mean_episode_length=float(np.mean([r["mean_episode_length"] for r in last])),
                    home_trained_play=home, physx_trained_play=physx)
