@@ -11,12 +11,7 @@ class BaseTask:
         self.sim_params = sim_params
         self.physics_engine = physics_engine
         self.sim_device = sim_device
-        dev = torch.device(sim_device)
-        if dev.type != "cuda":
-            raise RuntimeError(f"sim_device='{sim_device}': the native env step needs an MI355X GPU (e.g. 'cuda:0'); "
-                               "the reference's Isaac-Gym CPU pipeline has no counterpart here")
-        self.sim_device_id = dev.index if dev.index is not None else 0
-        self.device = f"cuda:{self.sim_device_id}"
+        self.sim_device_id, self.device = self._resolve_sim_device(sim_device)
         self.headless = headless
         self.graphics_device_id = -1
 
@@ -39,6 +34,16 @@ class BaseTask:
         self.time_out_buf = t["time_out_buf"].view(torch.bool)
         self.enable_viewer_sync = True
         self.viewer = None
+
+    @staticmethod
+    def _resolve_sim_device(sim_device):
+        """(index, torch device name) of `sim_device`; anything but a GPU is refused: the step has no CPU path."""
+        dev = torch.device(sim_device)
+        if dev.type != "cuda":
+            raise RuntimeError(f"sim_device='{sim_device}': the native env step needs an MI355X GPU (e.g. 'cuda:0'); "
+                               "the reference's Isaac-Gym CPU pipeline has no counterpart here")
+        idx = dev.index if dev.index is not None else 0
+        return idx, f"cuda:{idx}"
 
     # the PPO runner rebinds this attribute (on_policy_runner.py:358-361); keep the native buffer authoritative
     @property
