@@ -121,6 +121,12 @@ class lg_tile_spec(C.Structure):
 LG_TILE_FLAT, LG_TILE_PYRAMID_SLOPE, LG_TILE_PYRAMID_STAIRS, LG_TILE_DISCRETE_OBSTACLES = 0, 1, 2, 3
 
 
+class lg_pose_params(C.Structure):
+    _fields_ = [("ranges", (f32 * 2) * 4), ("resampling_steps", i32), ("scale_orientation", f32), ("scale_base_height", f32),
+                ("scale_termination", f32), ("only_positive_rewards", i32), ("max_episode_length_s", f32), ("clip_observations", f32),
+                ("num_heights", i32)]
+
+
 class lg_depth_params(C.Structure):
     _fields_ = [("width", i32), ("height", i32), ("resized_width", i32), ("resized_height", i32), ("buffer_len", i32),
                 ("near_clip", f32), ("far_clip", f32), ("position", f32 * 3), ("quat_offset", f32 * 4)]
@@ -173,6 +179,8 @@ def declare_product(lib):
     lib.lg_terrain_generate.restype = C.c_int
     lib.lg_heightfield_to_trimesh.argtypes = [vp, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]
     lib.lg_heightfield_to_trimesh.restype = C.c_int
+    lib.lg_pose_layer_step.argtypes = [C.POINTER(lg_pose_params), i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.lg_pose_layer_step.restype = C.c_int
     lib.lg_mesh_create.argtypes = [C.POINTER(f32), C.c_int64, C.POINTER(i32), C.c_int64, C.c_int]
     lib.lg_mesh_create.restype = vp
     lib.lg_mesh_destroy.argtypes = [vp]
@@ -242,4 +250,4 @@ PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
                    "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_last_error",
                    "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update",
-                   "lg_terrain_generate", "lg_heightfield_to_trimesh", "lg_set_reward_terms", "lg_set_async_gait", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed"]
+                   "lg_terrain_generate", "lg_heightfield_to_trimesh", "lg_pose_layer_step", "lg_set_reward_terms", "lg_set_async_gait", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed"]

@@ -200,6 +200,40 @@ def pose_layer_step(st, nat, u_cb, u_reset, noise_u, par):
     return torch.clip(obs, -par["clip_observations"], par["clip_observations"]), rew
 
 
+def pose_layer_step_native(st, nat, u8, noise_u, par, obs_out, rew_out, acc):
+    """`pose_layer_step` as two launches of the library (`lg_pose_layer_step`, csrc/lg_pose.hip) on the current stream: same inputs (device
+    tensors; `u8` = the callback and reset draws side by side, (N, 8)), results into `obs_out` (N, 52 + P) and `rew_out` (N,), `st` updated in
+    place; `acc` is the caller's scratch of three doubles (zero before the first call)."""
+    import ctypes as C
+    from extended_legged_gym_amd import abi
+    from extended_legged_gym_amd.native import load_library
+    lib = load_library()
+    pp = abi.lg_pose_params()
+    r = par["ranges"].detach().cpu().tolist()
+    for k in range(4):
+        pp.ranges[k][0], pp.ranges[k][1] = r[k][0], r[k][1]
+    pp.resampling_steps = int(par["resampling_steps"])
+    pp.scale_orientation, pp.scale_base_height, pp.scale_termination = par["scale_orientation"], par["scale_base_height"], par["scale_termination"]
+    pp.only_positive_rewards = int(par["only_positive_rewards"])
+    pp.max_episode_length_s, pp.clip_observations = par["max_episode_length_s"], par["clip_observations"]
+    h = nat["measured_heights"]
+    pp.num_heights = 0 if h is None else int(h.shape[1])
+    n = int(nat["rew"].shape[0])
+    cmd, bz = st["pose_cmd"], nat["base_z"]
+    assert cmd.stride(1) == 1 and st["sums"].is_contiguous() and u8.is_contiguous() and obs_out.is_contiguous() and nat["obs"].is_contiguous()
+    assert nat["reset"].element_size() == 1 and nat["time_out"].element_size() == 1 and nat["eplen_before"].dtype == torch.int64
+
+    def p(t):
+        return C.c_void_p(None if t is None else t.data_ptr())
+    rc = lib.lg_pose_layer_step(C.byref(pp), n, p(cmd), int(cmd.stride(0)), p(st["sums"]), p(st["extras"]), p(nat["obs"]), p(nat["rew"]),
+                                p(nat["reset"]), p(nat["time_out"]), p(nat["eplen_before"]), p(bz), int(bz.stride(0)), p(nat["projected_gravity"]),
+                                p(h), p(u8), p(noise_u), p(par["noise_scale_vec"]), p(obs_out), p(rew_out), p(acc),
+                                C.c_void_p(torch.cuda.current_stream(obs_out.device).cuda_stream))
+    if rc != abi.LG_OK:
+        raise RuntimeError(f"lg_pose_layer_step failed ({rc})")
+    return obs_out, rew_out
+
+
 class pose_native_cfg:
     """Context: `cfg` as the native step under `PoseAnymal` sees it -- the 48 (+ heights) observation row without noise, the
     reward sum without the two pose terms and without the positivity clip -- restored on exit."""
@@ -241,10 +275,10 @@ class PoseCommandsMixin:
     commanded pose.
 
     The native step runs the robot, the twelve-joint actuator, contacts, the other reward terms, termination, resets and the
-    48-entry observation row; `pose_layer_step` (device torch ops after `lg_step`, about twenty small launches) adds what the
-    class adds.  `commands` is this class's own (N, 8) tensor: columns 0-3 are copied into the native tensor before every step
-    and back after it, so host writes (`play.py` fixes them) still reach the kernel.  This is class glue of one task, kept out of
-    the fused kernel; its cost (~0.2 ms per step) is not part of any measured number."""
+    48-entry observation row; `lg_pose_layer_step` (two launches behind `lg_step`; `pose_layer_step` is the same arithmetic in torch and
+    its checker) adds what the class adds.  `commands` is this class's own (N, 8) tensor: columns 0-3 are copied into the native tensor before every step
+    and back after it, so host writes (`play.py` fixes them) still reach the kernel.  This is class glue of two tasks, kept out
+    of the fused kernel."""
 
     def __init__(self, cfg, sim_params, physics_engine, sim_device, headless):
         full = (cfg.env.num_observations, cfg.noise.add_noise)
@@ -260,6 +294,7 @@ class PoseCommandsMixin:
                           extras=torch.zeros(2, device=self.device))
         self.obs_buf = torch.zeros(self.num_envs, self.num_obs, device=self.device)
         self.rew_buf = torch.zeros(self.num_envs, device=self.device)
+        self._pose_acc = torch.zeros(3, dtype=torch.float64, device=self.device)
         for k, name in enumerate(("orientation", "base_height")):
             if self._pose_par["scale_" + name] != 0.:
                 self.reward_scales[name] = self._pose_par["scale_" + name]
@@ -283,8 +318,8 @@ class PoseCommandsMixin:
                    base_z=t["rigid_body_state"][:, 0, 2], projected_gravity=self.projected_gravity,
                    measured_heights=self.measured_heights if self.cfg.terrain.measure_heights else None)
         noise_u = torch.rand(n, self.num_obs, device=self.device) if self.add_noise else None
-        self.obs_buf, rew = pose_layer_step(self._pose, nat, u[:, :4], u[:, 4:], noise_u, self._pose_par)
-        self.rew_buf.copy_(rew)            # in place, as `compute_reward` writes it (`legged_robot.py:222`); obs_buf is rebound there too
+        # two launches of the library (csrc/lg_pose.hip); `pose_layer_step` above is the same arithmetic in torch and stays as its checker
+        pose_layer_step_native(self._pose, nat, u, noise_u, self._pose_par, self.obs_buf, self.rew_buf, self._pose_acc)
         self.commands[:, :4] = self._native_commands
 
     def step(self, actions):

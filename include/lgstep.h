@@ -440,6 +440,30 @@ int lg_depth_camera_update(lg_mesh* mesh, const lg_depth_params* params, const f
                            const int64_t* episode_length_buf, int32_t num_envs, const float* env_noise,
                            float* camera_pos, float* camera_rot, float* depth_buffer, void* stream);
 
+/* ---- PoseAnymal / PoseGo2 (reference envs/anymal_c/anymal.py:146-250, envs/go2/go2.py:146-246): what those classes add to a step, behind
+ * lg_step on the same stream.  In the reference's order: envs whose episode length hits a multiple of the resampling period draw the four pose
+ * channels (yaw / pitch / roll shift, base height) from `ranges` with the uniforms u[:, 0:4]; `_reward_orientation` against the commanded pitch /
+ * roll and `_reward_base_height` against the commanded height are added to the native reward (which ran without these two terms and without the
+ * positivity clip) before the clip, the termination term after it (legged_robot.py:226-232); the two terms' episode sums (2, n) accumulate, the
+ * sums of the envs reset in this step go to `extras` as means over those envs / max_episode_length_s and are cleared; reset envs draw again
+ * (u[:, 4:8]); observation rows = native[0:12] | pose channels | native[12:], + (2 noise_u - 1) * noise_scale_vec when noise_u is given, clipped.
+ * pose_cmd: rows of `cmd_stride` floats (columns 4..7 of the class's (n, 8) commands tensor); base_z: root height before the reset, one value per
+ * `base_z_stride` floats (column 2 of the base row of rigid_body_state); measured_heights (n, num_heights) or NULL; acc: 3 doubles, zero before the
+ * first call, owned by the caller (left zero by every call).  Device pointers; asynchronous on `stream`. */
+typedef struct lg_pose_params {
+  float ranges[4][2];                    /* commands.ranges: base_yaw_shift, base_pitch_shift, base_roll_shift, base_height */
+  int32_t resampling_steps;              /* int(commands.resampling_time / dt) */
+  float scale_orientation, scale_base_height, scale_termination;   /* rewards.scales x dt */
+  int32_t only_positive_rewards;
+  float max_episode_length_s, clip_observations;
+  int32_t num_heights;                   /* height-scan points in the native row (0 without measure_heights) */
+} lg_pose_params;
+int lg_pose_layer_step(const lg_pose_params* params, int32_t n, float* pose_cmd, int32_t cmd_stride, float* sums, float* extras,
+                       const float* nat_obs, const float* nat_rew, const uint8_t* reset, const uint8_t* time_out, const int64_t* eplen_before,
+                       const float* base_z, int32_t base_z_stride, const float* projected_gravity, const float* measured_heights,
+                       const float* u, const float* noise_u, const float* noise_scale_vec, float* obs_out, float* rew_out, double* acc,
+                       void* stream);
+
 /* Per-kernel timing with HIP events recorded on the caller's stream around the kernels of lg_step.
  * lg_profile_begin arms up to `max_samples` instrumented steps (every `stride`-th lg_step call is sampled);
  * lg_profile_end synchronises the events and returns the mean duration in ms of {physics, post-physics, finalize}

@@ -20,7 +20,7 @@ RTOL, ATOL = 2e-5, 2e-6
 POSE_TERMS = ("orientation", "base_height")
 
 
-def run_case(make_core, to_np, from_np):
+def run_case(make_core, to_np, from_np, native_layer=False):
     z, meta = load_golden("flat_pose")
     cfg, s = golden_setup(z, meta)
     names = meta["reward_names"]
@@ -64,7 +64,20 @@ def run_case(make_core, to_np, from_np):
                    projected_gravity=g("projected_gravity"), measured_heights=None)
         up = torch.from_numpy(np.nan_to_num(z["rand_pose"][t], nan=0.0))
         noise_u = torch.from_numpy(z["rand"][t][:, abi.LG_RS_NOISE:abi.LG_RS_NOISE + 52].copy())
-        obs, rew = pose_layer_step(st, nat, up[:, :4], up[:, 4:], noise_u, par)
+        if native_layer:          # the library's two launches (lg_pose_layer_step) instead of the torch restatement
+            from extended_legged_gym_amd.envs.anymal_c.anymal import pose_layer_step_native
+            dv = lambda x: None if x is None else x.cuda().contiguous()      # noqa: E731
+            st_d = {k: dv(v) for k, v in st.items()}
+            nat_d = {k: dv(v) for k, v in nat.items()}
+            par_d = dict(par, ranges=par["ranges"].cuda(), noise_scale_vec=par["noise_scale_vec"].cuda())
+            acc = torch.zeros(3, dtype=torch.float64, device="cuda")
+            obs_d, rew_d = torch.zeros(N, 52, device="cuda"), torch.zeros(N, device="cuda")
+            pose_layer_step_native(st_d, nat_d, dv(up), dv(noise_u), par_d, obs_d, rew_d, acc)
+            assert float(acc.abs().sum()) == 0.0                       # left clear for the next step
+            obs, rew = obs_d.cpu(), rew_d.cpu()
+            st = {k: v.cpu() for k, v in st_d.items()}
+        else:
+            obs, rew = pose_layer_step(st, nat, up[:, :4], up[:, 4:], noise_u, par)
         assert np.array_equal(nat["reset"].numpy(), z["reset"][t].astype(bool)), f"step {t}: reset"
         np.testing.assert_allclose(obs.numpy(), z["obs"][t], rtol=RTOL, atol=ATOL, err_msg=f"step {t}: obs")
         np.testing.assert_allclose(rew.numpy(), z["rew"][t], rtol=RTOL, atol=ATOL, err_msg=f"step {t}: rew")
@@ -94,6 +107,48 @@ def test_pose_layer_over_the_hip_step_matches_the_reference():
     from extended_legged_gym_amd.native import NativeCore
     run_case(lambda s: NativeCore(s, "cuda:0"), lambda a: a.detach().cpu().numpy(),
              lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda())
+
+
+@pytest.mark.gpu
+def test_native_pose_kernels_match_the_reference():
+    """The same vectors through `lg_pose_layer_step` (csrc/lg_pose.hip), the path the env classes run."""
+    from extended_legged_gym_amd.native import NativeCore
+    run_case(lambda s: NativeCore(s, "cuda:0"), lambda a: a.detach().cpu().numpy(),
+             lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda(), native_layer=True)
+
+
+@pytest.mark.gpu
+def test_native_pose_kernels_match_the_torch_layer_with_a_height_scan():
+    """Random inputs incl. a height scan in the row (the golden case has none), callback hits, resets and time-outs."""
+    from extended_legged_gym_amd.envs.anymal_c.anymal import pose_layer_step_native
+    g = torch.Generator().manual_seed(0)
+    n, P = 333, 187
+    par = dict(ranges=torch.tensor([[0.0, 0.0], [-0.5, 0.5], [-0.3, 0.3], [0.3, 0.7]]), resampling_steps=7, scale_orientation=-0.1, scale_base_height=-0.4,
+               scale_termination=-2.0, only_positive_rewards=True, max_episode_length_s=20.0, clip_observations=3.0,
+               noise_scale_vec=0.1 * torch.rand(52 + P, generator=g))
+    st = dict(pose_cmd=torch.rand(n, 8, generator=g)[:, 4:8], sums=torch.randn(2, n, generator=g), extras=torch.tensor([1.5, -2.5]))
+    acc = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for it in range(4):
+        reset = torch.rand(n, generator=g) < (0.2 if it != 2 else 0.0)              # (step 2: no reset, the extras stay)
+        nat = dict(obs=torch.randn(n, 48 + P, generator=g) * 2, rew=torch.randn(n, generator=g), reset=reset, time_out=reset & (torch.rand(n, generator=g) < 0.5),
+                   eplen_before=torch.randint(0, 30, (n,), generator=g), base_z=torch.rand(n, 5, generator=g)[:, 2], projected_gravity=torch.randn(n, 3, generator=g),
+                   measured_heights=torch.rand(n, P, generator=g) - 0.5)
+        u, noise_u = torch.rand(n, 8, generator=g), torch.rand(n, 52 + P, generator=g)
+        dv = lambda x: x.cuda() if isinstance(x, torch.Tensor) else x      # noqa: E731
+        st_d = dict(pose_cmd=st["pose_cmd"].cuda(), sums=st["sums"].clone().cuda(), extras=st["extras"].clone().cuda())   # (pose_cmd stays a strided view)
+        cmd_full = torch.zeros(n, 8, device="cuda"); cmd_full[:, 4:8] = st_d["pose_cmd"]; st_d["pose_cmd"] = cmd_full[:, 4:8]
+        nat_d = {k: dv(v) for k, v in nat.items()}
+        nat_d["base_z"] = nat["base_z"].contiguous().cuda()
+        par_d = dict(par, ranges=par["ranges"].cuda(), noise_scale_vec=par["noise_scale_vec"].cuda())
+        obs_d, rew_d = torch.zeros(n, 52 + P, device="cuda"), torch.zeros(n, device="cuda")
+        pose_layer_step_native(st_d, nat_d, u.cuda(), noise_u.cuda(), par_d, obs_d, rew_d, acc)
+        obs, rew = pose_layer_step(st, nat, u[:, :4], u[:, 4:], noise_u, par)
+        torch.testing.assert_close(obs_d.cpu(), obs, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rew_d.cpu(), rew, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(st_d["pose_cmd"].cpu(), st["pose_cmd"], rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(st_d["sums"].cpu(), st["sums"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(st_d["extras"].cpu(), st["extras"], rtol=1e-5, atol=1e-6)
+        assert float(acc.abs().sum()) == 0.0
 
 
 def test_exp_quat_heading_drops_out_of_the_expected_gravity():
