@@ -1427,6 +1427,9 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   const int P = g.measure_heights ? C->P : 0;
   const int64_t step = ro ? C->counters[3] + 1 : C->counters[0] + 1;   // LR:123 (finalize_kernel stores it)
   const uint32_t rstream = ro ? 2u : 0u;
+  // what the gait term's "has a scheduler step run yet" test sees (reward_term: step <= 1 -> nothing): a rollout step of AnymalCBatchRollout
+  // sees the phases left by the main steps before it
+  const int64_t gstep = ro ? C->counters[0] + 1 : step;
   const float dt = g.sim_dt * g.decimation;
   const int B = C->B;
 #ifdef LG_STAMPS
@@ -1700,7 +1703,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
     if (have && sl == 0 && kfat < g.num_reward_terms) {
 #pragma unroll
       for (int f = 0; f < 4; ++f) { L.s_old[el][f] = V.air[f]; L.s_old[el][4 + f] = V.ctime[f]; L.s_oldc[el][f] = V.lastc[f]; }
-      L.s_rk[el][kfat] = reward_term(C, V, e, LG_REW_FEET_AIR_TIME, L.s_fsum[el], L.s_fn[el], L.s_bh[el], step) * g.reward_scales[kfat];
+      L.s_rk[el][kfat] = reward_term(C, V, e, LG_REW_FEET_AIR_TIME, L.s_fsum[el], L.s_fn[el], L.s_bh[el], gstep) * g.reward_scales[kfat];
     }
     lds_barrier();
     // (2.3b) every other term on its own lane (they only read); more than sixteen terms take a second round
@@ -1709,7 +1712,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
       const int id = g.reward_term_ids[k];
       EnvView Vk = V;
       if (k < kfat && kfat < g.num_reward_terms) { Vk.air = L.s_old[el]; Vk.ctime = L.s_old[el] + 4; Vk.lastc = L.s_oldc[el]; }
-      L.s_rk[el][k] = id != LG_REW_TERMINATION ? reward_term(C, Vk, e, id, L.s_fsum[el], L.s_fn[el], L.s_bh[el], step) * g.reward_scales[k] : 0.f;
+      L.s_rk[el][k] = id != LG_REW_TERMINATION ? reward_term(C, Vk, e, id, L.s_fsum[el], L.s_fn[el], L.s_bh[el], gstep) * g.reward_scales[k] : 0.f;
     }
     lds_barrier();
     STAMP(21);

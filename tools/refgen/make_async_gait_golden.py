@@ -40,6 +40,20 @@ def main():
                dof_nominal_pos=np.array(ag.dof_nominal_pos, np.float32), dof_nominal_pos_weight=np.array(ag.dof_nominal_pos_weight, np.float32),
                shipped_weight_len=np.int32(len(shipped)), shipped_weight_error=np.frombuffer(err.encode(), dtype=np.uint8))
     ag.dof_nominal_pos_weight = shipped
+    # the time-driven GaitScheduler of AnymalCBatchRollout (`anymal_c_batch_rollout.py:69-82, 143-149, 222-225`): step(foot_pos, foot_vel, cmd, t)
+    # with the env's scalar clock, then reward_foot_z_track() on what that step stored
+    from legged_gym.utils.gait_scheduler import GaitScheduler
+    gs_cfg = task_registry.env_cfgs["anymal_c_dialmpc_flat"].gait_scheduler
+    g = GaitScheduler(None, None, None, None, None, dof, None, foot, None, N, "cpu", gait_cfg=gs_cfg)
+    out["tg_before_first_step"] = g.reward_foot_z_track().numpy()
+    ts = np.array([0.0, 0.02, 0.26, 0.5, 0.74, 1.0, 3.3400000000000003, 12.580000000000002], np.float64)     # sums of 0.02 as the env accumulates them
+    feet_t = 0.1 * torch.rand(len(ts), N, 4, 3)
+    tg_idx, tg_rew = [], []
+    for k, t in enumerate(ts):
+        g.step(feet_t[k], None, None, float(t))
+        tg_idx.append(g.gait_idx.numpy().copy()); tg_rew.append(g.reward_foot_z_track().numpy())
+    out.update(tg_t=ts, tg_feet=feet_t.numpy(), tg_gait_idx=np.stack(tg_idx), tg_reward=np.stack(tg_rew),
+               tg_period=np.float64(gs_cfg.period), tg_swing_height=np.float64(gs_cfg.swing_height), tg_foot_phases=np.array(gs_cfg.foot_phases, np.float64))
     path = os.path.join(ref_loader.REPO_ROOT, "tests", "golden", "async_gait.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "| shipped config error:", err)
