@@ -25,11 +25,11 @@ rc = lib.lg_debug_read_stamps(env.core.ctx, out)
 import extended_legged_gym_amd.native as nat
 print('lib', nat.LIB_PATH, 'rc', rc)
 STEPS = 301
-sub = {15: "substep prologue", 0: "publish q/qd | inline actuator", 1: "kinematics", 2: "bias (RNEA)", 3: "CRBA+Schur+chol",
+sub = {15: "substep prologue", 0: "publish q/qd | inline actuator", 1: "kinematics", 2: "bias set-up | mesh terrains: this wave's contact queries", 3: "CRBA+Schur+chol",
        29: "own contact detection", 5: "wait at rendezvous (A2) + slot mask", 6: "contact pass B (setup)", 4: "wait for torques (barrier B)",
        7: "unconstrained + solver passes", 8: "limits+forces+integrate", 9: "fault guard", 10: "write-back + final FK"}
 tail = {39: "publish final state + wait at (F)", 11: "TAIL: main part 1 (rows, features, rotations)", 19: "TAIL: wait at (G1)", 20: "TAIL: serial part (callback, rewards, reset)",
-        21: "TAIL: wait at (G2)", 12: "TAIL: state stores", 32: "TAIL wb: row stores", 33: "TAIL wb: stats + ticket", 49: "TAIL wb: obs rows: per-lane set-up (noise scales, offsets)", 50: "TAIL wb: obs rows: Philox + entries -> LDS rows", 34: "TAIL wb: obs rows: LDS rows -> global stores",
+        21: "TAIL: wait at (G2)", 12: "TAIL: state stores", 32: "TAIL wb: row stores", 33: "TAIL wb: stats + ticket", 49: "TAIL wb: obs rows: entry table loads", 50: "TAIL wb: obs rows: entries (+ noise) -> LDS rows", 34: "TAIL wb: obs rows: LDS rows -> global stores",
         13: "TAIL: (call overhead)", 14: "TAIL: arrival + finalize"}
 helper = {40: "HELPER: wait at (A) [recurrent half + the main wave's sweeps]", 41: "HELPER: state fetch + kinematics", 42: "HELPER: bias / detection loads",
           43: "HELPER: LSTM input half + detection finish", 44: "HELPER: wait at (A2)", 45: "HELPER: contact set-up share"}
