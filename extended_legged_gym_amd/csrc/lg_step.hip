@@ -474,6 +474,14 @@ LG_DEV int xcd_block(unsigned b, unsigned nb) {
   const unsigned x = b & 7u, i = b >> 3, per = nb >> 3, rem = nb & 7u;
   return (int)(x * per + min(x, rem) + i);
 }
+// The context pointer behind an opaque zero: loads through it cannot be scheduled in front of this point.  The tail of a fused step reads ~40
+// row pointers and scalars of the context; hoisted to the top of the kernel as "invariant" scalar loads they sat in SGPRs through the whole
+// substep loop -- i.e. were spilled to VGPR lanes in the wave prologues and read back in the tail (~140 of the kernel's ~200 SGPR spills).
+LG_DEV const DevCtx* late_ctx(const DevCtx* C) {
+  long zero;
+  asm volatile("s_mov_b64 %0, 0" : "=s"(zero));
+  return reinterpret_cast<const DevCtx*>(reinterpret_cast<const char*>(C) + zero);
+}
 #define FUSED_STATS_WAVE 1   // which wave of a fused workgroup adds the statistics, draws the arrival ticket and tests for the last arrival (a helper wave: with the rigid-body rows moved in front of (G2) the helpers reach the write-back with less left to do than the main wave; A/B -0.5 %)
 LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out);
 LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid);
@@ -673,7 +681,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (fuse && sub + 1 == nsub) {                   // ... in the last substep: what the post-physics tail needs from HBM
         if (net) *fused_act_slot(xs, lane, d) = a;     // (the mass-factor table is dead after (A3): the env rows live there)
         STAMP(46);                                     // (diagnostic: (A3) of the last substep)
-        fused_prefetch(C, xs, &xbias[0][0], bid, n, (wv - 1) * 64 + lane, fstep, sink.values);
+        fused_prefetch(late_ctx(C), xs, &xbias[0][0], bid, n, (wv - 1) * 64 + lane, fstep, sink.values);
 #ifdef LG_STAMPS
         __builtin_amdgcn_s_waitcnt(0);
 #endif
@@ -684,15 +692,16 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     const bool predraw = fuse && fused_noise_predrawn(hot);
     if (predraw) fused_noise_draw(hot, bid, n, (wv - 1) * 64 + lane, fstep, nz);   // (these waves would wait for the main wave's last sweeps now)
     lds_barrier();                                     // (F) main wave has published the final state of the step
+    const DevCtx* const Ct = late_ctx(C);                // (everything behind the last substep reads the context through this: see late_ctx)
     STAMP(48);
     if (predraw) fused_noise_park(hot, cst, bid, n, (wv - 1) * 64 + lane, nz);
-    if (TMESH && valid) mesh_cache_io<false>(C, cqc, e, l, lane, 2 * wv);
+    if (TMESH && valid) mesh_cache_io<false>(Ct, cqc, e, l, lane, 2 * wv);
     bool zero_state = false;
     if (!fuse) {
       if (valid) {                                       // wave w stores link w-1 of every leg (+ base / + foot body)
         float r13[13], qq[3], qdd[3];
         fetch_state(xst[lane], r13, qq, qdd);
-        write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, wv - 1);
+        write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, wv - 1);
       }
     } else {
       // fused step: first what the rest of the tail waits for (the height scan; the feet rows when a reward term reads them),
@@ -700,27 +709,27 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       const bool feet_early = fused_needs_feet_rows(C);  // (kernel-uniform)
       if (feet_early && wv == 3 && valid) {
         if (g.inject_sim_state) {                        // parity tests: the feet rows the caller injected
-          const float* o = C->rigid + ((size_t)e * C->B + 1 + C->per_leg * l + (C->per_leg == 4 ? 3 : 2)) * 13;
+          const float* o = Ct->rigid + ((size_t)e * Ct->B + 1 + Ct->per_leg * l + (Ct->per_leg == 4 ? 3 : 2)) * 13;
           float* fr = fused_foot_row(xs, lane);
 #pragma unroll
           for (int i = 0; i < 13; ++i) fr[i] = o[i];
         } else {
           float r13[13], qq[3], qdd[3];
           fetch_state(xst[lane], r13, qq, qdd);
-          write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane));   // (gait_foot_z is stored late: the serial part still reads the old one)
+          write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane));   // (gait_foot_z is stored late: the serial part still reads the old one)
         }
       }
-      fused_height_scan(C, xst, cst, bid, n, (wv - 1) * 64 + lane);
+      fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane);
       // the rigid-body rows (stores nobody in this launch reads) while the main wave runs the serial part: these waves wait ~6 k cycles for
       // it at (G2); behind the write-back, where they used to be, they were on the tail of the launch
       if (valid && g.inject_sim_state) {                         // parity tests: the injected rows stay; gait_foot_z from the injected foot row
-        if (wv == 3 && g.gait_enabled) C->gait_foot_z[(size_t)e * 4 + l] = C->rigid[((size_t)e * C->B + 1 + C->per_leg * l + (C->per_leg == 4 ? 3 : 2)) * 13 + 2];
+        if (wv == 3 && g.gait_enabled) Ct->gait_foot_z[(size_t)e * 4 + l] = Ct->rigid[((size_t)e * Ct->B + 1 + Ct->per_leg * l + (Ct->per_leg == 4 ? 3 : 2)) * 13 + 2];
       } else if (valid && !(feet_early && wv == 3)) {            // rigid-body rows of the post-physics (pre-reset) pose, LR:118-120
         float r13[13], qq[3], qdd[3];
         fetch_state(xst[lane], r13, qq, qdd);
-        write_rigid_body_state(C, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled) ? C->gait_foot_z + (size_t)e * 4 + l : nullptr);
+        write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled) ? Ct->gait_foot_z + (size_t)e * 4 + l : nullptr);
       } else if (valid && g.gait_enabled) {
-        C->gait_foot_z[(size_t)e * 4 + l] = fused_foot_row(xs, lane)[2];
+        Ct->gait_foot_z[(size_t)e * 4 + l] = fused_foot_row(xs, lane)[2];
       }
       STAMP(51);
       if (feet_early || fused_needs_heights_early(C)) lds_barrier();   // (G1) only when the serial part reads a helper's product
@@ -733,22 +742,22 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #pragma unroll
         for (int i = 0; i < 8; ++i) { h0[i] = 0.f; c0[i] = 0.f; h1[i] = 0.f; c1[i] = 0.f; }
       }
-      float4* p = (float4*)(C->sea_h + row * 8);
+      float4* p = (float4*)(Ct->sea_h + row * 8);
       p[0] = make_float4(h0[0], h0[1], h0[2], h0[3]); p[1] = make_float4(h0[4], h0[5], h0[6], h0[7]);
-      p = (float4*)(C->sea_c + row * 8);
+      p = (float4*)(Ct->sea_c + row * 8);
       p[0] = make_float4(c0[0], c0[1], c0[2], c0[3]); p[1] = make_float4(c0[4], c0[5], c0[6], c0[7]);
-      p = (float4*)(C->sea_h + (N12 + row) * 8);
+      p = (float4*)(Ct->sea_h + (N12 + row) * 8);
       p[0] = make_float4(h1[0], h1[1], h1[2], h1[3]); p[1] = make_float4(h1[4], h1[5], h1[6], h1[7]);
-      p = (float4*)(C->sea_c + (N12 + row) * 8);
+      p = (float4*)(Ct->sea_c + (N12 + row) * 8);
       p[0] = make_float4(c1[0], c1[1], c1[2], c1[3]); p[1] = make_float4(c1[4], c1[5], c1[6], c1[7]);
-      C->actions[(size_t)e * 12 + d] = a;
-      if (!(fuse && g.inject_sim_state)) C->torques[(size_t)e * 12 + d] = xtau[j][lane];
+      Ct->actions[(size_t)e * 12 + d] = a;
+      if (!(fuse && g.inject_sim_state)) Ct->torques[(size_t)e * 12 + d] = xtau[j][lane];
     }
     if (fuse) {
-      const bool last = fused_writeback_obs(C, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out);
+      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out);
       if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last ? 1 : 0;
       __syncthreads();
-      if (s_last_f) fused_finalize(C, gridDim.x, threadIdx.x);
+      if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x);
     }
     return;
   }
@@ -882,19 +891,20 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
   }
   STAMP(9);
+  const DevCtx* const Ct = late_ctx(C);                  // (see late_ctx)
   if (fuse && g.inject_sim_state) {
     // parity tests (lg_config.inject_sim_state): the post-physics half starts from the post-simulation state the caller left in the
     // tensors -- this workgroup's rows still hold it, nothing of this launch has stored to them yet
-    const int per_leg = C->per_leg, B = C->B;
+    const int per_leg = Ct->per_leg, B = Ct->B;
     const int ee = valid ? e : 0;
 #pragma unroll
-    for (int i = 0; i < 13; ++i) s.root[i] = C->root[(size_t)ee * 13 + i];
+    for (int i = 0; i < 13; ++i) s.root[i] = Ct->root[(size_t)ee * 13 + i];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      s.q[j] = C->dof[((size_t)ee * 12 + 3 * l + j) * 2]; s.qd[j] = C->dof[((size_t)ee * 12 + 3 * l + j) * 2 + 1];
-      tau[j] = C->torques[(size_t)ee * 12 + 3 * l + j];
+      s.q[j] = Ct->dof[((size_t)ee * 12 + 3 * l + j) * 2]; s.qd[j] = Ct->dof[((size_t)ee * 12 + 3 * l + j) * 2 + 1];
+      tau[j] = Ct->torques[(size_t)ee * 12 + 3 * l + j];
     }
-    const float* cf = C->cforce + (size_t)ee * B * 3;
+    const float* cf = Ct->cforce + (size_t)ee * B * 3;
     fbody[0] = v3(cf[0], cf[1], cf[2]);
 #pragma unroll
     for (int b = 0; b < 3; ++b) { const float* cl = cf + (size_t)(1 + per_leg * l + b) * 3; fbody[1 + b] = v3(cl[0], cl[1], cl[2]); }
@@ -914,16 +924,16 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   STAMP(39);
   if (fuse) {
     // ---- fused step: the post-physics step of the workgroup's envs, from the registers of this wave (lg_fused_post.h)
-    fused_main_and_serial(C, hot, lm_, xs, &xbias[0][0], cst, lane, e, valid, s.root, s.q, s.qd, tau, last_qd, fbody, split ? nullptr : act, fault, fstep, stamps, sink);
+    fused_main_and_serial(Ct, hot, lm_, xs, &xbias[0][0], cst, lane, e, valid, s.root, s.q, s.qd, tau, last_qd, fbody, split ? nullptr : act, fault, fstep, stamps, sink);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     if (valid) {
-      if (TMESH && helpers) mesh_cache_io<false>(C, cqc, e, l, lane, 0);
+      if (TMESH && helpers) mesh_cache_io<false>(Ct, cqc, e, l, lane, 0);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) if (!split) C->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
-      const int per_leg = C->per_leg, B = C->B;
-      float* cf = C->cforce + (size_t)e * B * 3;
+      for (int j = 0; j < 3; ++j) if (!split) Ct->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
+      const int per_leg = Ct->per_leg, B = Ct->B;
+      float* cf = Ct->cforce + (size_t)e * B * 3;
       if (l == 0) { cf[0] = fbody[0].x; cf[1] = fbody[0].y; cf[2] = fbody[0].z; }
       float* cl = cf + (size_t)(1 + per_leg * l) * 3;
       V3 last = fbody[3];
@@ -934,14 +944,14 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (per_leg == 4) { cl[9] = fbody[4].x; cl[10] = fbody[4].y; cl[11] = fbody[4].z; }
     }
     STAMP(12);
-    const bool last_wg = fused_writeback_obs(C, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out);
+    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     STAMP(13);
     if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last_wg ? 1 : 0;
     __syncthreads();
-    if (s_last_f) fused_finalize(C, gridDim.x, threadIdx.x);
+    if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x);
     STAMP(14);
 #ifdef LG_STAMPS
     if (stamps) stamps[36] += __builtin_amdgcn_s_memtime() - t_entry;      // the main wave's whole kernel

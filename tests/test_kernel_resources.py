@@ -35,9 +35,10 @@ def test_headline_kernel_register_and_lds_budget(tmp_path):
     r = blocks[key[0]]
     print(r)
     assert r["VGPRs Spill"] == 0, r
-    # round 2: 1 157.  What is left (~200) is written once per launch in the wave prologues (config scalars and row pointers of the fused
-    # tail that stay live through the substep loop) and read back where used; none of it is inside the Gauss-Seidel passes
-    assert r["SGPRs Spill"] <= 256, r
+    # round 2: 1 157.  What is left (~160) is written once per launch in the wave prologues (terrain view, solver parameters, actuator scales:
+    # scalars the helper waves use in every substep next to the SGPR-resident LSTM weights) and read back where used; none of it is inside the
+    # Gauss-Seidel passes.  The tail reads the context through `late_ctx`, so its ~40 row pointers are no longer among them.
+    assert r["SGPRs Spill"] <= 200, r
     assert r["ScratchSize"] <= 64, r
     assert r["VGPRs"] + r["AGPRs"] <= 512 and r["Occupancy"] == 1, r     # one wave per SIMD by design (s5): the budget of a lone wave
     assert r["LDS Size"] <= 160 * 1024, r
