@@ -5,9 +5,11 @@ header and checks every enum value and struct size against this file so the two 
 """
 import ctypes as C
 
-LG_ABI_VERSION = 3
-LG_NUM_LEGS, LG_JOINTS_PER_LEG, LG_NUM_DOF = 4, 3, 12
-LG_MAX_CP, LG_MAX_BODIES, LG_MAX_REWARD_TERMS, LG_MAX_INDEX_LIST = 8, 17, 32, 16
+LG_ABI_VERSION = 4
+LG_MAX_LEGS, LG_JOINTS_PER_LEG = 6, 3
+LG_MAX_DOF = LG_MAX_LEGS * LG_JOINTS_PER_LEG
+LG_MAX_CP, LG_MAX_BODIES, LG_MAX_REWARD_TERMS, LG_MAX_INDEX_LIST = 8, 25, 32, 16
+SUPPORTED_LEG_COUNTS = (4, 6)          # kernel instances of the library (csrc/lg_instance.h)
 LG_LSTM_NPARAM = 969
 
 LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_UNSUPPORTED, LG_ERR_NO_DEVICE = 0, -1, -2, -3, -4
@@ -18,8 +20,21 @@ LG_RNG_PHILOX, LG_RNG_INJECT = 0, 1
 LG_SOLVER_PGS, LG_SOLVER_TGS = 0, 1
 LG_FRICTION_CONE, LG_FRICTION_PYRAMID = 0, 1
 
-RAND_SLOTS = dict(LG_RS_CMD_CB=0, LG_RS_PUSH=4, LG_RS_LEVEL=6, LG_RS_DOF=8, LG_RS_ROOT_XY=20, LG_RS_ROOT_VEL=22,
-                  LG_RS_CMD_RESET=28, LG_RS_NOISE=32)
+
+
+def rand_slots(num_dof=12):
+    """Slots of the per-env uniform-draw table (enum lg_rand_slot + the LG_RS_*_OF(dof) macros of lgstep.h)."""
+    root_xy = 8 + num_dof
+    return dict(LG_RS_CMD_CB=0, LG_RS_PUSH=4, LG_RS_LEVEL=6, LG_RS_DOF=8, LG_RS_ROOT_XY=root_xy, LG_RS_ROOT_VEL=root_xy + 2,
+                LG_RS_CMD_RESET=root_xy + 8, LG_RS_NOISE=(root_xy + 8 + 3 + 3) & ~3)
+
+
+def num_proprio(num_dof=12):
+    """Observation entries in front of the height scan (LG_NUM_PROPRIO_OF): 48 for 12 DOF, 66 for 18."""
+    return 12 + 3 * num_dof
+
+
+RAND_SLOTS = rand_slots(12)            # the four-legged robots' table (20 / 22 / 28 / 32)
 LG_RS_NOISE = RAND_SLOTS["LG_RS_NOISE"]
 
 # reward term name (as in cfg.rewards.scales) -> lg_reward_term
@@ -50,15 +65,15 @@ f32, i32 = C.c_float, C.c_int32
 
 class lg_robot_model(C.Structure):
     _fields_ = [
-        ("num_bodies", i32), ("has_foot_body", i32),
+        ("num_legs", i32), ("num_bodies", i32), ("has_foot_body", i32),
         ("base_mass", f32), ("base_com", f32 * 3), ("base_inertia", f32 * 6),
-        ("joint_pos", (f32 * 3) * 3 * 4), ("joint_rot", (f32 * 9) * 3 * 4), ("joint_axis", (f32 * 3) * 3 * 4),
-        ("link_mass", (f32 * 3) * 4), ("link_com", (f32 * 3) * 3 * 4), ("link_inertia", (f32 * 6) * 3 * 4),
-        ("foot_pos", (f32 * 3) * 4), ("foot_rot", (f32 * 9) * 4),
-        ("dof_lower", f32 * 12), ("dof_upper", f32 * 12), ("dof_vel_limit", f32 * 12), ("torque_limit", f32 * 12),
-        ("cp_count", i32 * 4), ("cp_link", (i32 * LG_MAX_CP) * 4), ("cp_body", (i32 * LG_MAX_CP) * 4),
-        ("cp_pos", (f32 * 3) * LG_MAX_CP * 4), ("cp_radius", (f32 * LG_MAX_CP) * 4),
-        ("feet_indices", i32 * 4),
+        ("joint_pos", (f32 * 3) * 3 * LG_MAX_LEGS), ("joint_rot", (f32 * 9) * 3 * LG_MAX_LEGS), ("joint_axis", (f32 * 3) * 3 * LG_MAX_LEGS),
+        ("link_mass", (f32 * 3) * LG_MAX_LEGS), ("link_com", (f32 * 3) * 3 * LG_MAX_LEGS), ("link_inertia", (f32 * 6) * 3 * LG_MAX_LEGS),
+        ("foot_pos", (f32 * 3) * LG_MAX_LEGS), ("foot_rot", (f32 * 9) * LG_MAX_LEGS),
+        ("dof_lower", f32 * LG_MAX_DOF), ("dof_upper", f32 * LG_MAX_DOF), ("dof_vel_limit", f32 * LG_MAX_DOF), ("torque_limit", f32 * LG_MAX_DOF),
+        ("cp_count", i32 * LG_MAX_LEGS), ("cp_link", (i32 * LG_MAX_CP) * LG_MAX_LEGS), ("cp_body", (i32 * LG_MAX_CP) * LG_MAX_LEGS),
+        ("cp_pos", (f32 * 3) * LG_MAX_CP * LG_MAX_LEGS), ("cp_radius", (f32 * LG_MAX_CP) * LG_MAX_LEGS),
+        ("feet_indices", i32 * LG_MAX_LEGS),
         ("num_penalised", i32), ("penalised_contact_indices", i32 * LG_MAX_INDEX_LIST),
         ("num_termination", i32), ("termination_contact_indices", i32 * LG_MAX_INDEX_LIST),
     ]
@@ -82,7 +97,7 @@ class lg_config(C.Structure):
         ("abi_version", i32), ("num_envs", i32), ("num_obs", i32), ("num_height_points", i32), ("num_extra_obs", i32),
         ("sim_dt", f32), ("decimation", i32), ("gravity", f32 * 3),
         ("control_type", i32), ("action_scale", f32),
-        ("p_gains", f32 * 12), ("d_gains", f32 * 12), ("default_dof_pos", f32 * 12),
+        ("p_gains", f32 * LG_MAX_DOF), ("d_gains", f32 * LG_MAX_DOF), ("default_dof_pos", f32 * LG_MAX_DOF),
         ("clip_actions", f32), ("clip_observations", f32),
         ("actuator_net", f32 * LG_LSTM_NPARAM), ("actuator_in_scale", f32 * 2), ("actuator_out_scale", f32),
         ("obs_scale_lin_vel", f32), ("obs_scale_ang_vel", f32), ("obs_scale_dof_pos", f32), ("obs_scale_dof_vel", f32),
@@ -97,17 +112,17 @@ class lg_config(C.Structure):
         ("reward_scales", f32 * LG_MAX_REWARD_TERMS), ("only_positive_rewards", i32), ("reward_class", i32),
         ("tracking_sigma", f32), ("base_height_target", f32), ("max_contact_force", f32), ("soft_dof_vel_limit", f32),
         ("soft_torque_limit", f32),
-        ("dof_pos_limits", (f32 * 2) * 12),
+        ("dof_pos_limits", (f32 * 2) * LG_MAX_DOF),
         ("max_episode_length", f32), ("max_episode_length_s", f32),
         ("curriculum", i32), ("custom_origins", i32), ("max_terrain_level", i32),
         ("reset_z_from_terrain", i32),
         ("terminate_on_flip", i32),
         ("base_init_state", f32 * 13),
-        ("gait_enabled", i32), ("gait_period", f32), ("gait_swing_height", f32), ("gait_foot_phases", f32 * 4),
+        ("gait_enabled", i32), ("gait_period", f32), ("gait_swing_height", f32), ("gait_foot_phases", f32 * LG_MAX_LEGS),
         ("solver_iterations", i32), ("contact_offset", f32), ("max_depenetration_velocity", f32), ("erp", f32),
         ("cfm", f32), ("solver_type", i32), ("friction_model", i32), ("self_collisions", i32),
         ("seed", C.c_uint64), ("rng_mode", i32),
-        ("async_num_dof_sets", i32), ("async_dof_sets", (i32 * 3) * 4), ("async_dof_nominal", f32 * 12), ("async_dof_weight", f32 * 12),
+        ("async_num_dof_sets", i32), ("async_dof_sets", (i32 * 3) * 4), ("async_dof_nominal", f32 * LG_MAX_DOF), ("async_dof_weight", f32 * LG_MAX_DOF),
         ("async_weights", f32 * 3), ("async_foot_z_align", f32), ("inject_sim_state", i32),
     ]
 

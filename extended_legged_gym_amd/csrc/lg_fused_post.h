@@ -22,10 +22,10 @@
 #define HI(i) (__float_as_int(hot[(i)]))
 
 // LDS row of one env during the tail (floats); lives in the memory of `xs` (dead after the last contact set-up)
-enum { FS_ROOT = 0, FS_DOF = 13, FS_CF = 37, FS_FRB = FS_CF + LG_MAX_BODIES * 3 /* four feet rows x 13 */, FS_ACT = FS_FRB + 52, FS_LACT = FS_ACT + 12,
+enum { FS_ROOT = 0, FS_DOF = 13, FS_CF = 37, FS_FRB = FS_CF + NBODY_MAX * 3 /* four feet rows x 13 */, FS_ACT = FS_FRB + 52, FS_LACT = FS_ACT + 12,
        FS_LRV = FS_LACT + 12, FS_CMD = FS_LRV + 6, FS_BLA = FS_CMD + 4, FS_BAA = FS_BLA + 3, FS_AIR = FS_BAA + 3, FS_CT = FS_AIR + 4, FS_BLV = FS_CT + 4,
        FS_BAV = FS_BLV + 3, FS_PG = FS_BAV + 3, FS_SUMS = FS_PG + 3, FS_GAIT = FS_SUMS + LG_MAX_REWARD_TERMS, FS_FN = FS_GAIT + 1,
-       FS_GFZ = FS_FN + LG_MAX_BODIES /* gait_foot_z of the previous step */, FS_VAL = FS_GFZ + 4 /* critic value (lg_step_transition) */,
+       FS_GFZ = FS_FN + NBODY_MAX /* gait_foot_z of the previous step */, FS_VAL = FS_GFZ + 4 /* critic value (lg_step_transition) */,
        FS_END = FS_VAL + 1, FS_STRIDE = FS_END + (FS_END % 2 == 0 ? 1 : 0) };
 static_assert(EPB * FS_STRIDE <= XS_STRIDE * 64, "the env rows of the fused tail must fit the memory of the mass-factor table");
 // uniforms + small integers of one env (fetched before the final barrier): in the memory of `xbias` (64 x 12 floats)

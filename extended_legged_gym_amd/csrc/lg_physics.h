@@ -1,6 +1,9 @@
-// lg_physics.h — articulated-body dynamics + contact for one environment, spread over a DPP quad (4 lanes):
-// lane l owns leg l (3 revolute joints, its links, its collision spheres); the floating base is replicated on all
-// four lanes and every cross-leg coupling goes through the 6x6 base Schur complement, reduced with quad DPP adds.
+// lg_physics.h — articulated-body dynamics + contact for one environment, spread over a lane GROUP: a DPP quad (4 lanes) for the
+// four-legged robots, eight lanes (half a DPP row, two of them idle) for the six-legged one.  Lane l of the group owns leg l
+// (3 revolute joints, its links, its collision spheres); the floating base is replicated on every lane of the group and every
+// cross-leg coupling goes through the 6x6 base Schur complement, reduced with DPP adds (grp_sum).
+// The group width is a compile-time constant of the translation unit (LG_LEGS -> GRP, lg_step.hip compiles one kernel instance per
+// supported leg count); this header is included inside that instance's namespace.
 //
 //   M = [ Mbb  Mb1 Mb2 Mb3 Mb4 ]      legs couple only through the base, so with  Y_k = Mkk^-1 Mbk^T
 //       [ Mb1' M11             ]        S   = Mbb - sum_k Mbk Y_k                      (6x6, replicated)
@@ -26,8 +29,35 @@
 #endif
 #include "lg_device.h"
 #include "lg_bvh.h"
+#ifndef LG_LEGS
+#define LG_LEGS 4
+#endif
+#if LG_LEGS == 4
+#define GRP 4            // lanes per env
+#elif LG_LEGS == 6
+#define GRP 8
+#else
+#error "kernel instances exist for 4 and 6 legs"
+#endif
+#define NLEG LG_LEGS
+#define NDOF (3 * NLEG)
+#define EPW (64 / GRP)   // envs per wave
+static_assert(NLEG <= LG_MAX_LEGS && NLEG <= GRP, "leg count of this instance");
 
-// Per-leg model constants staged in LDS as [field][leg]: lane l reads field*4 + l, i.e. a wave touches 4 consecutive
+// ---- all-reduce over the lanes of an env's group.  Quad: two v_add_f32_dpp quad_perm.  Eight lanes: lanes NLEG..7 carry no leg -- their
+// model is a copy of leg 0's (finite arithmetic everywhere) and they are selected out of every sum here --, then row_half_mirror + the two
+// quad permutes: three DPP adds, no LDS.
+LG_DEV int lane_in_group() { return (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & (GRP - 1)); }
+#if GRP == 4
+LG_DEV float grp_sum(float x) { return quad_sum(x); }
+#else
+LG_DEV float dpp_half_mirror(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true)); }
+LG_DEV float grp_sum(float x) { x = lane_in_group() < NLEG ? x : 0.f; x += dpp_half_mirror(x); x += dpp_xor1(x); x += dpp_xor2(x); return x; }
+#endif
+LG_DEV V3 grp_sum(V3 a) { return v3(grp_sum(a.x), grp_sum(a.y), grp_sum(a.z)); }
+LG_DEV S3 grp_sum(S3 a) { return S3{grp_sum(a.xx), grp_sum(a.xy), grp_sum(a.xz), grp_sum(a.yy), grp_sum(a.yz), grp_sum(a.zz)}; }
+
+// Per-leg model constants staged in LDS as [field][lane of the group]: lane l reads field*GRP + l, i.e. a wave touches GRP consecutive
 // dwords per field (broadcast, conflict-free) instead of issuing ~100 dependent global loads per substep.
 enum { LM_JPOS = 0, LM_JROT = 9, LM_JAXIS = 36, LM_MASS = 45, LM_COM = 48, LM_INERTIA = 57, LM_FOOT_POS = 75, LM_FOOT_ROT = 78,
        LM_VEL_LIMIT = 87, LM_TORQUE_LIMIT = 90, LM_DEFAULT_POS = 93, LM_PGAIN = 96, LM_DGAIN = 99, LM_CP_COUNT = 102,
@@ -35,7 +65,7 @@ enum { LM_JPOS = 0, LM_JROT = 9, LM_JAXIS = 36, LM_MASS = 45, LM_COM = 48, LM_IN
        LM_SOFT_LO = 149, LM_SOFT_HI = 152 /* cfg.dof_pos_limits: the soft limits of _reward_dof_pos_limits */, LM_FIELDS = 155 };
 struct LegModel {
   const float* t; int l;
-  LG_DEV float f(int field) const { return t[field * 4 + l]; }
+  LG_DEV float f(int field) const { return t[field * GRP + l]; }
   LG_DEV V3 v(int field) const { return v3(f(field), f(field + 1), f(field + 2)); }
   LG_DEV int i(int field) const { return __float_as_int(f(field)); }
 };
@@ -44,7 +74,10 @@ struct LegModel {
 // copy the packed table into LDS.  (Filled in the kernel it was ~25 divergent branches with a dependent load each, ten times over:
 // 6-8 k cycles in front of the first barrier of every launch.)
 __host__ __device__ inline float leg_model_entry(const lg_robot_model* m, const lg_config* g, int idx) {
-  const int field = idx >> 2, l = idx & 3;
+  const int field = idx / GRP, lg_ = idx % GRP;
+  const int l = lg_ < NLEG ? lg_ : 0;      // lanes without a leg (six legs on eight lanes): a copy of leg 0, no collision points, no joint limits
+  if (lg_ >= NLEG && field == LM_CP_COUNT) return 0.f;
+  if (lg_ >= NLEG && field >= LM_LOWER && field < LM_SOFT_LO) return 0.f;
   if (field < LM_JROT) return m->joint_pos[l][field / 3][field % 3];
   if (field < LM_JAXIS) { int k = field - LM_JROT; return m->joint_rot[l][k / 9][k % 9]; }
   if (field < LM_MASS) { int k = field - LM_JAXIS; return m->joint_axis[l][k / 3][k % 3]; }
@@ -69,11 +102,11 @@ __host__ __device__ inline float leg_model_entry(const lg_robot_model* m, const 
   return g->dof_pos_limits[3 * l + field - LM_SOFT_HI][1];
 }
 inline void pack_leg_model(float* t, const lg_robot_model* m, const lg_config* g) {
-  for (int idx = 0; idx < LM_FIELDS * 4; ++idx) t[idx] = leg_model_entry(m, g, idx);
+  for (int idx = 0; idx < LM_FIELDS * GRP; ++idx) t[idx] = leg_model_entry(m, g, idx);
 }
 // LDS copy of the packed table by `nthreads` threads (tid 0 .. nthreads-1); the caller holds the barrier
 LG_DEV void fill_leg_model(float* t, const float* __restrict__ packed, int tid, int nthreads) {
-  for (int idx = tid; idx < LM_FIELDS * 4; idx += nthreads) t[idx] = packed[idx];
+  for (int idx = tid; idx < LM_FIELDS * GRP; idx += nthreads) t[idx] = packed[idx];
 }
 LG_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
@@ -277,7 +310,7 @@ struct PhysParams {
   float dt; V3 grav; int iters; float contact_offset, max_depen, erp, cfm, terrain_mu; int solver, fric;
 };
 
-struct QuadState {           // per lane: replicated base + own leg
+struct QuadState {           // per lane: replicated base + own leg (the name is from the four-legged instance)
   float root[13];            // pos3, quat xyzw, lin vel3, ang vel3 (world)
   float q[3], qd[3];
 };
@@ -815,15 +848,15 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   }
   float L[21];
   {
-    const float mt = m0 + quad_sum(mc);
-    const V3 ht = m0 * rc0 + quad_sum(hc);
-    const S3 It = inertia_about(I0, m0, rc0) + quad_sum(Icp);
+    const float mt = m0 + grp_sum(mc);
+    const V3 ht = m0 * rc0 + grp_sum(hc);
+    const S3 It = inertia_about(I0, m0, rc0) + grp_sum(Icp);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int b = 0; b <= a; ++b) {
         float sk = Mbk[a][0] * Y[0][b] + Mbk[a][1] * Y[1][b] + Mbk[a][2] * Y[2][b];
-        L[LT(a, b)] = -quad_sum(sk);
+        L[LT(a, b)] = -grp_sum(sk);
       }
     L[LT(0, 0)] += mt; L[LT(1, 1)] += mt; L[LT(2, 2)] += mt;
     // rows 3..5, cols 0..2 : [h]x
@@ -857,7 +890,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     V3 ac = cross(wb, cross(wb, rc0));
     V3 Fb = m0 * (ac - P.grav);
     V3 Nb = cross(wb, mul(I0, wb)) + cross(rc0, Fb);
-    V3 Ft = Fb + quad_sum(Fs), Nt = Nb + quad_sum(Ns);
+    V3 Ft = Fb + grp_sum(Fs), Nt = Nb + grp_sum(Ns);
     bb[0] = Ft.x; bb[1] = Ft.y; bb[2] = Ft.z; bb[3] = Nt.x; bb[4] = Nt.y; bb[5] = Nt.z;
   }
   const float mu = 0.5f * (mu_robot + P.terrain_mu);   // PhysX default friction combine mode: average
@@ -901,7 +934,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     sym3_mul(Mi, rk, y);
     float g[6], g0[6];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) g0[a] = -bb[a] - quad_sum(Mbk[a][0] * y[0] + Mbk[a][1] * y[1] + Mbk[a][2] * y[2]);
+    for (int a = 0; a < 6; ++a) g0[a] = -bb[a] - grp_sum(Mbk[a][0] * y[0] + Mbk[a][1] * y[1] + Mbk[a][2] * y[2]);
     symv6(Si, g0, g);
 #pragma unroll
     for (int a = 0; a < 6; ++a) vB[a] += dt * g[a];
@@ -1032,7 +1065,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
         pk2 acc = pk_splat(d0) * (pk2){rec[CF_WB + 2 * p], rec[CF_WB + 2 * p + 1]};
         acc = pk_fma(pk_splat(d12.x), (pk2){rec[CF_WB + 6 + 2 * p], rec[CF_WB + 6 + 2 * p + 1]}, acc);
         acc = pk_fma(pk_splat(d12.y), (pk2){rec[CF_WB + 12 + 2 * p], rec[CF_WB + 12 + 2 * p + 1]}, acc);
-        g[p].x = quad_sum(acc.x); g[p].y = quad_sum(acc.y);
+        g[p].x = grp_sum(acc.x); g[p].y = grp_sum(acc.y);
       }
 #pragma unroll
       for (int p = 0; p < 3; ++p) vBp[p] = vBp[p] + g[p];
@@ -1079,7 +1112,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
           if (jl_act[j]) jl_lam[j] = ln;
           float gq[6];
 #pragma unroll
-          for (int a = 0; a < 6; ++a) gq[a] = quad_sum(dl * jl_Wb[j][a]);
+          for (int a = 0; a < 6; ++a) gq[a] = grp_sum(dl * jl_Wb[j][a]);
 #pragma unroll
           for (int a = 0; a < 6; ++a) vBs[a] += gq[a];
 #pragma unroll
@@ -1145,7 +1178,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
 #pragma unroll
       for (int b = 0; b < 5; ++b) if (b == slotb) fb[b] = fb[b] + f;
     }
-    fbody[0] = quad_sum(fb[0]);
+    fbody[0] = grp_sum(fb[0]);
 #pragma unroll
     for (int b = 1; b < 5; ++b) fbody[b] = fb[b];
   }

@@ -376,8 +376,10 @@ int lg_collect_rollout(lg_ctx* env, lg_mlp* actor, lg_mlp* critic, const float* 
   if (lg_get_tensor(env, LG_T_OBS_BUF, &p, shp, &nd, &dt) != LG_OK) return LG_ERR_INVALID;
   const float* obs = (const float*)p; const int64_t n = shp[0], O = shp[1];
   const int A = actor->h.dims[actor->h.L];
-  if (actor->h.dims[0] != O || critic->h.dims[0] != O || critic->h.dims[critic->h.L] != 1 || A != LG_NUM_DOF) {
-    actor->err = "lg_collect_rollout: network widths do not match the env (obs width, 12 actions, scalar value)"; return LG_ERR_INVALID;
+  int64_t ashp[4];
+  if (lg_get_tensor(env, LG_T_ACTIONS, &p, ashp, &nd, &dt) != LG_OK) return LG_ERR_INVALID;
+  if (actor->h.dims[0] != O || critic->h.dims[0] != O || critic->h.dims[critic->h.L] != 1 || A != ashp[1]) {
+    actor->err = "lg_collect_rollout: network widths do not match the env (obs width, one action per DOF, scalar value)"; return LG_ERR_INVALID;
   }
   hipStream_t st = (hipStream_t)stream;
   // the first observation row is copied from the env; every later one is written by the step itself (lg_step_transition),

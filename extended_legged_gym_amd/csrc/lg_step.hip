@@ -20,23 +20,36 @@
 #include <string>
 #include <vector>
 
+#include "lg_device.h"
+#include "lg_bvh.h"
+#define LG_INSTANCE_TU
+#include "lg_instance.h"          // LG_LEGS -> this instance's namespace and the names of its entry points (lg4_* / lg6_*)
+
+namespace LG_NS {
 #include "lg_physics.h"
 
 #define LG_MESH_OOB_MARGIN 1.0f   // metres beyond the collision mesh's bounding box before an env counts as lost
-#define EPB 16          // envs per workgroup (= per main wave) in physics_kernel
-#define EPBP 4          // envs per 256-thread workgroup in post_kernel (a wave per env in the wide stages, 16 lanes per env in the narrow ones); 4 workgroups per CU at N = 4096
+#define EPB EPW         // envs per workgroup (= per main wave) in physics_kernel: 16 quads, or 8 groups of eight lanes
+#define LPE (4 * GRP)   // lanes per env in the narrow stages of post_kernel: one lane per DOF (12 of 16, 18 of 32)
+#define EPBP (64 / LPE) // envs per 256-thread workgroup in post_kernel (a wave per env in the wide stages, LPE lanes per env in the narrow ones); quadrupeds: 4 workgroups per CU at N = 4096
 #define MAX_P 192       // height-scan points per env held in LDS
 #define PART_STRIDE (LG_MAX_REWARD_TERMS + 3)
+#define NBODY_MAX (1 + 4 * NLEG)                // rigid bodies of this instance's robots: base + legs x (3 links + FOOT)
+#define NPROP LG_NUM_PROPRIO_OF(NDOF)           // observation entries in front of the height scan (48 / 66)
+#define LG_RS_ROOT_XY LG_RS_ROOT_XY_OF(NDOF)
+#define LG_RS_ROOT_VEL LG_RS_ROOT_VEL_OF(NDOF)
+#define LG_RS_CMD_RESET LG_RS_CMD_RESET_OF(NDOF)
+#define LG_RS_NOISE LG_RS_NOISE_OF(NDOF)
 
 // The scalars the post-physics tail of the fused step reads, packed into one contiguous block (built on the host, copied into
 // LDS at kernel start): lg_config is 8 KB (the actuator weights sit in the middle of it) and the tail touches ~20 different
 // 64-byte lines of it, each a scalar-cache miss on first touch, serialised by the tail's dependent chain.
 enum { HC_DT = 0, HC_K, HC_KFAT, HC_KTERM, HC_TERM_SCALE, HC_TERM_MASK, HC_RESAMPLING_STEPS, HC_HEADING, HC_PUSH, HC_PUSH_INTERVAL, HC_MAX_PUSH,
-       HC_FLIP, HC_MAX_EPLEN, HC_ONLY_POS, HC_STAND, HC_CURRICULUM, HC_GAIT_ON, HC_GAIT_PERIOD, HC_GAIT_SWING, HC_GAIT_PHASE /* 4 */, HC_SIGMA = HC_GAIT_PHASE + 4,
-       HC_BH_TARGET, HC_MAX_CF, HC_MEASURE_H, HC_P, HC_FEET /* 4 */, HC_NPEN = HC_FEET + 4, HC_PEN /* 16 */, HC_NTERM = HC_PEN + LG_MAX_INDEX_LIST,
+       HC_FLIP, HC_MAX_EPLEN, HC_ONLY_POS, HC_STAND, HC_CURRICULUM, HC_GAIT_ON, HC_GAIT_PERIOD, HC_GAIT_SWING, HC_GAIT_PHASE /* NLEG */, HC_SIGMA = HC_GAIT_PHASE + NLEG,
+       HC_BH_TARGET, HC_MAX_CF, HC_MEASURE_H, HC_P, HC_FEET /* NLEG */, HC_NPEN = HC_FEET + NLEG, HC_PEN /* 16 */, HC_NTERM = HC_PEN + LG_MAX_INDEX_LIST,
        HC_TERMB /* 16 */, HC_SOFT_VEL = HC_TERMB + LG_MAX_INDEX_LIST, HC_SOFT_TQ, HC_NUM_OBS, HC_ADD_NOISE, HC_INJECT, HC_OS_LIN, HC_OS_ANG, HC_OS_POS,
        HC_OS_VEL, HC_OS_H, HC_CLIP_OBS, HC_SEED_LO, HC_SEED_HI, HC_NUM_EXTRA, HC_IDS /* 32 */, HC_SCALES = HC_IDS + LG_MAX_REWARD_TERMS /* 32 */,
-       HC_DEFAULT_POS = HC_SCALES + LG_MAX_REWARD_TERMS /* 12 */, HC_COUNT = HC_DEFAULT_POS + 12 };
+       HC_DEFAULT_POS = HC_SCALES + LG_MAX_REWARD_TERMS /* NDOF */, HC_COUNT = HC_DEFAULT_POS + NDOF };
 
 // Device-side view of every pointer member: the global address space.  A pointer read out of a struct is generic to the compiler and
 // every access through it a flat_load / flat_store, which counts on BOTH wait counters and returns out of order, so that any wait for
@@ -71,14 +84,14 @@ struct DevCtx {
   long long LG_G* acc;      // [PART_STRIDE] fixed-point (x 2^24) sums of the reset envs' rows of one post-kernel launch
   unsigned LG_G* tickets;   // 9 counters, one per 128-B line: per-shard arrivals of the post kernel's workgroups + the shards' own
   float mesh_lo[3], mesh_hi[3];   // bounding box of the collision mesh (LG_MESH_TRIMESH): a base that leaves it by more than LG_MESH_OOB_MARGIN ends the episode
-  float LG_G* mesh_cache;   // [N][4 legs][LG_MAX_CP][4]: last closest-point query of every collision sphere (mesh terrains)
+  float LG_G* mesh_cache;   // [N][NLEG][LG_MAX_CP][4]: last closest-point query of every collision sphere (mesh terrains)
   float lstm_w[912];   // actuator network weights, gate-interleaved (pack_lstm_weights): read with scalar loads
   int nblocks_post;
   // reward-term bookkeeping of the post kernel, derived from cfg.reward_term_ids on the host (reward_meta): a walk over the
   // term list in the kernel is one dependent scalar load per term on the narrow-stage chain
   unsigned rew_term_mask; int rew_kfat, rew_kterm; float rew_term_scale;
   float hot[HC_COUNT];          // see the HC_* enum (ints stored as bit patterns)
-  float lmod[LM_FIELDS * 4];    // per-leg model table, packed on the host (pack_leg_model)
+  float lmod[LM_FIELDS * GRP];  // per-leg model table, packed on the host (pack_leg_model)
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
   float lvl_total_before;       // subset steps with a terrain curriculum: sum of ALL terrain levels before the launch (level_total_kernel)
   unsigned long long LG_G* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
@@ -87,6 +100,7 @@ struct DevCtx {
 struct TensorInfo { size_t off; int64_t shape[4]; int ndim; int dtype; };
 
 struct lg_ctx {
+  int32_t legs = NLEG; // first member: how the library's entry points (lg_dispatch.cpp) find the instance a context belongs to
   DevCtx h;            // host copy
   DevCtx* d = nullptr; // device copy
   void* arena = nullptr; bool own_arena = false; size_t arena_bytes = 0;
@@ -118,7 +132,7 @@ static void hot_config(DevCtx& h) {
   I(HC_PUSH_INTERVAL, g.push_interval); F(HC_MAX_PUSH, g.max_push_vel_xy); I(HC_FLIP, g.terminate_on_flip); F(HC_MAX_EPLEN, g.max_episode_length);
   I(HC_ONLY_POS, g.only_positive_rewards); I(HC_STAND, g.reward_class == LG_RC_STAND); I(HC_CURRICULUM, g.curriculum); I(HC_GAIT_ON, g.gait_enabled); F(HC_GAIT_PERIOD, g.gait_period);
   F(HC_GAIT_SWING, g.gait_swing_height);
-  for (int f = 0; f < 4; ++f) { F(HC_GAIT_PHASE + f, g.gait_foot_phases[f]); I(HC_FEET + f, m.feet_indices[f]); }
+  for (int f = 0; f < NLEG; ++f) { F(HC_GAIT_PHASE + f, g.gait_foot_phases[f]); I(HC_FEET + f, m.feet_indices[f]); }
   F(HC_SIGMA, g.tracking_sigma); F(HC_BH_TARGET, g.base_height_target); F(HC_MAX_CF, g.max_contact_force); I(HC_MEASURE_H, g.measure_heights);
   I(HC_P, g.measure_heights ? h.P : 0);
   I(HC_NPEN, m.num_penalised); I(HC_NTERM, m.num_termination);
@@ -128,7 +142,7 @@ static void hot_config(DevCtx& h) {
   F(HC_OS_VEL, g.obs_scale_dof_vel); F(HC_OS_H, g.obs_scale_height); F(HC_CLIP_OBS, g.clip_observations);
   U(HC_SEED_LO, (unsigned)g.seed); U(HC_SEED_HI, (unsigned)(g.seed >> 32)); I(HC_NUM_EXTRA, g.num_extra_obs);
   for (int k = 0; k < LG_MAX_REWARD_TERMS; ++k) { I(HC_IDS + k, g.reward_term_ids[k]); F(HC_SCALES + k, g.reward_scales[k]); }
-  for (int d = 0; d < 12; ++d) F(HC_DEFAULT_POS + d, g.default_dof_pos[d]);
+  for (int d = 0; d < NDOF; ++d) F(HC_DEFAULT_POS + d, g.default_dof_pos[d]);
 }
 
 static void reward_meta(DevCtx& h) {
@@ -317,7 +331,7 @@ LG_DEV void lstm_actuator3(const float* __restrict__ W, const float x0[3], const
 }
 
 LG_DEV void load_lstm(const DevCtx* __restrict__ C, int e, int l, LegActuator& A) {
-  const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + 3 * l;
+  const size_t N12 = (size_t)C->N * NDOF, row = (size_t)e * NDOF + 3 * l;
 #pragma unroll
   for (int lay = 0; lay < 2; ++lay)
 #pragma unroll
@@ -332,7 +346,7 @@ LG_DEV void load_lstm(const DevCtx* __restrict__ C, int e, int l, LegActuator& A
     }
 }
 LG_DEV void store_lstm(const DevCtx* __restrict__ C, int e, int l, const LegActuator& A) {
-  const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + 3 * l;
+  const size_t N12 = (size_t)C->N * NDOF, row = (size_t)e * NDOF + 3 * l;
 #pragma unroll
   for (int lay = 0; lay < 2; ++lay)
 #pragma unroll
@@ -425,7 +439,7 @@ LG_DEV void write_rigid_body_state(const DevCtx* __restrict__ C, const LegModel&
 // persisted closest-point cache of one lane's slots [s0, s0 + 2): global [env][leg][slot][4] <-> LDS [slot][4][lane]
 template <bool LOAD>
 LG_DEV void mesh_cache_io(const DevCtx* __restrict__ C, float* cqc, int e, int l, int lane, int s0) {
-  float4* g = (float4*)(C->mesh_cache + ((size_t)e * 4 + l) * LG_MAX_CP * 4);
+  float4* g = (float4*)(C->mesh_cache + ((size_t)e * NLEG + l) * LG_MAX_CP * 4);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int sl = s0 + i;
@@ -508,7 +522,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
   __shared__ __attribute__((aligned(16))) float cst[LG_CST_FLOATS];
-  __shared__ float lmod[LM_FIELDS * 4];
+  __shared__ float lmod[LM_FIELDS * GRP];
 #ifdef LG_STAMPS
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -536,10 +550,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // L2 sees one eighth of the map instead of all of it.
   const int bid = TMESH ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   // row kq of the launch <-> env e (identity, or ids[kq] for subset stepping: main-only / rollout-only steps)
-  const int kq = bid * EPB + (lane >> 2);
-  const int l = lane & 3;
-  const bool valid = kq < n;
-  const int krow = valid ? kq : n - 1;   // whole quads are (in)valid together; invalid quads compute on a copy and store nothing
+  const int kq = bid * EPB + lane / GRP;
+  const int lg_ = lane % GRP;               // lane of the env's group
+  const bool has_leg = lg_ < NLEG;          // six legs on eight lanes: lanes 6 and 7 shadow leg 0 of their env and store nothing
+  const int l = has_leg ? lg_ : 0;          // the leg whose rows this lane reads (and, with `valid`, writes)
+  const bool env_ok = kq < n;
+  const bool valid = env_ok && has_leg;
+  const int krow = env_ok ? kq : n - 1;     // whole groups are (in)valid together; invalid groups compute on a copy and store nothing
   const int e = ids ? ids[krow] : krow;
   const lg_robot_model* __restrict__ m = &C->model;
   const lg_config& g = C->cfg;
@@ -551,7 +568,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #ifdef LG_STAMPS
   const unsigned long long t_bar0 = __builtin_amdgcn_s_memtime();
 #endif
-  const LegModel lm_{lmod, l};
+  const LegModel lm_{lmod, lg_};
 
   if (MODE == 0 && HELPERS && wv > 0) {
     // ---------------------------------------------------------------- actuator wave: joint j of leg l of env e
@@ -561,7 +578,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     float a = net ? actions_in[(size_t)krow * act_stride + d] : 0.f;
     a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);
     const float tgt = a * g.action_scale + lm_.f(LM_DEFAULT_POS + j);
-    const size_t N12 = (size_t)C->N * 12, row = (size_t)e * 12 + d;
+    const size_t N12 = (size_t)C->N * NDOF, row = (size_t)e * NDOF + d;
     float h0[8], c0[8], h1[8], c1[8];
     if (net) {
       const float4* p = (const float4*)(C->sea_h + row * 8); float4 u = p[0], v = p[1];
@@ -723,19 +740,19 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       // the rigid-body rows (stores nobody in this launch reads) while the main wave runs the serial part: these waves wait ~6 k cycles for
       // it at (G2); behind the write-back, where they used to be, they were on the tail of the launch
       if (valid && g.inject_sim_state) {                         // parity tests: the injected rows stay; gait_foot_z from the injected foot row
-        if (wv == 3 && g.gait_enabled) Ct->gait_foot_z[(size_t)e * 4 + l] = Ct->rigid[((size_t)e * Ct->B + 1 + Ct->per_leg * l + (Ct->per_leg == 4 ? 3 : 2)) * 13 + 2];
+        if (wv == 3 && g.gait_enabled) Ct->gait_foot_z[(size_t)e * NLEG + l] = Ct->rigid[((size_t)e * Ct->B + 1 + Ct->per_leg * l + (Ct->per_leg == 4 ? 3 : 2)) * 13 + 2];
       } else if (valid && !(feet_early && wv == 3)) {            // rigid-body rows of the post-physics (pre-reset) pose, LR:118-120
         float r13[13], qq[3], qdd[3];
         fetch_state(xst[lane], r13, qq, qdd);
-        write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled) ? Ct->gait_foot_z + (size_t)e * 4 + l : nullptr);
+        write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled) ? Ct->gait_foot_z + (size_t)e * NLEG + l : nullptr);
       } else if (valid && g.gait_enabled) {
-        Ct->gait_foot_z[(size_t)e * 4 + l] = fused_foot_row(xs, lane)[2];
+        Ct->gait_foot_z[(size_t)e * NLEG + l] = fused_foot_row(xs, lane)[2];
       }
       STAMP(51);
       if (feet_early || fused_needs_heights_early(C)) lds_barrier();   // (G1) only when the serial part reads a helper's product
       lds_barrier();                                   // (G2) serial part + height scan done
       STAMP(52);
-      zero_state = fused_did_reset(cst, lane >> 2);     // anymal.py:78-82: a reset env starts from the zero LSTM state
+      zero_state = fused_did_reset(cst, lane / GRP);    // anymal.py:78-82: a reset env starts from the zero LSTM state
     }
     if (valid && net) {
       if (zero_state) {
@@ -750,8 +767,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       p[0] = make_float4(h1[0], h1[1], h1[2], h1[3]); p[1] = make_float4(h1[4], h1[5], h1[6], h1[7]);
       p = (float4*)(Ct->sea_c + (N12 + row) * 8);
       p[0] = make_float4(c1[0], c1[1], c1[2], c1[3]); p[1] = make_float4(c1[4], c1[5], c1[6], c1[7]);
-      Ct->actions[(size_t)e * 12 + d] = a;
-      if (!(fuse && g.inject_sim_state)) Ct->torques[(size_t)e * 12 + d] = xtau[j][lane];
+      Ct->actions[(size_t)e * NDOF + d] = a;
+      if (!(fuse && g.inject_sim_state)) Ct->torques[(size_t)e * NDOF + d] = xtau[j][lane];
     }
     if (fuse) {
       const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out);
@@ -770,18 +787,18 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   float last_qd[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    s.q[j] = C->dof[((size_t)e * 12 + 3 * l + j) * 2];
-    s.qd[j] = C->dof[((size_t)e * 12 + 3 * l + j) * 2 + 1];
-    last_qd[j] = C->last_dof_vel[(size_t)e * 12 + 3 * l + j];
+    s.q[j] = C->dof[((size_t)e * NDOF + 3 * l + j) * 2];
+    s.qd[j] = C->dof[((size_t)e * NDOF + 3 * l + j) * 2 + 1];
+    last_qd[j] = C->last_dof_vel[(size_t)e * NDOF + 3 * l + j];
   }
   float act[3] = {0, 0, 0};
   if (MODE != 1 && !split) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      float a = actions_in ? actions_in[(size_t)krow * act_stride + 3 * l + j] : C->actions[(size_t)e * 12 + 3 * l + j];
+      float a = actions_in ? actions_in[(size_t)krow * act_stride + 3 * l + j] : C->actions[(size_t)e * NDOF + 3 * l + j];
       a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);        // LR:93-94
       act[j] = a;
-      if (valid && actions_in) C->actions[(size_t)e * 12 + 3 * l + j] = a;
+      if (valid && actions_in) C->actions[(size_t)e * NDOF + 3 * l + j] = a;
     }
   }
   LegActuator A;
@@ -792,7 +809,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     leg_torques(C, lm_, wlstm, act, s.q, s.qd, last_qd, A, tau);
     if (valid) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) C->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
+      for (int j = 0; j < 3; ++j) C->torques[(size_t)e * NDOF + 3 * l + j] = tau[j];
       if (net) store_lstm(C, e, l, A);
     }
     return;
@@ -827,7 +844,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       leg_torques<!HELPERS>(C, lm_, wlstm, act, s.q, s.qd, last_qd, A, tau);
     } else {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) tau[j] = C->torques[(size_t)e * 12 + 3 * l + j];
+      for (int j = 0; j < 3; ++j) tau[j] = C->torques[(size_t)e * NDOF + 3 * l + j];
     }
     float root0[7], q0[3];
 #pragma unroll
@@ -877,7 +894,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     for (int j = 0; j < 3; ++j) { acc += s.q[j] * 0.f + s.qd[j] * 0.f; acc0 += q0[j] * 0.f; }
 #pragma unroll
     for (int i = 0; i < 7; ++i) acc0 += root0[i] * 0.f;
-    acc = quad_sum(acc); acc0 = quad_sum(acc0);
+    acc = grp_sum(acc); acc0 = grp_sum(acc0);
     if (!(acc == 0.f)) {
       const bool ok0 = acc0 == 0.f;
       fault = true;
@@ -896,13 +913,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     // parity tests (lg_config.inject_sim_state): the post-physics half starts from the post-simulation state the caller left in the
     // tensors -- this workgroup's rows still hold it, nothing of this launch has stored to them yet
     const int per_leg = Ct->per_leg, B = Ct->B;
-    const int ee = valid ? e : 0;
+    const int ee = env_ok ? e : 0;
 #pragma unroll
     for (int i = 0; i < 13; ++i) s.root[i] = Ct->root[(size_t)ee * 13 + i];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      s.q[j] = Ct->dof[((size_t)ee * 12 + 3 * l + j) * 2]; s.qd[j] = Ct->dof[((size_t)ee * 12 + 3 * l + j) * 2 + 1];
-      tau[j] = Ct->torques[(size_t)ee * 12 + 3 * l + j];
+      s.q[j] = Ct->dof[((size_t)ee * NDOF + 3 * l + j) * 2]; s.qd[j] = Ct->dof[((size_t)ee * NDOF + 3 * l + j) * 2 + 1];
+      tau[j] = Ct->torques[(size_t)ee * NDOF + 3 * l + j];
     }
     const float* cf = Ct->cforce + (size_t)ee * B * 3;
     fbody[0] = v3(cf[0], cf[1], cf[2]);
@@ -931,7 +948,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     if (valid) {
       if (TMESH && helpers) mesh_cache_io<false>(Ct, cqc, e, l, lane, 0);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) if (!split) Ct->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
+      for (int j = 0; j < 3; ++j) if (!split) Ct->torques[(size_t)e * NDOF + 3 * l + j] = tau[j];
       const int per_leg = Ct->per_leg, B = Ct->B;
       float* cf = Ct->cforce + (size_t)e * B * 3;
       if (l == 0) { cf[0] = fbody[0].x; cf[1] = fbody[0].y; cf[2] = fbody[0].z; }
@@ -969,9 +986,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    C->dof[((size_t)e * 12 + 3 * l + j) * 2] = s.q[j];
-    C->dof[((size_t)e * 12 + 3 * l + j) * 2 + 1] = s.qd[j];
-    if (MODE == 0 && !split) C->torques[(size_t)e * 12 + 3 * l + j] = tau[j];
+    C->dof[((size_t)e * NDOF + 3 * l + j) * 2] = s.q[j];
+    C->dof[((size_t)e * NDOF + 3 * l + j) * 2 + 1] = s.qd[j];
+    if (MODE == 0 && !split) C->torques[(size_t)e * NDOF + 3 * l + j] = tau[j];
   }
   if (MODE == 0 && net && !split) store_lstm(C, e, l, A);
   const int per_leg = C->per_leg, B = C->B;
@@ -1007,16 +1024,16 @@ struct EnvView {
   float *root, *dof, *cmd, *air, *ctime, *blv, *bav, *pg;
   const float *tq, *act, *lact, *ldv, *cf, *rb, *bla;
   uint8_t* lastc;
-  int feet_rows = 0;      // rb holds only the four feet rows (foot f at rb + 13 f) instead of all bodies: the fused step's rows
+  int feet_rows = 0;      // rb holds only the feet rows (foot f at rb + 13 f) instead of all bodies: the fused step's rows
 };
 LG_DEV EnvView global_view(const DevCtx* __restrict__ C, int e) {
   EnvView V;
-  V.root = C->root + (size_t)e * 13; V.dof = C->dof + (size_t)e * 24; V.cmd = C->commands + (size_t)e * 4;
-  V.air = C->feet_air + (size_t)e * 4; V.ctime = C->feet_ctime + (size_t)e * 4;
+  V.root = C->root + (size_t)e * 13; V.dof = C->dof + (size_t)e * 2 * NDOF; V.cmd = C->commands + (size_t)e * 4;
+  V.air = C->feet_air + (size_t)e * NLEG; V.ctime = C->feet_ctime + (size_t)e * NLEG;
   V.blv = C->base_lin_vel + (size_t)e * 3; V.bav = C->base_ang_vel + (size_t)e * 3; V.pg = C->proj_grav + (size_t)e * 3;
-  V.tq = C->torques + (size_t)e * 12; V.act = C->actions + (size_t)e * 12; V.lact = C->last_actions + (size_t)e * 12;
-  V.ldv = C->last_dof_vel + (size_t)e * 12; V.cf = C->cforce + (size_t)e * C->B * 3; V.rb = C->rigid + (size_t)e * C->B * 13;
-  V.lastc = C->last_contacts + (size_t)e * 4; V.bla = C->base_lin_acc + (size_t)e * 3;
+  V.tq = C->torques + (size_t)e * NDOF; V.act = C->actions + (size_t)e * NDOF; V.lact = C->last_actions + (size_t)e * NDOF;
+  V.ldv = C->last_dof_vel + (size_t)e * NDOF; V.cf = C->cforce + (size_t)e * C->B * 3; V.rb = C->rigid + (size_t)e * C->B * 13;
+  V.lastc = C->last_contacts + (size_t)e * NLEG; V.bla = C->base_lin_acc + (size_t)e * 3;
   return V;
 }
 
@@ -1082,7 +1099,7 @@ LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int
     o0 = to[0]; o1 = to[1]; o2 = to[2];
     org[0] = o0; org[1] = o1; org[2] = o2;
   }
-  for (int d = 0; d < 12; ++d) {   // LR:450-465
+  for (int d = 0; d < NDOF; ++d) {   // LR:450-465
     dof[2 * d] = g.default_dof_pos[d] * rand_float(0.5f, 1.5f, U[LG_RS_DOF + d]);
     dof[2 * d + 1] = 0.f;
   }
@@ -1105,17 +1122,17 @@ LG_DEV void reset_env(const DevCtx* __restrict__ C, const EnvView& V, int e, int
   for (int i = 0; i < 6; ++i) r[7 + i] = rand_float(-0.5f, 0.5f, U[LG_RS_ROOT_VEL + i]);
   for (int i = 0; i < 13; ++i) root[i] = r[i];
   resample_commands(C, cmd, U, LG_RS_CMD_RESET);
-  if (zero_sea) for (int d = 0; d < 12; ++d) { C->last_actions[(size_t)e * 12 + d] = 0.f; C->last_dof_vel[(size_t)e * 12 + d] = 0.f; }
-  for (int f = 0; f < 4; ++f) { V.air[f] = 0.f; V.ctime[f] = 0.f; }
+  if (zero_sea) for (int d = 0; d < NDOF; ++d) { C->last_actions[(size_t)e * NDOF + d] = 0.f; C->last_dof_vel[(size_t)e * NDOF + d] = 0.f; }
+  for (int f = 0; f < NLEG; ++f) { V.air[f] = 0.f; V.ctime[f] = 0.f; }
   C->ep_len[e] = 0;
   C->reset_buf[e] = 1;
   if (zero_sea && g.control_type == LG_CTRL_ACTUATOR_NET) {   // anymal.py:78-82
-    const size_t N12 = (size_t)C->N * 12;
+    const size_t N12 = (size_t)C->N * NDOF;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int lay = 0; lay < 2; ++lay) {
-      float4* ph = (float4*)(C->sea_h + (lay * N12 + (size_t)e * 12) * 8);
-      float4* pc = (float4*)(C->sea_c + (lay * N12 + (size_t)e * 12) * 8);
-      for (int k = 0; k < 24; ++k) { ph[k] = z4; pc[k] = z4; }
+      float4* ph = (float4*)(C->sea_h + (lay * N12 + (size_t)e * NDOF) * 8);
+      float4* pc = (float4*)(C->sea_c + (lay * N12 + (size_t)e * NDOF) * 8);
+      for (int k = 0; k < 2 * NDOF; ++k) { ph[k] = z4; pc[k] = z4; }
     }
   }
 }
@@ -1138,7 +1155,7 @@ LG_DEV float async_gait_value(const lg_config& g, const float* dof) {
     align += sqrtf(ss / (float)(n - 1));
   }
   float nominal = 0.f;
-  for (int d = 0; d < LG_NUM_DOF; ++d) { const float x = dof[2 * d] - g.async_dof_nominal[d]; nominal += x * x * g.async_dof_weight[d]; }
+  for (int d = 0; d < NDOF; ++d) { const float x = dof[2 * d] - g.async_dof_nominal[d]; nominal += x * x * g.async_dof_weight[d]; }
   return align * g.async_weights[0] + nominal * g.async_weights[1] + g.async_foot_z_align * g.async_weights[2];
 }
 LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, int id, const float* feat, const float* fn, float bh,
@@ -1166,7 +1183,7 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     }
     case LG_REW_BASE_FOOT_HEIGHT: {
       float s = 0.f; int n = 0;
-      for (int f = 0; f < 4; ++f) if (ctime[f] > 1e-3f) { s += FRB(f, 2); ++n; }
+      for (int f = 0; f < NLEG; ++f) if (ctime[f] > 1e-3f) { s += FRB(f, 2); ++n; }
       float est = n > 0 ? s / (float)n : root[2] - g.base_height_target;
       return SQ((root[2] - est) - g.base_height_target);
     }
@@ -1180,27 +1197,27 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     case LG_REW_COLLISION: { float s = 0.f; for (int i = 0; i < m.num_penalised; ++i) s += fn[m.penalised_contact_indices[i]] > 0.1f ? 1.f : 0.f; return s; }
     case LG_REW_FEET_STUMBLE: {
       bool any = false;
-      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; any |= sqrtf(SQ(cf[3 * b]) + SQ(cf[3 * b + 1])) > 5.f * fabsf(cf[3 * b + 2]); }
+      for (int f = 0; f < NLEG; ++f) { int b = m.feet_indices[f]; any |= sqrtf(SQ(cf[3 * b]) + SQ(cf[3 * b + 1])) > 5.f * fabsf(cf[3 * b + 2]); }
       return any ? 1.f : 0.f;
     }
     case LG_REW_FEET_STUMBLE_LIFTUP: {
       float s = 0.f;
-      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool st = sqrtf(SQ(cf[3 * b]) + SQ(cf[3 * b + 1])) > 5.f * fabsf(cf[3 * b + 2]); s += (st ? 1.f : 0.f) * FRB(f, 9); }
+      for (int f = 0; f < NLEG; ++f) { int b = m.feet_indices[f]; bool st = sqrtf(SQ(cf[3 * b]) + SQ(cf[3 * b + 1])) > 5.f * fabsf(cf[3 * b + 2]); s += (st ? 1.f : 0.f) * FRB(f, 9); }
       return s;
     }
     case LG_REW_FEET_SLIP: {
       float s = 0.f;
-      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool cfl = (cf[3 * b + 2] > 1.f) || lastc[f]; float vn = sqrtf(SQ(FRB(f, 7)) + SQ(FRB(f, 8))); s += (cfl ? 1.f : 0.f) * SQ(vn); }
+      for (int f = 0; f < NLEG; ++f) { int b = m.feet_indices[f]; bool cfl = (cf[3 * b + 2] > 1.f) || lastc[f]; float vn = sqrtf(SQ(FRB(f, 7)) + SQ(FRB(f, 8))); s += (cfl ? 1.f : 0.f) * SQ(vn); }
       return s;
     }
     case LG_REW_JUMP_AIR: {
       float s = 0.f;
-      for (int f = 0; f < 4; ++f) { int b = m.feet_indices[f]; bool cfl = (cf[3 * b + 2] > 1.f) || lastc[f]; s += (cfl ? 0.f : 1.f) * (air[f] - 0.5f); }
-      return fmaxf(s - 2.f, 0.f);
+      for (int f = 0; f < NLEG; ++f) { int b = m.feet_indices[f]; bool cfl = (cf[3 * b + 2] > 1.f) || lastc[f]; s += (cfl ? 0.f : 1.f) * (air[f] - 0.5f); }
+      return fmaxf(s - NLEG / 2.f, 0.f);      // RM:148: len(feet_indices) / 2
     }
     case LG_REW_FEET_AIR_TIME: {   // RM:150-163, stateful; the stand classes run it on feet 1 and 3 only and leave feet_contact_time alone (anymal.py:287-299)
       float s = 0.f;
-      for (int f = stand ? 1 : 0; f < 4; f += stand ? 2 : 1) {
+      for (int f = stand ? 1 : 0; f < NLEG; f += stand ? 2 : 1) {
         int b = m.feet_indices[f]; bool contact = cf[3 * b + 2] > 1.f; bool cfl = contact || lastc[f];
         lastc[f] = contact ? 1 : 0;
         float first = (air[f] > 0.f && cfl) ? 1.f : 0.f;
@@ -1215,17 +1232,22 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
       for (int f = 1; f < 4; f += 2) any |= (cf[3 * m.feet_indices[f] + 2] > 1.f) || lastc[f];
       return any ? 0.f : 1.f;
     }
-    case LG_REW_FEET_CONTACT_FORCES: { float s = 0.f; for (int f = 0; f < 4; ++f) s += fmaxf(fn[m.feet_indices[f]] - g.max_contact_force, 0.f); return s; }
+    case LG_REW_FEET_CONTACT_FORCES: { float s = 0.f; for (int f = 0; f < NLEG; ++f) s += fmaxf(fn[m.feet_indices[f]] - g.max_contact_force, 0.f); return s; }
     case LG_REW_GAIT_2_STEP: {
 #define SYNC(a, b) (fminf(SQ(air[a] - air[b]), 4.f) + fminf(SQ(ctime[a] - ctime[b]), 4.f))
 #define ASYN(a, b) (fminf(SQ(air[a] - ctime[b]), 4.f) + fminf(SQ(ctime[a] - air[b]), 4.f))
+#if NLEG == 6   // ElSpider._reward_gait_2_step (elspider.py:365-407): feet (alphabetical) 0 LB, 1 LF, 2 LM, 3 RB, 4 RF, 5 RM; tripods (0, 1, 5) and (2, 3, 4)
+      float sr = ((SYNC(0, 1) + SYNC(0, 5) + SYNC(1, 5)) / 3 + (SYNC(2, 3) + SYNC(2, 4) + SYNC(3, 4)) / 3) / 2;
+      float ar = (ASYN(0, 2) + ASYN(0, 3) + ASYN(0, 4) + ASYN(1, 2) + ASYN(1, 3) + ASYN(1, 4) + ASYN(5, 2) + ASYN(5, 3) + ASYN(5, 4)) / 9;
+#else
       float sr = (SYNC(0, 3) + SYNC(1, 2)) / 2;
       float ar = (ASYN(0, 1) + ASYN(0, 2) + ASYN(3, 2) + ASYN(3, 1)) / 4;
+#endif
       float other = g.heading_command ? cmd[3] : cmd[2];
       bool on = cmdn > 0.1f || fabsf(other) >= 0.05f;
       return (sr + ar) * (on ? 1.f : 0.f);
     }
-    case LG_REW_FOUR_FOOTUP: { bool all = true; for (int f = 0; f < 4; ++f) all &= cf[3 * m.feet_indices[f] + 2] < 1.f; return 0.1f * (all ? 1.f : 0.f); }
+    case LG_REW_FOUR_FOOTUP: { bool all = true; for (int f = 0; f < NLEG; ++f) all &= cf[3 * m.feet_indices[f] + 2] < 1.f; return 0.1f * (all ? 1.f : 0.f); }
     case LG_REW_TERMINATION: return (C->reset_buf[e] && !C->time_out[e]) ? 1.f : 0.f;
     case LG_REW_STAND_STILL: return feat[F_STILL] * (cmdn < 0.1f ? 1.f : 0.f);
     case LG_REW_ASYNC_GAIT_SCHEDULER: return async_gait_value(g, V.dof);
@@ -1234,8 +1256,8 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     case LG_REW_TRACKING_ANG_VEL: return expf(-SQ(cmd[2] - (stand ? bav[0] : bav[2])) / g.tracking_sigma);   // anymal.py:283-286
     case LG_REW_GAIT_SCHEDULER: {   // gait_scheduler.py:74-81 on the foot heights / phase stored by the previous step
       if (!g.gait_enabled || step <= 1) return 0.f;
-      float gi = C->gait_idx[e]; const float* fz = C->gait_foot_z + (size_t)e * 4; float s = 0.f;
-      for (int f = 0; f < 4; ++f) {
+      float gi = C->gait_idx[e]; const float* fz = C->gait_foot_z + (size_t)e * NLEG; float s = 0.f;
+      for (int f = 0; f < NLEG; ++f) {
         float ph = fmodf(gi + g.gait_foot_phases[f], 1.0f);
         float tgt = ph < 0.5f ? g.gait_swing_height * sinf(6.28318530717958647692f * ph) : 0.f;
         s += SQ(tgt - fz[f]);
@@ -1381,9 +1403,9 @@ LG_DEV void finalize_from_acc(const DevCtx* __restrict__ C, int nblocks, int bum
 
 // ============================================================================================ post-physics kernel
 // LDS staging area per env (floats)
-enum { S_ROOT = 0, S_DOF = 13, S_CF = 37, S_RB = S_CF + LG_MAX_BODIES * 3, S_ACT = S_RB + LG_MAX_BODIES * 13, S_LACT = S_ACT + 12,
-       S_LDV = S_LACT + 12, S_TQ = S_LDV + 12, S_LRV = S_TQ + 12, S_CMD = S_LRV + 6, S_BLA = S_CMD + 4, S_BAA = S_BLA + 3,
-       S_AIR = S_BAA + 3, S_CT = S_AIR + 4, S_BLV = S_CT + 4, S_BAV = S_BLV + 3, S_PG = S_BAV + 3, S_SUMS = S_PG + 3,
+enum { S_ROOT = 0, S_DOF = 13, S_CF = S_DOF + 2 * NDOF, S_RB = S_CF + NBODY_MAX * 3, S_ACT = S_RB + NBODY_MAX * 13, S_LACT = S_ACT + NDOF,
+       S_LDV = S_LACT + NDOF, S_TQ = S_LDV + NDOF, S_LRV = S_TQ + NDOF, S_CMD = S_LRV + 6, S_BLA = S_CMD + 4, S_BAA = S_BLA + 3,
+       S_AIR = S_BAA + 3, S_CT = S_AIR + NLEG, S_BLV = S_CT + NLEG, S_BAV = S_BLV + 3, S_PG = S_BAV + 3, S_SUMS = S_PG + 3,
        S_GAIT = S_SUMS + LG_MAX_REWARD_TERMS, S_STRIDE = S_GAIT + 1 + 2 };
 
 // LDS of one post-physics instance (EPBP envs): a workgroup of post_kernel, or one wave of the fused step kernel
@@ -1391,23 +1413,23 @@ struct alignas(16) PostLds {
   int64_t s_eplen[EPBP];
   float s_h[EPBP][MAX_P];
   float s_env[EPBP][S_STRIDE];
-  float s_prop[EPBP][48];
+  float s_prop[EPBP][NPROP];
   float s_part[EPBP][PART_STRIDE];
   float s_u[EPBP][LG_RS_NOISE];      // uniforms of slots 0..31 (commands, push, curriculum, reset)
-  float s_feat[EPBP][F_COUNT][12];
+  float s_feat[EPBP][F_COUNT][NDOF];
   float s_fsum[EPBP][F_COUNT];
-  float s_fn[EPBP][LG_MAX_BODIES];
+  float s_fn[EPBP][NBODY_MAX];
   float s_rk[EPBP][LG_MAX_REWARD_TERMS];
-  float s_old[EPBP][8];
+  float s_old[EPBP][2 * NLEG];
   float s_rootz[EPBP], s_bh[EPBP];
   float s_level[EPBP];               // terrain level at the start of the step (re-read after a reset)
   float s_level0[EPBP];              // ... and a copy that stays (subset steps: the finisher needs the sum before and after)
   int s_e[EPBP];
-  uint8_t s_lastc[EPBP][4], s_oldc[EPBP][4];
+  uint8_t s_lastc[EPBP][NLEG], s_oldc[EPBP][NLEG];
   uint8_t s_flag[EPBP], s_did_reset[EPBP], s_root_dirty[EPBP], s_term[EPBP], s_tout[EPBP];
 };
 
-// The post-physics step of one instance = EPBP (4) envs: rows [inst * 4, inst * 4 + 4) of the launch.
+// The post-physics step of one instance = EPBP envs (4; 2 for the hexapod): rows [inst * EPBP, inst * EPBP + EPBP) of the launch.
 //   FUSED = false: the instance is a 256-thread workgroup of post_kernel; in the wide stages wave w owns env w.
 //   FUSED = true:  the instance is ONE wave of the fused step kernel (physics_kernel's tail: the four waves of a physics
 //                  workgroup take four envs each of its sixteen); the wave owns all four envs in the wide stages (NQ = 4
@@ -1462,14 +1484,14 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   // Per-DOF constants of the narrow stages (lane sl of an env's sixteen owns DOF sl there), requested now so that their
   // latency overlaps the staging loads instead of standing in the dependent chain of stage (2.1) / (2.4); likewise the
   // 64-bit modulo of the push schedule.
-  const int sl_pf = ln & 15, d_pf = min(sl_pf, 11);
+  const int sl_pf = ln & (LPE - 1), d_pf = min(sl_pf, NDOF - 1);
   const float pf_lim0 = g.dof_pos_limits[d_pf][0], pf_lim1 = g.dof_pos_limits[d_pf][1];
   const float pf_vlim = m.dof_vel_limit[d_pf], pf_tlim = m.torque_limit[d_pf], pf_dflt = g.default_dof_pos[d_pf];
-  const float pf_dflt_r0 = g.default_dof_pos[max(sl_pf - 12, 0)], pf_dflt_r1 = g.default_dof_pos[min(sl_pf + 4, 11)];   // entries 12..23 of the observation
+  const float pf_dflt_r0 = g.default_dof_pos[min(max(sl_pf - 12, 0), NDOF - 1)], pf_dflt_r1 = g.default_dof_pos[min(sl_pf + LPE - 12, NDOF - 1)];   // entries 12..12+NDOF-1 of the observation: rounds 0 / 1 of stage (2.4)
   // (the step counter is 64-bit; its modulo is a ~150-instruction emulation, a 32-bit one a fifth of that: taken whenever it fits)
   const bool push_hit = (step >> 32) == 0 ? ((uint32_t)step % (uint32_t)g.push_interval == 0u) : (step % g.push_interval == 0);
   const bool push_now = !ro && g.push_robots && push_hit;                                                               // LR:402-403
-  const float pf_value = K.values ? K.values[min(inst * EPBP + (ln >> 4), n - 1)] : 0.f;   // critic value of the narrow-stage lane's env (time-out bootstrap)
+  const float pf_value = K.values ? K.values[min(inst * EPBP + ln / LPE, n - 1)] : 0.f;   // critic value of the narrow-stage lane's env (time-out bootstrap)
 
   // ---- (1a) height scan from the post-physics root pose (LR:400-401).  Order of the memory traffic of this kernel's
   // first stage: [scan inputs: base pose + scan points] -> [all staging loads] -> wait for the scan inputs only ->
@@ -1515,10 +1537,10 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
 
   // ---- (0) stage the env rows in LDS.  Every global load is issued before the first LDS store, so the phase costs one
   // memory latency instead of one per tensor.
-  static_assert(LG_MAX_BODIES * 13 <= 256 && LG_MAX_BODIES * 3 <= 64 && LG_MAX_REWARD_TERMS <= 64 && LG_RS_NOISE / 4 <= 64,
-                "staging assumes <= 4 row chunks of 64 lanes for the body states and one for every other row");
+  constexpr int RBC = (NBODY_MAX * 13 + 63) / 64, CFC = (NBODY_MAX * 3 + 63) / 64;   // 64-lane chunks of the body-state / contact-force rows
+  static_assert(2 * NDOF <= 64 && LG_MAX_REWARD_TERMS <= 64 && LG_RS_NOISE / 4 <= 64, "staging assumes one 64-lane chunk for every row but the per-body ones");
   const int LRB = B * 13;
-  float v_rb[NQ][4], v_row[NQ][14], v_sum[NQ];
+  float v_rb[NQ][RBC], v_cf[NQ][CFC], v_row[NQ][14], v_sum[NQ];
   uint8_t v_lc[NQ], v_flag[NQ]; int64_t v_len[NQ], v_lvl[NQ];
 #define LDV(i, SRC, LEN) v_row[q][i] = 0.f; if (ln < (LEN)) v_row[q][i] = (SRC)[(size_t)e * (LEN) + ln];
 #define STV(i, OFF, LEN) if (hv_[q] && ln < (LEN)) S[(OFF) + ln] = v_row[q][i];
@@ -1526,17 +1548,22 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   for (int q = 0; q < NQ; ++q) {
     const int e = eq[q];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RBC; ++j) {
       const int k_ = ln + j * 64; v_rb[q][j] = 0.f;
       if (k_ < LRB) v_rb[q][j] = C->rigid[(size_t)e * LRB + k_];
     }
-    LDV(0, C->root, 13) LDV(1, C->dof, 24) LDV(2, C->cforce, B * 3)
-    LDV(3, C->actions, 12) LDV(4, C->last_actions, 12) LDV(5, C->last_dof_vel, 12) LDV(6, C->torques, 12)
+#pragma unroll
+    for (int j = 0; j < CFC; ++j) {
+      const int k_ = ln + j * 64; v_cf[q][j] = 0.f;
+      if (k_ < B * 3) v_cf[q][j] = C->cforce[(size_t)e * (B * 3) + k_];
+    }
+    LDV(0, C->root, 13) LDV(1, C->dof, 2 * NDOF)
+    LDV(3, C->actions, NDOF) LDV(4, C->last_actions, NDOF) LDV(5, C->last_dof_vel, NDOF) LDV(6, C->torques, NDOF)
     LDV(7, C->last_root_vel, 6) LDV(8, C->commands, 4) LDV(9, C->base_lin_acc, 3) LDV(10, C->base_ang_acc, 3)
-    LDV(11, C->feet_air, 4) LDV(12, C->feet_ctime, 4) LDV(13, C->gait_idx, 1)
+    LDV(11, C->feet_air, NLEG) LDV(12, C->feet_ctime, NLEG) LDV(13, C->gait_idx, 1)
     v_sum[q] = 0.f;                                    // episode sums are (K, N): row k, envs contiguous
     if (ln < g.num_reward_terms) v_sum[q] = C->ep_sums[(size_t)ln * C->N + e];
-    v_lc[q] = 0; if (ln < 4) v_lc[q] = C->last_contacts[(size_t)e * 4 + ln];
+    v_lc[q] = 0; if (ln < NLEG) v_lc[q] = C->last_contacts[(size_t)e * NLEG + ln];
     v_len[q] = C->ep_len[e]; v_flag[q] = C->reset_buf[e]; v_lvl[q] = C->levels[e];
     if (!(g.curriculum && !ro)) v_lvl[q] = 0;
   }
@@ -1565,16 +1592,21 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
     const int el = FUSED ? q : wv_el;
     float* S = L.s_env[el];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RBC; ++j) {
       const int k_ = ln + j * 64;
       if (hv_[q] && k_ < LRB) S[S_RB + k_] = v_rb[q][j];
     }
-    STV(0, S_ROOT, 13) STV(1, S_DOF, 24) STV(2, S_CF, B * 3)
-    STV(3, S_ACT, 12) STV(4, S_LACT, 12) STV(5, S_LDV, 12) STV(6, S_TQ, 12)
+#pragma unroll
+    for (int j = 0; j < CFC; ++j) {
+      const int k_ = ln + j * 64;
+      if (hv_[q] && k_ < B * 3) S[S_CF + k_] = v_cf[q][j];
+    }
+    STV(0, S_ROOT, 13) STV(1, S_DOF, 2 * NDOF)
+    STV(3, S_ACT, NDOF) STV(4, S_LACT, NDOF) STV(5, S_LDV, NDOF) STV(6, S_TQ, NDOF)
     STV(7, S_LRV, 6) STV(8, S_CMD, 4) STV(9, S_BLA, 3) STV(10, S_BAA, 3)
-    STV(11, S_AIR, 4) STV(12, S_CT, 4) STV(13, S_GAIT, 1)
+    STV(11, S_AIR, NLEG) STV(12, S_CT, NLEG) STV(13, S_GAIT, 1)
     if (hv_[q] && ln < g.num_reward_terms) S[S_SUMS + ln] = v_sum[q];
-    if (hv_[q] && ln < 4) L.s_lastc[el][ln] = v_lc[q];
+    if (hv_[q] && ln < NLEG) L.s_lastc[el][ln] = v_lc[q];
     if (hv_[q] && ln == 0) { L.s_eplen[el] = v_len[q]; L.s_flag[el] = v_flag[q]; L.s_level[el] = (float)v_lvl[q]; L.s_level0[el] = (float)v_lvl[q]; }
   }
 #undef LDV
@@ -1594,12 +1626,12 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   //   (2.2) feature sums (one lane per feature, DOF order = the serial order), callback + termination (one lane);
   //   (2.3) reward terms in config order, episode sums, reset;
   //   (2.4) proprioceptive observation entries, gait phase.
-  static_assert(EPBP * 16 == 64 && F_COUNT <= 8, "phase 2: sixteen lanes per env on one wave");
+  static_assert(EPBP * LPE == 64 && F_COUNT <= 8 && NDOF <= LPE, "phase 2: LPE lanes per env on one wave, a lane per DOF");
   const unsigned term_mask = C->rew_term_mask;  // which reward terms are switched on (wave-uniform)
   const int kfat = C->rew_kfat, kterm = C->rew_kterm; const float term_scale = C->rew_term_scale;   // see reward_meta()
   {
     const bool mine = FUSED || wv == (int)((blockIdx.x >> 8) & 3u);   // (workgroups 256 apart share a CU when all 1024 are resident)
-    const int el = ln >> 4, sl = ln & 15;                   // env of the workgroup, lane within the env (shadow the wave-per-env names)
+    const int el = ln / LPE, sl = ln & (LPE - 1);           // env of the workgroup, lane within the env (shadow the wave-per-env names)
     const bool have = mine && el < nenv;
     float* S = L.s_env[have ? el : 0];
     EnvView V;
@@ -1620,10 +1652,10 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
       if (sl == 1 || sl == 3) { dst[0] = dst[0] * ema + oma * r.x / dt; dst[1] = dst[1] * ema + oma * r.y / dt; dst[2] = dst[2] * ema + oma * r.z / dt; }
       else { dst[0] = r.x; dst[1] = r.y; dst[2] = r.z; }
     }
-    if (have && sl < 12) {
+    if (have && sl < NDOF) {
       const int d = sl;
       const float q_ = dof[2 * d], qd = dof[2 * d + 1], tq = V.tq[d];
-      float (*F)[12] = L.s_feat[el];
+      float (*F)[NDOF] = L.s_feat[el];
       F[F_TQ2][d] = tq * tq;
       F[F_QD2][d] = qd * qd;
       { float a = (V.ldv[d] - qd) / dt; F[F_ACC2][d] = a * a; }
@@ -1634,7 +1666,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
       F[F_STILL][d] = fabsf(q_ - pf_dflt);
     }
     if (have) {
-      for (int b = sl; b < B; b += 16) {
+      for (int b = sl; b < B; b += LPE) {
         const float* cf = V.cf + 3 * b;
         L.s_fn[el][b] = sqrtf(cf[0] * cf[0] + cf[1] * cf[1] + cf[2] * cf[2]);
       }
@@ -1655,7 +1687,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   STAMP(19);
   {
     const bool mine = FUSED || wv == (int)((blockIdx.x >> 8) & 3u);
-    const int el = ln >> 4, sl = ln & 15;
+    const int el = ln / LPE, sl = ln & (LPE - 1);
     const bool have = mine && el < nenv;
     const int e = L.s_e[have ? el : 0];
     float* S = L.s_env[have ? el : 0];
@@ -1668,7 +1700,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
     // (2.2)
     if (have && sl < F_COUNT) {
       float sacc = 0.f;
-      for (int d = 0; d < 12; ++d) sacc += L.s_feat[el][sl][d];
+      for (int d = 0; d < NDOF; ++d) sacc += L.s_feat[el][sl][d];
       L.s_fsum[el][sl] = sacc;
     } else if (have && sl == 8) {
       float sacc = 0.f;
@@ -1712,16 +1744,16 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
     // Terms that come before it in the config order must still see the old values: keep a copy.
     if (have && sl == 0 && kfat < g.num_reward_terms) {
 #pragma unroll
-      for (int f = 0; f < 4; ++f) { L.s_old[el][f] = V.air[f]; L.s_old[el][4 + f] = V.ctime[f]; L.s_oldc[el][f] = V.lastc[f]; }
+      for (int f = 0; f < NLEG; ++f) { L.s_old[el][f] = V.air[f]; L.s_old[el][NLEG + f] = V.ctime[f]; L.s_oldc[el][f] = V.lastc[f]; }
       L.s_rk[el][kfat] = reward_term(C, V, e, LG_REW_FEET_AIR_TIME, L.s_fsum[el], L.s_fn[el], L.s_bh[el], gstep) * g.reward_scales[kfat];
     }
     lds_barrier();
     // (2.3b) every other term on its own lane (they only read); more than sixteen terms take a second round
-    for (int k = sl; have && k < g.num_reward_terms; k += 16) {
+    for (int k = sl; have && k < g.num_reward_terms; k += LPE) {
       if (k == kfat) continue;
       const int id = g.reward_term_ids[k];
       EnvView Vk = V;
-      if (k < kfat && kfat < g.num_reward_terms) { Vk.air = L.s_old[el]; Vk.ctime = L.s_old[el] + 4; Vk.lastc = L.s_oldc[el]; }
+      if (k < kfat && kfat < g.num_reward_terms) { Vk.air = L.s_old[el]; Vk.ctime = L.s_old[el] + NLEG; Vk.lastc = L.s_oldc[el]; }
       L.s_rk[el][k] = id != LG_REW_TERMINATION ? reward_term(C, Vk, e, id, L.s_fsum[el], L.s_fn[el], L.s_bh[el], gstep) * g.reward_scales[k] : 0.f;
     }
     lds_barrier();
@@ -1757,23 +1789,24 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
       // entry i = (S[off_i] - sub_i) * scale_i, branch-free (sub is the default DOF position for entries 12..23, else 0;
       // x - 0 and x * 1 are exact, so this is the reference's arithmetic entry by entry)
       const float ls = g.obs_scale_lin_vel, as = g.obs_scale_ang_vel, ps = g.obs_scale_dof_pos, vs = g.obs_scale_dof_vel;
+      static_assert(3 * LPE >= NPROP && 2 * LPE >= 12 + NDOF, "three rounds cover the proprioceptive entries, the first two the joint angles");
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const int i = sl + 16 * r;
+        const int i = min(sl + LPE * r, NPROP - 1);       // (lanes past the row recompute its last entry)
         const int off = i < 3 ? S_BLV + i : i < 6 ? S_BAV + i - 3 : i < 9 ? S_PG + i - 6 : i < 12 ? S_CMD + i - 9
-                      : i < 24 ? S_DOF + 2 * (i - 12) : i < 36 ? S_DOF + 2 * (i - 24) + 1 : S_ACT + i - 36;
-        const float scale = i < 3 ? ls : i < 6 ? as : i < 9 ? 1.f : i < 11 ? ls : i < 12 ? as : i < 24 ? ps : i < 36 ? vs : 1.f;
-        const float sub = (i >= 12 && i < 24) ? (r == 0 ? pf_dflt_r0 : pf_dflt_r1) : 0.f;
+                      : i < 12 + NDOF ? S_DOF + 2 * (i - 12) : i < 12 + 2 * NDOF ? S_DOF + 2 * (i - 12 - NDOF) + 1 : S_ACT + i - 12 - 2 * NDOF;
+        const float scale = i < 3 ? ls : i < 6 ? as : i < 9 ? 1.f : i < 11 ? ls : i < 12 ? as : i < 12 + NDOF ? ps : i < 12 + 2 * NDOF ? vs : 1.f;
+        const float sub = (i >= 12 && i < 12 + NDOF) ? (r == 0 ? pf_dflt_r0 : pf_dflt_r1) : 0.f;
         sp[i] = (S[off] - sub) * scale;
       }
-      if (sl == 15 && g.gait_enabled && !ro) {
+      if (sl == LPE - 1 && g.gait_enabled && !ro) {
         float x = fmodf(S[S_GAIT] + dt / g.gait_period, 1.0f); if (x < 0.f) x += 1.0f;
         S[S_GAIT] = x;
       }
       // episode sums and the statistics of LR:200-206, one lane per term
       const bool do_reset = L.s_did_reset[el] != 0;
       const int K_ = g.num_reward_terms;
-      for (int k = sl; k < K_ + 3; k += 16) {
+      for (int k = sl; k < K_ + 3; k += LPE) {
         if (k < K_) {
           float tot = S[S_SUMS + k] + (ro ? 0.f : L.s_rk[el][k]);  // compute_reward_rollout does not touch the episode sums
           L.s_part[el][k] = do_reset ? tot : 0.f;
@@ -1793,22 +1826,25 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   for (int q = 0; q < NQ; ++q) {
     const int el = FUSED ? q : wv_el, e = eq[q];
     const float* S = L.s_env[el];
-    UNSTAGE(C->commands, S_CMD, 4) UNSTAGE(C->feet_air, S_AIR, 4) UNSTAGE(C->feet_ctime, S_CT, 4)
+    UNSTAGE(C->commands, S_CMD, 4) UNSTAGE(C->feet_air, S_AIR, NLEG) UNSTAGE(C->feet_ctime, S_CT, NLEG)
     UNSTAGE(C->base_lin_vel, S_BLV, 3) UNSTAGE(C->base_ang_vel, S_BAV, 3) UNSTAGE(C->proj_grav, S_PG, 3)
     UNSTAGE(C->base_lin_acc, S_BLA, 3) UNSTAGE(C->base_ang_acc, S_BAA, 3) UNSTAGE(C->gait_idx, S_GAIT, 1)
-    UNSTAGE(C->last_actions, S_ACT, 12) UNSTAGE(C->last_root_vel, S_ROOT + 7, 6)
-    if (hv_[q] && ln < 4) C->last_contacts[(size_t)e * 4 + ln] = L.s_lastc[el][ln];
+    UNSTAGE(C->last_actions, S_ACT, NDOF) UNSTAGE(C->last_root_vel, S_ROOT + 7, 6)
+    if (hv_[q] && ln < NLEG) C->last_contacts[(size_t)e * NLEG + ln] = L.s_lastc[el][ln];
     if (hv_[q] && ln < 13 && L.s_root_dirty[el]) C->root[(size_t)e * 13 + ln] = S[S_ROOT + ln];
-    if (hv_[q] && ln < 24 && L.s_did_reset[el]) C->dof[(size_t)e * 24 + ln] = S[S_DOF + ln];
-    if (hv_[q] && ln < 12) C->last_dof_vel[(size_t)e * 12 + ln] = S[S_DOF + 2 * ln + 1];
-    if (g.gait_enabled && !ro && hv_[q] && ln < 4) C->gait_foot_z[(size_t)e * 4 + ln] = S[S_RB + m.feet_indices[ln] * 13 + 2];
+    if (hv_[q] && ln < 2 * NDOF && L.s_did_reset[el]) C->dof[(size_t)e * (2 * NDOF) + ln] = S[S_DOF + ln];
+    if (hv_[q] && ln < NDOF) C->last_dof_vel[(size_t)e * NDOF + ln] = S[S_DOF + 2 * ln + 1];
+    if (g.gait_enabled && !ro && hv_[q] && ln < NLEG) C->gait_foot_z[(size_t)e * NLEG + ln] = S[S_RB + m.feet_indices[ln] * 13 + 2];
     if (g.control_type == LG_CTRL_ACTUATOR_NET && hv_[q] && L.s_did_reset[el]) {   // anymal.py:78-82: clear the LSTM state of a reset env
-      const size_t N12 = (size_t)C->N * 12;
+      const size_t N12 = (size_t)C->N * NDOF;
+      constexpr int PL = NDOF * 8;                     // floats per env and layer
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int idx = ln + 64 * j, lay = idx >= 96 ? 1 : 0, k = idx - 96 * lay;
-        C->sea_h[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
-        C->sea_c[(lay * N12 + (size_t)e * 12) * 8 + k] = 0.f;
+      for (int j = 0; j < (2 * PL + 63) / 64; ++j) {
+        const int idx = ln + 64 * j, lay = idx >= PL ? 1 : 0, k = idx - PL * lay;
+        if (idx < 2 * PL) {
+          C->sea_h[(lay * N12 + (size_t)e * NDOF) * 8 + k] = 0.f;
+          C->sea_c[(lay * N12 + (size_t)e * NDOF) * 8 + k] = 0.f;
+        }
       }
     }
     if (hv_[q] && ln < g.num_reward_terms) C->ep_sums[(size_t)ln * C->N + e] = S[S_SUMS + ln];   // back to the (K, N) rows
@@ -1865,7 +1901,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
         const bool in = idx < O;
         if (g.add_noise && in) nv[i] = gq == ln ? nv_pre[i] : C->noise_vec[idx];
         if (g.add_noise && inject && in) u[i] = C->rand_inject[(size_t)e3 * (LG_RS_NOISE + O) + LG_RS_NOISE + idx];
-        if (in && idx >= 48 + P && C->extra_obs) ex[i] = C->extra_obs[(size_t)e3 * g.num_extra_obs + (idx - 48 - P)];
+        if (in && idx >= NPROP + P && C->extra_obs) ex[i] = C->extra_obs[(size_t)e3 * g.num_extra_obs + (idx - NPROP - P)];
       }
       if (g.add_noise && !inject) {
         uint32_t o4[4];
@@ -1878,9 +1914,9 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
         const int idx = 4 * gq + i;
         if (idx < O) {
           float o;
-          if (idx < 48) o = L.s_prop[el3][idx];
-          else if (idx >= 48 + P) o = ex[i];
-          else { float h = (L.s_rootz[el3] - 0.5f) - L.s_h[el3][idx - 48]; o = fminf(fmaxf(h, -1.f), 1.f) * g.obs_scale_height; }
+          if (idx < NPROP) o = L.s_prop[el3][idx];
+          else if (idx >= NPROP + P) o = ex[i];
+          else { float h = (L.s_rootz[el3] - 0.5f) - L.s_h[el3][idx - NPROP]; o = fminf(fmaxf(h, -1.f), 1.f) * g.obs_scale_height; }
           if (g.add_noise) o += (2.f * u[i] - 1.f) * nv[i];
           o = fminf(fmaxf(o, -g.clip_observations), g.clip_observations);
           C->obs[(size_t)e3 * O + idx] = o;
@@ -1911,6 +1947,7 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   post_instance<false>(C, ids, n, mode, rew_out, rew_stride, L, (int)blockIdx.x, (int)gridDim.x, sink);
 }
 
+#if LG_LEGS == 4
 #include "lg_fused_post.h"
 
 // Observation entry idx of the fused tail as one float4: x = bits(source offset | kind << 16) (kind 0: float of the env's LDS row, 1: height
@@ -1924,12 +1961,12 @@ static std::vector<float> pack_obs_table(const lg_config& g, int P) {
     if (idx < O) {
       const float ls = g.obs_scale_lin_vel, as = g.obs_scale_ang_vel, ps = g.obs_scale_dof_pos, vs = g.obs_scale_dof_vel;
       off = idx < 3 ? FS_BLV + idx : idx < 6 ? FS_BAV + idx - 3 : idx < 9 ? FS_PG + idx - 6 : idx < 12 ? FS_CMD + idx - 9
-          : idx < 24 ? FS_DOF + 2 * (idx - 12) : idx < 36 ? FS_DOF + 2 * (idx - 24) + 1 : idx < 48 ? FS_ACT + idx - 36 : 0;
-      scale = idx < 3 ? ls : idx < 6 ? as : idx < 9 ? 1.f : idx < 11 ? ls : idx < 12 ? as : idx < 24 ? ps : idx < 36 ? vs : 1.f;
-      sub = (idx >= 12 && idx < 24) ? g.default_dof_pos[idx - 12] : 0.f;
-      kind = idx < 48 ? 0 : (idx < 48 + P ? 1 : 2);
-      if (kind == 1) { off = std::min(std::max(idx - 48, 0), MAX_P - 1); scale = g.obs_scale_height; }
-      if (kind == 2) off = idx - 48 - P;
+          : idx < 12 + NDOF ? FS_DOF + 2 * (idx - 12) : idx < 12 + 2 * NDOF ? FS_DOF + 2 * (idx - 12 - NDOF) + 1 : idx < NPROP ? FS_ACT + idx - 12 - 2 * NDOF : 0;
+      scale = idx < 3 ? ls : idx < 6 ? as : idx < 9 ? 1.f : idx < 11 ? ls : idx < 12 ? as : idx < 12 + NDOF ? ps : idx < 12 + 2 * NDOF ? vs : 1.f;
+      sub = (idx >= 12 && idx < 12 + NDOF) ? g.default_dof_pos[idx - 12] : 0.f;
+      kind = idx < NPROP ? 0 : (idx < NPROP + P ? 1 : 2);
+      if (kind == 1) { off = std::min(std::max(idx - NPROP, 0), MAX_P - 1); scale = g.obs_scale_height; }
+      if (kind == 2) off = idx - NPROP - P;
       nv = g.add_noise ? g.noise_scale_vec[idx] : 0.f;
     }
     const int code = off | (kind << 16);
@@ -1940,8 +1977,8 @@ static std::vector<float> pack_obs_table(const lg_config& g, int P) {
 // glue between physics_kernel (which only sees declarations) and the tail
 LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid) { finalize_from_acc(C, nblocks, 1, tid, false); }
 LG_DEV bool fused_did_reset(const float* HB, int el) { return HB[FH_MISC + el * FM_STRIDE + FM_DID_RESET] != 0.f; }
-LG_DEV float* fused_foot_row(float* xs, int lane) { return xs + (lane >> 2) * FS_STRIDE + FS_FRB + 13 * (lane & 3); }
-LG_DEV float* fused_act_slot(float* xs, int lane, int d) { return xs + (lane >> 2) * FS_STRIDE + FS_ACT + d; }
+LG_DEV float* fused_foot_row(float* xs, int lane) { return xs + (lane / GRP) * FS_STRIDE + FS_FRB + 13 * (lane % GRP); }
+LG_DEV float* fused_act_slot(float* xs, int lane, int d) { return xs + (lane / GRP) * FS_STRIDE + FS_ACT + d; }
 LG_DEV bool fused_needs_heights_early(const DevCtx* __restrict__ C) {
   return ((C->rew_term_mask >> LG_REW_BASE_HEIGHT) & 1u) != 0u && C->cfg.measure_heights && C->P > 0;
 }
@@ -1952,7 +1989,7 @@ LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot
                                   const float* root, const float* q, const float* qd, const float* tau, const float* last_qd, const V3* fbody,
                                   const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K) {
   STAMP_DECL
-  const int l = lane & 3, el = lane >> 2;
+  const int l = lane % GRP, el = lane / GRP;
   float* S = xs + el * FS_STRIDE;
   if (act_or_null) {        // PD-controlled robot with helper waves: the clipped actions are in this wave's registers
 #pragma unroll
@@ -1972,25 +2009,45 @@ LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot
   STAMP(21);
 }
 
+#else
+// The post-physics step as the tail of the physics kernel (lg_fused_post.h) exists for the four-legged instance; the six-legged one ends
+// its policy step in post_kernel (can_fuse() is false there, these are never called).
+static std::vector<float> pack_obs_table(const lg_config&, int) { return std::vector<float>(4, 0.f); }
+LG_DEV void fused_prefetch(const DevCtx* __restrict__, float*, float*, int, int, int, int64_t, const float*) {}
+LG_DEV void fused_height_scan(const DevCtx* __restrict__, const float (*)[20], float*, int, int, int) {}
+LG_DEV bool fused_noise_predrawn(const float*) { return false; }
+LG_DEV void fused_noise_draw(const float*, int, int, int, int64_t, float (*)[4]) {}
+LG_DEV void fused_noise_park(const float*, float*, int, int, int, const float (*)[4]) {}
+LG_DEV void fused_main_and_serial(const DevCtx* __restrict__, const float*, const LegModel&, float*, float*, float*, int, int, bool, const float*, const float*,
+                                  const float*, const float*, const float*, const V3*, const float*, bool, int64_t, unsigned long long*, const PostSink&) {}
+LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__, const float*, const float*, const float*, int, int, int, int64_t, unsigned long long*, float*) { return false; }
+LG_DEV void fused_finalize(const DevCtx* __restrict__, int, int) {}
+LG_DEV bool fused_did_reset(const float*, int) { return false; }
+LG_DEV float* fused_foot_row(float* xs, int) { return xs; }
+LG_DEV float* fused_act_slot(float* xs, int, int) { return xs; }
+LG_DEV bool fused_needs_heights_early(const DevCtx* __restrict__) { return false; }
+LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__) { return false; }
+#endif
+
 __global__ __launch_bounds__(256) void finalize_kernel(const DevCtx* __restrict__ C, int nblocks, int bump_step, int use_flags) {
   finalize_step(C, nblocks, bump_step, threadIdx.x, use_flags != 0);
 }
 
-// lg_set_state_indexed: one quad per listed env (lane = leg): rows of the caller's full tensors -> simulation state, then the
+// lg_set_state_indexed: one lane group per listed env (lane = leg): rows of the caller's full tensors -> simulation state, then the
 // rigid-body rows of the new pose
 __global__ __launch_bounds__(64) void set_state_kernel(const DevCtx* __restrict__ C, const float* __restrict__ root_src, const float* __restrict__ dof_src,
                                                        const int32_t* __restrict__ ids, int n) {
-  __shared__ float lmod[LM_FIELDS * 4];
-  const int lane = threadIdx.x, l = lane & 3;
+  __shared__ float lmod[LM_FIELDS * GRP];
+  const int lane = threadIdx.x, l = lane % GRP;
   fill_leg_model(lmod, C->lmod, lane, 64);
   lds_barrier();
-  const int kq = blockIdx.x * 16 + (lane >> 2);
-  if (kq >= n) return;
+  const int kq = blockIdx.x * EPW + lane / GRP;
+  if (kq >= n || l >= NLEG) return;
   const int e = ids[kq];
   if (e < 0 || e >= C->N) return;
   const LegModel lm_{lmod, l};
   const float* rs = (root_src ? root_src : C->root) + (size_t)e * 13;
-  const float* ds = (dof_src ? dof_src : C->dof) + ((size_t)e * 12 + 3 * l) * 2;
+  const float* ds = (dof_src ? dof_src : C->dof) + ((size_t)e * NDOF + 3 * l) * 2;
   float r13[13], q[3], qd[3];
 #pragma unroll
   for (int i = 0; i < 13; ++i) r13[i] = rs[i];
@@ -2002,7 +2059,7 @@ __global__ __launch_bounds__(64) void set_state_kernel(const DevCtx* __restrict_
   }
   if (dof_src && dof_src != C->dof) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { C->dof[((size_t)e * 12 + 3 * l + j) * 2] = q[j]; C->dof[((size_t)e * 12 + 3 * l + j) * 2 + 1] = qd[j]; }
+    for (int j = 0; j < 3; ++j) { C->dof[((size_t)e * NDOF + 3 * l + j) * 2] = q[j]; C->dof[((size_t)e * NDOF + 3 * l + j) * 2 + 1] = qd[j]; }
   }
   write_rigid_body_state(C, lm_, e, l, r13, q, qd);
   const int B = C->B, per_leg = C->per_leg;
@@ -2053,19 +2110,19 @@ static size_t build_layout(const lg_config* cfg, const lg_robot_model* model, co
     for (auto s : shp) T.shape[i++] = s;
     for (; i < 4; ++i) T.shape[i] = 1;
   };
-  set(LG_T_ROOT_STATES, LG_F32, {N, 13}); set(LG_T_DOF_STATE, LG_F32, {N, 12, 2});
+  set(LG_T_ROOT_STATES, LG_F32, {N, 13}); set(LG_T_DOF_STATE, LG_F32, {N, NDOF, 2});
   set(LG_T_RIGID_BODY_STATE, LG_F32, {N, B, 13}); set(LG_T_CONTACT_FORCES, LG_F32, {N, B, 3});
-  set(LG_T_TORQUES, LG_F32, {N, 12}); set(LG_T_ACTIONS, LG_F32, {N, 12}); set(LG_T_LAST_ACTIONS, LG_F32, {N, 12});
-  set(LG_T_LAST_DOF_VEL, LG_F32, {N, 12}); set(LG_T_LAST_ROOT_VEL, LG_F32, {N, 6}); set(LG_T_COMMANDS, LG_F32, {N, 4});
+  set(LG_T_TORQUES, LG_F32, {N, NDOF}); set(LG_T_ACTIONS, LG_F32, {N, NDOF}); set(LG_T_LAST_ACTIONS, LG_F32, {N, NDOF});
+  set(LG_T_LAST_DOF_VEL, LG_F32, {N, NDOF}); set(LG_T_LAST_ROOT_VEL, LG_F32, {N, 6}); set(LG_T_COMMANDS, LG_F32, {N, 4});
   set(LG_T_BASE_LIN_VEL, LG_F32, {N, 3}); set(LG_T_BASE_ANG_VEL, LG_F32, {N, 3}); set(LG_T_PROJECTED_GRAVITY, LG_F32, {N, 3});
   set(LG_T_BASE_LIN_ACC, LG_F32, {N, 3}); set(LG_T_BASE_ANG_ACC, LG_F32, {N, 3});
-  set(LG_T_FEET_AIR_TIME, LG_F32, {N, 4}); set(LG_T_FEET_CONTACT_TIME, LG_F32, {N, 4}); set(LG_T_LAST_CONTACTS, LG_U8, {N, 4});
+  set(LG_T_FEET_AIR_TIME, LG_F32, {N, NLEG}); set(LG_T_FEET_CONTACT_TIME, LG_F32, {N, NLEG}); set(LG_T_LAST_CONTACTS, LG_U8, {N, NLEG});
   set(LG_T_MEASURED_HEIGHTS, LG_F32, {N, P > 0 ? P : 1}); set(LG_T_OBS_BUF, LG_F32, {N, O}); set(LG_T_REW_BUF, LG_F32, {N});
   set(LG_T_RESET_BUF, LG_U8, {N}); set(LG_T_TIME_OUT_BUF, LG_U8, {N}); set(LG_T_EPISODE_LENGTH_BUF, LG_I64, {N});
   set(LG_T_EPISODE_SUMS, LG_F32, {LG_MAX_REWARD_TERMS, N}); set(LG_T_TERRAIN_LEVELS, LG_I64, {N}); set(LG_T_TERRAIN_TYPES, LG_I64, {N});
   set(LG_T_ENV_ORIGINS, LG_F32, {N, 3}); set(LG_T_FRICTION_COEFFS, LG_F32, {N}); set(LG_T_BASE_MASS_ADDED, LG_F32, {N});
-  set(LG_T_SEA_HIDDEN_STATE, LG_F32, {2, N * 12, 8}); set(LG_T_SEA_CELL_STATE, LG_F32, {2, N * 12, 8});
-  set(LG_T_GAIT_IDX, LG_F32, {N}); set(LG_T_GAIT_FOOT_Z, LG_F32, {N, 4}); set(LG_T_EXTRAS_EPISODE, LG_F32, {LG_MAX_REWARD_TERMS + 1});
+  set(LG_T_SEA_HIDDEN_STATE, LG_F32, {2, N * NDOF, 8}); set(LG_T_SEA_CELL_STATE, LG_F32, {2, N * NDOF, 8});
+  set(LG_T_GAIT_IDX, LG_F32, {N}); set(LG_T_GAIT_FOOT_Z, LG_F32, {N, NLEG}); set(LG_T_EXTRAS_EPISODE, LG_F32, {LG_MAX_REWARD_TERMS + 1});
   set(LG_T_RAND_INJECT, LG_F32, {N, LG_RS_NOISE + O}); set(LG_T_STEP_COUNTERS, LG_I64, {4});
   int64_t r = ter->rows > 0 ? ter->rows : 1, cc = ter->cols > 0 ? ter->cols : 1;
   set(LG_T_HEIGHT_SAMPLES, LG_I16, {r, cc});
@@ -2088,8 +2145,9 @@ static const char* validate(const lg_config* cfg, const lg_robot_model* model, c
   if (cfg->num_reward_terms < 0 || cfg->num_reward_terms > LG_MAX_REWARD_TERMS) return "too many reward terms";
   if (cfg->num_height_points > MAX_P) return "num_height_points exceeds the 192 points the post kernel stages in LDS";
   if (cfg->num_extra_obs < 0) return "num_extra_obs is negative";
-  if (cfg->num_obs != 48 + (cfg->measure_heights ? cfg->num_height_points : 0) + cfg->num_extra_obs) return "num_obs does not match the observation layout";
-  if (model->num_bodies != 1 + 4 * (3 + model->has_foot_body) || model->num_bodies > LG_MAX_BODIES) return "unsupported body count";
+  if (model->num_legs != NLEG) return "num_legs does not match this kernel instance";
+  if (cfg->num_obs != NPROP + (cfg->measure_heights ? cfg->num_height_points : 0) + cfg->num_extra_obs) return "num_obs does not match the observation layout";
+  if (model->num_bodies != 1 + NLEG * (3 + model->has_foot_body) || model->num_bodies > NBODY_MAX) return "unsupported body count";
   if (cfg->decimation <= 0 || cfg->sim_dt <= 0.f) return "bad dt / decimation";
   if (cfg->resampling_steps <= 0) return "resampling_steps must be positive";
   if (cfg->push_robots && cfg->push_interval <= 0) return "push_interval must be positive";
@@ -2097,7 +2155,7 @@ static const char* validate(const lg_config* cfg, const lg_robot_model* model, c
   if (ter->mesh_type != LG_MESH_PLANE && (ter->rows < 2 || ter->cols < 2 || !ter->height_samples)) return "rough terrain without height samples";
   if (ter->mesh_type == LG_MESH_TRIMESH && !ter->collision_mesh) return "trimesh terrain without a collision mesh (lg_mesh_create)";
   if (cfg->curriculum && (ter->num_levels <= 0 || ter->num_types <= 0 || !ter->terrain_origins)) return "curriculum needs terrain_origins";
-  for (int l = 0; l < 4; ++l) if (model->cp_count[l] < 0 || model->cp_count[l] > LG_MAX_CP) return "bad cp_count";
+  for (int l = 0; l < NLEG; ++l) if (model->cp_count[l] < 0 || model->cp_count[l] > LG_MAX_CP) return "bad cp_count";
   for (int k = 0; k < cfg->num_reward_terms; ++k) if (cfg->reward_term_ids[k] < 0 || cfg->reward_term_ids[k] >= LG_REW_COUNT) return "unknown reward term id";
   if (!cfg->noise_scale_vec) return "noise_scale_vec is null";
   if (cfg->num_height_points > 0 && !cfg->height_points) return "height_points is null";
@@ -2168,7 +2226,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   hot_config(h);
   h.mesh_cache = nullptr;
   if (ter->mesh_type == LG_MESH_TRIMESH) {
-    const size_t nf = (size_t)cfg->num_envs * 4 * LG_MAX_CP * 4;
+    const size_t nf = (size_t)cfg->num_envs * NLEG * LG_MAX_CP * 4;
     std::vector<float> init(nf, -1.f);                   // distance < 0: no entry
     if (hipMalloc((void**)&c->mesh_cache, nf * 4) != hipSuccess ||
         hipMemcpy(c->mesh_cache, init.data(), nf * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("mesh contact cache allocation failed");
@@ -2280,9 +2338,9 @@ int lg_get_tensor(lg_ctx* c, int id, void** dptr, int64_t shape[4], int32_t* ndi
   return LG_OK;
 }
 
-__global__ void set_n_stepped(DevCtx* C, int n) { C->n_stepped = n; }
+static __global__ void set_n_stepped(DevCtx* C, int n) { C->n_stepped = n; }
 // sum of all terrain levels before a subset step (exact in float up to 2^24)
-__global__ __launch_bounds__(256) void level_total_kernel(DevCtx* C) {
+static __global__ __launch_bounds__(256) void level_total_kernel(DevCtx* C) {
   __shared__ float red[256];
   float s = 0.f;
   for (int e = threadIdx.x; e < C->N; e += 256) s += (float)C->levels[e];
@@ -2306,8 +2364,8 @@ static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t*
 
 // fuse: the post-physics step runs as the tail of the physics kernel (full steps of all envs with helper waves; LG_FUSE=0 keeps
 // the two-launch path, which every split / subset / rollout entry point uses anyway)
-static bool can_fuse(const lg_ctx* c) { return c->fuse && (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) && c->h.P <= MAX_P; }
-static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = 12, bool fuse = false,
+static bool can_fuse(const lg_ctx* c) { return LG_LEGS == 4 && c->fuse && (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) && c->h.P <= MAX_P; }
+static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = NDOF, bool fuse = false,
                            PostSink sink = PostSink{nullptr, nullptr, nullptr, nullptr, 0.f}) {
   const int nb = (n + EPB - 1) / EPB;
   // helper waves (leg bias, contact detection, a share of the contact set-up; with the actuator network also its three
@@ -2335,7 +2393,7 @@ int lg_step(lg_ctx* c, const float* actions, void* stream) {
   }
   if (ev) (void)hipEventRecord(ev[0], st);
   const bool fuse = can_fuse(c);
-  launch_physics(c, st, actions, nullptr, c->h.N, 12, fuse);
+  launch_physics(c, st, actions, nullptr, c->h.N, NDOF, fuse);
   if (ev) (void)hipEventRecord(ev[1], st);
   if (fuse) {                                            // one launch per policy step
     if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
@@ -2355,7 +2413,7 @@ int lg_step_transition(lg_ctx* c, const float* actions, float* next_observations
   hipStream_t st = (hipStream_t)stream;
   const PostSink sink{next_observations, values, rewards, dones, gamma};
   if (can_fuse(c)) {
-    launch_physics(c, st, actions, nullptr, c->h.N, 12, true, sink);
+    launch_physics(c, st, actions, nullptr, c->h.N, NDOF, true, sink);
     HIP_TRY(c, hipGetLastError());
     return LG_OK;
   }
@@ -2430,10 +2488,10 @@ int lg_step_physics(lg_ctx* c, const float* actions, void* stream) {
 
 // RobotBatchRollout._sync_main_to_rollout (robot_batch_rollout.py:1447-1535): env i*(1+R) is main i, the next R envs are
 // its rollouts; one lane per (rollout env, float) copies the 12 state tensors the reference copies.
-__global__ __launch_bounds__(256) void sync_kernel(const DevCtx* __restrict__ C, int R, float drift, uint32_t seed_lo, uint32_t call) {
+static __global__ __launch_bounds__(256) void sync_kernel(const DevCtx* __restrict__ C, int R, float drift, uint32_t seed_lo, uint32_t call) {
   const int B = C->B;
   const bool net = C->cfg.control_type == LG_CTRL_ACTUATOR_NET;
-  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1 + B * 16 + (net ? 12 + 4 * 96 : 0);   // floats (+ one slot for the 4 contact bytes)
+  const int per = 13 + 2 * NDOF + NDOF + NDOF + NDOF + 6 + 3 + 3 + 3 + NLEG + NLEG + 1 + B * 16 + (net ? NDOF + 4 * (NDOF * 8) : 0);   // floats (+ one slot for the contact bytes)
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)C->N * per;
   if (gid >= total) return;
@@ -2449,18 +2507,18 @@ __global__ __launch_bounds__(256) void sync_kernel(const DevCtx* __restrict__ C,
     }
     C->root[(size_t)e * 13 + o] = v; return;
   }
-  o -= 13; if (o < 24) { C->dof[(size_t)e * 24 + o] = C->dof[(size_t)src * 24 + o]; return; }
-  o -= 24; if (o < 12) { C->actions[(size_t)e * 12 + o] = C->actions[(size_t)src * 12 + o]; return; }
-  o -= 12; if (o < 12) { C->last_actions[(size_t)e * 12 + o] = C->last_actions[(size_t)src * 12 + o]; return; }
-  o -= 12; if (o < 12) { C->last_dof_vel[(size_t)e * 12 + o] = C->last_dof_vel[(size_t)src * 12 + o]; return; }
-  o -= 12; if (o < 6) { C->last_root_vel[(size_t)e * 6 + o] = C->last_root_vel[(size_t)src * 6 + o]; return; }
+  o -= 13; if (o < 2 * NDOF) { C->dof[(size_t)e * (2 * NDOF) + o] = C->dof[(size_t)src * (2 * NDOF) + o]; return; }
+  o -= 2 * NDOF; if (o < NDOF) { C->actions[(size_t)e * NDOF + o] = C->actions[(size_t)src * NDOF + o]; return; }
+  o -= NDOF; if (o < NDOF) { C->last_actions[(size_t)e * NDOF + o] = C->last_actions[(size_t)src * NDOF + o]; return; }
+  o -= NDOF; if (o < NDOF) { C->last_dof_vel[(size_t)e * NDOF + o] = C->last_dof_vel[(size_t)src * NDOF + o]; return; }
+  o -= NDOF; if (o < 6) { C->last_root_vel[(size_t)e * 6 + o] = C->last_root_vel[(size_t)src * 6 + o]; return; }
   o -= 6; if (o < 3) { C->base_lin_vel[(size_t)e * 3 + o] = C->base_lin_vel[(size_t)src * 3 + o]; return; }
   o -= 3; if (o < 3) { C->base_ang_vel[(size_t)e * 3 + o] = C->base_ang_vel[(size_t)src * 3 + o]; return; }
   o -= 3; if (o < 3) { C->proj_grav[(size_t)e * 3 + o] = C->proj_grav[(size_t)src * 3 + o]; return; }
-  o -= 3; if (o < 4) { C->feet_air[(size_t)e * 4 + o] = C->feet_air[(size_t)src * 4 + o]; return; }
-  o -= 4; if (o < 4) { C->feet_ctime[(size_t)e * 4 + o] = C->feet_ctime[(size_t)src * 4 + o]; return; }
-  o -= 4; if (o < 1) {
-    for (int f = 0; f < 4; ++f) C->last_contacts[(size_t)e * 4 + f] = C->last_contacts[(size_t)src * 4 + f];
+  o -= 3; if (o < NLEG) { C->feet_air[(size_t)e * NLEG + o] = C->feet_air[(size_t)src * NLEG + o]; return; }
+  o -= NLEG; if (o < NLEG) { C->feet_ctime[(size_t)e * NLEG + o] = C->feet_ctime[(size_t)src * NLEG + o]; return; }
+  o -= NLEG; if (o < 1) {
+    for (int f = 0; f < NLEG; ++f) C->last_contacts[(size_t)e * NLEG + f] = C->last_contacts[(size_t)src * NLEG + f];
     // termination flags: the reference's rollouts are stepped with their main (:554-594) and so raise the same contact
     // termination; their stale flags then feed `_reward_termination` of the rollout steps (:806-809)
     C->reset_buf[e] = C->reset_buf[src]; C->time_out[e] = C->time_out[src];
@@ -2481,13 +2539,14 @@ __global__ __launch_bounds__(256) void sync_kernel(const DevCtx* __restrict__ C,
   // actuator network (control.use_actuator_network in a batch-rollout task): the reference steps the rollouts along with their
   // main, with the main's action (anymal_c_batch_rollout.py:157-182), so their LSTM state and torques equal the main's at
   // every sync; here the mains are stepped alone and the state is copied
-  o -= B * 3; if (o < 12) { C->torques[(size_t)e * 12 + o] = C->torques[(size_t)src * 12 + o]; return; }
-  o -= 12;
+  o -= B * 3; if (o < NDOF) { C->torques[(size_t)e * NDOF + o] = C->torques[(size_t)src * NDOF + o]; return; }
+  o -= NDOF;
   {
-    const size_t N12 = (size_t)C->N * 12;
-    const int which = o / 192, r = o - 192 * which, lay = r / 96, i = r - 96 * lay;      // [h | c] x [layer 0 | layer 1] x (12 x 8)
+    const size_t N12 = (size_t)C->N * NDOF;
+    constexpr int PL = NDOF * 8;
+    const int which = o / (2 * PL), r = o - 2 * PL * which, lay = r / PL, i = r - PL * lay;      // [h | c] x [layer 0 | layer 1] x (dof x 8)
     float* T = which == 0 ? C->sea_h : C->sea_c;
-    T[(lay * N12 + (size_t)e * 12) * 8 + i] = T[(lay * N12 + (size_t)src * 12) * 8 + i];
+    T[(lay * N12 + (size_t)e * NDOF) * 8 + i] = T[(lay * N12 + (size_t)src * NDOF) * 8 + i];
   }
 }
 
@@ -2495,7 +2554,7 @@ int lg_sync_main_to_rollout(lg_ctx* c, int32_t rollouts_per_main, float pos_drif
   if (!c) return LG_ERR_INVALID;
   DeviceScope ds_(c->device);
   if (rollouts_per_main <= 0 || c->h.N % (1 + rollouts_per_main) != 0) { c->err = "num_envs is not num_main * (1 + rollouts_per_main)"; return LG_ERR_INVALID; }
-  const int per = 13 + 24 + 12 + 12 + 12 + 6 + 3 + 3 + 3 + 4 + 4 + 1 + c->h.B * 16 + (c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET ? 12 + 4 * 96 : 0);
+  const int per = 13 + 2 * NDOF + NDOF + NDOF + NDOF + 6 + 3 + 3 + 3 + NLEG + NLEG + 1 + c->h.B * 16 + (c->h.cfg.control_type == LG_CTRL_ACTUATOR_NET ? NDOF + 4 * (NDOF * 8) : 0);
   int64_t total = (int64_t)c->h.N * per;
   hipLaunchKernelGGL(sync_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c->d, rollouts_per_main, pos_drift,
                      (uint32_t)c->h.cfg.seed, (uint32_t)(c->sync_calls++));
@@ -2514,7 +2573,7 @@ int lg_rollout_batch(lg_ctx* c, const float* all_us, int32_t horizon, const int3
   int rc = lg_sync_main_to_rollout(c, rollouts_per_main, pos_drift, stream);
   if (rc != LG_OK) return rc;
   for (int i = 0; i < horizon; ++i) {
-    launch_physics(c, st, all_us + (size_t)i * 12, env_ids, n, horizon * 12);
+    launch_physics(c, st, all_us + (size_t)i * NDOF, env_ids, n, horizon * NDOF);
     rc = launch_post(c, st, nullptr, env_ids, n, 1, rewards + i, horizon);
     if (rc != LG_OK) return rc;
   }
@@ -2526,7 +2585,7 @@ int lg_set_state_indexed(lg_ctx* c, const float* root_states, const float* dof_s
   DeviceScope ds_(c->device);
   if (n < 0 || (n > 0 && !env_ids)) { c->err = "lg_set_state_indexed: bad id list"; return LG_ERR_INVALID; }
   if (n == 0) return LG_OK;
-  hipLaunchKernelGGL(set_state_kernel, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, (hipStream_t)stream, c->d, root_states, dof_state, env_ids, n);
+  hipLaunchKernelGGL(set_state_kernel, dim3((unsigned)((n + EPW - 1) / EPW)), dim3(64), 0, (hipStream_t)stream, c->d, root_states, dof_state, env_ids, n);
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -2569,7 +2628,7 @@ int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
   DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
-  hipLaunchKernelGGL((physics_kernel<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N, 12, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
+  hipLaunchKernelGGL((physics_kernel<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -2579,9 +2638,9 @@ int lg_simulate(lg_ctx* c, void* stream) {
   DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
-    hipLaunchKernelGGL((physics_kernel<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, 12, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
+    hipLaunchKernelGGL((physics_kernel<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
   else
-    hipLaunchKernelGGL((physics_kernel<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, 12, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
+    hipLaunchKernelGGL((physics_kernel<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -2605,3 +2664,4 @@ int lg_reset_idx(lg_ctx* c, const int32_t* env_ids, int32_t n, int32_t update_cu
 }
 
 }  // extern "C"
+}  // namespace LG_NS

@@ -52,21 +52,25 @@ def _fill(arr, values):
 
 def model_struct(m):
     s = abi.lg_robot_model()
+    nl = int(m.get("num_legs", len(m["cp_count"])))
+    if nl not in abi.SUPPORTED_LEG_COUNTS:
+        raise ValueError(f"robot with {nl} legs: the library holds kernel instances for {abi.SUPPORTED_LEG_COUNTS} legs of three joints")
+    s.num_legs = nl
     s.num_bodies, s.has_foot_body = int(m["num_bodies"]), int(m["has_foot_body"])
     s.base_mass = float(m["base_mass"])
     for name in ("base_com", "base_inertia", "joint_pos", "joint_rot", "joint_axis", "link_mass", "link_com",
                  "link_inertia", "foot_pos", "foot_rot", "dof_lower", "dof_upper", "dof_vel_limit", "torque_limit",
                  "cp_pos", "cp_radius"):
         _fill(getattr(s, name), m[name])
-    for l in range(4):
+    for l in range(nl):
         s.cp_count[l] = int(m["cp_count"][l])
         for k in range(abi.LG_MAX_CP):
             s.cp_link[l][k] = int(m["cp_link"][l][k])
             s.cp_body[l][k] = int(m["cp_body"][l][k])
     feet = m["feet_indices"]
-    if len(feet) != 4:
-        raise ValueError(f"expected 4 feet bodies, got {feet} (cfg.asset.foot_name)")
-    for i in range(4):
+    if len(feet) != nl:
+        raise ValueError(f"expected {nl} feet bodies, got {feet} (cfg.asset.foot_name)")
+    for i in range(nl):
         s.feet_indices[i] = int(feet[i])
     pen, term = m["penalised_contact_indices"], m["termination_contact_indices"]
     if len(pen) > abi.LG_MAX_INDEX_LIST or len(term) > abi.LG_MAX_INDEX_LIST:
@@ -110,13 +114,13 @@ def async_gait_weights(cfg, stage):
     return [w("dof_align"), w("dof_nominal_pos"), w("reward_foot_z_align")]
 
 
-def fill_async_gait(c, cfg, stage):
+def fill_async_gait(c, cfg, stage, num_dof=12):
     """`lg_config.async_*` from `cfg.async_gait_scheduler` (`utils/gait_scheduler.py:97-121`) and the stage's weights.  The index sets
     are used as the reference uses them: positions in the section's own `dof_names` list applied to the simulator's DOF order."""
     ag = getattr(cfg, "async_gait_scheduler", None)
     if ag is None or not hasattr(ag, "dof_align_sets_idx"):
         raise AttributeError("rewards.scales.async_gait_scheduler is set but the config has no async_gait_scheduler section")
-    nd = abi.LG_NUM_DOF
+    nd = int(num_dof)
     if len(ag.dof_names) != nd or len(ag.dof_nominal_pos) != nd:
         raise ValueError(f"async_gait_scheduler: {len(ag.dof_names)} joints in a {nd}-DOF robot")
     if len(ag.dof_nominal_pos_weight) != nd:
@@ -124,7 +128,8 @@ def fill_async_gait(c, cfg, stage):
         # (`utils/gait_scheduler.py:158-166`) multiplies a (N, 12) error by it and raises on the first step of any task that scales the term
         raise RuntimeError(f"The size of tensor a ({nd}) must match the size of tensor b ({len(ag.dof_nominal_pos_weight)}) at non-singleton "
                            "dimension 1 [AsyncGaitScheduler.reward_dof_nominal_pos: async_gait_scheduler.dof_nominal_pos_weight must have one "
-                           "entry per joint; the reference raises this on the first step of the task]")
+                           "entry per joint; the reference raises this on the first step of the task.  To run it, set "
+                           f"cfg.async_gait_scheduler.dof_nominal_pos_weight to {nd} entries, e.g. [1.0, 1.0, 3.0] * {nd // 3}]")
     sets = ag.dof_align_sets_idx
     if len(sets) > 4 or any(len(x) > 3 for x in sets) or len(ag.foot_z_align_sets_idx) > 2:
         raise ValueError("async_gait_scheduler: at most 4 joint sets of 3 and 2 foot sets")
@@ -138,16 +143,18 @@ def fill_async_gait(c, cfg, stage):
     c.async_foot_z_align = 0.0          # set by the env once the spawn pose exists (lg_set_async_gait)
 
 
-def noise_scale_vec(cfg, num_obs):
+def noise_scale_vec(cfg, num_obs, num_dof=12):
+    """`_get_noise_scale_vec` (legged_robot.py:533-556; 18 DOF: elspider.py:309-332): the height block is the reference's fixed 187-entry slice."""
     v = np.zeros(num_obs, dtype=np.float32)
     ns, lvl, os_ = cfg.noise.noise_scales, cfg.noise.noise_level, cfg.normalization.obs_scales
+    nd, npro = num_dof, abi.num_proprio(num_dof)
     v[:3] = ns.lin_vel * lvl * os_.lin_vel
     v[3:6] = ns.ang_vel * lvl * os_.ang_vel
     v[6:9] = ns.gravity * lvl
-    v[12:24] = ns.dof_pos * lvl * os_.dof_pos
-    v[24:36] = ns.dof_vel * lvl * os_.dof_vel
+    v[12:12 + nd] = ns.dof_pos * lvl * os_.dof_pos
+    v[12 + nd:12 + 2 * nd] = ns.dof_vel * lvl * os_.dof_vel
     if cfg.terrain.measure_heights:
-        v[48:235] = ns.height_measurements * lvl * os_.height_measurements
+        v[npro:npro + 187] = ns.height_measurements * lvl * os_.height_measurements
     return v
 
 
@@ -180,7 +187,10 @@ class NativeSetup:
         # control
         dof_names = model["dof_names"]
         self.dof_names = dof_names
-        p_gains, d_gains, default_pos = np.zeros(12), np.zeros(12), np.zeros(12)
+        nd = len(dof_names)
+        self.num_dof, self.num_legs = nd, nd // 3
+        self.rand_slots = abi.rand_slots(nd)
+        p_gains, d_gains, default_pos = np.zeros(nd), np.zeros(nd), np.zeros(nd)
         for i, name in enumerate(dof_names):
             default_pos[i] = cfg.init_state.default_joint_angles[name]
             found = False
@@ -213,13 +223,13 @@ class NativeSetup:
         c.obs_scale_lin_vel, c.obs_scale_ang_vel, c.obs_scale_dof_pos = os_.lin_vel, os_.ang_vel, os_.dof_pos
         c.obs_scale_dof_vel, c.obs_scale_height = os_.dof_vel, os_.height_measurements
         c.measure_heights, c.add_noise = int(cfg.terrain.measure_heights), int(cfg.noise.add_noise)
-        self.noise_scale_vec = noise_scale_vec(cfg, num_obs)
+        self.noise_scale_vec = noise_scale_vec(cfg, num_obs, nd)
         c.noise_scale_vec = self.noise_scale_vec.ctypes.data_as(C.POINTER(C.c_float))
         self.height_points = height_points(cfg) if cfg.terrain.measure_heights else np.zeros((0, 2), np.float32)
         c.num_height_points = self.height_points.shape[0]
         c.height_points = self.height_points.ctypes.data_as(C.POINTER(C.c_float))
         c.num_extra_obs = int(num_extra_obs)
-        expect = 48 + (c.num_height_points if cfg.terrain.measure_heights else 0) + c.num_extra_obs
+        expect = abi.num_proprio(nd) + (c.num_height_points if cfg.terrain.measure_heights else 0) + c.num_extra_obs
         if num_obs != expect:
             raise ValueError(f"num_observations={num_obs} but the observation layout has {expect} entries")
 
@@ -246,7 +256,7 @@ class NativeSetup:
         if "async_gait_scheduler" in self.reward_names or any(
                 any(float(x) != 0.0 for x in (v if isinstance(v, (list, tuple)) else [v]))
                 for k, v in class_to_dict(cfg.rewards.scales).items() if k == "async_gait_scheduler"):
-            fill_async_gait(c, cfg, cfg.rewards.reward_min_stage if (reward_stage is None and cfg.rewards.multi_stage_rewards) else (reward_stage or 0))
+            fill_async_gait(c, cfg, cfg.rewards.reward_min_stage if (reward_stage is None and cfg.rewards.multi_stage_rewards) else (reward_stage or 0), nd)
         for k, (n, v) in enumerate(zip(self.reward_names, self.reward_scales)):
             c.reward_term_ids[k] = abi.REWARD_TERM_ID[(reward_term_variants or {}).get(n, n)]
             c.reward_scales[k] = v

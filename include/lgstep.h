@@ -28,13 +28,17 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION 3
+#define LG_ABI_VERSION 4
 
-#define LG_NUM_LEGS 4
+/* Robots of this library: a floating base carrying `lg_robot_model.num_legs` serial chains ("legs") of LG_JOINTS_PER_LEG revolute joints
+ * each.  The library holds one instance of its kernels per supported leg count -- 4 (ANYmal-B/C, A1, Go2) and 6 (ElSpider Air, el_mini.urdf) --
+ * chosen by lg_create from the model; the structs below are sized for the largest, and every (N, dof) / (N, legs) / (N, bodies) tensor has the
+ * model's own extents (12 / 4 / 17 for a quadruped with FOOT bodies, 18 / 6 / 25 for the hexapod). */
+#define LG_MAX_LEGS 6
 #define LG_JOINTS_PER_LEG 3
-#define LG_NUM_DOF 12
+#define LG_MAX_DOF (LG_MAX_LEGS * LG_JOINTS_PER_LEG)
 #define LG_MAX_CP 8            /* collision points per leg lane */
-#define LG_MAX_BODIES 17       /* base + 4 x (HIP, THIGH, SHANK, FOOT) */
+#define LG_MAX_BODIES 25       /* base + 6 x (HIP, THIGH, SHANK, FOOT) */
 #define LG_MAX_REWARD_TERMS 32
 #define LG_MAX_INDEX_LIST 16
 #define LG_LSTM_HIDDEN 8
@@ -75,17 +79,19 @@ enum lg_friction { LG_FRICTION_CONE = 0, LG_FRICTION_PYRAMID = 1 };
 /* rng_mode: counter-based Philox4x32-10 in-kernel, or uniforms injected by the host (parity / golden tests) */
 enum lg_rng { LG_RNG_PHILOX = 0, LG_RNG_INJECT = 1 };
 
-/* slots of the per-env uniform-draw table (one row per env, LG_RS_NOISE + num_obs columns) */
+/* slots of the per-env uniform-draw table (one row per env, LG_RS_NOISE_OF(dof) + num_obs columns); the slots behind the per-DOF draws
+ * depend on the robot's DOF count: 12 DOF -> 20 / 22 / 28 / 32, 18 DOF -> 26 / 28 / 34 / 40 */
 enum lg_rand_slot {
   LG_RS_CMD_CB = 0,     /* 3 draws: _resample_commands from _post_physics_step_callback (:391-393) */
   LG_RS_PUSH = 4,       /* 2 draws: _push_robots (:495) */
   LG_RS_LEVEL = 6,      /* 1 draw : randint_like in _update_terrain_curriculum (:516) */
-  LG_RS_DOF = 8,        /* 12 draws: _reset_dofs (:459) */
-  LG_RS_ROOT_XY = 20,   /* 2 draws: _reset_root_states (:479) */
-  LG_RS_ROOT_VEL = 22,  /* 6 draws: _reset_root_states (:485) */
-  LG_RS_CMD_RESET = 28, /* 3 draws: _resample_commands from reset_idx (:185) */
-  LG_RS_NOISE = 32      /* num_obs draws: compute_observations (:252) */
+  LG_RS_DOF = 8         /* dof draws: _reset_dofs (:459) */
 };
+#define LG_RS_ROOT_XY_OF(dof)   (LG_RS_DOF + (dof))                     /* 2 draws: _reset_root_states (:479) */
+#define LG_RS_ROOT_VEL_OF(dof)  (LG_RS_ROOT_XY_OF(dof) + 2)             /* 6 draws: _reset_root_states (:485) */
+#define LG_RS_CMD_RESET_OF(dof) (LG_RS_ROOT_VEL_OF(dof) + 6)            /* 3 draws: _resample_commands from reset_idx (:185) */
+#define LG_RS_NOISE_OF(dof)     ((LG_RS_CMD_RESET_OF(dof) + 3 + 3) & ~3) /* num_obs draws: compute_observations (:252); a multiple of 4 */
+#define LG_NUM_PROPRIO_OF(dof)  (12 + 3 * (dof))                        /* observation entries in front of the height scan (:237-244): 48 / 66 */
 
 /* reward terms: legged_robot_rew_mixin.py:41-234 (+ Anymal._reward_gait_scheduler, anymal.py:112-114) */
 enum lg_reward_term {
@@ -113,13 +119,13 @@ enum lg_reward_class { LG_RC_BASE = 0, LG_RC_STAND = 1 };
 /* arena tensors (names follow the reference's attribute names, legged_robot.py:559-647, base_task.py:71-79) */
 enum lg_tensor_id {
   LG_T_ROOT_STATES = 0,     /* (N,13) f32  pos3, quat xyzw4, lin vel3, ang vel3 — world frame          */
-  LG_T_DOF_STATE,           /* (N,12,2) f32 pos, vel                                                   */
+  LG_T_DOF_STATE,           /* (N,dof,2) f32 pos, vel                                                  */
   LG_T_RIGID_BODY_STATE,    /* (N,B,13) f32                                                            */
   LG_T_CONTACT_FORCES,      /* (N,B,3) f32 net contact force per body, world frame, last substep       */
-  LG_T_TORQUES,             /* (N,12) f32                                                              */
-  LG_T_ACTIONS,             /* (N,12) f32 clipped actions                                              */
-  LG_T_LAST_ACTIONS,        /* (N,12)                                                                  */
-  LG_T_LAST_DOF_VEL,        /* (N,12)                                                                  */
+  LG_T_TORQUES,             /* (N,dof) f32                                                             */
+  LG_T_ACTIONS,             /* (N,dof) f32 clipped actions                                             */
+  LG_T_LAST_ACTIONS,        /* (N,dof)                                                                 */
+  LG_T_LAST_DOF_VEL,        /* (N,dof)                                                                 */
   LG_T_LAST_ROOT_VEL,       /* (N,6)                                                                   */
   LG_T_COMMANDS,            /* (N,4)                                                                   */
   LG_T_BASE_LIN_VEL,        /* (N,3)                                                                   */
@@ -127,9 +133,9 @@ enum lg_tensor_id {
   LG_T_PROJECTED_GRAVITY,   /* (N,3)                                                                   */
   LG_T_BASE_LIN_ACC,        /* (N,3)                                                                   */
   LG_T_BASE_ANG_ACC,        /* (N,3)                                                                   */
-  LG_T_FEET_AIR_TIME,       /* (N,4)                                                                   */
-  LG_T_FEET_CONTACT_TIME,   /* (N,4)                                                                   */
-  LG_T_LAST_CONTACTS,       /* (N,4) u8                                                                */
+  LG_T_FEET_AIR_TIME,       /* (N,legs)                                                                */
+  LG_T_FEET_CONTACT_TIME,   /* (N,legs)                                                                */
+  LG_T_LAST_CONTACTS,       /* (N,legs) u8                                                             */
   LG_T_MEASURED_HEIGHTS,    /* (N,P) f32                                                               */
   LG_T_OBS_BUF,             /* (N,num_obs) f32                                                         */
   LG_T_REW_BUF,             /* (N) f32                                                                 */
@@ -142,13 +148,13 @@ enum lg_tensor_id {
   LG_T_ENV_ORIGINS,         /* (N,3) f32                                                               */
   LG_T_FRICTION_COEFFS,     /* (N) f32 per-env shape friction (legged_robot.py:332-343)                */
   LG_T_BASE_MASS_ADDED,     /* (N) f32 per-env payload (legged_robot.py:381-383)                       */
-  LG_T_SEA_HIDDEN_STATE,    /* (2,N*12,8) f32 (anymal.py:88)                                           */
-  LG_T_SEA_CELL_STATE,      /* (2,N*12,8) f32 (anymal.py:89)                                           */
+  LG_T_SEA_HIDDEN_STATE,    /* (2,N*dof,8) f32 (anymal.py:88)                                          */
+  LG_T_SEA_CELL_STATE,      /* (2,N*dof,8) f32 (anymal.py:89)                                          */
   LG_T_GAIT_IDX,            /* (N) f32 (gait_scheduler.py:60)                                          */
-  LG_T_GAIT_FOOT_Z,         /* (N,4) f32 foot heights handed to GaitScheduler.step by the previous step (gait_scheduler.py:71) */
+  LG_T_GAIT_FOOT_Z,         /* (N,legs) f32 foot heights handed to GaitScheduler.step by the previous step (gait_scheduler.py:71) */
   LG_T_EXTRAS_EPISODE,      /* (LG_MAX_REWARD_TERMS+1) f32: [k < K] mean episode sum / max_episode_length_s per reward term
                                over the envs reset in the most recent step that reset any (:200-203); [K] = mean terrain level */
-  LG_T_RAND_INJECT,         /* (N, LG_RS_NOISE+num_obs) f32, only read when rng_mode == LG_RNG_INJECT   */
+  LG_T_RAND_INJECT,         /* (N, LG_RS_NOISE_OF(dof)+num_obs) f32, only read when rng_mode == LG_RNG_INJECT   */
   LG_T_STEP_COUNTERS,       /* (4) i64: [0] common_step_counter, [1] #envs reset by the last step       */
   LG_T_HEIGHT_SAMPLES,      /* (rows, cols) i16, read-only terrain grid                                */
   LG_T_TERRAIN_ORIGINS,     /* (levels, types, 3) f32                                                  */
@@ -162,30 +168,31 @@ enum lg_tensor_id {
 };
 
 typedef struct lg_robot_model {
-  int32_t num_bodies;                 /* 1 + 4*(3 + has_foot_body) */
+  int32_t num_legs;                   /* 4 or 6 */
+  int32_t num_bodies;                 /* 1 + num_legs*(3 + has_foot_body) */
   int32_t has_foot_body;              /* FOOT links kept by dont_collapse="true" */
   float base_mass;
   float base_com[3];                  /* base frame */
   float base_inertia[6];              /* about COM, base axes: xx xy xz yy yz zz */
   /* DOF / leg order = Isaac Gym asset order (alphabetical depth-first): leg l, joint j -> dof 3*l+j */
-  float joint_pos[LG_NUM_LEGS][LG_JOINTS_PER_LEG][3];   /* joint frame origin in parent body frame */
-  float joint_rot[LG_NUM_LEGS][LG_JOINTS_PER_LEG][9];   /* row-major rotation parent body -> joint frame at q = 0 */
-  float joint_axis[LG_NUM_LEGS][LG_JOINTS_PER_LEG][3];  /* unit axis, joint frame */
-  float link_mass[LG_NUM_LEGS][LG_JOINTS_PER_LEG];
-  float link_com[LG_NUM_LEGS][LG_JOINTS_PER_LEG][3];    /* link frame */
-  float link_inertia[LG_NUM_LEGS][LG_JOINTS_PER_LEG][6];/* about COM, link axes */
-  float foot_pos[LG_NUM_LEGS][3];     /* FOOT body frame in the last link's frame */
-  float foot_rot[LG_NUM_LEGS][9];
-  float dof_lower[LG_NUM_DOF], dof_upper[LG_NUM_DOF]; /* hard limits; lower >= upper means unlimited */
-  float dof_vel_limit[LG_NUM_DOF];
-  float torque_limit[LG_NUM_DOF];     /* URDF effort */
+  float joint_pos[LG_MAX_LEGS][LG_JOINTS_PER_LEG][3];   /* joint frame origin in parent body frame */
+  float joint_rot[LG_MAX_LEGS][LG_JOINTS_PER_LEG][9];   /* row-major rotation parent body -> joint frame at q = 0 */
+  float joint_axis[LG_MAX_LEGS][LG_JOINTS_PER_LEG][3];  /* unit axis, joint frame */
+  float link_mass[LG_MAX_LEGS][LG_JOINTS_PER_LEG];
+  float link_com[LG_MAX_LEGS][LG_JOINTS_PER_LEG][3];    /* link frame */
+  float link_inertia[LG_MAX_LEGS][LG_JOINTS_PER_LEG][6];/* about COM, link axes */
+  float foot_pos[LG_MAX_LEGS][3];     /* FOOT body frame in the last link's frame */
+  float foot_rot[LG_MAX_LEGS][9];
+  float dof_lower[LG_MAX_DOF], dof_upper[LG_MAX_DOF]; /* hard limits; lower >= upper means unlimited */
+  float dof_vel_limit[LG_MAX_DOF];
+  float torque_limit[LG_MAX_DOF];     /* URDF effort */
   /* collision spheres, grouped by the leg lane that owns them; link -1 = base, 0..2 = leg link, 3 = foot body */
-  int32_t cp_count[LG_NUM_LEGS];
-  int32_t cp_link[LG_NUM_LEGS][LG_MAX_CP];
-  int32_t cp_body[LG_NUM_LEGS][LG_MAX_CP];              /* rigid-body index the contact force is reported on */
-  float cp_pos[LG_NUM_LEGS][LG_MAX_CP][3];              /* in the owning link's frame (foot: last link frame) */
-  float cp_radius[LG_NUM_LEGS][LG_MAX_CP];
-  int32_t feet_indices[LG_NUM_LEGS];
+  int32_t cp_count[LG_MAX_LEGS];
+  int32_t cp_link[LG_MAX_LEGS][LG_MAX_CP];
+  int32_t cp_body[LG_MAX_LEGS][LG_MAX_CP];              /* rigid-body index the contact force is reported on */
+  float cp_pos[LG_MAX_LEGS][LG_MAX_CP][3];              /* in the owning link's frame (foot: last link frame) */
+  float cp_radius[LG_MAX_LEGS][LG_MAX_CP];
+  int32_t feet_indices[LG_MAX_LEGS];
   int32_t num_penalised, penalised_contact_indices[LG_MAX_INDEX_LIST];
   int32_t num_termination, termination_contact_indices[LG_MAX_INDEX_LIST];
 } lg_robot_model;
@@ -215,7 +222,7 @@ typedef struct lg_config {
   float sim_dt; int32_t decimation; float gravity[3];
   /* control */
   int32_t control_type; float action_scale;
-  float p_gains[LG_NUM_DOF], d_gains[LG_NUM_DOF], default_dof_pos[LG_NUM_DOF];
+  float p_gains[LG_MAX_DOF], d_gains[LG_MAX_DOF], default_dof_pos[LG_MAX_DOF];
   float clip_actions, clip_observations;
   float actuator_net[LG_LSTM_NPARAM]; /* w_ih0(32x2) w_hh0(32x8) b_ih0(32) b_hh0(32) w_ih1(32x8) w_hh1(32x8) b_ih1 b_hh1 lin_w(8) lin_b(1) */
   float actuator_in_scale[2], actuator_out_scale;
@@ -238,7 +245,7 @@ typedef struct lg_config {
   int32_t only_positive_rewards;
   int32_t reward_class;               /* enum lg_reward_class */
   float tracking_sigma, base_height_target, max_contact_force, soft_dof_vel_limit, soft_torque_limit;
-  float dof_pos_limits[LG_NUM_DOF][2];/* soft limits (:366-370) */
+  float dof_pos_limits[LG_MAX_DOF][2];/* soft limits (:366-370) */
   /* episode / curriculum */
   float max_episode_length, max_episode_length_s;
   int32_t curriculum, custom_origins, max_terrain_level;
@@ -248,7 +255,7 @@ typedef struct lg_config {
                                        * when projected_gravity.z > 0 (robot upside down) */
   float base_init_state[13];
   /* gait scheduler (anymal.py:59-63, gait_scheduler.py:63-81) */
-  int32_t gait_enabled; float gait_period, gait_swing_height, gait_foot_phases[LG_NUM_LEGS];
+  int32_t gait_enabled; float gait_period, gait_swing_height, gait_foot_phases[LG_MAX_LEGS];
   /* contact solver (legged_robot_config.py:250-267) */
   int32_t solver_iterations;          /* physx.num_position_iterations */
   float contact_offset, max_depenetration_velocity, erp, cfm;
@@ -266,7 +273,7 @@ typedef struct lg_config {
    *                     first tensor): a constant of the spawn pose, async_foot_z_align
    *   term = dof_align * w[0] + dof_nominal_pos * w[1] + foot_z_align * w[2]         (w: the stage's weights, lg_set_async_gait) */
   int32_t async_num_dof_sets, async_dof_sets[4][3];
-  float async_dof_nominal[LG_NUM_DOF], async_dof_weight[LG_NUM_DOF];
+  float async_dof_nominal[LG_MAX_DOF], async_dof_weight[LG_MAX_DOF];
   float async_weights[3], async_foot_z_align;
   int32_t inject_sim_state;           /* parity tests only (like LG_RNG_INJECT): lg_step's post-physics half takes the post-simulation state
                                        * from what the caller put into LG_T_ROOT_STATES / DOF_STATE / TORQUES / CONTACT_FORCES / RIGID_BODY_STATE
@@ -319,7 +326,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
 int lg_get_tensor(lg_ctx* ctx, int tensor_id, void** dptr, int64_t shape[4], int32_t* ndim, int32_t* dtype);
 
 /* One policy step: clip actions, `decimation` x (actuator torques + articulated dynamics + contact), then the
- * fused post-physics step.  `actions` is a device pointer to (N,12) f32.  Replaces legged_robot.py:93-110. */
+ * fused post-physics step.  `actions` is a device pointer to (N,dof) f32.  Replaces legged_robot.py:93-110. */
 int lg_step(lg_ctx* ctx, const float* actions, void* stream);
 
 /* The physics half of lg_step only (LR:93-103): used when a sensor update (ray caster, LR raycast :219-230) must run
@@ -334,7 +341,7 @@ int lg_step_transition(lg_ctx* ctx, const float* actions, float* next_observatio
                        float* rewards, float* dones, void* stream);
 
 /* Main-rollout stepping (envs/batch_rollout/robot_batch_rollout.py): advance only the n listed envs; row k of `actions`
- * (n,12) belongs to env_ids[k] (device pointers).  rollout_mode = 0: the listed envs take a full LeggedRobot step
+ * (n,dof) belongs to env_ids[k] (device pointers).  rollout_mode = 0: the listed envs take a full LeggedRobot step
  * (RobotBatchRollout.step :535-600 for the main envs); rollout_mode = 1: post_physics_step_rollout semantics (:763-817) —
  * no command resampling / pushes / termination / reset, rewards computed but not added to the episode sums, the other
  * envs are not touched (the reference simulates and then restores them, :687, :1585-1640). */
@@ -360,7 +367,7 @@ int lg_post_physics_subset(lg_ctx* ctx, const int32_t* env_ids, int32_t n, int32
 int lg_sync_main_to_rollout(lg_ctx* ctx, int32_t rollouts_per_main, float pos_drift, void* stream);
 
 /* rollout_batch (envs/batch_rollout/robot_traj_grad_sampling.py:249-280, the horizon loop every sampling planner drives):
- * _sync_main_to_rollout, then `horizon` times step_rollout with all_us[:, i, :] (row k of the (n, horizon, 12) plan belongs
+ * _sync_main_to_rollout, then `horizon` times step_rollout with all_us[:, i, :] (row k of the (n, horizon, dof) plan belongs
  * to env_ids[k]; read in place, no per-step copy) while rewards[k, i] receives the reward of that step, then
  * _sync_main_to_rollout again.  Device pointers; 2 + 2 * horizon launches enqueued by one call.  Envs without perception
  * sensors between physics and post-physics only (RobotBatchRollout; the percept env keeps its per-step calls). */

@@ -35,7 +35,15 @@ def test_enums_match_the_header():
     r = parse_enum("lg_reward_term")
     assert r.pop("LG_REW_COUNT") == len(abi.REWARD_TERMS)
     assert {k[len("LG_REW_"):].lower(): v for k, v in r.items()} == abi.REWARD_TERM_ID
-    assert parse_enum("lg_rand_slot") == abi.RAND_SLOTS
+    head = parse_enum("lg_rand_slot")            # the slots in front of the per-DOF draws; the rest follow from the DOF count
+    assert head == {k: v for k, v in abi.RAND_SLOTS.items() if k in head} and set(head) == {"LG_RS_CMD_CB", "LG_RS_PUSH", "LG_RS_LEVEL", "LG_RS_DOF"}
+    assert abi.rand_slots(12) == dict(head, LG_RS_ROOT_XY=20, LG_RS_ROOT_VEL=22, LG_RS_CMD_RESET=28, LG_RS_NOISE=32)
+    assert abi.rand_slots(18) == dict(head, LG_RS_ROOT_XY=26, LG_RS_ROOT_VEL=28, LG_RS_CMD_RESET=34, LG_RS_NOISE=40)
+    for macro in ("LG_RS_ROOT_XY_OF(dof)   (LG_RS_DOF + (dof))", "LG_RS_ROOT_VEL_OF(dof)  (LG_RS_ROOT_XY_OF(dof) + 2)",
+                  "LG_RS_CMD_RESET_OF(dof) (LG_RS_ROOT_VEL_OF(dof) + 6)", "LG_RS_NOISE_OF(dof)     ((LG_RS_CMD_RESET_OF(dof) + 3 + 3) & ~3)",
+                  "LG_NUM_PROPRIO_OF(dof)  (12 + 3 * (dof))"):
+        assert "#define " + macro in HEADER, macro
+    assert (abi.num_proprio(12), abi.num_proprio(18)) == (48, 66)
     d = parse_enum("lg_dtype")
     assert (d["LG_F32"], d["LG_I64"], d["LG_U8"], d["LG_I16"], d["LG_I32"], d["LG_F64"]) == (
         abi.LG_F32, abi.LG_I64, abi.LG_U8, abi.LG_I16, abi.LG_I32, abi.LG_F64)
@@ -44,7 +52,7 @@ def test_enums_match_the_header():
                      LG_CTRL_ACTUATOR_NET=abi.LG_CTRL_ACTUATOR_NET)
     for macro, val in [("LG_MAX_CP", abi.LG_MAX_CP), ("LG_MAX_REWARD_TERMS", abi.LG_MAX_REWARD_TERMS),
                        ("LG_LSTM_NPARAM", abi.LG_LSTM_NPARAM), ("LG_ABI_VERSION", abi.LG_ABI_VERSION),
-                       ("LG_MAX_INDEX_LIST", abi.LG_MAX_INDEX_LIST)]:
+                       ("LG_MAX_INDEX_LIST", abi.LG_MAX_INDEX_LIST), ("LG_MAX_LEGS", abi.LG_MAX_LEGS), ("LG_MAX_BODIES", abi.LG_MAX_BODIES)]:
         assert int(re.search(r"#define\s+%s\s+(\d+)" % macro, HEADER).group(1)) == val
 
 

@@ -6,12 +6,16 @@ in the other: those envs are COUNTED, at most 3 %, and left out).  Measured leve
 DESIGN.md s2.
 
   * ONE SUBSTEP (`lg_compute_torques` + `lg_simulate`) from identical state -- the comparison that isolates the kernel's arithmetic:
-    median <= 1e-6, 99.5 % of the entries of every tensor within 5e-4, every entry within 5e-2 (contact forces 0.25).
+    median <= 1e-6, 99.5 % of the entries of every tensor within 5e-4, every entry within 2e-2 (contact forces 8e-2, root states 1e-3,
+    torques 1e-4): <= 3x the levels measured over all solver / friction combinations (`profiles/r04_parity_levels.json`, written by
+    this module on the GPU box).  The same bar holds for each of the four substeps of a policy step when the state is re-synchronised
+    from the oracle in front of every substep (`test_four_substeps_resynchronised_match_at_the_substep_bar`): substeps 2-4 run the
+    same arithmetic as substep 1, what differs in a whole step is only the input they get.
   * ONE POLICY STEP (4 substeps + post-physics).  Differences of the first substep pass through three more contact solves; how
     fast they grow is a property of the solver, which the oracle shows by itself (a 1e-6 m shift of the ground moves joint speeds
     by up to 0.05 rad/s at a landing under TGS, 0.003 under PGS: tests/test_oracle_physics.py).  TGS (sim.physx.solver_type = 1, the
-    reference's setting; bias velocities taken over dt / 4): median <= 1e-5, 99.5 % within 1e-2, every entry within 0.5 (contact
-    forces and torques 1.0).  PGS: median <= 2e-5, 99.5 % within 2e-3, every entry within 5e-2 (contact forces 0.25).
+    reference's setting; bias velocities taken over dt / 4): median <= 1e-5, 99.5 % within 1e-2, 99.9 % within 5e-2, every entry within
+    0.35 (root states 3e-2, observations 5e-2; contact forces and torques 1.0: a foot that lands a substep earlier).  PGS: median <= 2e-5, 99.5 % within 2e-3, every entry within 5e-2 (contact forces 0.25).
 Integer / index outputs are bit-exact for envs whose float state agrees."""
 import numpy as np
 import pytest
@@ -79,18 +83,33 @@ def contact_pattern(t, n):
 
 MAX_DIFFERENT_CONTACT_ENVS = 0.03      # fraction of envs whose set of loaded bodies differs between HIP and oracle
 BARS = {
-    "substep": dict(frac_ok=0.995, tol=5e-4, med=1e-6, any=5e-2, any_by_name={"contact_forces": 0.25}),
-    "step_tgs": dict(frac_ok=0.995, tol=1e-2, med=1e-5, any=0.5, any_by_name={"contact_forces": 1.0, "torques": 1.0}),
-    "step_pgs": dict(frac_ok=0.995, tol=2e-3, med=2e-5, any=5e-2, any_by_name={"contact_forces": 0.25}),
+    "substep": dict(frac_ok=0.995, tol=5e-4, med=1e-6, any=2e-2, any_by_name={"contact_forces": 8e-2, "root_states": 1e-3, "torques": 1e-4}),
+    "step_tgs": dict(frac_ok=0.995, tol=1e-2, med=1e-5, q999=5e-2, any=0.35,
+                     any_by_name={"contact_forces": 1.0, "torques": 1.0, "root_states": 3e-2, "obs_buf": 5e-2}),
+    "step_pgs": dict(frac_ok=0.995, tol=2e-3, med=2e-5, q999=1e-2, any=5e-2, any_by_name={"contact_forces": 0.25}),
 }
 REPORT = []
+LEVELS = {}      # "<bars or tag>:<tensor>" -> [median, q99.5, q99.9, max] per comparison; dumped to gpurun_out/r04_parity_levels.json at module teardown
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_levels():
+    yield
+    import json, os
+    out = {k: dict(comparisons=len(v), median=max(x[0] for x in v), q995=max(x[1] for x in v), q999=max(x[2] for x in v), max=max(x[3] for x in v))
+           for k, v in sorted(LEVELS.items())}
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(root, exist_ok=True)
+    with open(os.path.join(root, "r04_parity_levels.json"), "w") as f:
+        json.dump(dict(note="err = |hip - oracle| / max(1, |oracle|) over envs whose contact sets agree; worst over all comparisons of tests/test_hip_vs_oracle.py",
+                       levels=out), f, indent=1)
 
 
 def step_bars(setup):
     return "step_tgs" if setup.cfg.solver_type == abi.LG_SOLVER_TGS else "step_pgs"
 
 
-def compare(core, o, names, bars="step_tgs", rows=None):
+def compare(core, o, names, bars="step_tgs", rows=None, tag=None):
     """The bars of the module docstring.  Envs in which a contact within rounding of its activation threshold is on in one
     implementation and off in the other (different bodies loaded in the last substep) are COUNTED -- at most 3 % of the envs -- and
     left out of the entry-wise bars."""
@@ -109,6 +128,9 @@ def compare(core, o, names, bars="step_tgs", rows=None):
         same = err[~differ]                     # the bars apply to the envs whose contact sets agree; the others are counted above
         ok = (same <= B["tol"]).mean() if same.size else 1.0
         worst[name] = (float(np.median(same)) if same.size else 0.0, float(same.max()) if same.size else 0.0, float(err.max()), float(ok))
+        q999 = float(np.quantile(same, 0.999)) if same.size else 0.0
+        LEVELS.setdefault(f"{tag or bars}:{name}", []).append([worst[name][0], float(np.quantile(same, 0.995)) if same.size else 0.0, q999, worst[name][1]])
+        assert "q999" not in B or q999 <= B["q999"], f"{name}: 99.9 % quantile {q999:.3g}"
         assert ok >= B["frac_ok"], f"{name}: only {ok:.4f} of entries within {B['tol']} (max {same.max():.3g})"
         assert same.size == 0 or np.median(same) <= B["med"], f"{name}: median error {np.median(same):.3g}"
         assert same.size == 0 or same.max() <= B["any_by_name"].get(name, B["any"]), \
@@ -146,7 +168,7 @@ def test_single_substep_parity_from_identical_state(kind, solver):
             o.compute_torques(act); o.simulate()
             core.compute_torques(torch.from_numpy(act).cuda()); core.simulate()
             compare(core, o, ["root_states", "dof_state", "rigid_body_state", "contact_forces", "torques", "sea_hidden_state", "sea_cell_state"],
-                    bars="substep")
+                    bars="substep", tag=f"substep/{kind}/{solver}")
             loaded += int((np.abs(o.t["contact_forces"]).reshape(n, -1).max(axis=1) > 1.0).sum())
             for k in COPY:                       # back to the pre-substep state: the policy step below starts from it
                 o.t[k][...] = keep[k]
@@ -175,7 +197,7 @@ def test_single_step_parity_from_identical_state(kind, solver):
                 core.t[name].copy_(torch.from_numpy(o.t[name].copy()))
             o.step(act)
             core.step(torch.from_numpy(act).cuda())
-            compare(core, o, STATE, bars=step_bars(s))
+            compare(core, o, STATE, bars=step_bars(s), tag=f"step/{kind}/{solver}")
             # integer outputs: identical wherever the float state agrees
             ra, rb = core.t["reset_buf"].cpu().numpy(), o.t["reset_buf"]
             assert (ra != rb).mean() <= 0.01
@@ -183,6 +205,34 @@ def test_single_step_parity_from_identical_state(kind, solver):
             assert np.array_equal(core.t["episode_length_buf"].cpu().numpy()[ra == rb], o.t["episode_length_buf"][ra == rb])
         else:
             o.step(act)
+    core.close(); o.close()
+
+
+@pytest.mark.parametrize("kind", ["flat_lstm", "rough_lstm"])
+def test_four_substeps_resynchronised_match_at_the_substep_bar(kind):
+    """Each of the four substeps of a policy step (TGS + pyramid, the default), started from the ORACLE's state of that substep:
+    substeps 2-4 -- the LSTM state carried over, contacts that opened or closed in between -- meet the same bar as the first."""
+    from extended_legged_gym_amd.native import NativeCore
+    from oracle.oracle_lib import OracleEnv
+    n = 256
+    cfg, s, terrain = build(kind, n, seed=13)
+    o = OracleEnv(s)
+    core = NativeCore(s, "cuda:0")
+    rng = init_oracle(o, cfg, s, terrain, n, 13)
+    names = ["root_states", "dof_state", "rigid_body_state", "contact_forces", "torques", "sea_hidden_state", "sea_cell_state"]
+    for it in range(30):
+        act = rng.normal(size=(n, 12)).astype(np.float32)
+        if it % 10 == 9:
+            keep = {k: o.t[k].copy() for k in COPY}
+            for sub in range(cfg.control.decimation):
+                for name in COPY:
+                    core.t[name].copy_(torch.from_numpy(o.t[name].copy()))
+                o.compute_torques(act); o.simulate()
+                core.compute_torques(torch.from_numpy(act).cuda()); core.simulate()
+                compare(core, o, names, bars="substep", tag=f"resync_substep{sub}/{kind}")
+            for k in COPY:
+                o.t[k][...] = keep[k]
+        o.step(act)
     core.close(); o.close()
 
 

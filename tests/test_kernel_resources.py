@@ -30,7 +30,8 @@ def test_headline_kernel_register_and_lds_budget(tmp_path):
         if m and name:
             blocks[name][m.group(1).strip()] = int(m.group(2))
     # physics_kernel<0, false, true>: heightfield / plane terrain, helper waves present = every policy step of the headline config
-    key = [k for k in blocks if k.startswith("_Z14physics_kernelILi0ELb0ELb1E")]
+    # (lg_step.hip is compiled once per leg count, lg_instance.h; without -DLG_LEGS this is the four-legged instance, namespace lg4)
+    key = [k for k in blocks if k.startswith("_ZN3lg414physics_kernelILi0ELb0ELb1E")]
     assert len(key) == 1, sorted(blocks)
     r = blocks[key[0]]
     print(r)
@@ -43,5 +44,28 @@ def test_headline_kernel_register_and_lds_budget(tmp_path):
     assert r["VGPRs"] + r["AGPRs"] <= 512 and r["Occupancy"] == 1, r     # one wave per SIMD by design (s5): the budget of a lone wave
     assert r["LDS Size"] <= 160 * 1024, r
     # the triangle-mesh instance: also without the fallback
-    key = [k for k in blocks if k.startswith("_Z14physics_kernelILi0ELb1ELb1E")]
+    key = [k for k in blocks if k.startswith("_ZN3lg414physics_kernelILi0ELb1ELb1E")]
     assert len(key) == 1 and blocks[key[0]]["SGPRs Spill"] <= 400 and blocks[key[0]]["LDS Size"] <= 160 * 1024, blocks[key[0]]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_six_legged_instance_fits_a_compute_unit(tmp_path):
+    """The hexapod instance (-DLG_LEGS=6: eight lanes per env) of the same source: no vector spills, one workgroup's LDS."""
+    src = os.path.join(ROOT, "extended_legged_gym_amd", "csrc", "lg_step.hip")
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-fno-slp-vectorize", "--cuda-device-only", "-DLG_LEGS=6",
+           "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "lg_step6.o")]
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    blocks, name = {}, None
+    for line in out.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = m.group(1); blocks[name] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/(?:lane|block)\])?(?: \[waves/SIMD\])?: (\d+)", line)
+        if m and name:
+            blocks[name][m.group(1).strip()] = int(m.group(2))
+    key = [k for k in blocks if k.startswith("_ZN3lg614physics_kernelILi0ELb0ELb1E")]
+    assert len(key) == 1, sorted(blocks)
+    r = blocks[key[0]]
+    print(r)
+    assert r["VGPRs Spill"] == 0 and r["ScratchSize"] <= 64 and r["LDS Size"] <= 160 * 1024, r
