@@ -1,7 +1,7 @@
-"""URDF → reduced quadruped model (what `gym.load_asset` does for the reference).
+"""URDF → reduced legged-robot model (what `gym.load_asset` does for the reference).
 
 Replaces the Isaac Gym URDF importer behind `legged_robot.py:738-763` for the robots the hot path
-supports: a floating base with four 3-revolute-joint legs.  Follows the asset options the reference sets
+supports: a floating base with four or six 3-revolute-joint legs (the kernel instances of `csrc/lg_instance.h`).  Follows the asset options the reference sets
 (`legged_robot_config.py:159-180`): `collapse_fixed_joints=True` (links behind fixed joints are merged into
 their parent: inertia, collision shapes, child joints), `dont_collapse="true"` fixed joints keep their child
 as a reported rigid body (the FOOT links, `anymal_c.urdf:701`), `replace_cylinder_with_capsule=True`.
@@ -9,7 +9,10 @@ Bodies and DOFs are ordered depth-first with children sorted by name, which repr
 LF, LH, RF, RH order for ANYmal-C (`anymal_c_rough_config.py:43-58`).
 
 Collision shapes are reduced to spheres: sphere → itself; capsule → spheres at both segment ends (+ centre when
-long); box → its 8 corners.  Mesh collisions are ignored.
+long); box → its 8 corners.  Mesh collisions (PhysX cooks a convex hull per mesh) cannot be reduced from the URDF alone: a link whose
+collision geometry is a mesh, or which has none, takes the primitives of the same-named link of `collision_urdf` when one is given --
+`el_mini_collsp.urdf`, the box / sphere approximation of the hexapod's STL hulls that ships next to `el_mini.urdf` -- and is
+ignored otherwise.
 """
 import json
 import xml.etree.ElementTree as ET
@@ -17,7 +20,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 MAX_CP = 8
-NUM_LEGS = 4
+LEG_COUNTS = (4, 6)
 
 
 def rpy_to_mat(rpy):
@@ -118,10 +121,25 @@ def _two_extremes(spheres):
     return [spheres[pair[0]], spheres[pair[1]]]
 
 
-def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on, collapse_fixed_joints=True):
+def _has_primitive_collision(link):
+    for col in link.findall("collision"):
+        g = col.find("geometry")
+        if g is not None and len(g) and g[0].tag in ("sphere", "cylinder", "capsule", "box"):
+            return True
+    return False
+
+
+def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on, collapse_fixed_joints=True, collision_urdf=None):
     """Returns a plain-dict robot model with the fields of `lg_robot_model` (include/lgstep.h)."""
     root = ET.parse(path).getroot()
     links = {l.get("name"): l for l in root.findall("link")}
+    col_links = {}
+    if collision_urdf is not None:
+        col_links = {l.get("name"): l for l in ET.parse(collision_urdf).getroot().findall("link") if _has_primitive_collision(l)}
+
+    def collision_source(name):
+        """The element whose <collision> primitives stand for link `name` (see the module docstring)."""
+        return links[name] if _has_primitive_collision(links[name]) or name not in col_links else col_links[name]
     joints = []
     child_names = set()
     for j in root.findall("joint"):
@@ -156,9 +174,9 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
                           [float(t.get("ixz")), float(t.get("iyz")), float(t.get("izz"))]])
             Rw = R @ Ri
             body.add_inertia(m, p + R @ pi, Rw @ I @ Rw.T)
-        for (sp, sr) in _link_spheres(link):
+        for (sp, sr) in _link_spheres(collision_source(link_name)):
             body.spheres.append((p + R @ sp, sr))
-        for (sp, sr) in _link_spheres(link, compact=True):
+        for (sp, sr) in _link_spheres(collision_source(link_name), compact=True):
             body.spheres_compact.append((p + R @ sp, sr))
         for j in sorted(by_parent.get(link_name, []), key=lambda jj: jj["child"]):
             Rj, pj = R @ j["R"], p + R @ j["p"]
@@ -173,7 +191,8 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
     absorb(base, roots[0], np.eye(3), np.zeros(3))
     base.children.sort(key=lambda jc: jc[1].name)
     legs = [jc for jc in base.children if jc[0]["type"] in ("revolute", "continuous")]
-    assert len(legs) == NUM_LEGS, f"hot path supports 4-legged robots, found {len(legs)} revolute children of the base"
+    assert len(legs) in LEG_COUNTS, f"hot path supports robots with {LEG_COUNTS} legs, found {len(legs)} revolute children of the base"
+    num_legs = len(legs)
 
     m = dict(base_mass=base.mass, base_com=base.com.tolist(), base_inertia=_sym6(base.inertia),
              joint_pos=[], joint_rot=[], joint_axis=[], link_mass=[], link_com=[], link_inertia=[],
@@ -235,7 +254,7 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
             m["torque_limit"].append(jj["effort"])
         if foot is not None:
             body_names.append(foot[1].name)
-        base_share = [(-1, 0, sp, sr) for bi, (sp, sr) in enumerate(base_spheres) if bi % NUM_LEGS == l]
+        base_share = [(-1, 0, sp, sr) for bi, (sp, sr) in enumerate(base_spheres) if bi % num_legs == l]
         if len(cps) + len(base_share) > MAX_CP:
             # does not fit the contact slots: reduced primitives for the leg, and the trunk keeps its share (the task
             # terminates on trunk contact, legged_robot.py:215-221) ahead of the proximal links
@@ -252,6 +271,7 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
             m[key].append(val)
 
     m["has_foot_body"] = int(has_foot)
+    m["num_legs"] = num_legs
     m["num_bodies"] = len(body_names)
     m["body_names"], m["dof_names"] = body_names, dof_names
     finalize_indices(m, foot_name, penalize_contacts_on, terminate_after_contacts_on)

@@ -17,9 +17,12 @@ from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_CASES = ["flat_pd", "flat_lstm", "rough_lstm", "rough_allrew", "flat_loadadapt", "flat_stand", "rough_student", "rough_teacher", "rough_anymal_b"]
+# recorded from the reference's `ElSpider.step()` (six legs: the lg6 instance of the kernels, which ends its step in post_kernel)
+HEXAPOD_GOLDEN_CASES = ["elspider_flat_lstm", "elspider_rough_allrew"]
 CLASS_VARIANTS = {"LoadAdaptAnymal": {"orientation": "orientation_load_adapt"}}   # = LoadAdaptAnymal.reward_term_variants
 CLASS_REWARD_CLASS = {"StandAnymal": "stand"}                                        # = StandAnymal.reward_class
 ANYMAL_GAIT = dict(period=0.6, swing_height=0.15, foot_phases=[0.0, 0.5, 0.5, 0.0])   # anymal.py:59-63
+ELSPIDER_GAIT = dict(period=1.4, swing_height=0.07, foot_phases=[0.0, 0.5, 0.0, 0.5, 0.0, 0.5])   # elspider.py:240-243, gait_scheduler.py:19-26
 
 
 class FixtureTerrain:
@@ -28,7 +31,7 @@ class FixtureTerrain:
 
 
 def load_golden(name):
-    z = np.load(os.path.join(GOLDEN_DIR, f"anymal_{name}.npz"))
+    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz" if name.startswith("elspider_") else f"anymal_{name}.npz"))
     meta = json.loads(bytes(z["meta_json"]).decode())
     return z, meta
 
@@ -52,6 +55,11 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
     if case.get("cfg") == "anymal_b":
         from extended_legged_gym_amd.envs.anymal_b.anymal_b_config import AnymalBRoughCfg
         cfg = AnymalBRoughCfg()
+    hexapod = case.get("cls") == "ElSpider"
+    if hexapod:
+        from extended_legged_gym_amd.envs.elspider_air.flat.elspider_air_flat_config import ElSpiderAirFlatCfg
+        from extended_legged_gym_amd.envs.elspider_air.mixed_terrains.elspider_air_rough_config import ElSpiderAirRoughCfg
+        cfg = ElSpiderAirFlatCfg() if case["base"] == "flat" else ElSpiderAirRoughCfg()
     cfg.env.num_envs = case["num_envs"]
     cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]
@@ -71,13 +79,14 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
         cfg.rewards.max_contact_force = case["max_contact_force"]
     cfg.rewards.only_positive_rewards = case.get("only_positive_rewards", True)
     model = load_robot_model(cfg.asset)
-    # the harness robot (tools/refgen/ref_loader.py:anymal_robot_description) carries these DOF limits
-    model["dof_lower"], model["dof_upper"] = [-9.42] * 12, [9.42] * 12
-    model["dof_vel_limit"], model["torque_limit"] = [20.0] * 12, [80.0] * 12
+    if not hexapod:      # the harness robot (tools/refgen/ref_loader.py:anymal_robot_description) carries these DOF limits; the hexapod's are the URDF's
+        model["dof_lower"], model["dof_upper"] = [-9.42] * 12, [9.42] * 12
+        model["dof_vel_limit"], model["torque_limit"] = [20.0] * 12, [80.0] * 12
     # AnymalStudent: the native step produces the teacher's row (what the class asks of it, anymal.py:AnymalStudent.__init__)
     # PoseAnymal: the native step runs without the two pose terms, the clip and the noise (anymal.py:pose_native_cfg)
     with (teacher_row_cfg(cfg) if student else pose_native_cfg(cfg) if pose else contextlib.nullcontext()):
-        setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ANYMAL_GAIT,
+        setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ELSPIDER_GAIT if hexapod else ANYMAL_GAIT,
+                            terminate_on_flip=hexapod,                                  # ElSpider.check_termination (elspider.py:339-346)
                             reward_term_variants=CLASS_VARIANTS.get(case.get("cls", "Anymal")),
                             reward_class=CLASS_REWARD_CLASS.get(case.get("cls", "Anymal"), "base"))
     return cfg, setup

@@ -86,6 +86,9 @@ BARS = {
     "substep": dict(frac_ok=0.995, tol=5e-4, med=1e-6, any=2e-2, any_by_name={"contact_forces": 8e-2, "root_states": 1e-3, "torques": 1e-4}),
     "step_tgs": dict(frac_ok=0.995, tol=1e-2, med=1e-5, q999=5e-2, any=0.35,
                      any_by_name={"contact_forces": 1.0, "torques": 1.0, "root_states": 3e-2, "obs_buf": 5e-2}),
+    # triangle-mesh terrains (closest-point contacts: normals turn with the contact point, a sphere may change the face it touches within a step)
+    "step_tgs_mesh": dict(frac_ok=0.995, tol=1e-2, med=1e-5, q999=0.1, any=0.6,
+                          any_by_name={"contact_forces": 1.0, "torques": 1.0, "root_states": 5e-2, "obs_buf": 0.1}),
     "step_pgs": dict(frac_ok=0.995, tol=2e-3, med=2e-5, q999=1e-2, any=5e-2, any_by_name={"contact_forces": 0.25}),
 }
 REPORT = []
@@ -106,7 +109,9 @@ def _dump_levels():
 
 
 def step_bars(setup):
-    return "step_tgs" if setup.cfg.solver_type == abi.LG_SOLVER_TGS else "step_pgs"
+    if setup.cfg.solver_type != abi.LG_SOLVER_TGS:
+        return "step_pgs"
+    return "step_tgs_mesh" if setup.terrain.mesh_type == abi.LG_MESH_TRIMESH else "step_tgs"
 
 
 def compare(core, o, names, bars="step_tgs", rows=None, tag=None):

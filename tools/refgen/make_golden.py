@@ -26,7 +26,12 @@ REPO = ref_loader.REPO_ROOT
 OUT = os.path.join(REPO, "tests", "golden")
 
 # uniform-draw slots (shared with include/lgstep.h: LG_RS_*)
-RS_CMD_CB, RS_PUSH, RS_LEVEL, RS_DOF, RS_ROOT_XY, RS_ROOT_VEL, RS_CMD_RESET, RS_NOISE = 0, 4, 6, 8, 20, 22, 28, 32
+RS_CMD_CB, RS_PUSH, RS_LEVEL, RS_DOF = 0, 4, 6, 8
+
+
+def rs_tail(nd):
+    """(ROOT_XY, ROOT_VEL, CMD_RESET, NOISE): the slots behind the per-DOF draws (LG_RS_*_OF(dof), include/lgstep.h)."""
+    return 8 + nd, 10 + nd, 16 + nd, (16 + nd + 3 + 3) & ~3
 
 
 def build(case):
@@ -35,13 +40,17 @@ def build(case):
     from legged_gym.envs import Anymal, AnymalCFlatCfg, AnymalCRoughCfg
     from legged_gym.envs.anymal_c.anymal import AnymalStudent, LoadAdaptAnymal, PoseAnymal, StandAnymal
     from legged_gym.envs import AnymalCRoughStudentCfg, PoseAnymalCFlatCfg
+    from legged_gym.envs import ElSpider, ElSpiderAirFlatCfg, ElSpiderAirRoughCfg
     Base = {"Anymal": Anymal, "LoadAdaptAnymal": LoadAdaptAnymal, "StandAnymal": StandAnymal,
-            "AnymalStudent": AnymalStudent, "PoseAnymal": PoseAnymal}[case.get("cls", "Anymal")]
+            "AnymalStudent": AnymalStudent, "PoseAnymal": PoseAnymal, "ElSpider": ElSpider}[case.get("cls", "Anymal")]
     import legged_gym.envs.base.legged_robot as LR
 
-    ref_loader.FakeGym.robot = ref_loader.anymal_robot_description()
+    hexapod = case.get("cls") == "ElSpider"
+    ref_loader.FakeGym.robot = ref_loader.elspider_robot_description() if hexapod else ref_loader.anymal_robot_description()
     N = case["num_envs"]
     cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
+    if hexapod:
+        cfg = ElSpiderAirFlatCfg() if case["base"] == "flat" else ElSpiderAirRoughCfg()
     if case.get("cfg") == "teacher":        # task anymal_c_rough_teacher
         from legged_gym.envs import AnymalCRoughTeacherCfg
         cfg = AnymalCRoughTeacherCfg()
@@ -140,10 +149,11 @@ def build(case):
     return env, cfg, rec
 
 
-def slots_from_log(log, N, nslots, pose=None):
+def slots_from_log(log, N, nslots, pose=None, nd=12):
     """Scatter the recorded draws into a dense (N, nslots) table, NaN = not drawn.  `pose` (N, 8): the four extra draws of
     PoseAnymal._resample_commands (anymal.py:213-220), columns 0-3 from the callback, 4-7 from reset_idx."""
     tab = np.full((N, nslots), np.nan, dtype=np.float32)
+    RS_ROOT_XY, RS_ROOT_VEL, RS_CMD_RESET, RS_NOISE = rs_tail(nd)
     counters = {}
     for ctx, sub, ids, u in log:
         if ctx == "noise":
@@ -164,7 +174,7 @@ def slots_from_log(log, N, nslots, pose=None):
         elif sub == "level":
             tab[ids, RS_LEVEL] = u
         elif sub == "dofs":
-            tab[ids, RS_DOF:RS_DOF + 12] = u
+            tab[ids, RS_DOF:RS_DOF + nd] = u
         elif sub == "root":
             if u.shape[1] == 2:
                 tab[ids, RS_ROOT_XY:RS_ROOT_XY + 2] = u
@@ -204,7 +214,8 @@ def run_case(case):
     N, T = env.num_envs, case["steps"]
     nb, nd = env.num_bodies, env.num_dof
     g = torch.Generator().manual_seed(1000 + case["seed"])
-    nslots = RS_NOISE + env.num_obs
+    nslots = rs_tail(nd)[3] + env.num_obs
+    nf = len(env.feet_indices)
     dec = cfg.control.decimation
 
     def randn(*s):
@@ -240,7 +251,7 @@ def run_case(case):
         pre = persistent(env)
         pre["common_step_counter"] = np.int64(env.common_step_counter)
         pre["reset_buf"] = env.reset_buf.clone().numpy().astype(np.uint8)
-        actions = 1.5 * randn(N, 12)
+        actions = 1.5 * randn(N, nd)
         actions[0, 0] = 150.0     # exercises clip_actions
         # scripted post-simulation state
         cur["dof_noise"] = randn(dec, N, nd, 2)
@@ -253,11 +264,11 @@ def run_case(case):
         root[:, 10:13] = 0.8 * randn(N, 3)
         rigid = randn(N, nb, 13)
         rigid[:, :, 0:3] = root[:, None, 0:3] + 0.4 * randn(N, nb, 3)
-        rigid[:, env.feet_indices, 2] = 0.05 + 0.1 * rand(N, 4)
+        rigid[:, env.feet_indices, 2] = 0.05 + 0.1 * rand(N, nf)
         contact = torch.zeros(N, nb, 3)
-        on = rand(N, 4) < 0.6
-        contact[:, env.feet_indices, 2] = on * (20.0 + 120.0 * rand(N, 4))
-        contact[:, env.feet_indices, 0:2] = on.unsqueeze(-1) * 60.0 * randn(N, 4, 2)
+        on = rand(N, nf) < 0.6
+        contact[:, env.feet_indices, 2] = on * (20.0 + 120.0 * rand(N, nf))
+        contact[:, env.feet_indices, 0:2] = on.unsqueeze(-1) * 60.0 * randn(N, nf, 2)
         hit = rand(N, len(env.penalised_contact_indices)) < 0.15
         contact[:, env.penalised_contact_indices, :] = hit.unsqueeze(-1) * 5.0 * randn(N, len(env.penalised_contact_indices), 3)
         base_hit = rand(N) < 0.12
@@ -283,7 +294,7 @@ def run_case(case):
         pose_u = np.full((N, 8), np.nan, dtype=np.float32)
         st.update(actions=actions.numpy(), sim_dof=cur["sim_dof"].numpy(), sim_root=root.numpy(),
                   sim_rigid=rigid.numpy(), sim_contact=contact.numpy(),
-                  rand=slots_from_log(rec["log"], N, nslots, pose_u), torques=torch.stack(torq).numpy(),
+                  rand=slots_from_log(rec["log"], N, nslots, pose_u, nd), torques=torch.stack(torq).numpy(),
                   obs=obs.clone().numpy(), rew=rew.clone().numpy(), reset=reset.clone().numpy().astype(np.uint8),
                   time_out=env.time_out_buf.clone().numpy().astype(np.uint8),
                   clipped_actions=env.actions.clone().numpy())
@@ -326,7 +337,7 @@ def run_case(case):
                 max_episode_length_s=float(env.max_episode_length_s))
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, f"anymal_{case['name']}.npz")
+    path = os.path.join(OUT, f"{'elspider' if case.get('cls') == 'ElSpider' else 'anymal'}_{case['name']}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", "resets per step:", out["reset"].sum(axis=1))
 
@@ -376,8 +387,19 @@ CASES += [
          resampling_time=0.1, heading_command=False, episode_length_s=20, num_rows=3, num_cols=4, border_size=5),
 ]
 
+# ElSpider (elspider.py:230-407): 18 joints, 25 bodies, six feet.  The flat case runs the task's own reward set (with the hexapod's
+# `_reward_gait_2_step` and the stage-0 scales) and the LSTM actuator on all 18 joints; the rough case turns every term the class can run on
+# (`_reward_four_footup` raises for six feet: `torch.all(...)` is fine, kept; `_reward_gait_scheduler` included)
+CASES += [
+    dict(name="flat_lstm", base="flat", cls="ElSpider", num_envs=24, steps=6, seed=11, actuator_net=True, push_interval_s=0.06,
+         resampling_time=0.1, heading_command=False, episode_length_s=20),
+    dict(name="rough_allrew", base="rough", cls="ElSpider", num_envs=32, steps=6, seed=12, actuator_net=False, push_interval_s=0.06,
+         resampling_time=0.1, heading_command=True, episode_length_s=20, num_rows=3, num_cols=4, border_size=5,
+         scales=dict(ALL_SCALES, feet_slip=-0.1, base_height=-1.0), only_positive_rewards=False),
+]
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for c in CASES:
-        if not only or c["name"] in only:
+        if not only or c["name"] in only or (("elspider_" if c.get("cls") == "ElSpider" else "anymal_") + c["name"]) in only:
             run_case(c)

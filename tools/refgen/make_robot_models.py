@@ -25,6 +25,13 @@ m = load_urdf(f"{REF}/robots/go2/urdf/go2_description.urdf", "foot", ["thigh", "
 save_model(m, f"{OUT}/robots/go2_description.json")
 print("go2", m["num_bodies"], m["body_names"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"])
 
+# ElSpider Air (envs/elspider_air/mixed_terrains/elspider_air_rough_config.py:110-117): six legs; the URDF's collision geometry is STL meshes
+# (convex hulls in PhysX) -- the box / sphere approximation the reference ships as el_mini_collsp.urdf stands in for them, the foot keeps
+# el_mini.urdf's own 2 cm sphere
+m = load_urdf(f"{REF}/robots/el_mini/urdf/el_mini.urdf", "FOOT", ["THIGH", "HIP"], ["trunk"], collision_urdf=f"{REF}/robots/el_mini/urdf/el_mini_collsp.urdf")
+save_model(m, f"{OUT}/robots/el_mini.json")
+print("el_mini", m["num_bodies"], m["body_names"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"], m["dof_names"])
+
 import torch
 net = torch.jit.load(f"{REF}/actuator_nets/anydrive_v3_lstm.pt")
 sd = {k: v.detach().numpy() for k, v in net.state_dict().items()}

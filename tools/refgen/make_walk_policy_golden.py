@@ -22,20 +22,27 @@ ref_loader.load_reference()
 sys.path.insert(0, "/root/reference/rsl_rl")
 from rsl_rl.modules import ActorCritic  # noqa: E402
 
-CKPT = "/root/reference/legged_gym/ckpt/anymal_c/plane_walk_200.pt"
-ck = torch.load(CKPT, map_location="cpu", weights_only=False)
-sd = ck["model_state_dict"]
-ac = ActorCritic(num_actor_obs=48, num_critic_obs=48, num_actions=12, actor_hidden_dims=[128, 64, 32],
-                 critic_hidden_dims=[128, 64, 32], activation="elu", init_noise_std=1.0)
-ac.load_state_dict(sd)
-ac.eval()
-out = {f"sd.{k}": v.detach().numpy().astype(np.float32) for k, v in sd.items()}
-g = torch.Generator().manual_seed(3)
-obs = torch.randn(64, 48, generator=g)
-with torch.no_grad():
-    out["obs"] = obs.numpy()
-    out["inference"] = ac.act_inference(obs).numpy()
-    out["value"] = ac.evaluate(obs).numpy()
-path = os.path.join(ref_loader.REPO_ROOT, "tests", "golden", "anymal_plane_walk_policy.npz")
-np.savez_compressed(path, **out)
-print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def export(ckpt, num_obs, num_actions, out_name, seed):
+    ck = torch.load(ckpt, map_location="cpu", weights_only=False)
+    sd = ck["model_state_dict"]
+    ac = ActorCritic(num_actor_obs=num_obs, num_critic_obs=num_obs, num_actions=num_actions, actor_hidden_dims=[128, 64, 32],
+                     critic_hidden_dims=[128, 64, 32], activation="elu", init_noise_std=1.0)
+    ac.load_state_dict(sd)
+    ac.eval()
+    out = {f"sd.{k}": v.detach().numpy().astype(np.float32) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(64, num_obs, generator=g)
+    with torch.no_grad():
+        out["obs"] = obs.numpy()
+        out["inference"] = ac.act_inference(obs).numpy()
+        out["value"] = ac.evaluate(obs).numpy()
+    path = os.path.join(ref_loader.REPO_ROOT, "tests", "golden", out_name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+export("/root/reference/legged_gym/ckpt/anymal_c/plane_walk_200.pt", 48, 12, "anymal_plane_walk_policy.npz", 3)
+# the hexapod's checkpoint (actor 66-128-64-32-18): the RL warm start of elspider_air_traj_grad_sampling_config.py:77-79
+export("/root/reference/legged_gym/ckpt/elspider_air/plane_walk_300.pt", 66, 18, "elspider_plane_walk_policy.npz", 4)

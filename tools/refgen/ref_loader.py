@@ -276,6 +276,24 @@ def anymal_robot_description():
                 body_masses=[30.0] + [1.0] * 16)
 
 
+ELSPIDER_LEGS = ["LB", "LF", "LM", "RB", "RF", "RM"]
+
+
+def elspider_robot_description():
+    """DOF / body naming of ElSpider Air (`el_mini.urdf`) after fixed-joint collapse, in Isaac Gym's (alphabetical DFS) order -- the order
+    `ElSpider._reward_gait_2_step` (elspider.py:366) and `AsyncGaitSchedulerCfg.dof_names` (utils/gait_scheduler.py:99-104) spell out --,
+    with the URDF's joint limits."""
+    dof_names, body_names = [], ["base"]
+    for leg in ELSPIDER_LEGS:
+        dof_names += [f"{leg}_HAA", f"{leg}_HFE", f"{leg}_KFE"]
+        body_names += [f"{leg}_HIP", f"{leg}_THIGH", f"{leg}_SHANK", f"{leg}_FOOT"]
+    n = len(dof_names)
+    return dict(dof_names=dof_names, body_names=body_names,
+                lower=np.tile(np.array([-0.785, -0.5233, -0.6978], np.float32), 6), upper=np.tile(np.array([0.785, 3.14, 3.925], np.float32), 6),
+                velocity=np.full(n, 21.0, np.float32), effort=np.full(n, 33.5, np.float32),
+                body_masses=[15.8991] + [1.0] * 24)
+
+
 def load_reference():
     """Returns the reference `legged_gym` package (real code) after installing stubs."""
     install_stubs()
