@@ -140,7 +140,23 @@ def config5():
                 rollout_env_steps_per_s=128 * 32 / dt, step_rollout_ms=dt * 1e3, rollout_batch_H16_ms=tb * 1e3, main_step_ms=dm * 1e3)
 
 
+def config_hexapod():
+    """ElSpider Air (six legs: the lg6 kernel instance, 8 envs per wave, post-physics as its own launch), tasks as registered."""
+    from extended_legged_gym_amd.envs import ElSpider, ElSpiderAirFlatCfg, ElSpiderAirRoughTrainCfg
+    out = {}
+    for name, Cfg in (("elspider_air_flat", ElSpiderAirFlatCfg), ("elspider_air_rough", ElSpiderAirRoughTrainCfg)):
+        cfg = Cfg(); cfg.env.num_envs = 4096; cfg.seed = 1
+        env = ElSpider(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
+        env.reset()
+        a = 0.5 * torch.randn(4096, 18, device="cuda")
+        dt = timeit(lambda: env.step(a), 200, 500)
+        out[name] = dict(env_steps_per_s=4096 / dt, ms_per_step=dt * 1e3, finite=bool(torch.isfinite(env.root_states).all()),
+                         mean_episode_len=float(env.episode_length_buf.float().mean()))
+        env.core.close()
+    return dict(config="hexapod: ElSpider Air 6 x 3 (LSTM actuator on 18 joints), 4096 envs on 1 GPU", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "3", "4", "5"]
+    which = sys.argv[1:] or ["1", "3", "4", "5", "hexapod"]
     for w in which:
-        print(json.dumps({"1": config1, "3": config3, "4": config4, "5": config5}[w]()))
+        print(json.dumps({"1": config1, "3": config3, "4": config4, "5": config5, "hexapod": config_hexapod}[w]()))
