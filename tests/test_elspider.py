@@ -302,7 +302,7 @@ def test_ragged_hexapod_env_counts_match_the_oracle(n):
 @pytest.mark.gpu
 def test_registered_task_and_the_reference_policy_on_the_hip_env():
     """GPU: task `elspider_air_flat` through `task_registry.make_env` (VecEnv attributes with the hexapod's extents), then the reference's
-    policy through `NativeActorCritic.act_inference` over the matrix, 9 cells x 510 envs x 400 steps."""
+    policy through `NativeActorCritic.act_inference` over the matrix, 15 cells x 510 envs x 400 steps."""
     import json
     import torch
     from extended_legged_gym_amd.envs import task_registry
