@@ -82,7 +82,7 @@ def test_config4_depth_camera_4096_envs_on_the_1p6m_triangle_mesh():
     resets = _run(env, 40, 12)
     d = env.get_depth_images()
     assert tuple(d.shape) == (4096, cfg.depth.buffer_len, cfg.depth.resized[1], cfg.depth.resized[0])
-    assert torch.isfinite(d).all() and float(d.min()) >= -0.5 - 1e-6 and float(d.max()) <= 0.5 + 1e-6
+    assert torch.isfinite(d).all() and float(d.min()) >= -0.6 and float(d.max()) <= 0.6      # [-0.5, 0.5] + the bicubic resize's overshoot
     assert float(d.std()) > 0.01 and float(d[:, -1].std(dim=(1, 2)).min()) >= 0.0
     assert float((d[:, -1].flatten(1).std(dim=1) > 0).float().mean()) > 0.9                       # nearly every camera sees structure
     assert torch.isfinite(env.root_states).all() and resets >= 0
@@ -116,9 +116,10 @@ def test_config5_main_rollout_128_x_32_with_a_16_step_rollout_batch():
     assert torch.equal(env.root_states[env.main_env_indices], main_before)                        # the mains are frozen during rollouts
     for t in (env.root_states, env.obs_buf, env.dof_state):
         assert torch.isfinite(t).all()
-    # rollouts of one main start from its state and then diverge under their own plans
+    # the rollouts of one main start from its state, earn different rewards under their own plans, and are re-synchronised at the end
+    assert float(rew.view(128, 32, 16)[:, :, -1].std(dim=1).min()) > 0.0
     r = env.root_states.view(128, 33, 13)
-    assert float((r[:, 1:, :3] - r[:, :1, :3]).norm(dim=2).max()) > 0.0
+    assert torch.equal(r[:, 1:], r[:, :1].expand(-1, 32, -1))
     env.core.close()
 
 
