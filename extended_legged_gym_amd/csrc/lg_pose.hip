@@ -103,11 +103,19 @@ extern "C" int lg_pose_layer_step(const lg_pose_params* p, int32_t n, float* pos
       (measured_heights && p->num_heights <= 0))
     return LG_ERR_INVALID;
   const int O = 52 + (measured_heights ? p->num_heights : 0);
+  // the launches run on the device the rows live on, whatever device is current in the calling thread (an env on cuda:1 driven from a
+  // thread whose current device is cuda:0), like every other entry point of the library
+  hipPointerAttribute_t pa_out, pa_cmd;
+  if (hipPointerGetAttributes(&pa_out, obs_out) != hipSuccess || hipPointerGetAttributes(&pa_cmd, pose_cmd) != hipSuccess) return LG_ERR_INVALID;
+  if (pa_out.device != pa_cmd.device) return LG_ERR_INVALID;
+  DeviceScope ds_(pa_out.device);
+  if (!ds_.ok) return LG_ERR_HIP;
   hipStream_t st = (hipStream_t)stream;
+  (void)hipGetLastError();                             // (a stale error of an earlier call is not this call's)
   hipLaunchKernelGGL(pose_env_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *p, n, pose_cmd, cmd_stride, sums, nat_rew, reset, time_out,
                      eplen_before, base_z, base_z_stride, projected_gravity, measured_heights, u, rew_out, acc);
   const int64_t tot = (int64_t)n * O;
   hipLaunchKernelGGL(pose_obs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, *p, n, O, pose_cmd, cmd_stride, nat_obs, noise_u,
                      noise_scale_vec, obs_out, extras, acc);
-  return hipGetLastError() == hipSuccess ? LG_OK : LG_ERR_HIP;
+  return (hipGetLastError() == hipSuccess && hipPeekAtLastError() == hipSuccess) ? LG_OK : LG_ERR_HIP;
 }

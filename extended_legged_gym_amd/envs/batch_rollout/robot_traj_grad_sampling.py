@@ -22,10 +22,8 @@ class RobotTrajGradSampling(RobotBatchRolloutPercept):
     def _init_action_normalization(self):
         self.use_action_normalization = bool(getattr(self.cfg.control, "jointpos_action_normalization", False))
         if self.use_action_normalization:
-            lim = self.dof_pos_limits_hard if hasattr(self, "dof_pos_limits_hard") else None
             lo = torch.tensor(self.robot_model["dof_lower"], device=self.device) - self.default_dof_pos.view(-1)
             hi = torch.tensor(self.robot_model["dof_upper"], device=self.device) - self.default_dof_pos.view(-1)
-            del lim
             self.joint_lower_limits, self.joint_upper_limits = lo, hi
             self.joint_ranges = hi - lo
             self.joint_mid_points = 0.5 * (hi + lo)

@@ -38,6 +38,17 @@ def interpolation_matrix(num_nodes, horizon, method="spline"):
     return phi.astype(np.float32)
 
 
+def shift_operator(phi):
+    """(K, K) = pinv(phi) @ S @ phi with S the one-step shift of the H sample times (the last sample repeats): the node trajectory whose
+    dense plan is, in the least-squares sense, the old plan advanced by one sample time."""
+    phi = np.asarray(phi, np.float64)
+    H = phi.shape[0]
+    S = np.zeros((H, H))
+    S[np.arange(H - 1), np.arange(1, H)] = 1.0
+    S[H - 1, H - 1] = 1.0
+    return (np.linalg.pinv(phi) @ S @ phi).astype(np.float32)
+
+
 class NativeTrajSampler:
     def __init__(self, env, cfg, seed=0):
         """env: a native `RobotBatchRollout` (rollout_envs samples per main env); cfg: `cfg.trajectory_opt`."""
@@ -49,7 +60,13 @@ class NativeTrajSampler:
         if self.R < 2:
             raise ValueError("trajectory optimisation needs at least 2 rollout envs per main env")
         self.H, self.K = int(cfg.horizon_samples), int(cfg.horizon_nodes) + 1
-        self.phi = torch.from_numpy(interpolation_matrix(self.K, self.H, getattr(cfg, "interp_method", "spline"))).to(self.device).contiguous()
+        phi = interpolation_matrix(self.K, self.H, getattr(cfg, "interp_method", "spline"))
+        self.phi = torch.from_numpy(phi).to(self.device).contiguous()
+        # shift(): the plan advanced by one sample time, projected back onto the node space in the least-squares sense -- (K, H) =
+        # pinv(phi) @ S with S the one-step shift of the sample times (last sample repeated).  A plan that stays representable after
+        # the shift is reproduced exactly; picking the shifted plan at the nearest sample index is not the inverse of phi and makes
+        # the warm-started mean drift at every control step even with zero updates.
+        self.shift_op = torch.from_numpy(shift_operator(phi)).to(self.device).contiguous()   # (K, K)
         self.mean = torch.zeros(self.M, self.K, self.A, device=self.device)            # node trajectories of the main envs
         self.gen = torch.Generator(device=self.device); self.gen.manual_seed(int(seed))
         k = torch.arange(self.K, device=self.device, dtype=torch.float32)
@@ -101,11 +118,8 @@ class NativeTrajSampler:
 
     def shift(self):
         """`shift_trajectory_batch` (`:200-209`): one control step has passed -- the plan advances by one sample time; re-sampled at
-        the node times (the last node repeats)."""
-        dense = self.plans_from_nodes(self.mean)                           # (M, H, A)
-        shifted = torch.cat([dense[:, 1:], dense[:, -1:]], dim=1)
-        idx = torch.linspace(0, self.H - 1, self.K, device=self.device).round().long()
-        self.mean = shifted[:, idx].contiguous()
+        the node times in the least-squares sense (see `shift_op`; the last sample repeats)."""
+        self.mean = torch.einsum("kj,mja->mka", self.shift_op, self.mean).contiguous()      # nodes <- pinv(phi) shift(phi nodes)
 
     def reset(self, env_ids=None):
         if env_ids is None:

@@ -17,6 +17,33 @@ def test_interpolation_matrix_is_an_interpolant():
         np.testing.assert_allclose(phi @ lin, np.linspace(0, 1, 17), atol=1e-6)   # ... and through straight lines
 
 
+def test_shift_operator_reproduces_plans_that_stay_representable():
+    """`NativeTrajSampler.shift()`: a constant plan is a fixed point; a plan whose one-step shift is again an interpolant of K nodes (a
+    straight line that has reached its end value stays there) comes back exactly; in general the shifted plan is matched in the
+    least-squares sense, never worse than re-sampling it at the nearest sample index."""
+    from extended_legged_gym_amd.utils.traj_sampler import interpolation_matrix, shift_operator
+    for method in ("linear", "spline"):
+        phi = interpolation_matrix(5, 16, method).astype(np.float64)
+        T = shift_operator(phi).astype(np.float64)
+        np.testing.assert_allclose(T @ np.ones(5), np.ones(5), atol=1e-5)                      # constants are a fixed point
+        S = np.eye(16, k=1); S[15, 15] = 1.0
+        rng = np.random.default_rng(0)
+        nodes = rng.normal(size=(5, 3))
+        target = S @ phi @ nodes
+        idx = np.linspace(0, 15, 5).round().astype(int)
+        err_ls = np.linalg.norm(phi @ (T @ nodes) - target)
+        err_nearest = np.linalg.norm(phi @ target[idx] - target)
+        assert err_ls <= err_nearest + 1e-6, (method, err_ls, err_nearest)
+        # repeated shifts of a zero-update plan settle on a constant inside no drift, no growth
+        x = nodes.copy()
+        for _ in range(200):
+            x = T @ x
+        assert np.abs(x - x.mean(axis=0)).max() < 5e-3
+        assert np.abs(x).max() <= 1.5 * np.abs(phi @ nodes).max()
+        ev = np.sort(np.abs(np.linalg.eigvals(T)))
+        assert abs(ev[-1] - 1.0) < 1e-4 and ev[-2] < 0.95              # the constants, and everything else decays
+
+
 def test_mppi_oracle_known_answers():
     rng = np.random.default_rng(0)
     M, R, H, K, A = 3, 16, 8, 5, 12
