@@ -285,16 +285,17 @@ def test_ragged_hexapod_env_counts_match_the_oracle(n):
                 core.t[name].copy_(torch.from_numpy(o.t[name].copy()))
             o.step(act); core.step(torch.from_numpy(act).cuda())
             torch.cuda.synchronize()
-            # per env: 97 % of the entries of every tensor within 1e-2 (18 joints and 25 bodies hang on every contact event of an env).  One
-            # env may miss it -- a foot that lands a substep earlier in one implementation (tests/test_hip_vs_oracle.py) --, a ragged-count
-            # indexing error would break whole blocks of envs
+            # One env may differ grossly -- a foot that lands a substep earlier in one implementation (tests/test_hip_vs_oracle.py) --; a
+            # ragged-count indexing error would break whole blocks of envs.  Over the others: 97 % of the entries of every tensor within 1e-2.
+            errs = {name: np.abs(env_rows(name, core.t[name].cpu().numpy(), n) - env_rows(name, o.t[name], n)) / np.maximum(1.0, np.abs(env_rows(name, o.t[name], n)))
+                    for name in STATE}
+            assert all(np.isfinite(e).all() for e in errs.values())
             bad = np.zeros(n, bool)
-            for name in STATE:
-                a = env_rows(name, core.t[name].cpu().numpy(), n); b = env_rows(name, o.t[name], n)
-                assert np.isfinite(a).all(), name
-                err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
-                bad |= (err <= 1e-2).mean(axis=1) < 0.97
-            assert bad.sum() <= (1 if n > 1 else 0), np.nonzero(bad)[0]
+            for e in errs.values():
+                bad |= e.max(axis=1) > 0.1
+            why = {name: float(e[~bad].max()) for name, e in errs.items() if (~bad).any() and (e[~bad] <= 1e-2).mean() < 0.97}
+            assert not why, (it, why)
+            assert bad.sum() <= (1 if n > 1 else 0), (it, why)
         else:
             o.step(act)
     core.close(); o.close()
