@@ -40,7 +40,11 @@ static_assert(FH_NOISE + EPB * FO_STRIDE <= LG_MAX_CP * CF_FIELDS * 64, "heights
 static_assert(LG_REW_COUNT <= 32, "reward-term masks (rew_term_mask, 1u << id) are 32 bits wide");
 
 // ---- helper waves, while the main wave runs the last sweeps: history rows, uniforms, pre-step integers -> LDS
-LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid /* 0..191 */, int64_t step, const float* values) {
+// `ids` (optional): row k of the launch is env ids[k] (subset steps); `ro`: RobotBatchRollout.post_physics_step_rollout semantics (no callback,
+// no termination of its own, no reset, rewards outside the episode sums: robot_batch_rollout.py:763-817), Philox stream 2.
+LG_DEV int fused_env_of(const int32_t* __restrict__ ids, int k) { return ids ? ids[k] : k; }
+LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid /* 0..191 */, int64_t step, const float* values,
+                           const int32_t* __restrict__ ids, bool ro) {
   // Every global load of this function is issued before the first LDS store: per element a load -> store chain inside a ten-way divergent
   // branch (the former form) was five passes of ten memory round trips each, ~17 k cycles -- longer than the sweeps it was meant to hide
   // behind, so the main wave waited 6.4 k cycles per step at barrier (F).
@@ -58,7 +62,7 @@ LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, i
     const int idx = htid + 192 * it;
     const int el = idx / PER, o = idx - el * PER;
     const bool ok = el < nenv;
-    const size_t e = (size_t)(e0 + (ok ? el : 0));
+    const size_t e = (size_t)fused_env_of(ids, e0 + (ok ? el : 0));
     const float LG_G* src; int dst;
     if (o < 12) { src = b_lact + e * 12 + o; dst = FS_LACT + o; }
     else if (o < 18) { src = b_lrv + e * 6 + (o - 12); dst = FS_LRV + (o - 12); }
@@ -80,21 +84,22 @@ LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, i
     const int el = idx & (EPB - 1), o = idx >> 4;
     const bool ok = el < nenv && o < K;
     sdst[it] = ok ? el * FS_STRIDE + FS_SUMS + o : -1;
-    sv[it] = C->ep_sums[(size_t)(ok ? o : 0) * C->N + e0 + (ok ? el : 0)];
+    sv[it] = C->ep_sums[(size_t)(ok ? o : 0) * C->N + fused_env_of(ids, e0 + (ok ? el : 0))];
   }
   static_assert(EPB == 16, "the (term, env) split of the episode sums assumes 16 envs per workgroup");
-  int64_t pl = 0; float plevel = 0.f, pval = 0.f; uint32_t plc = 0;
+  int64_t pl = 0; float plevel = 0.f, pval = 0.f; uint32_t plc = 0; float pflags = 0.f;
   if (htid < nenv) {
-    const int e = e0 + htid;
+    const int e = fused_env_of(ids, e0 + htid);
     pl = C->ep_len[e];
-    plevel = g.curriculum ? (float)C->levels[e] : 0.f;
+    plevel = (g.curriculum && !ro) ? (float)C->levels[e] : 0.f;
     pval = values ? values[e] : 0.f;
     plc = *reinterpret_cast<const uint32_t*>(C->last_contacts + (size_t)e * 4);
+    if (ro) pflags = (float)((int)C->reset_buf[e] | ((int)C->time_out[e] << 8));     // a rollout env carries the flags of its main's last step
   }
-  // one Philox call per (env, slot group): 8 groups of the 32 control slots (computed while the loads are in flight)
-  for (int idx = htid; idx < nenv * (LG_RS_NOISE / 4); idx += 192) {
+  // one Philox call per (env, slot group): 8 groups of the 32 control slots (computed while the loads are in flight); rollout steps draw none
+  for (int idx = htid; !ro && idx < nenv * (LG_RS_NOISE / 4); idx += 192) {
     const int el = idx / (LG_RS_NOISE / 4), grp = idx - el * (LG_RS_NOISE / 4);
-    uniform_draw4(C, e0 + el, grp, step, 0u, UB + FU_U + el * LG_RS_NOISE + 4 * grp);
+    uniform_draw4(C, fused_env_of(ids, e0 + el), grp, step, 0u, UB + FU_U + el * LG_RS_NOISE + 4 * grp);
   }
 #pragma unroll
   for (int it = 0; it < NF; ++it) if (fdst[it] >= 0) SR[fdst[it]] = fv[it];
@@ -106,6 +111,7 @@ LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, i
     pre[2] = plevel;
     SR[htid * FS_STRIDE + FS_VAL] = pval;
     *reinterpret_cast<uint32_t*>(pre + 3) = plc;
+    pre[4] = pflags;
   }
 }
 
@@ -117,7 +123,7 @@ LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, i
 LG_DEV bool fused_noise_predrawn(const float* hot) {       // (kernel-uniform)
   return HI(HC_ADD_NOISE) != 0 && HI(HC_INJECT) == 0 && HI(HC_NUM_OBS) <= FO_STRIDE;
 }
-LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid /* 0..191 */, int64_t step, float nz[NZ_IT][4]) {
+LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid /* 0..191 */, int64_t step, float nz[NZ_IT][4], const int32_t* __restrict__ ids, bool ro) {
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
   const int G4 = (HI(HC_NUM_OBS) + 3) >> 2;
 #pragma unroll
@@ -125,7 +131,7 @@ LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid /* 0..19
     const int idx = htid + 192 * it;
     const int el = idx / G4, gq = idx - el * G4;
     uint32_t o4[4] = {0u, 0u, 0u, 0u};
-    if (el < nenv) philox4((uint32_t)(e0 + el), (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), 0u, (uint32_t)HI(HC_SEED_LO), (uint32_t)HI(HC_SEED_HI), o4);
+    if (el < nenv) philox4((uint32_t)fused_env_of(ids, e0 + el), (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), ro ? 2u : 0u, (uint32_t)HI(HC_SEED_LO), (uint32_t)HI(HC_SEED_HI), o4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) nz[it][i] = u01(o4[i]);
   }
@@ -143,10 +149,15 @@ LG_DEV void fused_noise_park(const float* hot, float* HB, int blk, int n, int ht
 static_assert(NZ_IT * 192 >= EPB * (FO_STRIDE / 4), "the helper lanes cover every (env, Philox group) of rows up to FO_STRIDE entries");
 
 // ---- helper waves, after the final state is published: the height scan of the workgroup's envs (LR:400-401), one point per lane
-LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid) {
+LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid, const int32_t* __restrict__ ids, bool ro) {
   const int P = C->cfg.measure_heights ? C->P : 0;
   if (P <= 0) return;
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
+  if (ro) {                  // rollout steps keep the heights the last main step measured (robot_batch_rollout.py:763-817 does not scan)
+    if (htid < P)
+      for (int el = 0; el < nenv; ++el) HB[FH_HEIGHTS + el * MAX_P + htid] = C->heights[(size_t)fused_env_of(ids, e0 + el) * C->P + htid];
+    return;
+  }
   const bool plane = C->ter.mesh_type == LG_MESH_PLANE;
   const int p = htid;
   const bool okp = p < P;
@@ -162,7 +173,7 @@ LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[2
     if (okp && el < nenv) {
       const float hv = plane ? 0.f : terrain_height_value(C, hp[el]);
       HB[FH_HEIGHTS + el * MAX_P + p] = hv;
-      C->heights[(size_t)(e0 + el) * C->P + p] = hv;
+      C->heights[(size_t)fused_env_of(ids, e0 + el) * C->P + p] = hv;
     }
   }
 }
@@ -357,8 +368,9 @@ LG_DEV void fused_reward_all(const DevCtx* __restrict__ C, const float* hot, uns
 #undef ON
 }
 
+// ro: the rollout variant (see fused_prefetch); krow: this env's row of the launch; rew_out / rew_stride: lg_rollout_batch's reward column.
 LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int e, float* S, const float* U, const float* pre, float* M, const float* H,
-                             const float feat[F_COUNT], bool fault, int64_t step, const PostSink& K) {
+                             const float feat[F_COUNT], bool fault, int64_t step, const PostSink& K, bool ro, int krow, float* rew_out, int rew_stride) {
   const float dt = HF(HC_DT);
   const int P = HI(HC_P);
   const unsigned term_mask = (unsigned)HI(HC_TERM_MASK);
@@ -394,11 +406,11 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
   for (int i = 0; i < 3; ++i) { R.blv[i] = S[FS_BLV + i]; R.bav[i] = S[FS_BAV + i]; R.pg[i] = S[FS_PG + i]; }
   R.bla[0] = S[FS_BLA]; R.bla[1] = S[FS_BLA + 1];
   R.rootz = root[2];
-  const int64_t eplen = *reinterpret_cast<const int64_t*>(pre) + 1;                   // LR:122
+  const int64_t eplen = *reinterpret_cast<const int64_t*>(pre) + (ro ? 0 : 1);        // LR:122 (not in rollout steps)
   bool root_dirty = false;
   // ---- _post_physics_step_callback (LR:386-403)
-  if ((int)eplen % HI(HC_RESAMPLING_STEPS) == 0) resample_commands(C, cmd, U, LG_RS_CMD_CB);
-  if (HI(HC_HEADING)) {
+  if (!ro && (int)eplen % HI(HC_RESAMPLING_STEPS) == 0) resample_commands(C, cmd, U, LG_RS_CMD_CB);
+  if (!ro && HI(HC_HEADING)) {
     float q[4] = {root[3], root[4], root[5], root[6]};
     V3 f = quat_apply(q, v3(1, 0, 0));
     float x = 0.5f * wrap_to_pi(cmd[3] - atan2f(f.y, f.x));
@@ -407,7 +419,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
 #pragma unroll
   for (int i = 0; i < 4; ++i) R.cmd[i] = cmd[i];
   const bool push_hit = (step >> 32) == 0 ? ((uint32_t)step % (uint32_t)HI(HC_PUSH_INTERVAL) == 0u) : (step % HI(HC_PUSH_INTERVAL) == 0);
-  if (HI(HC_PUSH) && push_hit) {                                                     // LR:402-403, 491-496
+  if (!ro && HI(HC_PUSH) && push_hit) {                                              // LR:402-403, 491-496
     root[7] = rand_float(-HF(HC_MAX_PUSH), HF(HC_MAX_PUSH), U[LG_RS_PUSH]);
     root[8] = rand_float(-HF(HC_MAX_PUSH), HF(HC_MAX_PUSH), U[LG_RS_PUSH + 1]);
     root_dirty = true;
@@ -415,9 +427,15 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
   // ---- check_termination (LR:155-160)
   term |= HI(HC_FLIP) && R.pg[2] > 0.f;
   term |= fault;                                   // physics fault / lost env flagged by this launch
-  const bool tout = (float)eplen > HF(HC_MAX_EPLEN);
-  C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0;
-  C->ep_len[e] = eplen;
+  bool tout = (float)eplen > HF(HC_MAX_EPLEN);
+  if (ro) {                                        // rollout envs never terminate on their own: the flags keep their last values (robot_batch_rollout.py:806-809)
+    const int fl = (int)pre[4];
+    tout = (fl >> 8) != 0; term = ((fl & 0xff) != 0 || fault) && !tout;
+    if (fault) C->reset_buf[e] = 1;
+  } else {
+    C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0;
+    C->ep_len[e] = eplen;
+  }
   // ---- compute_reward (LR:215-232): terms in config order; _reward_feet_air_time rewrites the feet timers where it stands in
   // that order (RM:150-163), so earlier terms see the old values and later ones the new, as in the reference
   R.bh = 0.f;
@@ -441,6 +459,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
     rew += r; M[FM_RK + kterm] = r;
   }
   C->rew[e] = rew;
+  if (rew_out) rew_out[(size_t)krow * rew_stride] = rew;
   if (K.rewards) {                               // PPO.process_env_step (ppo.py:165, 179-183): three roundings
 #pragma clang fp contract(off)
     const float boot = K.gamma * (S[FS_VAL] * (tout ? 1.f : 0.f));
@@ -450,7 +469,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
 #pragma unroll
   for (int f = 0; f < 4; ++f) { S[FS_AIR + f] = R.air[f]; S[FS_CT + f] = R.ct[f]; }       // what _reward_feet_air_time left (reset_env zeroes them)
   float level = pre[2];
-  const bool do_reset = term || tout;
+  const bool do_reset = !ro && (term || tout);
   if (do_reset) {
     EnvView V;
     uint8_t lastc_unused[4] = {0, 0, 0, 0};
@@ -466,14 +485,14 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
   M[FM_ROOT_DIRTY] = root_dirty ? 1.f : 0.f;
 #pragma unroll
   for (int f = 0; f < 4; ++f) M[FM_LASTC + f] = R.lastc[f] ? 1.f : 0.f;
-  if (HI(HC_GAIT_ON)) {                                                                 // anymal.py:107-110
+  if (HI(HC_GAIT_ON) && !ro) {                                                          // anymal.py:107-110
     float x = fmodf(S[FS_GAIT] + dt / HF(HC_GAIT_PERIOD), 1.0f); if (x < 0.f) x += 1.0f;
     S[FS_GAIT] = x;
   }
   // ---- episode sums and the statistics of LR:200-206
 #pragma unroll 4
   for (int k = 0; k < K_; ++k) {
-    const float tot = S[FS_SUMS + k] + M[FM_RK + k];
+    const float tot = S[FS_SUMS + k] + (ro ? 0.f : M[FM_RK + k]);                 // compute_reward_rollout does not touch the episode sums
     M[FM_PART + k] = do_reset ? tot : 0.f;
     S[FS_SUMS + k] = do_reset ? 0.f : tot;
   }
@@ -484,7 +503,8 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
 
 // ---- all four waves: write-back of the env rows + observation rows, 4 envs per wave; statistics + arrival by wave 0
 // Returns true on the LAST workgroup of the launch to arrive (it then runs finalize_from_acc).
-LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out) {
+LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out,
+                                const int32_t* __restrict__ ids, bool ro) {
   STAMP_DECL
   const int wv = tid >> 6, ln = tid & 63;
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
@@ -494,7 +514,8 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   // (env, row) was 60, each with a handful of active lanes.  All LDS reads first (one round trip), then the stores.
   {
     const int K_ = HI(HC_K);
-    const size_t eb = (size_t)(e0 + 4 * wv);                 // first env of this wave
+    const int kb = e0 + 4 * wv;                              // first row of this wave; row kb + q is env EQ(q)
+#define EQ(q) ((size_t)fused_env_of(ids, min(kb + (q), n - 1)))
 #define ROWI(LEN) const int q = ln / (LEN), i = ln - q * (LEN);
 #define ROWQ(LEN) ROWI(LEN) const bool ok = q < 4 && 4 * wv + q < nenv; const float* S = SR + (4 * wv + (ok ? q : 0)) * FS_STRIDE;
     float v_root, v_d0, v_d1, v_a = 0.f, v_b = 0.f, v_act, v_lrv, v_ldv, v_s0 = 0.f, v_s1 = 0.f, v_lc;
@@ -507,7 +528,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
       ROWQ(13)
       const int off = i < 4 ? FS_CMD + i : i < 8 ? FS_AIR + i - 4 : i < 12 ? FS_CT + i - 8 : FS_GAIT;
       v_a = S[off]; k_a = ok;
-      const size_t e = eb + (ok ? q : 0);
+      const size_t e = EQ(ok ? q : 0);
       p_a = i < 4 ? C->commands + e * 4 + i : i < 8 ? C->feet_air + e * 4 + (i - 4) : i < 12 ? C->feet_ctime + e * 4 + (i - 8) : C->gait_idx + e;
     }
     {   // base_lin_vel | base_ang_vel | projected_gravity | base_lin_acc | base_ang_acc: 15 lanes per env
@@ -515,7 +536,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
       const int r = i / 3, c = i - 3 * r;
       const int off = (r == 0 ? FS_BLV : r == 1 ? FS_BAV : r == 2 ? FS_PG : r == 3 ? FS_BLA : FS_BAA) + c;
       v_b = S[off]; k_b = ok;
-      const size_t e = eb + (ok ? q : 0);
+      const size_t e = EQ(ok ? q : 0);
       float LG_G* base = r == 0 ? C->base_lin_vel : r == 1 ? C->base_ang_vel : r == 2 ? C->proj_grav : r == 3 ? C->base_lin_acc : C->base_ang_acc;
       p_b = base + e * 3 + c;
     }
@@ -528,17 +549,18 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
     }
     { const int q = ln >> 2, f = ln & 3; k_lc = q < 4 && 4 * wv + q < nenv; v_lc = MB[(4 * wv + (k_lc ? q : 0)) * FM_STRIDE + FM_LASTC + f]; }
     static_assert(LG_MAX_REWARD_TERMS <= 32, "two passes of 16 terms cover the episode sums");
-    { ROWI(13) if (k_root) C->root[(eb + q) * 13 + i] = v_root; }
-    { ROWI(12) if (k_d) { C->dof[(eb + q) * 24 + i] = v_d0; C->dof[(eb + q) * 24 + 12 + i] = v_d1; C->last_actions[(eb + q) * 12 + i] = v_act; C->last_dof_vel[(eb + q) * 12 + i] = v_ldv; } }
-    { ROWI(6) if (k_lrv) C->last_root_vel[(eb + q) * 6 + i] = v_lrv; }
+    { ROWI(13) if (k_root) C->root[EQ(q) * 13 + i] = v_root; }
+    { ROWI(12) if (k_d) { const size_t e = EQ(q); C->dof[e * 24 + i] = v_d0; C->dof[e * 24 + 12 + i] = v_d1; C->last_actions[e * 12 + i] = v_act; C->last_dof_vel[e * 12 + i] = v_ldv; } }
+    { ROWI(6) if (k_lrv) C->last_root_vel[EQ(q) * 6 + i] = v_lrv; }
     if (k_a) *p_a = v_a;
     if (k_b) *p_b = v_b;
     { const int q = ln & 3, k0 = ln >> 2;
-      if (k_s0) C->ep_sums[(size_t)k0 * C->N + eb + q] = v_s0;
-      if (k_s1) C->ep_sums[(size_t)(k0 + 16) * C->N + eb + q] = v_s1; }
-    if (k_lc) C->last_contacts[(eb + (ln >> 2)) * 4 + (ln & 3)] = v_lc != 0.f ? 1 : 0;
+      if (k_s0) C->ep_sums[(size_t)k0 * C->N + EQ(q)] = v_s0;
+      if (k_s1) C->ep_sums[(size_t)(k0 + 16) * C->N + EQ(q)] = v_s1; }
+    if (k_lc) C->last_contacts[EQ(ln >> 2) * 4 + (ln & 3)] = v_lc != 0.f ? 1 : 0;
 #undef ROWQ
 #undef ROWI
+#undef EQ
   }
   STAMP(32);
   // statistics of the workgroup's envs (fixed env order), arrival
@@ -582,7 +604,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
     for (int q = 0; q < 4; ++q) {                 // (unrolled: the four envs' LDS reads interleave)
       const int el = 4 * wv + q;
       if (el >= nenv) continue;
-      const int e = e0 + el;
+      const int e = fused_env_of(ids, e0 + el);
       const float* S = SR + el * FS_STRIDE; const float* H = HB + FH_HEIGHTS + el * MAX_P;
       const float rootz = MB[el * FM_STRIDE + FM_ROOTZ];
       float u[4] = {0.5f, 0.5f, 0.5f, 0.5f}, ex[4] = {0.f, 0.f, 0.f, 0.f}, val[4];
@@ -607,7 +629,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
           u[0] = t.x; u[1] = t.y; u[2] = t.z; u[3] = t.w;
         } else {
           uint32_t o4[4];
-          philox4((uint32_t)e, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), 0u, (uint32_t)HI(HC_SEED_LO), (uint32_t)HI(HC_SEED_HI), o4);
+          philox4((uint32_t)e, (uint32_t)step, (uint32_t)((LG_RS_NOISE >> 2) + gq), ro ? 2u : 0u, (uint32_t)HI(HC_SEED_LO), (uint32_t)HI(HC_SEED_HI), o4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) u[i] = u01(o4[i]);
         }
@@ -636,7 +658,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
     for (int q = 0; q < 4; ++q) {
       const int el = 4 * wv + q;
       if (el >= nenv) continue;
-      const int e = e0 + el;
+      const int e = fused_env_of(ids, e0 + el);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int idx = 4 * g0 + ln + 64 * j;

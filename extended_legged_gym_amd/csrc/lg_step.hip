@@ -473,19 +473,20 @@ LG_DEV void fetch_state(const float* rec, float root[13], float q[3], float qd[3
 // MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
 // MODE 2: lg_compute_torques only.
 // Optional second destinations of a step that feeds a rollout storage directly (lg_step_transition), see post_instance
-struct PostSink { float* obs_out; const float* values; float* rewards; float* dones; float gamma; };
+struct PostSink { float* obs_out; const float* values; float* rewards; float* dones; float gamma;
+                  float* rew_out; int rew_stride; };       // (fused rollout steps: the reward column of lg_rollout_batch's (n, horizon) matrix)
 
 // the post-physics step as the tail of this kernel (lg_fused_post.h, defined below the post-physics helpers)
 struct FusedMainIn;
-LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid, int64_t step, const float* values);
-LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid);
+LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid, int64_t step, const float* values, const int32_t* __restrict__ ids, bool ro);
+LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid, const int32_t* __restrict__ ids, bool ro);
 enum { NZ_IT = 6 };          // Philox calls per helper lane that cover the observation noise of the workgroup's 16 envs (rows of up to 256 entries)
 LG_DEV bool fused_noise_predrawn(const float* hot);
-LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid, int64_t step, float nz[NZ_IT][4]);
+LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid, int64_t step, float nz[NZ_IT][4], const int32_t* __restrict__ ids, bool ro);
 LG_DEV void fused_noise_park(const float* hot, float* HB, int blk, int n, int htid, const float nz[NZ_IT][4]);
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot, const LegModel& lm_, float* xs, float* UB, float* HB, int lane, int e, bool valid,
                                   const float* root, const float* q, const float* qd, const float* tau, const float* last_qd, const V3* fbody,
-                                  const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K);
+                                  const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K, bool ro, int krow);
 // blockIdx -> env block with the blocks of one XCD contiguous (blockIdx % 8 = XCD, round-robin dispatch): a bijection on [0, nb)
 LG_DEV int xcd_block(unsigned b, unsigned nb) {
   const unsigned x = b & 7u, i = b >> 3, per = nb >> 3, rem = nb & 7u;
@@ -500,8 +501,9 @@ LG_DEV const DevCtx* late_ctx(const DevCtx* C) {
   return reinterpret_cast<const DevCtx*>(reinterpret_cast<const char*>(C) + zero);
 }
 #define FUSED_STATS_WAVE 1   // which wave of a fused workgroup adds the statistics, draws the arrival ticket and tests for the last arrival (a helper wave: with the rigid-body rows moved in front of (G2) the helpers reach the write-back with less left to do than the main wave; A/B -0.5 %)
-LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out);
-LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid);
+LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out,
+                                const int32_t* __restrict__ ids, bool ro);
+LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid, bool ro);
 LG_DEV bool fused_did_reset(const float* HB, int el);
 LG_DEV float* fused_foot_row(float* xs, int lane);
 LG_DEV float* fused_act_slot(float* xs, int lane, int d);
@@ -546,7 +548,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // reads take issue slots of the wave whose chain of gate evaluations is the critical path in front of rendezvous (A2).
   constexpr bool LSTM_LDS = !TMESH && LG_LSTM_LDS;
   __shared__ __attribute__((aligned(16))) float wlds[LSTM_LDS ? LW_COUNT + 3 : 4];
-  const int64_t fstep = C->counters[0] + 1;               // LR:123 (the statistics step of the previous launch stored it)
+  const bool ro = fuse == 2;                              // fused ROLLOUT step of an env subset (lg_step_subset rollout_mode = 1, lg_rollout_batch)
+  const int64_t fstep = ro ? C->counters[3] + 1 : C->counters[0] + 1;   // LR:123 (the statistics step of the previous launch stored it)
+  const int64_t gstep_f = C->counters[0] + 1;             // what the gait term's "has a scheduler step run yet" test sees (post_instance: gstep)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // Which block of 16 envs this workgroup steps.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own
   // L2; on triangle-mesh terrains the BVH (13 MB of nodes + 34 MB of triangles on config 3) is what the contact queries read, and envs with
@@ -726,7 +730,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (fuse && sub + 1 == nsub) {                   // ... in the last substep: what the post-physics tail needs from HBM
         if (net) *fused_act_slot(xs, lane, d) = a;     // (the mass-factor table is dead after (A3): the env rows live there)
         STAMP(46);                                     // (diagnostic: (A3) of the last substep)
-        fused_prefetch(late_ctx(C), xs, &xbias[0][0], bid, n, (wv - 1) * 64 + lane, fstep, sink.values);
+        fused_prefetch(late_ctx(C), xs, &xbias[0][0], bid, n, (wv - 1) * 64 + lane, fstep, sink.values, ids, ro);
 #ifdef LG_STAMPS
         __builtin_amdgcn_s_waitcnt(0);
 #endif
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     float nz[NZ_IT][4];
     const bool predraw = fuse && fused_noise_predrawn(hot);
-    if (predraw) fused_noise_draw(hot, bid, n, (wv - 1) * 64 + lane, fstep, nz);   // (these waves would wait for the main wave's last sweeps now)
+    if (predraw) fused_noise_draw(hot, bid, n, (wv - 1) * 64 + lane, fstep, nz, ids, ro);   // (these waves would wait for the main wave's last sweeps now)
     lds_barrier();                                     // (F) main wave has published the final state of the step
     const DevCtx* const Ct = late_ctx(C);                // (everything behind the last substep reads the context through this: see late_ctx)
     STAMP(48);
@@ -764,16 +768,16 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane));   // (gait_foot_z is stored late: the serial part still reads the old one)
         }
       }
-      fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane);
+      fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane, ids, ro);
       // the rigid-body rows (stores nobody in this launch reads) while the main wave runs the serial part: these waves wait ~6 k cycles for
       // it at (G2); behind the write-back, where they used to be, they were on the tail of the launch
       if (valid && g.inject_sim_state) {                         // parity tests: the injected rows stay; gait_foot_z from the injected foot row
-        if (wv == 3 && g.gait_enabled) Ct->gait_foot_z[(size_t)e * NLEG + l] = Ct->rigid[((size_t)e * Ct->B + 1 + Ct->per_leg * l + (Ct->per_leg == 4 ? 3 : 2)) * 13 + 2];
+        if (wv == 3 && g.gait_enabled && !ro) Ct->gait_foot_z[(size_t)e * NLEG + l] = Ct->rigid[((size_t)e * Ct->B + 1 + Ct->per_leg * l + (Ct->per_leg == 4 ? 3 : 2)) * 13 + 2];
       } else if (valid && !(feet_early && wv == 3)) {            // rigid-body rows of the post-physics (pre-reset) pose, LR:118-120
         float r13[13], qq[3], qdd[3];
         fetch_state(xst[lane], r13, qq, qdd);
-        write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled) ? Ct->gait_foot_z + (size_t)e * NLEG + l : nullptr);
-      } else if (valid && g.gait_enabled) {
+        write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled && !ro) ? Ct->gait_foot_z + (size_t)e * NLEG + l : nullptr);
+      } else if (valid && g.gait_enabled && !ro) {
         Ct->gait_foot_z[(size_t)e * NLEG + l] = fused_foot_row(xs, lane)[2];
       }
       STAMP(51);
@@ -799,10 +803,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (!(fuse && g.inject_sim_state)) Ct->torques[(size_t)e * NDOF + d] = xtau[j][lane];
     }
     if (fuse) {
-      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out);
+      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out, ids, ro);
       if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last ? 1 : 0;
       __syncthreads();
-      if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x);
+      if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x, ro);
     }
     return;
   }
@@ -965,7 +969,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   STAMP(39);
   if (fuse) {
     // ---- fused step: the post-physics step of the workgroup's envs, from the registers of this wave (lg_fused_post.h)
-    fused_main_and_serial(Ct, hot, lm_, xs, &xbias[0][0], cst, lane, e, valid, s.root, s.q, s.qd, tau, last_qd, fbody, split ? nullptr : act, fault, fstep, stamps, sink);
+    fused_main_and_serial(Ct, hot, lm_, xs, &xbias[0][0], cst, lane, e, valid, s.root, s.q, s.qd, tau, last_qd, fbody, split ? nullptr : act, fault, ro ? gstep_f : fstep, stamps, sink, ro, krow);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -985,14 +989,14 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (per_leg == 4) { cl[9] = fbody[4].x; cl[10] = fbody[4].y; cl[11] = fbody[4].z; }
     }
     STAMP(12);
-    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out);
+    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out, ids, ro);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     STAMP(13);
     if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last_wg ? 1 : 0;
     __syncthreads();
-    if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x);
+    if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x, ro);
     STAMP(14);
 #ifdef LG_STAMPS
     if (stamps) stamps[36] += __builtin_amdgcn_s_memtime() - t_entry;      // the main wave's whole kernel
@@ -1999,7 +2003,7 @@ static std::vector<float> pack_obs_table(const lg_config& g, int P) {
   return t;
 }
 // glue between physics_kernel (which only sees declarations) and the tail
-LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid) { finalize_from_acc(C, nblocks, 1, tid, false); }
+LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid, bool ro) { finalize_from_acc(C, nblocks, ro ? 2 : 1, tid, false); }
 LG_DEV bool fused_did_reset(const float* HB, int el) { return HB[FH_MISC + el * FM_STRIDE + FM_DID_RESET] != 0.f; }
 LG_DEV float* fused_foot_row(float* xs, int lane) { return xs + (lane / GRP) * FS_STRIDE + FS_FRB + 13 * (lane % GRP); }
 LG_DEV float* fused_act_slot(float* xs, int lane, int d) { return xs + (lane / GRP) * FS_STRIDE + FS_ACT + d; }
@@ -2011,7 +2015,7 @@ LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__ C) {    // reward t
 }
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot, const LegModel& lm_, float* xs, float* UB, float* HB, int lane, int e, bool valid,
                                   const float* root, const float* q, const float* qd, const float* tau, const float* last_qd, const V3* fbody,
-                                  const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K) {
+                                  const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K, bool ro, int krow) {
   STAMP_DECL
   const int l = lane % GRP, el = lane / GRP;
   float* S = xs + el * FS_STRIDE;
@@ -2027,7 +2031,7 @@ LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot
   STAMP(19);
   if (l == 0 && valid)
     fused_env_serial(C, hot, e, S, UB + FU_U + el * LG_RS_NOISE, UB + FU_PRE + el * FU_PRE_STRIDE, HB + FH_MISC + el * FM_STRIDE,
-                     HB + FH_HEIGHTS + el * MAX_P, feat, fault, step, K);
+                     HB + FH_HEIGHTS + el * MAX_P, feat, fault, step, K, ro, krow, K.rew_out, K.rew_stride);
   STAMP(20);
   lds_barrier();                                         // (G2) serial part + height scan done
   STAMP(21);
@@ -2037,15 +2041,15 @@ LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot
 // The post-physics step as the tail of the physics kernel (lg_fused_post.h) exists for the four-legged instance; the six-legged one ends
 // its policy step in post_kernel (can_fuse() is false there, these are never called).
 static std::vector<float> pack_obs_table(const lg_config&, int) { return std::vector<float>(4, 0.f); }
-LG_DEV void fused_prefetch(const DevCtx* __restrict__, float*, float*, int, int, int, int64_t, const float*) {}
-LG_DEV void fused_height_scan(const DevCtx* __restrict__, const float (*)[20], float*, int, int, int) {}
+LG_DEV void fused_prefetch(const DevCtx* __restrict__, float*, float*, int, int, int, int64_t, const float*, const int32_t* __restrict__, bool) {}
+LG_DEV void fused_height_scan(const DevCtx* __restrict__, const float (*)[20], float*, int, int, int, const int32_t* __restrict__, bool) {}
 LG_DEV bool fused_noise_predrawn(const float*) { return false; }
-LG_DEV void fused_noise_draw(const float*, int, int, int, int64_t, float (*)[4]) {}
+LG_DEV void fused_noise_draw(const float*, int, int, int, int64_t, float (*)[4], const int32_t* __restrict__, bool) {}
 LG_DEV void fused_noise_park(const float*, float*, int, int, int, const float (*)[4]) {}
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__, const float*, const LegModel&, float*, float*, float*, int, int, bool, const float*, const float*,
-                                  const float*, const float*, const float*, const V3*, const float*, bool, int64_t, unsigned long long*, const PostSink&) {}
-LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__, const float*, const float*, const float*, int, int, int, int64_t, unsigned long long*, float*) { return false; }
-LG_DEV void fused_finalize(const DevCtx* __restrict__, int, int) {}
+                                  const float*, const float*, const float*, const V3*, const float*, bool, int64_t, unsigned long long*, const PostSink&, bool, int) {}
+LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__, const float*, const float*, const float*, int, int, int, int64_t, unsigned long long*, float*, const int32_t* __restrict__, bool) { return false; }
+LG_DEV void fused_finalize(const DevCtx* __restrict__, int, int, bool) {}
 LG_DEV bool fused_did_reset(const float*, int) { return false; }
 LG_DEV float* fused_foot_row(float* xs, int) { return xs; }
 LG_DEV float* fused_act_slot(float* xs, int, int) { return xs; }
@@ -2390,7 +2394,8 @@ static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t*
 // fuse: the post-physics step runs as the tail of the physics kernel (full steps of all envs with helper waves; LG_FUSE=0 keeps
 // the two-launch path, which every split / subset / rollout entry point uses anyway)
 static bool can_fuse(const lg_ctx* c) { return LG_LEGS == 4 && c->fuse && (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) && c->h.P <= MAX_P; }
-static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = NDOF, bool fuse = false,
+// fuse: 0 = physics only (a post kernel follows), 1 = full policy step with the fused tail, 2 = fused ROLLOUT step of the listed envs
+static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = NDOF, int fuse = 0,
                            PostSink sink = PostSink{nullptr, nullptr, nullptr, nullptr, 0.f}) {
   const int nb = (n + EPB - 1) / EPB;
   // helper waves (leg bias, contact detection, a share of the contact set-up; with the actuator network also its three
@@ -2400,15 +2405,15 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
   const int nact = (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) ? 3 : 0;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
-    hipLaunchKernelGGL((physics_kernel<0, true, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
+    hipLaunchKernelGGL((physics_kernel<0, true, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
   else
 #if LG_AB == 13
     if (nact == 3 && c->h.cfg.solver_type == LG_SOLVER_TGS && c->h.cfg.friction_model == LG_FRICTION_PYRAMID && c->spec)
-      hipLaunchKernelGGL((physics_kernel<0, false, true, 1>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
+      hipLaunchKernelGGL((physics_kernel<0, false, true, 1>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
     else
 #endif
-    if (nact == 3) hipLaunchKernelGGL((physics_kernel<0, false, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
-    else hipLaunchKernelGGL((physics_kernel<0, false, false>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse ? 1 : 0, sink);
+    if (nact == 3) hipLaunchKernelGGL((physics_kernel<0, false, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
+    else hipLaunchKernelGGL((physics_kernel<0, false, false>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
 }
 
 int lg_step(lg_ctx* c, const float* actions, void* stream) {
@@ -2423,7 +2428,7 @@ int lg_step(lg_ctx* c, const float* actions, void* stream) {
   }
   if (ev) (void)hipEventRecord(ev[0], st);
   const bool fuse = can_fuse(c);
-  launch_physics(c, st, actions, nullptr, c->h.N, NDOF, fuse);
+  launch_physics(c, st, actions, nullptr, c->h.N, NDOF, fuse ? 1 : 0);
   if (ev) (void)hipEventRecord(ev[1], st);
   if (fuse) {                                            // one launch per policy step
     if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
@@ -2443,7 +2448,7 @@ int lg_step_transition(lg_ctx* c, const float* actions, float* next_observations
   hipStream_t st = (hipStream_t)stream;
   const PostSink sink{next_observations, values, rewards, dones, gamma};
   if (can_fuse(c)) {
-    launch_physics(c, st, actions, nullptr, c->h.N, NDOF, true, sink);
+    launch_physics(c, st, actions, nullptr, c->h.N, NDOF, 1, sink);
     HIP_TRY(c, hipGetLastError());
     return LG_OK;
   }
@@ -2456,6 +2461,11 @@ int lg_step_subset(lg_ctx* c, const float* actions, const int32_t* env_ids, int3
   DeviceScope ds_(c->device);
   if (!actions || !env_ids || n <= 0 || n > c->h.N) { c->err = "bad subset step arguments"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
+  if (rollout_mode && can_fuse(c)) {                     // rollout steps end inside the physics kernel as well (LG_FUSE=0: two launches)
+    launch_physics(c, st, actions, env_ids, n, NDOF, 2);
+    HIP_TRY(c, hipGetLastError());
+    return LG_OK;
+  }
   launch_physics(c, st, actions, env_ids, n);
   return launch_post(c, st, nullptr, env_ids, n, rollout_mode ? 1 : 0);
 }
@@ -2602,11 +2612,17 @@ int lg_rollout_batch(lg_ctx* c, const float* all_us, int32_t horizon, const int3
   hipStream_t st = (hipStream_t)stream;
   int rc = lg_sync_main_to_rollout(c, rollouts_per_main, pos_drift, stream);
   if (rc != LG_OK) return rc;
+  const bool fuse = can_fuse(c);
   for (int i = 0; i < horizon; ++i) {
+    if (fuse) {                                          // one launch per rollout step: the reward column is written by the kernel's tail
+      launch_physics(c, st, all_us + (size_t)i * NDOF, env_ids, n, horizon * NDOF, 2, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f, rewards + i, horizon});
+      continue;
+    }
     launch_physics(c, st, all_us + (size_t)i * NDOF, env_ids, n, horizon * NDOF);
     rc = launch_post(c, st, nullptr, env_ids, n, 1, rewards + i, horizon);
     if (rc != LG_OK) return rc;
   }
+  HIP_TRY(c, hipGetLastError());
   return lg_sync_main_to_rollout(c, rollouts_per_main, pos_drift, stream);
 }
 

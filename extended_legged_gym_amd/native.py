@@ -139,11 +139,12 @@ class NativeCore:
         self._check(self.lib.lg_sync_main_to_rollout(self.ctx, int(rollouts_per_main), float(pos_drift), self._stream()))
 
     def rollout_batch(self, all_us, env_ids_i32, rollouts_per_main, pos_drift=0.0):
-        """(n, H, 12) plan -> (n, H) rewards: sync, H rollout steps, sync, enqueued by one library call."""
+        """(n, H, num_dof) plan -> (n, H) rewards: sync, H rollout steps, sync, enqueued by one library call."""
         a = self._f32(all_us)
         n, H = int(a.shape[0]), int(a.shape[1])
-        if n != int(env_ids_i32.numel()) or a.dim() != 3 or a.shape[2] != 12:
-            raise ValueError(f"expected a plan of shape ({int(env_ids_i32.numel())}, H, 12), got {tuple(a.shape)}")
+        nd = int(self.t["actions"].shape[1])
+        if n != int(env_ids_i32.numel()) or a.dim() != 3 or a.shape[2] != nd:
+            raise ValueError(f"expected a plan of shape ({int(env_ids_i32.numel())}, H, {nd}), got {tuple(a.shape)}")
         rew = torch.empty(n, H, dtype=torch.float32, device=self.device)
         self._check(self.lib.lg_rollout_batch(self.ctx, C.c_void_p(a.data_ptr()), H, C.c_void_p(env_ids_i32.data_ptr()), n,
                                               int(rollouts_per_main), float(pos_drift), C.c_void_p(rew.data_ptr()), self._stream()))

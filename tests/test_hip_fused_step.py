@@ -99,3 +99,53 @@ def test_fused_step_equals_physics_plus_post_kernel(kind, n):
         resets += int(fused.t["reset_buf"].sum()); tos += int(fused.t["time_out_buf"].sum())
     assert tos > 0 and (n < 50 or (resets > n // 4 and resets > tos))     # time-outs and contact terminations both happened
     fused.close(); split.close()
+
+
+@pytest.mark.parametrize("kind", ["flat_allrew", "rough_lstm"])
+def test_fused_rollout_steps_equal_physics_plus_post_kernel(kind):
+    """Main-rollout stepping (`lg_step_subset(..., rollout_mode = 1)`, `lg_rollout_batch`: config 5) also ends inside the physics kernel: the
+    rollout variant of the tail (no callback / termination / reset, rewards outside the episode sums, kept heights, Philox stream 2, the
+    reward column of a plan) against the physics + post-kernel pair on the same state, rows of an env SUBSET in both."""
+    R, M = 3, 20
+    n = M * (1 + R)
+    cfg, setup, terrain, fused = make(kind, n, True)
+    _, _, _, split = make(kind, n, False)
+    rng = np.random.default_rng(0)
+    fused.t["friction_coeffs"].copy_(torch.from_numpy(rng.uniform(0.5, 1.25, n).astype(np.float32)))
+    if terrain is not None:
+        lv = torch.from_numpy(rng.integers(0, 4, n)); ty = torch.from_numpy(np.floor(np.arange(n) / (n / 4)).astype(np.int64))
+        fused.t["terrain_levels"].copy_(lv); fused.t["terrain_types"].copy_(ty)
+        fused.t["env_origins"].copy_(torch.from_numpy(terrain.env_origins[lv.numpy(), ty.numpy()].astype(np.float32)))
+    ids_all = torch.arange(n, device="cuda")
+    fused.reset_idx(ids_all)
+    g = torch.Generator().manual_seed(2)
+    for _ in range(12):                                     # full steps: contacts, heights, feet timers, flags
+        fused.step((1.5 * torch.randn(n, 12, generator=g)).cuda())
+    roll = torch.tensor([e for e in range(n) if e % (1 + R)], dtype=torch.int32, device="cuda")
+    untouched = torch.tensor([e for e in range(n) if e % (1 + R) == 0], device="cuda")
+    names = [x for x in SYNC if x != "step_counters"]
+    for it in range(10):
+        for name in SYNC:
+            split.t[name].copy_(fused.t[name])
+        before = {k: fused.t[k][untouched].clone() for k in ("root_states", "obs_buf", "episode_length_buf")}
+        a = (1.5 * torch.randn(len(roll), 12, generator=g)).cuda()
+        fused.step_subset(a, roll, 1); split.step_subset(a, roll, 1)
+        torch.cuda.synchronize()
+        for name in EXACT:
+            assert torch.equal(fused.t[name], split.t[name]), (it, name)
+        for name in FLOAT:
+            np.testing.assert_allclose(fused.t[name].double().cpu().numpy(), split.t[name].double().cpu().numpy(), rtol=2e-6, atol=2e-6, err_msg=f"rollout step {it}: {name}")
+        for k, v in before.items():
+            assert torch.equal(fused.t[k][untouched], v), k                 # the mains are not touched
+    # the horizon loop: reward matrix and final state
+    H = 6
+    for name in SYNC:
+        split.t[name].copy_(fused.t[name])
+    us = (1.5 * torch.randn(len(roll), H, 12, generator=g)).cuda()
+    rf = fused.rollout_batch(us, roll, R, 0.0); rs = split.rollout_batch(us, roll, R, 0.0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(rf.cpu().numpy(), rs.cpu().numpy(), rtol=2e-6, atol=2e-6)
+    assert float(rf.std()) > 0
+    for name in names:
+        np.testing.assert_allclose(fused.t[name].double().cpu().numpy(), split.t[name].double().cpu().numpy(), rtol=2e-6, atol=2e-6, err_msg=name)
+    fused.close(); split.close()
