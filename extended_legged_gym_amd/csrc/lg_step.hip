@@ -513,7 +513,7 @@ LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__ C);
 // HELPERS: the launch has the three helper waves (every policy step unless LG_SPLIT=0).  A separate instance, so that the kernel the
 // headline runs does not carry the single-wave fallback (the whole LSTM inlined in the main wave, inline leg bias and contact
 // detection): that dead code accounted for most of the register spills the compiler reported for the kernel.
-// SPEC: see physics_substep (1 = TGS + pyramid friction rows fixed at compile time: the headline instance).
+// SPEC: 1 = TGS + pyramid friction rows fixed at compile time (A/B build 13 only, see physics_substep); 2 = the fused tail in its rollout variant.
 template <int MODE, bool TMESH, bool HELPERS = false, int SPEC = 0>
 #if LG_AB == 9      // timing probe: cap the kernel at the 256 registers per wave that two workgroups per CU would leave (spills go to scratch)
 __attribute__((amdgpu_num_vgpr(120)))
@@ -548,7 +548,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // reads take issue slots of the wave whose chain of gate evaluations is the critical path in front of rendezvous (A2).
   constexpr bool LSTM_LDS = !TMESH && LG_LSTM_LDS;
   __shared__ __attribute__((aligned(16))) float wlds[LSTM_LDS ? LW_COUNT + 3 : 4];
-  const bool ro = fuse == 2;                              // fused ROLLOUT step of an env subset (lg_step_subset rollout_mode = 1, lg_rollout_batch)
+  // fused ROLLOUT step of an env subset (lg_step_subset rollout_mode = 1, lg_rollout_batch): its own instance (SPEC = 2), so that the
+  // full step's tail carries none of the variant's selects (as run-time branches they cost the headline step 1.3 %: A/B in one session)
+  constexpr bool ro = SPEC == 2;
   const int64_t fstep = ro ? C->counters[3] + 1 : C->counters[0] + 1;   // LR:123 (the statistics step of the previous launch stored it)
   const int64_t gstep_f = C->counters[0] + 1;             // what the gait term's "has a scheduler step run yet" test sees (post_instance: gstep)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     };
     auto share_fn = [&]() { if (helpers) lds_barrier(); };   // (A3) every wave has finished its slots
     const SlotShare share{helpers ? 4 : 1, helpers ? 3 : 0, helpers};     // set-up order: wave 1, 2, 3, then this wave
-    physics_substep<TMESH, TMESH ? 2 : DS0, !(MODE == 0 && HELPERS), SPEC>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
+    physics_substep<TMESH, TMESH ? 2 : DS0, !(MODE == 0 && HELPERS), SPEC == 1 ? 1 : 0>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
                               sub == nsub - 1 ? fbody : nullptr, stamps, (TMESH && helpers) ? cqc : nullptr);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
@@ -2404,6 +2406,15 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
   // as well: the main wave alone took 0.134 ms per rollout step of 4096 envs on the plane
   const int nact = (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) ? 3 : 0;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
+#if LG_LEGS == 4
+  if (fuse == 2) {                                       // (can_fuse() held: helper waves are present)
+    if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
+      hipLaunchKernelGGL((physics_kernel<0, true, true, 2>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
+    else
+      hipLaunchKernelGGL((physics_kernel<0, false, true, 2>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
+    return;
+  }
+#endif
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
     hipLaunchKernelGGL((physics_kernel<0, true, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
   else
