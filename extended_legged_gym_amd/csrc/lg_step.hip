@@ -551,6 +551,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // fused ROLLOUT step of an env subset (lg_step_subset rollout_mode = 1, lg_rollout_batch): its own instance (SPEC = 2), so that the
   // full step's tail carries none of the variant's selects (as run-time branches they cost the headline step 1.3 %: A/B in one session)
   constexpr bool ro = SPEC == 2;
+  const int32_t* const fids = ro ? ids : nullptr;           // the tail's row -> env map: a literal null (rows = envs) in the full step's instance
   const int64_t fstep = ro ? C->counters[3] + 1 : C->counters[0] + 1;   // LR:123 (the statistics step of the previous launch stored it)
   const int64_t gstep_f = C->counters[0] + 1;             // what the gait term's "has a scheduler step run yet" test sees (post_instance: gstep)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (fuse && sub + 1 == nsub) {                   // ... in the last substep: what the post-physics tail needs from HBM
         if (net) *fused_act_slot(xs, lane, d) = a;     // (the mass-factor table is dead after (A3): the env rows live there)
         STAMP(46);                                     // (diagnostic: (A3) of the last substep)
-        fused_prefetch(late_ctx(C), xs, &xbias[0][0], bid, n, (wv - 1) * 64 + lane, fstep, sink.values, ids, ro);
+        fused_prefetch(late_ctx(C), xs, &xbias[0][0], bid, n, (wv - 1) * 64 + lane, fstep, sink.values, fids, ro);
 #ifdef LG_STAMPS
         __builtin_amdgcn_s_waitcnt(0);
 #endif
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     float nz[NZ_IT][4];
     const bool predraw = fuse && fused_noise_predrawn(hot);
-    if (predraw) fused_noise_draw(hot, bid, n, (wv - 1) * 64 + lane, fstep, nz, ids, ro);   // (these waves would wait for the main wave's last sweeps now)
+    if (predraw) fused_noise_draw(hot, bid, n, (wv - 1) * 64 + lane, fstep, nz, fids, ro);   // (these waves would wait for the main wave's last sweeps now)
     lds_barrier();                                     // (F) main wave has published the final state of the step
     const DevCtx* const Ct = late_ctx(C);                // (everything behind the last substep reads the context through this: see late_ctx)
     STAMP(48);
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane));   // (gait_foot_z is stored late: the serial part still reads the old one)
         }
       }
-      fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane, ids, ro);
+      fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro);
       // the rigid-body rows (stores nobody in this launch reads) while the main wave runs the serial part: these waves wait ~6 k cycles for
       // it at (G2); behind the write-back, where they used to be, they were on the tail of the launch
       if (valid && g.inject_sim_state) {                         // parity tests: the injected rows stay; gait_foot_z from the injected foot row
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (!(fuse && g.inject_sim_state)) Ct->torques[(size_t)e * NDOF + d] = xtau[j][lane];
     }
     if (fuse) {
-      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out, ids, ro);
+      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out, fids, ro);
       if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last ? 1 : 0;
       __syncthreads();
       if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x, ro);
@@ -991,7 +992,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (per_leg == 4) { cl[9] = fbody[4].x; cl[10] = fbody[4].y; cl[11] = fbody[4].z; }
     }
     STAMP(12);
-    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out, ids, ro);
+    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out, fids, ro);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif

@@ -31,7 +31,7 @@ def test_headline_kernel_register_and_lds_budget(tmp_path):
             blocks[name][m.group(1).strip()] = int(m.group(2))
     # physics_kernel<0, false, true>: heightfield / plane terrain, helper waves present = every policy step of the headline config
     # (lg_step.hip is compiled once per leg count, lg_instance.h; without -DLG_LEGS this is the four-legged instance, namespace lg4)
-    key = [k for k in blocks if k.startswith("_ZN3lg414physics_kernelILi0ELb0ELb1E")]
+    key = [k for k in blocks if k.startswith("_ZN3lg414physics_kernelILi0ELb0ELb1ELi0E")]
     assert len(key) == 1, sorted(blocks)
     r = blocks[key[0]]
     print(r)
@@ -44,7 +44,7 @@ def test_headline_kernel_register_and_lds_budget(tmp_path):
     assert r["VGPRs"] + r["AGPRs"] <= 512 and r["Occupancy"] == 1, r     # one wave per SIMD by design (s5): the budget of a lone wave
     assert r["LDS Size"] <= 160 * 1024, r
     # the triangle-mesh instance: also without the fallback
-    key = [k for k in blocks if k.startswith("_ZN3lg414physics_kernelILi0ELb1ELb1E")]
+    key = [k for k in blocks if k.startswith("_ZN3lg414physics_kernelILi0ELb1ELb1ELi0E")]
     assert len(key) == 1 and blocks[key[0]]["SGPRs Spill"] <= 400 and blocks[key[0]]["LDS Size"] <= 160 * 1024, blocks[key[0]]
 
 
@@ -64,7 +64,7 @@ def test_six_legged_instance_fits_a_compute_unit(tmp_path):
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/(?:lane|block)\])?(?: \[waves/SIMD\])?: (\d+)", line)
         if m and name:
             blocks[name][m.group(1).strip()] = int(m.group(2))
-    key = [k for k in blocks if k.startswith("_ZN3lg614physics_kernelILi0ELb0ELb1E")]
+    key = [k for k in blocks if k.startswith("_ZN3lg614physics_kernelILi0ELb0ELb1ELi0E")]
     assert len(key) == 1, sorted(blocks)
     r = blocks[key[0]]
     print(r)
