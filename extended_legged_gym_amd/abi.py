@@ -134,6 +134,7 @@ class lg_tile_spec(C.Structure):
 
 
 LG_TILE_FLAT, LG_TILE_PYRAMID_SLOPE, LG_TILE_PYRAMID_STAIRS, LG_TILE_DISCRETE_OBSTACLES = 0, 1, 2, 3
+LG_TILE_STEPPING_STONES, LG_TILE_GAP, LG_TILE_PIT = 4, 5, 6
 
 
 class lg_pose_params(C.Structure):

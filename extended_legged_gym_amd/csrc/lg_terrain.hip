@@ -47,6 +47,37 @@ LG_DEV int tile_height(const lg_tile_spec& t, int i, int j, int L, int W) {
     }
     const int x1 = (W - t.platform) / 2, x2 = (W + t.platform) / 2, y1 = (L - t.platform) / 2, y2 = (L + t.platform) / 2;
     if (i >= x1 && i < x2 && j >= y1 && j < y2) h = 0;
+  } else if (t.kind == LG_TILE_STEPPING_STONES) {
+    // terrain_utils.stepping_stones_terrain (square tiles: the `length >= width` branch): strips of stones along axis 1, every strip with its
+    // own random offset along axis 0 and a leading partial stone [0, offset - distance); a height per stone from arange(-max_height - 1,
+    // max_height); everything else at `depth`; a flat platform in the middle.  rect_min = stone size, rect_max = stone distance (pixels),
+    // clip_lo = depth (vertical units).
+    const int sz = max(1, t.rect_min), pitch = sz + max(0, t.rect_max), nh = max(1, 2 * t.max_height + 1);
+    h = t.clip_lo;
+    const int strip = j / pitch;
+    if (j - strip * pitch < sz) {
+      uint32_t o[4];
+      philox4((uint32_t)strip, 0u, 0u, 17u, t.seed, 0x7e55u, o);
+      const int x0 = (int)(o[0] % (uint32_t)sz);
+      int stone = -2;                                         // -1: the leading partial stone, m >= 0: the m-th full stone of the strip
+      if (i < max(0, x0 - t.rect_max)) stone = -1;
+      else if (i >= x0 && (i - x0) % pitch < sz) stone = (i - x0) / pitch;
+      if (stone > -2) {
+        philox4((uint32_t)strip, (uint32_t)(stone + 1), 1u, 17u, t.seed, 0x7e55u, o);
+        h = -t.max_height - 1 + (int)(o[0] % (uint32_t)nh);
+      }
+    }
+    const int x1 = (W - t.platform) / 2, x2 = (W + t.platform) / 2, y1 = (L - t.platform) / 2, y2 = (L + t.platform) / 2;
+    if (i >= x1 && i < x2 && j >= y1 && j < y2) h = 0;
+  } else if (t.kind == LG_TILE_GAP) {
+    // terrain.py:gap_terrain: a square moat of width rect_min pixels at -1000 units around the central platform
+    const int cx = L / 2, cy = W / 2, x1 = (L - t.platform) / 2, y1 = (W - t.platform) / 2, x2 = x1 + t.rect_min, y2 = y1 + t.rect_min;
+    if (i >= cx - x2 && i < cx + x2 && j >= cy - y2 && j < cy + y2) h = -1000;
+    if (i >= cx - x1 && i < cx + x1 && j >= cy - y1 && j < cy + y1) h = 0;
+  } else if (t.kind == LG_TILE_PIT) {
+    // terrain.py:pit_terrain: the central square of half-width `platform` pixels lowered by max_height units
+    const int cx = L / 2, cy = W / 2;
+    if (i >= cx - t.platform && i < cx + t.platform && j >= cy - t.platform && j < cy + t.platform) h = -t.max_height;
   }
   if (t.noise_levels > 0) {
     // terrain_utils.random_uniform_terrain: levels drawn on a coarse grid, bilinear up-sampling, rint

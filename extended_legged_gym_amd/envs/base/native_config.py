@@ -166,6 +166,19 @@ def height_points(cfg):
     return np.stack([gx.reshape(-1), gy.reshape(-1)], axis=1).astype(np.float32)
 
 
+_SELF_COLLISION_WARNED = False
+
+
+def _warn_self_collisions_once():
+    global _SELF_COLLISION_WARNED
+    if not _SELF_COLLISION_WARNED:
+        _SELF_COLLISION_WARNED = True
+        import warnings
+        warnings.warn("asset.self_collisions = 0 asks for contacts between the robot's own links; this simulator generates terrain contacts "
+                      "only (DESIGN.md: out of scope, measured on the walk matrix: no link pair within 3.2 cm).  Set asset.self_collisions = 1 "
+                      "to silence this.", stacklevel=3)
+
+
 class NativeSetup:
     """Owns the structs plus the numpy buffers their pointers refer to (keeps them alive)."""
 
@@ -321,8 +334,14 @@ class NativeSetup:
         if not 0.0 < erp <= 1.0:
             raise ValueError(f"sim.physx.penetration_recovery must be in (0, 1], got {erp}")
         c.erp, c.cfm = erp, 1e-6
-        # asset.self_collisions is a collision-filter bitmask: 0 = the actor's shapes collide with each other (legged_robot_config.py:176)
-        c.self_collisions = 0
+        # asset.self_collisions is PhysX's collision-filter bitmask (legged_robot_config.py:176, create_actor at legged_robot.py:792):
+        # 0 = the actor's own shapes collide with each other.  lg_config.self_collisions carries the REQUEST with one meaning (1 = the task
+        # asks for leg-leg / leg-trunk contacts); the kernels generate terrain contacts only -- a pair across two legs couples two leg blocks
+        # and does not fit the per-leg Schur structure -- so a task that asks is told once.  Measured (tools/physics/self_collision_probe.py):
+        # on the walk matrix no such pair comes within 3.2 cm, i.e. none would be generated at contact_offset = 1 cm.
+        c.self_collisions = 1 if int(getattr(cfg.asset, "self_collisions", 0)) == 0 else 0
+        if c.self_collisions:
+            _warn_self_collisions_once()
         c.seed, c.rng_mode = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_mode)
         self.cfg = c
 

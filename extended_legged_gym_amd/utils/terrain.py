@@ -30,8 +30,8 @@ class Terrain:
     def __init__(self, cfg, num_robots, device=None) -> None:
         """`device` (e.g. "cuda:0", passed by the env): build on the GPU -- `cfg.device_generation` = "mesh" (default): tiles by the host
         generators (numpy's stream, the reference's grids bit for bit), the heightfield -> triangle-mesh conversion as a kernel
-        (bit-exact); "all": the five curriculum tile types as a kernel too (Philox draws instead of numpy's: same distributions,
-        other samples); "off" or `device=None` (tools, CPU tests): host numpy throughout."""
+        (bit-exact); "all": every `make_terrain` tile type as a kernel too (slopes, stairs, gaps and pits integer-identical; rough slopes, discrete
+        obstacles and stepping stones with Philox draws instead of numpy's: same distributions, other samples); "off" or `device=None` (tools, CPU tests): host numpy throughout."""
         self.cfg = cfg
         self._device = device
         self._mode = getattr(cfg, "device_generation", "mesh") if device is not None else "off"

@@ -83,9 +83,18 @@ def tile_spec_for(choice, difficulty, proportions, tile_px, horizontal_scale, ve
         t.kind = abi.LG_TILE_DISCRETE_OBSTACLES
         t.max_height = int(obstacle_height / vs)
         t.rect_min, t.rect_max, t.rect_count, t.platform = int(1. / hs), int(2. / hs), 20, int(3. / hs)
-    else:
-        raise NotImplementedError("device generation covers the five curriculum terrain types (slope, rough slope, stairs up / down, "
-                                  "discrete obstacles); stepping stones, gaps and pits are host generators")
+    elif choice < p[5]:          # terrain.py:145-147
+        stone_size = 1.5 * (1.05 - difficulty)
+        stone_distance = 0.05 if difficulty == 0 else 0.1
+        t.kind = abi.LG_TILE_STEPPING_STONES
+        t.rect_min, t.rect_max = int(stone_size / hs), int(stone_distance / hs)
+        t.max_height, t.clip_lo, t.platform = int(0. / vs), int(-10 / vs), int(4. / hs)
+    elif choice < p[6]:          # gap_terrain(tile, gap_size=1. * difficulty, platform_size=3.)
+        t.kind = abi.LG_TILE_GAP
+        t.rect_min, t.platform = int(1. * difficulty / hs), int(3. / hs)
+    else:                        # pit_terrain(tile, depth=1. * difficulty, platform_size=4.)
+        t.kind = abi.LG_TILE_PIT
+        t.max_height, t.platform = int(1. * difficulty / vs), int(4. / hs / 2)
     return t
 
 

@@ -261,8 +261,9 @@ typedef struct lg_config {
   float contact_offset, max_depenetration_velocity, erp, cfm;
   int32_t solver_type;                /* enum lg_solver: physx.solver_type */
   int32_t friction_model;             /* enum lg_friction */
-  int32_t self_collisions;            /* 1 = the robot's own collision spheres collide with each other (asset.self_collisions == 0,
-                                       * legged_robot_config.py:176, passed to create_actor at legged_robot.py:792) */
+  int32_t self_collisions;            /* the task's REQUEST, recorded only: 1 = asset.self_collisions == 0 (legged_robot_config.py:176, create_actor at
+                                       * legged_robot.py:792), i.e. PhysX would collide the robot's own shapes.  No kernel reads it: contacts are
+                                       * link-terrain only (out of scope); the host warns once when a task asks. */
   /* rng */
   uint64_t seed; int32_t rng_mode;
   /* AsyncGaitScheduler (utils/gait_scheduler.py:97-175; sections cfg.async_gait_scheduler / cfg.rewards.async_gait_scheduler):
@@ -287,12 +288,15 @@ typedef struct lg_ctx lg_ctx;
  * lg_terrain_generate fills the (tot_rows, tot_cols) int16 height grid tile by tile -- the curriculum / random layouts of Terrain
  * (`terrain.py:82-173`) hand it one lg_tile_spec per (row, col) -- and the (num_rows, num_cols, 3) tile origins
  * [(row + 0.5) length, (col + 0.5) width, max height of the central 2 m x 2 m window] (`:156-173`).  The deterministic generators
- * (pyramid slope, pyramid stairs, flat) produce the host generators' integers exactly; the random ones (uniform noise, discrete
- * obstacles) draw from Philox4x32-10 keyed by the tile seed instead of numpy's global stream: same distributions, other samples.
+ * (pyramid slope, pyramid stairs, gap, pit, flat) produce the host generators' integers exactly; the random ones (uniform noise, discrete
+ * obstacles, stepping stones) draw from Philox4x32-10 keyed by the tile seed instead of numpy's global stream: same distributions, other samples.
  * lg_heightfield_to_trimesh is convert_heightfield_to_trimesh (`terrain.py:77-80`) -- regular triangulation, cell (i, j) ->
  * (v0, v3, v1), (v0, v2, v3), vertices next to a step steeper than slope_threshold moved by one cell -- bit for bit.
  * Device pointers; asynchronous on `stream`. */
-enum lg_tile_kind { LG_TILE_FLAT = 0, LG_TILE_PYRAMID_SLOPE = 1, LG_TILE_PYRAMID_STAIRS = 2, LG_TILE_DISCRETE_OBSTACLES = 3 };
+enum lg_tile_kind { LG_TILE_FLAT = 0, LG_TILE_PYRAMID_SLOPE = 1, LG_TILE_PYRAMID_STAIRS = 2, LG_TILE_DISCRETE_OBSTACLES = 3,
+                    LG_TILE_STEPPING_STONES = 4,   /* rect_min = stone size, rect_max = stone distance (pixels), max_height, clip_lo = depth (units), platform */
+                    LG_TILE_GAP = 5,               /* terrain.py:125-136 gap_terrain: rect_min = gap width, platform (pixels) */
+                    LG_TILE_PIT = 6 };             /* terrain.py:139-148 pit_terrain: max_height = depth (units), platform = HALF the pit's width (pixels) */
 typedef struct lg_tile_spec {
   int32_t kind;               /* enum lg_tile_kind */
   int32_t max_height;         /* PYRAMID_SLOPE: int(slope * hs / vs * width / 2) (may be negative); OBSTACLES: int(max_height / vs) */

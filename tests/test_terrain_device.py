@@ -75,6 +75,47 @@ def test_device_tiles_random_kinds_have_the_host_generators_statistics():
     assert abs(dev.env_origins[:, :, 2].mean() - host.env_origins[:, :, 2].mean()) < 0.1
 
 
+def test_device_gap_and_pit_tiles_equal_the_host_generators():
+    """Seven-entry terrain_proportions reach the gap and pit branches of make_terrain (`terrain.py:148-153`): deterministic, integer-identical."""
+    from extended_legged_gym_amd.utils.terrain import Terrain
+    props = [0.2, 0.0, 0.0, 0.2, 0.0, 0.0, 0.3]                # slopes | stairs up | gaps | the rest: pits
+    kw = dict(mesh_type="heightfield", terrain_proportions=props, num_rows=5, num_cols=10)
+    np.random.seed(4)
+    host = Terrain(_cfg(**kw), 16)
+    np.random.seed(4)
+    dev = Terrain(_cfg(device_generation="all", **kw), 16, device="cuda:0")
+    assert (host.height_field_raw == -1000).any() and len(np.unique(host.height_field_raw)) > 8       # there are moats and pits of several depths
+    assert np.array_equal(dev.height_field_raw, host.height_field_raw)
+    np.testing.assert_allclose(dev.env_origins, host.env_origins, rtol=0, atol=1e-6)
+
+
+def test_device_stepping_stones_have_the_host_generators_structure():
+    from extended_legged_gym_amd.utils.terrain import Terrain
+    props = [0.0, 0.0, 0.0, 0.0, 0.0, 1.0]                     # stepping stones only
+    kw = dict(mesh_type="heightfield", terrain_proportions=props, num_rows=5, num_cols=4)
+    np.random.seed(6)
+    host = Terrain(_cfg(**kw), 16)
+    np.random.seed(6)
+    dev = Terrain(_cfg(device_generation="all", **kw), 16, device="cuda:0")
+    b, L = host.border, host.length_per_env_pixels
+    for i in range(5):
+        th = host.height_field_raw[b + i * L:b + (i + 1) * L, b:b + L].astype(np.int64)
+        starts = set()
+        for j in range(4):
+            td = dev.height_field_raw[b + i * L:b + (i + 1) * L, b + j * L:b + (j + 1) * L].astype(np.int64)
+            assert set(np.unique(td)) == set(np.unique(th)) <= {-2000, -1, 0}            # depth | stones (max_height 0: arange(-1, 0)) | platform
+            c = L // 2
+            assert not td[c - 20:c + 20, c - 20:c + 20].any() and (td[c - 20:c + 20, c - 20:c + 20] == th[c - 20:c + 20, c - 20:c + 20]).all()
+            # the strips along axis 1: the same columns are all-gap in both, stone columns have the same stone / gap pitch
+            gap_cols_h, gap_cols_d = (th[:8] == -2000).all(axis=0), (td[:8] == -2000).all(axis=0)
+            assert np.array_equal(gap_cols_h, gap_cols_d)
+            assert abs((td == -1).mean() - (th == -1).mean()) < 0.05
+            # per-strip offsets are random: the first stone column's pattern differs between tiles
+            starts.add(tuple(td[:, 0] == -1))
+        assert len(starts) > 1 or i == 0
+    np.testing.assert_allclose(dev.env_origins, host.env_origins, rtol=0, atol=1e-6)
+
+
 def test_env_runs_on_a_device_generated_terrain():
     import torch
     from tests.test_env_api import make
