@@ -82,7 +82,7 @@ def test_config4_depth_camera_4096_envs_on_the_1p6m_triangle_mesh():
     resets = _run(env, 40, 12)
     d = env.get_depth_images()
     assert tuple(d.shape) == (4096, cfg.depth.buffer_len, cfg.depth.resized[1], cfg.depth.resized[0])
-    assert torch.isfinite(d).all() and float(d.min()) >= -0.6 and float(d.max()) <= 0.6      # [-0.5, 0.5] + the bicubic resize's overshoot
+    assert torch.isfinite(d).all() and float(d.min()) >= -0.95 and float(d.max()) <= 0.95    # [-0.5, 0.5] + the bicubic resize's overshoot (Keys a = -0.75: at most 0.445 of the range in 2-D)
     assert float(d.std()) > 0.01 and float(d[:, -1].std(dim=(1, 2)).min()) >= 0.0
     assert float((d[:, -1].flatten(1).std(dim=1) > 0).float().mean()) > 0.9                       # nearly every camera sees structure
     assert torch.isfinite(env.root_states).all() and resets >= 0
