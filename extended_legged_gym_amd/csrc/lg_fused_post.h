@@ -509,6 +509,14 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   const int wv = tid >> 6, ln = tid & 63;
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
   const float* MB = HB + FH_MISC;
+  // The observation rows' per-lane table and the context members of that phase are requested HERE: behind the row stores below their loads
+  // would queue up behind ~20 stores (vmcnt counts both, in order), and a scalar load between the LDS reads of the entry loop makes every
+  // `s_waitcnt lgkmcnt(0)` for it wait for the LDS reads too, i.e. the four envs of the wave stop overlapping.
+  const int O = HI(HC_NUM_OBS), G4 = (O + 3) >> 2;
+  float4 tb0[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tb0[i] = C->obs_tab[4 * ln + i];
+  const float LG_G* const x_extra = C->extra_obs; const float LG_G* const x_inj = C->rand_inject; float LG_G* const x_obs = C->obs;
   // Row stores, 4 envs per wave.  One store instruction covers a row of ALL FOUR envs of the wave (lane = (env q, entry i): rows are
   // 1-24 entries long), small rows share an instruction (the destination is chosen by selects): 12 stores per wave where a store per
   // (env, row) was 60, each with a handful of active lanes.  All LDS reads first (one round trip), then the stores.
@@ -552,6 +560,17 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
     { ROWI(13) if (k_root) C->root[EQ(q) * 13 + i] = v_root; }
     { ROWI(12) if (k_d) { const size_t e = EQ(q); C->dof[e * 24 + i] = v_d0; C->dof[e * 24 + 12 + i] = v_d1; C->last_actions[e * 12 + i] = v_act; C->last_dof_vel[e * 12 + i] = v_ldv; } }
     { ROWI(6) if (k_lrv) C->last_root_vel[EQ(q) * 6 + i] = v_lrv; }
+    {   // net contact forces (B x 3 floats per env, the global layout): dense rows from LDS; from the main wave's registers these were 12-15
+        // stores of one dword per lane at a 36-48 byte stride, ~2.5 k cycles of that wave's issue alone
+      const int B3 = C->B * 3;
+      float LG_G* const cf = C->cforce;
+#pragma unroll
+      for (int it = 0; it < (4 * NBODY_MAX * 3 + 63) / 64; ++it) {
+        const int idx = ln + 64 * it;
+        const int q = (idx >= B3) + (idx >= 2 * B3) + (idx >= 3 * B3), i = idx - q * B3;
+        if (idx < 4 * B3 && 4 * wv + q < nenv) cf[EQ(q) * B3 + i] = SR[(4 * wv + q) * FS_STRIDE + FS_CF + i];
+      }
+    }
     if (k_a) *p_a = v_a;
     if (k_b) *p_b = v_b;
     { const int q = ln & 3, k0 = ln >> 2;
@@ -589,7 +608,6 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   // depend on the env (noise scales, source offsets, scales) is formed once per lane in front of the env loop.  The entries go
   // through an LDS row so that the global stores are dense (lane = entry): four 16-byte-strided dword stores per env were the
   // most expensive part of this phase (the memory pipeline handles 4 lanes per 64-byte segment).
-  const int O = HI(HC_NUM_OBS), G4 = (O + 3) >> 2;
   const bool inject = HI(HC_INJECT) != 0, add_noise = HI(HC_ADD_NOISE) != 0, predrawn = fused_noise_predrawn(hot);
   const float clip = HF(HC_CLIP_OBS);
   float* OB = const_cast<float*>(HB) + FH_OBS + 4 * wv * FO_STRIDE;  // this wave's staging rows, one per env: with ONE row the four envs of the wave
@@ -598,8 +616,33 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
     const int gq = g0 + ln;
     float4 tb[4];                                  // this lane's four entries of the host-packed table (pack_obs_table)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tb[i] = C->obs_tab[4 * gq + i];
+    for (int i = 0; i < 4; ++i) { if (g0 == 0) tb[i] = tb0[i]; else tb[i] = C->obs_tab[4 * gq + i]; }
     STAMP(49);
+    if (!inject && !x_extra && (predrawn || !add_noise)) {
+      // the usual case as straight-line code (no injected uniforms, no extra observations, noise parked by the helper waves): nothing between the
+      // LDS reads of the four envs but arithmetic, rows past the last env of a ragged workgroup recomputed from the last one (their staging row is private)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int el = min(4 * wv + q, max(nenv - 1, 0));
+        const float* S = SR + el * FS_STRIDE; const float* H = HB + FH_HEIGHTS + el * MAX_P;
+        const float rootz = MB[el * FM_STRIDE + FM_ROOTZ] - 0.5f;
+        float4 t = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+        if (add_noise) t = *reinterpret_cast<const float4*>(HB + FH_NOISE + el * FO_STRIDE + 4 * min(gq, FO_STRIDE / 4 - 1));
+        const float u[4] = {t.x, t.y, t.z, t.w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int code = __float_as_int(tb[i].x), off = code & 0xffff, kind = code >> 16;
+          const float val = (kind == 1 ? H : S)[kind <= 1 ? off : 0];
+          const float op = (val - tb[i].z) * tb[i].y;
+          const float oh = fminf(fmaxf(rootz - val, -1.f), 1.f) * tb[i].y;
+          float v = kind == 0 ? op : (kind == 1 ? oh : 0.f);
+          if (add_noise) v += (2.f * u[i] - 1.f) * tb[i].w;
+          o[i] = fminf(fmaxf(v, -clip), clip);
+        }
+        *reinterpret_cast<float4*>(OB + q * FO_STRIDE + 4 * ln) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    } else
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                 // (unrolled: the four envs' LDS reads interleave)
       const int el = 4 * wv + q;
@@ -617,11 +660,11 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
       }
       if (add_noise && inject) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (4 * gq + i < O) u[i] = C->rand_inject[(size_t)e * (LG_RS_NOISE + O) + LG_RS_NOISE + 4 * gq + i];
+        for (int i = 0; i < 4; ++i) if (4 * gq + i < O) u[i] = x_inj[(size_t)e * (LG_RS_NOISE + O) + LG_RS_NOISE + 4 * gq + i];
       }
-      if (C->extra_obs) {
+      if (x_extra) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (kind[i] == 2) ex[i] = C->extra_obs[(size_t)e * HI(HC_NUM_EXTRA) + (__float_as_int(tb[i].x) & 0xffff)];
+        for (int i = 0; i < 4; ++i) if (kind[i] == 2) ex[i] = x_extra[(size_t)e * HI(HC_NUM_EXTRA) + (__float_as_int(tb[i].x) & 0xffff)];
       }
       if (add_noise && !inject) {
         if (predrawn) {                            // (O <= FO_STRIDE: one pass, g0 == 0) drawn by the helper waves in front of (F)
@@ -663,7 +706,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
       for (int j = 0; j < 4; ++j) {
         const int idx = 4 * g0 + ln + 64 * j;
         if (idx < O) {
-          C->obs[(size_t)e * O + idx] = ov[q][j];
+          x_obs[(size_t)e * O + idx] = ov[q][j];
           if (obs_out) obs_out[(size_t)e * O + idx] = ov[q][j];     // RolloutStorage.observations[t + 1]
         }
       }

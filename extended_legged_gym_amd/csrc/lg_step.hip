@@ -980,16 +980,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (TMESH && helpers) mesh_cache_io<false>(Ct, cqc, e, l, lane, 0);
 #pragma unroll
       for (int j = 0; j < 3; ++j) if (!split) Ct->torques[(size_t)e * NDOF + 3 * l + j] = tau[j];
-      const int per_leg = Ct->per_leg, B = Ct->B;
-      float* cf = Ct->cforce + (size_t)e * B * 3;
-      if (l == 0) { cf[0] = fbody[0].x; cf[1] = fbody[0].y; cf[2] = fbody[0].z; }
-      float* cl = cf + (size_t)(1 + per_leg * l) * 3;
-      V3 last = fbody[3];
-      if (per_leg == 3) last = last + fbody[4];
-      cl[0] = fbody[1].x; cl[1] = fbody[1].y; cl[2] = fbody[1].z;
-      cl[3] = fbody[2].x; cl[4] = fbody[2].y; cl[5] = fbody[2].z;
-      cl[6] = last.x; cl[7] = last.y; cl[8] = last.z;
-      if (per_leg == 4) { cl[9] = fbody[4].x; cl[10] = fbody[4].y; cl[11] = fbody[4].z; }
+      // (the net contact forces go out with the env rows: fused_writeback_obs, from the LDS rows fused_main_part1 wrote)
     }
     STAMP(12);
     const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out, fids, ro);
