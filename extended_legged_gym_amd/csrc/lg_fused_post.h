@@ -36,7 +36,9 @@ enum { FM_RK = 0, FM_PART = LG_MAX_REWARD_TERMS, FM_ROOTZ = FM_PART + PART_STRID
        FM_STRIDE = FM_RAW + 2 * LG_REW_COUNT + 1 };
 enum { FO_STRIDE = 256, FH_HEIGHTS = 0, FH_MISC = EPB * MAX_P, FH_OBS = FH_MISC + EPB * FM_STRIDE + 3 - (FH_MISC + EPB * FM_STRIDE + 3) % 4 /* 16-B aligned */ };
 enum { FH_NOISE = FH_OBS + EPB * FO_STRIDE /* observation-noise uniforms, one FO_STRIDE row per env, drawn by the helper waves (fused_noise_*) */ };
-static_assert(FH_NOISE + EPB * FO_STRIDE <= LG_MAX_CP * CF_FIELDS * 64, "heights + per-env results + observation staging and noise rows must fit the memory of the contact-slot table");
+enum { FH_TAB = FH_NOISE + EPB * FO_STRIDE /* the per-entry table of the observation rows (pack_obs_table), FO_STRIDE x 16 bytes, staged by the helper waves */ };
+static_assert(FH_TAB % 4 == 0, "16-byte aligned table rows");
+static_assert(FH_TAB + 4 * FO_STRIDE <= LG_MAX_CP * CF_FIELDS * 64, "heights + per-env results + observation staging and noise rows must fit the memory of the contact-slot table");
 static_assert(LG_REW_COUNT <= 32, "reward-term masks (rew_term_mask, 1u << id) are 32 bits wide");
 
 // ---- helper waves, while the main wave runs the last sweeps: history rows, uniforms, pre-step integers -> LDS
@@ -135,6 +137,14 @@ LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid /* 0..19
 #pragma unroll
     for (int i = 0; i < 4; ++i) nz[it][i] = u01(o4[i]);
   }
+}
+// ... and the per-entry table of the observation rows: behind the row stores of the write-back a global load of it waits for every store issued
+// before it (vmcnt counts loads and stores together), ~1.5 k cycles on the tail of the launch
+LG_DEV void fused_stage_obs_table(const DevCtx* __restrict__ C, const float* hot, float* HB, int htid) {
+  const int O = HI(HC_NUM_OBS);
+  if (O > FO_STRIDE) return;
+  float4* T = reinterpret_cast<float4*>(HB + FH_TAB);
+  for (int i = htid; i < FO_STRIDE; i += 192) T[i] = C->obs_tab[i];     // (entries past O: kind 3, as the lanes past the last group expect)
 }
 LG_DEV void fused_noise_park(const float* hot, float* HB, int blk, int n, int htid, const float nz[NZ_IT][4]) {
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
@@ -371,6 +381,10 @@ LG_DEV void fused_reward_all(const DevCtx* __restrict__ C, const float* hot, uns
 // ro: the rollout variant (see fused_prefetch); krow: this env's row of the launch; rew_out / rew_stride: lg_rollout_batch's reward column.
 LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int e, float* S, const float* U, const float* pre, float* M, const float* H,
                              const float feat[F_COUNT], bool fault, int64_t step, const PostSink& K, bool ro, int krow, float* rew_out, int rew_stride) {
+#ifdef LG_STAMPS
+  unsigned long long* stamps = (blockIdx.x == 0 && threadIdx.x == 0) ? C->stamps : nullptr;    // (diagnostic: the serial part's own phases, ids 58-63)
+#endif
+  STAMP_DECL
   const float dt = HF(HC_DT);
   const int P = HI(HC_P);
   const unsigned term_mask = (unsigned)HI(HC_TERM_MASK);
@@ -408,6 +422,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
   R.rootz = root[2];
   const int64_t eplen = *reinterpret_cast<const int64_t*>(pre) + (ro ? 0 : 1);        // LR:122 (not in rollout steps)
   bool root_dirty = false;
+  STAMP(58);
   // ---- _post_physics_step_callback (LR:386-403)
   if (!ro && (int)eplen % HI(HC_RESAMPLING_STEPS) == 0) resample_commands(C, cmd, U, LG_RS_CMD_CB);
   if (!ro && HI(HC_HEADING)) {
@@ -424,6 +439,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
     root[8] = rand_float(-HF(HC_MAX_PUSH), HF(HC_MAX_PUSH), U[LG_RS_PUSH + 1]);
     root_dirty = true;
   }
+  STAMP(59);
   // ---- check_termination (LR:155-160)
   term |= HI(HC_FLIP) && R.pg[2] > 0.f;
   term |= fault;                                   // physics fault / lost env flagged by this launch
@@ -440,6 +456,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
   // that order (RM:150-163), so earlier terms see the old values and later ones the new, as in the reference
   R.bh = 0.f;
   if ((term_mask >> LG_REW_BASE_HEIGHT) & 1u) for (int p = 0; p < P; ++p) R.bh += root[2] - H[p];
+  STAMP(60);
   float rew = 0.f;
   const int K_ = HI(HC_K), kfat = HI(HC_KFAT);
   float* RAW0 = M + FM_RAW; float* RAW1 = RAW0 + LG_REW_COUNT;
@@ -453,6 +470,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
     M[FM_RK + k] = r;
     rew += r;
   }
+  STAMP(61);
   if (HI(HC_ONLY_POS)) rew = fmaxf(rew, 0.f);
   if (kterm >= 0) {
     const float r = ((term || tout) && !tout ? 1.f : 0.f) * term_scale;
@@ -480,6 +498,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
     root_dirty = true;
     if (HI(HC_CURRICULUM)) level = (float)C->levels[e];
   }
+  STAMP(62);
   M[FM_ROOTZ] = root[2];
   M[FM_DID_RESET] = do_reset ? 1.f : 0.f;
   M[FM_ROOT_DIRTY] = root_dirty ? 1.f : 0.f;
@@ -499,6 +518,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
   M[FM_PART + K_] = do_reset ? 1.f : 0.f;
   M[FM_PART + K_ + 1] = level;
   M[FM_PART + K_ + 2] = do_reset ? (float)eplen : 0.f;
+  STAMP(63);
 }
 
 // ---- all four waves: write-back of the env rows + observation rows, 4 envs per wave; statistics + arrival by wave 0
@@ -513,9 +533,12 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   // would queue up behind ~20 stores (vmcnt counts both, in order), and a scalar load between the LDS reads of the entry loop makes every
   // `s_waitcnt lgkmcnt(0)` for it wait for the LDS reads too, i.e. the four envs of the wave stop overlapping.
   const int O = HI(HC_NUM_OBS), G4 = (O + 3) >> 2;
+  const bool tab_lds = O <= FO_STRIDE;                         // the table is in LDS (fused_stage_obs_table)
   float4 tb0[4];
+  if (!tab_lds) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) tb0[i] = C->obs_tab[4 * ln + i];
+    for (int i = 0; i < 4; ++i) tb0[i] = C->obs_tab[4 * ln + i];
+  }
   const float LG_G* const x_extra = C->extra_obs; const float LG_G* const x_inj = C->rand_inject; float LG_G* const x_obs = C->obs;
   // Row stores, 4 envs per wave.  One store instruction covers a row of ALL FOUR envs of the wave (lane = (env q, entry i): rows are
   // 1-24 entries long), small rows share an instruction (the destination is chosen by selects): 12 stores per wave where a store per
@@ -616,7 +639,11 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
     const int gq = g0 + ln;
     float4 tb[4];                                  // this lane's four entries of the host-packed table (pack_obs_table)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { if (g0 == 0) tb[i] = tb0[i]; else tb[i] = C->obs_tab[4 * gq + i]; }
+    for (int i = 0; i < 4; ++i) {
+      if (tab_lds) tb[i] = reinterpret_cast<const float4*>(HB + FH_TAB)[min(4 * gq + i, FO_STRIDE - 1)];
+      else if (g0 == 0) tb[i] = tb0[i];
+      else tb[i] = C->obs_tab[4 * gq + i];
+    }
     STAMP(49);
     if (!inject && !x_extra && (predrawn || !add_noise)) {
       // the usual case as straight-line code (no injected uniforms, no extra observations, noise parked by the helper waves): nothing between the

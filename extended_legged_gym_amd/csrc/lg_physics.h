@@ -225,7 +225,9 @@ LG_DEV void symv6(const float* Si, const float* x, float* y) {
 
 // terrain surface under (x, y): height and unit normal of the regular-grid triangulation (diagonal v(i,j)->v(i+1,j+1)).
 // Split in two so that callers can put other work between the four sample loads and their first use.
-struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t LG_G* __restrict__ H; MeshView M;
+struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t LG_G* __restrict__ H;
+                     const int16_t LG_G* __restrict__ Hmin;   /* per cell: min(H[i][j], H[i+1][j], H[i][j+1]) -- what the height scan takes (LR:929-936); built by lg_create */
+                     MeshView M;
                      const float* __restrict__ GV; /* non-null: grid mesh */ const float4* __restrict__ GV4; /* its vertices (rows x cols) x (x, y, z, 0), world frame */
                      const float* __restrict__ GM; int mcols; /* max vertex z per 2 x 2 block of vertices */ };
 struct TerrainCell { float u, v; int16_t h0, h1, h2, h3; };

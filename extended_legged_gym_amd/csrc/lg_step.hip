@@ -108,6 +108,7 @@ struct lg_ctx {
   void* obs_tab = nullptr;
   void* mesh_cache = nullptr;
   void* grid_verts = nullptr;   // device copy of lg_terrain.grid_vertices
+  void* hmin = nullptr;         // TerrainView::Hmin
   int grid_mesh = 1;           // LG_GRID_MESH=0: walk the BVH for grid meshes too (diagnostic / A-B)
   TensorInfo t[LG_T_COUNT];
   int device = 0;
@@ -469,6 +470,17 @@ LG_DEV void fetch_state(const float* rec, float root[13], float q[3], float qd[3
   qd[0] = e.x; qd[1] = e.y; qd[2] = e.z;
 }
 
+LG_DEV void store_lstm_rows(const DevCtx* __restrict__ C, size_t row, size_t N12, const float* h0, const float* c0, const float* h1, const float* c1) {
+  float4* p = (float4*)(C->sea_h + row * 8);
+  p[0] = make_float4(h0[0], h0[1], h0[2], h0[3]); p[1] = make_float4(h0[4], h0[5], h0[6], h0[7]);
+  p = (float4*)(C->sea_c + row * 8);
+  p[0] = make_float4(c0[0], c0[1], c0[2], c0[3]); p[1] = make_float4(c0[4], c0[5], c0[6], c0[7]);
+  p = (float4*)(C->sea_h + (N12 + row) * 8);
+  p[0] = make_float4(h1[0], h1[1], h1[2], h1[3]); p[1] = make_float4(h1[4], h1[5], h1[6], h1[7]);
+  p = (float4*)(C->sea_c + (N12 + row) * 8);
+  p[0] = make_float4(c1[0], c1[1], c1[2], c1[3]); p[1] = make_float4(c1[4], c1[5], c1[6], c1[7]);
+}
+
 // ============================================================================================ physics kernel
 // MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
 // MODE 2: lg_compute_torques only.
@@ -484,6 +496,7 @@ enum { NZ_IT = 6 };          // Philox calls per helper lane that cover the obse
 LG_DEV bool fused_noise_predrawn(const float* hot);
 LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid, int64_t step, float nz[NZ_IT][4], const int32_t* __restrict__ ids, bool ro);
 LG_DEV void fused_noise_park(const float* hot, float* HB, int blk, int n, int htid, const float nz[NZ_IT][4]);
+LG_DEV void fused_stage_obs_table(const DevCtx* __restrict__ C, const float* hot, float* HB, int htid);
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot, const LegModel& lm_, float* xs, float* UB, float* HB, int lane, int e, bool valid,
                                   const float* root, const float* q, const float* qd, const float* tau, const float* last_qd, const V3* fbody,
                                   const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K, bool ro, int krow);
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       const V3 pb = v3(r13[0], r13[1], r13[2]), vb = v3(r13[7], r13[8], r13[9]), wb = v3(r13[10], r13[11], r13[12]);
       LegKin k;
       leg_kinematics(lm_, Rb, pb, vb, wb, qq, qdd, k);
-      STAMP(41);
+      if (sub == 0) STAMP(53); else STAMP(41);
       // heightfield terrains: two slots per wave (the main wave takes slots 0, 1); this wave issues its height-sample
       // loads now and uses them after the actuator network
       // slot ranges [DS0, DS1) wave 1 (which also has the leg bias), [DS1, DS2) wave 2, [DS2, 8) wave 3; the main wave
@@ -692,7 +705,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       } else {
         contact_detect_begin<DS2, 8>(lm_, T, k, Rb, pb, pr3);
       }
-      STAMP(42);
+      if (sub == 0) STAMP(54); else STAMP(42);
       if (net) {
         const float x0 = (tgt - qq[j]) * g.actuator_in_scale[0], x1 = qdd[j] * g.actuator_in_scale[1];
         // an opaque zero keeps the ~60 weight addresses from being hoisted out of the substep loop as loop invariants
@@ -706,9 +719,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (!TMESH && wv == 1) { if (DS0 < DS1) contact_detect_finish<DS0, DS1P>(lm_, T, P, pb, pr1, cst, lane); }
       else if (!TMESH && wv == 2) contact_detect_finish<DS1, DS2>(lm_, T, P, pb, pr2, cst, lane);
       else if (!TMESH && wv == 3) contact_detect_finish<DS2, 8>(lm_, T, P, pb, pr3, cst, lane);
-      STAMP(43);
+      if (sub == 0) STAMP(55); else STAMP(43);
       lds_barrier();                                   // (A2) bias, contact detection, torques | mass-matrix factors
-      STAMP(44);
+      if (sub == 0) STAMP(56); else STAMP(44);
       // this wave's share of the contact set-up (every fourth active slot)
       {
         float Mi[6], Mbk[6][3], Y[3][6], Si[21];
@@ -724,12 +737,14 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           }
         }
       }
-      STAMP(45);
+      if (sub == 0) STAMP(57); else STAMP(45);
       lds_barrier();                                   // (A3) slot table complete
+      STAMP(22);                                       // (diagnostic)
       if (net && sub + 1 < nsub) {                     // while the main wave sweeps: recurrent half of the next substep's network
         if (LSTM_LDS) lstm_recurrent_part(wlds, h0, h1, lpre);
         else { int zero; asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); lstm_recurrent_part(wlstm + zero, h0, h1, lpre); }
       }
+      STAMP(23);                                       // (diagnostic)
       if (fuse && sub + 1 == nsub) {                   // ... in the last substep: what the post-physics tail needs from HBM
         if (net) *fused_act_slot(xs, lane, d) = a;     // (the mass-factor table is dead after (A3): the env rows live there)
         STAMP(46);                                     // (diagnostic: (A3) of the last substep)
@@ -747,6 +762,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     const DevCtx* const Ct = late_ctx(C);                // (everything behind the last substep reads the context through this: see late_ctx)
     STAMP(48);
     if (predraw) fused_noise_park(hot, cst, bid, n, (wv - 1) * 64 + lane, nz);
+    if (fuse) fused_stage_obs_table(Ct, hot, cst, (wv - 1) * 64 + lane);
     if (TMESH && valid) mesh_cache_io<false>(Ct, cqc, e, l, lane, 2 * wv);
     bool zero_state = false;
     if (!fuse) {
@@ -772,6 +788,12 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         }
       }
       fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro);
+      STAMP(35);                                       // (diagnostic)
+#if defined(LG_STAMPS) && defined(LG_SCAN_TWICE)
+      { const DevCtx* Cx = Ct; asm volatile("" : "+s"(Cx));     // (diagnostic: the same code a second time, now warm in the instruction cache)
+        fused_height_scan(Cx, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro); }
+      STAMP(27);
+#endif
       // the rigid-body rows (stores nobody in this launch reads) while the main wave runs the serial part: these waves wait ~6 k cycles for
       // it at (G2); behind the write-back, where they used to be, they were on the tail of the launch
       if (valid && g.inject_sim_state) {                         // parity tests: the injected rows stay; gait_foot_z from the injected foot row
@@ -783,27 +805,29 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       } else if (valid && g.gait_enabled && !ro) {
         Ct->gait_foot_z[(size_t)e * NLEG + l] = fused_foot_row(xs, lane)[2];
       }
+      // the LSTM state, action and torque rows while the main wave is still in the serial part (these waves wait for it at (G2)); what a reset
+      // changes -- a zero LSTM state, anymal.py:78-82 -- is stored over it behind (G2)
+      if (valid && net) {
+        store_lstm_rows(Ct, row, N12, h0, c0, h1, c1);
+        Ct->actions[(size_t)e * NDOF + d] = a;
+        if (!g.inject_sim_state) Ct->torques[(size_t)e * NDOF + d] = xtau[j][lane];
+      }
       STAMP(51);
       if (feet_early || fused_needs_heights_early(C)) lds_barrier();   // (G1) only when the serial part reads a helper's product
       lds_barrier();                                   // (G2) serial part + height scan done
       STAMP(52);
       zero_state = fused_did_reset(cst, lane / GRP);    // anymal.py:78-82: a reset env starts from the zero LSTM state
     }
-    if (valid && net) {
-      if (zero_state) {
+    if (valid && net && (!fuse || zero_state)) {         // (fused step: stored in front of (G2) already; a reset env's rows are overwritten with zeros here --
+      if (zero_state) {                                  //  same lane, same addresses: the stores of one wave stay in order)
 #pragma unroll
         for (int i = 0; i < 8; ++i) { h0[i] = 0.f; c0[i] = 0.f; h1[i] = 0.f; c1[i] = 0.f; }
       }
-      float4* p = (float4*)(Ct->sea_h + row * 8);
-      p[0] = make_float4(h0[0], h0[1], h0[2], h0[3]); p[1] = make_float4(h0[4], h0[5], h0[6], h0[7]);
-      p = (float4*)(Ct->sea_c + row * 8);
-      p[0] = make_float4(c0[0], c0[1], c0[2], c0[3]); p[1] = make_float4(c0[4], c0[5], c0[6], c0[7]);
-      p = (float4*)(Ct->sea_h + (N12 + row) * 8);
-      p[0] = make_float4(h1[0], h1[1], h1[2], h1[3]); p[1] = make_float4(h1[4], h1[5], h1[6], h1[7]);
-      p = (float4*)(Ct->sea_c + (N12 + row) * 8);
-      p[0] = make_float4(c1[0], c1[1], c1[2], c1[3]); p[1] = make_float4(c1[4], c1[5], c1[6], c1[7]);
+      store_lstm_rows(Ct, row, N12, h0, c0, h1, c1);
+    }
+    if (valid && net && !fuse) {
       Ct->actions[(size_t)e * NDOF + d] = a;
-      if (!(fuse && g.inject_sim_state)) Ct->torques[(size_t)e * NDOF + d] = xtau[j][lane];
+      Ct->torques[(size_t)e * NDOF + d] = xtau[j][lane];
     }
     if (fuse) {
       const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out, fids, ro);
@@ -867,8 +891,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   for (int sub = 0; sub < nsub; ++sub) {
     STAMP(15);
     if (helpers) {
-    publish_state(xst[lane], s.root, s.q, s.qd);
+      publish_state(xst[lane], s.root, s.q, s.qd);
+      STAMP(24);                                       // (diagnostic)
+      // Measured and dropped (round 4): the first substep without this rendezvous (the helper waves load the rows themselves).  The main wave
+      // waits 6.5 k cycles here in the first substep of a launch -- the helper waves' LSTM state loads and first recurrent half, all of it cold
+      // -- but without it it waits as long at (A2) instead (their first substep takes 17 k cycles against 12 k later on): +1 % on the step.
       lds_barrier();                                   // (A) root, q, qd of this substep visible to the helper waves
+      if (sub == 0) STAMP(26); else STAMP(25);         // (diagnostic: the first substep's rendezvous apart)
     }
     if (split) {
     } else if (MODE == 0) {
@@ -1075,7 +1104,10 @@ LG_DEV void resample_commands(const DevCtx* __restrict__ C, float* cmd, const fl
 // LR:900-938 + math_utils.quat_apply_yaw: the index arithmetic must round exactly like the reference's separate
 // fp32 torch kernels, so contraction into FMAs is disabled for this function.
 #pragma clang fp contract(off)
-struct HeightProbe { int16_t h1, h2, h3; };
+// The scan takes min(H[i][j], H[i+1][j], H[i][j+1]) (LR:929-936): the table TerrainView::Hmin holds that minimum per cell, so a probe is ONE
+// 2-byte gather.  As three gathers per probe the scan of a fused workgroup was 16 x 187 x 3 = 8 976 scattered 2-byte reads -- one L1 request
+// each: the texture path does not merge them -- i.e. ~9 k cycles of the CU's L1 for 6 k cycles of arithmetic.
+struct HeightProbe { int16_t h; };
 LG_DEV HeightProbe terrain_height_probe(const DevCtx* __restrict__ C, float qz, float qw, float px0, float py0, float bx, float by) {
   float tx = (0.f - qz * by) * 2.f, ty = (qz * bx - 0.f) * 2.f;
   float rx = (bx + qw * tx) + (0.f - qz * ty);
@@ -1084,15 +1116,10 @@ LG_DEV HeightProbe terrain_height_probe(const DevCtx* __restrict__ C, float qz, 
   float py = ((ry + py0) + C->ter.border) / C->ter.hscale;
   int ix = (int)px, iy = (int)py;                       // trunc toward zero (tensor.long())
   ix = max(0, min(ix, C->ter.rows - 2)); iy = max(0, min(iy, C->ter.cols - 2));
-  const int16_t* H = C->ter.H + (size_t)ix * C->ter.cols + iy;
-  const int dr = C->ter.rows > 1 ? C->ter.cols : 0, dc = C->ter.cols > 1 ? 1 : 0;    // plane: the 1 x 1 dummy grid
-  HeightProbe r; r.h1 = H[0]; r.h2 = H[dr]; r.h3 = H[dc];
+  HeightProbe r; r.h = C->ter.Hmin[(size_t)ix * C->ter.cols + iy];                   // (plane: the 1 x 1 dummy grid)
   return r;
 }
-LG_DEV float terrain_height_value(const DevCtx* __restrict__ C, const HeightProbe& r) {
-  int16_t h = r.h1 < r.h2 ? r.h1 : r.h2; h = h < r.h3 ? h : r.h3;
-  return (float)h * C->ter.vscale;
-}
+LG_DEV float terrain_height_value(const DevCtx* __restrict__ C, const HeightProbe& r) { return (float)r.h * C->ter.vscale; }
 LG_DEV float terrain_height_at(const DevCtx* __restrict__ C, float qz, float qw, float px0, float py0, float bx, float by) {
   return terrain_height_value(C, terrain_height_probe(C, qz, qw, px0, py0, bx, by));
 }
@@ -2040,6 +2067,7 @@ LG_DEV void fused_height_scan(const DevCtx* __restrict__, const float (*)[20], f
 LG_DEV bool fused_noise_predrawn(const float*) { return false; }
 LG_DEV void fused_noise_draw(const float*, int, int, int, int64_t, float (*)[4], const int32_t* __restrict__, bool) {}
 LG_DEV void fused_noise_park(const float*, float*, int, int, int, const float (*)[4]) {}
+LG_DEV void fused_stage_obs_table(const DevCtx* __restrict__, const float*, float*, int) {}
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__, const float*, const LegModel&, float*, float*, float*, int, int, bool, const float*, const float*,
                                   const float*, const float*, const float*, const V3*, const float*, bool, int64_t, unsigned long long*, const PostSink&, bool, int) {}
 LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__, const float*, const float*, const float*, int, int, int, int64_t, unsigned long long*, float*, const int32_t* __restrict__, bool) { return false; }
@@ -2217,6 +2245,7 @@ void lg_destroy(lg_ctx* c) {
   if (c->obs_tab) (void)hipFree(c->obs_tab);
   if (c->mesh_cache) (void)hipFree(c->mesh_cache);
   if (c->grid_verts) (void)hipFree(c->grid_verts);
+  if (c->hmin) (void)hipFree(c->hmin);
   if (c->own_arena && c->arena) (void)hipFree(c->arena);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   delete c;
@@ -2328,6 +2357,23 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   if (ter->mesh_type != LG_MESH_PLANE &&
       hipMemcpy(P(LG_T_HEIGHT_SAMPLES), ter->height_samples, (size_t)ter->rows * ter->cols * 2, hipMemcpyHostToDevice) != hipSuccess)
     return fail("copy height_samples failed");
+  {   // the height scan's table: per cell the minimum of the three samples LR:929-936 takes (the last row / column are never indexed: the
+      // scan clamps its cell to rows - 2, cols - 2); the plane's 1 x 1 dummy grid is its own minimum
+    const int R = ter->mesh_type != LG_MESH_PLANE ? ter->rows : 1, Cc = ter->mesh_type != LG_MESH_PLANE ? ter->cols : 1;
+    std::vector<int16_t> hm((size_t)R * Cc, 0);
+    if (ter->mesh_type != LG_MESH_PLANE)
+      for (int i = 0; i < R; ++i)
+        for (int j = 0; j < Cc; ++j) {
+          const int16_t* Hs = ter->height_samples;
+          int16_t v = Hs[(size_t)i * Cc + j];
+          if (i + 1 < R) v = std::min(v, Hs[(size_t)(i + 1) * Cc + j]);
+          if (j + 1 < Cc) v = std::min(v, Hs[(size_t)i * Cc + j + 1]);
+          hm[(size_t)i * Cc + j] = v;
+        }
+    if (hipMalloc(&c->hmin, hm.size() * 2) != hipSuccess || hipMemcpy(c->hmin, hm.data(), hm.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+      return fail("height-scan table upload failed");
+    h.ter.Hmin = (const int16_t LG_G*)c->hmin;
+  }
   if (ter->num_levels > 0 && ter->terrain_origins &&
       hipMemcpy(P(LG_T_TERRAIN_ORIGINS), ter->terrain_origins, (size_t)ter->num_levels * ter->num_types * 12, hipMemcpyHostToDevice) != hipSuccess)
     return fail("copy terrain_origins failed");
