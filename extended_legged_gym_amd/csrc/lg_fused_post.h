@@ -140,11 +140,20 @@ LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid /* 0..19
 }
 // ... and the per-entry table of the observation rows: behind the row stores of the write-back a global load of it waits for every store issued
 // before it (vmcnt counts loads and stores together), ~1.5 k cycles on the tail of the launch
-LG_DEV void fused_stage_obs_table(const DevCtx* __restrict__ C, const float* hot, float* HB, int htid) {
-  const int O = HI(HC_NUM_OBS);
-  if (O > FO_STRIDE) return;
+// What the helper waves need from HBM behind (F) that does not depend on the step: this lane's scan point and its two entries of the observation
+// table.  Requested in front of (F), where these waves wait for the main wave anyway; behind it each was a memory round trip on their path to (G2).
+LG_DEV void fused_prefetch_static(const DevCtx* __restrict__ C, const float* hot, int htid, FusedPre& F) {
+  const int P = C->cfg.measure_heights ? C->P : 0;
+  const int p = htid < P ? htid : 0;
+  F.bx = 0.f; F.by = 0.f;
+  if (P > 0) { F.bx = C->height_points[2 * p]; F.by = C->height_points[2 * p + 1]; }
+  F.tab[0] = C->obs_tab[htid]; F.tab[1] = C->obs_tab[min(htid + 192, FO_STRIDE - 1)];     // (the table holds >= 256 entries: pack_obs_table)
+}
+LG_DEV void fused_stage_obs_table(const float* hot, float* HB, int htid, const FusedPre& F) {
+  if (HI(HC_NUM_OBS) > FO_STRIDE) return;
   float4* T = reinterpret_cast<float4*>(HB + FH_TAB);
-  for (int i = htid; i < FO_STRIDE; i += 192) T[i] = C->obs_tab[i];     // (entries past O: kind 3, as the lanes past the last group expect)
+  T[htid] = F.tab[0];                                     // (entries past O: kind 3, as the lanes past the last group expect)
+  if (htid + 192 < FO_STRIDE) T[htid + 192] = F.tab[1];
 }
 LG_DEV void fused_noise_park(const float* hot, float* HB, int blk, int n, int htid, const float nz[NZ_IT][4]) {
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
@@ -159,7 +168,8 @@ LG_DEV void fused_noise_park(const float* hot, float* HB, int blk, int n, int ht
 static_assert(NZ_IT * 192 >= EPB * (FO_STRIDE / 4), "the helper lanes cover every (env, Philox group) of rows up to FO_STRIDE entries");
 
 // ---- helper waves, after the final state is published: the height scan of the workgroup's envs (LR:400-401), one point per lane
-LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid, const int32_t* __restrict__ ids, bool ro) {
+LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid, const int32_t* __restrict__ ids, bool ro,
+                              float bx, float by) {
   const int P = C->cfg.measure_heights ? C->P : 0;
   if (P <= 0) return;
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
@@ -171,7 +181,9 @@ LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[2
   const bool plane = C->ter.mesh_type == LG_MESH_PLANE;
   const int p = htid;
   const bool okp = p < P;
-  const float bx = C->height_points[2 * (okp ? p : 0)], by = C->height_points[2 * (okp ? p : 0) + 1];
+  // every context member of the store loop in a local: read inside it they are re-loaded after each global store (which might have changed
+  // *C, for all the compiler knows) -- two dependent scalar round trips per env, ~8 k of this function's 11 k cycles
+  float LG_G* const hts = C->heights; const int Pn = C->P; const float vs = C->ter.vscale;
   HeightProbe hp[EPB];
 #pragma unroll
   for (int el = 0; el < EPB; ++el) {
@@ -181,9 +193,9 @@ LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[2
 #pragma unroll
   for (int el = 0; el < EPB; ++el) {
     if (okp && el < nenv) {
-      const float hv = plane ? 0.f : terrain_height_value(C, hp[el]);
+      const float hv = plane ? 0.f : (float)hp[el].h * vs;
       HB[FH_HEIGHTS + el * MAX_P + p] = hv;
-      C->heights[(size_t)fused_env_of(ids, e0 + el) * C->P + p] = hv;
+      hts[(size_t)fused_env_of(ids, e0 + el) * Pn + p] = hv;
     }
   }
 }
@@ -379,8 +391,21 @@ LG_DEV void fused_reward_all(const DevCtx* __restrict__ C, const float* hot, uns
 }
 
 // ro: the rollout variant (see fused_prefetch); krow: this env's row of the launch; rew_out / rew_stride: lg_rollout_batch's reward column.
-LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int e, float* S, const float* U, const float* pre, float* M, const float* H,
+LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot_lds, int e, float* S, const float* U, const float* pre, float* M, const float* H,
                              const float feat[F_COUNT], bool fault, int64_t step, const PostSink& K, bool ro, int krow, float* rew_out, int rew_stride) {
+  // The scalar block of the tail's constants (HC_DT .. HC_NUM_EXTRA) in registers, fetched as ONE batch of 16-byte LDS reads: read where they are
+  // used -- ~100 ds_read_b32 at a uniform address, each with its own wait, on a wave with nothing to overlap them with -- they were most of this
+  // function's time (121 s_waitcnt in ~3 600 instructions).  HF / HI below index this copy with compile-time constants (unused words cost nothing);
+  // the per-term tables (HC_IDS, HC_SCALES: run-time index) stay in LDS.
+  float hv[(HC_IDS + 3) & ~3];
+  {
+    const float4* h4 = reinterpret_cast<const float4*>(hot_lds);
+#pragma unroll
+    for (int i = 0; i < (HC_IDS + 3) / 4; ++i) { const float4 t = h4[i]; hv[4 * i] = t.x; hv[4 * i + 1] = t.y; hv[4 * i + 2] = t.z; hv[4 * i + 3] = t.w; }
+  }
+  const float* const hot = hv;
+  // (the context members this function stores through, requested up front: see fused_writeback_obs)
+  uint8_t LG_G* const s_reset = C->reset_buf; uint8_t LG_G* const s_tout = C->time_out; int64_t LG_G* const s_eplen = C->ep_len; float LG_G* const s_rew = C->rew;
 #ifdef LG_STAMPS
   unsigned long long* stamps = (blockIdx.x == 0 && threadIdx.x == 0) ? C->stamps : nullptr;    // (diagnostic: the serial part's own phases, ids 58-63)
 #endif
@@ -447,10 +472,10 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
   if (ro) {                                        // rollout envs never terminate on their own: the flags keep their last values (robot_batch_rollout.py:806-809)
     const int fl = (int)pre[4];
     tout = (fl >> 8) != 0; term = ((fl & 0xff) != 0 || fault) && !tout;
-    if (fault) C->reset_buf[e] = 1;
+    if (fault) s_reset[e] = 1;
   } else {
-    C->time_out[e] = tout ? 1 : 0; C->reset_buf[e] = (term || tout) ? 1 : 0;
-    C->ep_len[e] = eplen;
+    s_tout[e] = tout ? 1 : 0; s_reset[e] = (term || tout) ? 1 : 0;
+    s_eplen[e] = eplen;
   }
   // ---- compute_reward (LR:215-232): terms in config order; _reward_feet_air_time rewrites the feet timers where it stands in
   // that order (RM:150-163), so earlier terms see the old values and later ones the new, as in the reference
@@ -464,9 +489,9 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
   if ((term_mask >> LG_REW_ASYNC_GAIT_SCHEDULER) & 1u) RAW0[LG_REW_ASYNC_GAIT_SCHEDULER] = RAW1[LG_REW_ASYNC_GAIT_SCHEDULER] = async_gait_value(C->cfg, S + FS_DOF);
 #pragma unroll 4
   for (int k = 0; k < K_; ++k) {                 // the reference's sum, in config order (LR:218-224)
-    const int id = HI(HC_IDS + k);
+    const int id = __float_as_int(hot_lds[HC_IDS + k]);
     const float raw = k < kfat ? RAW0[id] : RAW1[id];
-    const float r = id != LG_REW_TERMINATION ? raw * HF(HC_SCALES + k) : 0.f;
+    const float r = id != LG_REW_TERMINATION ? raw * hot_lds[HC_SCALES + k] : 0.f;
     M[FM_RK + k] = r;
     rew += r;
   }
@@ -476,7 +501,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot, int
     const float r = ((term || tout) && !tout ? 1.f : 0.f) * term_scale;
     rew += r; M[FM_RK + kterm] = r;
   }
-  C->rew[e] = rew;
+  s_rew[e] = rew;
   if (rew_out) rew_out[(size_t)krow * rew_stride] = rew;
   if (K.rewards) {                               // PPO.process_env_step (ppo.py:165, 179-183): three roundings
 #pragma clang fp contract(off)
@@ -529,6 +554,15 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   const int wv = tid >> 6, ln = tid & 63;
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
   const float* MB = HB + FH_MISC;
+  // Every context member this function uses, in locals, requested as ONE batch: read where they are used, each is re-loaded behind the stores
+  // in front of it (a store might have changed *C, for all the compiler knows -- the pointer comes through late_ctx) and is a scalar round trip
+  // of its own: ~30 of them, one after the other, on the tail of the launch.
+  float LG_G* const w_root = C->root; float LG_G* const w_dof = C->dof; float LG_G* const w_lact = C->last_actions; float LG_G* const w_ldv = C->last_dof_vel;
+  float LG_G* const w_lrv = C->last_root_vel; float LG_G* const w_cmd = C->commands; float LG_G* const w_air = C->feet_air; float LG_G* const w_ct = C->feet_ctime;
+  float LG_G* const w_gait = C->gait_idx; float LG_G* const w_blv = C->base_lin_vel; float LG_G* const w_bav = C->base_ang_vel; float LG_G* const w_pg = C->proj_grav;
+  float LG_G* const w_bla = C->base_lin_acc; float LG_G* const w_baa = C->base_ang_acc; float LG_G* const w_sums = C->ep_sums; float LG_G* const w_cf = C->cforce;
+  uint8_t LG_G* const w_lastc = C->last_contacts; long long LG_G* const w_acc = C->acc; float LG_G* const w_lvl = C->lvl_part; unsigned LG_G* const w_tickets = C->tickets;
+  const int w_N = C->N, w_B = C->B;
   // The observation rows' per-lane table and the context members of that phase are requested HERE: behind the row stores below their loads
   // would queue up behind ~20 stores (vmcnt counts both, in order), and a scalar load between the LDS reads of the entry loop makes every
   // `s_waitcnt lgkmcnt(0)` for it wait for the LDS reads too, i.e. the four envs of the wave stop overlapping.
@@ -560,7 +594,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
       const int off = i < 4 ? FS_CMD + i : i < 8 ? FS_AIR + i - 4 : i < 12 ? FS_CT + i - 8 : FS_GAIT;
       v_a = S[off]; k_a = ok;
       const size_t e = EQ(ok ? q : 0);
-      p_a = i < 4 ? C->commands + e * 4 + i : i < 8 ? C->feet_air + e * 4 + (i - 4) : i < 12 ? C->feet_ctime + e * 4 + (i - 8) : C->gait_idx + e;
+      p_a = i < 4 ? w_cmd + e * 4 + i : i < 8 ? w_air + e * 4 + (i - 4) : i < 12 ? w_ct + e * 4 + (i - 8) : w_gait + e;
     }
     {   // base_lin_vel | base_ang_vel | projected_gravity | base_lin_acc | base_ang_acc: 15 lanes per env
       ROWQ(15)
@@ -568,7 +602,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
       const int off = (r == 0 ? FS_BLV : r == 1 ? FS_BAV : r == 2 ? FS_PG : r == 3 ? FS_BLA : FS_BAA) + c;
       v_b = S[off]; k_b = ok;
       const size_t e = EQ(ok ? q : 0);
-      float LG_G* base = r == 0 ? C->base_lin_vel : r == 1 ? C->base_ang_vel : r == 2 ? C->proj_grav : r == 3 ? C->base_lin_acc : C->base_ang_acc;
+      float LG_G* base = r == 0 ? w_blv : r == 1 ? w_bav : r == 2 ? w_pg : r == 3 ? w_bla : w_baa;
       p_b = base + e * 3 + c;
     }
     {   // episode sums, (K, N) rows: lane = (term, env) with the env fastest
@@ -580,13 +614,13 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
     }
     { const int q = ln >> 2, f = ln & 3; k_lc = q < 4 && 4 * wv + q < nenv; v_lc = MB[(4 * wv + (k_lc ? q : 0)) * FM_STRIDE + FM_LASTC + f]; }
     static_assert(LG_MAX_REWARD_TERMS <= 32, "two passes of 16 terms cover the episode sums");
-    { ROWI(13) if (k_root) C->root[EQ(q) * 13 + i] = v_root; }
-    { ROWI(12) if (k_d) { const size_t e = EQ(q); C->dof[e * 24 + i] = v_d0; C->dof[e * 24 + 12 + i] = v_d1; C->last_actions[e * 12 + i] = v_act; C->last_dof_vel[e * 12 + i] = v_ldv; } }
-    { ROWI(6) if (k_lrv) C->last_root_vel[EQ(q) * 6 + i] = v_lrv; }
+    { ROWI(13) if (k_root) w_root[EQ(q) * 13 + i] = v_root; }
+    { ROWI(12) if (k_d) { const size_t e = EQ(q); w_dof[e * 24 + i] = v_d0; w_dof[e * 24 + 12 + i] = v_d1; w_lact[e * 12 + i] = v_act; w_ldv[e * 12 + i] = v_ldv; } }
+    { ROWI(6) if (k_lrv) w_lrv[EQ(q) * 6 + i] = v_lrv; }
     {   // net contact forces (B x 3 floats per env, the global layout): dense rows from LDS; from the main wave's registers these were 12-15
         // stores of one dword per lane at a 36-48 byte stride, ~2.5 k cycles of that wave's issue alone
-      const int B3 = C->B * 3;
-      float LG_G* const cf = C->cforce;
+      const int B3 = w_B * 3;
+      float LG_G* const cf = w_cf;
 #pragma unroll
       for (int it = 0; it < (4 * NBODY_MAX * 3 + 63) / 64; ++it) {
         const int idx = ln + 64 * it;
@@ -597,9 +631,9 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
     if (k_a) *p_a = v_a;
     if (k_b) *p_b = v_b;
     { const int q = ln & 3, k0 = ln >> 2;
-      if (k_s0) C->ep_sums[(size_t)k0 * C->N + EQ(q)] = v_s0;
-      if (k_s1) C->ep_sums[(size_t)(k0 + 16) * C->N + EQ(q)] = v_s1; }
-    if (k_lc) C->last_contacts[EQ(ln >> 2) * 4 + (ln & 3)] = v_lc != 0.f ? 1 : 0;
+      if (k_s0) w_sums[(size_t)k0 * w_N + EQ(q)] = v_s0;
+      if (k_s1) w_sums[(size_t)(k0 + 16) * w_N + EQ(q)] = v_s1; }
+    if (k_lc) w_lastc[EQ(ln >> 2) * 4 + (ln & 3)] = v_lc != 0.f ? 1 : 0;
 #undef ROWQ
 #undef ROWI
 #undef EQ
@@ -612,18 +646,18 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   if (wv == FUSED_STATS_WAVE && ln < KP && any_reset) {
     float sacc = 0.f;
     for (int el = 0; el < nenv; ++el) sacc += MB[el * FM_STRIDE + FM_PART + ln];
-    __hip_atomic_fetch_add(C->acc + ln, __double2ll_rn((double)sacc * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(w_acc + ln, __double2ll_rn((double)sacc * ACC_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (wv == FUSED_STATS_WAVE && ln == KP + 1) {
     float sacc = 0.f;
     for (int el = 0; el < nenv; ++el) sacc += MB[el * FM_STRIDE + FM_PART + HI(HC_K) + 1];
-    st_dev(C->lvl_part + blk, sacc);
+    st_dev(w_lvl + blk, sacc);
   }
   unsigned arrival = 0;
   const unsigned shard = (unsigned)blk & 7u, nsh = min(8u, gridDim.x);
   const unsigned want = (gridDim.x + 7u - shard) >> 3;
   if (wv == FUSED_STATS_WAVE) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the statistics stores / atomics of this wave have completed
-  if (tid == 64 * FUSED_STATS_WAVE) arrival = __hip_atomic_fetch_add(C->tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 64 * FUSED_STATS_WAVE) arrival = __hip_atomic_fetch_add(w_tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   STAMP(33);
 
   // observation rows (LR:234-252, :107-108): proprio | heights | extra, + uniform noise, clipped.  A lane forms the 4 entries of
@@ -743,9 +777,9 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   STAMP(34);
   bool last = false;
   if (tid == 64 * FUSED_STATS_WAVE && arrival == want - 1u) {
-    if (__hip_atomic_fetch_add(C->tickets + 32 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1u) {
+    if (__hip_atomic_fetch_add(w_tickets + 32 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1u) {
       last = true;
-      for (int i = 0; i < 9; ++i) __hip_atomic_store(C->tickets + 32 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(w_tickets + 32 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   return last;

@@ -471,13 +471,14 @@ LG_DEV void fetch_state(const float* rec, float root[13], float q[3], float qd[3
 }
 
 LG_DEV void store_lstm_rows(const DevCtx* __restrict__ C, size_t row, size_t N12, const float* h0, const float* c0, const float* h1, const float* c1) {
-  float4* p = (float4*)(C->sea_h + row * 8);
+  float LG_G* const sh = C->sea_h; float LG_G* const sc = C->sea_c;      // (both pointers in front of the first store: see fused_writeback_obs)
+  float4* p = (float4*)(sh + row * 8);
   p[0] = make_float4(h0[0], h0[1], h0[2], h0[3]); p[1] = make_float4(h0[4], h0[5], h0[6], h0[7]);
-  p = (float4*)(C->sea_c + row * 8);
+  p = (float4*)(sc + row * 8);
   p[0] = make_float4(c0[0], c0[1], c0[2], c0[3]); p[1] = make_float4(c0[4], c0[5], c0[6], c0[7]);
-  p = (float4*)(C->sea_h + (N12 + row) * 8);
+  p = (float4*)(sh + (N12 + row) * 8);
   p[0] = make_float4(h1[0], h1[1], h1[2], h1[3]); p[1] = make_float4(h1[4], h1[5], h1[6], h1[7]);
-  p = (float4*)(C->sea_c + (N12 + row) * 8);
+  p = (float4*)(sc + (N12 + row) * 8);
   p[0] = make_float4(c1[0], c1[1], c1[2], c1[3]); p[1] = make_float4(c1[4], c1[5], c1[6], c1[7]);
 }
 
@@ -491,12 +492,14 @@ struct PostSink { float* obs_out; const float* values; float* rewards; float* do
 // the post-physics step as the tail of this kernel (lg_fused_post.h, defined below the post-physics helpers)
 struct FusedMainIn;
 LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid, int64_t step, const float* values, const int32_t* __restrict__ ids, bool ro);
-LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid, const int32_t* __restrict__ ids, bool ro);
+struct FusedPre { float bx, by; float4 tab[2]; };      // what the helper waves fetch in front of (F) for their work behind it (lg_fused_post.h)
+LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid, const int32_t* __restrict__ ids, bool ro, float bx, float by);
+LG_DEV void fused_prefetch_static(const DevCtx* __restrict__ C, const float* hot, int htid, FusedPre& F);
 enum { NZ_IT = 6 };          // Philox calls per helper lane that cover the observation noise of the workgroup's 16 envs (rows of up to 256 entries)
 LG_DEV bool fused_noise_predrawn(const float* hot);
 LG_DEV void fused_noise_draw(const float* hot, int blk, int n, int htid, int64_t step, float nz[NZ_IT][4], const int32_t* __restrict__ ids, bool ro);
 LG_DEV void fused_noise_park(const float* hot, float* HB, int blk, int n, int htid, const float nz[NZ_IT][4]);
-LG_DEV void fused_stage_obs_table(const DevCtx* __restrict__ C, const float* hot, float* HB, int htid);
+LG_DEV void fused_stage_obs_table(const float* hot, float* HB, int htid, const FusedPre& F);
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot, const LegModel& lm_, float* xs, float* UB, float* HB, int lane, int e, bool valid,
                                   const float* root, const float* q, const float* qd, const float* tau, const float* last_qd, const V3* fbody,
                                   const float* act_or_null, bool fault, int64_t step, unsigned long long* stamps, const PostSink& K, bool ro, int krow);
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ __attribute__((aligned(16))) float xs[XS_STRIDE * 64];              // main wave's mass-matrix factors for the helpers' share of the contact set-up
   __shared__ float cqc[TMESH ? LG_MAX_CP * 4 * 64 : 1];   // mesh terrains: last closest-point query of every collision sphere
   __shared__ int s_last_f;                                 // fused step: this workgroup is the last of the launch to arrive
-  __shared__ float hot[HC_COUNT];                          // fused step: the scalars of the post-physics tail (HC_*)
+  __shared__ __attribute__((aligned(16))) float hot[(HC_COUNT + 3) & ~3];                          // fused step: the scalars of the post-physics tail (HC_*)
   // A/B build 7 only: an LDS copy of the 905 gate-interleaved LSTM weights for the actuator waves (one ds_read_b128 at a wave-uniform
   // address = four weights).  Measured against the scalar loads (s_load_dwordx16 -> SGPR pairs feeding the packed FMAs) in one session:
   // 0.0897 ms per step from LDS, 0.0818 ms through SGPRs -- the scalar unit fetches the weights beside the vector ALU, while LDS
@@ -758,11 +761,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     float nz[NZ_IT][4];
     const bool predraw = fuse && fused_noise_predrawn(hot);
     if (predraw) fused_noise_draw(hot, bid, n, (wv - 1) * 64 + lane, fstep, nz, fids, ro);   // (these waves would wait for the main wave's last sweeps now)
+    FusedPre fpre;
+    if (fuse) fused_prefetch_static(late_ctx(C), hot, (wv - 1) * 64 + lane, fpre);
     lds_barrier();                                     // (F) main wave has published the final state of the step
     const DevCtx* const Ct = late_ctx(C);                // (everything behind the last substep reads the context through this: see late_ctx)
     STAMP(48);
     if (predraw) fused_noise_park(hot, cst, bid, n, (wv - 1) * 64 + lane, nz);
-    if (fuse) fused_stage_obs_table(Ct, hot, cst, (wv - 1) * 64 + lane);
+    if (fuse) fused_stage_obs_table(hot, cst, (wv - 1) * 64 + lane, fpre);
     if (TMESH && valid) mesh_cache_io<false>(Ct, cqc, e, l, lane, 2 * wv);
     bool zero_state = false;
     if (!fuse) {
@@ -787,11 +792,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane));   // (gait_foot_z is stored late: the serial part still reads the old one)
         }
       }
-      fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro);
+      fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro, fpre.bx, fpre.by);
       STAMP(35);                                       // (diagnostic)
 #if defined(LG_STAMPS) && defined(LG_SCAN_TWICE)
       { const DevCtx* Cx = Ct; asm volatile("" : "+s"(Cx));     // (diagnostic: the same code a second time, now warm in the instruction cache)
-        fused_height_scan(Cx, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro); }
+        fused_height_scan(Cx, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro, fpre.bx, fpre.by); }
       STAMP(27);
 #endif
       // the rigid-body rows (stores nobody in this launch reads) while the main wave runs the serial part: these waves wait ~6 k cycles for
@@ -808,9 +813,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       // the LSTM state, action and torque rows while the main wave is still in the serial part (these waves wait for it at (G2)); what a reset
       // changes -- a zero LSTM state, anymal.py:78-82 -- is stored over it behind (G2)
       if (valid && net) {
+        float LG_G* const p_act = Ct->actions; float LG_G* const p_tq = Ct->torques;
         store_lstm_rows(Ct, row, N12, h0, c0, h1, c1);
-        Ct->actions[(size_t)e * NDOF + d] = a;
-        if (!g.inject_sim_state) Ct->torques[(size_t)e * NDOF + d] = xtau[j][lane];
+        p_act[(size_t)e * NDOF + d] = a;
+        if (!g.inject_sim_state) p_tq[(size_t)e * NDOF + d] = xtau[j][lane];
       }
       STAMP(51);
       if (feet_early || fused_needs_heights_early(C)) lds_barrier();   // (G1) only when the serial part reads a helper's product
@@ -1112,8 +1118,15 @@ LG_DEV HeightProbe terrain_height_probe(const DevCtx* __restrict__ C, float qz, 
   float tx = (0.f - qz * by) * 2.f, ty = (qz * bx - 0.f) * 2.f;
   float rx = (bx + qw * tx) + (0.f - qz * ty);
   float ry = (by + qw * ty) + (qz * tx - 0.f);
-  float px = ((rx + px0) + C->ter.border) / C->ter.hscale;
-  float py = ((ry + py0) + C->ter.border) / C->ter.hscale;
+  // (points + border) / horizontal_scale, then .long(): only the INTEGER PART of the correctly rounded quotient is used.  A product with the
+  // rounded reciprocal is within 2.5 ulp of it, so both truncate alike unless an integer lies within that distance: the two IEEE divisions
+  // (v_div_scale / v_rcp / five FMAs / v_div_fmas / v_div_fixup each, a serial chain) are taken only by wave rounds in which some lane is that
+  // close to an integer -- a few per cent of them; the result is the reference's bit for bit either way.
+  const float fx = (rx + px0) + C->ter.border, fy = (ry + py0) + C->ter.border;
+  const float ih = 1.0f / C->ter.hscale;
+  float px = fx * ih, py = fy * ih;
+  const bool near_int = fabsf(px - rintf(px)) <= 8e-7f * fmaxf(fabsf(px), 1.f) || fabsf(py - rintf(py)) <= 8e-7f * fmaxf(fabsf(py), 1.f);
+  if (__any(near_int)) { px = fx / C->ter.hscale; py = fy / C->ter.hscale; }
   int ix = (int)px, iy = (int)py;                       // trunc toward zero (tensor.long())
   ix = max(0, min(ix, C->ter.rows - 2)); iy = max(0, min(iy, C->ter.cols - 2));
   HeightProbe r; r.h = C->ter.Hmin[(size_t)ix * C->ter.cols + iy];                   // (plane: the 1 x 1 dummy grid)
@@ -2063,11 +2076,12 @@ LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot
 // its policy step in post_kernel (can_fuse() is false there, these are never called).
 static std::vector<float> pack_obs_table(const lg_config&, int) { return std::vector<float>(4, 0.f); }
 LG_DEV void fused_prefetch(const DevCtx* __restrict__, float*, float*, int, int, int, int64_t, const float*, const int32_t* __restrict__, bool) {}
-LG_DEV void fused_height_scan(const DevCtx* __restrict__, const float (*)[20], float*, int, int, int, const int32_t* __restrict__, bool) {}
+LG_DEV void fused_height_scan(const DevCtx* __restrict__, const float (*)[20], float*, int, int, int, const int32_t* __restrict__, bool, float, float) {}
+LG_DEV void fused_prefetch_static(const DevCtx* __restrict__, const float*, int, FusedPre&) {}
 LG_DEV bool fused_noise_predrawn(const float*) { return false; }
 LG_DEV void fused_noise_draw(const float*, int, int, int, int64_t, float (*)[4], const int32_t* __restrict__, bool) {}
 LG_DEV void fused_noise_park(const float*, float*, int, int, int, const float (*)[4]) {}
-LG_DEV void fused_stage_obs_table(const DevCtx* __restrict__, const float*, float*, int) {}
+LG_DEV void fused_stage_obs_table(const float*, float*, int, const FusedPre&) {}
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__, const float*, const LegModel&, float*, float*, float*, int, int, bool, const float*, const float*,
                                   const float*, const float*, const float*, const V3*, const float*, bool, int64_t, unsigned long long*, const PostSink&, bool, int) {}
 LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__, const float*, const float*, const float*, int, int, int, int64_t, unsigned long long*, float*, const int32_t* __restrict__, bool) { return false; }
