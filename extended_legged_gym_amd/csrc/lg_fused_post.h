@@ -148,6 +148,9 @@ LG_DEV void fused_prefetch_static(const DevCtx* __restrict__ C, const float* hot
   F.bx = 0.f; F.by = 0.f;
   if (P > 0) { F.bx = C->height_points[2 * p]; F.by = C->height_points[2 * p + 1]; }
   F.tab[0] = C->obs_tab[htid]; F.tab[1] = C->obs_tab[min(htid + 192, FO_STRIDE - 1)];     // (the table holds >= 256 entries: pack_obs_table)
+  F.inject = C->cfg.inject_sim_state; F.gait_on = C->cfg.gait_enabled; F.feet_early = fused_needs_feet_rows(C); F.heights_early = fused_needs_heights_early(C);
+  F.per_leg = C->per_leg; F.B = C->B; F.P = P; F.plane = C->ter.mesh_type == LG_MESH_PLANE; F.vscale = C->ter.vscale;
+  F.rigid = C->rigid; F.gfz = C->gait_foot_z; F.act = C->actions; F.tq = C->torques; F.heights = C->heights;
 }
 LG_DEV void fused_stage_obs_table(const float* hot, float* HB, int htid, const FusedPre& F) {
   if (HI(HC_NUM_OBS) > FO_STRIDE) return;
@@ -169,21 +172,22 @@ static_assert(NZ_IT * 192 >= EPB * (FO_STRIDE / 4), "the helper lanes cover ever
 
 // ---- helper waves, after the final state is published: the height scan of the workgroup's envs (LR:400-401), one point per lane
 LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid, const int32_t* __restrict__ ids, bool ro,
-                              float bx, float by) {
-  const int P = C->cfg.measure_heights ? C->P : 0;
+                              const FusedPre& F) {
+  const int P = F.P;
+  const float bx = F.bx, by = F.by;
   if (P <= 0) return;
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
   if (ro) {                  // rollout steps keep the heights the last main step measured (robot_batch_rollout.py:763-817 does not scan)
     if (htid < P)
-      for (int el = 0; el < nenv; ++el) HB[FH_HEIGHTS + el * MAX_P + htid] = C->heights[(size_t)fused_env_of(ids, e0 + el) * C->P + htid];
+      for (int el = 0; el < nenv; ++el) HB[FH_HEIGHTS + el * MAX_P + htid] = F.heights[(size_t)fused_env_of(ids, e0 + el) * P + htid];
     return;
   }
-  const bool plane = C->ter.mesh_type == LG_MESH_PLANE;
+  const bool plane = F.plane != 0;
   const int p = htid;
   const bool okp = p < P;
   // every context member of the store loop in a local: read inside it they are re-loaded after each global store (which might have changed
   // *C, for all the compiler knows) -- two dependent scalar round trips per env, ~8 k of this function's 11 k cycles
-  float LG_G* const hts = C->heights; const int Pn = C->P; const float vs = C->ter.vscale;
+  float LG_G* const hts = F.heights; const int Pn = P; const float vs = F.vscale;
   HeightProbe hp[EPB];
 #pragma unroll
   for (int el = 0; el < EPB; ++el) {

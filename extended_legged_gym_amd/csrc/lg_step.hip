@@ -395,14 +395,16 @@ LG_DEV void leg_torques(const DevCtx* __restrict__ C, const LegModel& lm_, const
 // Body states of one leg (+ the base from leg 0) from the generalised state: forward kinematics once more, then the
 // (N, B, 13) rows [pos3, quat xyzw4, lin vel3, ang vel3] the reference reads from refresh_rigid_body_state_tensor.
 // `part` selects what this caller stores: -1 everything; 0 / 1 / 2 = link 0 (+ base) / link 1 / link 2 (+ foot body).
+// per_leg_ >= 0: the caller has read C->per_leg, C->B, C->rigid already
 LG_DEV void write_rigid_body_state(const DevCtx* __restrict__ C, const LegModel& lm_, int e, int l, const float* root, const float* q,
-                                   const float* qd, int part = -1, float* foot_row_lds = nullptr, float* foot_z_dst = nullptr) {
-  const int per_leg = C->per_leg, B = C->B;
+                                   const float* qd, int part = -1, float* foot_row_lds = nullptr, float* foot_z_dst = nullptr,
+                                   int per_leg_ = -1, int B_ = 0, float LG_G* rigid_ = nullptr) {
+  const int per_leg = per_leg_ >= 0 ? per_leg_ : C->per_leg, B = per_leg_ >= 0 ? B_ : C->B;
   const M3 Rb = quat_to_mat(root + 3);
   const V3 pb = v3(root[0], root[1], root[2]), vb = v3(root[7], root[8], root[9]), wb = v3(root[10], root[11], root[12]);
   LegKin k;
   leg_kinematics(lm_, Rb, pb, vb, wb, q, qd, k);
-  float* rb = C->rigid + (size_t)e * B * 13;
+  float* rb = (per_leg_ >= 0 ? rigid_ : C->rigid) + (size_t)e * B * 13;
   if (l == 0 && part <= 0) {
 #pragma unroll
     for (int i = 0; i < 13; ++i) rb[i] = root[i];
@@ -492,8 +494,12 @@ struct PostSink { float* obs_out; const float* values; float* rewards; float* do
 // the post-physics step as the tail of this kernel (lg_fused_post.h, defined below the post-physics helpers)
 struct FusedMainIn;
 LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid, int64_t step, const float* values, const int32_t* __restrict__ ids, bool ro);
-struct FusedPre { float bx, by; float4 tab[2]; };      // what the helper waves fetch in front of (F) for their work behind it (lg_fused_post.h)
-LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid, const int32_t* __restrict__ ids, bool ro, float bx, float by);
+// what the helper waves fetch in front of (F) for their work behind it (lg_fused_post.h): their scan point, their entries of the observation
+// table, and every context member / config flag that work reads -- behind (F) each of those was a scalar round trip of its own on the way to (G2)
+struct FusedPre { float bx, by; float4 tab[2];
+                  int inject, gait_on, feet_early, heights_early, per_leg, B, P, plane; float vscale;
+                  float LG_G *rigid, *gfz, *act, *tq, *heights; };
+LG_DEV void fused_height_scan(const DevCtx* __restrict__ C, const float (*xst)[20], float* HB, int blk, int n, int htid, const int32_t* __restrict__ ids, bool ro, const FusedPre& F);
 LG_DEV void fused_prefetch_static(const DevCtx* __restrict__ C, const float* hot, int htid, FusedPre& F);
 enum { NZ_IT = 6 };          // Philox calls per helper lane that cover the observation noise of the workgroup's 16 envs (rows of up to 256 entries)
 LG_DEV bool fused_noise_predrawn(const float* hot);
@@ -779,47 +785,47 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     } else {
       // fused step: first what the rest of the tail waits for (the height scan; the feet rows when a reward term reads them),
       // the rigid-body rows -- stores nobody in this launch reads -- come last
-      const bool feet_early = fused_needs_feet_rows(C);  // (kernel-uniform)
+      const bool feet_early = fpre.feet_early != 0;       // (kernel-uniform)
       if (feet_early && wv == 3 && valid) {
-        if (g.inject_sim_state) {                        // parity tests: the feet rows the caller injected
-          const float* o = Ct->rigid + ((size_t)e * Ct->B + 1 + Ct->per_leg * l + (Ct->per_leg == 4 ? 3 : 2)) * 13;
+        if (fpre.inject) {                               // parity tests: the feet rows the caller injected
+          const float* o = fpre.rigid + ((size_t)e * fpre.B + 1 + fpre.per_leg * l + (fpre.per_leg == 4 ? 3 : 2)) * 13;
           float* fr = fused_foot_row(xs, lane);
 #pragma unroll
           for (int i = 0; i < 13; ++i) fr[i] = o[i];
         } else {
           float r13[13], qq[3], qdd[3];
           fetch_state(xst[lane], r13, qq, qdd);
-          write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane));   // (gait_foot_z is stored late: the serial part still reads the old one)
+          write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane), nullptr, fpre.per_leg, fpre.B, fpre.rigid);   // (gait_foot_z is stored late: the serial part still reads the old one)
         }
       }
-      fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro, fpre.bx, fpre.by);
+      fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro, fpre);
       STAMP(35);                                       // (diagnostic)
 #if defined(LG_STAMPS) && defined(LG_SCAN_TWICE)
       { const DevCtx* Cx = Ct; asm volatile("" : "+s"(Cx));     // (diagnostic: the same code a second time, now warm in the instruction cache)
-        fused_height_scan(Cx, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro, fpre.bx, fpre.by); }
+        fused_height_scan(Cx, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro, fpre); }
       STAMP(27);
 #endif
       // the rigid-body rows (stores nobody in this launch reads) while the main wave runs the serial part: these waves wait ~6 k cycles for
       // it at (G2); behind the write-back, where they used to be, they were on the tail of the launch
-      if (valid && g.inject_sim_state) {                         // parity tests: the injected rows stay; gait_foot_z from the injected foot row
-        if (wv == 3 && g.gait_enabled && !ro) Ct->gait_foot_z[(size_t)e * NLEG + l] = Ct->rigid[((size_t)e * Ct->B + 1 + Ct->per_leg * l + (Ct->per_leg == 4 ? 3 : 2)) * 13 + 2];
+      if (valid && fpre.inject) {                                // parity tests: the injected rows stay; gait_foot_z from the injected foot row
+        if (wv == 3 && fpre.gait_on && !ro) fpre.gfz[(size_t)e * NLEG + l] = fpre.rigid[((size_t)e * fpre.B + 1 + fpre.per_leg * l + (fpre.per_leg == 4 ? 3 : 2)) * 13 + 2];
       } else if (valid && !(feet_early && wv == 3)) {            // rigid-body rows of the post-physics (pre-reset) pose, LR:118-120
         float r13[13], qq[3], qdd[3];
         fetch_state(xst[lane], r13, qq, qdd);
-        write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && g.gait_enabled && !ro) ? Ct->gait_foot_z + (size_t)e * NLEG + l : nullptr);
-      } else if (valid && g.gait_enabled && !ro) {
-        Ct->gait_foot_z[(size_t)e * NLEG + l] = fused_foot_row(xs, lane)[2];
+        write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, wv - 1, nullptr, (wv == 3 && fpre.gait_on && !ro) ? fpre.gfz + (size_t)e * NLEG + l : nullptr,
+                               fpre.per_leg, fpre.B, fpre.rigid);
+      } else if (valid && fpre.gait_on && !ro) {
+        fpre.gfz[(size_t)e * NLEG + l] = fused_foot_row(xs, lane)[2];
       }
       // the LSTM state, action and torque rows while the main wave is still in the serial part (these waves wait for it at (G2)); what a reset
       // changes -- a zero LSTM state, anymal.py:78-82 -- is stored over it behind (G2)
       if (valid && net) {
-        float LG_G* const p_act = Ct->actions; float LG_G* const p_tq = Ct->torques;
         store_lstm_rows(Ct, row, N12, h0, c0, h1, c1);
-        p_act[(size_t)e * NDOF + d] = a;
-        if (!g.inject_sim_state) p_tq[(size_t)e * NDOF + d] = xtau[j][lane];
+        fpre.act[(size_t)e * NDOF + d] = a;
+        if (!fpre.inject) fpre.tq[(size_t)e * NDOF + d] = xtau[j][lane];
       }
       STAMP(51);
-      if (feet_early || fused_needs_heights_early(C)) lds_barrier();   // (G1) only when the serial part reads a helper's product
+      if (feet_early || fpre.heights_early) lds_barrier();   // (G1) only when the serial part reads a helper's product
       lds_barrier();                                   // (G2) serial part + height scan done
       STAMP(52);
       zero_state = fused_did_reset(cst, lane / GRP);    // anymal.py:78-82: a reset env starts from the zero LSTM state
@@ -2076,8 +2082,8 @@ LG_DEV void fused_main_and_serial(const DevCtx* __restrict__ C, const float* hot
 // its policy step in post_kernel (can_fuse() is false there, these are never called).
 static std::vector<float> pack_obs_table(const lg_config&, int) { return std::vector<float>(4, 0.f); }
 LG_DEV void fused_prefetch(const DevCtx* __restrict__, float*, float*, int, int, int, int64_t, const float*, const int32_t* __restrict__, bool) {}
-LG_DEV void fused_height_scan(const DevCtx* __restrict__, const float (*)[20], float*, int, int, int, const int32_t* __restrict__, bool, float, float) {}
-LG_DEV void fused_prefetch_static(const DevCtx* __restrict__, const float*, int, FusedPre&) {}
+LG_DEV void fused_height_scan(const DevCtx* __restrict__, const float (*)[20], float*, int, int, int, const int32_t* __restrict__, bool, const FusedPre&) {}
+LG_DEV void fused_prefetch_static(const DevCtx* __restrict__, const float*, int, FusedPre& F) { F = FusedPre{}; }
 LG_DEV bool fused_noise_predrawn(const float*) { return false; }
 LG_DEV void fused_noise_draw(const float*, int, int, int, int64_t, float (*)[4], const int32_t* __restrict__, bool) {}
 LG_DEV void fused_noise_park(const float*, float*, int, int, int, const float (*)[4]) {}
