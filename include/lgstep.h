@@ -156,7 +156,7 @@ enum lg_tensor_id {
                                over the envs reset in the most recent step that reset any (:200-203); [K] = mean terrain level */
   LG_T_RAND_INJECT,         /* (N, LG_RS_NOISE_OF(dof)+num_obs) f32, only read when rng_mode == LG_RNG_INJECT   */
   LG_T_STEP_COUNTERS,       /* (4) i64: [0] common_step_counter, [1] #envs reset by the last step       */
-  LG_T_HEIGHT_SAMPLES,      /* (rows, cols) i16, read-only terrain grid                                */
+  LG_T_HEIGHT_SAMPLES,      /* (rows, cols) i16, read-only terrain grid (lg_create derives the scan's table from it) */
   LG_T_TERRAIN_ORIGINS,     /* (levels, types, 3) f32                                                  */
   LG_T_EPISODE_STATS,       /* (4) f64 running totals since lg_create: sum of finished-episode returns, sum of their
                                lengths, #finished episodes, #env-steps — what a rank contributes to the cross-GPU
