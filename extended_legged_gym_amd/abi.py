@@ -8,7 +8,7 @@ import ctypes as C
 LG_ABI_VERSION = 4
 LG_MAX_LEGS, LG_JOINTS_PER_LEG = 6, 3
 LG_MAX_DOF = LG_MAX_LEGS * LG_JOINTS_PER_LEG
-LG_MAX_CP, LG_MAX_BODIES, LG_MAX_REWARD_TERMS, LG_MAX_INDEX_LIST = 8, 25, 32, 16
+LG_MAX_CP, LG_MAX_BODIES, LG_MAX_REWARD_TERMS, LG_MAX_INDEX_LIST = 8, 25, 32, 25
 SUPPORTED_LEG_COUNTS = (4, 6)          # kernel instances of the library (csrc/lg_instance.h)
 LG_LSTM_NPARAM = 969
 

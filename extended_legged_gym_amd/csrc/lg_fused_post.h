@@ -427,7 +427,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot_lds,
   for (int f = 0; f < 4; ++f) fidx[f] = HI(HC_FEET + f);
   float ncoll = 0.f; bool term = false;
 #pragma unroll
-  for (int i = 0; i < LG_MAX_INDEX_LIST; ++i) {          // fixed bounds: the index loads and the LDS reads behind them go out together
+  for (int i = 0; i < NBODY_MAX; ++i) {          // fixed bounds (a robot of this instance has at most NBODY_MAX bodies): the index loads and the LDS reads behind them go out together
     const bool pen = i < HI(HC_NPEN), trm = i < HI(HC_NTERM);
     const float fp = fn[HI(HC_PEN + i)], ft = fn[HI(HC_TERMB + i)];
     ncoll += (pen && fp > 0.1f) ? 1.f : 0.f;

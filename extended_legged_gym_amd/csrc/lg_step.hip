@@ -46,8 +46,8 @@ namespace LG_NS {
 // 64-byte lines of it, each a scalar-cache miss on first touch, serialised by the tail's dependent chain.
 enum { HC_DT = 0, HC_K, HC_KFAT, HC_KTERM, HC_TERM_SCALE, HC_TERM_MASK, HC_RESAMPLING_STEPS, HC_HEADING, HC_PUSH, HC_PUSH_INTERVAL, HC_MAX_PUSH,
        HC_FLIP, HC_MAX_EPLEN, HC_ONLY_POS, HC_STAND, HC_CURRICULUM, HC_GAIT_ON, HC_GAIT_PERIOD, HC_GAIT_SWING, HC_GAIT_PHASE /* NLEG */, HC_SIGMA = HC_GAIT_PHASE + NLEG,
-       HC_BH_TARGET, HC_MAX_CF, HC_MEASURE_H, HC_P, HC_FEET /* NLEG */, HC_NPEN = HC_FEET + NLEG, HC_PEN /* 16 */, HC_NTERM = HC_PEN + LG_MAX_INDEX_LIST,
-       HC_TERMB /* 16 */, HC_SOFT_VEL = HC_TERMB + LG_MAX_INDEX_LIST, HC_SOFT_TQ, HC_NUM_OBS, HC_ADD_NOISE, HC_INJECT, HC_OS_LIN, HC_OS_ANG, HC_OS_POS,
+       HC_BH_TARGET, HC_MAX_CF, HC_MEASURE_H, HC_P, HC_FEET /* NLEG */, HC_NPEN = HC_FEET + NLEG, HC_PEN /* NBODY_MAX */, HC_NTERM = HC_PEN + NBODY_MAX,
+       HC_TERMB /* NBODY_MAX */, HC_SOFT_VEL = HC_TERMB + NBODY_MAX, HC_SOFT_TQ, HC_NUM_OBS, HC_ADD_NOISE, HC_INJECT, HC_OS_LIN, HC_OS_ANG, HC_OS_POS,
        HC_OS_VEL, HC_OS_H, HC_CLIP_OBS, HC_SEED_LO, HC_SEED_HI, HC_NUM_EXTRA, HC_IDS /* 32 */, HC_SCALES = HC_IDS + LG_MAX_REWARD_TERMS /* 32 */,
        HC_DEFAULT_POS = HC_SCALES + LG_MAX_REWARD_TERMS /* NDOF */, HC_COUNT = HC_DEFAULT_POS + NDOF };
 
@@ -140,7 +140,7 @@ static void hot_config(DevCtx& h) {
   F(HC_SIGMA, g.tracking_sigma); F(HC_BH_TARGET, g.base_height_target); F(HC_MAX_CF, g.max_contact_force); I(HC_MEASURE_H, g.measure_heights);
   I(HC_P, g.measure_heights ? h.P : 0);
   I(HC_NPEN, m.num_penalised); I(HC_NTERM, m.num_termination);
-  for (int i = 0; i < LG_MAX_INDEX_LIST; ++i) { I(HC_PEN + i, i < m.num_penalised ? m.penalised_contact_indices[i] : 0); I(HC_TERMB + i, i < m.num_termination ? m.termination_contact_indices[i] : 0); }
+  for (int i = 0; i < NBODY_MAX; ++i) { I(HC_PEN + i, i < m.num_penalised ? m.penalised_contact_indices[i] : 0); I(HC_TERMB + i, i < m.num_termination ? m.termination_contact_indices[i] : 0); }
   F(HC_SOFT_VEL, g.soft_dof_vel_limit); F(HC_SOFT_TQ, g.soft_torque_limit); I(HC_NUM_OBS, g.num_obs); I(HC_ADD_NOISE, g.add_noise);
   I(HC_INJECT, g.rng_mode == LG_RNG_INJECT); F(HC_OS_LIN, g.obs_scale_lin_vel); F(HC_OS_ANG, g.obs_scale_ang_vel); F(HC_OS_POS, g.obs_scale_dof_pos);
   F(HC_OS_VEL, g.obs_scale_dof_vel); F(HC_OS_H, g.obs_scale_height); F(HC_CLIP_OBS, g.clip_observations);
@@ -2225,6 +2225,8 @@ static const char* validate(const lg_config* cfg, const lg_robot_model* model, c
   if (ter->mesh_type != LG_MESH_PLANE && (ter->rows < 2 || ter->cols < 2 || !ter->height_samples)) return "rough terrain without height samples";
   if (ter->mesh_type == LG_MESH_TRIMESH && !ter->collision_mesh) return "trimesh terrain without a collision mesh (lg_mesh_create)";
   if (cfg->curriculum && (ter->num_levels <= 0 || ter->num_types <= 0 || !ter->terrain_origins)) return "curriculum needs terrain_origins";
+  if (model->num_penalised < 0 || model->num_penalised > NBODY_MAX || model->num_termination < 0 || model->num_termination > NBODY_MAX)
+    return "more penalised / termination bodies than the robot has";
   for (int l = 0; l < NLEG; ++l) if (model->cp_count[l] < 0 || model->cp_count[l] > LG_MAX_CP) return "bad cp_count";
   for (int k = 0; k < cfg->num_reward_terms; ++k) if (cfg->reward_term_ids[k] < 0 || cfg->reward_term_ids[k] >= LG_REW_COUNT) return "unknown reward term id";
   if (!cfg->noise_scale_vec) return "noise_scale_vec is null";

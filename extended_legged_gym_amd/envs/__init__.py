@@ -51,3 +51,13 @@ from .elspider_air.flat.elspider_air_flat_config import ElSpiderAirFlatCfg, ElSp
 # the six-legged robot (reference envs/__init__.py:154, 157): the hexapod instance of the kernels
 task_registry.register("elspider_air_rough", ElSpider, ElSpiderAirRoughTrainCfg(), ElSpiderAirRoughTrainCfgPPO())
 task_registry.register("elspider_air_flat", ElSpider, ElSpiderAirFlatCfg(), ElSpiderAirFlatCfgPPO())
+from .elspider_air.batch_rollout.elspider_air_batch_rollout import ElSpiderAirBatchRollout  # noqa: E402
+from .elspider_air.batch_rollout.elspider_air_batch_rollout_config import (  # noqa: E402
+    ElSpiderAirBatchRolloutCfg, ElSpiderAirBatchRolloutCfgPPO, ElSpiderAirBatchRolloutFlatCfg, ElSpiderAirBatchRolloutFlatCfgPPO,
+    ElSpiderAirDialMPCCfg, ElSpiderAirDialMPCCfgPPO, ElSpiderAirDialMPCFlatCfg, ElSpiderAirDialMPCFlatCfgPPO)
+# the hexapod's main-rollout and DIAL-MPC tasks (reference envs/__init__.py:166-173); `elspider_air_dialmpc` needs the user's OBJ terrain,
+# `elspider_air_dialmpc_flat` cannot be built (in the reference either: see ElSpiderAirDialMPCFlatCfg)
+task_registry.register("elspider_air_batch_rollout", ElSpiderAirBatchRollout, ElSpiderAirBatchRolloutCfg(), ElSpiderAirBatchRolloutCfgPPO())
+task_registry.register("elspider_air_batch_rollout_flat", ElSpiderAirBatchRollout, ElSpiderAirBatchRolloutFlatCfg(), ElSpiderAirBatchRolloutFlatCfgPPO())
+task_registry.register("elspider_air_dialmpc_flat", ElSpiderAirBatchRollout, ElSpiderAirDialMPCFlatCfg(), ElSpiderAirDialMPCFlatCfgPPO())
+task_registry.register("elspider_air_dialmpc", ElSpiderAirBatchRollout, ElSpiderAirDialMPCCfg(), ElSpiderAirDialMPCCfgPPO())

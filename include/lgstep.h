@@ -40,7 +40,7 @@ extern "C" {
 #define LG_MAX_CP 8            /* collision points per leg lane */
 #define LG_MAX_BODIES 25       /* base + 6 x (HIP, THIGH, SHANK, FOOT) */
 #define LG_MAX_REWARD_TERMS 32
-#define LG_MAX_INDEX_LIST 16
+#define LG_MAX_INDEX_LIST 25     /* = LG_MAX_BODIES: a task may penalise contacts on every body (elspider_air_batch_rollout: base + 18 links) */
 #define LG_LSTM_HIDDEN 8
 #define LG_LSTM_NPARAM 969     /* 2-layer LSTM(2->8->8) + Linear(8->1), anydrive_v3_lstm */
 

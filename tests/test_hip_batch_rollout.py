@@ -161,12 +161,14 @@ class _HipAsOracle:
         self.core.sync_main_to_rollout(R, drift)
 
 
-def test_hip_main_and_rollout_steps_match_reference_golden():
+@pytest.mark.parametrize("fixture", ["batch_rollout.npz", "elspider_batch_rollout.npz"])
+def test_hip_main_and_rollout_steps_match_reference_golden(fixture):
     """The HIP subset post-physics kernels and the sync kernel against the vectors recorded from the reference's
-    RobotBatchRollout.step / step_rollout (same replay and the same bar as tests/test_oracle_rollout_golden.py)."""
+    RobotBatchRollout.step / step_rollout (same replay and the same bar as tests/test_oracle_rollout_golden.py); the second
+    fixture is the hexapod's own class, ElSpiderAirBatchRollout, on the six-legged kernel instance."""
     from extended_legged_gym_amd.native import NativeCore
     from tests import test_oracle_rollout_golden as G
-    z, meta = G.load()
+    z, meta = G.load(fixture)
     cfg, s = G.rollout_setup(meta)
     core = NativeCore(s, "cuda:0")
     o = _HipAsOracle(core)
@@ -258,6 +260,80 @@ def test_anymal_c_batch_rollout_tasks_and_flip_termination():
     assert env.reward_scales_stage == 0
     env.update_reward_scales(100.0)
     assert env.reward_scales_stage == 1
+
+
+def test_elspider_air_batch_rollout_tasks():
+    """The hexapod's main-rollout tasks (reference envs/__init__.py:166-173) on the six-legged kernel instance: the plane task with rollouts
+    (step, step_rollout, rollout_batch, flip termination, two reward stages), the confined-mesh task with the collision-sphere URDF, the
+    DIAL-MPC task's AsyncGaitScheduler term with the hexapod's own 18-entry weights, and the one task the reference cannot build."""
+    from tests.test_env_api import make
+    env = make("elspider_air_batch_rollout_flat", 8, **{"env.rollout_envs": 3, "noise.add_noise": False, "domain_rand.push_robots": False})
+    assert (env.num_envs, env.total_num_envs, env.num_obs, env.num_actions) == (8, 32, 66, 18)
+    assert env.setup.cfg.terminate_on_flip == 1 and env.setup.model.num_termination == 0      # ("trunk" is merged into "base": nothing matches, as in Isaac Gym)
+    obs, _ = env.reset()
+    assert obs.shape == (8, 66)
+    for _ in range(10):
+        obs, _, rew, done, _ = env.step(torch.zeros(8, 18, device=env.device))
+    assert int(done.sum()) == 0 and torch.isfinite(obs).all() and (rew >= 0).all()
+    obs_r, _, rew_r, _, _ = env.step_rollout(0.1 * torch.randn(24, 18, device=env.device))
+    assert obs_r.shape == (24, 66) and torch.isfinite(obs_r).all() and torch.isfinite(rew_r).all()
+    rews = env.rollout_batch(0.1 * torch.randn(24, 6, 18, device=env.device))
+    rews = rews[0] if isinstance(rews, tuple) else rews
+    assert tuple(rews.shape)[:2] == (24, 6) and torch.isfinite(rews).all()
+    m = int(env.main_env_indices[5])
+    env.root_states[m, 3:7] = torch.tensor([1.0, 0.0, 0.0, 0.0], device=env.device)
+    env.root_states[m, 2] = 2.0
+    _, _, _, done, _ = env.step(torch.zeros(8, 18, device=env.device))
+    assert done.tolist() == [False] * 5 + [True, False, False]
+    assert env.reward_scales_stage == 0 and env.cfg.rewards.reward_max_stage == 0      # (no list-valued scale in this config: one stage)
+    env.core.close()
+    # the training task on the confined two-layer mesh (el_mini_collsp.urdf: shanks and trunk penalised, gait_2_step, feet_stumble)
+    env = make("elspider_air_batch_rollout", 8, **{"env.rollout_envs": 1})
+    assert env.total_num_envs == 16 and env.setup.terrain.mesh_type == 2          # LG_MESH_TRIMESH
+    env.reset()
+    for _ in range(10):
+        obs, _, rew, done, _ = env.step(0.1 * torch.randn(8, 18, device=env.device))
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert float(env.root_states[env.main_env_indices, 2].min()) > 0.05             # nobody fell through the mesh
+    # list-valued scales (feet_slip [-0.0, -0.4], the async-gait weights) but `reward_max_stage` left at the base class's 0, as in the reference's
+    # config: the task stays in its first stage
+    assert not env.update_reward_scales(100.0) and env.reward_scales_stage == 0 and "feet_slip" not in env.setup.reward_names
+    assert "gait_2_step" in env.setup.reward_names and "feet_stumble" in env.setup.reward_names
+    env.core.close()
+    with pytest.raises(AttributeError, match="gait_scheduler"):
+        make("elspider_air_dialmpc_flat", 4)
+    with pytest.raises((FileNotFoundError, OSError)):                               # the task's terrain is the user's OBJ file
+        make("elspider_air_dialmpc", 4)
+
+
+def test_elspider_dialmpc_async_gait_term_with_the_hexapod_weights():
+    """`elspider_air_dialmpc`'s reward set on a plane (the shipped task needs an OBJ file): the AsyncGaitScheduler term with the 18-entry
+    `dof_nominal_pos_weight` it was written for runs as shipped, HIP value = oracle value."""
+    from tests.test_env_api import make
+    from oracle.oracle_lib import OracleEnv
+    env = make("elspider_air_dialmpc", 8, **{"terrain.mesh_type": "plane", "terrain.use_terrain_obj": False, "terrain.random_origins": False,
+                                             "sdf.enable_sdf": False, "env.num_observations": 66, "env.rollout_envs": 2,
+                                             "noise.add_noise": False, "domain_rand.push_robots": False})
+    assert env.setup.cfg.async_num_dof_sets == 4
+    env.reset()
+    for _ in range(3):
+        env.step(0.2 * torch.randn(8, 18, device=env.device))
+    o = OracleEnv(env.setup)
+    for name in ("root_states", "dof_state", "commands", "last_actions", "last_dof_vel", "last_root_vel", "episode_length_buf",
+                 "feet_air_time", "feet_contact_time", "last_contacts", "friction_coeffs", "base_mass_added", "env_origins",
+                 "base_lin_acc", "base_ang_acc", "step_counters", "episode_sums", "rigid_body_state", "contact_forces"):
+        o.t[name][...] = env.core.t[name].cpu().numpy()
+    from extended_legged_gym_amd.envs.base.native_config import async_gait_weights
+    o.set_async_gait(async_gait_weights(env.cfg, env.reward_scales_stage), env._async_foot_z_align)
+    a = 0.2 * torch.randn(8, 18, device=env.device)
+    _, _, rew, _, _ = env.step(a)
+    mains = env.main_env_indices.cpu().numpy()
+    o.sync_main_to_rollout(2, 0.0, 0)
+    o.step_subset(a.cpu().numpy(), mains.astype(np.int32), 0)
+    k = list(env.setup.reward_names).index("async_gait_scheduler")
+    assert abs(float(env.core.t["episode_sums"][k, mains[0]])) > 0.0
+    np.testing.assert_allclose(o.t["rew_buf"][mains], rew.cpu().numpy(), rtol=5e-3, atol=5e-3)
+    o.close(); env.core.close()
 
 
 def test_subset_step_reports_the_mean_terrain_level_of_all_envs():

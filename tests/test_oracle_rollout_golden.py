@@ -31,15 +31,25 @@ RESTORED = ["root_states", "dof_state", "actions", "last_actions", "last_dof_vel
             "last_contacts", "commands", "episode_length_buf"]
 
 
-def load():
-    z = np.load(os.path.join(GOLDEN_DIR, "batch_rollout.npz"))
+FIXTURES = ["batch_rollout.npz",            # ANYmal-C over the generic RobotBatchRollout
+            "elspider_batch_rollout.npz"]   # the reference's ElSpiderAirBatchRollout with its flat task config (six legs: the other kernel instance)
+
+
+def load(name="batch_rollout.npz"):
+    z = np.load(os.path.join(GOLDEN_DIR, name))
     return z, json.loads(bytes(z["meta_json"]).decode())
 
 
 def rollout_setup(meta, rng_mode=abi.LG_RNG_INJECT):
     """Our own config classes, edited exactly as make_rollout_golden.py edited the reference's."""
     M, R = meta["M"], meta["R"]
-    cfg = AnymalCFlatCfg()
+    hexapod = meta.get("robot", "anymal") == "elspider"
+    if hexapod:
+        from extended_legged_gym_amd.envs.elspider_air.batch_rollout.elspider_air_batch_rollout_config import ElSpiderAirBatchRolloutFlatCfg
+        cfg = ElSpiderAirBatchRolloutFlatCfg()
+        cfg.rewards.multi_stage_rewards = False
+    else:
+        cfg = AnymalCFlatCfg()
     cfg.env.num_envs = M * (1 + R)
     cfg.env.env_spacing = meta["env_spacing"]
     cfg.env.episode_length_s = 20
@@ -55,6 +65,10 @@ def rollout_setup(meta, rng_mode=abi.LG_RNG_INJECT):
     for k, v in meta["scales"].items():
         setattr(cfg.rewards.scales, k, v)
     model = load_robot_model(cfg.asset)
+    if hexapod:                                                                  # (tools/refgen/ref_loader.py:elspider_robot_description: the URDF's own limits)
+        model["dof_lower"], model["dof_upper"] = [-0.785, -0.5233, -0.6978] * 6, [0.785, 3.14, 3.925] * 6
+        model["dof_vel_limit"], model["torque_limit"] = [21.0] * 18, [33.5] * 18
+        return cfg, NativeSetup(cfg, sim_params_for(cfg), model, seed=0, rng_mode=rng_mode, terminate_on_flip=True)   # elspider_air_batch_rollout.py:176-180
     model["dof_lower"], model["dof_upper"] = [-9.42] * 12, [9.42] * 12          # the harness robot's DOF limits
     model["dof_vel_limit"], model["torque_limit"] = [20.0] * 12, [80.0] * 12
     return cfg, NativeSetup(cfg, sim_params_for(cfg), model, seed=0, rng_mode=rng_mode)   # no gait scheduler in this class
@@ -104,8 +118,9 @@ def replay_call(o, z, meta, t, cfg):
         o.sync_main_to_rollout(R, 0.0, 1)                                      # :594
 
 
-def test_index_maps_and_origins_match_reference():
-    z, meta = load()
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_index_maps_and_origins_match_reference(fixture):
+    z, meta = load(fixture)
     M, R = meta["M"], meta["R"]
     T = M * (1 + R)
     ar = np.arange(T)
@@ -117,8 +132,9 @@ def test_index_maps_and_origins_match_reference():
     np.testing.assert_allclose(centered_grid_origins(T, meta["env_spacing"]), z["env_origins"], atol=1e-6)
 
 
-def test_oracle_main_and_rollout_steps_match_reference():
-    z, meta = load()
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_oracle_main_and_rollout_steps_match_reference(fixture):
+    z, meta = load(fixture)
     cfg, s = rollout_setup(meta)
     assert [n for n in s.reward_names] == meta["reward_names"]
     np.testing.assert_allclose(s.noise_scale_vec, z["noise_scale_vec"], rtol=1e-6)
@@ -168,3 +184,5 @@ def run_golden(o, z, meta, cfg):
             seen_rollout += 1
             seen_term += int(z["ret_reset"][t][rolls].sum() > 0)               # _reward_termination active on rollouts
     assert seen_main_reset >= 2 and seen_rollout >= 4 and seen_term >= 2
+    if meta.get("robot") == "elspider":                                        # the upside-down main env of call 5 ended its episode (and nothing else did there)
+        assert int(z["ret_reset"][5][mains].sum()) == 1 and bool(z["ret_reset"][5][mains[2]])

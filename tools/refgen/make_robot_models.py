@@ -32,6 +32,11 @@ m = load_urdf(f"{REF}/robots/el_mini/urdf/el_mini.urdf", "FOOT", ["THIGH", "HIP"
 save_model(m, f"{OUT}/robots/el_mini.json")
 print("el_mini", m["num_bodies"], m["body_names"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"], m["dof_names"])
 
+# the main-rollout tasks of the hexapod name the collision-sphere URDF itself (elspider_air_batch_rollout_config.py:196)
+m = load_urdf(f"{REF}/robots/el_mini/urdf/el_mini_collsp.urdf", "FOOT", ["base", "HIP", "THIGH", "SHANK"], [])
+save_model(m, f"{OUT}/robots/el_mini_collsp.json")
+print("el_mini_collsp", m["num_bodies"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"])
+
 import torch
 net = torch.jit.load(f"{REF}/actuator_nets/anydrive_v3_lstm.pt")
 sd = {k: v.detach().numpy() for k, v in net.state_dict().items()}

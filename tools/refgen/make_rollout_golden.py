@@ -9,7 +9,9 @@ deterministic simulator does with identical state and action); in `step_rollout(
 Recorded per call: all persistent buffers of all `total_num_envs` envs before and after, the returned tuple, the index
 maps and the env-origin grid.  Output: tests/golden/batch_rollout.npz (data only).
 
-Usage:  python tools/refgen/make_rollout_golden.py
+Usage:  python tools/refgen/make_rollout_golden.py            (ANYmal-C over the generic RobotBatchRollout -> batch_rollout.npz)
+        python tools/refgen/make_rollout_golden.py elspider   (the reference's ElSpiderAirBatchRollout with its flat task config, 6 legs x 3 joints,
+                                                               incl. the tripod form of gait_2_step and an upside-down main env -> elspider_batch_rollout.npz)
 """
 import json
 import os
@@ -21,7 +23,12 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_loader  # noqa: E402
-from make_golden import RS_CMD_CB, RS_PUSH, RS_DOF, RS_ROOT_VEL, RS_CMD_RESET, RS_NOISE  # noqa: E402
+from make_golden import RS_CMD_CB, RS_PUSH, RS_DOF, rs_tail  # noqa: E402
+
+ROBOT = sys.argv[1] if len(sys.argv) > 1 else "anymal"
+ND = 18 if ROBOT == "elspider" else 12
+NFEET = ND // 3
+_, RS_ROOT_VEL, RS_CMD_RESET, RS_NOISE = rs_tail(ND)
 
 REPO = ref_loader.REPO_ROOT
 OUT = os.path.join(REPO, "tests", "golden")
@@ -31,6 +38,8 @@ SCALES = dict(termination=-2.0, tracking_lin_vel=1.0, tracking_ang_vel=0.5, lin_
               orientation=-5.0, torques=-0.00002, dof_vel=-1e-4, dof_acc=-2.5e-7, base_height=-1.0, feet_air_time=1.0,
               collision=-1.0, feet_stumble=-0.5, action_rate=-0.01, stand_still=-0.2, dof_pos_limits=-3.0,
               feet_slip=-0.1, jump_air=-0.4, feet_contact_forces=-0.01)
+if ROBOT == "elspider":
+    SCALES["gait_2_step"] = -0.3
 
 
 def build(seed):
@@ -40,8 +49,15 @@ def build(seed):
     from legged_gym.envs.batch_rollout.robot_batch_rollout import RobotBatchRollout
     import legged_gym.envs.batch_rollout.robot_batch_rollout as RB
 
-    ref_loader.FakeGym.robot = ref_loader.anymal_robot_description()
-    cfg = AnymalCFlatCfg()
+    if ROBOT == "elspider":
+        from legged_gym.envs import ElSpiderAirBatchRollout, ElSpiderAirBatchRolloutFlatCfg
+        RobotBatchRollout = ElSpiderAirBatchRollout          # the robot's own class (flip termination, tripod gait_2_step, 18-joint noise vector)
+        ref_loader.FakeGym.robot = ref_loader.elspider_robot_description()
+        cfg = ElSpiderAirBatchRolloutFlatCfg()
+        cfg.rewards.multi_stage_rewards = False
+    else:
+        ref_loader.FakeGym.robot = ref_loader.anymal_robot_description()
+        cfg = AnymalCFlatCfg()
     cfg.env.num_envs = M
     cfg.env.rollout_envs = R
     cfg.env.env_spacing = 4.0
@@ -130,7 +146,7 @@ def slots_from_log(log, N, nslots):
         elif sub == "push":
             tab[ids, RS_PUSH:RS_PUSH + 2] = u
         elif sub == "dofs":
-            tab[ids, RS_DOF:RS_DOF + 12] = u
+            tab[ids, RS_DOF:RS_DOF + ND] = u
         elif sub == "root":
             assert u.shape[1] == 6
             tab[ids, RS_ROOT_VEL:RS_ROOT_VEL + 6] = u
@@ -170,11 +186,11 @@ def scripted_state(env, g, n, feet_on=0.6):
     root[:, 10:13] = 0.8 * randn(n, 3)
     rigid = randn(n, nb, 13)
     rigid[:, :, 0:3] = root[:, None, 0:3] + 0.4 * randn(n, nb, 3)
-    rigid[:, env.feet_indices, 2] = 0.05 + 0.1 * rand(n, 4)
+    rigid[:, env.feet_indices, 2] = 0.05 + 0.1 * rand(n, NFEET)
     contact = torch.zeros(n, nb, 3)
-    on = rand(n, 4) < feet_on
-    contact[:, env.feet_indices, 2] = on * (20.0 + 120.0 * rand(n, 4))
-    contact[:, env.feet_indices, 0:2] = on.unsqueeze(-1) * 60.0 * randn(n, 4, 2)
+    on = rand(n, NFEET) < feet_on
+    contact[:, env.feet_indices, 2] = on * (20.0 + 120.0 * rand(n, NFEET))
+    contact[:, env.feet_indices, 0:2] = on.unsqueeze(-1) * 60.0 * randn(n, NFEET, 2)
     pen = env.penalised_contact_indices
     hit = rand(n, len(pen)) < 0.15
     contact[:, pen, :] = hit.unsqueeze(-1) * 5.0 * randn(n, len(pen), 3)
@@ -223,6 +239,8 @@ def main():
         root, rigid, contact = scripted_state(env, g, T)
         root[:, :3] += env.env_origins
         rigid[:, :, :3] += env.env_origins[:, None, :]
+        if ROBOT == "elspider" and t == 5:                  # one main env lands on its back: the class's extra termination rule (projected_gravity.z > 0)
+            root[mains[2], 3:7] = torch.tensor([1.0, 0.0, 0.0, 0.0])
         noise = torch.randn(dec, T, nd, 2, generator=g)
         if kind == "main":                              # identical simulator outcome for a main env and its rollouts
             root, rigid, contact, noise = root[src], rigid[src], contact[src], noise[:, src]
@@ -240,16 +258,16 @@ def main():
         rec["log"].clear()
         extras_before = env.extras.get("episode", None)
         if kind == "main":
-            a = 1.5 * torch.randn(M, 12, generator=g)
+            a = 1.5 * torch.randn(M, ND, generator=g)
             a[0, 0] = 150.0
             obs, _, rew, reset, extras = env.step(a.clone())
-            act_full = torch.zeros(T, 12)
+            act_full = torch.zeros(T, ND)
             act_full[mains] = a
         else:
-            a = 1.5 * torch.randn(M * R, 12, generator=g)
+            a = 1.5 * torch.randn(M * R, ND, generator=g)
             a[1, 3] = -150.0
             obs, _, rew, reset, extras = env.step_rollout(a.clone())
-            act_full = torch.zeros(T, 12)
+            act_full = torch.zeros(T, ND)
             act_full[rolls] = a
         env._compute_torques = orig_ct
         post = persistent(env)
@@ -277,12 +295,12 @@ def main():
                main_to_rollout_indices=torch.stack(env.main_to_rollout_indices).numpy(),
                noise_scale_vec=env.noise_scale_vec.numpy(), p_gains=env.p_gains.numpy(), d_gains=env.d_gains.numpy(),
                reward_scales=np.array([env.reward_scales[k] for k in names], dtype=np.float64))
-    meta = dict(M=M, R=R, reward_names=names, scales=SCALES, num_obs=int(env.num_obs), dt=float(env.dt),
+    meta = dict(robot=ROBOT, M=M, R=R, reward_names=names, scales=SCALES, num_obs=int(env.num_obs), dt=float(env.dt),
                 max_episode_length=float(env.max_episode_length), push_interval=float(cfg.domain_rand.push_interval),
                 schedule=schedule, resampling_time=cfg.commands.resampling_time,
                 push_interval_s=cfg.domain_rand.push_interval_s, env_spacing=cfg.env.env_spacing)
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-    path = os.path.join(OUT, "batch_rollout.npz")
+    path = os.path.join(OUT, "elspider_batch_rollout.npz" if ROBOT == "elspider" else "batch_rollout.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; resets per call:", out["post_reset_buf"].sum(axis=1),
           "main resets:", out["ret_reset"][:, mains.numpy()].sum(axis=1))
