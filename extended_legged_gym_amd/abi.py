@@ -140,7 +140,7 @@ LG_TILE_STEPPING_STONES, LG_TILE_GAP, LG_TILE_PIT = 4, 5, 6
 class lg_pose_params(C.Structure):
     _fields_ = [("ranges", (f32 * 2) * 4), ("resampling_steps", i32), ("scale_orientation", f32), ("scale_base_height", f32),
                 ("scale_termination", f32), ("only_positive_rewards", i32), ("max_episode_length_s", f32), ("clip_observations", f32),
-                ("num_heights", i32)]
+                ("num_heights", i32), ("num_proprio", i32)]
 
 
 class lg_depth_params(C.Structure):

@@ -102,7 +102,7 @@ extern "C" int lg_pose_layer_step(const lg_pose_params* p, int32_t n, float* pos
       !projected_gravity || !u || !obs_out || !rew_out || !acc || p->resampling_steps <= 0 || (noise_u && !noise_scale_vec) ||
       (measured_heights && p->num_heights <= 0))
     return LG_ERR_INVALID;
-  const int O = 52 + (measured_heights ? p->num_heights : 0);
+  const int O = (p->num_proprio > 0 ? p->num_proprio : 48) + 4 + (measured_heights ? p->num_heights : 0);      // PoseElSpider: 66 + 4 (elspider.py:448-467)
   // the launches run on the device the rows live on, whatever device is current in the calling thread (an env on cuda:1 driven from a
   // thread whose current device is cuda:0), like every other entry point of the library
   hipPointerAttribute_t pa_out, pa_cmd;

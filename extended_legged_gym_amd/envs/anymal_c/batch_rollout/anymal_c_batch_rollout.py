@@ -30,17 +30,17 @@ def _scaled(cfg, name):
     return any(float(x) != 0.0 for x in (v if isinstance(v, (list, tuple)) else [v]))
 
 
-class AnymalCBatchRollout(RobotBatchRolloutPercept):
-    _terminate_on_flip = True
+class AsyncGaitTermMixin:
+    """Env-side glue of the native `LG_REW_ASYNC_GAIT_SCHEDULER` term (call `_init_async_gait()` once the env is built): the scheduler object of
+    the reference keeps the feet tensor it was constructed with, so its foot-height term is a constant of the spawn pose, handed to the
+    library together with the reward stage's weights (`lg_set_async_gait`), again after every stage switch."""
+    _async_foot_z_align = 0.0
 
-    def __init__(self, cfg, sim_params, physics_engine, sim_device, headless):
-        self._time_gait = _scaled(cfg, "gait_scheduler")
-        super().__init__(cfg, sim_params, physics_engine, sim_device, headless)
-        self._async_foot_z_align = 0.0
+    def _init_async_gait(self):
         if self.setup.cfg.async_num_dof_sets > 0:
-            # AsyncGaitScheduler.reward_foot_z_align on the feet positions of the freshly built env (what the scheduler object keeps)
-            # (every env is built in the same pose, so one value serves all of them)
-            feet = self.rigid_body_state.view(self.total_num_envs, self.num_bodies, 13)[:1, self.feet_indices, 0:3]
+            # AsyncGaitScheduler.reward_foot_z_align on the feet positions of the freshly built env (every env is built in the same pose)
+            n = getattr(self, "total_num_envs", self.num_envs)
+            feet = self.rigid_body_state.view(n, self.num_bodies, 13)[:1, self.feet_indices, 0:3]
             self._async_foot_z_align = float(foot_z_align(feet, self.cfg.async_gait_scheduler.foot_z_align_sets_idx)[0])
             self._set_async_gait()
 
@@ -52,6 +52,15 @@ class AnymalCBatchRollout(RobotBatchRolloutPercept):
         if changed and self.setup.cfg.async_num_dof_sets > 0:
             self._set_async_gait()
         return changed
+
+
+class AnymalCBatchRollout(AsyncGaitTermMixin, RobotBatchRolloutPercept):
+    _terminate_on_flip = True
+
+    def __init__(self, cfg, sim_params, physics_engine, sim_device, headless):
+        self._time_gait = _scaled(cfg, "gait_scheduler")
+        super().__init__(cfg, sim_params, physics_engine, sim_device, headless)
+        self._init_async_gait()
 
     # ------------------------------------------------------------------ time-driven gait scheduler
     def _gait_config(self):

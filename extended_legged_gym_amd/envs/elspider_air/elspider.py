@@ -14,7 +14,10 @@ kernels (`csrc/lg_instance.h`: eight lanes per env); what the class adds to `Leg
 observation layout only."""
 import torch
 
+from extended_legged_gym_amd.envs.anymal_c.anymal import PoseCommandsMixin
+from extended_legged_gym_amd.envs.anymal_c.batch_rollout.anymal_c_batch_rollout import AsyncGaitTermMixin
 from extended_legged_gym_amd.envs.base.legged_robot import LeggedRobot
+from extended_legged_gym_amd.utils.gait_scheduler import AsyncGaitSchedulerCfg
 
 
 @torch.no_grad()
@@ -47,8 +50,16 @@ def get_symmetric_observation_action(obs=None, actions=None, env=None, obs_type=
     return obs_aug, act_aug
 
 
-class ElSpider(LeggedRobot):
+class ElSpider(AsyncGaitTermMixin, LeggedRobot):
     _terminate_on_flip = True            # elspider.py:339-346
+
+    def __init__(self, cfg, sim_params, physics_engine, sim_device, headless):
+        # `_reward_async_gait_scheduler` (elspider.py:351-363) runs on a scheduler built from the DEFAULT `AsyncGaitSchedulerCfg()` (:255-266), not
+        # from a section of the task config: a task that scales the term (`pose_elspider_air_flat`) gets that section here
+        if not hasattr(cfg, "async_gait_scheduler"):
+            cfg.async_gait_scheduler = AsyncGaitSchedulerCfg()
+        super().__init__(cfg, sim_params, physics_engine, sim_device, headless)
+        self._init_async_gait()
 
     def _gait_config(self):
         return dict(period=1.4, swing_height=0.07, foot_phases=[0.0, 0.5, 0.0, 0.5, 0.0, 0.5])     # elspider.py:240-243, gait_scheduler.py:19-26
@@ -61,6 +72,13 @@ class ElSpider(LeggedRobot):
         self.sea_hidden_state_per_env = self.sea_hidden_state.view(2, self.num_envs, self.num_actions, 8)
         self.sea_cell_state_per_env = self.sea_cell_state.view(2, self.num_envs, self.num_actions, 8)
         self.gait_idx = t["gait_idx"]
+
+
+class PoseElSpider(PoseCommandsMixin, ElSpider):
+    """Task `pose_elspider_air_flat` (reference `elspider.py:444-545`, `envs/__init__.py:158`): `PoseAnymal`'s four extra command channels, 70-entry
+    observation and pose-relative `orientation` / `base_height` terms on the hexapod -- the same device layer (`lg_pose_layer_step`, 66 + 4 entries);
+    the task stages the two pose terms themselves (`orientation = [-0.5, -0.5, -3.0]`) and enables the command curriculum (native: the statistics
+    step widens `lin_vel_x` up to `max_curriculum`)."""
 
 
 class LoadAdaptElSpider(ElSpider):

@@ -468,6 +468,7 @@ typedef struct lg_pose_params {
   int32_t only_positive_rewards;
   float max_episode_length_s, clip_observations;
   int32_t num_heights;                   /* height-scan points in the native row (0 without measure_heights) */
+  int32_t num_proprio;                   /* proprioceptive entries of the native row: 12 + 9 x legs (48 | 66; 0 = 48) */
 } lg_pose_params;
 int lg_pose_layer_step(const lg_pose_params* params, int32_t n, float* pose_cmd, int32_t cmd_stride, float* sums, float* extras,
                        const float* nat_obs, const float* nat_rew, const uint8_t* reset, const uint8_t* time_out, const int64_t* eplen_before,

@@ -44,10 +44,10 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
     """Our own config classes, edited exactly as tools/refgen/make_golden.py edited the reference's."""
     case = meta["case"]
     cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
-    student, pose = case.get("cls") == "AnymalStudent", case.get("cls") == "PoseAnymal"
+    student, pose = case.get("cls") == "AnymalStudent", case.get("cls") in ("PoseAnymal", "PoseElSpider")
     if student:
         cfg = AnymalCRoughStudentCfg()
-    if pose:
+    if case.get("cls") == "PoseAnymal":
         cfg = PoseAnymalCFlatCfg()
     if case.get("cfg") == "teacher":
         from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_teacher_config import AnymalCRoughTeacherCfg
@@ -55,11 +55,12 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
     if case.get("cfg") == "anymal_b":
         from extended_legged_gym_amd.envs.anymal_b.anymal_b_config import AnymalBRoughCfg
         cfg = AnymalBRoughCfg()
-    hexapod = case.get("cls") == "ElSpider"
+    hexapod = case.get("cls") in ("ElSpider", "PoseElSpider")
     if hexapod:
         from extended_legged_gym_amd.envs.elspider_air.flat.elspider_air_flat_config import ElSpiderAirFlatCfg
+        from extended_legged_gym_amd.envs.elspider_air.flat.pose_elspider_air_flat_config import PoseElSpiderAirFlatCfg
         from extended_legged_gym_amd.envs.elspider_air.mixed_terrains.elspider_air_rough_config import ElSpiderAirRoughCfg
-        cfg = ElSpiderAirFlatCfg() if case["base"] == "flat" else ElSpiderAirRoughCfg()
+        cfg = PoseElSpiderAirFlatCfg() if pose else ElSpiderAirFlatCfg() if case["base"] == "flat" else ElSpiderAirRoughCfg()
     cfg.env.num_envs = case["num_envs"]
     cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]

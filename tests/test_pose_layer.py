@@ -20,16 +20,23 @@ RTOL, ATOL = 2e-5, 2e-6
 POSE_TERMS = ("orientation", "base_height")
 
 
-def run_case(make_core, to_np, from_np, native_layer=False):
-    z, meta = load_golden("flat_pose")
+GOLDENS = ["flat_pose",              # PoseAnymal (12 joints: 48 + 4 observations)
+           "elspider_flat_pose"]     # PoseElSpider (18 joints: 66 + 4), the same device layer on the six-legged instance
+
+
+def run_case(make_core, to_np, from_np, native_layer=False, golden="flat_pose"):
+    z, meta = load_golden(golden)
     cfg, s = golden_setup(z, meta)
     names = meta["reward_names"]
     native_names = [n for n in names if n not in POSE_TERMS]
-    assert s.reward_names == native_names and s.cfg.num_obs == 48 and cfg.env.num_observations == 52
+    NP = s.cfg.num_obs                        # proprioceptive entries of the native row
+    ND = (NP - 12) // 3
+    assert s.reward_names == native_names and NP == (66 if golden.startswith("elspider") else 48) and cfg.env.num_observations == NP + 4
     assert not s.cfg.only_positive_rewards and cfg.rewards.only_positive_rewards
-    np.testing.assert_array_equal(noise_scale_vec(cfg, 52), z["noise_scale_vec"])
+    np.testing.assert_array_equal(noise_scale_vec(cfg, NP + 4, ND), z["noise_scale_vec"])
     core = make_core(s)
-    par = pose_layer_params(cfg, s.dt, noise_scale_vec(cfg, 52), "cpu")
+    par = pose_layer_params(cfg, s.dt, noise_scale_vec(cfg, NP + 4, ND), "cpu")
+    RS_NOISE = abi.rand_slots(ND)["LG_RS_NOISE"]
     rows = [names.index(n) for n in native_names]
     pose_rows = [names.index(n) for n in POSE_TERMS]
     T, dec, N = z["actions"].shape[0], cfg.control.decimation, meta["num_envs"]
@@ -47,7 +54,7 @@ def run_case(make_core, to_np, from_np, native_layer=False):
         sc[0] = int(z["pre_common_step_counter"][t])
         core.t["step_counters"][...] = from_np(sc)
         core.t["reset_buf"][...] = from_np(z["pre_reset_buf"][t])
-        rand = np.nan_to_num(z["rand"][t], nan=0.0)[:, :abi.LG_RS_NOISE + 48]
+        rand = np.nan_to_num(z["rand"][t], nan=0.0)[:, :RS_NOISE + NP]
         core.t["rand_inject"][...] = from_np(rand)
         for sub in range(dec):
             core.compute_torques(from_np(z["actions"][t]) if sub == 0 else None)
@@ -63,7 +70,7 @@ def run_case(make_core, to_np, from_np, native_layer=False):
                    eplen_before=torch.from_numpy(z["pre_episode_length_buf"][t]), base_z=torch.from_numpy(z["sim_root"][t][:, 2].copy()),
                    projected_gravity=g("projected_gravity"), measured_heights=None)
         up = torch.from_numpy(np.nan_to_num(z["rand_pose"][t], nan=0.0))
-        noise_u = torch.from_numpy(z["rand"][t][:, abi.LG_RS_NOISE:abi.LG_RS_NOISE + 52].copy())
+        noise_u = torch.from_numpy(z["rand"][t][:, RS_NOISE:RS_NOISE + NP + 4].copy())
         if native_layer:          # the library's two launches (lg_pose_layer_step) instead of the torch restatement
             from extended_legged_gym_amd.envs.anymal_c.anymal import pose_layer_step_native
             dv = lambda x: None if x is None else x.cuda().contiguous()      # noqa: E731
@@ -71,7 +78,7 @@ def run_case(make_core, to_np, from_np, native_layer=False):
             nat_d = {k: dv(v) for k, v in nat.items()}
             par_d = dict(par, ranges=par["ranges"].cuda(), noise_scale_vec=par["noise_scale_vec"].cuda())
             acc = torch.zeros(3, dtype=torch.float64, device="cuda")
-            obs_d, rew_d = torch.zeros(N, 52, device="cuda"), torch.zeros(N, device="cuda")
+            obs_d, rew_d = torch.zeros(N, NP + 4, device="cuda"), torch.zeros(N, device="cuda")
             pose_layer_step_native(st_d, nat_d, dv(up), dv(noise_u), par_d, obs_d, rew_d, acc)
             assert float(acc.abs().sum()) == 0.0                       # left clear for the next step
             obs, rew = obs_d.cpu(), rew_d.cpu()
@@ -92,29 +99,32 @@ def run_case(make_core, to_np, from_np, native_layer=False):
             assert torch.isnan(st["extras"]).all()          # no reset in this step: the previous means stay
         # the reward really was clipped somewhere, and the pose terms really matter
         if t == T - 1:
-            assert fresh_seen >= 3
+            assert fresh_seen >= (1 if golden.startswith("elspider") else 3)      # (the hexapod has no contact termination: "trunk" matches no body)
     assert (z["rew"] == 0).any() and (z["rew"] > 0).any()
     core.close()
 
 
-def test_pose_layer_over_the_oracle_matches_the_reference():
+@pytest.mark.parametrize("golden", GOLDENS)
+def test_pose_layer_over_the_oracle_matches_the_reference(golden):
     from oracle.oracle_lib import OracleEnv
-    run_case(OracleEnv, lambda a: a, lambda a: a)
+    run_case(OracleEnv, lambda a: a, lambda a: a, golden=golden)
 
 
 @pytest.mark.gpu
-def test_pose_layer_over_the_hip_step_matches_the_reference():
+@pytest.mark.parametrize("golden", GOLDENS)
+def test_pose_layer_over_the_hip_step_matches_the_reference(golden):
     from extended_legged_gym_amd.native import NativeCore
     run_case(lambda s: NativeCore(s, "cuda:0"), lambda a: a.detach().cpu().numpy(),
-             lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda())
+             lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda(), golden=golden)
 
 
 @pytest.mark.gpu
-def test_native_pose_kernels_match_the_reference():
+@pytest.mark.parametrize("golden", GOLDENS)
+def test_native_pose_kernels_match_the_reference(golden):
     """The same vectors through `lg_pose_layer_step` (csrc/lg_pose.hip), the path the env classes run."""
     from extended_legged_gym_amd.native import NativeCore
     run_case(lambda s: NativeCore(s, "cuda:0"), lambda a: a.detach().cpu().numpy(),
-             lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda(), native_layer=True)
+             lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda(), native_layer=True, golden=golden)
 
 
 @pytest.mark.gpu
@@ -204,3 +214,34 @@ def test_pose_env_on_the_device():
         rb = env.core.t["rigid_body_state"]
         assert torch.equal(rb[keep][:, 0, :3], env.root_states[keep][:, :3])
     assert torch.isfinite(obs).all() and float(env.episode_sums["base_height"].abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_pose_elspider_task_on_the_device():
+    """Task `pose_elspider_air_flat` (reference envs/__init__.py:158): the pose layer on the six-legged instance -- 70 observations with the pose
+    channels at 12:16, the AsyncGaitScheduler term on the default (hexapod) scheduler config, the two pose terms staged over three reward
+    stages, and the command curriculum the task enables (native: the statistics step widens lin_vel_x)."""
+    from tests.test_env_api import make
+    env = make("pose_elspider_air_flat", 64, **{"noise.add_noise": False})
+    assert env.num_obs == 70 and env.num_actions == 18 and env.commands.shape == (64, 8)
+    assert env.setup.cfg.async_num_dof_sets == 4 and "async_gait_scheduler" in env.setup.reward_names
+    assert env.reward_scales["orientation"] == pytest.approx(-0.5 * env.dt) and env.reward_scales["base_height"] == pytest.approx(-8.0 * env.dt)
+    obs, _ = env.reset()
+    assert obs.shape == (64, 70)
+    g = torch.Generator().manual_seed(3)
+    for _ in range(40):
+        obs, _, rew, done, _ = env.step(0.2 * torch.randn(64, 18, generator=g).cuda())
+        assert torch.equal(obs[:, 12:16], env.commands[:, 4:8]) and (rew >= 0).all()
+    assert torch.isfinite(obs).all() and float(env.episode_sums["base_height"].abs().sum()) > 0
+    lo, hi = env.command_ranges["base_height"]
+    assert ((env.commands[:, 7] >= lo) & (env.commands[:, 7] <= hi)).all()
+    # three reward stages: the pose terms' own scales move with the stage (orientation -0.5, -0.5, -3.0; base_height -8, -8, -12)
+    assert env.update_reward_scales(100.0) and env.reward_scales_stage == 1 and "feet_slip" in env.setup.reward_names
+    assert "orientation" not in env.setup.reward_names and "base_height" not in env.setup.reward_names        # ... and stay in the device layer
+    assert env.update_reward_scales(100.0) and env.reward_scales_stage == 2
+    assert env.reward_scales["orientation"] == pytest.approx(-3.0 * env.dt) and env.reward_scales["base_height"] == pytest.approx(-12.0 * env.dt)
+    assert not env.update_reward_scales(100.0)
+    for _ in range(5):
+        obs, _, rew, _, _ = env.step(0.2 * torch.randn(64, 18, generator=g).cuda())
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert env.cfg.commands.curriculum and env.setup.cfg.command_curriculum == 1

@@ -27,6 +27,7 @@ OUT = os.path.join(REPO, "tests", "golden")
 
 # uniform-draw slots (shared with include/lgstep.h: LG_RS_*)
 RS_CMD_CB, RS_PUSH, RS_LEVEL, RS_DOF = 0, 4, 6, 8
+HEXAPOD_CLASSES = ("ElSpider", "PoseElSpider")
 
 
 def rs_tail(nd):
@@ -40,12 +41,12 @@ def build(case):
     from legged_gym.envs import Anymal, AnymalCFlatCfg, AnymalCRoughCfg
     from legged_gym.envs.anymal_c.anymal import AnymalStudent, LoadAdaptAnymal, PoseAnymal, StandAnymal
     from legged_gym.envs import AnymalCRoughStudentCfg, PoseAnymalCFlatCfg
-    from legged_gym.envs import ElSpider, ElSpiderAirFlatCfg, ElSpiderAirRoughCfg
+    from legged_gym.envs import ElSpider, ElSpiderAirFlatCfg, ElSpiderAirRoughCfg, PoseElSpider, PoseElSpiderAirFlatCfg
     Base = {"Anymal": Anymal, "LoadAdaptAnymal": LoadAdaptAnymal, "StandAnymal": StandAnymal,
-            "AnymalStudent": AnymalStudent, "PoseAnymal": PoseAnymal, "ElSpider": ElSpider}[case.get("cls", "Anymal")]
+            "AnymalStudent": AnymalStudent, "PoseAnymal": PoseAnymal, "ElSpider": ElSpider, "PoseElSpider": PoseElSpider}[case.get("cls", "Anymal")]
     import legged_gym.envs.base.legged_robot as LR
 
-    hexapod = case.get("cls") == "ElSpider"
+    hexapod = case.get("cls") in HEXAPOD_CLASSES
     ref_loader.FakeGym.robot = ref_loader.elspider_robot_description() if hexapod else ref_loader.anymal_robot_description()
     N = case["num_envs"]
     cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
@@ -61,6 +62,8 @@ def build(case):
         cfg = AnymalCRoughStudentCfg()
     if case.get("cls") == "PoseAnymal":
         cfg = PoseAnymalCFlatCfg()
+    if case.get("cls") == "PoseElSpider":
+        cfg = PoseElSpiderAirFlatCfg()
     cfg.env.num_envs = N
     cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]
@@ -90,6 +93,8 @@ def build(case):
     LR.torch_rand_float = rand_float
     import legged_gym.envs.anymal_c.anymal as AM
     AM.torch_rand_float = rand_float          # PoseAnymal._resample_commands draws through its own module's name
+    import legged_gym.envs.elspider_air.elspider as EM
+    EM.torch_rand_float = rand_float          # ... and PoseElSpider's through its module's
 
     orig_rand_like, orig_randint_like = torch.rand_like, torch.randint_like
 
@@ -337,7 +342,7 @@ def run_case(case):
                 max_episode_length_s=float(env.max_episode_length_s))
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, f"{'elspider' if case.get('cls') == 'ElSpider' else 'anymal'}_{case['name']}.npz")
+    path = os.path.join(OUT, f"{'elspider' if case.get('cls') in HEXAPOD_CLASSES else 'anymal'}_{case['name']}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", "resets per step:", out["reset"].sum(axis=1))
 
@@ -398,8 +403,17 @@ CASES += [
          scales=dict(ALL_SCALES, feet_slip=-0.1, base_height=-1.0), only_positive_rewards=False),
 ]
 
+# PoseElSpider (elspider.py:444-545): PoseAnymal's layer on 18 joints -- 70 observations, eight command channels; the async-gait term the task scales
+# is switched off here (its constant of the spawn pose is pinned by tests/golden/async_gait.npz)
+CASES += [
+    dict(name="flat_pose", base="flat", cls="PoseElSpider", num_envs=24, steps=8, seed=13, actuator_net=False, push_interval_s=0.06,
+         resampling_time=0.1, heading_command=False, episode_length_s=20,
+         scales=dict(base_height=-1.0, orientation=-0.2, lin_vel_z=-0.1, collision=-0.05, tracking_lin_vel=2.0, tracking_ang_vel=1.0,
+                     action_rate=-0.0005, dof_acc=-2.5e-8, async_gait_scheduler=0.0, feet_slip=0.0)),
+]
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for c in CASES:
-        if not only or c["name"] in only or (("elspider_" if c.get("cls") == "ElSpider" else "anymal_") + c["name"]) in only:
+        if not only or (("elspider_" if c.get("cls") in HEXAPOD_CLASSES else "anymal_") + c["name"]) in only:
             run_case(c)
