@@ -621,7 +621,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   fill_leg_model(lmod, C->lmod, threadIdx.x, blockDim.x);
   if (fuse && wv == 1) for (int i = lane; i < HC_COUNT; i += 64) hot[i] = C->hot[i];
   if (LSTM_LDS && MODE == 0 && net && wv >= 2) for (int i = (wv - 2) * 64 + lane; i < LW_COUNT; i += 128) wlds[i] = wlstm[i];
-  lds_barrier();
+  // With helper waves nobody reads these tables before rendezvous (A) of the first substep (every wave's first use is the kinematics behind it), and
+  // every wave has filled its share before it gets there: (A) stands in for a barrier here, and the helper waves start their first recurrent half
+  // as soon as their own rows have landed instead of waiting for every wave's (A/B: -0.7 % on the step)
+  if (!(MODE == 0 && HELPERS && !LSTM_LDS)) lds_barrier();
 #ifdef LG_STAMPS
   const unsigned long long t_bar0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -634,7 +637,6 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     // present for triangle-mesh terrains) the main wave keeps the torques and barrier (B) does not exist
     float a = net ? pre_act : 0.f;
     a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);
-    const float tgt = a * g.action_scale + lm_.f(LM_DEFAULT_POS + j);
     const size_t N12 = (size_t)C->N * NDOF, row = (size_t)e * NDOF + d;
     float h0[8], c0[8], h1[8], c1[8];
     if (net) {
@@ -716,6 +718,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       }
       if (sub == 0) STAMP(54); else STAMP(42);
       if (net) {
+        const float tgt = a * g.action_scale + lm_.f(LM_DEFAULT_POS + j);      // (the model table: first read behind (A), see the kernel's first barrier)
         const float x0 = (tgt - qq[j]) * g.actuator_in_scale[0], x1 = qdd[j] * g.actuator_in_scale[1];
         // an opaque zero keeps the ~60 weight addresses from being hoisted out of the substep loop as loop invariants
         // (they would fill the SGPR file and spill): inside the loop they fold into the s_load immediate offsets
