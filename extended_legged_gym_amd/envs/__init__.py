@@ -63,3 +63,6 @@ task_registry.register("elspider_air_dialmpc_flat", ElSpiderAirBatchRollout, ElS
 task_registry.register("elspider_air_dialmpc", ElSpiderAirBatchRollout, ElSpiderAirDialMPCCfg(), ElSpiderAirDialMPCCfgPPO())
 from .elspider_air.flat.pose_elspider_air_flat_config import PoseElSpiderAirFlatCfg, PoseElSpiderAirFlatCfgPPO  # noqa: E402
 task_registry.register("pose_elspider_air_flat", PoseElSpider, PoseElSpiderAirFlatCfg(), PoseElSpiderAirFlatCfgPPO())
+from .elspider_air.elspider_raycast import ElSpiderRayCast  # noqa: E402
+from .elspider_air.mixed_terrains.elspider_air_rough_raycast_config import ElSpiderAirRoughRaycastCfg, ElSpiderAirRoughRaycastCfgPPO  # noqa: E402
+task_registry.register("elspider_air_rough_raycast", ElSpiderRayCast, ElSpiderAirRoughRaycastCfg(), ElSpiderAirRoughRaycastCfgPPO())

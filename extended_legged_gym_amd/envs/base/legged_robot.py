@@ -116,7 +116,8 @@ class LeggedRobot(BaseTask):
                                  gait=self._gait_config(), num_extra_obs=self._num_extra_obs(),
                                  reset_z_from_terrain=self._reset_z_from_terrain,
                                  custom_origins=self._custom_origins_rule(), terminate_on_flip=self._terminate_on_flip,
-                                 reward_term_variants=self.reward_term_variants, reward_class=self.reward_class)
+                                 reward_term_variants=self.reward_term_variants, reward_class=self.reward_class,
+                                 noise_layout_dof=self._noise_layout_dof)
         self.core = NativeCore(self.setup, self.device)
         t = self.core.t
 
@@ -149,6 +150,7 @@ class LeggedRobot(BaseTask):
     reward_class = "base"           # "stand": the StandAnymal / StandGo2 overrides (enum lg_reward_class)
     reward_term_variants = {}        # cfg.rewards.scales name -> native term for classes that override a `_reward_*`
     _terminate_on_flip = False       # AnymalCBatchRollout: an upside-down robot ends the episode
+    _noise_layout_dof = None         # ElSpiderRayCast: the base class's twelve-joint noise-vector layout on an 18-joint robot
     _reset_z_from_terrain = False    # RobotBatchRollout: root z from the height sample under the reset position
 
     def _gait_config(self):

@@ -184,7 +184,7 @@ class NativeSetup:
 
     def __init__(self, cfg, sim_params, model, terrain=None, seed=0, rng_mode=abi.LG_RNG_PHILOX, gait=None,
                  reward_stage=None, num_extra_obs=0, reset_z_from_terrain=False,
-                 custom_origins=None, terminate_on_flip=False, reward_term_variants=None, reward_class="base"):
+                 custom_origins=None, terminate_on_flip=False, reward_term_variants=None, reward_class="base", noise_layout_dof=None):
         self.model_dict = model
         self.model = model_struct(model)
         dt = cfg.control.decimation * sim_params.dt
@@ -236,7 +236,9 @@ class NativeSetup:
         c.obs_scale_lin_vel, c.obs_scale_ang_vel, c.obs_scale_dof_pos = os_.lin_vel, os_.ang_vel, os_.dof_pos
         c.obs_scale_dof_vel, c.obs_scale_height = os_.dof_vel, os_.height_measurements
         c.measure_heights, c.add_noise = int(cfg.terrain.measure_heights), int(cfg.noise.add_noise)
-        self.noise_scale_vec = noise_scale_vec(cfg, num_obs, nd)
+        # (noise_layout_dof: a class that inherits `_get_noise_scale_vec` from the twelve-joint base class on another robot -- ElSpiderRayCast --
+        #  gets that vector's block boundaries, misaligned as they are there)
+        self.noise_scale_vec = noise_scale_vec(cfg, num_obs, nd if noise_layout_dof is None else int(noise_layout_dof))
         c.noise_scale_vec = self.noise_scale_vec.ctypes.data_as(C.POINTER(C.c_float))
         self.height_points = height_points(cfg) if cfg.terrain.measure_heights else np.zeros((0, 2), np.float32)
         c.num_height_points = self.height_points.shape[0]

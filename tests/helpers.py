@@ -18,7 +18,8 @@ from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_CASES = ["flat_pd", "flat_lstm", "rough_lstm", "rough_allrew", "flat_loadadapt", "flat_stand", "rough_student", "rough_teacher", "rough_anymal_b"]
 # recorded from the reference's `ElSpider.step()` (six legs: the lg6 instance of the kernels, which ends its step in post_kernel)
-HEXAPOD_GOLDEN_CASES = ["elspider_flat_lstm", "elspider_rough_allrew"]
+HEXAPOD_GOLDEN_CASES = ["elspider_flat_lstm", "elspider_rough_allrew",
+                        "elspider_raycast_allrew"]     # ElSpiderRayCast with its sensors off: ElSpider's pieces restated + the base class's twelve-joint noise layout
 CLASS_VARIANTS = {"LoadAdaptAnymal": {"orientation": "orientation_load_adapt"}}   # = LoadAdaptAnymal.reward_term_variants
 CLASS_REWARD_CLASS = {"StandAnymal": "stand"}                                        # = StandAnymal.reward_class
 ANYMAL_GAIT = dict(period=0.6, swing_height=0.15, foot_phases=[0.0, 0.5, 0.5, 0.0])   # anymal.py:59-63
@@ -55,12 +56,17 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
     if case.get("cfg") == "anymal_b":
         from extended_legged_gym_amd.envs.anymal_b.anymal_b_config import AnymalBRoughCfg
         cfg = AnymalBRoughCfg()
-    hexapod = case.get("cls") in ("ElSpider", "PoseElSpider")
+    hexapod = case.get("cls") in ("ElSpider", "PoseElSpider", "ElSpiderRayCast")
+    raycast = case.get("cls") == "ElSpiderRayCast"
     if hexapod:
         from extended_legged_gym_amd.envs.elspider_air.flat.elspider_air_flat_config import ElSpiderAirFlatCfg
         from extended_legged_gym_amd.envs.elspider_air.flat.pose_elspider_air_flat_config import PoseElSpiderAirFlatCfg
         from extended_legged_gym_amd.envs.elspider_air.mixed_terrains.elspider_air_rough_config import ElSpiderAirRoughCfg
         cfg = PoseElSpiderAirFlatCfg() if pose else ElSpiderAirFlatCfg() if case["base"] == "flat" else ElSpiderAirRoughCfg()
+        if raycast:
+            from extended_legged_gym_amd.envs.elspider_air.mixed_terrains.elspider_air_rough_raycast_config import ElSpiderAirRoughRaycastCfg
+            cfg = ElSpiderAirRoughRaycastCfg()
+            cfg.raycaster.enable_raycast, cfg.depth.camera_type, cfg.env.num_observations, cfg.terrain.mesh_type = False, None, 66, "plane"
     cfg.env.num_envs = case["num_envs"]
     cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]
@@ -87,7 +93,8 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
     # PoseAnymal: the native step runs without the two pose terms, the clip and the noise (anymal.py:pose_native_cfg)
     with (teacher_row_cfg(cfg) if student else pose_native_cfg(cfg) if pose else contextlib.nullcontext()):
         setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ELSPIDER_GAIT if hexapod else ANYMAL_GAIT,
-                            terminate_on_flip=hexapod,                                  # ElSpider.check_termination (elspider.py:339-346)
+                            terminate_on_flip=hexapod,                                  # ElSpider.check_termination (elspider.py:339-346; elspider_raycast.py:296-303)
+                            noise_layout_dof=12 if raycast else None,                    # = ElSpiderRayCast._noise_layout_dof
                             reward_term_variants=CLASS_VARIANTS.get(case.get("cls", "Anymal")),
                             reward_class=CLASS_REWARD_CLASS.get(case.get("cls", "Anymal"), "base"))
     return cfg, setup

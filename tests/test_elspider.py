@@ -345,3 +345,32 @@ def test_registered_task_and_the_reference_policy_on_the_hip_env():
     env.core.close()
     check_walk(stats)
     assert 0.24 < float(bz[SETTLE:].mean()) < 0.31
+
+
+@pytest.mark.gpu
+def test_elspider_raycast_task_on_the_device():
+    """Task `elspider_air_rough_raycast` (reference envs/__init__.py:155-156): the hexapod on the confined two-layer mesh with 512 spherical rays
+    appended to the observation (66 + 512) and the ray-cast depth camera; reward stage 2 from the start (`reward_min_stage = 2`); the
+    base class's twelve-joint noise layout on the 66-entry row (golden `elspider_raycast_allrew` pins the class with its sensors off)."""
+    import torch
+    from tests.test_env_api import make
+    with pytest.raises(IndexError, match="confined_terrain_proportions"):           # as shipped the tile proportions sum to 0.8: the reference's generator
+        make("elspider_air_rough_raycast", 16)                                        # indexes past the list for the rest (24 random tiles: 99.5 % of the builds)
+    env = make("elspider_air_rough_raycast", 64, **{"terrain.num_rows": 2, "terrain.num_cols": 3, "terrain.confined_terrain_proportions": [0.0, 0.2, 0.4, 0.4]})
+    assert env.num_obs == 66 + 512 and env.num_actions == 18 and env.setup.cfg.terminate_on_flip == 1
+    assert env.reward_scales_stage == 2 and env.setup.cfg.async_num_dof_sets == 4
+    names = env.setup.reward_names
+    assert "orientation" not in names and "base_height" not in names and "feet_contact_forces" in names      # stage-2 scales: the first two are 0 there
+    nv = env.noise_scale_vec.cpu().numpy()
+    assert nv[12:24].min() > 0 and nv[24:36].min() > 0 and not nv[36:66].any() and not nv[66:].any()           # twelve-joint blocks on the 18-joint row
+    obs, _ = env.reset()
+    assert obs.shape == (64, 578)
+    g = torch.Generator().manual_seed(4)
+    for _ in range(20):
+        obs, _, rew, done, _ = env.step(0.2 * torch.randn(64, 18, generator=g).cuda())
+    rays = obs[:, 66:]
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and float(rays.std()) > 0.01 and float(rays.min()) >= 0.0
+    d = env.get_depth_images()
+    assert tuple(d.shape) == (64, 2, 28, 56) and torch.isfinite(d).all() and float(d.std()) > 0.0
+    assert float(env.root_states[:, 2].min()) > 0.05
+    env.core.close()

@@ -27,7 +27,7 @@ OUT = os.path.join(REPO, "tests", "golden")
 
 # uniform-draw slots (shared with include/lgstep.h: LG_RS_*)
 RS_CMD_CB, RS_PUSH, RS_LEVEL, RS_DOF = 0, 4, 6, 8
-HEXAPOD_CLASSES = ("ElSpider", "PoseElSpider")
+HEXAPOD_CLASSES = ("ElSpider", "PoseElSpider", "ElSpiderRayCast")
 
 
 def rs_tail(nd):
@@ -43,7 +43,11 @@ def build(case):
     from legged_gym.envs import AnymalCRoughStudentCfg, PoseAnymalCFlatCfg
     from legged_gym.envs import ElSpider, ElSpiderAirFlatCfg, ElSpiderAirRoughCfg, PoseElSpider, PoseElSpiderAirFlatCfg
     Base = {"Anymal": Anymal, "LoadAdaptAnymal": LoadAdaptAnymal, "StandAnymal": StandAnymal,
-            "AnymalStudent": AnymalStudent, "PoseAnymal": PoseAnymal, "ElSpider": ElSpider, "PoseElSpider": PoseElSpider}[case.get("cls", "Anymal")]
+            "AnymalStudent": AnymalStudent, "PoseAnymal": PoseAnymal, "ElSpider": ElSpider, "PoseElSpider": PoseElSpider}
+    if case.get("cls") == "ElSpiderRayCast":
+        from legged_gym.envs import ElSpiderRayCast
+        Base["ElSpiderRayCast"] = ElSpiderRayCast
+    Base = Base[case.get("cls", "Anymal")]
     import legged_gym.envs.base.legged_robot as LR
 
     hexapod = case.get("cls") in HEXAPOD_CLASSES
@@ -64,6 +68,10 @@ def build(case):
         cfg = PoseAnymalCFlatCfg()
     if case.get("cls") == "PoseElSpider":
         cfg = PoseElSpiderAirFlatCfg()
+    if case.get("cls") == "ElSpiderRayCast":      # the class's own task config with the sensors off (they need Warp) and a plane under the robot
+        from legged_gym.envs import ElSpiderAirRoughRaycastCfg
+        cfg = ElSpiderAirRoughRaycastCfg()
+        cfg.raycaster.enable_raycast, cfg.depth.camera_type, cfg.env.num_observations, cfg.terrain.mesh_type = False, None, 66, "plane"
     cfg.env.num_envs = N
     cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]
@@ -410,6 +418,14 @@ CASES += [
          resampling_time=0.1, heading_command=False, episode_length_s=20,
          scales=dict(base_height=-1.0, orientation=-0.2, lin_vel_z=-0.1, collision=-0.05, tracking_lin_vel=2.0, tracking_ang_vel=1.0,
                      action_rate=-0.0005, dof_acc=-2.5e-8, async_gait_scheduler=0.0, feet_slip=0.0)),
+]
+
+# ElSpiderRayCast (elspider_raycast.py:24-303) with its sensors off (they need Warp): the class restates ElSpider's pieces on top of LeggedRobotDepth
+# but keeps the base class's twelve-joint noise vector on the 66-entry row
+CASES += [
+    dict(name="raycast_allrew", base="flat", cls="ElSpiderRayCast", num_envs=24, steps=6, seed=14, actuator_net=True, push_interval_s=0.06,
+         resampling_time=0.1, heading_command=False, episode_length_s=20,
+         scales=dict(ALL_SCALES, feet_slip=-0.1, base_height=-1.0, async_gait_scheduler=0.0), only_positive_rewards=False),
 ]
 
 if __name__ == "__main__":
