@@ -786,6 +786,133 @@ LG_DEV void fetch_mass_factors(const float* xs, int lane, float Mi[6], float Mbk
   for (int i = 0; i < 21; ++i) Si[i] = rec[42 + i];
 }
 
+// Layout of a lane's record (floats): everything the helper waves' slot set-up multiplies PAIRWISE sits in (even, odd) pairs, so that a
+// ds_read_b128 delivers two operands of a v_pk_fma_f32 each:
+//   0..5  Mi (3 x 3 symmetric, packed) | 6, 7 unused
+//   8 + 2 (3 j + p)   (Mbk[2p][j], Mbk[2p+1][j])           j = 0..2 joints, p = 0..2 pairs of base coordinates
+//   26 + 2 a          (Y[0][a], Y[1][a])                    a = 0..5
+//   38 + a            Y[2][a]
+//   44 + 2 (3 b + p)  (S^-1[2p][b], S^-1[2p+1][b])          the full symmetric 6 x 6, column b in three pairs
+// (heightfield / plane instances; the triangle-mesh instances keep the scalar record below: their LDS has no room for the 16 extra dwords per lane)
+#define XS_FIELDS_PK 80
+#define XS_STRIDE_PK 84   // dwords per lane: 16-B aligned rows, 21 (odd) 16-B units -> conflict-free ds_read/write_b128
+struct MassFactorsP { float Mi[6]; pk2 Mbk[3][3]; pk2 Y01[6]; float Y2[6]; pk2 Si[6][3]; };
+LG_DEV void publish_mass_factors_pk(float* xs, int lane, const float Mi[6], const float Mbk[6][3], const float Y[3][6], const float Si[21]) {
+  float rec[XS_FIELDS_PK];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) rec[i] = Mi[i];
+  rec[6] = 0.f; rec[7] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) { rec[8 + 2 * (3 * j + pp)] = Mbk[2 * pp][j]; rec[8 + 2 * (3 * j + pp) + 1] = Mbk[2 * pp + 1][j]; }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) { rec[26 + 2 * a] = Y[0][a]; rec[26 + 2 * a + 1] = Y[1][a]; rec[38 + a] = Y[2][a]; }
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) {
+      const int r0 = 2 * pp, r1 = 2 * pp + 1;
+      rec[44 + 2 * (3 * b + pp)] = r0 >= b ? Si[LT(r0, b)] : Si[LT(b, r0)];
+      rec[44 + 2 * (3 * b + pp) + 1] = r1 >= b ? Si[LT(r1, b)] : Si[LT(b, r1)];
+    }
+  float4* p = reinterpret_cast<float4*>(xs + lane * XS_STRIDE_PK);
+#pragma unroll
+  for (int i = 0; i < XS_FIELDS_PK / 4; ++i) p[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+}
+LG_DEV void fetch_mass_factors_pk(const float* xs, int lane, MassFactorsP& F) {
+  float rec[XS_FIELDS_PK];
+  const float4* p = reinterpret_cast<const float4*>(xs + lane * XS_STRIDE_PK);
+#pragma unroll
+  for (int i = 0; i < XS_FIELDS_PK / 4; ++i) { float4 v = p[i]; rec[4 * i] = v.x; rec[4 * i + 1] = v.y; rec[4 * i + 2] = v.z; rec[4 * i + 3] = v.w; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) F.Mi[i] = rec[i];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) { F.Mbk[j][pp].x = rec[8 + 2 * (3 * j + pp)]; F.Mbk[j][pp].y = rec[8 + 2 * (3 * j + pp) + 1]; }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) { F.Y01[a].x = rec[26 + 2 * a]; F.Y01[a].y = rec[26 + 2 * a + 1]; F.Y2[a] = rec[38 + a]; }
+#pragma unroll
+  for (int b = 0; b < 6; ++b)
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) { F.Si[b][pp].x = rec[44 + 2 * (3 * b + pp)]; F.Si[b][pp].y = rec[44 + 2 * (3 * b + pp) + 1]; }
+}
+
+// contact_setup_slot on packed fp32 (the helper waves' form: their factors come from LDS already paired).  Same quantities and the same
+// record as the scalar form above (which stays for the main wave, whose factors live in scalar registers); the sums are formed in another
+// order, so the two agree to rounding (1e-7 relative), not bit for bit.  ~290 instead of ~450 instructions per slot.
+LG_DEV void contact_setup_slot_pk(int sl, const LegModel& lm_, const LegKin& k, V3 pb, const MassFactorsP& F, float cfm, int fric, float* cst, int lane) {
+  const int ncp = lm_.i(LM_CP_COUNT);
+  int lk = -1;
+  if (sl < ncp) { int link = lm_.i(LM_CP_LINK + sl); lk = link < 0 ? -1 : (link > 2 ? 2 : link); }
+  const float4 n4 = CS4(sl, 0), r4 = CS4(sl, 1);
+  const V3 n = v3(n4.x, n4.y, n4.z), r = v3(r4.x, r4.y, r4.z);
+  const V3 p = r + pb;
+  float out[CF_FIELDS - CF_SETUP];
+#define OUT(f) out[(f) - CF_SETUP]
+  V3 a0 = fabsf(n.x) < 0.57735f ? v3(1, 0, 0) : v3(0, 1, 0);
+  V3 t1 = cross(a0, n); t1 = __builtin_amdgcn_rsqf(dot(t1, t1)) * t1;
+  V3 t2 = cross(n, t1);
+  V3 jk[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) jk[j] = j <= lk ? cross(k.ax[j], p - k.O[j]) : v3(0, 0, 0);
+  const V3 dirs[3] = {n, t1, t2};
+  pk2 J[3][3], jk01[3], Wb[3][3], Wk01[3]; float jk2[3], Wk2[3];       // per direction: the base row (d, r x d) in pairs, the joint row, the responses
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const V3 d = dirs[c], rd = cross(r, d);
+    J[c][0].x = d.x; J[c][0].y = d.y; J[c][1].x = d.z; J[c][1].y = rd.x; J[c][2].x = rd.y; J[c][2].y = rd.z;
+    const float jkv[3] = {dot(jk[0], d), dot(jk[1], d), dot(jk[2], d)};
+    jk01[c].x = jkv[0]; jk01[c].y = jkv[1]; jk2[c] = jkv[2];
+    float z[3];
+    sym3_mul(F.Mi, jkv, z);
+    pk2 g[3] = {J[c][0], J[c][1], J[c][2]};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) g[pp] = pk_fma(-F.Mbk[j][pp], pk_splat(z[j]), g[pp]);
+    pk2 w[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const float gb = (b & 1) ? g[b >> 1].y : g[b >> 1].x;
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) w[pp] = pk_fma(F.Si[b][pp], pk_splat(gb), w[pp]);
+    }
+    pk2 wk = {z[0], z[1]}; float wk2 = z[2];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const float wa = (a & 1) ? w[a >> 1].y : w[a >> 1].x;
+      wk = pk_fma(-F.Y01[a], pk_splat(wa), wk);
+      wk2 -= F.Y2[a] * wa;
+    }
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) { Wb[c][pp] = w[pp]; OUT(CF_WB + 6 * c + 2 * pp) = w[pp].x; OUT(CF_WB + 6 * c + 2 * pp + 1) = w[pp].y; }
+    Wk01[c] = wk; Wk2[c] = wk2;
+    OUT(CF_ZCP + 2 * c) = z[0]; OUT(CF_ZCP + 2 * c + 1) = z[1]; OUT(CF_ZC2 + c) = z[2];
+  }
+  // A[b][c] = J_b . W_c over the base coordinates and the leg's joints
+  auto Aij = [&](int b, int c) {
+    pk2 acc = J[b][0] * Wb[c][0];
+    acc = pk_fma(J[b][1], Wb[c][1], acc); acc = pk_fma(J[b][2], Wb[c][2], acc); acc = pk_fma(jk01[b], Wk01[c], acc);
+    return acc.x + acc.y + jk2[b] * Wk2[c];
+  };
+  const float A00 = Aij(0, 0), A10 = Aij(1, 0), A20 = Aij(2, 0), A11 = Aij(1, 1), A12 = Aij(1, 2), A22 = Aij(2, 2);
+  OUT(CF_T12) = t1.x; OUT(CF_T12 + 1) = t2.x; OUT(CF_T12 + 2) = t1.y; OUT(CF_T12 + 3) = t2.y; OUT(CF_T12 + 4) = t1.z; OUT(CF_T12 + 5) = t2.z;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { OUT(CF_JK0 + 3 * j) = jk[j].x; OUT(CF_JK0 + 3 * j + 1) = jk[j].y; OUT(CF_JK0 + 3 * j + 2) = jk[j].z; }
+  const float a11 = A11 + cfm, a12 = A12, a22 = A22 + cfm;
+  const float idet = frcp(a11 * a22 - a12 * a12);
+  CS4(sl, 2) = make_float4(0.f, frcp(A00 + cfm), 0.f, 0.f);
+  OUT(CF_AN12) = A10; OUT(CF_AN12 + 1) = A20;
+  const bool pyr = fric != LG_FRICTION_CONE;
+  OUT(CF_B) = pyr ? frcp(a11) : a22 * idet; OUT(CF_B + 1) = pyr ? a12 : -a12 * idet; OUT(CF_B + 2) = pyr ? a12 : -a12 * idet; OUT(CF_B + 3) = pyr ? frcp(a22) : a11 * idet;
+#undef OUT
+  float4* dst = reinterpret_cast<float4*>(&CS(sl, CF_SETUP));
+#pragma unroll
+  for (int i = 0; i < (CF_FIELDS - CF_SETUP) / 4; ++i) dst[i] = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+}
+
 // One physics step of length P.dt for the env this quad owns.  tau_fn(tau[3]) delivers this leg's joint torques; it is
 // called after everything that does not depend on them (kinematics, bias, mass matrix, contact set-up).
 // fbody[5] (optional) receives the net contact force on {base (already quad-summed), link0, link1, link2, foot}.
@@ -873,7 +1000,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   }
   float Si[21];
   spd6_inverse_from_chol(L, Si);
-  if (share.n > 1) publish_mass_factors(xs, lane, Mi, Mbk, Y, Si);
+  if (share.n > 1) { if (TMESH) publish_mass_factors(xs, lane, Mi, Mbk, Y, Si); else publish_mass_factors_pk(xs, lane, Mi, Mbk, Y, Si); }
 
   STAMP(3);
   // ---------------------------------------------------------------- leg bias + contact detection: helper waves or inline
@@ -967,10 +1094,22 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     jl_any |= jl_act[j];
   }
   const bool jl_wave = __ballot(jl_any) != 0ull;
-  // (skipping, wave-uniformly, the rows no lane needs was measured: +2 us on the kernel -- the branches cost more than the rows)
+  // joint j's row is set up and relaxed only when some lane of the wave is near that joint's limit (wave-uniform): a robot whose hip-flexion and knee
+  // joints are continuous (ANYmal) never pays for two of the three rows -- ~60 instructions each per pass of the sweeps
+  bool jl_jw[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) jl_jw[j] = __ballot(jl_act[j]) != 0ull;
   if (jl_wave) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
+      if (!jl_jw[j]) {
+        jl_iA[j] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) jl_Wb[j][a] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) jl_y[j][a] = 0.f;
+        continue;
+      }
       float ej[3] = {j == 0 ? jl_sgn[j] : 0.f, j == 1 ? jl_sgn[j] : 0.f, j == 2 ? jl_sgn[j] : 0.f};
       sym3_mul(Mi, ej, jl_y[j]);
       float gvec[6];
@@ -1114,6 +1253,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
         const float dqs[3] = {dqK01.x, dqK01.y, dqK2};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {           // joint j of the four legs together, like a contact slot
+          if (!jl_jw[j]) continue;
           const float u = jl_sgn[j] * vKs[j];
           const float gap = fmaf(tgsf * jl_sgn[j], dqs[j], jl_gap[j]);
           const float bn = gap >= 0.f ? -gap * ih : fminf(-gap * erp_ih, 10.f);

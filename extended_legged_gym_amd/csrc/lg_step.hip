@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ __attribute__((aligned(16))) float xst[64][20];
   __shared__ float xtau[3][64];
   __shared__ __attribute__((aligned(16))) float xbias[64][12];   // leg bias of wave 1: [lane][bk 3 | Fs 3 | Ns 3 | pad], three 16-byte units
-  __shared__ __attribute__((aligned(16))) float xs[XS_STRIDE * 64];              // main wave's mass-matrix factors for the helpers' share of the contact set-up
+  __shared__ __attribute__((aligned(16))) float xs[(TMESH ? XS_STRIDE : XS_STRIDE_PK) * 64];              // main wave's mass-matrix factors for the helpers' share of the contact set-up
   __shared__ float cqc[TMESH ? LG_MAX_CP * 4 * 64 : 1];   // mesh terrains: last closest-point query of every collision sphere
   __shared__ int s_last_f;                                 // fused step: this workgroup is the last of the launch to arrive
   __shared__ __attribute__((aligned(16))) float hot[(HC_COUNT + 3) & ~3];                          // fused step: the scalars of the post-physics tail (HC_*)
@@ -736,16 +736,18 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (sub == 0) STAMP(56); else STAMP(44);
       // this wave's share of the contact set-up (every fourth active slot)
       {
+        MassFactorsP MF;
         float Mi[6], Mbk[6][3], Y[3][6], Si[21];
         const unsigned slot_mask = active_slot_mask(cst, lane);
         if (slot_mask) {
-          fetch_mass_factors(xs, lane, Mi, Mbk, Y, Si);
+          if (TMESH) fetch_mass_factors(xs, lane, Mi, Mbk, Y, Si); else fetch_mass_factors_pk(xs, lane, MF);
           int seen = 0;
 #pragma unroll 1
           for (int sl = 0; sl < LG_MAX_CP; ++sl) {
             if (!((slot_mask >> sl) & 1u)) continue;
             if ((seen++ & 3) != wv - 1) continue;       // set-up order: waves 1, 2, 3, then the main wave (A/B: -1.9 us on the kernel)
-            contact_setup_slot(sl, lm_, k, pb, Mi, Mbk, Y, Si, P.cfm, P.fric, cst, lane);
+            if (TMESH) contact_setup_slot(sl, lm_, k, pb, Mi, Mbk, Y, Si, P.cfm, P.fric, cst, lane);
+            else contact_setup_slot_pk(sl, lm_, k, pb, MF, P.cfm, P.fric, cst, lane);
           }
         }
       }
