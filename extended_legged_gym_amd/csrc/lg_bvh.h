@@ -32,6 +32,10 @@ struct lg_mesh {
   BvhNode4* d_nodes = nullptr;
   float4* d_tris = nullptr;            // 3 float4 per triangle: v0, v1, v2 (w unused)
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};   // bounding box of the mesh
+  // ray lattice (rays only; built by lg_mesh_create when the vertices sit on a rectilinear lattice in x and y, i.e. a heightfield-derived mesh)
+  float* d_gxb = nullptr; float* d_gyb = nullptr; int gnx = 0, gny = 0;   // cell boundaries: gnx + 1 and gny + 1 ascending coordinates
+  int4* d_gcells = nullptr;            // per cell (iy * gnx + ix): first triangle of its run in d_gtris, count, min z, max z (float bits)
+  float4* d_gtris = nullptr;           // triangles in cell order (a triangle that overlaps k cells is stored k times)
   float4* d_sdf_cache = nullptr;       // lg_sdf_bodies_update: last closest surface point per query slot (xyz, w = 1 when set)
   int64_t sdf_cache_n = 0;
   std::string err;
@@ -128,6 +132,89 @@ LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
       }
     }
     if (!pop()) done = true;
+  }
+  return hit ? best : -1.f;
+}
+
+// ---- ray lattice: closest hit by walking the cells of a rectilinear xy lattice under the ray (heightfield-derived meshes)
+// A tree walk costs a ray ~15 node visits of seven 16-byte loads and ~110 instructions each; the vertices of a heightfield mesh sit on a lattice
+// (also the ones the slope correction moved: they land on the neighbouring lattice line), so "which triangles can the ray meet while it is over
+// cell (ix, iy)" is a table: one 16-byte record per cell (run of triangles whose xy extent overlaps the cell, their z range).  The walk visits
+// the cells in the order the ray crosses them, skips a cell whose z range the ray does not reach while it is over it, and tests the listed
+// triangles with the SAME arithmetic as trace_ray, so a hit has the same t, bit for bit.  It stops one cell AFTER the cell a hit was found in:
+// the cell the walk believes the ray is in and the cell the hit point really lies in can differ by rounding at the line between two cells.
+struct RayGrid { const float* __restrict__ xb; const float* __restrict__ yb; int nx, ny; const int4* __restrict__ cells; const float4* __restrict__ tris; };
+LG_DEV int raygrid_locate(const float* b, int n, float x, int guess) {
+  int i = guess < 0 ? 0 : (guess > n - 1 ? n - 1 : guess);
+  while (i > 0 && x < b[i]) --i;
+  while (i < n - 1 && x >= b[i + 1]) ++i;
+  return i;
+}
+// xb, yb: the boundary tables (the kernels copy them to LDS: one dependent read per cell crossed)
+LG_DEV float trace_ray_grid(const RayGrid& G, const float* xb, const float* yb, V3 o, V3 d, float max_dist) {
+  const V3 inv = v3(1.f / (fabsf(d.x) > 1e-12f ? d.x : copysignf(1e-12f, d.x)), 1.f / (fabsf(d.y) > 1e-12f ? d.y : copysignf(1e-12f, d.y)),
+                    1.f / (fabsf(d.z) > 1e-12f ? d.z : copysignf(1e-12f, d.z)));
+  // the part of the ray over the lattice
+  float t0 = 0.f, t1 = max_dist;
+  {
+    const float ax = (xb[0] - o.x) * inv.x, bx = (xb[G.nx] - o.x) * inv.x, ay = (yb[0] - o.y) * inv.y, by = (yb[G.ny] - o.y) * inv.y;
+    t0 = fmaxf(t0, fmaxf(fminf(ax, bx), fminf(ay, by)));
+    t1 = fminf(t1, fminf(fmaxf(ax, bx), fmaxf(ay, by)));
+  }
+  if (!(t0 <= t1)) return -1.f;
+  const float px = o.x + t0 * d.x, py = o.y + t0 * d.y;
+  const float ux = (float)G.nx / (xb[G.nx] - xb[0]), uy = (float)G.ny / (yb[G.ny] - yb[0]);
+  int ix = raygrid_locate(xb, G.nx, px, (int)((px - xb[0]) * ux)), iy = raygrid_locate(yb, G.ny, py, (int)((py - yb[0]) * uy));
+  const int sx = inv.x >= 0.f ? 1 : -1, sy = inv.y >= 0.f ? 1 : -1;
+  float tmx = (xb[ix + (sx > 0 ? 1 : 0)] - o.x) * inv.x, tmy = (yb[iy + (sy > 0 ? 1 : 0)] - o.y) * inv.y;
+  float best = max_dist; bool hit = false;
+  float tcur = t0;
+  // "while-while", like the tree walk: every lane skips cells until it stands on one whose z range it reaches (or its ray is over), THEN the wave
+  // tests triangles together -- with the test inside the walk, nearly every step of the wave had some lane in the (long, load-bound) triangle loop
+  bool done = false;
+  while (!done) {
+    int4 c = make_int4(0, 0, 0, 0);
+    bool cand = false;
+    float tnext = 0.f;
+    while (!done && !cand) {
+      tnext = fminf(tmx, tmy);
+      const float tend = fminf(tnext, t1);
+      c = G.cells[(size_t)iy * G.nx + ix];
+      // z reached while over the cell (a little beyond either end: the ends are rounded)
+      const float pad = 1e-5f * (fabsf(tend) + fabsf(tcur)) + 1e-6f;
+      const float za = o.z + (tcur - pad) * d.z, zb = o.z + (tend + pad) * d.z;
+      cand = c.y > 0 && !(fminf(za, zb) > __int_as_float(c.w) || fmaxf(za, zb) < __int_as_float(c.z));
+      if (!cand) {
+        // found before this cell began: every cell the hit point can lie in has been seen; or the ray ends / leaves the lattice in this cell
+        if ((hit && best <= tcur) || !(tnext < t1)) done = true;
+        else if (tmx <= tmy) { ix += sx; if (ix < 0 || ix >= G.nx) done = true; else tmx = (xb[ix + (sx > 0 ? 1 : 0)] - o.x) * inv.x; }
+        else { iy += sy; if (iy < 0 || iy >= G.ny) done = true; else tmy = (yb[iy + (sy > 0 ? 1 : 0)] - o.y) * inv.y; }
+        tcur = tnext;
+      }
+    }
+    if (cand) {
+      for (int i = 0; i < c.y; ++i) {
+        const float4* T = G.tris + (size_t)(c.x + i) * 3;
+        float4 a = T[0], b = T[1], cc = T[2];
+        V3 v0 = v3(a.x, a.y, a.z), e1 = v3(b.x - a.x, b.y - a.y, b.z - a.z), e2 = v3(cc.x - a.x, cc.y - a.y, cc.z - a.z);
+        V3 p = cross(d, e2);
+        float det = dot(e1, p);
+        if (fabsf(det) < 1e-20f) continue;
+        float idet = 1.f / det;
+        V3 s = o - v0;
+        float u = dot(s, p) * idet;
+        if (u < 0.f || u > 1.f) continue;
+        V3 q = cross(s, e1);
+        float v = dot(d, q) * idet;
+        if (v < 0.f || u + v > 1.f) continue;
+        float t = dot(e2, q) * idet;
+        if (t >= 0.f && t <= best) { best = t; hit = true; }
+      }
+      if ((hit && best <= tcur) || !(tnext < t1)) done = true;
+      else if (tmx <= tmy) { ix += sx; if (ix < 0 || ix >= G.nx) done = true; else tmx = (xb[ix + (sx > 0 ? 1 : 0)] - o.x) * inv.x; }
+      else { iy += sy; if (iy < 0 || iy >= G.ny) done = true; else tmy = (yb[iy + (sy > 0 ? 1 : 0)] - o.y) * inv.y; }
+      tcur = tnext;
+    }
   }
   return hit ? best : -1.f;
 }

@@ -13,8 +13,10 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -121,17 +123,87 @@ struct Collapser {
     return me;
   }
 };
+
+// ---- ray lattice (lg_bvh.h: trace_ray_grid).  Built when the triangle vertices sit on a rectilinear lattice: few distinct x and y values compared
+// with the number of triangles (a heightfield mesh of R x C vertices has R and C of them, slope-corrected or not).  Cell (ix, iy) is
+// [xb[ix], xb[ix+1]] x [yb[iy], yb[iy+1]] between consecutive distinct coordinates, so every triangle edge lies ON cell lines and a triangle is listed
+// exactly in the cells its xy bounding box overlaps with positive area (a box of zero width -- a vertical face -- in the cells on both sides of its line).
+struct RayGridHost {
+  std::vector<float> xb, yb; std::vector<int4> cells; std::vector<float4> tris;
+  bool build(const std::vector<BuildTri>& t) {
+    const size_t T = t.size();
+    std::vector<float> xs, ys; xs.reserve(3 * T); ys.reserve(3 * T);
+    for (const BuildTri& b : t) for (int v = 0; v < 3; ++v) { xs.push_back(b.v[3 * v]); ys.push_back(b.v[3 * v + 1]); }
+    for (const BuildTri& b : t) for (int k = 0; k < 9; ++k) if (!std::isfinite(b.v[k])) return false;
+    std::sort(xs.begin(), xs.end()); xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
+    std::sort(ys.begin(), ys.end()); ys.erase(std::unique(ys.begin(), ys.end()), ys.end());
+    if (xs.size() < 2 || ys.size() < 2 || xs.size() + ys.size() > 6000) return false;        // the boundary tables must fit LDS next to a depth image
+    const size_t nx = xs.size() - 1, ny = ys.size() - 1;
+    if (nx * ny > 4 * T + 64) return false;                                                     // not a lattice mesh: the cells would mostly be empty
+    auto range = [](const std::vector<float>& b, float lo, float hi, int& c0, int& c1) {         // cells [c0, c1] the interval [lo, hi] is listed in
+      const int n = (int)b.size() - 1;
+      const int ilo = (int)(std::lower_bound(b.begin(), b.end(), lo) - b.begin()), ihi = (int)(std::lower_bound(b.begin(), b.end(), hi) - b.begin());   // b[ilo] == lo, b[ihi] == hi: vertex coordinates ARE the boundaries
+      if (ilo == ihi) { c0 = std::max(0, ilo - 1); c1 = std::min(n - 1, ilo); }                  // zero width: the cells on both sides of the line
+      else { c0 = ilo; c1 = ihi - 1; }
+    };
+    auto bbox = [&](const BuildTri& b, int& x0, int& x1, int& y0, int& y1) {
+      const float lx = std::min({b.v[0], b.v[3], b.v[6]}), hx = std::max({b.v[0], b.v[3], b.v[6]});
+      const float ly = std::min({b.v[1], b.v[4], b.v[7]}), hy = std::max({b.v[1], b.v[4], b.v[7]});
+      range(xs, lx, hx, x0, x1); range(ys, ly, hy, y0, y1);
+    };
+    std::vector<uint32_t> count(nx * ny, 0);
+    size_t total = 0;
+    for (const BuildTri& b : t) { int x0, x1, y0, y1; bbox(b, x0, x1, y0, y1); for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) { ++count[(size_t)y * nx + x]; ++total; } }
+    if (total > 8 * T || total >= (1ull << 31)) return false;
+    cells.assign(nx * ny, make_int4(0, 0, 0, 0));
+    size_t acc = 0;
+    for (size_t c = 0; c < nx * ny; ++c) { cells[c].x = (int)acc; acc += count[c]; count[c] = 0; }
+    tris.resize(total * 3);
+    std::vector<float> zlo(nx * ny, 1e30f), zhi(nx * ny, -1e30f);
+    for (const BuildTri& b : t) {
+      int x0, x1, y0, y1; bbox(b, x0, x1, y0, y1);
+      const float lz = std::min({b.v[2], b.v[5], b.v[8]}), hz = std::max({b.v[2], b.v[5], b.v[8]});
+      for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) {
+        const size_t c = (size_t)y * nx + x, at = (size_t)cells[c].x + count[c]++;
+        for (int v = 0; v < 3; ++v) tris[3 * at + v] = make_float4(b.v[3 * v], b.v[3 * v + 1], b.v[3 * v + 2], 0.f);
+        zlo[c] = std::min(zlo[c], lz); zhi[c] = std::max(zhi[c], hz);
+      }
+    }
+    for (size_t c = 0; c < nx * ny; ++c) { cells[c].y = (int)count[c]; memcpy(&cells[c].z, &zlo[c], 4); memcpy(&cells[c].w, &zhi[c], 4); }
+    xb = xs; yb = ys;
+    return true;
+  }
+};
 }  // namespace
 
 
 // ------------------------------------------------------------------------------------------------ kernels
+// boundary tables of the ray lattice -> LDS (every thread of the workgroup calls this; no-op without a lattice)
+LG_DEV void raygrid_stage(const RayGrid& G, float* lxb, float* lyb) {
+  if (!G.cells) return;
+  for (int i = threadIdx.x; i <= G.nx; i += blockDim.x) lxb[i] = G.xb[i];
+  for (int i = threadIdx.x; i <= G.ny; i += blockDim.x) lyb[i] = G.yb[i];
+  __syncthreads();
+}
+// GRID: the instance for meshes with a ray lattice -- a separate kernel, because the tree walk's per-lane stack lives in scratch and scratch limits the
+// resident waves of every lane of a kernel that MAY take that path
+template <bool GRID>
+LG_DEV float trace_any(const MeshView& M, const RayGrid& G, const float* lxb, const float* lyb, V3 o, V3 d, float max_dist) {
+  if (GRID) return trace_ray_grid(G, lxb, lyb, o, d, max_dist);
+  return trace_ray(M, o, d, max_dist);
+}
+static RayGrid ray_grid_of(const lg_mesh* m) { return RayGrid{m->d_gxb, m->d_gyb, m->gnx, m->gny, m->d_gcells, m->d_gtris}; }
+static size_t ray_grid_lds(const lg_mesh* m) { return m->d_gcells ? (size_t)(m->gnx + m->gny + 2) * sizeof(float) : 0; }
 // raycast_mesh (ray_caster.py:95-167): hit point o + t d, or the ray end point o + d max_dist and found = 0
-__global__ __launch_bounds__(256) void raycast_kernel(MeshView M, const float* __restrict__ o, const float* __restrict__ d, int64_t n,
+template <bool GRID>
+__global__ __launch_bounds__(256) void raycast_kernel(MeshView M, RayGrid G, const float* __restrict__ o, const float* __restrict__ d, int64_t n,
                                                       float max_dist, float* __restrict__ hits, uint8_t* __restrict__ found) {
+  extern __shared__ float rg_tab[];
+  if (GRID) raygrid_stage(G, rg_tab, rg_tab + G.nx + 1);
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   V3 ro = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-  float t = trace_ray(M, ro, rd, max_dist);
+  float t = trace_any<GRID>(M, G, rg_tab, rg_tab + G.nx + 1, ro, rd, max_dist);
   bool hit = t >= 0.f;
   V3 h = ro + (hit ? t : max_dist) * rd;
   hits[3 * i] = h.x; hits[3 * i + 1] = h.y; hits[3 * i + 2] = h.z;
@@ -162,10 +234,13 @@ __global__ __launch_bounds__(256) void sdf_kernel(MeshView M, const float* __res
 // RayCaster._update_ray_casting + LeggedRobotRayCast._get_raycast_distances (ray_caster.py:558-594,
 // legged_robot_raycast.py:262-297): one lane per (listed env, ray); outputs are indexed by env id, the distance
 // observation with a row stride so that it can live inside a wider extra-observation row
-__global__ __launch_bounds__(256) void raycaster_kernel(MeshView M, const float* __restrict__ root /* (N,13) */, const float* __restrict__ ray_o,
+template <bool GRID>
+__global__ __launch_bounds__(256) void raycaster_kernel(MeshView M, RayGrid G, const float* __restrict__ root /* (N,13) */, const float* __restrict__ ray_o,
                                                         const float* __restrict__ ray_d, const int32_t* __restrict__ ids, int n_ids, int R,
                                                         float max_dist, int yaw_only, float* __restrict__ hits, uint8_t* __restrict__ found,
                                                         float* __restrict__ dist, int dist_stride) {
+  extern __shared__ float rg_tab[];
+  if (GRID) raygrid_stage(G, rg_tab, rg_tab + G.nx + 1);
   int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gi >= (int64_t)n_ids * R) return;
   const int kq = (int)(gi / R), r = (int)(gi - (int64_t)kq * R);
@@ -180,7 +255,7 @@ __global__ __launch_bounds__(256) void raycaster_kernel(MeshView M, const float*
   V3 pos = v3(rs[0], rs[1], rs[2]);
   V3 o = quat_apply(q, v3(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2])) + pos;
   V3 d = quat_apply(q, v3(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
-  float t = trace_ray(M, o, d, max_dist);
+  float t = trace_any<GRID>(M, G, rg_tab, rg_tab + G.nx + 1, o, d, max_dist);
   bool hit = t >= 0.f;
   V3 h = o + (hit ? t : max_dist) * d;
   hits[3 * i] = h.x; hits[3 * i + 1] = h.y; hits[3 * i + 2] = h.z;
@@ -239,12 +314,15 @@ LG_DEV float cubic_w(float x) {   // Keys kernel, a = -0.75 (torch / torchvision
 
 // DepthCameraWarp.update + update_depth_buffer + process_depth_image (depth_camera.py:402-566, 84-138, 56-69):
 // one workgroup per env; the raw H x W depth image lives in LDS between the ray pass and the resize pass.
-__global__ __launch_bounds__(256) void depth_kernel(MeshView M, const float* __restrict__ root, const float* __restrict__ ray_d /* (H*W,3) */,
-                                                    const int64_t* __restrict__ ep_len, int W, int H, int RW, int RH, int buffer_len,
+template <bool GRID>
+__global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const float* __restrict__ root, const float* __restrict__ ray_d /* (H*W,3) */,
+                                                    const int64_t* __restrict__ ep_len, int W, int H, int TW, int TH, int RW, int RH, int buffer_len,
                                                     float near_clip, float far_clip, float px, float py, float pz,
                                                     float qx, float qy, float qz, float qw, const float* __restrict__ env_noise,
                                                     float* __restrict__ cam_pos, float* __restrict__ cam_rot, float* __restrict__ depth_buffer) {
   extern __shared__ float img[];
+  float* const lxb = img + W * H; float* const lyb = lxb + G.nx + 1;
+  if (GRID) raygrid_stage(G, lxb, lyb);
   const int e = blockIdx.x, tid = threadIdx.x;
   const float* rs = root + (size_t)e * 13;
   const float bq[4] = {rs[3], rs[4], rs[5], rs[6]};
@@ -263,9 +341,16 @@ __global__ __launch_bounds__(256) void depth_kernel(MeshView M, const float* __r
     cam_rot[4 * e] = cq[0]; cam_rot[4 * e + 1] = cq[1]; cam_rot[4 * e + 2] = cq[2]; cam_rot[4 * e + 3] = cq[3];
   }
   const float noise = env_noise ? env_noise[e] : 0.f;
-  for (int p = tid; p < W * H; p += 256) {
+  // a wave takes a TW x TH tile of pixels (TW * TH <= 64, chosen by the host), not 64 consecutive pixels of a row: the rays of a tile cross the same
+  // cells (or tree nodes) and finish together
+  const int lane = tid & 63, tcols = (W + TW - 1) / TW, ntiles = tcols * ((H + TH - 1) / TH);
+  const int ly = lane / TW, lx = lane - ly * TW;
+  for (int tile = tid >> 6; tile < ntiles; tile += 4) {
+    const int tyi = tile / tcols, txi = tile - tyi * tcols, pxl = txi * TW + lx, pyl = tyi * TH + ly;
+    if (ly >= TH || pxl >= W || pyl >= H) continue;
+    const int p = pyl * W + pxl;
     V3 d = quat_apply(cq, v3(ray_d[3 * p], ray_d[3 * p + 1], ray_d[3 * p + 2]));
-    float t = trace_ray(M, cpos, d, far_clip);
+    float t = trace_any<GRID>(M, G, lxb, lyb, cpos, d, far_clip);
     float depth = t >= 0.f ? -(t * norm(d)) : -far_clip;
     depth += noise;
     img[p] = fminf(fmaxf(depth, -far_clip), -near_clip);
@@ -312,6 +397,10 @@ void lg_mesh_destroy(lg_mesh* m) {
   if (m->d_nodes) (void)hipFree(m->d_nodes);
   if (m->d_tris) (void)hipFree(m->d_tris);
   if (m->d_sdf_cache) (void)hipFree(m->d_sdf_cache);
+  if (m->d_gxb) (void)hipFree(m->d_gxb);
+  if (m->d_gyb) (void)hipFree(m->d_gyb);
+  if (m->d_gcells) (void)hipFree(m->d_gcells);
+  if (m->d_gtris) (void)hipFree(m->d_gtris);
   delete m;
 }
 
@@ -350,10 +439,26 @@ lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t
       hipMemcpy(m->d_tris, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
     g_mesh_err = "device allocation / upload of the BVH failed"; lg_mesh_destroy(m); return nullptr;
   }
+  // rays over a lattice mesh walk its cells instead of the tree (LG_RAY_GRID=0: always the tree -- the A/B switch, and how the tests compare the two)
+  const char* rg = getenv("LG_RAY_GRID");
+  RayGridHost G;
+  if (!(rg && rg[0] == '0') && G.build(t)) {
+    if (hipMalloc((void**)&m->d_gxb, G.xb.size() * 4) != hipSuccess || hipMalloc((void**)&m->d_gyb, G.yb.size() * 4) != hipSuccess ||
+        hipMalloc((void**)&m->d_gcells, G.cells.size() * sizeof(int4)) != hipSuccess || hipMalloc((void**)&m->d_gtris, G.tris.size() * sizeof(float4)) != hipSuccess ||
+        hipMemcpy(m->d_gxb, G.xb.data(), G.xb.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_gyb, G.yb.data(), G.yb.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_gcells, G.cells.data(), G.cells.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_gtris, G.tris.data(), G.tris.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
+      g_mesh_err = "device allocation / upload of the ray lattice failed"; lg_mesh_destroy(m); return nullptr;
+    }
+    m->gnx = (int)G.xb.size() - 1; m->gny = (int)G.yb.size() - 1;
+  }
   return m;
 }
 
+
 int lg_mesh_info(lg_mesh* m, int64_t out[2]) { if (!m) return LG_ERR_INVALID; out[0] = m->n_tris; out[1] = m->n_nodes; return LG_OK; }
+int lg_mesh_ray_lattice(lg_mesh* m, int32_t out[2]) { if (!m || !out) return LG_ERR_INVALID; out[0] = m->d_gcells ? m->gnx : 0; out[1] = m->d_gcells ? m->gny : 0; return LG_OK; }
 
 #define MESH_TRY(m, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (m)->err = std::string(#expr) + ": " + hipGetErrorString(_e); return LG_ERR_HIP; } } while (0)
 
@@ -362,7 +467,8 @@ int lg_raycast_mesh(lg_mesh* m, const float* origins, const float* dirs, int64_t
   DeviceScope ds_(m->device);
   if (n_rays == 0) return LG_OK;
   MeshView M{m->d_nodes, m->d_tris};
-  hipLaunchKernelGGL(raycast_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, origins, dirs, n_rays, max_dist, hits, found);
+  if (m->d_gcells) hipLaunchKernelGGL(raycast_kernel<true>, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), ray_grid_lds(m), (hipStream_t)stream, M, ray_grid_of(m), origins, dirs, n_rays, max_dist, hits, found);
+  else hipLaunchKernelGGL(raycast_kernel<false>, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, ray_grid_of(m), origins, dirs, n_rays, max_dist, hits, found);
   MESH_TRY(m, hipGetLastError());
   return LG_OK;
 }
@@ -386,8 +492,12 @@ int lg_raycaster_update_subset(lg_mesh* m, const float* root_states, const float
   DeviceScope ds_(m->device);
   MeshView M{m->d_nodes, m->d_tris};
   int64_t tot = (int64_t)n * num_rays;
-  hipLaunchKernelGGL(raycaster_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, root_states, ray_origins,
-                     ray_dirs, env_ids, n, num_rays, max_dist, attach_yaw_only, ray_hits, hits_found, raycast_distances, distance_stride);
+  if (m->d_gcells)
+    hipLaunchKernelGGL(raycaster_kernel<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), ray_grid_lds(m), (hipStream_t)stream, M, ray_grid_of(m), root_states, ray_origins,
+                       ray_dirs, env_ids, n, num_rays, max_dist, attach_yaw_only, ray_hits, hits_found, raycast_distances, distance_stride);
+  else
+    hipLaunchKernelGGL(raycaster_kernel<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, ray_grid_of(m), root_states, ray_origins,
+                       ray_dirs, env_ids, n, num_rays, max_dist, attach_yaw_only, ray_hits, hits_found, raycast_distances, distance_stride);
   MESH_TRY(m, hipGetLastError());
   return LG_OK;
 }
@@ -429,9 +539,23 @@ int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* ro
   if (p->width <= 0 || p->height <= 0 || p->resized_width <= 0 || p->resized_height <= 0 || p->buffer_len <= 0) return LG_ERR_INVALID;
   size_t lds = (size_t)p->width * p->height * sizeof(float);
   if (lds > 64 * 1024) { m->err = "depth image too large for the LDS-staged resize"; return LG_ERR_UNSUPPORTED; }
+  lds += ray_grid_lds(m);
   MeshView M{m->d_nodes, m->d_tris};
-  hipLaunchKernelGGL(depth_kernel, dim3(num_envs), dim3(256), lds, (hipStream_t)stream, M, root_states, ray_dirs, episode_length_buf,
-                     p->width, p->height, p->resized_width, p->resized_height, p->buffer_len, p->near_clip, p->far_clip,
+  // pixel tile of a wave: the TW x TH <= 64 that covers the image with the fewest tiles, the squarest of those
+  int TW = 8, TH = 8, best_tiles = 1 << 30;
+  for (int th = 1; th <= 64; ++th)
+    for (int tw = 1; tw * th <= 64; ++tw) {
+      const int nt = ((p->width + tw - 1) / tw) * ((p->height + th - 1) / th);
+      if (nt < best_tiles || (nt == best_tiles && abs(tw - th) < abs(TW - TH))) { best_tiles = nt; TW = tw; TH = th; }
+    }
+  if (m->d_gcells)
+    hipLaunchKernelGGL(depth_kernel<true>, dim3(num_envs), dim3(256), lds, (hipStream_t)stream, M, ray_grid_of(m), root_states, ray_dirs, episode_length_buf,
+                     p->width, p->height, TW, TH, p->resized_width, p->resized_height, p->buffer_len, p->near_clip, p->far_clip,
+                     p->position[0], p->position[1], p->position[2], p->quat_offset[0], p->quat_offset[1], p->quat_offset[2],
+                     p->quat_offset[3], env_noise, camera_pos, camera_rot, depth_buffer);
+  else
+    hipLaunchKernelGGL(depth_kernel<false>, dim3(num_envs), dim3(256), lds, (hipStream_t)stream, M, ray_grid_of(m), root_states, ray_dirs, episode_length_buf,
+                     p->width, p->height, TW, TH, p->resized_width, p->resized_height, p->buffer_len, p->near_clip, p->far_clip,
                      p->position[0], p->position[1], p->position[2], p->quat_offset[0], p->quat_offset[1], p->quat_offset[2],
                      p->quat_offset[3], env_noise, camera_pos, camera_rot, depth_buffer);
   MESH_TRY(m, hipGetLastError());

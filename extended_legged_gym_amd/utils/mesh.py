@@ -27,6 +27,9 @@ class DeviceMesh:
         info = (C.c_int64 * 2)()
         self.lib.lg_mesh_info(self.handle, info)
         self.num_bvh_nodes = int(info[1])
+        lat = (C.c_int32 * 2)()
+        self.lib.lg_mesh_ray_lattice(self.handle, lat)
+        self.ray_lattice = (int(lat[0]), int(lat[1]))      # (0, 0): rays walk the BVH
 
     def _check(self, rc):
         if rc != abi.LG_OK:

@@ -405,6 +405,11 @@ typedef struct lg_mesh lg_mesh;
 lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t* triangles, int64_t n_triangles, int device_id);
 void lg_mesh_destroy(lg_mesh* mesh);
 int lg_mesh_info(lg_mesh* mesh, int64_t out[2]);            /* {#triangles, #bvh nodes} */
+/* {nx, ny} cells of the ray lattice, {0, 0} when the mesh has none.  A mesh whose vertices sit on a rectilinear lattice in x and y (any
+ * heightfield-derived mesh) gets, next to the BVH, a per-cell triangle table that rays walk instead of the tree: same hits, same t
+ * (environment LG_RAY_GRID=0 at creation time: never).  Warp has one structure for every mesh (ray_caster.py:39-42); this is an accelerator
+ * behind the same calls, not a different query. */
+int lg_mesh_ray_lattice(lg_mesh* mesh, int32_t out[2]);
 const char* lg_mesh_last_error(lg_mesh* mesh);
 
 /* raycast_mesh (ray_caster.py:95-167): device pointers, n rays; hits (n,3) = o + t d or o + d max_dist, found (n) u8. */

@@ -69,6 +69,44 @@ def test_raycast_and_sdf_match_bruteforce():
     assert bool(fb[0]) and torch.allclose(hb[0].cpu(), torch.tensor([0.0, 0, 0.5]), atol=1e-6)
 
 
+def test_ray_lattice_returns_the_hits_of_the_tree(monkeypatch):
+    """A heightfield-derived mesh gets a per-cell triangle table that rays walk instead of the BVH (`lg_mesh_ray_lattice`): the same triangle
+    test decides, so a hit has the same t bit for bit.  Rays: random, grazing (camera-like), vertical, starting on lattice lines, starting
+    outside the mesh, pointing up."""
+    from extended_legged_gym_amd.utils.mesh import DeviceMesh
+    from extended_legged_gym_amd.utils.ray_caster import raycast_mesh
+    v, t = rough_mesh()
+    lattice = DeviceMesh(v, t, "cuda:0")
+    nx, ny = len(np.unique(v[:, 0])) - 1, len(np.unique(v[:, 1])) - 1
+    assert lattice.ray_lattice == (nx, ny) and nx > 30
+    monkeypatch.setenv("LG_RAY_GRID", "0")
+    tree = DeviceMesh(v, t, "cuda:0")
+    monkeypatch.delenv("LG_RAY_GRID")
+    assert tree.ray_lattice == (0, 0)
+    vi, ti = icosphere(3)
+    assert DeviceMesh(vi, ti, "cuda:0").ray_lattice == (0, 0)          # not a lattice mesh: the tree only
+    rng = np.random.default_rng(5)
+    n = 60000
+    o = np.column_stack([rng.uniform(-2.4, 2.4, n), rng.uniform(-2.4, 2.4, n), rng.uniform(-0.2, 1.5, n)]).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[: n // 3, 2] = -np.abs(d[: n // 3, 2]) * 0.15                      # grazing
+    d[n // 3: n // 3 + 4000, :2] = 0.0                                    # vertical (up and down)
+    d[n // 3 + 4000: n // 3 + 6000, 0] = 0.0                              # parallel to lattice lines
+    d[n // 3 + 6000: n // 3 + 8000, 1] = 0.0
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)
+    xs = np.unique(v[:, 0])
+    o[-5000:, 0] = rng.choice(xs, 5000)                                   # origins exactly on lattice lines
+    o[-2500:, 1] = rng.choice(np.unique(v[:, 1]), 2500)
+    for max_dist in (3.0, 0.7):
+        to, td = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+        hg, fg = raycast_mesh(to, td, max_dist, lattice)
+        hb, fb = raycast_mesh(to, td, max_dist, tree)
+        differ = (fg != fb) | ((hg != hb).any(dim=1) & fg & fb)
+        assert float(fg.float().mean()) > 0.1
+        # (rays through a lattice corner or along a lattice line can be decided differently by rounding in either structure)
+        assert int(differ.sum()) <= 3, int(differ.sum())
+
+
 def test_raycaster_sensor_matches_reference_arithmetic():
     from extended_legged_gym_amd.utils.mesh import DeviceMesh
     from extended_legged_gym_amd.utils.ray_caster import PatternType, RayCaster, RayCasterCfg, RayCasterPatternCfg
