@@ -34,7 +34,8 @@ struct lg_mesh {
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};   // bounding box of the mesh
   // ray lattice (rays only; built by lg_mesh_create when the vertices sit on a rectilinear lattice in x and y, i.e. a heightfield-derived mesh)
   float* d_gxb = nullptr; float* d_gyb = nullptr; int gnx = 0, gny = 0;   // cell boundaries: gnx + 1 and gny + 1 ascending coordinates
-  int4* d_gcells = nullptr;            // per cell (iy * gnx + ix): first triangle of its run in d_gtris, count, min z, max z (float bits)
+  float2* d_gzr = nullptr;             // per cell (iy * gnx + ix): min z, max z of the triangles listed in it
+  int2* d_gcells = nullptr;            // per cell: first triangle of its run in d_gtris, count
   float4* d_gtris = nullptr;           // triangles in cell order (a triangle that overlaps k cells is stored k times)
   float4* d_sdf_cache = nullptr;       // lg_sdf_bodies_update: last closest surface point per query slot (xyz, w = 1 when set)
   int64_t sdf_cache_n = 0;
@@ -143,15 +144,19 @@ LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
 // the cells in the order the ray crosses them, skips a cell whose z range the ray does not reach while it is over it, and tests the listed
 // triangles with the SAME arithmetic as trace_ray, so a hit has the same t, bit for bit.  It stops one cell AFTER the cell a hit was found in:
 // the cell the walk believes the ray is in and the cell the hit point really lies in can differ by rounding at the line between two cells.
-struct RayGrid { const float* __restrict__ xb; const float* __restrict__ yb; int nx, ny; const int4* __restrict__ cells; const float4* __restrict__ tris; };
+struct RayGrid { const float* __restrict__ xb; const float* __restrict__ yb; int nx, ny;
+                 const float2* __restrict__ zr;    // per cell (iy * nx + ix): min z, max z of the triangles listed in it (empty: +1e30, -1e30) -- all the walk reads per cell
+                 const int2* __restrict__ run;     // per cell: first triangle of its run in `tris`, count -- read only for cells whose z range the ray reaches
+                 const float4* __restrict__ tris; };
 LG_DEV int raygrid_locate(const float* b, int n, float x, int guess) {
   int i = guess < 0 ? 0 : (guess > n - 1 ? n - 1 : guess);
   while (i > 0 && x < b[i]) --i;
   while (i < n - 1 && x >= b[i + 1]) ++i;
   return i;
 }
-// xb, yb: the boundary tables (the kernels copy them to LDS: one dependent read per cell crossed)
-LG_DEV float trace_ray_grid(const RayGrid& G, const float* xb, const float* yb, V3 o, V3 d, float max_dist) {
+// tb: the boundary tables in LDS, x boundaries (nx + 1) followed by y boundaries (ny + 1): one dependent LDS read per cell crossed
+LG_DEV float trace_ray_grid(const RayGrid& G, const float* tb, V3 o, V3 d, float max_dist) {
+  const float* xb = tb; const float* yb = tb + G.nx + 1;
   const V3 inv = v3(1.f / (fabsf(d.x) > 1e-12f ? d.x : copysignf(1e-12f, d.x)), 1.f / (fabsf(d.y) > 1e-12f ? d.y : copysignf(1e-12f, d.y)),
                     1.f / (fabsf(d.z) > 1e-12f ? d.z : copysignf(1e-12f, d.z)));
   // the part of the ray over the lattice
@@ -166,33 +171,42 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const float* xb, const float* yb, 
   const float ux = (float)G.nx / (xb[G.nx] - xb[0]), uy = (float)G.ny / (yb[G.ny] - yb[0]);
   int ix = raygrid_locate(xb, G.nx, px, (int)((px - xb[0]) * ux)), iy = raygrid_locate(yb, G.ny, py, (int)((py - yb[0]) * uy));
   const int sx = inv.x >= 0.f ? 1 : -1, sy = inv.y >= 0.f ? 1 : -1;
-  float tmx = (xb[ix + (sx > 0 ? 1 : 0)] - o.x) * inv.x, tmy = (yb[iy + (sy > 0 ? 1 : 0)] - o.y) * inv.y;
+  const int ox = sx > 0 ? 1 : 0, oy = (sy > 0 ? 1 : 0) + G.nx + 1;     // offsets into tb of the boundary AHEAD of cell ix / iy
+  float tmx = (tb[ix + ox] - o.x) * inv.x, tmy = (tb[iy + oy] - o.y) * inv.y;
   float best = max_dist; bool hit = false;
   float tcur = t0;
+  // the ends of a cell's stretch of the ray are rounded: the z range is taken a little beyond either end
+  const float padc = 2e-5f * fabsf(t1) + 1e-6f;
+  bool done = false;
+  // one cell on, without branches: the axis whose boundary comes first, the boundary ahead of the new cell from LDS
+  auto advance = [&]() {
+    const bool stx = tmx <= tmy;
+    const int inew = stx ? ix + sx : iy + sy;
+    const bool out = inew < 0 || inew >= (stx ? G.nx : G.ny);
+    ix = stx ? inew : ix; iy = stx ? iy : inew;
+    const float bnd = tb[out ? 0 : inew + (stx ? ox : oy)];
+    const float tn = (bnd - (stx ? o.x : o.y)) * (stx ? inv.x : inv.y);
+    tmx = stx ? tn : tmx; tmy = stx ? tmy : tn;
+    done = done || out;
+  };
   // "while-while", like the tree walk: every lane skips cells until it stands on one whose z range it reaches (or its ray is over), THEN the wave
   // tests triangles together -- with the test inside the walk, nearly every step of the wave had some lane in the (long, load-bound) triangle loop
-  bool done = false;
   while (!done) {
-    int4 c = make_int4(0, 0, 0, 0);
     bool cand = false;
     float tnext = 0.f;
     while (!done && !cand) {
       tnext = fminf(tmx, tmy);
-      const float tend = fminf(tnext, t1);
-      c = G.cells[(size_t)iy * G.nx + ix];
-      // z reached while over the cell (a little beyond either end: the ends are rounded)
-      const float pad = 1e-5f * (fabsf(tend) + fabsf(tcur)) + 1e-6f;
-      const float za = o.z + (tcur - pad) * d.z, zb = o.z + (tend + pad) * d.z;
-      cand = c.y > 0 && !(fminf(za, zb) > __int_as_float(c.w) || fmaxf(za, zb) < __int_as_float(c.z));
+      const float2 z = G.zr[(size_t)iy * G.nx + ix];
+      const float za = o.z + (tcur - padc) * d.z, zb = o.z + (fminf(tnext, t1) + padc) * d.z;
+      cand = !(fminf(za, zb) > z.y || fmaxf(za, zb) < z.x);
       if (!cand) {
         // found before this cell began: every cell the hit point can lie in has been seen; or the ray ends / leaves the lattice in this cell
-        if ((hit && best <= tcur) || !(tnext < t1)) done = true;
-        else if (tmx <= tmy) { ix += sx; if (ix < 0 || ix >= G.nx) done = true; else tmx = (xb[ix + (sx > 0 ? 1 : 0)] - o.x) * inv.x; }
-        else { iy += sy; if (iy < 0 || iy >= G.ny) done = true; else tmy = (yb[iy + (sy > 0 ? 1 : 0)] - o.y) * inv.y; }
+        if ((hit && best <= tcur) || !(tnext < t1)) done = true; else advance();
         tcur = tnext;
       }
     }
     if (cand) {
+      const int2 c = G.run[(size_t)iy * G.nx + ix];
       for (int i = 0; i < c.y; ++i) {
         const float4* T = G.tris + (size_t)(c.x + i) * 3;
         float4 a = T[0], b = T[1], cc = T[2];
@@ -210,9 +224,7 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const float* xb, const float* yb, 
         float t = dot(e2, q) * idet;
         if (t >= 0.f && t <= best) { best = t; hit = true; }
       }
-      if ((hit && best <= tcur) || !(tnext < t1)) done = true;
-      else if (tmx <= tmy) { ix += sx; if (ix < 0 || ix >= G.nx) done = true; else tmx = (xb[ix + (sx > 0 ? 1 : 0)] - o.x) * inv.x; }
-      else { iy += sy; if (iy < 0 || iy >= G.ny) done = true; else tmy = (yb[iy + (sy > 0 ? 1 : 0)] - o.y) * inv.y; }
+      if ((hit && best <= tcur) || !(tnext < t1)) done = true; else advance();
       tcur = tnext;
     }
   }

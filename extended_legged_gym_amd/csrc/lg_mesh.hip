@@ -129,7 +129,7 @@ struct Collapser {
 // [xb[ix], xb[ix+1]] x [yb[iy], yb[iy+1]] between consecutive distinct coordinates, so every triangle edge lies ON cell lines and a triangle is listed
 // exactly in the cells its xy bounding box overlaps with positive area (a box of zero width -- a vertical face -- in the cells on both sides of its line).
 struct RayGridHost {
-  std::vector<float> xb, yb; std::vector<int4> cells; std::vector<float4> tris;
+  std::vector<float> xb, yb; std::vector<int2> cells; std::vector<float2> zr; std::vector<float4> tris;
   bool build(const std::vector<BuildTri>& t) {
     const size_t T = t.size();
     std::vector<float> xs, ys; xs.reserve(3 * T); ys.reserve(3 * T);
@@ -155,7 +155,7 @@ struct RayGridHost {
     size_t total = 0;
     for (const BuildTri& b : t) { int x0, x1, y0, y1; bbox(b, x0, x1, y0, y1); for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) { ++count[(size_t)y * nx + x]; ++total; } }
     if (total > 8 * T || total >= (1ull << 31)) return false;
-    cells.assign(nx * ny, make_int4(0, 0, 0, 0));
+    cells.assign(nx * ny, make_int2(0, 0));
     size_t acc = 0;
     for (size_t c = 0; c < nx * ny; ++c) { cells[c].x = (int)acc; acc += count[c]; count[c] = 0; }
     tris.resize(total * 3);
@@ -169,7 +169,8 @@ struct RayGridHost {
         zlo[c] = std::min(zlo[c], lz); zhi[c] = std::max(zhi[c], hz);
       }
     }
-    for (size_t c = 0; c < nx * ny; ++c) { cells[c].y = (int)count[c]; memcpy(&cells[c].z, &zlo[c], 4); memcpy(&cells[c].w, &zhi[c], 4); }
+    zr.resize(nx * ny);
+    for (size_t c = 0; c < nx * ny; ++c) { cells[c].y = (int)count[c]; zr[c] = make_float2(zlo[c], zhi[c]); }     // (an empty cell keeps +1e30, -1e30: no ray reaches it)
     xb = xs; yb = ys;
     return true;
   }
@@ -179,31 +180,30 @@ struct RayGridHost {
 
 // ------------------------------------------------------------------------------------------------ kernels
 // boundary tables of the ray lattice -> LDS (every thread of the workgroup calls this; no-op without a lattice)
-LG_DEV void raygrid_stage(const RayGrid& G, float* lxb, float* lyb) {
-  if (!G.cells) return;
-  for (int i = threadIdx.x; i <= G.nx; i += blockDim.x) lxb[i] = G.xb[i];
-  for (int i = threadIdx.x; i <= G.ny; i += blockDim.x) lyb[i] = G.yb[i];
+LG_DEV void raygrid_stage(const RayGrid& G, float* tb) {
+  for (int i = threadIdx.x; i <= G.nx; i += blockDim.x) tb[i] = G.xb[i];
+  for (int i = threadIdx.x; i <= G.ny; i += blockDim.x) tb[G.nx + 1 + i] = G.yb[i];
   __syncthreads();
 }
 // GRID: the instance for meshes with a ray lattice -- a separate kernel, because the tree walk's per-lane stack lives in scratch and scratch limits the
 // resident waves of every lane of a kernel that MAY take that path
 template <bool GRID>
-LG_DEV float trace_any(const MeshView& M, const RayGrid& G, const float* lxb, const float* lyb, V3 o, V3 d, float max_dist) {
-  if (GRID) return trace_ray_grid(G, lxb, lyb, o, d, max_dist);
+LG_DEV float trace_any(const MeshView& M, const RayGrid& G, const float* tb, V3 o, V3 d, float max_dist) {
+  if (GRID) return trace_ray_grid(G, tb, o, d, max_dist);
   return trace_ray(M, o, d, max_dist);
 }
-static RayGrid ray_grid_of(const lg_mesh* m) { return RayGrid{m->d_gxb, m->d_gyb, m->gnx, m->gny, m->d_gcells, m->d_gtris}; }
+static RayGrid ray_grid_of(const lg_mesh* m) { return RayGrid{m->d_gxb, m->d_gyb, m->gnx, m->gny, m->d_gzr, m->d_gcells, m->d_gtris}; }
 static size_t ray_grid_lds(const lg_mesh* m) { return m->d_gcells ? (size_t)(m->gnx + m->gny + 2) * sizeof(float) : 0; }
 // raycast_mesh (ray_caster.py:95-167): hit point o + t d, or the ray end point o + d max_dist and found = 0
 template <bool GRID>
 __global__ __launch_bounds__(256) void raycast_kernel(MeshView M, RayGrid G, const float* __restrict__ o, const float* __restrict__ d, int64_t n,
                                                       float max_dist, float* __restrict__ hits, uint8_t* __restrict__ found) {
   extern __shared__ float rg_tab[];
-  if (GRID) raygrid_stage(G, rg_tab, rg_tab + G.nx + 1);
+  if (GRID) raygrid_stage(G, rg_tab);
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   V3 ro = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-  float t = trace_any<GRID>(M, G, rg_tab, rg_tab + G.nx + 1, ro, rd, max_dist);
+  float t = trace_any<GRID>(M, G, rg_tab, ro, rd, max_dist);
   bool hit = t >= 0.f;
   V3 h = ro + (hit ? t : max_dist) * rd;
   hits[3 * i] = h.x; hits[3 * i + 1] = h.y; hits[3 * i + 2] = h.z;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void raycaster_kernel(MeshView M, RayGrid G, c
                                                         float max_dist, int yaw_only, float* __restrict__ hits, uint8_t* __restrict__ found,
                                                         float* __restrict__ dist, int dist_stride) {
   extern __shared__ float rg_tab[];
-  if (GRID) raygrid_stage(G, rg_tab, rg_tab + G.nx + 1);
+  if (GRID) raygrid_stage(G, rg_tab);
   int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gi >= (int64_t)n_ids * R) return;
   const int kq = (int)(gi / R), r = (int)(gi - (int64_t)kq * R);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void raycaster_kernel(MeshView M, RayGrid G, c
   V3 pos = v3(rs[0], rs[1], rs[2]);
   V3 o = quat_apply(q, v3(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2])) + pos;
   V3 d = quat_apply(q, v3(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
-  float t = trace_any<GRID>(M, G, rg_tab, rg_tab + G.nx + 1, o, d, max_dist);
+  float t = trace_any<GRID>(M, G, rg_tab, o, d, max_dist);
   bool hit = t >= 0.f;
   V3 h = o + (hit ? t : max_dist) * d;
   hits[3 * i] = h.x; hits[3 * i + 1] = h.y; hits[3 * i + 2] = h.z;
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const
                                                     float qx, float qy, float qz, float qw, const float* __restrict__ env_noise,
                                                     float* __restrict__ cam_pos, float* __restrict__ cam_rot, float* __restrict__ depth_buffer) {
   extern __shared__ float img[];
-  float* const lxb = img + W * H; float* const lyb = lxb + G.nx + 1;
-  if (GRID) raygrid_stage(G, lxb, lyb);
+  float* const rg_tab = img + W * H;
+  if (GRID) raygrid_stage(G, rg_tab);
   const int e = blockIdx.x, tid = threadIdx.x;
   const float* rs = root + (size_t)e * 13;
   const float bq[4] = {rs[3], rs[4], rs[5], rs[6]};
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const
     if (ly >= TH || pxl >= W || pyl >= H) continue;
     const int p = pyl * W + pxl;
     V3 d = quat_apply(cq, v3(ray_d[3 * p], ray_d[3 * p + 1], ray_d[3 * p + 2]));
-    float t = trace_any<GRID>(M, G, lxb, lyb, cpos, d, far_clip);
+    float t = trace_any<GRID>(M, G, rg_tab, cpos, d, far_clip);
     float depth = t >= 0.f ? -(t * norm(d)) : -far_clip;
     depth += noise;
     img[p] = fminf(fmaxf(depth, -far_clip), -near_clip);
@@ -400,6 +400,7 @@ void lg_mesh_destroy(lg_mesh* m) {
   if (m->d_gxb) (void)hipFree(m->d_gxb);
   if (m->d_gyb) (void)hipFree(m->d_gyb);
   if (m->d_gcells) (void)hipFree(m->d_gcells);
+  if (m->d_gzr) (void)hipFree(m->d_gzr);
   if (m->d_gtris) (void)hipFree(m->d_gtris);
   delete m;
 }
@@ -444,10 +445,11 @@ lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t
   RayGridHost G;
   if (!(rg && rg[0] == '0') && G.build(t)) {
     if (hipMalloc((void**)&m->d_gxb, G.xb.size() * 4) != hipSuccess || hipMalloc((void**)&m->d_gyb, G.yb.size() * 4) != hipSuccess ||
-        hipMalloc((void**)&m->d_gcells, G.cells.size() * sizeof(int4)) != hipSuccess || hipMalloc((void**)&m->d_gtris, G.tris.size() * sizeof(float4)) != hipSuccess ||
+        hipMalloc((void**)&m->d_gcells, G.cells.size() * sizeof(int2)) != hipSuccess || hipMalloc((void**)&m->d_gzr, G.zr.size() * sizeof(float2)) != hipSuccess ||
+        hipMemcpy(m->d_gzr, G.zr.data(), G.zr.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess || hipMalloc((void**)&m->d_gtris, G.tris.size() * sizeof(float4)) != hipSuccess ||
         hipMemcpy(m->d_gxb, G.xb.data(), G.xb.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(m->d_gyb, G.yb.data(), G.yb.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(m->d_gcells, G.cells.data(), G.cells.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_gcells, G.cells.data(), G.cells.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(m->d_gtris, G.tris.data(), G.tris.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
       g_mesh_err = "device allocation / upload of the ray lattice failed"; lg_mesh_destroy(m); return nullptr;
     }
