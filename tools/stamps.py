@@ -12,7 +12,7 @@ if "--config3" in sys.argv:                       # A1 on the confined OBJ mesh 
     import bench_configs
     env = bench_configs.config3_env()
 else:
-    env, cfg = bench.build_env(0, 1, 4096, pd)
+    env, cfg = bench.build_env(0, 1, 4096, pd, mesh_type="trimesh" if "--trimesh" in sys.argv else "heightfield")   # --trimesh: anymal_c_rough as registered
     env.reset()
 g = torch.Generator().manual_seed(0)
 pool = [torch.randn(4096, 12, generator=g).cuda() for _ in range(16)]
