@@ -541,7 +541,9 @@ int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* ro
   if (p->width <= 0 || p->height <= 0 || p->resized_width <= 0 || p->resized_height <= 0 || p->buffer_len <= 0) return LG_ERR_INVALID;
   size_t lds = (size_t)p->width * p->height * sizeof(float);
   if (lds > 64 * 1024) { m->err = "depth image too large for the LDS-staged resize"; return LG_ERR_UNSUPPORTED; }
-  lds += ray_grid_lds(m);
+  // the lattice instance keeps its boundary tables in LDS next to the image; together they must stay within the 64 KB a launch gets without opting in
+  const bool lattice = m->d_gcells && lds + ray_grid_lds(m) <= 64 * 1024;
+  if (lattice) lds += ray_grid_lds(m);
   MeshView M{m->d_nodes, m->d_tris};
   // pixel tile of a wave: the TW x TH <= 64 that covers the image with the fewest tiles, the squarest of those
   int TW = 8, TH = 8, best_tiles = 1 << 30;
@@ -550,7 +552,7 @@ int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* ro
       const int nt = ((p->width + tw - 1) / tw) * ((p->height + th - 1) / th);
       if (nt < best_tiles || (nt == best_tiles && abs(tw - th) < abs(TW - TH))) { best_tiles = nt; TW = tw; TH = th; }
     }
-  if (m->d_gcells)
+  if (lattice)
     hipLaunchKernelGGL(depth_kernel<true>, dim3(num_envs), dim3(256), lds, (hipStream_t)stream, M, ray_grid_of(m), root_states, ray_dirs, episode_length_buf,
                      p->width, p->height, TW, TH, p->resized_width, p->resized_height, p->buffer_len, p->near_clip, p->far_clip,
                      p->position[0], p->position[1], p->position[2], p->quat_offset[0], p->quat_offset[1], p->quat_offset[2],
