@@ -103,8 +103,7 @@ class RobotBatchRollout(LeggedRobot):
         self.core.step_subset(actions.to(self.device), self._main_ids_i32, rollout_mode=0)
         self.common_step_counter += 1
         self.commands[self.rollout_env_indices] = self.commands[self._rollout_sources]      # `:829-838`, `:900-911`
-        m = self.main_env_indices
-        out = (self.obs_buf[m], None, self.rew_buf[m], self.reset_buf[m], self._main_extras())
+        out = self._step_rows(self._main_ids_i32, self.main_env_indices)
         self._cache_main_env_states()
         self._sync_main_to_rollout()
         self.t_main += self.dt
@@ -125,11 +124,16 @@ class RobotBatchRollout(LeggedRobot):
                                  f"got {actions.shape}")
         self.core.step_subset(actions.to(self.device), self._rollout_ids_i32, rollout_mode=1)
         self._restore_main_env_states()
-        r = self.rollout_env_indices
-        extras = {k: (v[r] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == self.total_num_envs else v)
-                  for k, v in self.extras.items()}
         self.t_rollout += self.dt
-        return self.obs_buf[r], None, self.rew_buf[r], self.reset_buf[r], extras
+        return self._step_rows(self._rollout_ids_i32, self.rollout_env_indices)
+
+    def _step_rows(self, ids_i32, idx):
+        """The 5-tuple of a subset step: `obs_buf[idx]`, `rew_buf[idx]`, `reset_buf[idx]` and the per-env extras (`:598-600`, `:714-716`) as fresh dense
+        tensors from ONE gather launch -- the framework's index kernels for the same rows cost a quarter of a rollout step of 4096 envs."""
+        obs, rew, reset, tout = self.core.gather_step_rows(ids_i32)
+        extras = {k: (tout if v is self.time_out_buf else (v[idx] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == self.total_num_envs else v))
+                  for k, v in self.extras.items()}
+        return obs, None, rew, reset, extras
 
     def _main_extras(self):
         m = self.main_env_indices

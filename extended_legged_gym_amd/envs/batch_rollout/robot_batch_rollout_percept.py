@@ -152,8 +152,7 @@ class RobotBatchRolloutPercept(RobotBatchRollout):
         self.core.post_physics_subset(self._main_ids_i32, rollout_mode=0)
         self.common_step_counter += 1
         self.commands[self.rollout_env_indices] = self.commands[self._rollout_sources]
-        m = self.main_env_indices
-        out = (self.obs_buf[m], None, self.rew_buf[m], self.reset_buf[m], self._main_extras())
+        out = self._step_rows(self._main_ids_i32, self.main_env_indices)
         self._sync_main_to_rollout()
         # the reference steps the rollouts with their main's action and senses from there (`:301-331` on all envs);
         # their state equals the main's, so the main's sensor row is theirs too
@@ -182,8 +181,5 @@ class RobotBatchRolloutPercept(RobotBatchRollout):
         self.core.step_subset_physics(actions.to(self.device), self._rollout_ids_i32)
         self._percept_update(self._rollout_ids_i32)
         self.core.post_physics_subset(self._rollout_ids_i32, rollout_mode=1)
-        r = self.rollout_env_indices
-        extras = {k: (v[r] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == self.total_num_envs else v)
-                  for k, v in self.extras.items()}
         self.t_rollout += self.dt
-        return self.obs_buf[r], None, self.rew_buf[r], self.reset_buf[r], extras
+        return self._step_rows(self._rollout_ids_i32, self.rollout_env_indices)

@@ -394,6 +394,12 @@ int lg_reset_idx(lg_ctx* ctx, const int32_t* env_ids, int32_t n, int32_t update_
  * from the new pose either way and their contact forces zeroed. */
 int lg_set_state_indexed(lg_ctx* ctx, const float* root_states, const float* dof_state, const int32_t* env_ids, int32_t n, void* stream);
 
+/* Dense copies of the listed envs' rows of obs_buf (n, num_obs), rew_buf (n), reset_buf (n) u8 and time_out_buf (n) u8 -- what `step()` /
+ * `step_rollout()` of the main-rollout env return (`obs_buf[main_env_indices]` ..., robot_batch_rollout.py:598-600, 714-716) -- in one launch.
+ * Any output may be null.  Device pointers. */
+int lg_gather_step_rows(lg_ctx* ctx, const int32_t* env_ids, int32_t n, float* obs_out, float* rew_out, uint8_t* reset_out,
+                        uint8_t* time_out_out, void* stream);
+
 /* Bind the (N, num_extra_obs) f32 device buffer whose rows are appended to the observation (legged_robot_raycast.py:252-254). */
 int lg_set_extra_obs(lg_ctx* ctx, const float* dptr);
 

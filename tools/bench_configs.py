@@ -117,7 +117,7 @@ def config4():
                 mesh_triangles=mesh.num_triangles, bvh_nodes=mesh.num_bvh_nodes)
 
 
-def config5():
+def config5_env():
     from extended_legged_gym_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
     from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout import RobotBatchRollout
     from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout_config import RobotBatchRolloutCfg
@@ -130,6 +130,11 @@ def config5():
     cfg.seed = 1
     env = RobotBatchRollout(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
     env.reset()
+    return env
+
+
+def config5():
+    env = config5_env()
     a = torch.randn(128 * 32, 12, device="cuda")
     dt = timeit(lambda: env.step_rollout(a), 50, 200)
     us = torch.randn(128 * 32, 16, 12, device="cuda")

@@ -11,13 +11,20 @@ if "--config3" in sys.argv:                       # A1 on the confined OBJ mesh 
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_configs
     env = bench_configs.config3_env()
+elif "--config5" in sys.argv:                     # main-rollout env (tools/bench_configs.py config 5): the ROLLOUT step of 128 x 32 envs
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs
+    env = bench_configs.config5_env()
 else:
     env, cfg = bench.build_env(0, 1, 4096, pd, mesh_type="trimesh" if "--trimesh" in sys.argv else "heightfield")   # --trimesh: anymal_c_rough as registered
     env.reset()
 g = torch.Generator().manual_seed(0)
 pool = [torch.randn(4096, 12, generator=g).cuda() for _ in range(16)]
 for i in range(300):
-    env.step(pool[i % 16])
+    if "--config5" in sys.argv:
+        env.step_rollout(pool[i % 16])
+    else:
+        env.step(pool[i % 16])
 lib = env.core.lib
 out = (C.c_ulonglong * 64)()
 lib.lg_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
