@@ -473,14 +473,18 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot_lds,
   term |= HI(HC_FLIP) && R.pg[2] > 0.f;
   term |= fault;                                   // physics fault / lost env flagged by this launch
   bool tout = (float)eplen > HF(HC_MAX_EPLEN);
+  bool row_reset;                                  // what reset_buf[e] holds behind this step (the dense row of lg_step_subset_rows)
   if (ro) {                                        // rollout envs never terminate on their own: the flags keep their last values (robot_batch_rollout.py:806-809)
     const int fl = (int)pre[4];
     tout = (fl >> 8) != 0; term = ((fl & 0xff) != 0 || fault) && !tout;
     if (fault) s_reset[e] = 1;
+    row_reset = fault || (fl & 0xff) != 0;
   } else {
     s_tout[e] = tout ? 1 : 0; s_reset[e] = (term || tout) ? 1 : 0;
     s_eplen[e] = eplen;
+    row_reset = term || tout;
   }
+  if (K.reset_rows) { K.reset_rows[krow] = row_reset ? 1 : 0; K.tout_rows[krow] = tout ? 1 : 0; }
   // ---- compute_reward (LR:215-232): terms in config order; _reward_feet_air_time rewrites the feet timers where it stands in
   // that order (RM:150-163), so earlier terms see the old values and later ones the new, as in the reference
   R.bh = 0.f;
@@ -552,7 +556,7 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot_lds,
 
 // ---- all four waves: write-back of the env rows + observation rows, 4 envs per wave; statistics + arrival by wave 0
 // Returns true on the LAST workgroup of the launch to arrive (it then runs finalize_from_acc).
-LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out,
+LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out, bool obs_by_row,
                                 const int32_t* __restrict__ ids, bool ro) {
   STAMP_DECL
   const int wv = tid >> 6, ln = tid & 63;
@@ -772,7 +776,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
         const int idx = 4 * g0 + ln + 64 * j;
         if (idx < O) {
           x_obs[(size_t)e * O + idx] = ov[q][j];
-          if (obs_out) obs_out[(size_t)e * O + idx] = ov[q][j];     // RolloutStorage.observations[t + 1]
+          if (obs_out) obs_out[(size_t)(obs_by_row ? e0 + el : e) * O + idx] = ov[q][j];     // RolloutStorage.observations[t + 1] | row of lg_step_subset_rows
         }
       }
     }

@@ -39,6 +39,8 @@
     (c, root_states, dof_state, env_ids, n, stream))                                                                                                  \
   X(int, lg_gather_step_rows, (lg_ctx * c, const int32_t* env_ids, int32_t n, float* obs_out, float* rew_out, uint8_t* reset_out, uint8_t* time_out_out, void* stream), \
     (c, env_ids, n, obs_out, rew_out, reset_out, time_out_out, stream))                                                                               \
+  X(int, lg_step_subset_rows, (lg_ctx * c, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, float* obs_out, float* rew_out, uint8_t* reset_out, uint8_t* time_out_out, void* stream), \
+    (c, actions, env_ids, n, rollout_mode, obs_out, rew_out, reset_out, time_out_out, stream))                                                        \
   X(int, lg_set_extra_obs, (lg_ctx * c, const float* dptr), (c, dptr))                                                                                \
   X(int, lg_profile_begin, (lg_ctx * c, int32_t max_samples, int32_t stride), (c, max_samples, stride))                                               \
   X(int, lg_profile_end, (lg_ctx * c, float mean_ms[3], int32_t* nsamples), (c, mean_ms, nsamples))                                                   \
@@ -67,6 +69,7 @@
 #define lg_reset_idx LG_ENTRY(lg_reset_idx)
 #define lg_set_state_indexed LG_ENTRY(lg_set_state_indexed)
 #define lg_gather_step_rows LG_ENTRY(lg_gather_step_rows)
+#define lg_step_subset_rows LG_ENTRY(lg_step_subset_rows)
 #define lg_set_extra_obs LG_ENTRY(lg_set_extra_obs)
 #define lg_profile_begin LG_ENTRY(lg_profile_begin)
 #define lg_profile_end LG_ENTRY(lg_profile_end)

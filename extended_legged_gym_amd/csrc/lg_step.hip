@@ -489,7 +489,8 @@ LG_DEV void store_lstm_rows(const DevCtx* __restrict__ C, size_t row, size_t N12
 // MODE 2: lg_compute_torques only.
 // Optional second destinations of a step that feeds a rollout storage directly (lg_step_transition), see post_instance
 struct PostSink { float* obs_out; const float* values; float* rewards; float* dones; float gamma;
-                  float* rew_out; int rew_stride; };       // (fused rollout steps: the reward column of lg_rollout_batch's (n, horizon) matrix)
+                  float* rew_out; int rew_stride;          // (fused rollout steps: the reward column of lg_rollout_batch's (n, horizon) matrix)
+                  uint8_t* reset_rows; uint8_t* tout_rows; int obs_by_row; };   // lg_step_subset_rows: dense rows by position in the id list (obs_out then too)
 
 // the post-physics step as the tail of this kernel (lg_fused_post.h, defined below the post-physics helpers)
 struct FusedMainIn;
@@ -523,7 +524,7 @@ LG_DEV const DevCtx* late_ctx(const DevCtx* C) {
   return reinterpret_cast<const DevCtx*>(reinterpret_cast<const char*>(C) + zero);
 }
 #define FUSED_STATS_WAVE 1   // which wave of a fused workgroup adds the statistics, draws the arrival ticket and tests for the last arrival (a helper wave: with the rigid-body rows moved in front of (G2) the helpers reach the write-back with less left to do than the main wave; A/B -0.5 %)
-LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out,
+LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out, bool obs_by_row,
                                 const int32_t* __restrict__ ids, bool ro);
 LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid, bool ro);
 LG_DEV bool fused_did_reset(const float* HB, int el);
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       Ct->torques[(size_t)e * NDOF + d] = xtau[j][lane];
     }
     if (fuse) {
-      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out, fids, ro);
+      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out, sink.obs_by_row != 0, fids, ro);
       if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last ? 1 : 0;
       __syncthreads();
       if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x, ro);
@@ -1029,7 +1030,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       // (the net contact forces go out with the env rows: fused_writeback_obs, from the LDS rows fused_main_part1 wrote)
     }
     STAMP(12);
-    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out, fids, ro);
+    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out, sink.obs_by_row != 0, fids, ro);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -2095,7 +2096,7 @@ LG_DEV void fused_noise_park(const float*, float*, int, int, int, const float (*
 LG_DEV void fused_stage_obs_table(const float*, float*, int, const FusedPre&) {}
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__, const float*, const LegModel&, float*, float*, float*, int, int, bool, const float*, const float*,
                                   const float*, const float*, const float*, const V3*, const float*, bool, int64_t, unsigned long long*, const PostSink&, bool, int) {}
-LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__, const float*, const float*, const float*, int, int, int, int64_t, unsigned long long*, float*, const int32_t* __restrict__, bool) { return false; }
+LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__, const float*, const float*, const float*, int, int, int, int64_t, unsigned long long*, float*, bool, const int32_t* __restrict__, bool) { return false; }
 LG_DEV void fused_finalize(const DevCtx* __restrict__, int, int, bool) {}
 LG_DEV bool fused_did_reset(const float*, int) { return false; }
 LG_DEV float* fused_foot_row(float* xs, int) { return xs; }
@@ -2718,6 +2719,22 @@ int lg_rollout_batch(lg_ctx* c, const float* all_us, int32_t horizon, const int3
   }
   HIP_TRY(c, hipGetLastError());
   return lg_sync_main_to_rollout(c, rollouts_per_main, pos_drift, stream);
+}
+
+int lg_gather_step_rows(lg_ctx* c, const int32_t* env_ids, int32_t n, float* obs_out, float* rew_out, uint8_t* reset_out, uint8_t* time_out_out, void* stream);
+int lg_step_subset_rows(lg_ctx* c, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, float* obs_out, float* rew_out, uint8_t* reset_out,
+                        uint8_t* time_out_out, void* stream) {
+  if (!c) return LG_ERR_INVALID;
+  DeviceScope ds_(c->device);
+  if (!actions || !env_ids || n <= 0 || n > c->h.N) { c->err = "bad subset step arguments"; return LG_ERR_INVALID; }
+  if (!obs_out || !rew_out || !reset_out || !time_out_out) { c->err = "lg_step_subset_rows: null output row"; return LG_ERR_INVALID; }
+  if (rollout_mode && can_fuse(c)) {                     // the rows leave the tail of the one launch of a rollout step
+    launch_physics(c, (hipStream_t)stream, actions, env_ids, n, NDOF, 2, PostSink{obs_out, nullptr, nullptr, nullptr, 0.f, rew_out, 1, reset_out, time_out_out, 1});
+    HIP_TRY(c, hipGetLastError());
+    return LG_OK;
+  }
+  const int rc = lg_step_subset(c, actions, env_ids, n, rollout_mode, stream);
+  return rc != LG_OK ? rc : lg_gather_step_rows(c, env_ids, n, obs_out, rew_out, reset_out, time_out_out, stream);
 }
 
 int lg_gather_step_rows(lg_ctx* c, const int32_t* env_ids, int32_t n, float* obs_out, float* rew_out, uint8_t* reset_out, uint8_t* time_out_out, void* stream) {

@@ -122,15 +122,15 @@ class RobotBatchRollout(LeggedRobot):
             if actions.shape[0] != len(self.rollout_env_indices):
                 raise ValueError(f"Expected actions shape ({len(self.rollout_env_indices)}, {self.num_actions}), "
                                  f"got {actions.shape}")
-        self.core.step_subset(actions.to(self.device), self._rollout_ids_i32, rollout_mode=1)
+        rows = self.core.step_subset_rows(actions.to(self.device), self._rollout_ids_i32, rollout_mode=1)
         self._restore_main_env_states()
         self.t_rollout += self.dt
-        return self._step_rows(self._rollout_ids_i32, self.rollout_env_indices)
+        return self._step_rows(self._rollout_ids_i32, self.rollout_env_indices, rows)
 
-    def _step_rows(self, ids_i32, idx):
+    def _step_rows(self, ids_i32, idx, rows=None):
         """The 5-tuple of a subset step: `obs_buf[idx]`, `rew_buf[idx]`, `reset_buf[idx]` and the per-env extras (`:598-600`, `:714-716`) as fresh dense
         tensors from ONE gather launch -- the framework's index kernels for the same rows cost a quarter of a rollout step of 4096 envs."""
-        obs, rew, reset, tout = self.core.gather_step_rows(ids_i32)
+        obs, rew, reset, tout = rows if rows is not None else self.core.gather_step_rows(ids_i32)
         extras = {k: (tout if v is self.time_out_buf else (v[idx] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == self.total_num_envs else v))
                   for k, v in self.extras.items()}
         return obs, None, rew, reset, extras

@@ -135,16 +135,27 @@ class NativeCore:
         self._check(self.lib.lg_step_subset(self.ctx, C.c_void_p(a.data_ptr()), C.c_void_p(env_ids_i32.data_ptr()),
                                             int(env_ids_i32.numel()), int(rollout_mode), self._stream()))
 
+    def _step_row_buffers(self, n):
+        dev = self.t["obs_buf"].device
+        return (torch.empty((n, int(self.t["obs_buf"].shape[1])), dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev),
+                torch.empty(n, dtype=self.t["reset_buf"].dtype, device=dev), torch.empty(n, dtype=self.t["time_out_buf"].dtype, device=dev))
+
     def gather_step_rows(self, env_ids_i32):
         """Fresh dense copies (obs, rew, reset, time_outs) of the listed envs' rows, one launch (`lg_gather_step_rows`)."""
         n = int(env_ids_i32.numel())
-        dev = self.t["obs_buf"].device
-        obs = torch.empty((n, int(self.t["obs_buf"].shape[1])), dtype=torch.float32, device=dev)
-        rew = torch.empty(n, dtype=torch.float32, device=dev)
-        reset = torch.empty(n, dtype=self.t["reset_buf"].dtype, device=dev)
-        tout = torch.empty(n, dtype=self.t["time_out_buf"].dtype, device=dev)
+        obs, rew, reset, tout = self._step_row_buffers(n)
         self._check(self.lib.lg_gather_step_rows(self.ctx, C.c_void_p(env_ids_i32.data_ptr()), n, C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()),
                                                  C.c_void_p(reset.data_ptr()), C.c_void_p(tout.data_ptr()), self._stream()))
+        return obs, rew, reset.view(torch.bool), tout.view(torch.bool)
+
+    def step_subset_rows(self, actions, env_ids_i32, rollout_mode):
+        """`step_subset` + `gather_step_rows` as one library call (`lg_step_subset_rows`): a rollout step hands the rows back from its one launch."""
+        a = self._f32(actions)
+        n = int(env_ids_i32.numel())
+        obs, rew, reset, tout = self._step_row_buffers(n)
+        self._check(self.lib.lg_step_subset_rows(self.ctx, C.c_void_p(a.data_ptr()), C.c_void_p(env_ids_i32.data_ptr()), n, int(rollout_mode),
+                                                 C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()), C.c_void_p(reset.data_ptr()), C.c_void_p(tout.data_ptr()),
+                                                 self._stream()))
         return obs, rew, reset.view(torch.bool), tout.view(torch.bool)
 
     def sync_main_to_rollout(self, rollouts_per_main, pos_drift=0.0):

@@ -399,6 +399,10 @@ int lg_set_state_indexed(lg_ctx* ctx, const float* root_states, const float* dof
  * Any output may be null.  Device pointers. */
 int lg_gather_step_rows(lg_ctx* ctx, const int32_t* env_ids, int32_t n, float* obs_out, float* rew_out, uint8_t* reset_out,
                         uint8_t* time_out_out, void* stream);
+/* lg_step_subset followed by lg_gather_step_rows of the same envs -- for a rollout step of a context that takes the one-launch path the rows leave
+ * the tail of that launch (no second kernel).  All four outputs required. */
+int lg_step_subset_rows(lg_ctx* ctx, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, float* obs_out, float* rew_out,
+                        uint8_t* reset_out, uint8_t* time_out_out, void* stream);
 
 /* Bind the (N, num_extra_obs) f32 device buffer whose rows are appended to the observation (legged_robot_raycast.py:252-254). */
 int lg_set_extra_obs(lg_ctx* ctx, const float* dptr);

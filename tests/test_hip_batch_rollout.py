@@ -88,8 +88,16 @@ def test_robot_batch_rollout_contract():
     ep_before = env.episode_length_buf.clone()
     # identical actions on all rollouts of a main env → identical (deterministic) rollouts; mains frozen
     acts = torch.randn(16, 12, generator=g).cuda().repeat_interleave(8, dim=0)
-    o1, _, r1, d1, _ = env.step_rollout(acts)
+    o1, _, r1, d1, x1 = env.step_rollout(acts)
     assert o1.shape == (128, 48) and r1.shape == (128,)
+    # what a subset step returns are dense copies of the listed envs' rows (`obs_buf[ids]` ...: robot_batch_rollout.py:714-716) -- written by the tail of
+    # the rollout step's one launch (lg_step_subset_rows) or by one gather launch (lg_gather_step_rows); both equal the env-indexed buffers, bit for bit
+    r_idx = env.rollout_env_indices
+    assert torch.equal(o1, env.obs_buf[r_idx]) and torch.equal(r1, env.rew_buf[r_idx]) and torch.equal(d1, env.reset_buf[r_idx])
+    assert d1.dtype == torch.bool and torch.equal(x1["time_outs"], env.time_out_buf[r_idx])
+    g_obs, g_rew, g_reset, g_tout = env.core.gather_step_rows(env._rollout_ids_i32)
+    assert torch.equal(g_obs, o1) and torch.equal(g_rew, r1) and torch.equal(g_reset, d1) and torch.equal(g_tout, x1["time_outs"])
+    assert o1.data_ptr() != env.step_rollout(acts)[0].data_ptr()     # fresh tensors per call, as indexing gives in the reference
     ro = env.root_states[env.rollout_env_indices].view(16, 8, 13)
     assert torch.allclose(ro, ro[:, :1].expand_as(ro), atol=1e-6)
     assert torch.equal(env.root_states[env.main_env_indices], main_before)
