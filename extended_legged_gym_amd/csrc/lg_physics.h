@@ -441,6 +441,7 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
   i0 = max(i0, 0); j0 = max(j0, 0); i1 = min(i1, T.rows - 2); j1 = min(j1, T.cols - 2);
   A.found = false; A.cp = p; A.fn = v3(0, 0, 1);
   if (i0 > i1 || j0 > j1) return;
+  int margin = 1;
   // the window that matters for a sphere whose centre is ABOVE the ground: only what lies within radius + contact_offset can touch it
   const float Rs = fminf(R, A.range + 1e-3f), grs = Rs * ihs + 1e-3f;
   const int si0 = max((int)floorf(gx - grs) - 1, 0), si1 = min((int)floorf(gx + grs) + 1, T.rows - 2);
@@ -450,6 +451,7 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
      // contact is possible, the exact closest point is not needed, and the caller's distance cache gets the proven lower bound.
     const int bi0 = i0 >> 1, bi1 = (i1 + 1) >> 1, bj0 = j0 >> 1, bj1 = (j1 + 1) >> 1;
     float top = -1e30f, top_s = -1e30f;
+    unsigned moved = 0u;                     // last mantissa bit of a block's height: the block holds a vertex the slope correction moved (lg_create)
     for (int bi = bi0; bi <= bi1; bi += 4)
       for (int bj = bj0; bj <= bj1; bj += 8) {
         float tv[32];
@@ -462,6 +464,7 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 #pragma unroll
           for (int t = 0; t < 8; ++t) {
             top = fmaxf(top, tv[8 * u + t]);
+            moved |= __float_as_uint(tv[8 * u + t]);
             const int b_i = min(bi + u, bi1), b_j = min(bj + t, bj1);
             const bool near = b_i >= (si0 >> 1) && b_i <= ((si1 + 1) >> 1) && b_j >= (sj0 >> 1) && b_j <= ((sj1 + 1) >> 1);
             top_s = fmaxf(top_s, near ? tv[8 * u + t] : -1e30f);
@@ -470,12 +473,24 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
     const float clear = p.z - top;
     GSTAMP(22);
     if (clear > A.range) { A.lb = fminf(R, clear); return; }
+    // No moved vertex among the vertices of the window: every triangle there lies inside its own cell's square, so the cells that can hold a point within
+    // the radius are the ones the radius reaches -- no ring of one cell around them (the ring exists because a moved vertex carries its triangles up to one cell
+    // over).  A sphere hovering a hand above the ground then scans one round of cells instead of four, a foot on the ground 4 cells instead of 9-16.
+    margin = (moved & 1u) ? 1 : 0;
+    if (!margin) {
+      i0 = max((int)floorf(gx - gr), 0); i1 = min((int)floorf(gx + gr), T.rows - 2); j0 = max((int)floorf(gy - gr), 0); j1 = min((int)floorf(gy + gr), T.cols - 2);
+    }
     // the centre is above every vertex near it: the sphere is not sunk into the ground (the margin in the caller's range is for
     // that case), so a contact needs a triangle within radius + contact_offset -- search that far only.  Nothing there: the cache
     // gets that radius as its lower bound.
-    if (p.z > top_s + 1e-4f) { R = Rs; A.lb = Rs; i0 = si0; i1 = si1; j0 = sj0; j1 = sj1; }
+    if (p.z > top_s + 1e-4f) {
+      R = Rs; A.lb = Rs;
+      i0 = max((int)floorf(gx - grs) - margin, 0); i1 = min((int)floorf(gx + grs) + margin, T.rows - 2);
+      j0 = max((int)floorf(gy - grs) - margin, 0); j1 = min((int)floorf(gy + grs) + margin, T.cols - 2);
+    }
   }
   float best2 = R * R;
+  int ci = -1, cj = -1;
   // box of a cell's four vertices against the current best distance (cheap, unrolled over a round's cells) ...
   auto box_ok = [&](float4 a0, float4 a1, float4 b0, float4 b1) -> bool {
     const float lox = fminf(fminf(a0.x, a1.x), fminf(b0.x, b1.x)), hix = fmaxf(fmaxf(a0.x, a1.x), fmaxf(b0.x, b1.x));
@@ -500,7 +515,7 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
     // below pass fewer neighbours (each passing cell costs two exact triangle tests, ~2 k cycles of a wave whose busiest lane
     // decides; with the radius-sized initial bound a foot near a cell border passed 4-6 cells).  The cell is met again by the scan:
     // a triangle met twice changes nothing, the update rules are idempotent.
-    const int ci = max(i0, min((int)floorf(gx), i1)), cj = max(j0, min((int)floorf(gy), j1));
+    ci = max(i0, min((int)floorf(gx), i1)); cj = max(j0, min((int)floorf(gy), j1));
     exact(ci, cj);
     GSTAMP(23);
 #if LG_AB == 2      // timing probe: the cell under the sphere only
@@ -508,8 +523,8 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 #endif
     if (found) {
       gr = sqrtf(best2) * ihs * (1.f + 1e-4f) + 1e-3f;
-      i0 = max(i0, (int)floorf(gx - gr) - 1); i1 = min(i1, (int)floorf(gx + gr) + 1);
-      j0 = max(j0, (int)floorf(gy - gr) - 1); j1 = min(j1, (int)floorf(gy + gr) + 1);
+      i0 = max(i0, (int)floorf(gx - gr) - margin); i1 = min(i1, (int)floorf(gx + gr) + margin);
+      j0 = max(j0, (int)floorf(gy - gr) - margin); j1 = min(j1, (int)floorf(gy + gr) + margin);
     }
   }
   // rounds of 4 x 4 cells = 5 x 5 vertices, twenty-five 16-byte loads in flight: the usual window (a foot on the ground, a sphere
@@ -534,7 +549,7 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          if (i + u <= i1 && jb + t <= j1 && box_ok(v[u][t], v[u][t + 1], v[u + 1][t], v[u + 1][t + 1])) pass |= 1u << (4 * u + t);
+          if (i + u <= i1 && jb + t <= j1 && !(i + u == ci && jb + t == cj) && box_ok(v[u][t], v[u][t + 1], v[u + 1][t], v[u + 1][t + 1])) pass |= 1u << (4 * u + t);   // (the cell under the sphere has had its exact test)
       GSTAMP(26);
 #pragma unroll 1
       while (pass) {

@@ -2355,13 +2355,21 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
     const size_t nvert = (size_t)ter->rows * ter->cols, nv = nvert * 4;
     const int mr = (ter->rows + 1) / 2, mc = (ter->cols + 1) / 2;
     std::vector<float> v4(nv, 0.f), top((size_t)mr * mc, -1e30f);
+    std::vector<uint8_t> moved((size_t)mr * mc, 0);       // block holds a vertex the slope correction moved off its lattice position
     for (int i = 0; i < ter->rows; ++i)
       for (int j = 0; j < ter->cols; ++j) {
         const size_t k = (size_t)i * ter->cols + j;
         for (int a = 0; a < 3; ++a) v4[4 * k + a] = ter->grid_vertices[3 * k + a];
         float& t = top[(size_t)(i >> 1) * mc + (j >> 1)];
         t = std::max(t, ter->grid_vertices[3 * k + 2]);
+        const float nx = (float)i * ter->horizontal_scale - ter->border_size, ny = (float)j * ter->horizontal_scale - ter->border_size, tol = 1e-3f * ter->horizontal_scale;
+        if (std::fabs(ter->grid_vertices[3 * k] - nx) > tol || std::fabs(ter->grid_vertices[3 * k + 1] - ny) > tol) moved[(size_t)(i >> 1) * mc + (j >> 1)] = 1;
       }
+    // the flag rides in the last mantissa bit of the block's height, which only ever moves UP for it (the height is an upper bound: one ulp more is still one)
+    for (size_t b = 0; b < top.size(); ++b) {
+      uint32_t u; memcpy(&u, &top[b], 4);
+      if ((u & 1u) != (uint32_t)moved[b]) { top[b] = std::nextafter(top[b], 1e38f); }
+    }
     if (hipMalloc((void**)&c->grid_verts, (nv + top.size()) * sizeof(float)) != hipSuccess ||
         hipMemcpy(c->grid_verts, v4.data(), nv * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy((float*)c->grid_verts + nv, top.data(), top.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
