@@ -5,11 +5,13 @@ header and checks every enum value and struct size against this file so the two 
 """
 import ctypes as C
 
-LG_ABI_VERSION = 4
-LG_MAX_LEGS, LG_JOINTS_PER_LEG = 6, 3
-LG_MAX_DOF = LG_MAX_LEGS * LG_JOINTS_PER_LEG
+LG_ABI_VERSION = 5
+LG_MAX_LEGS, LG_JOINTS_PER_LEG, LG_MAX_JOINTS_PER_LEG = 6, 3, 6
+LG_MAX_DOF = 18
 LG_MAX_CP, LG_MAX_BODIES, LG_MAX_REWARD_TERMS, LG_MAX_INDEX_LIST = 8, 25, 32, 25
-SUPPORTED_LEG_COUNTS = (4, 6)          # kernel instances of the library (csrc/lg_instance.h)
+LG_MAX_SC_PAIRS = 96
+SUPPORTED_LEG_COUNTS = (4, 6, 2)       # kernel instances of the library (csrc/lg_instance.h): 4 x 3, 6 x 3, 2 x 6 joints
+JOINTS_PER_LEG_OF = {4: 3, 6: 3, 2: 6}
 LG_LSTM_NPARAM = 969
 
 LG_OK, LG_ERR_INVALID, LG_ERR_HIP, LG_ERR_UNSUPPORTED, LG_ERR_NO_DEVICE = 0, -1, -2, -3, -4
@@ -65,14 +67,18 @@ f32, i32 = C.c_float, C.c_int32
 
 class lg_robot_model(C.Structure):
     _fields_ = [
-        ("num_legs", i32), ("num_bodies", i32), ("has_foot_body", i32),
+        ("num_legs", i32), ("num_joints_per_leg", i32), ("num_bodies", i32), ("has_foot_body", i32),
         ("base_mass", f32), ("base_com", f32 * 3), ("base_inertia", f32 * 6),
-        ("joint_pos", (f32 * 3) * 3 * LG_MAX_LEGS), ("joint_rot", (f32 * 9) * 3 * LG_MAX_LEGS), ("joint_axis", (f32 * 3) * 3 * LG_MAX_LEGS),
-        ("link_mass", (f32 * 3) * LG_MAX_LEGS), ("link_com", (f32 * 3) * 3 * LG_MAX_LEGS), ("link_inertia", (f32 * 6) * 3 * LG_MAX_LEGS),
+        ("joint_pos", (f32 * 3) * LG_MAX_JOINTS_PER_LEG * LG_MAX_LEGS), ("joint_rot", (f32 * 9) * LG_MAX_JOINTS_PER_LEG * LG_MAX_LEGS),
+        ("joint_axis", (f32 * 3) * LG_MAX_JOINTS_PER_LEG * LG_MAX_LEGS),
+        ("link_mass", (f32 * LG_MAX_JOINTS_PER_LEG) * LG_MAX_LEGS), ("link_com", (f32 * 3) * LG_MAX_JOINTS_PER_LEG * LG_MAX_LEGS),
+        ("link_inertia", (f32 * 6) * LG_MAX_JOINTS_PER_LEG * LG_MAX_LEGS),
         ("foot_pos", (f32 * 3) * LG_MAX_LEGS), ("foot_rot", (f32 * 9) * LG_MAX_LEGS),
         ("dof_lower", f32 * LG_MAX_DOF), ("dof_upper", f32 * LG_MAX_DOF), ("dof_vel_limit", f32 * LG_MAX_DOF), ("torque_limit", f32 * LG_MAX_DOF),
         ("cp_count", i32 * LG_MAX_LEGS), ("cp_link", (i32 * LG_MAX_CP) * LG_MAX_LEGS), ("cp_body", (i32 * LG_MAX_CP) * LG_MAX_LEGS),
         ("cp_pos", (f32 * 3) * LG_MAX_CP * LG_MAX_LEGS), ("cp_radius", (f32 * LG_MAX_CP) * LG_MAX_LEGS),
+        ("cp_slide", (f32 * 3) * LG_MAX_CP * LG_MAX_LEGS),
+        ("num_sc_pairs", i32), ("sc_pairs", (i32 * 4) * LG_MAX_SC_PAIRS),
         ("feet_indices", i32 * LG_MAX_LEGS),
         ("num_penalised", i32), ("penalised_contact_indices", i32 * LG_MAX_INDEX_LIST),
         ("num_termination", i32), ("termination_contact_indices", i32 * LG_MAX_INDEX_LIST),

@@ -55,6 +55,17 @@ LG_DEV float dpp_half_mirror(float x) { return __builtin_bit_cast(float, __built
 LG_DEV float grp_sum(float x) { x = lane_in_group() < NLEG ? x : 0.f; x += dpp_half_mirror(x); x += dpp_xor1(x); x += dpp_xor2(x); return x; }
 #endif
 LG_DEV V3 grp_sum(V3 a) { return v3(grp_sum(a.x), grp_sum(a.y), grp_sum(a.z)); }
+// minimum over ALL lanes of the group (the self-collision pass deals its pair tests to every lane, the idle ones of the six-legged instance included)
+LG_DEV int dpp_xor1_i(int x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true); }
+LG_DEV int dpp_xor2_i(int x) { return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true); }
+#if GRP == 4
+LG_DEV float grp_min_all(float x) { x = fminf(x, dpp_xor1(x)); x = fminf(x, dpp_xor2(x)); return x; }
+LG_DEV int grp_min_all(int x) { x = min(x, dpp_xor1_i(x)); x = min(x, dpp_xor2_i(x)); return x; }
+#else
+LG_DEV int dpp_half_mirror_i(int x) { return __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true); }
+LG_DEV float grp_min_all(float x) { x = fminf(x, dpp_half_mirror(x)); x = fminf(x, dpp_xor1(x)); x = fminf(x, dpp_xor2(x)); return x; }
+LG_DEV int grp_min_all(int x) { x = min(x, dpp_half_mirror_i(x)); x = min(x, dpp_xor1_i(x)); x = min(x, dpp_xor2_i(x)); return x; }
+#endif
 LG_DEV S3 grp_sum(S3 a) { return S3{grp_sum(a.xx), grp_sum(a.xy), grp_sum(a.xz), grp_sum(a.yy), grp_sum(a.yz), grp_sum(a.zz)}; }
 
 // Per-leg model constants staged in LDS as [field][lane of the group]: lane l reads field*GRP + l, i.e. a wave touches GRP consecutive
@@ -62,7 +73,8 @@ LG_DEV S3 grp_sum(S3 a) { return S3{grp_sum(a.xx), grp_sum(a.xy), grp_sum(a.xz),
 enum { LM_JPOS = 0, LM_JROT = 9, LM_JAXIS = 36, LM_MASS = 45, LM_COM = 48, LM_INERTIA = 57, LM_FOOT_POS = 75, LM_FOOT_ROT = 78,
        LM_VEL_LIMIT = 87, LM_TORQUE_LIMIT = 90, LM_DEFAULT_POS = 93, LM_PGAIN = 96, LM_DGAIN = 99, LM_CP_COUNT = 102,
        LM_CP_LINK = 103, LM_CP_POS = 111, LM_CP_RADIUS = 135, LM_LOWER = 143, LM_UPPER = 146,
-       LM_SOFT_LO = 149, LM_SOFT_HI = 152 /* cfg.dof_pos_limits: the soft limits of _reward_dof_pos_limits */, LM_FIELDS = 155 };
+       LM_SOFT_LO = 149, LM_SOFT_HI = 152 /* cfg.dof_pos_limits: the soft limits of _reward_dof_pos_limits */,
+       LM_CP_SLIDE = 155 /* 8 x 3: half-vector of the capsule part a sphere slides on (link frame), lg_robot_model.cp_slide */, LM_FIELDS = 179 };
 struct LegModel {
   const float* t; int l;
   LG_DEV float f(int field) const { return t[field * GRP + l]; }
@@ -99,7 +111,8 @@ __host__ __device__ inline float leg_model_entry(const lg_robot_model* m, const 
   if (field < LM_UPPER) return m->dof_lower[3 * l + field - LM_LOWER];
   if (field < LM_SOFT_LO) return m->dof_upper[3 * l + field - LM_UPPER];
   if (field < LM_SOFT_HI) return g->dof_pos_limits[3 * l + field - LM_SOFT_LO][0];
-  return g->dof_pos_limits[3 * l + field - LM_SOFT_HI][1];
+  if (field < LM_CP_SLIDE) return g->dof_pos_limits[3 * l + field - LM_SOFT_HI][1];
+  { int k = field - LM_CP_SLIDE; return lg_ >= NLEG ? 0.f : m->cp_slide[l][k / 3][k % 3]; }
 }
 inline void pack_leg_model(float* t, const lg_robot_model* m, const lg_config* g) {
   for (int idx = 0; idx < LM_FIELDS * GRP; ++idx) t[idx] = leg_model_entry(m, g, idx);
@@ -310,6 +323,7 @@ LG_DEV void sts3(float* cst, int slot, int f, int lane, V3 a) { CS(slot, f) = a.
 
 struct PhysParams {
   float dt; V3 grav; int iters; float contact_offset, max_depen, erp, cfm, terrain_mu; int solver, fric;
+  unsigned slide_mask;      // bit sl: some leg's sphere in slot sl stands for a capsule part (lg_robot_model.cp_slide), kernel-uniform
 };
 
 struct QuadState {           // per lane: replicated base + own leg (the name is from the four-legged instance)
@@ -387,6 +401,117 @@ LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const Phys
   ContactProbe<S0, S1> pr;
   contact_detect_begin<S0, S1>(lm_, T, k, Rb, pb, pr);
   contact_detect_finish<S0, S1>(lm_, T, P, pb, pr, cst, lane);
+}
+
+// ---- capsule parts (lg_robot_model.cp_slide): a sphere that stands for the part [x - s, x + s] of a capsule's axis collides where that part is
+// deepest in the terrain.  Along the part's ground track the surface is piecewise linear with kinks on the lines of the height grid, so the minimum of
+// the gap sits at a kink or at an end: candidates = the crossing of the x line and of the y line nearest the middle (the middle itself when the part
+// crosses none), then the two ends; a later candidate wins by more than 10 um only (oracle: the same four, the same order, the same rule).  All four
+// cells are requested in `begin` like the fixed spheres' one; slots without a sliding sphere on any leg (slide_mask, kernel-uniform) take the fixed path.
+// What a wave holds per sliding slot between `begin` and `finish` (the actuator network runs in between on the helper waves, whose registers are
+// nearly all taken): middle, half-vector, the two crossing parameters, and per candidate the four height samples packed in two registers -- the
+// cell coordinates (u, v) are recomputed in `finish` by the arithmetic of terrain_fetch.
+struct PackedCell { unsigned h01, h23; };
+LG_DEV PackedCell terrain_fetch_packed(const TerrainView& T, float x, float y) {
+  const TerrainCell c = terrain_fetch(T, x, y);
+  PackedCell p;
+  p.h01 = (unsigned)(unsigned short)c.h0 | ((unsigned)(unsigned short)c.h1 << 16);
+  p.h23 = (unsigned)(unsigned short)c.h2 | ((unsigned)(unsigned short)c.h3 << 16);
+  return p;
+}
+LG_DEV TerrainCell terrain_unpack(const TerrainView& T, float x, float y, const PackedCell& p) {
+  TerrainCell c;
+  const float ihs = T.hscale > 0.f ? frcp(T.hscale) : 0.f;
+  const float fx = (x + T.border) * ihs, fy = (y + T.border) * ihs;
+  int i = (int)floorf(fx), j = (int)floorf(fy);
+  i = max(0, min(i, T.rows - 2)); j = max(0, min(j, T.cols - 2));
+  c.u = fminf(fmaxf(fx - (float)i, 0.f), 1.f); c.v = fminf(fmaxf(fy - (float)j, 0.f), 1.f);
+  c.h0 = (int16_t)(p.h01 & 0xffffu); c.h1 = (int16_t)(p.h01 >> 16); c.h2 = (int16_t)(p.h23 & 0xffffu); c.h3 = (int16_t)(p.h23 >> 16);
+  return c;
+}
+template <int S0, int S1>
+struct ContactProbeC { V3 x[S1 - S0], sv[S1 - S0]; float tx[S1 - S0], ty[S1 - S0], rads[S1 - S0]; PackedCell cell[S1 - S0][4]; };
+template <int S0, int S1>
+LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T, const LegKin& k, const M3& Rb, V3 pb, unsigned slide_mask, ContactProbeC<S0, S1>& pr) {
+  const float ihs = T.hscale > 0.f ? frcp(T.hscale) : 0.f;
+#pragma unroll
+  for (int sl = S0; sl < S1; ++sl) {
+    const int i = sl - S0;
+    const int link = lm_.i(LM_CP_LINK + sl);
+    const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
+    pr.rads[i] = lm_.f(LM_CP_RADIUS + sl);
+    const V3 xb = pb + mul(Rb, lp), x0 = k.O[0] + mul(k.R[0], lp), x1 = k.O[1] + mul(k.R[1], lp), x2 = k.O[2] + mul(k.R[2], lp);
+    const V3 x = link < 0 ? xb : (link == 0 ? x0 : (link == 1 ? x1 : x2));
+    pr.x[i] = x; pr.sv[i] = v3(0, 0, 0); pr.tx[i] = 0.f; pr.ty[i] = 0.f;
+    if ((slide_mask >> sl) & 1u) {                      // (kernel-uniform)
+      const V3 ls = lm_.v(LM_CP_SLIDE + 3 * sl);
+      const V3 sb = mul(Rb, ls), s0 = mul(k.R[0], ls), s1 = mul(k.R[1], ls), s2 = mul(k.R[2], ls);
+      const V3 sv = link < 0 ? sb : (link == 0 ? s0 : (link == 1 ? s1 : s2));
+      const float fxc = (x.x + T.border) * ihs, fyc = (x.y + T.border) * ihs, dfx = sv.x * ihs, dfy = sv.y * ihs;
+      const float Lx = rintf(fxc), Ly = rintf(fyc);
+      pr.tx[i] = fabsf(Lx - fxc) < fabsf(dfx) ? (Lx - fxc) / dfx : 0.f;
+      pr.ty[i] = fabsf(Ly - fyc) < fabsf(dfy) ? (Ly - fyc) / dfy : 0.f;
+      pr.sv[i] = sv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < S1 - S0; ++i) {
+    const V3 x = pr.x[i], sv = pr.sv[i];
+    pr.cell[i][0] = terrain_fetch_packed(T, fmaf(pr.tx[i], sv.x, x.x), fmaf(pr.tx[i], sv.y, x.y));
+    if ((slide_mask >> (S0 + i)) & 1u) {
+      pr.cell[i][1] = terrain_fetch_packed(T, fmaf(pr.ty[i], sv.x, x.x), fmaf(pr.ty[i], sv.y, x.y));
+      pr.cell[i][2] = terrain_fetch_packed(T, x.x - sv.x, x.y - sv.y);
+      pr.cell[i][3] = terrain_fetch_packed(T, x.x + sv.x, x.y + sv.y);
+    }
+  }
+}
+template <int S0, int S1>
+LG_DEV void contact_detect_finish_caps(const LegModel& lm_, const TerrainView& T, const PhysParams& P, V3 pb, unsigned slide_mask, const ContactProbeC<S0, S1>& pr,
+                                       float* cst, int lane) {
+  const int ncp = lm_.i(LM_CP_COUNT);
+#pragma unroll
+  for (int sl = S0; sl < S1; ++sl) {
+    const int i = sl - S0;
+    const V3 xm = pr.x[i], sv = pr.sv[i];
+    const float rad = pr.rads[i];
+    float hh; V3 n;
+    V3 x = v3(fmaf(pr.tx[i], sv.x, xm.x), fmaf(pr.tx[i], sv.y, xm.y), fmaf(pr.tx[i], sv.z, xm.z));
+    terrain_eval(T, terrain_unpack(T, x.x, x.y, pr.cell[i][0]), &hh, &n);
+    float phi = (x.z - hh) * n.z - rad;
+    if ((slide_mask >> sl) & 1u) {
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        const float t = q == 1 ? pr.ty[i] : (q == 2 ? -1.f : 1.f);
+        const V3 xq = q == 1 ? v3(fmaf(t, sv.x, xm.x), fmaf(t, sv.y, xm.y), fmaf(t, sv.z, xm.z)) : (q == 2 ? xm - sv : xm + sv);
+        float hq; V3 nq;
+        terrain_eval(T, terrain_unpack(T, xq.x, xq.y, pr.cell[i][q]), &hq, &nq);
+        const float pq = (xq.z - hq) * nq.z - rad;
+        const bool better = pq < phi - 1e-5f;
+        phi = better ? pq : phi; n = better ? nq : n; x = better ? xq : x;
+      }
+    }
+    const bool active = (sl < ncp) && (phi < P.contact_offset);
+    const V3 r = (x - rad * n) - pb;
+    CS4(sl, 0) = make_float4(n.x, n.y, n.z, phi);
+    CS4(sl, 1) = make_float4(r.x, r.y, r.z, active ? 1.f : 0.f);
+    CS4(sl, 2) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned long long am = __ballot(active);
+    if (lane == 0) AMASK(sl) = am;
+  }
+}
+// begin + finish in one place (the main wave's share, the single-wave instances): one slot at a time -- four cells in flight, ~30 live registers -- because
+// this runs where the mass-matrix factors are live
+template <int S0, int S1>
+LG_DEV void contact_detect_caps(const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k, const M3& Rb, V3 pb,
+                                float* cst, int lane) {
+  if constexpr (S0 < S1) {
+    {
+      ContactProbeC<S0, S0 + 1> pr;
+      contact_detect_begin_caps<S0, S0 + 1>(lm_, T, k, Rb, pb, P.slide_mask, pr);
+      contact_detect_finish_caps<S0, S0 + 1>(lm_, T, P, pb, P.slide_mask, pr, cst, lane);
+    }
+    contact_detect_caps<S0 + 1, S1>(lm_, T, P, k, Rb, pb, cst, lane);
+  }
 }
 
 // Closest point on a GRID mesh (lg_terrain.grid_vertices): the triangles of cell (i, j) are (v0, v3, v1) and (v0, v2, v3) with
@@ -593,11 +718,11 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
   // slots in pairs: one BVH traversal serves two neighbouring spheres (closest_point_pair)
 #pragma unroll 1
   for (int sp0 = s0; sp0 < s1; sp0 += 2) {
-    V3 xs[2]; float rads[2], ranges[2], reaches[2]; ClosestQuery Q[2];
+    V3 xs[2], svs[2]; float rads[2], ranges[2], reaches[2]; ClosestQuery Q[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int sl = sp0 + h;
-      xs[h] = pb; rads[h] = 0.f; ranges[h] = 0.f; reaches[h] = 0.f;
+      xs[h] = pb; svs[h] = v3(0, 0, 0); rads[h] = 0.f; ranges[h] = 0.f; reaches[h] = 0.f;
       Q[h].p = pb; Q[h].max_dist = 0.f; Q[h].on = false; Q[h].found = false; Q[h].cp = pb; Q[h].fn = v3(0, 0, 1); Q[h].range = 0.f; Q[h].lb = 0.f;
       if (sl < s1 && sl < ncp) {
         const int link = lm_.i(LM_CP_LINK + sl);
@@ -605,21 +730,27 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
         rads[h] = lm_.f(LM_CP_RADIUS + sl);
         const V3 x = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
         xs[h] = x;
+        // capsule part (lg_robot_model.cp_slide; zero for a fixed sphere): ONE query from the part's middle that reaches the part's half length
+        // further; the sphere then slides to the point of its segment nearest to the mesh point found (oracle: the same rule)
+        const V3 ls = lm_.v(LM_CP_SLIDE + 3 * sl);
+        svs[h] = link < 0 ? mul(Rb, ls) : (link == 0 ? mul(k.R[0], ls) : (link == 1 ? mul(k.R[1], ls) : mul(k.R[2], ls)));
+        const float ext = norm(ls);
         const float range = rads[h] + P.contact_offset + LG_MESH_CONTACT_MARGIN;
-        const float reach = cq ? range + LG_MESH_CACHE_REACH : range;
+        const float range_q = range + ext;
+        const float reach = cq ? range_q + LG_MESH_CACHE_REACH : range_q;
         ranges[h] = range; reaches[h] = reach;
         bool query = true; float bound = reach;
         if (cq) {
           const float dq = CQ(sl, 3);
           if (dq >= 0.f) {
             const float travel = norm(x - v3(CQ(sl, 0), CQ(sl, 1), CQ(sl, 2)));
-            query = !(travel < dq - range);
+            query = !(travel < dq - range_q);
             bound = fminf(reach, dq + travel * 1.0001f + 1e-4f);
           }
         }
         // grid meshes: a sphere higher above everything around it than radius + contact_offset cannot touch (the margin in `range`
         // is for centres that have sunk BELOW the surface)
-        Q[h].p = x; Q[h].max_dist = bound; Q[h].on = query; Q[h].range = rads[h] + P.contact_offset; Q[h].lb = bound;
+        Q[h].p = x; Q[h].max_dist = bound; Q[h].on = query; Q[h].range = rads[h] + P.contact_offset + ext; Q[h].lb = bound;
       }
     }
 #ifdef LG_STAMPS
@@ -645,12 +776,17 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       const int sl = sp0 + h;
       if (sl >= s1) continue;
       bool active = false; V3 n = v3(0, 0, 1); float phi = 1.f;
-      const V3 x = xs[h]; const float rad = rads[h];
+      V3 x = xs[h]; const float rad = rads[h];
       if (Q[h].on) {
         // nothing found: nothing lies within the radius that was searched (= `reach` whenever the cached distance was exact; a grid
         // mesh may return a smaller proven bound)
-        const V3 diff = x - Q[h].cp; const float dist = Q[h].found ? norm(diff) : (T.GV ? Q[h].lb : reaches[h]);
-        if (cq) { CQ(sl, 0) = x.x; CQ(sl, 1) = x.y; CQ(sl, 2) = x.z; CQ(sl, 3) = dist; }
+        V3 diff = x - Q[h].cp; float dist = Q[h].found ? norm(diff) : (T.GV ? Q[h].lb : reaches[h]);
+        if (cq) { CQ(sl, 0) = x.x; CQ(sl, 1) = x.y; CQ(sl, 2) = x.z; CQ(sl, 3) = dist; }       // (the cache is about the part's middle)
+        const float s2 = dot(svs[h], svs[h]);
+        if (Q[h].found && s2 > 0.f) {
+          const float t = fminf(fmaxf(dot(Q[h].cp - x, svs[h]) / s2, -1.f), 1.f);
+          x = x + t * svs[h]; diff = x - Q[h].cp; dist = norm(diff);
+        }
         if (Q[h].found && dist <= ranges[h]) {
           const float sign = dot(diff, Q[h].fn) < 0.f ? -1.f : 1.f;
           n = dist > 1e-6f ? (sign / dist) * diff : Q[h].fn;
@@ -928,6 +1064,21 @@ LG_DEV void contact_setup_slot_pk(int sl, const LegModel& lm_, const LegKin& k, 
   for (int i = 0; i < (CF_FIELDS - CF_SETUP) / 4; ++i) dst[i] = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
 }
 
+// ---- self-collision (lg_config.self_collisions; oracle: the PairRow block of simulate_env).  Candidate sphere pairs (leg a, slot a, leg b, slot b), one
+// packed word each; every substep the lanes of a group test a share each against the sphere centres the contact detection left in the slot records
+// (centre = base + r + radius * n), the two deepest pairs closer than contact_offset become frictionless unilateral rows between the two bodies.  Both
+// sides of such a row act on the same point, so its base part cancels: the row has joint entries only, like a joint-limit row -- z = Mkk^-1 f per leg,
+// base response S^-1 (-sum Mbk z), joint response z - Y W_b -- and is relaxed behind the terrain contacts of every pass.
+struct SelfCol { const unsigned* pairs; int n; };
+struct SelfRow { bool on; float phi, iA, lam; V3 n; float f[3], Wb[6], Wk[3]; int slot_a, slot_b; /* fbody index of each side on THIS lane, -1: not mine */ };
+LG_DEV V3 sc_sphere(const float* cst, const LegModel& lm_, int gb, int leg, int slot, V3 pb, float* rad) {
+  const float4 n4 = reinterpret_cast<const float4*>(cst + ((slot) * 64 + gb + leg) * CF_FIELDS)[0];
+  const float4 r4 = reinterpret_cast<const float4*>(cst + ((slot) * 64 + gb + leg) * CF_FIELDS)[1];
+  const float r = lm_.t[(LM_CP_RADIUS + slot) * GRP + leg];
+  *rad = r;
+  return v3(pb.x + r4.x + r * n4.x, pb.y + r4.y + r * n4.y, pb.z + r4.z + r * n4.z);
+}
+
 // One physics step of length P.dt for the env this quad owns.  tau_fn(tau[3]) delivers this leg's joint torques; it is
 // called after everything that does not depend on them (kinematics, bias, mass matrix, contact set-up).
 // fbody[5] (optional) receives the net contact force on {base (already quad-summed), link0, link1, link2, foot}.
@@ -937,11 +1088,13 @@ LG_DEV void contact_setup_slot_pk(int sl, const LegModel& lm_, const LegKin& k, 
 // [0, MAIN_DETECT) before the rendezvous (0: the helpers, or the inline path, detect everything).
 // SPEC = 1: the instance of the reference's own solver settings (sim.physx.solver_type = 1: TGS, PhysX's pyramid friction rows) with both
 // choices fixed at compile time; SPEC = 0 reads them from the parameters (the unified step evaluates both friction forms and selects).
-template <bool TMESH, int MAIN_DETECT, bool ALLOW_INLINE, int SPEC = 0, class TauFn, class PrepFn, class ShareFn>
+// FEAT: bit 0 = capsule parts (sliding spheres, contact_detect_*_caps), bit 1 = the self-collision pass -- compile-time, so that the instance without
+// them is the kernel it was before they existed.
+template <bool TMESH, int MAIN_DETECT, bool ALLOW_INLINE, int SPEC = 0, int FEAT = 0, class TauFn, class PrepFn, class ShareFn>
 LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel& lm_, const TerrainView& T, const PhysParams& P,
                             int lane, float* cst, QuadState& s, TauFn tau_fn, PrepFn prep_fn, ShareFn share_fn, SlotShare share,
                             float* xs, float mu_robot, float madd, V3* fbody, unsigned long long* stamps = nullptr,
-                            float* cq = nullptr) {
+                            float* cq = nullptr, SelfCol scol = SelfCol{nullptr, 0}) {
   STAMP_DECL
   const float dt = P.dt;
   const V3 pb = v3(s.root[0], s.root[1], s.root[2]);
@@ -1020,7 +1173,10 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   STAMP(3);
   // ---------------------------------------------------------------- leg bias + contact detection: helper waves or inline
   float bk[3]; V3 Fs, Ns;
-  if (!TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
+  if (!TMESH && MAIN_DETECT > 0 && share.n > 1) {
+    if (FEAT & 1) contact_detect_caps<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
+    else contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
+  }
   STAMP(29);   // (diagnostic: this wave's own detection ends here; what follows in stamp 5 is the wait at the rendezvous)
   if (!prep_fn(bk, Fs, Ns)) {
     // (ALLOW_INLINE = false: a launch with helper waves never gets here; the inlined fallback, unreachable, still costs the main wave
@@ -1028,6 +1184,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     if (ALLOW_INLINE) {
       leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);
       if (TMESH) contact_detect_mesh(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);
+      else if (FEAT & 1) contact_detect_caps<0, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
       else contact_detect<0, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
     }
   }
@@ -1138,6 +1295,74 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     }
   }
 
+  // ---------------------------------------------------------------- self-collision rows (FEAT bit 1)
+  SelfRow sc[2];
+  bool sc_wave = false;
+  if (FEAT & 2) {
+    const int gb = lane & ~(GRP - 1), lgi = lane & (GRP - 1);
+    const int BIG = 0x7fffffff;
+    float p0 = P.contact_offset, p1 = P.contact_offset; int i0 = BIG, i1 = BIG;     // this lane's two deepest of its share of the pairs
+    for (int i = lgi; i < scol.n; i += GRP) {
+      const unsigned pk = scol.pairs[i];
+      float ra, rb;
+      const V3 ca = sc_sphere(cst, lm_, gb, pk & 255u, (pk >> 8) & 255u, pb, &ra), cb = sc_sphere(cst, lm_, gb, (pk >> 16) & 255u, pk >> 24, pb, &rb);
+      const float ph = norm(ca - cb) - ra - rb;
+      if (ph < p0) { p1 = p0; i1 = i0; p0 = ph; i0 = i; } else if (ph < p1) { p1 = ph; i1 = i; }
+    }
+    // the group's two deepest, lowest index first among equals (the order the oracle meets them in)
+    const float m1 = grp_min_all(p0); const int w1 = grp_min_all(p0 == m1 ? i0 : BIG);
+    const float c2 = i0 == w1 ? p1 : p0; const int ci2 = i0 == w1 ? i1 : i0;
+    const float m2 = grp_min_all(c2); const int w2 = grp_min_all(c2 == m2 ? ci2 : BIG);
+    const int win[2] = {w1, w2};
+    sc_wave = __ballot(w1 != BIG) != 0ull;
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      SelfRow& R = sc[q2];
+      R.on = false; R.lam = 0.f; R.phi = 0.f; R.iA = 0.f; R.n = v3(0, 0, 1); R.slot_a = -1; R.slot_b = -1;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { R.f[j] = 0.f; R.Wk[j] = 0.f; }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) R.Wb[a] = 0.f;
+      if (__ballot(win[q2] != BIG) == 0ull) continue;                               // (wave-uniform)
+      const bool on = win[q2] != BIG;
+      const unsigned pk = scol.pairs[on ? win[q2] : 0];
+      const int la = pk & 255u, sa = (pk >> 8) & 255u, lb = (pk >> 16) & 255u, sb = pk >> 24;
+      float ra, rb;
+      const V3 ca = sc_sphere(cst, lm_, gb, la, sa, pb, &ra), cb = sc_sphere(cst, lm_, gb, lb, sb, pb, &rb);
+      const V3 d = ca - cb; const float dist = norm(d);
+      const bool ok = on && dist > 1e-9f;
+      const V3 n = ok ? frcp(dist) * d : v3(0, 0, 1);
+      const float phi = dist - ra - rb;
+      const V3 pc = cb + (rb + 0.5f * phi) * n;
+      const int link_a = __float_as_int(lm_.t[(LM_CP_LINK + sa) * GRP + la]), link_b = __float_as_int(lm_.t[(LM_CP_LINK + sb) * GRP + lb]);
+      const int ka = link_a < 0 ? -1 : (link_a > 2 ? 2 : link_a), kb = link_b < 0 ? -1 : (link_b > 2 ? 2 : link_b);
+      const bool mine_a = ok && lgi == la, mine_b = ok && lgi == lb;
+      float f[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float jn = dot(n, cross(k.ax[j], pc - k.O[j]));
+        f[j] = (mine_a && j <= ka ? jn : 0.f) - (mine_b && j <= kb ? jn : 0.f);
+      }
+      float z[3]; sym3_mul(Mi, f, z);
+      float gvec[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) gvec[a] = -grp_sum(Mbk[a][0] * z[0] + Mbk[a][1] * z[1] + Mbk[a][2] * z[2]);
+      symv6(Si, gvec, R.Wb);
+      float A = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float w = z[j];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) w -= Y[j][a] * R.Wb[a];
+        R.Wk[j] = w; R.f[j] = f[j]; A += f[j] * w;
+      }
+      A = grp_sum(A) + P.cfm;
+      R.on = ok; R.phi = phi; R.n = n; R.iA = ok ? frcp(A) : 0.f;
+      R.slot_a = mine_a ? (link_a < 0 ? 0 : (link_a > 3 ? 4 : link_a + 1)) : -1;
+      R.slot_b = mine_b ? (link_b < 0 ? 0 : (link_b > 3 ? 4 : link_b + 1)) : -1;
+    }
+  }
+
   // ---------------------------------------------------------------- contact / limit rows: TGS sub-intervals or PGS sweeps
   int my_count; const unsigned my_list = active_slot_list(cst, lane, &my_count);
   int my_steps = 0;                                   // wave-uniform: the longest list
@@ -1154,7 +1379,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   const float h = tgs ? dt * frcp((float)iters) : dt, ih = frcp(h);
   const float tgsf = tgs ? 1.f : 0.f;
   const float vlim[3] = {lm_.f(LM_VEL_LIMIT), lm_.f(LM_VEL_LIMIT + 1), lm_.f(LM_VEL_LIMIT + 2)};
-  if (slot_mask || jl_wave) {
+  if (slot_mask || jl_wave || ((FEAT & 2) && sc_wave)) {
     // packed state of the sweeps: base velocity in three pairs, joints (0, 1) as a pair and joint 2 alone, Y by joint pair
     pk2 vBp[3] = {{vB[0], vB[1]}, {vB[2], vB[3]}, {vB[4], vB[5]}};
     pk2 vK01 = {vK[0], vK[1]}; float vK2 = vK[2];
@@ -1263,6 +1488,22 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
         // multipliers back to the record, without a branch: an idle lane rewrites what it has just read
         *reinterpret_cast<float4*>(&CS(sl, CF_L0)) = make_float4(rec[CF_L0], rec[CF_ANN], rec[CF_L1], rec[CF_L2]);
       }
+      if ((FEAT & 2) && sc_wave) {
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {        // the self-collision rows, one after the other
+          SelfRow& R = sc[q2];
+          const float u = grp_sum(R.f[0] * vK01.x + R.f[1] * vK01.y + R.f[2] * vK2);
+          const float dsep = grp_sum(R.f[0] * dqK01.x + R.f[1] * dqK01.y + R.f[2] * dqK2);
+          const float sep = fmaf(tgsf, dsep, R.phi);
+          const float bn = sep >= 0.f ? -sep * ih : fminf(-sep * erp_ih, P.max_depen);
+          const float ln = fmaxf(R.lam - (u - bn) * R.iA, 0.f);
+          const float dl = R.on ? ln - R.lam : 0.f;
+          R.lam = R.on ? ln : R.lam;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) { vBp[p].x = fmaf(dl, R.Wb[2 * p], vBp[p].x); vBp[p].y = fmaf(dl, R.Wb[2 * p + 1], vBp[p].y); }
+          vK01.x = fmaf(dl, R.Wk[0], vK01.x); vK01.y = fmaf(dl, R.Wk[1], vK01.y); vK2 = fmaf(dl, R.Wk[2], vK2);
+        }
+      }
       if (jl_wave) {
         float vBs[6] = {vBp[0].x, vBp[0].y, vBp[1].x, vBp[1].y, vBp[2].x, vBp[2].y}, vKs[3] = {vK01.x, vK01.y, vK2};
         const float dqs[3] = {dqK01.x, dqK01.y, dqK2};
@@ -1342,6 +1583,17 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
       int slotb = link < 0 ? 0 : (link > 3 ? 4 : link + 1);
 #pragma unroll
       for (int b = 0; b < 5; ++b) if (b == slotb) fb[b] = fb[b] + f;
+    }
+    if ((FEAT & 2) && sc_wave) {                // a self-contact loads both of its bodies: each side by the lane that owns it
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const V3 f = (idt * sc[q2].lam) * sc[q2].n;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          if (b == sc[q2].slot_a) fb[b] = fb[b] + f;
+          if (b == sc[q2].slot_b) fb[b] = fb[b] - f;
+        }
+      }
     }
     fbody[0] = grp_sum(fb[0]);
 #pragma unroll

@@ -92,6 +92,8 @@ struct DevCtx {
   unsigned rew_term_mask; int rew_kfat, rew_kterm; float rew_term_scale;
   float hot[HC_COUNT];          // see the HC_* enum (ints stored as bit patterns)
   float lmod[LM_FIELDS * GRP];  // per-leg model table, packed on the host (pack_leg_model)
+  unsigned slide_mask;          // bit sl: some leg's collision sphere in slot sl stands for a capsule part (lg_robot_model.cp_slide)
+  int n_sc; unsigned sc_pairs[LG_MAX_SC_PAIRS];   // self-collision candidates, packed leg a | slot a << 8 | leg b << 16 | slot b << 24 (0 pairs unless lg_config.self_collisions)
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
   float lvl_total_before;       // subset steps with a terrain curriculum: sum of ALL terrain levels before the launch (level_total_kernel)
   unsigned long long LG_G* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
@@ -536,7 +538,11 @@ LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__ C);
 // HELPERS: the launch has the three helper waves (every policy step unless LG_SPLIT=0).  A separate instance, so that the kernel the
 // headline runs does not carry the single-wave fallback (the whole LSTM inlined in the main wave, inline leg bias and contact
 // detection): that dead code accounted for most of the register spills the compiler reported for the kernel.
-// SPEC: 1 = TGS + pyramid friction rows fixed at compile time (A/B build 13 only, see physics_substep); 2 = the fused tail in its rollout variant.
+// SPEC & 3: 1 = TGS + pyramid friction rows fixed at compile time (A/B build 13 only, see physics_substep); 2 = the fused tail in its rollout variant.
+// SPEC >> 2 = FEAT of physics_substep: bit 0 capsule parts (sliding spheres), bit 1 the self-collision pass.  Launches with helper waves pick the
+// instance the model / config needs (launch_physics); the single-wave instances always carry both (FEAT_ALL: a model without sliding spheres or
+// pairs takes the same paths with an empty mask / list), so the kernel of a robot of fixed spheres without self-collision is what it was.
+#define FEAT_ALL 12
 template <int MODE, bool TMESH, bool HELPERS = false, int SPEC = 0>
 #if LG_AB == 9      // timing probe: cap the kernel at the 256 registers per wave that two workgroups per CU would leave (spills go to scratch)
 __attribute__((amdgpu_num_vgpr(120)))
@@ -564,7 +570,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ __attribute__((aligned(16))) float xs[(TMESH ? XS_STRIDE : XS_STRIDE_PK) * 64];              // main wave's mass-matrix factors for the helpers' share of the contact set-up
   __shared__ float cqc[TMESH ? LG_MAX_CP * 4 * 64 : 1];   // mesh terrains: last closest-point query of every collision sphere
   __shared__ int s_last_f;                                 // fused step: this workgroup is the last of the launch to arrive
-  __shared__ __attribute__((aligned(16))) float hot[(HC_COUNT + 3) & ~3];                          // fused step: the scalars of the post-physics tail (HC_*)
+  constexpr bool FUSABLE = LG_LEGS == 4;                    // (can_fuse: the fused tail exists for the four-legged instance only; the others keep the LDS)
+  __shared__ __attribute__((aligned(16))) float hot[FUSABLE ? ((HC_COUNT + 3) & ~3) : 4];             // fused step: the scalars of the post-physics tail (HC_*)
   // A/B build 7 only: an LDS copy of the 905 gate-interleaved LSTM weights for the actuator waves (one ds_read_b128 at a wave-uniform
   // address = four weights).  Measured against the scalar loads (s_load_dwordx16 -> SGPR pairs feeding the packed FMAs) in one session:
   // 0.0897 ms per step from LDS, 0.0818 ms through SGPRs -- the scalar unit fetches the weights beside the vector ALU, while LDS
@@ -573,7 +580,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ __attribute__((aligned(16))) float wlds[LSTM_LDS ? LW_COUNT + 3 : 4];
   // fused ROLLOUT step of an env subset (lg_step_subset rollout_mode = 1, lg_rollout_batch): its own instance (SPEC = 2), so that the
   // full step's tail carries none of the variant's selects (as run-time branches they cost the headline step 1.3 %: A/B in one session)
-  constexpr bool ro = SPEC == 2;
+  constexpr bool ro = (SPEC & 3) == 2;
+  constexpr int FEAT = SPEC >> 2;
+  constexpr bool CAPS = !TMESH && (FEAT & 1);
   const int32_t* const fids = ro ? ids : nullptr;           // the tail's row -> env map: a literal null (rows = envs) in the full step's instance
   const int64_t fstep = ro ? C->counters[3] + 1 : C->counters[0] + 1;   // LR:123 (the statistics step of the previous launch stored it)
   const int64_t gstep_f = C->counters[0] + 1;             // what the gait term's "has a scheduler step run yet" test sees (post_instance: gstep)
@@ -620,7 +629,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     pre_act = actions_in[(size_t)krow * act_stride + 3 * l + (wv - 1)];
   }
   fill_leg_model(lmod, C->lmod, threadIdx.x, blockDim.x);
-  if (fuse && wv == 1) for (int i = lane; i < HC_COUNT; i += 64) hot[i] = C->hot[i];
+  if (FUSABLE && fuse && wv == 1) for (int i = lane; i < HC_COUNT; i += 64) hot[i] = C->hot[i];
   if (LSTM_LDS && MODE == 0 && net && wv >= 2) for (int i = (wv - 2) * 64 + lane; i < LW_COUNT; i += 128) wlds[i] = wlstm[i];
   // With helper waves nobody reads these tables before rendezvous (A) of the first substep (every wave's first use is the kinematics behind it), and
   // every wave has filled its share before it gets there: (A) stands in for a barrier here, and the helper waves start their first recurrent half
@@ -656,7 +665,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     PhysParams P;
     P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
     P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-    P.terrain_mu = C->terrain_mu;
+    P.terrain_mu = C->terrain_mu; P.slide_mask = CAPS ? C->slide_mask : 0u;
     const TerrainView T = C->ter;
     if (TMESH) mesh_cache_io<true>(C, cqc, e, l, lane, 2 * wv);   // this wave's two slots of the persisted query cache -> LDS
 #ifdef LG_STAMPS
@@ -691,6 +700,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       // takes [0, DS0) while it waits for nothing else
       constexpr int DS1P = DS1 > DS0 ? DS1 : DS0 + 1;   // (wave 1 may have no slot at all: its probe type still needs a size)
       ContactProbe<DS0, DS1P> pr1; ContactProbe<DS1, DS2> pr2; ContactProbe<DS2, 8> pr3;
+      ContactProbeC<DS0, DS1P> pc1; ContactProbeC<DS1, DS2> pc2; ContactProbeC<DS2, 8> pc3;     // (capsule-part instances; dead otherwise)
       static_assert(LG_MAX_CP == 8, "slot split assumes 8 contact slots");
       if (wv == 1) {
         float bk[3]; V3 Fs, Ns;
@@ -699,7 +709,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           float4* pb4 = reinterpret_cast<float4*>(xbias[lane]);
           pb4[0] = make_float4(bk[0], bk[1], bk[2], Fs.x); pb4[1] = make_float4(Fs.y, Fs.z, Ns.x, Ns.y); pb4[2] = make_float4(Ns.z, 0.f, 0.f, 0.f);
         }
-        if (!TMESH) { if (DS0 < DS1) contact_detect_begin<DS0, DS1P>(lm_, T, k, Rb, pb, pr1); }
+        if (!TMESH) { if (DS0 < DS1) { if (CAPS) contact_detect_begin_caps<DS0, DS1P>(lm_, T, k, Rb, pb, P.slide_mask, pc1); else contact_detect_begin<DS0, DS1P>(lm_, T, k, Rb, pb, pr1); } }
         else contact_detect_mesh(2, 4, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (TMESH) {
 #ifdef LG_STAMPS
@@ -713,9 +723,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         contact_detect_mesh(2 * wv, 2 * wv + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
 #endif
       } else if (wv == 2) {
-        contact_detect_begin<DS1, DS2>(lm_, T, k, Rb, pb, pr2);
+        if (CAPS) contact_detect_begin_caps<DS1, DS2>(lm_, T, k, Rb, pb, P.slide_mask, pc2); else contact_detect_begin<DS1, DS2>(lm_, T, k, Rb, pb, pr2);
       } else {
-        contact_detect_begin<DS2, 8>(lm_, T, k, Rb, pb, pr3);
+        if (CAPS) contact_detect_begin_caps<DS2, 8>(lm_, T, k, Rb, pb, P.slide_mask, pc3); else contact_detect_begin<DS2, 8>(lm_, T, k, Rb, pb, pr3);
       }
       if (sub == 0) STAMP(54); else STAMP(42);
       if (net) {
@@ -729,9 +739,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           xtau[j][lane] = lstm_input_part(wlstm + zero, x0, x1, lpre, h0, c0, h1, c1, g.actuator_out_scale);
         }
       }
-      if (!TMESH && wv == 1) { if (DS0 < DS1) contact_detect_finish<DS0, DS1P>(lm_, T, P, pb, pr1, cst, lane); }
-      else if (!TMESH && wv == 2) contact_detect_finish<DS1, DS2>(lm_, T, P, pb, pr2, cst, lane);
-      else if (!TMESH && wv == 3) contact_detect_finish<DS2, 8>(lm_, T, P, pb, pr3, cst, lane);
+      if (!TMESH && wv == 1) { if (DS0 < DS1) { if (CAPS) contact_detect_finish_caps<DS0, DS1P>(lm_, T, P, pb, P.slide_mask, pc1, cst, lane); else contact_detect_finish<DS0, DS1P>(lm_, T, P, pb, pr1, cst, lane); } }
+      else if (!TMESH && wv == 2) { if (CAPS) contact_detect_finish_caps<DS1, DS2>(lm_, T, P, pb, P.slide_mask, pc2, cst, lane); else contact_detect_finish<DS1, DS2>(lm_, T, P, pb, pr2, cst, lane); }
+      else if (!TMESH && wv == 3) { if (CAPS) contact_detect_finish_caps<DS2, 8>(lm_, T, P, pb, P.slide_mask, pc3, cst, lane); else contact_detect_finish<DS2, 8>(lm_, T, P, pb, pr3, cst, lane); }
       if (sub == 0) STAMP(55); else STAMP(43);
       lds_barrier();                                   // (A2) bias, contact detection, torques | mass-matrix factors
       if (sub == 0) STAMP(56); else STAMP(44);
@@ -891,8 +901,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   PhysParams P;
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-  P.terrain_mu = C->terrain_mu;
+  P.terrain_mu = C->terrain_mu; P.slide_mask = CAPS ? C->slide_mask : 0u;
   const TerrainView T = C->ter;
+  const SelfCol scol{C->sc_pairs, (FEAT & 2) ? C->n_sc : 0};
   const float mu_robot = pre_mu, madd = pre_madd;
   V3 fbody[5];
   bool fault = false;
@@ -949,8 +960,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     };
     auto share_fn = [&]() { if (helpers) lds_barrier(); };   // (A3) every wave has finished its slots
     const SlotShare share{helpers ? 4 : 1, helpers ? 3 : 0, helpers};     // set-up order: wave 1, 2, 3, then this wave
-    physics_substep<TMESH, TMESH ? 2 : DS0, !(MODE == 0 && HELPERS), SPEC == 1 ? 1 : 0>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
-                              sub == nsub - 1 ? fbody : nullptr, stamps, (TMESH && helpers) ? cqc : nullptr);
+    physics_substep<TMESH, TMESH ? 2 : DS0, !(MODE == 0 && HELPERS), (SPEC & 3) == 1 ? 1 : 0, FEAT>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
+                              sub == nsub - 1 ? fbody : nullptr, stamps, (TMESH && helpers) ? cqc : nullptr, scol);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -2252,6 +2263,12 @@ static const char* validate(const lg_config* cfg, const lg_robot_model* model, c
   if (model->num_penalised < 0 || model->num_penalised > NBODY_MAX || model->num_termination < 0 || model->num_termination > NBODY_MAX)
     return "more penalised / termination bodies than the robot has";
   for (int l = 0; l < NLEG; ++l) if (model->cp_count[l] < 0 || model->cp_count[l] > LG_MAX_CP) return "bad cp_count";
+  if (model->num_sc_pairs < 0 || model->num_sc_pairs > LG_MAX_SC_PAIRS) return "bad num_sc_pairs";
+  for (int i = 0; i < model->num_sc_pairs; ++i) {
+    const int32_t* q = model->sc_pairs[i];
+    if (q[0] < 0 || q[0] >= NLEG || q[2] < 0 || q[2] >= NLEG || q[1] < 0 || q[1] >= model->cp_count[q[0]] || q[3] < 0 || q[3] >= model->cp_count[q[2]])
+      return "sc_pairs names a collision sphere the model does not have";
+  }
   for (int k = 0; k < cfg->num_reward_terms; ++k) if (cfg->reward_term_ids[k] < 0 || cfg->reward_term_ids[k] >= LG_REW_COUNT) return "unknown reward term id";
   if (!cfg->noise_scale_vec) return "noise_scale_vec is null";
   if (cfg->num_height_points > 0 && !cfg->height_points) return "height_points is null";
@@ -2321,6 +2338,13 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   pack_lstm_weights(h.lstm_w, cfg->actuator_net);
   reward_meta(h);
   hot_config(h);
+  h.slide_mask = 0u;
+  for (int l = 0; l < NLEG; ++l)
+    for (int sl = 0; sl < model->cp_count[l]; ++sl)
+      if (model->cp_slide[l][sl][0] != 0.f || model->cp_slide[l][sl][1] != 0.f || model->cp_slide[l][sl][2] != 0.f) h.slide_mask |= 1u << sl;
+  h.n_sc = cfg->self_collisions ? model->num_sc_pairs : 0;
+  for (int i = 0; i < h.n_sc; ++i)
+    h.sc_pairs[i] = (unsigned)model->sc_pairs[i][0] | (unsigned)model->sc_pairs[i][1] << 8 | (unsigned)model->sc_pairs[i][2] << 16 | (unsigned)model->sc_pairs[i][3] << 24;
   h.mesh_cache = nullptr;
   if (ter->mesh_type == LG_MESH_TRIMESH) {
     const size_t nf = (size_t)cfg->num_envs * NLEG * LG_MAX_CP * 4;
@@ -2498,25 +2522,35 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
   // as well: the main wave alone took 0.134 ms per rollout step of 4096 envs on the plane
   const int nact = (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) ? 3 : 0;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
+  // Which instance (physics_kernel's SPEC): rollout tail or not, and the model features the launch needs -- capsule parts (heightfield / plane: the
+  // triangle-mesh detection slides its spheres without a flag) and the self-collision pass.  A robot of fixed spheres without self-collision runs
+  // the plain instance.
+  const bool tm = c->h.ter.mesh_type == LG_MESH_TRIMESH;
+  const bool caps = !tm && c->h.slide_mask != 0u, selfc = c->h.n_sc > 0;
+#define LG_LAUNCH_PK(TM, HELP, SPEC_, THREADS) \
+  hipLaunchKernelGGL((physics_kernel<0, TM, HELP, SPEC_>), dim3(nb), dim3(THREADS), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink)
 #if LG_LEGS == 4
   if (fuse == 2) {                                       // (can_fuse() held: helper waves are present)
-    if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
-      hipLaunchKernelGGL((physics_kernel<0, true, true, 2>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
-    else
-      hipLaunchKernelGGL((physics_kernel<0, false, true, 2>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
+    if (tm) { if (selfc) LG_LAUNCH_PK(true, true, 2 + 8, 256); else LG_LAUNCH_PK(true, true, 2, 256); }
+    else if (selfc) LG_LAUNCH_PK(false, true, 2 + 12, 256);
+    else if (caps) LG_LAUNCH_PK(false, true, 2 + 4, 256);
+    else LG_LAUNCH_PK(false, true, 2, 256);
     return;
   }
 #endif
-  if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
-    hipLaunchKernelGGL((physics_kernel<0, true, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
+  if (tm) { if (selfc) LG_LAUNCH_PK(true, true, 8, 256); else LG_LAUNCH_PK(true, true, 0, 256); }
   else
 #if LG_AB == 13
-    if (nact == 3 && c->h.cfg.solver_type == LG_SOLVER_TGS && c->h.cfg.friction_model == LG_FRICTION_PYRAMID && c->spec)
-      hipLaunchKernelGGL((physics_kernel<0, false, true, 1>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
+    if (nact == 3 && c->h.cfg.solver_type == LG_SOLVER_TGS && c->h.cfg.friction_model == LG_FRICTION_PYRAMID && c->spec && !caps && !selfc)
+      LG_LAUNCH_PK(false, true, 1, 256);
     else
 #endif
-    if (nact == 3) hipLaunchKernelGGL((physics_kernel<0, false, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
-    else hipLaunchKernelGGL((physics_kernel<0, false, false>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink);
+    if (nact == 3) {
+      if (selfc) LG_LAUNCH_PK(false, true, 12, 256);
+      else if (caps) LG_LAUNCH_PK(false, true, 4, 256);
+      else LG_LAUNCH_PK(false, true, 0, 256);
+    } else LG_LAUNCH_PK(false, false, FEAT_ALL, 64);
+#undef LG_LAUNCH_PK
 }
 
 int lg_step(lg_ctx* c, const float* actions, void* stream) {
@@ -2815,9 +2849,9 @@ int lg_simulate(lg_ctx* c, void* stream) {
   DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
-    hipLaunchKernelGGL((physics_kernel<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
+    hipLaunchKernelGGL((physics_kernel<1, true, false, FEAT_ALL>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
   else
-    hipLaunchKernelGGL((physics_kernel<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
+    hipLaunchKernelGGL((physics_kernel<1, false, false, FEAT_ALL>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }

@@ -54,19 +54,41 @@ def model_struct(m):
     s = abi.lg_robot_model()
     nl = int(m.get("num_legs", len(m["cp_count"])))
     if nl not in abi.SUPPORTED_LEG_COUNTS:
-        raise ValueError(f"robot with {nl} legs: the library holds kernel instances for {abi.SUPPORTED_LEG_COUNTS} legs of three joints")
-    s.num_legs = nl
+        raise ValueError(f"robot with {nl} legs: the library holds kernel instances for 4 x 3, 6 x 3 and 2 x 6 joints")
+    nj = int(m.get("num_joints_per_leg", len(m["joint_pos"][0])))
+    if nj != abi.JOINTS_PER_LEG_OF[nl]:
+        raise ValueError(f"robot with {nl} legs of {nj} joints: the {nl}-legged instance has {abi.JOINTS_PER_LEG_OF[nl]} joints per leg")
+    s.num_legs, s.num_joints_per_leg = nl, nj
     s.num_bodies, s.has_foot_body = int(m["num_bodies"]), int(m["has_foot_body"])
     s.base_mass = float(m["base_mass"])
-    for name in ("base_com", "base_inertia", "joint_pos", "joint_rot", "joint_axis", "link_mass", "link_com",
-                 "link_inertia", "foot_pos", "foot_rot", "dof_lower", "dof_upper", "dof_vel_limit", "torque_limit",
-                 "cp_pos", "cp_radius"):
+    for name in ("base_com", "base_inertia", "dof_lower", "dof_upper", "dof_vel_limit", "torque_limit"):
         _fill(getattr(s, name), m[name])
+    # per-leg tables: the struct's rows are sized for the largest instance (LG_MAX_LEGS x LG_MAX_JOINTS_PER_LEG)
+    for name, tail in (("joint_pos", (3,)), ("joint_rot", (9,)), ("joint_axis", (3,)), ("link_mass", ()), ("link_com", (3,)), ("link_inertia", (6,))):
+        buf = np.zeros((abi.LG_MAX_LEGS, abi.LG_MAX_JOINTS_PER_LEG) + tail)
+        buf[:nl, :nj] = np.asarray(m[name], np.float64).reshape((nl, nj) + tail)
+        _fill(getattr(s, name), buf)
+    for name, tail in (("foot_pos", (3,)), ("foot_rot", (9,))):
+        buf = np.zeros((abi.LG_MAX_LEGS,) + tail)
+        buf[:nl] = np.asarray(m[name], np.float64).reshape((nl,) + tail)
+        _fill(getattr(s, name), buf)
+    for name, tail in (("cp_pos", (3,)), ("cp_radius", ()), ("cp_slide", (3,))):
+        buf = np.zeros((abi.LG_MAX_LEGS, abi.LG_MAX_CP) + tail)
+        if name in m:
+            buf[:nl] = np.asarray(m[name], np.float64).reshape((nl, abi.LG_MAX_CP) + tail)
+        _fill(getattr(s, name), buf)
     for l in range(nl):
         s.cp_count[l] = int(m["cp_count"][l])
         for k in range(abi.LG_MAX_CP):
             s.cp_link[l][k] = int(m["cp_link"][l][k])
             s.cp_body[l][k] = int(m["cp_body"][l][k])
+    pairs = m.get("sc_pairs", [])
+    if len(pairs) > abi.LG_MAX_SC_PAIRS:
+        raise ValueError(f"{len(pairs)} self-collision candidate pairs, the pass holds {abi.LG_MAX_SC_PAIRS}")
+    s.num_sc_pairs = len(pairs)
+    for i, pr in enumerate(pairs):
+        for k in range(4):
+            s.sc_pairs[i][k] = int(pr[k])
     feet = m["feet_indices"]
     if len(feet) != nl:
         raise ValueError(f"expected {nl} feet bodies, got {feet} (cfg.asset.foot_name)")
@@ -166,19 +188,6 @@ def height_points(cfg):
     return np.stack([gx.reshape(-1), gy.reshape(-1)], axis=1).astype(np.float32)
 
 
-_SELF_COLLISION_WARNED = False
-
-
-def _warn_self_collisions_once():
-    global _SELF_COLLISION_WARNED
-    if not _SELF_COLLISION_WARNED:
-        _SELF_COLLISION_WARNED = True
-        import warnings
-        warnings.warn("asset.self_collisions = 0 asks for contacts between the robot's own links; this simulator generates terrain contacts "
-                      "only (DESIGN.md: out of scope, measured on the walk matrix: no link pair within 3.2 cm).  Set asset.self_collisions = 1 "
-                      "to silence this.", stacklevel=3)
-
-
 class NativeSetup:
     """Owns the structs plus the numpy buffers their pointers refer to (keeps them alive)."""
 
@@ -186,6 +195,10 @@ class NativeSetup:
                  reward_stage=None, num_extra_obs=0, reset_z_from_terrain=False,
                  custom_origins=None, terminate_on_flip=False, reward_term_variants=None, reward_class="base", noise_layout_dof=None):
         self.model_dict = model
+        if not getattr(cfg.asset, "replace_cylinder_with_capsule", True) and "cp_slide" in model:
+            # (legged_robot_config.py:171; every task of the reference leaves it True.)  Without the option the cylinders stay cylinders in PhysX;
+            # here their spheres then stay where they are
+            model = dict(model, cp_slide=np.zeros_like(np.asarray(model["cp_slide"], np.float64)).tolist())
         self.model = model_struct(model)
         dt = cfg.control.decimation * sim_params.dt
         self.dt = dt
@@ -337,13 +350,9 @@ class NativeSetup:
             raise ValueError(f"sim.physx.penetration_recovery must be in (0, 1], got {erp}")
         c.erp, c.cfm = erp, 1e-6
         # asset.self_collisions is PhysX's collision-filter bitmask (legged_robot_config.py:176, create_actor at legged_robot.py:792):
-        # 0 = the actor's own shapes collide with each other.  lg_config.self_collisions carries the REQUEST with one meaning (1 = the task
-        # asks for leg-leg / leg-trunk contacts); the kernels generate terrain contacts only -- a pair across two legs couples two leg blocks
-        # and does not fit the per-leg Schur structure -- so a task that asks is told once.  Measured (tools/physics/self_collision_probe.py):
-        # on the walk matrix no such pair comes within 3.2 cm, i.e. none would be generated at contact_offset = 1 cm.
-        c.self_collisions = 1 if int(getattr(cfg.asset, "self_collisions", 0)) == 0 else 0
-        if c.self_collisions:
-            _warn_self_collisions_once()
+        # 0 = the actor's own shapes collide with each other.  lg_config.self_collisions = 1 selects the kernel instance with the
+        # self-collision pass over the model's candidate sphere pairs (lg_robot_model.sc_pairs, utils/urdf.self_collision_pairs).
+        c.self_collisions = 1 if (int(getattr(cfg.asset, "self_collisions", 0)) == 0 and self.model.num_sc_pairs > 0) else 0
         c.seed, c.rng_mode = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_mode)
         self.cfg = c
 

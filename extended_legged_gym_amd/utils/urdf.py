@@ -1,7 +1,7 @@
 """URDF → reduced legged-robot model (what `gym.load_asset` does for the reference).
 
 Replaces the Isaac Gym URDF importer behind `legged_robot.py:738-763` for the robots the hot path
-supports: a floating base with four or six 3-revolute-joint legs (the kernel instances of `csrc/lg_instance.h`).  Follows the asset options the reference sets
+supports: a floating base with four or six 3-revolute-joint legs, or two 6-revolute-joint legs (the kernel instances of `csrc/lg_instance.h`).  Follows the asset options the reference sets
 (`legged_robot_config.py:159-180`): `collapse_fixed_joints=True` (links behind fixed joints are merged into
 their parent: inertia, collision shapes, child joints), `dont_collapse="true"` fixed joints keep their child
 as a reported rigid body (the FOOT links, `anymal_c.urdf:701`), `replace_cylinder_with_capsule=True`.
@@ -9,7 +9,8 @@ Bodies and DOFs are ordered depth-first with children sorted by name, which repr
 LF, LH, RF, RH order for ANYmal-C (`anymal_c_rough_config.py:43-58`).
 
 Collision shapes are reduced to spheres: sphere → itself; capsule → spheres at both segment ends (+ centre when
-long); box → its 8 corners.  Mesh collisions (PhysX cooks a convex hull per mesh) cannot be reduced from the URDF alone: a link whose
+long), or -- a capsule whose parts are longer than its radius -- K SLIDING spheres: each stands for one K-th of the axis and collides where
+that part is deepest (`cp_slide`, `include/lgstep.h`); box → its 8 corners.  Mesh collisions (PhysX cooks a convex hull per mesh) cannot be reduced from the URDF alone: a link whose
 collision geometry is a mesh, or which has none, takes the primitives of the same-named link of `collision_urdf` when one is given --
 `el_mini_collsp.urdf`, the box / sphere approximation of the hexapod's STL hulls that ships next to `el_mini.urdf` -- and is
 ignored otherwise.
@@ -20,7 +21,9 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 MAX_CP = 8
-LEG_COUNTS = (4, 6)
+LEG_COUNTS = (4, 6, 2)
+JOINTS_PER_LEG = {4: 3, 6: 3, 2: 6}
+MAX_SC_PAIRS = 96
 
 
 def rpy_to_mat(rpy):
@@ -54,7 +57,7 @@ class _Body:
         self.mass = 0.0
         self.com = np.zeros(3)
         self.inertia = np.zeros((3, 3))   # about com, body axes
-        self.spheres = []                 # (pos, radius)
+        self.spheres = []                 # (pos, radius, slide half-vector)
         self.spheres_compact = []         # the reduced set, used when a leg overflows the contact slots
         self.children = []                # (joint dict, _Body)
 
@@ -67,14 +70,29 @@ class _Body:
         self.mass, self.com = mt, cn
 
 
+def _capsule_parts(p, axis_half, r, parts):
+    """`parts` spheres along the capsule axis [p - axis_half, p + axis_half].  Parts longer than the radius slide (an edge narrower than the
+    sphere spacing would pass between fixed spheres): sphere i sits in the middle of its part with the half part as `slide`.  Shorter parts:
+    fixed spheres at the two ends (+ the middle for three)."""
+    part_len = 2.0 * np.linalg.norm(axis_half) / parts
+    if part_len > r:
+        return [(p + axis_half * (-1.0 + (2 * i + 1.0) / parts), r, axis_half / parts) for i in range(parts)]
+    z = np.zeros(3)
+    out = [(p + axis_half, r, z), (p - axis_half, r, z)]
+    if parts == 3:
+        out.append((p, r, z))
+    return out
+
+
 def _link_spheres(link, compact=False):
-    """Collision primitives of one URDF link as spheres (centre in the link frame, radius): sphere -> itself; cylinder /
-    capsule -> its two end caps (+ the middle when long); box -> its 8 corners as points.
+    """Collision primitives of one URDF link as spheres (centre in the link frame, radius, slide half-vector): sphere -> itself; cylinder /
+    capsule -> two parts (three when long), see `_capsule_parts`; box -> its 8 corners as points.
 
     `compact=True` is the reduced set used when a leg does not fit the MAX_CP contact slots: a slender box (longest edge
-    >= 4x the others) becomes a capsule along that edge (two end spheres of the mean half-width), a stubby cylinder
-    (length < 2 r) one sphere, and the optional middle spheres are left out."""
+    >= 4x the others) becomes a capsule along that edge (two parts, radius = the mean half-width), a stubby cylinder
+    (length < 2 r) one sphere, and long capsules get two parts instead of three."""
     out = []
+    z = np.zeros(3)
     for col in link.findall("collision"):
         R, p = _origin(col)
         g = col.find("geometry")
@@ -82,16 +100,13 @@ def _link_spheres(link, compact=False):
             continue
         s = g[0]
         if s.tag == "sphere":
-            out.append((p, float(s.get("radius"))))
+            out.append((p, float(s.get("radius")), z))
         elif s.tag in ("cylinder", "capsule"):
             L, r = float(s.get("length")), float(s.get("radius"))
             if compact and L < 2.0 * r:
-                out.append((p, r))
+                out.append((p, r, z))
                 continue
-            ends = [p + R @ np.array([0, 0, 0.5 * L]), p - R @ np.array([0, 0, 0.5 * L])]
-            out += [(e, r) for e in ends]
-            if L > 4.0 * r and not compact:
-                out.append((p, r))
+            out += _capsule_parts(p, R @ np.array([0, 0, 0.5 * L]), r, 3 if (L > 4.0 * r and not compact) else 2)
         elif s.tag == "box":
             sz = _vec(s.get("size"))
             ax = int(np.argmax(sz))
@@ -99,12 +114,12 @@ def _link_spheres(link, compact=False):
             if compact and sz[ax] >= 4.0 * max(others):
                 r = 0.25 * (others[0] + others[1])
                 d = np.zeros(3); d[ax] = 0.5 * sz[ax] - r
-                out += [(p + R @ d, r), (p - R @ d, r)]
+                out += _capsule_parts(p, R @ d, r, 2)
                 continue
             for sx in (-0.5, 0.5):
                 for sy in (-0.5, 0.5):
                     for szz in (-0.5, 0.5):
-                        out.append((p + R @ (sz * np.array([sx, sy, szz])), 0.0))
+                        out.append((p + R @ (sz * np.array([sx, sy, szz])), 0.0, z))
     return out
 
 
@@ -115,7 +130,7 @@ def _two_extremes(spheres):
     best, pair = -1.0, (0, 1)
     for i in range(len(spheres)):
         for j in range(i + 1, len(spheres)):
-            d = float(np.linalg.norm(np.asarray(spheres[i][0]) - np.asarray(spheres[j][0])))
+            d = float(np.linalg.norm(np.asarray(spheres[i][0]) - np.asarray(spheres[j][0])))      # (pos, radius, slide)
             if d > best:
                 best, pair = d, (i, j)
     return [spheres[pair[0]], spheres[pair[1]]]
@@ -174,10 +189,10 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
                           [float(t.get("ixz")), float(t.get("iyz")), float(t.get("izz"))]])
             Rw = R @ Ri
             body.add_inertia(m, p + R @ pi, Rw @ I @ Rw.T)
-        for (sp, sr) in _link_spheres(collision_source(link_name)):
-            body.spheres.append((p + R @ sp, sr))
-        for (sp, sr) in _link_spheres(collision_source(link_name), compact=True):
-            body.spheres_compact.append((p + R @ sp, sr))
+        for (sp, sr, ss) in _link_spheres(collision_source(link_name)):
+            body.spheres.append((p + R @ sp, sr, R @ ss))
+        for (sp, sr, ss) in _link_spheres(collision_source(link_name), compact=True):
+            body.spheres_compact.append((p + R @ sp, sr, R @ ss))
         for j in sorted(by_parent.get(link_name, []), key=lambda jj: jj["child"]):
             Rj, pj = R @ j["R"], p + R @ j["p"]
             if j["type"] == "fixed" and collapse_fixed_joints and not j["keep"]:
@@ -193,11 +208,12 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
     legs = [jc for jc in base.children if jc[0]["type"] in ("revolute", "continuous")]
     assert len(legs) in LEG_COUNTS, f"hot path supports robots with {LEG_COUNTS} legs, found {len(legs)} revolute children of the base"
     num_legs = len(legs)
+    nj = JOINTS_PER_LEG[num_legs]
 
     m = dict(base_mass=base.mass, base_com=base.com.tolist(), base_inertia=_sym6(base.inertia),
              joint_pos=[], joint_rot=[], joint_axis=[], link_mass=[], link_com=[], link_inertia=[],
              foot_pos=[], foot_rot=[], dof_lower=[], dof_upper=[], dof_vel_limit=[], torque_limit=[],
-             cp_count=[], cp_link=[], cp_body=[], cp_pos=[], cp_radius=[])
+             cp_count=[], cp_link=[], cp_body=[], cp_pos=[], cp_radius=[], cp_slide=[])
     body_names, dof_names = [base.name], []
     has_foot = True
     base_spheres = list(base.spheres)
@@ -213,17 +229,17 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
                 break
             assert len(nxt) == 1 and not fixed, "legs must be serial chains"
             j, b = nxt[0]
-        assert len(chain) == 3, f"leg {b0.name}: expected 3 revolute joints, got {len(chain)}"
+        assert len(chain) == nj, f"leg {b0.name}: expected {nj} revolute joints, got {len(chain)}"
         jp, jr, ja, lm, lc, li = [], [], [], [], [], []
-        cps, cps_c = [], []   # (link, body index, pos, radius): full and reduced primitive sets
+        cps, cps_c = [], []   # (link, body index, pos, radius, slide): full and reduced primitive sets
         for k, (jj, bb) in enumerate(chain):
             body_index = len(body_names)
             body_names.append(bb.name)
             dof_names.append(jj["name"])
             mass, com, ine = bb.mass, bb.com.copy(), bb.inertia.copy()
-            spheres = [(k, body_index, sp, sr) for (sp, sr) in bb.spheres]
-            spheres_c = [(k, body_index, sp, sr) for (sp, sr) in _two_extremes(bb.spheres_compact)]
-            if k == 2:
+            spheres = [(k, body_index, sp, sr, ss) for (sp, sr, ss) in bb.spheres]
+            spheres_c = [(k, body_index, sp, sr, ss) for (sp, sr, ss) in _two_extremes(bb.spheres_compact)]
+            if k == nj - 1:
                 if foot is not None:
                     fj, fb = foot
                     tmp = _Body("tmp")
@@ -233,8 +249,8 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
                     m["foot_pos"].append(fj["p"].tolist())
                     m["foot_rot"].append(fj["R"].reshape(-1).tolist())
                     foot_index = body_index + 1
-                    spheres = [(3, foot_index, fj["p"] + fj["R"] @ sp, sr) for (sp, sr) in fb.spheres] + spheres
-                    spheres_c = [(3, foot_index, fj["p"] + fj["R"] @ sp, sr) for (sp, sr) in fb.spheres_compact] + spheres_c
+                    spheres = [(nj, foot_index, fj["p"] + fj["R"] @ sp, sr, fj["R"] @ ss) for (sp, sr, ss) in fb.spheres] + spheres
+                    spheres_c = [(nj, foot_index, fj["p"] + fj["R"] @ sp, sr, fj["R"] @ ss) for (sp, sr, ss) in fb.spheres_compact] + spheres_c
                 else:
                     has_foot = False
                     m["foot_pos"].append([0.0, 0.0, 0.0])
@@ -254,7 +270,7 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
             m["torque_limit"].append(jj["effort"])
         if foot is not None:
             body_names.append(foot[1].name)
-        base_share = [(-1, 0, sp, sr) for bi, (sp, sr) in enumerate(base_spheres) if bi % num_legs == l]
+        base_share = [(-1, 0, sp, sr, ss) for bi, (sp, sr, ss) in enumerate(base_spheres) if bi % num_legs == l]
         if len(cps) + len(base_share) > MAX_CP:
             # does not fit the contact slots: reduced primitives for the leg, and the trunk keeps its share (the task
             # terminates on trunk contact, legged_robot.py:215-221) ahead of the proximal links
@@ -266,16 +282,82 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
         m["cp_body"].append([c[1] for c in cps] + [0] * pad)
         m["cp_pos"].append([np.asarray(c[2]).tolist() for c in cps] + [[0.0, 0.0, 0.0]] * pad)
         m["cp_radius"].append([c[3] for c in cps] + [0.0] * pad)
+        m["cp_slide"].append([np.asarray(c[4]).tolist() for c in cps] + [[0.0, 0.0, 0.0]] * pad)
         for key, val in (("joint_pos", jp), ("joint_rot", jr), ("joint_axis", ja), ("link_mass", lm),
                          ("link_com", lc), ("link_inertia", li)):
             m[key].append(val)
 
     m["has_foot_body"] = int(has_foot)
     m["num_legs"] = num_legs
+    m["num_joints_per_leg"] = nj
     m["num_bodies"] = len(body_names)
     m["body_names"], m["dof_names"] = body_names, dof_names
+    m["sc_pairs"] = self_collision_pairs(m)
     finalize_indices(m, foot_name, penalize_contacts_on, terminate_after_contacts_on)
     return m
+
+
+def sphere_centres(m, q):
+    """World positions (base frame = identity) of every collision sphere at joint angles q (S, dof): {(leg, slot): (S, 3)}.  Numpy forward
+    kinematics of the reduced model (the kernels' `leg_kinematics`), used on the host only."""
+    q = np.atleast_2d(np.asarray(q, np.float64))
+    S = q.shape[0]
+    nl, nj = m["num_legs"], len(m["joint_pos"][0])
+    out = {}
+
+    def rodrigues(a, ang):
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3)[None] + np.sin(ang)[:, None, None] * K[None] + (1 - np.cos(ang))[:, None, None] * (K @ K)[None]
+    for l in range(nl):
+        R = np.broadcast_to(np.eye(3), (S, 3, 3)).copy()
+        O = np.zeros((S, 3))
+        frames = [(R.copy(), O.copy())]                    # index 0: the base; 1 + j: link j
+        for j in range(nj):
+            O = O + R @ np.asarray(m["joint_pos"][l][j])
+            R = R @ np.asarray(m["joint_rot"][l][j]).reshape(3, 3) @ rodrigues(np.asarray(m["joint_axis"][l][j]), q[:, nj * l + j])
+            frames.append((R.copy(), O.copy()))
+        for s in range(m["cp_count"][l]):
+            link = m["cp_link"][l][s]
+            Rl, Ol = frames[0] if link < 0 else frames[1 + min(link, nj - 1)]
+            out[(l, s)] = Ol + Rl @ np.asarray(m["cp_pos"][l][s])
+    return out
+
+
+def self_collision_pairs(m, samples=20000, seed=0, reach=0.02):
+    """Candidate sphere pairs of the self-collision pass (`lg_robot_model.sc_pairs`): pairs PhysX would test with `asset.self_collisions = 0`
+    -- shapes of different bodies that are not parent and child -- that come within `reach` of each other somewhere in the joint-limit box
+    (limits, cut to +-1.5 rad around the middle of unlimited or very wide joints), found by sampling; the most frequent MAX_SC_PAIRS when there
+    are more.  Two zero-radius points (box corners) never meet and are left out.  [leg a, slot a, leg b, slot b]."""
+    nl, nj = m["num_legs"], len(m["joint_pos"][0])
+    lo, hi = np.asarray(m["dof_lower"], np.float64), np.asarray(m["dof_upper"], np.float64)
+    wide = ~(lo < hi) | (hi - lo > 3.0)
+    mid = np.where(~(lo < hi), 0.0, 0.5 * (lo + hi))
+    lo, hi = np.where(wide, mid - 1.5, lo), np.where(wide, mid + 1.5, hi)
+    rng = np.random.RandomState(seed)
+    q = lo + (hi - lo) * rng.rand(samples, nl * nj)
+    cen = sphere_centres(m, q)
+    keys = sorted(cen)
+    found = []
+    for ia, (la, sa) in enumerate(keys):
+        for (lb, sb) in keys[ia + 1:]:
+            ka, kb = m["cp_link"][la][sa], m["cp_link"][lb][sb]
+            ra, rb = m["cp_radius"][la][sa], m["cp_radius"][lb][sb]
+            if ra == 0.0 and rb == 0.0:
+                continue
+            ka, kb = min(ka, nj - 1), min(kb, nj - 1)          # the foot body is fixed to the last link
+            if ka < 0 and kb < 0:
+                continue                                      # both on the trunk
+            if (ka < 0) != (kb < 0):
+                if max(ka, kb) == 0:
+                    continue                                  # trunk and a first link: parent and child
+            elif la == lb and abs(ka - kb) < 2:
+                continue                                      # same link, or parent and child
+            d = np.linalg.norm(cen[(la, sa)] - cen[(lb, sb)], axis=1) - ra - rb
+            hits = int((d < reach).sum())
+            if hits:
+                found.append((hits, [la, sa, lb, sb]))
+    found.sort(key=lambda t: (-t[0], t[1]))
+    return sorted(p for _, p in found[:MAX_SC_PAIRS])
 
 
 def finalize_indices(m, foot_name, penalize_contacts_on, terminate_after_contacts_on):

@@ -28,16 +28,19 @@
 extern "C" {
 #endif
 
-#define LG_ABI_VERSION 4
+#define LG_ABI_VERSION 5
 
-/* Robots of this library: a floating base carrying `lg_robot_model.num_legs` serial chains ("legs") of LG_JOINTS_PER_LEG revolute joints
- * each.  The library holds one instance of its kernels per supported leg count -- 4 (ANYmal-B/C, A1, Go2) and 6 (ElSpider Air, el_mini.urdf) --
- * chosen by lg_create from the model; the structs below are sized for the largest, and every (N, dof) / (N, legs) / (N, bodies) tensor has the
- * model's own extents (12 / 4 / 17 for a quadruped with FOOT bodies, 18 / 6 / 25 for the hexapod). */
+/* Robots of this library: a floating base carrying `lg_robot_model.num_legs` serial chains ("legs") of `num_joints_per_leg` revolute joints
+ * each.  The library holds one instance of its kernels per supported topology -- 4 x 3 (ANYmal-B/C, A1, Go2), 6 x 3 (ElSpider Air, el_mini.urdf)
+ * and 2 x 6 (Cassie, cassie.urdf: an open chain, the knee-spring joints are commented out in the reference's file) -- chosen by lg_create from the
+ * model; the structs below are sized for the largest, and every (N, dof) / (N, legs) / (N, bodies) tensor has the model's own extents (12 / 4 / 17
+ * for a quadruped with FOOT bodies, 18 / 6 / 25 for the hexapod, 12 / 2 / 13 for the biped). */
 #define LG_MAX_LEGS 6
-#define LG_JOINTS_PER_LEG 3
-#define LG_MAX_DOF (LG_MAX_LEGS * LG_JOINTS_PER_LEG)
+#define LG_JOINTS_PER_LEG 3    /* the three-joint instances */
+#define LG_MAX_JOINTS_PER_LEG 6
+#define LG_MAX_DOF 18          /* max over the instances of num_legs * num_joints_per_leg */
 #define LG_MAX_CP 8            /* collision points per leg lane */
+#define LG_MAX_SC_PAIRS 96     /* candidate sphere pairs of the self-collision pass */
 #define LG_MAX_BODIES 25       /* base + 6 x (HIP, THIGH, SHANK, FOOT) */
 #define LG_MAX_REWARD_TERMS 32
 #define LG_MAX_INDEX_LIST 25     /* = LG_MAX_BODIES: a task may penalise contacts on every body (elspider_air_batch_rollout: base + 18 links) */
@@ -168,30 +171,41 @@ enum lg_tensor_id {
 };
 
 typedef struct lg_robot_model {
-  int32_t num_legs;                   /* 4 or 6 */
-  int32_t num_bodies;                 /* 1 + num_legs*(3 + has_foot_body) */
+  int32_t num_legs;                   /* 4, 6 or 2 */
+  int32_t num_joints_per_leg;         /* 3 (num_legs 4, 6) or 6 (num_legs 2) */
+  int32_t num_bodies;                 /* 1 + num_legs*(num_joints_per_leg + has_foot_body) */
   int32_t has_foot_body;              /* FOOT links kept by dont_collapse="true" */
   float base_mass;
   float base_com[3];                  /* base frame */
   float base_inertia[6];              /* about COM, base axes: xx xy xz yy yz zz */
-  /* DOF / leg order = Isaac Gym asset order (alphabetical depth-first): leg l, joint j -> dof 3*l+j */
-  float joint_pos[LG_MAX_LEGS][LG_JOINTS_PER_LEG][3];   /* joint frame origin in parent body frame */
-  float joint_rot[LG_MAX_LEGS][LG_JOINTS_PER_LEG][9];   /* row-major rotation parent body -> joint frame at q = 0 */
-  float joint_axis[LG_MAX_LEGS][LG_JOINTS_PER_LEG][3];  /* unit axis, joint frame */
-  float link_mass[LG_MAX_LEGS][LG_JOINTS_PER_LEG];
-  float link_com[LG_MAX_LEGS][LG_JOINTS_PER_LEG][3];    /* link frame */
-  float link_inertia[LG_MAX_LEGS][LG_JOINTS_PER_LEG][6];/* about COM, link axes */
+  /* DOF / leg order = Isaac Gym asset order (alphabetical depth-first): leg l, joint j -> dof num_joints_per_leg*l+j */
+  float joint_pos[LG_MAX_LEGS][LG_MAX_JOINTS_PER_LEG][3];   /* joint frame origin in parent body frame */
+  float joint_rot[LG_MAX_LEGS][LG_MAX_JOINTS_PER_LEG][9];   /* row-major rotation parent body -> joint frame at q = 0 */
+  float joint_axis[LG_MAX_LEGS][LG_MAX_JOINTS_PER_LEG][3];  /* unit axis, joint frame */
+  float link_mass[LG_MAX_LEGS][LG_MAX_JOINTS_PER_LEG];
+  float link_com[LG_MAX_LEGS][LG_MAX_JOINTS_PER_LEG][3];    /* link frame */
+  float link_inertia[LG_MAX_LEGS][LG_MAX_JOINTS_PER_LEG][6];/* about COM, link axes */
   float foot_pos[LG_MAX_LEGS][3];     /* FOOT body frame in the last link's frame */
   float foot_rot[LG_MAX_LEGS][9];
   float dof_lower[LG_MAX_DOF], dof_upper[LG_MAX_DOF]; /* hard limits; lower >= upper means unlimited */
   float dof_vel_limit[LG_MAX_DOF];
   float torque_limit[LG_MAX_DOF];     /* URDF effort */
-  /* collision spheres, grouped by the leg lane that owns them; link -1 = base, 0..2 = leg link, 3 = foot body */
+  /* collision spheres, grouped by the leg lane that owns them; link -1 = base, 0..J-1 = leg link, J = foot body (J = num_joints_per_leg) */
   int32_t cp_count[LG_MAX_LEGS];
   int32_t cp_link[LG_MAX_LEGS][LG_MAX_CP];
   int32_t cp_body[LG_MAX_LEGS][LG_MAX_CP];              /* rigid-body index the contact force is reported on */
   float cp_pos[LG_MAX_LEGS][LG_MAX_CP][3];              /* in the owning link's frame (foot: last link frame) */
   float cp_radius[LG_MAX_LEGS][LG_MAX_CP];
+  /* Capsule segments (asset.replace_cylinder_with_capsule, legged_robot_config.py:171): a sphere with a non-zero cp_slide stands for the part
+   * [cp_pos - cp_slide, cp_pos + cp_slide] of a capsule's axis (link frame) and collides where that part is deepest in the terrain -- its ends, or
+   * where its ground track crosses a line of the height grid (the surface is piecewise linear along the track: the minimum of the gap sits at one
+   * of those).  Zero: a fixed sphere. */
+  float cp_slide[LG_MAX_LEGS][LG_MAX_CP][3];
+  /* Self-collision (asset.self_collisions = 0, legged_robot_config.py:170,176: PhysX collides the actor's own shapes, parent-child links excepted):
+   * the sphere pairs (leg a, slot a, leg b, slot b) the pass tests every substep -- the pairs the host found reachable within the joint limits.
+   * Read only when lg_config.self_collisions is set. */
+  int32_t num_sc_pairs;
+  int32_t sc_pairs[LG_MAX_SC_PAIRS][4];
   int32_t feet_indices[LG_MAX_LEGS];
   int32_t num_penalised, penalised_contact_indices[LG_MAX_INDEX_LIST];
   int32_t num_termination, termination_contact_indices[LG_MAX_INDEX_LIST];
@@ -261,9 +275,10 @@ typedef struct lg_config {
   float contact_offset, max_depenetration_velocity, erp, cfm;
   int32_t solver_type;                /* enum lg_solver: physx.solver_type */
   int32_t friction_model;             /* enum lg_friction */
-  int32_t self_collisions;            /* the task's REQUEST, recorded only: 1 = asset.self_collisions == 0 (legged_robot_config.py:176, create_actor at
-                                       * legged_robot.py:792), i.e. PhysX would collide the robot's own shapes.  No kernel reads it: contacts are
-                                       * link-terrain only (out of scope); the host warns once when a task asks. */
+  int32_t self_collisions;            /* 1 = asset.self_collisions == 0 (legged_robot_config.py:176, create_actor at legged_robot.py:792): PhysX collides
+                                       * the robot's own shapes.  Selects the kernel instance with the self-collision pass: every substep the pairs
+                                       * lg_robot_model.sc_pairs are tested, and the (up to two) deepest ones closer than contact_offset become
+                                       * frictionless unilateral rows between the two bodies, relaxed behind the terrain contacts of each pass. */
   /* rng */
   uint64_t seed; int32_t rng_mode;
   /* AsyncGaitScheduler (utils/gait_scheduler.py:97-175; sections cfg.async_gait_scheduler / cfg.rewards.async_gait_scheduler):

@@ -52,8 +52,11 @@ def momenta(model, rb, added_mass=0.0):
 SOLVERS = [("tgs", "pyramid"), ("tgs", "cone"), ("pgs", "cone")]      # sim.physx.solver_type 1 / 0, friction rows
 
 
-def make(cfg_cls=AnymalCFlatCfg, n=4, control="T", gravity=(0, 0, -9.81), terrain=None, mutate=None, speed_limit=True, solver=None):
+def make(cfg_cls=AnymalCFlatCfg, n=4, control="T", gravity=(0, 0, -9.81), terrain=None, mutate=None, speed_limit=True, solver=None,
+         self_collisions=False):
     cfg = cfg_cls()
+    cfg.asset.self_collisions = 0 if self_collisions else 1      # (PhysX's filter mask: 0 = the robot's own shapes collide; the known answers below are about
+                                                                 #  the free dynamics and the terrain contacts: random poses may start with two spheres overlapping)
     if solver is not None:
         cfg.sim.physx.solver_type = {"pgs": 0, "tgs": 1}[solver[0]]
         cfg.sim.physx.friction_model = solver[1]

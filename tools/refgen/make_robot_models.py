@@ -17,6 +17,9 @@ OUT = os.path.join(REPO, "extended_legged_gym_amd", "resources")
 m = load_urdf(f"{REF}/robots/anymal_c/urdf/anymal_c.urdf", "FOOT", ["SHANK", "THIGH"], ["base"])
 save_model(m, f"{OUT}/robots/anymal_c.json")
 print("anymal_c", m["num_bodies"], m["body_names"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"])
+m = load_urdf(f"{REF}/robots/anymal_b/urdf/anymal_b.urdf", "FOOT", ["SHANK", "THIGH"], ["base"])
+save_model(m, f"{OUT}/robots/anymal_b.json")
+print("anymal_b", m["num_bodies"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"])
 m = load_urdf(f"{REF}/robots/a1/urdf/a1.urdf", "foot", ["thigh", "calf"], ["base"])
 save_model(m, f"{OUT}/robots/a1.json")
 print("a1", m["num_bodies"], m["body_names"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"])
