@@ -405,12 +405,15 @@ LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const Phys
 
 // ---- capsule parts (lg_robot_model.cp_slide): a sphere that stands for the part [x - s, x + s] of a capsule's axis collides where that part is
 // deepest in the terrain.  Along the part's ground track the surface is piecewise linear with kinks on the lines of the height grid, so the minimum of
-// the gap sits at a kink or at an end: candidates = the crossing of the x line and of the y line nearest the middle (the middle itself when the part
-// crosses none), then the two ends; a later candidate wins by more than 10 um only (oracle: the same four, the same order, the same rule).  All four
-// cells are requested in `begin` like the fixed spheres' one; slots without a sliding sphere on any leg (slide_mask, kernel-uniform) take the fixed path.
-// What a wave holds per sliding slot between `begin` and `finish` (the actuator network runs in between on the helper waves, whose registers are
-// nearly all taken): middle, half-vector, the two crossing parameters, and per candidate the four height samples packed in two registers -- the
-// cell coordinates (u, v) are recomputed in `finish` by the arithmetic of terrain_fetch.
+// the gap sits at a kink or at an end.  Candidates, in this order: just in front of and just behind the crossing of the x line nearest the middle
+// (LG_CAPS_NUDGE cells off the line on either side: ON the line the two cells disagree about the normal, and which of them a sample lands in would be
+// decided by the last bit), the same for the y line (the middle itself, twice, when the part crosses no line), then the two ends; a later candidate
+// wins by more than 10 um only (oracle: the same six, the same order, the same rule).  All cells are requested in `begin` like the fixed spheres'
+// one; slots without a sliding sphere on any leg (slide_mask, kernel-uniform) take the fixed path.
+#define LG_CAPS_NUDGE 2e-3f
+// (a conditional between two V3 OBJECTS may be compiled as a conditional between their addresses -- the objects then live in scratch; component by
+//  component it is three v_cndmask)
+LG_DEV V3 sel3(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 struct PackedCell { unsigned h01, h23; };
 LG_DEV PackedCell terrain_fetch_packed(const TerrainView& T, float x, float y) {
   const TerrainCell c = terrain_fetch(T, x, y);
@@ -430,7 +433,9 @@ LG_DEV TerrainCell terrain_unpack(const TerrainView& T, float x, float y, const 
   return c;
 }
 template <int S0, int S1>
-struct ContactProbeC { V3 x[S1 - S0], sv[S1 - S0]; float tx[S1 - S0], ty[S1 - S0], rads[S1 - S0]; PackedCell cell[S1 - S0][4]; };
+struct ContactProbeC { V3 x[S1 - S0], sv[S1 - S0]; float t[S1 - S0][4], rads[S1 - S0]; PackedCell cell[S1 - S0][6]; };
+// parameter of candidate q (0..5) of a part: t[0..3] = the four samples around the two crossings, then the ends
+LG_DEV float caps_t(const float t[4], int q) { return q < 4 ? t[q] : (q == 4 ? -1.f : 1.f); }
 template <int S0, int S1>
 LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T, const LegKin& k, const M3& Rb, V3 pb, unsigned slide_mask, ContactProbeC<S0, S1>& pr) {
   const float ihs = T.hscale > 0.f ? frcp(T.hscale) : 0.f;
@@ -441,27 +446,30 @@ LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T,
     const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
     pr.rads[i] = lm_.f(LM_CP_RADIUS + sl);
     const V3 xb = pb + mul(Rb, lp), x0 = k.O[0] + mul(k.R[0], lp), x1 = k.O[1] + mul(k.R[1], lp), x2 = k.O[2] + mul(k.R[2], lp);
-    const V3 x = link < 0 ? xb : (link == 0 ? x0 : (link == 1 ? x1 : x2));
-    pr.x[i] = x; pr.sv[i] = v3(0, 0, 0); pr.tx[i] = 0.f; pr.ty[i] = 0.f;
+    const V3 x = sel3(link < 0, xb, sel3(link == 0, x0, sel3(link == 1, x1, x2)));
+    pr.x[i] = x; pr.sv[i] = v3(0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pr.t[i][q] = 0.f;
     if ((slide_mask >> sl) & 1u) {                      // (kernel-uniform)
       const V3 ls = lm_.v(LM_CP_SLIDE + 3 * sl);
       const V3 sb = mul(Rb, ls), s0 = mul(k.R[0], ls), s1 = mul(k.R[1], ls), s2 = mul(k.R[2], ls);
-      const V3 sv = link < 0 ? sb : (link == 0 ? s0 : (link == 1 ? s1 : s2));
+      const V3 sv = sel3(link < 0, sb, sel3(link == 0, s0, sel3(link == 1, s1, s2)));
       const float fxc = (x.x + T.border) * ihs, fyc = (x.y + T.border) * ihs, dfx = sv.x * ihs, dfy = sv.y * ihs;
       const float Lx = rintf(fxc), Ly = rintf(fyc);
-      pr.tx[i] = fabsf(Lx - fxc) < fabsf(dfx) ? (Lx - fxc) / dfx : 0.f;
-      pr.ty[i] = fabsf(Ly - fyc) < fabsf(dfy) ? (Ly - fyc) / dfy : 0.f;
+      const bool cx = fabsf(Lx - fxc) < fabsf(dfx), cy = fabsf(Ly - fyc) < fabsf(dfy);
+      const float tx = cx ? (Lx - fxc) / dfx : 0.f, ex = cx ? LG_CAPS_NUDGE / fabsf(dfx) : 0.f;
+      const float ty = cy ? (Ly - fyc) / dfy : 0.f, ey = cy ? LG_CAPS_NUDGE / fabsf(dfy) : 0.f;
+      pr.t[i][0] = fmaxf(tx - ex, -1.f); pr.t[i][1] = fminf(tx + ex, 1.f); pr.t[i][2] = fmaxf(ty - ey, -1.f); pr.t[i][3] = fminf(ty + ey, 1.f);
       pr.sv[i] = sv;
     }
   }
 #pragma unroll
   for (int i = 0; i < S1 - S0; ++i) {
     const V3 x = pr.x[i], sv = pr.sv[i];
-    pr.cell[i][0] = terrain_fetch_packed(T, fmaf(pr.tx[i], sv.x, x.x), fmaf(pr.tx[i], sv.y, x.y));
+    pr.cell[i][0] = terrain_fetch_packed(T, fmaf(pr.t[i][0], sv.x, x.x), fmaf(pr.t[i][0], sv.y, x.y));
     if ((slide_mask >> (S0 + i)) & 1u) {
-      pr.cell[i][1] = terrain_fetch_packed(T, fmaf(pr.ty[i], sv.x, x.x), fmaf(pr.ty[i], sv.y, x.y));
-      pr.cell[i][2] = terrain_fetch_packed(T, x.x - sv.x, x.y - sv.y);
-      pr.cell[i][3] = terrain_fetch_packed(T, x.x + sv.x, x.y + sv.y);
+#pragma unroll
+      for (int q = 1; q < 6; ++q) { const float t = caps_t(pr.t[i], q); pr.cell[i][q] = terrain_fetch_packed(T, fmaf(t, sv.x, x.x), fmaf(t, sv.y, x.y)); }
     }
   }
 }
@@ -475,19 +483,19 @@ LG_DEV void contact_detect_finish_caps(const LegModel& lm_, const TerrainView& T
     const V3 xm = pr.x[i], sv = pr.sv[i];
     const float rad = pr.rads[i];
     float hh; V3 n;
-    V3 x = v3(fmaf(pr.tx[i], sv.x, xm.x), fmaf(pr.tx[i], sv.y, xm.y), fmaf(pr.tx[i], sv.z, xm.z));
+    V3 x = v3(fmaf(pr.t[i][0], sv.x, xm.x), fmaf(pr.t[i][0], sv.y, xm.y), fmaf(pr.t[i][0], sv.z, xm.z));
     terrain_eval(T, terrain_unpack(T, x.x, x.y, pr.cell[i][0]), &hh, &n);
     float phi = (x.z - hh) * n.z - rad;
     if ((slide_mask >> sl) & 1u) {
 #pragma unroll
-      for (int q = 1; q < 4; ++q) {
-        const float t = q == 1 ? pr.ty[i] : (q == 2 ? -1.f : 1.f);
-        const V3 xq = q == 1 ? v3(fmaf(t, sv.x, xm.x), fmaf(t, sv.y, xm.y), fmaf(t, sv.z, xm.z)) : (q == 2 ? xm - sv : xm + sv);
+      for (int q = 1; q < 6; ++q) {
+        const float t = caps_t(pr.t[i], q);
+        const V3 xq = v3(fmaf(t, sv.x, xm.x), fmaf(t, sv.y, xm.y), fmaf(t, sv.z, xm.z));
         float hq; V3 nq;
         terrain_eval(T, terrain_unpack(T, xq.x, xq.y, pr.cell[i][q]), &hq, &nq);
         const float pq = (xq.z - hq) * nq.z - rad;
         const bool better = pq < phi - 1e-5f;
-        phi = better ? pq : phi; n = better ? nq : n; x = better ? xq : x;
+        phi = better ? pq : phi; n = sel3(better, nq, n); x = sel3(better, xq, x);
       }
     }
     const bool active = (sl < ncp) && (phi < P.contact_offset);
@@ -733,7 +741,7 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
         // capsule part (lg_robot_model.cp_slide; zero for a fixed sphere): ONE query from the part's middle that reaches the part's half length
         // further; the sphere then slides to the point of its segment nearest to the mesh point found (oracle: the same rule)
         const V3 ls = lm_.v(LM_CP_SLIDE + 3 * sl);
-        svs[h] = link < 0 ? mul(Rb, ls) : (link == 0 ? mul(k.R[0], ls) : (link == 1 ? mul(k.R[1], ls) : mul(k.R[2], ls)));
+        svs[h] = sel3(link < 0, mul(Rb, ls), sel3(link == 0, mul(k.R[0], ls), sel3(link == 1, mul(k.R[1], ls), mul(k.R[2], ls))));
         const float ext = norm(ls);
         const float range = rads[h] + P.contact_offset + LG_MESH_CONTACT_MARGIN;
         const float range_q = range + ext;
@@ -1331,7 +1339,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
       const V3 ca = sc_sphere(cst, lm_, gb, la, sa, pb, &ra), cb = sc_sphere(cst, lm_, gb, lb, sb, pb, &rb);
       const V3 d = ca - cb; const float dist = norm(d);
       const bool ok = on && dist > 1e-9f;
-      const V3 n = ok ? frcp(dist) * d : v3(0, 0, 1);
+      const V3 n = sel3(ok, frcp(dist) * d, v3(0, 0, 1));
       const float phi = dist - ra - rb;
       const V3 pc = cb + (rb + 0.5f * phi) * n;
       const int link_a = __float_as_int(lm_.t[(LM_CP_LINK + sa) * GRP + la]), link_b = __float_as_int(lm_.t[(LM_CP_LINK + sb) * GRP + lb]);

@@ -60,6 +60,7 @@ class _Body:
         self.spheres = []                 # (pos, radius, slide half-vector)
         self.spheres_compact = []         # the reduced set, used when a leg overflows the contact slots
         self.children = []                # (joint dict, _Body)
+        self.slide = True                 # capsule parts of this body slide (False: the trunk)
 
     def add_inertia(self, m, c, I):
         if m <= 0.0:
@@ -70,12 +71,13 @@ class _Body:
         self.mass, self.com = mt, cn
 
 
-def _capsule_parts(p, axis_half, r, parts):
+def _capsule_parts(p, axis_half, r, parts, slide=True):
     """`parts` spheres along the capsule axis [p - axis_half, p + axis_half].  Parts longer than the radius slide (an edge narrower than the
-    sphere spacing would pass between fixed spheres): sphere i sits in the middle of its part with the half part as `slide`.  Shorter parts:
-    fixed spheres at the two ends (+ the middle for three)."""
+    sphere spacing would pass between fixed spheres): sphere i sits in the middle of its part with the half part as `slide`.  Shorter parts,
+    and the trunk's capsules (`slide=False`: a trunk contact ends the episode, where on the capsule it is found first matters little): fixed spheres at
+    the two ends (+ the middle for three)."""
     part_len = 2.0 * np.linalg.norm(axis_half) / parts
-    if part_len > r:
+    if slide and part_len > r:
         return [(p + axis_half * (-1.0 + (2 * i + 1.0) / parts), r, axis_half / parts) for i in range(parts)]
     z = np.zeros(3)
     out = [(p + axis_half, r, z), (p - axis_half, r, z)]
@@ -84,7 +86,7 @@ def _capsule_parts(p, axis_half, r, parts):
     return out
 
 
-def _link_spheres(link, compact=False):
+def _link_spheres(link, compact=False, slide=True):
     """Collision primitives of one URDF link as spheres (centre in the link frame, radius, slide half-vector): sphere -> itself; cylinder /
     capsule -> two parts (three when long), see `_capsule_parts`; box -> its 8 corners as points.
 
@@ -106,7 +108,7 @@ def _link_spheres(link, compact=False):
             if compact and L < 2.0 * r:
                 out.append((p, r, z))
                 continue
-            out += _capsule_parts(p, R @ np.array([0, 0, 0.5 * L]), r, 3 if (L > 4.0 * r and not compact) else 2)
+            out += _capsule_parts(p, R @ np.array([0, 0, 0.5 * L]), r, 3 if (L > 4.0 * r and not compact) else 2, slide)
         elif s.tag == "box":
             sz = _vec(s.get("size"))
             ax = int(np.argmax(sz))
@@ -114,7 +116,7 @@ def _link_spheres(link, compact=False):
             if compact and sz[ax] >= 4.0 * max(others):
                 r = 0.25 * (others[0] + others[1])
                 d = np.zeros(3); d[ax] = 0.5 * sz[ax] - r
-                out += _capsule_parts(p, R @ d, r, 2)
+                out += _capsule_parts(p, R @ d, r, 2, slide)
                 continue
             for sx in (-0.5, 0.5):
                 for sy in (-0.5, 0.5):
@@ -189,9 +191,9 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
                           [float(t.get("ixz")), float(t.get("iyz")), float(t.get("izz"))]])
             Rw = R @ Ri
             body.add_inertia(m, p + R @ pi, Rw @ I @ Rw.T)
-        for (sp, sr, ss) in _link_spheres(collision_source(link_name)):
+        for (sp, sr, ss) in _link_spheres(collision_source(link_name), slide=body.slide):
             body.spheres.append((p + R @ sp, sr, R @ ss))
-        for (sp, sr, ss) in _link_spheres(collision_source(link_name), compact=True):
+        for (sp, sr, ss) in _link_spheres(collision_source(link_name), compact=True, slide=body.slide):
             body.spheres_compact.append((p + R @ sp, sr, R @ ss))
         for j in sorted(by_parent.get(link_name, []), key=lambda jj: jj["child"]):
             Rj, pj = R @ j["R"], p + R @ j["p"]
@@ -203,6 +205,7 @@ def load_urdf(path, foot_name, penalize_contacts_on, terminate_after_contacts_on
                 body.children.append((dict(j, R=Rj, p=pj), cb))
 
     base = _Body(roots[0])
+    base.slide = False
     absorb(base, roots[0], np.eye(3), np.zeros(3))
     base.children.sort(key=lambda jc: jc[1].name)
     legs = [jc for jc in base.children if jc[0]["type"] in ("revolute", "continuous")]

@@ -102,13 +102,16 @@ def cell_statistics(cell, vx_cmd, vx, vy, term, rst):
     return out
 
 
-def check(stats):
+def check(stats, per_cell=1023):
+    """`per_cell`: envs behind every cell's fractions.  The fall bar is 10 % per cell where a cell has ~1000 envs (GPU: measured 3-7 %); the CPU run has 48
+    per cell, where a true 4 % reads 0-10 % (binomial): there the bar per cell is 15 % and the mean over the matrix is held to 7 %."""
     for name, st in stats.items():
         assert st["track_err"] < 0.25, (name, st)
         for c, v in zip(CMDS, st["per_cmd"]):
             assert abs(v - c) < 0.15, (name, st)
         assert st["rew_tracking"] >= 0.6, (name, st)
-        assert st["frac_envs_fallen_after_settle"] < 0.10, (name, st)
+        assert st["frac_envs_fallen_after_settle"] < (0.10 if per_cell >= 500 else 0.15), (name, st)
+    assert np.mean([st["frac_envs_fallen_after_settle"] for st in stats.values()]) < 0.07
     assert stats["+0kg_mu1.0"]["frac_envs_fallen_steady"] <= 0.02, stats["+0kg_mu1.0"]
 
 
@@ -151,7 +154,7 @@ def test_reference_policy_walks_on_the_oracle_physics():
     stats = cell_statistics(cell, vx_cmd, vx, vy, term, rst)
     for k, v in stats.items():
         print("oracle", k, {a: (round(b, 3) if isinstance(b, float) else np.round(b, 2).tolist()) for a, b in v.items()})
-    check(stats)
+    check(stats, per_cell=48)
 
 
 @pytest.mark.gpu
