@@ -403,17 +403,14 @@ LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const Phys
   contact_detect_finish<S0, S1>(lm_, T, P, pb, pr, cst, lane);
 }
 
-// ---- capsule parts (lg_robot_model.cp_slide): a sphere that stands for the part [x - s, x + s] of a capsule's axis collides where that part is
-// deepest in the terrain.  Along the part's ground track the surface is piecewise linear with kinks on the lines of the height grid, so the minimum of
-// the gap sits at a kink or at an end.  Candidates, in this order: just in front of and just behind the crossing of the x line nearest the middle
-// (LG_CAPS_NUDGE cells off the line on either side: ON the line the two cells disagree about the normal, and which of them a sample lands in would be
-// decided by the last bit), the same for the y line (the middle itself, twice, when the part crosses no line), then the two ends; a later candidate
-// wins by more than 10 um only (oracle: the same six, the same order, the same rule).  All cells are requested in `begin` like the fixed spheres'
-// one; slots without a sliding sphere on any leg (slide_mask, kernel-uniform) take the fixed path.
-#define LG_CAPS_NUDGE 2e-3f
-// (a conditional between two V3 OBJECTS may be compiled as a conditional between their addresses -- the objects then live in scratch; component by
-//  component it is three v_cndmask)
-LG_DEV V3 sel3(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+// ---- capsule segments (lg_robot_model.cp_slide = the vector from a sphere of a capsule's chain to the next one, link frame; zero: none).  Against the
+// piecewise-planar surface of a height grid the FACES of the terrain meet a capsule at its spheres first; what passes between two spheres is a convex
+// EDGE -- and the creases of the surface lie on the grid lines.  So a slot with a segment has up to three candidates: its sphere (as ever), and the
+// segment [x, x + g] against the piece of the first x line and of the first y line its ground track crosses (the two height samples on that line: an
+// exact segment-segment closest-point pair, normal = the direction between the two points).  An edge candidate takes the slot when it is deeper than the
+// sphere by more than 10 um.  The oracle restates the same rule.  Plane terrains have no lines: the plain instance serves them.
+LG_DEV V3 sel3(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }   // (a conditional between two V3 OBJECTS may be compiled as a
+                                                                                                  //  conditional between their addresses: scratch)
 struct PackedCell { unsigned h01, h23; };
 LG_DEV PackedCell terrain_fetch_packed(const TerrainView& T, float x, float y) {
   const TerrainCell c = terrain_fetch(T, x, y);
@@ -432,10 +429,34 @@ LG_DEV TerrainCell terrain_unpack(const TerrainView& T, float x, float y, const 
   c.h0 = (int16_t)(p.h01 & 0xffffu); c.h1 = (int16_t)(p.h01 >> 16); c.h2 = (int16_t)(p.h23 & 0xffffu); c.h3 = (int16_t)(p.h23 >> 16);
   return c;
 }
+// The piece of a grid line a segment's ground track crosses first.  axis 0: a line of constant x (index L along the rows, piece [j, j + 1] along the
+// columns); axis 1: constant y.  f0 / g0: grid coordinates of the segment's start along / across the axis, df / dg: of its vector.
+struct EdgePiece { bool on; int L, j; };
+LG_DEV EdgePiece caps_edge_piece(float f0, float df, float g0, float dg, int nL, int nJ) {
+  EdgePiece e;
+  const float fl0 = floorf(f0), fl1 = floorf(f0 + df);
+  e.on = fl0 != fl1;
+  const float L = df > 0.f ? fl0 + 1.f : fl0;
+  const float sc = e.on ? (L - f0) / df : 0.f;
+  e.L = (int)L;
+  e.j = (int)floorf(fmaf(sc, dg, g0));
+  e.on = e.on && e.L >= 0 && e.L <= nL - 1 && e.j >= 0 && e.j <= nJ - 2;
+  e.L = max(0, min(e.L, nL - 1)); e.j = max(0, min(e.j, nJ - 2));
+  return e;
+}
+// closest points of the segments A0 + s d1 and E0 + u d2 (s, u in [0, 1]); d2 is never degenerate here (a grid step long)
+LG_DEV void seg_seg_closest(V3 A0, V3 d1, V3 E0, V3 d2, V3* A, V3* E) {
+  const V3 r = A0 - E0;
+  const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
+  const float den = a * e - b * b;
+  float sN = den > 1e-12f * a * e ? fminf(fmaxf((b * f - c * e) / den, 0.f), 1.f) : 0.f;
+  float u = (b * sN + f) / e;
+  const float uc = fminf(fmaxf(u, 0.f), 1.f);
+  if (uc != u) sN = a > 0.f ? fminf(fmaxf((b * uc - c) / a, 0.f), 1.f) : 0.f;
+  *A = A0 + sN * d1; *E = E0 + uc * d2;
+}
 template <int S0, int S1>
-struct ContactProbeC { V3 x[S1 - S0], sv[S1 - S0]; float t[S1 - S0][4], rads[S1 - S0]; PackedCell cell[S1 - S0][6]; };
-// parameter of candidate q (0..5) of a part: t[0..3] = the four samples around the two crossings, then the ends
-LG_DEV float caps_t(const float t[4], int q) { return q < 4 ? t[q] : (q == 4 ? -1.f : 1.f); }
+struct ContactProbeC { V3 x[S1 - S0], gv[S1 - S0]; float rads[S1 - S0]; PackedCell cell[S1 - S0]; unsigned ex[S1 - S0], ey[S1 - S0]; };
 template <int S0, int S1>
 LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T, const LegKin& k, const M3& Rb, V3 pb, unsigned slide_mask, ContactProbeC<S0, S1>& pr) {
   const float ihs = T.hscale > 0.f ? frcp(T.hscale) : 0.f;
@@ -447,29 +468,19 @@ LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T,
     pr.rads[i] = lm_.f(LM_CP_RADIUS + sl);
     const V3 xb = pb + mul(Rb, lp), x0 = k.O[0] + mul(k.R[0], lp), x1 = k.O[1] + mul(k.R[1], lp), x2 = k.O[2] + mul(k.R[2], lp);
     const V3 x = sel3(link < 0, xb, sel3(link == 0, x0, sel3(link == 1, x1, x2)));
-    pr.x[i] = x; pr.sv[i] = v3(0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) pr.t[i][q] = 0.f;
+    pr.x[i] = x; pr.gv[i] = v3(0, 0, 0); pr.ex[i] = 0u; pr.ey[i] = 0u;
+    pr.cell[i] = terrain_fetch_packed(T, x.x, x.y);
     if ((slide_mask >> sl) & 1u) {                      // (kernel-uniform)
       const V3 ls = lm_.v(LM_CP_SLIDE + 3 * sl);
-      const V3 sb = mul(Rb, ls), s0 = mul(k.R[0], ls), s1 = mul(k.R[1], ls), s2 = mul(k.R[2], ls);
-      const V3 sv = sel3(link < 0, sb, sel3(link == 0, s0, sel3(link == 1, s1, s2)));
-      const float fxc = (x.x + T.border) * ihs, fyc = (x.y + T.border) * ihs, dfx = sv.x * ihs, dfy = sv.y * ihs;
-      const float Lx = rintf(fxc), Ly = rintf(fyc);
-      const bool cx = fabsf(Lx - fxc) < fabsf(dfx), cy = fabsf(Ly - fyc) < fabsf(dfy);
-      const float tx = cx ? (Lx - fxc) / dfx : 0.f, ex = cx ? LG_CAPS_NUDGE / fabsf(dfx) : 0.f;
-      const float ty = cy ? (Ly - fyc) / dfy : 0.f, ey = cy ? LG_CAPS_NUDGE / fabsf(dfy) : 0.f;
-      pr.t[i][0] = fmaxf(tx - ex, -1.f); pr.t[i][1] = fminf(tx + ex, 1.f); pr.t[i][2] = fmaxf(ty - ey, -1.f); pr.t[i][3] = fminf(ty + ey, 1.f);
-      pr.sv[i] = sv;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < S1 - S0; ++i) {
-    const V3 x = pr.x[i], sv = pr.sv[i];
-    pr.cell[i][0] = terrain_fetch_packed(T, fmaf(pr.t[i][0], sv.x, x.x), fmaf(pr.t[i][0], sv.y, x.y));
-    if ((slide_mask >> (S0 + i)) & 1u) {
-#pragma unroll
-      for (int q = 1; q < 6; ++q) { const float t = caps_t(pr.t[i], q); pr.cell[i][q] = terrain_fetch_packed(T, fmaf(t, sv.x, x.x), fmaf(t, sv.y, x.y)); }
+      const V3 gv = sel3(link < 0, mul(Rb, ls), sel3(link == 0, mul(k.R[0], ls), sel3(link == 1, mul(k.R[1], ls), mul(k.R[2], ls))));
+      pr.gv[i] = gv;
+      const float fx0 = (x.x + T.border) * ihs, fy0 = (x.y + T.border) * ihs, dfx = gv.x * ihs, dfy = gv.y * ihs;
+      const EdgePiece px = caps_edge_piece(fx0, dfx, fy0, dfy, T.rows, T.cols), py = caps_edge_piece(fy0, dfy, fx0, dfx, T.cols, T.rows);
+      const int16_t* hx = T.H + (size_t)px.L * T.cols + px.j;      // (L, j), (L, j + 1)
+      const int16_t* hy = T.H + (size_t)py.j * T.cols + py.L;      // (j, L), (j + 1, L)
+      const int16_t a0 = hx[0], a1 = hx[1], b0 = hy[0], b1 = hy[T.cols];
+      pr.ex[i] = (unsigned)(unsigned short)a0 | ((unsigned)(unsigned short)a1 << 16);
+      pr.ey[i] = (unsigned)(unsigned short)b0 | ((unsigned)(unsigned short)b1 << 16);
     }
   }
 }
@@ -477,25 +488,33 @@ template <int S0, int S1>
 LG_DEV void contact_detect_finish_caps(const LegModel& lm_, const TerrainView& T, const PhysParams& P, V3 pb, unsigned slide_mask, const ContactProbeC<S0, S1>& pr,
                                        float* cst, int lane) {
   const int ncp = lm_.i(LM_CP_COUNT);
+  const float ihs = T.hscale > 0.f ? frcp(T.hscale) : 0.f;
 #pragma unroll
   for (int sl = S0; sl < S1; ++sl) {
     const int i = sl - S0;
-    const V3 xm = pr.x[i], sv = pr.sv[i];
     const float rad = pr.rads[i];
     float hh; V3 n;
-    V3 x = v3(fmaf(pr.t[i][0], sv.x, xm.x), fmaf(pr.t[i][0], sv.y, xm.y), fmaf(pr.t[i][0], sv.z, xm.z));
-    terrain_eval(T, terrain_unpack(T, x.x, x.y, pr.cell[i][0]), &hh, &n);
+    V3 x = pr.x[i];
+    terrain_eval(T, terrain_unpack(T, x.x, x.y, pr.cell[i]), &hh, &n);
     float phi = (x.z - hh) * n.z - rad;
     if ((slide_mask >> sl) & 1u) {
+      const V3 x0 = pr.x[i], gv = pr.gv[i];
+      const float fx0 = (x0.x + T.border) * ihs, fy0 = (x0.y + T.border) * ihs, dfx = gv.x * ihs, dfy = gv.y * ihs;
 #pragma unroll
-      for (int q = 1; q < 6; ++q) {
-        const float t = caps_t(pr.t[i], q);
-        const V3 xq = v3(fmaf(t, sv.x, xm.x), fmaf(t, sv.y, xm.y), fmaf(t, sv.z, xm.z));
-        float hq; V3 nq;
-        terrain_eval(T, terrain_unpack(T, xq.x, xq.y, pr.cell[i][q]), &hq, &nq);
-        const float pq = (xq.z - hq) * nq.z - rad;
-        const bool better = pq < phi - 1e-5f;
-        phi = better ? pq : phi; n = sel3(better, nq, n); x = sel3(better, xq, x);
+      for (int ax = 0; ax < 2; ++ax) {
+        const EdgePiece pc = ax == 0 ? caps_edge_piece(fx0, dfx, fy0, dfy, T.rows, T.cols) : caps_edge_piece(fy0, dfy, fx0, dfx, T.cols, T.rows);
+        const unsigned pk = ax == 0 ? pr.ex[i] : pr.ey[i];
+        const float h0 = T.vscale * (float)(int16_t)(pk & 0xffffu), h1 = T.vscale * (float)(int16_t)(pk >> 16);
+        const float cl = (float)pc.L * T.hscale - T.border, cj = (float)pc.j * T.hscale - T.border;
+        const V3 E0 = ax == 0 ? v3(cl, cj, h0) : v3(cj, cl, h0);
+        const V3 d2 = ax == 0 ? v3(0.f, T.hscale, h1 - h0) : v3(T.hscale, 0.f, h1 - h0);
+        V3 A, E; seg_seg_closest(x0, gv, E0, d2, &A, &E);
+        const V3 d = A - E; const float dist = norm(d);
+        const float sg = d.z >= 0.f ? 1.f : -1.f;
+        const V3 ne = dist > 1e-9f ? (sg * frcp(dist)) * d : v3(0, 0, 1);
+        const float pe = sg * dist - rad;
+        const bool better = pc.on && pe < phi - 1e-5f;
+        phi = better ? pe : phi; n = sel3(better, ne, n); x = sel3(better, A, x);
       }
     }
     const bool active = (sl < ncp) && (phi < P.contact_offset);
@@ -507,19 +526,13 @@ LG_DEV void contact_detect_finish_caps(const LegModel& lm_, const TerrainView& T
     if (lane == 0) AMASK(sl) = am;
   }
 }
-// begin + finish in one place (the main wave's share, the single-wave instances): one slot at a time -- four cells in flight, ~30 live registers -- because
-// this runs where the mass-matrix factors are live
+// begin + finish in one place (the main wave's share, the single-wave instances)
 template <int S0, int S1>
 LG_DEV void contact_detect_caps(const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k, const M3& Rb, V3 pb,
                                 float* cst, int lane) {
-  if constexpr (S0 < S1) {
-    {
-      ContactProbeC<S0, S0 + 1> pr;
-      contact_detect_begin_caps<S0, S0 + 1>(lm_, T, k, Rb, pb, P.slide_mask, pr);
-      contact_detect_finish_caps<S0, S0 + 1>(lm_, T, P, pb, P.slide_mask, pr, cst, lane);
-    }
-    contact_detect_caps<S0 + 1, S1>(lm_, T, P, k, Rb, pb, cst, lane);
-  }
+  ContactProbeC<S0, S1> pr;
+  contact_detect_begin_caps<S0, S1>(lm_, T, k, Rb, pb, P.slide_mask, pr);
+  contact_detect_finish_caps<S0, S1>(lm_, T, P, pb, P.slide_mask, pr, cst, lane);
 }
 
 // Closest point on a GRID mesh (lg_terrain.grid_vertices): the triangles of cell (i, j) are (v0, v3, v1) and (v0, v2, v3) with
@@ -736,12 +749,13 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
         const int link = lm_.i(LM_CP_LINK + sl);
         const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
         rads[h] = lm_.f(LM_CP_RADIUS + sl);
-        const V3 x = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
-        xs[h] = x;
-        // capsule part (lg_robot_model.cp_slide; zero for a fixed sphere): ONE query from the part's middle that reaches the part's half length
-        // further; the sphere then slides to the point of its segment nearest to the mesh point found (oracle: the same rule)
-        const V3 ls = lm_.v(LM_CP_SLIDE + 3 * sl);
+        const V3 x0 = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
+        // capsule segment to the next sphere of the chain (lg_robot_model.cp_slide; zero: a lone sphere): ONE query from the segment's middle that
+        // reaches half its length further; the sphere then slides to the point of the segment nearest to the mesh point found (oracle: the same rule)
+        const V3 ls = 0.5f * lm_.v(LM_CP_SLIDE + 3 * sl);
         svs[h] = sel3(link < 0, mul(Rb, ls), sel3(link == 0, mul(k.R[0], ls), sel3(link == 1, mul(k.R[1], ls), mul(k.R[2], ls))));
+        const V3 x = x0 + svs[h];
+        xs[h] = x;
         const float ext = norm(ls);
         const float range = rads[h] + P.contact_offset + LG_MESH_CONTACT_MARGIN;
         const float range_q = range + ext;

@@ -552,7 +552,13 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // act_stride: floats between consecutive action rows (12, or horizon * 12 when the rows are one step of a (n, horizon, 12) plan)
   // contact-detection split of a heightfield step with actuator waves (see the helper loop); mesh terrains: two slots a wave
   // (heightfield / plane steps; on triangle-mesh terrains every wave takes the slot pair [2 w, 2 w + 2), the main wave [0, 2))
+#if LG_AB == 23
+  constexpr int DS0 = (SPEC & 4) ? 1 : 3, DS1 = (SPEC & 4) ? 2 : 4, DS2 = (SPEC & 4) ? 5 : 6;
+#elif LG_AB == 24
+  constexpr int DS0 = (SPEC & 4) ? 2 : 3, DS1 = (SPEC & 4) ? 3 : 4, DS2 = (SPEC & 4) ? 5 : 6;
+#else
   constexpr int DS0 = 3, DS1 = 4, DS2 = 6;   // main 3 / wave 1 (which also has the leg bias) 1 / 2 / 2: the helpers are the last to arrive at (A2), the main wave has ~3 k cycles of slack there (A/B in one session: 2/2/2/2 +1.4 us, 4/0/2/2 +0.3 us; 1/2/2/3 and 0/2/3/3: worse still)
+#endif
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
@@ -666,6 +672,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
     P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
     P.terrain_mu = C->terrain_mu; P.slide_mask = CAPS ? C->slide_mask : 0u;
+#if LG_AB == 21
+    P.slide_mask = 0u;
+#endif
     const TerrainView T = C->ter;
     if (TMESH) mesh_cache_io<true>(C, cqc, e, l, lane, 2 * wv);   // this wave's two slots of the persisted query cache -> LDS
 #ifdef LG_STAMPS
@@ -902,6 +911,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
   P.terrain_mu = C->terrain_mu; P.slide_mask = CAPS ? C->slide_mask : 0u;
+#if LG_AB == 21
+  P.slide_mask = 0u;
+#endif
   const TerrainView T = C->ter;
   const SelfCol scol{C->sc_pairs, (FEAT & 2) ? C->n_sc : 0};
   const float mu_robot = pre_mu, madd = pre_madd;
@@ -2342,6 +2354,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   for (int l = 0; l < NLEG; ++l)
     for (int sl = 0; sl < model->cp_count[l]; ++sl)
       if (model->cp_slide[l][sl][0] != 0.f || model->cp_slide[l][sl][1] != 0.f || model->cp_slide[l][sl][2] != 0.f) h.slide_mask |= 1u << sl;
+  if (const char* ev = getenv("LG_CAPS")) { if (atoi(ev) == 0) h.slide_mask = 0u; }      // (diagnostic / A-B: every sphere stays in the middle of its part)
   h.n_sc = cfg->self_collisions ? model->num_sc_pairs : 0;
   for (int i = 0; i < h.n_sc; ++i)
     h.sc_pairs[i] = (unsigned)model->sc_pairs[i][0] | (unsigned)model->sc_pairs[i][1] << 8 | (unsigned)model->sc_pairs[i][2] << 16 | (unsigned)model->sc_pairs[i][3] << 24;

@@ -9,8 +9,8 @@ Bodies and DOFs are ordered depth-first with children sorted by name, which repr
 LF, LH, RF, RH order for ANYmal-C (`anymal_c_rough_config.py:43-58`).
 
 Collision shapes are reduced to spheres: sphere → itself; capsule → spheres at both segment ends (+ centre when
-long), or -- a capsule whose parts are longer than its radius -- K SLIDING spheres: each stands for one K-th of the axis and collides where
-that part is deepest (`cp_slide`, `include/lgstep.h`); box → its 8 corners.  Mesh collisions (PhysX cooks a convex hull per mesh) cannot be reduced from the URDF alone: a link whose
+long), each with the segment to the next sphere of the capsule (`cp_slide`, `include/lgstep.h`: the slot also holds the contact of that piece of the
+capsule with a terrain EDGE, which would pass between two spheres); box → its 8 corners.  Mesh collisions (PhysX cooks a convex hull per mesh) cannot be reduced from the URDF alone: a link whose
 collision geometry is a mesh, or which has none, takes the primitives of the same-named link of `collision_urdf` when one is given --
 `el_mini_collsp.urdf`, the box / sphere approximation of the hexapod's STL hulls that ships next to `el_mini.urdf` -- and is
 ignored otherwise.
@@ -72,18 +72,18 @@ class _Body:
 
 
 def _capsule_parts(p, axis_half, r, parts, slide=True):
-    """`parts` spheres along the capsule axis [p - axis_half, p + axis_half].  Parts longer than the radius slide (an edge narrower than the
-    sphere spacing would pass between fixed spheres): sphere i sits in the middle of its part with the half part as `slide`.  Shorter parts,
-    and the trunk's capsules (`slide=False`: a trunk contact ends the episode, where on the capsule it is found first matters little): fixed spheres at
-    the two ends (+ the middle for three)."""
-    part_len = 2.0 * np.linalg.norm(axis_half) / parts
-    if slide and part_len > r:
-        return [(p + axis_half * (-1.0 + (2 * i + 1.0) / parts), r, axis_half / parts) for i in range(parts)]
+    """The spheres of a capsule with axis [p - axis_half, p + axis_half]: its two ends (+ the middle for three), each with the vector to the NEXT
+    sphere of the chain (`cp_slide`: the segment of the capsule's axis whose edge contacts the slot also holds, `include/lgstep.h`; zero for the
+    last sphere).  A chain so tight that an edge cannot get more than 5 mm past the spheres' envelope -- r - sqrt(r^2 - d^2 / 4) for spheres d apart --
+    carries none, and neither do the trunk's capsules (`slide=False`: a trunk contact ends the episode, where on the capsule it is found first
+    matters little)."""
     z = np.zeros(3)
-    out = [(p + axis_half, r, z), (p - axis_half, r, z)]
+    step = 2.0 * axis_half / (parts - 1)
+    d = float(np.linalg.norm(step))
+    seg = step if (slide and r - np.sqrt(max(r * r - 0.25 * d * d, 0.0)) > 0.005) else z
     if parts == 3:
-        out.append((p, r, z))
-    return out
+        return [(p + axis_half, r, z), (p - axis_half, r, seg), (p, r, seg)]
+    return [(p + axis_half, r, z), (p - axis_half, r, seg)]
 
 
 def _link_spheres(link, compact=False, slide=True):

@@ -196,10 +196,12 @@ typedef struct lg_robot_model {
   int32_t cp_body[LG_MAX_LEGS][LG_MAX_CP];              /* rigid-body index the contact force is reported on */
   float cp_pos[LG_MAX_LEGS][LG_MAX_CP][3];              /* in the owning link's frame (foot: last link frame) */
   float cp_radius[LG_MAX_LEGS][LG_MAX_CP];
-  /* Capsule segments (asset.replace_cylinder_with_capsule, legged_robot_config.py:171): a sphere with a non-zero cp_slide stands for the part
-   * [cp_pos - cp_slide, cp_pos + cp_slide] of a capsule's axis (link frame) and collides where that part is deepest in the terrain -- its ends, or
-   * where its ground track crosses a line of the height grid (the surface is piecewise linear along the track: the minimum of the gap sits at one
-   * of those).  Zero: a fixed sphere. */
+  /* Capsule segments (asset.replace_cylinder_with_capsule, legged_robot_config.py:171): a capsule is a chain of spheres along its axis; cp_slide is the
+   * vector (link frame) from a sphere to the NEXT one of its chain, zero for the last and for lone spheres.  The faces of a piecewise-planar terrain meet
+   * a capsule at its spheres first; what would pass between two spheres is a convex edge, and the creases of a height grid lie on its lines: the slot of
+   * a sphere with a segment also holds the contact of [cp_pos, cp_pos + cp_slide] with the pieces of the first x line and first y line its ground track
+   * crosses (exact segment-segment closest points), whenever that is deeper than the sphere's own contact.  Triangle-mesh terrains: one closest-point
+   * query from the segment's middle, the sphere slides to the point of the segment nearest to the mesh point found. */
   float cp_slide[LG_MAX_LEGS][LG_MAX_CP][3];
   /* Self-collision (asset.self_collisions = 0, legged_robot_config.py:170,176: PhysX collides the actor's own shapes, parent-child links excepted):
    * the sphere pairs (leg a, slot a, leg b, slot b) the pass tests every substep -- the pairs the host found reachable within the joint limits.
