@@ -437,7 +437,7 @@ LG_DEV EdgePiece caps_edge_piece(float f0, float df, float g0, float dg, int nL,
   const float fl0 = floorf(f0), fl1 = floorf(f0 + df);
   e.on = fl0 != fl1;
   const float L = df > 0.f ? fl0 + 1.f : fl0;
-  const float sc = e.on ? (L - f0) / df : 0.f;
+  const float sc = e.on ? (L - f0) * frcp(df) : 0.f;      // (which piece of the line: a last-bit difference picks the neighbour piece, which shares the vertex there)
   e.L = (int)L;
   e.j = (int)floorf(fmaf(sc, dg, g0));
   e.on = e.on && e.L >= 0 && e.L <= nL - 1 && e.j >= 0 && e.j <= nJ - 2;
@@ -456,7 +456,7 @@ LG_DEV void seg_seg_closest(V3 A0, V3 d1, V3 E0, V3 d2, V3* A, V3* E) {
   *A = A0 + sN * d1; *E = E0 + uc * d2;
 }
 template <int S0, int S1>
-struct ContactProbeC { V3 x[S1 - S0], gv[S1 - S0]; float rads[S1 - S0]; PackedCell cell[S1 - S0]; unsigned ex[S1 - S0], ey[S1 - S0]; };
+struct ContactProbeC { V3 x[S1 - S0], gv[S1 - S0]; float rads[S1 - S0]; PackedCell cell[S1 - S0]; unsigned e[S1 - S0][2]; int lj[S1 - S0][2]; /* L | j << 16, bit 31: no crossing */ };
 template <int S0, int S1>
 LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T, const LegKin& k, const M3& Rb, V3 pb, unsigned slide_mask, ContactProbeC<S0, S1>& pr) {
   const float ihs = T.hscale > 0.f ? frcp(T.hscale) : 0.f;
@@ -468,7 +468,7 @@ LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T,
     pr.rads[i] = lm_.f(LM_CP_RADIUS + sl);
     const V3 xb = pb + mul(Rb, lp), x0 = k.O[0] + mul(k.R[0], lp), x1 = k.O[1] + mul(k.R[1], lp), x2 = k.O[2] + mul(k.R[2], lp);
     const V3 x = sel3(link < 0, xb, sel3(link == 0, x0, sel3(link == 1, x1, x2)));
-    pr.x[i] = x; pr.gv[i] = v3(0, 0, 0); pr.ex[i] = 0u; pr.ey[i] = 0u;
+    pr.x[i] = x; pr.gv[i] = v3(0, 0, 0); pr.e[i][0] = 0u; pr.e[i][1] = 0u; pr.lj[i][0] = (int)0x80000000; pr.lj[i][1] = (int)0x80000000;
     pr.cell[i] = terrain_fetch_packed(T, x.x, x.y);
     if ((slide_mask >> sl) & 1u) {                      // (kernel-uniform)
       const V3 ls = lm_.v(LM_CP_SLIDE + 3 * sl);
@@ -479,8 +479,10 @@ LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T,
       const int16_t* hx = T.H + (size_t)px.L * T.cols + px.j;      // (L, j), (L, j + 1)
       const int16_t* hy = T.H + (size_t)py.j * T.cols + py.L;      // (j, L), (j + 1, L)
       const int16_t a0 = hx[0], a1 = hx[1], b0 = hy[0], b1 = hy[T.cols];
-      pr.ex[i] = (unsigned)(unsigned short)a0 | ((unsigned)(unsigned short)a1 << 16);
-      pr.ey[i] = (unsigned)(unsigned short)b0 | ((unsigned)(unsigned short)b1 << 16);
+      pr.e[i][0] = (unsigned)(unsigned short)a0 | ((unsigned)(unsigned short)a1 << 16);
+      pr.e[i][1] = (unsigned)(unsigned short)b0 | ((unsigned)(unsigned short)b1 << 16);
+      pr.lj[i][0] = px.L | (px.j << 16) | (px.on ? 0 : (int)0x80000000);
+      pr.lj[i][1] = py.L | (py.j << 16) | (py.on ? 0 : (int)0x80000000);
     }
   }
 }
@@ -488,7 +490,6 @@ template <int S0, int S1>
 LG_DEV void contact_detect_finish_caps(const LegModel& lm_, const TerrainView& T, const PhysParams& P, V3 pb, unsigned slide_mask, const ContactProbeC<S0, S1>& pr,
                                        float* cst, int lane) {
   const int ncp = lm_.i(LM_CP_COUNT);
-  const float ihs = T.hscale > 0.f ? frcp(T.hscale) : 0.f;
 #pragma unroll
   for (int sl = S0; sl < S1; ++sl) {
     const int i = sl - S0;
@@ -499,13 +500,17 @@ LG_DEV void contact_detect_finish_caps(const LegModel& lm_, const TerrainView& T
     float phi = (x.z - hh) * n.z - rad;
     if ((slide_mask >> sl) & 1u) {
       const V3 x0 = pr.x[i], gv = pr.gv[i];
-      const float fx0 = (x0.x + T.border) * ihs, fy0 = (x0.y + T.border) * ihs, dfx = gv.x * ihs, dfy = gv.y * ihs;
+      const float zlow = fminf(x0.z, x0.z + gv.z) - rad - P.contact_offset;     // nothing of the segment's capsule is lower than this
 #pragma unroll
       for (int ax = 0; ax < 2; ++ax) {
-        const EdgePiece pc = ax == 0 ? caps_edge_piece(fx0, dfx, fy0, dfy, T.rows, T.cols) : caps_edge_piece(fy0, dfy, fx0, dfx, T.cols, T.rows);
-        const unsigned pk = ax == 0 ? pr.ex[i] : pr.ey[i];
+        const int lj = pr.lj[i][ax];
+        const unsigned pk = pr.e[i][ax];
         const float h0 = T.vscale * (float)(int16_t)(pk & 0xffffu), h1 = T.vscale * (float)(int16_t)(pk >> 16);
-        const float cl = (float)pc.L * T.hscale - T.border, cj = (float)pc.j * T.hscale - T.border;
+        // an edge piece wholly below the capsule cannot touch it: most substeps no lane of the wave has a candidate (wave-uniform skip)
+        const bool cand = lj >= 0 && zlow < fmaxf(h0, h1);
+        if (!__any(cand)) continue;
+        const int L = lj & 0xffff, j = (lj >> 16) & 0x7fff;
+        const float cl = (float)L * T.hscale - T.border, cj = (float)j * T.hscale - T.border;
         const V3 E0 = ax == 0 ? v3(cl, cj, h0) : v3(cj, cl, h0);
         const V3 d2 = ax == 0 ? v3(0.f, T.hscale, h1 - h0) : v3(T.hscale, 0.f, h1 - h0);
         V3 A, E; seg_seg_closest(x0, gv, E0, d2, &A, &E);
@@ -513,7 +518,7 @@ LG_DEV void contact_detect_finish_caps(const LegModel& lm_, const TerrainView& T
         const float sg = d.z >= 0.f ? 1.f : -1.f;
         const V3 ne = dist > 1e-9f ? (sg * frcp(dist)) * d : v3(0, 0, 1);
         const float pe = sg * dist - rad;
-        const bool better = pc.on && pe < phi - 1e-5f;
+        const bool better = cand && pe < phi - 1e-5f;
         phi = better ? pe : phi; n = sel3(better, ne, n); x = sel3(better, A, x);
       }
     }

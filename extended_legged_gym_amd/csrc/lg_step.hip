@@ -552,13 +552,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // act_stride: floats between consecutive action rows (12, or horizon * 12 when the rows are one step of a (n, horizon, 12) plan)
   // contact-detection split of a heightfield step with actuator waves (see the helper loop); mesh terrains: two slots a wave
   // (heightfield / plane steps; on triangle-mesh terrains every wave takes the slot pair [2 w, 2 w + 2), the main wave [0, 2))
-#if LG_AB == 23
-  constexpr int DS0 = (SPEC & 4) ? 1 : 3, DS1 = (SPEC & 4) ? 2 : 4, DS2 = (SPEC & 4) ? 5 : 6;
-#elif LG_AB == 24
-  constexpr int DS0 = (SPEC & 4) ? 2 : 3, DS1 = (SPEC & 4) ? 3 : 4, DS2 = (SPEC & 4) ? 5 : 6;
-#else
-  constexpr int DS0 = 3, DS1 = 4, DS2 = 6;   // main 3 / wave 1 (which also has the leg bias) 1 / 2 / 2: the helpers are the last to arrive at (A2), the main wave has ~3 k cycles of slack there (A/B in one session: 2/2/2/2 +1.4 us, 4/0/2/2 +0.3 us; 1/2/2/3 and 0/2/3/3: worse still)
-#endif
+  constexpr int DS0 = 3, DS1 = 4, DS2 = 6;   // main 3 / wave 1 (which also has the leg bias) 1 / 2 / 2: the helpers are the last to arrive at (A2), the main wave has ~3 k cycles of slack there (A/B in one session: 2/2/2/2 +1.4 us, 4/0/2/2 +0.3 us; 1/2/2/3 and 0/2/3/3: worse still; the capsule-segment instance, round 5: 4/0/2/2 +3.5 us, 2/1/2/3 +0.3 us against this deal)
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.

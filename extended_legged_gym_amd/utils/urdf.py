@@ -74,13 +74,12 @@ class _Body:
 def _capsule_parts(p, axis_half, r, parts, slide=True):
     """The spheres of a capsule with axis [p - axis_half, p + axis_half]: its two ends (+ the middle for three), each with the vector to the NEXT
     sphere of the chain (`cp_slide`: the segment of the capsule's axis whose edge contacts the slot also holds, `include/lgstep.h`; zero for the
-    last sphere).  A chain so tight that an edge cannot get more than 5 mm past the spheres' envelope -- r - sqrt(r^2 - d^2 / 4) for spheres d apart --
-    carries none, and neither do the trunk's capsules (`slide=False`: a trunk contact ends the episode, where on the capsule it is found first
-    matters little)."""
+    last sphere).  A chain whose spheres overlap (d <= 2 r: an edge cannot reach the axis between them; ANYmal's drive housings) carries none, and
+    neither do the trunk's capsules (`slide=False`: a trunk contact ends the episode, where on the capsule it is found first matters little)."""
     z = np.zeros(3)
     step = 2.0 * axis_half / (parts - 1)
     d = float(np.linalg.norm(step))
-    seg = step if (slide and r - np.sqrt(max(r * r - 0.25 * d * d, 0.0)) > 0.005) else z
+    seg = step if (slide and d > 2.0 * r) else z
     if parts == 3:
         return [(p + axis_half, r, z), (p - axis_half, r, seg), (p, r, seg)]
     return [(p + axis_half, r, z), (p - axis_half, r, seg)]

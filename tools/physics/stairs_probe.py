@@ -1,11 +1,13 @@
-"""Diagnostic (GPU): what the sphere model of a shank misses on stairs.
+"""Diagnostic (GPU): what the collision model of a shank misses on stairs.
 
 The reference's ANYmal-C shank collides as a mesh; here it is three spheres (r = 17.5 mm, 0.1 m apart, `resources/robots/anymal_c.json`) plus the
 foot sphere.  A stair edge can enter the gap between two spheres unseen.  This probe walks 1024 robots into pyramid stairs (`anymal_c_rough`'s terrain
 with `terrain_proportions = [0, 0, 0.5, 0.5, 0]`, heightfield, levels 0-5) under the reference's PhysX-trained FLAT-ground policy at 0.6 m/s
 (`tests/golden/anymal_plane_walk_policy.npz`: it does not see the steps, so shanks and steps do meet) and, every step and for every shank, samples 21 points along the sphere chain's axis: a sample is "inside" when the terrain surface under it (the cell's height samples, interpolated) is higher
-than the sample minus the sphere radius.  Reported: how often some INTERIOR sample is inside by more than 5 mm while none of the model's spheres on that
-link touches -- the events the model does not answer with a contact -- and how deep they go.
+than the sample minus the sphere radius.  Reported: how often some sample is inside by more than 5 mm while the env reports NO contact force on that shank
+-- the events the model does not answer with a contact -- and how deep they go.  Round 5: the surface is the collision surface itself (the grid's
+triangulation, `terrain_eval`), and "answered" is read off `contact_forces`, so the probe sees whatever the kernel does (spheres, and the capsule
+segments' edge contacts when the model carries them; `LG_CAPS=0` in the environment runs the spheres alone).
 
     python tools/physics/stairs_probe.py [steps]        (prints one JSON object)
 """
@@ -58,11 +60,14 @@ def main(steps=400, n=1024):
         chains.append((torch.as_tensor(pos[order], device="cuda"), rad, 1 + 4 * leg + 2))      # body index of the shank
     T = torch.linspace(0.0, 1.0, 21, device="cuda")
 
-    def height_at(p):          # the collision surface of heightfield mode: the cell's samples, interpolated
+    def height_at(p):          # the collision surface of heightfield mode: the grid's triangulation (diagonal (i, j) -> (i + 1, j + 1)), as terrain_eval
         fx, fy = (p[..., 0] + border) / hscale, (p[..., 1] + border) / hscale
         i = fx.floor().long().clamp(0, hs.shape[0] - 2); j = fy.floor().long().clamp(0, hs.shape[1] - 2)
         u, v = (fx - i).clamp(0, 1), (fy - j).clamp(0, 1)
-        return (1 - u) * (1 - v) * hs[i, j] + u * (1 - v) * hs[i + 1, j] + (1 - u) * v * hs[i, j + 1] + u * v * hs[i + 1, j + 1]
+        h0, h1, h2, h3 = hs[i, j], hs[i, j + 1], hs[i + 1, j], hs[i + 1, j + 1]
+        upper = v >= u
+        dhdu = torch.where(upper, h3 - h1, h2 - h0); dhdv = torch.where(upper, h1 - h0, h3 - h2)
+        return h0 + u * dhdu + v * dhdv
 
     from extended_legged_gym_amd.utils.isaac_torch_utils import quat_apply
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -79,9 +84,10 @@ def main(steps=400, n=1024):
             clear = w[..., 2] - rad - height_at(w)                                                     # < 0: inside
             sph = p0[:, None, :] + quat_apply(q[:, None, :].expand(n, len(pos), 4).reshape(-1, 4), pos[None].expand(n, len(pos), 3).reshape(-1, 3)).view(n, len(pos), 3)
             sph_clear = sph[..., 2] - rad - height_at(sph)
-            unseen = (clear.min(dim=1).values < -0.005) & (sph_clear.min(dim=1).values > 0.0)
+            answered = env.contact_forces[:, body].norm(dim=1) > 0.0
+            unseen = (clear.min(dim=1).values < -0.005) & ~answered
             events += int(unseen.sum()); samples += n
-            touching += int((sph_clear.min(dim=1).values <= 0.0).sum())
+            touching += int(answered.sum())
             if unseen.any():
                 depths.append((-clear.min(dim=1).values[unseen]).cpu())
     d = torch.cat(depths) if depths else torch.zeros(0)
