@@ -328,13 +328,14 @@ def sphere_centres(m, q):
 def self_collision_pairs(m, samples=20000, seed=0, reach=0.02):
     """Candidate sphere pairs of the self-collision pass (`lg_robot_model.sc_pairs`): pairs PhysX would test with `asset.self_collisions = 0`
     -- shapes of different bodies that are not parent and child -- that come within `reach` of each other somewhere in the joint-limit box
-    (limits, cut to +-1.5 rad around the middle of unlimited or very wide joints), found by sampling; the most frequent MAX_SC_PAIRS when there
-    are more.  Two zero-radius points (box corners) never meet and are left out.  [leg a, slot a, leg b, slot b]."""
+    (limits; unlimited joints and joints with more than 2 rad of range: +-1 rad around the middle -- ANYmal's URDF limits none of its joints, and a
+    hip swung by 1.5 rad puts pairs in front that no gait comes near while the feet of neighbouring legs drop off the list), found by sampling; the most
+    frequent MAX_SC_PAIRS when there are more.  Two zero-radius points (box corners) never meet and are left out.  [leg a, slot a, leg b, slot b]."""
     nl, nj = m["num_legs"], len(m["joint_pos"][0])
     lo, hi = np.asarray(m["dof_lower"], np.float64), np.asarray(m["dof_upper"], np.float64)
-    wide = ~(lo < hi) | (hi - lo > 3.0)
+    wide = ~(lo < hi) | (hi - lo > 2.0)
     mid = np.where(~(lo < hi), 0.0, 0.5 * (lo + hi))
-    lo, hi = np.where(wide, mid - 1.5, lo), np.where(wide, mid + 1.5, hi)
+    lo, hi = np.where(wide, mid - 1.0, lo), np.where(wide, mid + 1.0, hi)
     rng = np.random.RandomState(seed)
     q = lo + (hi - lo) * rng.rand(samples, nl * nj)
     cen = sphere_centres(m, q)

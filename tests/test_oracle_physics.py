@@ -413,3 +413,89 @@ def test_flip_termination_without_contact_termination():
         o.step(np.zeros((4, 12), np.float32))
         assert o.t["reset_buf"].tolist() == ([0, 1, 0, 0] if flag else [0, 0, 0, 0])
         o.close()
+
+
+# ---------------------------------------------------------------------------------------------- self-collision (asset.self_collisions = 0)
+def crossing_state(model, default_pos, n=4, gap=0.015, seed=0, pair=(0, 0, 1, 0)):
+    """Joint poses in which two collision spheres -- by default the FOOT spheres of LF and LH (legs 0 and 1: front and hind leg of one side) -- are `gap`
+    apart with every other candidate pair at least 3 cm clear, and joint speeds that close the gap at 1 m/s: found by walking the joints of the two legs down
+    the gradient of the distance (numpy forward kinematics of the model)."""
+    from extended_legged_gym_amd.utils.urdf import sphere_centres
+    rng = np.random.default_rng(seed)
+    la, sa, lb, sb = pair
+    ra, rb = model["cp_radius"][la][sa], model["cp_radius"][lb][sb]
+
+    def dist(q):
+        c = sphere_centres(model, q)
+        return np.linalg.norm(c[(la, sa)] - c[(lb, sb)], axis=1) - ra - rb
+    free = [3 * la + j for j in range(3)] + [3 * lb + j for j in range(3)]        # the joints of the two legs
+    q = np.tile(np.asarray(default_pos, np.float64), (n, 1)) + 0.05 * rng.normal(size=(n, 12))
+
+    def grad(q):
+        g = np.zeros_like(q)
+        for d in free:
+            e = np.zeros(12); e[d] = 1e-4
+            g[:, d] = (dist(q + e) - dist(q - e)) / 2e-4
+        return g
+    for _ in range(400):
+        dq = dist(q) - gap
+        if np.all(np.abs(dq) < 1e-4):
+            break
+        g = grad(q)
+        q -= (dq / np.maximum((g * g).sum(1), 1e-9))[:, None] * g * 0.5
+    assert np.all(np.abs(dist(q) - gap) < 1e-3), dist(q)
+    cen = sphere_centres(model, q)
+    for (a_, b_, c_, d_) in model["sc_pairs"]:
+        if (a_, b_, c_, d_) != tuple(pair):
+            clear = np.linalg.norm(cen[(a_, b_)] - cen[(c_, d_)], axis=1) - model["cp_radius"][a_][b_] - model["cp_radius"][c_][d_]
+            assert clear.min() > 0.03, ((a_, b_, c_, d_), clear.min())
+    g = grad(q)
+    qd = -g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-9) ** 2 * 1.0      # d(dist)/dt = g . qd = -1 m/s
+    return q.astype(np.float32), qd.astype(np.float32), dist
+
+
+@pytest.mark.parametrize("solver", SOLVERS[:1] if "SOLVERS" in globals() else [None])
+def test_two_legs_crossing_meet_a_self_collision_row(solver):
+    """Known answers for the self-collision pass, in free space (no gravity, no terrain in reach, no torques): the LF and LH feet driven into each other
+      * stop at each other: the gap never falls below -2 mm (without the pass the same start ends 5 cm deep in the other foot);
+      * the contact is an INTERNAL force: linear momentum of the robot unchanged, the two feet report equal and opposite contact forces, nothing else does;
+      * it is inelastic and frictionless: kinetic energy does not grow."""
+    from extended_legged_gym_amd.utils.urdf import sphere_centres
+    results = {}
+    for sc in (True, False):
+        cfg, s, model, o = make(gravity=(0, 0, 0), speed_limit=False, self_collisions=sc, solver=solver)
+        assert s.cfg.self_collisions == (1 if sc else 0) and s.model.num_sc_pairs > 0
+        n = 4
+        q, qd, dist = crossing_state(model, s.default_dof_pos, n)
+        o.t["root_states"][:, :3] = [0, 0, 30.0]
+        o.t["root_states"][:, 7:13] = 0.0
+        o.t["dof_state"][:, :, 0] = q
+        o.t["dof_state"][:, :, 1] = qd
+        o.refresh_rigid_body_state()
+        rb0 = o.t["rigid_body_state"].copy()
+        o.t["torques"][:] = 0.0
+        gaps, forces = [], []
+        for _ in range(16):
+            o.simulate()
+            gaps.append(dist(o.t["dof_state"][:, :, 0].astype(np.float64)))
+            forces.append(o.t["contact_forces"].reshape(n, -1, 3).copy())
+        gaps, forces = np.array(gaps), np.array(forces)
+        results[sc] = gaps
+        for e in range(n):
+            M, P0, L0, K0 = momenta(model, rb0[e])
+            _, P1, L1, K1 = momenta(model, o.t["rigid_body_state"][e])
+            np.testing.assert_allclose(P1, P0, atol=2e-3 * M)
+            if sc:
+                assert K1 <= K0 * 1.02, (K0, K1)
+        if sc:
+            assert gaps.min() > -2e-3, gaps.min()
+            lf, rf = model["feet_indices"][0], model["feet_indices"][1]
+            hit = np.linalg.norm(forces[:, :, lf], axis=2) > 1.0
+            assert hit.any(axis=0).all()                                          # every env's feet met
+            np.testing.assert_allclose(forces[:, :, lf], -forces[:, :, rf], atol=1e-3 * np.abs(forces).max())
+            others = [b for b in range(forces.shape[2]) if b not in (lf, rf)]
+            assert np.abs(forces[:, :, others]).max() == 0.0
+            late = gaps[-4:]                                                      # the feet stay together or part: no bounce back into each other
+            assert late.min() > -2e-3
+        o.close()
+    assert results[False].min() < -0.03, results[False].min()                    # the same start without the pass: the feet pass through each other
