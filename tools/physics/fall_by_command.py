@@ -1,0 +1,44 @@
+"""Diagnostic (GPU): which commands make the reference's ANYmal checkpoint fall on this simulator?  Task anymal_c_flat as registered (commands resampled every
+4 s from lin_vel_x, lin_vel_y in [-1, 1], yaw rate in [-1.5, 1.5]), deterministic actions, no observation noise, no pushes; steady-state (>= 100 steps after
+a reset) contact terminations binned by the command in force.  Prints one JSON object."""
+import json, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tools.physics.value_calibration import mlp
+
+
+def main(n=4096, steps=1500):
+    from extended_legged_gym_amd.envs import task_registry
+    from extended_legged_gym_amd.utils.helpers import get_args
+    z = np.load(os.path.join(ROOT, "tests", "golden", "anymal_plane_walk_policy.npz"))
+    cfg, _ = task_registry.get_cfgs("anymal_c_flat")
+    cfg.env.num_envs = n; cfg.seed = 1
+    cfg.noise.add_noise = False; cfg.domain_rand.push_robots = False
+    env, _ = task_registry.make_env("anymal_c_flat", args=get_args(["--headless", "--sim_device", "cuda:0"]), env_cfg=cfg)
+    actor = mlp(z, "actor", env.device)
+    env.reset()
+    obs = env.get_observations()
+    age = torch.zeros(n, dtype=torch.int64, device=env.device)
+    bins = {k: [0, 0] for k in ("fwd(|vy|<.3,|w|<.5,vx>0)", "back(|vy|<.3,|w|<.5,vx<0)", "lateral(|vy|>=.3,|w|<.5)", "yaw(|w|>=.5,|vy|<.3)", "lateral+yaw", "stand(cmd=0)")}
+    speed_err = []
+    for t in range(steps):
+        cmd = env.commands.clone()
+        obs, _, _, dones, infos = env.step(actor(obs).detach())
+        term = (dones != 0) & (infos["time_outs"] == 0) & (age >= 100)
+        vx, vy, w = cmd[:, 0], cmd[:, 1], cmd[:, 2]
+        lat, yaw = vy.abs() >= 0.3, w.abs() >= 0.5
+        zero = (vx == 0) & (vy == 0)
+        sel = {"fwd(|vy|<.3,|w|<.5,vx>0)": ~lat & ~yaw & (vx > 0) & ~zero, "back(|vy|<.3,|w|<.5,vx<0)": ~lat & ~yaw & (vx < 0) & ~zero,
+               "lateral(|vy|>=.3,|w|<.5)": lat & ~yaw, "yaw(|w|>=.5,|vy|<.3)": yaw & ~lat, "lateral+yaw": lat & yaw, "stand(cmd=0)": zero & ~yaw}
+        steady = age >= 100
+        for k, m in sel.items():
+            bins[k][0] += int((m & steady).sum()); bins[k][1] += int((m & term).sum())
+        age = torch.where(dones != 0, torch.zeros_like(age), age + 1)
+    out = {k: dict(env_steps=v[0], falls=v[1], falls_per_env_step=v[1] / max(v[0], 1)) for k, v in bins.items()}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

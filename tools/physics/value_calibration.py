@@ -61,7 +61,7 @@ def record(env, z, steps, seed=0):
     for t in range(steps):
         V[t] = critic(obs).squeeze(1)
         since[t] = age
-        a = actor(obs) + std * torch.randn(n, std.numel(), device=dev, generator=g)
+        a = actor(obs) + (0.0 if os.environ.get("VC_DET") else 1.0) * std * torch.randn(n, std.numel(), device=dev, generator=g)
         obs, _, rew, dones, infos = env.step(a.detach())
         R[t], done[t], tout[t] = rew, dones != 0, infos["time_outs"] != 0
         vx[t] = env.base_lin_vel[:, 0]
@@ -108,6 +108,17 @@ def anymal(n, steps):
     cfg, _ = task_registry.get_cfgs("anymal_c_flat")               # the task as registered = the training configuration
     cfg.env.num_envs = n
     cfg.seed = 1
+    if os.environ.get("VC_NONOISE"):          # (diagnostic variants, never the asserted run)
+        cfg.noise.add_noise = False
+    if os.environ.get("VC_NOPUSH"):
+        cfg.domain_rand.push_robots = False
+    if os.environ.get("VC_NOSELFC"):
+        cfg.asset.self_collisions = 1
+    if os.environ.get("VC_CMD"):              # "x0,x1,y0,y1,w0,w1": command ranges
+        r = [float(x) for x in os.environ["VC_CMD"].split(",")]
+        cfg.commands.ranges.lin_vel_x, cfg.commands.ranges.lin_vel_y, cfg.commands.ranges.ang_vel_yaw = r[0:2], r[2:4], r[4:6]
+    if os.environ.get("VC_FRICTION"):
+        cfg.domain_rand.friction_range = [float(x) for x in os.environ["VC_FRICTION"].split(",")]
     env, _ = task_registry.make_env("anymal_c_flat", args=get_args(["--headless", "--sim_device", "cuda:0"]), env_cfg=cfg)
     rec = record(env, z, steps)
     out = calibration(*rec[:5])
