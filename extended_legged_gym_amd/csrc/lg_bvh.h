@@ -172,7 +172,10 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const float* tb, V3 o, V3 d, float
   int ix = raygrid_locate(xb, G.nx, px, (int)((px - xb[0]) * ux)), iy = raygrid_locate(yb, G.ny, py, (int)((py - yb[0]) * uy));
   const int sx = inv.x >= 0.f ? 1 : -1, sy = inv.y >= 0.f ? 1 : -1;
   const int ox = sx > 0 ? 1 : 0, oy = (sy > 0 ? 1 : 0) + G.nx + 1;     // offsets into tb of the boundary AHEAD of cell ix / iy
-  float tmx = (tb[ix + ox] - o.x) * inv.x, tmy = (tb[iy + oy] - o.y) * inv.y;
+  // a ray that does not move along an axis (|d| <= 1e-12: a vertical ray) never crosses that axis's lines: its boundary time is +inf, not the
+  // 0 * 1e12 a start exactly ON a lattice line gives (the cell was then left before it was looked at: a miss where the tree walk hits)
+  const bool mvx = fabsf(d.x) > 1e-12f, mvy = fabsf(d.y) > 1e-12f;
+  float tmx = mvx ? (tb[ix + ox] - o.x) * inv.x : 3.0e38f, tmy = mvy ? (tb[iy + oy] - o.y) * inv.y : 3.0e38f;
   float best = max_dist; bool hit = false;
   float tcur = t0;
   // the ends of a cell's stretch of the ray are rounded: the z range is taken a little beyond either end
@@ -185,7 +188,7 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const float* tb, V3 o, V3 d, float
     const bool out = inew < 0 || inew >= (stx ? G.nx : G.ny);
     ix = stx ? inew : ix; iy = stx ? iy : inew;
     const float bnd = tb[out ? 0 : inew + (stx ? ox : oy)];
-    const float tn = (bnd - (stx ? o.x : o.y)) * (stx ? inv.x : inv.y);
+    const float tn = (stx ? mvx : mvy) ? (bnd - (stx ? o.x : o.y)) * (stx ? inv.x : inv.y) : 3.0e38f;
     tmx = stx ? tn : tmx; tmy = stx ? tmy : tn;
     done = done || out;
   };

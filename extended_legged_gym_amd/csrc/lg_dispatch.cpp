@@ -31,6 +31,10 @@ void lg6_lg_destroy(lg_ctx*);
 LG_INSTANCE_ENTRIES(DEF)
 #undef DEF
 
+int lg_step_rollout(lg_ctx* c, const float* actions, const int32_t* env_ids, int32_t n, float* obs_out, float* rew_out, uint8_t* reset_out, uint8_t* time_out_out, void* stream) {
+  return lg_step_subset_rows(c, actions, env_ids, n, 1, obs_out, rew_out, reset_out, time_out_out, stream);
+}
+
 void lg_abi_sizes(int32_t out[4]) { lg4_lg_abi_sizes(out); }    // (the structs are the same for every instance)
 
 size_t lg_arena_bytes(const lg_config* cfg, const lg_robot_model* model, const lg_terrain* terrain) {

@@ -125,6 +125,7 @@ struct lg_ctx {
   std::vector<hipEvent_t> ev; int prof_max = 0, prof_stride = 1, prof_n = 0; long prof_calls = 0;
 };
 
+static_assert(offsetof(lg_ctx, legs) == 0, "lg_dispatch.cpp finds a context's kernel instance in its first four bytes");
 static thread_local std::string g_err;
 
 static void hot_config(DevCtx& h) {

@@ -38,15 +38,24 @@ def interpolation_matrix(num_nodes, horizon, method="spline"):
     return phi.astype(np.float32)
 
 
-def shift_operator(phi):
-    """(K, K) = pinv(phi) @ S @ phi with S the one-step shift of the H sample times (the last sample repeats): the node trajectory whose
-    dense plan is, in the least-squares sense, the old plan advanced by one sample time."""
+def shift_operator(phi, mode="resample"):
+    """(K, K) node operator of one control step passing: the dense plan phi @ nodes advanced by one sample time (S: the last sample repeats), brought
+    back to nodes.  mode "resample" (the default): the shifted plan read off at the node times, u2node(roll(node2u(Y))) -- the form the DIAL-MPC
+    style samplers use (`robot_traj_grad_sampling.py:200-209` calls into the absent `traj_sampling` package: not pinnable, so the conventional form
+    is the default); "lsq": pinv(phi) @ S @ phi, the least-squares projection (exact for plans that stay representable; `trajectory_opt.shift_mode`)."""
     phi = np.asarray(phi, np.float64)
-    H = phi.shape[0]
+    H, K = phi.shape
     S = np.zeros((H, H))
     S[np.arange(H - 1), np.arange(1, H)] = 1.0
     S[H - 1, H - 1] = 1.0
-    return (np.linalg.pinv(phi) @ S @ phi).astype(np.float32)
+    if mode == "lsq":
+        back = np.linalg.pinv(phi)
+    elif mode == "resample":
+        tn, ts = np.linspace(0.0, 1.0, K), np.linspace(0.0, 1.0, H)
+        back = np.stack([np.interp(tn, ts, np.eye(H)[h]) for h in range(H)], axis=1)      # (K, H): linear read-off of the samples at the node times
+    else:
+        raise ValueError(f"unknown shift_mode {mode!r} (resample | lsq)")
+    return (back @ S @ phi).astype(np.float32)
 
 
 class NativeTrajSampler:
@@ -62,11 +71,9 @@ class NativeTrajSampler:
         self.H, self.K = int(cfg.horizon_samples), int(cfg.horizon_nodes) + 1
         phi = interpolation_matrix(self.K, self.H, getattr(cfg, "interp_method", "spline"))
         self.phi = torch.from_numpy(phi).to(self.device).contiguous()
-        # shift(): the plan advanced by one sample time, projected back onto the node space in the least-squares sense -- (K, H) =
-        # pinv(phi) @ S with S the one-step shift of the sample times (last sample repeated).  A plan that stays representable after
-        # the shift is reproduced exactly; picking the shifted plan at the nearest sample index is not the inverse of phi and makes
-        # the warm-started mean drift at every control step even with zero updates.
-        self.shift_op = torch.from_numpy(shift_operator(phi)).to(self.device).contiguous()   # (K, K)
+        # shift(): the plan advanced by one sample time and brought back to the nodes (shift_operator: re-sampled at the node times by default,
+        # `trajectory_opt.shift_mode = "lsq"` for the least-squares projection)
+        self.shift_op = torch.from_numpy(shift_operator(phi, getattr(cfg, "shift_mode", "resample"))).to(self.device).contiguous()   # (K, K)
         self.mean = torch.zeros(self.M, self.K, self.A, device=self.device)            # node trajectories of the main envs
         self.gen = torch.Generator(device=self.device); self.gen.manual_seed(int(seed))
         k = torch.arange(self.K, device=self.device, dtype=torch.float32)
@@ -118,7 +125,7 @@ class NativeTrajSampler:
 
     def shift(self):
         """`shift_trajectory_batch` (`:200-209`): one control step has passed -- the plan advances by one sample time; re-sampled at
-        the node times in the least-squares sense (see `shift_op`; the last sample repeats)."""
+        the node times (see `shift_operator`; the last sample repeats)."""
         self.mean = torch.einsum("kj,mja->mka", self.shift_op, self.mean).contiguous()      # nodes <- pinv(phi) shift(phi nodes)
 
     def reset(self, env_ids=None):

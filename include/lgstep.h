@@ -368,6 +368,11 @@ int lg_step_transition(lg_ctx* ctx, const float* actions, float* next_observatio
  * envs are not touched (the reference simulates and then restores them, :687, :1585-1640). */
 int lg_step_subset(lg_ctx* ctx, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, void* stream);
 
+/* RobotBatchRollout.step_rollout (robot_batch_rollout.py:602-716): one rollout step of the n listed rollout envs with dense row outputs -- the name SURVEY s8(b)
+ * gives the entry point; = lg_step_subset_rows(..., rollout_mode = 1, ...). */
+int lg_step_rollout(lg_ctx* ctx, const float* actions, const int32_t* env_ids, int32_t n, float* obs_out, float* rew_out, uint8_t* reset_out,
+                    uint8_t* time_out_out, void* stream);
+
 /* Multi-stage rewards (legged_robot_rew_mixin.py:15-38: update_reward_scales -> _prepare_reward_function): replace the
  * active reward terms (evaluation order, scales already multiplied by dt, num_terms <= LG_MAX_REWARD_TERMS; HOST
  * pointers) and zero every episode sum, as re-creating `episode_sums` does (:672-674).  Stream-ordered. */

@@ -105,6 +105,19 @@ def test_ray_lattice_returns_the_hits_of_the_tree(monkeypatch):
         assert float(fg.float().mean()) > 0.1
         # (rays through a lattice corner or along a lattice line can be decided differently by rounding in either structure)
         assert int(differ.sum()) <= 3, int(differ.sum())
+    # vertical rays that start exactly on the LAST lattice line of an axis and on the mesh border (the advisor's case: the boundary time of an axis the
+    # ray does not move along was 0 * 1e12, the cell was left before it was looked at): the lattice must answer as the tree does
+    ys = np.unique(v[:, 1])
+    m = 2000
+    ob = np.column_stack([np.full(m, xs[-1]), rng.uniform(ys[0], ys[-1], m), np.full(m, 3.0)]).astype(np.float32)
+    ob[m // 2:, 0] = rng.uniform(xs[0], xs[-1], m - m // 2); ob[m // 2:, 1] = ys[-1]
+    ob[:50, 1] = ys[-1]                                                  # the far corner itself
+    db = np.tile(np.array([[0.0, 0.0, -1.0]], np.float32), (m, 1))
+    to, td = torch.from_numpy(ob).cuda(), torch.from_numpy(db).cuda()
+    hg, fg = raycast_mesh(to, td, 10.0, lattice)
+    hb, fb = raycast_mesh(to, td, 10.0, tree)
+    assert float(fb.float().mean()) > 0.9                                 # the tree's edge tests are inclusive: border rays hit
+    assert int(((fg != fb) | ((hg - hb).abs().max(dim=1).values > 1e-5)).sum()) <= 3
 
 
 def test_raycaster_sensor_matches_reference_arithmetic():

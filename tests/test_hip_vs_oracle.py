@@ -98,18 +98,20 @@ BARS = {
     "step_pgs": dict(frac_ok=0.995, tol=2e-3, med=2e-5, q999=1e-2, any=5e-2, any_by_name={"contact_forces": 0.25}),
 }
 REPORT = []
-LEVELS = {}      # "<bars or tag>:<tensor>" -> [median, q99.5, q99.9, max] per comparison; dumped to gpurun_out/r04_parity_levels.json at module teardown
+LEVELS = {}      # "<bars or tag>:<tensor>" -> [median, q99.5, q99.9, max] per comparison; dumped to gpurun_out/parity_levels.json at module teardown when LG_DUMP_PARITY=1
 
 
 @pytest.fixture(scope="module", autouse=True)
 def _dump_levels():
     yield
     import json, os
+    if os.environ.get("LG_DUMP_PARITY") != "1":       # (the reviewed copy lives in profiles/; a partial or failed run must not overwrite anything)
+        return
     out = {k: dict(comparisons=len(v), median=max(x[0] for x in v), q995=max(x[1] for x in v), q999=max(x[2] for x in v), max=max(x[3] for x in v))
            for k, v in sorted(LEVELS.items())}
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(root, exist_ok=True)
-    with open(os.path.join(root, "r04_parity_levels.json"), "w") as f:
+    with open(os.path.join(root, "parity_levels.json"), "w") as f:
         json.dump(dict(note="err = |hip - oracle| / max(1, |oracle|) over envs whose contact sets agree; worst over all comparisons of tests/test_hip_vs_oracle.py",
                        levels=out), f, indent=1)
 
@@ -322,6 +324,8 @@ def test_ragged_env_counts_match_oracle(n):
                 a = core.t[name].cpu().numpy().astype(np.float64).reshape(-1); b = o.t[name].astype(np.float64).reshape(-1)
                 err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
                 assert np.isfinite(a).all() and (err <= 5e-3).mean() >= 0.98, (name, err.max())
+                # every entry: the step bar of the full-size comparisons (a foot that lands a substep earlier: contact forces / torques 1.0, the rest 0.5)
+                assert err.max() <= (1.0 if name in ("contact_forces", "torques") else 0.5), (name, err.max())
         else:
             o.step(act)
     # an empty reset list and a single-env subset step are legal

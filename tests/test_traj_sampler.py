@@ -18,13 +18,20 @@ def test_interpolation_matrix_is_an_interpolant():
 
 
 def test_shift_operator_reproduces_plans_that_stay_representable():
-    """`NativeTrajSampler.shift()`: a constant plan is a fixed point; a plan whose one-step shift is again an interpolant of K nodes (a
-    straight line that has reached its end value stays there) comes back exactly; in general the shifted plan is matched in the
-    least-squares sense, never worse than re-sampling it at the nearest sample index."""
+    """`NativeTrajSampler.shift()`: a constant plan is a fixed point of both modes; "lsq" (`trajectory_opt.shift_mode`) matches the shifted plan in the
+    least-squares sense, never worse than re-sampling it at the nearest sample index; the default "resample" reads the shifted plan off at the node
+    times (u2node(roll(node2u(Y))), the conventional form) and is stable under repetition."""
     from extended_legged_gym_amd.utils.traj_sampler import interpolation_matrix, shift_operator
     for method in ("linear", "spline"):
         phi = interpolation_matrix(5, 16, method).astype(np.float64)
-        T = shift_operator(phi).astype(np.float64)
+        Tr = shift_operator(phi).astype(np.float64)                                           # default: re-sampled at the node times
+        np.testing.assert_allclose(Tr @ np.ones(5), np.ones(5), atol=1e-5)
+        tn, ts = np.linspace(0, 1, 5), np.linspace(0, 1, 16)
+        y = np.random.default_rng(1).normal(size=5)
+        u = np.roll(phi @ y, -1); u[-1] = (phi @ y)[-1]
+        np.testing.assert_allclose(Tr @ y, np.interp(tn, ts, u), atol=1e-6)                    # = u2node(roll(node2u(y)))
+        assert np.abs(np.linalg.eigvals(Tr)).max() < 1.0 + 1e-4
+        T = shift_operator(phi, "lsq").astype(np.float64)
         np.testing.assert_allclose(T @ np.ones(5), np.ones(5), atol=1e-5)                      # constants are a fixed point
         S = np.eye(16, k=1); S[15, 15] = 1.0
         rng = np.random.default_rng(0)
