@@ -48,7 +48,8 @@ REWARD_TERMS = [
     # class-specific variants: selected through an env class's `reward_term_variants`, never named in a config
     "orientation_load_adapt",
     # StandAnymal / StandGo2 only (anymal.py:301-308); the other overrides of those classes come with lg_config.reward_class
-    "penalty_in_the_air", "async_gait_scheduler"]
+    "penalty_in_the_air", "async_gait_scheduler",
+    "no_fly"]                                              # Cassie (cassie.py:42-45)
 REWARD_CLASSES = {"base": 0, "stand": 1}                   # enum lg_reward_class
 REWARD_TERM_ID = {n: i for i, n in enumerate(REWARD_TERMS)}
 

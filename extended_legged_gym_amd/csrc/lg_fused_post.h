@@ -327,6 +327,12 @@ LG_DEV void fused_reward_all(const DevCtx* __restrict__ C, const float* hot, uns
     for (int f = 0; f < 4; ++f) all &= R.cfz[f] < 1.f;
     RAW0[LG_REW_FOUR_FOOTUP] = RAW1[LG_REW_FOUR_FOOTUP] = 0.1f * (all ? 1.f : 0.f);
   }
+  if (ON(LG_REW_NO_FLY)) {           // cassie.py:42-45 (a term of the biped's class; here for any config that scales it)
+    int nc = 0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) nc += R.cfz[f] > 0.1f ? 1 : 0;
+    RAW0[LG_REW_NO_FLY] = RAW1[LG_REW_NO_FLY] = nc == 1 ? 1.f : 0.f;
+  }
   if (ON(LG_REW_GAIT_SCHEDULER)) {   // gait_scheduler.py:74-81 on the foot heights / phase stored by the previous step
     float s = 0.f;
     if (HI(HC_GAIT_ON) && step > 1) {

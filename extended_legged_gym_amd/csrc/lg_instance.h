@@ -1,4 +1,4 @@
-// lg_instance.h — one kernel instance per supported leg count.
+// lg_instance.h — one kernel instance per supported topology (legs x joints per leg).
 //
 // lg_step.hip is compiled once per robot topology (-DLG_LEGS=4: one DPP quad per env, 16 envs per wave; -DLG_LEGS=6: eight lanes per env,
 // 8 envs per wave): lanes per env, DOF / body / feet extents and every LDS layout that follows from them are compile-time constants of the
@@ -9,6 +9,15 @@
 #pragma once
 #ifndef LG_LEGS
 #define LG_LEGS 4
+#endif
+// joints per leg of the instance: 3 for the four- and six-legged robots; the two-legged instance is Cassie's open 2 x 6 chain (cassie.urdf:315-416; the
+// knee-spring joints that would close a loop are commented out in the reference's file)
+#ifndef LG_JOINTS
+#if LG_LEGS == 2
+#define LG_JOINTS 6
+#else
+#define LG_JOINTS 3
+#endif
 #endif
 #define LG_CAT2(a, b) a##b
 #define LG_CAT(a, b) LG_CAT2(a, b)

@@ -36,11 +36,18 @@
 #define GRP 4            // lanes per env
 #elif LG_LEGS == 6
 #define GRP 8
+#elif LG_LEGS == 2
+#define GRP 2
 #else
-#error "kernel instances exist for 4 and 6 legs"
+#error "kernel instances exist for 4, 6 and 2 legs"
+#endif
+#ifndef LG_JOINTS
+#define LG_JOINTS 3
 #endif
 #define NLEG LG_LEGS
-#define NDOF (3 * NLEG)
+#define NJ LG_JOINTS     // joints per leg: 3 (the tuned kernels below), 6 (lg_chain.h: the two-legged instance)
+#define NDOF (NJ * NLEG)
+static_assert(NJ <= LG_MAX_JOINTS_PER_LEG && NDOF <= LG_MAX_DOF, "joint count of this instance");
 #define EPW (64 / GRP)   // envs per wave
 static_assert(NLEG <= LG_MAX_LEGS && NLEG <= GRP, "leg count of this instance");
 
@@ -50,6 +57,8 @@ static_assert(NLEG <= LG_MAX_LEGS && NLEG <= GRP, "leg count of this instance");
 LG_DEV int lane_in_group() { return (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & (GRP - 1)); }
 #if GRP == 4
 LG_DEV float grp_sum(float x) { return quad_sum(x); }
+#elif GRP == 2
+LG_DEV float grp_sum(float x) { return x + dpp_xor1(x); }
 #else
 LG_DEV float dpp_half_mirror(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true)); }
 LG_DEV float grp_sum(float x) { x = lane_in_group() < NLEG ? x : 0.f; x += dpp_half_mirror(x); x += dpp_xor1(x); x += dpp_xor2(x); return x; }
@@ -61,6 +70,9 @@ LG_DEV int dpp_xor2_i(int x) { return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF
 #if GRP == 4
 LG_DEV float grp_min_all(float x) { x = fminf(x, dpp_xor1(x)); x = fminf(x, dpp_xor2(x)); return x; }
 LG_DEV int grp_min_all(int x) { x = min(x, dpp_xor1_i(x)); x = min(x, dpp_xor2_i(x)); return x; }
+#elif GRP == 2
+LG_DEV float grp_min_all(float x) { return fminf(x, dpp_xor1(x)); }
+LG_DEV int grp_min_all(int x) { return min(x, dpp_xor1_i(x)); }
 #else
 LG_DEV int dpp_half_mirror_i(int x) { return __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true); }
 LG_DEV float grp_min_all(float x) { x = fminf(x, dpp_half_mirror(x)); x = fminf(x, dpp_xor1(x)); x = fminf(x, dpp_xor2(x)); return x; }
@@ -70,11 +82,15 @@ LG_DEV S3 grp_sum(S3 a) { return S3{grp_sum(a.xx), grp_sum(a.xy), grp_sum(a.xz),
 
 // Per-leg model constants staged in LDS as [field][lane of the group]: lane l reads field*GRP + l, i.e. a wave touches GRP consecutive
 // dwords per field (broadcast, conflict-free) instead of issuing ~100 dependent global loads per substep.
-enum { LM_JPOS = 0, LM_JROT = 9, LM_JAXIS = 36, LM_MASS = 45, LM_COM = 48, LM_INERTIA = 57, LM_FOOT_POS = 75, LM_FOOT_ROT = 78,
-       LM_VEL_LIMIT = 87, LM_TORQUE_LIMIT = 90, LM_DEFAULT_POS = 93, LM_PGAIN = 96, LM_DGAIN = 99, LM_CP_COUNT = 102,
-       LM_CP_LINK = 103, LM_CP_POS = 111, LM_CP_RADIUS = 135, LM_LOWER = 143, LM_UPPER = 146,
-       LM_SOFT_LO = 149, LM_SOFT_HI = 152 /* cfg.dof_pos_limits: the soft limits of _reward_dof_pos_limits */,
-       LM_CP_SLIDE = 155 /* 8 x 3: half-vector of the capsule part a sphere slides on (link frame), lg_robot_model.cp_slide */, LM_FIELDS = 179 };
+enum { LM_JPOS = 0, LM_JROT = LM_JPOS + 3 * NJ, LM_JAXIS = LM_JROT + 9 * NJ, LM_MASS = LM_JAXIS + 3 * NJ, LM_COM = LM_MASS + NJ, LM_INERTIA = LM_COM + 3 * NJ,
+       LM_FOOT_POS = LM_INERTIA + 6 * NJ, LM_FOOT_ROT = LM_FOOT_POS + 3, LM_VEL_LIMIT = LM_FOOT_ROT + 9, LM_TORQUE_LIMIT = LM_VEL_LIMIT + NJ,
+       LM_DEFAULT_POS = LM_TORQUE_LIMIT + NJ, LM_PGAIN = LM_DEFAULT_POS + NJ, LM_DGAIN = LM_PGAIN + NJ, LM_CP_COUNT = LM_DGAIN + NJ,
+       LM_CP_LINK = LM_CP_COUNT + 1, LM_CP_POS = LM_CP_LINK + LG_MAX_CP, LM_CP_RADIUS = LM_CP_POS + 3 * LG_MAX_CP, LM_LOWER = LM_CP_RADIUS + LG_MAX_CP, LM_UPPER = LM_LOWER + NJ,
+       LM_SOFT_LO = LM_UPPER + NJ, LM_SOFT_HI = LM_SOFT_LO + NJ /* cfg.dof_pos_limits: the soft limits of _reward_dof_pos_limits */,
+       LM_CP_SLIDE = LM_SOFT_HI + NJ /* 8 x 3: segment to the next sphere of a capsule's chain (link frame), lg_robot_model.cp_slide */, LM_FIELDS = LM_CP_SLIDE + 3 * LG_MAX_CP };
+#if LG_JOINTS == 3
+static_assert(LM_JROT == 9 && LM_MASS == 45 && LM_FOOT_POS == 75 && LM_CP_COUNT == 102 && LM_CP_POS == 111 && LM_LOWER == 143 && LM_CP_SLIDE == 155 && LM_FIELDS == 179, "the three-joint table is the one the tuned kernels were measured with");
+#endif
 struct LegModel {
   const float* t; int l;
   LG_DEV float f(int field) const { return t[field * GRP + l]; }
@@ -98,20 +114,20 @@ __host__ __device__ inline float leg_model_entry(const lg_robot_model* m, const 
   if (field < LM_FOOT_POS) { int k = field - LM_INERTIA; return m->link_inertia[l][k / 6][k % 6]; }
   if (field < LM_FOOT_ROT) return m->foot_pos[l][field - LM_FOOT_POS];
   if (field < LM_VEL_LIMIT) return m->foot_rot[l][field - LM_FOOT_ROT];
-  if (field < LM_TORQUE_LIMIT) return m->dof_vel_limit[3 * l + field - LM_VEL_LIMIT];
-  if (field < LM_DEFAULT_POS) return m->torque_limit[3 * l + field - LM_TORQUE_LIMIT];
-  if (field < LM_PGAIN) return g->default_dof_pos[3 * l + field - LM_DEFAULT_POS];
-  if (field < LM_DGAIN) return g->p_gains[3 * l + field - LM_PGAIN];
-  if (field < LM_CP_COUNT) return g->d_gains[3 * l + field - LM_DGAIN];
+  if (field < LM_TORQUE_LIMIT) return m->dof_vel_limit[NJ * l + field - LM_VEL_LIMIT];
+  if (field < LM_DEFAULT_POS) return m->torque_limit[NJ * l + field - LM_TORQUE_LIMIT];
+  if (field < LM_PGAIN) return g->default_dof_pos[NJ * l + field - LM_DEFAULT_POS];
+  if (field < LM_DGAIN) return g->p_gains[NJ * l + field - LM_PGAIN];
+  if (field < LM_CP_COUNT) return g->d_gains[NJ * l + field - LM_DGAIN];
   float val; int iv;
   if (field < LM_CP_LINK) { iv = m->cp_count[l]; memcpy(&val, &iv, 4); return val; }
   if (field < LM_CP_POS) { iv = m->cp_link[l][field - LM_CP_LINK]; memcpy(&val, &iv, 4); return val; }
   if (field < LM_CP_RADIUS) { int k = field - LM_CP_POS; return m->cp_pos[l][k / 3][k % 3]; }
   if (field < LM_LOWER) return m->cp_radius[l][field - LM_CP_RADIUS];
-  if (field < LM_UPPER) return m->dof_lower[3 * l + field - LM_LOWER];
-  if (field < LM_SOFT_LO) return m->dof_upper[3 * l + field - LM_UPPER];
-  if (field < LM_SOFT_HI) return g->dof_pos_limits[3 * l + field - LM_SOFT_LO][0];
-  if (field < LM_CP_SLIDE) return g->dof_pos_limits[3 * l + field - LM_SOFT_HI][1];
+  if (field < LM_UPPER) return m->dof_lower[NJ * l + field - LM_LOWER];
+  if (field < LM_SOFT_LO) return m->dof_upper[NJ * l + field - LM_UPPER];
+  if (field < LM_SOFT_HI) return g->dof_pos_limits[NJ * l + field - LM_SOFT_LO][0];
+  if (field < LM_CP_SLIDE) return g->dof_pos_limits[NJ * l + field - LM_SOFT_HI][1];
   { int k = field - LM_CP_SLIDE; return lg_ >= NLEG ? 0.f : m->cp_slide[l][k / 3][k % 3]; }
 }
 inline void pack_leg_model(float* t, const lg_robot_model* m, const lg_config* g) {
@@ -124,16 +140,16 @@ LG_DEV void fill_leg_model(float* t, const float* __restrict__ packed, int tid, 
 LG_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 struct LegKin {
-  M3 R[3];
-  V3 O[3], ax[3], com[3], w[3], vO[3];
-  S3 Ic[3];
+  M3 R[NJ];
+  V3 O[NJ], ax[NJ], com[NJ], w[NJ], vO[NJ];
+  S3 Ic[NJ];
 };
 
 LG_DEV void leg_kinematics(const LegModel& lm_, const M3& Rb, V3 pb, V3 vb, V3 wb,
-                           const float q[3], const float qd[3], LegKin& k) {
+                           const float q[NJ], const float qd[NJ], LegKin& k) {
   M3 Rp = Rb; V3 Op = pb, wp = wb, vp = vb;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     M3 fix;
 #pragma unroll
     for (int i = 0; i < 9; ++i) fix.m[i] = lm_.f(LM_JROT + 9 * j + i);
@@ -273,6 +289,7 @@ LG_DEV void terrain_query(const TerrainView& T, float x, float y, float* h, V3* 
   terrain_eval(T, c, h, n);
 }
 
+#if NJ == 3      // ---- the tuned three-joint kernels' own piece (lg_chain.h holds the six-joint instance's)
 // per-contact-slot scratch in LDS, laid out [slot][lane][field]: one lane's record of a slot is 60 contiguous floats
 // (240 B, 16-B aligned), so the sweeps fetch it with 15 ds_read_b128 instead of 59 ds_read_b32 -- a lone wave on a SIMD
 // gets a fifth of the LDS rate on 4-byte reads and the full rate on 16-byte ones (MI355X_MICROARCH.md, LDS).  Rows of
@@ -311,6 +328,7 @@ LG_DEV void load_slot_record(const float* cst, int slot, int lane, float rec[CF_
 LG_DEV V3 lds3(const float* cst, int slot, int f, int lane) { return v3(CS(slot, f), CS(slot, f + 1), CS(slot, f + 2)); }
 LG_DEV void sts3(float* cst, int slot, int f, int lane, V3 a) { CS(slot, f) = a.x; CS(slot, f + 1) = a.y; CS(slot, f + 2) = a.z; }
 
+#endif           // NJ == 3
 // Diagnostic build only (-DLG_STAMPS): lane 0 of workgroup 0 accumulates shader-clock deltas per phase.
 #ifdef LG_STAMPS
 #define STAMP(i) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
@@ -326,11 +344,16 @@ struct PhysParams {
   unsigned slide_mask;      // bit sl: some leg's sphere in slot sl stands for a capsule part (lg_robot_model.cp_slide), kernel-uniform
 };
 
+#define LG_MESH_CONTACT_MARGIN 0.1f      // triangle-mesh contacts: how far below a surface a sphere's centre may have sunk and still be pushed out
+#define LG_MESH_CACHE_REACH 0.15f
+struct SelfCol { const unsigned* pairs; int n; };      // self-collision candidates (packed leg a | slot a << 8 | leg b << 16 | slot b << 24), see the pass below
+
 struct QuadState {           // per lane: replicated base + own leg (the name is from the four-legged instance)
   float root[13];            // pos3, quat xyzw, lin vel3, ang vel3 (world)
-  float q[3], qd[3];
+  float q[NJ], qd[NJ];
 };
 
+#if NJ == 3      // ---- the tuned three-joint kernels' own piece (lg_chain.h holds the six-joint instance's)
 // Leg part of the bias forces: recursive Newton-Euler with zero generalised acceleration, moments about the base origin.
 // Outputs the three joint bias torques and the leg's total force / moment (the caller adds the base and quad-sums).
 LG_DEV void leg_bias(const LegModel& lm_, const LegKin& k, V3 pb, V3 wb, const float qd[3], V3 grav, float bk[3], V3& Fs, V3& Ns) {
@@ -403,6 +426,7 @@ LG_DEV void contact_detect(const LegModel& lm_, const TerrainView& T, const Phys
   contact_detect_finish<S0, S1>(lm_, T, P, pb, pr, cst, lane);
 }
 
+#endif           // NJ == 3
 // ---- capsule segments (lg_robot_model.cp_slide = the vector from a sphere of a capsule's chain to the next one, link frame; zero: none).  Against the
 // piecewise-planar surface of a height grid the FACES of the terrain meet a capsule at its spheres first; what passes between two spheres is a convex
 // EDGE -- and the creases of the surface lie on the grid lines.  So a slot with a segment has up to three candidates: its sphere (as ever), and the
@@ -455,6 +479,7 @@ LG_DEV void seg_seg_closest(V3 A0, V3 d1, V3 E0, V3 d2, V3* A, V3* E) {
   if (uc != u) sN = a > 0.f ? fminf(fmaxf((b * uc - c) / a, 0.f), 1.f) : 0.f;
   *A = A0 + sN * d1; *E = E0 + uc * d2;
 }
+#if NJ == 3      // ---- the tuned three-joint kernels' own piece (lg_chain.h holds the six-joint instance's)
 template <int S0, int S1>
 struct ContactProbeC { V3 x[S1 - S0], gv[S1 - S0]; float rads[S1 - S0]; PackedCell cell[S1 - S0]; unsigned e[S1 - S0][2]; int lj[S1 - S0][2]; /* L | j << 16, bit 31: no crossing */ };
 template <int S0, int S1>
@@ -540,6 +565,7 @@ LG_DEV void contact_detect_caps(const LegModel& lm_, const TerrainView& T, const
   contact_detect_finish_caps<S0, S1>(lm_, T, P, pb, P.slide_mask, pr, cst, lane);
 }
 
+#endif           // NJ == 3
 // Closest point on a GRID mesh (lg_terrain.grid_vertices): the triangles of cell (i, j) are (v0, v3, v1) and (v0, v2, v3) with
 // v0 = (i, j), v1 = (i, j+1), v2 = (i+1, j), v3 = (i+1, j+1), and the slope correction moved every vertex by at most one cell in x and
 // y, so a cell's triangles lie inside [(i-1) hs, (i+2) hs] x [(j-1) hs, (j+2) hs]: the cells that can hold a point within R of p are
@@ -713,6 +739,7 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
   A.found = found; A.cp = bestp; A.fn = bestn;
 }
 
+#if NJ == 3      // ---- the tuned three-joint kernels' own piece (lg_chain.h holds the six-joint instance's)
 // Triangle-mesh terrain (LG_MESH_TRIMESH): the surface under a sphere is the closest point of the collision mesh within
 // range = radius + contact_offset + LG_MESH_CONTACT_MARGIN (the margin lets a sphere whose centre has sunk below the surface
 // still find it); normal = direction from that point to the sphere centre (flipped when the centre is behind the deciding
@@ -722,8 +749,6 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 // query, which looked LG_MESH_CACHE_REACH further than `range`.  While the sphere has moved less than that distance minus
 // `range` since, no triangle can be within `range` and the traversal is skipped — an exact cull, the result is what
 // the query would have returned (nothing).  Most spheres of a walking robot (trunk, hips, thighs) ride on it.
-#define LG_MESH_CONTACT_MARGIN 0.1f
-#define LG_MESH_CACHE_REACH 0.15f
 #define CQ(slot, f) cq[((slot) * 4 + (f)) * 64 + lane]
 // `cq` (optional, LDS, [slot][4][lane], persisted per env between steps) caches per sphere the position and the unsigned
 // surface distance of its last query (distance < 0: no entry).  Two exact uses of it:
@@ -1096,7 +1121,6 @@ LG_DEV void contact_setup_slot_pk(int sl, const LegModel& lm_, const LegKin& k, 
 // (centre = base + r + radius * n), the two deepest pairs closer than contact_offset become frictionless unilateral rows between the two bodies.  Both
 // sides of such a row act on the same point, so its base part cancels: the row has joint entries only, like a joint-limit row -- z = Mkk^-1 f per leg,
 // base response S^-1 (-sum Mbk z), joint response z - Y W_b -- and is relaxed behind the terrain contacts of every pass.
-struct SelfCol { const unsigned* pairs; int n; };
 struct SelfRow { bool on; float phi, iA, lam; V3 n; float f[3], Wb[6], Wk[3]; int slot_a, slot_b; /* fbody index of each side on THIS lane, -1: not mine */ };
 LG_DEV V3 sc_sphere(const float* cst, const LegModel& lm_, int gb, int leg, int slot, V3 pb, float* rad) {
   const float4 n4 = reinterpret_cast<const float4*>(cst + ((slot) * 64 + gb + leg) * CF_FIELDS)[0];
@@ -1647,3 +1671,4 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   s.q[0] += dqK01.x; s.q[1] += dqK01.y; s.q[2] += dqK2;
   STAMP(8);
 }
+#endif           // NJ == 3

@@ -27,14 +27,17 @@
 
 namespace LG_NS {
 #include "lg_physics.h"
+#if NJ != 3
+#include "lg_chain.h"             // the instances with longer legs (2 x 6): generic-NJ physics, one wave per workgroup
+#endif
 
 #define LG_MESH_OOB_MARGIN 1.0f   // metres beyond the collision mesh's bounding box before an env counts as lost
 #define EPB EPW         // envs per workgroup (= per main wave) in physics_kernel: 16 quads, or 8 groups of eight lanes
-#define LPE (4 * GRP)   // lanes per env in the narrow stages of post_kernel: one lane per DOF (12 of 16, 18 of 32)
+#define LPE (NDOF <= 16 ? 16 : 32)   // lanes per env in the narrow stages of post_kernel: one lane per DOF (12 of 16, 18 of 32)
 #define EPBP (64 / LPE) // envs per 256-thread workgroup in post_kernel (a wave per env in the wide stages, LPE lanes per env in the narrow ones); quadrupeds: 4 workgroups per CU at N = 4096
 #define MAX_P 192       // height-scan points per env held in LDS
 #define PART_STRIDE (LG_MAX_REWARD_TERMS + 3)
-#define NBODY_MAX (1 + 4 * NLEG)                // rigid bodies of this instance's robots: base + legs x (3 links + FOOT)
+#define NBODY_MAX (1 + (NJ + 1) * NLEG)         // rigid bodies of this instance's robots: base + legs x (NJ links + FOOT)
 #define NPROP LG_NUM_PROPRIO_OF(NDOF)           // observation entries in front of the height scan (48 / 66)
 #define LG_RS_ROOT_XY LG_RS_ROOT_XY_OF(NDOF)
 #define LG_RS_ROOT_VEL LG_RS_ROOT_VEL_OF(NDOF)
@@ -218,6 +221,7 @@ static void pack_lstm_weights(float* W, const float* net) {
   }
 }
 
+#if NJ == 3      // ---- three-joint instances: LSTM actuator waves, the tuned physics kernel (lg_chain.h + physics_kernel_chain below serve NJ = 6)
 LG_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 LG_DEV float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 LG_DEV v2f splat2(float x) { v2f r = {x, x}; return r; }
@@ -487,6 +491,8 @@ LG_DEV void store_lstm_rows(const DevCtx* __restrict__ C, size_t row, size_t N12
   p[0] = make_float4(c1[0], c1[1], c1[2], c1[3]); p[1] = make_float4(c1[4], c1[5], c1[6], c1[7]);
 }
 
+#endif           // NJ == 3
+
 // ============================================================================================ physics kernel
 // MODE 0: fused step (clip actions, nsub x (actuator + physics)); MODE 1: lg_simulate (one dt, torques from LG_T_TORQUES);
 // MODE 2: lg_compute_torques only.
@@ -536,6 +542,7 @@ LG_DEV float* fused_act_slot(float* xs, int lane, int d);
 LG_DEV bool fused_needs_heights_early(const DevCtx* __restrict__ C);
 LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__ C);
 
+#if NJ == 3
 // HELPERS: the launch has the three helper waves (every policy step unless LG_SPLIT=0).  A separate instance, so that the kernel the
 // headline runs does not carry the single-wave fallback (the whole LSTM inlined in the main wave, inline leg bias and contact
 // detection): that dead code accounted for most of the register spills the compiler reported for the kernel.
@@ -1096,6 +1103,166 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   STAMP(10);
 }
 
+
+#else            // NJ != 3
+// Body states of one leg (+ the base from leg 0) from the generalised state: the (N, B, 13) rows the reference reads from refresh_rigid_body_state_tensor
+LG_DEV void write_rigid_body_state(const DevCtx* __restrict__ C, const LegModel& lm_, int e, int l, const float* root, const float* q, const float* qd) {
+  const int per_leg = C->per_leg, B = C->B;
+  const M3 Rb = quat_to_mat(root + 3);
+  const V3 pb = v3(root[0], root[1], root[2]), vb = v3(root[7], root[8], root[9]), wb = v3(root[10], root[11], root[12]);
+  LegKin k;
+  leg_kinematics(lm_, Rb, pb, vb, wb, q, qd, k);
+  float* rb = C->rigid + (size_t)e * B * 13;
+  if (l == 0) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) rb[i] = root[i];
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    float* o = rb + (size_t)(1 + per_leg * l + j) * 13;
+    float qq[4]; mat_to_quat(k.R[j], qq);
+    o[0] = k.O[j].x; o[1] = k.O[j].y; o[2] = k.O[j].z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
+    o[7] = k.vO[j].x; o[8] = k.vO[j].y; o[9] = k.vO[j].z; o[10] = k.w[j].x; o[11] = k.w[j].y; o[12] = k.w[j].z;
+  }
+  if (per_leg == NJ + 1) {
+    float* o = rb + (size_t)(1 + per_leg * l + NJ) * 13;
+    const V3 r = mul(k.R[NJ - 1], lm_.v(LM_FOOT_POS));
+    const V3 p = k.O[NJ - 1] + r, v = k.vO[NJ - 1] + cross(k.w[NJ - 1], r);
+    M3 fr;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fr.m[i] = lm_.f(LM_FOOT_ROT + i);
+    float qq[4]; mat_to_quat(mul(k.R[NJ - 1], fr), qq);
+    o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
+    o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = k.w[NJ - 1].x; o[11] = k.w[NJ - 1].y; o[12] = k.w[NJ - 1].z;
+  }
+}
+
+// The physics of a policy step (MODE 0: clip actions, nsub x (PD torques + one dt)), one dt with the torques of LG_T_TORQUES (MODE 1: lg_simulate), or the
+// torques alone (MODE 2: lg_compute_torques) for the chain instance: ONE wave per workgroup, a lane per leg, EPW envs per wave; post_kernel ends the step.
+// TMESH: contacts against a grid mesh (closest-point queries by cell index; the instance has no BVH walk).
+template <int MODE, bool TMESH>
+__global__ __launch_bounds__(64) void physics_kernel_chain(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, const int32_t* __restrict__ ids, int n, int act_stride) {
+  __shared__ __attribute__((aligned(16))) float cst[CH_CST_FLOATS];
+  __shared__ float lmod[LM_FIELDS * GRP];
+  const int lane = threadIdx.x;
+  const int kq = blockIdx.x * EPW + lane / GRP;
+  const int l = lane % GRP;
+  const bool valid = kq < n;
+  const int krow = valid ? kq : n - 1;
+  const int e = ids ? ids[krow] : krow;
+  const lg_robot_model* __restrict__ m = &C->model;
+  const lg_config& g = C->cfg;
+  fill_leg_model(lmod, C->lmod, threadIdx.x, blockDim.x);
+  lds_barrier();
+  const LegModel lm_{lmod, l};
+  QuadState s;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) s.root[i] = C->root[(size_t)e * 13 + i];
+  float last_qd[NJ], act[NJ], tau[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    s.q[j] = C->dof[((size_t)e * NDOF + NJ * l + j) * 2]; s.qd[j] = C->dof[((size_t)e * NDOF + NJ * l + j) * 2 + 1];
+    last_qd[j] = C->last_dof_vel[(size_t)e * NDOF + NJ * l + j];
+    act[j] = 0.f; tau[j] = 0.f;
+  }
+  if (MODE != 1) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float a = actions_in ? actions_in[(size_t)krow * act_stride + NJ * l + j] : C->actions[(size_t)e * NDOF + NJ * l + j];
+      a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);        // LR:93-94
+      act[j] = a;
+      if (valid && actions_in) C->actions[(size_t)e * NDOF + NJ * l + j] = a;
+    }
+  }
+  if (MODE == 2) {
+    ch_leg_torques(g, lm_, act, s.q, s.qd, last_qd, tau);
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) C->torques[(size_t)e * NDOF + NJ * l + j] = tau[j];
+    }
+    return;
+  }
+  PhysParams P;
+  P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
+  P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
+  P.terrain_mu = C->terrain_mu; P.slide_mask = C->slide_mask;
+  const TerrainView T = C->ter;
+  const SelfCol scol{C->sc_pairs, C->n_sc};
+  const float mu_robot = C->friction[e], madd = C->mass_added[e];
+  V3 fbody[NJ + 2];
+#pragma unroll
+  for (int b = 0; b < NJ + 2; ++b) fbody[b] = v3(0, 0, 0);
+  bool fault = false;
+#pragma unroll 1
+  for (int sub = 0; sub < nsub; ++sub) {
+    if (MODE == 0) ch_leg_torques(g, lm_, act, s.q, s.qd, last_qd, tau);
+    else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) tau[j] = C->torques[(size_t)e * NDOF + NJ * l + j];
+    }
+    float root0[7], q0[NJ];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) root0[i] = s.root[i];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) q0[j] = s.q[j];
+    chain_substep<TMESH>(m, lm_, T, P, lane, cst, s, tau, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr, scol);
+    // fault guard: a non-finite or diverged state is rolled back to the pre-step pose at rest and flagged for termination
+    float acc = 0.f, acc0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) acc += s.root[i] * 0.f;
+#pragma unroll
+    for (int i = 7; i < 13; ++i) acc += fabsf(s.root[i]) < 1e3f ? 0.f : 1.f;
+    if (TMESH) {
+      acc += (s.root[0] < C->mesh_lo[0] - LG_MESH_OOB_MARGIN || s.root[0] > C->mesh_hi[0] + LG_MESH_OOB_MARGIN ||
+              s.root[1] < C->mesh_lo[1] - LG_MESH_OOB_MARGIN || s.root[1] > C->mesh_hi[1] + LG_MESH_OOB_MARGIN ||
+              s.root[2] < C->mesh_lo[2] - LG_MESH_OOB_MARGIN) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { acc += s.q[j] * 0.f + s.qd[j] * 0.f; acc0 += q0[j] * 0.f; }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc0 += root0[i] * 0.f;
+    acc = grp_sum(acc); acc0 = grp_sum(acc0);
+    if (!(acc == 0.f)) {
+      const bool ok0 = acc0 == 0.f;
+      fault = true;
+#pragma unroll
+      for (int i = 0; i < 13; ++i)
+        s.root[i] = ok0 ? (i < 7 ? root0[i] : 0.f) : g.base_init_state[i] + (i < 3 ? C->origins[(size_t)e * 3 + i] : 0.f);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { s.q[j] = ok0 ? q0[j] : lm_.f(LM_DEFAULT_POS + j); s.qd[j] = 0.f; }
+#pragma unroll
+      for (int b = 0; b < NJ + 2; ++b) fbody[b] = v3(0, 0, 0);
+    }
+  }
+  if (!valid) return;
+  if (fault && l == 0) C->reset_buf[e] = 2;
+  if (l == 0) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) C->root[(size_t)e * 13 + i] = s.root[i];
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    C->dof[((size_t)e * NDOF + NJ * l + j) * 2] = s.q[j];
+    C->dof[((size_t)e * NDOF + NJ * l + j) * 2 + 1] = s.qd[j];
+    if (MODE == 0) C->torques[(size_t)e * NDOF + NJ * l + j] = tau[j];
+  }
+  const int per_leg = C->per_leg, B = C->B;
+  {
+    float* cf = C->cforce + (size_t)e * B * 3;
+    if (l == 0) { cf[0] = fbody[0].x; cf[1] = fbody[0].y; cf[2] = fbody[0].z; }
+    float* cl = cf + (size_t)(1 + per_leg * l) * 3;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      V3 f = fbody[1 + j];
+      if (j == NJ - 1 && per_leg == NJ) f = f + fbody[NJ + 1];      // no separate foot body: its spheres report on the last link
+      cl[3 * j] = f.x; cl[3 * j + 1] = f.y; cl[3 * j + 2] = f.z;
+    }
+    if (per_leg == NJ + 1) { cl[3 * NJ] = fbody[NJ + 1].x; cl[3 * NJ + 1] = fbody[NJ + 1].y; cl[3 * NJ + 2] = fbody[NJ + 1].z; }
+  }
+  write_rigid_body_state(C, lm_, e, l, s.root, s.q, s.qd);
+}
+#endif           // NJ == 3
+
 // ============================================================================================ post-physics helpers
 LG_DEV float wrap_to_pi(float a) {   // math_utils.py:55-58
   const float two_pi = 6.28318530717958647692f, pi = 3.14159265358979323846f;
@@ -1309,7 +1476,7 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     }
     case LG_REW_FEET_AIR_TIME: {   // RM:150-163, stateful; the stand classes run it on feet 1 and 3 only and leave feet_contact_time alone (anymal.py:287-299)
       float s = 0.f;
-      for (int f = stand ? 1 : 0; f < NLEG; f += stand ? 2 : 1) {
+      for (int f = stand ? 1 : 0; f < (stand ? 4 : NLEG); f += stand ? 2 : 1) {     // (the stand classes of both robots: feet_indices[1] and [3], anymal.py:289, elspider.py:706)
         int b = m.feet_indices[f]; bool contact = cf[3 * b + 2] > 1.f; bool cfl = contact || lastc[f];
         lastc[f] = contact ? 1 : 0;
         float first = (air[f] > 0.f && cfl) ? 1.f : 0.f;
@@ -1343,6 +1510,7 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
     case LG_REW_TERMINATION: return (C->reset_buf[e] && !C->time_out[e]) ? 1.f : 0.f;
     case LG_REW_STAND_STILL: return feat[F_STILL] * (cmdn < 0.1f ? 1.f : 0.f);
     case LG_REW_ASYNC_GAIT_SCHEDULER: return async_gait_value(g, V.dof);
+    case LG_REW_NO_FLY: { int nc = 0; for (int f = 0; f < NLEG; ++f) nc += cf[3 * m.feet_indices[f] + 2] > 0.1f ? 1 : 0; return nc == 1 ? 1.f : 0.f; }   // cassie.py:42-45
     case LG_REW_TRACKING_LIN_VEL:       // stand: commands against -base_lin_vel[1:] (anymal.py:277-281)
       return expf(-(stand ? SQ(cmd[0] + blv[1]) + SQ(cmd[1] + blv[2]) : SQ(cmd[0] - blv[0]) + SQ(cmd[1] - blv[1])) / g.tracking_sigma);
     case LG_REW_TRACKING_ANG_VEL: return expf(-SQ(cmd[2] - (stand ? bav[0] : bav[2])) / g.tracking_sigma);   // anymal.py:283-286
@@ -2159,19 +2327,19 @@ __global__ __launch_bounds__(64) void set_state_kernel(const DevCtx* __restrict_
   if (e < 0 || e >= C->N) return;
   const LegModel lm_{lmod, l};
   const float* rs = (root_src ? root_src : C->root) + (size_t)e * 13;
-  const float* ds = (dof_src ? dof_src : C->dof) + ((size_t)e * NDOF + 3 * l) * 2;
-  float r13[13], q[3], qd[3];
+  const float* ds = (dof_src ? dof_src : C->dof) + ((size_t)e * NDOF + NJ * l) * 2;
+  float r13[13], q[NJ], qd[NJ];
 #pragma unroll
   for (int i = 0; i < 13; ++i) r13[i] = rs[i];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { q[j] = ds[2 * j]; qd[j] = ds[2 * j + 1]; }
+  for (int j = 0; j < NJ; ++j) { q[j] = ds[2 * j]; qd[j] = ds[2 * j + 1]; }
   if (root_src && root_src != C->root && l == 0) {
 #pragma unroll
     for (int i = 0; i < 13; ++i) C->root[(size_t)e * 13 + i] = r13[i];
   }
   if (dof_src && dof_src != C->dof) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { C->dof[((size_t)e * NDOF + 3 * l + j) * 2] = q[j]; C->dof[((size_t)e * NDOF + 3 * l + j) * 2 + 1] = qd[j]; }
+    for (int j = 0; j < NJ; ++j) { C->dof[((size_t)e * NDOF + NJ * l + j) * 2] = q[j]; C->dof[((size_t)e * NDOF + NJ * l + j) * 2 + 1] = qd[j]; }
   }
   write_rigid_body_state(C, lm_, e, l, r13, q, qd);
   const int B = C->B, per_leg = C->per_leg;
@@ -2258,8 +2426,14 @@ static const char* validate(const lg_config* cfg, const lg_robot_model* model, c
   if (cfg->num_height_points > MAX_P) return "num_height_points exceeds the 192 points the post kernel stages in LDS";
   if (cfg->num_extra_obs < 0) return "num_extra_obs is negative";
   if (model->num_legs != NLEG) return "num_legs does not match this kernel instance";
+  if (model->num_joints_per_leg != NJ) return "num_joints_per_leg does not match this kernel instance (4 x 3, 6 x 3, 2 x 6)";
+#if NJ != 3
+  if (cfg->control_type == LG_CTRL_ACTUATOR_NET) return "the 2 x 6 instance has no actuator network (cassie_config.py: PD control)";
+  if (ter->mesh_type == LG_MESH_TRIMESH && !ter->grid_vertices) return "the 2 x 6 instance collides with grid meshes (lg_terrain.grid_vertices) only: it has no BVH walk";
+  for (int l = 0; l < NLEG; ++l) if (model->cp_count[l] > CH_NCP) return "the 2 x 6 instance holds four collision spheres per leg";
+#endif
   if (cfg->num_obs != NPROP + (cfg->measure_heights ? cfg->num_height_points : 0) + cfg->num_extra_obs) return "num_obs does not match the observation layout";
-  if (model->num_bodies != 1 + NLEG * (3 + model->has_foot_body) || model->num_bodies > NBODY_MAX) return "unsupported body count";
+  if (model->num_bodies != 1 + NLEG * (NJ + model->has_foot_body) || model->num_bodies > NBODY_MAX) return "unsupported body count";
   if (cfg->decimation <= 0 || cfg->sim_dt <= 0.f) return "bad dt / decimation";
   if (cfg->resampling_steps <= 0) return "resampling_steps must be positive";
   if (cfg->push_robots && cfg->push_interval <= 0) return "push_interval must be positive";
@@ -2341,7 +2515,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.cfg = *cfg; h.model = *model;
   h.cfg.noise_scale_vec = nullptr; h.cfg.height_points = nullptr;
   h.N = cfg->num_envs; h.B = model->num_bodies; h.K = cfg->num_reward_terms; h.P = cfg->num_height_points;
-  h.per_leg = 3 + model->has_foot_body;
+  h.per_leg = NJ + model->has_foot_body;
   pack_lstm_weights(h.lstm_w, cfg->actuator_net);
   reward_meta(h);
   hot_config(h);
@@ -2524,6 +2698,13 @@ static bool can_fuse(const lg_ctx* c) { return LG_LEGS == 4 && c->fuse && (c->sp
 static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = NDOF, int fuse = 0,
                            PostSink sink = PostSink{nullptr, nullptr, nullptr, nullptr, 0.f}) {
   const int nb = (n + EPB - 1) / EPB;
+#if NJ != 3
+  (void)fuse; (void)sink;
+  if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
+  if (c->h.ter.mesh_type == LG_MESH_TRIMESH) hipLaunchKernelGGL((physics_kernel_chain<0, true>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride);
+  else hipLaunchKernelGGL((physics_kernel_chain<0, false>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride);
+  return;
+#else
   // helper waves (leg bias, contact detection, a share of the contact set-up; with the actuator network also its three
   // joints per leg): always, unless LG_SPLIT=0 (diagnostic) -- and even then on triangle-mesh terrains, whose contact
   // detection is a BVH traversal per collision sphere that should not sit on the main wave.  PD-controlled robots gain
@@ -2559,6 +2740,7 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
       else LG_LAUNCH_PK(false, true, 0, 256);
     } else LG_LAUNCH_PK(false, false, FEAT_ALL, 64);
 #undef LG_LAUNCH_PK
+#endif
 }
 
 int lg_step(lg_ctx* c, const float* actions, void* stream) {
@@ -2847,7 +3029,11 @@ int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
   if (!c) return LG_ERR_INVALID;
   DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
+#if NJ != 3
+  hipLaunchKernelGGL((physics_kernel_chain<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, (const int32_t*)nullptr, c->h.N, NDOF);
+#else
   hipLaunchKernelGGL((physics_kernel<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
+#endif
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }
@@ -2856,10 +3042,15 @@ int lg_simulate(lg_ctx* c, void* stream) {
   if (!c) return LG_ERR_INVALID;
   DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
+#if NJ != 3
+  if (c->h.ter.mesh_type == LG_MESH_TRIMESH) hipLaunchKernelGGL((physics_kernel_chain<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, (const int32_t*)nullptr, c->h.N, NDOF);
+  else hipLaunchKernelGGL((physics_kernel_chain<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, (const int32_t*)nullptr, c->h.N, NDOF);
+#else
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
     hipLaunchKernelGGL((physics_kernel<1, true, false, FEAT_ALL>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
   else
     hipLaunchKernelGGL((physics_kernel<1, false, false, FEAT_ALL>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
+#endif
   HIP_TRY(c, hipGetLastError());
   return LG_OK;
 }

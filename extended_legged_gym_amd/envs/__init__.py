@@ -66,3 +66,7 @@ task_registry.register("pose_elspider_air_flat", PoseElSpider, PoseElSpiderAirFl
 from .elspider_air.elspider_raycast import ElSpiderRayCast  # noqa: E402
 from .elspider_air.mixed_terrains.elspider_air_rough_raycast_config import ElSpiderAirRoughRaycastCfg, ElSpiderAirRoughRaycastCfgPPO  # noqa: E402
 task_registry.register("elspider_air_rough_raycast", ElSpiderRayCast, ElSpiderAirRoughRaycastCfg(), ElSpiderAirRoughRaycastCfgPPO())
+from .cassie.cassie import Cassie  # noqa: E402
+from .cassie.cassie_config import CassieRoughCfg, CassieRoughCfgPPO  # noqa: E402
+# the biped (reference envs/__init__.py:149): the 2 x 6 instance of the kernels (csrc/lg_chain.h)
+task_registry.register("cassie", Cassie, CassieRoughCfg(), CassieRoughCfgPPO())

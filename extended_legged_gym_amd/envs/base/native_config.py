@@ -214,7 +214,7 @@ class NativeSetup:
         dof_names = model["dof_names"]
         self.dof_names = dof_names
         nd = len(dof_names)
-        self.num_dof, self.num_legs = nd, nd // 3
+        self.num_dof, self.num_legs = nd, int(self.model.num_legs)
         self.rand_slots = abi.rand_slots(nd)
         p_gains, d_gains, default_pos = np.zeros(nd), np.zeros(nd), np.zeros(nd)
         for i, name in enumerate(dof_names):

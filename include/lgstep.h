@@ -109,6 +109,7 @@ enum lg_reward_term {
   LG_REW_PENALTY_IN_THE_AIR,         /* StandAnymal / StandGo2._reward_penalty_in_the_air (anymal.py:301-308): neither of feet 1, 3 in (filtered) contact */
   LG_REW_ASYNC_GAIT_SCHEDULER,       /* AnymalCBatchRollout / Go2BatchRollout._reward_async_gait_scheduler (anymal_c_batch_rollout.py:207-220) over
                                       * AsyncGaitScheduler's three terms (utils/gait_scheduler.py:151-175), see lg_config.async_* */
+  LG_REW_NO_FLY,                     /* Cassie._reward_no_fly (envs/cassie/cassie.py:42-45): exactly one foot with contact_forces z > 0.1 */
   LG_REW_COUNT
 };
 

@@ -40,6 +40,11 @@ m = load_urdf(f"{REF}/robots/el_mini/urdf/el_mini_collsp.urdf", "FOOT", ["base",
 save_model(m, f"{OUT}/robots/el_mini_collsp.json")
 print("el_mini_collsp", m["num_bodies"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"])
 
+# Cassie (envs/cassie/cassie_config.py:76-82): two legs of six revolute joints, an open chain (cassie.urdf:343-349, 397-403: the knee-spring joints are comments)
+m = load_urdf(f"{REF}/robots/cassie/urdf/cassie.urdf", "toe", [], ["pelvis"])
+save_model(m, f"{OUT}/robots/cassie.json")
+print("cassie", m["num_bodies"], m["body_names"], "mass", m["base_mass"] + sum(map(sum, m["link_mass"])), m["cp_count"], m["dof_names"])
+
 import torch
 net = torch.jit.load(f"{REF}/actuator_nets/anydrive_v3_lstm.pt")
 sd = {k: v.detach().numpy() for k, v in net.state_dict().items()}
