@@ -20,6 +20,8 @@ GOLDEN_CASES = ["flat_pd", "flat_lstm", "rough_lstm", "rough_allrew", "flat_load
 # recorded from the reference's `ElSpider.step()` (six legs: the lg6 instance of the kernels, which ends its step in post_kernel)
 HEXAPOD_GOLDEN_CASES = ["elspider_flat_lstm", "elspider_rough_allrew",
                         "elspider_raycast_allrew"]     # ElSpiderRayCast with its sensors off: ElSpider's pieces restated + the base class's twelve-joint noise layout
+# recorded from the reference's `Cassie.step()` (two legs of six joints: the lg2 instance, csrc/lg_chain.h)
+BIPED_GOLDEN_CASES = ["cassie_rough"]
 CLASS_VARIANTS = {"LoadAdaptAnymal": {"orientation": "orientation_load_adapt"}}   # = LoadAdaptAnymal.reward_term_variants
 CLASS_REWARD_CLASS = {"StandAnymal": "stand"}                                        # = StandAnymal.reward_class
 ANYMAL_GAIT = dict(period=0.6, swing_height=0.15, foot_phases=[0.0, 0.5, 0.5, 0.0])   # anymal.py:59-63
@@ -32,7 +34,7 @@ class FixtureTerrain:
 
 
 def load_golden(name):
-    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz" if name.startswith("elspider_") else f"anymal_{name}.npz"))
+    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz" if name.startswith(("elspider_", "cassie_")) else f"anymal_{name}.npz"))
     meta = json.loads(bytes(z["meta_json"]).decode())
     return z, meta
 
@@ -67,8 +69,13 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
             from extended_legged_gym_amd.envs.elspider_air.mixed_terrains.elspider_air_rough_raycast_config import ElSpiderAirRoughRaycastCfg
             cfg = ElSpiderAirRoughRaycastCfg()
             cfg.raycaster.enable_raycast, cfg.depth.camera_type, cfg.env.num_observations, cfg.terrain.mesh_type = False, None, 66, "plane"
+    biped = case.get("cls") == "Cassie"
+    if biped:
+        from extended_legged_gym_amd.envs.cassie.cassie_config import CassieRoughCfg
+        cfg = CassieRoughCfg()
     cfg.env.num_envs = case["num_envs"]
-    cfg.control.use_actuator_network = case["actuator_net"]
+    if not biped:
+        cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]
     cfg.commands.resampling_time = case["resampling_time"]
     cfg.commands.heading_command = case["heading_command"]
@@ -86,13 +93,13 @@ def golden_setup(z, meta, rng_mode=abi.LG_RNG_INJECT):
         cfg.rewards.max_contact_force = case["max_contact_force"]
     cfg.rewards.only_positive_rewards = case.get("only_positive_rewards", True)
     model = load_robot_model(cfg.asset)
-    if not hexapod:      # the harness robot (tools/refgen/ref_loader.py:anymal_robot_description) carries these DOF limits; the hexapod's are the URDF's
+    if not hexapod and not biped:      # the harness robot (tools/refgen/ref_loader.py:anymal_robot_description) carries these DOF limits; the hexapod's are the URDF's
         model["dof_lower"], model["dof_upper"] = [-9.42] * 12, [9.42] * 12
         model["dof_vel_limit"], model["torque_limit"] = [20.0] * 12, [80.0] * 12
     # AnymalStudent: the native step produces the teacher's row (what the class asks of it, anymal.py:AnymalStudent.__init__)
     # PoseAnymal: the native step runs without the two pose terms, the clip and the noise (anymal.py:pose_native_cfg)
     with (teacher_row_cfg(cfg) if student else pose_native_cfg(cfg) if pose else contextlib.nullcontext()):
-        setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ELSPIDER_GAIT if hexapod else ANYMAL_GAIT,
+        setup = NativeSetup(cfg, sim_params_for(cfg), model, terrain=terrain, seed=0, rng_mode=rng_mode, gait=ELSPIDER_GAIT if hexapod else None if biped else ANYMAL_GAIT,
                             terminate_on_flip=hexapod,                                  # ElSpider.check_termination (elspider.py:339-346; elspider_raycast.py:296-303)
                             noise_layout_dof=12 if raycast else None,                    # = ElSpiderRayCast._noise_layout_dof
                             reward_term_variants=CLASS_VARIANTS.get(case.get("cls", "Anymal")),

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import GOLDEN_CASES, HEXAPOD_GOLDEN_CASES, golden_setup, load_golden, load_pre_state, post_keys
+from tests.helpers import BIPED_GOLDEN_CASES, GOLDEN_CASES, HEXAPOD_GOLDEN_CASES, golden_setup, load_golden, load_pre_state, post_keys
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 2e-5, 2e-6
@@ -22,7 +22,7 @@ def check(name, got, want, t):
         np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL_BY_NAME.get(name, ATOL), err_msg=f"step {t}: {name}")
 
 
-@pytest.mark.parametrize("case", GOLDEN_CASES + HEXAPOD_GOLDEN_CASES)
+@pytest.mark.parametrize("case", GOLDEN_CASES + HEXAPOD_GOLDEN_CASES + BIPED_GOLDEN_CASES)
 def test_hip_step_matches_reference(case):
     from extended_legged_gym_amd.native import NativeCore
     z, meta = load_golden(case)

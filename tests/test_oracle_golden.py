@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle_lib import OracleEnv
-from tests.helpers import GOLDEN_CASES, HEXAPOD_GOLDEN_CASES, golden_setup, load_golden, load_pre_state, post_keys
+from tests.helpers import BIPED_GOLDEN_CASES, GOLDEN_CASES, HEXAPOD_GOLDEN_CASES, golden_setup, load_golden, load_pre_state, post_keys
 
 RTOL, ATOL = 2e-5, 2e-6
 # LSTM actuator torques are 20 x a cancelling 8-term dot product of O(1) activations: absolute error scales with out_scale
@@ -21,7 +21,7 @@ def check(name, got, want, t):
         np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL_BY_NAME.get(name, ATOL), err_msg=f"step {t}: {name}")
 
 
-@pytest.mark.parametrize("case", GOLDEN_CASES + HEXAPOD_GOLDEN_CASES)
+@pytest.mark.parametrize("case", GOLDEN_CASES + HEXAPOD_GOLDEN_CASES + BIPED_GOLDEN_CASES)
 def test_static_tables_match_reference(case):
     z, meta = load_golden(case)
     cfg, s = golden_setup(z, meta)
@@ -43,7 +43,7 @@ def test_static_tables_match_reference(case):
         np.testing.assert_array_equal(s.height_points, z["height_points"][:, :2])
 
 
-@pytest.mark.parametrize("case", GOLDEN_CASES + HEXAPOD_GOLDEN_CASES)
+@pytest.mark.parametrize("case", GOLDEN_CASES + HEXAPOD_GOLDEN_CASES + BIPED_GOLDEN_CASES)
 def test_oracle_step_matches_reference(case):
     z, meta = load_golden(case)
     cfg, s = golden_setup(z, meta)

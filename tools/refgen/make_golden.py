@@ -47,11 +47,18 @@ def build(case):
     if case.get("cls") == "ElSpiderRayCast":
         from legged_gym.envs import ElSpiderRayCast
         Base["ElSpiderRayCast"] = ElSpiderRayCast
+    if case.get("cls") == "Cassie":
+        from legged_gym.envs import Cassie
+        Base["Cassie"] = Cassie
     Base = Base[case.get("cls", "Anymal")]
     import legged_gym.envs.base.legged_robot as LR
 
     hexapod = case.get("cls") in HEXAPOD_CLASSES
     ref_loader.FakeGym.robot = ref_loader.elspider_robot_description() if hexapod else ref_loader.anymal_robot_description()
+    if case.get("cls") == "Cassie":           # task cassie (envs/__init__.py:149): LeggedRobot + _reward_no_fly on the biped's 12 joints / 13 bodies
+        from legged_gym.envs import Cassie, CassieRoughCfg
+        Base = Cassie
+        ref_loader.FakeGym.robot = ref_loader.cassie_robot_description()
     N = case["num_envs"]
     cfg = AnymalCFlatCfg() if case["base"] == "flat" else AnymalCRoughCfg()
     if hexapod:
@@ -68,12 +75,15 @@ def build(case):
         cfg = PoseAnymalCFlatCfg()
     if case.get("cls") == "PoseElSpider":
         cfg = PoseElSpiderAirFlatCfg()
+    if case.get("cls") == "Cassie":
+        cfg = CassieRoughCfg()
     if case.get("cls") == "ElSpiderRayCast":      # the class's own task config with the sensors off (they need Warp) and a plane under the robot
         from legged_gym.envs import ElSpiderAirRoughRaycastCfg
         cfg = ElSpiderAirRoughRaycastCfg()
         cfg.raycaster.enable_raycast, cfg.depth.camera_type, cfg.env.num_observations, cfg.terrain.mesh_type = False, None, 66, "plane"
     cfg.env.num_envs = N
-    cfg.control.use_actuator_network = case["actuator_net"]
+    if case.get("cls") != "Cassie":
+        cfg.control.use_actuator_network = case["actuator_net"]
     cfg.domain_rand.push_interval_s = case["push_interval_s"]
     cfg.commands.resampling_time = case["resampling_time"]
     cfg.commands.heading_command = case["heading_command"]
@@ -207,13 +217,18 @@ def persistent(env):
         feet_air_time=env.feet_air_time, feet_contact_time=env.feet_contact_time, last_contacts=env.last_contacts,
         episode_length_buf=env.episode_length_buf,
         episode_sums=torch.stack([env.episode_sums[k] for k in env.episode_sums.keys()]),
-        env_origins=env.env_origins, gait_idx=env.gait_scheduler.gait_idx,
-        gait_foot_z=env.gait_scheduler.foot_pos[:, :, 2],
-        sea_hidden=env.sea_hidden_state, sea_cell=env.sea_cell_state,
+        env_origins=env.env_origins,
     )
+    if hasattr(env, "gait_scheduler"):
+        d.update(gait_idx=env.gait_scheduler.gait_idx, gait_foot_z=env.gait_scheduler.foot_pos[:, :, 2],
+                 sea_hidden=env.sea_hidden_state, sea_cell=env.sea_cell_state)
+    else:                                     # plain LeggedRobot classes (Cassie): no gait scheduler, no actuator-network state
+        nd_, nf_ = env.num_dof, len(env.feet_indices)
+        d.update(gait_idx=torch.zeros(env.num_envs), gait_foot_z=torch.zeros(env.num_envs, nf_),
+                 sea_hidden=torch.zeros(2, env.num_envs * nd_, 8), sea_cell=torch.zeros(2, env.num_envs * nd_, 8))
     if hasattr(env, "terrain_levels"):
         d["terrain_levels"] = env.terrain_levels
-    if env.feet_air_time.shape[1] == 2:       # StandAnymal's two-wide buffers (anymal.py:256-260) = feet 1 and 3 of four
+    if env.feet_air_time.shape[1] == 2 and len(env.feet_indices) == 4:       # StandAnymal's two-wide buffers (anymal.py:256-260) = feet 1 and 3 of four
         for k in ("feet_air_time", "last_contacts"):
             wide = torch.zeros(env.num_envs, 4, dtype=d[k].dtype)
             wide[:, 1::2] = d[k]
@@ -350,7 +365,7 @@ def run_case(case):
                 max_episode_length_s=float(env.max_episode_length_s))
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, f"{'elspider' if case.get('cls') in HEXAPOD_CLASSES else 'anymal'}_{case['name']}.npz")
+    path = os.path.join(OUT, f"{'elspider' if case.get('cls') in HEXAPOD_CLASSES else 'cassie' if case.get('cls') == 'Cassie' else 'anymal'}_{case['name']}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", "resets per step:", out["reset"].sum(axis=1))
 
@@ -428,8 +443,18 @@ CASES += [
          scales=dict(ALL_SCALES, feet_slip=-0.1, base_height=-1.0, async_gait_scheduler=0.0), only_positive_rewards=False),
 ]
 
+# Cassie (envs/cassie/cassie.py:42-45, cassie_config.py): LeggedRobot's step on 2 x 6 joints with `_reward_no_fly`; the rough config's 11 x 11 height scan
+# (169 observations), every term of the config on plus a few the base class offers
+CASES += [
+    dict(name="rough", base="rough", cls="Cassie", num_envs=32, steps=6, seed=21, actuator_net=False, push_interval_s=0.06,
+         resampling_time=0.1, heading_command=True, episode_length_s=20, num_rows=4, num_cols=4, border_size=5,
+         scales=dict(dof_vel=-1e-4, ang_vel_xy=-0.05, feet_contact_forces=-0.01, orientation=-1.0, base_height=-0.5, feet_slip=-0.1, stand_still=-0.1),
+         only_positive_rewards=False),
+]
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for c in CASES:
-        if not only or (("elspider_" if c.get("cls") in HEXAPOD_CLASSES else "anymal_") + c["name"]) in only:
+        prefix = "elspider_" if c.get("cls") in HEXAPOD_CLASSES else "cassie_" if c.get("cls") == "Cassie" else "anymal_"
+        if not only or (prefix + c["name"]) in only:
             run_case(c)

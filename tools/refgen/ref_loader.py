@@ -294,6 +294,20 @@ def elspider_robot_description():
                 body_masses=[15.8991] + [1.0] * 24)
 
 
+def cassie_robot_description():
+    """DOF / body naming of Cassie (`cassie.urdf`) after fixed-joint collapse, in Isaac Gym's (alphabetical DFS) order, with the URDF's joint limits
+    (`cassie.urdf:315-416`)."""
+    joints = ["hip_abduction", "hip_rotation", "hip_flexion", "thigh_joint", "ankle_joint", "toe_joint"]
+    links = ["pelvis_rotation", "hip", "thigh", "shin", "tarsus", "toe"]
+    dof_names = [f"{j}_{side}" for side in ("left", "right") for j in joints]
+    body_names = ["pelvis"] + [f"{side}_{l}" for side in ("left", "right") for l in links]
+    lower = np.array([-0.2618, -0.3927, -0.8727, -2.8623, 0.6458, -2.4435, -0.3927, -0.3927, -0.8727, -2.8623, 0.6458, -2.4435], np.float32)
+    upper = np.array([0.3927, 0.3927, 1.3963, -0.6458, 2.8623, -0.5236, 0.2618, 0.3927, 1.3963, -0.6458, 2.8623, -0.5236], np.float32)
+    vel = np.tile(np.array([20.1475, 20.1475, 20.5085, 20.5085, 20.5085, 20.5192], np.float32), 2)
+    eff = np.tile(np.array([112.0, 112.0, 195.0, 195.0, 195.0, 45.0], np.float32), 2)
+    return dict(dof_names=dof_names, body_names=body_names, lower=lower, upper=upper, velocity=vel, effort=eff, body_masses=[10.33] + [1.0] * 12)
+
+
 def load_reference():
     """Returns the reference `legged_gym` package (real code) after installing stubs."""
     install_stubs()
