@@ -2451,6 +2451,9 @@ static const char* validate(const lg_config* cfg, const lg_robot_model* model, c
       return "sc_pairs names a collision sphere the model does not have";
   }
   for (int k = 0; k < cfg->num_reward_terms; ++k) if (cfg->reward_term_ids[k] < 0 || cfg->reward_term_ids[k] >= LG_REW_COUNT) return "unknown reward term id";
+  for (int k = 0; k < cfg->num_reward_terms; ++k)
+    if (NLEG != 4 && cfg->reward_term_ids[k] == LG_REW_PENALTY_IN_THE_AIR) return "penalty_in_the_air is the four-legged stand classes' term (feet 1 and 3 of four)";
+  if (cfg->reward_class == LG_RC_STAND && NLEG < 4) return "the stand reward class reads feet 1 and 3: it needs at least four legs";
   if (!cfg->noise_scale_vec) return "noise_scale_vec is null";
   if (cfg->num_height_points > 0 && !cfg->height_points) return "height_points is null";
   return nullptr;

@@ -44,7 +44,7 @@ task_registry.register("stand_go2_flat", StandGo2, StandGo2FlatCfg(), StandGo2Fl
 task_registry.register("anymal_c_rough_student", AnymalStudent, AnymalCRoughStudentCfg(), AnymalCRoughStudentCfgPPO())
 task_registry.register("pose_anymal_c_flat", PoseAnymal, PoseAnymalCFlatCfg(), PoseAnymalCFlatCfgPPO())
 task_registry.register("pose_go2_flat", PoseGo2, PoseGo2FlatCfg(), PoseGo2FlatCfgPPO())
-from .elspider_air.elspider import ElSpider, LoadAdaptElSpider, PoseElSpider  # noqa: E402
+from .elspider_air.elspider import ElSpider, LoadAdaptElSpider, PoseElSpider, StandElSpider  # noqa: E402
 from .elspider_air.mixed_terrains.elspider_air_rough_config import ElSpiderAirRoughCfg, ElSpiderAirRoughCfgPPO  # noqa: E402
 from .elspider_air.mixed_terrains.elspider_air_rough_train_config import ElSpiderAirRoughTrainCfg, ElSpiderAirRoughTrainCfgPPO  # noqa: E402
 from .elspider_air.flat.elspider_air_flat_config import ElSpiderAirFlatCfg, ElSpiderAirFlatCfgPPO  # noqa: E402

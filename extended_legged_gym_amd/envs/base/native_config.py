@@ -291,6 +291,10 @@ class NativeSetup:
         r = cfg.rewards
         c.only_positive_rewards = int(r.only_positive_rewards)
         c.reward_class = abi.REWARD_CLASSES[reward_class]
+        if reward_class == "stand" and self.num_legs == 6 and "penalty_in_the_air" in self.reward_names:
+            raise RuntimeError("The size of tensor a (6) must match the size of tensor b (2) at non-singleton dimension 1 [StandElSpider._reward_penalty_in_the_air "
+                               "(elspider.py:718-725) ORs the contacts of all six feet with the class's two-wide last_contacts: the reference raises this on the "
+                               "first step; set rewards.scales.penalty_in_the_air = 0]")
         if reward_class == "stand":        # StandAnymal's (N, 2) feet buffers: the four-footed timer terms cannot run on them
             bad = {"four_footup", "jump_air", "gait_2_step", "feet_slip"} & set(self.reward_names)
             if bad:

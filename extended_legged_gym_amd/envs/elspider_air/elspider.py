@@ -84,3 +84,18 @@ class PoseElSpider(PoseCommandsMixin, ElSpider):
 class LoadAdaptElSpider(ElSpider):
     """`LoadAdaptElSpider` (reference `elspider.py:410-444`): `_reward_orientation` against gravity + acceleration, as `LoadAdaptAnymal`."""
     reward_term_variants = {"orientation": "orientation_load_adapt"}
+
+
+class StandElSpider(ElSpider):
+    """`StandElSpider` (reference `elspider.py:678-731`; the class exists there, no task registers it): the hexapod balancing with its x axis up -- the
+    reward overrides of `StandAnymal` (`ang_vel_xy`, `orientation`, `tracking_lin_vel`, `tracking_ang_vel` on the turned axes; `feet_air_time` on
+    `feet_indices[1]` and `[3]` with two-wide buffers, `:703-716`), natively `lg_config.reward_class = LG_RC_STAND` on the six-legged instance: the two
+    feet are columns 1 and 3 of the six-wide arena tensors, exposed two wide as the reference has them.  `_reward_penalty_in_the_air` (`:718-725`)
+    compares the (N, 6) contacts of ALL feet with the class's (N, 2) `last_contacts` and raises in the reference; `_reward_standing` sums a 1-D tensor
+    over dim 1 and raises as well: a config that scales either is refused with the reference's error (`NativeSetup`)."""
+    reward_class = "stand"
+
+    def _init_buffers(self):
+        super()._init_buffers()
+        self.feet_air_time = self.feet_air_time[:, 1:4:2]        # (N, 2) strided views of the arena tensors
+        self.last_contacts = self.last_contacts[:, 1:4:2]
