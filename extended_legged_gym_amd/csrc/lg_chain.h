@@ -57,17 +57,13 @@ LG_DEV void ch_detect_slot(int sl, const LegModel& lm_, const TerrainView& T, co
   const V3 gv = mul(Rl, lm_.v(LM_CP_SLIDE + 3 * sl));
   const bool seg = gv.x != 0.f || gv.y != 0.f || gv.z != 0.f;
   V3 x = x0, n = v3(0, 0, 1); float phi = 1.f; bool hit = true;
-  if (TMESH) {
-    const V3 sv = 0.5f * gv; const float ext = norm(sv);
+  if (TMESH) {                                         // (triangle meshes: the spheres stand alone, see contact_detect_mesh)
     ClosestQuery Q;
-    x = x0 + sv;
-    Q.p = x; Q.max_dist = rad + P.contact_offset + LG_MESH_CONTACT_MARGIN + ext; Q.on = sl < ncp; Q.found = false; Q.cp = x; Q.fn = v3(0, 0, 1);
-    Q.range = rad + P.contact_offset + ext; Q.lb = Q.max_dist;
+    Q.p = x; Q.max_dist = rad + P.contact_offset + LG_MESH_CONTACT_MARGIN; Q.on = sl < ncp; Q.found = false; Q.cp = x; Q.fn = v3(0, 0, 1);
+    Q.range = rad + P.contact_offset; Q.lb = Q.max_dist;
     closest_point_grid(T, Q);
     hit = false;
     if (Q.on && Q.found) {
-      const float s2 = dot(sv, sv);
-      if (s2 > 0.f) { const float t = fminf(fmaxf(dot(Q.cp - x, sv) / s2, -1.f), 1.f); x = x + t * sv; }
       const V3 diff = x - Q.cp; const float dist = norm(diff);
       if (dist <= rad + P.contact_offset + LG_MESH_CONTACT_MARGIN) {
         const float sign = dot(diff, Q.fn) < 0.f ? -1.f : 1.f;

@@ -769,40 +769,35 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
   // slots in pairs: one BVH traversal serves two neighbouring spheres (closest_point_pair)
 #pragma unroll 1
   for (int sp0 = s0; sp0 < s1; sp0 += 2) {
-    V3 xs[2], svs[2]; float rads[2], ranges[2], reaches[2]; ClosestQuery Q[2];
+    V3 xs[2]; float rads[2], ranges[2], reaches[2]; ClosestQuery Q[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int sl = sp0 + h;
-      xs[h] = pb; svs[h] = v3(0, 0, 0); rads[h] = 0.f; ranges[h] = 0.f; reaches[h] = 0.f;
+      xs[h] = pb; rads[h] = 0.f; ranges[h] = 0.f; reaches[h] = 0.f;
       Q[h].p = pb; Q[h].max_dist = 0.f; Q[h].on = false; Q[h].found = false; Q[h].cp = pb; Q[h].fn = v3(0, 0, 1); Q[h].range = 0.f; Q[h].lb = 0.f;
       if (sl < s1 && sl < ncp) {
         const int link = lm_.i(LM_CP_LINK + sl);
         const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
         rads[h] = lm_.f(LM_CP_RADIUS + sl);
-        const V3 x0 = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
-        // capsule segment to the next sphere of the chain (lg_robot_model.cp_slide; zero: a lone sphere): ONE query from the segment's middle that
-        // reaches half its length further; the sphere then slides to the point of the segment nearest to the mesh point found (oracle: the same rule)
-        const V3 ls = 0.5f * lm_.v(LM_CP_SLIDE + 3 * sl);
-        svs[h] = sel3(link < 0, mul(Rb, ls), sel3(link == 0, mul(k.R[0], ls), sel3(link == 1, mul(k.R[1], ls), mul(k.R[2], ls))));
-        const V3 x = x0 + svs[h];
+        const V3 x = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
         xs[h] = x;
-        const float ext = norm(ls);
+        // (capsule segments, lg_robot_model.cp_slide, are matched against the EDGES of a height grid; on a triangle mesh the spheres stand alone: a
+        //  closest-point query of a segment is not built, and sliding the sphere to the segment point nearest ONE mesh point loses the contact of its own end)
         const float range = rads[h] + P.contact_offset + LG_MESH_CONTACT_MARGIN;
-        const float range_q = range + ext;
-        const float reach = cq ? range_q + LG_MESH_CACHE_REACH : range_q;
+        const float reach = cq ? range + LG_MESH_CACHE_REACH : range;
         ranges[h] = range; reaches[h] = reach;
         bool query = true; float bound = reach;
         if (cq) {
           const float dq = CQ(sl, 3);
           if (dq >= 0.f) {
             const float travel = norm(x - v3(CQ(sl, 0), CQ(sl, 1), CQ(sl, 2)));
-            query = !(travel < dq - range_q);
+            query = !(travel < dq - range);
             bound = fminf(reach, dq + travel * 1.0001f + 1e-4f);
           }
         }
         // grid meshes: a sphere higher above everything around it than radius + contact_offset cannot touch (the margin in `range`
         // is for centres that have sunk BELOW the surface)
-        Q[h].p = x; Q[h].max_dist = bound; Q[h].on = query; Q[h].range = rads[h] + P.contact_offset + ext; Q[h].lb = bound;
+        Q[h].p = x; Q[h].max_dist = bound; Q[h].on = query; Q[h].range = rads[h] + P.contact_offset; Q[h].lb = bound;
       }
     }
 #ifdef LG_STAMPS
@@ -828,17 +823,12 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       const int sl = sp0 + h;
       if (sl >= s1) continue;
       bool active = false; V3 n = v3(0, 0, 1); float phi = 1.f;
-      V3 x = xs[h]; const float rad = rads[h];
+      const V3 x = xs[h]; const float rad = rads[h];
       if (Q[h].on) {
         // nothing found: nothing lies within the radius that was searched (= `reach` whenever the cached distance was exact; a grid
         // mesh may return a smaller proven bound)
-        V3 diff = x - Q[h].cp; float dist = Q[h].found ? norm(diff) : (T.GV ? Q[h].lb : reaches[h]);
-        if (cq) { CQ(sl, 0) = x.x; CQ(sl, 1) = x.y; CQ(sl, 2) = x.z; CQ(sl, 3) = dist; }       // (the cache is about the part's middle)
-        const float s2 = dot(svs[h], svs[h]);
-        if (Q[h].found && s2 > 0.f) {
-          const float t = fminf(fmaxf(dot(Q[h].cp - x, svs[h]) / s2, -1.f), 1.f);
-          x = x + t * svs[h]; diff = x - Q[h].cp; dist = norm(diff);
-        }
+        const V3 diff = x - Q[h].cp; const float dist = Q[h].found ? norm(diff) : (T.GV ? Q[h].lb : reaches[h]);
+        if (cq) { CQ(sl, 0) = x.x; CQ(sl, 1) = x.y; CQ(sl, 2) = x.z; CQ(sl, 3) = dist; }
         if (Q[h].found && dist <= ranges[h]) {
           const float sign = dot(diff, Q[h].fn) < 0.f ? -1.f : 1.f;
           n = dist > 1e-6f ? (sign / dist) * diff : Q[h].fn;
