@@ -1149,9 +1149,9 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   // mass matrix and its factors it sat in the middle of ~500 live registers and the inlined closest-point scan spilled them
   // (~800 scratch loads in the substep of the main wave)
 #if defined(LG_STAMPS) && defined(LG_STAMP_MAIN_MESH)
-  if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh(0, MAIN_DETECT, lm_, T, P, k, Rb, pb, cst, lane, cq, stamps);   // diagnostic: the query counters watch this wave
+  if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh(MAIN_DETECT - 100, MAIN_DETECT - 98, lm_, T, P, k, Rb, pb, cst, lane, cq, stamps);   // diagnostic: the query counters watch this wave
 #else
-  if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh(0, MAIN_DETECT, lm_, T, P, k, Rb, pb, cst, lane, cq);
+  if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh(MAIN_DETECT - 100, MAIN_DETECT - 98, lm_, T, P, k, Rb, pb, cst, lane, cq);   // (triangle-mesh instances: MAIN_DETECT = 100 + the first slot of this wave's pair)
 #endif
   // ---------------------------------------------------------------- bias forces (RNEA, zero generalised acceleration)
   const float m0 = m->base_mass + madd, iscale = m0 * frcp(m->base_mass);
@@ -1214,9 +1214,11 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   STAMP(3);
   // ---------------------------------------------------------------- leg bias + contact detection: helper waves or inline
   float bk[3]; V3 Fs, Ns;
-  if (!TMESH && MAIN_DETECT > 0 && share.n > 1) {
-    if (FEAT & 1) contact_detect_caps<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
-    else contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
+  if constexpr (!TMESH && MAIN_DETECT > 0) {
+    if (share.n > 1) {
+      if (FEAT & 1) contact_detect_caps<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
+      else contact_detect<0, MAIN_DETECT>(lm_, T, P, k, Rb, pb, cst, lane);
+    }
   }
   STAMP(29);   // (diagnostic: this wave's own detection ends here; what follows in stamp 5 is the wait at the rendezvous)
   if (!prep_fn(bk, Fs, Ns)) {

@@ -560,6 +560,15 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // act_stride: floats between consecutive action rows (12, or horizon * 12 when the rows are one step of a (n, horizon, 12) plan)
   // contact-detection split of a heightfield step with actuator waves (see the helper loop); mesh terrains: two slots a wave
   // (heightfield / plane steps; on triangle-mesh terrains every wave takes the slot pair [2 w, 2 w + 2), the main wave [0, 2))
+  // Triangle-mesh steps: every wave takes one PAIR of slots (one traversal serves two neighbouring spheres).  The feet and the lowest shank spheres
+  // (slots 0, 1: always near the ground, never skipped by the distance cache) are the expensive pair: they go to a helper wave -- wave 2, wave 1 has
+  // the leg bias as well --, the main wave takes the cheapest pair (6, 7: trunk spheres, skipped by the cache in nearly every substep).  Round 4 had the
+  // main wave on (0, 1): its queries were 76 % of the kernel on config 3 while the helper waves of a PD robot idled (A/B build 31 = that deal).
+#if LG_AB == 31
+#define MESH_PAIR0(wv_) (2 * (wv_))
+#else
+#define MESH_PAIR0(wv_) ((wv_) == 0 ? 6 : ((wv_) == 1 ? 2 : ((wv_) == 2 ? 0 : 4)))
+#endif
   constexpr int DS0 = 3, DS1 = 4, DS2 = 6;   // main 3 / wave 1 (which also has the leg bias) 1 / 2 / 2: the helpers are the last to arrive at (A2), the main wave has ~3 k cycles of slack there (A/B in one session: 2/2/2/2 +1.4 us, 4/0/2/2 +0.3 us; 1/2/2/3 and 0/2/3/3: worse still; the capsule-segment instance, round 5: 4/0/2/2 +3.5 us, 2/1/2/3 +0.3 us against this deal)
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     P.slide_mask = 0u;
 #endif
     const TerrainView T = C->ter;
-    if (TMESH) mesh_cache_io<true>(C, cqc, e, l, lane, 2 * wv);   // this wave's two slots of the persisted query cache -> LDS
+    if (TMESH) mesh_cache_io<true>(C, cqc, e, l, lane, MESH_PAIR0(wv));   // this wave's two slots of the persisted query cache -> LDS
 #ifdef LG_STAMPS
 #ifndef LG_STAMP_WAVE
 #define LG_STAMP_WAVE 2          // which helper wave the diagnostic build watches
@@ -721,17 +730,17 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           pb4[0] = make_float4(bk[0], bk[1], bk[2], Fs.x); pb4[1] = make_float4(Fs.y, Fs.z, Ns.x, Ns.y); pb4[2] = make_float4(Ns.z, 0.f, 0.f, 0.f);
         }
         if (!TMESH) { if (DS0 < DS1) { if (CAPS) contact_detect_begin_caps<DS0, DS1P>(lm_, T, k, Rb, pb, P.slide_mask, pc1); else contact_detect_begin<DS0, DS1P>(lm_, T, k, Rb, pb, pr1); } }
-        else contact_detect_mesh(2, 4, lm_, T, P, k, Rb, pb, cst, lane, cqc);
+        else contact_detect_mesh(MESH_PAIR0(1), MESH_PAIR0(1) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (TMESH) {
 #ifdef LG_STAMPS
-        contact_detect_mesh(2 * wv, 2 * wv + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc,
+        contact_detect_mesh(MESH_PAIR0(wv), MESH_PAIR0(wv) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc,
 #ifdef LG_STAMP_MAIN_MESH
                             nullptr);
 #else
                             (blockIdx.x == 0 && wv == 2) ? C->stamps : nullptr);
 #endif
 #else
-        contact_detect_mesh(2 * wv, 2 * wv + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
+        contact_detect_mesh(MESH_PAIR0(wv), MESH_PAIR0(wv) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
 #endif
       } else if (wv == 2) {
         if (CAPS) contact_detect_begin_caps<DS1, DS2>(lm_, T, k, Rb, pb, P.slide_mask, pc2); else contact_detect_begin<DS1, DS2>(lm_, T, k, Rb, pb, pr2);
@@ -801,7 +810,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     STAMP(48);
     if (predraw) fused_noise_park(hot, cst, bid, n, (wv - 1) * 64 + lane, nz);
     if (fuse) fused_stage_obs_table(hot, cst, (wv - 1) * 64 + lane, fpre);
-    if (TMESH && valid) mesh_cache_io<false>(Ct, cqc, e, l, lane, 2 * wv);
+    if (TMESH && valid) mesh_cache_io<false>(Ct, cqc, e, l, lane, MESH_PAIR0(wv));
     bool zero_state = false;
     if (!fuse) {
       if (valid) {                                       // wave w stores link w-1 of every leg (+ base / + foot body)
@@ -921,7 +930,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const float mu_robot = pre_mu, madd = pre_madd;
   V3 fbody[5];
   bool fault = false;
-  if (TMESH && helpers) mesh_cache_io<true>(C, cqc, e, l, lane, 0);
+  if (TMESH && helpers) mesh_cache_io<true>(C, cqc, e, l, lane, MESH_PAIR0(0));
 #ifdef LG_STAMPS
   unsigned long long* stamps = (blockIdx.x == 0 && lane == 0) ? C->stamps : nullptr;
   __builtin_amdgcn_s_waitcnt(0);                      // (diagnostic: the state loads have landed)
@@ -974,7 +983,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     };
     auto share_fn = [&]() { if (helpers) lds_barrier(); };   // (A3) every wave has finished its slots
     const SlotShare share{helpers ? 4 : 1, helpers ? 3 : 0, helpers};     // set-up order: wave 1, 2, 3, then this wave
-    physics_substep<TMESH, TMESH ? 2 : DS0, !(MODE == 0 && HELPERS), (SPEC & 3) == 1 ? 1 : 0, FEAT>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
+    physics_substep<TMESH, TMESH ? MESH_PAIR0(0) + 100 : DS0, !(MODE == 0 && HELPERS), (SPEC & 3) == 1 ? 1 : 0, FEAT>(m, lm_, T, P, lane, cst, s, tau_fn, prep_fn, share_fn, share, xs, mu_robot, madd,
                               sub == nsub - 1 ? fbody : nullptr, stamps, (TMESH && helpers) ? cqc : nullptr, scol);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
@@ -1049,7 +1058,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     if (valid) {
-      if (TMESH && helpers) mesh_cache_io<false>(Ct, cqc, e, l, lane, 0);
+      if (TMESH && helpers) mesh_cache_io<false>(Ct, cqc, e, l, lane, MESH_PAIR0(0));
 #pragma unroll
       for (int j = 0; j < 3; ++j) if (!split) Ct->torques[(size_t)e * NDOF + 3 * l + j] = tau[j];
       // (the net contact forces go out with the env rows: fused_writeback_obs, from the LDS rows fused_main_part1 wrote)
@@ -1070,7 +1079,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     return;
   }
   if (!valid) return;
-  if (TMESH && helpers) mesh_cache_io<false>(C, cqc, e, l, lane, 0);
+  if (TMESH && helpers) mesh_cache_io<false>(C, cqc, e, l, lane, MESH_PAIR0(0));
   if (fault && l == 0) C->reset_buf[e] = 2;
 
   // ---- write back state, torques, contact forces
