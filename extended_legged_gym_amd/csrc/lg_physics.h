@@ -242,6 +242,47 @@ LG_DEV void spd6_inverse_from_chol(const float* L, float* Si) {
       Si[LT(a, b)] = sacc;
     }
 }
+// Inverse of an SPD 6 x 6 (packed lower) by 3 x 3 blocks: S = [A B^T; B D] (A: rows 0..2, D: rows 3..5, B = rows 3..5 x cols 0..2),
+//   A^-1 and the Schur complement's inverse C^-1 = (D - B A^-1 B^T)^-1 in closed form (cofactors, one reciprocal each),
+//   S^-1 = [A^-1 + E^T C^-1 E, -E^T C^-1; -C^-1 E, C^-1] with E = B A^-1.
+// Against the Cholesky route (six dependent rsqrt / row chains, then a triangular inverse) this is two short chains of independent products: what a wave
+// that is alone on its SIMD is short of is not arithmetic but dependent latency.
+LG_DEV void spd6_inverse_blocks(const float* S, float* Si) {
+  const float A[6] = {S[LT(0, 0)], S[LT(1, 0)], S[LT(2, 0)], S[LT(1, 1)], S[LT(2, 1)], S[LT(2, 2)]};      // 00 01 02 11 12 22
+  const float D[6] = {S[LT(3, 3)], S[LT(4, 3)], S[LT(5, 3)], S[LT(4, 4)], S[LT(5, 4)], S[LT(5, 5)]};
+  float B[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) B[i][j] = S[LT(3 + i, j)];
+  float Ai[6]; sym3_inverse(A, Ai);
+  float E[3][3];                      // E = B A^-1
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const float bi[3] = {B[i][0], B[i][1], B[i][2]}; sym3_mul(Ai, bi, E[i]); }
+  float C[6];                         // D - E B^T (symmetric)
+  C[0] = D[0] - (E[0][0] * B[0][0] + E[0][1] * B[0][1] + E[0][2] * B[0][2]);
+  C[1] = D[1] - (E[0][0] * B[1][0] + E[0][1] * B[1][1] + E[0][2] * B[1][2]);
+  C[2] = D[2] - (E[0][0] * B[2][0] + E[0][1] * B[2][1] + E[0][2] * B[2][2]);
+  C[3] = D[3] - (E[1][0] * B[1][0] + E[1][1] * B[1][1] + E[1][2] * B[1][2]);
+  C[4] = D[4] - (E[1][0] * B[2][0] + E[1][1] * B[2][1] + E[1][2] * B[2][2]);
+  C[5] = D[5] - (E[2][0] * B[2][0] + E[2][1] * B[2][1] + E[2][2] * B[2][2]);
+  float Ci[6]; sym3_inverse(C, Ci);
+  float G[3][3];                      // G = C^-1 E  (rows 3..5 x cols 0..2 of -S^-1)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { const float ej[3] = {E[0][j], E[1][j], E[2][j]}; float g[3]; sym3_mul(Ci, ej, g); G[0][j] = g[0]; G[1][j] = g[1]; G[2][j] = g[2]; }
+  // lower-right block
+  Si[LT(3, 3)] = Ci[0]; Si[LT(4, 3)] = Ci[1]; Si[LT(5, 3)] = Ci[2]; Si[LT(4, 4)] = Ci[3]; Si[LT(5, 4)] = Ci[4]; Si[LT(5, 5)] = Ci[5];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Si[LT(3 + i, j)] = -G[i][j];
+  // upper-left block: A^-1 + E^T G
+  const int ai[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) Si[LT(a, b)] = Ai[ai[a][b]] + E[0][a] * G[0][b] + E[1][a] * G[1][b] + E[2][a] * G[2][b];
+}
 LG_DEV void symv6(const float* Si, const float* x, float* y) {
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
@@ -1205,10 +1246,16 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     L[LT(5, 0)] += -ht.y; L[LT(5, 1)] += ht.x;
     L[LT(3, 3)] += It.xx; L[LT(4, 3)] += It.xy; L[LT(5, 3)] += It.xz;
     L[LT(4, 4)] += It.yy; L[LT(5, 4)] += It.yz; L[LT(5, 5)] += It.zz;
+#if LG_AB == 32
     chol6(L);
+#endif
   }
   float Si[21];
+#if LG_AB == 32
   spd6_inverse_from_chol(L, Si);
+#else
+  spd6_inverse_blocks(L, Si);        // (round 5; A/B build 32 = the Cholesky route)
+#endif
   if (share.n > 1) { if (TMESH) publish_mass_factors(xs, lane, Mi, Mbk, Y, Si); else publish_mass_factors_pk(xs, lane, Mi, Mbk, Y, Si); }
 
   STAMP(3);
