@@ -1246,15 +1246,17 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     L[LT(5, 0)] += -ht.y; L[LT(5, 1)] += ht.x;
     L[LT(3, 3)] += It.xx; L[LT(4, 3)] += It.xy; L[LT(5, 3)] += It.xz;
     L[LT(4, 4)] += It.yy; L[LT(5, 4)] += It.yz; L[LT(5, 5)] += It.zz;
-#if LG_AB == 32
+#if LG_AB != 32
     chol6(L);
 #endif
   }
   float Si[21];
-#if LG_AB == 32
-  spd6_inverse_from_chol(L, Si);
+#if LG_AB == 32      // measured and dropped (round 5, four same-session pairs): the inverse by 3 x 3 blocks -- two short chains instead of six dependent
+                     // rsqrt rows -- leaves the step where it was (0.0806 vs 0.0808 ms; 0.0752 vs 0.0752 on the plain instance): the main wave has slack in front
+                     // of rendezvous (A2), the helper waves arrive last
+  spd6_inverse_blocks(L, Si);
 #else
-  spd6_inverse_blocks(L, Si);        // (round 5; A/B build 32 = the Cholesky route)
+  spd6_inverse_from_chol(L, Si);
 #endif
   if (share.n > 1) { if (TMESH) publish_mass_factors(xs, lane, Mi, Mbk, Y, Si); else publish_mass_factors_pk(xs, lane, Mi, Mbk, Y, Si); }
 
