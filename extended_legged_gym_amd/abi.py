@@ -130,7 +130,7 @@ class lg_config(C.Structure):
         ("cfm", f32), ("solver_type", i32), ("friction_model", i32), ("self_collisions", i32),
         ("seed", C.c_uint64), ("rng_mode", i32),
         ("async_num_dof_sets", i32), ("async_dof_sets", (i32 * 3) * 4), ("async_dof_nominal", f32 * LG_MAX_DOF), ("async_dof_weight", f32 * LG_MAX_DOF),
-        ("async_weights", f32 * 3), ("async_foot_z_align", f32), ("inject_sim_state", i32),
+        ("async_weights", f32 * 3), ("async_foot_z_align", f32), ("keep_small_commands", i32), ("feet_air_time_ungated", i32), ("inject_sim_state", i32),
     ]
 
 
@@ -202,6 +202,8 @@ def declare_product(lib):
     lib.lg_step_subset_rows.restype = C.c_int
     lib.lg_step_rollout.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.lg_step_rollout.restype = C.c_int
+    lib.lg_set_extra_termination.argtypes = [vp, vp]
+    lib.lg_set_extra_termination.restype = C.c_int
     lib.lg_set_extra_obs.argtypes = [vp, vp]
     lib.lg_set_extra_obs.restype = C.c_int
     lib.lg_terrain_generate.argtypes = [C.POINTER(lg_tile_spec), i32, i32, i32, i32, i32, f32, f32, f32, f32, vp, vp, vp]
@@ -281,4 +283,4 @@ PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
                    "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_ray_lattice", "lg_mesh_last_error",
                    "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update",
-                   "lg_terrain_generate", "lg_heightfield_to_trimesh", "lg_pose_layer_step", "lg_set_reward_terms", "lg_set_async_gait", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed", "lg_gather_step_rows", "lg_step_subset_rows", "lg_step_rollout"]
+                   "lg_terrain_generate", "lg_heightfield_to_trimesh", "lg_pose_layer_step", "lg_set_reward_terms", "lg_set_async_gait", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed", "lg_gather_step_rows", "lg_step_subset_rows", "lg_step_rollout", "lg_set_extra_termination"]

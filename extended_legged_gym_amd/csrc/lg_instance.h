@@ -51,6 +51,7 @@
   X(int, lg_step_subset_rows, (lg_ctx * c, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, float* obs_out, float* rew_out, uint8_t* reset_out, uint8_t* time_out_out, void* stream), \
     (c, actions, env_ids, n, rollout_mode, obs_out, rew_out, reset_out, time_out_out, stream))                                                        \
   X(int, lg_set_extra_obs, (lg_ctx * c, const float* dptr), (c, dptr))                                                                                \
+  X(int, lg_set_extra_termination, (lg_ctx * c, const uint8_t* dptr), (c, dptr))                                                                     \
   X(int, lg_profile_begin, (lg_ctx * c, int32_t max_samples, int32_t stride), (c, max_samples, stride))                                               \
   X(int, lg_profile_end, (lg_ctx * c, float mean_ms[3], int32_t* nsamples), (c, mean_ms, nsamples))                                                   \
   X(int, lg_debug_read_stamps, (lg_ctx * c, unsigned long long out[64]), (c, out))
@@ -80,6 +81,7 @@
 #define lg_gather_step_rows LG_ENTRY(lg_gather_step_rows)
 #define lg_step_subset_rows LG_ENTRY(lg_step_subset_rows)
 #define lg_set_extra_obs LG_ENTRY(lg_set_extra_obs)
+#define lg_set_extra_termination LG_ENTRY(lg_set_extra_termination)
 #define lg_profile_begin LG_ENTRY(lg_profile_begin)
 #define lg_profile_end LG_ENTRY(lg_profile_end)
 #define lg_debug_read_stamps LG_ENTRY(lg_debug_read_stamps)

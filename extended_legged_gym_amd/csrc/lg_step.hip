@@ -80,6 +80,7 @@ struct DevCtx {
   const float LG_G* terrain_origins;
   const float LG_G *noise_vec, *height_points;
   const float LG_G* extra_obs;   // (N, cfg.num_extra_obs) caller-owned rows appended to the observation
+  const uint8_t LG_G* extra_term;   // (N) caller-owned flags ORed into the contact terminations (lg_set_extra_termination), or null
   const float4 LG_G* obs_tab;    // fused tail: per observation entry (source code, scale, offset, noise scale), packed on the host (pack_obs_table)
   float LG_G* partials;     // [nblocks][PART_STRIDE] : per-workgroup sums of episode_sums over reset envs, #reset, sum of levels, sum of finished lengths
   float LG_G* lvl_part;     // [nblocks] : per-workgroup sum of terrain levels
@@ -1309,7 +1310,7 @@ LG_DEV void resample_commands(const DevCtx* __restrict__ C, float* cmd, const fl
   float u2 = U[slot0 + 2];
   if (g.heading_command) cmd[3] = rand_float(R[6], R[7], u2);
   else cmd[2] = rand_float(R[4], R[5], u2);
-  float keep = sqrtf(c0 * c0 + c1 * c1) > 0.2f ? 1.f : 0.f;
+  float keep = (g.keep_small_commands || sqrtf(c0 * c0 + c1 * c1) > 0.2f) ? 1.f : 0.f;
   cmd[0] = c0 * keep; cmd[1] = c1 * keep;
 }
 
@@ -1493,7 +1494,7 @@ LG_DEV float reward_term(const DevCtx* __restrict__ C, const EnvView& V, int e, 
         s += (a - 0.5f) * first;
         air[f] = a * (cfl ? 0.f : 1.f); if (!stand) ctime[f] = ct * (cfl ? 1.f : 0.f);
       }
-      return s * (cmdn > 0.1f ? 1.f : 0.f);
+      return s * ((g.feet_air_time_ungated || cmdn > 0.1f) ? 1.f : 0.f);
     }
     case LG_REW_PENALTY_IN_THE_AIR: {   // anymal.py:301-308
       bool any = false;
@@ -1996,6 +1997,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
       for (int i = 0; i < m.num_termination; ++i) term |= L.s_fn[el][m.termination_contact_indices[i]] > 1.f;
       term |= g.terminate_on_flip && V.pg[2] > 0.f;   // anymal_c_batch_rollout.py:192-198 (stage 2.1 left the new vector in LDS)
       term |= L.s_flag[el] == 2;        // physics fault flagged by physics_kernel
+      if (!ro && C->extra_term) term |= C->extra_term[e] != 0;       // the env class's own reset rule (lg_set_extra_termination)
       bool tout = (float)eplen > g.max_episode_length;
       if (ro) {                       // rollout envs never terminate on their own: flags keep their last values
         tout = C->time_out[e] != 0; term = (L.s_flag[el] != 0) && !tout;
@@ -2705,7 +2707,7 @@ static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t*
 
 // fuse: the post-physics step runs as the tail of the physics kernel (full steps of all envs with helper waves; LG_FUSE=0 keeps
 // the two-launch path, which every split / subset / rollout entry point uses anyway)
-static bool can_fuse(const lg_ctx* c) { return LG_LEGS == 4 && c->fuse && (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) && c->h.P <= MAX_P; }
+static bool can_fuse(const lg_ctx* c) { return LG_LEGS == 4 && c->fuse && !c->h.extra_term && !c->h.cfg.keep_small_commands && !c->h.cfg.feet_air_time_ungated && (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) && c->h.P <= MAX_P; }
 // fuse: 0 = physics only (a post kernel follows), 1 = full policy step with the fused tail, 2 = fused ROLLOUT step of the listed envs
 static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = NDOF, int fuse = 0,
                            PostSink sink = PostSink{nullptr, nullptr, nullptr, nullptr, 0.f}) {
@@ -3007,6 +3009,13 @@ int lg_set_extra_obs(lg_ctx* c, const float* dptr) {
   if (!c) return LG_ERR_INVALID;
   if (c->h.cfg.num_extra_obs > 0 && !dptr) { c->err = "extra obs buffer is null"; return LG_ERR_INVALID; }
   c->h.extra_obs = (const float LG_G*)dptr;
+  HIP_TRY(c, hipMemcpy(c->d, &c->h, sizeof(DevCtx), hipMemcpyHostToDevice));
+  return LG_OK;
+}
+
+int lg_set_extra_termination(lg_ctx* c, const uint8_t* dptr) {
+  if (!c) return LG_ERR_INVALID;
+  c->h.extra_term = (const uint8_t LG_G*)dptr;
   HIP_TRY(c, hipMemcpy(c->d, &c->h, sizeof(DevCtx), hipMemcpyHostToDevice));
   return LG_OK;
 }

@@ -44,7 +44,7 @@ task_registry.register("stand_go2_flat", StandGo2, StandGo2FlatCfg(), StandGo2Fl
 task_registry.register("anymal_c_rough_student", AnymalStudent, AnymalCRoughStudentCfg(), AnymalCRoughStudentCfgPPO())
 task_registry.register("pose_anymal_c_flat", PoseAnymal, PoseAnymalCFlatCfg(), PoseAnymalCFlatCfgPPO())
 task_registry.register("pose_go2_flat", PoseGo2, PoseGo2FlatCfg(), PoseGo2FlatCfgPPO())
-from .elspider_air.elspider import ElSpider, LoadAdaptElSpider, PoseElSpider, StandElSpider  # noqa: E402
+from .elspider_air.elspider import ElSpider, FootTrackElSpider, LoadAdaptElSpider, PoseElSpider, StandElSpider  # noqa: E402
 from .elspider_air.mixed_terrains.elspider_air_rough_config import ElSpiderAirRoughCfg, ElSpiderAirRoughCfgPPO  # noqa: E402
 from .elspider_air.mixed_terrains.elspider_air_rough_train_config import ElSpiderAirRoughTrainCfg, ElSpiderAirRoughTrainCfgPPO  # noqa: E402
 from .elspider_air.flat.elspider_air_flat_config import ElSpiderAirFlatCfg, ElSpiderAirFlatCfgPPO  # noqa: E402
@@ -63,6 +63,10 @@ task_registry.register("elspider_air_dialmpc_flat", ElSpiderAirBatchRollout, ElS
 task_registry.register("elspider_air_dialmpc", ElSpiderAirBatchRollout, ElSpiderAirDialMPCCfg(), ElSpiderAirDialMPCCfgPPO())
 from .elspider_air.flat.pose_elspider_air_flat_config import PoseElSpiderAirFlatCfg, PoseElSpiderAirFlatCfgPPO  # noqa: E402
 task_registry.register("pose_elspider_air_flat", PoseElSpider, PoseElSpiderAirFlatCfg(), PoseElSpiderAirFlatCfgPPO())
+from .elspider_air.flat.foot_track_elspider_air_flat_config import FootTrackElSpiderAirFlatCfg, FootTrackElSpiderAirFlatCfgPPO  # noqa: E402
+from .elspider_air.flat.foot_track_elspider_air_hang_config import FootTrackElSpiderAirHangCfg, FootTrackElSpiderAirHangCfgPPO  # noqa: E402
+task_registry.register("foot_track_elspider_air_flat", FootTrackElSpider, FootTrackElSpiderAirFlatCfg(), FootTrackElSpiderAirFlatCfgPPO())
+task_registry.register("foot_track_elspider_air_hang", FootTrackElSpider, FootTrackElSpiderAirHangCfg(), FootTrackElSpiderAirHangCfgPPO())
 from .elspider_air.elspider_raycast import ElSpiderRayCast  # noqa: E402
 from .elspider_air.mixed_terrains.elspider_air_rough_raycast_config import ElSpiderAirRoughRaycastCfg, ElSpiderAirRoughRaycastCfgPPO  # noqa: E402
 task_registry.register("elspider_air_rough_raycast", ElSpiderRayCast, ElSpiderAirRoughRaycastCfg(), ElSpiderAirRoughRaycastCfgPPO())

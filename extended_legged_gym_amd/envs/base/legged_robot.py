@@ -117,7 +117,8 @@ class LeggedRobot(BaseTask):
                                  reset_z_from_terrain=self._reset_z_from_terrain,
                                  custom_origins=self._custom_origins_rule(), terminate_on_flip=self._terminate_on_flip,
                                  reward_term_variants=self.reward_term_variants, reward_class=self.reward_class,
-                                 noise_layout_dof=self._noise_layout_dof)
+                                 noise_layout_dof=self._noise_layout_dof,
+                                 keep_small_commands=self._keep_small_commands, feet_air_time_ungated=self._feet_air_time_ungated)
         self.core = NativeCore(self.setup, self.device)
         t = self.core.t
 
@@ -151,6 +152,8 @@ class LeggedRobot(BaseTask):
     reward_term_variants = {}        # cfg.rewards.scales name -> native term for classes that override a `_reward_*`
     _terminate_on_flip = False       # AnymalCBatchRollout: an upside-down robot ends the episode
     _noise_layout_dof = None         # ElSpiderRayCast: the base class's twelve-joint noise-vector layout on an 18-joint robot
+    _keep_small_commands = False     # FootTrackElSpider: resampled xy commands under 0.2 m/s are not zeroed
+    _feet_air_time_ungated = False   # FootTrackElSpider: `feet_air_time` pays at standstill commands too
     _reset_z_from_terrain = False    # RobotBatchRollout: root z from the height sample under the reset position
 
     def _gait_config(self):

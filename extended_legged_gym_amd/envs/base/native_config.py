@@ -193,7 +193,8 @@ class NativeSetup:
 
     def __init__(self, cfg, sim_params, model, terrain=None, seed=0, rng_mode=abi.LG_RNG_PHILOX, gait=None,
                  reward_stage=None, num_extra_obs=0, reset_z_from_terrain=False,
-                 custom_origins=None, terminate_on_flip=False, reward_term_variants=None, reward_class="base", noise_layout_dof=None):
+                 custom_origins=None, terminate_on_flip=False, reward_term_variants=None, reward_class="base", noise_layout_dof=None,
+                 keep_small_commands=False, feet_air_time_ungated=False):
         self.model_dict = model
         if not getattr(cfg.asset, "replace_cylinder_with_capsule", True) and "cp_slide" in model:
             # (legged_robot_config.py:171; every task of the reference leaves it True.)  Without the option the cylinders stay cylinders in PhysX;
@@ -323,6 +324,8 @@ class NativeSetup:
         c.max_terrain_level = cfg.terrain.num_rows
         c.reset_z_from_terrain = int(bool(reset_z_from_terrain))
         c.terminate_on_flip = int(bool(terminate_on_flip))
+        c.keep_small_commands = int(bool(keep_small_commands))          # FootTrackElSpider._resample_commands (elspider.py:614-633)
+        c.feet_air_time_ungated = int(bool(feet_air_time_ungated))      # FootTrackElSpider._reward_feet_air_time (:635-646)
         init = cfg.init_state
         _fill(c.base_init_state, list(init.pos) + list(init.rot) + list(init.lin_vel) + list(init.ang_vel))
 

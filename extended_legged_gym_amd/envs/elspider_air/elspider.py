@@ -99,3 +99,167 @@ class StandElSpider(ElSpider):
         super()._init_buffers()
         self.feet_air_time = self.feet_air_time[:, 1:4:2]        # (N, 2) strided views of the arena tensors
         self.last_contacts = self.last_contacts[:, 1:4:2]
+
+
+RAIBERT_TERMS = ("raibert_base_pos_track", "raibert_base_quat_track", "raibert_foot_pos_track", "raibert_foot_pos_track_z", "raibert_foot_swing_contact")
+
+
+class foot_track_native_cfg:
+    """Context: `cfg` as the native step under `FootTrackElSpider` sees it -- the 66-entry observation row without noise, the reward sum without the
+    five planner terms and without the positivity clip -- restored on exit (the same device as `pose_native_cfg`)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def __enter__(self):
+        c, sc = self.cfg, self.cfg.rewards.scales
+        self.saved = (c.env.num_observations, c.noise.add_noise, c.rewards.only_positive_rewards, {n: getattr(sc, n, 0.) for n in RAIBERT_TERMS})
+        c.env.num_observations -= 28
+        c.noise.add_noise, c.rewards.only_positive_rewards = False, False
+        for n in RAIBERT_TERMS:
+            setattr(sc, n, 0.)
+        return c
+
+    def __exit__(self, *exc):
+        c, sc = self.cfg, self.cfg.rewards.scales
+        c.env.num_observations, c.noise.add_noise, c.rewards.only_positive_rewards, terms = self.saved
+        for n, v in terms.items():
+            setattr(sc, n, v)
+        return False
+
+
+class FootTrackElSpider(ElSpider):
+    """Task `foot_track_elspider_air_flat` (reference `elspider.py:547-676`, `envs/__init__.py:159-160`): the hexapod asked to follow a Raibert-style
+    planner -- a reference base pose that integrates the velocity command, six footholds swinging in two tripods (`utils/raibert_planner.py`).
+
+    The native step runs everything `ElSpider` runs; this class adds, as device-side torch between and behind the two halves of the split step
+    (`lg_step_physics` ... `lg_post_physics_step`):
+      * `check_termination` (`:583-588`): an env whose base strays more than 0.5 m from the planner's base position ends its episode -- a per-env flag
+        bound with `lg_set_extra_termination`, evaluated after the physics and OR-ed by the kernel into the contact terminations, so resets, time-out
+        flags and the episode statistics see it as the reference's `reset_buf |=` does;
+      * five reward terms on the planner's state (`:660-674`), added to the native sum BEFORE the positivity clip (the native step runs unclipped);
+      * the 94-entry observation (`:561-581`): the planner's 31 entries where the base class has its three commands; the noise vector is `ElSpider`'s,
+        laid out for the 66-entry row (`:309-332`) and applied to this one as it is -- joint-angle noise lands on planner entries -- as in the reference;
+      * `_resample_commands` without the small-command cut and `_reward_feet_air_time` without the command gate (`:614-646`): `lg_config.keep_small_commands`,
+        `lg_config.feet_air_time_ungated`;
+      * the planner is re-anchored at the reset envs' new pose (`:590-592`) and stepped once per policy step with the commands (`:594-597`).
+    `cfg.rewards.raibert_planner.planner_type`: 0 `SimpleRaibertPlanner`, 1 `RaibertPlanner` (`:549-561`); the registered `foot_track_elspider_air_hang`
+    (88 observations configured, 94 built, noise on) stops on its first step in the reference with a shape error and is refused here with the same."""
+    _keep_small_commands = True
+    _feet_air_time_ungated = True
+
+    def __init__(self, cfg, sim_params, physics_engine, sim_device, headless):
+        from extended_legged_gym_amd.envs.base.native_config import noise_scale_vec
+        from extended_legged_gym_amd.utils.raibert_planner import RaibertPlanner, RaibertPlannerConfig
+        if not hasattr(cfg.rewards, "raibert_planner"):      # raised by the reference after the simulator is up (`:551`); here before anything is built
+            raise AttributeError("type object 'rewards' has no attribute 'raibert_planner'")
+        planner_type = cfg.rewards.raibert_planner.planner_type
+        if planner_type not in (0, 1):
+            raise ValueError("Invalid planner type")
+        built = 94 + (187 if cfg.terrain.measure_heights else 0)
+        if cfg.env.num_observations != built:
+            # `compute_observations` (`:561-581`) rebinds `obs_buf` to its own 94-wide row whatever the config says; the noise vector keeps the
+            # configured width (`:309-332`), so the reference stops on the first step of such a task (`foot_track_elspider_air_hang`: 88)
+            if cfg.noise.add_noise:
+                raise RuntimeError(f"The size of tensor a ({built}) must match the size of tensor b ({cfg.env.num_observations}) at non-singleton dimension 1 "
+                                   "[FootTrackElSpider.compute_observations adds the noise vector of env.num_observations entries to its own "
+                                   f"{built}-entry row: the reference raises this on the first step; set env.num_observations = {built}]")
+            raise ValueError(f"FootTrackElSpider builds {built} observations, env.num_observations = {cfg.env.num_observations}")
+        if getattr(cfg.asset, "fix_base_link", False):
+            raise NotImplementedError("asset.fix_base_link: the native step has no fixed-base robot")
+        full = (cfg.env.num_observations, cfg.noise.add_noise, cfg.rewards.only_positive_rewards)
+        with foot_track_native_cfg(cfg):
+            super().__init__(cfg, sim_params, physics_engine, sim_device, headless)
+        self.num_obs, self.add_noise, self._only_positive = full
+        self.noise_scale_vec = torch.from_numpy(noise_scale_vec(cfg, self.num_obs, self.num_dof)).to(self.device)
+        self._native_obs, self._native_rew = self.obs_buf, self.rew_buf
+        self.obs_buf = torch.zeros(self.num_envs, self.num_obs, device=self.device)
+        self.rew_buf = torch.zeros(self.num_envs, device=self.device)
+        self._stray = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+        self.core.set_extra_termination(self._stray)
+        self.raibert_pos_diff = torch.zeros(self.num_envs, device=self.device)
+        pc = RaibertPlannerConfig()
+        pc.dt = self.dt
+        self.raibert_planner = RaibertPlanner(self.num_envs, self.device, pc, simple=(planner_type == 0))
+        self.raibert_planner.init(self.base_pos, self.base_quat)
+        self._layer_sums = torch.zeros(len(RAIBERT_TERMS), self.num_envs, device=self.device)
+        self._layer_extras = torch.zeros(len(RAIBERT_TERMS), device=self.device)
+        self._bind_layer_terms()
+
+    def _bind_layer_terms(self):
+        stage = self._get_reward_scales(self.reward_scales_stage)
+        self._layer_scales = [float(stage.get(n, 0.)) * self.dt for n in RAIBERT_TERMS]
+        self._termination_scale = float(stage.get("termination", 0.)) * self.dt
+        for k, n in enumerate(RAIBERT_TERMS):
+            if self._layer_scales[k] != 0.:
+                self.reward_scales[n] = self._layer_scales[k]
+                self.episode_sums[n] = self._layer_sums[k]
+                self.extras["episode"]["rew_" + n] = self._layer_extras[k]
+
+    def _layer_terms(self):
+        """The five `_reward_raibert_*` (`:660-674`) on the state the reference's `compute_reward` sees: the pose before any reset."""
+        rb, p = self.core.t["rigid_body_state"], self.raibert_planner
+        feet = rb[:, self.feet_indices, 0:3]
+        return (p.penalty_base_pos_track(rb[:, 0, 0:3]), p.penalty_base_quat_track(rb[:, 0, 3:7]), p.reward_foot_pos_track(feet),
+                p.penalty_foot_pos_track_z(feet), p.penalty_foot_swing_contact(self.contact_forces, self.feet_indices))
+
+    def _after_native(self):
+        rew = self._native_rew.clone()
+        term = self._termination_scale * (self.reset_buf & ~self.time_out_buf).float() if self._termination_scale != 0. else None
+        if term is not None:          # (`compute_reward`, `legged_robot.py:215-232`: the termination term joins after the clip)
+            rew -= term
+        for k, value in enumerate(self._layer_terms()):      # evaluated in the reference's (alphabetical) order; the fifth keeps state
+            if self._layer_scales[k] != 0.:
+                r = value * self._layer_scales[k]
+                rew += r
+                self._layer_sums[k] += r
+        if self._only_positive:
+            rew = torch.clip(rew, min=0.)
+        self.rew_buf[:] = rew if term is None else rew + term
+        env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+        if len(env_ids):
+            for k in range(len(RAIBERT_TERMS)):
+                if self._layer_scales[k] != 0.:
+                    self._layer_extras[k] = torch.mean(self._layer_sums[k, env_ids]) / self.max_episode_length_s
+            self._layer_sums[:, env_ids] = 0.
+            self.raibert_planner.reset_idx(self.base_pos, self.base_quat, env_ids)
+        self.compute_observations()
+        self.raibert_planner.step(self.commands[:, :3])
+
+    def compute_observations(self):
+        nat = self._native_obs
+        self.obs_buf[:] = torch.cat((nat[:, 0:9], self.raibert_planner.get_obs_tensor(self.base_pos, self.base_quat), nat[:, 12:]), dim=-1)
+        if self.add_noise:
+            self.obs_buf += (2 * torch.rand_like(self.obs_buf) - 1) * self.noise_scale_vec
+        clip = self.cfg.normalization.clip_observations
+        torch.clip(self.obs_buf, -clip, clip, out=self.obs_buf)
+
+    def check_termination(self):
+        """The planner's part of `check_termination` (`:583-588`), on the pose the physics just produced."""
+        self.raibert_pos_diff = torch.norm(self.base_pos - self.raibert_planner.base_pos, dim=1)
+        self._stray.copy_(self.raibert_pos_diff > 0.5)
+
+    def step(self, actions):
+        self.core.compute_torques_and_simulate(actions.to(self.device))
+        self.post_physics_step()
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def post_physics_step(self):
+        self.check_termination()
+        super().post_physics_step()
+        self._after_native()
+
+    def reset_idx(self, env_ids):
+        if len(env_ids) == 0:
+            return
+        super().reset_idx(env_ids)
+        self._layer_sums[:, env_ids] = 0.
+        self.raibert_planner.reset_idx(self.base_pos, self.base_quat, env_ids)
+
+    def update_reward_scales(self, mean_reward):
+        with foot_track_native_cfg(self.cfg):
+            changed = super().update_reward_scales(mean_reward)
+        if changed:
+            self._layer_sums.zero_()
+            self._bind_layer_terms()
+        return changed

@@ -104,6 +104,12 @@ class NativeCore:
         self._extra_obs = rows
         self._check(self.lib.lg_set_extra_obs(self.ctx, C.c_void_p(rows.data_ptr())))
 
+    def set_extra_termination(self, flags):
+        """Bind the (N,) uint8 device tensor of per-env flags that the next post-physics steps OR into their contact terminations (None: unbind)."""
+        assert flags is None or (flags.is_contiguous() and flags.dtype == torch.uint8)
+        self._extra_term = flags
+        self._check(self.lib.lg_set_extra_termination(self.ctx, C.c_void_p(flags.data_ptr() if flags is not None else 0)))
+
     def compute_torques_and_simulate(self, actions):
         """The physics half of `lg_step` (clip actions, `decimation` x (actuators + one dt)), without post-physics."""
         a = self._f32(actions)

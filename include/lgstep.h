@@ -294,6 +294,8 @@ typedef struct lg_config {
   int32_t async_num_dof_sets, async_dof_sets[4][3];
   float async_dof_nominal[LG_MAX_DOF], async_dof_weight[LG_MAX_DOF];
   float async_weights[3], async_foot_z_align;
+  int32_t keep_small_commands;        /* 1 = FootTrackElSpider._resample_commands (elspider.py:620-637): drawn xy commands with norm <= 0.2 are NOT zeroed */
+  int32_t feet_air_time_ungated;      /* 1 = FootTrackElSpider._reward_feet_air_time (elspider.py:639-650): no "zero command, zero reward" factor */
   int32_t inject_sim_state;           /* parity tests only (like LG_RNG_INJECT): lg_step's post-physics half takes the post-simulation state
                                        * from what the caller put into LG_T_ROOT_STATES / DOF_STATE / TORQUES / CONTACT_FORCES / RIGID_BODY_STATE
                                        * before the call -- the way the recording harness injected it under the reference's step() -- and
@@ -426,6 +428,11 @@ int lg_gather_step_rows(lg_ctx* ctx, const int32_t* env_ids, int32_t n, float* o
  * the tail of that launch (no second kernel).  All four outputs required. */
 int lg_step_subset_rows(lg_ctx* ctx, const float* actions, const int32_t* env_ids, int32_t n, int32_t rollout_mode, float* obs_out, float* rew_out,
                         uint8_t* reset_out, uint8_t* time_out_out, void* stream);
+
+/* Bind a (N) u8 device buffer of per-env flags that check_termination ORs into the contact terminations of the next post-physics steps (an env class's
+ * own reset rule on top of LeggedRobot.check_termination: FootTrackElSpider, elspider.py:598-603, resets when the base strays from its planner); NULL
+ * unbinds.  The caller fills it between lg_step_physics and lg_post_physics_step. */
+int lg_set_extra_termination(lg_ctx* ctx, const uint8_t* dptr);
 
 /* Bind the (N, num_extra_obs) f32 device buffer whose rows are appended to the observation (legged_robot_raycast.py:252-254). */
 int lg_set_extra_obs(lg_ctx* ctx, const float* dptr);

@@ -43,6 +43,7 @@ def lib():
         L.lgo_max_threads.restype = C.c_int
         L.lgo_debug_terrain.argtypes = [vp, C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.lgo_set_extra_obs.argtypes = [vp, vp]
+        L.lgo_set_extra_termination.argtypes = [vp, vp]
         L.lgo_step_subset.argtypes = [vp, vp, vp, C.c_int32, C.c_int32]
         L.lgo_step_subset_physics.argtypes = [vp, vp, vp, C.c_int32]
         L.lgo_post_physics_subset.argtypes = [vp, vp, C.c_int32, C.c_int32]
@@ -116,6 +117,11 @@ class OracleEnv:
     def set_async_gait(self, weights, foot_z_align):
         w = np.ascontiguousarray(weights, dtype=np.float32)
         assert self.L.lgo_set_async_gait(self.ctx, w.ctypes.data_as(C.c_void_p), float(foot_z_align)) == 0
+
+    def set_extra_termination(self, flags):
+        """(N,) uint8 array ORed into the contact terminations of the next post-physics steps (None: none); the array must stay alive."""
+        self._extra_term = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint8)
+        self.L.lgo_set_extra_termination(self.ctx, self._extra_term.ctypes.data_as(C.c_void_p) if flags is not None else None)
 
     def reset_idx(self, env_ids, update_curriculum=0):
         ids = np.ascontiguousarray(env_ids, dtype=np.int32)
