@@ -81,6 +81,11 @@ LG_DEV bool descend4(int cand[4], float key[4], int* stack_i, float* stack_k, in
   return true;
 }
 
+// A ray that runs within rounding of an edge two triangles share must hit one of them: the barycentric tests accept a band of RAY_EDGE_EPS (the rounding of
+// u, v for origins metres away from a decimetre triangle is ~2e-6; strict tests let 9 % of the vertical rays that start exactly on a lattice line of a
+// heightfield mesh fall through the crack).  The plane of either neighbour gives the same t to rounding.  The oracle's brute-force scan uses the same band.
+#define RAY_EDGE_EPS 1e-5f
+
 // closest two-sided hit with 0 <= t <= max_dist (Moller-Trumbore); returns t or -1
 LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
   const V3 inv = v3(1.f / (fabsf(d.x) > 1e-12f ? d.x : copysignf(1e-12f, d.x)), 1.f / (fabsf(d.y) > 1e-12f ? d.y : copysignf(1e-12f, d.y)),
@@ -124,10 +129,10 @@ LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
         float idet = 1.f / det;
         V3 s = o - v0;
         float u = dot(s, p) * idet;
-        if (u < 0.f || u > 1.f) continue;
+        if (u < -RAY_EDGE_EPS || u > 1.f + RAY_EDGE_EPS) continue;
         V3 q = cross(s, e1);
         float v = dot(d, q) * idet;
-        if (v < 0.f || u + v > 1.f) continue;
+        if (v < -RAY_EDGE_EPS || u + v > 1.f + RAY_EDGE_EPS) continue;
         float t = dot(e2, q) * idet;
         if (t >= 0.f && t <= best) { best = t; hit = true; }
       }
@@ -220,10 +225,10 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const float* tb, V3 o, V3 d, float
         float idet = 1.f / det;
         V3 s = o - v0;
         float u = dot(s, p) * idet;
-        if (u < 0.f || u > 1.f) continue;
+        if (u < -RAY_EDGE_EPS || u > 1.f + RAY_EDGE_EPS) continue;
         V3 q = cross(s, e1);
         float v = dot(d, q) * idet;
-        if (v < 0.f || u + v > 1.f) continue;
+        if (v < -RAY_EDGE_EPS || u + v > 1.f + RAY_EDGE_EPS) continue;
         float t = dot(e2, q) * idet;
         if (t >= 0.f && t <= best) { best = t; hit = true; }
       }

@@ -119,12 +119,19 @@ def test_ray_lattice_returns_the_hits_of_the_tree(monkeypatch):
     # (whether a ray that runs exactly down the mesh's outer edge hits is decided by the last bit of the edge tests; what is held is that the two
     #  structures decide alike)
     assert int(((fg != fb) | ((hg - hb).abs().max(dim=1).values > 1e-5)).sum()) <= 3
-    # the same rays one cell inside the border: lattice lines in the interior, where every ray hits
-    ob[: m // 2, 0] = xs[-2]; ob[m // 2:, 1] = ys[-2]; ob[:50, 1] = ys[-2]
+    # the same rays on lattice lines in the middle of the mesh, where cells on both sides carry triangles: (nearly) every ray hits, in both structures, where
+    # the brute-force scan of the oracle hits.  (A ray with no motion along an axis that starts exactly on a lattice line / a box face belongs to the cell /
+    # box on its + side in both structures; the barycentric band RAY_EDGE_EPS lets it hit the triangle whose edge it runs down.)
+    ob[: m // 2, 0] = xs[len(xs) // 2]; ob[m // 2:, 1] = ys[len(ys) // 2]; ob[:50, 1] = ys[len(ys) // 2]
     to = torch.from_numpy(ob).cuda()
     hg, fg = raycast_mesh(to, td, 10.0, lattice)
     hb, fb = raycast_mesh(to, td, 10.0, tree)
     assert float(fb.float().mean()) > 0.95 and int(((fg != fb) | ((hg - hb).abs().max(dim=1).values > 1e-5)).sum()) <= 3
+    h_ref, f_ref = raycast_bruteforce(v, t, ob, db, 10.0)
+    f = fb.cpu().numpy()
+    assert (f != f_ref).mean() < 0.02
+    both = f & f_ref
+    assert np.abs(hb.cpu().numpy()[both] - h_ref[both]).max() < 2e-4
 
 
 def test_raycaster_sensor_matches_reference_arithmetic():
