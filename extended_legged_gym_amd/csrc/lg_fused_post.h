@@ -563,7 +563,8 @@ LG_DEV void fused_env_serial(const DevCtx* __restrict__ C, const float* hot_lds,
 // ---- all four waves: write-back of the env rows + observation rows, 4 envs per wave; statistics + arrival by wave 0
 // Returns true on the LAST workgroup of the launch to arrive (it then runs finalize_from_acc).
 LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out, bool obs_by_row,
-                                const int32_t* __restrict__ ids, bool ro) {
+                                const int32_t* __restrict__ ids, bool ro, bool arrive) {
+  // arrive: false in all but the last step of a persistent rollout launch (no arrival ticket: workgroups do not wait for each other between steps)
   STAMP_DECL
   const int wv = tid >> 6, ln = tid & 63;
   const int e0 = blk * EPB, nenv = max(0, min(EPB, n - e0));
@@ -671,7 +672,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   const unsigned shard = (unsigned)blk & 7u, nsh = min(8u, gridDim.x);
   const unsigned want = (gridDim.x + 7u - shard) >> 3;
   if (wv == FUSED_STATS_WAVE) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the statistics stores / atomics of this wave have completed
-  if (tid == 64 * FUSED_STATS_WAVE) arrival = __hip_atomic_fetch_add(w_tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 64 * FUSED_STATS_WAVE && arrive) arrival = __hip_atomic_fetch_add(w_tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   STAMP(33);
 
   // observation rows (LR:234-252, :107-108): proprio | heights | extra, + uniform noise, clipped.  A lane forms the 4 entries of
@@ -790,7 +791,7 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   }
   STAMP(34);
   bool last = false;
-  if (tid == 64 * FUSED_STATS_WAVE && arrival == want - 1u) {
+  if (tid == 64 * FUSED_STATS_WAVE && arrive && arrival == want - 1u) {
     if (__hip_atomic_fetch_add(w_tickets + 32 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1u) {
       last = true;
       for (int i = 0; i < 9; ++i) __hip_atomic_store(w_tickets + 32 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

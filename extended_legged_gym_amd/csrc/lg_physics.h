@@ -387,7 +387,10 @@ struct PhysParams {
 
 #define LG_MESH_CONTACT_MARGIN 0.1f      // triangle-mesh contacts: how far below a surface a sphere's centre may have sunk and still be pushed out
 #define LG_MESH_CACHE_REACH 0.15f
-struct SelfCol { const unsigned* pairs; int n; };      // self-collision candidates (packed leg a | slot a << 8 | leg b << 16 | slot b << 24), see the pass below
+// self-collision candidates: pairs[i] = leg a | slot a << 8 | leg b << 16 | slot b << 24 (global memory; read for the rare pairs that pass the filter);
+// tab[i] = {slot-record offsets of the two spheres, radius a, radius b, filter threshold} (sc_prefilter; the workgroup's LDS copy where there is room for
+// one); mask: LDS words [3][64] through which the helper waves hand their share of the filter to the main wave (null: this wave filters every pair).
+struct SelfCol { const unsigned* pairs; int n; const uint4* tab; unsigned* mask; };
 
 struct QuadState {           // per lane: replicated base + own leg (the name is from the four-legged instance)
   float root[13];            // pos3, quat xyzw, lin vel3, ang vel3 (world)
@@ -1153,6 +1156,40 @@ LG_DEV void contact_setup_slot_pk(int sl, const LegModel& lm_, const LegKin& k, 
 // sides of such a row act on the same point, so its base part cancels: the row has joint entries only, like a joint-limit row -- z = Mkk^-1 f per leg,
 // base response S^-1 (-sum Mbk z), joint response z - Y W_b -- and is relaxed behind the terrain contacts of every pass.
 struct SelfRow { bool on; float phi, iA, lam; V3 n; float f[3], Wb[6], Wk[3]; int slot_a, slot_b; /* fbody index of each side on THIS lane, -1: not mine */ };
+// The filter of the self-collision pass: bit k of the result = "pair lgi + GRP k of this lane's share may be closer than contact_offset".  A lane's pairs
+// are the indices lgi, lgi + GRP, ...; of their ordinals k this call takes share, share + nshare, ... (the four waves of a workgroup a quarter each, between
+// rendezvous (A2) and (A3)).  Per pair: the two spheres' records (2 x 2 ds_read_b128; centre - base = r + radius n, the base cancels in the difference) and a
+// squared distance against the entry's threshold (radius a + radius b + contact_offset)^2 (1 + 1e-4) -- no root, conservative; three pairs per round, loads
+// batched.  Robots walk with their links decimetres apart: the mask is zero nearly always, and the exact pass behind it then does not run.
+LG_DEV unsigned sc_prefilter(const float* cst, const uint4* tab, int n, int lane, int share, int nshare) {
+#if LG_AB == 41      // (timing probe: no filter work at all; the rows' code stays)
+  return 0u;
+#endif
+  const int gb = lane & ~(GRP - 1), lgi = lane & (GRP - 1);
+  const float4* rec = reinterpret_cast<const float4*>(cst);
+  const unsigned gb4 = (unsigned)gb * (CF_FIELDS / 4);
+  unsigned mask = 0u;
+  for (int k = share; k * GRP < n; k += 3 * nshare) {
+    uint4 en[3]; float4 na[3], pa[3], nb[3], pq[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { const int i = lgi + GRP * (k + u * nshare); en[u] = tab[i < n ? i : 0]; }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const unsigned oa = gb4 + (en[u].x & 0xFFFFu) * (CF_FIELDS / 4), ob = gb4 + (en[u].x >> 16) * (CF_FIELDS / 4);
+      na[u] = rec[oa]; pa[u] = rec[oa + 1]; nb[u] = rec[ob]; pq[u] = rec[ob + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int kk = k + u * nshare;
+      const float ra = __uint_as_float(en[u].y), rb = __uint_as_float(en[u].z);
+      const float dx = (pa[u].x - pq[u].x) + (ra * na[u].x - rb * nb[u].x), dy = (pa[u].y - pq[u].y) + (ra * na[u].y - rb * nb[u].y),
+                  dz = (pa[u].z - pq[u].z) + (ra * na[u].z - rb * nb[u].z);
+      const bool near = lgi + GRP * kk < n && dx * dx + dy * dy + dz * dz < __uint_as_float(en[u].w);
+      mask |= near ? 1u << kk : 0u;
+    }
+  }
+  return mask;
+}
 LG_DEV V3 sc_sphere(const float* cst, const LegModel& lm_, int gb, int leg, int slot, V3 pb, float* rad) {
   const float4 n4 = reinterpret_cast<const float4*>(cst + ((slot) * 64 + gb + leg) * CF_FIELDS)[0];
   const float4 r4 = reinterpret_cast<const float4*>(cst + ((slot) * 64 + gb + leg) * CF_FIELDS)[1];
@@ -1176,7 +1213,7 @@ template <bool TMESH, int MAIN_DETECT, bool ALLOW_INLINE, int SPEC = 0, int FEAT
 LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel& lm_, const TerrainView& T, const PhysParams& P,
                             int lane, float* cst, QuadState& s, TauFn tau_fn, PrepFn prep_fn, ShareFn share_fn, SlotShare share,
                             float* xs, float mu_robot, float madd, V3* fbody, unsigned long long* stamps = nullptr,
-                            float* cq = nullptr, SelfCol scol = SelfCol{nullptr, 0}) {
+                            float* cq = nullptr, SelfCol scol = SelfCol{nullptr, 0, nullptr, nullptr}) {
   STAMP_DECL
   const float dt = P.dt;
   const V3 pb = v3(s.root[0], s.root[1], s.root[2]);
@@ -1387,18 +1424,37 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     }
   }
 
-  // ---------------------------------------------------------------- self-collision rows (FEAT bit 1)
+  // ---------------------------------------------------------------- self-collision, part 1 (FEAT bit 1): this wave's share of the pair filter
+  unsigned scm = 0u;
+  if (FEAT & 2) scm = sc_prefilter(cst, scol.tab, scol.n, lane, 0, scol.mask ? 4 : 1);
+
+  // ---------------------------------------------------------------- contact / limit rows: TGS sub-intervals or PGS sweeps
+  int my_count; const unsigned my_list = active_slot_list(cst, lane, &my_count);
+  int my_steps = 0;                                   // wave-uniform: the longest list
+#pragma unroll
+  for (int j = 0; j < LG_MAX_CP; ++j) my_steps += __ballot(my_count > j) != 0ull ? 1 : 0;
+  // With helper waves this wave is the last to be dealt a slot of the set-up (share.late): the unconstrained velocity, the
+  // joint-limit rows and the slot lists above need nothing from the slot records, so they ran while the other waves set
+  // their slots up; the rendezvous that closes the set-up comes only now.
+  if (share.late) share_fn();
+  // ---------------------------------------------------------------- self-collision, part 2: the rows (behind (A3): the helper waves' shares of the filter are in)
   SelfRow sc[2];
   bool sc_wave = false;
   if (FEAT & 2) {
     const int gb = lane & ~(GRP - 1), lgi = lane & (GRP - 1);
     const int BIG = 0x7fffffff;
-    float p0 = P.contact_offset, p1 = P.contact_offset; int i0 = BIG, i1 = BIG;     // this lane's two deepest of its share of the pairs
-    for (int i = lgi; i < scol.n; i += GRP) {
-      const unsigned pk = scol.pairs[i];
+    if (scol.mask) scm |= scol.mask[lane] | scol.mask[64 + lane] | scol.mask[128 + lane];
+    float p0 = P.contact_offset, p1 = P.contact_offset; int i0 = BIG, i1 = BIG;     // this lane's two deepest of the pairs the filter let through
+    // (every lane walks its own set bits, lowest first: as many rounds as the busiest lane has candidates -- one or two --, not one per ordinal flagged
+    //  anywhere in the wave; everything from the LDS table: a global load per round was most of this pass under flailing random actions)
+    for (unsigned rest = scm; __ballot(rest != 0u) != 0ull; rest &= rest - 1u) {
+      const bool mine = rest != 0u;
+      const int kk = mine ? __ffs((int)rest) - 1 : 0, i = lgi + GRP * kk;
+      const uint4 en = scol.tab[mine ? i : 0];
+      const unsigned ia = en.x & 0xFFFFu, ib = en.x >> 16;                          // record index = slot * 64 + leg
       float ra, rb;
-      const V3 ca = sc_sphere(cst, lm_, gb, pk & 255u, (pk >> 8) & 255u, pb, &ra), cb = sc_sphere(cst, lm_, gb, (pk >> 16) & 255u, pk >> 24, pb, &rb);
-      const float ph = norm(ca - cb) - ra - rb;
+      const V3 ca = sc_sphere(cst, lm_, gb, ia & 63u, ia >> 6, pb, &ra), cb = sc_sphere(cst, lm_, gb, ib & 63u, ib >> 6, pb, &rb);
+      const float ph = mine ? norm(ca - cb) - ra - rb : P.contact_offset;
       if (ph < p0) { p1 = p0; i1 = i0; p0 = ph; i0 = i; } else if (ph < p1) { p1 = ph; i1 = i; }
     }
     // the group's two deepest, lowest index first among equals (the order the oracle meets them in)
@@ -1417,8 +1473,8 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
       for (int a = 0; a < 6; ++a) R.Wb[a] = 0.f;
       if (__ballot(win[q2] != BIG) == 0ull) continue;                               // (wave-uniform)
       const bool on = win[q2] != BIG;
-      const unsigned pk = scol.pairs[on ? win[q2] : 0];
-      const int la = pk & 255u, sa = (pk >> 8) & 255u, lb = (pk >> 16) & 255u, sb = pk >> 24;
+      const unsigned ix = scol.tab[on ? win[q2] : 0].x;
+      const int la = ix & 63u, sa = (ix & 0xFFFFu) >> 6, lb = (ix >> 16) & 63u, sb = ix >> 22;
       float ra, rb;
       const V3 ca = sc_sphere(cst, lm_, gb, la, sa, pb, &ra), cb = sc_sphere(cst, lm_, gb, lb, sb, pb, &rb);
       const V3 d = ca - cb; const float dist = norm(d);
@@ -1455,15 +1511,6 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     }
   }
 
-  // ---------------------------------------------------------------- contact / limit rows: TGS sub-intervals or PGS sweeps
-  int my_count; const unsigned my_list = active_slot_list(cst, lane, &my_count);
-  int my_steps = 0;                                   // wave-uniform: the longest list
-#pragma unroll
-  for (int j = 0; j < LG_MAX_CP; ++j) my_steps += __ballot(my_count > j) != 0ull ? 1 : 0;
-  // With helper waves this wave is the last to be dealt a slot of the set-up (share.late): the unconstrained velocity, the
-  // joint-limit rows and the slot lists above need nothing from the slot records, so they ran while the other waves set
-  // their slots up; the rendezvous that closes the set-up comes only now.
-  if (share.late) share_fn();
   // the step's generalised displacement: dq = sum over the sub-intervals of h * v (TGS), dt * v of the last sweep (PGS)
   pk2 dqB[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}; pk2 dqK01 = {0.f, 0.f}; float dqK2 = 0.f;
   const bool tgs = SPEC == 1 ? true : P.solver == LG_SOLVER_TGS;

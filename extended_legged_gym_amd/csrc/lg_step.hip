@@ -98,6 +98,7 @@ struct DevCtx {
   float lmod[LM_FIELDS * GRP];  // per-leg model table, packed on the host (pack_leg_model)
   unsigned slide_mask;          // bit sl: some leg's collision sphere in slot sl stands for a capsule part (lg_robot_model.cp_slide)
   int n_sc; unsigned sc_pairs[LG_MAX_SC_PAIRS];   // self-collision candidates, packed leg a | slot a << 8 | leg b << 16 | slot b << 24 (0 pairs unless lg_config.self_collisions)
+  uint4 sc_tab[LG_MAX_SC_PAIRS];                  // ... as the pair filter reads them (sc_prefilter): {slot-record indices (slot * 64 + leg) a | b << 16, radius a, radius b, (ra + rb + contact_offset)^2 (1 + 1e-4)}
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
   float lvl_total_before;       // subset steps with a terrain curriculum: sum of ALL terrain levels before the launch (level_total_kernel)
   unsigned long long LG_G* stamps;   // 16 counters, written only by the -DLG_STAMPS diagnostic build
@@ -121,6 +122,7 @@ struct lg_ctx {
   unsigned long sync_calls = 0;
   int split = 1;       // fused step: run the LSTM actuators on three extra waves (LG_SPLIT=0 disables, diagnostic)
   int fuse = 1;        // lg_step ends inside the physics kernel (LG_FUSE=0: separate post kernel, diagnostic / A-B)
+  int persist = 1;     // lg_rollout_batch is one launch per horizon (LG_PERSIST=0: one launch per step, the checker of that path)
   int spec = 1;        // A/B build 13 only: TGS + pyramid steps run a compile-time instance of that solver.  Measured (one session, three
                        // rounds each): 0.0792 ms per step against 0.0782 for the generic instance -- 20 instructions fewer per relaxation, a
                        // different schedule of the same dependent chain, 1.2 % slower; not instantiated in the product library
@@ -500,7 +502,8 @@ LG_DEV void store_lstm_rows(const DevCtx* __restrict__ C, size_t row, size_t N12
 // Optional second destinations of a step that feeds a rollout storage directly (lg_step_transition), see post_instance
 struct PostSink { float* obs_out; const float* values; float* rewards; float* dones; float gamma;
                   float* rew_out; int rew_stride;          // (fused rollout steps: the reward column of lg_rollout_batch's (n, horizon) matrix)
-                  uint8_t* reset_rows; uint8_t* tout_rows; int obs_by_row; };   // lg_step_subset_rows: dense rows by position in the id list (obs_out then too)
+                  uint8_t* reset_rows; uint8_t* tout_rows; int obs_by_row;      // lg_step_subset_rows: dense rows by position in the id list (obs_out then too)
+                  int nsteps; };                                                // persistent rollout launch (SPEC & 3 == 3): steps this launch runs, action rows NDOF apart, reward columns 1 apart
 
 // the post-physics step as the tail of this kernel (lg_fused_post.h, defined below the post-physics helpers)
 struct FusedMainIn;
@@ -535,9 +538,10 @@ LG_DEV const DevCtx* late_ctx(const DevCtx* C) {
 }
 #define FUSED_STATS_WAVE 1   // which wave of a fused workgroup adds the statistics, draws the arrival ticket and tests for the last arrival (a helper wave: with the rigid-body rows moved in front of (G2) the helpers reach the write-back with less left to do than the main wave; A/B -0.5 %)
 LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, const float* SR, const float* HB, int blk, int n, int tid, int64_t step, unsigned long long* stamps, float* obs_out, bool obs_by_row,
-                                const int32_t* __restrict__ ids, bool ro);
-LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid, bool ro);
+                                const int32_t* __restrict__ ids, bool ro, bool arrive);
+LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid, bool ro, int nsteps);
 LG_DEV bool fused_did_reset(const float* HB, int el);
+LG_DEV void fused_reload_state(const float* SR, int lane, int l, float* root, float* q, float* qd);
 LG_DEV float* fused_foot_row(float* xs, int lane);
 LG_DEV float* fused_act_slot(float* xs, int lane, int d);
 LG_DEV bool fused_needs_heights_early(const DevCtx* __restrict__ C);
@@ -598,11 +602,21 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   __shared__ __attribute__((aligned(16))) float wlds[LSTM_LDS ? LW_COUNT + 3 : 4];
   // fused ROLLOUT step of an env subset (lg_step_subset rollout_mode = 1, lg_rollout_batch): its own instance (SPEC = 2), so that the
   // full step's tail carries none of the variant's selects (as run-time branches they cost the headline step 1.3 %: A/B in one session)
-  constexpr bool ro = (SPEC & 3) == 2;
+  // SPEC & 3 == 3: the same tail, and the launch runs sink.nsteps rollout steps of its envs back to back (lg_rollout_batch: one launch per horizon).  A
+  // workgroup owns its envs for the whole horizon and rollout steps never reset, so the main wave keeps the robot state and the helper waves the LSTM state
+  // in registers from step to step; what the tail exchanges through memory (history rows, written by one wave and read by another of the SAME workgroup one
+  // step later) is ordered by the workgroup barrier at the end of a step.  Arrivals are counted in the last step only.
+  constexpr bool ro = (SPEC & 3) >= 2;
+  constexpr bool PERSIST = (SPEC & 3) == 3;
+  const DevCtx* const Cq = C;                             // (the step loops shadow C)
+  // the self-collision pair table (96 x 16 B) in LDS, except where the workgroup has no 1.5 KB left (six legs on a triangle mesh: 163 840 B taken)
+  constexpr bool SC_LDS = ((SPEC >> 2) & 2) && !(TMESH && NLEG == 6);
+  __shared__ uint4 sctab[SC_LDS ? LG_MAX_SC_PAIRS : 1];
+  const int nsteps = PERSIST ? (sink.nsteps > 1 ? sink.nsteps : 1) : 1;
   constexpr int FEAT = SPEC >> 2;
   constexpr bool CAPS = !TMESH && (FEAT & 1);
   const int32_t* const fids = ro ? ids : nullptr;           // the tail's row -> env map: a literal null (rows = envs) in the full step's instance
-  const int64_t fstep = ro ? C->counters[3] + 1 : C->counters[0] + 1;   // LR:123 (the statistics step of the previous launch stored it)
+  int64_t fstep = ro ? C->counters[3] + 1 : C->counters[0] + 1;         // LR:123 (the statistics step of the previous launch stored it)
   const int64_t gstep_f = C->counters[0] + 1;             // what the gait term's "has a scheduler step run yet" test sees (post_instance: gstep)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // Which block of 16 envs this workgroup steps.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own
@@ -647,6 +661,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     pre_act = actions_in[(size_t)krow * act_stride + 3 * l + (wv - 1)];
   }
   fill_leg_model(lmod, C->lmod, threadIdx.x, blockDim.x);
+  if (SC_LDS) for (int i = threadIdx.x; i < C->n_sc; i += blockDim.x) sctab[i] = C->sc_tab[i];      // (first read by the main wave behind (A2) of the first substep)
   if (FUSABLE && fuse && wv == 1) for (int i = lane; i < HC_COUNT; i += 64) hot[i] = C->hot[i];
   if (LSTM_LDS && MODE == 0 && net && wv >= 2) for (int i = (wv - 2) * 64 + lane; i < LW_COUNT; i += 128) wlds[i] = wlstm[i];
   // With helper waves nobody reads these tables before rendezvous (A) of the first substep (every wave's first use is the kinematics behind it), and
@@ -680,6 +695,16 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #pragma unroll
       for (int i = 0; i < 8; ++i) { h0[i] = 0.f; c0[i] = 0.f; h1[i] = 0.f; c1[i] = 0.f; }
     }
+#pragma unroll 1
+    for (int st = 0;; ++st) {                            // (one pass unless PERSIST: the steps of a persistent rollout launch)
+    // PERSIST: every step reads the context afresh through an opaque pointer, as a launch of its own would -- otherwise every context member the
+    // step reads is loop-invariant, gets hoisted in front of the step loop and stays live through all of it (138-156 VGPR spills, measured)
+    const DevCtx* __restrict__ const C = PERSIST ? late_ctx(Cq) : Cq;
+    const lg_config& g = C->cfg;
+    if (PERSIST && st > 0 && net) {                      // this step's action row of the plan; the LSTM state stays in the registers
+      a = actions_in[(size_t)krow * act_stride + (size_t)st * NDOF + 3 * l + (wv - 1)];
+      a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);
+    }
     PhysParams P;
     P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
     P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
@@ -688,7 +713,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     P.slide_mask = 0u;
 #endif
     const TerrainView T = C->ter;
-    if (TMESH) mesh_cache_io<true>(C, cqc, e, l, lane, MESH_PAIR0(wv));   // this wave's two slots of the persisted query cache -> LDS
+    if (TMESH && st == 0) mesh_cache_io<true>(C, cqc, e, l, lane, MESH_PAIR0(wv));   // this wave's two slots of the persisted query cache -> LDS
 #ifdef LG_STAMPS
 #ifndef LG_STAMP_WAVE
 #define LG_STAMP_WAVE 2          // which helper wave the diagnostic build watches
@@ -783,6 +808,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           }
         }
       }
+      // this wave's quarter of the self-collision pair filter (the records it reads are complete since (A2); the published state in xst is dead since every
+      // helper wave fetched it behind (A): its first 768 bytes carry the masks to the main wave)
+      if (FEAT & 2) reinterpret_cast<unsigned*>(&xst[0][0])[(wv - 1) * 64 + lane] = sc_prefilter(cst, SC_LDS ? sctab : C->sc_tab, C->n_sc, lane, wv, 4);
       if (sub == 0) STAMP(57); else STAMP(45);
       lds_barrier();                                   // (A3) slot table complete
       STAMP(22);                                       // (diagnostic)
@@ -879,12 +907,15 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       Ct->torques[(size_t)e * NDOF + d] = xtau[j][lane];
     }
     if (fuse) {
-      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out, sink.obs_by_row != 0, fids, ro);
+      const bool arrive = !PERSIST || st + 1 >= nsteps;  // (the launch's last step counts the workgroup's arrival)
+      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out, sink.obs_by_row != 0, fids, ro, arrive);
+      if (!arrive) { __syncthreads(); fstep += 1; continue; }     // (the step's rows are stored and visible to the workgroup; its LDS is free again)
       if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last ? 1 : 0;
       __syncthreads();
-      if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x, ro);
+      if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x, ro, nsteps);
     }
     return;
+    }
   }
   const bool helpers = MODE == 0 && HELPERS;             // helper waves present (leg bias + contact detection); the host launches this instance with nact == 3
   const bool split = helpers && net;                     // ... and they evaluate the actuator network too
@@ -919,6 +950,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     return;
   }
 
+#pragma unroll 1
+  for (int st = 0;; ++st) {                              // (one pass unless PERSIST)
+  const DevCtx* __restrict__ const C = PERSIST ? late_ctx(Cq) : Cq;      // (see the helper waves' step loop)
+  const lg_config& g = C->cfg;
+  const lg_robot_model* __restrict__ m = &C->model;
   PhysParams P;
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
@@ -927,11 +963,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   P.slide_mask = 0u;
 #endif
   const TerrainView T = C->ter;
-  const SelfCol scol{C->sc_pairs, (FEAT & 2) ? C->n_sc : 0};
+  const SelfCol scol{C->sc_pairs, (FEAT & 2) ? C->n_sc : 0, SC_LDS ? sctab : C->sc_tab, ((FEAT & 2) && helpers) ? reinterpret_cast<unsigned*>(&xst[0][0]) : nullptr};
   const float mu_robot = pre_mu, madd = pre_madd;
   V3 fbody[5];
   bool fault = false;
-  if (TMESH && helpers) mesh_cache_io<true>(C, cqc, e, l, lane, MESH_PAIR0(0));
+  if (TMESH && helpers && st == 0) mesh_cache_io<true>(C, cqc, e, l, lane, MESH_PAIR0(0));
 #ifdef LG_STAMPS
   unsigned long long* stamps = (blockIdx.x == 0 && lane == 0) ? C->stamps : nullptr;
   __builtin_amdgcn_s_waitcnt(0);                      // (diagnostic: the state loads have landed)
@@ -940,6 +976,25 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #else
   unsigned long long* stamps = nullptr;
 #endif
+  PostSink sk = sink;
+  if (PERSIST && st > 0) {                               // the next rollout step of this launch: state in registers, this step's action rows and reward column
+    if (!split) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float a = actions_in[(size_t)krow * act_stride + (size_t)st * NDOF + 3 * l + j];
+        a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);
+        act[j] = a;
+        if (valid) C->actions[(size_t)e * NDOF + 3 * l + j] = a;
+      }
+    }
+    // the state the previous step ended with, from the env rows its tail left in LDS (what it stored to the state tensors): re-read rather than kept,
+    // so that these 19 registers are free during the tail -- the kernel has none to spare there
+    fused_reload_state(xs, lane, l, s.root, s.q, s.qd);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { last_qd[j] = s.qd[j]; tau[j] = 0.f; }      // (what the tail stored as last_dof_vel: the joint speeds the step ended with)
+    fault = false;
+    if (sink.rew_out) sk.rew_out = sink.rew_out + st;
+  }
 #pragma unroll 1
   for (int sub = 0; sub < nsub; ++sub) {
     STAMP(15);
@@ -1054,7 +1109,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   STAMP(39);
   if (fuse) {
     // ---- fused step: the post-physics step of the workgroup's envs, from the registers of this wave (lg_fused_post.h)
-    fused_main_and_serial(Ct, hot, lm_, xs, &xbias[0][0], cst, lane, e, valid, s.root, s.q, s.qd, tau, last_qd, fbody, split ? nullptr : act, fault, ro ? gstep_f : fstep, stamps, sink, ro, krow);
+    fused_main_and_serial(Ct, hot, lm_, xs, &xbias[0][0], cst, lane, e, valid, s.root, s.q, s.qd, tau, last_qd, fbody, split ? nullptr : act, fault, ro ? gstep_f : fstep, stamps, sk, ro, krow);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -1065,14 +1120,16 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       // (the net contact forces go out with the env rows: fused_writeback_obs, from the LDS rows fused_main_part1 wrote)
     }
     STAMP(12);
-    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out, sink.obs_by_row != 0, fids, ro);
+    const bool arrive = !PERSIST || st + 1 >= nsteps;
+    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out, sink.obs_by_row != 0, fids, ro, arrive);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     STAMP(13);
+    if (!arrive) { __syncthreads(); fstep += 1; continue; }
     if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last_wg ? 1 : 0;
     __syncthreads();
-    if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x, ro);
+    if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x, ro, nsteps);
     STAMP(14);
 #ifdef LG_STAMPS
     if (stamps) stamps[36] += __builtin_amdgcn_s_memtime() - t_entry;      // the main wave's whole kernel
@@ -1111,6 +1168,8 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // waves, they write it (one link each) from the published final state while this wave stores the rest
   if (!helpers) write_rigid_body_state(C, lm_, e, l, s.root, s.q, s.qd);
   STAMP(10);
+  return;
+  }
 }
 
 
@@ -1197,7 +1256,7 @@ __global__ __launch_bounds__(64) void physics_kernel_chain(const DevCtx* __restr
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
   P.terrain_mu = C->terrain_mu; P.slide_mask = C->slide_mask;
   const TerrainView T = C->ter;
-  const SelfCol scol{C->sc_pairs, C->n_sc};
+  const SelfCol scol{C->sc_pairs, C->n_sc, nullptr, nullptr};
   const float mu_robot = C->friction[e], madd = C->mass_added[e];
   V3 fbody[NJ + 2];
 #pragma unroll
@@ -1649,11 +1708,11 @@ LG_DEV void finalize_step(const DevCtx* __restrict__ C, int nblocks, int bump, i
 // added their rows to 64-bit fixed-point accumulators (integer atomics: the sum does not depend on arrival order), so
 // this is one round trip (the accumulators and the per-workgroup level sums together) instead of a list walk.
 #define ACC_SCALE 16777216.0
-LG_DEV void finalize_from_acc(const DevCtx* __restrict__ C, int nblocks, int bump, int tid, bool subset) {
+LG_DEV void finalize_from_acc(const DevCtx* __restrict__ C, int nblocks, int bump, int tid, bool subset, int nsteps = 1) {
   const int K = C->cfg.num_reward_terms, KP = K + 3;
   __shared__ float tot[PART_STRIDE];
   __shared__ float f_lvl[256];
-  if (bump == 2) { if (tid == 0) C->counters[3] += 1; return; }
+  if (bump == 2) { if (tid == 0) C->counters[3] += nsteps; return; }      // (a persistent rollout launch has run nsteps steps)
   float lvl_acc = 0.f;
   if (C->cfg.curriculum != 0) for (int b = tid; b < nblocks; b += 256) lvl_acc += ld_dev(C->lvl_part + b);
   if (C->cfg.curriculum != 0 && subset) {
@@ -2246,8 +2305,16 @@ static std::vector<float> pack_obs_table(const lg_config& g, int P) {
   return t;
 }
 // glue between physics_kernel (which only sees declarations) and the tail
-LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid, bool ro) { finalize_from_acc(C, nblocks, ro ? 2 : 1, tid, false); }
+LG_DEV void fused_finalize(const DevCtx* __restrict__ C, int nblocks, int tid, bool ro, int nsteps) { finalize_from_acc(C, nblocks, ro ? 2 : 1, tid, false, nsteps); }
 LG_DEV bool fused_did_reset(const float* HB, int el) { return HB[FH_MISC + el * FM_STRIDE + FM_DID_RESET] != 0.f; }
+// the robot state a step ended with, from the env rows of its tail (persistent rollout launches: the next step starts from them)
+LG_DEV void fused_reload_state(const float* SR, int lane, int l, float* root, float* q, float* qd) {
+  const float* S = SR + (lane / GRP) * FS_STRIDE;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) root[i] = S[FS_ROOT + i];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { q[j] = S[FS_DOF + 2 * (3 * l + j)]; qd[j] = S[FS_DOF + 2 * (3 * l + j) + 1]; }
+}
 LG_DEV float* fused_foot_row(float* xs, int lane) { return xs + (lane / GRP) * FS_STRIDE + FS_FRB + 13 * (lane % GRP); }
 LG_DEV float* fused_act_slot(float* xs, int lane, int d) { return xs + (lane / GRP) * FS_STRIDE + FS_ACT + d; }
 LG_DEV bool fused_needs_heights_early(const DevCtx* __restrict__ C) {
@@ -2293,9 +2360,10 @@ LG_DEV void fused_noise_park(const float*, float*, int, int, int, const float (*
 LG_DEV void fused_stage_obs_table(const float*, float*, int, const FusedPre&) {}
 LG_DEV void fused_main_and_serial(const DevCtx* __restrict__, const float*, const LegModel&, float*, float*, float*, int, int, bool, const float*, const float*,
                                   const float*, const float*, const float*, const V3*, const float*, bool, int64_t, unsigned long long*, const PostSink&, bool, int) {}
-LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__, const float*, const float*, const float*, int, int, int, int64_t, unsigned long long*, float*, bool, const int32_t* __restrict__, bool) { return false; }
-LG_DEV void fused_finalize(const DevCtx* __restrict__, int, int, bool) {}
+LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__, const float*, const float*, const float*, int, int, int, int64_t, unsigned long long*, float*, bool, const int32_t* __restrict__, bool, bool) { return false; }
+LG_DEV void fused_finalize(const DevCtx* __restrict__, int, int, bool, int) {}
 LG_DEV bool fused_did_reset(const float*, int) { return false; }
+LG_DEV void fused_reload_state(const float*, int, int, float*, float*, float*) {}
 LG_DEV float* fused_foot_row(float* xs, int) { return xs; }
 LG_DEV float* fused_act_slot(float* xs, int, int) { return xs; }
 LG_DEV bool fused_needs_heights_early(const DevCtx* __restrict__) { return false; }
@@ -2539,8 +2607,17 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
       if (model->cp_slide[l][sl][0] != 0.f || model->cp_slide[l][sl][1] != 0.f || model->cp_slide[l][sl][2] != 0.f) h.slide_mask |= 1u << sl;
   if (const char* ev = getenv("LG_CAPS")) { if (atoi(ev) == 0) h.slide_mask = 0u; }      // (diagnostic / A-B: every sphere stays in the middle of its part)
   h.n_sc = cfg->self_collisions ? model->num_sc_pairs : 0;
-  for (int i = 0; i < h.n_sc; ++i)
-    h.sc_pairs[i] = (unsigned)model->sc_pairs[i][0] | (unsigned)model->sc_pairs[i][1] << 8 | (unsigned)model->sc_pairs[i][2] << 16 | (unsigned)model->sc_pairs[i][3] << 24;
+  for (int i = 0; i < h.n_sc; ++i) {
+    const int32_t* q = model->sc_pairs[i];
+    h.sc_pairs[i] = (unsigned)q[0] | (unsigned)q[1] << 8 | (unsigned)q[2] << 16 | (unsigned)q[3] << 24;
+#if NJ == 3
+    const float ra = model->cp_radius[q[0]][q[1]], rb = model->cp_radius[q[2]][q[3]];
+    const float reach = ra + rb + cfg->contact_offset, thr2 = reach * reach * 1.0001f;
+    unsigned ua, ub, ut; memcpy(&ua, &ra, 4); memcpy(&ub, &rb, 4); memcpy(&ut, &thr2, 4);
+    const unsigned oa = (unsigned)(q[1] * 64 + q[0]), ob = (unsigned)(q[3] * 64 + q[2]);      // record index slot * 64 + leg (the lane group's first lane is added in the kernel)
+    h.sc_tab[i] = make_uint4(oa | ob << 16, ua, ub, ut);
+#endif
+  }
   h.mesh_cache = nullptr;
   if (ter->mesh_type == LG_MESH_TRIMESH) {
     const size_t nf = (size_t)cfg->num_envs * NLEG * LG_MAX_CP * 4;
@@ -2668,6 +2745,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   if (hipDeviceSynchronize() != hipSuccess) return fail("device sync failed");
   if (const char* ev = getenv("LG_SPLIT")) c->split = atoi(ev) != 0;
   if (const char* ev = getenv("LG_FUSE")) c->fuse = atoi(ev) != 0;
+  if (const char* ev = getenv("LG_PERSIST")) c->persist = atoi(ev) != 0;
   if (const char* ev = getenv("LG_SPEC")) c->spec = atoi(ev) != 0;
   return c;
 }
@@ -2708,7 +2786,7 @@ static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t*
 // fuse: the post-physics step runs as the tail of the physics kernel (full steps of all envs with helper waves; LG_FUSE=0 keeps
 // the two-launch path, which every split / subset / rollout entry point uses anyway)
 static bool can_fuse(const lg_ctx* c) { return LG_LEGS == 4 && c->fuse && !c->h.extra_term && !c->h.cfg.keep_small_commands && !c->h.cfg.feet_air_time_ungated && (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) && c->h.P <= MAX_P; }
-// fuse: 0 = physics only (a post kernel follows), 1 = full policy step with the fused tail, 2 = fused ROLLOUT step of the listed envs
+// fuse: 0 = physics only (a post kernel follows), 1 = full policy step with the fused tail, 2 = fused ROLLOUT step of the listed envs, 3 = sink.nsteps of them in one launch
 static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = NDOF, int fuse = 0,
                            PostSink sink = PostSink{nullptr, nullptr, nullptr, nullptr, 0.f}) {
   const int nb = (n + EPB - 1) / EPB;
@@ -2733,6 +2811,12 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
 #define LG_LAUNCH_PK(TM, HELP, SPEC_, THREADS) \
   hipLaunchKernelGGL((physics_kernel<0, TM, HELP, SPEC_>), dim3(nb), dim3(THREADS), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink)
 #if LG_LEGS == 4
+  if (fuse == 3 && !tm) {                                // persistent rollout launch: sink.nsteps steps (heightfield / plane terrains; mesh terrains go step by step)
+    if (selfc) LG_LAUNCH_PK(false, true, 3 + 12, 256);
+    else if (caps) LG_LAUNCH_PK(false, true, 3 + 4, 256);
+    else LG_LAUNCH_PK(false, true, 3, 256);
+    return;
+  }
   if (fuse == 2) {                                       // (can_fuse() held: helper waves are present)
     if (tm) { if (selfc) LG_LAUNCH_PK(true, true, 2 + 8, 256); else LG_LAUNCH_PK(true, true, 2, 256); }
     else if (selfc) LG_LAUNCH_PK(false, true, 2 + 12, 256);
@@ -2954,6 +3038,15 @@ int lg_rollout_batch(lg_ctx* c, const float* all_us, int32_t horizon, const int3
   int rc = lg_sync_main_to_rollout(c, rollouts_per_main, pos_drift, stream);
   if (rc != LG_OK) return rc;
   const bool fuse = can_fuse(c);
+  // One launch for the whole horizon (round 5): the workgroup that owns an env keeps its state on chip from step to step.  Not with the clock-driven gait
+  // term (its phase changes inside a horizon: the env class goes step by step anyway), not on mesh terrains (no persistent instance), LG_PERSIST=0 = the A/B switch.
+  if (fuse && horizon > 1 && c->persist && c->h.ter.mesh_type != LG_MESH_TRIMESH) {
+    PostSink sk{nullptr, nullptr, nullptr, nullptr, 0.f, rewards, horizon};
+    sk.nsteps = horizon;
+    launch_physics(c, st, all_us, env_ids, n, horizon * NDOF, 3, sk);
+    HIP_TRY(c, hipGetLastError());
+    return lg_sync_main_to_rollout(c, rollouts_per_main, pos_drift, stream);
+  }
   for (int i = 0; i < horizon; ++i) {
     if (fuse) {                                          // one launch per rollout step: the reward column is written by the kernel's tail
       launch_physics(c, st, all_us + (size_t)i * NDOF, env_ids, n, horizon * NDOF, 2, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f, rewards + i, horizon});

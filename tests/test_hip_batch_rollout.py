@@ -1,5 +1,7 @@
 """GPU: main-rollout env.  Subset stepping and the main→rollout sync against the CPU oracle, and the
 behavioural contract of RobotBatchRollout.step / step_rollout (robot_batch_rollout.py:535-716, 1447-1640)."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -421,3 +423,54 @@ def test_sync_copies_the_actuator_network_state_to_the_rollouts():
             assert np.array_equal(h[:, mains + r], h[:, mains]) and np.array_equal(c[:, mains + r], c[:, mains])
             assert np.array_equal(tq[mains + r], tq[mains])
     core.close(); o.close()
+
+
+@pytest.mark.parametrize("kind", ["plane_pd", "plane_lstm", "heightfield_lstm"])
+def test_persistent_rollout_batch_equals_the_stepwise_launches(kind, monkeypatch):
+    """`lg_rollout_batch` as ONE launch per horizon (the workgroup keeps robot and actuator state in registers from step to step) against the same
+    library with LG_PERSIST=0 (one launch per rollout step): rewards and every tensor of the arena bit for bit, H = 16, ragged env count."""
+    from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout import RobotBatchRollout
+    from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout_config import RobotBatchRolloutCfg
+
+    def build(persist):
+        monkeypatch.setenv("LG_PERSIST", "1" if persist else "0")
+        base = AnymalCFlatCfg()
+        cfg = RobotBatchRolloutCfg()
+        for sec in ("init_state", "control", "asset", "rewards", "commands", "terrain"):
+            setattr(cfg, sec, copy.deepcopy(getattr(base, sec)))
+        cfg.env.num_envs, cfg.env.rollout_envs, cfg.env.num_observations = 7, 5, 48       # 42 envs: the last workgroup is partial
+        cfg.control.use_actuator_network = kind.endswith("lstm")
+        cfg.domain_rand.push_robots = False
+        cfg.rewards.only_positive_rewards = False
+        if kind.startswith("heightfield"):
+            cfg.terrain.mesh_type = "heightfield"
+            cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size, cfg.terrain.max_init_terrain_level = 3, 3, 5, 2
+            cfg.terrain.measure_heights = True
+            cfg.env.num_observations = 235
+        cfg.seed = 4
+        np.random.seed(4); torch.manual_seed(4)            # (terrain and the per-env friction / payload draws come from the global generators, as in the reference)
+        env = RobotBatchRollout(cfg, sim_params_for(cfg), "native_hip", "cuda:0", True)
+        env.reset()
+        g = torch.Generator().manual_seed(1)
+        for _ in range(6):
+            env.step(0.5 * torch.randn(7, 12, generator=g).cuda())
+        plan = 0.7 * torch.randn(35, 16, 12, generator=g).cuda()
+        rews = env.rollout_batch(plan).clone()
+        torch.cuda.synchronize()
+        state = {k: v.clone() for k, v in env.core.t.items()}
+        counters = env.core.arena.clone()                                  # (every byte the library owns, scratch included)
+        # the launch after a horizon starts from what the horizon left: one more main step, again compared
+        env.step(0.5 * torch.randn(7, 12, generator=g).cuda())
+        after = {k: env.core.t[k].clone() for k in ("root_states", "dof_state", "obs_buf", "rew_buf")}
+        env.core.close()
+        return rews, state, counters, after
+
+    r1, s1, c1, a1 = build(True)
+    r0, s0, c0, a0 = build(False)
+    assert torch.isfinite(r1).all() and float(r1.std()) > 0
+    assert torch.equal(r1, r0)
+    assert torch.equal(c1, c0)
+    for k in s1:
+        assert torch.equal(s1[k], s0[k]), k
+    for k in a1:
+        assert torch.equal(a1[k], a0[k]), k
