@@ -383,6 +383,7 @@ LG_DEV void sts3(float* cst, int slot, int f, int lane, V3 a) { CS(slot, f) = a.
 struct PhysParams {
   float dt; V3 grav; int iters; float contact_offset, max_depen, erp, cfm, terrain_mu; int solver, fric;
   unsigned slide_mask;      // bit sl: some leg's sphere in slot sl stands for a capsule part (lg_robot_model.cp_slide), kernel-uniform
+  unsigned slot_perm;       // nibble p: the slot at position p of the detection deal (capsule instances; contact_detect_begin_caps)
 };
 
 #define LG_MESH_CONTACT_MARGIN 0.1f      // triangle-mesh contacts: how far below a surface a sphere's centre may have sunk and still be pushed out
@@ -526,12 +527,16 @@ LG_DEV void seg_seg_closest(V3 A0, V3 d1, V3 E0, V3 d2, V3* A, V3* E) {
 #if NJ == 3      // ---- the tuned three-joint kernels' own piece (lg_chain.h holds the six-joint instance's)
 template <int S0, int S1>
 struct ContactProbeC { V3 x[S1 - S0], gv[S1 - S0]; float rads[S1 - S0]; PackedCell cell[S1 - S0]; unsigned e[S1 - S0][2]; int lj[S1 - S0][2]; /* L | j << 16, bit 31: no crossing */ };
+// perm: which slot stands at position p of the deal (nibble p).  The waves take POSITIONS [S0, S1); the host orders the slots so that the ones with a
+// segment (twice the work: two edge pieces each) are spread over the waves that have room -- one to the main wave, one to wave 3, whose second position
+// is usually empty, none to wave 1, which has the leg bias (PhysParams::slot_perm; results do not depend on who detects a slot).
 template <int S0, int S1>
-LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T, const LegKin& k, const M3& Rb, V3 pb, unsigned slide_mask, ContactProbeC<S0, S1>& pr) {
+LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T, const LegKin& k, const M3& Rb, V3 pb, unsigned slide_mask, ContactProbeC<S0, S1>& pr,
+                                      unsigned perm = 0x76543210u) {
   const float ihs = T.hscale > 0.f ? frcp(T.hscale) : 0.f;
 #pragma unroll
-  for (int sl = S0; sl < S1; ++sl) {
-    const int i = sl - S0;
+  for (int ps = S0; ps < S1; ++ps) {
+    const int i = ps - S0, sl = (int)((perm >> (4 * ps)) & 7u);
     const int link = lm_.i(LM_CP_LINK + sl);
     const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
     pr.rads[i] = lm_.f(LM_CP_RADIUS + sl);
@@ -557,11 +562,11 @@ LG_DEV void contact_detect_begin_caps(const LegModel& lm_, const TerrainView& T,
 }
 template <int S0, int S1>
 LG_DEV void contact_detect_finish_caps(const LegModel& lm_, const TerrainView& T, const PhysParams& P, V3 pb, unsigned slide_mask, const ContactProbeC<S0, S1>& pr,
-                                       float* cst, int lane) {
+                                       float* cst, int lane, unsigned perm = 0x76543210u) {
   const int ncp = lm_.i(LM_CP_COUNT);
 #pragma unroll
-  for (int sl = S0; sl < S1; ++sl) {
-    const int i = sl - S0;
+  for (int ps = S0; ps < S1; ++ps) {
+    const int i = ps - S0, sl = (int)((perm >> (4 * ps)) & 7u);
     const float rad = pr.rads[i];
     float hh; V3 n;
     V3 x = pr.x[i];
@@ -605,8 +610,9 @@ template <int S0, int S1>
 LG_DEV void contact_detect_caps(const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k, const M3& Rb, V3 pb,
                                 float* cst, int lane) {
   ContactProbeC<S0, S1> pr;
-  contact_detect_begin_caps<S0, S1>(lm_, T, k, Rb, pb, P.slide_mask, pr);
-  contact_detect_finish_caps<S0, S1>(lm_, T, P, pb, P.slide_mask, pr, cst, lane);
+  const unsigned perm = (S0 == 0 && S1 == LG_MAX_CP) ? 0x76543210u : P.slot_perm;      // (all slots: any order)
+  contact_detect_begin_caps<S0, S1>(lm_, T, k, Rb, pb, P.slide_mask, pr, perm);
+  contact_detect_finish_caps<S0, S1>(lm_, T, P, pb, P.slide_mask, pr, cst, lane, perm);
 }
 
 #endif           // NJ == 3

@@ -97,6 +97,7 @@ struct DevCtx {
   float hot[HC_COUNT];          // see the HC_* enum (ints stored as bit patterns)
   float lmod[LM_FIELDS * GRP];  // per-leg model table, packed on the host (pack_leg_model)
   unsigned slide_mask;          // bit sl: some leg's collision sphere in slot sl stands for a capsule part (lg_robot_model.cp_slide)
+  unsigned slot_perm;           // nibble p: the slot at position p of the contact-detection deal (main wave 0-2, wave 1: 3, wave 2: 4-5, wave 3: 6-7), see lg_create
   int n_sc; unsigned sc_pairs[LG_MAX_SC_PAIRS];   // self-collision candidates, packed leg a | slot a << 8 | leg b << 16 | slot b << 24 (0 pairs unless lg_config.self_collisions)
   uint4 sc_tab[LG_MAX_SC_PAIRS];                  // ... as the pair filter reads them (sc_prefilter): {slot-record indices (slot * 64 + leg) a | b << 16, radius a, radius b, (ra + rb + contact_offset)^2 (1 + 1e-4)}
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     PhysParams P;
     P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
     P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-    P.terrain_mu = C->terrain_mu; P.slide_mask = CAPS ? C->slide_mask : 0u;
+    P.terrain_mu = C->terrain_mu; P.slide_mask = CAPS ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : 0x76543210u;
 #if LG_AB == 21
     P.slide_mask = 0u;
 #endif
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           float4* pb4 = reinterpret_cast<float4*>(xbias[lane]);
           pb4[0] = make_float4(bk[0], bk[1], bk[2], Fs.x); pb4[1] = make_float4(Fs.y, Fs.z, Ns.x, Ns.y); pb4[2] = make_float4(Ns.z, 0.f, 0.f, 0.f);
         }
-        if (!TMESH) { if (DS0 < DS1) { if (CAPS) contact_detect_begin_caps<DS0, DS1P>(lm_, T, k, Rb, pb, P.slide_mask, pc1); else contact_detect_begin<DS0, DS1P>(lm_, T, k, Rb, pb, pr1); } }
+        if (!TMESH) { if (DS0 < DS1) { if (CAPS) contact_detect_begin_caps<DS0, DS1P>(lm_, T, k, Rb, pb, P.slide_mask, pc1, P.slot_perm); else contact_detect_begin<DS0, DS1P>(lm_, T, k, Rb, pb, pr1); } }
         else contact_detect_mesh(MESH_PAIR0(1), MESH_PAIR0(1) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (TMESH) {
 #ifdef LG_STAMPS
@@ -769,9 +770,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
         contact_detect_mesh(MESH_PAIR0(wv), MESH_PAIR0(wv) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
 #endif
       } else if (wv == 2) {
-        if (CAPS) contact_detect_begin_caps<DS1, DS2>(lm_, T, k, Rb, pb, P.slide_mask, pc2); else contact_detect_begin<DS1, DS2>(lm_, T, k, Rb, pb, pr2);
+        if (CAPS) contact_detect_begin_caps<DS1, DS2>(lm_, T, k, Rb, pb, P.slide_mask, pc2, P.slot_perm); else contact_detect_begin<DS1, DS2>(lm_, T, k, Rb, pb, pr2);
       } else {
-        if (CAPS) contact_detect_begin_caps<DS2, 8>(lm_, T, k, Rb, pb, P.slide_mask, pc3); else contact_detect_begin<DS2, 8>(lm_, T, k, Rb, pb, pr3);
+        if (CAPS) contact_detect_begin_caps<DS2, 8>(lm_, T, k, Rb, pb, P.slide_mask, pc3, P.slot_perm); else contact_detect_begin<DS2, 8>(lm_, T, k, Rb, pb, pr3);
       }
       if (sub == 0) STAMP(54); else STAMP(42);
       if (net) {
@@ -785,9 +786,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           xtau[j][lane] = lstm_input_part(wlstm + zero, x0, x1, lpre, h0, c0, h1, c1, g.actuator_out_scale);
         }
       }
-      if (!TMESH && wv == 1) { if (DS0 < DS1) { if (CAPS) contact_detect_finish_caps<DS0, DS1P>(lm_, T, P, pb, P.slide_mask, pc1, cst, lane); else contact_detect_finish<DS0, DS1P>(lm_, T, P, pb, pr1, cst, lane); } }
-      else if (!TMESH && wv == 2) { if (CAPS) contact_detect_finish_caps<DS1, DS2>(lm_, T, P, pb, P.slide_mask, pc2, cst, lane); else contact_detect_finish<DS1, DS2>(lm_, T, P, pb, pr2, cst, lane); }
-      else if (!TMESH && wv == 3) { if (CAPS) contact_detect_finish_caps<DS2, 8>(lm_, T, P, pb, P.slide_mask, pc3, cst, lane); else contact_detect_finish<DS2, 8>(lm_, T, P, pb, pr3, cst, lane); }
+      if (!TMESH && wv == 1) { if (DS0 < DS1) { if (CAPS) contact_detect_finish_caps<DS0, DS1P>(lm_, T, P, pb, P.slide_mask, pc1, cst, lane, P.slot_perm); else contact_detect_finish<DS0, DS1P>(lm_, T, P, pb, pr1, cst, lane); } }
+      else if (!TMESH && wv == 2) { if (CAPS) contact_detect_finish_caps<DS1, DS2>(lm_, T, P, pb, P.slide_mask, pc2, cst, lane, P.slot_perm); else contact_detect_finish<DS1, DS2>(lm_, T, P, pb, pr2, cst, lane); }
+      else if (!TMESH && wv == 3) { if (CAPS) contact_detect_finish_caps<DS2, 8>(lm_, T, P, pb, P.slide_mask, pc3, cst, lane, P.slot_perm); else contact_detect_finish<DS2, 8>(lm_, T, P, pb, pr3, cst, lane); }
       if (sub == 0) STAMP(55); else STAMP(43);
       lds_barrier();                                   // (A2) bias, contact detection, torques | mass-matrix factors
       if (sub == 0) STAMP(56); else STAMP(44);
@@ -958,7 +959,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   PhysParams P;
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-  P.terrain_mu = C->terrain_mu; P.slide_mask = CAPS ? C->slide_mask : 0u;
+  P.terrain_mu = C->terrain_mu; P.slide_mask = CAPS ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : 0x76543210u;
 #if LG_AB == 21
   P.slide_mask = 0u;
 #endif
@@ -1254,7 +1255,7 @@ __global__ __launch_bounds__(64) void physics_kernel_chain(const DevCtx* __restr
   PhysParams P;
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-  P.terrain_mu = C->terrain_mu; P.slide_mask = C->slide_mask;
+  P.terrain_mu = C->terrain_mu; P.slide_mask = C->slide_mask; P.slot_perm = 0x76543210u;
   const TerrainView T = C->ter;
   const SelfCol scol{C->sc_pairs, C->n_sc, nullptr, nullptr};
   const float mu_robot = C->friction[e], madd = C->mass_added[e];
@@ -2606,6 +2607,30 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
     for (int sl = 0; sl < model->cp_count[l]; ++sl)
       if (model->cp_slide[l][sl][0] != 0.f || model->cp_slide[l][sl][1] != 0.f || model->cp_slide[l][sl][2] != 0.f) h.slide_mask |= 1u << sl;
   if (const char* ev = getenv("LG_CAPS")) { if (atoi(ev) == 0) h.slide_mask = 0u; }      // (diagnostic / A-B: every sphere stays in the middle of its part)
+  // Who detects which slot (capsule instances on a height grid).  A slot with a segment costs about twice a plain one (two edge pieces), an empty slot
+  // nothing; the waves take positions 0-2 (main) / 3 (wave 1, which also has the leg bias and arrives last) / 4-5 / 6-7.  Segment slots go to positions
+  // 6, 2, 4, 5 in that order, slots no leg has fill up behind them (7 first), plain slots take what is left in ascending order.  ANYmal-C (foot, three
+  // shank spheres of which two carry segments, two thigh-drive spheres, a trunk sphere): {0, 1, 3 | 4 | 5, 6 | 2, -}.  LG_DEAL=0: the identity (A/B).
+  {
+    int max_cp = 0;
+    for (int l = 0; l < NLEG; ++l) max_cp = model->cp_count[l] > max_cp ? model->cp_count[l] : max_cp;
+    int at[LG_MAX_CP]; bool used[LG_MAX_CP] = {false};
+    for (int p = 0; p < LG_MAX_CP; ++p) at[p] = -1;
+    const int seg_pos[LG_MAX_CP] = {6, 2, 4, 5, 7, 0, 1, 3}, empty_pos[LG_MAX_CP] = {7, 3, 5, 1, 6, 4, 2, 0};
+    int ns = 0;
+    for (int sl = 0; sl < max_cp; ++sl) if ((h.slide_mask >> sl) & 1u) { at[seg_pos[ns++]] = sl; used[sl] = true; }
+    int ne = 0;
+    for (int sl = max_cp; sl < LG_MAX_CP; ++sl) { while (at[empty_pos[ne]] >= 0) ++ne; at[empty_pos[ne]] = sl; used[sl] = true; }
+    int pp = 0;
+    for (int sl = 0; sl < max_cp; ++sl) if (!used[sl]) { while (at[pp] >= 0) ++pp; at[pp] = sl; }
+    h.slot_perm = 0u;
+    for (int p = 0; p < LG_MAX_CP; ++p) h.slot_perm |= (unsigned)at[p] << (4 * p);
+    if (h.slide_mask == 0u) h.slot_perm = 0x76543210u;
+    if (const char* ev = getenv("LG_DEAL")) {            // (A/B: "0" = the identity; eight digits = the slots at positions 0..7)
+      if (strlen(ev) == 8) { h.slot_perm = 0u; for (int p = 0; p < 8; ++p) h.slot_perm |= (unsigned)((ev[p] - '0') & 7) << (4 * p); }
+      else if (atoi(ev) == 0) h.slot_perm = 0x76543210u;
+    }
+  }
   h.n_sc = cfg->self_collisions ? model->num_sc_pairs : 0;
   for (int i = 0; i < h.n_sc; ++i) {
     const int32_t* q = model->sc_pairs[i];
