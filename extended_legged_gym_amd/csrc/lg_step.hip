@@ -610,6 +610,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   constexpr bool ro = (SPEC & 3) >= 2;
   constexpr bool PERSIST = (SPEC & 3) == 3;
   const DevCtx* const Cq = C;                             // (the step loops shadow C)
+  // ... and the three values every row address of the tail is formed from: loop-invariant otherwise, i.e. some sixty 64-bit addresses per lane computed in front
+  // of the step loop and kept through all of it
+  auto opaque_v = [](int v) { if (PERSIST) asm volatile("" : "+v"(v)); return v; };
+  auto opaque_s = [](int v) { if (PERSIST) asm volatile("" : "+s"(v)); return v; };
   // the self-collision pair table (96 x 16 B) in LDS, except where the workgroup has no 1.5 KB left (six legs on a triangle mesh: 163 840 B taken)
   constexpr bool SC_LDS = ((SPEC >> 2) & 2) && !(TMESH && NLEG == 6);
   __shared__ uint4 sctab[SC_LDS ? LG_MAX_SC_PAIRS : 1];
@@ -634,6 +638,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const bool valid = env_ok && has_leg;
   const int krow = env_ok ? kq : n - 1;     // whole groups are (in)valid together; invalid groups compute on a copy and store nothing
   const int e = ids ? ids[krow] : krow;
+  const int e_q = e, krow_q = krow, bid_q = bid;
   const lg_robot_model* __restrict__ m = &C->model;
   const lg_config& g = C->cfg;
   const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     // present for triangle-mesh terrains) the main wave keeps the torques and barrier (B) does not exist
     float a = net ? pre_act : 0.f;
     a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);
-    const size_t N12 = (size_t)C->N * NDOF, row = (size_t)e * NDOF + d;
+    const size_t N12_o = (size_t)C->N * NDOF, row_o = (size_t)e * NDOF + d;
     float h0[8], c0[8], h1[8], c1[8];
     if (net) {
       float4 u = pre_sea[0], v = pre_sea[1];
@@ -702,6 +707,9 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     // step reads is loop-invariant, gets hoisted in front of the step loop and stays live through all of it (138-156 VGPR spills, measured)
     const DevCtx* __restrict__ const C = PERSIST ? late_ctx(Cq) : Cq;
     const lg_config& g = C->cfg;
+    const int e = opaque_v(e_q), krow = opaque_v(krow_q), bid = opaque_s(bid_q);
+    const int htid = opaque_v((wv - 1) * 64 + lane), tid_it = opaque_v((int)threadIdx.x);      // (what the tail's lane -> (env, entry) maps are formed from)
+    const size_t N12 = PERSIST ? (size_t)C->N * NDOF : N12_o, row = PERSIST ? (size_t)e * NDOF + d : row_o;      // (PERSIST: formed from this step's opaque e)
     if (PERSIST && st > 0 && net) {                      // this step's action row of the plan; the LSTM state stays in the registers
       a = actions_in[(size_t)krow * act_stride + (size_t)st * NDOF + 3 * l + (wv - 1)];
       a = fminf(fmaxf(a, -g.clip_actions), g.clip_actions);
@@ -811,7 +819,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       }
       // this wave's quarter of the self-collision pair filter (the records it reads are complete since (A2); the published state in xst is dead since every
       // helper wave fetched it behind (A): its first 768 bytes carry the masks to the main wave)
-      if (FEAT & 2) reinterpret_cast<unsigned*>(&xst[0][0])[(wv - 1) * 64 + lane] = sc_prefilter(cst, SC_LDS ? sctab : C->sc_tab, C->n_sc, lane, wv, 4);
+      if (FEAT & 2) reinterpret_cast<unsigned*>(&xst[0][0])[htid] = sc_prefilter(cst, SC_LDS ? sctab : C->sc_tab, C->n_sc, lane, wv, 4);
       if (sub == 0) STAMP(57); else STAMP(45);
       lds_barrier();                                   // (A3) slot table complete
       STAMP(22);                                       // (diagnostic)
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       if (fuse && sub + 1 == nsub) {                   // ... in the last substep: what the post-physics tail needs from HBM
         if (net) *fused_act_slot(xs, lane, d) = a;     // (the mass-factor table is dead after (A3): the env rows live there)
         STAMP(46);                                     // (diagnostic: (A3) of the last substep)
-        fused_prefetch(late_ctx(C), xs, &xbias[0][0], bid, n, (wv - 1) * 64 + lane, fstep, sink.values, fids, ro);
+        fused_prefetch(late_ctx(C), xs, &xbias[0][0], bid, n, htid, fstep, sink.values, fids, ro);
 #ifdef LG_STAMPS
         __builtin_amdgcn_s_waitcnt(0);
 #endif
@@ -832,14 +840,14 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     float nz[NZ_IT][4];
     const bool predraw = fuse && fused_noise_predrawn(hot);
-    if (predraw) fused_noise_draw(hot, bid, n, (wv - 1) * 64 + lane, fstep, nz, fids, ro);   // (these waves would wait for the main wave's last sweeps now)
+    if (predraw) fused_noise_draw(hot, bid, n, htid, fstep, nz, fids, ro);   // (these waves would wait for the main wave's last sweeps now)
     FusedPre fpre;
-    if (fuse) fused_prefetch_static(late_ctx(C), hot, (wv - 1) * 64 + lane, fpre);
+    if (fuse) fused_prefetch_static(late_ctx(C), hot, htid, fpre);
     lds_barrier();                                     // (F) main wave has published the final state of the step
     const DevCtx* const Ct = late_ctx(C);                // (everything behind the last substep reads the context through this: see late_ctx)
     STAMP(48);
-    if (predraw) fused_noise_park(hot, cst, bid, n, (wv - 1) * 64 + lane, nz);
-    if (fuse) fused_stage_obs_table(hot, cst, (wv - 1) * 64 + lane, fpre);
+    if (predraw) fused_noise_park(hot, cst, bid, n, htid, nz);
+    if (fuse) fused_stage_obs_table(hot, cst, htid, fpre);
     if (TMESH && valid) mesh_cache_io<false>(Ct, cqc, e, l, lane, MESH_PAIR0(wv));
     bool zero_state = false;
     if (!fuse) {
@@ -864,11 +872,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           write_rigid_body_state(Ct, lm_, e, l, r13, qq, qdd, 2, fused_foot_row(xs, lane), nullptr, fpre.per_leg, fpre.B, fpre.rigid);   // (gait_foot_z is stored late: the serial part still reads the old one)
         }
       }
-      fused_height_scan(Ct, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro, fpre);
+      fused_height_scan(Ct, xst, cst, bid, n, htid, fids, ro, fpre);
       STAMP(35);                                       // (diagnostic)
 #if defined(LG_STAMPS) && defined(LG_SCAN_TWICE)
       { const DevCtx* Cx = Ct; asm volatile("" : "+s"(Cx));     // (diagnostic: the same code a second time, now warm in the instruction cache)
-        fused_height_scan(Cx, xst, cst, bid, n, (wv - 1) * 64 + lane, fids, ro, fpre); }
+        fused_height_scan(Cx, xst, cst, bid, n, htid, fids, ro, fpre); }
       STAMP(27);
 #endif
       // the rigid-body rows (stores nobody in this launch reads) while the main wave runs the serial part: these waves wait ~6 k cycles for
@@ -909,11 +917,11 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     if (fuse) {
       const bool arrive = !PERSIST || st + 1 >= nsteps;  // (the launch's last step counts the workgroup's arrival)
-      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, nullptr, sink.obs_out, sink.obs_by_row != 0, fids, ro, arrive);
+      const bool last = fused_writeback_obs(Ct, hot, xs, cst, bid, n, tid_it, fstep, nullptr, sink.obs_out, sink.obs_by_row != 0, fids, ro, arrive);
       if (!arrive) { __syncthreads(); fstep += 1; continue; }     // (the step's rows are stored and visible to the workgroup; its LDS is free again)
-      if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last ? 1 : 0;
+      if (tid_it == 64 * FUSED_STATS_WAVE) s_last_f = last ? 1 : 0;
       __syncthreads();
-      if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x, ro, nsteps);
+      if (s_last_f) fused_finalize(Ct, gridDim.x, tid_it, ro, nsteps);
     }
     return;
     }
@@ -956,6 +964,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const DevCtx* __restrict__ const C = PERSIST ? late_ctx(Cq) : Cq;      // (see the helper waves' step loop)
   const lg_config& g = C->cfg;
   const lg_robot_model* __restrict__ m = &C->model;
+  const int e = opaque_v(e_q), krow = opaque_v(krow_q), bid = opaque_s(bid_q), tid_it = opaque_v((int)threadIdx.x);
   PhysParams P;
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
@@ -1122,15 +1131,15 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     }
     STAMP(12);
     const bool arrive = !PERSIST || st + 1 >= nsteps;
-    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, threadIdx.x, fstep, stamps, sink.obs_out, sink.obs_by_row != 0, fids, ro, arrive);
+    const bool last_wg = fused_writeback_obs(Ct, hot, xs, cst, bid, n, tid_it, fstep, stamps, sink.obs_out, sink.obs_by_row != 0, fids, ro, arrive);
 #ifdef LG_STAMPS
     stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     STAMP(13);
     if (!arrive) { __syncthreads(); fstep += 1; continue; }
-    if (threadIdx.x == 64 * FUSED_STATS_WAVE) s_last_f = last_wg ? 1 : 0;
+    if (tid_it == 64 * FUSED_STATS_WAVE) s_last_f = last_wg ? 1 : 0;
     __syncthreads();
-    if (s_last_f) fused_finalize(Ct, gridDim.x, threadIdx.x, ro, nsteps);
+    if (s_last_f) fused_finalize(Ct, gridDim.x, tid_it, ro, nsteps);
     STAMP(14);
 #ifdef LG_STAMPS
     if (stamps) stamps[36] += __builtin_amdgcn_s_memtime() - t_entry;      // the main wave's whole kernel
