@@ -124,6 +124,7 @@ struct lg_ctx {
   int split = 1;       // fused step: run the LSTM actuators on three extra waves (LG_SPLIT=0 disables, diagnostic)
   int fuse = 1;        // lg_step ends inside the physics kernel (LG_FUSE=0: separate post kernel, diagnostic / A-B)
   int persist = 1;     // lg_rollout_batch is one launch per horizon (LG_PERSIST=0: one launch per step, the checker of that path)
+  int gfuse = 0;       // LG_GFUSE=1: the six-legged instance's lg_step in one launch (can_gfuse)
   int spec = 1;        // A/B build 13 only: TGS + pyramid steps run a compile-time instance of that solver.  Measured (one session, three
                        // rounds each): 0.0792 ms per step against 0.0782 for the generic instance -- 20 instructions fewer per relaxation, a
                        // different schedule of the same dependent chain, 1.2 % slower; not instantiated in the product library
@@ -508,6 +509,8 @@ struct PostSink { float* obs_out; const float* values; float* rewards; float* do
 
 // the post-physics step as the tail of this kernel (lg_fused_post.h, defined below the post-physics helpers)
 struct FusedMainIn;
+// ... and for an instance without that tail: post_instance<true> on the four waves of the workgroup, its LDS in the dead contact-slot table (defined behind post_instance)
+LG_DEV void generic_fused_tail(const DevCtx* __restrict__ C, float* lds, const int32_t* __restrict__ ids, int n, int mode, const PostSink& K);
 LG_DEV void fused_prefetch(const DevCtx* __restrict__ C, float* SR, float* UB, int blk, int n, int htid, int64_t step, const float* values, const int32_t* __restrict__ ids, bool ro);
 // what the helper waves fetch in front of (F) for their work behind it (lg_fused_post.h): their scan point, their entries of the observation
 // table, and every context member / config flag that work reads -- behind (F) each of those was a scalar round trip of its own on the way to (G2)
@@ -562,7 +565,13 @@ template <int MODE, bool TMESH, bool HELPERS = false, int SPEC = 0>
 __attribute__((amdgpu_num_vgpr(120)))
 #endif
 __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, int nact,
-                                                      const int32_t* __restrict__ ids, int n, int act_stride, int fuse, PostSink sink) {
+                                                      const int32_t* __restrict__ ids, int n, int act_stride, int fuse_arg, PostSink sink) {
+  // fuse_arg != 0: the launch ends the policy step itself -- through the hand-tuned tail of lg_fused_post.h (four-legged instance: `fuse`), or, for an
+  // instance without one (six legs, height grid / plane: `gfuse`, round 5), by running the post kernel's own code (post_instance<true>: one wave per two
+  // envs) behind the write-back: the same arithmetic in the same order as the two-launch path, minus a kernel boundary.
+  constexpr bool GFUSABLE = LG_LEGS == 6 && !TMESH && MODE == 0 && HELPERS;      // (triangle-mesh instances of the hexapod have no LDS left for the statistics step's arrays)
+  const int fuse = LG_LEGS == 4 ? fuse_arg : 0;
+  const bool gfuse = GFUSABLE && fuse_arg != 0;
   // act_stride: floats between consecutive action rows (12, or horizon * 12 when the rows are one step of a (n, horizon, 12) plan)
   // contact-detection split of a heightfield step with actuator waves (see the helper loop); mesh terrains: two slots a wave
   // (heightfield / plane steps; on triangle-mesh terrains every wave takes the slot pair [2 w, 2 w + 2), the main wave [0, 2))
@@ -923,6 +932,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
       __syncthreads();
       if (s_last_f) fused_finalize(Ct, gridDim.x, tid_it, ro, nsteps);
     }
+    if (GFUSABLE && gfuse) {                           // (every row this workgroup's envs own is stored; the barrier makes them visible to its four waves)
+      __syncthreads();
+      generic_fused_tail(Ct, cst, ids, n, ro ? 1 : 0, sink);
+    }
     return;
     }
   }
@@ -1146,7 +1159,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #endif
     return;
   }
-  if (!valid) return;
+  if (valid) {
   if (TMESH && helpers) mesh_cache_io<false>(C, cqc, e, l, lane, MESH_PAIR0(0));
   if (fault && l == 0) C->reset_buf[e] = 2;
 
@@ -1177,7 +1190,12 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   // ---- rigid-body state of the post-step configuration (LR:118-120 refresh_rigid_body_state_tensor); with helper
   // waves, they write it (one link each) from the published final state while this wave stores the rest
   if (!helpers) write_rigid_body_state(C, lm_, e, l, s.root, s.q, s.qd);
+  }
   STAMP(10);
+  if (GFUSABLE && gfuse) {
+    __syncthreads();
+    generic_fused_tail(C, cst, ids, n, ro ? 1 : 0, sink);
+  }
   return;
   }
 }
@@ -2287,6 +2305,16 @@ __global__ __launch_bounds__(256) void post_kernel(const DevCtx* __restrict__ C,
   post_instance<false>(C, ids, n, mode, rew_out, rew_stride, L, (int)blockIdx.x, (int)gridDim.x, sink);
 }
 
+LG_DEV void generic_fused_tail(const DevCtx* __restrict__ C, float* lds, const int32_t* __restrict__ ids, int n, int mode, const PostSink& K) {
+#if NJ == 3
+  static_assert(4 * sizeof(PostLds) <= (size_t)LG_MAX_CP * CF_FIELDS * 64 * sizeof(float), "four post-physics instances must fit the contact-slot table");
+#endif
+  static_assert(EPB == 4 * EPBP || LG_LEGS != 6, "a physics workgroup's envs = four post-physics instances");
+  const int wv = threadIdx.x >> 6;
+  PostLds& L = reinterpret_cast<PostLds*>(lds)[wv];
+  post_instance<true>(C, ids, n, mode, K.rew_out, K.rew_stride, L, (int)blockIdx.x * 4 + wv, (int)gridDim.x * 4, K);
+}
+
 #if LG_LEGS == 4
 #include "lg_fused_post.h"
 
@@ -2780,6 +2808,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   if (const char* ev = getenv("LG_SPLIT")) c->split = atoi(ev) != 0;
   if (const char* ev = getenv("LG_FUSE")) c->fuse = atoi(ev) != 0;
   if (const char* ev = getenv("LG_PERSIST")) c->persist = atoi(ev) != 0;
+  if (const char* ev = getenv("LG_GFUSE")) c->gfuse = atoi(ev) != 0;
   if (const char* ev = getenv("LG_SPEC")) c->spec = atoi(ev) != 0;
   return c;
 }
@@ -2820,6 +2849,11 @@ static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t*
 // fuse: the post-physics step runs as the tail of the physics kernel (full steps of all envs with helper waves; LG_FUSE=0 keeps
 // the two-launch path, which every split / subset / rollout entry point uses anyway)
 static bool can_fuse(const lg_ctx* c) { return LG_LEGS == 4 && c->fuse && !c->h.extra_term && !c->h.cfg.keep_small_commands && !c->h.cfg.feet_air_time_ungated && (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) && c->h.P <= MAX_P; }
+// The six-legged instance can end lg_step / lg_step_transition in the physics launch too, through the post kernel's own code (generic_fused_tail): OFF unless
+// LG_GFUSE=1.  Measured (round 5, 4096 envs, same session): 0.159 / 0.162 ms in one launch against 0.158 / 0.153 ms in two -- the post-physics chain is latency-bound,
+// and on one wave per SIMD it takes as long as the separate kernel (eight workgroups per CU) plus its launch gap; round 1 found the same for the quadruped.  The
+// path stays as the bit-exact checker of a future hand-tuned tail (tests/test_elspider.py).
+static bool can_gfuse(const lg_ctx* c) { return LG_LEGS == 6 && NJ == 3 && c->gfuse && c->fuse && c->split && c->h.ter.mesh_type != LG_MESH_TRIMESH && !c->h.cfg.inject_sim_state; }
 // fuse: 0 = physics only (a post kernel follows), 1 = full policy step with the fused tail, 2 = fused ROLLOUT step of the listed envs, 3 = sink.nsteps of them in one launch
 static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = NDOF, int fuse = 0,
                            PostSink sink = PostSink{nullptr, nullptr, nullptr, nullptr, 0.f}) {
@@ -2886,7 +2920,7 @@ int lg_step(lg_ctx* c, const float* actions, void* stream) {
     c->prof_calls++;
   }
   if (ev) (void)hipEventRecord(ev[0], st);
-  const bool fuse = can_fuse(c);
+  const bool fuse = can_fuse(c) || can_gfuse(c);
   launch_physics(c, st, actions, nullptr, c->h.N, NDOF, fuse ? 1 : 0);
   if (ev) (void)hipEventRecord(ev[1], st);
   if (fuse) {                                            // one launch per policy step
@@ -2906,7 +2940,7 @@ int lg_step_transition(lg_ctx* c, const float* actions, float* next_observations
   if (!actions || !values || !rewards || !dones) { c->err = "lg_step_transition: null row"; return LG_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   const PostSink sink{next_observations, values, rewards, dones, gamma};
-  if (can_fuse(c)) {
+  if (can_fuse(c) || can_gfuse(c)) {
     launch_physics(c, st, actions, nullptr, c->h.N, NDOF, 1, sink);
     HIP_TRY(c, hipGetLastError());
     return LG_OK;

@@ -477,3 +477,46 @@ def test_foot_track_hang_task_is_refused_with_the_reference_error():
     from tests.test_env_api import make
     with pytest.raises(RuntimeError, match=r"size of tensor a \(94\) must match the size of tensor b \(88\)"):
         make("foot_track_elspider_air_hang", 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n", [("flat_lstm", 130), ("rough_lstm", 61)])
+def test_hexapod_step_in_one_launch_equals_physics_plus_post_kernel(kind, n, monkeypatch):
+    """`lg_step` of the six-legged instance ending inside the physics launch (LG_GFUSE=1: the post kernel's own code on the four waves of a physics
+    workgroup, `generic_fused_tail`; off by default -- measured no faster than two launches) against the two-launch path: every byte the library owns,
+    step after step with resets, time-outs, pushes and command resampling, ragged env counts (the last workgroup and its last post-physics instance are
+    partial)."""
+    import torch
+    from extended_legged_gym_amd.native import NativeCore
+
+    def shorten(cfg):
+        cfg.commands.resampling_time = 0.1
+        cfg.domain_rand.push_interval_s = 0.14
+        cfg.env.episode_length_s = 0.5
+
+    def build(fuse):
+        monkeypatch.setenv("LG_GFUSE", "1" if fuse else "0")
+        cfg, s, terrain, _ = hexapod_setup(n, kind, seed=5, mutate=shorten)
+        core = NativeCore(s, "cuda:0")
+        rng = np.random.default_rng(1)
+        core.t["friction_coeffs"].copy_(torch.from_numpy(rng.uniform(0.5, 1.25, n).astype(np.float32)))
+        if terrain is not None:
+            lv = rng.integers(0, 4, n); ty = np.floor(np.arange(n) / (n / 4)).astype(np.int64)
+            core.t["terrain_levels"].copy_(torch.from_numpy(lv)); core.t["terrain_types"].copy_(torch.from_numpy(ty))
+            core.t["env_origins"].copy_(torch.from_numpy(terrain.env_origins[lv, ty].astype(np.float32)))
+        core.reset_idx(torch.arange(n, device="cuda"))
+        return core
+
+    one, two = build(True), build(False)
+    g = torch.Generator().manual_seed(2)
+    resets = touts = 0
+    for it in range(45):
+        a = (1.5 * torch.randn(n, 18, generator=g)).cuda()
+        one.step(a); two.step(a)
+        torch.cuda.synchronize()
+        for name in one.t:
+            assert torch.equal(one.t[name], two.t[name]), (it, name)
+        resets += int(one.t["reset_buf"].sum()); touts += int(one.t["time_out_buf"].sum())
+    assert torch.equal(one.arena, two.arena)
+    assert touts > 0 and resets >= touts and torch.isfinite(one.t["obs_buf"]).all()      # (only a flip ends a hexapod's episode early)
+    one.close(); two.close()
