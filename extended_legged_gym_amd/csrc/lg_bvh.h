@@ -164,10 +164,15 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const float* tb, V3 o, V3 d, float
   const float* xb = tb; const float* yb = tb + G.nx + 1;
   const V3 inv = v3(1.f / (fabsf(d.x) > 1e-12f ? d.x : copysignf(1e-12f, d.x)), 1.f / (fabsf(d.y) > 1e-12f ? d.y : copysignf(1e-12f, d.y)),
                     1.f / (fabsf(d.z) > 1e-12f ? d.z : copysignf(1e-12f, d.z)));
+  // a ray that does not move along an axis (|d| <= 1e-12: a vertical ray) never crosses that axis's lines: its boundary times are -inf / +inf while it
+  // is between the outer lines (those included), not the 0 * 1e12 a start exactly ON a line gives
+  const bool mvx = fabsf(d.x) > 1e-12f, mvy = fabsf(d.y) > 1e-12f;
   // the part of the ray over the lattice
   float t0 = 0.f, t1 = max_dist;
   {
-    const float ax = (xb[0] - o.x) * inv.x, bx = (xb[G.nx] - o.x) * inv.x, ay = (yb[0] - o.y) * inv.y, by = (yb[G.ny] - o.y) * inv.y;
+    const bool inx = o.x >= xb[0] && o.x <= xb[G.nx], iny = o.y >= yb[0] && o.y <= yb[G.ny];
+    const float ax = mvx ? (xb[0] - o.x) * inv.x : (inx ? -3.0e38f : 3.0e38f), bx = mvx ? (xb[G.nx] - o.x) * inv.x : (inx ? 3.0e38f : -3.0e38f);
+    const float ay = mvy ? (yb[0] - o.y) * inv.y : (iny ? -3.0e38f : 3.0e38f), by = mvy ? (yb[G.ny] - o.y) * inv.y : (iny ? 3.0e38f : -3.0e38f);
     t0 = fmaxf(t0, fmaxf(fminf(ax, bx), fminf(ay, by)));
     t1 = fminf(t1, fminf(fmaxf(ax, bx), fmaxf(ay, by)));
   }
@@ -177,15 +182,22 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const float* tb, V3 o, V3 d, float
   int ix = raygrid_locate(xb, G.nx, px, (int)((px - xb[0]) * ux)), iy = raygrid_locate(yb, G.ny, py, (int)((py - yb[0]) * uy));
   const int sx = inv.x >= 0.f ? 1 : -1, sy = inv.y >= 0.f ? 1 : -1;
   const int ox = sx > 0 ? 1 : 0, oy = (sy > 0 ? 1 : 0) + G.nx + 1;     // offsets into tb of the boundary AHEAD of cell ix / iy
-  // a ray that does not move along an axis (|d| <= 1e-12: a vertical ray) never crosses that axis's lines: its boundary time is +inf, not the
-  // 0 * 1e12 a start exactly ON a lattice line gives (the cell was then left before it was looked at: a miss where the tree walk hits)
-  const bool mvx = fabsf(d.x) > 1e-12f, mvy = fabsf(d.y) > 1e-12f;
-  float tmx = mvx ? (tb[ix + ox] - o.x) * inv.x : 3.0e38f, tmy = mvy ? (tb[iy + oy] - o.y) * inv.y : 3.0e38f;
+  // (the boundary AHEAD of a cell on such an axis: +inf as well -- the cell was left before it was looked at: a miss where the tree walk hits)
+  // ... and a ray without motion across the lines of an axis that starts exactly ON one of them runs down the border of two columns of cells: triangles
+  // of the - side column reach it only with an edge (they are not listed in the + side cells), and where the slope correction folded the surface the
+  // nearest hit may be one of theirs.  Such rays (a measure-zero set; tested wave-wide, so other waves pay three ballots) walk the - side column(s) too.
+  const int ix0 = ix, iy0 = iy;
+  const bool lx = !mvx && ix0 > 0 && px == xb[ix0], ly = !mvy && iy0 > 0 && py == yb[iy0];
   float best = max_dist; bool hit = false;
+  for (int var = 0; var < 4; ++var) {
+  const bool use = var == 0 || (((var & 1) == 0 || lx) && ((var & 2) == 0 || ly));
+  if (var > 0 && __ballot(use) == 0ull) continue;
+  ix = ix0 - (var & 1); iy = iy0 - (var >> 1);
+  float tmx = mvx ? (tb[ix + ox] - o.x) * inv.x : 3.0e38f, tmy = mvy ? (tb[iy + oy] - o.y) * inv.y : 3.0e38f;
   float tcur = t0;
   // the ends of a cell's stretch of the ray are rounded: the z range is taken a little beyond either end
   const float padc = 2e-5f * fabsf(t1) + 1e-6f;
-  bool done = false;
+  bool done = !use;
   // one cell on, without branches: the axis whose boundary comes first, the boundary ahead of the new cell from LDS
   auto advance = [&]() {
     const bool stx = tmx <= tmy;
@@ -235,6 +247,7 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const float* tb, V3 o, V3 d, float
       if ((hit && best <= tcur) || !(tnext < t1)) done = true; else advance();
       tcur = tnext;
     }
+  }
   }
   return hit ? best : -1.f;
 }

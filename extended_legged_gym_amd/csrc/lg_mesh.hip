@@ -114,8 +114,14 @@ struct Collapser {
       BvhNode4& N = n4[me];
       if (k >= nk) { N.minx[k] = N.miny[k] = N.minz[k] = 1e30f; N.maxx[k] = N.maxy[k] = N.maxz[k] = -1e30f; N.child[k] = BVH4_EMPTY; N.pad[k] = 0; continue; }
       const BvhNode& c = n2[kids[k]];
-      N.minx[k] = c.bmin[0]; N.miny[k] = c.bmin[1]; N.minz[k] = c.bmin[2];
-      N.maxx[k] = c.bmax[0]; N.maxy[k] = c.bmax[1]; N.maxz[k] = c.bmax[2];
+      // Boxes a micrometre (and two ulps) wider than their triangles: a ray without motion along an axis that runs exactly down a box face (a vertical ray on a lattice line
+      // of a heightfield mesh) then lies INSIDE the box -- the slab test's 0 * 1e12 for that axis rejected the box on the ray's - side, and with it
+      // triangles that reach the ray with an edge.  Wider boxes change no result (the triangle tests decide), only which leaves are looked at.
+      // (an absolute part as well: two ulps of a coordinate near zero are denormal, and 1e-45 * 1e12 is still nothing)
+      auto lo = [](float v) { return nextafterf(nextafterf(v - 1e-6f, -INFINITY), -INFINITY); };
+      auto hi = [](float v) { return nextafterf(nextafterf(v + 1e-6f, INFINITY), INFINITY); };
+      N.minx[k] = lo(c.bmin[0]); N.miny[k] = lo(c.bmin[1]); N.minz[k] = lo(c.bmin[2]);
+      N.maxx[k] = hi(c.bmax[0]); N.maxy[k] = hi(c.bmax[1]); N.maxz[k] = hi(c.bmax[2]);
       N.pad[k] = 0;
       if (c.count > 0) N.child[k] = ~((c.left_first << 3) | (c.count - 1));
       else { const int idx = emit(kids[k]); n4[me].child[k] = idx; }   // (n4 may have been reallocated: index, not reference)

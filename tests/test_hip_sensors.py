@@ -119,19 +119,22 @@ def test_ray_lattice_returns_the_hits_of_the_tree(monkeypatch):
     # (whether a ray that runs exactly down the mesh's outer edge hits is decided by the last bit of the edge tests; what is held is that the two
     #  structures decide alike)
     assert int(((fg != fb) | ((hg - hb).abs().max(dim=1).values > 1e-5)).sum()) <= 3
-    # the same rays on lattice lines in the middle of the mesh, where cells on both sides carry triangles: (nearly) every ray hits, in both structures, where
-    # the brute-force scan of the oracle hits.  (A ray with no motion along an axis that starts exactly on a lattice line / a box face belongs to the cell /
-    # box on its + side in both structures; the barycentric band RAY_EDGE_EPS lets it hit the triangle whose edge it runs down.)
+    # the same rays on lattice lines in the middle of the mesh: both structures answer as the brute-force scan of the oracle does.  What that takes for a ray
+    # with no motion across a lattice line that starts exactly ON it (this mesh is folded by the slope correction nearly everywhere -- +-0.1 m of noise on
+    # 0.1 m cells -- so the nearest hit is often on a triangle that only reaches the ray with an edge): the barycentric band RAY_EDGE_EPS in the triangle
+    # test, BVH boxes a micrometre wider than their triangles (the slab test's 0 * 1e12 rejected the box on the ray's - side), the lattice walk down the
+    # - side column of cells as well and its clip against the outer lines taken as +-inf for an axis without motion.
     ob[: m // 2, 0] = xs[len(xs) // 2]; ob[m // 2:, 1] = ys[len(ys) // 2]; ob[:50, 1] = ys[len(ys) // 2]
     to = torch.from_numpy(ob).cuda()
     hg, fg = raycast_mesh(to, td, 10.0, lattice)
     hb, fb = raycast_mesh(to, td, 10.0, tree)
     assert float(fb.float().mean()) > 0.95 and int(((fg != fb) | ((hg - hb).abs().max(dim=1).values > 1e-5)).sum()) <= 3
     h_ref, f_ref = raycast_bruteforce(v, t, ob, db, 10.0)
-    f = fb.cpu().numpy()
-    assert (f != f_ref).mean() < 0.02
-    both = f & f_ref
-    assert np.abs(hb.cpu().numpy()[both] - h_ref[both]).max() < 2e-4
+    for h, f in ((hg, fg), (hb, fb)):
+        f = f.cpu().numpy()
+        assert (f != f_ref).sum() <= 3
+        both = f & f_ref
+        assert (np.abs(h.cpu().numpy()[both] - h_ref[both]).max(axis=1) > 1e-4).sum() <= 3
 
 
 def test_raycaster_sensor_matches_reference_arithmetic():
