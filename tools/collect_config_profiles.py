@@ -28,7 +28,7 @@ ALGO = {
 out = {}
 for W in ("3", "4", "5", "hexapod", "rollout"):
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_cfg{W}")
-    stats = sorted(glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True))
+    stats = sorted(glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)   # (newest: gpurun_out/ keeps earlier runs)
     if not stats:
         continue
     shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_cfg{W}_kernel_stats.csv"))

@@ -23,7 +23,7 @@ def out(name):
 
 if os.path.exists(os.path.join(prof, "summary.txt")):
     shutil.copy(os.path.join(prof, "summary.txt"), out("rocprofv3_summary.txt"))
-stats = sorted(glob.glob(os.path.join(prof, "trace", "**", "*kernel_stats.csv"), recursive=True))
+stats = sorted(glob.glob(os.path.join(prof, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)   # (newest: gpurun_out/ keeps earlier runs)
 if stats:
     shutil.copy(stats[0], out("kernel_stats.csv"))
 for src, name in (("trace_bench.json", "bench_under_rocprof.json"),):
