@@ -150,6 +150,18 @@ class lg_pose_params(C.Structure):
                 ("num_heights", i32), ("num_proprio", i32)]
 
 
+class lg_foottrack_params(C.Structure):
+    _fields_ = [("dt", f32), ("gait_period", f32), ("swing_ema", f32), ("reward_sigma", f32), ("swing_height", f32), ("phase_offsets", f32 * 6),
+                ("base_bounds", (f32 * 6) * 2), ("foot_mean", f32 * 18), ("foot_sigma", f32 * 18), ("base_interval", f32), ("base_max_vel", f32),
+                ("foot_interval", f32), ("foot_max_vel", f32), ("scales", f32 * 5), ("scale_termination", f32), ("only_positive_rewards", i32),
+                ("max_episode_length_s", f32), ("clip_observations", f32), ("num_bodies", i32), ("feet_indices", i32 * 6), ("add_noise", i32)]
+
+
+class lg_foottrack_state(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("base_pos", "base_quat", "base_pos_shift", "base_quat_shift", "base_x_world", "base_y_world", "foot_pos", "gait_idx",
+                                          "gait_phases", "last_contacts", "bw_cur", "bw_tgt", "bw_timer", "fw_cur", "fw_tgt", "fw_timer")]
+
+
 class lg_depth_params(C.Structure):
     _fields_ = [("width", i32), ("height", i32), ("resized_width", i32), ("resized_height", i32), ("buffer_len", i32),
                 ("near_clip", f32), ("far_clip", f32), ("position", f32 * 3), ("quat_offset", f32 * 4)]
@@ -212,6 +224,10 @@ def declare_product(lib):
     lib.lg_heightfield_to_trimesh.restype = C.c_int
     lib.lg_pose_layer_step.argtypes = [C.POINTER(lg_pose_params), i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.lg_pose_layer_step.restype = C.c_int
+    lib.lg_foottrack_stray.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.lg_foottrack_stray.restype = C.c_int
+    lib.lg_foottrack_layer_step.argtypes = [C.POINTER(lg_foottrack_params), C.POINTER(lg_foottrack_state), i32, i32] + [vp] * 8 + [i32] + [vp] * 10
+    lib.lg_foottrack_layer_step.restype = C.c_int
     lib.lg_mesh_create.argtypes = [C.POINTER(f32), C.c_int64, C.POINTER(i32), C.c_int64, C.c_int]
     lib.lg_mesh_create.restype = vp
     lib.lg_mesh_destroy.argtypes = [vp]
@@ -283,4 +299,4 @@ PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
                    "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_ray_lattice", "lg_mesh_last_error",
                    "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update",
-                   "lg_terrain_generate", "lg_heightfield_to_trimesh", "lg_pose_layer_step", "lg_set_reward_terms", "lg_set_async_gait", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed", "lg_gather_step_rows", "lg_step_subset_rows", "lg_step_rollout", "lg_set_extra_termination"]
+                   "lg_terrain_generate", "lg_heightfield_to_trimesh", "lg_pose_layer_step", "lg_set_reward_terms", "lg_set_async_gait", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed", "lg_gather_step_rows", "lg_step_subset_rows", "lg_step_rollout", "lg_set_extra_termination", "lg_foottrack_stray", "lg_foottrack_layer_step"]

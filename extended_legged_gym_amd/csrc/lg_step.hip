@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const int krow = env_ok ? kq : n - 1;     // whole groups are (in)valid together; invalid groups compute on a copy and store nothing
   const int e = ids ? ids[krow] : krow;
   const int e_q = e, krow_q = krow, bid_q = bid;
-  const lg_robot_model* __restrict__ m = &C->model;
+  const lg_robot_model* __restrict__ m = &C->model; (void)m;
   const lg_config& g = C->cfg;
   const bool net = g.control_type == LG_CTRL_ACTUATOR_NET;
   // The rows this wave starts from are requested in FRONT of the table copy and its barrier (loads return in order: by the time the

@@ -132,8 +132,11 @@ class FootTrackElSpider(ElSpider):
     """Task `foot_track_elspider_air_flat` (reference `elspider.py:547-676`, `envs/__init__.py:159-160`): the hexapod asked to follow a Raibert-style
     planner -- a reference base pose that integrates the velocity command, six footholds swinging in two tripods (`utils/raibert_planner.py`).
 
-    The native step runs everything `ElSpider` runs; this class adds, as device-side torch between and behind the two halves of the split step
-    (`lg_step_physics` ... `lg_post_physics_step`):
+    The native step runs everything `ElSpider` runs; this class adds, between and behind the two halves of the split step (`lg_step_physics` ...
+    `lg_post_physics_step`), a device layer: three launches of the library (`lg_foottrack_stray`, `lg_foottrack_layer_step`: `csrc/lg_foottrack.hip`, planner
+    type 1) -- or the same arithmetic in torch (`_after_native_torch` over `utils/raibert_planner.py`: planner type 0, `LG_FOOTTRACK_TORCH=1`, and the checker
+    of the kernels; ~350 small launches, 4.7 ms per step at 4096 envs against 0.2 ms).  The random draws of a step (the two walks' redraws, the observation
+    noise) are made here, every step, and handed to either:
       * `check_termination` (`:583-588`): an env whose base strays more than 0.5 m from the planner's base position ends its episode -- a per-env flag
         bound with `lg_set_extra_termination`, evaluated after the physics and OR-ed by the kernel into the contact terminations, so resets, time-out
         flags and the episode statistics see it as the reference's `reset_buf |=` does;
@@ -185,6 +188,11 @@ class FootTrackElSpider(ElSpider):
         self._layer_sums = torch.zeros(len(RAIBERT_TERMS), self.num_envs, device=self.device)
         self._layer_extras = torch.zeros(len(RAIBERT_TERMS), device=self.device)
         self._bind_layer_terms()
+        import os
+        self._native_layer = planner_type == 1 and os.environ.get("LG_FOOTTRACK_TORCH", "0") != "1"
+        self._planner_steps = 0
+        self._layer_acc = torch.zeros(6, dtype=torch.float64, device=self.device)
+        self._stray_diff = torch.zeros(self.num_envs, device=self.device)
 
     def _bind_layer_terms(self):
         stage = self._get_reward_scales(self.reward_scales_stage)
@@ -203,7 +211,74 @@ class FootTrackElSpider(ElSpider):
         return (p.penalty_base_pos_track(rb[:, 0, 0:3]), p.penalty_base_quat_track(rb[:, 0, 3:7]), p.reward_foot_pos_track(feet),
                 p.penalty_foot_pos_track_z(feet), p.penalty_foot_swing_contact(self.contact_forces, self.feet_indices))
 
+    # ---- the device layer (csrc/lg_foottrack.hip)
+    def _layer_params(self):
+        from extended_legged_gym_amd import abi
+        p, c = abi.lg_foottrack_params(), self.raibert_planner.cfg
+        p.dt, p.gait_period, p.swing_ema, p.reward_sigma, p.swing_height = c.dt, c.gait_period, c.swing_foot_track_ema, c.reward_sigma, 0.1
+        for i in range(6):
+            p.phase_offsets[i] = c.foot_phases[i]
+            p.feet_indices[i] = int(self.feet_indices[i])
+        bw, fw = self.raibert_planner.base_pose_randwalk, self.raibert_planner.foothold_base_randwalk
+        for i in range(6):
+            p.base_bounds[0][i], p.base_bounds[1][i] = float(bw.bounds[0, i]), float(bw.bounds[1, i])
+        for i in range(18):
+            p.foot_mean[i], p.foot_sigma[i] = float(fw.bounds[0, i]), float(fw.bounds[1, i])
+        p.base_interval, p.base_max_vel, p.foot_interval, p.foot_max_vel = bw.target_interval, bw.max_track_vel, fw.target_interval, fw.max_track_vel
+        for k in range(5):
+            p.scales[k] = self._layer_scales[k]
+        p.scale_termination, p.only_positive_rewards = self._termination_scale, int(self._only_positive)
+        p.max_episode_length_s, p.clip_observations = float(self.max_episode_length_s), float(self.cfg.normalization.clip_observations)
+        p.num_bodies, p.add_noise = int(self.num_bodies), int(bool(self.add_noise))
+        return p
+
+    def _layer_state(self):
+        """Pointers to the planner's own tensors, taken afresh every call (its torch methods -- `reset_idx` from `env.reset()` -- rebind some of them)."""
+        from extended_legged_gym_amd import abi
+        pl = self.raibert_planner
+        bw, fw = pl.base_pose_randwalk, pl.foothold_base_randwalk
+        st, keep = abi.lg_foottrack_state(), []
+        for name, t in (("base_pos", pl.base_pos), ("base_quat", pl.base_quat), ("base_pos_shift", pl.base_pos_shift), ("base_quat_shift", pl.base_quat_shift),
+                        ("base_x_world", pl.base_x_world), ("base_y_world", pl.base_y_world), ("foot_pos", pl.foot_pos), ("gait_idx", pl.gait_idx),
+                        ("gait_phases", pl.gait_phases), ("last_contacts", pl.last_contacts), ("bw_cur", bw.current_pos), ("bw_tgt", bw.target_pos),
+                        ("bw_timer", bw.timers), ("fw_cur", fw.current_pos), ("fw_tgt", fw.target_pos), ("fw_timer", fw.timers)):
+            assert t.is_contiguous() and t.element_size() == (1 if name == "last_contacts" else 4), name
+            setattr(st, name, t.data_ptr())
+            keep.append(t)
+        return st, keep
+
+    def _after_native_device(self, draws, noise_u):
+        import ctypes as C
+        from extended_legged_gym_amd import abi
+        lib, t = self.core.lib, self.core.t
+        if getattr(self, "_layer_par", None) is None:
+            self._layer_par = self._layer_params()
+        st, keep = self._layer_state()
+
+        def p(x):
+            return C.c_void_p(None if x is None else x.data_ptr())
+        cmd = self.commands
+        rc = lib.lg_foottrack_layer_step(C.byref(self._layer_par), C.byref(st), self.num_envs, int(self._planner_steps > 0), p(self._native_obs), p(self._native_rew),
+                                         p(t["reset_buf"]), p(t["time_out_buf"]), p(t["rigid_body_state"]), p(t["contact_forces"]), p(t["root_states"]),
+                                         p(cmd), int(cmd.stride(0)), p(draws[0]), p(draws[1]), p(noise_u), p(self.noise_scale_vec), p(self.obs_buf), p(self.rew_buf),
+                                         p(self._layer_sums), p(self._layer_extras), p(self._layer_acc),
+                                         C.c_void_p(torch.cuda.current_stream(self.obs_buf.device).cuda_stream))
+        if rc != abi.LG_OK:
+            raise RuntimeError(f"lg_foottrack_layer_step failed ({rc})")
+        self.raibert_planner._swing_from_phases = True
+        del keep
+
     def _after_native(self):
+        n = self.num_envs
+        draws = (torch.rand(n, 6, device=self.device), torch.randn(n, 18, device=self.device))
+        noise_u = torch.rand(n, self.num_obs, device=self.device) if self.add_noise else None
+        if self._native_layer:
+            self._after_native_device(draws, noise_u)
+        else:
+            self._after_native_torch(draws, noise_u)
+        self._planner_steps += 1
+
+    def _after_native_torch(self, draws, noise_u):
         rew = self._native_rew.clone()
         term = self._termination_scale * (self.reset_buf & ~self.time_out_buf).float() if self._termination_scale != 0. else None
         if term is not None:          # (`compute_reward`, `legged_robot.py:215-232`: the termination term joins after the clip)
@@ -223,19 +298,30 @@ class FootTrackElSpider(ElSpider):
                     self._layer_extras[k] = torch.mean(self._layer_sums[k, env_ids]) / self.max_episode_length_s
             self._layer_sums[:, env_ids] = 0.
             self.raibert_planner.reset_idx(self.base_pos, self.base_quat, env_ids)
-        self.compute_observations()
-        self.raibert_planner.step(self.commands[:, :3])
+        self.compute_observations(noise_u)
+        self.raibert_planner.step(self.commands[:, :3], draws if not self.raibert_planner.simple else None)
 
-    def compute_observations(self):
+    def compute_observations(self, noise_u=None):
         nat = self._native_obs
         self.obs_buf[:] = torch.cat((nat[:, 0:9], self.raibert_planner.get_obs_tensor(self.base_pos, self.base_quat), nat[:, 12:]), dim=-1)
         if self.add_noise:
-            self.obs_buf += (2 * torch.rand_like(self.obs_buf) - 1) * self.noise_scale_vec
+            self.obs_buf += (2 * (torch.rand_like(self.obs_buf) if noise_u is None else noise_u) - 1) * self.noise_scale_vec
         clip = self.cfg.normalization.clip_observations
         torch.clip(self.obs_buf, -clip, clip, out=self.obs_buf)
 
     def check_termination(self):
         """The planner's part of `check_termination` (`:583-588`), on the pose the physics just produced."""
+        if self._native_layer:
+            import ctypes as C
+            pb = self.raibert_planner.base_pos
+            assert pb.is_contiguous()
+            rc = self.core.lib.lg_foottrack_stray(self.num_envs, C.c_void_p(self.root_states.data_ptr()), C.c_void_p(pb.data_ptr()),
+                                                  C.c_void_p(self._stray_diff.data_ptr()), C.c_void_p(self._stray.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream(self._stray.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"lg_foottrack_stray failed ({rc})")
+            self.raibert_pos_diff = self._stray_diff
+            return
         self.raibert_pos_diff = torch.norm(self.base_pos - self.raibert_planner.base_pos, dim=1)
         self._stray.copy_(self.raibert_pos_diff > 0.5)
 
@@ -262,4 +348,5 @@ class FootTrackElSpider(ElSpider):
         if changed:
             self._layer_sums.zero_()
             self._bind_layer_terms()
+            self._layer_par = None
         return changed

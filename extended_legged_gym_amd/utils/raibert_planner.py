@@ -32,10 +32,21 @@ class RandomWalker:
             return torch.rand((self.num_envs, self.dim), device=self.bounds.device) * (self.bounds[1] - self.bounds[0]) + self.bounds[0]
         return torch.normal(self.bounds[0].unsqueeze(0).expand(self.num_envs, -1), self.bounds[1].unsqueeze(0).expand(self.num_envs, -1))
 
-    def step(self, dt):
+    def fresh_from(self, draw):
+        """Candidate targets from raw draws (uniforms in [0, 1) | standard normals), the arithmetic of `_random_positions`."""
+        if self.distribution_type == "uniform":
+            return draw * (self.bounds[1] - self.bounds[0]) + self.bounds[0]
+        return self.bounds[0] + self.bounds[1] * draw
+
+    def step(self, dt, fresh=None):
+        """`fresh` (optional, (N, dim)): the targets due envs take, drawn by the caller (the env hands the same draws to the device layer and to this
+        checker, and draws every step without a host round trip); None: drawn here, when some env is due, in the reference's order."""
         self.timers -= dt
         due = self.timers <= 0
-        if torch.any(due):
+        if fresh is not None:
+            self.target_pos = torch.where(due.unsqueeze(-1), fresh, self.target_pos)
+            self.timers = torch.where(due, torch.full_like(self.timers, float(self.target_interval)), self.timers)
+        elif torch.any(due):
             self.target_pos[due] = self._random_positions()[due]
             self.timers[due] = self.target_interval
         direction = self.target_pos - self.current_pos
@@ -103,6 +114,7 @@ class RaibertPlanner:
         self.gait_phases = torch.zeros(num_envs, 6, **f32)
         self.phase_offsets = torch.tensor(c.foot_phases, **f32)
         self.last_contacts = torch.zeros(num_envs, 6, dtype=torch.bool, device=device)
+        self._swing_from_phases = False
         self.foot_is_swing = torch.zeros(6, **f32)
         if simple:
             self.nominal_foothold = torch.tensor(c.nominal_foothold_base, **f32).repeat(num_envs, 1, 1) + torch.randn(num_envs, 6, 3, device=device) * c.simple_nominal_foothold_base_sigma
@@ -115,6 +127,15 @@ class RaibertPlanner:
                                                        c.foothold_target_track_kp, c.foothold_max_track_vel, "normal")
 
     # ---- what the random walks say right now (type 1) / the per-env constants (type 0)
+    # (a property: with the env's device layer stepping the planner, the flags are read off the phases it left)
+    @property
+    def foot_is_swing(self):
+        return (self.gait_phases[0] < 0.5).float() if self._swing_from_phases else self._foot_is_swing
+
+    @foot_is_swing.setter
+    def foot_is_swing(self, value):
+        self._foot_is_swing = value
+
     def _footholds_base(self):
         return self.nominal_foothold.clone() if self.simple else self.foothold_base_randwalk.positions.view(self.num_envs, 6, 3)
 
@@ -170,11 +191,16 @@ class RaibertPlanner:
                 torch.randn(len(env_ids), 6, 3, device=self.device) * c.simple_nominal_foothold_base_sigma
         self.foot_pos[env_ids] = self._place_feet(env_ids)
 
-    def step(self, command):
+    def step(self, command, draws=None):
+        """`draws` (optional): (uniforms (N, 6), standard normals (N, 18)) for the two walks' redraws of this step (`RandomWalker.step`)."""
         c = self.cfg
         if not self.simple:
-            self.base_pose_randwalk.step(c.dt)
-            self.foothold_base_randwalk.step(c.dt)
+            if draws is None:
+                self.base_pose_randwalk.step(c.dt)
+                self.foothold_base_randwalk.step(c.dt)
+            else:
+                self.base_pose_randwalk.step(c.dt, self.base_pose_randwalk.fresh_from(draws[0]))
+                self.foothold_base_randwalk.step(c.dt, self.foothold_base_randwalk.fresh_from(draws[1]))
         self.base_x_world = quat_apply(self.base_quat, self.x_vec)
         self.base_y_world = quat_apply(self.base_quat, self.y_vec)
         # where the base stands at the middle of every foot's next stance

@@ -521,6 +521,44 @@ int lg_pose_layer_step(const lg_pose_params* params, int32_t n, float* pose_cmd,
                        const float* u, const float* noise_u, const float* noise_scale_vec, float* obs_out, float* rew_out, double* acc,
                        void* stream);
 
+/* What FootTrackElSpider adds to an env step (reference envs/elspider_air/elspider.py:547-676; the foothold planner of type 1, utils/raibert_planner.py:304-497,
+ * with its two random walks, utils/math_utils.py:217-288), on the device: csrc/lg_foottrack.hip.  The planner's state lives in caller-owned device arrays
+ * (lg_foottrack_state), one row per env, updated in place.
+ *   lg_foottrack_stray       between lg_step_physics and lg_post_physics_step: |root position - planner base position| > 0.5 m -> the per-env flags that
+ *                            lg_set_extra_termination has bound (check_termination, :583-588);
+ *   lg_foottrack_layer_step  behind lg_post_physics_step: the five `_reward_raibert_*` terms (:660-674) on the pre-reset pose added to the native reward
+ *                            before the positivity clip, their episode sums (sums: (5, n)) and `extras` means (acc: six doubles of scratch, zero before the
+ *                            first call), the planner re-anchored at reset envs (:590-592), the 94-entry observation row (:561-581; noise_u: (n, 94) uniforms,
+ *                            noise_scale_vec: 94 scales), then the planner's step with the commands (:594-597).  u_base (n, 6) uniforms and n_foot (n, 18)
+ *                            standard normals: the targets a walk redraws in this step.  planner_stepped = 0 until the planner has taken its first step
+ *                            (all six feet count as supporting before). */
+typedef struct lg_foottrack_params {
+  float dt, gait_period, swing_ema, reward_sigma, swing_height;
+  float phase_offsets[6];
+  float base_bounds[2][6];               /* uniform walk [min | max] of (x shift, y shift, height, yaw, pitch, roll) */
+  float foot_mean[18], foot_sigma[18];   /* normal walk of the six nominal footholds in the base frame */
+  float base_interval, base_max_vel, foot_interval, foot_max_vel;
+  float scales[5];                       /* x dt: raibert_base_pos_track, raibert_base_quat_track, raibert_foot_pos_track, raibert_foot_pos_track_z, raibert_foot_swing_contact */
+  float scale_termination;
+  int32_t only_positive_rewards;
+  float max_episode_length_s, clip_observations;
+  int32_t num_bodies, feet_indices[6];
+  int32_t add_noise;
+} lg_foottrack_params;
+typedef struct lg_foottrack_state {
+  float *base_pos, *base_quat, *base_pos_shift, *base_quat_shift;   /* (n, 3) (n, 4) (n, 3) (n, 4) */
+  float *base_x_world, *base_y_world;                                /* (n, 3): the planner's heading axes as its last step left them */
+  float *foot_pos, *gait_idx, *gait_phases;                          /* (n, 6, 3) (n) (n, 6) */
+  uint8_t* last_contacts;                                            /* (n, 6) */
+  float *bw_cur, *bw_tgt, *bw_timer;                                 /* base-pose walk: (n, 6) (n, 6) (n) */
+  float *fw_cur, *fw_tgt, *fw_timer;                                 /* foothold walk: (n, 18) (n, 18) (n) */
+} lg_foottrack_state;
+int lg_foottrack_stray(int32_t n, const float* root_states, const float* planner_base_pos, float* pos_diff, uint8_t* stray, void* stream);
+int lg_foottrack_layer_step(const lg_foottrack_params* params, const lg_foottrack_state* state, int32_t n, int32_t planner_stepped, const float* nat_obs,
+                            const float* nat_rew, const uint8_t* reset, const uint8_t* time_out, const float* rigid_body_state, const float* contact_forces,
+                            const float* root_states, const float* commands, int32_t cmd_stride, const float* u_base, const float* n_foot, const float* noise_u,
+                            const float* noise_scale_vec, float* obs_out, float* rew_out, float* sums, float* extras, double* acc, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the caller's stream around the kernels of lg_step.
  * lg_profile_begin arms up to `max_samples` instrumented steps (every `stride`-th lg_step call is sampled);
  * lg_profile_end synchronises the events and returns the mean duration in ms of {physics, post-physics, finalize}

@@ -520,3 +520,56 @@ def test_hexapod_step_in_one_launch_equals_physics_plus_post_kernel(kind, n, mon
     assert torch.equal(one.arena, two.arena)
     assert touts > 0 and resets >= touts and torch.isfinite(one.t["obs_buf"]).all()      # (only a flip ends a hexapod's episode early)
     one.close(); two.close()
+
+
+@pytest.mark.gpu
+def test_foot_track_device_layer_equals_the_torch_layer(monkeypatch):
+    """`lg_foottrack_stray` / `lg_foottrack_layer_step` (csrc/lg_foottrack.hip) against the torch layer they replace (`LG_FOOTTRACK_TORCH=1`: the arithmetic the
+    reference-recorded planner vectors pin), fed the same random draws: observations, rewards, flags, episode sums, `extras` and every piece of planner
+    state, step after step, with strayed robots, time-outs, command resampling and observation noise."""
+    import torch
+    from extended_legged_gym_amd.envs.elspider_air.elspider import RAIBERT_TERMS
+    from tests.test_env_api import make
+    n = 300
+
+    def build(torch_layer):
+        monkeypatch.setenv("LG_FOOTTRACK_TORCH", "1" if torch_layer else "0")
+        torch.manual_seed(3); np.random.seed(3)
+        env = make("foot_track_elspider_air_flat", n, **{"domain_rand.push_robots": False, "env.episode_length_s": 1.2, "commands.resampling_time": 0.4})
+        assert env._native_layer == (not torch_layer)
+        torch.manual_seed(4)
+        env.reset()
+        return env
+
+    dev, ref = build(False), build(True)
+    g = torch.Generator().manual_seed(0)
+    resets = 0
+    for it in range(160):
+        a = (0.3 * torch.randn(n, 18, generator=g)).cuda()
+        if it % 40 == 20:                               # push a few robots away from their planner
+            ids = torch.arange(5, device="cuda:0")
+            for env in (dev, ref):
+                rs = env.root_states[ids].clone(); rs[:, 0] += 0.7
+                env.core.set_state_indexed(ids, root_states=rs)
+        outs = []
+        for env in (dev, ref):
+            torch.manual_seed(100 + it)                 # the same draws for both layers
+            outs.append(env.step(a))
+        (o1, _, r1, d1, x1), (o2, _, r2, d2, x2) = outs
+        assert torch.equal(d1, d2) and torch.equal(x1["time_outs"], x2["time_outs"]), it
+        torch.testing.assert_close(o1, o2, rtol=1e-5, atol=2e-5, msg=lambda m: f"step {it} obs: {m}")
+        torch.testing.assert_close(r1, r2, rtol=1e-5, atol=2e-6, msg=lambda m: f"step {it} rew: {m}")
+        p1, p2 = dev.raibert_planner, ref.raibert_planner
+        for name in ("base_pos", "base_quat", "base_pos_shift", "base_quat_shift", "foot_pos", "gait_idx", "gait_phases"):
+            torch.testing.assert_close(getattr(p1, name), getattr(p2, name), rtol=1e-5, atol=2e-5, msg=lambda m: f"step {it} planner.{name}: {m}")
+        assert torch.equal(p1.last_contacts.bool(), p2.last_contacts.bool()) and torch.equal(p1.foot_is_swing, p2.foot_is_swing)
+        for w in ("base_pose_randwalk", "foothold_base_randwalk"):
+            for name in ("current_pos", "target_pos", "timers"):
+                torch.testing.assert_close(getattr(getattr(p1, w), name), getattr(getattr(p2, w), name), rtol=1e-5, atol=1e-6, msg=lambda m: f"step {it} {w}.{name}: {m}")
+        torch.testing.assert_close(dev._layer_sums, ref._layer_sums, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(dev.raibert_pos_diff, ref.raibert_pos_diff, rtol=1e-5, atol=1e-5)
+        resets += int(d1.sum())
+    for k in RAIBERT_TERMS:
+        torch.testing.assert_close(dev.extras["episode"]["rew_" + k], ref.extras["episode"]["rew_" + k], rtol=1e-4, atol=1e-6)
+    assert resets > n        # time-outs (1.2 s episodes) and strays
+    dev.core.close(); ref.core.close()
