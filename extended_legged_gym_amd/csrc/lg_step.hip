@@ -1238,13 +1238,16 @@ LG_DEV void write_rigid_body_state(const DevCtx* __restrict__ C, const LegModel&
 // torques alone (MODE 2: lg_compute_torques) for the chain instance: ONE wave per workgroup, a lane per leg, EPW envs per wave; post_kernel ends the step.
 // TMESH: contacts against a grid mesh (closest-point queries by cell index; the instance has no BVH walk).
 template <int MODE, bool TMESH>
-__global__ __launch_bounds__(64) void physics_kernel_chain(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, const int32_t* __restrict__ ids, int n, int act_stride) {
+__global__ __launch_bounds__(64) void physics_kernel_chain(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, const int32_t* __restrict__ ids, int n, int act_stride,
+                                                           int epb) {
+  // epb: envs this workgroup steps (<= EPW; chain_epb).  The kernel is a chain of dependent latencies, one workgroup per CU (86 KB of LDS): a launch of few
+  // workgroups leaves CUs idle, so the host deals the envs over up to 256 of them and the lanes past epb groups compute on a copy and store nothing.
   __shared__ __attribute__((aligned(16))) float cst[CH_CST_FLOATS];
   __shared__ float lmod[LM_FIELDS * GRP];
   const int lane = threadIdx.x;
-  const int kq = blockIdx.x * EPW + lane / GRP;
+  const int kq = blockIdx.x * epb + lane / GRP;
   const int l = lane % GRP;
-  const bool valid = kq < n;
+  const bool valid = kq < n && lane / GRP < epb;
   const int krow = valid ? kq : n - 1;
   const int e = ids ? ids[krow] : krow;
   const lg_robot_model* __restrict__ m = &C->model;
@@ -2855,16 +2858,24 @@ static bool can_fuse(const lg_ctx* c) { return LG_LEGS == 4 && c->fuse && !c->h.
 // path stays as the bit-exact checker of a future hand-tuned tail (tests/test_elspider.py).
 static bool can_gfuse(const lg_ctx* c) { return LG_LEGS == 6 && NJ == 3 && c->gfuse && c->fuse && c->split && c->h.ter.mesh_type != LG_MESH_TRIMESH && !c->h.cfg.inject_sim_state; }
 // fuse: 0 = physics only (a post kernel follows), 1 = full policy step with the fused tail, 2 = fused ROLLOUT step of the listed envs, 3 = sink.nsteps of them in one launch
+// envs per workgroup of the chain instance's physics kernel: EPW, halved while the launch would have fewer workgroups than the chip has CUs (LG_CHAIN_EPB sets it)
+static int chain_epb(int n) {
+  int epb = EPW;
+  while (epb > 4 && (n + epb - 1) / epb < 256) epb >>= 1;
+  if (const char* ev = getenv("LG_CHAIN_EPB")) { const int v = atoi(ev); if (v >= 1 && v <= EPW) epb = v; }
+  return epb;
+}
 static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, const int32_t* ids, int n, int act_stride = NDOF, int fuse = 0,
                            PostSink sink = PostSink{nullptr, nullptr, nullptr, nullptr, 0.f}) {
-  const int nb = (n + EPB - 1) / EPB;
 #if NJ != 3
   (void)fuse; (void)sink;
+  const int epb = chain_epb(n), nb = (n + epb - 1) / epb;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
-  if (c->h.ter.mesh_type == LG_MESH_TRIMESH) hipLaunchKernelGGL((physics_kernel_chain<0, true>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride);
-  else hipLaunchKernelGGL((physics_kernel_chain<0, false>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride);
+  if (c->h.ter.mesh_type == LG_MESH_TRIMESH) hipLaunchKernelGGL((physics_kernel_chain<0, true>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride, epb);
+  else hipLaunchKernelGGL((physics_kernel_chain<0, false>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride, epb);
   return;
 #else
+  const int nb = (n + EPB - 1) / EPB;
   // helper waves (leg bias, contact detection, a share of the contact set-up; with the actuator network also its three
   // joints per leg): always, unless LG_SPLIT=0 (diagnostic) -- and even then on triangle-mesh terrains, whose contact
   // detection is a BVH traversal per collision sphere that should not sit on the main wave.  PD-controlled robots gain
@@ -3212,7 +3223,7 @@ int lg_compute_torques(lg_ctx* c, const float* actions, void* stream) {
   DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
 #if NJ != 3
-  hipLaunchKernelGGL((physics_kernel_chain<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, (const int32_t*)nullptr, c->h.N, NDOF);
+  hipLaunchKernelGGL((physics_kernel_chain<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, (const int32_t*)nullptr, c->h.N, NDOF, EPW);
 #else
   hipLaunchKernelGGL((physics_kernel<2, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, actions, 0, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
 #endif
@@ -3225,8 +3236,8 @@ int lg_simulate(lg_ctx* c, void* stream) {
   DeviceScope ds_(c->device);
   const int nb = (c->h.N + EPB - 1) / EPB;
 #if NJ != 3
-  if (c->h.ter.mesh_type == LG_MESH_TRIMESH) hipLaunchKernelGGL((physics_kernel_chain<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, (const int32_t*)nullptr, c->h.N, NDOF);
-  else hipLaunchKernelGGL((physics_kernel_chain<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, (const int32_t*)nullptr, c->h.N, NDOF);
+  if (c->h.ter.mesh_type == LG_MESH_TRIMESH) hipLaunchKernelGGL((physics_kernel_chain<1, true>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, (const int32_t*)nullptr, c->h.N, NDOF, EPW);
+  else hipLaunchKernelGGL((physics_kernel_chain<1, false>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, (const int32_t*)nullptr, c->h.N, NDOF, EPW);
 #else
   if (c->h.ter.mesh_type == LG_MESH_TRIMESH)
     hipLaunchKernelGGL((physics_kernel<1, true, false, FEAT_ALL>), dim3(nb), dim3(64), 0, (hipStream_t)stream, c->d, (const float*)nullptr, 1, 0, (const int32_t*)nullptr, c->h.N, NDOF, 0, PostSink{nullptr, nullptr, nullptr, nullptr, 0.f});
