@@ -1,64 +1,49 @@
-"""Config tree of task `cassie` (reference `envs/cassie/cassie_config.py:33-112`; values held to the reference's registry by tests/test_task_configs.py)."""
+"""Config tree of task `cassie` (values of the reference's `envs/cassie/cassie_config.py:33-112`, held to its registry by tests/test_task_configs.py).
+Written from the joint list: the biped's two legs differ in the sign of the hip abduction only."""
 from extended_legged_gym_amd.envs.base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgPPO
+
+_JOINTS = ("hip_abduction", "hip_rotation", "hip_flexion", "thigh_joint", "ankle_joint", "toe_joint")
+_STANCE = (0.1, 0., 1., -1.8, 1.57, -1.57)                      # left leg; the right leg mirrors the abduction
+_SCAN = [round(0.1 * i, 1) for i in range(-5, 6)]               # 11 x 11 points, 1 m x 1 m
 
 
 class CassieRoughCfg(LeggedRobotCfg):
     class env(LeggedRobotCfg.env):
-        num_envs = 4096
-        num_observations = 169
-        num_actions = 12
+        num_envs, num_observations, num_actions = 4096, 169, 12          # 48 + 121 heights
 
     class terrain(LeggedRobotCfg.terrain):
-        measured_points_x = [-0.5, -0.4, -0.3, -0.2, -0.1, 0., 0.1, 0.2, 0.3, 0.4, 0.5]
-        measured_points_y = [-0.5, -0.4, -0.3, -0.2, -0.1, 0., 0.1, 0.2, 0.3, 0.4, 0.5]
+        measured_points_x, measured_points_y = list(_SCAN), list(_SCAN)
 
     class init_state(LeggedRobotCfg.init_state):
         pos = [0.0, 0.0, 1.]
-        default_joint_angles = {
-            'hip_abduction_left': 0.1, 'hip_rotation_left': 0., 'hip_flexion_left': 1., 'thigh_joint_left': -1.8,
-            'ankle_joint_left': 1.57, 'toe_joint_left': -1.57,
-            'hip_abduction_right': -0.1, 'hip_rotation_right': 0., 'hip_flexion_right': 1., 'thigh_joint_right': -1.8,
-            'ankle_joint_right': 1.57, 'toe_joint_right': -1.57}
+        default_joint_angles = {f"{j}_{side}": (-q if (side == "right" and j == "hip_abduction") else q)
+                                for side in ("left", "right") for j, q in zip(_JOINTS, _STANCE)}
 
     class control(LeggedRobotCfg.control):
-        stiffness = {'hip_abduction': 100.0, 'hip_rotation': 100.0, 'hip_flexion': 200., 'thigh_joint': 200., 'ankle_joint': 200., 'toe_joint': 40.}
-        damping = {'hip_abduction': 3.0, 'hip_rotation': 3.0, 'hip_flexion': 6., 'thigh_joint': 6., 'ankle_joint': 6., 'toe_joint': 1.}
-        action_scale = 0.5
-        decimation = 4
+        stiffness = dict(zip(_JOINTS, (100.0, 100.0, 200., 200., 200., 40.)))     # [N m / rad]
+        damping = dict(zip(_JOINTS, (3.0, 3.0, 6., 6., 6., 1.)))                  # [N m s / rad]
+        action_scale, decimation = 0.5, 4
 
     class asset(LeggedRobotCfg.asset):
-        file = '{LEGGED_GYM_ROOT_DIR}/resources/robots/cassie/urdf/cassie.urdf'
-        name = "cassie"
-        foot_name = 'toe'
+        name, foot_name = "cassie", "toe"
+        file = '{LEGGED_GYM_ROOT_DIR}/resources/robots/' + f'{name}/urdf/{name}.urdf'
         terminate_after_contacts_on = ['pelvis']
         flip_visual_attachments = False
-        self_collisions = 1
+        self_collisions = 1                                              # (the bitmask convention: 1 = off)
 
     class rewards(LeggedRobotCfg.rewards):
-        soft_dof_pos_limit = 0.95
-        soft_dof_vel_limit = 0.9
-        soft_torque_limit = 0.9
-        max_contact_force = 300.
-        only_positive_rewards = False
+        soft_dof_pos_limit, soft_dof_vel_limit, soft_torque_limit = 0.95, 0.9, 0.9
+        max_contact_force, only_positive_rewards = 300., False
 
         class scales(LeggedRobotCfg.rewards.scales):
-            termination = -200.
-            tracking_ang_vel = 1.0
-            torques = -5.e-6
-            dof_acc = -2.e-7
-            lin_vel_z = -0.5
-            feet_air_time = 5.
-            dof_pos_limits = -1.
-            no_fly = 0.25
-            dof_vel = -0.0
-            ang_vel_xy = -0.0
-            feet_contact_forces = -0.
+            termination, tracking_ang_vel, no_fly, feet_air_time = -200., 1.0, 0.25, 5.
+            torques, dof_acc, lin_vel_z, dof_pos_limits = -5.e-6, -2.e-7, -0.5, -1.
+            dof_vel = ang_vel_xy = feet_contact_forces = -0.0
 
 
 class CassieRoughCfgPPO(LeggedRobotCfgPPO):
-    class runner(LeggedRobotCfgPPO.runner):
-        run_name = ''
-        experiment_name = 'rough_cassie'
-
     class algorithm(LeggedRobotCfgPPO.algorithm):
         entropy_coef = 0.01
+
+    class runner(LeggedRobotCfgPPO.runner):
+        run_name, experiment_name = '', 'rough_cassie'
