@@ -92,3 +92,21 @@ def test_product_has_no_path_through_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 for needle in ("import oracle", "from oracle", "liblg_oracle", "lgo_", "oracle_lib", "lg_oracle"):
                     assert needle not in txt, f"{f} reaches into the oracle ({needle})"
+
+
+def test_layer_parameter_structs_mirror_the_header(tmp_path):
+    """The ctypes mirrors of the device layers' parameter blocks (`lg_pose_params`, `lg_foottrack_params`, `lg_foottrack_state`: passed by value into kernels)
+    against `sizeof` / `offsetof` as the C compiler lays the header's structs out."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lgstep.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(lg_pose_params), sizeof(lg_foottrack_params), sizeof(lg_foottrack_state),\n'
+                   '         offsetof(lg_foottrack_params, scales), offsetof(lg_foottrack_params, feet_indices), offsetof(lg_foottrack_state, fw_timer));\n  return 0;\n}\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(abi.lg_pose_params), C.sizeof(abi.lg_foottrack_params), C.sizeof(abi.lg_foottrack_state),
+            abi.lg_foottrack_params.scales.offset, abi.lg_foottrack_params.feet_indices.offset, abi.lg_foottrack_state.fw_timer.offset]
+    assert got == want
