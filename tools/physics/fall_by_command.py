@@ -16,6 +16,15 @@ def main(n=4096, steps=1500):
     cfg, _ = task_registry.get_cfgs("anymal_c_flat")
     cfg.env.num_envs = n; cfg.seed = 1
     cfg.noise.add_noise = False; cfg.domain_rand.push_robots = False
+    # FB_VARIANT: physics variants the lateral / yaw fall rates are looked at under (comma-separated): cone | iters8 | noselfc | rec02 | mu1 (no friction randomisation)
+    for v in filter(None, os.environ.get("FB_VARIANT", "").split(",")):
+        if v == "cone": cfg.sim.physx.friction_model = "cone"
+        elif v == "iters8": cfg.sim.physx.num_position_iterations = 8
+        elif v == "noselfc": cfg.asset.self_collisions = 1
+        elif v == "rec02": cfg.sim.physx.penetration_recovery = 0.2
+        elif v == "mu1": cfg.domain_rand.randomize_friction = False
+        elif v == "pgs": cfg.sim.physx.solver_type = 0
+        else: raise ValueError(v)
     env, _ = task_registry.make_env("anymal_c_flat", args=get_args(["--headless", "--sim_device", "cuda:0"]), env_cfg=cfg)
     actor = mlp(z, "actor", env.device)
     env.reset()
