@@ -51,3 +51,23 @@ def test_elspider_critic_recognises_the_drive_of_the_config_that_loads_the_check
     assert r["drive_with_smallest_steady_bias"] == "pd_0.2", {k: v.get("steady", {}).get("bias") for k, v in r.items() if isinstance(v, dict)}
     assert r["pd_0.2"]["startup_fall_rate"] <= BANDS["elspider_startup_fall_rate"]
     assert abs(r["pd_0.2"]["steady"]["bias"]) < 0.5 * abs(r["pd_0.3"]["steady"]["bias"])
+
+
+def test_control_a_critic_trained_on_this_physics_meets_both_bands(tmp_path, monkeypatch):
+    """The control of the method: PPO with the reference's hyper-parameters trains `anymal_c_flat` from scratch on this simulator (300 iterations, ~17 s:
+    `tools/train_acceptance.py`); ITS critic, measured by the same protocol, has to sit inside the bands the PhysX-trained critic is held to.  Measured
+    (round 5, `profiles/r05_value_calibration_home_trained.json`): steady bias / mean|G| = -0.002, r = 0.55; first 100 steps after a reset -0.04, r = 0.78;
+    start-up fall rate 0.002; 4e-5 falls per env-step in steady state (the PhysX-trained checkpoint: 5e-3)."""
+    from tools import train_acceptance
+    from tools.physics import value_calibration as vc
+    out = tmp_path / "home.json"
+    train_acceptance.main(["--iters", "300", "--no-play", "--out", str(out)])
+    monkeypatch.setenv("VC_POLICY", str(tmp_path / "home_model.pt"))
+    r = vc.anymal(4096, 800)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/r05_value_calibration_home_trained.json", "w") as f:
+        json.dump(dict(bands=BANDS, result=r), f, indent=1)
+    assert abs(r["steady"]["bias_over_mean_abs_G"]) <= BANDS["steady_bias_over_mean_abs_G"], r["steady"]
+    assert abs(r["startup"]["bias_over_mean_abs_G"]) <= BANDS["startup_bias_over_mean_abs_G"], r["startup"]
+    assert r["steady"]["pearson_r"] >= BANDS["steady_pearson_r"] and r["startup"]["pearson_r"] >= BANDS["steady_pearson_r"]
+    assert r["startup_fall_rate"] <= 0.05 and r["steady_falls_per_env_step"] <= 1e-3

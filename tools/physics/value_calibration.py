@@ -105,6 +105,9 @@ def anymal(n, steps):
     from extended_legged_gym_amd.envs import task_registry
     from extended_legged_gym_amd.utils.helpers import get_args
     z = np.load(os.path.join(ROOT, "tests", "golden", "anymal_plane_walk_policy.npz"))
+    if os.environ.get("VC_POLICY"):           # CONTROL of the method: a checkpoint trained on THIS physics (tools/train_acceptance.py writes <out>_model.pt) -- its critic
+        sd = torch.load(os.environ["VC_POLICY"], map_location="cpu")["model_state_dict"]      # has to be calibrated here if the comparison means anything
+        z = {"sd." + k: v.detach().cpu().numpy() for k, v in sd.items()}
     cfg, _ = task_registry.get_cfgs("anymal_c_flat")               # the task as registered = the training configuration
     cfg.env.num_envs = n
     cfg.seed = 1
