@@ -92,6 +92,39 @@ def ppo_update(ac, opt, data, cfg, lr):
     return lr, {k: v / n for k, v in stats.items()}
 
 
+def collect_rollout_py(env, ac, T, gamma, lam):
+    """The runner's collection loop driven from Python (`on_policy_runner.py:395-445`, `ppo.py:147-183`, `rollout_storage.py:145-167`) for env classes whose
+    step is more than the native one (device layers around it: `FootTrackElSpider`); same dictionary as `rl.collect_rollout`."""
+    obs = env.get_observations()
+    N, dev = env.num_envs, env.device
+    O, A = obs.shape[1], env.num_actions
+    d = dict(observations=torch.zeros(T, N, O, device=dev), actions=torch.zeros(T, N, A, device=dev), mu=torch.zeros(T, N, A, device=dev), sigma=torch.zeros(T, N, A, device=dev),
+             values=torch.zeros(T, N, 1, device=dev), rewards=torch.zeros(T, N, 1, device=dev), dones=torch.zeros(T, N, 1, device=dev), actions_log_prob=torch.zeros(T, N, 1, device=dev))
+    with torch.no_grad():
+        for t in range(T):
+            mu = ac.actor(obs); sigma = ac.std.expand_as(mu)
+            dist = torch.distributions.Normal(mu, sigma)
+            a = dist.sample()
+            v = ac.critic(obs)
+            d["observations"][t], d["actions"][t], d["mu"][t], d["sigma"][t], d["values"][t] = obs, a, mu, sigma, v
+            d["actions_log_prob"][t] = dist.log_prob(a).sum(-1, keepdim=True)
+            obs, _, rew, done, info = env.step(a)
+            d["rewards"][t, :, 0] = rew + gamma * v[:, 0] * info["time_outs"].float()       # the time-out bootstrap
+            d["dones"][t, :, 0] = (done != 0).float()
+        last_v = ac.critic(obs)
+        adv = torch.zeros(N, 1, device=dev)
+        d["returns"] = torch.zeros_like(d["values"])
+        for t in reversed(range(T)):
+            nv = last_v if t == T - 1 else d["values"][t + 1]
+            nt = 1.0 - d["dones"][t]
+            delta = d["rewards"][t] + nt * gamma * nv - d["values"][t]
+            adv = delta + nt * gamma * lam * adv
+            d["returns"][t] = adv + d["values"][t]
+        d["advantages"] = d["returns"] - d["values"]
+        d["advantages"] = (d["advantages"] - d["advantages"].mean()) / (d["advantages"].std() + 1e-8)
+    return d
+
+
 def native_policy(ac, seed):
     sd = {k: v.detach() for k, v in ac.state_dict().items()}
     return NativeActorCritic(sd, "elu", device="cuda:0", seed=seed)
@@ -135,6 +168,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-play", action="store_true", help="skip the play-back comparison with the PhysX-trained policy")
     ap.add_argument("--task", default="anymal_c_flat", help="registered task (anymal_c_rough: terrain curriculum; use --no-play)")
+    ap.add_argument("--set", action="append", default=[], metavar="section.key=value", help="override of the task's env config, e.g. rewards.reward_min_stage=0")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "train_acceptance.json"))
     a = ap.parse_args(argv)
     torch.manual_seed(a.seed); np.random.seed(a.seed)
@@ -143,12 +177,21 @@ def main(argv=None):
     env_cfg = copy.deepcopy(env_cfg)                 # (the registry's instance stays untouched)
     env_cfg.env.num_envs = a.envs
     env_cfg.seed = a.seed
+    import ast
+    for kv in a.set:
+        key, val = kv.split("=", 1)
+        obj = env_cfg
+        parts = key.split(".")
+        for pth in parts[:-1]:
+            obj = getattr(obj, pth)
+        setattr(obj, parts[-1], ast.literal_eval(val))
     env, env_cfg = task_registry.make_env(a.task, args=get_args(["--headless", "--sim_device", "cuda:0"]), env_cfg=env_cfg)
     tc = class_to_dict(train_cfg)
     alg, pol, T = tc["algorithm"], tc["policy"], tc["runner"]["num_steps_per_env"]
     ac = ActorCritic(env.num_obs, env.num_actions, pol["actor_hidden_dims"], pol["critic_hidden_dims"], pol["init_noise_std"]).cuda()
     opt = torch.optim.Adam(ac.parameters(), lr=alg["learning_rate"])
     lr = alg["learning_rate"]
+    layered = hasattr(env, "_after_native")          # env classes with a layer around the native step: the collection loop runs in Python
     env.reset()
     # OnPolicyRunner.learn(init_at_random_ep_len=True), on_policy_runner.py:358-361
     env.episode_length_buf[:] = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
@@ -156,9 +199,12 @@ def main(argv=None):
     ep_ret = torch.zeros(a.envs, device="cuda"); ep_len = torch.zeros(a.envs, device="cuda")
     retbuf, lenbuf = [], []
     for it in range(a.iters):
-        nat = native_policy(ac, seed=a.seed * 1000 + it)
-        data = collect_rollout(env, nat, T, gamma=alg["gamma"], lam=alg["lam"])
-        nat.actor.close(); nat.critic.close()
+        if layered:
+            data = collect_rollout_py(env, ac, T, alg["gamma"], alg["lam"])
+        else:
+            nat = native_policy(ac, seed=a.seed * 1000 + it)
+            data = collect_rollout(env, nat, T, gamma=alg["gamma"], lam=alg["lam"])
+            nat.actor.close(); nat.critic.close()
         # episode bookkeeping of the runner (on_policy_runner.py:427-441)
         rew, dones = data["rewards"][..., 0], data["dones"][..., 0] > 0
         for t in range(T):
@@ -169,16 +215,21 @@ def main(argv=None):
                 ep_ret[d] = 0; ep_len[d] = 0
         retbuf, lenbuf = retbuf[-100:], lenbuf[-100:]
         lr, st = ppo_update(ac, opt, data, alg, lr)
+        if env.cfg.rewards.multi_stage_rewards and retbuf:       # (the runner's call, on_policy_runner.py: next reward stage once the mean return clears the threshold)
+            env.update_reward_scales(float(np.mean(retbuf)))
         names = env.setup.reward_names
         ep = env.core.t["extras_episode"][:len(names)].cpu().numpy()
         row = dict(iter=it, mean_reward=float(np.mean(retbuf)) if retbuf else 0.0, mean_episode_length=float(np.mean(lenbuf)) if lenbuf else 0.0,
                    mean_step_reward=float(rew.mean()), dones_per_env_step=float(dones.float().mean()), lr=lr, action_std=float(ac.std.mean()),
                    **{"rew_" + n: float(v) for n, v in zip(names, ep)}, **st)
+        if layered:
+            row.update({k: float(v) for k, v in env.extras["episode"].items() if k.startswith("rew_raibert")})
         if env.cfg.terrain.curriculum:
             row["terrain_level"] = float(env.terrain_levels.float().mean())
         curve.append(row)
         if it % 10 == 0 or it == a.iters - 1:
-            print(f"it {it:4d}  R {row['mean_reward']:7.2f}  len {row['mean_episode_length']:6.1f}  track {row.get('rew_tracking_lin_vel', 0):.3f}  level {row.get('terrain_level', 0):.2f}  "
+            extra = "".join(f"  {k[12:]} {v:.3f}" for k, v in row.items() if k.startswith("rew_raibert"))
+            print(f"it {it:4d}  R {row['mean_reward']:7.2f}  len {row['mean_episode_length']:6.1f}  track {row.get('rew_tracking_lin_vel', 0):.3f}  level {row.get('terrain_level', 0):.2f}{extra}  "
                   f"std {row['action_std']:.2f}  lr {lr:.1e}  kl {st['kl']:.4f}  {time.time() - t0:5.0f} s", flush=True)
     env_steps = a.iters * T * a.envs
     wall = time.time() - t0
