@@ -168,6 +168,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-play", action="store_true", help="skip the play-back comparison with the PhysX-trained policy")
     ap.add_argument("--task", default="anymal_c_flat", help="registered task (anymal_c_rough: terrain curriculum; use --no-play)")
+    ap.add_argument("--stages", action="store_true", help="multi-stage tasks: switch reward stages like the reference's runner (default: stay in the first stage, as the acceptance records were made)")
     ap.add_argument("--set", action="append", default=[], metavar="section.key=value", help="override of the task's env config, e.g. rewards.reward_min_stage=0")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "train_acceptance.json"))
     a = ap.parse_args(argv)
@@ -215,7 +216,7 @@ def main(argv=None):
                 ep_ret[d] = 0; ep_len[d] = 0
         retbuf, lenbuf = retbuf[-100:], lenbuf[-100:]
         lr, st = ppo_update(ac, opt, data, alg, lr)
-        if env.cfg.rewards.multi_stage_rewards and retbuf:       # (the runner's call, on_policy_runner.py: next reward stage once the mean return clears the threshold)
+        if a.stages and env.cfg.rewards.multi_stage_rewards and retbuf:       # (the runner's call, on_policy_runner.py:472: next reward stage once the mean return clears the threshold)
             env.update_reward_scales(float(np.mean(retbuf)))
         names = env.setup.reward_names
         ep = env.core.t["extras_episode"][:len(names)].cpu().numpy()
