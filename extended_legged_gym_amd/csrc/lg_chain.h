@@ -459,7 +459,14 @@ LG_DEV void chain_substep(const lg_robot_model* __restrict__ m, const LegModel& 
       for (int step = 0; step < my_steps; ++step) {
         const bool active = step < my_count;
         const int sl = active ? (int)((my_list >> (4 * step)) & 0xfu) : idle_sl;
-        const float* rec = &CHS(sl, 0);
+        // the whole record in ONE batch of 16-byte LDS reads, then arithmetic on registers (a lone wave gets a fifth of the LDS rate on 4-byte reads, and
+        // read-next-to-use put every round trip on the dependent chain: the lesson of the three-joint kernels' load_slot_record)
+        float rec[CH_FIELDS];
+        {
+          const float4* rp = reinterpret_cast<const float4*>(&CHS(sl, 0));
+#pragma unroll
+          for (int q4 = 0; q4 < CH_FIELDS / 4; ++q4) { const float4 v4 = rp[q4]; rec[4 * q4] = v4.x; rec[4 * q4 + 1] = v4.y; rec[4 * q4 + 2] = v4.z; rec[4 * q4 + 3] = v4.w; }
+        }
         const V3 n = v3(rec[CH_N], rec[CH_N + 1], rec[CH_N + 2]), r = v3(rec[CH_R], rec[CH_R + 1], rec[CH_R + 2]);
         const V3 t1 = v3(rec[CH_T1], rec[CH_T1 + 1], rec[CH_T1 + 2]), t2 = v3(rec[CH_T2], rec[CH_T2 + 1], rec[CH_T2 + 2]);
         V3 dp = v3(dqB[0], dqB[1], dqB[2]) + cross(v3(dqB[3], dqB[4], dqB[5]), r);
