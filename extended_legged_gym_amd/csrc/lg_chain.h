@@ -115,7 +115,9 @@ struct ChSelfRow { bool on; float phi, iA, lam; V3 n; float f[NJ], Wb[6], Wk[NJ]
 
 // One physics step of length P.dt for the env this lane group owns (see physics_substep of lg_physics.h: the same steps in the same order).
 // fbody[NJ + 2] (optional): net contact force on {base (group-summed), link 0 .. NJ-1, foot body}.
-template <bool TMESH>
+// EXT_DETECT: helper waves of the workgroup detect the contact slots while this wave builds the bias and the mass matrix (physics_kernel_chain<.., HELP = true>);
+// the rendezvous with them stands in front of the first read of a slot record.
+template <bool TMESH, bool EXT_DETECT = false>
 LG_DEV void chain_substep(const lg_robot_model* __restrict__ m, const LegModel& lm_, const TerrainView& T, const PhysParams& P, int lane, float* cst, QuadState& s,
                           const float tau[NJ], float mu_robot, float madd, V3* fbody, SelfCol scol) {
   const float dt = P.dt;
@@ -128,8 +130,10 @@ LG_DEV void chain_substep(const lg_robot_model* __restrict__ m, const LegModel& 
 #pragma unroll
   for (int j = 0; j < NJ; ++j) lm[j] = lm_.f(LM_MASS + j);
   // ---- contact detection (reads only the kinematics): before the mass matrix is live
+  if (!EXT_DETECT) {
 #pragma unroll 1
-  for (int sl = 0; sl < CH_NCP; ++sl) ch_detect_slot<TMESH>(sl, lm_, T, P, k, Rb, pb, cst, lane);
+    for (int sl = 0; sl < CH_NCP; ++sl) ch_detect_slot<TMESH>(sl, lm_, T, P, k, Rb, pb, cst, lane);
+  }
   // ---- leg bias (RNEA, zero generalised acceleration, moments about the base origin)
   float bk[NJ]; V3 Fs = v3(0, 0, 0), Ns = v3(0, 0, 0);
   {
@@ -223,6 +227,7 @@ LG_DEV void chain_substep(const lg_robot_model* __restrict__ m, const LegModel& 
   const float mu = 0.5f * (mu_robot + P.terrain_mu);
   const float idt = frcp(dt);
   // ---- per-contact solver data of the active slots
+  if (EXT_DETECT) lds_barrier();                         // (A2) the helper waves have written the detection block of every slot
   unsigned my_list = 0; int my_count = 0;
 #pragma unroll 1
   for (int sl = 0; sl < CH_NCP; ++sl) {

@@ -1237,14 +1237,18 @@ LG_DEV void write_rigid_body_state(const DevCtx* __restrict__ C, const LegModel&
 // The physics of a policy step (MODE 0: clip actions, nsub x (PD torques + one dt)), one dt with the torques of LG_T_TORQUES (MODE 1: lg_simulate), or the
 // torques alone (MODE 2: lg_compute_torques) for the chain instance: ONE wave per workgroup, a lane per leg, EPW envs per wave; post_kernel ends the step.
 // TMESH: contacts against a grid mesh (closest-point queries by cell index; the instance has no BVH walk).
-template <int MODE, bool TMESH>
-__global__ __launch_bounds__(64) void physics_kernel_chain(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, const int32_t* __restrict__ ids, int n, int act_stride,
+// HELP (round 5): a 256-thread launch whose waves 1-3 detect the contact slots -- kinematics of the published state, then their slots' queries, on a grid mesh
+// ~10 k cycles each -- while the main wave runs the bias, the mass matrix and its factorisation (Cassie, 4096 envs, trimesh: 0.281 -> ms per step, see the A/B log).
+template <int MODE, bool TMESH, bool HELP = false>
+__global__ __launch_bounds__(HELP ? 256 : 64) void physics_kernel_chain(const DevCtx* __restrict__ C, const float* __restrict__ actions_in, int nsub, const int32_t* __restrict__ ids, int n, int act_stride,
                                                            int epb) {
   // epb: envs this workgroup steps (<= EPW; chain_epb).  The kernel is a chain of dependent latencies, one workgroup per CU (86 KB of LDS): a launch of few
   // workgroups leaves CUs idle, so the host deals the envs over up to 256 of them and the lanes past epb groups compute on a copy and store nothing.
   __shared__ __attribute__((aligned(16))) float cst[CH_CST_FLOATS];
   __shared__ float lmod[LM_FIELDS * GRP];
-  const int lane = threadIdx.x;
+  constexpr int XST = 13 + 2 * NJ;                       // state a helper wave needs, per lane: root 13 | q NJ | qd NJ (an odd stride: conflict-free)
+  __shared__ float xst[HELP ? 64 * XST : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int kq = blockIdx.x * epb + lane / GRP;
   const int l = lane % GRP;
   const bool valid = kq < n && lane / GRP < epb;
@@ -1255,6 +1259,33 @@ __global__ __launch_bounds__(64) void physics_kernel_chain(const DevCtx* __restr
   fill_leg_model(lmod, C->lmod, threadIdx.x, blockDim.x);
   lds_barrier();
   const LegModel lm_{lmod, l};
+  if (HELP && wv > 0) {
+    // ---- helper wave: per substep, the kinematics of the state the main wave published and the detection of this wave's slots
+    PhysParams P;
+    P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
+    P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
+    P.terrain_mu = C->terrain_mu; P.slide_mask = C->slide_mask; P.slot_perm = 0x76543210u;
+    const TerrainView T = C->ter;
+#pragma unroll 1
+    for (int sub = 0; sub < nsub; ++sub) {
+      lds_barrier();                                     // (A) the main wave has published root, q, qd of this substep
+      float r13[13], qq[NJ], qdd[NJ];
+      const float* x = xst + lane * XST;
+#pragma unroll
+      for (int i = 0; i < 13; ++i) r13[i] = x[i];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { qq[j] = x[13 + j]; qdd[j] = x[13 + NJ + j]; }
+      const M3 Rb = quat_to_mat(r13 + 3);
+      const V3 pb = v3(r13[0], r13[1], r13[2]), vb = v3(r13[7], r13[8], r13[9]), wb = v3(r13[10], r13[11], r13[12]);
+      LegKin k;
+      leg_kinematics(lm_, Rb, pb, vb, wb, qq, qdd, k);
+      // slots dealt round-robin over the three helper waves (CH_NCP = 4: wave 1 takes slots 0 and 3)
+#pragma unroll 1
+      for (int sl = wv - 1; sl < CH_NCP; sl += 3) ch_detect_slot<TMESH>(sl, lm_, T, P, k, Rb, pb, cst, lane);
+      lds_barrier();                                     // (A2) detection blocks complete
+    }
+    return;
+  }
   QuadState s;
 #pragma unroll
   for (int i = 0; i < 13; ++i) s.root[i] = C->root[(size_t)e * 13 + i];
@@ -1305,7 +1336,15 @@ __global__ __launch_bounds__(64) void physics_kernel_chain(const DevCtx* __restr
     for (int i = 0; i < 7; ++i) root0[i] = s.root[i];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) q0[j] = s.q[j];
-    chain_substep<TMESH>(m, lm_, T, P, lane, cst, s, tau, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr, scol);
+    if (HELP) {
+      float* x = xst + lane * XST;
+#pragma unroll
+      for (int i = 0; i < 13; ++i) x[i] = s.root[i];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { x[13 + j] = s.q[j]; x[13 + NJ + j] = s.qd[j]; }
+      lds_barrier();                                     // (A)
+    }
+    chain_substep<TMESH, HELP>(m, lm_, T, P, lane, cst, s, tau, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr, scol);
     // fault guard: a non-finite or diverged state is rolled back to the pre-step pose at rest and flagged for termination
     float acc = 0.f, acc0 = 0.f;
 #pragma unroll
@@ -2871,7 +2910,11 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
   (void)fuse; (void)sink;
   const int epb = chain_epb(n), nb = (n + epb - 1) / epb;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
-  if (c->h.ter.mesh_type == LG_MESH_TRIMESH) hipLaunchKernelGGL((physics_kernel_chain<0, true>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride, epb);
+  // (helper waves for the contact detection: LG_SPLIT=0 keeps the single-wave launch, the checker of that path)
+  if (c->split) {
+    if (c->h.ter.mesh_type == LG_MESH_TRIMESH) hipLaunchKernelGGL((physics_kernel_chain<0, true, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride, epb);
+    else hipLaunchKernelGGL((physics_kernel_chain<0, false, true>), dim3(nb), dim3(256), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride, epb);
+  } else if (c->h.ter.mesh_type == LG_MESH_TRIMESH) hipLaunchKernelGGL((physics_kernel_chain<0, true>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride, epb);
   else hipLaunchKernelGGL((physics_kernel_chain<0, false>), dim3(nb), dim3(64), 0, st, c->d, actions, c->h.cfg.decimation, ids, n, act_stride, epb);
   return;
 #else

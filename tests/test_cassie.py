@@ -224,3 +224,43 @@ def test_registered_task_steps_and_resets():
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and torch.isfinite(env.root_states).all()
     assert resets > 100 and "rew_no_fly" in infos["episode"]
     env.core.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,n", [("plane", 70), ("heightfield", 45), ("trimesh", 45)])
+def test_helper_wave_detection_equals_the_single_wave_launch(mesh, n, monkeypatch):
+    """The chain kernel with its contact detection on three helper waves (`physics_kernel_chain<.., HELP>`, the default) against the 64-thread launch
+    that detects in line (LG_SPLIT=0): every byte the library owns, 60 steps with falls and resets, ragged env counts."""
+    import torch
+    from extended_legged_gym_amd.native import NativeCore
+
+    def mutate(cfg):
+        if mesh != "plane":
+            cfg.terrain.mesh_type = mesh
+        cfg.env.episode_length_s = 0.6
+
+    def build(split):
+        monkeypatch.setenv("LG_SPLIT", "1" if split else "0")
+        _, s, terrain, _ = cassie_setup(n, "flat" if mesh == "plane" else "rough", seed=3, mutate=mutate)
+        core = NativeCore(s, "cuda:0")
+        if terrain is not None:
+            rng = np.random.default_rng(1)
+            lv = rng.integers(0, 4, n); ty = np.floor(np.arange(n) / (n / 4)).astype(np.int64)
+            core.t["terrain_levels"].copy_(torch.from_numpy(lv)); core.t["terrain_types"].copy_(torch.from_numpy(ty))
+            core.t["env_origins"].copy_(torch.from_numpy(terrain.env_origins[lv, ty].astype(np.float32)))
+        core.reset_idx(torch.arange(n, device="cuda"))
+        return core
+
+    helped, inline = build(True), build(False)
+    g = torch.Generator().manual_seed(4)
+    resets = 0
+    for it in range(60):
+        a = (0.8 * torch.randn(n, 12, generator=g)).cuda()
+        helped.step(a); inline.step(a)
+        torch.cuda.synchronize()
+        for name in helped.t:
+            assert torch.equal(helped.t[name], inline.t[name]), (it, name)
+        resets += int(helped.t["reset_buf"].sum())
+    assert torch.equal(helped.arena, inline.arena)
+    assert resets > 0 and torch.isfinite(helped.t["obs_buf"]).all()
+    helped.close(); inline.close()
