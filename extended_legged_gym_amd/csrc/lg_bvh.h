@@ -37,6 +37,13 @@ struct lg_mesh {
   float2* d_gzr = nullptr;             // per cell (iy * gnx + ix): min z, max z of the triangles listed in it
   int2* d_gcells = nullptr;            // per cell: first triangle of its run in d_gtris, count
   float4* d_gtris = nullptr;           // triangles in cell order (a triangle that overlaps k cells is stored k times)
+  // closest-point queries over the same cells (closest_point_lattice, lg_physics.h): present when the boundaries are evenly spaced (a heightfield-derived mesh
+  // read back from an OBJ file), so that the cells a ball reaches are an index range computed without the boundary tables
+  // A cell's faces are sorted by height and split at their largest gap into a lower and an upper group (floor and ceiling of a two-layer terrain, the
+  // foot and the top of a wall): a ball between the layers is within reach of a cell's whole z range and of neither group's.
+  float4* d_gcz = nullptr;             // per cell: min z, max z of the lower group, min z, max z of the upper group (an empty group: +1e30, -1e30)
+  uint2* d_gcr = nullptr;              // per cell: first triangle of its run in d_gtris, (faces in the lower group) | (faces in the upper group) << 16
+  float gx0 = 0.f, gy0 = 0.f, ghx = 0.f, ghy = 0.f;   // boundary i of an axis = g?0 + i * gh? to within LATTICE_TOL * gh?
   float4* d_sdf_cache = nullptr;       // lg_sdf_bodies_update: last closest surface point per query slot (xyz, w = 1 when set)
   int64_t sdf_cache_n = 0;
   std::string err;
@@ -44,6 +51,8 @@ struct lg_mesh {
 
 // ------------------------------------------------------------------------------------------------ device: traversal
 struct MeshView { const BvhNode4* __restrict__ nodes; const float4* __restrict__ tris; };
+#define LATTICE_TOL 1e-3f
+struct LatticeView { const float4* __restrict__ cell; const uint2* __restrict__ run; const float4* __restrict__ tris; int nx, ny; float x0, y0, hx, hy; };
 #define BVH_STACK 40      // <= 3 pushes per level of a 4-wide tree
 
 struct Node4Regs { float4 minx, miny, minz, maxx, maxy, maxz; int4 child; };

@@ -407,6 +407,8 @@ void lg_mesh_destroy(lg_mesh* m) {
   if (m->d_gyb) (void)hipFree(m->d_gyb);
   if (m->d_gcells) (void)hipFree(m->d_gcells);
   if (m->d_gzr) (void)hipFree(m->d_gzr);
+  if (m->d_gcz) (void)hipFree(m->d_gcz);
+  if (m->d_gcr) (void)hipFree(m->d_gcr);
   if (m->d_gtris) (void)hipFree(m->d_gtris);
   delete m;
 }
@@ -460,6 +462,52 @@ lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t
       g_mesh_err = "device allocation / upload of the ray lattice failed"; lg_mesh_destroy(m); return nullptr;
     }
     m->gnx = (int)G.xb.size() - 1; m->gny = (int)G.yb.size() - 1;
+    // evenly spaced boundaries: the cell table of the closest-point queries (LG_LATTICE_CP=0: none -- contact queries walk the tree; the A/B switch and the tests' checker)
+    const char* lc = getenv("LG_LATTICE_CP");
+    const float hx = (G.xb.back() - G.xb.front()) / (float)m->gnx, hy = (G.yb.back() - G.yb.front()) / (float)m->gny;
+    bool even = !(lc && lc[0] == '0') && hx > 0.f && hy > 0.f;
+    for (int i = 0; even && i <= m->gnx; ++i) even = std::fabs(G.xb[i] - (G.xb[0] + (float)i * hx)) <= 0.5f * LATTICE_TOL * hx;
+    for (int i = 0; even && i <= m->gny; ++i) even = std::fabs(G.yb[i] - (G.yb[0] + (float)i * hy)) <= 0.5f * LATTICE_TOL * hy;
+    if (even) {
+      // the faces of a cell by height (the ray walk does not care about their order), split at the largest gap between the faces below and the face above
+      std::vector<float4> cz(G.cells.size()); std::vector<uint2> cr(G.cells.size());
+      struct Face { float lo, hi; float4 v[3]; };
+      std::vector<Face> fs;
+      bool ok = true;
+      for (size_t c = 0; c < cz.size() && ok; ++c) {
+        const int first = G.cells[c].x, cnt = G.cells[c].y;
+        ok = cnt <= 255 && G.tris.size() / 3 < (1u << 25) - 1u;     // (closest_point_lattice_pair: a group fits an empty table; 25-bit face numbers)
+        fs.resize((size_t)cnt);
+        for (int i = 0; i < cnt; ++i) {
+          Face& f = fs[(size_t)i];
+          for (int v = 0; v < 3; ++v) f.v[v] = G.tris[3 * (size_t)(first + i) + v];
+          f.lo = std::min({f.v[0].z, f.v[1].z, f.v[2].z}); f.hi = std::max({f.v[0].z, f.v[1].z, f.v[2].z});
+        }
+        std::stable_sort(fs.begin(), fs.end(), [](const Face& x, const Face& y) { return x.lo < y.lo; });
+        int split = cnt; float gap = 0.f, top = -1e30f;
+        for (int i = 0; i < cnt; ++i) {
+          if (i > 0 && fs[(size_t)i].lo - top > gap) { gap = fs[(size_t)i].lo - top; split = i; }
+          top = std::max(top, fs[(size_t)i].hi);
+        }
+        float z[4] = {1e30f, -1e30f, 1e30f, -1e30f};
+        for (int i = 0; i < cnt; ++i) {
+          const int g = i < split ? 0 : 1;
+          z[2 * g] = std::min(z[2 * g], fs[(size_t)i].lo); z[2 * g + 1] = std::max(z[2 * g + 1], fs[(size_t)i].hi);
+          for (int v = 0; v < 3; ++v) G.tris[3 * (size_t)(first + i) + v] = fs[(size_t)i].v[v];
+        }
+        cz[c] = make_float4(z[0], z[1], z[2], z[3]);
+        cr[c] = make_uint2((uint32_t)first, (uint32_t)split | ((uint32_t)(cnt - split) << 16));
+      }
+      if (ok) {
+        if (hipMalloc((void**)&m->d_gcz, cz.size() * sizeof(float4)) != hipSuccess || hipMalloc((void**)&m->d_gcr, cr.size() * sizeof(uint2)) != hipSuccess ||
+            hipMemcpy(m->d_gcz, cz.data(), cz.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(m->d_gcr, cr.data(), cr.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(m->d_gtris, G.tris.data(), G.tris.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
+          g_mesh_err = "device allocation / upload of the closest-point cell table failed"; lg_mesh_destroy(m); return nullptr;
+        }
+      }
+      m->gx0 = G.xb[0]; m->gy0 = G.yb[0]; m->ghx = hx; m->ghy = hy;
+    }
   }
   return m;
 }

@@ -298,6 +298,7 @@ LG_DEV void symv6(const float* Si, const float* x, float* y) {
 struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; const int16_t LG_G* __restrict__ H;
                      const int16_t LG_G* __restrict__ Hmin;   /* per cell: min(H[i][j], H[i+1][j], H[i][j+1]) -- what the height scan takes (LR:929-936); built by lg_create */
                      MeshView M;
+                     LatticeView L;   /* cell != null: the mesh's triangles by lattice cell (closest_point_lattice) */
                      const float* __restrict__ GV; /* non-null: grid mesh */ const float4* __restrict__ GV4; /* its vertices (rows x cols) x (x, y, z, 0), world frame */
                      const float* __restrict__ GM; int mcols; /* max vertex z per 2 x 2 block of vertices */ };
 struct TerrainCell { float u, v; int16_t h0, h1, h2, h3; };
@@ -789,6 +790,110 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
   A.found = found; A.cp = bestp; A.fn = bestn;
 }
 
+// Closest point on a LATTICE mesh (lg_mesh.d_gcz / d_gcr: an OBJ mesh whose vertices sit on an evenly spaced lattice in x and y -- what the confined-space and
+// heightfield converters write; any number of layers, ceilings, walls).  Every triangle is listed in each cell its xy bounding box overlaps, so the triangles
+// that hold a point within R of p are listed in the cells the square [p - R, p + R] reaches: the cell under p first (its distance bounds the rest), then
+// rounds of 4 x 4 cell records -- thirty-two independent loads, a box test per cell and height group from the record's z ranges -- and the faces of the groups
+// that pass.  Per-face arithmetic, tolerances and tie rule are `closest_point`'s, which does not depend on the order the faces are met in (a face met twice
+// changes nothing): the result is the tree walk's.  The walk pays ~25 DEPENDENT 128-byte node fetches per query.
+LG_DEV void closest_point_lattice(const LatticeView& L, ClosestQuery& A, unsigned long long* v64 = nullptr) {
+  if (!A.on) return;
+  typedef unsigned u2v __attribute__((ext_vector_type(2))); typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef const u2v __attribute__((address_space(1)))* gu2; typedef const f4v __attribute__((address_space(1)))* gf4;
+  const gf4 CELL = (gf4)L.cell; const gu2 RUN = (gu2)L.run; const gf4 TRI = (gf4)L.tris;
+  const V3 p = A.p; const float R = A.max_dist;
+  const float ihx = frcp(L.hx), ihy = frcp(L.hy);
+  float best2 = R * R, bestabs = -1.f; bool found = false;
+  V3 bestp = p, bestn = v3(0, 0, 1);
+  A.found = false; A.cp = p; A.fn = v3(0, 0, 1);
+  const float fx = (p.x - L.x0) * ihx, fy = (p.y - L.y0) * ihy;
+  // (cell indices from arithmetic boundaries: the true ones lie within LATTICE_TOL / 2 of a cell width of them, the window is taken that much wider)
+  float grx = R * ihx + 2.f * LATTICE_TOL, gry = R * ihy + 2.f * LATTICE_TOL;
+  int i0 = max((int)floorf(fx - grx), 0), i1 = min((int)floorf(fx + grx), L.nx - 1), j0 = max((int)floorf(fy - gry), 0), j1 = min((int)floorf(fy + gry), L.ny - 1);
+  if (i0 > i1 || j0 > j1) return;
+  // a run of faces: fetched four at a time, the box of each against the current best in front of the exact test
+  auto exact = [&](int first, int cnt) {
+#pragma unroll 1
+    for (int t0 = 0; t0 < cnt; t0 += 4) {
+      f4v ta[4], tb[4], tc[4];
+      if (v64) *v64 += 1ull << 21;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const gf4 T = TRI + (size_t)(first + min(t0 + u, cnt - 1)) * 3;
+        ta[u] = T[0]; tb[u] = T[1]; tc[u] = T[2];
+      }
+#pragma unroll 1
+      for (int u = 0; u < 4; ++u) {
+        if (t0 + u >= cnt) break;
+        const V3 a = v3(ta[u].x, ta[u].y, ta[u].z), b = v3(tb[u].x, tb[u].y, tb[u].z), cc = v3(tc[u].x, tc[u].y, tc[u].z);
+        if (!(tri_box_dist2(p, a, b, cc) <= best2 * (1.f + 1e-5f) + 1e-12f)) continue;
+        if (v64) *v64 += 1ull << 42;
+        closest_grid_triangle(p, a, b, cc, best2, found, bestabs, bestp, bestn);
+      }
+    }
+  };
+  // which of a cell's two groups (bit 0 lower, bit 1 upper) can hold a point within the current best distance
+  auto cell_ok = [&](int i, int j, f4v z, u2v r) -> unsigned {
+    const float xa = L.x0 + ((float)i - LATTICE_TOL) * L.hx, xb = L.x0 + ((float)(i + 1) + LATTICE_TOL) * L.hx;
+    const float ya = L.y0 + ((float)j - LATTICE_TOL) * L.hy, yb = L.y0 + ((float)(j + 1) + LATTICE_TOL) * L.hy;
+    const float dx = fmaxf(fmaxf(xa - p.x, 0.f), p.x - xb), dy = fmaxf(fmaxf(ya - p.y, 0.f), p.y - yb);
+    const float dz0 = fmaxf(fmaxf(z.x - p.z, 0.f), p.z - z.y), dz1 = fmaxf(fmaxf(z.z - p.z, 0.f), p.z - z.w);     // (an empty group: 1e30 -> never passes)
+    const float dxy = dx * dx + dy * dy, lim = best2 * (1.f + 1e-5f) + 1e-12f;
+    return (((r.y & 0xffffu) != 0u && dxy + dz0 * dz0 <= lim) ? 1u : 0u) | (((r.y >> 16) != 0u && dxy + dz1 * dz1 <= lim) ? 2u : 0u);
+  };
+  auto visit = [&](int i, int j) {
+    const size_t c = (size_t)j * L.nx + i;
+    const f4v z = CELL[c]; const u2v r = RUN[c];
+    if (v64) *v64 += 1ull;
+    const unsigned ok = cell_ok(i, j, z, r);
+    const int n0 = (int)(r.y & 0xffffu), n1 = (int)(r.y >> 16);
+    // the nearer group first: what it finds may rule the other one out
+    const bool upper_first = ok == 3u && fabsf(p.z - z.z) < fabsf(p.z - z.y);
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const bool upper = (h == 1) != upper_first;
+      if (!((h == 0 ? ok : cell_ok(i, j, z, r)) & (upper ? 2u : 1u))) continue;
+      exact((int)r.x + (upper ? n0 : 0), upper ? n1 : n0);
+    }
+  };
+  const int ci = max(i0, min((int)floorf(fx), i1)), cj = max(j0, min((int)floorf(fy), j1));
+  visit(ci, cj);
+  if (found) {
+    const float r = sqrtf(best2) * (1.f + 1e-4f);
+    grx = r * ihx + 2.f * LATTICE_TOL; gry = r * ihy + 2.f * LATTICE_TOL;
+    i0 = max(i0, (int)floorf(fx - grx)); i1 = min(i1, (int)floorf(fx + grx)); j0 = max(j0, (int)floorf(fy - gry)); j1 = min(j1, (int)floorf(fy + gry));
+  }
+#pragma unroll 1
+  for (int jb = j0; jb <= j1; jb += 4) {
+#pragma unroll 1
+    for (int ib = i0; ib <= i1; ib += 4) {
+      unsigned pass = 0u;
+      {
+        f4v z[16]; u2v r[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const size_t c = (size_t)min(jb + u, L.ny - 1) * L.nx + min(ib + t, L.nx - 1);
+            z[4 * u + t] = CELL[c]; r[4 * u + t] = RUN[c];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (jb + u <= j1 && ib + t <= i1 && !(ib + t == ci && jb + u == cj) && cell_ok(ib + t, jb + u, z[4 * u + t], r[4 * u + t])) pass |= 1u << (4 * u + t);
+      }
+      // (a cell that passed: its records again, cache hits -- indexing the register arrays by `bit` would put them in scratch; and the bound may have shrunk)
+#pragma unroll 1
+      while (pass) {
+        const int bit = __ffs(pass) - 1; pass &= pass - 1u;
+        visit(ib + (bit & 3), jb + (bit >> 2));
+      }
+    }
+  }
+  A.found = found; A.cp = bestp; A.fn = bestn;
+}
+
 #if NJ == 3      // ---- the tuned three-joint kernels' own piece (lg_chain.h holds the six-joint instance's)
 // Triangle-mesh terrain (LG_MESH_TRIMESH): the surface under a sphere is the closest point of the collision mesh within
 // range = radius + contact_offset + LG_MESH_CONTACT_MARGIN (the margin lets a sphere whose centre has sunk below the surface
@@ -813,6 +918,235 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
 static_assert(CF_FIELDS - CF_SETUP >= BVH_STACK && (LG_MAX_CP % 2) == 0, "a slot record's set-up block holds one traversal stack");
 LG_DEV float* mesh_stack_k(float* cst, int sp0, int lane) { return cst + ((sp0 * 64 + lane) * CF_FIELDS + CF_SETUP); }
 LG_DEV int* mesh_stack_i(float* cst, int sp0, int lane) { return reinterpret_cast<int*>(cst + (((sp0 + 1) * 64 + lane) * CF_FIELDS + CF_SETUP)); }
+// ---- the same queries, a PAIR per lane, with the faces of the whole wave's queries dealt over its 64 lanes.  Lane by lane (closest_point_lattice) the wave
+// waits for its busiest lane: measured on config 3, 13 cells / 18 face fetches / 37 exact tests against a mean of 3.6 / 4.2 / 8.2.  Here every lane
+//   0. tests the cell under each of its two spheres itself (that distance bounds the window),
+//   1. lists the faces of the groups its windows reach in a table in LDS (space claimed with one LDS atomic add per group),
+//   2. tests the table's faces t = lane, lane + 64, ...: squared distance -> 64-bit atomic min per query (distance bits | face), then, among the faces within the
+//      tolerance band of that minimum, the deciding normal -> atomic max (|plane distance| bits | face): `closest_point`'s tie rule, which is order-free,
+//   3. and recomputes point and normal of its own queries' winners.
+// The table lives in the set-up blocks of the wave's two slot records (dwords 12..59 of [slot][lane][CF_FIELDS], where the tree walk keeps its stacks): per
+// lane and slot 8 dwords of query record (centre xyz, acceptance limit, min key, max key) and 13 table entries of 3 dwords (query | face, distance, |plane distance|).
+// A table that fills up is tested and refilled (the lanes keep their place in their windows).
+#define LATP_PER 13
+#define LATP_CAP (128 * LATP_PER)
+#define LATP_INVALID 0xffffffffu
+struct LatQ { V3 p; float best2, bestabs, prev; bool on, found, centre_in; V3 bestp, bestn; int i0, i1, j0, j1, ci, cj; };
+LG_DEV void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0); one wave's LDS operations complete in order
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+LG_DEV void closest_point_lattice_pair(const LatticeView& L, ClosestQuery& QA, ClosestQuery& QB, float* cst, int sp0, int lane) {
+  static_assert(CF_FIELDS - CF_SETUP >= 48, "a slot record's set-up block holds a query record and LATP_PER table entries");
+  typedef unsigned u2v __attribute__((ext_vector_type(2))); typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef const u2v __attribute__((address_space(1)))* gu2; typedef const f4v __attribute__((address_space(1)))* gf4;
+  const gf4 CELL = (gf4)L.cell; const gu2 RUN = (gu2)L.run; const gf4 TRI = (gf4)L.tris;
+  const float ihx = frcp(L.hx), ihy = frcp(L.hy);
+  auto frag = [&](int hh, int ln) -> float* { return cst + (((sp0 + hh) * 64 + ln) * CF_FIELDS + CF_SETUP); };
+  auto qrec = [&](int qid) -> float* { return frag(qid & 1, qid >> 1); };
+  auto ent = [&](int t) -> float* { const int fr = t / LATP_PER, w = t - LATP_PER * fr; return frag(fr >> 6, fr & 63) + 8 + 3 * w; };
+  unsigned* const ctr = reinterpret_cast<unsigned*>(frag(0, 0) + 47);
+  auto cell_ok = [&](V3 p, float best2, int i, int j, f4v z, u2v r) -> unsigned {
+    const float xa = L.x0 + ((float)i - LATTICE_TOL) * L.hx, xb = L.x0 + ((float)(i + 1) + LATTICE_TOL) * L.hx;
+    const float ya = L.y0 + ((float)j - LATTICE_TOL) * L.hy, yb = L.y0 + ((float)(j + 1) + LATTICE_TOL) * L.hy;
+    const float dx = fmaxf(fmaxf(xa - p.x, 0.f), p.x - xb), dy = fmaxf(fmaxf(ya - p.y, 0.f), p.y - yb);
+    const float dz0 = fmaxf(fmaxf(z.x - p.z, 0.f), p.z - z.y), dz1 = fmaxf(fmaxf(z.z - p.z, 0.f), p.z - z.w);
+    const float dxy = dx * dx + dy * dy, lim = best2 * (1.f + 1e-5f) + 1e-12f;
+    return (((r.y & 0xffffu) != 0u && dxy + dz0 * dz0 <= lim) ? 1u : 0u) | (((r.y >> 16) != 0u && dxy + dz1 * dz1 <= lim) ? 2u : 0u);
+  };
+  // ---- 0. per lane: the window, and the cell under the sphere (as closest_point_lattice)
+  auto open = [&](ClosestQuery& A, LatQ& s) {
+    s.on = A.on; s.p = A.p; s.best2 = A.max_dist * A.max_dist; s.bestabs = -1.f; s.found = false; s.bestp = A.p; s.bestn = v3(0, 0, 1);
+    A.found = false; A.cp = A.p; A.fn = v3(0, 0, 1);
+    const float fx = (s.p.x - L.x0) * ihx, fy = (s.p.y - L.y0) * ihy;
+    float grx = A.max_dist * ihx + 2.f * LATTICE_TOL, gry = A.max_dist * ihy + 2.f * LATTICE_TOL;
+    s.i0 = max((int)floorf(fx - grx), 0); s.i1 = min((int)floorf(fx + grx), L.nx - 1); s.j0 = max((int)floorf(fy - gry), 0); s.j1 = min((int)floorf(fy + gry), L.ny - 1);
+    if (s.i0 > s.i1 || s.j0 > s.j1) s.on = false;
+    s.ci = max(s.i0, min((int)floorf(fx), s.i1)); s.cj = max(s.j0, min((int)floorf(fy), s.j1));
+    if (s.on) {
+      const size_t c = (size_t)s.cj * L.nx + s.ci;
+      const f4v z = CELL[c]; const u2v r = RUN[c];
+      const unsigned ok = cell_ok(s.p, s.best2, s.ci, s.cj, z, r);
+      const int n0 = (int)(r.y & 0xffffu), n1 = (int)(r.y >> 16);
+      const bool upper_first = ok == 3u && fabsf(s.p.z - z.z) < fabsf(s.p.z - z.y);
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        const bool upper = (h == 1) != upper_first;
+        if (!((h == 0 ? ok : cell_ok(s.p, s.best2, s.ci, s.cj, z, r)) & (upper ? 2u : 1u))) continue;
+        const int first = (int)r.x + (upper ? n0 : 0), cnt = upper ? n1 : n0;
+#pragma unroll 1
+        for (int t0 = 0; t0 < cnt; t0 += 4) {
+          f4v ta[4], tb[4], tc[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const gf4 T = TRI + (size_t)(first + min(t0 + u, cnt - 1)) * 3; ta[u] = T[0]; tb[u] = T[1]; tc[u] = T[2]; }
+#pragma unroll 1
+          for (int u = 0; u < 4; ++u) {
+            if (t0 + u >= cnt) break;
+            const V3 a = v3(ta[u].x, ta[u].y, ta[u].z), b = v3(tb[u].x, tb[u].y, tb[u].z), cc = v3(tc[u].x, tc[u].y, tc[u].z);
+            if (!(tri_box_dist2(s.p, a, b, cc) <= s.best2 * (1.f + 1e-5f) + 1e-12f)) continue;
+            closest_grid_triangle(s.p, a, b, cc, s.best2, s.found, s.bestabs, s.bestp, s.bestn);
+          }
+        }
+      }
+      if (s.found) {
+        const float rr = sqrtf(s.best2) * (1.f + 1e-4f);
+        grx = rr * ihx + 2.f * LATTICE_TOL; gry = rr * ihy + 2.f * LATTICE_TOL;
+        s.i0 = max(s.i0, (int)floorf(fx - grx)); s.i1 = min(s.i1, (int)floorf(fx + grx)); s.j0 = max(s.j0, (int)floorf(fy - gry)); s.j1 = min(s.j1, (int)floorf(fy + gry));
+      }
+      // a window of one cell is the cell that has just been tested
+      if (s.i0 == s.i1 && s.j0 == s.j1) s.on = false;
+    }
+    s.prev = s.found ? s.best2 : __builtin_inff(); s.centre_in = s.found;
+  };
+  LatQ q0, q1;
+  open(QA, q0); open(QB, q1);
+  const bool want0 = q0.on, want1 = q1.on;        // (on = "has a window to list"; the centre result stands either way)
+  if (__ballot(want0 || want1) != 0ull) {
+    // query records
+    {
+      float* r0 = frag(0, lane); float* r1 = frag(1, lane);
+      r0[0] = q0.p.x; r0[1] = q0.p.y; r0[2] = q0.p.z; r0[3] = q0.best2 * (1.f + 1e-5f) + 1e-12f;
+      r1[0] = q1.p.x; r1[1] = q1.p.y; r1[2] = q1.p.z; r1[3] = q1.best2 * (1.f + 1e-5f) + 1e-12f;
+      reinterpret_cast<unsigned long long*>(r0 + 4)[0] = (unsigned long long)__float_as_uint(q0.prev) << 32; reinterpret_cast<unsigned long long*>(r0 + 4)[1] = 0ull;
+      reinterpret_cast<unsigned long long*>(r1 + 4)[0] = (unsigned long long)__float_as_uint(q1.prev) << 32; reinterpret_cast<unsigned long long*>(r1 + 4)[1] = 0ull;
+    }
+    // the lane's place in its windows: query h, block (ib, jb), the block's groups still to list
+    int h = -1, ib = 0, jb = 0, wi0 = 0, wi1 = -1, wj0 = 0, wj1 = -1, wci = 0, wcj = 0; V3 wp = q0.p; float wbest = 0.f; unsigned pm = 0u;
+    bool lane_more = want0 || want1;
+#pragma unroll 1
+    for (;;) {
+      if (lane == 0) *ctr = 0u;
+      wave_lds_sync();
+      // ---- 1. list faces
+      bool full = false;
+#pragma unroll 1
+      while (lane_more && !full) {
+        if (pm == 0u) {
+          bool have = false;
+          if (h >= 0) { ib += 4; if (ib > wi1) { ib = wi0; jb += 4; } have = jb <= wj1; }
+          if (!have) {
+            ++h; if (h == 0 && !want0) ++h; if (h == 1 && !want1) ++h;
+            if (h >= 2) { lane_more = false; break; }
+            const bool s1 = h == 1;
+            wp = s1 ? q1.p : q0.p; wbest = s1 ? q1.best2 : q0.best2; wi0 = s1 ? q1.i0 : q0.i0; wi1 = s1 ? q1.i1 : q0.i1; wj0 = s1 ? q1.j0 : q0.j0; wj1 = s1 ? q1.j1 : q0.j1;
+            wci = s1 ? q1.ci : q0.ci; wcj = s1 ? q1.cj : q0.cj;
+            ib = wi0; jb = wj0;
+          }
+          f4v z[16]; u2v r[16];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const size_t c = (size_t)min(jb + u, L.ny - 1) * L.nx + min(ib + t, L.nx - 1);
+              z[4 * u + t] = CELL[c]; r[4 * u + t] = RUN[c];
+            }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (jb + u <= wj1 && ib + t <= wi1 && !(ib + t == wci && jb + u == wcj)) pm |= cell_ok(wp, wbest, ib + t, jb + u, z[4 * u + t], r[4 * u + t]) << (2 * (4 * u + t));
+          continue;
+        }
+        const int bit = __ffs(pm) - 1, cell = bit >> 1;
+        const u2v r = RUN[(size_t)(jb + (cell >> 2)) * L.nx + ib + (cell & 3)];         // (again: a cache hit; the block's records are not kept)
+        const int n0 = (int)(r.y & 0xffffu), n1 = (int)(r.y >> 16);
+        const int first = (int)r.x + ((bit & 1) ? n0 : 0), n = (bit & 1) ? n1 : n0;
+        const int off = (int)__hip_atomic_fetch_add(ctr, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (off + n > LATP_CAP) {
+          for (int t = off; t < LATP_CAP; ++t) reinterpret_cast<unsigned*>(ent(t))[0] = LATP_INVALID;
+          full = true; break;
+        }
+        const unsigned tag = (unsigned)(2 * lane + h) << 25;
+        for (int kf = 0; kf < n; ++kf) reinterpret_cast<unsigned*>(ent(off + kf))[0] = tag | (unsigned)(first + kf);
+        pm &= pm - 1u;
+      }
+      wave_lds_sync();
+      const int T = (int)min(*ctr, (unsigned)LATP_CAP);
+      // ---- 2a. distances
+#pragma unroll 1
+      for (int t = lane; t < T; t += 64) {
+        float* e = ent(t);
+        const unsigned code = reinterpret_cast<unsigned*>(e)[0];
+        float d2o = -1.f, abo = 0.f;
+        if (code != LATP_INVALID) {
+          const int qid = (int)(code >> 25), f = (int)(code & 0x1ffffffu);
+          float* qr = qrec(qid);
+          const gf4 Tp = TRI + (size_t)f * 3;
+          const f4v ta = Tp[0], tb = Tp[1], tc = Tp[2];
+          const float4 pr = *reinterpret_cast<const float4*>(qr);
+          const float run = __uint_as_float(reinterpret_cast<const unsigned*>(qr)[5]);          // the query's best so far (high word of the min key)
+          const float lim = fminf(pr.w, run * (1.f + 1e-5f) + 1e-12f);
+          const V3 p = v3(pr.x, pr.y, pr.z), a = v3(ta.x, ta.y, ta.z), b = v3(tb.x, tb.y, tb.z), cc = v3(tc.x, tc.y, tc.z);
+          if (tri_box_dist2(p, a, b, cc) <= lim) {
+            const V3 fn = cross(b - a, cc - a); const float fl = norm(fn);
+            if (fl > 1e-10f) {
+              const V3 qp = closest_on_triangle(p, a, b, cc);
+              const V3 dq = p - qp; const float d2 = dot(dq, dq);
+              if (d2 <= lim) {
+                const V3 nh = (1.f / fl) * fn;
+                const float sd = dot(dq, nh);
+                abo = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f); d2o = d2;
+                __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(qr + 4), ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)(f + 1),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              }
+            }
+          }
+        }
+        e[1] = d2o; e[2] = abo;
+      }
+      wave_lds_sync();
+      // the owner: a strictly smaller distance than before this table drops the normals chosen so far
+      {
+        const float n0d = __uint_as_float(reinterpret_cast<const unsigned*>(frag(0, lane))[5]), n1d = __uint_as_float(reinterpret_cast<const unsigned*>(frag(1, lane))[5]);
+        if (n0d < q0.prev * (1.f - 1e-5f) - 1e-12f) { reinterpret_cast<unsigned long long*>(frag(0, lane) + 4)[1] = 0ull; q0.centre_in = false; }
+        if (n1d < q1.prev * (1.f - 1e-5f) - 1e-12f) { reinterpret_cast<unsigned long long*>(frag(1, lane) + 4)[1] = 0ull; q1.centre_in = false; }
+        q0.prev = n0d; q1.prev = n1d;
+      }
+      wave_lds_sync();
+      // ---- 2b. the deciding normal among the faces within the band of the minimum
+#pragma unroll 1
+      for (int t = lane; t < T; t += 64) {
+        float* e = ent(t);
+        const unsigned code = reinterpret_cast<unsigned*>(e)[0];
+        const float d2 = e[1];
+        if (code == LATP_INVALID || !(d2 >= 0.f)) continue;
+        float* qr = qrec((int)(code >> 25));
+        const float dmin = __uint_as_float(reinterpret_cast<const unsigned*>(qr)[5]);
+        if (d2 <= dmin * (1.f + 1e-5f) + 1e-12f)
+          __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(qr + 6), ((unsigned long long)__float_as_uint(e[2]) << 32) | (0xffffffffu - ((code & 0x1ffffffu) + 1u)),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      wave_lds_sync();
+      if (__ballot(lane_more) == 0ull) break;
+    }
+    // ---- 3. the winners of this lane's queries
+    auto close = [&](LatQ& s, bool want, const float* qr) {
+      if (!want) return;
+      const unsigned long long kmin = reinterpret_cast<const unsigned long long*>(qr + 4)[0], kab = reinterpret_cast<const unsigned long long*>(qr + 4)[1];
+      const unsigned fmin = (unsigned)kmin, fab = kab ? 0xffffffffu - (unsigned)kab : 0u;     // face + 1; 0: none (the centre's result stands)
+      if (fmin) {
+        const gf4 Tp = TRI + (size_t)(fmin - 1u) * 3;
+        const f4v ta = Tp[0], tb = Tp[1], tc = Tp[2];
+        s.bestp = closest_on_triangle(s.p, v3(ta.x, ta.y, ta.z), v3(tb.x, tb.y, tb.z), v3(tc.x, tc.y, tc.z));
+        s.best2 = __uint_as_float((unsigned)(kmin >> 32)); s.found = true;
+      }
+      const float abw = __uint_as_float((unsigned)(kab >> 32));
+      if (fab && !(s.centre_in && !(abw > s.bestabs))) {
+        const gf4 Tp = TRI + (size_t)(fab - 1u) * 3;
+        const f4v ta = Tp[0], tb = Tp[1], tc = Tp[2];
+        const V3 a = v3(ta.x, ta.y, ta.z), fn = cross(v3(tb.x, tb.y, tb.z) - a, v3(tc.x, tc.y, tc.z) - a);
+        s.bestn = (1.f / norm(fn)) * fn;
+      }
+    };
+    close(q0, want0, frag(0, lane)); close(q1, want1, frag(1, lane));
+    wave_lds_sync();                                                     // (the records are the caller's again)
+  }
+  if (QA.on) { QA.found = q0.found; QA.cp = q0.bestp; QA.fn = q0.bestn; }
+  if (QB.on) { QB.found = q1.found; QB.cp = q1.bestp; QB.fn = q1.bestn; }
+}
+
 LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k,
                                 const M3& Rb, V3 pb, float* cst, int lane, float* cq = nullptr, unsigned long long* dbg = nullptr) {
   const int ncp = lm_.i(LM_CP_COUNT);
@@ -855,6 +1189,17 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       int visits = 0;
       const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
       if (T.GV) { closest_point_grid(T, Q[0], &visits, (dbg && lane == 0) ? dbg : nullptr); closest_point_grid(T, Q[1], &visits, (dbg && lane == 0) ? dbg : nullptr); }
+#ifndef LG_LATVIS
+      else if (T.L.cell) closest_point_lattice_pair(T.L, Q[0], Q[1], cst, sp0, lane);
+#else
+      else if (T.L.cell) {
+        unsigned long long v64 = 0ull;
+        closest_point_lattice(T.L, Q[0], &v64); closest_point_lattice(T.L, Q[1], &v64);
+        int f[3] = {(int)(v64 & 0x1fffffull), (int)((v64 >> 21) & 0x1fffffull), (int)(v64 >> 42)}, fs[3], fm[3];
+        for (int q = 0; q < 3; ++q) { fs[q] = fm[q] = f[q]; for (int off = 32; off > 0; off >>= 1) { fm[q] = max(fm[q], __shfl_xor(fm[q], off)); fs[q] += __shfl_xor(fs[q], off); } }
+        if (dbg && lane == 0) { dbg[16] += fs[0]; dbg[17] += fs[1]; dbg[18] += fs[2]; dbg[28] += fm[0]; dbg[30] += fm[1]; dbg[31] += fm[2]; }
+      }
+#endif
       else closest_point_pair_t<true>(T.M, Q[0], Q[1], mesh_stack_k(cst, sp0, lane), mesh_stack_i(cst, sp0, lane), &visits);
       __builtin_amdgcn_s_waitcnt(0);
       if (dbg && lane == 0) dbg[53] += __builtin_amdgcn_s_memtime() - tq0;
@@ -866,6 +1211,7 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
     }
 #else
     if (T.GV) { closest_point_grid(T, Q[0]); closest_point_grid(T, Q[1]); }
+    else if (T.L.cell) closest_point_lattice_pair(T.L, Q[0], Q[1], cst, sp0, lane);
     else closest_point_pair_t<true>(T.M, Q[0], Q[1], mesh_stack_k(cst, sp0, lane), mesh_stack_i(cst, sp0, lane), nullptr);
 #endif
 #pragma unroll
@@ -1342,8 +1688,10 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
       am += __popcll(b);
       for (int w = 0; w < 4; ++w) g4 += ((b >> (16 * w)) & 0xffffull) ? 1 : 0;
     }
+#ifndef LG_LATVIS
     if (stamps) { stamps[16] += __popc(slot_mask); stamps[17] += 1; stamps[18] += am; stamps[28] += g4;
-                  stamps[30] += __popc(slot_mask) >= 4 ? 1 : 0; stamps[31] += __popc(slot_mask) >= 5 ? 1 : 0; }   // (heightfield runs: 30 / 31 are free)
+                  stamps[30] += __popc(slot_mask) >= 4 ? 1 : 0; stamps[31] += __popc(slot_mask) >= 5 ? 1 : 0; }
+#endif   // (heightfield runs: 30 / 31 are free)
   }
 #endif
   STAMP(5);

@@ -106,3 +106,42 @@ def test_a1_on_confined_obj_mesh_never_falls_through(tmp_path):
     # base bodies stay above the surface they are over (a base under the ground sheet would read a negative distance)
     assert float(vals[:, 0].min()) > -0.2
     print("config 3 property run: lowest base z %.3f (mesh z_min %.3f), %d resets in %d env-steps" % (z_low, zmin, resets, n * steps))
+
+
+def test_lattice_contact_queries_equal_the_tree_walk(tmp_path, monkeypatch):
+    """The OBJ mesh the confined-terrain converter writes has its vertices on an evenly spaced lattice: `lg_mesh_create` lists its faces by cell and the
+    physics kernel's contact queries index the cells around a sphere (`closest_point_lattice`) instead of walking the tree (`LG_LATTICE_CP=0`).  Both see
+    every face that can hold the closest point and share the per-face arithmetic and the order-independent tie rule: same contacts, same trajectories
+    (the closest POINT on an edge two faces share may come from either, a last-bit difference -- so the state is re-synchronised in front of each step)."""
+    from tests.test_hip_fused_step import SYNC
+    n = 128
+    envs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LG_LATTICE_CP", flag)
+        d = tmp_path / flag
+        d.mkdir()
+        envs.append(make_env(d, n)[0])
+    a, b = envs
+    a.reset(); b.reset()
+    for name in list(a.core.t):
+        b.core.t[name].copy_(a.core.t[name])
+    g = torch.Generator().manual_seed(1)
+    contacts = mismatched = 0
+    for it in range(60):
+        for name in SYNC:
+            b.core.t[name].copy_(a.core.t[name])
+        act = torch.randn(n, 12, generator=g).cuda()
+        a.core.step(act); b.core.step(act)
+        torch.cuda.synchronize()
+        for name in ("root_states", "dof_state", "contact_forces", "rew_buf"):
+            x, y = a.core.t[name].cpu().numpy().reshape(n, -1), b.core.t[name].cpu().numpy().reshape(n, -1)
+            tol = 1e-3 if name == "contact_forces" else 1e-5
+            bad = (np.abs(x - y) > tol + 1e-4 * np.abs(y)).any(axis=1)
+            assert bad.sum() <= 2, (it, name, int(bad.sum()))
+            if name != "contact_forces":
+                assert float(np.abs(x - y).max()) < 5e-3, (it, name)
+            mismatched += int(bad.sum())
+        assert torch.equal(a.core.t["reset_buf"], b.core.t["reset_buf"])
+        contacts += int((a.core.t["contact_forces"].view(n, -1, 3).norm(dim=2) > 1.0).sum())
+    assert contacts > 60 * n and mismatched <= 12
+    a.core.close(); b.core.close()
