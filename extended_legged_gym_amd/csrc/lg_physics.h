@@ -920,25 +920,31 @@ LG_DEV float* mesh_stack_k(float* cst, int sp0, int lane) { return cst + ((sp0 *
 LG_DEV int* mesh_stack_i(float* cst, int sp0, int lane) { return reinterpret_cast<int*>(cst + (((sp0 + 1) * 64 + lane) * CF_FIELDS + CF_SETUP)); }
 // ---- the same queries, a PAIR per lane, with the faces of the whole wave's queries dealt over its 64 lanes.  Lane by lane (closest_point_lattice) the wave
 // waits for its busiest lane: measured on config 3, 13 cells / 18 face fetches / 37 exact tests against a mean of 3.6 / 4.2 / 8.2.  Here every lane
-//   0. tests the cell under each of its two spheres itself (that distance bounds the window),
-//   1. lists the faces of the groups its windows reach in a table in LDS (space claimed with one LDS atomic add per group),
+//   1. lists the faces of the groups its queries reach in a table in LDS (space claimed with one LDS atomic add per cell) -- in the first round(s) the cell
+//      under each sphere, whose distance then bounds the window, afterwards the window's cells, sixteen at a time,
 //   2. tests the table's faces t = lane, lane + 64, ...: squared distance -> 64-bit atomic min per query (distance bits | face), then, among the faces within the
 //      tolerance band of that minimum, the deciding normal -> atomic max (|plane distance| bits | face): `closest_point`'s tie rule, which is order-free,
 //   3. and recomputes point and normal of its own queries' winners.
 // The table lives in the set-up blocks of the wave's two slot records (dwords 12..59 of [slot][lane][CF_FIELDS], where the tree walk keeps its stacks): per
 // lane and slot 8 dwords of query record (centre xyz, acceptance limit, min key, max key) and 13 table entries of 3 dwords (query | face, distance, |plane distance|).
-// A table that fills up is tested and refilled (the lanes keep their place in their windows).
+// A table that fills up is tested and refilled (the lanes keep their place).
 #define LATP_PER 13
 #define LATP_CAP (128 * LATP_PER)
 #define LATP_INVALID 0xffffffffu
-struct LatQ { V3 p; float best2, bestabs, prev; bool on, found, centre_in; V3 bestp, bestn; int i0, i1, j0, j1, ci, cj; };
+struct LatQ { V3 p; float best2, prev; bool on; int i0, i1, j0, j1, ci, cj; float fx, fy; };
 LG_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0); one wave's LDS operations complete in order
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-LG_DEV void closest_point_lattice_pair(const LatticeView& L, ClosestQuery& QA, ClosestQuery& QB, float* cst, int sp0, int lane) {
+LG_DEV void closest_point_lattice_pair(const LatticeView& L, ClosestQuery& QA, ClosestQuery& QB, float* cst, int sp0, int lane, unsigned long long* dbg = nullptr) {
+#ifdef LG_LATVIS
+  unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+#define LSTAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (dbg && lane == 0) dbg[k] += t_ - tl0; tl0 = t_; } while (0)
+#else
+#define LSTAMP(k)
+#endif
   static_assert(CF_FIELDS - CF_SETUP >= 48, "a slot record's set-up block holds a query record and LATP_PER table entries");
   typedef unsigned u2v __attribute__((ext_vector_type(2))); typedef float f4v __attribute__((ext_vector_type(4)));
   typedef const u2v __attribute__((address_space(1)))* gu2; typedef const f4v __attribute__((address_space(1)))* gf4;
@@ -956,195 +962,205 @@ LG_DEV void closest_point_lattice_pair(const LatticeView& L, ClosestQuery& QA, C
     const float dxy = dx * dx + dy * dy, lim = best2 * (1.f + 1e-5f) + 1e-12f;
     return (((r.y & 0xffffu) != 0u && dxy + dz0 * dz0 <= lim) ? 1u : 0u) | (((r.y >> 16) != 0u && dxy + dz1 * dz1 <= lim) ? 2u : 0u);
   };
-  // ---- 0. per lane: the window, and the cell under the sphere (as closest_point_lattice)
-  auto open = [&](ClosestQuery& A, LatQ& s) {
-    s.on = A.on; s.p = A.p; s.best2 = A.max_dist * A.max_dist; s.bestabs = -1.f; s.found = false; s.bestp = A.p; s.bestn = v3(0, 0, 1);
-    A.found = false; A.cp = A.p; A.fn = v3(0, 0, 1);
-    const float fx = (s.p.x - L.x0) * ihx, fy = (s.p.y - L.y0) * ihy;
-    float grx = A.max_dist * ihx + 2.f * LATTICE_TOL, gry = A.max_dist * ihy + 2.f * LATTICE_TOL;
-    s.i0 = max((int)floorf(fx - grx), 0); s.i1 = min((int)floorf(fx + grx), L.nx - 1); s.j0 = max((int)floorf(fy - gry), 0); s.j1 = min((int)floorf(fy + gry), L.ny - 1);
-    if (s.i0 > s.i1 || s.j0 > s.j1) s.on = false;
-    s.ci = max(s.i0, min((int)floorf(fx), s.i1)); s.cj = max(s.j0, min((int)floorf(fy), s.j1));
-    if (s.on) {
-      const size_t c = (size_t)s.cj * L.nx + s.ci;
-      const f4v z = CELL[c]; const u2v r = RUN[c];
-      const unsigned ok = cell_ok(s.p, s.best2, s.ci, s.cj, z, r);
-      const int n0 = (int)(r.y & 0xffffu), n1 = (int)(r.y >> 16);
-      const bool upper_first = ok == 3u && fabsf(s.p.z - z.z) < fabsf(s.p.z - z.y);
-#pragma unroll 1
-      for (int h = 0; h < 2; ++h) {
-        const bool upper = (h == 1) != upper_first;
-        if (!((h == 0 ? ok : cell_ok(s.p, s.best2, s.ci, s.cj, z, r)) & (upper ? 2u : 1u))) continue;
-        const int first = (int)r.x + (upper ? n0 : 0), cnt = upper ? n1 : n0;
-#pragma unroll 1
-        for (int t0 = 0; t0 < cnt; t0 += 4) {
-          f4v ta[4], tb[4], tc[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { const gf4 T = TRI + (size_t)(first + min(t0 + u, cnt - 1)) * 3; ta[u] = T[0]; tb[u] = T[1]; tc[u] = T[2]; }
-#pragma unroll 1
-          for (int u = 0; u < 4; ++u) {
-            if (t0 + u >= cnt) break;
-            const V3 a = v3(ta[u].x, ta[u].y, ta[u].z), b = v3(tb[u].x, tb[u].y, tb[u].z), cc = v3(tc[u].x, tc[u].y, tc[u].z);
-            if (!(tri_box_dist2(s.p, a, b, cc) <= s.best2 * (1.f + 1e-5f) + 1e-12f)) continue;
-            closest_grid_triangle(s.p, a, b, cc, s.best2, s.found, s.bestabs, s.bestp, s.bestn);
-          }
-        }
-      }
-      if (s.found) {
-        const float rr = sqrtf(s.best2) * (1.f + 1e-4f);
-        grx = rr * ihx + 2.f * LATTICE_TOL; gry = rr * ihy + 2.f * LATTICE_TOL;
-        s.i0 = max(s.i0, (int)floorf(fx - grx)); s.i1 = min(s.i1, (int)floorf(fx + grx)); s.j0 = max(s.j0, (int)floorf(fy - gry)); s.j1 = min(s.j1, (int)floorf(fy + gry));
-      }
-      // a window of one cell is the cell that has just been tested
-      if (s.i0 == s.i1 && s.j0 == s.j1) s.on = false;
+  // the faces of a cell's passing group(s) are ONE run of the face list: claimed with one atomic add, written as (query | face) entries
+  auto claim = [&](unsigned ok, u2v r, unsigned tag) -> bool {
+    const int n0 = (int)(r.y & 0xffffu), n1 = (int)(r.y >> 16);
+    const int first = (int)r.x + ((ok & 1u) ? 0 : n0), n = ((ok & 1u) ? n0 : 0) + ((ok & 2u) ? n1 : 0);
+    const int off = (int)__hip_atomic_fetch_add(ctr, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (off + n > LATP_CAP) {
+      for (int t = off; t < LATP_CAP; ++t) reinterpret_cast<unsigned*>(ent(t))[0] = LATP_INVALID;
+      return false;
     }
-    s.prev = s.found ? s.best2 : __builtin_inff(); s.centre_in = s.found;
+    for (int kf = 0; kf < n; ++kf) reinterpret_cast<unsigned*>(ent(off + kf))[0] = tag | (unsigned)(first + kf);
+    return true;
+  };
+  auto open = [&](ClosestQuery& A, LatQ& s) {
+    s.on = A.on; s.p = A.p; s.best2 = A.max_dist * A.max_dist; s.prev = __builtin_inff();
+    A.found = false; A.cp = A.p; A.fn = v3(0, 0, 1);
+    s.fx = (s.p.x - L.x0) * ihx; s.fy = (s.p.y - L.y0) * ihy;
+    const float grx = A.max_dist * ihx + 2.f * LATTICE_TOL, gry = A.max_dist * ihy + 2.f * LATTICE_TOL;
+    s.i0 = max((int)floorf(s.fx - grx), 0); s.i1 = min((int)floorf(s.fx + grx), L.nx - 1); s.j0 = max((int)floorf(s.fy - gry), 0); s.j1 = min((int)floorf(s.fy + gry), L.ny - 1);
+    if (s.i0 > s.i1 || s.j0 > s.j1) s.on = false;
+    s.ci = min(max(s.i0, min((int)floorf(s.fx), s.i1)), L.nx - 1); s.cj = min(max(s.j0, min((int)floorf(s.fy), s.j1)), L.ny - 1);     // (inside the table also for a query that is off)
   };
   LatQ q0, q1;
   open(QA, q0); open(QB, q1);
-  const bool want0 = q0.on, want1 = q1.on;        // (on = "has a window to list"; the centre result stands either way)
-  if (__ballot(want0 || want1) != 0ull) {
-    // query records
-    {
-      float* r0 = frag(0, lane); float* r1 = frag(1, lane);
-      r0[0] = q0.p.x; r0[1] = q0.p.y; r0[2] = q0.p.z; r0[3] = q0.best2 * (1.f + 1e-5f) + 1e-12f;
-      r1[0] = q1.p.x; r1[1] = q1.p.y; r1[2] = q1.p.z; r1[3] = q1.best2 * (1.f + 1e-5f) + 1e-12f;
-      reinterpret_cast<unsigned long long*>(r0 + 4)[0] = (unsigned long long)__float_as_uint(q0.prev) << 32; reinterpret_cast<unsigned long long*>(r0 + 4)[1] = 0ull;
-      reinterpret_cast<unsigned long long*>(r1 + 4)[0] = (unsigned long long)__float_as_uint(q1.prev) << 32; reinterpret_cast<unsigned long long*>(r1 + 4)[1] = 0ull;
-    }
-    // the lane's place in its windows: query h, block (ib, jb), the block's groups still to list
-    int h = -1, ib = 0, jb = 0, wi0 = 0, wi1 = -1, wj0 = 0, wj1 = -1, wci = 0, wcj = 0; V3 wp = q0.p; float wbest = 0.f; unsigned pm = 0u;
-    bool lane_more = want0 || want1;
+  if (__ballot(q0.on || q1.on) == 0ull) return;
+  {
+    float* r0 = frag(0, lane); float* r1 = frag(1, lane);
+    r0[0] = q0.p.x; r0[1] = q0.p.y; r0[2] = q0.p.z; r0[3] = q0.best2 * (1.f + 1e-5f) + 1e-12f;
+    r1[0] = q1.p.x; r1[1] = q1.p.y; r1[2] = q1.p.z; r1[3] = q1.best2 * (1.f + 1e-5f) + 1e-12f;
+    reinterpret_cast<unsigned long long*>(r0 + 4)[0] = 0x7f800000ull << 32; reinterpret_cast<unsigned long long*>(r0 + 4)[1] = 0ull;
+    reinterpret_cast<unsigned long long*>(r1 + 4)[0] = 0x7f800000ull << 32; reinterpret_cast<unsigned long long*>(r1 + 4)[1] = 0ull;
+  }
+  LSTAMP(16);
+  // round(s) A: the cells under the spheres (cpend: bit h = query h's centre cell still to list); rounds B: the windows, sixteen cells of the row-major
+  // window at a time (kb = first of them, pm = two bits per cell still to list)
+  unsigned cpend = (q0.on ? 1u : 0u) | (q1.on ? 2u : 0u);
+  bool centres = true;                       // wave-uniform
+  int h = -1, kb = 0, ww = 1, wn = 0, wi0 = 0, wj0 = 0, wci = 0, wcj = 0; V3 wp = q0.p; float wbest = 0.f, wrw = 1.f; unsigned pm = 0u;
+  bool lane_more = false;
 #pragma unroll 1
-    for (;;) {
-      if (lane == 0) *ctr = 0u;
-      wave_lds_sync();
-      // ---- 1. list faces
+  for (;;) {
+    if (lane == 0) *ctr = 0u;
+    wave_lds_sync();
+    // ---- 1. list faces
+    if (centres) {
+      if (cpend) {
+        const size_t c0 = (size_t)q0.cj * L.nx + q0.ci, c1 = (size_t)q1.cj * L.nx + q1.ci;
+        const f4v z0 = CELL[c0], z1 = CELL[c1]; const u2v r0 = RUN[c0], r1 = RUN[c1];
+        bool full = false;
+        if (cpend & 1u) {
+          const unsigned ok = cell_ok(q0.p, q0.best2, q0.ci, q0.cj, z0, r0);
+          if (ok == 0u || claim(ok, r0, (unsigned)(2 * lane) << 25)) cpend &= ~1u; else full = true;
+        }
+        if ((cpend & 2u) && !full) {
+          const unsigned ok = cell_ok(q1.p, q1.best2, q1.ci, q1.cj, z1, r1);
+          if (ok == 0u || claim(ok, r1, (unsigned)(2 * lane + 1) << 25)) cpend &= ~2u;
+        }
+      }
+    } else {
       bool full = false;
 #pragma unroll 1
       while (lane_more && !full) {
-        if (pm == 0u) {
+        const bool fresh = pm == 0u;
+        if (fresh) {
           bool have = false;
-          if (h >= 0) { ib += 4; if (ib > wi1) { ib = wi0; jb += 4; } have = jb <= wj1; }
+          if (h >= 0) { kb += 16; have = kb < wn; }
           if (!have) {
-            ++h; if (h == 0 && !want0) ++h; if (h == 1 && !want1) ++h;
+            ++h; if (h == 0 && !q0.on) ++h; if (h == 1 && !q1.on) ++h;
             if (h >= 2) { lane_more = false; break; }
             const bool s1 = h == 1;
-            wp = s1 ? q1.p : q0.p; wbest = s1 ? q1.best2 : q0.best2; wi0 = s1 ? q1.i0 : q0.i0; wi1 = s1 ? q1.i1 : q0.i1; wj0 = s1 ? q1.j0 : q0.j0; wj1 = s1 ? q1.j1 : q0.j1;
+            wp = s1 ? q1.p : q0.p; wbest = s1 ? q1.best2 : q0.best2; wi0 = s1 ? q1.i0 : q0.i0; wj0 = s1 ? q1.j0 : q0.j0;
+            ww = (s1 ? q1.i1 : q0.i1) - wi0 + 1; wn = ww * ((s1 ? q1.j1 : q0.j1) - wj0 + 1); wrw = 1.f / (float)ww;
             wci = s1 ? q1.ci : q0.ci; wcj = s1 ? q1.cj : q0.cj;
-            ib = wi0; jb = wj0;
+            kb = 0;
           }
-          f4v z[16]; u2v r[16];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const size_t c = (size_t)min(jb + u, L.ny - 1) * L.nx + min(ib + t, L.nx - 1);
-              z[4 * u + t] = CELL[c]; r[4 * u + t] = RUN[c];
-            }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              if (jb + u <= wj1 && ib + t <= wi1 && !(ib + t == wci && jb + u == wcj)) pm |= cell_ok(wp, wbest, ib + t, jb + u, z[4 * u + t], r[4 * u + t]) << (2 * (4 * u + t));
-          continue;
         }
-        const int bit = __ffs(pm) - 1, cell = bit >> 1;
-        const u2v r = RUN[(size_t)(jb + (cell >> 2)) * L.nx + ib + (cell & 3)];         // (again: a cache hit; the block's records are not kept)
-        const int n0 = (int)(r.y & 0xffffu), n1 = (int)(r.y >> 16);
-        const int first = (int)r.x + ((bit & 1) ? n0 : 0), n = (bit & 1) ? n1 : n0;
-        const int off = (int)__hip_atomic_fetch_add(ctr, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (off + n > LATP_CAP) {
-          for (int t = off; t < LATP_CAP; ++t) reinterpret_cast<unsigned*>(ent(t))[0] = LATP_INVALID;
-          full = true; break;
+        // (a lane that found the table full comes back to its sixteen cells with pm = the cells still to list, and fetches the records again)
+        f4v z[16]; u2v r[16]; int ci_[16], cj_[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const int k = min(kb + c, wn - 1), jj = (int)(((float)k + 0.5f) * wrw), ii = k - jj * ww;
+          ci_[c] = wi0 + ii; cj_[c] = wj0 + jj;
+          const size_t cidx = (size_t)cj_[c] * L.nx + ci_[c];
+          z[c] = CELL[cidx]; r[c] = RUN[cidx];
+        }
+        if (fresh) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c)
+            if (kb + c < wn && !(ci_[c] == wci && cj_[c] == wcj)) pm |= cell_ok(wp, wbest, ci_[c], cj_[c], z[c], r[c]) << (2 * c);
         }
         const unsigned tag = (unsigned)(2 * lane + h) << 25;
-        for (int kf = 0; kf < n; ++kf) reinterpret_cast<unsigned*>(ent(off + kf))[0] = tag | (unsigned)(first + kf);
-        pm &= pm - 1u;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const unsigned ok = (pm >> (2 * c)) & 3u;
+          if (ok == 0u || full) continue;
+          if (claim(ok, r[c], tag)) pm &= ~(3u << (2 * c)); else full = true;
+        }
       }
-      wave_lds_sync();
-      const int T = (int)min(*ctr, (unsigned)LATP_CAP);
-      // ---- 2a. distances
+    }
+    wave_lds_sync();
+    const int T = (int)min(*ctr, (unsigned)LATP_CAP);
+    LSTAMP(17);
+#ifdef LG_LATVIS
+    if (dbg && lane == 0) { dbg[30] += T; dbg[31] += 1; }
+#endif
+    // ---- 2a. distances
 #pragma unroll 1
-      for (int t = lane; t < T; t += 64) {
-        float* e = ent(t);
-        const unsigned code = reinterpret_cast<unsigned*>(e)[0];
-        float d2o = -1.f, abo = 0.f;
-        if (code != LATP_INVALID) {
-          const int qid = (int)(code >> 25), f = (int)(code & 0x1ffffffu);
-          float* qr = qrec(qid);
-          const gf4 Tp = TRI + (size_t)f * 3;
-          const f4v ta = Tp[0], tb = Tp[1], tc = Tp[2];
-          const float4 pr = *reinterpret_cast<const float4*>(qr);
-          const float run = __uint_as_float(reinterpret_cast<const unsigned*>(qr)[5]);          // the query's best so far (high word of the min key)
-          const float lim = fminf(pr.w, run * (1.f + 1e-5f) + 1e-12f);
-          const V3 p = v3(pr.x, pr.y, pr.z), a = v3(ta.x, ta.y, ta.z), b = v3(tb.x, tb.y, tb.z), cc = v3(tc.x, tc.y, tc.z);
-          if (tri_box_dist2(p, a, b, cc) <= lim) {
-            const V3 fn = cross(b - a, cc - a); const float fl = norm(fn);
-            if (fl > 1e-10f) {
-              const V3 qp = closest_on_triangle(p, a, b, cc);
-              const V3 dq = p - qp; const float d2 = dot(dq, dq);
-              if (d2 <= lim) {
-                const V3 nh = (1.f / fl) * fn;
-                const float sd = dot(dq, nh);
-                abo = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f); d2o = d2;
-                __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(qr + 4), ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)(f + 1),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-              }
+    for (int t = lane; t < T; t += 64) {
+      float* e = ent(t);
+      const unsigned code = reinterpret_cast<unsigned*>(e)[0];
+      float d2o = -1.f, abo = 0.f;
+      if (code != LATP_INVALID) {
+        const int qid = (int)(code >> 25), f = (int)(code & 0x1ffffffu);
+        float* qr = qrec(qid);
+        const gf4 Tp = TRI + (size_t)f * 3;
+        const f4v ta = Tp[0], tb = Tp[1], tc = Tp[2];
+        const float4 pr = *reinterpret_cast<const float4*>(qr);
+        const float run = __uint_as_float(reinterpret_cast<const unsigned*>(qr)[5]);          // the query's best so far (high word of the min key)
+        const float lim = fminf(pr.w, run * (1.f + 1e-5f) + 1e-12f);
+        const V3 p = v3(pr.x, pr.y, pr.z), a = v3(ta.x, ta.y, ta.z), b = v3(tb.x, tb.y, tb.z), cc = v3(tc.x, tc.y, tc.z);
+        if (tri_box_dist2(p, a, b, cc) <= lim) {
+          const V3 fn = cross(b - a, cc - a); const float fl = norm(fn);
+          if (fl > 1e-10f) {
+            const V3 qp = closest_on_triangle(p, a, b, cc);
+            const V3 dq = p - qp; const float d2 = dot(dq, dq);
+            if (d2 <= lim) {
+              const V3 nh = (1.f / fl) * fn;
+              const float sd = dot(dq, nh);
+              abo = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f); d2o = d2;
+              __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(qr + 4), ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)(f + 1),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
           }
         }
-        e[1] = d2o; e[2] = abo;
       }
-      wave_lds_sync();
-      // the owner: a strictly smaller distance than before this table drops the normals chosen so far
-      {
-        const float n0d = __uint_as_float(reinterpret_cast<const unsigned*>(frag(0, lane))[5]), n1d = __uint_as_float(reinterpret_cast<const unsigned*>(frag(1, lane))[5]);
-        if (n0d < q0.prev * (1.f - 1e-5f) - 1e-12f) { reinterpret_cast<unsigned long long*>(frag(0, lane) + 4)[1] = 0ull; q0.centre_in = false; }
-        if (n1d < q1.prev * (1.f - 1e-5f) - 1e-12f) { reinterpret_cast<unsigned long long*>(frag(1, lane) + 4)[1] = 0ull; q1.centre_in = false; }
-        q0.prev = n0d; q1.prev = n1d;
-      }
-      wave_lds_sync();
-      // ---- 2b. the deciding normal among the faces within the band of the minimum
-#pragma unroll 1
-      for (int t = lane; t < T; t += 64) {
-        float* e = ent(t);
-        const unsigned code = reinterpret_cast<unsigned*>(e)[0];
-        const float d2 = e[1];
-        if (code == LATP_INVALID || !(d2 >= 0.f)) continue;
-        float* qr = qrec((int)(code >> 25));
-        const float dmin = __uint_as_float(reinterpret_cast<const unsigned*>(qr)[5]);
-        if (d2 <= dmin * (1.f + 1e-5f) + 1e-12f)
-          __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(qr + 6), ((unsigned long long)__float_as_uint(e[2]) << 32) | (0xffffffffu - ((code & 0x1ffffffu) + 1u)),
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      }
-      wave_lds_sync();
-      if (__ballot(lane_more) == 0ull) break;
+      e[1] = d2o; e[2] = abo;
     }
-    // ---- 3. the winners of this lane's queries
-    auto close = [&](LatQ& s, bool want, const float* qr) {
-      if (!want) return;
-      const unsigned long long kmin = reinterpret_cast<const unsigned long long*>(qr + 4)[0], kab = reinterpret_cast<const unsigned long long*>(qr + 4)[1];
-      const unsigned fmin = (unsigned)kmin, fab = kab ? 0xffffffffu - (unsigned)kab : 0u;     // face + 1; 0: none (the centre's result stands)
-      if (fmin) {
-        const gf4 Tp = TRI + (size_t)(fmin - 1u) * 3;
-        const f4v ta = Tp[0], tb = Tp[1], tc = Tp[2];
-        s.bestp = closest_on_triangle(s.p, v3(ta.x, ta.y, ta.z), v3(tb.x, tb.y, tb.z), v3(tc.x, tc.y, tc.z));
-        s.best2 = __uint_as_float((unsigned)(kmin >> 32)); s.found = true;
+    wave_lds_sync();
+    LSTAMP(18);
+    // the owner: a strictly smaller distance than before this table drops the normals chosen so far
+    const bool last_centres = centres && __ballot(cpend != 0u) == 0ull;
+    {
+      const float n0d = __uint_as_float(reinterpret_cast<const unsigned*>(frag(0, lane))[5]), n1d = __uint_as_float(reinterpret_cast<const unsigned*>(frag(1, lane))[5]);
+      if (n0d < q0.prev * (1.f - 1e-5f) - 1e-12f) reinterpret_cast<unsigned long long*>(frag(0, lane) + 4)[1] = 0ull;
+      if (n1d < q1.prev * (1.f - 1e-5f) - 1e-12f) reinterpret_cast<unsigned long long*>(frag(1, lane) + 4)[1] = 0ull;
+      q0.prev = n0d; q1.prev = n1d;
+      if (last_centres) {
+        // every centre cell has been tested: its distance bounds the window (a window of one cell is that cell: done)
+        auto shrink = [&](LatQ& s, float d) {
+          if (!s.on) return;
+          if (d < __builtin_inff()) {
+            s.best2 = d;
+            const float rr = sqrtf(d) * (1.f + 1e-4f), grx = rr * ihx + 2.f * LATTICE_TOL, gry = rr * ihy + 2.f * LATTICE_TOL;
+            s.i0 = max(s.i0, (int)floorf(s.fx - grx)); s.i1 = min(s.i1, (int)floorf(s.fx + grx)); s.j0 = max(s.j0, (int)floorf(s.fy - gry)); s.j1 = min(s.j1, (int)floorf(s.fy + gry));
+          }
+          if (s.i0 == s.i1 && s.j0 == s.j1) s.on = false;
+        };
+        shrink(q0, n0d); shrink(q1, n1d);
+        lane_more = q0.on || q1.on;
       }
-      const float abw = __uint_as_float((unsigned)(kab >> 32));
-      if (fab && !(s.centre_in && !(abw > s.bestabs))) {
-        const gf4 Tp = TRI + (size_t)(fab - 1u) * 3;
-        const f4v ta = Tp[0], tb = Tp[1], tc = Tp[2];
-        const V3 a = v3(ta.x, ta.y, ta.z), fn = cross(v3(tb.x, tb.y, tb.z) - a, v3(tc.x, tc.y, tc.z) - a);
-        s.bestn = (1.f / norm(fn)) * fn;
-      }
-    };
-    close(q0, want0, frag(0, lane)); close(q1, want1, frag(1, lane));
-    wave_lds_sync();                                                     // (the records are the caller's again)
+    }
+    wave_lds_sync();
+    // ---- 2b. the deciding normal among the faces within the band of the minimum
+#pragma unroll 1
+    for (int t = lane; t < T; t += 64) {
+      float* e = ent(t);
+      const unsigned code = reinterpret_cast<unsigned*>(e)[0];
+      const float d2 = e[1];
+      if (code == LATP_INVALID || !(d2 >= 0.f)) continue;
+      float* qr = qrec((int)(code >> 25));
+      const float dmin = __uint_as_float(reinterpret_cast<const unsigned*>(qr)[5]);
+      if (d2 <= dmin * (1.f + 1e-5f) + 1e-12f)
+        __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(qr + 6), ((unsigned long long)__float_as_uint(e[2]) << 32) | (0xffffffffu - ((code & 0x1ffffffu) + 1u)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    wave_lds_sync();
+    LSTAMP(28);
+    if (last_centres) centres = false;
+    if (!centres && __ballot(lane_more) == 0ull) break;
   }
-  if (QA.on) { QA.found = q0.found; QA.cp = q0.bestp; QA.fn = q0.bestn; }
-  if (QB.on) { QB.found = q1.found; QB.cp = q1.bestp; QB.fn = q1.bestn; }
+  // ---- 3. the winners of this lane's queries
+  auto close = [&](ClosestQuery& A, const LatQ& s, const float* qr) {
+    if (!A.on) return;
+    const unsigned long long kmin = reinterpret_cast<const unsigned long long*>(qr + 4)[0], kab = reinterpret_cast<const unsigned long long*>(qr + 4)[1];
+    const unsigned fmin = (unsigned)kmin, fab = kab ? 0xffffffffu - (unsigned)kab : 0u;     // face + 1; 0: none
+    if (fmin) {
+      const gf4 Tp = TRI + (size_t)(fmin - 1u) * 3;
+      const f4v ta = Tp[0], tb = Tp[1], tc = Tp[2];
+      A.cp = closest_on_triangle(s.p, v3(ta.x, ta.y, ta.z), v3(tb.x, tb.y, tb.z), v3(tc.x, tc.y, tc.z));
+      A.found = true;
+    }
+    if (fab) {
+      const gf4 Tp = TRI + (size_t)(fab - 1u) * 3;
+      const f4v ta = Tp[0], tb = Tp[1], tc = Tp[2];
+      const V3 a = v3(ta.x, ta.y, ta.z), fn = cross(v3(tb.x, tb.y, tb.z) - a, v3(tc.x, tc.y, tc.z) - a);
+      A.fn = (1.f / norm(fn)) * fn;
+    }
+  };
+  close(QA, q0, frag(0, lane)); close(QB, q1, frag(1, lane));
+  wave_lds_sync();                                                     // (the records are the caller's again)
 }
 
 LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k,
@@ -1189,8 +1205,8 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
       int visits = 0;
       const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
       if (T.GV) { closest_point_grid(T, Q[0], &visits, (dbg && lane == 0) ? dbg : nullptr); closest_point_grid(T, Q[1], &visits, (dbg && lane == 0) ? dbg : nullptr); }
-#ifndef LG_LATVIS
-      else if (T.L.cell) closest_point_lattice_pair(T.L, Q[0], Q[1], cst, sp0, lane);
+#if 1
+      else if (T.L.cell) closest_point_lattice_pair(T.L, Q[0], Q[1], cst, sp0, lane, dbg);
 #else
       else if (T.L.cell) {
         unsigned long long v64 = 0ull;
