@@ -236,6 +236,8 @@ def declare_product(lib):
     lib.lg_mesh_info.restype = C.c_int
     lib.lg_mesh_ray_lattice.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.lg_mesh_ray_lattice.restype = C.c_int
+    lib.lg_mesh_contact_lattice.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.lg_mesh_contact_lattice.restype = C.c_int
     lib.lg_mesh_last_error.argtypes = [vp]
     lib.lg_mesh_last_error.restype = C.c_char_p
     lib.lg_raycast_mesh.argtypes = [vp, vp, vp, C.c_int64, f32, vp, vp, vp]
@@ -297,6 +299,6 @@ ACTIVATIONS = {"elu": 0, "relu": 1, "tanh": 2, "lrelu": 3, "selu": 4}
 
 PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_step_physics", "lg_step_subset", "lg_step_transition", "lg_sync_main_to_rollout", "lg_rollout_batch", "lg_compute_torques",
                    "lg_simulate", "lg_post_physics_step", "lg_reset_idx", "lg_profile_begin", "lg_profile_end", "lg_last_error",
-                   "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_ray_lattice", "lg_mesh_last_error",
+                   "lg_destroy", "lg_set_extra_obs", "lg_mesh_create", "lg_mesh_destroy", "lg_mesh_info", "lg_mesh_ray_lattice", "lg_mesh_contact_lattice", "lg_mesh_last_error",
                    "lg_raycast_mesh", "lg_mesh_query_sdf", "lg_raycaster_update", "lg_depth_camera_update",
                    "lg_terrain_generate", "lg_heightfield_to_trimesh", "lg_pose_layer_step", "lg_set_reward_terms", "lg_set_async_gait", "lg_step_subset_physics", "lg_post_physics_subset", "lg_raycaster_update_subset", "lg_sdf_bodies_update", "lg_set_state_indexed", "lg_gather_step_rows", "lg_step_subset_rows", "lg_step_rollout", "lg_set_extra_termination", "lg_foottrack_stray", "lg_foottrack_layer_step"]

@@ -514,6 +514,7 @@ lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t
 
 
 int lg_mesh_info(lg_mesh* m, int64_t out[2]) { if (!m) return LG_ERR_INVALID; out[0] = m->n_tris; out[1] = m->n_nodes; return LG_OK; }
+int lg_mesh_contact_lattice(lg_mesh* m, int32_t out[2]) { if (!m || !out) return LG_ERR_INVALID; out[0] = m->d_gcz ? m->gnx : 0; out[1] = m->d_gcz ? m->gny : 0; return LG_OK; }
 int lg_mesh_ray_lattice(lg_mesh* m, int32_t out[2]) { if (!m || !out) return LG_ERR_INVALID; out[0] = m->d_gcells ? m->gnx : 0; out[1] = m->d_gcells ? m->gny : 0; return LG_OK; }
 
 #define MESH_TRY(m, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (m)->err = std::string(#expr) + ": " + hipGetErrorString(_e); return LG_ERR_HIP; } } while (0)

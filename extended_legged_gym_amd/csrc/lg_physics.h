@@ -921,7 +921,7 @@ LG_DEV int* mesh_stack_i(float* cst, int sp0, int lane) { return reinterpret_cas
 // ---- the same queries, a PAIR per lane, with the faces of the whole wave's queries dealt over its 64 lanes.  Lane by lane (closest_point_lattice) the wave
 // waits for its busiest lane: measured on config 3, 13 cells / 18 face fetches / 37 exact tests against a mean of 3.6 / 4.2 / 8.2.  Here every lane
 //   1. lists the faces of the groups its queries reach in a table in LDS (space claimed with one LDS atomic add per cell) -- in the first round(s) the cell
-//      under each sphere, whose distance then bounds the window, afterwards the window's cells, sixteen at a time,
+//      under each sphere, whose distance then bounds the window, afterwards the window's cells, eight at a time,
 //   2. tests the table's faces t = lane, lane + 64, ...: squared distance -> 64-bit atomic min per query (distance bits | face), then, among the faces within the
 //      tolerance band of that minimum, the deciding normal -> atomic max (|plane distance| bits | face): `closest_point`'s tie rule, which is order-free,
 //   3. and recomputes point and normal of its own queries' winners.
@@ -931,6 +931,7 @@ LG_DEV int* mesh_stack_i(float* cst, int sp0, int lane) { return reinterpret_cas
 #define LATP_PER 13
 #define LATP_CAP (128 * LATP_PER)
 #define LATP_INVALID 0xffffffffu
+#define LATP_BLOCK 8
 struct LatQ { V3 p; float best2, prev; bool on; int i0, i1, j0, j1, ci, cj; float fx, fy; };
 LG_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -994,7 +995,7 @@ LG_DEV void closest_point_lattice_pair(const LatticeView& L, ClosestQuery& QA, C
     reinterpret_cast<unsigned long long*>(r1 + 4)[0] = 0x7f800000ull << 32; reinterpret_cast<unsigned long long*>(r1 + 4)[1] = 0ull;
   }
   LSTAMP(16);
-  // round(s) A: the cells under the spheres (cpend: bit h = query h's centre cell still to list); rounds B: the windows, sixteen cells of the row-major
+  // round(s) A: the cells under the spheres (cpend: bit h = query h's centre cell still to list); rounds B: the windows, LATP_BLOCK cells of the row-major
   // window at a time (kb = first of them, pm = two bits per cell still to list)
   unsigned cpend = (q0.on ? 1u : 0u) | (q1.on ? 2u : 0u);
   bool centres = true;                       // wave-uniform
@@ -1026,7 +1027,7 @@ LG_DEV void closest_point_lattice_pair(const LatticeView& L, ClosestQuery& QA, C
         const bool fresh = pm == 0u;
         if (fresh) {
           bool have = false;
-          if (h >= 0) { kb += 16; have = kb < wn; }
+          if (h >= 0) { kb += LATP_BLOCK; have = kb < wn; }
           if (!have) {
             ++h; if (h == 0 && !q0.on) ++h; if (h == 1 && !q1.on) ++h;
             if (h >= 2) { lane_more = false; break; }
@@ -1037,23 +1038,25 @@ LG_DEV void closest_point_lattice_pair(const LatticeView& L, ClosestQuery& QA, C
             kb = 0;
           }
         }
-        // (a lane that found the table full comes back to its sixteen cells with pm = the cells still to list, and fetches the records again)
-        f4v z[16]; u2v r[16]; int ci_[16], cj_[16];
+        // (a lane that found the table full comes back to its cells with pm = the cells still to list, and fetches the records again.  LATP_BLOCK = 8:
+        //  with sixteen records in registers the instance spilled 57 VGPRs -- in every phase of the kernel, not only here)
+        f4v z[LATP_BLOCK]; u2v r[LATP_BLOCK];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < LATP_BLOCK; ++c) {
           const int k = min(kb + c, wn - 1), jj = (int)(((float)k + 0.5f) * wrw), ii = k - jj * ww;
-          ci_[c] = wi0 + ii; cj_[c] = wj0 + jj;
-          const size_t cidx = (size_t)cj_[c] * L.nx + ci_[c];
+          const size_t cidx = (size_t)(wj0 + jj) * L.nx + wi0 + ii;
           z[c] = CELL[cidx]; r[c] = RUN[cidx];
         }
         if (fresh) {
 #pragma unroll
-          for (int c = 0; c < 16; ++c)
-            if (kb + c < wn && !(ci_[c] == wci && cj_[c] == wcj)) pm |= cell_ok(wp, wbest, ci_[c], cj_[c], z[c], r[c]) << (2 * c);
+          for (int c = 0; c < LATP_BLOCK; ++c) {
+            const int k = kb + c, jj = (int)(((float)k + 0.5f) * wrw), ci_ = wi0 + k - jj * ww, cj_ = wj0 + jj;
+            if (k < wn && !(ci_ == wci && cj_ == wcj)) pm |= cell_ok(wp, wbest, ci_, cj_, z[c], r[c]) << (2 * c);
+          }
         }
         const unsigned tag = (unsigned)(2 * lane + h) << 25;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < LATP_BLOCK; ++c) {
           const unsigned ok = (pm >> (2 * c)) & 3u;
           if (ok == 0u || full) continue;
           if (claim(ok, r[c], tag)) pm &= ~(3u << (2 * c)); else full = true;

@@ -30,6 +30,8 @@ class DeviceMesh:
         lat = (C.c_int32 * 2)()
         self.lib.lg_mesh_ray_lattice(self.handle, lat)
         self.ray_lattice = (int(lat[0]), int(lat[1]))      # (0, 0): rays walk the BVH
+        self.lib.lg_mesh_contact_lattice(self.handle, lat)
+        self.contact_lattice = (int(lat[0]), int(lat[1]))  # (0, 0): the physics kernel's contact queries walk the BVH
 
     def _check(self, rc):
         if rc != abi.LG_OK:

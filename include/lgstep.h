@@ -450,6 +450,11 @@ int lg_mesh_info(lg_mesh* mesh, int64_t out[2]);            /* {#triangles, #bvh
  * (environment LG_RAY_GRID=0 at creation time: never).  Warp has one structure for every mesh (ray_caster.py:39-42); this is an accelerator
  * behind the same calls, not a different query. */
 int lg_mesh_ray_lattice(lg_mesh* mesh, int32_t out[2]);
+/* {nx, ny} cells of the contact-query table, {0, 0} when the mesh has none.  A lattice mesh whose lines are evenly spaced (what the heightfield and
+ * confined-terrain converters write) also gets, per cell, its faces sorted by height in two groups; the physics kernel's closest-point contact queries
+ * (legged_robot.py:87-153 on `mesh_type = 'trimesh'` with `use_terrain_obj`) index those cells instead of walking the tree -- same contacts
+ * (environment LG_LATTICE_CP=0 at creation time: never). */
+int lg_mesh_contact_lattice(lg_mesh* mesh, int32_t out[2]);
 const char* lg_mesh_last_error(lg_mesh* mesh);
 
 /* raycast_mesh (ray_caster.py:95-167): device pointers, n rays; hits (n,3) = o + t d or o + d max_dist, found (n) u8. */

@@ -121,6 +121,8 @@ def test_lattice_contact_queries_equal_the_tree_walk(tmp_path, monkeypatch):
         d = tmp_path / flag
         d.mkdir()
         envs.append(make_env(d, n)[0])
+        lat = envs[-1].core.collision_mesh.contact_lattice
+        assert (lat[0] > 100 and lat[1] > 100) if flag == "1" else lat == (0, 0), lat      # (the first env's queries go by cell, the second's walk the tree)
     a, b = envs
     a.reset(); b.reset()
     for name in list(a.core.t):
