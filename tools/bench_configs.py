@@ -166,7 +166,24 @@ def config_hexapod():
     return dict(config="hexapod: ElSpider Air 6 x 3 (LSTM actuator on 18 joints), 4096 envs on 1 GPU", **out)
 
 
+def config_cassie():
+    """Cassie (two legs of six joints: the lg2 kernel instance, `lg_chain.h`), task `cassie` as registered (trimesh terrain, PD)."""
+    import copy
+    from extended_legged_gym_amd.envs import task_registry
+    from extended_legged_gym_amd.utils.helpers import get_args
+    cfg = copy.deepcopy(task_registry.get_cfgs("cassie")[0])
+    torch.manual_seed(1)
+    env = task_registry.make_env("cassie", args=get_args(["--headless", "--sim_device", "cuda:0", "--num_envs", "4096"]), env_cfg=cfg)[0]
+    env.reset()
+    a = 0.3 * torch.randn(4096, 12, device="cuda")
+    dt = timeit(lambda: env.step(a), 200, 500)
+    out = dict(config="cassie: Cassie 2 x 6 (PD, trimesh terrain as registered), 4096 envs on 1 GPU", env_steps_per_s=4096 / dt, ms_per_step=dt * 1e3,
+               finite=bool(torch.isfinite(env.root_states).all()), mean_episode_len=float(env.episode_length_buf.float().mean()))
+    env.core.close()
+    return out
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "3", "4", "5", "hexapod"]
+    which = sys.argv[1:] or ["1", "3", "4", "5", "hexapod", "cassie"]
     for w in which:
-        print(json.dumps({"1": config1, "3": config3, "4": config4, "5": config5, "hexapod": config_hexapod}[w]()))
+        print(json.dumps({"1": config1, "3": config3, "4": config4, "5": config5, "hexapod": config_hexapod, "cassie": config_cassie}[w]()))

@@ -1,4 +1,4 @@
-"""Summarise gpurun_out/prof_<tag>_cfg{3,4,5,hexapod,rollout}/ (tools/profile_configs.sh) into profiles/<tag>_other_kernels.json: per kernel the
+"""Summarise gpurun_out/prof_<tag>_cfg{3,4,5,hexapod,cassie,rollout}/ (tools/profile_configs.sh) into profiles/<tag>_other_kernels.json: per kernel the
 rocprofv3 average duration and call count, HBM traffic per launch from the separate FETCH_SIZE / WRITE_SIZE passes, and a roofline object
 from the algorithmic bytes (or flops) one launch processes.      usage: python tools/collect_config_profiles.py <tag>"""
 import csv
@@ -26,7 +26,7 @@ ALGO = {
     ("rollout", "policy_act_kernel"): dict(flops=2.0 * N * (235 * 512 + 512 * 256 + 256 * 128 + 128 * 12 + 235 * 512 + 512 * 256 + 256 * 128 + 128), unit="PPO.act on 4096 rows"),
 }
 out = {}
-for W in ("3", "4", "5", "hexapod", "rollout"):
+for W in ("3", "4", "5", "hexapod", "cassie", "rollout"):
     d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_cfg{W}")
     stats = sorted(glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)   # (newest: gpurun_out/ keeps earlier runs)
     if not stats:
