@@ -46,6 +46,13 @@ LG_DEV void ch_leg_torques(const lg_config& g, const LegModel& lm_, const float 
   }
 }
 
+LG_DEV void ch_wave_sync() {          // LDS writes of one half of the wave visible to the other (one wave's LDS operations complete in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // contact detection of slot sl: plane / height grid (sphere + the capsule segment's edge candidates) or grid mesh (closest point; a segment slides)
 template <bool TMESH>
 LG_DEV void ch_detect_slot(int sl, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k, const M3& Rb, V3 pb, float* cst, int lane) {
@@ -119,7 +126,8 @@ struct ChSelfRow { bool on; float phi, iA, lam; V3 n; float f[NJ], Wb[6], Wk[NJ]
 // the rendezvous with them stands in front of the first read of a slot record.
 template <bool TMESH, bool EXT_DETECT = false>
 LG_DEV void chain_substep(const lg_robot_model* __restrict__ m, const LegModel& lm_, const TerrainView& T, const PhysParams& P, int lane, float* cst, QuadState& s,
-                          const float tau[NJ], float mu_robot, float madd, V3* fbody, SelfCol scol) {
+                          const float tau[NJ], float mu_robot, float madd, V3* fbody, SelfCol scol, int half = -1) {
+  // half >= 0: this lane and lane + 32 of the wave are mirrors (same env and leg, `lane` = their common row): slot `sl` is set up by the half sl & 1
   const float dt = P.dt;
   const V3 pb = v3(s.root[0], s.root[1], s.root[2]);
   const V3 vb = v3(s.root[7], s.root[8], s.root[9]), wb = v3(s.root[10], s.root[11], s.root[12]);
@@ -229,10 +237,15 @@ LG_DEV void chain_substep(const lg_robot_model* __restrict__ m, const LegModel& 
   // ---- per-contact solver data of the active slots
   if (EXT_DETECT) lds_barrier();                         // (A2) the helper waves have written the detection block of every slot
   unsigned my_list = 0; int my_count = 0;
+#pragma unroll
+  for (int sl = 0; sl < CH_NCP; ++sl)
+    if (CHS(sl, CH_ACTIVE) != 0.f) { my_list |= (unsigned)sl << (4 * my_count); ++my_count; }
+  // (mirrored halves: round `it` sets up slot 2 it on the lower and slot 2 it + 1 on the upper half -- half the rounds; both write the rows they share)
+  const int nround = half < 0 ? CH_NCP : (CH_NCP + 1) / 2;
 #pragma unroll 1
-  for (int sl = 0; sl < CH_NCP; ++sl) {
-    const bool act = CHS(sl, CH_ACTIVE) != 0.f;
-    if (act) { my_list |= (unsigned)sl << (4 * my_count); ++my_count; }
+  for (int it = 0; it < nround; ++it) {
+    const int slq = half < 0 ? it : 2 * it + half, sl = slq < CH_NCP ? slq : CH_NCP - 1;
+    const bool act = slq < CH_NCP && CHS(sl, CH_ACTIVE) != 0.f;
     if (!__any(act)) continue;
     const int link = lm_.i(LM_CP_LINK + sl);
     const int lk = link < 0 ? -1 : (link > NJ - 1 ? NJ - 1 : link);
@@ -299,6 +312,7 @@ LG_DEV void chain_substep(const lg_robot_model* __restrict__ m, const LegModel& 
     const bool pyr = P.fric != LG_FRICTION_CONE;
     CHS(sl, CH_B) = pyr ? frcp(a11) : a22 * idet; CHS(sl, CH_B + 1) = pyr ? a12 : -a12 * idet; CHS(sl, CH_B + 2) = pyr ? a12 : -a12 * idet; CHS(sl, CH_B + 3) = pyr ? frcp(a22) : a11 * idet;
   }
+  if (half >= 0) ch_wave_sync();                         // the other half's set-up blocks
   // ---- unconstrained velocity v* = v + dt M^-1 (tau - c)
   float vB[6] = {vb.x, vb.y, vb.z, wb.x, wb.y, wb.z};
   float vK[NJ];

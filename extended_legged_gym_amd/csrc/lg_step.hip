@@ -1249,10 +1249,17 @@ __global__ __launch_bounds__(HELP ? 256 : 64) void physics_kernel_chain(const De
   constexpr int XST = 13 + 2 * NJ;                       // state a helper wave needs, per lane: root 13 | q NJ | qd NJ (an odd stride: conflict-free)
   __shared__ float xst[HELP ? 64 * XST : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int kq = blockIdx.x * epb + lane / GRP;
+  // HALVES (the helper-wave instance at <= 16 envs per workgroup, i.e. N <= 4096): the upper 32 lanes of every wave would be idle copies; instead they MIRROR
+  // the lower 32 -- same env, same leg, same arithmetic, same slot-record rows -- and the work that is per contact slot is split between the halves:
+  // a helper wave detects two slots at once, the main wave sets up the even slots on its lower and the odd slots on its upper half.
+  const bool halves = HELP && epb * GRP <= 32;
+  const int le = halves ? (lane & 31) : lane;              // the lane's row in the slot records and in the published state
+  const int half = halves ? (lane >> 5) : -1;
+  const int kq = blockIdx.x * epb + le / GRP;
   const int l = lane % GRP;
-  const bool valid = kq < n && lane / GRP < epb;
-  const int krow = valid ? kq : n - 1;
+  const bool live = kq < n && le / GRP < epb;
+  const bool valid = live && half <= 0;                   // (the lower half stores)
+  const int krow = live ? kq : n - 1;
   const int e = ids ? ids[krow] : krow;
   const lg_robot_model* __restrict__ m = &C->model;
   const lg_config& g = C->cfg;
@@ -1270,7 +1277,8 @@ __global__ __launch_bounds__(HELP ? 256 : 64) void physics_kernel_chain(const De
     for (int sub = 0; sub < nsub; ++sub) {
       lds_barrier();                                     // (A) the main wave has published root, q, qd of this substep
       float r13[13], qq[NJ], qdd[NJ];
-      const float* x = xst + lane * XST;
+      // (halves: a helper wave's two halves detect two slots of the same 32 rows at once -- the four slots take ONE slot's time on three waves instead of two)
+      const float* x = xst + le * XST;
 #pragma unroll
       for (int i = 0; i < 13; ++i) r13[i] = x[i];
 #pragma unroll
@@ -1280,8 +1288,13 @@ __global__ __launch_bounds__(HELP ? 256 : 64) void physics_kernel_chain(const De
       LegKin k;
       leg_kinematics(lm_, Rb, pb, vb, wb, qq, qdd, k);
       // slots dealt round-robin over the three helper waves (CH_NCP = 4: wave 1 takes slots 0 and 3)
+      if (halves) {
+        const int sl = lane < 32 ? wv - 1 : wv + 2;
+        if (sl < CH_NCP) ch_detect_slot<TMESH>(sl, lm_, T, P, k, Rb, pb, cst, le);
+      } else {
 #pragma unroll 1
-      for (int sl = wv - 1; sl < CH_NCP; sl += 3) ch_detect_slot<TMESH>(sl, lm_, T, P, k, Rb, pb, cst, lane);
+        for (int sl = wv - 1; sl < CH_NCP; sl += 3) ch_detect_slot<TMESH>(sl, lm_, T, P, k, Rb, pb, cst, lane);
+      }
       lds_barrier();                                     // (A2) detection blocks complete
     }
     return;
@@ -1337,14 +1350,14 @@ __global__ __launch_bounds__(HELP ? 256 : 64) void physics_kernel_chain(const De
 #pragma unroll
     for (int j = 0; j < NJ; ++j) q0[j] = s.q[j];
     if (HELP) {
-      float* x = xst + lane * XST;
+      float* x = xst + le * XST;                           // (halves: both mirrors write the same values)
 #pragma unroll
       for (int i = 0; i < 13; ++i) x[i] = s.root[i];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) { x[13 + j] = s.q[j]; x[13 + NJ + j] = s.qd[j]; }
       lds_barrier();                                     // (A)
     }
-    chain_substep<TMESH, HELP>(m, lm_, T, P, lane, cst, s, tau, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr, scol);
+    chain_substep<TMESH, HELP>(m, lm_, T, P, le, cst, s, tau, mu_robot, madd, sub == nsub - 1 ? fbody : nullptr, scol, half);
     // fault guard: a non-finite or diverged state is rolled back to the pre-step pose at rest and flagged for termination
     float acc = 0.f, acc0 = 0.f;
 #pragma unroll

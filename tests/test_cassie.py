@@ -227,10 +227,12 @@ def test_registered_task_steps_and_resets():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mesh,n", [("plane", 70), ("heightfield", 45), ("trimesh", 45)])
-def test_helper_wave_detection_equals_the_single_wave_launch(mesh, n, monkeypatch):
+@pytest.mark.parametrize("mesh,n,epb", [("plane", 70, None), ("heightfield", 45, None), ("trimesh", 45, None), ("heightfield", 70, "32")])
+def test_helper_wave_detection_equals_the_single_wave_launch(mesh, n, epb, monkeypatch):
     """The chain kernel with its contact detection on three helper waves (`physics_kernel_chain<.., HELP>`, the default) against the 64-thread launch
-    that detects in line (LG_SPLIT=0): every byte the library owns, 60 steps with falls and resets, ragged env counts."""
+    that detects in line (LG_SPLIT=0): every byte the library owns, 60 steps with falls and resets, ragged env counts.  Up to 16 envs per workgroup
+    (N <= 4096) the upper 32 lanes of every wave mirror the lower 32 and the per-slot work is split between the halves; the last case forces 32 envs
+    per workgroup (`LG_CHAIN_EPB`, what N > 8160 gets): every lane its own (env, leg)."""
     import torch
     from extended_legged_gym_amd.native import NativeCore
 
@@ -238,6 +240,9 @@ def test_helper_wave_detection_equals_the_single_wave_launch(mesh, n, monkeypatc
         if mesh != "plane":
             cfg.terrain.mesh_type = mesh
         cfg.env.episode_length_s = 0.6
+
+    if epb:
+        monkeypatch.setenv("LG_CHAIN_EPB", epb)
 
     def build(split):
         monkeypatch.setenv("LG_SPLIT", "1" if split else "0")
