@@ -62,3 +62,18 @@ if __name__ == "__main__":
             env.step(torch.randn(128, 12, generator=g).cuda())
     print(f"config 5: 300 persistent horizons of 16 steps: rewards finite={bool(torch.isfinite(rews).all())} state finite={bool(torch.isfinite(env.root_states).all())}", flush=True)
     assert torch.isfinite(rews).all() and torch.isfinite(env.root_states).all()
+    env.core.close()
+    # config 3: A1 on the confined OBJ mesh -- contact queries over the mesh's lattice cells (closest_point_lattice_pair)
+    from tools.bench_configs import config3_env
+    env = config3_env()
+    assert env.core.collision_mesh.contact_lattice[0] > 0
+    zmin = float(env.core.collision_mesh_zmin) if hasattr(env.core, "collision_mesh_zmin") else float(env.setup.collision_vertices[:, 2].min())
+    pool = [torch.randn(4096, 12, generator=g).cuda() for _ in range(32)]
+    low = 1e9
+    for i in range(4000):
+        env.step(pool[i % 32])
+        if i % 50 == 0:
+            low = min(low, float(env.root_states[:, 2].min()))
+    report("config 3 (A1, confined OBJ mesh, lattice contact queries)", env, 4000)
+    print(f"   lowest base z seen {low:.3f} (mesh z_min {zmin:.3f})", flush=True)
+    assert low > zmin - 1.0
