@@ -44,6 +44,7 @@ struct lg_mesh {
   float4* d_gcz = nullptr;             // per cell: min z, max z of the lower group, min z, max z of the upper group (an empty group: +1e30, -1e30)
   uint2* d_gcr = nullptr;              // per cell: first triangle of its run in d_gtris, (faces in the lower group) | (faces in the upper group) << 16
   float gx0 = 0.f, gy0 = 0.f, ghx = 0.f, ghy = 0.f;   // boundary i of an axis = g?0 + i * gh? to within LATTICE_TOL * gh?
+  int gmaxrun = 0;                     // most faces listed in one cell (the least a query table must hold: closest_point_lattice_pair)
   float4* d_sdf_cache = nullptr;       // lg_sdf_bodies_update: last closest surface point per query slot (xyz, w = 1 when set)
   int64_t sdf_cache_n = 0;
   std::string err;
@@ -52,7 +53,10 @@ struct lg_mesh {
 // ------------------------------------------------------------------------------------------------ device: traversal
 struct MeshView { const BvhNode4* __restrict__ nodes; const float4* __restrict__ tris; };
 #define LATTICE_TOL 1e-3f
-struct LatticeView { const float4* __restrict__ cell; const uint2* __restrict__ run; const float4* __restrict__ tris; int nx, ny; float x0, y0, hx, hy; };
+struct LatticeView { const float4* __restrict__ cell; const uint2* __restrict__ run; const float4* __restrict__ tris; int nx, ny; float x0, y0, hx, hy;
+                     int cap; /* entries of a wave's query table (<= LATP_CAP; LG_LATTICE_CAP shrinks it: the tests' way to the refill path) */ };
+#define LATP_PER 13
+#define LATP_CAP (128 * LATP_PER)
 #define BVH_STACK 40      // <= 3 pushes per level of a 4-wide tree
 
 struct Node4Regs { float4 minx, miny, minz, maxx, maxy, maxz; int4 child; };

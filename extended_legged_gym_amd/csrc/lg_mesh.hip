@@ -497,6 +497,7 @@ lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t
         }
         cz[c] = make_float4(z[0], z[1], z[2], z[3]);
         cr[c] = make_uint2((uint32_t)first, (uint32_t)split | ((uint32_t)(cnt - split) << 16));
+        m->gmaxrun = std::max(m->gmaxrun, cnt);
       }
       if (ok) {
         if (hipMalloc((void**)&m->d_gcz, cz.size() * sizeof(float4)) != hipSuccess || hipMalloc((void**)&m->d_gcr, cr.size() * sizeof(uint2)) != hipSuccess ||

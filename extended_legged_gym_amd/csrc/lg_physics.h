@@ -928,8 +928,6 @@ LG_DEV int* mesh_stack_i(float* cst, int sp0, int lane) { return reinterpret_cas
 // The table lives in the set-up blocks of the wave's two slot records (dwords 12..59 of [slot][lane][CF_FIELDS], where the tree walk keeps its stacks): per
 // lane and slot 8 dwords of query record (centre xyz, acceptance limit, min key, max key) and 13 table entries of 3 dwords (query | face, distance, |plane distance|).
 // A table that fills up is tested and refilled (the lanes keep their place).
-#define LATP_PER 13
-#define LATP_CAP (128 * LATP_PER)
 #define LATP_INVALID 0xffffffffu
 #define LATP_BLOCK 8
 struct LatQ { V3 p; float best2, prev; bool on; int i0, i1, j0, j1, ci, cj; float fx, fy; };
@@ -968,8 +966,8 @@ LG_DEV void closest_point_lattice_pair(const LatticeView& L, ClosestQuery& QA, C
     const int n0 = (int)(r.y & 0xffffu), n1 = (int)(r.y >> 16);
     const int first = (int)r.x + ((ok & 1u) ? 0 : n0), n = ((ok & 1u) ? n0 : 0) + ((ok & 2u) ? n1 : 0);
     const int off = (int)__hip_atomic_fetch_add(ctr, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (off + n > LATP_CAP) {
-      for (int t = off; t < LATP_CAP; ++t) reinterpret_cast<unsigned*>(ent(t))[0] = LATP_INVALID;
+    if (off + n > L.cap) {
+      for (int t = off; t < L.cap; ++t) reinterpret_cast<unsigned*>(ent(t))[0] = LATP_INVALID;
       return false;
     }
     for (int kf = 0; kf < n; ++kf) reinterpret_cast<unsigned*>(ent(off + kf))[0] = tag | (unsigned)(first + kf);
@@ -1064,7 +1062,7 @@ LG_DEV void closest_point_lattice_pair(const LatticeView& L, ClosestQuery& QA, C
       }
     }
     wave_lds_sync();
-    const int T = (int)min(*ctr, (unsigned)LATP_CAP);
+    const int T = (int)min(*ctr, (unsigned)L.cap);
     LSTAMP(17);
 #ifdef LG_LATVIS
     if (dbg && lane == 0) { dbg[30] += T; dbg[31] += 1; }

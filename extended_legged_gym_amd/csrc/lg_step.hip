@@ -2762,7 +2762,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.ter.mesh_type = ter->mesh_type; h.ter.rows = ter->rows; h.ter.cols = ter->cols;
   h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
   h.ter.H = (const int16_t LG_G*)P(LG_T_HEIGHT_SAMPLES);
-  h.ter.L = LatticeView{nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 1.f, 1.f};
+  h.ter.L = LatticeView{nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 1.f, 1.f, LATP_CAP};
   h.ter.M = MeshView{nullptr, nullptr}; h.ter.GV = nullptr; h.ter.GV4 = nullptr; h.ter.GM = nullptr; h.ter.mcols = 0;
   if (const char* ev = getenv("LG_GRID_MESH")) c->grid_mesh = atoi(ev) != 0;
   if (ter->mesh_type == LG_MESH_TRIMESH && ter->grid_vertices && c->grid_mesh) {      // grid mesh: contact queries by cell index
@@ -2795,7 +2795,11 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
     if (ter->collision_mesh->device != device_id) return fail("collision mesh lives on another device");
     h.ter.M = MeshView{ter->collision_mesh->d_nodes, ter->collision_mesh->d_tris};
     if (const lg_mesh* cm = ter->collision_mesh; cm->d_gcz && cm->d_gcr && !h.ter.GV)      // a lattice mesh: contact queries by cell (closest_point_lattice)
-      h.ter.L = LatticeView{cm->d_gcz, cm->d_gcr, cm->d_gtris, cm->gnx, cm->gny, cm->gx0, cm->gy0, cm->ghx, cm->ghy};
+    {
+      int cap = LATP_CAP;                                  // LG_LATTICE_CAP: a smaller query table (never below the longest run of faces: a run must fit an empty table)
+      if (const char* ev = getenv("LG_LATTICE_CAP")) cap = std::min(LATP_CAP, std::max(atoi(ev), std::max(cm->gmaxrun, 1)));
+      h.ter.L = LatticeView{cm->d_gcz, cm->d_gcr, cm->d_gtris, cm->gnx, cm->gny, cm->gx0, cm->gy0, cm->ghx, cm->ghy, cap};
+    }
     for (int k = 0; k < 3; ++k) { h.mesh_lo[k] = ter->collision_mesh->bmin[k]; h.mesh_hi[k] = ter->collision_mesh->bmax[k]; }
   }
   h.nblocks_post = (h.N + EPBP - 1) / EPBP;

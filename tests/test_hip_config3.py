@@ -108,11 +108,16 @@ def test_a1_on_confined_obj_mesh_never_falls_through(tmp_path):
     print("config 3 property run: lowest base z %.3f (mesh z_min %.3f), %d resets in %d env-steps" % (z_low, zmin, resets, n * steps))
 
 
-def test_lattice_contact_queries_equal_the_tree_walk(tmp_path, monkeypatch):
+@pytest.mark.parametrize("cap", [None, "48"])
+def test_lattice_contact_queries_equal_the_tree_walk(tmp_path, monkeypatch, cap):
     """The OBJ mesh the confined-terrain converter writes has its vertices on an evenly spaced lattice: `lg_mesh_create` lists its faces by cell and the
     physics kernel's contact queries index the cells around a sphere (`closest_point_lattice`) instead of walking the tree (`LG_LATTICE_CP=0`).  Both see
     every face that can hold the closest point and share the per-face arithmetic and the order-independent tie rule: same contacts, same trajectories
-    (the closest POINT on an edge two faces share may come from either, a last-bit difference -- so the state is re-synchronised in front of each step)."""
+    (the closest POINT on an edge two faces share may come from either, a last-bit difference -- so the state is re-synchronised in front of each step).
+    `cap`: a query table of 48 entries per wave instead of 1664 (`LG_LATTICE_CAP`; never below the longest run of faces of a cell) -- every call of
+    every wave fills its table several times over: the refill path, which the full-size table meets only when many spheres lose their cached bound at once."""
+    if cap:
+        monkeypatch.setenv("LG_LATTICE_CAP", cap)
     from tests.test_hip_fused_step import SYNC
     n = 128
     envs = []
