@@ -166,58 +166,110 @@ struct RayGrid { const float* __restrict__ xb; const float* __restrict__ yb; int
                  const float2* __restrict__ zr;    // per cell (iy * nx + ix): min z, max z of the triangles listed in it (empty: +1e30, -1e30) -- all the walk reads per cell
                  const int2* __restrict__ run;     // per cell: first triangle of its run in `tris`, count -- read only for cells whose z range the ray reaches
                  const float4* __restrict__ tris; };
-LG_DEV int raygrid_locate(const float* b, int n, float x, int guess) {
+// How the walk reads the lattice.  RayTables: the boundary tables of the whole lattice in LDS (x boundaries (nx + 1) followed by y boundaries (ny + 1)), the
+// cell records from global memory -- one dependent L2 round trip per cell crossed.  RayPatch (round 6; the depth camera): one camera's rays all start at the
+// camera and end within far_clip of it, so the workgroup stages the boundaries AND the z ranges of the cells under that square in LDS once (<= PATCH x PATCH
+// cells) and the walk of its 1800 rays reads LDS; a cell outside the staged block (a lattice finer than far_clip / (PATCH / 2)) falls back to global memory.
+// Both deliver the same numbers, so the walk visits the same cells and tests the same triangles: the hit is the same t bit for bit.
+struct RayTables {
+  const float* tb; const RayGrid* G;
+  LG_DEV float xb(int i) const { return tb[i]; }
+  LG_DEV float yb(int i) const { return tb[G->nx + 1 + i]; }
+  LG_DEV float2 zr(int ix, int iy) const { return G->zr[(size_t)iy * G->nx + ix]; }
+  LG_DEV float x_lo() const { return tb[0]; }
+  LG_DEV float x_hi() const { return tb[G->nx]; }
+  LG_DEV float y_lo() const { return tb[G->nx + 1]; }
+  LG_DEV float y_hi() const { return tb[G->nx + 1 + G->ny]; }
+  LG_DEV float z_top() const { return 3.0e38f; }
+};
+struct RayGlobal {     // everything from global memory (the depth kernel locating its patch: wave-uniform addresses)
+  const RayGrid* G;
+  LG_DEV float xb(int i) const { return G->xb[i]; }
+  LG_DEV float yb(int i) const { return G->yb[i]; }
+};
+#define RAY_PATCH 48
+struct RayPatch {
+  const float* px; const float* py; const float2* pz;     // LDS: boundaries ix0 .. ix0 + pw, iy0 .. iy0 + ph; z ranges of the pw x ph cells (row stride RAY_PATCH)
+  int ix0, iy0, pw, ph; const RayGrid* G;
+  float xlo, xhi, ylo, yhi;                               // the outer lines of the whole lattice
+  float ztop;                                             // no triangle of a cell the rays can reach is higher than this (3e38: unknown)
+  LG_DEV float z_top() const { return ztop; }
+  LG_DEV float x_lo() const { return xlo; }
+  LG_DEV float x_hi() const { return xhi; }
+  LG_DEV float y_lo() const { return ylo; }
+  LG_DEV float y_hi() const { return yhi; }
+  LG_DEV float xb(int i) const { const unsigned r = (unsigned)(i - ix0); return r <= (unsigned)pw ? px[r] : G->xb[i]; }
+  LG_DEV float yb(int i) const { const unsigned r = (unsigned)(i - iy0); return r <= (unsigned)ph ? py[r] : G->yb[i]; }
+  LG_DEV float2 zr(int ix, int iy) const {
+    const unsigned rx = (unsigned)(ix - ix0), ry = (unsigned)(iy - iy0);
+    return (rx < (unsigned)pw && ry < (unsigned)ph) ? pz[ry * RAY_PATCH + rx] : G->zr[(size_t)iy * G->nx + ix];
+  }
+};
+template <class Acc>
+LG_DEV int raygrid_locate(const Acc& A, bool xaxis, int n, float x, int guess) {
   int i = guess < 0 ? 0 : (guess > n - 1 ? n - 1 : guess);
-  while (i > 0 && x < b[i]) --i;
-  while (i < n - 1 && x >= b[i + 1]) ++i;
+  while (i > 0 && x < (xaxis ? A.xb(i) : A.yb(i))) --i;
+  while (i < n - 1 && x >= (xaxis ? A.xb(i + 1) : A.yb(i + 1))) ++i;
   return i;
 }
-// tb: the boundary tables in LDS, x boundaries (nx + 1) followed by y boundaries (ny + 1): one dependent LDS read per cell crossed
-LG_DEV float trace_ray_grid(const RayGrid& G, const float* tb, V3 o, V3 d, float max_dist) {
-  const float* xb = tb; const float* yb = tb + G.nx + 1;
+template <class Acc>
+LG_DEV float trace_ray_grid(const RayGrid& G, const Acc& A, V3 o, V3 d, float max_dist) {
   const V3 inv = v3(1.f / (fabsf(d.x) > 1e-12f ? d.x : copysignf(1e-12f, d.x)), 1.f / (fabsf(d.y) > 1e-12f ? d.y : copysignf(1e-12f, d.y)),
                     1.f / (fabsf(d.z) > 1e-12f ? d.z : copysignf(1e-12f, d.z)));
   // a ray that does not move along an axis (|d| <= 1e-12: a vertical ray) never crosses that axis's lines: its boundary times are -inf / +inf while it
   // is between the outer lines (those included), not the 0 * 1e12 a start exactly ON a line gives
   const bool mvx = fabsf(d.x) > 1e-12f, mvy = fabsf(d.y) > 1e-12f;
+  const float xlo = A.x_lo(), xhi = A.x_hi(), ylo = A.y_lo(), yhi = A.y_hi();
   // the part of the ray over the lattice
   float t0 = 0.f, t1 = max_dist;
   {
-    const bool inx = o.x >= xb[0] && o.x <= xb[G.nx], iny = o.y >= yb[0] && o.y <= yb[G.ny];
-    const float ax = mvx ? (xb[0] - o.x) * inv.x : (inx ? -3.0e38f : 3.0e38f), bx = mvx ? (xb[G.nx] - o.x) * inv.x : (inx ? 3.0e38f : -3.0e38f);
-    const float ay = mvy ? (yb[0] - o.y) * inv.y : (iny ? -3.0e38f : 3.0e38f), by = mvy ? (yb[G.ny] - o.y) * inv.y : (iny ? 3.0e38f : -3.0e38f);
+    const bool inx = o.x >= xlo && o.x <= xhi, iny = o.y >= ylo && o.y <= yhi;
+    const float ax = mvx ? (xlo - o.x) * inv.x : (inx ? -3.0e38f : 3.0e38f), bx = mvx ? (xhi - o.x) * inv.x : (inx ? 3.0e38f : -3.0e38f);
+    const float ay = mvy ? (ylo - o.y) * inv.y : (iny ? -3.0e38f : 3.0e38f), by = mvy ? (yhi - o.y) * inv.y : (iny ? 3.0e38f : -3.0e38f);
     t0 = fmaxf(t0, fmaxf(fminf(ax, bx), fminf(ay, by)));
     t1 = fminf(t1, fminf(fmaxf(ax, bx), fmaxf(ay, by)));
   }
+  {
+    // while the ray is above every triangle it can reach, no cell is a candidate: the walk starts where the ray comes down to that height (a ray that never
+    // does misses) -- the cells in front of that point would all have been skipped one by one
+    const float ztop = A.z_top();
+    if (ztop < 3.0e37f && o.z > ztop) {
+      const float pad = 2e-5f * fabsf(t1) + 1e-6f;
+      const float ts = d.z < 0.f ? (ztop - o.z) * inv.z - pad * (1.f + fabsf(inv.z)) - 1e-4f : 3.0e38f;      // o.z + t d.z <= ztop from ts on (taken early by the walk's own padding and more)
+      t0 = fmaxf(t0, ts);
+    }
+  }
   if (!(t0 <= t1)) return -1.f;
   const float px = o.x + t0 * d.x, py = o.y + t0 * d.y;
-  const float ux = (float)G.nx / (xb[G.nx] - xb[0]), uy = (float)G.ny / (yb[G.ny] - yb[0]);
-  int ix = raygrid_locate(xb, G.nx, px, (int)((px - xb[0]) * ux)), iy = raygrid_locate(yb, G.ny, py, (int)((py - yb[0]) * uy));
+  const float ux = (float)G.nx / (xhi - xlo), uy = (float)G.ny / (yhi - ylo);
+  int ix = raygrid_locate(A, true, G.nx, px, (int)((px - xlo) * ux)), iy = raygrid_locate(A, false, G.ny, py, (int)((py - ylo) * uy));
   const int sx = inv.x >= 0.f ? 1 : -1, sy = inv.y >= 0.f ? 1 : -1;
-  const int ox = sx > 0 ? 1 : 0, oy = (sy > 0 ? 1 : 0) + G.nx + 1;     // offsets into tb of the boundary AHEAD of cell ix / iy
+  const int ox = sx > 0 ? 1 : 0, oy = sy > 0 ? 1 : 0;     // the boundary AHEAD of cell ix / iy is boundary ix + ox / iy + oy
   // (the boundary AHEAD of a cell on such an axis: +inf as well -- the cell was left before it was looked at: a miss where the tree walk hits)
   // ... and a ray without motion across the lines of an axis that starts exactly ON one of them runs down the border of two columns of cells: triangles
   // of the - side column reach it only with an edge (they are not listed in the + side cells), and where the slope correction folded the surface the
   // nearest hit may be one of theirs.  Such rays (a measure-zero set; tested wave-wide, so other waves pay three ballots) walk the - side column(s) too.
   const int ix0 = ix, iy0 = iy;
-  const bool lx = !mvx && ix0 > 0 && px == xb[ix0], ly = !mvy && iy0 > 0 && py == yb[iy0];
+  const bool lx = !mvx && ix0 > 0 && px == A.xb(ix0), ly = !mvy && iy0 > 0 && py == A.yb(iy0);
   float best = max_dist; bool hit = false;
   for (int var = 0; var < 4; ++var) {
   const bool use = var == 0 || (((var & 1) == 0 || lx) && ((var & 2) == 0 || ly));
   if (var > 0 && __ballot(use) == 0ull) continue;
-  ix = ix0 - (var & 1); iy = iy0 - (var >> 1);
-  float tmx = mvx ? (tb[ix + ox] - o.x) * inv.x : 3.0e38f, tmy = mvy ? (tb[iy + oy] - o.y) * inv.y : 3.0e38f;
+  // (a lane that does not take part keeps its own cell: ix0 - 1 would be -1 for a lane in the first column -- an index below the tables)
+  ix = use ? ix0 - (var & 1) : ix0; iy = use ? iy0 - (var >> 1) : iy0;
+  float tmx = mvx ? (A.xb(ix + ox) - o.x) * inv.x : 3.0e38f, tmy = mvy ? (A.yb(iy + oy) - o.y) * inv.y : 3.0e38f;
   float tcur = t0;
   // the ends of a cell's stretch of the ray are rounded: the z range is taken a little beyond either end
   const float padc = 2e-5f * fabsf(t1) + 1e-6f;
   bool done = !use;
-  // one cell on, without branches: the axis whose boundary comes first, the boundary ahead of the new cell from LDS
+  // one cell on, without branches: the axis whose boundary comes first, the boundary ahead of the new cell
   auto advance = [&]() {
     const bool stx = tmx <= tmy;
     const int inew = stx ? ix + sx : iy + sy;
     const bool out = inew < 0 || inew >= (stx ? G.nx : G.ny);
     ix = stx ? inew : ix; iy = stx ? iy : inew;
-    const float bnd = tb[out ? 0 : inew + (stx ? ox : oy)];
+    const int ib = out ? 0 : inew + (stx ? ox : oy);
+    const float bnd = stx ? A.xb(ib) : A.yb(ib);
     const float tn = (stx ? mvx : mvy) ? (bnd - (stx ? o.x : o.y)) * (stx ? inv.x : inv.y) : 3.0e38f;
     tmx = stx ? tn : tmx; tmy = stx ? tmy : tn;
     done = done || out;
@@ -229,7 +281,7 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const float* tb, V3 o, V3 d, float
     float tnext = 0.f;
     while (!done && !cand) {
       tnext = fminf(tmx, tmy);
-      const float2 z = G.zr[(size_t)iy * G.nx + ix];
+      const float2 z = A.zr(ix, iy);
       const float za = o.z + (tcur - padc) * d.z, zb = o.z + (fminf(tnext, t1) + padc) * d.z;
       cand = !(fminf(za, zb) > z.y || fmaxf(za, zb) < z.x);
       if (!cand) {
@@ -264,6 +316,8 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const float* tb, V3 o, V3 d, float
   }
   return hit ? best : -1.f;
 }
+// tb: the boundary tables in LDS, x boundaries (nx + 1) followed by y boundaries (ny + 1)
+LG_DEV float trace_ray_grid_tb(const RayGrid& G, const float* tb, V3 o, V3 d, float max_dist) { return trace_ray_grid(G, RayTables{tb, &G}, o, d, max_dist); }
 
 // closest point on triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5)
 LG_DEV V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
@@ -473,5 +527,126 @@ LG_DEV void closest_point_pair_t(const MeshView& M, ClosestQuery& A, ClosestQuer
 }
 LG_DEV void closest_point_pair(const MeshView& M, ClosestQuery& A, ClosestQuery& B, int* visits = nullptr) {
   closest_point_pair_t<false>(M, A, B, nullptr, nullptr, visits);
+}
+
+// one face of a grid / lattice mesh against the running closest point: `closest_point`'s arithmetic, tolerances and tie rule (order-free)
+LG_DEV void closest_grid_triangle(V3 p, V3 a, V3 b, V3 cc, float& best2, bool& found, float& bestabs, V3& bestp, V3& bestn) {
+  V3 fn = cross(b - a, cc - a); float fl = norm(fn);
+  if (!(fl > 1e-10f)) return;                                 // zero-area faces of the slope correction
+  V3 q = closest_on_triangle(p, a, b, cc);
+  V3 dq = p - q; float d2 = dot(dq, dq);
+  if (!(d2 <= best2 * (1.f + 1e-5f) + 1e-12f)) return;
+  const bool strictly = !found || d2 < best2 * (1.f - 1e-5f) - 1e-12f;
+  if (strictly) { bestabs = -1.f; bestn = v3(0, 0, 1); }
+  V3 nh = (1.f / fl) * fn;
+  float sd = dot(dq, nh);
+  float ab = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f);
+  if (ab > bestabs) { bestn = nh; bestabs = ab; }
+  if (!found || d2 < best2) { best2 = d2; bestp = q; }
+  found = true;
+}
+
+// Closest point on a LATTICE mesh (lg_mesh.d_gcz / d_gcr: an OBJ mesh whose vertices sit on an evenly spaced lattice in x and y -- what the confined-space and
+// heightfield converters write; any number of layers, ceilings, walls).  Every triangle is listed in each cell its xy bounding box overlaps, so the triangles
+// that hold a point within R of p are listed in the cells the square [p - R, p + R] reaches: the cell under p first (its distance bounds the rest), then
+// rounds of 4 x 4 cell records -- thirty-two independent loads, a box test per cell and height group from the record's z ranges -- and the faces of the groups
+// that pass.  Per-face arithmetic, tolerances and tie rule are `closest_point`'s, which does not depend on the order the faces are met in (a face met twice
+// changes nothing): the result is the tree walk's.  The walk pays ~25 DEPENDENT 128-byte node fetches per query.
+LG_DEV void closest_point_lattice(const LatticeView& L, ClosestQuery& A, unsigned long long* v64 = nullptr) {
+  if (!A.on) return;
+  typedef unsigned u2v __attribute__((ext_vector_type(2))); typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef const u2v __attribute__((address_space(1)))* gu2; typedef const f4v __attribute__((address_space(1)))* gf4;
+  const gf4 CELL = (gf4)L.cell; const gu2 RUN = (gu2)L.run; const gf4 TRI = (gf4)L.tris;
+  const V3 p = A.p; const float R = A.max_dist;
+  const float ihx = frcp(L.hx), ihy = frcp(L.hy);
+  float best2 = R * R, bestabs = -1.f; bool found = false;
+  V3 bestp = p, bestn = v3(0, 0, 1);
+  A.found = false; A.cp = p; A.fn = v3(0, 0, 1);
+  const float fx = (p.x - L.x0) * ihx, fy = (p.y - L.y0) * ihy;
+  // (cell indices from arithmetic boundaries: the true ones lie within LATTICE_TOL / 2 of a cell width of them, the window is taken that much wider)
+  float grx = R * ihx + 2.f * LATTICE_TOL, gry = R * ihy + 2.f * LATTICE_TOL;
+  int i0 = max((int)floorf(fx - grx), 0), i1 = min((int)floorf(fx + grx), L.nx - 1), j0 = max((int)floorf(fy - gry), 0), j1 = min((int)floorf(fy + gry), L.ny - 1);
+  if (i0 > i1 || j0 > j1) return;
+  // a run of faces: fetched four at a time, the box of each against the current best in front of the exact test
+  auto exact = [&](int first, int cnt) {
+#pragma unroll 1
+    for (int t0 = 0; t0 < cnt; t0 += 4) {
+      f4v ta[4], tb[4], tc[4];
+      if (v64) *v64 += 1ull << 21;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const gf4 T = TRI + (size_t)(first + min(t0 + u, cnt - 1)) * 3;
+        ta[u] = T[0]; tb[u] = T[1]; tc[u] = T[2];
+      }
+#pragma unroll 1
+      for (int u = 0; u < 4; ++u) {
+        if (t0 + u >= cnt) break;
+        const V3 a = v3(ta[u].x, ta[u].y, ta[u].z), b = v3(tb[u].x, tb[u].y, tb[u].z), cc = v3(tc[u].x, tc[u].y, tc[u].z);
+        if (!(tri_box_dist2(p, a, b, cc) <= best2 * (1.f + 1e-5f) + 1e-12f)) continue;
+        if (v64) *v64 += 1ull << 42;
+        closest_grid_triangle(p, a, b, cc, best2, found, bestabs, bestp, bestn);
+      }
+    }
+  };
+  // which of a cell's two groups (bit 0 lower, bit 1 upper) can hold a point within the current best distance
+  auto cell_ok = [&](int i, int j, f4v z, u2v r) -> unsigned {
+    const float xa = L.x0 + ((float)i - LATTICE_TOL) * L.hx, xb = L.x0 + ((float)(i + 1) + LATTICE_TOL) * L.hx;
+    const float ya = L.y0 + ((float)j - LATTICE_TOL) * L.hy, yb = L.y0 + ((float)(j + 1) + LATTICE_TOL) * L.hy;
+    const float dx = fmaxf(fmaxf(xa - p.x, 0.f), p.x - xb), dy = fmaxf(fmaxf(ya - p.y, 0.f), p.y - yb);
+    const float dz0 = fmaxf(fmaxf(z.x - p.z, 0.f), p.z - z.y), dz1 = fmaxf(fmaxf(z.z - p.z, 0.f), p.z - z.w);     // (an empty group: 1e30 -> never passes)
+    const float dxy = dx * dx + dy * dy, lim = best2 * (1.f + 1e-5f) + 1e-12f;
+    return (((r.y & 0xffffu) != 0u && dxy + dz0 * dz0 <= lim) ? 1u : 0u) | (((r.y >> 16) != 0u && dxy + dz1 * dz1 <= lim) ? 2u : 0u);
+  };
+  auto visit = [&](int i, int j) {
+    const size_t c = (size_t)j * L.nx + i;
+    const f4v z = CELL[c]; const u2v r = RUN[c];
+    if (v64) *v64 += 1ull;
+    const unsigned ok = cell_ok(i, j, z, r);
+    const int n0 = (int)(r.y & 0xffffu), n1 = (int)(r.y >> 16);
+    // the nearer group first: what it finds may rule the other one out
+    const bool upper_first = ok == 3u && fabsf(p.z - z.z) < fabsf(p.z - z.y);
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const bool upper = (h == 1) != upper_first;
+      if (!((h == 0 ? ok : cell_ok(i, j, z, r)) & (upper ? 2u : 1u))) continue;
+      exact((int)r.x + (upper ? n0 : 0), upper ? n1 : n0);
+    }
+  };
+  const int ci = max(i0, min((int)floorf(fx), i1)), cj = max(j0, min((int)floorf(fy), j1));
+  visit(ci, cj);
+  if (found) {
+    const float r = sqrtf(best2) * (1.f + 1e-4f);
+    grx = r * ihx + 2.f * LATTICE_TOL; gry = r * ihy + 2.f * LATTICE_TOL;
+    i0 = max(i0, (int)floorf(fx - grx)); i1 = min(i1, (int)floorf(fx + grx)); j0 = max(j0, (int)floorf(fy - gry)); j1 = min(j1, (int)floorf(fy + gry));
+  }
+#pragma unroll 1
+  for (int jb = j0; jb <= j1; jb += 4) {
+#pragma unroll 1
+    for (int ib = i0; ib <= i1; ib += 4) {
+      unsigned pass = 0u;
+      {
+        f4v z[16]; u2v r[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const size_t c = (size_t)min(jb + u, L.ny - 1) * L.nx + min(ib + t, L.nx - 1);
+            z[4 * u + t] = CELL[c]; r[4 * u + t] = RUN[c];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (jb + u <= j1 && ib + t <= i1 && !(ib + t == ci && jb + u == cj) && cell_ok(ib + t, jb + u, z[4 * u + t], r[4 * u + t])) pass |= 1u << (4 * u + t);
+      }
+      // (a cell that passed: its records again, cache hits -- indexing the register arrays by `bit` would put them in scratch; and the bound may have shrunk)
+#pragma unroll 1
+      while (pass) {
+        const int bit = __ffs(pass) - 1; pass &= pass - 1u;
+        visit(ib + (bit & 3), jb + (bit >> 2));
+      }
+    }
+  }
+  A.found = found; A.cp = bestp; A.fn = bestn;
 }
 

@@ -34,6 +34,7 @@ LG_DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
 LG_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 LG_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 LG_DEV float norm(V3 a) { return sqrtf(dot(a, a)); }
+LG_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 LG_DEV V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
 
 struct M3 { float m[9]; };

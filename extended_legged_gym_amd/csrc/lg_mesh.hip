@@ -195,7 +195,7 @@ LG_DEV void raygrid_stage(const RayGrid& G, float* tb) {
 // resident waves of every lane of a kernel that MAY take that path
 template <bool GRID>
 LG_DEV float trace_any(const MeshView& M, const RayGrid& G, const float* tb, V3 o, V3 d, float max_dist) {
-  if (GRID) return trace_ray_grid(G, tb, o, d, max_dist);
+  if (GRID) return trace_ray_grid_tb(G, tb, o, d, max_dist);
   return trace_ray(M, o, d, max_dist);
 }
 static RayGrid ray_grid_of(const lg_mesh* m) { return RayGrid{m->d_gxb, m->d_gyb, m->gnx, m->gny, m->d_gzr, m->d_gcells, m->d_gtris}; }
@@ -276,12 +276,18 @@ __global__ __launch_bounds__(256) void raycaster_kernel(MeshView M, RayGrid G, c
 // body, the collision-sphere centre = body position + body rotation * offset, then signed distance, unit gradient and the
 // nearest surface point p - sdf * grad (mesh_sdf.py:295-336) — all bodies of all envs in one launch (the reference runs
 // two Warp queries per body).  sdf rows have a stride so they can be the tail of the extra-observation row.
-__global__ __launch_bounds__(256) void sdf_bodies_kernel(MeshView M, const float* __restrict__ rb /* (N,B,13) */, int B,
-                                                         const int32_t* __restrict__ body_idx, const float* __restrict__ offsets, int nb,
-                                                         const int32_t* __restrict__ ids, int n_ids, float max_dist,
-                                                         float* __restrict__ sdf, int sdf_stride, float* __restrict__ grad,
-                                                         float* __restrict__ nearest, float4* __restrict__ cache) {
-  int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// Round 6: on a lattice mesh (the OBJ meshes of the confined-space / heightfield converters: lg_mesh.d_gcz) the query walks the cells around the body
+// (closest_point_lattice, lg_bvh.h: the cell under the point, then the window the distance found there leaves) instead of the tree -- the tree walk paid
+// ~30 dependent 128-byte node fetches per query and re-fetched 14 x its algorithmic bytes; the lattice reads the cell under a foot and a handful of
+// neighbours.  Same per-face arithmetic and tie rule: the same answer (tests/test_hip_sensors.py).  A query whose bound is wider than LATTICE_SDF_CELLS
+// cell widths (no cache entry yet; a body far above the surface) keeps the tree: its window would be hundreds of cells.
+#define LATTICE_SDF_CELLS 12.f
+__global__ __launch_bounds__(64) void sdf_bodies_kernel(MeshView M, LatticeView L, const float* __restrict__ rb /* (N,B,13) */, int B,
+                                                        const int32_t* __restrict__ body_idx, const float* __restrict__ offsets, int nb,
+                                                        const int32_t* __restrict__ ids, int n_ids, float max_dist,
+                                                        float* __restrict__ sdf, int sdf_stride, float* __restrict__ grad,
+                                                        float* __restrict__ nearest, float4* __restrict__ cache) {
+  int64_t gi = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (gi >= (int64_t)n_ids * nb) return;
   const int kq = (int)(gi / nb), b = (int)(gi - (int64_t)kq * nb);
   const int e = ids ? ids[kq] : kq;
@@ -289,14 +295,22 @@ __global__ __launch_bounds__(256) void sdf_bodies_kernel(MeshView M, const float
   const float q[4] = {s[3], s[4], s[5], s[6]};
   V3 p = v3(s[0], s[1], s[2]);
   if (offsets) p = p + quat_apply(q, v3(offsets[3 * b], offsets[3 * b + 1], offsets[3 * b + 2]));
-  V3 cp, fn; float sd = max_dist; V3 g = v3(0, 0, 0);
+  V3 cp = p, fn = v3(0, 0, 1); float sd = max_dist; V3 g = v3(0, 0, 0);
   // The closest point this slot found last time is a point of the surface, so its distance from the new position bounds the new
   // distance from above -- whatever the body did in between: the search starts with that radius instead of max_dist (10 m in the
-  // reference's configs) and opens a handful of nodes instead of ~100.  Exact: every face within the true distance is still visited.
+  // reference's configs) and opens a handful of nodes / cells instead of ~100.  Exact: every face within the true distance is still visited.
   float md = max_dist;
   const float4 c4 = cache[gi];
   if (c4.w == 1.f) md = fminf(max_dist, norm(p - v3(c4.x, c4.y, c4.z)) * (1.f + 1e-4f) + 1e-5f);
-  bool found = closest_point(M, p, md, &cp, &fn);
+  bool found = false;
+  const bool by_cell = L.cell != nullptr && md <= LATTICE_SDF_CELLS * fminf(L.hx, L.hy);
+  if (by_cell) {
+    ClosestQuery Q; Q.p = p; Q.max_dist = md; Q.on = true; Q.found = false; Q.cp = p; Q.fn = v3(0, 0, 1); Q.range = md; Q.lb = 0.f;
+    closest_point_lattice(L, Q);
+    found = Q.found; cp = Q.cp; fn = Q.fn;
+  } else {
+    found = closest_point(M, p, md, &cp, &fn);
+  }
   if (!found && md < max_dist) found = closest_point(M, p, max_dist, &cp, &fn);     // (rounding at the boundary of the reduced radius)
   cache[gi] = found ? make_float4(cp.x, cp.y, cp.z, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
   if (found) {
@@ -320,15 +334,17 @@ LG_DEV float cubic_w(float x) {   // Keys kernel, a = -0.75 (torch / torchvision
 
 // DepthCameraWarp.update + update_depth_buffer + process_depth_image (depth_camera.py:402-566, 84-138, 56-69):
 // one workgroup per env; the raw H x W depth image lives in LDS between the ray pass and the resize pass.
-template <bool GRID>
+// GRID: 0 the tree walk, 1 the lattice walk with the whole boundary tables in LDS and the cell records from global memory (round 4/5; LG_RAY_PATCH=0: the
+// A/B switch and the checker of the patch), 2 the lattice walk over the camera's patch in LDS (round 6).
+template <int GRID>
 __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const float* __restrict__ root, const float* __restrict__ ray_d /* (H*W,3) */,
                                                     const int64_t* __restrict__ ep_len, int W, int H, int TW, int TH, int RW, int RH, int buffer_len,
                                                     float near_clip, float far_clip, float px, float py, float pz,
                                                     float qx, float qy, float qz, float qw, const float* __restrict__ env_noise,
-                                                    float* __restrict__ cam_pos, float* __restrict__ cam_rot, float* __restrict__ depth_buffer) {
+                                                    float* __restrict__ cam_pos, float* __restrict__ cam_rot, float* __restrict__ depth_buffer, int getenv_skip) {
   extern __shared__ float img[];
-  float* const rg_tab = img + W * H;
-  if (GRID) raygrid_stage(G, rg_tab);
+  float* const rg_tab = img + W * H;       // GRID: x boundaries [RAY_PATCH + 1] | y boundaries [RAY_PATCH + 1] | 4 wave maxima | z ranges [RAY_PATCH][RAY_PATCH] x 2
+  if (GRID == 1) raygrid_stage(G, rg_tab);
   const int e = blockIdx.x, tid = threadIdx.x;
   const float* rs = root + (size_t)e * 13;
   const float bq[4] = {rs[3], rs[4], rs[5], rs[6]};
@@ -347,6 +363,48 @@ __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const
     cam_rot[4 * e] = cq[0]; cam_rot[4 * e + 1] = cq[1]; cam_rot[4 * e + 2] = cq[2]; cam_rot[4 * e + 3] = cq[3];
   }
   const float noise = env_noise ? env_noise[e] : 0.f;
+  // The camera's patch of the lattice (lg_bvh.h, RayPatch): every ray starts at cpos and ends within far_clip * |d| of it, so the cells under the square
+  // [cpos - R, cpos + R] are all the walk can visit: their boundaries and z ranges go to LDS once (one round of independent, coalesced loads) and the
+  // walk of the workgroup's W x H rays reads LDS where it paid a dependent L2 round trip per cell crossed.  A lattice so fine that the square spans more
+  // than RAY_PATCH cells keeps the block around the camera; cells outside it are read from global memory (same numbers, same hits).
+  RayPatch patch{};
+  if (GRID == 2) {
+    float* const ppx = rg_tab; float* const ppy = rg_tab + RAY_PATCH + 1; float* const red = rg_tab + 2 * (RAY_PATCH + 1);
+    float2* const ppz = reinterpret_cast<float2*>(rg_tab + 2 * (RAY_PATCH + 1) + 4);
+    float m2 = 0.f;
+    for (int p = tid; p < W * H; p += 256) m2 = fmaxf(m2, ray_d[3 * p] * ray_d[3 * p] + ray_d[3 * p + 1] * ray_d[3 * p + 1] + ray_d[3 * p + 2] * ray_d[3 * p + 2]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m2;
+    __syncthreads();
+    m2 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float R = far_clip * sqrtf(m2) * (1.f + 1e-4f) + 1e-4f;       // (the rotation by the camera quaternion keeps a length to rounding)
+    const RayGlobal A{&G};
+    const float xlo = G.xb[0], xhi = G.xb[G.nx], ylo = G.yb[0], yhi = G.yb[G.ny];
+    const float ux = (float)G.nx / (xhi - xlo), uy = (float)G.ny / (yhi - ylo);
+    auto cell_x = [&](float x) { return raygrid_locate(A, true, G.nx, x, (int)((x - xlo) * ux)); };
+    auto cell_y = [&](float y) { return raygrid_locate(A, false, G.ny, y, (int)((y - ylo) * uy)); };
+    int ix0 = cell_x(cpos.x - R), pw = cell_x(cpos.x + R) - ix0 + 1, iy0 = cell_y(cpos.y - R), ph = cell_y(cpos.y + R) - iy0 + 1;
+    const bool whole = pw <= RAY_PATCH && ph <= RAY_PATCH;       // the staged block holds every cell the rays can reach (else: nothing is known about the cells beyond it)
+    if (pw > RAY_PATCH) { ix0 = min(max(cell_x(cpos.x) - RAY_PATCH / 2, 0), G.nx - RAY_PATCH); pw = RAY_PATCH; }
+    if (ph > RAY_PATCH) { iy0 = min(max(cell_y(cpos.y) - RAY_PATCH / 2, 0), G.ny - RAY_PATCH); ph = RAY_PATCH; }
+    for (int i = tid; i <= pw; i += 256) ppx[i] = G.xb[ix0 + i];
+    for (int i = tid; i <= ph; i += 256) ppy[i] = G.yb[iy0 + i];
+    float ztop = -3.0e38f;
+    for (int i = tid; i < pw * ph; i += 256) {
+      const int ry = i / pw, rx = i - ry * pw;
+      const float2 z = G.zr[(size_t)(iy0 + ry) * G.nx + ix0 + rx];
+      ppz[ry * RAY_PATCH + rx] = z;
+      ztop = fmaxf(ztop, z.y);                               // (an empty cell: -1e30)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ztop = fmaxf(ztop, __shfl_xor(ztop, o));
+    __syncthreads();                                         // (red[] was read above)
+    if ((tid & 63) == 0) red[tid >> 6] = ztop;
+    __syncthreads();
+    ztop = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    patch = RayPatch{ppx, ppy, ppz, ix0, iy0, pw, ph, &G, xlo, xhi, ylo, yhi, (whole && getenv_skip) ? ztop : 3.0e38f};
+  }
   // a wave takes a TW x TH tile of pixels (TW * TH <= 64, chosen by the host), not 64 consecutive pixels of a row: the rays of a tile cross the same
   // cells (or tree nodes) and finish together
   const int lane = tid & 63, tcols = (W + TW - 1) / TW, ntiles = tcols * ((H + TH - 1) / TH);
@@ -356,7 +414,7 @@ __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const
     if (ly >= TH || pxl >= W || pyl >= H) continue;
     const int p = pyl * W + pxl;
     V3 d = quat_apply(cq, v3(ray_d[3 * p], ray_d[3 * p + 1], ray_d[3 * p + 2]));
-    float t = trace_any<GRID>(M, G, rg_tab, cpos, d, far_clip);
+    float t = GRID == 2 ? trace_ray_grid(G, patch, cpos, d, far_clip) : (GRID == 1 ? trace_ray_grid_tb(G, rg_tab, cpos, d, far_clip) : trace_ray(M, cpos, d, far_clip));
     float depth = t >= 0.f ? -(t * norm(d)) : -far_clip;
     depth += noise;
     img[p] = fminf(fmaxf(depth, -far_clip), -near_clip);
@@ -583,7 +641,11 @@ int lg_sdf_bodies_update(lg_mesh* m, const float* rigid_body_state, int32_t num_
     m->sdf_cache_n = tot;
     MESH_TRY(m, hipMemsetAsync(m->d_sdf_cache, 0, (size_t)tot * sizeof(float4), (hipStream_t)stream));
   }
-  hipLaunchKernelGGL(sdf_bodies_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, rigid_body_state, num_bodies,
+  // LG_SDF_LATTICE=0: always the tree (the A/B switch and the tests' checker)
+  const char* sl = getenv("LG_SDF_LATTICE");
+  LatticeView L{nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 1.f, 1.f, LATP_CAP};
+  if (m->d_gcz && m->d_gcr && !(sl && sl[0] == '0')) L = LatticeView{m->d_gcz, m->d_gcr, m->d_gtris, m->gnx, m->gny, m->gx0, m->gy0, m->ghx, m->ghy, LATP_CAP};
+  hipLaunchKernelGGL(sdf_bodies_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, (hipStream_t)stream, M, L, rigid_body_state, num_bodies,
                      body_indices, sphere_offsets, num_query_bodies, env_ids, n, max_dist, sdf_values, sdf_stride, sdf_gradients, nearest_points, m->d_sdf_cache);
   MESH_TRY(m, hipGetLastError());
   return LG_OK;
@@ -597,9 +659,16 @@ int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* ro
   if (p->width <= 0 || p->height <= 0 || p->resized_width <= 0 || p->resized_height <= 0 || p->buffer_len <= 0) return LG_ERR_INVALID;
   size_t lds = (size_t)p->width * p->height * sizeof(float);
   if (lds > 64 * 1024) { m->err = "depth image too large for the LDS-staged resize"; return LG_ERR_UNSUPPORTED; }
-  // the lattice instance keeps its boundary tables in LDS next to the image; together they must stay within the 64 KB a launch gets without opting in
-  const bool lattice = m->d_gcells && lds + ray_grid_lds(m) <= 64 * 1024;
-  if (lattice) lds += ray_grid_lds(m);
+  // the lattice instances keep the camera's patch of the lattice (depth_kernel<2>) or the whole boundary tables (<1>) in LDS next to the image; together
+  // they must stay within the 64 KB a launch gets without opting in
+  const size_t patch_lds = (size_t)(2 * (RAY_PATCH + 1) + 4 + 2 * RAY_PATCH * RAY_PATCH) * sizeof(float);
+  const char* rp = getenv("LG_RAY_PATCH");
+  const char* rs_ = getenv("LG_RAY_SKIP"); const int skip = (rs_ && rs_[0] == '0') ? 0 : 1;      // (A/B switch: the start of the walk at the height of the patch's highest triangle)
+  int mode = 0;
+  if (m->d_gcells && m->gnx >= 1 && m->gny >= 1) {
+    if (!(rp && rp[0] == '0') && lds + patch_lds <= 64 * 1024) { mode = 2; lds += patch_lds; }
+    else if (lds + ray_grid_lds(m) <= 64 * 1024) { mode = 1; lds += ray_grid_lds(m); }
+  }
   MeshView M{m->d_nodes, m->d_tris};
   // pixel tile of a wave: the TW x TH <= 64 that covers the image with the fewest tiles, the squarest of those
   int TW = 8, TH = 8, best_tiles = 1 << 30;
@@ -608,16 +677,12 @@ int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* ro
       const int nt = ((p->width + tw - 1) / tw) * ((p->height + th - 1) / th);
       if (nt < best_tiles || (nt == best_tiles && abs(tw - th) < abs(TW - TH))) { best_tiles = nt; TW = tw; TH = th; }
     }
-  if (lattice)
-    hipLaunchKernelGGL(depth_kernel<true>, dim3(num_envs), dim3(256), lds, (hipStream_t)stream, M, ray_grid_of(m), root_states, ray_dirs, episode_length_buf,
-                     p->width, p->height, TW, TH, p->resized_width, p->resized_height, p->buffer_len, p->near_clip, p->far_clip,
-                     p->position[0], p->position[1], p->position[2], p->quat_offset[0], p->quat_offset[1], p->quat_offset[2],
-                     p->quat_offset[3], env_noise, camera_pos, camera_rot, depth_buffer);
-  else
-    hipLaunchKernelGGL(depth_kernel<false>, dim3(num_envs), dim3(256), lds, (hipStream_t)stream, M, ray_grid_of(m), root_states, ray_dirs, episode_length_buf,
-                     p->width, p->height, TW, TH, p->resized_width, p->resized_height, p->buffer_len, p->near_clip, p->far_clip,
-                     p->position[0], p->position[1], p->position[2], p->quat_offset[0], p->quat_offset[1], p->quat_offset[2],
-                     p->quat_offset[3], env_noise, camera_pos, camera_rot, depth_buffer);
+#define LG_DEPTH_LAUNCH(MODE) hipLaunchKernelGGL(depth_kernel<MODE>, dim3(num_envs), dim3(256), lds, (hipStream_t)stream, M, ray_grid_of(m), root_states, ray_dirs, \
+                     episode_length_buf, p->width, p->height, TW, TH, p->resized_width, p->resized_height, p->buffer_len, p->near_clip, p->far_clip, \
+                     p->position[0], p->position[1], p->position[2], p->quat_offset[0], p->quat_offset[1], p->quat_offset[2], \
+                     p->quat_offset[3], env_noise, camera_pos, camera_rot, depth_buffer, skip)
+  if (mode == 2) LG_DEPTH_LAUNCH(2); else if (mode == 1) LG_DEPTH_LAUNCH(1); else LG_DEPTH_LAUNCH(0);
+#undef LG_DEPTH_LAUNCH
   MESH_TRY(m, hipGetLastError());
   return LG_OK;
 }

@@ -137,7 +137,6 @@ inline void pack_leg_model(float* t, const lg_robot_model* m, const lg_config* g
 LG_DEV void fill_leg_model(float* t, const float* __restrict__ packed, int tid, int nthreads) {
   for (int idx = tid; idx < LM_FIELDS * GRP; idx += nthreads) t[idx] = packed[idx];
 }
-LG_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 struct LegKin {
   M3 R[NJ];
@@ -624,21 +623,7 @@ LG_DEV void contact_detect_caps(const LegModel& lm_, const TerrainView& T, const
 // tests.  Same per-triangle arithmetic, tolerances and tie rule as `closest_point` (lg_bvh.h), which is independent of the order
 // the triangles are met in: the result is the BVH's.  ~10-30 triangle tests for a foot on the ground instead of a tree walk with
 // dependent 128-byte node fetches.
-LG_DEV void closest_grid_triangle(V3 p, V3 a, V3 b, V3 cc, float& best2, bool& found, float& bestabs, V3& bestp, V3& bestn) {
-  V3 fn = cross(b - a, cc - a); float fl = norm(fn);
-  if (!(fl > 1e-10f)) return;                                 // zero-area faces of the slope correction
-  V3 q = closest_on_triangle(p, a, b, cc);
-  V3 dq = p - q; float d2 = dot(dq, dq);
-  if (!(d2 <= best2 * (1.f + 1e-5f) + 1e-12f)) return;
-  const bool strictly = !found || d2 < best2 * (1.f - 1e-5f) - 1e-12f;
-  if (strictly) { bestabs = -1.f; bestn = v3(0, 0, 1); }
-  V3 nh = (1.f / fl) * fn;
-  float sd = dot(dq, nh);
-  float ab = fabsf(sd) * (sd > 0.f ? 1.001f : 1.f);
-  if (ab > bestabs) { bestn = nh; bestabs = ab; }
-  if (!found || d2 < best2) { best2 = d2; bestp = q; }
-  found = true;
-}
+// (closest_grid_triangle: lg_bvh.h)
 // Every stage below is a few ROUNDS of independent loads (indices clamped, loads unconditional) followed by arithmetic: a wave pays
 // one L2 latency per round whatever its lanes need, and the first version's one-cell-at-a-time loop spent 36 k cycles per pair of
 // queries on ~20 dependent rounds each.
@@ -790,110 +775,7 @@ LG_DEV void closest_point_grid(const TerrainView& T, ClosestQuery& A, int* visit
   A.found = found; A.cp = bestp; A.fn = bestn;
 }
 
-// Closest point on a LATTICE mesh (lg_mesh.d_gcz / d_gcr: an OBJ mesh whose vertices sit on an evenly spaced lattice in x and y -- what the confined-space and
-// heightfield converters write; any number of layers, ceilings, walls).  Every triangle is listed in each cell its xy bounding box overlaps, so the triangles
-// that hold a point within R of p are listed in the cells the square [p - R, p + R] reaches: the cell under p first (its distance bounds the rest), then
-// rounds of 4 x 4 cell records -- thirty-two independent loads, a box test per cell and height group from the record's z ranges -- and the faces of the groups
-// that pass.  Per-face arithmetic, tolerances and tie rule are `closest_point`'s, which does not depend on the order the faces are met in (a face met twice
-// changes nothing): the result is the tree walk's.  The walk pays ~25 DEPENDENT 128-byte node fetches per query.
-LG_DEV void closest_point_lattice(const LatticeView& L, ClosestQuery& A, unsigned long long* v64 = nullptr) {
-  if (!A.on) return;
-  typedef unsigned u2v __attribute__((ext_vector_type(2))); typedef float f4v __attribute__((ext_vector_type(4)));
-  typedef const u2v __attribute__((address_space(1)))* gu2; typedef const f4v __attribute__((address_space(1)))* gf4;
-  const gf4 CELL = (gf4)L.cell; const gu2 RUN = (gu2)L.run; const gf4 TRI = (gf4)L.tris;
-  const V3 p = A.p; const float R = A.max_dist;
-  const float ihx = frcp(L.hx), ihy = frcp(L.hy);
-  float best2 = R * R, bestabs = -1.f; bool found = false;
-  V3 bestp = p, bestn = v3(0, 0, 1);
-  A.found = false; A.cp = p; A.fn = v3(0, 0, 1);
-  const float fx = (p.x - L.x0) * ihx, fy = (p.y - L.y0) * ihy;
-  // (cell indices from arithmetic boundaries: the true ones lie within LATTICE_TOL / 2 of a cell width of them, the window is taken that much wider)
-  float grx = R * ihx + 2.f * LATTICE_TOL, gry = R * ihy + 2.f * LATTICE_TOL;
-  int i0 = max((int)floorf(fx - grx), 0), i1 = min((int)floorf(fx + grx), L.nx - 1), j0 = max((int)floorf(fy - gry), 0), j1 = min((int)floorf(fy + gry), L.ny - 1);
-  if (i0 > i1 || j0 > j1) return;
-  // a run of faces: fetched four at a time, the box of each against the current best in front of the exact test
-  auto exact = [&](int first, int cnt) {
-#pragma unroll 1
-    for (int t0 = 0; t0 < cnt; t0 += 4) {
-      f4v ta[4], tb[4], tc[4];
-      if (v64) *v64 += 1ull << 21;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const gf4 T = TRI + (size_t)(first + min(t0 + u, cnt - 1)) * 3;
-        ta[u] = T[0]; tb[u] = T[1]; tc[u] = T[2];
-      }
-#pragma unroll 1
-      for (int u = 0; u < 4; ++u) {
-        if (t0 + u >= cnt) break;
-        const V3 a = v3(ta[u].x, ta[u].y, ta[u].z), b = v3(tb[u].x, tb[u].y, tb[u].z), cc = v3(tc[u].x, tc[u].y, tc[u].z);
-        if (!(tri_box_dist2(p, a, b, cc) <= best2 * (1.f + 1e-5f) + 1e-12f)) continue;
-        if (v64) *v64 += 1ull << 42;
-        closest_grid_triangle(p, a, b, cc, best2, found, bestabs, bestp, bestn);
-      }
-    }
-  };
-  // which of a cell's two groups (bit 0 lower, bit 1 upper) can hold a point within the current best distance
-  auto cell_ok = [&](int i, int j, f4v z, u2v r) -> unsigned {
-    const float xa = L.x0 + ((float)i - LATTICE_TOL) * L.hx, xb = L.x0 + ((float)(i + 1) + LATTICE_TOL) * L.hx;
-    const float ya = L.y0 + ((float)j - LATTICE_TOL) * L.hy, yb = L.y0 + ((float)(j + 1) + LATTICE_TOL) * L.hy;
-    const float dx = fmaxf(fmaxf(xa - p.x, 0.f), p.x - xb), dy = fmaxf(fmaxf(ya - p.y, 0.f), p.y - yb);
-    const float dz0 = fmaxf(fmaxf(z.x - p.z, 0.f), p.z - z.y), dz1 = fmaxf(fmaxf(z.z - p.z, 0.f), p.z - z.w);     // (an empty group: 1e30 -> never passes)
-    const float dxy = dx * dx + dy * dy, lim = best2 * (1.f + 1e-5f) + 1e-12f;
-    return (((r.y & 0xffffu) != 0u && dxy + dz0 * dz0 <= lim) ? 1u : 0u) | (((r.y >> 16) != 0u && dxy + dz1 * dz1 <= lim) ? 2u : 0u);
-  };
-  auto visit = [&](int i, int j) {
-    const size_t c = (size_t)j * L.nx + i;
-    const f4v z = CELL[c]; const u2v r = RUN[c];
-    if (v64) *v64 += 1ull;
-    const unsigned ok = cell_ok(i, j, z, r);
-    const int n0 = (int)(r.y & 0xffffu), n1 = (int)(r.y >> 16);
-    // the nearer group first: what it finds may rule the other one out
-    const bool upper_first = ok == 3u && fabsf(p.z - z.z) < fabsf(p.z - z.y);
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-      const bool upper = (h == 1) != upper_first;
-      if (!((h == 0 ? ok : cell_ok(i, j, z, r)) & (upper ? 2u : 1u))) continue;
-      exact((int)r.x + (upper ? n0 : 0), upper ? n1 : n0);
-    }
-  };
-  const int ci = max(i0, min((int)floorf(fx), i1)), cj = max(j0, min((int)floorf(fy), j1));
-  visit(ci, cj);
-  if (found) {
-    const float r = sqrtf(best2) * (1.f + 1e-4f);
-    grx = r * ihx + 2.f * LATTICE_TOL; gry = r * ihy + 2.f * LATTICE_TOL;
-    i0 = max(i0, (int)floorf(fx - grx)); i1 = min(i1, (int)floorf(fx + grx)); j0 = max(j0, (int)floorf(fy - gry)); j1 = min(j1, (int)floorf(fy + gry));
-  }
-#pragma unroll 1
-  for (int jb = j0; jb <= j1; jb += 4) {
-#pragma unroll 1
-    for (int ib = i0; ib <= i1; ib += 4) {
-      unsigned pass = 0u;
-      {
-        f4v z[16]; u2v r[16];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const size_t c = (size_t)min(jb + u, L.ny - 1) * L.nx + min(ib + t, L.nx - 1);
-            z[4 * u + t] = CELL[c]; r[4 * u + t] = RUN[c];
-          }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (jb + u <= j1 && ib + t <= i1 && !(ib + t == ci && jb + u == cj) && cell_ok(ib + t, jb + u, z[4 * u + t], r[4 * u + t])) pass |= 1u << (4 * u + t);
-      }
-      // (a cell that passed: its records again, cache hits -- indexing the register arrays by `bit` would put them in scratch; and the bound may have shrunk)
-#pragma unroll 1
-      while (pass) {
-        const int bit = __ffs(pass) - 1; pass &= pass - 1u;
-        visit(ib + (bit & 3), jb + (bit >> 2));
-      }
-    }
-  }
-  A.found = found; A.cp = bestp; A.fn = bestn;
-}
-
+// (closest_point_lattice, the lane-by-lane form of the lattice query, lives in lg_bvh.h: the SDF kernel of lg_mesh.hip uses it too)
 #if NJ == 3      // ---- the tuned three-joint kernels' own piece (lg_chain.h holds the six-joint instance's)
 // Triangle-mesh terrain (LG_MESH_TRIMESH): the surface under a sphere is the closest point of the collision mesh within
 // range = radius + contact_offset + LG_MESH_CONTACT_MARGIN (the margin lets a sphere whose centre has sunk below the surface

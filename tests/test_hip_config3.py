@@ -152,3 +152,35 @@ def test_lattice_contact_queries_equal_the_tree_walk(tmp_path, monkeypatch, cap)
         contacts += int((a.core.t["contact_forces"].view(n, -1, 3).norm(dim=2) > 1.0).sum())
     assert contacts > 60 * n and mismatched <= 12
     a.core.close(); b.core.close()
+
+
+def test_body_sdf_by_cell_equals_the_tree_walk(tmp_path, monkeypatch):
+    """Round 6: `lg_sdf_bodies_update` answers the 5-body SDF of config 3 from the lattice cells around each body (`closest_point_lattice`) once a body has
+    a cached bound; `LG_SDF_LATTICE=0` keeps the tree walk.  Same per-face arithmetic and order-free tie rule: signed distance, gradient and nearest
+    point agree (a closest point on an edge two faces share may come from either face: a last-bit difference)."""
+    from extended_legged_gym_amd.utils.mesh_sdf import MeshSDF, MeshSDFCfg
+    n = 256
+    env, cfg, _ = make_env(tmp_path, n, rows=2, cols=2)
+    env.reset()
+    assert env.core.collision_mesh.contact_lattice[0] > 100
+    bodies = torch.tensor([0] + env.feet_indices.tolist(), dtype=torch.int32, device="cuda")
+    rb = env.rigid_body_state.view(n, env.num_bodies, 13)
+    out = {}
+    for mode in ("cell", "tree"):
+        out[mode] = [torch.zeros(n, 5, device="cuda"), torch.zeros(n, 5, 3, device="cuda"), torch.zeros(n, 5, 3, device="cuda")]
+    sdfs = {m: MeshSDF(MeshSDFCfg(max_distance=10.0), device="cuda:0", mesh=env.core.collision_mesh) for m in ("cell", "tree")}
+    g = torch.Generator().manual_seed(3)
+    worst = 0.0
+    for it in range(40):
+        env.step(torch.randn(n, 12, generator=g).cuda())
+        for mode in ("cell", "tree"):
+            if mode == "tree":
+                monkeypatch.setenv("LG_SDF_LATTICE", "0")
+            sdfs[mode].query_bodies(rb, env.num_bodies, bodies, None, *out[mode])
+            monkeypatch.delenv("LG_SDF_LATTICE", raising=False)
+        torch.cuda.synchronize()
+        for a, b in zip(out["cell"], out["tree"]):
+            worst = max(worst, float((a - b).abs().max()))
+    assert torch.isfinite(out["cell"][0]).all() and float(out["cell"][0].abs().max()) < 5.0
+    assert float(out["cell"][0][:, 1:].abs().median()) < 0.1                    # feet are near the surface
+    assert worst <= 2e-5, worst

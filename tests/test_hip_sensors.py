@@ -220,6 +220,51 @@ def test_depth_camera_matches_torch_pipeline():
     assert got[:, -1].min() >= -0.5 - 0.2 and got[:, -1].max() <= 0.5 + 0.2    # bicubic overshoot of the new frame stays small
 
 
+def test_depth_camera_patch_walk_equals_the_table_walk_and_the_tree(monkeypatch):
+    """Round 6: the depth kernel stages the lattice cells under the camera's far-clip square in LDS (`RayPatch`, lg_bvh.h) and walks those.  Same boundaries,
+    same z ranges, same triangle tests: the images are those of the round-5 walk (whole boundary tables in LDS, cell records from global memory;
+    `LG_RAY_PATCH=0`) bit for bit, and the tree's (`LG_RAY_GRID=0`) up to a pixel that a ray through a lattice corner flips.  Two meshes: 0.1 m cells (the
+    square fits the patch; cameras near the mesh border clamp it) and 0.04 m cells (the square spans ~100 cells: the block around the camera is staged, the
+    cells beyond it are read from global memory)."""
+    from extended_legged_gym_amd.utils.depth_camera import DepthCameraWarp
+    from extended_legged_gym_amd.utils.mesh import DeviceMesh
+    cfg = LeggedRobotCfg().depth
+    N = 48
+    g = torch.Generator().manual_seed(7)
+    for hs, n in ((0.1, 60), (0.04, 150)):
+        rng = np.random.default_rng(11)
+        hf = (rng.integers(-20, 20, size=(n, n)) + 30 * np.sin(np.arange(n) / 5.0)[:, None]).astype(np.int16)
+        hf[n // 4: n // 4 + 4, n // 4: 3 * n // 4] = 120
+        v, t = terrain_utils.convert_heightfield_to_trimesh(hf, hs, 0.005, 0.75)
+        half = 0.5 * hs * (n - 1)
+        v[:, :2] -= half
+        t = t.astype(np.int32)
+        root = torch.zeros(N, 13)
+        root[:, 0:2] = (torch.rand(N, 2, generator=g) - 0.5) * 2.0 * (half + 0.3)        # some cameras stand outside the mesh
+        root[:, 2] = 0.4 + 0.4 * torch.rand(N, generator=g)
+        q = torch.randn(N, 4, generator=g) * torch.tensor([0.2, 0.2, 1.0, 1.0]); root[:, 3:7] = q / q.norm(dim=1, keepdim=True)
+        root[0, 0:2] = torch.tensor([float(np.unique(v[:, 0])[n // 2]), float(np.unique(v[:, 1])[n // 3])])   # a camera exactly on a lattice corner
+        eplen = torch.zeros(N, dtype=torch.int64)
+        imgs = {}
+        for mode in ("patch", "tables", "tree"):
+            if mode == "tree":
+                monkeypatch.setenv("LG_RAY_GRID", "0")
+            mesh = DeviceMesh(v, t, "cuda:0")
+            monkeypatch.delenv("LG_RAY_GRID", raising=False)
+            assert (mesh.ray_lattice == (0, 0)) == (mode == "tree")
+            if mode == "tables":
+                monkeypatch.setenv("LG_RAY_PATCH", "0")
+            cam = DepthCameraWarp(cfg, "cuda:0", N, mesh=mesh)
+            cam.update_from_root_states(root.cuda(), eplen.cuda())
+            torch.cuda.synchronize()
+            monkeypatch.delenv("LG_RAY_PATCH", raising=False)
+            imgs[mode] = cam.depth_buffer[:, -1].cpu()
+        assert float(imgs["patch"].std()) > 0.01
+        assert torch.equal(imgs["patch"], imgs["tables"]), hs
+        bad = ((imgs["patch"] - imgs["tree"]).abs() > 1e-6).float().mean()
+        assert float(bad) < 2e-4, (hs, float(bad))
+
+
 def test_env_with_raycaster_and_depth_camera():
     from extended_legged_gym_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
     from extended_legged_gym_amd.envs.base.legged_robot_depthcam import LeggedRobotDepth
