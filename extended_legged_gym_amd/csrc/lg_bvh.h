@@ -35,6 +35,7 @@ struct lg_mesh {
   // ray lattice (rays only; built by lg_mesh_create when the vertices sit on a rectilinear lattice in x and y, i.e. a heightfield-derived mesh)
   float* d_gxb = nullptr; float* d_gyb = nullptr; int gnx = 0, gny = 0;   // cell boundaries: gnx + 1 and gny + 1 ascending coordinates
   float2* d_gzr = nullptr;             // per cell (iy * gnx + ix): min z, max z of the triangles listed in it
+  float* d_gzb = nullptr; int gnbx = 0, gnby = 0;   // per block of RAY_BLK x RAY_BLK cells: the highest z of a triangle listed in one of its cells
   int2* d_gcells = nullptr;            // per cell: first triangle of its run in d_gtris, count
   float4* d_gtris = nullptr;           // triangles in cell order (a triangle that overlaps k cells is stored k times)
   // closest-point queries over the same cells (closest_point_lattice, lg_physics.h): present when the boundaries are evenly spaced (a heightfield-derived mesh
@@ -99,6 +100,26 @@ LG_DEV bool descend4(int cand[4], float key[4], int* stack_i, float* stack_k, in
 // heightfield mesh fall through the crack).  The plane of either neighbour gives the same t to rounding.  The oracle's brute-force scan uses the same band.
 #define RAY_EDGE_EPS 1e-5f
 
+// One triangle against a ray (Moller-Trumbore, two-sided, barycentric band RAY_EDGE_EPS): updates the closest hit.  ONE body for the tree walk and the lattice
+// walk, compiled without floating-point contraction: with the default contraction a product and a sum fuse or not depending on the code AROUND the
+// expression, and "the same arithmetic" in two walks gave hits that differed in the last bit once one of the loops was unrolled.
+LG_DEV void ray_triangle(V3 o, V3 d, float4 a, float4 b, float4 cc, float& best, bool& hit) {
+#pragma clang fp contract(off)
+  const V3 v0 = v3(a.x, a.y, a.z), e1 = v3(b.x - a.x, b.y - a.y, b.z - a.z), e2 = v3(cc.x - a.x, cc.y - a.y, cc.z - a.z);
+  const V3 p = v3(d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x);
+  const float det = (e1.x * p.x + e1.y * p.y) + e1.z * p.z;
+  if (fabsf(det) < 1e-20f) return;
+  const float idet = 1.f / det;
+  const V3 s = v3(o.x - v0.x, o.y - v0.y, o.z - v0.z);
+  const float u = ((s.x * p.x + s.y * p.y) + s.z * p.z) * idet;
+  if (u < -RAY_EDGE_EPS || u > 1.f + RAY_EDGE_EPS) return;
+  const V3 q = v3(s.y * e1.z - s.z * e1.y, s.z * e1.x - s.x * e1.z, s.x * e1.y - s.y * e1.x);
+  const float v = ((d.x * q.x + d.y * q.y) + d.z * q.z) * idet;
+  if (v < -RAY_EDGE_EPS || u + v > 1.f + RAY_EDGE_EPS) return;
+  const float t = ((e2.x * q.x + e2.y * q.y) + e2.z * q.z) * idet;
+  if (t >= 0.f && t <= best) { best = t; hit = true; }
+}
+
 // closest two-sided hit with 0 <= t <= max_dist (Moller-Trumbore); returns t or -1
 LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
   const V3 inv = v3(1.f / (fabsf(d.x) > 1e-12f ? d.x : copysignf(1e-12f, d.x)), 1.f / (fabsf(d.y) > 1e-12f ? d.y : copysignf(1e-12f, d.y)),
@@ -134,20 +155,7 @@ LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
       const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
       for (int i = 0; i < cnt; ++i) {
         const float4* T = M.tris + (size_t)(first + i) * 3;
-        float4 a = T[0], b = T[1], cc = T[2];
-        V3 v0 = v3(a.x, a.y, a.z), e1 = v3(b.x - a.x, b.y - a.y, b.z - a.z), e2 = v3(cc.x - a.x, cc.y - a.y, cc.z - a.z);
-        V3 p = cross(d, e2);
-        float det = dot(e1, p);
-        if (fabsf(det) < 1e-20f) continue;
-        float idet = 1.f / det;
-        V3 s = o - v0;
-        float u = dot(s, p) * idet;
-        if (u < -RAY_EDGE_EPS || u > 1.f + RAY_EDGE_EPS) continue;
-        V3 q = cross(s, e1);
-        float v = dot(d, q) * idet;
-        if (v < -RAY_EDGE_EPS || u + v > 1.f + RAY_EDGE_EPS) continue;
-        float t = dot(e2, q) * idet;
-        if (t >= 0.f && t <= best) { best = t; hit = true; }
+        ray_triangle(o, d, T[0], T[1], T[2], best, hit);
       }
     }
     if (!pop()) done = true;
@@ -165,45 +173,24 @@ LG_DEV float trace_ray(const MeshView& M, V3 o, V3 d, float max_dist) {
 struct RayGrid { const float* __restrict__ xb; const float* __restrict__ yb; int nx, ny;
                  const float2* __restrict__ zr;    // per cell (iy * nx + ix): min z, max z of the triangles listed in it (empty: +1e30, -1e30) -- all the walk reads per cell
                  const int2* __restrict__ run;     // per cell: first triangle of its run in `tris`, count -- read only for cells whose z range the ray reaches
-                 const float4* __restrict__ tris; };
-// How the walk reads the lattice.  RayTables: the boundary tables of the whole lattice in LDS (x boundaries (nx + 1) followed by y boundaries (ny + 1)), the
-// cell records from global memory -- one dependent L2 round trip per cell crossed.  RayPatch (round 6; the depth camera): one camera's rays all start at the
-// camera and end within far_clip of it, so the workgroup stages the boundaries AND the z ranges of the cells under that square in LDS once (<= PATCH x PATCH
-// cells) and the walk of its 1800 rays reads LDS; a cell outside the staged block (a lattice finer than far_clip / (PATCH / 2)) falls back to global memory.
-// Both deliver the same numbers, so the walk visits the same cells and tests the same triangles: the hit is the same t bit for bit.
+                                                   // (measured and dropped, round 6: both in ONE 16-byte record and a run's triangles fetched four at a time: 0.627 against 0.589 ms per step of config 4)
+                 const float4* __restrict__ tris;
+                 const float* __restrict__ zb; int nbx, nby; };   // per block of RAY_BLK x RAY_BLK cells: max z (a camera's rays start where they come down to the highest block in reach)
+#define RAY_BLK 8
+// How the walk reads the boundaries: the tables of the whole lattice in LDS (x boundaries (nx + 1) followed by y boundaries (ny + 1)).  ztop / blocks: what the
+// depth camera knows about its rays (they start at the camera and end within far_clip of it): no triangle in reach is higher than ztop, and the block
+// maxima may be walked in front of the cells.  (Measured and dropped, round 6: the cells' z ranges of the camera's square staged in LDS -- 18 KB and three
+// barriers per workgroup cost more than the L1-resident loads they replaced: 0.65 against 0.59 ms per step of config 4.)
 struct RayTables {
-  const float* tb; const RayGrid* G;
+  const float* tb; const RayGrid* G; float ztop; bool blocks;
   LG_DEV float xb(int i) const { return tb[i]; }
   LG_DEV float yb(int i) const { return tb[G->nx + 1 + i]; }
-  LG_DEV float2 zr(int ix, int iy) const { return G->zr[(size_t)iy * G->nx + ix]; }
   LG_DEV float x_lo() const { return tb[0]; }
   LG_DEV float x_hi() const { return tb[G->nx]; }
   LG_DEV float y_lo() const { return tb[G->nx + 1]; }
   LG_DEV float y_hi() const { return tb[G->nx + 1 + G->ny]; }
-  LG_DEV float z_top() const { return 3.0e38f; }
-};
-struct RayGlobal {     // everything from global memory (the depth kernel locating its patch: wave-uniform addresses)
-  const RayGrid* G;
-  LG_DEV float xb(int i) const { return G->xb[i]; }
-  LG_DEV float yb(int i) const { return G->yb[i]; }
-};
-#define RAY_PATCH 48
-struct RayPatch {
-  const float* px; const float* py; const float2* pz;     // LDS: boundaries ix0 .. ix0 + pw, iy0 .. iy0 + ph; z ranges of the pw x ph cells (row stride RAY_PATCH)
-  int ix0, iy0, pw, ph; const RayGrid* G;
-  float xlo, xhi, ylo, yhi;                               // the outer lines of the whole lattice
-  float ztop;                                             // no triangle of a cell the rays can reach is higher than this (3e38: unknown)
-  LG_DEV float z_top() const { return ztop; }
-  LG_DEV float x_lo() const { return xlo; }
-  LG_DEV float x_hi() const { return xhi; }
-  LG_DEV float y_lo() const { return ylo; }
-  LG_DEV float y_hi() const { return yhi; }
-  LG_DEV float xb(int i) const { const unsigned r = (unsigned)(i - ix0); return r <= (unsigned)pw ? px[r] : G->xb[i]; }
-  LG_DEV float yb(int i) const { const unsigned r = (unsigned)(i - iy0); return r <= (unsigned)ph ? py[r] : G->yb[i]; }
-  LG_DEV float2 zr(int ix, int iy) const {
-    const unsigned rx = (unsigned)(ix - ix0), ry = (unsigned)(iy - iy0);
-    return (rx < (unsigned)pw && ry < (unsigned)ph) ? pz[ry * RAY_PATCH + rx] : G->zr[(size_t)iy * G->nx + ix];
-  }
+  LG_DEV float z_top() const { return ztop; }       // no triangle the ray can reach is higher than this (3e38: unknown)
+  LG_DEV bool coarse() const { return blocks; }     // walk the blocks in front of the cells
 };
 template <class Acc>
 LG_DEV int raygrid_locate(const Acc& A, bool xaxis, int n, float x, int guess) {
@@ -212,13 +199,19 @@ LG_DEV int raygrid_locate(const Acc& A, bool xaxis, int n, float x, int guess) {
   while (i < n - 1 && x >= (xaxis ? A.xb(i + 1) : A.yb(i + 1))) ++i;
   return i;
 }
+// The stretch [t0, t1] of a ray its walk has to cover: [0, max_dist] cut to the part over the lattice and, where the caller knows a ceiling of the reachable
+// triangles (A.z_top()), to the part below that ceiling.  False: nothing to walk -- a miss.  (Its own function since round 6: the depth kernel sorts its rays
+// by this answer before it walks any.)
+struct RaySpan { V3 inv; bool mvx, mvy; float t0, t1; };
 template <class Acc>
-LG_DEV float trace_ray_grid(const RayGrid& G, const Acc& A, V3 o, V3 d, float max_dist) {
-  const V3 inv = v3(1.f / (fabsf(d.x) > 1e-12f ? d.x : copysignf(1e-12f, d.x)), 1.f / (fabsf(d.y) > 1e-12f ? d.y : copysignf(1e-12f, d.y)),
-                    1.f / (fabsf(d.z) > 1e-12f ? d.z : copysignf(1e-12f, d.z)));
+LG_DEV bool ray_span(const Acc& A, V3 o, V3 d, float max_dist, RaySpan& S) {
+  S.inv = v3(1.f / (fabsf(d.x) > 1e-12f ? d.x : copysignf(1e-12f, d.x)), 1.f / (fabsf(d.y) > 1e-12f ? d.y : copysignf(1e-12f, d.y)),
+             1.f / (fabsf(d.z) > 1e-12f ? d.z : copysignf(1e-12f, d.z)));
+  const V3 inv = S.inv;
   // a ray that does not move along an axis (|d| <= 1e-12: a vertical ray) never crosses that axis's lines: its boundary times are -inf / +inf while it
   // is between the outer lines (those included), not the 0 * 1e12 a start exactly ON a line gives
   const bool mvx = fabsf(d.x) > 1e-12f, mvy = fabsf(d.y) > 1e-12f;
+  S.mvx = mvx; S.mvy = mvy;
   const float xlo = A.x_lo(), xhi = A.x_hi(), ylo = A.y_lo(), yhi = A.y_hi();
   // the part of the ray over the lattice
   float t0 = 0.f, t1 = max_dist;
@@ -239,7 +232,16 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const Acc& A, V3 o, V3 d, float ma
       t0 = fmaxf(t0, ts);
     }
   }
-  if (!(t0 <= t1)) return -1.f;
+  S.t0 = t0; S.t1 = t1;
+  return t0 <= t1;
+}
+template <class Acc>
+LG_DEV float trace_ray_grid(const RayGrid& G, const Acc& A, V3 o, V3 d, float max_dist) {
+  RaySpan S;
+  if (!ray_span(A, o, d, max_dist, S)) return -1.f;
+  const V3 inv = S.inv; const bool mvx = S.mvx, mvy = S.mvy;
+  float t0 = S.t0; const float t1 = S.t1;
+  const float xlo = A.x_lo(), xhi = A.x_hi(), ylo = A.y_lo(), yhi = A.y_hi();
   const float px = o.x + t0 * d.x, py = o.y + t0 * d.y;
   const float ux = (float)G.nx / (xhi - xlo), uy = (float)G.ny / (yhi - ylo);
   int ix = raygrid_locate(A, true, G.nx, px, (int)((px - xlo) * ux)), iy = raygrid_locate(A, false, G.ny, py, (int)((py - ylo) * uy));
@@ -249,8 +251,37 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const Acc& A, V3 o, V3 d, float ma
   // ... and a ray without motion across the lines of an axis that starts exactly ON one of them runs down the border of two columns of cells: triangles
   // of the - side column reach it only with an edge (they are not listed in the + side cells), and where the slope correction folded the surface the
   // nearest hit may be one of theirs.  Such rays (a measure-zero set; tested wave-wide, so other waves pay three ballots) walk the - side column(s) too.
+  bool lx = !mvx && ix > 0 && px == A.xb(ix), ly = !mvy && iy > 0 && py == A.yb(iy);
+  if (A.coarse() && A.z_top() < 3.0e37f && G.zb != nullptr && !lx && !ly) {
+    // (round 6; callers that know a ceiling of the reachable triangles -- the depth camera -- also get the coarse walk)  Blocks of RAY_BLK x RAY_BLK cells
+    // with the highest z of their triangles: the ray crosses the blocks in front of it one by one until it comes down to a block's top; the cell walk
+    // starts where it enters THAT block (eight cells further on per step; a ray that stays above every block it crosses misses without a cell walk).
+    // Conservative like the cell walk's own z test (same padding), so the cells left out would all have been skipped: the hit is the same.
+    const float padb = 2e-5f * fabsf(t1) + 1e-6f;
+    int bx = ix / RAY_BLK, by = iy / RAY_BLK;
+    auto edge_x = [&](int b) { return mvx ? (A.xb(min((b + ox) * RAY_BLK, G.nx)) - o.x) * inv.x : 3.0e38f; };
+    auto edge_y = [&](int b) { return mvy ? (A.yb(min((b + oy) * RAY_BLK, G.ny)) - o.y) * inv.y : 3.0e38f; };
+    float tbx = edge_x(bx), tby = edge_y(by), tc = t0;
+    bool reach = false;
+    while (true) {
+      const float tn = fminf(tbx, tby);
+      const float top = G.zb[(size_t)by * G.nbx + bx];
+      const float za = o.z + (tc - padb) * d.z, zb_ = o.z + (fminf(tn, t1) + padb) * d.z;
+      if (fminf(za, zb_) <= top) { reach = true; break; }
+      if (!(tn < t1)) break;
+      const bool stx = tbx <= tby;
+      if (stx) { bx += sx; if (bx < 0 || bx >= G.nbx) break; tbx = edge_x(bx); }
+      else { by += sy; if (by < 0 || by >= G.nby) break; tby = edge_y(by); }
+      tc = tn;
+    }
+    if (!reach) return -1.f;
+    if (tc > t0) {
+      t0 = tc;
+      const float qx = o.x + t0 * d.x, qy = o.y + t0 * d.y;
+      ix = raygrid_locate(A, true, G.nx, qx, (int)((qx - xlo) * ux)); iy = raygrid_locate(A, false, G.ny, qy, (int)((qy - ylo) * uy));
+    }
+  }
   const int ix0 = ix, iy0 = iy;
-  const bool lx = !mvx && ix0 > 0 && px == A.xb(ix0), ly = !mvy && iy0 > 0 && py == A.yb(iy0);
   float best = max_dist; bool hit = false;
   for (int var = 0; var < 4; ++var) {
   const bool use = var == 0 || (((var & 1) == 0 || lx) && ((var & 2) == 0 || ly));
@@ -281,7 +312,7 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const Acc& A, V3 o, V3 d, float ma
     float tnext = 0.f;
     while (!done && !cand) {
       tnext = fminf(tmx, tmy);
-      const float2 z = A.zr(ix, iy);
+      const float2 z = G.zr[(size_t)iy * G.nx + ix];
       const float za = o.z + (tcur - padc) * d.z, zb = o.z + (fminf(tnext, t1) + padc) * d.z;
       cand = !(fminf(za, zb) > z.y || fmaxf(za, zb) < z.x);
       if (!cand) {
@@ -294,20 +325,7 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const Acc& A, V3 o, V3 d, float ma
       const int2 c = G.run[(size_t)iy * G.nx + ix];
       for (int i = 0; i < c.y; ++i) {
         const float4* T = G.tris + (size_t)(c.x + i) * 3;
-        float4 a = T[0], b = T[1], cc = T[2];
-        V3 v0 = v3(a.x, a.y, a.z), e1 = v3(b.x - a.x, b.y - a.y, b.z - a.z), e2 = v3(cc.x - a.x, cc.y - a.y, cc.z - a.z);
-        V3 p = cross(d, e2);
-        float det = dot(e1, p);
-        if (fabsf(det) < 1e-20f) continue;
-        float idet = 1.f / det;
-        V3 s = o - v0;
-        float u = dot(s, p) * idet;
-        if (u < -RAY_EDGE_EPS || u > 1.f + RAY_EDGE_EPS) continue;
-        V3 q = cross(s, e1);
-        float v = dot(d, q) * idet;
-        if (v < -RAY_EDGE_EPS || u + v > 1.f + RAY_EDGE_EPS) continue;
-        float t = dot(e2, q) * idet;
-        if (t >= 0.f && t <= best) { best = t; hit = true; }
+        ray_triangle(o, d, T[0], T[1], T[2], best, hit);
       }
       if ((hit && best <= tcur) || !(tnext < t1)) done = true; else advance();
       tcur = tnext;
@@ -317,7 +335,7 @@ LG_DEV float trace_ray_grid(const RayGrid& G, const Acc& A, V3 o, V3 d, float ma
   return hit ? best : -1.f;
 }
 // tb: the boundary tables in LDS, x boundaries (nx + 1) followed by y boundaries (ny + 1)
-LG_DEV float trace_ray_grid_tb(const RayGrid& G, const float* tb, V3 o, V3 d, float max_dist) { return trace_ray_grid(G, RayTables{tb, &G}, o, d, max_dist); }
+LG_DEV float trace_ray_grid_tb(const RayGrid& G, const float* tb, V3 o, V3 d, float max_dist, float ztop = 3.0e38f, bool blocks = false) { return trace_ray_grid(G, RayTables{tb, &G, ztop, blocks}, o, d, max_dist); }
 
 // closest point on triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5)
 LG_DEV V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {

@@ -198,8 +198,8 @@ LG_DEV float trace_any(const MeshView& M, const RayGrid& G, const float* tb, V3 
   if (GRID) return trace_ray_grid_tb(G, tb, o, d, max_dist);
   return trace_ray(M, o, d, max_dist);
 }
-static RayGrid ray_grid_of(const lg_mesh* m) { return RayGrid{m->d_gxb, m->d_gyb, m->gnx, m->gny, m->d_gzr, m->d_gcells, m->d_gtris}; }
-static size_t ray_grid_lds(const lg_mesh* m) { return m->d_gcells ? (size_t)(m->gnx + m->gny + 2) * sizeof(float) : 0; }
+static RayGrid ray_grid_of(const lg_mesh* m) { return RayGrid{m->d_gxb, m->d_gyb, m->gnx, m->gny, m->d_gzr, m->d_gcells, m->d_gtris, m->d_gzb, m->gnbx, m->gnby}; }
+static size_t ray_grid_lds(const lg_mesh* m) { return m->d_gcells ? (size_t)(m->gnx + m->gny + 2 + 4) * sizeof(float) : 0; }   // (+ 4: a workgroup's reduction scratch, depth_kernel)
 // raycast_mesh (ray_caster.py:95-167): hit point o + t d, or the ray end point o + d max_dist and found = 0
 template <bool GRID>
 __global__ __launch_bounds__(256) void raycast_kernel(MeshView M, RayGrid G, const float* __restrict__ o, const float* __restrict__ d, int64_t n,
@@ -334,8 +334,7 @@ LG_DEV float cubic_w(float x) {   // Keys kernel, a = -0.75 (torch / torchvision
 
 // DepthCameraWarp.update + update_depth_buffer + process_depth_image (depth_camera.py:402-566, 84-138, 56-69):
 // one workgroup per env; the raw H x W depth image lives in LDS between the ray pass and the resize pass.
-// GRID: 0 the tree walk, 1 the lattice walk with the whole boundary tables in LDS and the cell records from global memory (round 4/5; LG_RAY_PATCH=0: the
-// A/B switch and the checker of the patch), 2 the lattice walk over the camera's patch in LDS (round 6).
+// GRID: 0 the tree walk, 1 the lattice walk (boundary tables in LDS, cell records from global memory).
 template <int GRID>
 __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const float* __restrict__ root, const float* __restrict__ ray_d /* (H*W,3) */,
                                                     const int64_t* __restrict__ ep_len, int W, int H, int TW, int TH, int RW, int RH, int buffer_len,
@@ -343,7 +342,7 @@ __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const
                                                     float qx, float qy, float qz, float qw, const float* __restrict__ env_noise,
                                                     float* __restrict__ cam_pos, float* __restrict__ cam_rot, float* __restrict__ depth_buffer, int getenv_skip) {
   extern __shared__ float img[];
-  float* const rg_tab = img + W * H;       // GRID: x boundaries [RAY_PATCH + 1] | y boundaries [RAY_PATCH + 1] | 4 wave maxima | z ranges [RAY_PATCH][RAY_PATCH] x 2
+  float* const rg_tab = img + W * H;       // GRID: x boundaries [nx + 1] | y boundaries [ny + 1] | 4 wave maxima
   if (GRID == 1) raygrid_stage(G, rg_tab);
   const int e = blockIdx.x, tid = threadIdx.x;
   const float* rs = root + (size_t)e * 13;
@@ -363,48 +362,31 @@ __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const
     cam_rot[4 * e] = cq[0]; cam_rot[4 * e + 1] = cq[1]; cam_rot[4 * e + 2] = cq[2]; cam_rot[4 * e + 3] = cq[3];
   }
   const float noise = env_noise ? env_noise[e] : 0.f;
-  // The camera's patch of the lattice (lg_bvh.h, RayPatch): every ray starts at cpos and ends within far_clip * |d| of it, so the cells under the square
-  // [cpos - R, cpos + R] are all the walk can visit: their boundaries and z ranges go to LDS once (one round of independent, coalesced loads) and the
-  // walk of the workgroup's W x H rays reads LDS where it paid a dependent L2 round trip per cell crossed.  A lattice so fine that the square spans more
-  // than RAY_PATCH cells keeps the block around the camera; cells outside it are read from global memory (same numbers, same hits).
-  RayPatch patch{};
-  if (GRID == 2) {
-    float* const ppx = rg_tab; float* const ppy = rg_tab + RAY_PATCH + 1; float* const red = rg_tab + 2 * (RAY_PATCH + 1);
-    float2* const ppz = reinterpret_cast<float2*>(rg_tab + 2 * (RAY_PATCH + 1) + 4);
-    float m2 = 0.f;
-    for (int p = tid; p < W * H; p += 256) m2 = fmaxf(m2, ray_d[3 * p] * ray_d[3 * p] + ray_d[3 * p + 1] * ray_d[3 * p + 1] + ray_d[3 * p + 2] * ray_d[3 * p + 2]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o));
-    if ((tid & 63) == 0) red[tid >> 6] = m2;
-    __syncthreads();
-    m2 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float R = far_clip * sqrtf(m2) * (1.f + 1e-4f) + 1e-4f;       // (the rotation by the camera quaternion keeps a length to rounding)
-    const RayGlobal A{&G};
-    const float xlo = G.xb[0], xhi = G.xb[G.nx], ylo = G.yb[0], yhi = G.yb[G.ny];
+  float ztop1 = 3.0e38f;
+  if (GRID == 1 && getenv_skip) {
+    // (round 6) the highest triangle the camera's rays can reach: block maxima over the square [cpos - R, cpos + R], R = far_clip * 1.001 (a ray longer than
+    // that -- |d| > 1.001: the pattern's rays are unit vectors -- does not use it).  The walk of a ray starts where it comes down to that height
+    // (trace_ray_grid); a ray that never does misses without a walk.
+    float* const red = rg_tab + G.nx + G.ny + 2;
+    const float R = far_clip * 1.001f * (1.f + 1e-4f) + 1e-4f;
+    const RayTables A{rg_tab, &G, 3.0e38f, false};
+    const float xlo = A.x_lo(), xhi = A.x_hi(), ylo = A.y_lo(), yhi = A.y_hi();
     const float ux = (float)G.nx / (xhi - xlo), uy = (float)G.ny / (yhi - ylo);
-    auto cell_x = [&](float x) { return raygrid_locate(A, true, G.nx, x, (int)((x - xlo) * ux)); };
-    auto cell_y = [&](float y) { return raygrid_locate(A, false, G.ny, y, (int)((y - ylo) * uy)); };
-    int ix0 = cell_x(cpos.x - R), pw = cell_x(cpos.x + R) - ix0 + 1, iy0 = cell_y(cpos.y - R), ph = cell_y(cpos.y + R) - iy0 + 1;
-    const bool whole = pw <= RAY_PATCH && ph <= RAY_PATCH;       // the staged block holds every cell the rays can reach (else: nothing is known about the cells beyond it)
-    if (pw > RAY_PATCH) { ix0 = min(max(cell_x(cpos.x) - RAY_PATCH / 2, 0), G.nx - RAY_PATCH); pw = RAY_PATCH; }
-    if (ph > RAY_PATCH) { iy0 = min(max(cell_y(cpos.y) - RAY_PATCH / 2, 0), G.ny - RAY_PATCH); ph = RAY_PATCH; }
-    for (int i = tid; i <= pw; i += 256) ppx[i] = G.xb[ix0 + i];
-    for (int i = tid; i <= ph; i += 256) ppy[i] = G.yb[iy0 + i];
-    float ztop = -3.0e38f;
-    for (int i = tid; i < pw * ph; i += 256) {
-      const int ry = i / pw, rx = i - ry * pw;
-      const float2 z = G.zr[(size_t)(iy0 + ry) * G.nx + ix0 + rx];
-      ppz[ry * RAY_PATCH + rx] = z;
-      ztop = fmaxf(ztop, z.y);                               // (an empty cell: -1e30)
-    }
+    const int bx0 = raygrid_locate(A, true, G.nx, cpos.x - R, (int)((cpos.x - R - xlo) * ux)) / RAY_BLK, bx1 = raygrid_locate(A, true, G.nx, cpos.x + R, (int)((cpos.x + R - xlo) * ux)) / RAY_BLK;
+    const int by0 = raygrid_locate(A, false, G.ny, cpos.y - R, (int)((cpos.y - R - ylo) * uy)) / RAY_BLK, by1 = raygrid_locate(A, false, G.ny, cpos.y + R, (int)((cpos.y + R - ylo) * uy)) / RAY_BLK;
+    const int bw = bx1 - bx0 + 1, nb = bw * (by1 - by0 + 1);
+    float zt = -3.0e38f;
+    for (int i = tid; i < nb; i += 256) { const int ry = i / bw, rx = i - ry * bw; zt = fmaxf(zt, G.zb[(size_t)(by0 + ry) * G.nbx + bx0 + rx]); }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ztop = fmaxf(ztop, __shfl_xor(ztop, o));
-    __syncthreads();                                         // (red[] was read above)
-    if ((tid & 63) == 0) red[tid >> 6] = ztop;
+    for (int o = 32; o > 0; o >>= 1) zt = fmaxf(zt, __shfl_xor(zt, o));
+    if ((tid & 63) == 0) red[tid >> 6] = zt;
     __syncthreads();
-    ztop = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    patch = RayPatch{ppx, ppy, ppz, ix0, iy0, pw, ph, &G, xlo, xhi, ylo, yhi, (whole && getenv_skip) ? ztop : 3.0e38f};
+    ztop1 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (getenv_skip == 9) ztop1 = -3.0e37f;        // (timing probe: every ray misses without a walk -- what is left is staging, resize and the FIFO)
   }
+  // (Measured and dropped, round 6: the rays sorted first -- spans for all, the ones with cells to cross queued in LDS, the walk over the queue -- 0.565 against
+  // 0.490 ms per step of config 4: the kernel is bound by the vector instructions of the walks themselves (SQ counters: 142 M per launch, 66 % of their lanes
+  // active), and a queue's neighbours are no longer the pixels of one tile, whose walks are equally long.)
   // a wave takes a TW x TH tile of pixels (TW * TH <= 64, chosen by the host), not 64 consecutive pixels of a row: the rays of a tile cross the same
   // cells (or tree nodes) and finish together
   const int lane = tid & 63, tcols = (W + TW - 1) / TW, ntiles = tcols * ((H + TH - 1) / TH);
@@ -414,7 +396,7 @@ __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const
     if (ly >= TH || pxl >= W || pyl >= H) continue;
     const int p = pyl * W + pxl;
     V3 d = quat_apply(cq, v3(ray_d[3 * p], ray_d[3 * p + 1], ray_d[3 * p + 2]));
-    float t = GRID == 2 ? trace_ray_grid(G, patch, cpos, d, far_clip) : (GRID == 1 ? trace_ray_grid_tb(G, rg_tab, cpos, d, far_clip) : trace_ray(M, cpos, d, far_clip));
+    float t = GRID == 1 ? trace_ray_grid_tb(G, rg_tab, cpos, d, far_clip, dot(d, d) <= 1.002f ? ztop1 : 3.0e38f, getenv_skip >= 2) : trace_ray(M, cpos, d, far_clip);
     float depth = t >= 0.f ? -(t * norm(d)) : -far_clip;
     depth += noise;
     img[p] = fminf(fmaxf(depth, -far_clip), -near_clip);
@@ -465,6 +447,7 @@ void lg_mesh_destroy(lg_mesh* m) {
   if (m->d_gyb) (void)hipFree(m->d_gyb);
   if (m->d_gcells) (void)hipFree(m->d_gcells);
   if (m->d_gzr) (void)hipFree(m->d_gzr);
+  if (m->d_gzb) (void)hipFree(m->d_gzb);
   if (m->d_gcz) (void)hipFree(m->d_gcz);
   if (m->d_gcr) (void)hipFree(m->d_gcr);
   if (m->d_gtris) (void)hipFree(m->d_gtris);
@@ -520,6 +503,17 @@ lg_mesh* lg_mesh_create(const float* vertices, int64_t n_vertices, const int32_t
       g_mesh_err = "device allocation / upload of the ray lattice failed"; lg_mesh_destroy(m); return nullptr;
     }
     m->gnx = (int)G.xb.size() - 1; m->gny = (int)G.yb.size() - 1;
+    {   // block maxima of the cells' z ranges (depth_kernel: where a camera's rays start their walk)
+      m->gnbx = (m->gnx + RAY_BLK - 1) / RAY_BLK; m->gnby = (m->gny + RAY_BLK - 1) / RAY_BLK;
+      std::vector<float> zb((size_t)m->gnbx * m->gnby, -3.0e38f);
+      for (int iy = 0; iy < m->gny; ++iy) for (int ix = 0; ix < m->gnx; ++ix) {
+        float& b = zb[(size_t)(iy / RAY_BLK) * m->gnbx + ix / RAY_BLK];
+        b = std::max(b, G.zr[(size_t)iy * m->gnx + ix].y);
+      }
+      if (hipMalloc((void**)&m->d_gzb, zb.size() * 4) != hipSuccess || hipMemcpy(m->d_gzb, zb.data(), zb.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        g_mesh_err = "device allocation / upload of the ray lattice failed"; lg_mesh_destroy(m); return nullptr;
+      }
+    }
     // evenly spaced boundaries: the cell table of the closest-point queries (LG_LATTICE_CP=0: none -- contact queries walk the tree; the A/B switch and the tests' checker)
     const char* lc = getenv("LG_LATTICE_CP");
     const float hx = (G.xb.back() - G.xb.front()) / (float)m->gnx, hy = (G.yb.back() - G.yb.front()) / (float)m->gny;
@@ -641,10 +635,11 @@ int lg_sdf_bodies_update(lg_mesh* m, const float* rigid_body_state, int32_t num_
     m->sdf_cache_n = tot;
     MESH_TRY(m, hipMemsetAsync(m->d_sdf_cache, 0, (size_t)tot * sizeof(float4), (hipStream_t)stream));
   }
-  // LG_SDF_LATTICE=0: always the tree (the A/B switch and the tests' checker)
+  // LG_SDF_LATTICE=1: the lane-by-lane cell walk (measured round 6, config 3: 0.123 ms against the tree's 0.072 -- a wave waits for its trunk queries,
+  // whose window is ~50 cells; off by default)
   const char* sl = getenv("LG_SDF_LATTICE");
   LatticeView L{nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 1.f, 1.f, LATP_CAP};
-  if (m->d_gcz && m->d_gcr && !(sl && sl[0] == '0')) L = LatticeView{m->d_gcz, m->d_gcr, m->d_gtris, m->gnx, m->gny, m->gx0, m->gy0, m->ghx, m->ghy, LATP_CAP};
+  if (m->d_gcz && m->d_gcr && sl && sl[0] == '1') L = LatticeView{m->d_gcz, m->d_gcr, m->d_gtris, m->gnx, m->gny, m->gx0, m->gy0, m->ghx, m->ghy, LATP_CAP};
   hipLaunchKernelGGL(sdf_bodies_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, (hipStream_t)stream, M, L, rigid_body_state, num_bodies,
                      body_indices, sphere_offsets, num_query_bodies, env_ids, n, max_dist, sdf_values, sdf_stride, sdf_gradients, nearest_points, m->d_sdf_cache);
   MESH_TRY(m, hipGetLastError());
@@ -659,16 +654,10 @@ int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* ro
   if (p->width <= 0 || p->height <= 0 || p->resized_width <= 0 || p->resized_height <= 0 || p->buffer_len <= 0) return LG_ERR_INVALID;
   size_t lds = (size_t)p->width * p->height * sizeof(float);
   if (lds > 64 * 1024) { m->err = "depth image too large for the LDS-staged resize"; return LG_ERR_UNSUPPORTED; }
-  // the lattice instances keep the camera's patch of the lattice (depth_kernel<2>) or the whole boundary tables (<1>) in LDS next to the image; together
-  // they must stay within the 64 KB a launch gets without opting in
-  const size_t patch_lds = (size_t)(2 * (RAY_PATCH + 1) + 4 + 2 * RAY_PATCH * RAY_PATCH) * sizeof(float);
-  const char* rp = getenv("LG_RAY_PATCH");
-  const char* rs_ = getenv("LG_RAY_SKIP"); const int skip = (rs_ && rs_[0] == '0') ? 0 : 1;      // (A/B switch: the start of the walk at the height of the patch's highest triangle)
+  // the lattice instance keeps its boundary tables in LDS next to the image; together they must stay within the 64 KB a launch gets without opting in
+  const char* rs_ = getenv("LG_RAY_SKIP"); const int skip = rs_ ? atoi(rs_) : 1;      // (A/B switch; 0: every ray walks from the camera, 2: also the coarse walk over blocks -- measured: +-1 %)
   int mode = 0;
-  if (m->d_gcells && m->gnx >= 1 && m->gny >= 1) {
-    if (!(rp && rp[0] == '0') && lds + patch_lds <= 64 * 1024) { mode = 2; lds += patch_lds; }
-    else if (lds + ray_grid_lds(m) <= 64 * 1024) { mode = 1; lds += ray_grid_lds(m); }
-  }
+  if (m->d_gcells && m->gnx >= 1 && m->gny >= 1 && lds + ray_grid_lds(m) <= 64 * 1024) { mode = 1; lds += ray_grid_lds(m); }
   MeshView M{m->d_nodes, m->d_tris};
   // pixel tile of a wave: the TW x TH <= 64 that covers the image with the fewest tiles, the squarest of those
   int TW = 8, TH = 8, best_tiles = 1 << 30;
@@ -681,7 +670,7 @@ int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* ro
                      episode_length_buf, p->width, p->height, TW, TH, p->resized_width, p->resized_height, p->buffer_len, p->near_clip, p->far_clip, \
                      p->position[0], p->position[1], p->position[2], p->quat_offset[0], p->quat_offset[1], p->quat_offset[2], \
                      p->quat_offset[3], env_noise, camera_pos, camera_rot, depth_buffer, skip)
-  if (mode == 2) LG_DEPTH_LAUNCH(2); else if (mode == 1) LG_DEPTH_LAUNCH(1); else LG_DEPTH_LAUNCH(0);
+  if (mode == 1) LG_DEPTH_LAUNCH(1); else LG_DEPTH_LAUNCH(0);
 #undef LG_DEPTH_LAUNCH
   MESH_TRY(m, hipGetLastError());
   return LG_OK;

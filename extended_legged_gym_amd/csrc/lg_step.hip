@@ -2611,6 +2611,10 @@ static const char* validate(const lg_config* cfg, const lg_robot_model* model, c
   if (cfg->push_robots && cfg->push_interval <= 0) return "push_interval must be positive";
   if (ter->mesh_type < LG_MESH_PLANE || ter->mesh_type > LG_MESH_TRIMESH) return "unknown terrain mesh_type";
   if (ter->mesh_type != LG_MESH_PLANE && (ter->rows < 2 || ter->cols < 2 || !ter->height_samples)) return "rough terrain without height samples";
+  if (ter->mesh_type == LG_MESH_HEIGHTFIELD && (ter->rows > 65535 || ter->cols > 32767)) {       // capsule edge pieces travel as L | j << 16 (lg_physics.h, ContactProbeC::lj)
+    for (int l = 0; l < model->num_legs; ++l) for (int s = 0; s < model->cp_count[l]; ++s)
+      if (model->cp_slide[l][s][0] != 0.f || model->cp_slide[l][s][1] != 0.f || model->cp_slide[l][s][2] != 0.f) return "height grid too large for the capsule-segment instance (rows <= 65535, cols <= 32767)";
+  }
   if (ter->mesh_type == LG_MESH_TRIMESH && !ter->collision_mesh) return "trimesh terrain without a collision mesh (lg_mesh_create)";
   if (cfg->curriculum && (ter->num_levels <= 0 || ter->num_types <= 0 || !ter->terrain_origins)) return "curriculum needs terrain_origins";
   if (model->num_penalised < 0 || model->num_penalised > NBODY_MAX || model->num_termination < 0 || model->num_termination > NBODY_MAX)
@@ -2949,7 +2953,7 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
   // triangle-mesh detection slides its spheres without a flag) and the self-collision pass.  A robot of fixed spheres without self-collision runs
   // the plain instance.
   const bool tm = c->h.ter.mesh_type == LG_MESH_TRIMESH;
-  const bool caps = !tm && c->h.slide_mask != 0u, selfc = c->h.n_sc > 0;
+  const bool caps = c->h.ter.mesh_type == LG_MESH_HEIGHTFIELD && c->h.slide_mask != 0u, selfc = c->h.n_sc > 0;       // (a plane has no grid lines: the plain instance)
 #define LG_LAUNCH_PK(TM, HELP, SPEC_, THREADS) \
   hipLaunchKernelGGL((physics_kernel<0, TM, HELP, SPEC_>), dim3(nb), dim3(THREADS), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink)
 #if LG_LEGS == 4
@@ -3181,8 +3185,9 @@ int lg_rollout_batch(lg_ctx* c, const float* all_us, int32_t horizon, const int3
   if (rc != LG_OK) return rc;
   const bool fuse = can_fuse(c);
   // One launch for the whole horizon (round 5): the workgroup that owns an env keeps its state on chip from step to step.  Not with the clock-driven gait
-  // term (its phase changes inside a horizon: the env class goes step by step anyway), not on mesh terrains (no persistent instance), LG_PERSIST=0 = the A/B switch.
-  if (fuse && horizon > 1 && c->persist && c->h.ter.mesh_type != LG_MESH_TRIMESH) {
+  // term (lg_config.gait_enabled: the two forms are not compared with it; the env class goes step by step anyway), not on mesh terrains (no persistent
+  // instance), LG_PERSIST=0 = the A/B switch.
+  if (fuse && horizon > 1 && c->persist && !c->h.cfg.gait_enabled && c->h.ter.mesh_type != LG_MESH_TRIMESH) {
     PostSink sk{nullptr, nullptr, nullptr, nullptr, 0.f, rewards, horizon};
     sk.nsteps = horizon;
     launch_physics(c, st, all_us, env_ids, n, horizon * NDOF, 3, sk);

@@ -189,7 +189,10 @@ class FootTrackElSpider(ElSpider):
         self._layer_extras = torch.zeros(len(RAIBERT_TERMS), device=self.device)
         self._bind_layer_terms()
         import os
-        self._native_layer = planner_type == 1 and os.environ.get("LG_FOOTTRACK_TORCH", "0") != "1"
+        # the device layer (csrc/lg_foottrack.hip) is written for the registered observation: 66 proprioceptive entries in, 94 out, no height scan; a config
+        # that scans heights (253 / 281 entries) runs the torch layer, which handles any width
+        self._native_layer = (planner_type == 1 and not self.cfg.terrain.measure_heights and self.cfg.env.num_observations == 94
+                              and os.environ.get("LG_FOOTTRACK_TORCH", "0") != "1")
         self._planner_steps = 0
         self._layer_acc = torch.zeros(6, dtype=torch.float64, device=self.device)
         self._stray_diff = torch.zeros(self.num_envs, device=self.device)

@@ -220,12 +220,12 @@ def test_depth_camera_matches_torch_pipeline():
     assert got[:, -1].min() >= -0.5 - 0.2 and got[:, -1].max() <= 0.5 + 0.2    # bicubic overshoot of the new frame stays small
 
 
-def test_depth_camera_patch_walk_equals_the_table_walk_and_the_tree(monkeypatch):
-    """Round 6: the depth kernel stages the lattice cells under the camera's far-clip square in LDS (`RayPatch`, lg_bvh.h) and walks those.  Same boundaries,
-    same z ranges, same triangle tests: the images are those of the round-5 walk (whole boundary tables in LDS, cell records from global memory;
-    `LG_RAY_PATCH=0`) bit for bit, and the tree's (`LG_RAY_GRID=0`) up to a pixel that a ray through a lattice corner flips.  Two meshes: 0.1 m cells (the
-    square fits the patch; cameras near the mesh border clamp it) and 0.04 m cells (the square spans ~100 cells: the block around the camera is staged, the
-    cells beyond it are read from global memory)."""
+def test_depth_camera_walk_from_the_highest_block_equals_the_walk_from_the_camera_and_the_tree(monkeypatch):
+    """Round 6: a camera's rays start their cell walk where they come down to the highest triangle within far_clip of the camera (block maxima of the lattice;
+    `LG_RAY_SKIP=0`: every ray walks from the camera, as in round 5), the cell records are one 16-byte load and a run's triangles are fetched four at a time.
+    The cells left out would all have been skipped and the triangle tests are the same arithmetic in the same order: the images are those of the walk from the
+    camera bit for bit, and the tree's (`LG_RAY_GRID=0`) up to a pixel that a ray through a lattice corner flips.  Two meshes: 0.1 m cells and 0.04 m cells;
+    some cameras stand outside the mesh, one exactly on a lattice corner.  `LG_RAY_SKIP=2` adds the coarse walk over the blocks."""
     from extended_legged_gym_amd.utils.depth_camera import DepthCameraWarp
     from extended_legged_gym_amd.utils.mesh import DeviceMesh
     cfg = LeggedRobotCfg().depth
@@ -246,22 +246,23 @@ def test_depth_camera_patch_walk_equals_the_table_walk_and_the_tree(monkeypatch)
         root[0, 0:2] = torch.tensor([float(np.unique(v[:, 0])[n // 2]), float(np.unique(v[:, 1])[n // 3])])   # a camera exactly on a lattice corner
         eplen = torch.zeros(N, dtype=torch.int64)
         imgs = {}
-        for mode in ("patch", "tables", "tree"):
+        for mode in ("skip", "blocks", "camera", "tree"):
             if mode == "tree":
                 monkeypatch.setenv("LG_RAY_GRID", "0")
             mesh = DeviceMesh(v, t, "cuda:0")
             monkeypatch.delenv("LG_RAY_GRID", raising=False)
             assert (mesh.ray_lattice == (0, 0)) == (mode == "tree")
-            if mode == "tables":
-                monkeypatch.setenv("LG_RAY_PATCH", "0")
+            if mode != "skip":
+                monkeypatch.setenv("LG_RAY_SKIP", "2" if mode == "blocks" else "0")
             cam = DepthCameraWarp(cfg, "cuda:0", N, mesh=mesh)
             cam.update_from_root_states(root.cuda(), eplen.cuda())
             torch.cuda.synchronize()
-            monkeypatch.delenv("LG_RAY_PATCH", raising=False)
+            monkeypatch.delenv("LG_RAY_SKIP", raising=False)
             imgs[mode] = cam.depth_buffer[:, -1].cpu()
-        assert float(imgs["patch"].std()) > 0.01
-        assert torch.equal(imgs["patch"], imgs["tables"]), hs
-        bad = ((imgs["patch"] - imgs["tree"]).abs() > 1e-6).float().mean()
+        assert float(imgs["skip"].std()) > 0.01
+        assert torch.equal(imgs["skip"], imgs["camera"]), hs
+        assert ((imgs["blocks"] - imgs["camera"]).abs() > 1e-6).float().mean() < 1e-5, hs      # (a restart on a block line: the cell is located anew)
+        bad = ((imgs["skip"] - imgs["tree"]).abs() > 1e-6).float().mean()
         assert float(bad) < 2e-4, (hs, float(bad))
 
 
