@@ -49,13 +49,14 @@ class RobotBatchRollout(LeggedRobot):
 
     # ------------------------------------------------------------------ index maps (`:119-164`)
     def _init_env_indices(self):
-        R, T, dev = self.num_rollout_per_main, self.total_num_envs, self.device
-        ar = torch.arange(T, device=dev)
-        self.main_env_indices = torch.arange(0, T, 1 + R, device=dev)
-        self.rollout_to_main_map = ar - ar % (1 + R)
-        self.is_main_env = (ar % (1 + R)) == 0
-        self.is_rollout_env = ~self.is_main_env
-        self.rollout_env_indices = torch.nonzero(self.is_rollout_env).flatten()
+        from extended_legged_gym_amd.utils.sharding import main_rollout_index_maps
+        R, dev = self.num_rollout_per_main, self.device
+        for k, v in main_rollout_index_maps(self.num_main_envs, R, dev).items():
+            setattr(self, k, v)
+        # a shard of a multi-GPU job (utils/sharding.py:shard_main_rollout_cfg) owns whole mains: its envs are a contiguous block of the job's numbering
+        self.global_env_offset = int(getattr(self.cfg.env, "global_env_offset", 0))
+        self.global_main_env_indices = self.main_env_indices + self.global_env_offset
+        self.global_rollout_env_indices = self.rollout_env_indices + self.global_env_offset
         self.main_to_rollout_indices = [self.main_env_indices[i] + 1 + torch.arange(R, device=dev)
                                         for i in range(self.num_main_envs)]
         self._main_ids_i32 = self.main_env_indices.to(torch.int32).contiguous()
@@ -94,7 +95,10 @@ class RobotBatchRollout(LeggedRobot):
             self.env_origins[:] = self.terrain_origins[self.terrain_levels, self.terrain_types]
         else:
             self.custom_origins = False
-            self.env_origins.copy_(torch.from_numpy(centered_grid_origins(self.num_envs, self.cfg.env.env_spacing)))
+            # (a shard takes its rows of the JOB's grid, so that the union of the shards is the single-process layout)
+            offset = int(getattr(self.cfg.env, "global_env_offset", 0))
+            total = int(getattr(self.cfg.env, "global_num_envs", self.num_envs))
+            self.env_origins.copy_(torch.from_numpy(centered_grid_origins(total, self.cfg.env.env_spacing)[offset:offset + self.num_envs]))
 
     # ------------------------------------------------------------------ stepping
     def step(self, actions):

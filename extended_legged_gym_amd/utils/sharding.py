@@ -14,6 +14,31 @@ def shard_env_cfg(cfg, rank, world, envs_per_rank):
     return cfg
 
 
+def shard_main_rollout_cfg(cfg, rank, world, mains_per_rank):
+    """The main-rollout sampler (`RobotBatchRollout`, BASELINE config 5) shards BY MAIN ENV: rank r owns mains
+    [r * mains_per_rank, (r + 1) * mains_per_rank) together with all of their rollout envs, so a main and its rollouts
+    never straddle ranks and `_sync_main_to_rollout` (`robot_batch_rollout.py:1447-1535`) stays a copy inside one
+    context -- no data-path collective.  In the job's global numbering env g = main * (1 + R) + k, exactly the single-process
+    layout (`:119-164`); `cfg.env.global_env_offset / global_num_envs` count ALL envs (mains and rollouts)."""
+    per_main = 1 + int(cfg.env.rollout_envs)
+    cfg.env.num_envs = mains_per_rank                      # (the class multiplies by 1 + rollout_envs itself)
+    cfg.env.global_env_offset = rank * mains_per_rank * per_main
+    cfg.env.global_num_envs = world * mains_per_rank * per_main
+    cfg.rng_stream_offset = rank
+    return cfg
+
+
+def main_rollout_index_maps(num_main, rollouts_per_main, device="cpu"):
+    """The index maps of `RobotBatchRollout._init_env_indices` (`robot_batch_rollout.py:119-164`) for `num_main` mains with
+    `rollouts_per_main` rollout envs each, in the numbering of ONE context: env i is main i // (1 + R) when i % (1 + R) == 0,
+    rollout (i % (1 + R)) - 1 of that main otherwise."""
+    R, T = int(rollouts_per_main), int(num_main) * (1 + int(rollouts_per_main))
+    ar = torch.arange(T, device=device)
+    is_main = (ar % (1 + R)) == 0
+    return dict(main_env_indices=torch.arange(0, T, 1 + R, device=device), rollout_to_main_map=ar - ar % (1 + R), is_main_env=is_main,
+                is_rollout_env=~is_main, rollout_env_indices=torch.nonzero(~is_main).flatten())
+
+
 def seed_shard_rngs(seed, shard):
     """Per-shard seed of the global torch / numpy generators for the per-env draws made at creation (friction buckets,
     payload, initial terrain level: `legged_robot.py:332-343,381-383,823`).  Called AFTER the terrain has been generated

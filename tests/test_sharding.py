@@ -156,3 +156,135 @@ def test_two_rank_hip_shards_on_one_gpu():
     union = np.concatenate([ty[0], ty[1]])
     single = np.floor(np.arange(2 * n) / (2 * n / 4))
     assert np.array_equal(union, single)                                                           # terrain columns by GLOBAL env index
+
+
+# ------------------------------------------------------------------------------------------------ the main-rollout sampler shards by main (BASELINE config 5)
+def _rollout_cfg(rank, world, mains, R):
+    from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout_config import RobotBatchRolloutCfg
+    from extended_legged_gym_amd.utils.sharding import shard_main_rollout_cfg
+    cfg = RobotBatchRolloutCfg()
+    cfg.env.rollout_envs = R
+    return shard_main_rollout_cfg(cfg, rank, world, mains)
+
+
+def _rollout_layout_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout import centered_grid_origins
+    from extended_legged_gym_amd.utils.sharding import main_rollout_index_maps
+    mains, R = 5, 3
+    cfg = _rollout_cfg(rank, world, mains, R)
+    T = cfg.env.num_envs * (1 + R)
+    maps = main_rollout_index_maps(cfg.env.num_envs, R)
+    off = cfg.env.global_env_offset
+    origins = torch.from_numpy(centered_grid_origins(cfg.env.global_num_envs, cfg.env.env_spacing)[off:off + T])
+    packed = torch.cat([(maps["main_env_indices"] + off).float(), (maps["rollout_env_indices"] + off).float(), (maps["rollout_to_main_map"] + off).float(),
+                        origins.reshape(-1), torch.tensor([float(off), float(cfg.env.global_num_envs), float(cfg.rng_stream_offset)])])
+    every = [torch.zeros_like(packed) for _ in range(world)]
+    dist.all_gather(every, packed)
+    if rank == 0:
+        out.put(torch.stack(every).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_main_rollout_shards_tile_the_single_process_layout():
+    """Config 5 over several GPUs (`tools/bench_configs.py --gpus N 5`): `shard_main_rollout_cfg` gives every rank whole mains.  The union of the shards'
+    `main_env_indices` / `rollout_env_indices` / `rollout_to_main_map` (in the job's numbering) and of their env origins is the single-process layout
+    (`robot_batch_rollout.py:119-164`, `:1264-1286`), and a main and its rollouts never straddle ranks."""
+    from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout import centered_grid_origins
+    from extended_legged_gym_amd.utils.sharding import main_rollout_index_maps
+    world, mains, R = 2, 5, 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rollout_layout_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    T = mains * (1 + R)
+    single = main_rollout_index_maps(world * mains, R)
+    a, b, c = mains, mains + mains * R, mains + mains * R + T
+    assert np.array_equal(np.concatenate([got[r, :a] for r in range(world)]), single["main_env_indices"].numpy())
+    assert np.array_equal(np.concatenate([got[r, a:b] for r in range(world)]), single["rollout_env_indices"].numpy())
+    assert np.array_equal(np.concatenate([got[r, b:c] for r in range(world)]), single["rollout_to_main_map"].numpy())
+    spacing = _rollout_cfg(0, 1, 1, R).env.env_spacing
+    assert np.array_equal(np.concatenate([got[r, c:c + 3 * T].reshape(T, 3) for r in range(world)]), centered_grid_origins(world * T, spacing))
+    for r in range(world):                                         # every env of a rank -- mains and the mains its rollouts copy from -- lies in the rank's block
+        lo, hi = r * T, (r + 1) * T
+        assert got[r, -3] == lo and got[r, -2] == world * T and got[r, -1] == r
+        for part in (got[r, :a], got[r, a:b], got[r, b:c]):
+            assert part.min() >= lo and part.max() < hi
+
+
+def _hip_rollout_worker(rank, world, port, out):
+    """One shard of a 2-rank main-rollout job, both on cuda:0 (gloo for the collective, see _hip_worker): `shard_main_rollout_cfg` + `RobotBatchRollout` +
+    `lg_step_subset` / `lg_rollout_batch`."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import copy
+    from extended_legged_gym_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+    from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout import RobotBatchRollout
+    from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
+    from extended_legged_gym_amd.utils.sharding import shard_main_rollout_cfg
+    from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout_config import RobotBatchRolloutCfg
+    base, cfg = AnymalCFlatCfg(), RobotBatchRolloutCfg()
+    for sec in ("init_state", "control", "asset", "rewards", "commands", "terrain"):
+        setattr(cfg, sec, copy.deepcopy(getattr(base, sec)))
+    mains, R = 6, 4
+    cfg.env.rollout_envs, cfg.env.num_observations = R, 48
+    cfg.control.use_actuator_network = False
+    cfg.rewards.only_positive_rewards = False
+    cfg.seed = 1
+    shard_main_rollout_cfg(cfg, rank, world, mains)
+    args = get_args([]); args.sim_device = "cuda:0"
+    env = RobotBatchRollout(cfg, parse_sim_params(args, {"sim": class_to_dict(cfg.sim)}), args.physics_engine, args.sim_device, True)
+    env.reset()
+    g = torch.Generator().manual_seed(50 + rank)
+    for _ in range(5):
+        env.step(0.5 * torch.randn(mains, 12, generator=g).cuda())
+    env.step_rollout(0.5 * torch.randn(mains * R, 12, generator=g).cuda())
+    rews = env.rollout_batch(0.5 * torch.randn(mains * R, 8, 12, generator=g).cuda())
+    torch.cuda.synchronize()
+    table, totals = gather_episode_stats(env.core.t["episode_stats"].cpu().clone(), dist)
+    T = mains * (1 + R)
+    packed = torch.cat([env.global_main_env_indices.cpu().float(), env.global_rollout_env_indices.cpu().float(), env.env_origins.cpu().reshape(-1),
+                        env.commands.cpu()[:, 0], torch.tensor([float(torch.isfinite(rews).all() and torch.isfinite(env.obs_buf).all()), float(T)])])
+    every = [torch.zeros_like(packed) for _ in range(world)]
+    dist.all_gather(every, packed)
+    if rank == 0:
+        out.put((table.numpy(), torch.stack(every).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_hip_main_rollout_shards_on_one_gpu():
+    """The sharded composition of config 5 on the HIP path: two processes on cuda:0, 6 mains x 4 rollouts each; main steps, a rollout step and a rollout
+    batch run inside each shard, the shards' global index maps and env origins tile the 12-main single-process layout, the command streams differ."""
+    from extended_legged_gym_amd.envs.batch_rollout.robot_batch_rollout import centered_grid_origins
+    from extended_legged_gym_amd.utils.sharding import main_rollout_index_maps
+    world, mains, R = 2, 6, 4
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hip_rollout_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    table, got = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    T = mains * (1 + R)
+    single = main_rollout_index_maps(world * mains, R)
+    a, b, c = mains, mains + mains * R, mains + mains * R + 3 * T
+    assert table.shape == (2, 4) and (table[:, 3] > 0).all()
+    assert np.array_equal(np.concatenate([got[r, :a] for r in range(world)]), single["main_env_indices"].numpy())
+    assert np.array_equal(np.concatenate([got[r, a:b] for r in range(world)]), single["rollout_env_indices"].numpy())
+    spacing = _rollout_cfg(0, 1, 1, R).env.env_spacing
+    assert np.array_equal(np.concatenate([got[r, b:c].reshape(T, 3) for r in range(world)]), centered_grid_origins(world * T, spacing))
+    assert got[0, -2] == 1.0 and got[1, -2] == 1.0 and got[0, -1] == T
+    assert not np.allclose(got[0, c:c + T], got[1, c:c + T])            # the shards resample commands from their own Philox streams

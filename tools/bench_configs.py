@@ -6,6 +6,13 @@ public Python API, synthetic N(0,1) actions, after a warm-up.  Informational; on
             TerrainObj), contacts by closest-point (SDF) queries on the mesh BVH inside the physics kernel, 4096 envs
   config 4  ANYmal-C rough + 60x30 ray-cast depth camera, 4096 envs on this GPU (of 8192 over 2 GPUs)
   config 5  ANYmal-C main-rollout sampler: 128 main x 32 rollouts on this GPU (of 1024 x 32 over 8 GPUs): step_rollout
+
+Multi-GPU compositions of configs 4 and 5 (BASELINE.json: 8192 envs over 2 GPUs env-sharded; 1024 mains x 32 over 8 GPUs sharded by main):
+    python tools/bench_configs.py --gpus N 4|5
+starts N ranks (one process per GPU, before this process touches a GPU; rendezvous on 127.0.0.1) -- or run it under
+`python -m torch.distributed.run --nproc-per-node N ... tools/bench_configs.py --gpus N 4`.  Every rank builds its shard
+(`utils/sharding.py`: shard_env_cfg / shard_main_rollout_cfg -- per-GPU sizes stay 4096 envs / 128 mains: weak scaling), the timed loops are bracketed by
+barriers, the slowest rank's time counts, rank 0 prints the whole-job rate; the only collective is the all-gather of the episode statistics.
 """
 import json
 import os
@@ -20,27 +27,63 @@ sys.path.insert(0, ROOT)
 from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params  # noqa: E402
 
 
+RANK, WORLD, LOCAL_RANK = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+DEV = f"cuda:{LOCAL_RANK}"
+_dist = None
+
+
+def dist():
+    """The process group of a multi-GPU run (RCCL), formed on first use; None on one GPU."""
+    global _dist
+    if WORLD > 1 and _dist is None:
+        import torch.distributed as d
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(LOCAL_RANK)
+        d.init_process_group("nccl", device_id=torch.device(DEV))
+        _dist = d
+    return _dist
+
+
 def sim_params(cfg):
-    return parse_sim_params(get_args([]), {"sim": class_to_dict(cfg.sim)})
+    a = get_args([]); a.sim_device = DEV
+    return parse_sim_params(a, {"sim": class_to_dict(cfg.sim)})
 
 
 def timeit(fn, warm, steps):
+    """Seconds per call; on several GPUs bracketed by barriers, the slowest rank's time."""
+    d = dist()
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if d is not None:
+        d.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    if d is not None:
+        d.barrier()
+    el = time.perf_counter() - t0
+    if d is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=DEV)
+        d.all_reduce(t, op=d.ReduceOp.MAX)
+        el = float(t.item())
+    return el / steps
+
+
+def job_episode_stats(env):
+    """The one exchange of a sharded job: all-gather of every rank's LG_T_EPISODE_STATS (4 doubles)."""
+    from extended_legged_gym_amd.utils.sharding import gather_episode_stats
+    table, totals = gather_episode_stats(env.core.t["episode_stats"].clone(), dist())
+    return dict(env_steps=float(totals[3]), finished_episodes=float(totals[2]), ranks=int(table.shape[0]))
 
 
 def config1():
     from extended_legged_gym_amd.envs import Anymal, AnymalCFlatCfg
     cfg = AnymalCFlatCfg(); cfg.env.num_envs = 64; cfg.seed = 1
-    env = Anymal(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
+    env = Anymal(cfg, sim_params(cfg), "native_hip", DEV, True)
     env.reset()
-    a = torch.randn(64, 12, device="cuda")
+    a = torch.randn(64, 12, device=DEV)
     dt = timeit(lambda: env.step(a), 200, 200)
     return dict(config="1: ANYmal-C flat, 64 envs", env_steps_per_s=64 / dt, ms_per_step=dt * 1e3)
 
@@ -104,22 +147,24 @@ def config4_env():
     class Env(LeggedRobotDepth):
         def _gait_config(self):
             return dict(period=0.6, swing_height=0.15, foot_phases=[0.0, 0.5, 0.5, 0.0])
-    cfg = AnymalCRoughCfg(); cfg.env.num_envs = 4096; cfg.seed = 1
+    from extended_legged_gym_amd.utils.sharding import shard_env_cfg
+    cfg = AnymalCRoughCfg(); cfg.seed = 1
+    shard_env_cfg(cfg, RANK, WORLD, 4096)              # (one GPU: the identity -- offset 0 of 4096)
     np.random.seed(1)
-    env = Env(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
+    env = Env(cfg, sim_params(cfg), "native_hip", DEV, True)
     env.reset()
     return env
 
 
 def config4():
     env = config4_env()
-    a = torch.randn(4096, 12, device="cuda")
+    a = torch.randn(4096, 12, device=DEV)
     dt = timeit(lambda: env.step(a), 50, 100)
     dcore = timeit(lambda: env.core.step(a), 50, 100)      # the env step without the camera
     mesh = env.terrain_mesh()
-    return dict(config="4: ANYmal-C rough (trimesh, 1.6M triangles) + 60x30 depth camera every step, 4096 envs on 1 GPU",
-                env_steps_per_s=4096 / dt, ms_per_step=dt * 1e3, ms_per_step_without_camera=dcore * 1e3, rays_per_s=4096 * 1800 / dt,
-                mesh_triangles=mesh.num_triangles, bvh_nodes=mesh.num_bvh_nodes)
+    return dict(config=f"4: ANYmal-C rough (trimesh, 1.6M triangles) + 60x30 depth camera every step, 4096 envs per GPU on {WORLD} GPU(s), env-sharded",
+                n_gpus=WORLD, scaling="weak", env_steps_per_s=WORLD * 4096 / dt, ms_per_step=dt * 1e3, ms_per_step_without_camera=dcore * 1e3,
+                rays_per_s=WORLD * 4096 * 1800 / dt, mesh_triangles=mesh.num_triangles, bvh_nodes=mesh.num_bvh_nodes, episode_stats=job_episode_stats(env))
 
 
 def config5_env():
@@ -129,25 +174,28 @@ def config5_env():
     base = AnymalCFlatCfg(); cfg = RobotBatchRolloutCfg()
     for sec in ("init_state", "control", "asset", "rewards", "commands", "terrain"):
         setattr(cfg, sec, getattr(base, sec))
-    cfg.env.num_envs, cfg.env.rollout_envs, cfg.env.num_observations = 128, 32, 48
+    from extended_legged_gym_amd.utils.sharding import shard_main_rollout_cfg
+    cfg.env.rollout_envs, cfg.env.num_observations = 32, 48
+    shard_main_rollout_cfg(cfg, RANK, WORLD, 128)     # shard by MAIN: this rank's 128 mains and all of their rollouts (one GPU: the identity)
     cfg.control.use_actuator_network = False          # anymal_c_batch_rollout_config.py:181-183
     cfg.rewards.only_positive_rewards = False
     cfg.seed = 1
-    env = RobotBatchRollout(cfg, sim_params(cfg), "native_hip", "cuda:0", True)
+    env = RobotBatchRollout(cfg, sim_params(cfg), "native_hip", DEV, True)
     env.reset()
     return env
 
 
 def config5():
     env = config5_env()
-    a = torch.randn(128 * 32, 12, device="cuda")
+    a = torch.randn(128 * 32, 12, device=DEV)
     dt = timeit(lambda: env.step_rollout(a), 50, 200)
-    us = torch.randn(128 * 32, 16, 12, device="cuda")
+    us = torch.randn(128 * 32, 16, 12, device=DEV)
     tb = timeit(lambda: env.rollout_batch(us), 3, 20)      # (one library call: sync + H rollout steps + sync; LG_PERSIST=0 = one launch per step)
-    am = torch.randn(128, 12, device="cuda")
+    am = torch.randn(128, 12, device=DEV)
     dm = timeit(lambda: env.step(am), 20, 50)
-    return dict(config="5: ANYmal-C main-rollout, 128 main x 32 rollouts on 1 GPU (PD actuators, plane)",
-                rollout_env_steps_per_s=128 * 32 / dt, step_rollout_ms=dt * 1e3, rollout_batch_H16_ms=tb * 1e3, main_step_ms=dm * 1e3)
+    return dict(config=f"5: ANYmal-C main-rollout, 128 main x 32 rollouts per GPU on {WORLD} GPU(s), sharded by main (PD actuators, plane)",
+                n_gpus=WORLD, scaling="weak", rollout_env_steps_per_s=WORLD * 128 * 32 / dt, step_rollout_ms=dt * 1e3, rollout_batch_H16_ms=tb * 1e3, main_step_ms=dm * 1e3,
+                first_global_main=int(env.global_main_env_indices[0]), episode_stats=job_episode_stats(env))
 
 
 def config_hexapod():
@@ -184,6 +232,27 @@ def config_cassie():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "3", "4", "5", "hexapod", "cassie"]
+    argv = sys.argv[1:]
+    gpus = 1
+    if "--gpus" in argv:
+        i = argv.index("--gpus"); gpus = int(argv[i + 1]); del argv[i:i + 2]
+    which = argv or ["1", "3", "4", "5", "hexapod", "cassie"]
+    if gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # this process has not touched a GPU: it may start the ranks as children (one process per GPU, rendezvous on the loopback address) and hand their exit code on
+        import socket
+        import subprocess
+        if any(w not in ("4", "5") for w in which):
+            sys.exit("--gpus N: the sharded compositions are configs 4 and 5")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(gpus)] + which
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
     for w in which:
-        print(json.dumps({"1": config1, "3": config3, "4": config4, "5": config5, "hexapod": config_hexapod, "cassie": config_cassie}[w]()))
+        line = {"1": config1, "3": config3, "4": config4, "5": config5, "hexapod": config_hexapod, "cassie": config_cassie}[w]()
+        if RANK == 0:
+            print(json.dumps(line))
+    if _dist is not None:
+        _dist.barrier()
+        _dist.destroy_process_group()
