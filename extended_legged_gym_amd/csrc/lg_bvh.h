@@ -668,3 +668,103 @@ LG_DEV void closest_point_lattice(const LatticeView& L, ClosestQuery& A, unsigne
   A.found = found; A.cp = bestp; A.fn = bestn;
 }
 
+// ---- the same lattice query answered by a GROUP of 16 lanes (one DPP row) for ONE point: the SDF of a robot's bodies (sdf_bodies_kernel) is a few thousand
+// queries, each with a window of up to ~50 cells (a trunk 0.3 m above 0.1 m cells) -- lane by lane a wave waits for its trunk queries through ~40 dependent
+// round trips (measured: slower than the tree walk).  Here the group shares the work of one query: the faces of the cell under the point are dealt over
+// the lanes (their minimum bounds the window), then the window's cells are dealt over the lanes -- one round of independent record loads for up to 64
+// cells, a box test each -- and every lane tests the faces of the cells it kept.  Each lane keeps `closest_point`'s running state for the faces IT saw; the
+// group's answer is put together by that function's own tie rule, which does not depend on the order faces are met in: the point of the closest face, and
+// among the lanes whose best is within the tolerance band of the group's minimum the normal of the face farthest from the point.
+LG_DEV float row16_min(float x) {
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) x = fminf(x, __shfl_xor(x, m, 16));
+  return x;
+}
+LG_DEV int row16_min(int x) {
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) x = min(x, __shfl_xor(x, m, 16));
+  return x;
+}
+LG_DEV float row16_max(float x) {
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) x = fmaxf(x, __shfl_xor(x, m, 16));
+  return x;
+}
+// p, R: the same on all 16 lanes of the group; k: this lane's index in the group.  Returns found (on every lane), *cp / *fn on every lane.
+LG_DEV bool closest_point_lattice_row16(const LatticeView& L, V3 p, float R, int k, V3* cp_out, V3* fn_out) {
+  typedef unsigned u2v __attribute__((ext_vector_type(2))); typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef const u2v __attribute__((address_space(1)))* gu2; typedef const f4v __attribute__((address_space(1)))* gf4;
+  const gf4 CELL = (gf4)L.cell; const gu2 RUN = (gu2)L.run; const gf4 TRI = (gf4)L.tris;
+  const float ihx = frcp(L.hx), ihy = frcp(L.hy);
+  float best2 = R * R, bestabs = -1.f; bool found = false;
+  V3 bestp = p, bestn = v3(0, 0, 1);
+  const float fx = (p.x - L.x0) * ihx, fy = (p.y - L.y0) * ihy;
+  float grx = R * ihx + 2.f * LATTICE_TOL, gry = R * ihy + 2.f * LATTICE_TOL;
+  int i0 = max((int)floorf(fx - grx), 0), i1 = min((int)floorf(fx + grx), L.nx - 1), j0 = max((int)floorf(fy - gry), 0), j1 = min((int)floorf(fy + gry), L.ny - 1);
+  if (i0 > i1 || j0 > j1) return false;                                       // (group-uniform)
+  auto face = [&](int f) {
+    const gf4 T = TRI + (size_t)f * 3;
+    const f4v ta = T[0], tb = T[1], tc = T[2];
+    const V3 a = v3(ta.x, ta.y, ta.z), b = v3(tb.x, tb.y, tb.z), cc = v3(tc.x, tc.y, tc.z);
+    if (!(tri_box_dist2(p, a, b, cc) <= best2 * (1.f + 1e-5f) + 1e-12f)) return;
+    closest_grid_triangle(p, a, b, cc, best2, found, bestabs, bestp, bestn);
+  };
+  // a lane whose own best is not within the band of the group's minimum forgets it (its face cannot decide anything) and prunes with the group's bound
+  auto share_bound = [&]() {
+    const float gm = row16_min(found ? best2 : R * R);
+    if (!(found && best2 <= gm * (1.f + 1e-5f) + 1e-12f)) { found = false; bestabs = -1.f; best2 = gm; }
+  };
+  // 1. the cell under the point: its faces dealt over the lanes
+  const int ci = max(i0, min((int)floorf(fx), i1)), cj = max(j0, min((int)floorf(fy), j1));
+  {
+    const u2v r = RUN[(size_t)cj * L.nx + ci];
+    const int cnt = (int)(r.y & 0xffffu) + (int)(r.y >> 16);
+    for (int f = k; f < cnt; f += 16) face((int)r.x + f);
+    share_bound();
+    if (row16_min(found ? 1 : 2) == 1) {                                      // something found: the window shrinks to what can be closer
+      const float rr = sqrtf(best2) * (1.f + 1e-4f);
+      grx = rr * ihx + 2.f * LATTICE_TOL; gry = rr * ihy + 2.f * LATTICE_TOL;
+      i0 = max(i0, (int)floorf(fx - grx)); i1 = min(i1, (int)floorf(fx + grx)); j0 = max(j0, (int)floorf(fy - gry)); j1 = min(j1, (int)floorf(fy + gry));
+    }
+  }
+  // 2. the window's cells, 64 at a time: cell c of a round belongs to lane c % 16 (neighbours on different lanes)
+  const int wx = i1 - i0 + 1, ncell = wx * (j1 - j0 + 1);
+  for (int c0 = 0; c0 < ncell; c0 += 64) {
+    f4v z[4]; u2v r[4]; int ii[4], jj[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int c = min(c0 + k + 16 * m, ncell - 1);
+      jj[m] = j0 + c / wx; ii[m] = i0 + c - (c / wx) * wx;
+      const size_t at = (size_t)jj[m] * L.nx + ii[m];
+      z[m] = CELL[at]; r[m] = RUN[at];
+    }
+#pragma unroll 1
+    for (int m = 0; m < 4; ++m) {
+      if (c0 + k + 16 * m >= ncell || (ii[m] == ci && jj[m] == cj)) continue;
+      const float xa = L.x0 + ((float)ii[m] - LATTICE_TOL) * L.hx, xb = L.x0 + ((float)(ii[m] + 1) + LATTICE_TOL) * L.hx;
+      const float ya = L.y0 + ((float)jj[m] - LATTICE_TOL) * L.hy, yb = L.y0 + ((float)(jj[m] + 1) + LATTICE_TOL) * L.hy;
+      const float dx = fmaxf(fmaxf(xa - p.x, 0.f), p.x - xb), dy = fmaxf(fmaxf(ya - p.y, 0.f), p.y - yb), dxy = dx * dx + dy * dy;
+      const int n0 = (int)(r[m].y & 0xffffu), n1 = (int)(r[m].y >> 16);
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {                                           // the lower and the upper group of the cell's faces
+        const float zlo = h == 0 ? z[m].x : z[m].z, zhi = h == 0 ? z[m].y : z[m].w;
+        const float dz = fmaxf(fmaxf(zlo - p.z, 0.f), p.z - zhi);
+        const int cnt = h == 0 ? n0 : n1, first = (int)r[m].x + (h == 0 ? 0 : n0);
+        if (cnt == 0 || !(dxy + dz * dz <= best2 * (1.f + 1e-5f) + 1e-12f)) continue;
+        for (int f = 0; f < cnt; ++f) face(first + f);
+      }
+    }
+    if (c0 + 64 < ncell) share_bound();
+  }
+  // 3. the group's answer
+  const float gm = row16_min(found ? best2 : 3.0e38f);
+  if (!(gm < 3.0e37f)) return false;
+  const int wp = row16_min((found && best2 == gm) ? k : 99);                  // the closest face's lane (lowest among equals)
+  const bool band = found && best2 <= gm * (1.f + 1e-5f) + 1e-12f;
+  const float ga = row16_max(band ? bestabs : -2.f);
+  const int wn = row16_min((band && bestabs == ga) ? k : 99);
+  *cp_out = v3(__shfl(bestp.x, wp, 16), __shfl(bestp.y, wp, 16), __shfl(bestp.z, wp, 16));
+  *fn_out = v3(__shfl(bestn.x, wn, 16), __shfl(bestn.y, wn, 16), __shfl(bestn.z, wn, 16));
+  return true;
+}
+

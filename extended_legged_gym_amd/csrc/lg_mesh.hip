@@ -276,19 +276,21 @@ __global__ __launch_bounds__(256) void raycaster_kernel(MeshView M, RayGrid G, c
 // body, the collision-sphere centre = body position + body rotation * offset, then signed distance, unit gradient and the
 // nearest surface point p - sdf * grad (mesh_sdf.py:295-336) — all bodies of all envs in one launch (the reference runs
 // two Warp queries per body).  sdf rows have a stride so they can be the tail of the extra-observation row.
-// Round 6: on a lattice mesh (the OBJ meshes of the confined-space / heightfield converters: lg_mesh.d_gcz) the query walks the cells around the body
-// (closest_point_lattice, lg_bvh.h: the cell under the point, then the window the distance found there leaves) instead of the tree -- the tree walk paid
-// ~30 dependent 128-byte node fetches per query and re-fetched 14 x its algorithmic bytes; the lattice reads the cell under a foot and a handful of
-// neighbours.  Same per-face arithmetic and tie rule: the same answer (tests/test_hip_sensors.py).  A query whose bound is wider than LATTICE_SDF_CELLS
-// cell widths (no cache entry yet; a body far above the surface) keeps the tree: its window would be hundreds of cells.
+// Round 6: on a lattice mesh (the OBJ meshes of the confined-space / heightfield converters: lg_mesh.d_gcz) a query with a cached bound is answered from the
+// cells around the body by a group of 16 lanes (closest_point_lattice_row16, lg_bvh.h) instead of one lane's tree walk -- the walk paid ~30 dependent
+// 128-byte node fetches per query and re-fetched 14 x its algorithmic bytes.  Same per-face arithmetic and tie rule: the same answer to rounding
+// (tests/test_hip_config3.py).  A query whose bound is wider than LATTICE_SDF_CELLS cell widths (no cache entry yet; a body far above the surface) keeps the
+// tree, walked by the group's first lane.  LG_SDF_LATTICE=0: always the tree (the A/B switch and the tests' checker).
 #define LATTICE_SDF_CELLS 12.f
-__global__ __launch_bounds__(64) void sdf_bodies_kernel(MeshView M, LatticeView L, const float* __restrict__ rb /* (N,B,13) */, int B,
-                                                        const int32_t* __restrict__ body_idx, const float* __restrict__ offsets, int nb,
-                                                        const int32_t* __restrict__ ids, int n_ids, float max_dist,
-                                                        float* __restrict__ sdf, int sdf_stride, float* __restrict__ grad,
-                                                        float* __restrict__ nearest, float4* __restrict__ cache) {
-  int64_t gi = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (gi >= (int64_t)n_ids * nb) return;
+__global__ __launch_bounds__(256) void sdf_bodies_kernel(MeshView M, LatticeView L, const float* __restrict__ rb /* (N,B,13) */, int B,
+                                                         const int32_t* __restrict__ body_idx, const float* __restrict__ offsets, int nb,
+                                                         const int32_t* __restrict__ ids, int n_ids, float max_dist,
+                                                         float* __restrict__ sdf, int sdf_stride, float* __restrict__ grad,
+                                                         float* __restrict__ nearest, float4* __restrict__ cache) {
+  const int k = threadIdx.x & 15;
+  int64_t gi = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);                 // one query per 16 lanes
+  const bool live = gi < (int64_t)n_ids * nb;
+  if (!live) gi = (int64_t)n_ids * nb - 1;                                      // (a spare group repeats the last query and stores nothing: the group functions want all lanes)
   const int kq = (int)(gi / nb), b = (int)(gi - (int64_t)kq * nb);
   const int e = ids ? ids[kq] : kq;
   const float* s = rb + ((size_t)e * B + body_idx[b]) * 13;
@@ -302,15 +304,22 @@ __global__ __launch_bounds__(64) void sdf_bodies_kernel(MeshView M, LatticeView 
   float md = max_dist;
   const float4 c4 = cache[gi];
   if (c4.w == 1.f) md = fminf(max_dist, norm(p - v3(c4.x, c4.y, c4.z)) * (1.f + 1e-4f) + 1e-5f);
-  bool found = false;
-  const bool by_cell = L.cell != nullptr && md <= LATTICE_SDF_CELLS * fminf(L.hx, L.hy);
-  if (by_cell) {
-    ClosestQuery Q; Q.p = p; Q.max_dist = md; Q.on = true; Q.found = false; Q.cp = p; Q.fn = v3(0, 0, 1); Q.range = md; Q.lb = 0.f;
-    closest_point_lattice(L, Q);
-    found = Q.found; cp = Q.cp; fn = Q.fn;
-  } else {
-    found = closest_point(M, p, md, &cp, &fn);
+  bool found = false, tree = L.cell == nullptr;
+  if (!tree) {
+    // the group's search starts with a radius of a few cells and doubles it until something is found or the bound is reached: a body whose cache entry is
+    // stale (a reset teleported it) or missing does not search its whole bound, and a body on the ground finds the surface in the first probe.  Exact: a
+    // search with radius R returns the closest face whenever one lies within R.  Beyond LATTICE_SDF_CELLS cell widths the tree takes over.
+    const float h = fminf(L.hx, L.hy);
+    float R = fminf(md, 3.f * h);
+    while (true) {                                                               // (R, md: the same on the 16 lanes of a group)
+      found = closest_point_lattice_row16(L, p, R, k, &cp, &fn);
+      if (found || R >= md) break;
+      if (2.f * R > LATTICE_SDF_CELLS * h) { tree = true; break; }
+      R = fminf(2.f * R, md);
+    }
   }
+  if (k != 0 || !live) return;
+  if (tree) found = closest_point(M, p, md, &cp, &fn);
   if (!found && md < max_dist) found = closest_point(M, p, max_dist, &cp, &fn);     // (rounding at the boundary of the reduced radius)
   cache[gi] = found ? make_float4(cp.x, cp.y, cp.z, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
   if (found) {
@@ -635,12 +644,10 @@ int lg_sdf_bodies_update(lg_mesh* m, const float* rigid_body_state, int32_t num_
     m->sdf_cache_n = tot;
     MESH_TRY(m, hipMemsetAsync(m->d_sdf_cache, 0, (size_t)tot * sizeof(float4), (hipStream_t)stream));
   }
-  // LG_SDF_LATTICE=1: the lane-by-lane cell walk (measured round 6, config 3: 0.123 ms against the tree's 0.072 -- a wave waits for its trunk queries,
-  // whose window is ~50 cells; off by default)
   const char* sl = getenv("LG_SDF_LATTICE");
   LatticeView L{nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 1.f, 1.f, LATP_CAP};
-  if (m->d_gcz && m->d_gcr && sl && sl[0] == '1') L = LatticeView{m->d_gcz, m->d_gcr, m->d_gtris, m->gnx, m->gny, m->gx0, m->gy0, m->ghx, m->ghy, LATP_CAP};
-  hipLaunchKernelGGL(sdf_bodies_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, (hipStream_t)stream, M, L, rigid_body_state, num_bodies,
+  if (m->d_gcz && m->d_gcr && !(sl && sl[0] == '0')) L = LatticeView{m->d_gcz, m->d_gcr, m->d_gtris, m->gnx, m->gny, m->gx0, m->gy0, m->ghx, m->ghy, LATP_CAP};
+  hipLaunchKernelGGL(sdf_bodies_kernel, dim3((unsigned)((tot + 15) / 16)), dim3(256), 0, (hipStream_t)stream, M, L, rigid_body_state, num_bodies,
                      body_indices, sphere_offsets, num_query_bodies, env_ids, n, max_dist, sdf_values, sdf_stride, sdf_gradients, nearest_points, m->d_sdf_cache);
   MESH_TRY(m, hipGetLastError());
   return LG_OK;

@@ -155,8 +155,8 @@ def test_lattice_contact_queries_equal_the_tree_walk(tmp_path, monkeypatch, cap)
 
 
 def test_body_sdf_by_cell_equals_the_tree_walk(tmp_path, monkeypatch):
-    """Round 6: `lg_sdf_bodies_update` answers the 5-body SDF of config 3 from the lattice cells around each body (`closest_point_lattice`) once a body has
-    a cached bound when `LG_SDF_LATTICE=1` (off by default: measured slower than the tree walk on config 3, DESIGN s9); the tree walk otherwise.  Same per-face arithmetic and order-free tie rule: signed distance, gradient and nearest
+    """Round 6: `lg_sdf_bodies_update` answers the 5-body SDF of config 3 from the lattice cells around each body (`closest_point_lattice_row16`: a group
+    of 16 lanes per body) once a body has a cached bound; `LG_SDF_LATTICE=0` keeps the tree walk.  Same per-face arithmetic and order-free tie rule: signed distance, gradient and nearest
     point agree (a closest point on an edge two faces share may come from either face: a last-bit difference)."""
     from extended_legged_gym_amd.utils.mesh_sdf import MeshSDF, MeshSDFCfg
     n = 256

@@ -9,6 +9,10 @@ What the first run showed (round 5; `profiles/r05_value_calibration.json`, `prof
     commands alone the critic brackets this simulator (stochastic G = 1.44 < V = 1.94 < deterministic G = 2.18), standing still V = 2.06 vs G = 2.18.  Whether
     PhysX carries this checkpoint through lateral / yaw commands is not known; the critic says its returns there were ~2.4 x what this simulator pays.  The
     band stays as written and the test reports the miss as an expected failure.
+  * Round 6: the one contact mechanism of PhysX that had not been tried -- patch friction's anchors and its velocity-aligned first friction row -- was added to
+    the oracle as an experiment switch and scored by the same two measures on the oracle (which reproduces this file's numbers: bias 1.41, r 0.56, start-up
+    falls 0.34, 5.1e-3 steady falls per env-step): steady falls 4.9e-3 -> 4.1e-3 per env-step (-16 %), bias 1.41 -> 1.56 (`profiles/r06_friction_anchors_oracle.txt`).
+    Less than a third: not the cause, and no kernel instance was built for it (DESIGN s2a).
   * ElSpider: smallest |bias| at PD / action_scale 0.2, the drive of the one reference config that loads the checkpoint (asserted)."""
 import json
 import os
@@ -17,7 +21,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-BANDS = dict(steady_bias_over_mean_abs_G=0.25, steady_pearson_r=0.4, startup_bias_over_mean_abs_G=0.5, anymal_startup_fall_rate=0.35, elspider_startup_fall_rate=0.05)
+# anymal_startup_fall_rate: round 5 asserted 0.35 -- a bar set to the measurement (0.33).  Round 6: the bar comes from the control instead: a policy trained on
+# THIS physics falls in 0.002 of its starts and is held to 0.05 (test_control_...), so a checkpoint the simulator carries as PhysX did should stay below
+# 0.05 + a margin of 0.05 for a 200-iteration policy; the PhysX-trained one does not (0.33) and the miss is reported as an expected failure with the numbers.
+BANDS = dict(steady_bias_over_mean_abs_G=0.25, steady_pearson_r=0.4, startup_bias_over_mean_abs_G=0.5, anymal_startup_fall_rate=0.10, elspider_startup_fall_rate=0.05)
 _RESULTS = {}
 
 
@@ -31,11 +38,19 @@ def _run(which):
     return _RESULTS[which]
 
 
-def test_anymal_critic_correlates_with_realised_returns_and_startup_falls_are_bounded():
+def test_anymal_critic_correlates_with_realised_returns():
     r = _run("anymal")
     assert r["steady"]["pearson_r"] >= BANDS["steady_pearson_r"], r["steady"]
     assert r["startup"]["pearson_r"] >= BANDS["steady_pearson_r"], r["startup"]
-    assert r["startup_fall_rate"] <= BANDS["anymal_startup_fall_rate"], r["startup_fall_rate"]
+    assert r["startup_fall_rate"] <= 0.5, r["startup_fall_rate"]            # (sanity only: most starts get going; the band is the next test's)
+
+
+def test_anymal_startup_fall_band():
+    r = _run("anymal")
+    if r["startup_fall_rate"] > BANDS["anymal_startup_fall_rate"]:
+        pytest.xfail("band from the home-trained control (<= 0.05) + 0.05: the PhysX-trained checkpoint falls in %.2f of its starts within 100 steps of a reset "
+                     "into the task's reset distribution (home-trained policy: 0.002); %.4f falls per env-step in steady state (home-trained: 4e-5)" %
+                     (r["startup_fall_rate"], r["steady_falls_per_env_step"]))
 
 
 def test_anymal_critic_bias_band():
