@@ -632,8 +632,9 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
     { ROWI(13) if (k_root) w_root[EQ(q) * 13 + i] = v_root; }
     { ROWI(12) if (k_d) { const size_t e = EQ(q); w_dof[e * 24 + i] = v_d0; w_dof[e * 24 + 12 + i] = v_d1; w_lact[e * 12 + i] = v_act; w_ldv[e * 12 + i] = v_ldv; } }
     { ROWI(6) if (k_lrv) w_lrv[EQ(q) * 6 + i] = v_lrv; }
-    {   // net contact forces (B x 3 floats per env, the global layout): dense rows from LDS; from the main wave's registers these were 12-15
-        // stores of one dword per lane at a 36-48 byte stride, ~2.5 k cycles of that wave's issue alone
+    if (arrive) {   // net contact forces (B x 3 floats per env, the global layout): dense rows from LDS; from the main wave's registers these were 12-15
+        // stores of one dword per lane at a 36-48 byte stride, ~2.5 k cycles of that wave's issue alone.  (Not in the inner steps of a persistent rollout
+        // launch, round 6: nothing reads them before the last step stores them again.)
       const int B3 = w_B * 3;
       float LG_G* const cf = w_cf;
 #pragma unroll
@@ -674,6 +675,10 @@ LG_DEV bool fused_writeback_obs(const DevCtx* __restrict__ C, const float* hot, 
   if (wv == FUSED_STATS_WAVE) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the statistics stores / atomics of this wave have completed
   if (tid == 64 * FUSED_STATS_WAVE && arrive) arrival = __hip_atomic_fetch_add(w_tickets + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   STAMP(33);
+  // An inner step of a persistent rollout launch (lg_rollout_batch: `arrive` is false in all but the last step) ends here: its observation rows would be
+  // overwritten by the next step before anybody could read them (round 6: -5 % on the horizon; what the NEXT step's prefetch reads -- the state and history
+  // rows above -- is stored every step).
+  if (!arrive) return false;
 
   // observation rows (LR:234-252, :107-108): proprio | heights | extra, + uniform noise, clipped.  A lane forms the 4 entries of
   // ONE Philox call (entries 4 gq .. 4 gq + 3, the post kernel's mapping, so the noise is the same draw for draw); what does not

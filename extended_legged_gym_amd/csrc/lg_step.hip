@@ -560,6 +560,9 @@ LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__ C);
 // instance the model / config needs (launch_physics); the single-wave instances always carry both (FEAT_ALL: a model without sliding spheres or
 // pairs takes the same paths with an empty mask / list), so the kernel of a robot of fixed spheres without self-collision is what it was.
 #define FEAT_ALL 12
+#ifndef LG_CAPS_DEAL
+#define LG_CAPS_DEAL (LG_LEGS == 4)      // the capsule-segment instance deals the contact slots 2 / 1 / 3 / 2 over main / waves 1-3 (0: 3 / 1 / 2 / 2 like the plain instance; A/B)
+#endif
 template <int MODE, bool TMESH, bool HELPERS = false, int SPEC = 0>
 #if LG_AB == 9      // timing probe: cap the kernel at the 256 registers per wave that two workgroups per CU would leave (spills go to scratch)
 __attribute__((amdgpu_num_vgpr(120)))
@@ -584,7 +587,10 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #else
 #define MESH_PAIR0(wv_) ((wv_) == 0 ? 6 : ((wv_) == 1 ? 2 : ((wv_) == 2 ? 0 : 4)))
 #endif
-  constexpr int DS0 = 3, DS1 = 4, DS2 = 6;   // main 3 / wave 1 (which also has the leg bias) 1 / 2 / 2: the helpers are the last to arrive at (A2), the main wave has ~3 k cycles of slack there (A/B in one session: 2/2/2/2 +1.4 us, 4/0/2/2 +0.3 us; 1/2/2/3 and 0/2/3/3: worse still; the capsule-segment instance, round 5: 4/0/2/2 +3.5 us, 2/1/2/3 +0.3 us against this deal)
+  // (round 6, capsule-segment instance of the quadruped: 2 / 1 / 3 / 2 -- with a segment slot on it the main wave was the LAST at (A2): per-wave stamps,
+  //  profiles/r06_phase_stamps_waves.txt: helper waves 1 / 2 / 3 waited 1.5 / 2.8 / 1.4 k cycles for it there; one plain slot moved to wave 2)
+  constexpr bool CAPS_DEAL = LG_CAPS_DEAL && ((SPEC >> 2) & 1) && !TMESH;
+  constexpr int DS0 = CAPS_DEAL ? 2 : 3, DS1 = CAPS_DEAL ? 3 : 4, DS2 = 6;   // main 3 / wave 1 (which also has the leg bias) 1 / 2 / 2: the helpers are the last to arrive at (A2), the main wave has ~3 k cycles of slack there (A/B in one session: 2/2/2/2 +1.4 us, 4/0/2/2 +0.3 us; 1/2/2/3 and 0/2/3/3: worse still; the capsule-segment instance, round 5: 4/0/2/2 +3.5 us, 2/1/2/3 +0.3 us against this deal)
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
   // LSTM actuator) waves 1..3 are actuator waves: wave w evaluates joint w-1 of every leg, concurrently with the main
   // wave's torque-independent work (kinematics, bias, mass matrix, contact set-up); they meet at two barriers per substep.
@@ -2704,15 +2710,20 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
       if (model->cp_slide[l][sl][0] != 0.f || model->cp_slide[l][sl][1] != 0.f || model->cp_slide[l][sl][2] != 0.f) h.slide_mask |= 1u << sl;
   if (const char* ev = getenv("LG_CAPS")) { if (atoi(ev) == 0) h.slide_mask = 0u; }      // (diagnostic / A-B: every sphere stays in the middle of its part)
   // Who detects which slot (capsule instances on a height grid).  A slot with a segment costs about twice a plain one (two edge pieces), an empty slot
-  // nothing; the waves take positions 0-2 (main) / 3 (wave 1, which also has the leg bias and arrives last) / 4-5 / 6-7.  Segment slots go to positions
-  // 6, 2, 4, 5 in that order, slots no leg has fill up behind them (7 first), plain slots take what is left in ascending order.  ANYmal-C (foot, three
-  // shank spheres of which two carry segments, two thigh-drive spheres, a trunk sphere): {0, 1, 3 | 4 | 5, 6 | 2, -}.  LG_DEAL=0: the identity (A/B).
+  // nothing; the waves take positions 0-2 (main) / 3 (wave 1, which also has the leg bias) / 4-5 / 6-7 -- the quadruped's capsule instance since round 6:
+  // 0-1 / 2 / 3-5 / 6-7 (LG_CAPS_DEAL).  Segment slots go to wave 3's first position, then the main wave's last, then wave 2's; slots no leg has fill up
+  // behind them (wave 3's second position first); plain slots take what is left in ascending order.  ANYmal-C (foot, three shank spheres of which two carry
+  // segments, two thigh-drive spheres, a trunk sphere): {0, 3 | 1 | 4, 5, 6 | 2, -}.  LG_DEAL=0: the identity (A/B).
   {
     int max_cp = 0;
     for (int l = 0; l < NLEG; ++l) max_cp = model->cp_count[l] > max_cp ? model->cp_count[l] : max_cp;
     int at[LG_MAX_CP]; bool used[LG_MAX_CP] = {false};
     for (int p = 0; p < LG_MAX_CP; ++p) at[p] = -1;
+#if LG_CAPS_DEAL      // positions 0-1 main / 2 wave 1 / 3-5 wave 2 / 6-7 wave 3: ANYmal-C {0, 3 | 1 | 4, 5, 6 | 2, -}
+    const int seg_pos[LG_MAX_CP] = {6, 1, 3, 4, 7, 0, 5, 2}, empty_pos[LG_MAX_CP] = {7, 5, 2, 4, 3, 6, 1, 0};
+#else
     const int seg_pos[LG_MAX_CP] = {6, 2, 4, 5, 7, 0, 1, 3}, empty_pos[LG_MAX_CP] = {7, 3, 5, 1, 6, 4, 2, 0};
+#endif
     int ns = 0;
     for (int sl = 0; sl < max_cp; ++sl) if ((h.slide_mask >> sl) & 1u) { at[seg_pos[ns++]] = sl; used[sl] = true; }
     int ne = 0;
