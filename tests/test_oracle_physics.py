@@ -499,3 +499,39 @@ def test_two_legs_crossing_meet_a_self_collision_row(solver):
             assert late.min() > -2e-3
         o.close()
     assert results[False].min() < -0.03, results[False].min()                    # the same start without the pass: the feet pass through each other
+
+
+def test_friction_anchors_hold_a_loaded_stance_foot():
+    """The oracle's experiment switch for PhysX's patch friction (`lgo_set_friction_anchors`, round 6): a standing robot under a steady side load
+    (a small lateral velocity kick on the base every policy step).  With velocity-level friction rows alone a sticking foot creeps -- each of the four TGS
+    sub-intervals leaves a residual slip -- ; with anchors the rows pull the foot back to where it touched down: the stance feet move an order of magnitude less.
+    (The switch exists in the oracle only: it scored the mechanism on the PhysX-trained checkpoint before any kernel was written, and the mechanism lost.)"""
+    from extended_legged_gym_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+    from extended_legged_gym_amd.envs.base.native_config import NativeSetup, load_robot_model
+    from oracle.oracle_lib import OracleEnv
+    from tests.helpers import ANYMAL_GAIT, sim_params_for
+
+    def creep(mode):
+        cfg = AnymalCFlatCfg(); cfg.env.num_envs = 8; cfg.seed = 1
+        cfg.noise.add_noise = False; cfg.domain_rand.push_robots = False; cfg.control.use_actuator_network = False
+        cfg.control.stiffness = {'HAA': 80., 'HFE': 80., 'KFE': 80.}; cfg.control.damping = {'HAA': 2., 'HFE': 2., 'KFE': 2.}
+        o = OracleEnv(NativeSetup(cfg, sim_params_for(cfg), load_robot_model(cfg.asset), seed=1, gait=ANYMAL_GAIT))
+        o.L.lgo_set_friction_anchors(o.ctx, mode)
+        o.t["friction_coeffs"][:] = 1.0
+        o.reset_idx(np.arange(8))
+        o.t["root_states"][:, 7:13] = 0
+        a = np.zeros((8, 12), np.float32)
+        for _ in range(60):                                   # settle on the feet
+            o.t["commands"][:] = 0
+            o.step(a)
+        feet0 = o.t["rigid_body_state"].reshape(8, -1, 13)[:, [4, 8, 12, 16], :2].copy()
+        for _ in range(100):
+            o.t["commands"][:] = 0
+            o.t["root_states"][:, 8] += 0.05
+            o.step(a)
+        assert (o.t["reset_buf"] == 0).all()                  # nobody fell
+        d = np.linalg.norm(o.t["rigid_body_state"].reshape(8, -1, 13)[:, [4, 8, 12, 16], :2] - feet0, axis=2)
+        o.close()
+        return float(d.mean())
+    plain, anchored = creep(0), creep(1)
+    assert plain > 0.01 and anchored < 0.25 * plain, (plain, anchored)          # measured: 26 mm against 3.3 mm in 100 steps
