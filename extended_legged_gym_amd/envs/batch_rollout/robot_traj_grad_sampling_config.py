@@ -30,6 +30,10 @@ class RobotTrajGradSamplingCfg(RobotBatchRolloutPerceptCfg):
         actor_hidden_dims = [128, 64, 32]
         critic_hidden_dims = [128, 64, 32]
         activation = 'elu'
+        device = "cuda:0"
+        use_for_append = True
+        standardize_obs = True
+        obs_type = "privileged"
 
 
 class RobotTrajGradSamplingCfgPPO(RobotBatchRolloutPerceptCfgPPO):

@@ -80,6 +80,42 @@ class NativeTrajSampler:
         self.sigma_nodes = float(getattr(cfg, "noise_scaling", 1.0)) * float(cfg.horizon_diffuse_factor) ** (self.K - 1 - k)
         self.last_weights = None
         self.last_rewards = None
+        # the dense plan read off at the node times ((K, H): what init_trajectories_from_rl turns the policy's action sequence into nodes with)
+        tn, ts = np.linspace(0.0, 1.0, self.K), np.linspace(0.0, 1.0, self.H)
+        self.u2node = torch.from_numpy(np.stack([np.interp(tn, ts, np.eye(self.H)[h]) for h in range(self.H)], axis=1).astype(np.float32)).to(self.device)
+        # RL warm start (`robot_traj_grad_sampling.py:59-125`; the sampler side lives in the absent traj_sampling package: restated, unpinned)
+        self.use_rl_warmstart, self.rl_policy, self.rl_traj_initialized, self.rl_cfg = False, None, False, None
+        self.obs_mean = self.obs_var = None
+
+    # ---- RL warm start
+    def init_rl_policy(self, rl_cfg, num_obs):
+        """Load the actor of an rsl_rl checkpoint (`cfg.rl_warmstart.policy_checkpoint`: `model_state_dict` with `actor.*` / `critic.*` / `std`, optionally
+        the observation normaliser's running mean / variance) into the fused policy kernels (`NativeActorCritic.act_inference`)."""
+        from extended_legged_gym_amd.rl.policy import NativeActorCritic
+        if getattr(rl_cfg, "actor_network", "mlp") != "mlp":
+            raise NotImplementedError("rl_warmstart.actor_network: only 'mlp' (the reference's LSTM actor lives in the external traj_sampling package)")
+        ck = torch.load(rl_cfg.policy_checkpoint, map_location="cpu")
+        sd = ck.get("model_state_dict", ck)
+        first = sd["actor.0.weight"]
+        if first.shape[1] != num_obs:
+            raise ValueError(f"rl_warmstart: the checkpoint's actor takes {first.shape[1]} observations, the env builds {num_obs}")
+        self.rl_policy = NativeActorCritic(sd, getattr(rl_cfg, "activation", "elu"), device=str(self.device))
+        norm = ck.get("obs_norm_state_dict") if isinstance(ck, dict) else None
+        if getattr(rl_cfg, "standardize_obs", True) and norm is not None and "_mean" in norm and "_var" in norm:
+            self.obs_mean, self.obs_var = norm["_mean"].to(self.device).float(), norm["_var"].to(self.device).float()
+        self.use_rl_warmstart, self.rl_cfg, self.rl_traj_initialized = True, rl_cfg, False
+
+    def _policy_action(self, obs):
+        if self.obs_mean is not None:
+            obs = (obs - self.obs_mean) / torch.sqrt(self.obs_var + 1e-8)
+        return self.rl_policy.act_inference(obs.contiguous())
+
+    def init_trajectories_from_rl(self, rollout_callback):
+        """`rollout_callback(policy_fn)` rolls the policy out through the rollout envs and returns its actions, (M, H + 1, A) (`:78-125`); the node
+        trajectories start as that plan read off at the node times instead of zeros."""
+        traj = rollout_callback(self._policy_action)
+        self.mean = torch.einsum("kh,mha->mka", self.u2node, traj[:, :self.H].to(self.device)).contiguous()
+        self.rl_traj_initialized = True
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -123,13 +159,17 @@ class NativeTrajSampler:
         """First action of every main env's current plan."""
         return self.plans_from_nodes(self.mean)[:, 0]
 
-    def shift(self):
+    def shift(self, policy_obs=None):
         """`shift_trajectory_batch` (`:200-209`): one control step has passed -- the plan advances by one sample time; re-sampled at
-        the node times (see `shift_operator`; the last sample repeats)."""
+        the node times (see `shift_operator`; the last sample repeats).  With the RL warm start and `use_for_append` the node that
+        enters at the end of the horizon is the policy's action on the observation the mean trajectory ended in (`:179-207`)."""
         self.mean = torch.einsum("kj,mja->mka", self.shift_op, self.mean).contiguous()      # nodes <- pinv(phi) shift(phi nodes)
+        if policy_obs is not None and self.rl_policy is not None:
+            self.mean[:, -1] = self._policy_action(policy_obs)
 
     def reset(self, env_ids=None):
         if env_ids is None:
             self.mean.zero_()
         else:
             self.mean[env_ids] = 0.0
+

@@ -132,3 +132,69 @@ def test_planner_env_improves_its_plan():
     first = env.planned_actions().clone()
     env.step(first)
     assert env.traj_grad_sampler.mean.shape == (8, 5, 12) and torch.isfinite(env.obs_buf).all()
+
+
+@pytest.mark.gpu
+def test_planner_rl_warm_start(tmp_path):
+    """`cfg.rl_warmstart` (reference `robot_traj_grad_sampling.py:59-125,179-207,234-237,269-280`; the sampler side is the absent `traj_sampling` package, so the
+    semantics are restated and checked on their own terms): the first optimisation starts from a rollout of the checkpoint's actor through the rollout envs --
+    the node trajectories are that action sequence read off at the node times, its first action the policy's action on the first rollout env's observation --
+    and with `use_for_append` a shift fills the node entering at the end of the horizon with the policy's action on the observation the mean trajectory
+    (rollout env 0: sample 0 of the MPPI pass is the mean itself) ended in."""
+    import torch
+    from extended_legged_gym_amd.envs.anymal_c.batch_rollout.anymal_c_batch_rollout_config import AnymalCBatchRolloutCfg
+    from extended_legged_gym_amd.envs.batch_rollout.robot_traj_grad_sampling import RobotTrajGradSampling
+    from extended_legged_gym_amd.envs.batch_rollout.robot_traj_grad_sampling_config import RobotTrajGradSamplingCfg
+    from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
+    cfg = AnymalCBatchRolloutCfg()
+    cfg.trajectory_opt = RobotTrajGradSamplingCfg.trajectory_opt()
+    cfg.rl_warmstart = RobotTrajGradSamplingCfg.rl_warmstart()
+    cfg.env.num_envs, cfg.env.rollout_envs = 6, 16
+    cfg.noise.add_noise = False; cfg.domain_rand.push_robots = False; cfg.domain_rand.randomize_friction = False
+    cfg.seed = 5
+    num_obs = cfg.env.num_observations
+    torch.manual_seed(0)
+
+    def mlp(out):
+        return torch.nn.Sequential(torch.nn.Linear(num_obs, 64), torch.nn.ELU(), torch.nn.Linear(64, 32), torch.nn.ELU(), torch.nn.Linear(32, out))
+    actor, critic = mlp(12), mlp(1)
+    with torch.no_grad():
+        for p in actor.parameters():
+            p.mul_(0.3)
+    sd = {"actor." + k: v for k, v in actor.state_dict().items()}
+    sd.update({"critic." + k: v for k, v in critic.state_dict().items()})
+    sd["std"] = torch.ones(12)
+    path = str(tmp_path / "model_10.pt")
+    torch.save({"model_state_dict": sd, "iter": 10, "infos": None}, path)
+    cfg.rl_warmstart.enable, cfg.rl_warmstart.policy_checkpoint, cfg.rl_warmstart.obs_type = True, path, "non_privileged"
+    env = RobotTrajGradSampling(cfg, parse_sim_params(get_args([]), {"sim": class_to_dict(cfg.sim)}), "native_hip", "cuda:0", True)
+    env.reset()
+    for _ in range(5):
+        env.step(torch.zeros(6, 12, device=env.device))
+    s = env.traj_grad_sampler
+    assert s.use_rl_warmstart and not s.rl_traj_initialized and not s.mean.any()
+    actor = actor.cuda()
+    first = env.main_env_indices + 1
+    want_a0 = actor(env.obs_buf[first]).detach()
+    env._init_trajectories_from_rl()
+    assert s.rl_traj_initialized and s.mean.shape == (6, s.K, 12) and float(s.mean.abs().max()) > 1e-3
+    # node 0 sits at sample time 0: the policy's first action
+    assert torch.allclose(s.mean[:, 0], want_a0, rtol=2e-5, atol=2e-6), float((s.mean[:, 0] - want_a0).abs().max())
+    # the rollout leaves the mains where they were (the first observation the policy sees is the rollout env's LAST observation row -- the sync copies the
+    # simulator state, not `obs_buf`: the reference's own behaviour, `robot_batch_rollout.py:1447-1535` -- so a second initialisation starts from another row)
+    mains_before = env.root_states[env.main_env_indices].clone()
+    want_a0 = actor(env.obs_buf[first]).detach()
+    env._init_trajectories_from_rl()
+    assert torch.equal(env.root_states[env.main_env_indices], mains_before)
+    assert torch.allclose(s.mean[:, 0], want_a0, rtol=2e-5, atol=2e-6)
+    # an optimisation keeps the flag, records the mean trajectory's final observation; the shift behind a step appends the policy's action on it
+    s.rl_traj_initialized = False
+    env.optimize_all_trajectories(initial=True)
+    assert s.rl_traj_initialized and env.last_mean_traj_obs is not None and env.last_mean_traj_obs.shape == (6, num_obs)
+    want_last = actor(env.last_mean_traj_obs).detach()
+    env.step(env.planned_actions().clone())
+    done = env.reset_buf[env.main_env_indices].bool() if hasattr(env, "reset_buf") else torch.zeros(6, dtype=torch.bool, device=env.device)
+    keep = ~done
+    assert keep.any()
+    assert torch.allclose(s.mean[keep, -1], want_last[keep], rtol=2e-5, atol=2e-6)
+    assert torch.isfinite(env.obs_buf).all()
