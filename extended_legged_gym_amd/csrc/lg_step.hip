@@ -560,6 +560,9 @@ LG_DEV bool fused_needs_feet_rows(const DevCtx* __restrict__ C);
 // instance the model / config needs (launch_physics); the single-wave instances always carry both (FEAT_ALL: a model without sliding spheres or
 // pairs takes the same paths with an empty mask / list), so the kernel of a robot of fixed spheres without self-collision is what it was.
 #define FEAT_ALL 12
+#ifndef LG_LSTM_WARM
+#define LG_LSTM_WARM 1       // helper waves warm the scalar cache with the LSTM weights at kernel entry (0: A/B)
+#endif
 #ifndef LG_CAPS_DEAL
 #define LG_CAPS_DEAL (LG_LEGS == 4)      // the capsule-segment instance deals the contact slots 2 / 1 / 3 / 2 over main / waves 1-3 (0: 3 / 1 / 2 / 2 like the plain instance; A/B)
 #endif
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
 #define MESH_PAIR0(wv_) ((wv_) == 0 ? 6 : ((wv_) == 1 ? 2 : ((wv_) == 2 ? 0 : 4)))
 #endif
   // (round 6, capsule-segment instance of the quadruped: 2 / 1 / 3 / 2 -- with a segment slot on it the main wave was the LAST at (A2): per-wave stamps,
-  //  profiles/r06_phase_stamps_waves.txt: helper waves 1 / 2 / 3 waited 1.5 / 2.8 / 1.4 k cycles for it there; one plain slot moved to wave 2)
+  //  profiles/r06_schedule_experiments.txt, r06_phase_stamps_wave{1,2,3}.txt: helper waves 1 / 2 / 3 waited 1.5 / 2.8 / 1.4 k cycles for it there; one plain slot moved to wave 2)
   constexpr bool CAPS_DEAL = LG_CAPS_DEAL && ((SPEC >> 2) & 1) && !TMESH;
   constexpr int DS0 = CAPS_DEAL ? 2 : 3, DS1 = CAPS_DEAL ? 3 : 4, DS2 = 6;   // main 3 / wave 1 (which also has the leg bias) 1 / 2 / 2: the helpers are the last to arrive at (A2), the main wave has ~3 k cycles of slack there (A/B in one session: 2/2/2/2 +1.4 us, 4/0/2/2 +0.3 us; 1/2/2/3 and 0/2/3/3: worse still; the capsule-segment instance, round 5: 4/0/2/2 +3.5 us, 2/1/2/3 +0.3 us against this deal)
   // Workgroup = 16 envs.  Wave 0 ("main") runs the dynamics, one leg per lane.  With nact == 3 (fused step with the
@@ -682,6 +685,17 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     pre_act = actions_in[(size_t)krow * act_stride + 3 * l + (wv - 1)];
   }
   fill_leg_model(lmod, C->lmod, threadIdx.x, blockDim.x);
+#if LG_LSTM_WARM
+  // (round 6) The scalar cache is invalidated at every launch, and the helper waves' first recurrent half fetches 2 KB of LSTM weights through it in six
+  // dependent batches of s_load_dwordx16 -- the main wave waited ~6 k cycles at the first barrier (A) for that.  A helper wave touches every 64-byte line
+  // of the weight block now, while its state rows are still on their way from HBM: one round of independent scalar loads, and the recurrent half hits.
+  if (helper_wave && net && !LSTM_LDS) {
+    float warm = 0.f;
+#pragma unroll
+    for (int i = 0; i < LW_COUNT; i += 16) warm += wlstm[i];
+    asm volatile("" :: "s"(warm));
+  }
+#endif
   if (SC_LDS) for (int i = threadIdx.x; i < C->n_sc; i += blockDim.x) sctab[i] = C->sc_tab[i];      // (first read by the main wave behind (A2) of the first substep)
   if (FUSABLE && fuse && wv == 1) for (int i = lane; i < HC_COUNT; i += 64) hot[i] = C->hot[i];
   if (LSTM_LDS && MODE == 0 && net && wv >= 2) for (int i = (wv - 2) * 64 + lane; i < LW_COUNT; i += 128) wlds[i] = wlstm[i];
@@ -1703,7 +1717,9 @@ LG_DEV float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAX
 LG_DEV void st_dev(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 LG_DEV unsigned ld_dev(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // the published half of the statistics step: extras, command curriculum, counters, running totals
-LG_DEV void finalize_publish(const DevCtx* __restrict__ C, const float* tot, float* f_lvl, float lvl_acc, int bump, int tid, bool use_flags) {
+// nthr: threads of the finishing workgroup, 256 or 128 (the hexapod's post kernel, round 6).  The level sum keeps the order of 256 threads either way -- a
+// thread of a 128-thread workgroup stands for the virtual threads tid and tid + 128 (lvl_hi) -- so the mean level does not depend on who finishes the step.
+LG_DEV void finalize_publish(const DevCtx* __restrict__ C, const float* tot, float* f_lvl, float lvl_acc, int bump, int tid, bool use_flags, float lvl_hi = 0.f, int nthr = 256) {
   const int K = C->cfg.num_reward_terms;
   const bool want_lvl = C->cfg.curriculum != 0;
   lds_barrier();
@@ -1711,8 +1727,9 @@ LG_DEV void finalize_publish(const DevCtx* __restrict__ C, const float* tot, flo
   if (cnt > 0.f && want_lvl) {            // mean terrain level over all envs (LR:205-206): only reported with a reset
     if (!use_flags) lvl_acc = tid == 0 ? ld_dev(C->partials + K + 1) : 0.f;
     f_lvl[tid] = lvl_acc;
+    if (nthr == 128) f_lvl[tid + 128] = use_flags ? lvl_hi : 0.f;
     lds_barrier();
-    for (int off = 128; off > 0; off >>= 1) { if (tid < off) f_lvl[tid] += f_lvl[tid + off]; lds_barrier(); }
+    for (int off = 128; off > 0; off >>= 1) { for (int vt = tid; vt < off; vt += nthr) f_lvl[vt] += f_lvl[vt + off]; lds_barrier(); }
   }
   if (cnt > 0.f) {
     if (tid < K) C->extras[tid] = tot[tid] / cnt / C->cfg.max_episode_length_s;
@@ -1802,10 +1819,13 @@ LG_DEV void finalize_from_acc(const DevCtx* __restrict__ C, int nblocks, int bum
   __shared__ float tot[PART_STRIDE];
   __shared__ float f_lvl[256];
   if (bump == 2) { if (tid == 0) C->counters[3] += nsteps; return; }      // (a persistent rollout launch has run nsteps steps)
-  float lvl_acc = 0.f;
+  const int nthr = (int)blockDim.x;                     // 256, or 128 (the hexapod's post kernel): see finalize_publish
+  float lvl_acc = 0.f, lvl_hi = 0.f;
   if (C->cfg.curriculum != 0) for (int b = tid; b < nblocks; b += 256) lvl_acc += ld_dev(C->lvl_part + b);
+  if (C->cfg.curriculum != 0 && nthr == 128) for (int b = tid + 128; b < nblocks; b += 256) lvl_hi += ld_dev(C->lvl_part + b);
   if (C->cfg.curriculum != 0 && subset) {
     for (int b = tid; b < nblocks; b += 256) lvl_acc -= ld_dev(reinterpret_cast<const float*>(C->part_flag) + b);
+    if (nthr == 128) for (int b = tid + 128; b < nblocks; b += 256) lvl_hi -= ld_dev(reinterpret_cast<const float*>(C->part_flag) + b);
     if (tid == 0) lvl_acc += C->lvl_total_before;
   }
   if (tid < PART_STRIDE) {
@@ -1816,7 +1836,7 @@ LG_DEV void finalize_from_acc(const DevCtx* __restrict__ C, int nblocks, int bum
     }
     tot[tid] = (float)((double)a * (1.0 / ACC_SCALE));
   }
-  finalize_publish(C, tot, f_lvl, lvl_acc, bump, tid, true);
+  finalize_publish(C, tot, f_lvl, lvl_acc, bump, tid, true, lvl_hi, nthr);
 }
 
 // ============================================================================================ post-physics kernel
@@ -1848,7 +1868,7 @@ struct alignas(16) PostLds {
 };
 
 // The post-physics step of one instance = EPBP envs (4; 2 for the hexapod): rows [inst * EPBP, inst * EPBP + EPBP) of the launch.
-//   FUSED = false: the instance is a 256-thread workgroup of post_kernel; in the wide stages wave w owns env w.
+//   FUSED = false: the instance is a workgroup of post_kernel, EPBP waves; in the wide stages wave w owns env w.
 //   FUSED = true:  the instance is ONE wave of the fused step kernel (physics_kernel's tail: the four waves of a physics
 //                  workgroup take four envs each of its sixteen); the wave owns all four envs in the wide stages (NQ = 4
 //                  rounds of the same lane mapping) and runs the narrow stages for them as below.  The workgroup barriers
@@ -2048,7 +2068,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   const unsigned term_mask = C->rew_term_mask;  // which reward terms are switched on (wave-uniform)
   const int kfat = C->rew_kfat, kterm = C->rew_kterm; const float term_scale = C->rew_term_scale;   // see reward_meta()
   {
-    const bool mine = FUSED || wv == (int)((blockIdx.x >> 8) & 3u);   // (workgroups 256 apart share a CU when all 1024 are resident)
+    const bool mine = FUSED || wv == (int)((blockIdx.x >> 8) & (unsigned)(EPBP - 1));   // (workgroups 256 apart share a CU when all 1024 are resident)
     const int el = ln / LPE, sl = ln & (LPE - 1);           // env of the workgroup, lane within the env (shadow the wave-per-env names)
     const bool have = mine && el < nenv;
     float* S = L.s_env[have ? el : 0];
@@ -2104,7 +2124,7 @@ LG_DEV void post_instance(const DevCtx* __restrict__ C, const int32_t* __restric
   lds_barrier();
   STAMP(19);
   {
-    const bool mine = FUSED || wv == (int)((blockIdx.x >> 8) & 3u);
+    const bool mine = FUSED || wv == (int)((blockIdx.x >> 8) & (unsigned)(EPBP - 1));
     const int el = ln / LPE, sl = ln & (LPE - 1);
     const bool have = mine && el < nenv;
     const int e = L.s_e[have ? el : 0];
@@ -2916,7 +2936,9 @@ static int launch_post(lg_ctx* c, hipStream_t st, hipEvent_t* ev, const int32_t*
   const int nb = (n + EPBP - 1) / EPBP;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }   // (a post step without its physics launch)
   if (ids && mode == 0 && c->h.cfg.curriculum) hipLaunchKernelGGL(level_total_kernel, dim3(1), dim3(256), 0, st, c->d);
-  hipLaunchKernelGGL(post_kernel, dim3(nb), dim3(256), 0, st, c->d, ids, n, mode, rew_out, rew_stride, sink);
+  // a wave per env in the wide stages: 64 * EPBP threads (the hexapod's two envs per workgroup ran on 256 threads until round 6 -- two of the four waves
+  // shadowed env 0 and stored nothing, and took the slots of another workgroup: 2048 workgroups in two rounds of four per CU instead of one round of eight)
+  hipLaunchKernelGGL(post_kernel, dim3(nb), dim3(64 * EPBP), 0, st, c->d, ids, n, mode, rew_out, rew_stride, sink);
   if (ev) (void)hipEventRecord(ev[2], st);
   if (ev) (void)hipEventRecord(ev[3], st);
   HIP_TRY(c, hipGetLastError());
