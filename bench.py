@@ -214,12 +214,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    # LG_REHEARSE_ONE_GPU=1 (tests only; never the driver's run): the N ranks of `--gpus N` share cuda:0 and the collectives go over gloo -- RCCL refuses two
+    # ranks on one device.  Everything else is the multi-GPU path as the driver runs it: the launcher, the rendezvous, shard configs, barriers, the MAX over
+    # ranks, the all-gathers.  The line says so ("rehearsal": true).
+    rehearse = os.environ.get("LG_REHEARSE_ONE_GPU") == "1" and world > 1
+    if rehearse:
+        local_rank = 0
+        os.environ["LOCAL_RANK"] = "0"
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # under torchrun the group is formed even for one rank (same code path)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if a.gpus != world:
         if rank == 0:
             print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -265,14 +275,16 @@ def main():
     # episode statistics of every shard: one all-gather (RCCL over xGMI when world > 1)
     from extended_legged_gym_amd.utils.sharding import gather_episode_stats
     if dist is not None:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
-    _, totals = gather_episode_stats(env.core.t["episode_stats"].clone(), dist)
+    _, totals = gather_episode_stats(env.core.t["episode_stats"].cpu().clone() if rehearse else env.core.t["episode_stats"].clone(), dist)
     stats_all = totals.cpu().numpy()
     # what each shard drew for itself (per-shard domain randomisation: disjoint Philox streams, shard-seeded host draws)
     fr = env.core.t["friction_coeffs"].double()
     mine = torch.stack([fr.mean(), fr[0], env.core.t["base_mass_added"].double().mean()])
+    if rehearse:
+        mine = mine.cpu()
     if dist is not None:
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -319,6 +331,8 @@ def main():
                               "episodes": float(stats_all[2]), "env_steps": float(stats_all[3])},
             "finite": finite, "shards": shards,
         }
+        if rehearse:
+            out["rehearsal"] = True          # ranks shared one GPU over gloo: a functional run of the N > 1 path, not a measurement
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(env, pool)
         print(json.dumps(out))

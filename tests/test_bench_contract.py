@@ -73,3 +73,35 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
     assert abs(out["ms_per_step"] * 1e-3 * out["value"] - 2 * 1024) < 2.0
     a, b = out["shards"]
     assert a["rank"] == 0 and b["rank"] == 1 and a["friction_first"] != b["friction_first"] and a["friction_mean"] != b["friction_mean"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on the one-GPU box: bench.py's own launcher starts two ranks (torch.distributed.run, rendezvous on 127.0.0.1), each
+    builds its shard (`shard_env_cfg`), steps it, and the barriers / MAX over ranks / all-gathers run -- over gloo with both ranks on cuda:0
+    (`LG_REHEARSE_ONE_GPU=1`: RCCL refuses two ranks on one device).  What this leaves unproven of the driver's scaling run is RCCL over xGMI itself."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LG_REHEARSE_ONE_GPU="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "10", "--envs-per-gpu", "512", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["finite"] is True and out["rehearsal"] is True
+    per_rank_steps = out["episode_stats"]["env_steps"] / (2 * 512)
+    assert per_rank_steps == int(per_rank_steps) and per_rank_steps >= 40
+    assert abs(out["ms_per_step"] * 1e-3 * out["value"] - 2 * 512) < 2.0
+    a, b = out["shards"]
+    assert a["rank"] == 0 and b["rank"] == 1 and a["friction_first"] != b["friction_first"] and a["friction_mean"] != b["friction_mean"]
+
+
+@pytest.mark.gpu
+def test_sharded_main_rollout_driver_rehearsed_on_one_gpu():
+    """`python tools/bench_configs.py --gpus 2 5` end to end on the one-GPU box (`LG_REHEARSE_ONE_GPU=1`, see above): two ranks, each with its 128 mains x 32
+    rollouts (`shard_main_rollout_cfg`), barriers around the timed loops, the slowest rank's time, the episode-statistics all-gather; rank 0 prints the job's line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LG_REHEARSE_ONE_GPU="1")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "--gpus", "2", "5"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["rehearsal"] is True and out["first_global_main"] == 0
+    assert out["episode_stats"]["ranks"] == 2 and out["episode_stats"]["env_steps"] > 0
+    assert out["rollout_env_steps_per_s"] > 0 and out["rollout_batch_H16_ms"] > 0

@@ -28,6 +28,10 @@ from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse
 
 
 RANK, WORLD, LOCAL_RANK = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+# LG_REHEARSE_ONE_GPU=1 (tests only, like bench.py): the ranks share cuda:0 and the collectives go over gloo -- a functional run of the N > 1 path on a one-GPU box
+REHEARSE = os.environ.get("LG_REHEARSE_ONE_GPU") == "1" and WORLD > 1
+if REHEARSE:
+    LOCAL_RANK = 0
 DEV = f"cuda:{LOCAL_RANK}"
 _dist = None
 
@@ -39,7 +43,10 @@ def dist():
         import torch.distributed as d
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(LOCAL_RANK)
-        d.init_process_group("nccl", device_id=torch.device(DEV))
+        if REHEARSE:
+            d.init_process_group("gloo")
+        else:
+            d.init_process_group("nccl", device_id=torch.device(DEV))
         _dist = d
     return _dist
 
@@ -65,7 +72,7 @@ def timeit(fn, warm, steps):
         d.barrier()
     el = time.perf_counter() - t0
     if d is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=DEV)
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if REHEARSE else DEV)
         d.all_reduce(t, op=d.ReduceOp.MAX)
         el = float(t.item())
     return el / steps
@@ -74,7 +81,8 @@ def timeit(fn, warm, steps):
 def job_episode_stats(env):
     """The one exchange of a sharded job: all-gather of every rank's LG_T_EPISODE_STATS (4 doubles)."""
     from extended_legged_gym_amd.utils.sharding import gather_episode_stats
-    table, totals = gather_episode_stats(env.core.t["episode_stats"].clone(), dist())
+    st = env.core.t["episode_stats"]
+    table, totals = gather_episode_stats(st.cpu().clone() if REHEARSE else st.clone(), dist())
     return dict(env_steps=float(totals[3]), finished_episodes=float(totals[2]), ranks=int(table.shape[0]))
 
 
@@ -251,6 +259,8 @@ if __name__ == "__main__":
         sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
     for w in which:
         line = {"1": config1, "3": config3, "4": config4, "5": config5, "hexapod": config_hexapod, "cassie": config_cassie}[w]()
+        if REHEARSE:
+            line["rehearsal"] = True
         if RANK == 0:
             print(json.dumps(line))
     if _dist is not None:
