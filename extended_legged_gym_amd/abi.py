@@ -290,11 +290,16 @@ def declare_policy(lib):
     lib.lg_plan_from_nodes.restype = C.c_int
     lib.lg_mppi_update.argtypes = [vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]
     lib.lg_mppi_update.restype = C.c_int
+    u64 = C.c_uint64
+    lib.lg_mppi_sample_plans.argtypes = [vp, vp, f32, vp, i32, i32, i32, i32, i32, u64, u64, vp, vp, vp]
+    lib.lg_mppi_sample_plans.restype = C.c_int
+    lib.lg_planner_diffuse.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, u64, u64, vp, i32, f32, vp, vp, vp, vp, vp]
+    lib.lg_planner_diffuse.restype = C.c_int
     return lib
 
 
 POLICY_SYMBOLS = ["lg_mlp_create", "lg_mlp_destroy", "lg_mlp_last_error", "lg_mlp_forward", "lg_policy_act", "lg_compute_returns",
-                  "lg_collect_rollout", "lg_plan_from_nodes", "lg_mppi_update"]
+                  "lg_collect_rollout", "lg_plan_from_nodes", "lg_mppi_update", "lg_mppi_sample_plans", "lg_planner_diffuse"]
 ACTIVATIONS = {"elu": 0, "relu": 1, "tanh": 2, "lrelu": 3, "selu": 4}
 
 PRODUCT_SYMBOLS = ["lg_abi_sizes", "lg_arena_bytes", "lg_create", "lg_get_tensor", "lg_step", "lg_step_physics", "lg_step_subset", "lg_step_transition", "lg_sync_main_to_rollout", "lg_rollout_batch", "lg_compute_torques",

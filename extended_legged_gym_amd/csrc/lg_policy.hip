@@ -483,3 +483,61 @@ int lg_mppi_update(const float* rewards, const float* nodes, int32_t num_main, i
                      new_nodes, weights);
   return hipGetLastError() == hipSuccess ? LG_OK : LG_ERR_HIP;
 }
+
+// lg_mppi_sample_plans: one workgroup per sample row; the row's K x A nodes in LDS between the draw and the interpolation
+__global__ __launch_bounds__(128) void mppi_sample_plans_kernel(const float* __restrict__ mean, const float* __restrict__ sigma_nodes, float sigma_scale,
+                                                                const float* __restrict__ phi, int R, int K, int H, int A, uint32_t seed_lo, uint32_t seed_hi,
+                                                                uint32_t call_lo, uint32_t call_hi, float* __restrict__ nodes, float* __restrict__ plans) {
+  extern __shared__ float nd[];                      // [K * A]
+  const int i = blockIdx.x, m = i / R, smp = i - m * R, KA = K * A;
+  for (int j = threadIdx.x; j < KA; j += blockDim.x) {
+    float z = 0.f;
+    if (smp != 0) {
+      uint32_t o[4];
+      philox4((uint32_t)i, call_lo, (uint32_t)(j >> 1), call_hi, seed_lo, seed_hi, o);
+      const float u1 = fmaxf(u01(o[0]), 5.9604645e-8f), u2 = u01(o[1]);
+      const float rad = sqrtf(-2.f * logf(u1));
+      z = (j & 1) ? rad * sinf(6.28318530717958647692f * u2) : rad * cosf(6.28318530717958647692f * u2);
+    }
+    const float v = mean[(size_t)m * KA + j] + (sigma_scale * sigma_nodes[j / A]) * z;
+    nd[j] = v;
+    nodes[(size_t)i * KA + j] = v;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < H * A; j += blockDim.x) {
+    const int h = j / A, a = j - h * A;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(phi[h * K + k], nd[k * A + a], acc);
+    plans[(size_t)i * H * A + j] = acc;
+  }
+}
+
+int lg_mppi_sample_plans(const float* mean, const float* sigma_nodes, float sigma_scale, const float* phi, int32_t num_main, int32_t R, int32_t K, int32_t H,
+                         int32_t A, uint64_t seed, uint64_t call, float* nodes, float* plans, void* stream) {
+  if (!mean || !sigma_nodes || !phi || !nodes || !plans || num_main <= 0 || R <= 0 || K <= 0 || H <= 0 || A <= 0) return LG_ERR_INVALID;
+  if ((size_t)K * A * sizeof(float) > 48 * 1024) return LG_ERR_UNSUPPORTED;
+  const int dev = device_of(mean);
+  if (dev < 0) return LG_ERR_INVALID;
+  DeviceScope ds_(dev);
+  hipLaunchKernelGGL(mppi_sample_plans_kernel, dim3((unsigned)(num_main * R)), dim3(128), (size_t)K * A * sizeof(float), (hipStream_t)stream, mean, sigma_nodes,
+                     sigma_scale, phi, R, K, H, A, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)call, (uint32_t)(call >> 32), nodes, plans);
+  return hipGetLastError() == hipSuccess ? LG_OK : LG_ERR_HIP;
+}
+
+// the diffusion passes of one control step, enqueued by one call (see lgpolicy.h)
+int lg_planner_diffuse(lg_ctx* ctx, float* mean, const float* sigma_nodes, const float* phi, int32_t num_main, int32_t R, int32_t K, int32_t H, int32_t A,
+                       int32_t n_diffuse, float traj_diffuse_factor, float temperature, uint64_t seed, uint64_t call0, const int32_t* env_ids,
+                       int32_t rollouts_per_main, float pos_drift, float* nodes, float* plans, float* rewards, float* weights, void* stream) {
+  if (!ctx || !mean || !env_ids || !rewards || !weights || n_diffuse < 0 || rollouts_per_main != R) return LG_ERR_INVALID;
+  float scale = 1.f;
+  for (int pass = 0; pass < n_diffuse; ++pass) {
+    int rc = lg_mppi_sample_plans(mean, sigma_nodes, scale, phi, num_main, R, K, H, A, seed, call0 + (uint64_t)pass, nodes, plans, stream);
+    if (rc != LG_OK) return rc;
+    rc = lg_rollout_batch(ctx, plans, H, env_ids, num_main * R, rollouts_per_main, pos_drift, rewards, stream);
+    if (rc != LG_OK) return rc;
+    rc = lg_mppi_update(rewards, nodes, num_main, R, H, K, A, temperature, mean, weights, stream);      // (the update reads `nodes`, not `mean`: in place)
+    if (rc != LG_OK) return rc;
+    scale *= traj_diffuse_factor;
+  }
+  return LG_OK;
+}

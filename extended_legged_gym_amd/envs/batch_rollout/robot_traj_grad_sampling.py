@@ -86,12 +86,16 @@ class RobotTrajGradSampling(RobotBatchRolloutPercept):
 
     def rollout_batch(self, all_us):
         rews = super().rollout_batch(self._denormalize_actions(all_us) if self.use_action_normalization else all_us)
+        self._after_rollout_batch()
+        return rews
+
+    def _after_rollout_batch(self):
+        """(also called behind the fused diffusion passes, `lg_planner_diffuse`)"""
         s = self.traj_grad_sampler
         if s is not None and s.use_rl_warmstart and getattr(s.rl_cfg, "use_for_append", True):
             # `:269-277`: what the mean trajectory (rollout env 0 of every main: sample 0 is the mean itself) observed at the end of the horizon -- the
             # last rollout step's observation rows (lg_rollout_batch's final sync copies the simulator state, not the observation rows)
             self.last_mean_traj_obs = self.obs_buf[self.main_env_indices + 1].clone()
-        return rews
 
     def step(self, actions):
         out = super().step(self._denormalize_actions(actions) if self.use_action_normalization else actions)

@@ -90,6 +90,26 @@ int lg_plan_from_nodes(const float* nodes, const float* phi, int64_t n, int32_t 
 int lg_mppi_update(const float* rewards, const float* nodes, int32_t num_main, int32_t R, int32_t H, int32_t K, int32_t A,
                    float temperature, float* new_nodes, float* weights, void* stream);
 
+
+/* The diffusion passes of one control step WITHOUT a return to the host between them (round 6; SURVEY s8(f) rank 4 "sampler glue fused":
+ * `optimize_all_trajectories`, robot_traj_grad_sampling.py:226-247, which in the reference is a Python loop of sample -> node2u -> rollout_batch -> softmax per pass).
+ *
+ * lg_mppi_sample_plans: the samples of one pass.  Row i = m R + s of the launch (main env m, sample s):
+ *     nodes[i, k, a] = mean[m, k, a] + sigma_scale * sigma_nodes[k] * z(i, k A + a),   z = 0 for s = 0 (sample 0 is the mean itself), else N(0, 1):
+ *         Philox4x32-10 with counter (i, call_lo, (k A + a) >> 1, call_hi) and key (seed_lo, seed_hi), Box-Muller on its first two words
+ *         (u1 = max(u01(o0), 2^-24), u2 = u01(o1); cosine for even k A + a, sine for odd) -- the generator of lg_policy_act;
+ *     plans[i, h, a] = sum_k phi[h, k] * nodes[i, k, a]                        (what lg_plan_from_nodes computes from the same nodes).
+ * lg_planner_diffuse: n_diffuse passes of { lg_mppi_sample_plans (sigma_scale = traj_diffuse_factor^pass, call = call0 + pass) -> lg_rollout_batch on `ctx`
+ *     (sync main -> rollout, H rollout steps, sync) -> lg_mppi_update -> mean }, enqueued by ONE call; `mean` (M, K, A) is updated in place, `weights` (M, R) and
+ *     `rewards` (M R, H) hold the last pass's.  nodes / plans / rewards are caller-provided workspaces of (M R, K, A), (M R, H, A), (M R, H) floats.
+ *     env_ids: the n = M R rollout envs of `ctx` in row order (RobotBatchRollout.rollout_env_indices); A must be the robot's DOF count. */
+struct lg_ctx;
+int lg_mppi_sample_plans(const float* mean, const float* sigma_nodes, float sigma_scale, const float* phi, int32_t num_main, int32_t R, int32_t K, int32_t H,
+                         int32_t A, uint64_t seed, uint64_t call, float* nodes, float* plans, void* stream);
+int lg_planner_diffuse(struct lg_ctx* ctx, float* mean, const float* sigma_nodes, const float* phi, int32_t num_main, int32_t R, int32_t K, int32_t H, int32_t A,
+                       int32_t n_diffuse, float traj_diffuse_factor, float temperature, uint64_t seed, uint64_t call0, const int32_t* env_ids,
+                       int32_t rollouts_per_main, float pos_drift, float* nodes, float* plans, float* rewards, float* weights, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

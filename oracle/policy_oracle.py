@@ -75,3 +75,34 @@ def mppi_update_oracle(rewards, nodes, num_main, temperature):
     w = np.exp(z); w /= w.sum(axis=1, keepdims=True)
     new = np.einsum("mr,mrka->mka", w, nodes.reshape(num_main, R, *nodes.shape[1:]))
     return new.astype(np.float32), w.astype(np.float32)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al. 2011) on uint32 arrays -- the generator of the kernels (csrc/lg_device.h: philox4)."""
+    c = [np.asarray(x, np.uint64) & 0xFFFFFFFF for x in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0 & 0xFFFFFFFF), np.uint64(k1 & 0xFFFFFFFF)
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & MASK, p1 & MASK, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & MASK, p0 & MASK]
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return [x.astype(np.uint32) for x in c]
+
+
+def mppi_sample_plans_oracle(mean, sigma_nodes, sigma_scale, phi, R, seed, call):
+    """include/lgpolicy.h: lg_mppi_sample_plans.  mean (M, K, A) -> nodes (M R, K, A), plans (M R, H, A); float32 like the kernel where it matters (the
+    uniforms and the Box-Muller radius), float64 accumulation for the interpolation."""
+    mean = np.asarray(mean, np.float32)
+    M, K, A = mean.shape
+    i = np.arange(M * R, dtype=np.uint64)[:, None]
+    j = np.arange(K * A, dtype=np.uint64)[None, :]
+    o = philox4x32_10(i, np.uint64(call & 0xFFFFFFFF), j >> np.uint64(1), np.uint64((call >> 32) & 0xFFFFFFFF), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u1 = np.maximum((o[0] >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0), np.float32(5.9604645e-8))
+    u2 = (o[1] >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    rad = np.sqrt(np.float32(-2.0) * np.log(u1))
+    ang = np.float32(6.28318530717958647692) * u2
+    z = np.where((np.arange(K * A) & 1)[None, :] == 1, rad * np.sin(ang), rad * np.cos(ang)).astype(np.float32)
+    z[np.arange(M * R) % R == 0] = 0.0                                    # sample 0 of every main env is the mean itself
+    sig = (np.float32(sigma_scale) * np.asarray(sigma_nodes, np.float32))[np.arange(K * A) // A]
+    nodes = (np.repeat(mean.reshape(M, K * A), R, axis=0) + sig[None, :] * z).astype(np.float32).reshape(M * R, K, A)
+    return nodes, plan_from_nodes_oracle(nodes, phi)

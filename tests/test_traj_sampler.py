@@ -3,7 +3,7 @@ numpy oracle known answers on the CPU, kernels vs oracle and the planner env end
 import numpy as np
 import pytest
 
-from oracle.policy_oracle import mppi_update_oracle, plan_from_nodes_oracle
+from oracle.policy_oracle import mppi_sample_plans_oracle, mppi_update_oracle, plan_from_nodes_oracle
 
 
 def test_interpolation_matrix_is_an_interpolant():
@@ -198,3 +198,73 @@ def test_planner_rl_warm_start(tmp_path):
     assert keep.any()
     assert torch.allclose(s.mean[keep, -1], want_last[keep], rtol=2e-5, atol=2e-6)
     assert torch.isfinite(env.obs_buf).all()
+
+
+def test_sample_plans_oracle_known_answers():
+    """`lg_mppi_sample_plans` restated: sample 0 of every main env is the mean, the other samples are mean + sigma_k N(0, 1) draws (unit variance per node after
+    the scale is divided out, independent between calls), and the plans are the interpolants of the nodes."""
+    from extended_legged_gym_amd.utils.traj_sampler import interpolation_matrix
+    rng = np.random.default_rng(0)
+    M, R, K, H, A = 4, 512, 5, 16, 12
+    mean = rng.normal(size=(M, K, A)).astype(np.float32)
+    sig = np.array([0.5, 0.25, 0.2, 0.1, 0.05], np.float32)
+    phi = interpolation_matrix(K, H, "spline")
+    nodes, plans = mppi_sample_plans_oracle(mean, sig, 0.5, phi, R, seed=7, call=3)
+    assert nodes.shape == (M * R, K, A) and plans.shape == (M * R, H, A)
+    np.testing.assert_array_equal(nodes[::R], mean)
+    z = (nodes.reshape(M, R, K, A)[:, 1:] - mean[:, None]) / (0.5 * sig)[None, None, :, None]
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01 and float(np.abs(z).max()) < 6.0
+    np.testing.assert_allclose(plans, plan_from_nodes_oracle(nodes, phi), rtol=1e-6, atol=1e-6)
+    other, _ = mppi_sample_plans_oracle(mean, sig, 0.5, phi, R, seed=7, call=4)
+    assert abs(float(np.corrcoef((other - nodes)[1::R].ravel(), (nodes - np.repeat(mean, R, axis=0))[1::R].ravel())[0, 1])) < 0.9   # another call, another draw
+    assert not np.allclose(other[1], nodes[1])
+
+
+@pytest.mark.gpu
+def test_sample_plans_kernel_matches_the_oracle_and_the_fused_passes_equal_the_python_loop(monkeypatch):
+    """`lg_mppi_sample_plans` against the numpy restatement (same Philox counters: nodes to 2e-5 -- logf / sinf / cosf of the device --, plans likewise), and
+    `lg_planner_diffuse` -- the passes of a control step enqueued by one call -- against the same kernels driven pass by pass from Python (`LG_PLANNER_FUSED=0`):
+    means, weights and rewards bit for bit."""
+    import torch
+    from extended_legged_gym_amd.envs.anymal_c.batch_rollout.anymal_c_batch_rollout_config import AnymalCBatchRolloutCfg
+    from extended_legged_gym_amd.envs.batch_rollout.robot_traj_grad_sampling import RobotTrajGradSampling
+    from extended_legged_gym_amd.envs.batch_rollout.robot_traj_grad_sampling_config import RobotTrajGradSamplingCfg
+    from extended_legged_gym_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
+
+    def build():
+        cfg = AnymalCBatchRolloutCfg()
+        cfg.trajectory_opt = RobotTrajGradSamplingCfg.trajectory_opt()
+        cfg.rl_warmstart = RobotTrajGradSamplingCfg.rl_warmstart()
+        cfg.env.num_envs, cfg.env.rollout_envs = 6, 32
+        cfg.noise.add_noise = False; cfg.domain_rand.push_robots = False; cfg.domain_rand.randomize_friction = False
+        cfg.seed = 3
+        env = RobotTrajGradSampling(cfg, parse_sim_params(get_args([]), {"sim": class_to_dict(cfg.sim)}), "native_hip", "cuda:0", True)
+        env.reset()
+        cmd = torch.zeros(6, 4, device=env.device); cmd[:, 0] = 0.5
+        for _ in range(8):
+            env.set_commands(env.main_env_indices, cmd)
+            env.step(torch.zeros(6, 12, device=env.device))
+        env.set_commands(env.main_env_indices, cmd)
+        return env
+    env = build()
+    s = env.traj_grad_sampler
+    s.mean.copy_(0.1 * torch.randn(s.M, s.K, s.A, generator=torch.Generator().manual_seed(1)).to(env.device))
+    nodes, plans = s.sample_plans(0.5, 11)
+    want_n, want_p = mppi_sample_plans_oracle(s.mean.cpu().numpy(), s.sigma_nodes.cpu().numpy(), 0.5, s.phi.cpu().numpy(), s.R, s.seed, 11)
+    np.testing.assert_allclose(nodes.cpu().numpy(), want_n, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(plans.cpu().numpy(), want_p, rtol=2e-5, atol=2e-5)
+    assert torch.equal(nodes.view(s.M, s.R, s.K, s.A)[:, 0], s.mean)
+    mean0 = s.mean.clone()
+    arena0 = env.core.arena.clone()                       # every byte the library owns: both runs start from the same simulator state
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LG_PLANNER_FUSED", mode)
+        env.core.arena.copy_(arena0)
+        s.mean = mean0.clone(); s.calls = 40
+        env.optimize_all_trajectories(initial=True)
+        torch.cuda.synchronize()
+        out[mode] = (s.mean.clone(), s.last_weights.clone(), s.last_rewards.clone(), s.calls)
+    assert out["1"][3] == out["0"][3] == 40 + int(env.cfg.trajectory_opt.num_diffuse_steps_init)
+    for a, b in zip(out["1"][:3], out["0"][:3]):
+        assert torch.equal(a, b)
+    assert float((out["1"][0] - mean0).abs().max()) > 1e-4
