@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const
                                                     const int64_t* __restrict__ ep_len, int W, int H, int TW, int TH, int RW, int RH, int buffer_len,
                                                     float near_clip, float far_clip, float px, float py, float pz,
                                                     float qx, float qy, float qz, float qw, const float* __restrict__ env_noise,
-                                                    float* __restrict__ cam_pos, float* __restrict__ cam_rot, float* __restrict__ depth_buffer, int getenv_skip) {
+                                                    float* __restrict__ cam_pos, float* __restrict__ cam_rot, float* __restrict__ depth_buffer, int getenv_skip, int rs_off) {
   extern __shared__ float img[];
   float* const rg_tab = img + W * H;       // GRID: x boundaries [nx + 1] | y boundaries [ny + 1] | 4 wave maxima
   if (GRID == 1) raygrid_stage(G, rg_tab);
@@ -410,24 +410,42 @@ __global__ __launch_bounds__(256) void depth_kernel(MeshView M, RayGrid G, const
     depth += noise;
     img[p] = fminf(fmaxf(depth, -far_clip), -near_clip);
   }
+  // The bicubic weights of an output pixel depend on its column and its row only: 4 + 4 weights and two source indices per column / row, formed ONCE per
+  // workgroup (round 6).  In the loop below they were 20 evaluations of the cubic per output pixel -- a quarter of the kernel's vector instructions
+  // (~380 of them per output, six outputs per thread).  Same expressions, same order of the sums: the same image bit for bit.
+  float* const rsx = img + rs_off;            // [RW][5]: source column of tap -1 (unclamped) as float bits, then the four x weights
+  float* const rsy = rsx + 5 * RW;            // [RH][5]
+  const float sx = (float)W / (float)RW, sy = (float)H / (float)RH;
+  const bool resize = !(RW == W && RH == H);
+  if (resize) {
+    for (int i = tid; i < RW + RH; i += 256) {
+      const bool isx = i < RW;
+      const int o = isx ? i : i - RW;
+      const float f = (o + 0.5f) * (isx ? sx : sy) - 0.5f;
+      const int i0 = (int)floorf(f);
+      const float t = f - i0;
+      float* dst = (isx ? rsx : rsy) + 5 * o;
+      dst[0] = __int_as_float(i0);
+#pragma unroll
+      for (int k = -1; k <= 2; ++k) dst[2 + k] = cubic_w(t - k);
+    }
+  }
   __syncthreads();
   const bool init = ep_len[e] <= 1;
-  const float sx = (float)W / (float)RW, sy = (float)H / (float)RH;
   float* buf = depth_buffer + (size_t)e * buffer_len * RW * RH;
   for (int p = tid; p < RW * RH; p += 256) {
     int oy = p / RW, ox = p - oy * RW;
     float v;
-    if (RW == W && RH == H) v = img[p];
+    if (!resize) v = img[p];
     else {   // bicubic, align_corners = False, no antialias
-      float fx = (ox + 0.5f) * sx - 0.5f, fy = (oy + 0.5f) * sy - 0.5f;
-      int ix = (int)floorf(fx), iy = (int)floorf(fy);
-      float tx = fx - ix, ty = fy - iy, acc = 0.f;
+      const int ix = __float_as_int(rsx[5 * ox]), iy = __float_as_int(rsy[5 * oy]);
+      float acc = 0.f;
 #pragma unroll
       for (int m = -1; m <= 2; ++m) {
-        int yy = min(max(iy + m, 0), H - 1); float wy = cubic_w(ty - m);
+        int yy = min(max(iy + m, 0), H - 1); float wy = rsy[5 * oy + 2 + m];
         float row = 0.f;
 #pragma unroll
-        for (int k = -1; k <= 2; ++k) { int xx = min(max(ix + k, 0), W - 1); row += cubic_w(tx - k) * img[yy * W + xx]; }
+        for (int k = -1; k <= 2; ++k) { int xx = min(max(ix + k, 0), W - 1); row += rsx[5 * ox + 2 + k] * img[yy * W + xx]; }
         acc += wy * row;
       }
       v = acc;
@@ -664,7 +682,11 @@ int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* ro
   // the lattice instance keeps its boundary tables in LDS next to the image; together they must stay within the 64 KB a launch gets without opting in
   const char* rs_ = getenv("LG_RAY_SKIP"); const int skip = rs_ ? atoi(rs_) : 1;      // (A/B switch; 0: every ray walks from the camera, 2: also the coarse walk over blocks -- measured: +-1 %)
   int mode = 0;
-  if (m->d_gcells && m->gnx >= 1 && m->gny >= 1 && lds + ray_grid_lds(m) <= 64 * 1024) { mode = 1; lds += ray_grid_lds(m); }
+  const size_t rs_lds = (size_t)5 * (p->resized_width + p->resized_height) * sizeof(float);      // the resize's per-column / per-row weights (depth_kernel)
+  if (m->d_gcells && m->gnx >= 1 && m->gny >= 1 && lds + ray_grid_lds(m) + rs_lds <= 64 * 1024) { mode = 1; lds += ray_grid_lds(m); }
+  if (lds + rs_lds > 64 * 1024) { m->err = "depth image too large for the LDS-staged resize"; return LG_ERR_UNSUPPORTED; }
+  const int rs_off = (int)(lds / sizeof(float));
+  lds += rs_lds;
   MeshView M{m->d_nodes, m->d_tris};
   // pixel tile of a wave: the TW x TH <= 64 that covers the image with the fewest tiles, the squarest of those
   int TW = 8, TH = 8, best_tiles = 1 << 30;
@@ -676,7 +698,7 @@ int lg_depth_camera_update(lg_mesh* m, const lg_depth_params* p, const float* ro
 #define LG_DEPTH_LAUNCH(MODE) hipLaunchKernelGGL(depth_kernel<MODE>, dim3(num_envs), dim3(256), lds, (hipStream_t)stream, M, ray_grid_of(m), root_states, ray_dirs, \
                      episode_length_buf, p->width, p->height, TW, TH, p->resized_width, p->resized_height, p->buffer_len, p->near_clip, p->far_clip, \
                      p->position[0], p->position[1], p->position[2], p->quat_offset[0], p->quat_offset[1], p->quat_offset[2], \
-                     p->quat_offset[3], env_noise, camera_pos, camera_rot, depth_buffer, skip)
+                     p->quat_offset[3], env_noise, camera_pos, camera_rot, depth_buffer, skip, rs_off)
   if (mode == 1) LG_DEPTH_LAUNCH(1); else LG_DEPTH_LAUNCH(0);
 #undef LG_DEPTH_LAUNCH
   MESH_TRY(m, hipGetLastError());
