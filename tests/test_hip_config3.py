@@ -178,7 +178,7 @@ def test_body_sdf_by_cell_equals_the_tree_walk(tmp_path, monkeypatch):
             sdfs[mode].query_bodies(rb, env.num_bodies, bodies, None, *out[mode])
             monkeypatch.delenv("LG_SDF_LATTICE", raising=False)
         torch.cuda.synchronize()
-        far = out["tree"][0].abs() > 1e-3                                       # (the gradient of a point ON the surface is a quotient of roundings)
+        far = out["tree"][0].abs() > 1e-2                                       # (the gradient of a point near the surface is a quotient of roundings)
         worst = max(worst, float((out["cell"][0] - out["tree"][0]).abs().max()), float((out["cell"][2] - out["tree"][2]).abs().max()),
                     float(((out["cell"][1] - out["tree"][1]).abs().amax(dim=2) * far).max()) * 1e-2)
     assert torch.isfinite(out["cell"][0]).all() and float(out["cell"][0].abs().max()) < 5.0
