@@ -299,7 +299,8 @@ struct TerrainView { int mesh_type, rows, cols; float hscale, vscale, border; co
                      MeshView M;
                      LatticeView L;   /* cell != null: the mesh's triangles by lattice cell (closest_point_lattice) */
                      const float* __restrict__ GV; /* non-null: grid mesh */ const float4* __restrict__ GV4; /* its vertices (rows x cols) x (x, y, z, 0), world frame */
-                     const float* __restrict__ GM; int mcols; /* max vertex z per 2 x 2 block of vertices */ };
+                     const float* __restrict__ GM; int mcols; /* max vertex z per 2 x 2 block of vertices */
+                     const float4* __restrict__ SEG4; /* non-null: the grid mesh's vertices as above, for the capsule segments' edge pieces (contact_detect_mesh<true>; set whichever way the sphere queries go) */ };
 struct TerrainCell { float u, v; int16_t h0, h1, h2, h3; };
 LG_DEV TerrainCell terrain_fetch(const TerrainView& T, float x, float y) {
   // branch-free on purpose (the plane reads its 1 x 1 dummy grid): a conditional around the loads would make the
@@ -1046,6 +1047,7 @@ LG_DEV void closest_point_lattice_pair(const LatticeView& L, ClosestQuery& QA, C
   wave_lds_sync();                                                     // (the records are the caller's again)
 }
 
+template <bool MCAPS = false>
 LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k,
                                 const M3& Rb, V3 pb, float* cst, int lane, float* cq = nullptr, unsigned long long* dbg = nullptr) {
   const int ncp = lm_.i(LM_CP_COUNT);
@@ -1064,8 +1066,8 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
         rads[h] = lm_.f(LM_CP_RADIUS + sl);
         const V3 x = link < 0 ? pb + mul(Rb, lp) : (link == 0 ? k.O[0] + mul(k.R[0], lp) : (link == 1 ? k.O[1] + mul(k.R[1], lp) : k.O[2] + mul(k.R[2], lp)));
         xs[h] = x;
-        // (capsule segments, lg_robot_model.cp_slide, are matched against the EDGES of a height grid; on a triangle mesh the spheres stand alone: a
-        //  closest-point query of a segment is not built, and sliding the sphere to the segment point nearest ONE mesh point loses the contact of its own end)
+        // (capsule segments, lg_robot_model.cp_slide: against the edges of a GRID mesh below (MCAPS); on other meshes the spheres stand alone -- a closest-point
+        //  query of a segment is not built, and sliding the sphere to the segment point nearest ONE mesh point loses the contact of its own end)
         const float range = rads[h] + P.contact_offset + LG_MESH_CONTACT_MARGIN;
         const float reach = cq ? range + LG_MESH_CACHE_REACH : range;
         ranges[h] = range; reaches[h] = reach;
@@ -1131,7 +1133,42 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
           active = phi < P.contact_offset;
         }
       }
-      const V3 r = (x - rad * n) - pb;
+      V3 xc = x;
+      if (MCAPS && sl < ncp && ((P.slide_mask >> sl) & 1u)) {                     // (kernel-uniform)
+        // Capsule segments on a GRID mesh (round 6; T.SEG4 = lg_terrain.grid_vertices): the height grid's rule (contact_detect_*_caps) with the mesh's own
+        // edges -- the segment [x, x + gv] against the mesh edge (L, j)-(L, j + 1) of the first lattice line of each axis its ground track crosses; the edge's
+        // end points are the mesh's vertices, wherever the slope correction put them.  The candidate takes the slot when it is
+        // deeper than what the sphere found within its range -- nothing: phi = 1 -- by more than 10 um.  Evaluated whatever the sphere's distance cache said: the
+        // cache speaks for the sphere's centre, not for the far end of its segment.
+        typedef float f4v __attribute__((ext_vector_type(4))); typedef const f4v __attribute__((address_space(1)))* gf4;
+        const gf4 SG = (gf4)T.SEG4;
+        const int link = lm_.i(LM_CP_LINK + sl);
+        const V3 ls = lm_.v(LM_CP_SLIDE + 3 * sl);
+        const V3 gv = sel3(link < 0, mul(Rb, ls), sel3(link == 0, mul(k.R[0], ls), sel3(link == 1, mul(k.R[1], ls), mul(k.R[2], ls))));
+        const float ihs = T.hscale > 0.f ? frcp(T.hscale) : 0.f;
+        const float fx0 = (x.x + T.border) * ihs, fy0 = (x.y + T.border) * ihs, dfx = gv.x * ihs, dfy = gv.y * ihs;
+        const EdgePiece px = caps_edge_piece(fx0, dfx, fy0, dfy, T.rows, T.cols), py = caps_edge_piece(fy0, dfy, fx0, dfx, T.cols, T.rows);
+        const gf4 ex = SG + (size_t)px.L * T.cols + px.j;      // (L, j), (L, j + 1)
+        const gf4 ey = SG + (size_t)py.j * T.cols + py.L;      // (j, L), (j + 1, L)
+        const f4v a0 = ex[0], a1 = ex[1], b0 = ey[0], b1 = ey[T.cols];
+        const float zlow = fminf(x.z, x.z + gv.z) - rad - P.contact_offset;       // nothing of the segment's capsule is lower than this
+#pragma unroll
+        for (int ax = 0; ax < 2; ++ax) {
+          const f4v e0 = ax == 0 ? a0 : b0, e1 = ax == 0 ? a1 : b1;
+          const V3 E0 = v3(e0.x, e0.y, e0.z), d2 = v3(e1.x - e0.x, e1.y - e0.y, e1.z - e0.z);
+          const bool cand = (ax == 0 ? px.on : py.on) && zlow < fmaxf(e0.z, e1.z) && d2.x * d2.x + d2.y * d2.y > 0.25f * T.hscale * T.hscale;   // (an edge the correction stood upright -- the seam of two wall faces -- or collapsed is no crease)
+          if (!__any(cand)) continue;                                             // most substeps no lane of the wave has a candidate
+          V3 A, E; seg_seg_closest(x, gv, E0, cand ? d2 : v3(0.f, T.hscale, 0.f), &A, &E);
+          const V3 d = A - E; const float dist = norm(d);
+          const float sg = d.z >= 0.f ? 1.f : -1.f;
+          const V3 ne = dist > 1e-9f ? (sg * frcp(dist)) * d : v3(0, 0, 1);
+          const float pe = sg * dist - rad;
+          const bool better = cand && pe < phi - 1e-5f && (sg > 0.f || dist <= rad);      // (an axis below the edge by more than the radius is the spheres' business: on a mesh with walls "below the edge" need not mean "under the surface")
+          phi = better ? pe : phi; n = sel3(better, ne, n); xc = sel3(better, A, xc);
+        }
+        active = phi < P.contact_offset;
+      }
+      const V3 r = (xc - rad * n) - pb;
       CS4(sl, 0) = make_float4(n.x, n.y, n.z, phi);
       CS4(sl, 1) = make_float4(r.x, r.y, r.z, active ? 1.f : 0.f);
       CS4(sl, 2) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1478,9 +1515,9 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
   // mass matrix and its factors it sat in the middle of ~500 live registers and the inlined closest-point scan spilled them
   // (~800 scratch loads in the substep of the main wave)
 #if defined(LG_STAMPS) && defined(LG_STAMP_MAIN_MESH)
-  if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh(MAIN_DETECT - 100, MAIN_DETECT - 98, lm_, T, P, k, Rb, pb, cst, lane, cq, stamps);   // diagnostic: the query counters watch this wave
+  if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh<(FEAT & 1) != 0>(MAIN_DETECT - 100, MAIN_DETECT - 98, lm_, T, P, k, Rb, pb, cst, lane, cq, stamps);   // diagnostic: the query counters watch this wave
 #else
-  if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh(MAIN_DETECT - 100, MAIN_DETECT - 98, lm_, T, P, k, Rb, pb, cst, lane, cq);   // (triangle-mesh instances: MAIN_DETECT = 100 + the first slot of this wave's pair)
+  if (TMESH && MAIN_DETECT > 0 && share.n > 1) contact_detect_mesh<(FEAT & 1) != 0>(MAIN_DETECT - 100, MAIN_DETECT - 98, lm_, T, P, k, Rb, pb, cst, lane, cq);   // (triangle-mesh instances: MAIN_DETECT = 100 + the first slot of this wave's pair)
 #endif
   // ---------------------------------------------------------------- bias forces (RNEA, zero generalised acceleration)
   const float m0 = m->base_mass + madd, iscale = m0 * frcp(m->base_mass);
@@ -1563,7 +1600,7 @@ LG_DEV void physics_substep(const lg_robot_model* __restrict__ m, const LegModel
     //  registers and code)
     if (ALLOW_INLINE) {
       leg_bias(lm_, k, pb, wb, s.qd, P.grav, bk, Fs, Ns);
-      if (TMESH) contact_detect_mesh(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);
+      if (TMESH) contact_detect_mesh<(FEAT & 1) != 0>(0, LG_MAX_CP, lm_, T, P, k, Rb, pb, cst, lane);
       else if (FEAT & 1) contact_detect_caps<0, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
       else contact_detect<0, LG_MAX_CP>(lm_, T, P, k, Rb, pb, cst, lane);
     }

@@ -638,6 +638,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   const int nsteps = PERSIST ? (sink.nsteps > 1 ? sink.nsteps : 1) : 1;
   constexpr int FEAT = SPEC >> 2;
   constexpr bool CAPS = !TMESH && (FEAT & 1);
+  constexpr bool MCAPS = TMESH && (FEAT & 1);               // capsule segments against the edges of a GRID mesh (contact_detect_mesh<true>; launch_physics picks the instance when the terrain has TerrainView::SEG4)
   const int32_t* const fids = ro ? ids : nullptr;           // the tail's row -> env map: a literal null (rows = envs) in the full step's instance
   int64_t fstep = ro ? C->counters[3] + 1 : C->counters[0] + 1;         // LR:123 (the statistics step of the previous launch stored it)
   const int64_t gstep_f = C->counters[0] + 1;             // what the gait term's "has a scheduler step run yet" test sees (post_instance: gstep)
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     PhysParams P;
     P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
     P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-    P.terrain_mu = C->terrain_mu; P.slide_mask = CAPS ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : 0x76543210u;
+    P.terrain_mu = C->terrain_mu; P.slide_mask = (CAPS || (MCAPS && C->ter.SEG4)) ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : 0x76543210u;
 #if LG_AB == 21
     P.slide_mask = 0u;
 #endif
@@ -794,17 +795,17 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
           pb4[0] = make_float4(bk[0], bk[1], bk[2], Fs.x); pb4[1] = make_float4(Fs.y, Fs.z, Ns.x, Ns.y); pb4[2] = make_float4(Ns.z, 0.f, 0.f, 0.f);
         }
         if (!TMESH) { if (DS0 < DS1) { if (CAPS) contact_detect_begin_caps<DS0, DS1P>(lm_, T, k, Rb, pb, P.slide_mask, pc1, P.slot_perm); else contact_detect_begin<DS0, DS1P>(lm_, T, k, Rb, pb, pr1); } }
-        else contact_detect_mesh(MESH_PAIR0(1), MESH_PAIR0(1) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
+        else contact_detect_mesh<MCAPS>(MESH_PAIR0(1), MESH_PAIR0(1) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
       } else if (TMESH) {
 #ifdef LG_STAMPS
-        contact_detect_mesh(MESH_PAIR0(wv), MESH_PAIR0(wv) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc,
+        contact_detect_mesh<MCAPS>(MESH_PAIR0(wv), MESH_PAIR0(wv) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc,
 #ifdef LG_STAMP_MAIN_MESH
                             nullptr);
 #else
                             (blockIdx.x == 0 && wv == 2) ? C->stamps : nullptr);
 #endif
 #else
-        contact_detect_mesh(MESH_PAIR0(wv), MESH_PAIR0(wv) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
+        contact_detect_mesh<MCAPS>(MESH_PAIR0(wv), MESH_PAIR0(wv) + 2, lm_, T, P, k, Rb, pb, cst, lane, cqc);
 #endif
       } else if (wv == 2) {
         if (CAPS) contact_detect_begin_caps<DS1, DS2>(lm_, T, k, Rb, pb, P.slide_mask, pc2, P.slot_perm); else contact_detect_begin<DS1, DS2>(lm_, T, k, Rb, pb, pr2);
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   PhysParams P;
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-  P.terrain_mu = C->terrain_mu; P.slide_mask = CAPS ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : 0x76543210u;
+  P.terrain_mu = C->terrain_mu; P.slide_mask = (CAPS || (MCAPS && C->ter.SEG4)) ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : 0x76543210u;
 #if LG_AB == 21
   P.slide_mask = 0u;
 #endif
@@ -2798,9 +2799,11 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
   h.ter.hscale = ter->horizontal_scale; h.ter.vscale = ter->vertical_scale; h.ter.border = ter->border_size;
   h.ter.H = (const int16_t LG_G*)P(LG_T_HEIGHT_SAMPLES);
   h.ter.L = LatticeView{nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 1.f, 1.f, LATP_CAP};
-  h.ter.M = MeshView{nullptr, nullptr}; h.ter.GV = nullptr; h.ter.GV4 = nullptr; h.ter.GM = nullptr; h.ter.mcols = 0;
+  h.ter.M = MeshView{nullptr, nullptr}; h.ter.GV = nullptr; h.ter.GV4 = nullptr; h.ter.GM = nullptr; h.ter.mcols = 0; h.ter.SEG4 = nullptr;
   if (const char* ev = getenv("LG_GRID_MESH")) c->grid_mesh = atoi(ev) != 0;
-  if (ter->mesh_type == LG_MESH_TRIMESH && ter->grid_vertices && c->grid_mesh) {      // grid mesh: contact queries by cell index
+  bool mesh_caps = true;                                   // LG_MESH_CAPS=0: the spheres alone on grid meshes (A/B, the tests' checker)
+  if (const char* ev = getenv("LG_MESH_CAPS")) mesh_caps = atoi(ev) != 0;
+  if (ter->mesh_type == LG_MESH_TRIMESH && ter->grid_vertices && (c->grid_mesh || mesh_caps)) {      // grid mesh: contact queries by cell index, capsule segments against its edges
     // vertices as (x, y, z, 0) -- one 16-byte load each --, then the max z of every 2 x 2 block of vertices (the clearance test in closest_point_grid)
     const size_t nvert = (size_t)ter->rows * ter->cols, nv = nvert * 4;
     const int mr = (ter->rows + 1) / 2, mc = (ter->cols + 1) / 2;
@@ -2824,7 +2827,8 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
         hipMemcpy(c->grid_verts, v4.data(), nv * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy((float*)c->grid_verts + nv, top.data(), top.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
       return fail("grid-mesh vertex upload failed");
-    h.ter.GV = (const float*)c->grid_verts; h.ter.GV4 = (const float4*)c->grid_verts; h.ter.GM = (const float*)c->grid_verts + nv; h.ter.mcols = mc;
+    if (c->grid_mesh) { h.ter.GV = (const float*)c->grid_verts; h.ter.GV4 = (const float4*)c->grid_verts; h.ter.GM = (const float*)c->grid_verts + nv; h.ter.mcols = mc; }
+    if (mesh_caps && ter->rows <= 65535 && ter->cols <= 32767) h.ter.SEG4 = (const float4*)c->grid_verts;      // (caps_edge_piece's packed indices; larger grids: spheres alone)
   }
   if (ter->mesh_type == LG_MESH_TRIMESH) {
     if (ter->collision_mesh->device != device_id) return fail("collision mesh lives on another device");
@@ -2982,11 +2986,12 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
   // as well: the main wave alone took 0.134 ms per rollout step of 4096 envs on the plane
   const int nact = (c->split || c->h.ter.mesh_type == LG_MESH_TRIMESH) ? 3 : 0;
   if (n != c->h.n_stepped) { c->h.n_stepped = n; hipLaunchKernelGGL(set_n_stepped, dim3(1), dim3(1), 0, st, c->d, n); }
-  // Which instance (physics_kernel's SPEC): rollout tail or not, and the model features the launch needs -- capsule parts (heightfield / plane: the
-  // triangle-mesh detection slides its spheres without a flag) and the self-collision pass.  A robot of fixed spheres without self-collision runs
+  // Which instance (physics_kernel's SPEC): rollout tail or not, and the model features the launch needs -- capsule segments (height grids against their grid lines, grid meshes against their own edges; other meshes and planes: spheres alone)
+  // and the self-collision pass.  A robot of fixed spheres without self-collision runs
   // the plain instance.
   const bool tm = c->h.ter.mesh_type == LG_MESH_TRIMESH;
   const bool caps = c->h.ter.mesh_type == LG_MESH_HEIGHTFIELD && c->h.slide_mask != 0u, selfc = c->h.n_sc > 0;       // (a plane has no grid lines: the plain instance)
+  const bool mcaps = tm && c->h.ter.SEG4 && c->h.slide_mask != 0u;      // grid meshes: the segments against the mesh's edges (other meshes: spheres alone)
 #define LG_LAUNCH_PK(TM, HELP, SPEC_, THREADS) \
   hipLaunchKernelGGL((physics_kernel<0, TM, HELP, SPEC_>), dim3(nb), dim3(THREADS), 0, st, c->d, actions, c->h.cfg.decimation, nact, ids, n, act_stride, fuse, sink)
 #if LG_LEGS == 4
@@ -2997,14 +3002,14 @@ static void launch_physics(lg_ctx* c, hipStream_t st, const float* actions, cons
     return;
   }
   if (fuse == 2) {                                       // (can_fuse() held: helper waves are present)
-    if (tm) { if (selfc) LG_LAUNCH_PK(true, true, 2 + 8, 256); else LG_LAUNCH_PK(true, true, 2, 256); }
+    if (tm) { if (selfc) { if (mcaps) LG_LAUNCH_PK(true, true, 2 + 12, 256); else LG_LAUNCH_PK(true, true, 2 + 8, 256); } else if (mcaps) LG_LAUNCH_PK(true, true, 2 + 4, 256); else LG_LAUNCH_PK(true, true, 2, 256); }
     else if (selfc) LG_LAUNCH_PK(false, true, 2 + 12, 256);
     else if (caps) LG_LAUNCH_PK(false, true, 2 + 4, 256);
     else LG_LAUNCH_PK(false, true, 2, 256);
     return;
   }
 #endif
-  if (tm) { if (selfc) LG_LAUNCH_PK(true, true, 8, 256); else LG_LAUNCH_PK(true, true, 0, 256); }
+  if (tm) { if (selfc) { if (mcaps) LG_LAUNCH_PK(true, true, 12, 256); else LG_LAUNCH_PK(true, true, 8, 256); } else if (mcaps) LG_LAUNCH_PK(true, true, 4, 256); else LG_LAUNCH_PK(true, true, 0, 256); }
   else
 #if LG_AB == 13
     if (nact == 3 && c->h.cfg.solver_type == LG_SOLVER_TGS && c->h.cfg.friction_model == LG_FRICTION_PYRAMID && c->spec && !caps && !selfc)

@@ -201,8 +201,10 @@ typedef struct lg_robot_model {
    * vector (link frame) from a sphere to the NEXT one of its chain, zero for the last and for lone spheres.  The faces of a piecewise-planar terrain meet
    * a capsule at its spheres first; what would pass between two spheres is a convex edge, and the creases of a height grid lie on its lines: the slot of
    * a sphere with a segment also holds the contact of [cp_pos, cp_pos + cp_slide] with the pieces of the first x line and first y line its ground track
-   * crosses (exact segment-segment closest points), whenever that is deeper than the sphere's own contact.  Plane terrains have no lines; on triangle-mesh
-   * terrains the spheres stand alone (a closest-point query of a segment is not built). */
+   * crosses (exact segment-segment closest points), whenever that is deeper than the sphere's own contact.  Plane terrains have no lines.  Triangle-mesh terrains: on a GRID mesh
+   * (lg_terrain.grid_vertices: the slope-corrected triangulation of the height grid, what the registered rough tasks collide with) the same rule with the mesh's own
+   * edges -- the edge (L, j)-(L, j + 1) of the first lattice line of each axis, wherever the correction put its vertices; upright or collapsed edges and candidates
+   * whose axis lies below the edge by more than the radius are left out; LG_MESH_CAPS=0 switches it off -- ; on other meshes the spheres stand alone. */
   float cp_slide[LG_MAX_LEGS][LG_MAX_CP][3];
   /* Self-collision (asset.self_collisions = 0, legged_robot_config.py:170,176: PhysX collides the actor's own shapes, parent-child links excepted):
    * the sphere pairs (leg a, slot a, leg b, slot b) the pass tests every substep -- the pairs the host found reachable within the joint limits.

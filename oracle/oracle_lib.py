@@ -43,6 +43,7 @@ def lib():
         L.lgo_max_threads.restype = C.c_int
         L.lgo_debug_terrain.argtypes = [vp, C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.lgo_set_extra_obs.argtypes = [vp, vp]
+        L.lgo_set_mesh_caps.argtypes = [vp, C.c_int]
         L.lgo_set_friction_anchors.argtypes = [vp, C.c_int]      # the oracle's own experiment switch (tools/physics/*_oracle.py; DESIGN s2a)
         L.lgo_set_extra_termination.argtypes = [vp, vp]
         L.lgo_step_subset.argtypes = [vp, vp, vp, C.c_int32, C.c_int32]

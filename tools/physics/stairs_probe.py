@@ -9,7 +9,10 @@ than the sample minus the sphere radius.  Reported: how often some sample is ins
 triangulation, `terrain_eval`), and "answered" is read off `contact_forces`, so the probe sees whatever the kernel does (spheres, and the capsule
 segments' edge contacts when the model carries them; `LG_CAPS=0` in the environment runs the spheres alone).
 
-    python tools/physics/stairs_probe.py [steps]        (prints one JSON object)
+Round 6: `trimesh` as a second argument runs the terrain as `anymal_c_rough` registers it (the slope-corrected triangle mesh; the surface under a sample is then found by
+a downward ray on the collision mesh itself), where the segments meet the mesh's own edges (`contact_detect_mesh<true>`); `LG_MESH_CAPS=0` runs the spheres alone there.
+
+    python tools/physics/stairs_probe.py [steps] [heightfield|trimesh]        (prints one JSON object)
 """
 import json
 import os
@@ -22,13 +25,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
-def main(steps=400, n=1024):
+def main(steps=400, n=1024, mesh_type="heightfield"):
     from extended_legged_gym_amd.envs import Anymal, AnymalCRoughCfg
     from tools.bench_configs import sim_params
     from tests.test_walk_policy import load_policy_fixture, play_cfg
     cfg = play_cfg(n)                                       # anymal_c_flat's 48 observations: the reference's flat-ground walking policy drives the robots
     rough = AnymalCRoughCfg().terrain
-    rough.mesh_type, rough.measure_heights, rough.curriculum = "heightfield", False, False
+    rough.mesh_type, rough.measure_heights, rough.curriculum = mesh_type, False, False
     rough.terrain_proportions = [0.0, 0.0, 0.5, 0.5, 0.0]
     rough.num_rows, rough.num_cols, rough.max_init_terrain_level = 6, 8, 5
     cfg.terrain = rough
@@ -69,6 +72,18 @@ def main(steps=400, n=1024):
         dhdu = torch.where(upper, h3 - h1, h2 - h0); dhdv = torch.where(upper, h1 - h0, h3 - h2)
         return h0 + u * dhdu + v * dhdv
 
+    if mesh_type == "trimesh":       # the collision surface is the slope-corrected mesh (vertical faces): read it off the mesh with downward rays
+        from extended_legged_gym_amd.utils.mesh import DeviceMesh
+        from extended_legged_gym_amd.utils.ray_caster import raycast_mesh
+        assert env.core.setup.terrain.mesh_type == 2 and bool(env.core.setup.terrain.grid_vertices)
+        dmesh = DeviceMesh(env.core.setup.collision_vertices, env.core.setup.collision_triangles, "cuda:0")
+        grid_height = height_at
+
+        def height_at(p):            # noqa: F811
+            o = p.reshape(-1, 3).clone(); o[:, 2] += 1.0
+            d = torch.zeros_like(o); d[:, 2] = -1.0
+            hits, found = raycast_mesh(o, d, 5.0, dmesh)
+            return torch.where(found, hits[:, 2], grid_height(p).reshape(-1)).reshape(p.shape[:-1])
     from extended_legged_gym_amd.utils.isaac_torch_utils import quat_apply
     g = torch.Generator(device="cpu").manual_seed(0)
     events = 0; samples = 0; depths = []; touching = 0
@@ -95,9 +110,10 @@ def main(steps=400, n=1024):
                unseen_per_sphere_contact=events / max(touching, 1),
                depth_mm_median=float(d.median() * 1e3) if len(d) else 0.0, depth_mm_p95=float(d.quantile(0.95) * 1e3) if len(d) else 0.0,
                depth_mm_max=float(d.max() * 1e3) if len(d) else 0.0, envs=n, steps=steps,
-               resets_per_env_step=float(env.reset_buf.float().mean()), mean_forward_speed=float(env.base_lin_vel[:, 0].mean()))
+               resets_per_env_step=float(env.reset_buf.float().mean()), mean_forward_speed=float(env.base_lin_vel[:, 0].mean()), mesh_type=mesh_type,
+               segments=os.environ.get("LG_MESH_CAPS" if mesh_type == "trimesh" else "LG_CAPS", "1") != "0")
     print(json.dumps(out))
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 400)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 400, mesh_type=sys.argv[2] if len(sys.argv) > 2 else "heightfield")
