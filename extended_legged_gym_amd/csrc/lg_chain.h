@@ -53,7 +53,7 @@ LG_DEV void ch_wave_sync() {          // LDS writes of one half of the wave visi
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// contact detection of slot sl: plane / height grid (sphere + the capsule segment's edge candidates) or grid mesh (closest point; a segment slides)
+// contact detection of slot sl: plane / height grid (sphere + the capsule segment's edge candidates) or grid mesh (closest point + the segment against the mesh's own edges)
 template <bool TMESH>
 LG_DEV void ch_detect_slot(int sl, const LegModel& lm_, const TerrainView& T, const PhysParams& P, const LegKin& k, const M3& Rb, V3 pb, float* cst, int lane) {
   const int ncp = lm_.i(LM_CP_COUNT);
@@ -64,7 +64,7 @@ LG_DEV void ch_detect_slot(int sl, const LegModel& lm_, const TerrainView& T, co
   const V3 gv = mul(Rl, lm_.v(LM_CP_SLIDE + 3 * sl));
   const bool seg = gv.x != 0.f || gv.y != 0.f || gv.z != 0.f;
   V3 x = x0, n = v3(0, 0, 1); float phi = 1.f; bool hit = true;
-  if (TMESH) {                                         // (triangle meshes: the spheres stand alone, see contact_detect_mesh)
+  if (TMESH) {                                         // (grid meshes only: validate())
     ClosestQuery Q;
     Q.p = x; Q.max_dist = rad + P.contact_offset + LG_MESH_CONTACT_MARGIN; Q.on = sl < ncp; Q.found = false; Q.cp = x; Q.fn = v3(0, 0, 1);
     Q.range = rad + P.contact_offset; Q.lb = Q.max_dist;
@@ -76,6 +76,29 @@ LG_DEV void ch_detect_slot(int sl, const LegModel& lm_, const TerrainView& T, co
         const float sign = dot(diff, Q.fn) < 0.f ? -1.f : 1.f;
         n = dist > 1e-6f ? (sign / dist) * diff : Q.fn;
         phi = sign * dist - rad; hit = true;
+      }
+    }
+    if (T.SEG4 && __any(seg && sl < ncp)) {            // capsule segments against the grid mesh's own edges (round 6: contact_detect_mesh<true> of lg_physics.h, the same rule)
+      typedef float f4v __attribute__((ext_vector_type(4))); typedef const f4v __attribute__((address_space(1)))* gf4;
+      const gf4 SG = (gf4)T.SEG4;
+      const float ihs = frcp(T.hscale);
+      const float fx0 = (x0.x + T.border) * ihs, fy0 = (x0.y + T.border) * ihs, dfx = gv.x * ihs, dfy = gv.y * ihs;
+      const float zlow = fminf(x0.z, x0.z + gv.z) - rad - P.contact_offset;
+#pragma unroll
+      for (int ax = 0; ax < 2; ++ax) {
+        const EdgePiece pc = ax == 0 ? caps_edge_piece(fx0, dfx, fy0, dfy, T.rows, T.cols) : caps_edge_piece(fy0, dfy, fx0, dfx, T.cols, T.rows);
+        const gf4 ep = ax == 0 ? SG + (size_t)pc.L * T.cols + pc.j : SG + (size_t)pc.j * T.cols + pc.L;
+        const f4v e0 = ep[0], e1 = ep[ax == 0 ? 1 : T.cols];
+        const V3 E0 = v3(e0.x, e0.y, e0.z), d2 = v3(e1.x - e0.x, e1.y - e0.y, e1.z - e0.z);
+        const bool cand = seg && sl < ncp && pc.on && zlow < fmaxf(e0.z, e1.z) && d2.x * d2.x + d2.y * d2.y > 0.25f * T.hscale * T.hscale;
+        if (!__any(cand)) continue;
+        V3 A, E; seg_seg_closest(x0, gv, E0, cand ? d2 : v3(0.f, T.hscale, 0.f), &A, &E);
+        const V3 d = A - E; const float dist = norm(d);
+        const float sg = d.z >= 0.f ? 1.f : -1.f;
+        const V3 ne = dist > 1e-9f ? (sg * frcp(dist)) * d : v3(0, 0, 1);
+        const float pe = sg * dist - rad;
+        const bool better = cand && pe < phi - 1e-5f && (sg > 0.f || dist <= rad);
+        phi = better ? pe : phi; n = sel3(better, ne, n); x = sel3(better, A, x); hit = hit || better;
       }
     }
   } else {

@@ -203,6 +203,49 @@ def test_biped_substep_and_step_parity_from_identical_state(kind):
 
 
 @pytest.mark.gpu
+def test_biped_on_a_grid_mesh_matches_the_oracle_substep():
+    """`cassie` as registered collides with the slope-corrected triangle mesh of its terrain (`mesh_type = 'trimesh'`): the chain instance's cell-indexed closest-point
+    queries and -- round 6 -- its capsule segments against the mesh's own edges (`ch_detect_slot`), against the oracle's brute-force scan of the same triangles."""
+    import torch
+    from extended_legged_gym_amd import abi
+    from extended_legged_gym_amd.native import NativeCore
+    from oracle.oracle_lib import OracleEnv
+    from tests.test_hip_vs_oracle import COPY, compare
+
+    def small_mesh(cfg):
+        cfg.terrain.mesh_type = "trimesh"
+        cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = 2, 2, 1
+        cfg.terrain.terrain_length = cfg.terrain.terrain_width = 4.0
+        cfg.terrain.max_init_terrain_level = 1
+    n = 128
+    cfg, s, terrain, m = cassie_setup(n, "rough", mutate=small_mesh)
+    assert s.terrain.mesh_type == abi.LG_MESH_TRIMESH and bool(s.terrain.grid_vertices) and np.abs(np.asarray(m["cp_slide"])).max() > 0.03
+    o, core = OracleEnv(s), NativeCore(s, "cuda:0")
+    rng = np.random.default_rng(5)
+    o.t["friction_coeffs"][:] = rng.uniform(0.5, 1.25, n)
+    lv, ty = rng.integers(0, 2, n), rng.integers(0, 2, n)
+    o.t["terrain_levels"][:] = lv; o.t["terrain_types"][:] = ty
+    o.t["env_origins"][:] = terrain.env_origins[lv, ty]
+    o.reset_idx(np.arange(n))
+    loaded = 0
+    for it in range(20):
+        act = (0.5 * rng.normal(size=(n, 12))).astype(np.float32)
+        if it % 5 == 4:
+            for name in COPY:
+                core.t[name].copy_(torch.from_numpy(o.t[name].copy()))
+            keep = {k: o.t[k].copy() for k in COPY}
+            o.compute_torques(act); o.simulate()
+            core.compute_torques(torch.from_numpy(act).cuda()); core.simulate()
+            compare(core, o, ["root_states", "dof_state", "rigid_body_state", "contact_forces", "torques"], bars="substep", tag="biped_substep/grid_mesh")
+            loaded += int((np.abs(o.t["contact_forces"]).reshape(n, -1).max(axis=1) > 1.0).sum())
+            for k in COPY:
+                o.t[k][...] = keep[k]
+        o.step(act)
+    assert loaded > n
+    core.close(); o.close()
+
+
+@pytest.mark.gpu
 def test_registered_task_steps_and_resets():
     """Task `cassie` through `task_registry.make_env` (the VecEnv attributes with the biped's extents): the registered rough config on its terrain
     (`mesh_type = 'trimesh'`: the grid-mesh contact path of the instance), 300 steps of random actions, resets and the episode statistics flowing."""
