@@ -1057,10 +1057,12 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
     V3 xs[2]; float rads[2], ranges[2], reaches[2]; ClosestQuery Q[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int sl = sp0 + h;
+      // POSITION sp0 + h of the deal holds slot `sl` (P.slot_perm: which spheres share a wave is the host's choice, lg_create; the scratch records and the
+      // distance cache are indexed by position, everything the model and the solver see by slot)
+      const int ps = sp0 + h, sl = (int)((P.slot_perm >> (4 * ps)) & 7u);
       xs[h] = pb; rads[h] = 0.f; ranges[h] = 0.f; reaches[h] = 0.f;
       Q[h].p = pb; Q[h].max_dist = 0.f; Q[h].on = false; Q[h].found = false; Q[h].cp = pb; Q[h].fn = v3(0, 0, 1); Q[h].range = 0.f; Q[h].lb = 0.f;
-      if (sl < s1 && sl < ncp) {
+      if (ps < s1 && sl < ncp) {
         const int link = lm_.i(LM_CP_LINK + sl);
         const V3 lp = lm_.v(LM_CP_POS + 3 * sl);
         rads[h] = lm_.f(LM_CP_RADIUS + sl);
@@ -1073,9 +1075,9 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
         ranges[h] = range; reaches[h] = reach;
         bool query = true; float bound = reach;
         if (cq) {
-          const float dq = CQ(sl, 3);
+          const float dq = CQ(ps, 3);
           if (dq >= 0.f) {
-            const float travel = norm(x - v3(CQ(sl, 0), CQ(sl, 1), CQ(sl, 2)));
+            const float travel = norm(x - v3(CQ(ps, 0), CQ(ps, 1), CQ(ps, 2)));
             query = !(travel < dq - range);
             bound = fminf(reach, dq + travel * 1.0001f + 1e-4f);
           }
@@ -1117,15 +1119,15 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int sl = sp0 + h;
-      if (sl >= s1) continue;
+      const int ps = sp0 + h, sl = (int)((P.slot_perm >> (4 * ps)) & 7u);
+      if (ps >= s1) continue;
       bool active = false; V3 n = v3(0, 0, 1); float phi = 1.f;
       const V3 x = xs[h]; const float rad = rads[h];
       if (Q[h].on) {
         // nothing found: nothing lies within the radius that was searched (= `reach` whenever the cached distance was exact; a grid
         // mesh may return a smaller proven bound)
         const V3 diff = x - Q[h].cp; const float dist = Q[h].found ? norm(diff) : (T.GV ? Q[h].lb : reaches[h]);
-        if (cq) { CQ(sl, 0) = x.x; CQ(sl, 1) = x.y; CQ(sl, 2) = x.z; CQ(sl, 3) = dist; }
+        if (cq) { CQ(ps, 0) = x.x; CQ(ps, 1) = x.y; CQ(ps, 2) = x.z; CQ(ps, 3) = dist; }
         if (Q[h].found && dist <= ranges[h]) {
           const float sign = dot(diff, Q[h].fn) < 0.f ? -1.f : 1.f;
           n = dist > 1e-6f ? (sign / dist) * diff : Q[h].fn;

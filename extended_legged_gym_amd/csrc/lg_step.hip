@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "lg_device.h"
@@ -98,6 +99,7 @@ struct DevCtx {
   float lmod[LM_FIELDS * GRP];  // per-leg model table, packed on the host (pack_leg_model)
   unsigned slide_mask;          // bit sl: some leg's collision sphere in slot sl stands for a capsule part (lg_robot_model.cp_slide)
   unsigned slot_perm;           // nibble p: the slot at position p of the contact-detection deal (main wave 0-2, wave 1: 3, wave 2: 4-5, wave 3: 6-7), see lg_create
+  unsigned mesh_perm;           // the same for triangle-mesh terrains, where every wave takes a PAIR of positions (MESH_PAIR0): which spheres share a wave
   int n_sc; unsigned sc_pairs[LG_MAX_SC_PAIRS];   // self-collision candidates, packed leg a | slot a << 8 | leg b << 16 | slot b << 24 (0 pairs unless lg_config.self_collisions)
   uint4 sc_tab[LG_MAX_SC_PAIRS];                  // ... as the pair filter reads them (sc_prefilter): {slot-record indices (slot * 64 + leg) a | b << 16, radius a, radius b, (ra + rb + contact_offset)^2 (1 + 1e-4)}
   int n_stepped;                // envs advanced by the last step launch (N, or the subset size)
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     PhysParams P;
     P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
     P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-    P.terrain_mu = C->terrain_mu; P.slide_mask = (CAPS || (MCAPS && C->ter.SEG4)) ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : 0x76543210u;
+    P.terrain_mu = C->terrain_mu; P.slide_mask = (CAPS || (MCAPS && C->ter.SEG4)) ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : (TMESH ? C->mesh_perm : 0x76543210u);
 #if LG_AB == 21
     P.slide_mask = 0u;
 #endif
@@ -1002,7 +1004,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   PhysParams P;
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-  P.terrain_mu = C->terrain_mu; P.slide_mask = (CAPS || (MCAPS && C->ter.SEG4)) ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : 0x76543210u;
+  P.terrain_mu = C->terrain_mu; P.slide_mask = (CAPS || (MCAPS && C->ter.SEG4)) ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : (TMESH ? C->mesh_perm : 0x76543210u);
 #if LG_AB == 21
   P.slide_mask = 0u;
 #endif
@@ -2758,6 +2760,33 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
       if (strlen(ev) == 8) { h.slot_perm = 0u; for (int p = 0; p < 8; ++p) h.slot_perm |= (unsigned)((ev[p] - '0') & 7) << (4 * p); }
       else if (atoi(ev) == 0) h.slot_perm = 0x76543210u;
     }
+  }
+  // Triangle-mesh terrains: every wave answers the closest-point queries of a PAIR of positions per substep, and the step waits for the slowest pair at
+  // rendezvous (A2).  LG_MESH_DEAL: eight digits = the slots at positions 0..7 (wave 2 takes positions 0-1, wave 1 2-3, wave 3 4-5, the main wave 6-7: MESH_PAIR0).
+  // Measured on config 3 (A1, seven slots: foot, two shank, two thigh spheres, two trunk corners; profiles/r06_schedule_experiments.txt): with the spheres in model order
+  // -- foot and lowest shank sphere on one wave -- 0.392 ms per step; with ONE ground-near sphere per wave 0.363-0.367 (fifteen deals tried: the level is the same
+  // whichever far sphere joins which near one).  So: slots ranked by how near the ground they work (distal link first, then lower in the link), ranks 0-3 lead the four
+  // pairs (wave 2 / wave 1 / wave 3 / main wave), ranks 4-7 fill them in the same order; a robot of seven slots leaves the main wave with one query.
+  // LG_MESH_DEAL: eight digits = the slots at positions 0..7; "0" = model order (A/B, tests).
+  {
+    int max_cp = 0, lref = 0;
+    for (int l = 0; l < NLEG; ++l) if (model->cp_count[l] > max_cp) { max_cp = model->cp_count[l]; lref = l; }
+    int rk[LG_MAX_CP];
+    for (int i = 0; i < LG_MAX_CP; ++i) rk[i] = i;
+    std::stable_sort(rk, rk + LG_MAX_CP, [&](int a, int b) {
+      const bool ea = a < max_cp, eb = b < max_cp;
+      if (ea != eb) return ea;
+      if (!ea) return false;
+      const int la = model->cp_link[lref][a], lb = model->cp_link[lref][b];
+      if (la != lb) return la > lb;
+      return model->cp_pos[lref][a][2] < model->cp_pos[lref][b][2];
+    });
+    h.mesh_perm = 0u;
+    for (int i = 0; i < 4; ++i) h.mesh_perm |= (unsigned)rk[i] << (4 * (2 * i)) | (unsigned)rk[4 + i] << (4 * (2 * i + 1));
+  }
+  if (const char* ev = getenv("LG_MESH_DEAL")) {
+    if (strlen(ev) == 8) { h.mesh_perm = 0u; for (int p = 0; p < 8; ++p) h.mesh_perm |= (unsigned)((ev[p] - '0') & 7) << (4 * p); }
+    else if (atoi(ev) == 0) h.mesh_perm = 0x76543210u;
   }
   h.n_sc = cfg->self_collisions ? model->num_sc_pairs : 0;
   for (int i = 0; i < h.n_sc; ++i) {

@@ -184,3 +184,56 @@ def test_body_sdf_by_cell_equals_the_tree_walk(tmp_path, monkeypatch):
     assert torch.isfinite(out["cell"][0]).all() and float(out["cell"][0].abs().max()) < 5.0
     assert float(out["cell"][0][:, 1:].abs().median()) < 0.1                    # feet are near the surface
     assert worst <= 1e-4, worst
+
+
+def test_which_spheres_share_a_wave_does_not_change_the_contacts(tmp_path, monkeypatch):
+    """On triangle-mesh terrains every wave answers the closest-point queries of a pair of contact slots, and `lg_create` deals the slots so that every wave
+    gets one ground-near sphere (`DevCtx::mesh_perm`; `LG_MESH_DEAL=0`: model order).  A query's answer does not depend on its partner (the tie rules are
+    order-free) and the distance cache travels with the position: the two deals step bit-equal states -- on the lattice mesh of config 3 and on a grid mesh."""
+    from extended_legged_gym_amd.native import NativeCore
+    from tests.test_mesh_capsules import stairs_setup, stairs_states
+    n = 128
+    envs = []
+    for deal in (None, "0"):
+        if deal is None:
+            monkeypatch.delenv("LG_MESH_DEAL", raising=False)
+        else:
+            monkeypatch.setenv("LG_MESH_DEAL", deal)
+        d = tmp_path / str(deal)
+        d.mkdir()
+        envs.append(make_env(d, n)[0])
+    a, b = envs
+    a.reset(); b.reset()
+    for name in list(a.core.t):
+        b.core.t[name].copy_(a.core.t[name])
+    g = torch.Generator().manual_seed(3)
+    for it in range(40):
+        act = torch.randn(n, 12, generator=g).cuda()
+        a.core.step(act); b.core.step(act)
+    torch.cuda.synchronize()
+    for name in ("root_states", "dof_state", "contact_forces", "rew_buf", "reset_buf", "obs_buf"):
+        assert torch.equal(a.core.t[name], b.core.t[name]), name
+    assert int((a.core.t["contact_forces"].view(n, -1, 3).norm(dim=2) > 1.0).sum()) > n
+    a.core.close(); b.core.close()
+    # the grid mesh of a procedural Terrain (cell-indexed queries + capsule segments), robots dropped into a staircase
+    cfg, ter, s, model = stairs_setup(n)
+    root, dof, _ = stairs_states(s, model, n, seed=4)
+    cores = []
+    for deal in (None, "0"):
+        if deal is None:
+            monkeypatch.delenv("LG_MESH_DEAL", raising=False)
+        else:
+            monkeypatch.setenv("LG_MESH_DEAL", deal)
+        c = NativeCore(s, "cuda:0")
+        c.t["friction_coeffs"].fill_(1.0)
+        c.t["root_states"].copy_(torch.from_numpy(root)); c.t["dof_state"].copy_(torch.from_numpy(dof.reshape(tuple(c.t["dof_state"].shape)))); c.t["torques"].zero_()
+        cores.append(c)
+    zero = torch.zeros(n, 12, device="cuda")
+    for _ in range(10):
+        for c in cores:
+            c.compute_torques_and_simulate(zero)           # (the launch with helper waves: the dealt pairs and the persisted distance cache)
+    torch.cuda.synchronize()
+    for name in ("root_states", "dof_state", "contact_forces"):
+        assert torch.equal(cores[0].t[name], cores[1].t[name]), name
+    for c in cores:
+        c.close()
