@@ -384,11 +384,12 @@ LG_DEV void sts3(float* cst, int slot, int f, int lane, V3 a) { CS(slot, f) = a.
 struct PhysParams {
   float dt; V3 grav; int iters; float contact_offset, max_depen, erp, cfm, terrain_mu; int solver, fric;
   unsigned slide_mask;      // bit sl: some leg's sphere in slot sl stands for a capsule part (lg_robot_model.cp_slide), kernel-uniform
+  float cache_reach;        // triangle meshes: how far beyond `range` a closest-point query looks for the distance cache (LG_MESH_CACHE_REACH; DevCtx::mesh_reach)
   unsigned slot_perm;       // nibble p: the slot at position p of the detection deal (capsule instances; contact_detect_begin_caps)
 };
 
 #define LG_MESH_CONTACT_MARGIN 0.1f      // triangle-mesh contacts: how far below a surface a sphere's centre may have sunk and still be pushed out
-#define LG_MESH_CACHE_REACH 0.15f
+#define LG_MESH_CACHE_REACH 0.05f      // (round 6: 0.15 -> 0.05, config 3 0.365 -> 0.345 ms: a wave pays for the widest window among its lanes, and windows grow with the square of the reach; LG_MESH_REACH: A/B)
 // self-collision candidates: pairs[i] = leg a | slot a << 8 | leg b << 16 | slot b << 24 (global memory; read for the rare pairs that pass the filter);
 // tab[i] = {slot-record offsets of the two spheres, radius a, radius b, filter threshold} (sc_prefilter; the workgroup's LDS copy where there is room for
 // one); mask: LDS words [3][64] through which the helper waves hand their share of the filter to the main wave (null: this wave filters every pair).
@@ -1071,7 +1072,7 @@ LG_DEV void contact_detect_mesh(int s0, int s1, const LegModel& lm_, const Terra
         // (capsule segments, lg_robot_model.cp_slide: against the edges of a GRID mesh below (MCAPS); on other meshes the spheres stand alone -- a closest-point
         //  query of a segment is not built, and sliding the sphere to the segment point nearest ONE mesh point loses the contact of its own end)
         const float range = rads[h] + P.contact_offset + LG_MESH_CONTACT_MARGIN;
-        const float reach = cq ? range + LG_MESH_CACHE_REACH : range;
+        const float reach = cq ? range + P.cache_reach : range;
         ranges[h] = range; reaches[h] = reach;
         bool query = true; float bound = reach;
         if (cq) {

@@ -99,6 +99,7 @@ struct DevCtx {
   float lmod[LM_FIELDS * GRP];  // per-leg model table, packed on the host (pack_leg_model)
   unsigned slide_mask;          // bit sl: some leg's collision sphere in slot sl stands for a capsule part (lg_robot_model.cp_slide)
   unsigned slot_perm;           // nibble p: the slot at position p of the contact-detection deal (main wave 0-2, wave 1: 3, wave 2: 4-5, wave 3: 6-7), see lg_create
+  float mesh_reach;             // PhysParams::cache_reach (LG_MESH_REACH overrides LG_MESH_CACHE_REACH: A/B)
   unsigned mesh_perm;           // the same for triangle-mesh terrains, where every wave takes a PAIR of positions (MESH_PAIR0): which spheres share a wave
   int n_sc; unsigned sc_pairs[LG_MAX_SC_PAIRS];   // self-collision candidates, packed leg a | slot a << 8 | leg b << 16 | slot b << 24 (0 pairs unless lg_config.self_collisions)
   uint4 sc_tab[LG_MAX_SC_PAIRS];                  // ... as the pair filter reads them (sc_prefilter): {slot-record indices (slot * 64 + leg) a | b << 16, radius a, radius b, (ra + rb + contact_offset)^2 (1 + 1e-4)}
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
     PhysParams P;
     P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
     P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-    P.terrain_mu = C->terrain_mu; P.slide_mask = (CAPS || (MCAPS && C->ter.SEG4)) ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : (TMESH ? C->mesh_perm : 0x76543210u);
+    P.terrain_mu = C->terrain_mu; P.slide_mask = (CAPS || (MCAPS && C->ter.SEG4)) ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : (TMESH ? C->mesh_perm : 0x76543210u); P.cache_reach = TMESH ? C->mesh_reach : 0.f;
 #if LG_AB == 21
     P.slide_mask = 0u;
 #endif
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(256) void physics_kernel(const DevCtx* __restrict__
   PhysParams P;
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-  P.terrain_mu = C->terrain_mu; P.slide_mask = (CAPS || (MCAPS && C->ter.SEG4)) ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : (TMESH ? C->mesh_perm : 0x76543210u);
+  P.terrain_mu = C->terrain_mu; P.slide_mask = (CAPS || (MCAPS && C->ter.SEG4)) ? C->slide_mask : 0u; P.slot_perm = CAPS ? C->slot_perm : (TMESH ? C->mesh_perm : 0x76543210u); P.cache_reach = TMESH ? C->mesh_reach : 0.f;
 #if LG_AB == 21
   P.slide_mask = 0u;
 #endif
@@ -1294,7 +1295,7 @@ __global__ __launch_bounds__(HELP ? 256 : 64) void physics_kernel_chain(const De
     PhysParams P;
     P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
     P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-    P.terrain_mu = C->terrain_mu; P.slide_mask = C->slide_mask; P.slot_perm = 0x76543210u;
+    P.terrain_mu = C->terrain_mu; P.slide_mask = C->slide_mask; P.slot_perm = 0x76543210u; P.cache_reach = LG_MESH_CACHE_REACH;
     const TerrainView T = C->ter;
 #pragma unroll 1
     for (int sub = 0; sub < nsub; ++sub) {
@@ -1352,7 +1353,7 @@ __global__ __launch_bounds__(HELP ? 256 : 64) void physics_kernel_chain(const De
   PhysParams P;
   P.dt = g.sim_dt; P.grav = v3(g.gravity[0], g.gravity[1], g.gravity[2]); P.iters = g.solver_iterations;
   P.contact_offset = g.contact_offset; P.max_depen = g.max_depenetration_velocity; P.erp = g.erp; P.cfm = g.cfm; P.solver = g.solver_type; P.fric = g.friction_model;
-  P.terrain_mu = C->terrain_mu; P.slide_mask = C->slide_mask; P.slot_perm = 0x76543210u;
+  P.terrain_mu = C->terrain_mu; P.slide_mask = C->slide_mask; P.slot_perm = 0x76543210u; P.cache_reach = LG_MESH_CACHE_REACH;
   const TerrainView T = C->ter;
   const SelfCol scol{C->sc_pairs, C->n_sc, nullptr, nullptr};
   const float mu_robot = C->friction[e], madd = C->mass_added[e];
@@ -2788,6 +2789,8 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
     if (strlen(ev) == 8) { h.mesh_perm = 0u; for (int p = 0; p < 8; ++p) h.mesh_perm |= (unsigned)((ev[p] - '0') & 7) << (4 * p); }
     else if (atoi(ev) == 0) h.mesh_perm = 0x76543210u;
   }
+  h.mesh_reach = LG_MESH_CACHE_REACH;
+  if (const char* ev = getenv("LG_MESH_REACH")) { const float v = (float)atof(ev); if (v >= 0.f && v <= 1.f) h.mesh_reach = v; }
   h.n_sc = cfg->self_collisions ? model->num_sc_pairs : 0;
   for (int i = 0; i < h.n_sc; ++i) {
     const int32_t* q = model->sc_pairs[i];
