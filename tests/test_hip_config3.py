@@ -189,32 +189,40 @@ def test_body_sdf_by_cell_equals_the_tree_walk(tmp_path, monkeypatch):
 def test_which_spheres_share_a_wave_does_not_change_the_contacts(tmp_path, monkeypatch):
     """On triangle-mesh terrains every wave answers the closest-point queries of a pair of contact slots, and `lg_create` deals the slots so that every wave
     gets one ground-near sphere (`DevCtx::mesh_perm`; `LG_MESH_DEAL=0`: model order).  A query's answer does not depend on its partner (the tie rules are
-    order-free) and the distance cache travels with the position: the two deals step bit-equal states -- on the lattice mesh of config 3 and on a grid mesh."""
+    order-free) and the distance cache travels with the position: the two deals step bit-equal states -- on the lattice mesh of config 3 and on a grid mesh.  So does
+    a different reach of the distance cache (`LG_MESH_REACH`): it only skips queries that would have found nothing."""
     from extended_legged_gym_amd.native import NativeCore
     from tests.test_mesh_capsules import stairs_setup, stairs_states
     n = 128
     envs = []
-    for deal in (None, "0"):
-        if deal is None:
-            monkeypatch.delenv("LG_MESH_DEAL", raising=False)
-        else:
-            monkeypatch.setenv("LG_MESH_DEAL", deal)
-        d = tmp_path / str(deal)
+    for deal, reach in ((None, None), ("0", None), (None, "0.15")):      # shipped | model order | the distance cache looking 0.15 m ahead instead of 0.05 (an exact cull either way)
+        for key, val in (("LG_MESH_DEAL", deal), ("LG_MESH_REACH", reach)):
+            if val is None:
+                monkeypatch.delenv(key, raising=False)
+            else:
+                monkeypatch.setenv(key, val)
+        d = tmp_path / f"{deal}_{reach}"
         d.mkdir()
         envs.append(make_env(d, n)[0])
-    a, b = envs
-    a.reset(); b.reset()
-    for name in list(a.core.t):
-        b.core.t[name].copy_(a.core.t[name])
+    monkeypatch.delenv("LG_MESH_REACH", raising=False)
+    a = envs[0]
+    for e in envs:
+        e.reset()
+    for b in envs[1:]:
+        for name in list(a.core.t):
+            b.core.t[name].copy_(a.core.t[name])
     g = torch.Generator().manual_seed(3)
     for it in range(40):
         act = torch.randn(n, 12, generator=g).cuda()
-        a.core.step(act); b.core.step(act)
+        for e in envs:
+            e.core.step(act)
     torch.cuda.synchronize()
-    for name in ("root_states", "dof_state", "contact_forces", "rew_buf", "reset_buf", "obs_buf"):
-        assert torch.equal(a.core.t[name], b.core.t[name]), name
+    for b in envs[1:]:
+        for name in ("root_states", "dof_state", "contact_forces", "rew_buf", "reset_buf", "obs_buf"):
+            assert torch.equal(a.core.t[name], b.core.t[name]), name
     assert int((a.core.t["contact_forces"].view(n, -1, 3).norm(dim=2) > 1.0).sum()) > n
-    a.core.close(); b.core.close()
+    for e in envs:
+        e.core.close()
     # the grid mesh of a procedural Terrain (cell-indexed queries + capsule segments), robots dropped into a staircase
     cfg, ter, s, model = stairs_setup(n)
     root, dof, _ = stairs_states(s, model, n, seed=4)
