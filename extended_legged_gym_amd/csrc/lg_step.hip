@@ -2733,6 +2733,7 @@ lg_ctx* lg_create(const lg_config* cfg, const lg_robot_model* model, const lg_te
     for (int sl = 0; sl < model->cp_count[l]; ++sl)
       if (model->cp_slide[l][sl][0] != 0.f || model->cp_slide[l][sl][1] != 0.f || model->cp_slide[l][sl][2] != 0.f) h.slide_mask |= 1u << sl;
   if (const char* ev = getenv("LG_CAPS")) { if (atoi(ev) == 0) h.slide_mask = 0u; }      // (diagnostic / A-B: every sphere stays in the middle of its part)
+  if (ter->mesh_type == LG_MESH_PLANE) h.slide_mask = 0u;       // a plane has no edges: the self-collision instances (which carry the capsule code) skip it at run time (config 5: -2 %)
   // Who detects which slot (capsule instances on a height grid).  A slot with a segment costs about twice a plain one (two edge pieces), an empty slot
   // nothing; the waves take positions 0-2 (main) / 3 (wave 1, which also has the leg bias) / 4-5 / 6-7 -- the quadruped's capsule instance since round 6:
   // 0-1 / 2 / 3-5 / 6-7 (LG_CAPS_DEAL).  Segment slots go to wave 3's first position, then the main wave's last, then wave 2's; slots no leg has fill up
