@@ -1,5 +1,5 @@
-"""Register / LDS budget of the kernel the headline number runs, from the compiler's own report (`-Rpass-analysis=kernel-resource-usage`,
-device compilation of csrc/lg_step.hip; no GPU needed).  Round 2's build of `physics_kernel<0, false>` spilled 1 157 SGPRs and 79 VGPRs,
+"""Register / LDS budget of the kernel the headline number runs, from the compiler's own report: the metadata of the code object `build()` left in csrc/ when it is
+current, else `-Rpass-analysis=kernel-resource-usage` of a device compilation of csrc/lg_step.hip (four minutes); no GPU needed.  Round 2's build of `physics_kernel<0, false>` spilled 1 157 SGPRs and 79 VGPRs,
 nearly all of it in the single-wave fallback paths inlined next to the hot code; they are a separate template instance now
 (`physics_kernel<0, TMESH, HELPERS>`), and this test keeps it that way."""
 import os
@@ -13,14 +13,57 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_headline_kernel_register_and_lds_budget(tmp_path):
-    src = os.path.join(ROOT, "extended_legged_gym_amd", "csrc", "lg_step.hip")
-    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-fno-slp-vectorize", "--cuda-device-only",
-           "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "lg_step.o")]
+CSRC = os.path.join(ROOT, "extended_legged_gym_amd", "csrc")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _from_built_object(obj):
+    """Kernel resources from the code object inside an object file `build()` left in csrc/ -- when it is at least as new as every source it was compiled from.
+    The same numbers the compiler reports (the metadata notes of the code object), without the four minutes of compiling the file again.  None: no such object."""
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(LLVM, "clang-offload-bundler"))):
+        return None
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f == "lg_step.hip"] + [os.path.join(ROOT, "include", "lgstep.h")]      # (what lg_step.hip includes)
+    if os.path.getmtime(obj) < max(os.path.getmtime(f) for f in srcs):
+        return None
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
+        if subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat]).returncode != 0:
+            return None
+        if subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}",
+                           "--unbundle"], capture_output=True).returncode != 0:
+            return None
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+    blocks, cur = {}, None
+    for line in notes.splitlines():
+        line = line.strip()
+        if line.startswith("- .agpr_count:") or line.startswith("- .args:"):
+            cur = {}
+        m = re.match(r"-?\s*\.(\w+):\s+(\S+)$", line)
+        if m and cur is not None:
+            k, v = m.group(1), m.group(2)
+            if k == "name":
+                blocks[v] = cur
+            elif v.isdigit():
+                cur[k] = int(v)
+    out = {}
+    for name, r in blocks.items():
+        if "vgpr_count" in r:
+            out[name] = {"VGPRs": r["vgpr_count"] - r.get("agpr_count", 0), "AGPRs": r.get("agpr_count", 0), "VGPRs Spill": r.get("vgpr_spill_count", 0),
+                         "SGPRs Spill": r.get("sgpr_spill_count", 0), "ScratchSize": r.get("private_segment_fixed_size", 0), "LDS Size": r.get("group_segment_fixed_size", 0),
+                         "Occupancy": 1 if r["vgpr_count"] > 256 else 2}
+    return out or None
+
+
+def _resources(tmp_path, legs):
+    built = _from_built_object(os.path.join(CSRC, f"lg_step{legs}.o"))
+    if built is not None:
+        return built
+    src = os.path.join(CSRC, "lg_step.hip")
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-fno-slp-vectorize", "--cuda-device-only", f"-DLG_LEGS={legs}",
+           "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / f"lg_step{legs}.o")]
     out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
-    blocks = {}
-    name = None
+    blocks, name = {}, None
     for line in out.splitlines():
         m = re.search(r"remark: Function Name: (\S+)", line)
         if m:
@@ -29,6 +72,12 @@ def test_headline_kernel_register_and_lds_budget(tmp_path):
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/(?:lane|block)\])?(?: \[waves/SIMD\])?: (\d+)", line)
         if m and name:
             blocks[name][m.group(1).strip()] = int(m.group(2))
+    return blocks
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_headline_kernel_register_and_lds_budget(tmp_path):
+    blocks = _resources(tmp_path, 4)
     # physics_kernel<0, false, true>: heightfield / plane terrain, helper waves present = every policy step of the headline config
     # (lg_step.hip is compiled once per leg count, lg_instance.h; without -DLG_LEGS this is the four-legged instance, namespace lg4)
     key = [k for k in blocks if k.startswith("_ZN3lg414physics_kernelILi0ELb0ELb1ELi0E")]
@@ -54,19 +103,7 @@ def test_headline_kernel_register_and_lds_budget(tmp_path):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_six_legged_instance_fits_a_compute_unit(tmp_path):
     """The hexapod instance (-DLG_LEGS=6: eight lanes per env) of the same source: no vector spills, one workgroup's LDS."""
-    src = os.path.join(ROOT, "extended_legged_gym_amd", "csrc", "lg_step.hip")
-    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-fno-slp-vectorize", "--cuda-device-only", "-DLG_LEGS=6",
-           "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "lg_step6.o")]
-    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
-    blocks, name = {}, None
-    for line in out.splitlines():
-        m = re.search(r"remark: Function Name: (\S+)", line)
-        if m:
-            name = m.group(1); blocks[name] = {}
-            continue
-        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/(?:lane|block)\])?(?: \[waves/SIMD\])?: (\d+)", line)
-        if m and name:
-            blocks[name][m.group(1).strip()] = int(m.group(2))
+    blocks = _resources(tmp_path, 6)
     key = [k for k in blocks if k.startswith("_ZN3lg614physics_kernelILi0ELb0ELb1ELi0E")]
     assert len(key) == 1, sorted(blocks)
     r = blocks[key[0]]
