@@ -191,3 +191,41 @@ def test_hip_segments_on_a_grid_mesh_match_the_oracle_and_both_query_paths():
     for c in (core, plain, tree):
         c.close()
     o.close()
+
+
+@pytest.mark.gpu
+def test_rollout_and_subset_steps_on_a_grid_mesh_match_the_oracle():
+    """The rollout-mode and main-only subset steps of a main-rollout layout on the staircase mesh: the fused ROLLOUT tail's triangle-mesh instances with the capsule
+    segments (`physics_kernel<0,true,true,6>`) and the two-launch subset path, against the oracle's `step_subset`, from states in which shanks rest on nosings."""
+    import torch
+    from extended_legged_gym_amd.native import NativeCore
+    from oracle.oracle_lib import OracleEnv
+    from tests.test_hip_vs_oracle import COPY, STATE, compare
+    M, R = 16, 3
+    n = M * (1 + R)
+    cfg, ter, s, model = stairs_setup(n)
+    root, dof, geom = stairs_states(s, model, n, seed=6)
+    o, core = OracleEnv(s), NativeCore(s, "cuda:0")
+    load_oracle(o, root, dof)
+    o.reset_idx(np.arange(n))                                       # (episode bookkeeping of a fresh env; the poses are put back below)
+    load_oracle(o, root, dof)
+    o.refresh_rigid_body_state()
+    for name in COPY + ["friction_coeffs", "actions", "rigid_body_state", "contact_forces", "torques", "obs_buf", "rew_buf", "base_lin_vel", "base_ang_vel",
+                        "projected_gravity", "reset_buf", "time_out_buf", "measured_heights"]:
+        core.t[name].copy_(torch.from_numpy(o.t[name].copy()))
+    roll = np.array([e for e in range(n) if e % (1 + R)], dtype=np.int32)
+    main = np.arange(0, n, 1 + R, dtype=np.int32)
+    rng = np.random.default_rng(0)
+    names = [x for x in STATE if x not in ("sea_hidden_state", "sea_cell_state")]
+    a = (0.5 * rng.normal(size=(len(roll), 12))).astype(np.float32)
+    o.step_subset(a, roll, 1); core.step_subset(torch.from_numpy(a).cuda(), torch.from_numpy(roll).cuda(), 1)
+    compare(core, o, names, bars="step_tgs_mesh", tag="rollout_step/stairs_mesh_capsules")
+    a = (0.5 * rng.normal(size=(M, 12))).astype(np.float32)
+    o.step_subset(a, main, 0); core.step_subset(torch.from_numpy(a).cuda(), torch.from_numpy(main).cuda(), 0)
+    rows = core.t["reset_buf"].cpu().numpy() == o.t["reset_buf"]
+    assert rows.mean() > 0.95
+    compare(core, o, names, bars="step_tgs_mesh", rows=rows, tag="subset_step/stairs_mesh_capsules")
+    cf = core.t["contact_forces"].cpu().numpy().reshape(n, -1, 3)
+    shank = [i for i, b in enumerate(model["body_names"]) if b.endswith("SHANK")]
+    assert (np.linalg.norm(cf[:, shank], axis=2) > 1.0).sum() > n // 4        # the shanks do carry load here
+    core.close(); o.close()
