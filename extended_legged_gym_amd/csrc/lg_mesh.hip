@@ -286,12 +286,13 @@ __global__ __launch_bounds__(256) void sdf_bodies_kernel(MeshView M, LatticeView
                                                          const int32_t* __restrict__ body_idx, const float* __restrict__ offsets, int nb,
                                                          const int32_t* __restrict__ ids, int n_ids, float max_dist,
                                                          float* __restrict__ sdf, int sdf_stride, float* __restrict__ grad,
-                                                         float* __restrict__ nearest, float4* __restrict__ cache) {
+                                                         float* __restrict__ nearest, float4* __restrict__ cache, int body_major) {
   const int k = threadIdx.x & 15;
-  int64_t gi = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);                 // one query per 16 lanes
+  int64_t gi = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);                 // one query per 16 lanes
   const bool live = gi < (int64_t)n_ids * nb;
   if (!live) gi = (int64_t)n_ids * nb - 1;                                      // (a spare group repeats the last query and stores nothing: the group functions want all lanes)
-  const int kq = (int)(gi / nb), b = (int)(gi - (int64_t)kq * nb);
+  int kq = (int)(gi / nb), b = (int)(gi - (int64_t)kq * nb);
+  if (body_major) { b = (int)(gi / n_ids); kq = (int)(gi - (int64_t)b * n_ids); }      // a wave's four groups = the same body of four envs (trunks with trunks: their windows are ~50 cells, the feet's a few)
   const int e = ids ? ids[kq] : kq;
   const float* s = rb + ((size_t)e * B + body_idx[b]) * 13;
   const float q[4] = {s[3], s[4], s[5], s[6]};
@@ -665,8 +666,14 @@ int lg_sdf_bodies_update(lg_mesh* m, const float* rigid_body_state, int32_t num_
   const char* sl = getenv("LG_SDF_LATTICE");
   LatticeView L{nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 1.f, 1.f, LATP_CAP};
   if (m->d_gcz && m->d_gcr && !(sl && sl[0] == '0')) L = LatticeView{m->d_gcz, m->d_gcr, m->d_gtris, m->gnx, m->gny, m->gx0, m->gy0, m->ghx, m->ghy, LATP_CAP};
-  hipLaunchKernelGGL(sdf_bodies_kernel, dim3((unsigned)((tot + 15) / 16)), dim3(256), 0, (hipStream_t)stream, M, L, rigid_body_state, num_bodies,
-                     body_indices, sphere_offsets, num_query_bodies, env_ids, n, max_dist, sdf_values, sdf_stride, sdf_gradients, nearest_points, m->d_sdf_cache);
+  // (round 6, measured on config 3, three rounds: 256 threads + one env's five bodies side by side 0.3435 ms per step; 128 threads + the same body of eight envs per
+  //  workgroup 0.3373: a wave no longer waits for the one trunk among its four queries.  LG_SDF_BLOCK / LG_SDF_ORDER: A/B)
+  int sdf_block = 128, sdf_order = 1;
+  if (const char* ev = getenv("LG_SDF_BLOCK")) { const int v = atoi(ev); if (v == 64 || v == 128 || v == 256) sdf_block = v; }
+  if (const char* ev = getenv("LG_SDF_ORDER")) sdf_order = atoi(ev) != 0;
+  const int qpb = sdf_block / 16;
+  hipLaunchKernelGGL(sdf_bodies_kernel, dim3((unsigned)((tot + qpb - 1) / qpb)), dim3(sdf_block), 0, (hipStream_t)stream, M, L, rigid_body_state, num_bodies,
+                     body_indices, sphere_offsets, num_query_bodies, env_ids, n, max_dist, sdf_values, sdf_stride, sdf_gradients, nearest_points, m->d_sdf_cache, sdf_order);
   MESH_TRY(m, hipGetLastError());
   return LG_OK;
 }
